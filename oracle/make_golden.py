@@ -1,0 +1,473 @@
+"""Generate ``tests/golden/*`` from the reference itself.  TEST INFRASTRUCTURE.
+
+For every case this script (run in the build container, where
+``/root/reference`` exists):
+
+1. builds the graph with the reference's public API;
+2. compiles it with ``mode="HIP"`` — i.e. through ``pytensor_amd.linker.HipLinker``,
+   the product's own boundary — and stores the lowered IR (``<case>.json``);
+3. evaluates the same graph with the reference C linker (``mode="CVM"``) and
+   NumPy linker (``Mode("py", optimizer=None)`` as the backend tests do,
+   tests/link/pytorch/test_basic.py:41-87) and stores inputs + both outputs in
+   ``<case>.npz``;
+4. checks ``oracle/np_graph.py`` on the IR against the C-linker outputs
+   (the "pinning" of the oracle).
+
+Usage:  python oracle/make_golden.py [case ...]
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import make_ref  # noqa: E402
+
+make_ref.activate()
+
+import numpy as np  # noqa: E402
+import pytensor  # noqa: E402
+import pytensor.tensor as pt  # noqa: E402
+from pytensor.compile.mode import Mode  # noqa: E402
+from pytensor.tensor.linalg import cho_solve, cholesky, solve_triangular  # noqa: E402
+
+import pytensor_amd  # noqa: E402
+from pytensor_amd import configs  # noqa: E402
+
+pytensor_amd.register()
+import np_graph  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+CASES = {}
+
+
+def case(name, rtol=None):
+    def deco(f):
+        CASES[name] = (f, rtol)
+        return f
+
+    return deco
+
+
+def _in(name, value):
+    value = np.asarray(value)
+    v = pt.tensor(name, dtype=str(value.dtype), shape=(None,) * value.ndim)
+    return v
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json configs (small sizes; the IR is shape-agnostic in N)
+# ---------------------------------------------------------------------------
+
+
+@case("c1_gauss")
+def c1():
+    vals = configs.c1_inputs(N=1000)
+    x = pt.dvector("x")
+    mu = pt.dscalar("mu")
+    y = pt.exp(-0.5 * (x - mu) ** 2).sum()
+    return [x, mu], [y, pytensor.grad(y, x)], vals
+
+
+def _c2_cheap(x, y):
+    acc = x
+    for k in range(4):
+        u = acc * (0.9 + 0.01 * k) + y
+        v = abs(u) - (0.3 + 0.1 * k) * x
+        acc = pt.switch(v > 0, v * v, u - v) * 0.5 + acc * 0.25
+    return acc + pt.exp(-x * x)
+
+
+def _c2_transc(x, y):
+    t = x
+    s = pt.zeros_like(x)
+    for k in range(10):
+        t = pt.tanh(t + y * (0.1 * (k + 1)))
+        s = s + pt.exp(-t * t) * (1.0 / (k + 1))
+    return s
+
+
+@case("c2_cheap")
+def c2_cheap():
+    vals = configs.c2_inputs(N=5000)
+    x, y = pt.dvector("x"), pt.dvector("y")
+    return [x, y], [_c2_cheap(x, y).sum()], vals
+
+
+@case("c2_transc")
+def c2_transc():
+    vals = configs.c2_inputs(N=5000)
+    x, y = pt.dvector("x"), pt.dvector("y")
+    return [x, y], [_c2_transc(x, y).sum()], vals
+
+
+@case("c3_dot22")
+def c3_dot22():
+    v = configs.c3_inputs(M=96, B=2, Bn=8)
+    A, B = pt.dmatrix("A"), pt.dmatrix("B")
+    return [A, B], [A @ B], {"A": v["A"], "B": v["B"]}
+
+
+@case("c3_gemv")
+def c3_gemv():
+    v = configs.c3_inputs(M=96, B=2, Bn=8)
+    A, x = pt.dmatrix("A"), pt.dvector("v")
+    return [A, x], [A @ x], {"A": v["A"], "v": v["v"]}
+
+
+@case("c3_bdot")
+def c3_bdot():
+    v = configs.c3_inputs(M=8, B=6, Bn=32)
+    X, Y = pt.ftensor3("X3"), pt.ftensor3("Y3")
+    return [X, Y], [pt.matmul(X, Y)], {"X3": v["X3"], "Y3": v["Y3"]}
+
+
+def build_c4(vals):
+    K = vals["X"].shape[1]
+    y = pytensor.shared(vals["y"], name="y")
+    X = pytensor.shared(vals["X"], name="X")
+    gidx = pytensor.shared(vals["gidx"], name="gidx")
+    Sigma = pytensor.shared(vals["Sigma"], name="Sigma")
+    mu_g, log_tau, log_sigma = pt.dscalar("mu_g"), pt.dscalar("log_tau"), pt.dscalar("log_sigma")
+    z, beta = pt.dvector("z"), pt.dvector("beta")
+    tau = pt.exp(log_tau)
+    sigma = pt.exp(log_sigma)
+    a = mu_g + tau * z
+    L = cholesky(Sigma)
+    alpha = solve_triangular(L, beta, lower=True)
+    logp_beta = -0.5 * pt.sum(alpha**2) - pt.sum(pt.log(pt.diag(L))) - 0.5 * K * np.log(2 * np.pi)
+    eta = a[gidx] + X @ beta
+    r = (y - eta) / sigma
+    logp_y = pt.sum(-0.5 * r**2 - log_sigma - 0.5 * np.log(2 * np.pi))
+    logp_z = pt.sum(-0.5 * z**2 - 0.5 * np.log(2 * np.pi))
+    logp_hyp = -0.5 * (mu_g**2 + log_tau**2 + log_sigma**2)
+    logp = logp_y + logp_z + logp_beta + logp_hyp
+    params = [mu_g, log_tau, z, beta, log_sigma]
+    return params, [logp, *pytensor.grad(logp, params)]
+
+
+@case("c4_hier")
+def c4():
+    vals = configs.c4_inputs(N=3000)
+    ins, outs = build_c4(vals)
+    return ins, outs, vals
+
+
+@case("c4_hier_small")
+def c4_small():
+    vals = configs.c4_inputs(N=257, K=16, G=8)
+    ins, outs = build_c4(vals)
+    return ins, outs, vals
+
+
+def build_c5():
+    xs = pt.ftensor3("xs")
+    h0 = pt.fmatrix("h0")
+    Ws = [pt.fmatrix(n) for n in ["Wz", "Wr", "Wh", "Uz", "Ur", "Uh"]]
+    bs = [pt.fvector(n) for n in ["bz", "br", "bh"]]
+
+    def step(x, h, Wz, Wr, Wh, Uz, Ur, Uh, bz, br, bh):
+        zz = pt.sigmoid(x @ Wz + h @ Uz + bz)
+        rr = pt.sigmoid(x @ Wr + h @ Ur + br)
+        hh = pt.tanh(x @ Wh + (rr * h) @ Uh + bh)
+        return (1 - zz) * h + zz * hh
+
+    hs = pytensor.scan(step, sequences=[xs], outputs_info=[h0], non_sequences=Ws + bs, return_updates=False)
+    return [xs, h0, *Ws, *bs], [hs[-1].sum(), hs[-1]]
+
+
+@case("c5_gru", rtol=1e-5)
+def c5():
+    vals = configs.c5_inputs(T=7, B=4, H=32)
+    ins, outs = build_c5()
+    return ins, outs, vals
+
+
+# ---------------------------------------------------------------------------
+# op-level cases (shapes follow the reference's own tests)
+# ---------------------------------------------------------------------------
+
+
+@case("elemwise_bcast")
+def elemwise_bcast():
+    # tests/tensor/test_elemwise.py:239-443 TestBroadcast shape matrix
+    rng = np.random.default_rng(10)
+    a = pt.tensor("a", dtype="float64", shape=(None, None))
+    b = pt.tensor("b", dtype="float64", shape=(1, None))
+    c = pt.tensor("c", dtype="float64", shape=(None, 1))
+    d = pt.dscalar("d")
+    out1 = a * b + c - d
+    out2 = pt.exp(a) / (1 + b**2) + pt.log1p(abs(c))
+    vals = {"a": rng.normal(size=(7, 5)), "b": rng.normal(size=(1, 5)), "c": rng.normal(size=(7, 1)), "d": np.asarray(0.7)}
+    return [a, b, c, d], [out1, out2], vals
+
+
+@case("elemwise_f32_mixed", rtol=1e-5)
+def elemwise_f32():
+    rng = np.random.default_rng(11)
+    a = pt.fmatrix("a")
+    i = pt.lvector("i")
+    out1 = pt.tanh(a) * i + pt.sigmoid(a)
+    out2 = pt.softplus(a) - pt.sqrt(abs(a))
+    out3 = pt.cast(a > 0, "int8") + pt.cast(i, "int8")
+    vals = {"a": rng.normal(size=(6, 9)).astype("float32") * 3, "i": rng.integers(-3, 3, size=9)}
+    return [a, i], [out1, out2, out3], vals
+
+
+@case("elemwise_ints")
+def elemwise_ints():
+    rng = np.random.default_rng(12)
+    i = pt.lvector("i")
+    j = pt.lvector("j")
+    out = [i // j, i % j, pt.maximum(i, j) - pt.minimum(i, j), pt.switch(pt.eq(i, j), i, -j), pt.bitwise_and(i, j) ^ 5, abs(i) * pt.sign(j)]
+    jj = rng.integers(1, 9, size=33) * rng.choice([-1, 1], size=33)
+    vals = {"i": rng.integers(-50, 50, size=33), "j": jj}
+    return [i, j], out, vals
+
+
+@case("careduce_axes")
+def careduce_axes():
+    # tests/tensor/test_elemwise.py:444-731 TestCAReduce / tests/benchmarks/test_careduce.py
+    rng = np.random.default_rng(13)
+    x = pt.dtensor3("x")
+    outs = [
+        x.sum(),
+        x.sum(axis=0),
+        x.sum(axis=1),
+        x.sum(axis=2),
+        x.sum(axis=(0, 1)),
+        x.sum(axis=(1, 2)),
+        x.sum(axis=(0, 2)),
+        x.prod(axis=2),
+        x.max(axis=1),
+        x.min(axis=(0, 2)),
+        x.max(),
+    ]
+    return [x], outs, {"x": rng.normal(size=(5, 17, 9))}
+
+
+@case("careduce_f32_acc", rtol=1e-6)
+def careduce_f32():
+    # accumulator upcast f32 -> f64 (pytensor/tensor/elemwise.py:1383-1417)
+    rng = np.random.default_rng(14)
+    x = pt.fmatrix("x")
+    b = pt.tensor("b", dtype="bool", shape=(None, None))
+    return [x, b], [x.sum(), x.sum(axis=0), x.sum(axis=1), x.mean(axis=1), b.all(axis=0), b.any(axis=1), b.sum()], {
+        "x": (rng.normal(size=(300, 41)) * 100).astype("float32"),
+        "b": rng.random(size=(6, 7)) > 0.3,
+    }
+
+
+@case("softmax_family")
+def softmax_family():
+    rng = np.random.default_rng(15)
+    x = pt.dmatrix("x")
+    from pytensor.tensor.special import log_softmax, softmax
+
+    return [x], [softmax(x, axis=-1), log_softmax(x, axis=-1), pt.logsumexp(x, axis=0), softmax(x, axis=0)], {
+        "x": rng.normal(size=(9, 13)) * 4
+    }
+
+
+@case("cholesky_solve")
+def cholesky_solve():
+    # tests/tensor/linalg/test_decomposition/test_cholesky.py:28-125
+    rng = np.random.default_rng(16)
+    A = pt.dmatrix("A")
+    b = pt.dvector("b")
+    Bm = pt.dmatrix("Bm")
+    L = cholesky(A)
+    U = cholesky(A, lower=False)
+    return [A, b, Bm], [
+        L,
+        U,
+        solve_triangular(L, b, lower=True),
+        solve_triangular(U, Bm, lower=False),
+        solve_triangular(L.T, b, lower=False),
+        cho_solve((L, True), b),
+        cho_solve((U, False), Bm),
+    ], {
+        "A": (lambda M: M @ M.T + 12 * np.eye(12))(rng.normal(size=(12, 12))),
+        "b": rng.normal(size=12),
+        "Bm": rng.normal(size=(12, 5)),
+    }
+
+
+@case("cholesky_indefinite")
+def cholesky_indefinite():
+    # NaN on failure: cholesky.py:78-80; test_cholesky.py:57-70
+    A = pt.dmatrix("A")
+    return [A], [cholesky(A)], {"A": np.array([[1.0, 0.2], [0.2, -2.0]])}
+
+
+@case("cholesky_batched")
+def cholesky_batched():
+    rng = np.random.default_rng(17)
+    A = pt.dtensor3("A")
+    b = pt.dmatrix("b")
+    L = cholesky(A)
+    M = rng.normal(size=(4, 6, 6))
+    return [A, b], [L, solve_triangular(L, b, lower=True, b_ndim=1)], {
+        "A": M @ M.transpose(0, 2, 1) + 6 * np.eye(6),
+        "b": rng.normal(size=(4, 6)),
+    }
+
+
+@case("indexing")
+def indexing():
+    rng = np.random.default_rng(18)
+    x = pt.dmatrix("x")
+    v = pt.dvector("v")
+    idx = pt.lvector("idx")
+    k = pt.lscalar("k")
+    outs = [
+        x[1:5],
+        x[::2, 1],
+        x[k],
+        x[:, -3:],
+        x[idx],
+        v[idx],
+        pt.set_subtensor(x[2:4], 7.0),
+        pt.inc_subtensor(x[:, 1], v[: x.shape[0]]),
+        pt.inc_subtensor(v[idx], 1.5),
+        pt.set_subtensor(v[idx[:3]], pt.stack([v[0], v[1], v[2]])),
+        pt.concatenate([x, x[::-1]], axis=0),
+        x.reshape((-1,)),
+        x.T.reshape((x.shape[1] * 2, x.shape[0] // 2)),
+        pt.diag(x[:6, :6]),
+        pt.alloc(v[0], 3, 4),
+    ]
+    return [x, v, idx, k], outs, {
+        "x": rng.normal(size=(8, 6)),
+        "v": rng.normal(size=11),
+        "idx": np.array([0, 3, 3, 7, 2, 3]),
+        "k": np.asarray(5),
+    }
+
+
+@case("gemm_variants")
+def gemm_variants():
+    # tests/tensor/test_blas.py:82-404 TestGemm (transposes, alpha/beta)
+    rng = np.random.default_rng(19)
+    A, B, C = pt.dmatrix("A"), pt.dmatrix("B"), pt.dmatrix("C")
+    x, y = pt.dvector("x"), pt.dvector("y")
+    outs = [
+        0.4 * C + 0.8 * pt.dot(A, B),
+        C - pt.dot(B.T, A.T).T * 2.0,
+        pt.dot(A.T, A),
+        pt.dot(A, A.T),
+        y * 0.5 + 1.5 * pt.dot(A, x),
+        x + pt.dot(A.T, y),
+        pt.outer(y, x) + A,
+        pt.dot(x, x),
+    ]
+    return [A, B, C, x, y], outs, {
+        "A": rng.normal(size=(21, 13)),
+        "B": rng.normal(size=(13, 17)),
+        "C": rng.normal(size=(21, 17)),
+        "x": rng.normal(size=13),
+        "y": rng.normal(size=21),
+    }
+
+
+@case("scan_cumsum_taps")
+def scan_taps():
+    # tests/link/jax/test_scan.py patterns: sit-sot, mit-sot (fibonacci-like), nit-sot
+    rng = np.random.default_rng(20)
+    xs = pt.dmatrix("xs")
+    s0 = pt.dvector("s0")
+    f0 = pt.dmatrix("f0")
+    w = pt.dscalar("w")
+
+    def step(x, s, fm2, fm1, w):
+        s_new = s * w + x
+        f_new = fm1 + 0.5 * fm2
+        return s_new, f_new, pt.tanh(s_new).sum()
+
+    (ss, fs, ns) = pytensor.scan(
+        step,
+        sequences=[xs],
+        outputs_info=[s0, dict(initial=f0, taps=[-2, -1]), None],
+        non_sequences=[w],
+        return_updates=False,
+    )
+    return [xs, s0, f0, w], [ss, fs, ns, ss[-1]], {
+        "xs": rng.normal(size=(9, 4)),
+        "s0": rng.normal(size=4),
+        "f0": rng.normal(size=(2, 4)),
+        "w": np.asarray(0.9),
+    }
+
+
+# ---------------------------------------------------------------------------
+
+
+def _tolerance(dtypes, rtol):
+    if rtol is not None:
+        return rtol
+    if any(np.dtype(d) == np.float32 for d in dtypes):
+        return 1e-5
+    return 1e-12
+
+
+def generate(name):
+    f, rtol = CASES[name]
+    ins, outs, vals = f()
+    fn_hip = pytensor.function(ins, outs, mode="HIP", on_unused_input="ignore")
+    graph = fn_hip.maker.linker.last_ir
+    host_nodes = [n.params["name"] for n in graph.nodes if n.op == "HostPerform"]
+    if host_nodes:
+        raise RuntimeError(f"{name}: ops without a hip lowering: {host_nodes}")
+    # input values in fgraph.inputs order (explicit + shared)
+    fg_inputs = fn_hip.maker.fgraph.inputs
+    names = []
+    in_vals = []
+    for v, cont in zip(fg_inputs, fn_hip.input_storage):
+        nm = v.name
+        names.append(nm)
+        if nm in vals:
+            in_vals.append(np.asarray(vals[nm], dtype=v.type.dtype))
+        else:
+            in_vals.append(np.asarray(cont.storage[0]))
+    explicit = [np.asarray(vals[v.name], dtype=v.type.dtype) for v in ins]
+
+    fn_c = pytensor.function(ins, outs, mode="CVM", on_unused_input="ignore")
+    out_c = [np.asarray(o) for o in fn_c(*explicit)]
+    fn_py = pytensor.function(ins, outs, mode=Mode("py", optimizer=None), on_unused_input="ignore")
+    out_py = [np.asarray(o) for o in fn_py(*explicit)]
+
+    out_or = np_graph.run_graph(graph, in_vals)
+    tol = _tolerance([o.dtype for o in out_c], rtol)
+    for k, (a, b, c) in enumerate(zip(out_or, out_c, out_py)):
+        a = np.asarray(a)
+        assert a.shape == b.shape, (name, k, a.shape, b.shape)
+        assert a.dtype == b.dtype, (name, k, a.dtype, b.dtype)
+        if b.dtype.kind in "biu":
+            np.testing.assert_array_equal(a, b, err_msg=f"{name} out{k} oracle vs C linker")
+        else:
+            np.testing.assert_allclose(a, b, rtol=tol, atol=tol * 1e-3, equal_nan=True, err_msg=f"{name} out{k} oracle vs C linker")
+            np.testing.assert_allclose(c, b, rtol=max(tol, 1e-10), atol=tol, equal_nan=True, err_msg=f"{name} out{k} py vs C linker")
+
+    os.makedirs(GOLDEN, exist_ok=True)
+    d = graph.to_dict()
+    d["input_names"] = names
+    d["rtol"] = tol
+    with open(os.path.join(GOLDEN, f"{name}.json"), "w") as fh:
+        json.dump(d, fh, separators=(",", ":"))
+    arrays = {f"in{k}": v for k, v in enumerate(in_vals)}
+    arrays.update({f"cvm{k}": v for k, v in enumerate(out_c)})
+    arrays.update({f"py{k}": v for k, v in enumerate(out_py)})
+    np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **arrays)
+    print(f"{name:24s} ok  [{graph.summary()}]")
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(CASES)
+    for n in names:
+        generate(n)

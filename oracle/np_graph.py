@@ -1,0 +1,694 @@
+"""CPU oracle — TEST INFRASTRUCTURE ONLY.
+
+A NumPy/SciPy restatement of the reference's *Python* (``Op.perform``) semantics
+for every op on the hot path, interpreting the portable IR
+(``pytensor_amd/ir.py``).  Only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import this module; the product path
+(``pytensor_amd.executor``) never does.
+
+Pinned against the reference itself: ``tests/golden/*.npz`` hold outputs of the
+reference C linker (``mode="CVM"``) and NumPy linker (``Mode("py")``) produced in
+the build container by ``oracle/make_golden.py`` from ``/root/reference``;
+``tests/test_oracle.py`` checks this interpreter against them.
+
+Third-party arithmetic that is *not* under ``/root/reference``:
+BLAS ``gemm/gemv`` and LAPACK ``potrf/trtrs/potrs`` come from the NumPy/SciPy
+wheels (OpenBLAS 0.3.29 here; the reference pins only ``numpy>=2.0``,
+``scipy>=1,<2`` in pyproject.toml:49-55).  We call the same entry points the
+reference's ``perform`` methods call.
+
+Every handler cites the reference ``perform`` it follows.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import scipy.linalg
+import scipy.special
+
+# ---------------------------------------------------------------------------
+# scalar ops — reference: pytensor/scalar/basic.py, pytensor/scalar/math.py
+# (``impl`` / ``nfunc_spec`` of each ScalarOp = what the NumPy linker runs)
+# ---------------------------------------------------------------------------
+
+
+def _softplus(x):
+    # scalar/math.py:1227-1245 (Softplus.impl), vectorised
+    x = np.asarray(x)
+    with np.errstate(over="ignore", invalid="ignore"):
+        return np.where(
+            x < -37.0,
+            np.exp(x),
+            np.where(x < 18.0, np.log1p(np.exp(x)), np.where(x < 33.3, x + np.exp(-x), x)),
+        )
+
+
+def _log1mexp(x):
+    # scalar/math.py:1295-1340 (Log1mexp.impl)
+    x = np.asarray(x)
+    with np.errstate(all="ignore"):
+        return np.where(x < np.log(0.5), np.log1p(-np.exp(x)), np.log(-np.expm1(x)))
+
+
+def _sign(x):
+    return np.sign(x)
+
+
+def _int_div(x, y):
+    # scalar/basic.py IntDiv.impl: x // y
+    with np.errstate(all="ignore"):
+        return np.floor_divide(x, y)
+
+
+def _mod(x, y):
+    with np.errstate(all="ignore"):
+        return np.mod(x, y)
+
+
+def _variadic(f):
+    def g(*a):
+        r = a[0]
+        for b in a[1:]:
+            r = f(r, b)
+        return r
+
+    return g
+
+
+def _switch(c, a, b):
+    return np.where(c, a, b)
+
+
+def _clip(x, lo, hi):
+    # scalar/basic.py:2335 Clip.impl: min/max chain
+    return np.where(x < lo, lo, np.where(x > hi, hi, x))
+
+
+def _round_half_to_even(x):
+    return np.round(x)
+
+
+def _round_half_away(x):
+    # scalar/basic.py RoundHalfAwayFromZero.impl
+    return np.where(x < 0, -np.floor(0.5 - x), np.floor(0.5 + x))
+
+
+SCALAR = {
+    "Add": _variadic(np.add),
+    "Mul": _variadic(np.multiply),
+    "Sub": np.subtract,
+    "TrueDiv": np.true_divide,
+    "IntDiv": _int_div,
+    "Mod": _mod,
+    "Pow": np.power,
+    "Neg": np.negative,
+    "Abs": np.abs,
+    "Sign": _sign,
+    "Sgn": _sign,
+    "Sqr": np.square,
+    "Sqrt": np.sqrt,
+    "Exp": np.exp,
+    "Exp2": np.exp2,
+    "Expm1": np.expm1,
+    "Log": np.log,
+    "Log2": np.log2,
+    "Log10": np.log10,
+    "Log1p": np.log1p,
+    "Sin": np.sin,
+    "Cos": np.cos,
+    "Tan": np.tan,
+    "ArcSin": np.arcsin,
+    "ArcCos": np.arccos,
+    "ArcTan": np.arctan,
+    "ArcTan2": np.arctan2,
+    "Sinh": np.sinh,
+    "Cosh": np.cosh,
+    "Tanh": np.tanh,
+    "ArcSinh": np.arcsinh,
+    "ArcCosh": np.arccosh,
+    "ArcTanh": np.arctanh,
+    "Sigmoid": scipy.special.expit,
+    "Softplus": _softplus,
+    "Log1mexp": _log1mexp,
+    "Erf": scipy.special.erf,
+    "Erfc": scipy.special.erfc,
+    "Erfinv": scipy.special.erfinv,
+    "Erfcinv": scipy.special.erfcinv,
+    "Erfcx": scipy.special.erfcx,
+    "GammaLn": scipy.special.gammaln,
+    "Gamma": scipy.special.gamma,
+    "Psi": scipy.special.psi,
+    "Reciprocal": np.reciprocal,
+    "Maximum": _variadic(np.maximum),
+    "Minimum": _variadic(np.minimum),
+    "ScalarMaximum": _variadic(np.maximum),
+    "ScalarMinimum": _variadic(np.minimum),
+    "EQ": np.equal,
+    "NEQ": np.not_equal,
+    "LT": np.less,
+    "GT": np.greater,
+    "LE": np.less_equal,
+    "GE": np.greater_equal,
+    "AND": _variadic(np.bitwise_and),
+    "OR": _variadic(np.bitwise_or),
+    "XOR": _variadic(np.bitwise_xor),
+    "Invert": np.invert,
+    "IsNan": np.isnan,
+    "IsInf": np.isinf,
+    "Switch": _switch,
+    "Clip": _clip,
+    "Identity": lambda x: x,
+    "Second": lambda a, b: np.broadcast_to(b, np.broadcast(a, b).shape),
+    "Floor": np.floor,
+    "Ceil": np.ceil,
+    "Trunc": np.trunc,
+    "RoundHalfToEven": _round_half_to_even,
+    "RoundHalfAwayFromZero": _round_half_away,
+    "Cast": lambda x: x,  # the dtype conversion is applied to every node below
+    "Deg2Rad": np.deg2rad,
+    "Rad2Deg": np.rad2deg,
+}
+
+
+def eval_scalar_body(body: dict, inputs):
+    """Evaluate a lowered scalar graph on (broadcastable) arrays."""
+    vals = []
+
+    def get(r):
+        if r[0] == "i":
+            return inputs[r[1]]
+        if r[0] == "t":
+            return vals[r[1]]
+        dt = np.dtype(r[2])
+        v = float.fromhex(r[1]) if dt.kind == "f" else r[1]
+        return np.asarray(v, dtype=dt)[()]
+
+    with np.errstate(all="ignore"):
+        for n in body["body"]:
+            args = [get(r) for r in n["in"]]
+            out = SCALAR[n["op"]](*args)
+            vals.append(np.asarray(out).astype(n["dtype"], copy=False))
+    return [get(r) for r in body["outs"]]
+
+
+# ---------------------------------------------------------------------------
+# tensor op handlers:  fn(params, inputs, node, graph) -> list of outputs
+# ---------------------------------------------------------------------------
+
+OPS = {}
+
+
+def op(name):
+    def deco(f):
+        OPS[name] = f
+        return f
+
+    return deco
+
+
+def _check_runtime_broadcast(node, graph, inputs):
+    # pytensor/tensor/elemwise.py:825-840: a dim that is not *statically*
+    # broadcastable may not be broadcast at run time.
+    ndim = max((np.ndim(i) for i in inputs), default=0)
+    for d in range(ndim):
+        lens = [np.shape(i)[d] for i in inputs if np.ndim(i) == ndim]
+        if len(set(lens)) > 1:
+            for vid, arr in zip(node.inputs, inputs):
+                if np.ndim(arr) != ndim:
+                    continue
+                static = graph.vars[vid].shape
+                if arr.shape[d] == 1 and (len(static) <= d or static[d] != 1):
+                    raise ValueError(
+                        f"Runtime broadcasting not allowed. Input has shape 1 along dimension {d}, "
+                        "but the static type does not declare it broadcastable"
+                    )
+
+
+@op("Elemwise")
+def _elemwise(p, inputs, node, graph):
+    # pytensor/tensor/elemwise.py:755-823 (Elemwise.perform)
+    _check_runtime_broadcast(node, graph, inputs)
+    outs = eval_scalar_body(p["scalar"], inputs)
+    shape = np.broadcast(*inputs).shape if inputs else ()
+    res = []
+    for o, vid in zip(outs, node.outputs):
+        dt = graph.vars[vid].dtype
+        res.append(np.array(np.broadcast_to(o, shape), dtype=dt, order="C"))
+    return res
+
+
+_REDUCE = {
+    "Add": np.add,
+    "Mul": np.multiply,
+    "Maximum": np.maximum,
+    "Minimum": np.minimum,
+    "ScalarMaximum": np.maximum,
+    "ScalarMinimum": np.minimum,
+    "AND": np.bitwise_and,
+    "OR": np.bitwise_or,
+    "XOR": np.bitwise_xor,
+}
+
+
+@op("CAReduce")
+def _careduce(p, inputs, node, graph):
+    # pytensor/tensor/elemwise.py:1493-1511 (CAReduce.perform): ufunc.reduce
+    # over the axes with ``dtype=acc_dtype`` and a final cast to ``dtype``.
+    (x,) = inputs
+    uf = _REDUCE[p["scalar_op"]]
+    axis = tuple(p["axis"])
+    acc = np.dtype(p["acc_dtype"])
+    if x.dtype.kind == "b" and p["scalar_op"] in ("AND", "OR", "XOR"):
+        r = uf.reduce(x, axis=axis)
+    else:
+        r = uf.reduce(x, axis=axis, dtype=acc) if x.size or uf.identity is not None else None
+        if r is None:
+            raise ValueError("zero-size array to reduction operation which has no identity")
+    return [np.asarray(r).astype(p["dtype"], copy=False)]
+
+
+@op("DimShuffle")
+def _dimshuffle(p, inputs, node, graph):
+    # pytensor/tensor/elemwise.py:301-320 (DimShuffle.perform): transpose +
+    # reshape; dropped dims must have length 1.
+    (x,) = inputs
+    x = np.asarray(x)
+    order = p["new_order"]
+    keep = [o for o in order if o != "x"]
+    drop = [d for d in range(x.ndim) if d not in keep]
+    for d in drop:
+        if x.shape[d] != 1:
+            raise ValueError("cannot drop a non-broadcastable dimension")
+    t = x.transpose(keep + drop)
+    shape = []
+    k = 0
+    for o in order:
+        if o == "x":
+            shape.append(1)
+        else:
+            shape.append(t.shape[k])
+            k += 1
+    return [t.reshape(shape)]
+
+
+@op("Dot22")
+def _dot22(p, inputs, node, graph):
+    # pytensor/tensor/blas/gemm.py:274 (Dot22.perform): np.dot
+    x, y = inputs
+    return [np.dot(x, y)]
+
+
+@op("Dot22Scalar")
+def _dot22s(p, inputs, node, graph):
+    # pytensor/tensor/blas/gemm.py:298+ (Dot22Scalar.perform): scalar * np.dot
+    x, y, a = inputs
+    return [np.asarray(a * np.dot(x, y))]
+
+
+@op("Dot")
+def _dot(p, inputs, node, graph):
+    # pytensor/tensor/math.py:3041+ (Dot.perform)
+    x, y = inputs
+    return [np.asarray(np.dot(x, y))]
+
+
+@op("Gemm")
+def _gemm(p, inputs, node, graph):
+    # pytensor/tensor/blas/gemm.py:183-216 (Gemm.perform): z <- b*z + a*dot(x,y);
+    # z broadcast along length-1 dims (194-198).
+    z, a, x, y, b = inputs
+    xy = np.dot(x, y)
+    if z.shape != xy.shape:
+        z = np.broadcast_to(z, xy.shape)
+    if b == 0.0:
+        out = a * xy if a != 1.0 else xy
+    else:
+        out = b * z + a * xy
+    return [np.asarray(out, dtype=z.dtype)]
+
+
+@op("Gemv")
+def _gemv(p, inputs, node, graph):
+    # pytensor/tensor/blas/gemv.py:64-108 (Gemv.perform): y <- beta*y + alpha*dot(A,x);
+    # beta == 0 => y is not read (79-86).
+    y, alpha, A, x, beta = inputs
+    if beta == 0.0:
+        out = alpha * np.dot(A, x)
+    else:
+        out = beta * y + alpha * np.dot(A, x)
+    return [np.asarray(out, dtype=y.dtype)]
+
+
+@op("Ger")
+def _ger(p, inputs, node, graph):
+    # pytensor/tensor/blas/ger.py (Ger.perform): A + alpha*outer(x,y)
+    A, alpha, x, y = inputs
+    return [np.asarray(A + alpha * np.outer(x, y), dtype=A.dtype)]
+
+
+@op("BatchedDot")
+def _bdot(p, inputs, node, graph):
+    # pytensor/tensor/blas/batched.py:69-79 (BatchedDot.perform): np.matmul,
+    # batch sizes must match exactly (44-61)
+    x, y = inputs
+    if x.shape[0] != y.shape[0]:
+        raise TypeError(f"Inputs {x.shape}, {y.shape} must have the same size in axis 0")
+    return [np.matmul(x, y)]
+
+
+@op("Cholesky")
+def _cholesky(p, inputs, node, graph):
+    # pytensor/tensor/linalg/decomposition/cholesky.py:48-83: LAPACK potrf,
+    # clean=True zeros the other triangle, info != 0 => NaN-filled result.
+    (a,) = inputs
+    if a.size == 0:
+        return [np.empty_like(a)]
+    (potrf,) = scipy.linalg.get_lapack_funcs(("potrf",), (a,))
+    c, info = potrf(a, lower=p["lower"], overwrite_a=False, clean=True)
+    if info != 0:
+        c = np.full(a.shape, np.nan, dtype=a.dtype)
+    return [np.asarray(c, dtype=a.dtype)]
+
+
+@op("SolveTriangular")
+def _solve_tri(p, inputs, node, graph):
+    # pytensor/tensor/linalg/solvers/triangular.py:32-71: LAPACK trtrs; NaN on info != 0
+    A, b = inputs
+    if A.size == 0 or b.size == 0:
+        return [np.empty_like(b)]
+    (trtrs,) = scipy.linalg.get_lapack_funcs(("trtrs",), (A, b))
+    x, info = trtrs(A, b, lower=p["lower"], trans=0, unitdiag=p["unit_diagonal"])
+    if info != 0:
+        x = np.full(b.shape, np.nan, dtype=x.dtype)
+    return [np.asarray(x)]
+
+
+@op("CholeskySolve")
+def _cho_solve(p, inputs, node, graph):
+    # pytensor/tensor/linalg/solvers/psd.py:35-53: LAPACK potrs
+    c, b = inputs
+    if c.size == 0 or b.size == 0:
+        return [np.empty_like(b)]
+    (potrs,) = scipy.linalg.get_lapack_funcs(("potrs",), (c, b))
+    x, info = potrs(c, b, lower=p["lower"])
+    if info != 0:
+        x = np.full(b.shape, np.nan, dtype=x.dtype)
+    return [np.asarray(x)]
+
+
+@op("Blockwise")
+def _blockwise(p, inputs, node, graph):
+    # pytensor/tensor/blockwise.py:542 (Blockwise.perform): loop the core op
+    # over broadcast leading batch dims (gufunc semantics).
+    core = OPS[p["core_op"]]
+    sig_in = p["signature"].split("->")[0]
+    core_ndims = [s.count(",") + 1 if s.strip("()") else 0 for s in sig_in.split("),(")]
+    batch_shapes = [np.shape(i)[: np.ndim(i) - c] for i, c in zip(inputs, core_ndims)]
+    bshape = np.broadcast_shapes(*batch_shapes)
+    bcast = [
+        np.broadcast_to(i, bshape + np.shape(i)[np.ndim(i) - c :]) for i, c in zip(inputs, core_ndims)
+    ]
+    out = None
+    for idx in np.ndindex(*bshape):
+        (r,) = core(p["core_params"], [b[idx] for b in bcast], node, graph)
+        if out is None:
+            out = np.empty(bshape + r.shape, dtype=r.dtype)
+        out[idx] = r
+    if out is None:  # empty batch
+        dt = graph.vars[node.outputs[0]].dtype
+        core_shape = np.shape(inputs[-1])[np.ndim(inputs[-1]) - core_ndims[-1] :]
+        out = np.empty(bshape + core_shape, dtype=dt)
+    return [out]
+
+
+def unflatten_index(idx_list, index_values):
+    """pytensor/tensor/subtensor.py ``unflatten_index_variables``: ints in
+    ``idx_list`` are positions into the runtime index inputs."""
+
+    def conv(e):
+        if isinstance(e, slice):
+            return slice(conv(e.start), conv(e.stop), conv(e.step))
+        if e is None:
+            return None
+        v = index_values[e]
+        if isinstance(v, np.ndarray) and v.ndim == 0:
+            return v[()]
+        return v
+
+    return tuple(conv(e) for e in idx_list)
+
+
+def _as_index(v):
+    if isinstance(v, np.ndarray) and v.ndim == 0:
+        return int(v)
+    return v
+
+
+@op("Subtensor")
+def _subtensor(p, inputs, node, graph):
+    # pytensor/tensor/subtensor.py:912-917 (Subtensor.perform)
+    x, *idx = inputs
+    cdata = unflatten_index(p["idx_list"], [_as_index(i) for i in idx])
+    return [np.asarray(x[cdata])]
+
+
+@op("IncSubtensor")
+def _inc_subtensor(p, inputs, node, graph):
+    # pytensor/tensor/subtensor.py:1441+ (IncSubtensor.perform)
+    x, y, *idx = inputs
+    cdata = unflatten_index(p["idx_list"], [_as_index(i) for i in idx])
+    out = x.copy()
+    if p["set_instead_of_inc"]:
+        out[cdata] = y
+    else:
+        out[cdata] += y
+    return [out]
+
+
+@op("AdvancedSubtensor")
+def _adv_subtensor(p, inputs, node, graph):
+    # pytensor/tensor/subtensor.py:1932+ (AdvancedSubtensor.perform): x[indices]
+    x, *idx = inputs
+    cdata = unflatten_index(p["idx_list"], idx)
+    return [np.asarray(x[cdata])]
+
+
+@op("AdvancedIncSubtensor")
+def _adv_inc_subtensor(p, inputs, node, graph):
+    # pytensor/tensor/subtensor.py:2275+ (AdvancedIncSubtensor.perform):
+    # set → out[idx] = y ; inc → np.add.at(out, idx, y) (duplicates accumulate)
+    x, y, *idx = inputs
+    cdata = unflatten_index(p["idx_list"], idx)
+    out = x.copy()
+    if p["set_instead_of_inc"]:
+        out[cdata] = y
+    elif p.get("ignore_duplicates"):
+        out[cdata] += y
+    else:
+        np.add.at(out, cdata, y)
+    return [out]
+
+
+@op("Alloc")
+def _alloc(p, inputs, node, graph):
+    # pytensor/tensor/basic.py:1545+ (Alloc.perform): broadcast value to shape
+    v, *shape = inputs
+    shape = tuple(int(s) for s in shape)
+    out = np.empty(shape, dtype=v.dtype)
+    out[...] = v
+    return [out]
+
+
+@op("AllocEmpty")
+def _alloc_empty(p, inputs, node, graph):
+    # pytensor/tensor/basic.py:4197+ (AllocEmpty.perform); contents unspecified,
+    # the oracle zero-fills so comparisons of *defined* regions stay meaningful.
+    shape = tuple(int(s) for s in inputs)
+    return [np.zeros(shape, dtype=p["dtype"])]
+
+
+@op("MakeVector")
+def _make_vector(p, inputs, node, graph):
+    # pytensor/tensor/basic.py:1900+ (MakeVector.perform)
+    return [np.asarray(inputs, dtype=p["dtype"]).reshape(len(inputs))]
+
+
+@op("Shape_i")
+def _shape_i(p, inputs, node, graph):
+    # pytensor/tensor/shape.py:201+ (Shape_i.perform)
+    return [np.asarray(np.shape(inputs[0])[p["i"]], dtype="int64")]
+
+
+@op("Shape")
+def _shape(p, inputs, node, graph):
+    return [np.asarray(np.shape(inputs[0]), dtype="int64")]
+
+
+@op("Reshape")
+def _reshape(p, inputs, node, graph):
+    # pytensor/tensor/shape.py:613+ (Reshape.perform)
+    x, shp = inputs
+    return [np.reshape(x, tuple(int(s) for s in np.asarray(shp).ravel()))]
+
+
+@op("SpecifyShape")
+def _specify_shape(p, inputs, node, graph):
+    x, *shape = inputs
+    for d, s in enumerate(shape):
+        if s is not None and np.shape(x)[d] != int(s):
+            raise AssertionError(f"SpecifyShape: dim {d} of input has shape {np.shape(x)[d]}, expected {int(s)}.")
+    return [x]
+
+
+@op("ExtractDiag")
+def _extract_diag(p, inputs, node, graph):
+    # pytensor/tensor/basic.py:3636+ (ExtractDiag.perform): np.diagonal
+    (x,) = inputs
+    return [np.asarray(x.diagonal(p["offset"], p["axis1"], p["axis2"]))]
+
+
+@op("ScalarFromTensor")
+def _scalar_from_tensor(p, inputs, node, graph):
+    # pytensor/tensor/basic.py:684+
+    return [np.asarray(inputs[0])[()]]
+
+
+@op("TensorFromScalar")
+def _tensor_from_scalar(p, inputs, node, graph):
+    # pytensor/tensor/basic.py:627+
+    return [np.asarray(inputs[0])]
+
+
+@op("Join")
+def _join(p, inputs, node, graph):
+    # pytensor/tensor/basic.py:2405+ (Join.perform): np.concatenate
+    return [np.concatenate(inputs, axis=p["axis"])]
+
+
+@op("CheckAndRaise")
+def _check_and_raise(p, inputs, node, graph):
+    # pytensor/raise_op.py:26+ (CheckAndRaise.perform)
+    x, *conds = inputs
+    if not all(np.all(c) for c in conds):
+        exc = {"AssertionError": AssertionError, "ValueError": ValueError}.get(p["exc_type"], RuntimeError)
+        raise exc(p["msg"])
+    return [x]
+
+
+@op("DeepCopyOp")
+def _deepcopy(p, inputs, node, graph):
+    # pytensor/compile/ops.py:121+
+    return [np.array(inputs[0], copy=True)]
+
+
+@op("ViewOp")
+def _view(p, inputs, node, graph):
+    # pytensor/compile/ops.py:87+
+    return [inputs[0]]
+
+
+@op("Scan")
+def _scan(p, inputs, node, graph):
+    """pytensor/scan/op.py:1827+ (``Scan.perform``), restricted to the tap kinds
+    the hot path uses: seqs, mit-sot / sit-sot recurrences, nit-sot outputs,
+    untraced sit-sot, non-seqs, optional while-condition.  (mit-mot — only
+    produced by ``Scan.pullback`` — is not restated.)
+
+    Outer input order (op.py:322-635): n_steps, seqs, mit_mot, mit_sot, sit_sot,
+    untraced_sit_sot, nit_sot lengths, non_seqs.  Recurrent buffers hold the
+    initial taps first; step t reads buffer[t + tap - min_tap] and writes
+    buffer[t - min_tap] (circularly when the buffer is shorter than needed).
+    """
+    info = p["info"]
+    inner: "Graph" = p["inner"]
+    if info["mit_mot_in_slices"]:
+        raise NotImplementedError("mit-mot scans are outside the oracle's scope")
+    n_steps = int(inputs[0])
+    k = 1
+    seqs = inputs[k : k + info["n_seqs"]]
+    k += info["n_seqs"]
+    mit_sot_taps = [list(t) for t in info["mit_sot_in_slices"]]
+    sit_sot_taps = [list(t) for t in info["sit_sot_in_slices"]]
+    n_ms, n_ss = len(mit_sot_taps), len(sit_sot_taps)
+    rec_bufs = [np.array(b, copy=True) for b in inputs[k : k + n_ms + n_ss]]
+    k += n_ms + n_ss
+    untraced = list(inputs[k : k + info["n_untraced_sit_sot"]])
+    k += info["n_untraced_sit_sot"]
+    nit_lens = [int(x) for x in inputs[k : k + info["n_nit_sot"]]]
+    k += info["n_nit_sot"]
+    non_seqs = list(inputs[k:])
+    taps = mit_sot_taps + sit_sot_taps
+    mintaps = [-min(t) for t in taps]
+    nit_bufs = [None] * info["n_nit_sot"]
+    steps_done = 0
+    for t in range(n_steps):
+        inner_in = [s[t] for s in seqs]
+        for buf, tp, mt in zip(rec_bufs, taps, mintaps):
+            L = buf.shape[0]
+            for tap in tp:
+                inner_in.append(buf[(t + mt + tap) % L])
+        inner_in += untraced
+        inner_in += non_seqs
+        outs = run_graph(inner, inner_in)
+        o = 0
+        for buf, mt in zip(rec_bufs, mintaps):
+            buf[(t + mt) % buf.shape[0]] = outs[o]
+            o += 1
+        for j in range(info["n_nit_sot"]):
+            if nit_bufs[j] is None:
+                nit_bufs[j] = np.zeros((nit_lens[j], *np.shape(outs[o])), dtype=np.asarray(outs[o]).dtype)
+            nit_bufs[j][t % nit_lens[j]] = outs[o]
+            o += 1
+        for j in range(info["n_untraced_sit_sot"]):
+            untraced[j] = outs[o]
+            o += 1
+        steps_done = t + 1
+        if info["as_while"] and bool(outs[o]):
+            break
+    res = []
+    for buf, mt in zip(rec_bufs, mintaps):
+        # rotate circular buffers so that the oldest entry comes first (op.py:2087-2130)
+        L = buf.shape[0]
+        end = (steps_done + mt) % L
+        if steps_done + mt > L and end != 0:
+            buf = np.concatenate([buf[end:], buf[:end]])
+        if info["as_while"]:
+            buf = buf[: steps_done + mt]
+        res.append(buf)
+    for j, buf in enumerate(nit_bufs):
+        if buf is None:
+            ov = inner.vars[inner.outputs[n_ms + n_ss + j]]
+            buf = np.zeros((0,) * (ov.ndim + 1), dtype=ov.dtype)
+        elif steps_done > nit_lens[j] and steps_done % nit_lens[j]:
+            e = steps_done % nit_lens[j]
+            buf = np.concatenate([buf[e:], buf[:e]])
+        if info["as_while"]:
+            buf = buf[:steps_done]
+        res.append(buf)
+    res += untraced
+    return res
+
+
+# ---------------------------------------------------------------------------
+# graph interpreter
+# ---------------------------------------------------------------------------
+
+
+def run_graph(graph, inputs):
+    """Evaluate ``graph`` (pytensor_amd.ir.Graph) on host arrays; returns a list."""
+    env = {}
+    for vid, v in graph.vars.items():
+        if v.const is not None:
+            env[vid] = v.const
+    if len(inputs) != len(graph.inputs):
+        raise TypeError(f"expected {len(graph.inputs)} inputs, got {len(inputs)}")
+    for vid, val in zip(graph.inputs, inputs):
+        env[vid] = val if graph.vars[vid].kind != "tensor" else np.asarray(val)
+    for node in graph.nodes:
+        f = OPS.get(node.op)
+        if f is None:
+            raise NotImplementedError(f"oracle has no handler for {node.op}")
+        outs = f(node.params, [env[i] for i in node.inputs], node, graph)
+        for vid, val in zip(node.outputs, outs):
+            env[vid] = val
+    return [env[o] for o in graph.outputs]

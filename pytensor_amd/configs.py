@@ -1,0 +1,78 @@
+"""Synthetic inputs for the BASELINE.json configs (NumPy only — no PyTensor).
+
+The *graphs* of the configs are built with the reference in
+``oracle/make_golden.py`` and lowered to the IR fixtures under
+``tests/golden/``; this module produces the matching synthetic inputs by
+variable name at any size, with fixed ``default_rng`` seeds.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+C4_K = 128
+C4_G = 128
+
+
+def c1_inputs(N=100_000, seed=0):
+    rng = np.random.default_rng(seed)
+    return {"x": rng.normal(size=N), "mu": np.asarray(0.3)}
+
+
+def c2_inputs(N=10_000_000, seed=1):
+    rng = np.random.default_rng(seed)
+    return {"x": rng.normal(size=N), "y": rng.normal(size=N)}
+
+
+def c3_inputs(M=4096, B=512, Bn=256, seed=2):
+    rng = np.random.default_rng(seed)
+    return {
+        "A": rng.normal(size=(M, M)),
+        "B": rng.normal(size=(M, M)),
+        "v": rng.normal(size=M),
+        "X3": rng.normal(size=(B, Bn, Bn)).astype("float32"),
+        "Y3": rng.normal(size=(B, Bn, Bn)).astype("float32"),
+    }
+
+
+def c4_inputs(N=1_000_000, K=C4_K, G=C4_G, seed=0, chain=0):
+    """Hierarchical-normal data (shared, device resident) + one parameter draw.
+
+    ``chain`` selects the parameter draw (8 independent chains = 8 draws over the
+    same data).
+    """
+    rng = np.random.default_rng(seed)
+    y = rng.normal(size=N)
+    X = rng.normal(size=(N, K))
+    gidx = rng.integers(0, G, size=N).astype("int64")
+    A = rng.normal(size=(K, K))
+    Sigma = A @ A.T + K * np.eye(K)
+    prng = np.random.default_rng(1000 + chain)
+    return {
+        "y": y,
+        "X": X,
+        "gidx": gidx,
+        "Sigma": Sigma,
+        "mu_g": np.asarray(0.1 + 0.01 * chain),
+        "log_tau": np.asarray(-0.2),
+        "z": prng.normal(size=G),
+        "beta": 0.1 * prng.normal(size=K),
+        "log_sigma": np.asarray(0.3),
+    }
+
+
+C4_DATA = ("y", "X", "gidx", "Sigma")  # shared (resident) inputs
+C4_PARAMS = ("mu_g", "log_tau", "z", "beta", "log_sigma")
+
+
+def c5_inputs(T=1000, B=64, H=1024, seed=5):
+    rng = np.random.default_rng(seed)
+    d = {
+        "xs": rng.normal(size=(T, B, H)).astype("float32"),
+        "h0": np.zeros((B, H), dtype="float32"),
+    }
+    for n in ("Wz", "Wr", "Wh", "Uz", "Ur", "Uh"):
+        d[n] = (0.03 * rng.normal(size=(H, H))).astype("float32")
+    for n in ("bz", "br", "bh"):
+        d[n] = (0.03 * rng.normal(size=H)).astype("float32")
+    return d

@@ -1,0 +1,389 @@
+"""Lower a rewritten PyTensor ``FunctionGraph`` to the portable IR (``pytensor_amd.ir``).
+
+This is the ``hip_funcify`` of the backend — the analogue of
+``pytorch_funcify`` (pytensor/link/pytorch/dispatch/basic.py:45-68) and of
+``fgraph_to_python`` (pytensor/link/utils.py:677-828) — except that instead of
+emitting Python source it records, per ``Apply`` node in toposort order, the
+reference ``Op`` class name and its ``__props__`` so the executor / oracle can
+interpret them without PyTensor.
+
+Needs PyTensor importable.  Ops without a device handler lower to a
+``HostPerform`` node that carries the live ``Op`` (not serialisable): the
+executor then does D2H → ``Op.perform`` → H2D for that node, mirroring numba's
+object-mode fallback (pytensor/link/numba/dispatch/basic.py:228-263).
+"""
+
+from __future__ import annotations
+
+from functools import singledispatch
+
+import numpy as np
+
+from pytensor.compile.ops import DeepCopyOp, TypeCastingOp, ViewOp
+from pytensor.graph.basic import Constant
+from pytensor.raise_op import CheckAndRaise
+from pytensor.scalar.basic import Cast, Composite, ScalarOp, ScalarType
+from pytensor.scan.op import Scan
+from pytensor.tensor.basic import (
+    Alloc,
+    AllocEmpty,
+    ExtractDiag,
+    Join,
+    MakeVector,
+    ScalarFromTensor,
+    TensorFromScalar,
+)
+from pytensor.tensor.blas import BatchedDot, Dot22, Dot22Scalar, Gemm, Gemv, Ger
+from pytensor.tensor.blockwise import Blockwise
+from pytensor.tensor.elemwise import CAReduce, DimShuffle, Elemwise
+from pytensor.tensor.linalg.decomposition.cholesky import Cholesky
+from pytensor.tensor.linalg.solvers.psd import CholeskySolve
+from pytensor.tensor.linalg.solvers.triangular import SolveTriangular
+from pytensor.tensor.math import Dot
+from pytensor.tensor.shape import Reshape, Shape, Shape_i, SpecifyShape
+from pytensor.tensor.subtensor import (
+    AdvancedIncSubtensor,
+    AdvancedSubtensor,
+    IncSubtensor,
+    Subtensor,
+)
+from pytensor.tensor.type import TensorType
+from pytensor.tensor.type_other import NoneTypeT, SliceType
+
+from pytensor_amd.ir import Graph
+
+
+# ---------------------------------------------------------------------------
+# scalar graphs (Composite bodies)
+# ---------------------------------------------------------------------------
+
+def _scalar_op_name(op) -> str:
+    return type(op).__name__
+
+
+def lower_scalar_op(op: ScalarOp, in_dtypes, out_dtypes) -> dict:
+    """Scalar op or ``Composite`` → SSA body.
+
+    Follows the walk of ``Composite.c_code_template``
+    (pytensor/scalar/basic.py:4111-4170): inner nodes in toposort order,
+    constants inlined as literals.
+    refs: ["i", k] input k · ["t", k] k-th body value · ["c", value, dtype] literal.
+    """
+    if isinstance(op, Composite):
+        fg = op.fgraph
+        ref = {}
+        for k, v in enumerate(fg.inputs):
+            ref[v] = ["i", k]
+        body = []
+        for node in fg.toposort():
+            args = []
+            for inp in node.inputs:
+                if inp in ref:
+                    args.append(ref[inp])
+                elif isinstance(inp, Constant):
+                    args.append(_const_ref(inp))
+                else:  # pragma: no cover
+                    raise NotImplementedError(f"dangling scalar input {inp}")
+            if isinstance(node.op, Composite):  # nested composite: flatten
+                sub = lower_scalar_op(
+                    node.op,
+                    [i.type.dtype for i in node.inputs],
+                    [o.type.dtype for o in node.outputs],
+                )
+                base = len(body)
+
+                def fix(r, base=base, args=args):
+                    if r[0] == "i":
+                        return args[r[1]]
+                    if r[0] == "t":
+                        return ["t", base + r[1]]
+                    return r
+
+                for sn in sub["body"]:
+                    body.append({**sn, "in": [fix(r) for r in sn["in"]]})
+                for out, r in zip(node.outputs, sub["outs"]):
+                    ref[out] = fix(r)
+                continue
+            if len(node.outputs) != 1:
+                raise NotImplementedError(f"multi-output scalar op {node.op}")
+            body.append(_scalar_node(node.op, args, node.outputs[0].type.dtype))
+            ref[node.outputs[0]] = ["t", len(body) - 1]
+        outs = []
+        for o in fg.outputs:
+            if o in ref:
+                outs.append(ref[o])
+            elif isinstance(o, Constant):
+                outs.append(_const_ref(o))
+            else:  # pragma: no cover
+                raise NotImplementedError
+        return {"in_dtypes": list(in_dtypes), "out_dtypes": list(out_dtypes), "body": body, "outs": outs}
+    if len(out_dtypes) != 1:
+        raise NotImplementedError(f"multi-output scalar op {op}")
+    args = [["i", k] for k in range(len(in_dtypes))]
+    return {
+        "in_dtypes": list(in_dtypes),
+        "out_dtypes": list(out_dtypes),
+        "body": [_scalar_node(op, args, out_dtypes[0])],
+        "outs": [["t", 0]],
+    }
+
+
+def _const_ref(c: Constant):
+    data = np.asarray(c.data)
+    dt = str(data.dtype)
+    if data.dtype.kind == "f":
+        return ["c", float(data).hex(), dt]
+    if data.dtype.kind == "b":
+        return ["c", int(bool(data)), dt]
+    return ["c", int(data), dt]
+
+
+def _scalar_node(op: ScalarOp, args, out_dtype) -> dict:
+    d = {"op": _scalar_op_name(op), "in": args, "dtype": str(out_dtype)}
+    return d
+
+
+# ---------------------------------------------------------------------------
+# tensor ops
+# ---------------------------------------------------------------------------
+
+def _jsonable(v):
+    if isinstance(v, (bool, int, float, str, type(None))):
+        return v
+    if isinstance(v, (np.integer,)):
+        return int(v)
+    if isinstance(v, (np.bool_,)):
+        return bool(v)
+    if isinstance(v, (tuple, list)):
+        return [_jsonable(x) for x in v]
+    if isinstance(v, np.dtype):
+        return str(v)
+    if isinstance(v, slice):
+        return v
+    raise NotImplementedError(f"prop {v!r} ({type(v)})")
+
+
+@singledispatch
+def hip_funcify(op, node, ctx):
+    """Return ``(op_name, params)`` for ``op`` or ``None`` for the host fallback."""
+    return None
+
+
+def _props(op):
+    return {k: _jsonable(v) for k, v in op._props_dict().items()}
+
+
+@hip_funcify.register(Elemwise)
+def _(op, node, ctx):
+    body = lower_scalar_op(
+        op.scalar_op,
+        [i.type.dtype for i in node.inputs],
+        [o.type.dtype for o in node.outputs],
+    )
+    return "Elemwise", {"scalar": body}
+
+
+@hip_funcify.register(CAReduce)
+def _(op, node, ctx):
+    # Sum/Prod/Max/Min/All/Any are subclasses (pytensor/tensor/math.py:3498...)
+    axis = op.axis
+    if axis is None:
+        axis = tuple(range(node.inputs[0].type.ndim))
+    acc = getattr(op, "acc_dtype", None)
+    in_dtype = node.inputs[0].type.dtype
+    out_dtype = node.outputs[0].type.dtype
+    acc_dtype = op._acc_dtype(in_dtype) if hasattr(op, "_acc_dtype") else (acc or out_dtype)
+    return "CAReduce", {
+        "scalar_op": _scalar_op_name(op.scalar_op),
+        "axis": [int(a) for a in axis],
+        "acc_dtype": str(acc_dtype),
+        "dtype": str(out_dtype),
+    }
+
+
+@hip_funcify.register(DimShuffle)
+def _(op, node, ctx):
+    return "DimShuffle", {"new_order": [("x" if o == "x" else int(o)) for o in op.new_order]}
+
+
+for _cls in (Dot22, Dot22Scalar, BatchedDot, Dot, Shape, Reshape, ScalarFromTensor,
+             TensorFromScalar, ViewOp, DeepCopyOp, SpecifyShape, Alloc):
+    @hip_funcify.register(_cls)
+    def _(op, node, ctx, _name=_cls.__name__):
+        return _name, {}
+
+
+@hip_funcify.register(TypeCastingOp)
+def _(op, node, ctx):
+    return "ViewOp", {}
+
+
+@hip_funcify.register(Gemm)
+@hip_funcify.register(Gemv)
+@hip_funcify.register(Ger)
+def _(op, node, ctx):
+    return type(op).__name__, {}
+
+
+@hip_funcify.register(AllocEmpty)
+@hip_funcify.register(MakeVector)
+def _(op, node, ctx):
+    return type(op).__name__, {"dtype": str(node.outputs[0].type.dtype)}
+
+
+@hip_funcify.register(Join)
+def _(op, node, ctx):
+    return "Join", {"axis": int(op.axis)}
+
+
+@hip_funcify.register(Shape_i)
+def _(op, node, ctx):
+    return "Shape_i", {"i": int(op.i)}
+
+
+@hip_funcify.register(ExtractDiag)
+def _(op, node, ctx):
+    return "ExtractDiag", {"offset": int(op.offset), "axis1": int(op.axis1), "axis2": int(op.axis2)}
+
+
+@hip_funcify.register(CheckAndRaise)
+def _(op, node, ctx):
+    return "CheckAndRaise", {"msg": str(op.msg), "exc_type": op.exc_type.__name__}
+
+
+@hip_funcify.register(Cholesky)
+def _(op, node, ctx):
+    return "Cholesky", {"lower": bool(op.lower)}
+
+
+@hip_funcify.register(SolveTriangular)
+def _(op, node, ctx):
+    return "SolveTriangular", {
+        "lower": bool(op.lower),
+        "unit_diagonal": bool(op.unit_diagonal),
+        "b_ndim": int(op.b_ndim),
+    }
+
+
+@hip_funcify.register(CholeskySolve)
+def _(op, node, ctx):
+    return "CholeskySolve", {"lower": bool(op.lower), "b_ndim": int(op.b_ndim)}
+
+
+@hip_funcify.register(Blockwise)
+def _(op, node, ctx):
+    core = hip_funcify(op.core_op, None, ctx)
+    if core is None or core[0] not in ("Cholesky", "SolveTriangular", "CholeskySolve"):
+        return None
+    name, params = core
+    return "Blockwise", {"core_op": name, "core_params": params, "signature": op.signature}
+
+
+def _idx_list(idx_list):
+    out = []
+    for e in idx_list:
+        if isinstance(e, slice):
+            out.append(slice(e.start, e.stop, e.step))
+        elif isinstance(e, (int, np.integer)):
+            out.append(int(e))
+        else:  # pragma: no cover
+            raise NotImplementedError(f"idx_list entry {e!r}")
+    return out
+
+
+@hip_funcify.register(Subtensor)
+def _(op, node, ctx):
+    return "Subtensor", {"idx_list": _idx_list(op.idx_list)}
+
+
+@hip_funcify.register(IncSubtensor)
+def _(op, node, ctx):
+    return "IncSubtensor", {
+        "idx_list": _idx_list(op.idx_list),
+        "set_instead_of_inc": bool(op.set_instead_of_inc),
+    }
+
+
+@hip_funcify.register(AdvancedSubtensor)
+def _(op, node, ctx):
+    return "AdvancedSubtensor", {"idx_list": _idx_list(op.idx_list)}
+
+
+@hip_funcify.register(AdvancedIncSubtensor)
+def _(op, node, ctx):
+    return "AdvancedIncSubtensor", {
+        "idx_list": _idx_list(op.idx_list),
+        "set_instead_of_inc": bool(op.set_instead_of_inc),
+        "ignore_duplicates": bool(op.ignore_duplicates),
+    }
+
+
+@hip_funcify.register(Scan)
+def _(op, node, ctx):
+    info = op.info
+    inner = lower_fgraph(op.fgraph, name="scan_inner")
+    return "Scan", {
+        "info": {
+            "n_seqs": info.n_seqs,
+            "mit_mot_in_slices": _jsonable(info.mit_mot_in_slices),
+            "mit_mot_out_slices": _jsonable(info.mit_mot_out_slices),
+            "mit_sot_in_slices": _jsonable(info.mit_sot_in_slices),
+            "sit_sot_in_slices": _jsonable(info.sit_sot_in_slices),
+            "n_nit_sot": info.n_nit_sot,
+            "n_untraced_sit_sot": info.n_untraced_sit_sot,
+            "n_non_seqs": info.n_non_seqs,
+            "as_while": bool(info.as_while),
+        },
+        "inner": inner,
+    }
+
+
+# ---------------------------------------------------------------------------
+# graph
+# ---------------------------------------------------------------------------
+
+def _var_spec(v):
+    t = v.type
+    if isinstance(t, TensorType):
+        return str(t.dtype), tuple(t.shape), "tensor"
+    if isinstance(t, ScalarType):
+        return str(t.dtype), (), "scalar"
+    if isinstance(t, SliceType):
+        return "object", (), "slice"
+    if isinstance(t, NoneTypeT):
+        return "object", (), "none"
+    raise NotImplementedError(f"unsupported variable type {t!r} for the hip linker")
+
+
+def lower_fgraph(fgraph, name="graph", allow_host_fallback=True) -> Graph:
+    g = Graph(name=name)
+    vid = {}
+
+    def get(v):
+        if v in vid:
+            return vid[v]
+        dtype, shape, kind = _var_spec(v)
+        const = None
+        if isinstance(v, Constant):
+            if kind in ("tensor", "scalar"):
+                const = np.asarray(v.data)
+                shape = const.shape
+            elif kind == "slice":
+                const = v.data
+        i = g.new_var(dtype, shape, kind=kind, const=const, name=getattr(v, "name", None))
+        vid[v] = i
+        return i
+
+    g.inputs = [get(v) for v in fgraph.inputs]
+    for node in fgraph.toposort():
+        ins = [get(v) for v in node.inputs]
+        outs = [get(v) for v in node.outputs]
+        lowered = hip_funcify(node.op, node, g)
+        if lowered is None:
+            if not allow_host_fallback:
+                raise NotImplementedError(f"no hip lowering for {node.op}")
+            g.add_node("HostPerform", {"op": node.op, "node": node, "name": str(node.op)}, ins, outs)
+        else:
+            g.add_node(lowered[0], lowered[1], ins, outs)
+    g.outputs = [get(v) for v in fgraph.outputs]
+    return g
