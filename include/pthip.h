@@ -1,0 +1,176 @@
+/* pthip.h — C ABI of the MI355X (gfx950) execution backend for PyTensor's `hip` linker.
+ *
+ * This is the drop-in boundary below `HipLinker` (pytensor_amd/linker.py): plain
+ * pointers and sizes, no Python / torch types.  The precedent in the reference is
+ * the C-thunk ABI `int (*fn)(void*)` with non-zero = failure
+ * (pytensor/link/c/cutils.py:25-43, pytensor/link/c/basic.py:1736-1761); every
+ * entry point here returns `int` (0 = ok) and parks a message retrievable with
+ * `pthip_last_error()`.
+ *
+ * Conventions
+ *   - all `const void*` / `void*` data arguments are DEVICE pointers unless named `host_*`;
+ *   - strides are in ELEMENTS (not bytes); arrays are described NumPy-style
+ *     (any sign/size of stride where noted, else contiguous row-major);
+ *   - every call enqueues on the context's single in-order HIP stream and returns
+ *     without synchronising (except where documented);
+ *   - LAPACK-style numerical failure is NOT an error: results are NaN-filled
+ *     (pytensor/tensor/linalg/decomposition/cholesky.py:78-80).
+ *
+ * Each entry point cites the reference interface it replaces.
+ */
+#ifndef PTHIP_H
+#define PTHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* dtype codes (subset of pytensor/tensor/type.py:300 `dtype_specs`) */
+enum pthip_dtype {
+  PTHIP_BOOL = 0,
+  PTHIP_I8 = 1,
+  PTHIP_I16 = 2,
+  PTHIP_I32 = 3,
+  PTHIP_I64 = 4,
+  PTHIP_U8 = 5,
+  PTHIP_F32 = 6,
+  PTHIP_F64 = 7
+};
+
+/* CAReduce scalar ops (pytensor/tensor/elemwise.py:1233; subclasses tensor/math.py:3498,3587,468,475,3438,3468) */
+enum pthip_reduce_op {
+  PTHIP_RED_ADD = 0,
+  PTHIP_RED_MUL = 1,
+  PTHIP_RED_MAX = 2,
+  PTHIP_RED_MIN = 3,
+  PTHIP_RED_AND = 4,
+  PTHIP_RED_OR = 5,
+  PTHIP_RED_XOR = 6
+};
+
+/* ---- context ------------------------------------------------------------------ */
+/* Bind the calling process to `device` (one process per GPU) and create the stream. Idempotent. */
+int pthip_init(int device);
+int pthip_device_count(int* n);
+int pthip_device_name(char* buf, size_t buflen);
+const char* pthip_last_error(void);
+int pthip_synchronize(void);
+/* raw hipStream_t of the context (for interop / event timing on the right stream) */
+void* pthip_stream(void);
+
+/* ---- memory: size-bucketed caching pool (replaces NumPy's allocator that backs
+ *      every output of Elemwise.perform etc., pytensor/tensor/elemwise.py:935-961) ---- */
+int pthip_alloc(size_t bytes, void** dptr);
+int pthip_free(void* dptr);
+int pthip_pool_stats(size_t* bytes_in_use, size_t* bytes_reserved, size_t* n_device_allocs);
+int pthip_pool_trim(void);
+int pthip_host_alloc(size_t bytes, void** hptr); /* pinned */
+int pthip_host_free(void* hptr);
+/* copies are stream-ordered; host memory may be pageable (then the copy is staged synchronously) */
+int pthip_h2d(void* dst, const void* host_src, size_t bytes);
+int pthip_d2h(void* host_dst, const void* src, size_t bytes);
+int pthip_d2d(void* dst, const void* src, size_t bytes);
+int pthip_memset(void* dst, int byte, size_t bytes);
+
+/* A private arena: between begin/end every pthip_alloc/pthip_free is served from a
+ * private free list, so that a second, captured run of the same launch sequence sees
+ * the same pointers.  Used to freeze a plan into a hipGraph. */
+int pthip_arena_begin(void** arena); /* *arena == NULL → create; else re-enter and rewind */
+int pthip_arena_end(void);
+int pthip_arena_destroy(void* arena);
+
+/* ---- hipGraph capture of the launch sequence of one Function call
+ *      (the analogue of the CVM, pytensor/link/c/c_code/lazylinker_c.c:749: one native
+ *      call per Function.__call__ instead of one Python call per node) ---- */
+int pthip_capture_begin(void);
+int pthip_capture_end(void** graph_exec);
+int pthip_graph_launch(void* graph_exec);
+int pthip_graph_destroy(void* graph_exec);
+
+/* ---- events (HIP events on the context stream) ---- */
+int pthip_event_create(void** ev);
+int pthip_event_record(void* ev);
+int pthip_event_synchronize(void* ev);
+int pthip_event_elapsed_ms(void* start, void* stop, float* ms);
+int pthip_event_destroy(void* ev);
+
+/* ---- JIT of generated fused Elemwise/Composite kernels.
+ *      Replaces the C linker's per-Op module build (pytensor/link/c/cmodule.py:2016
+ *      GCC_compiler, 612 ModuleCache) with hiprtc for gfx950. ---- */
+/* Compile HIP source to a gfx950 code object. *code is malloc'd (free with pthip_buffer_free).
+ * Works without a GPU (used by build()). `log` receives the compiler log (may be NULL). */
+int pthip_jit_compile(const char* src, const char* name, const char* const* opts, int n_opts,
+                      void** code, size_t* code_size, char* log, size_t log_len);
+void pthip_buffer_free(void* p);
+int pthip_module_load(const void* code, size_t code_size, void** module);
+int pthip_module_unload(void* module);
+int pthip_module_get_function(void* module, const char* name, void** fn);
+/* Launch with a packed argument buffer (kernel params laid out with natural alignment). */
+int pthip_launch(void* fn, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t bx, uint32_t by,
+                 uint32_t bz, uint32_t shmem_bytes, const void* host_argbuf, size_t argbuf_bytes);
+
+/* ---- CAReduce (pytensor/tensor/elemwise.py:1233 CAReduce, perform 1493-1511,
+ *      C loops elemwise_cgen.py:467-761).
+ *      out[a,b] = reduce_{r<R} x[a*sA + r*sR + b*sB], accumulated in `acc_dtype`
+ *      (elemwise.py:1383-1417) and cast to `out_dtype`; `out` is contiguous (A,B).
+ *      `ws` must hold pthip_reduce_workspace(...) bytes (may be NULL if that is 0). ---- */
+size_t pthip_reduce_workspace(int acc_dtype, int64_t A, int64_t R, int64_t B);
+int pthip_reduce(int op, int in_dtype, int acc_dtype, int out_dtype, const void* x, void* out,
+                 int64_t A, int64_t R, int64_t B, int64_t sA, int64_t sR, int64_t sB, void* ws,
+                 size_t ws_bytes);
+
+/* ---- BLAS (pytensor/tensor/blas/: Gemv gemv.py:16, Gemm gemm.py:76, Dot22 gemm.py:248,
+ *      Dot22Scalar gemm.py:298, Ger ger.py:8, BatchedDot batched.py:18).  dtype F32 or F64.
+ *      Operands are strided 2-D views (element strides), outputs contiguous row-major. ---- */
+/* out[i] = beta*y[i*sy] + alpha * sum_j A[i*sA0 + j*sA1] * x[j*sx];  beta==0 => y not read
+ * (gemv.py:79-86).  ws: pthip_gemv_workspace bytes. */
+size_t pthip_gemv_workspace(int dtype, int64_t M, int64_t N, int64_t sA0, int64_t sA1);
+int pthip_gemv(int dtype, int64_t M, int64_t N, double alpha, const void* A, int64_t sA0,
+               int64_t sA1, const void* x, int64_t sx, double beta, const void* y, int64_t sy,
+               void* out, void* ws, size_t ws_bytes);
+/* out[b] (M×N, contiguous) = beta*C[b] + alpha * A[b] (M×K) @ B[b] (K×N); batch stride 0 = shared.
+ * beta==0 => C not read (gemm.py:183-216; codegen.py:159-250). MFMA tiles. */
+int pthip_gemm(int dtype, int64_t batch, int64_t M, int64_t N, int64_t K, double alpha,
+               const void* A, int64_t sAb, int64_t sA0, int64_t sA1, const void* B, int64_t sBb,
+               int64_t sB0, int64_t sB1, double beta, const void* C, int64_t sCb, int64_t sC0,
+               int64_t sC1, void* out);
+/* out (M×N contiguous) = A + alpha * x y^T  (ger.py) */
+int pthip_ger(int dtype, int64_t M, int64_t N, double alpha, const void* A, int64_t sA0,
+              int64_t sA1, const void* x, int64_t sx, const void* y, int64_t sy, void* out);
+
+/* ---- dense linear algebra (reference calls SciPy LAPACK: Cholesky potrf
+ *      decomposition/cholesky.py:48-83; SolveTriangular trtrs solvers/triangular.py:32-71;
+ *      CholeskySolve potrs solvers/psd.py:35-53).  Row-major n×n per batch item, contiguous.
+ *      Failure (non-PD / singular) => the item's result is NaN-filled. ---- */
+int pthip_potrf(int dtype, int lower, int64_t batch, int64_t n, const void* A, void* L);
+/* solve op(T) X = B, T triangular n×n (strided), B n×nrhs (contiguous row-major), out contiguous */
+int pthip_trsm(int dtype, int lower, int trans, int unit_diag, int64_t batch, int64_t n,
+               int64_t nrhs, const void* T, int64_t sTb, int64_t sT0, int64_t sT1, const void* B,
+               int64_t sBb, void* out);
+
+/* ---- indexing / data movement (bit-exact tier; pytensor/tensor/subtensor.py:868-2614,
+ *      pytensor/tensor/basic.py:1545 Alloc, 2405 Join, compile/ops.py:121 DeepCopyOp) ---- */
+/* N-d strided copy with broadcasting (src stride 0): dst[idx·dstr] = src[idx·sstr]; ndim<=6 */
+int pthip_copy_strided(int itemsize, int ndim, const int64_t* shape, void* dst,
+                       const int64_t* dst_strides, const void* src, const int64_t* src_strides);
+/* out[i, :] = x[idx[i], :] rows of `inner` contiguous elements; x has n_rows rows with
+ * element stride sx0; negative indices wrap; out-of-range => status flag (see pthip_check_status) */
+int pthip_take_rows(int itemsize, int64_t n_idx, int64_t inner, const void* x, int64_t n_rows,
+                    int64_t sx0, const int64_t* idx, void* out);
+/* out = x (already copied by the caller); out[idx[i], :] (+)= y[i, :] — AdvancedIncSubtensor
+ * (subtensor.py:2275).  inc: deterministic (index-sorted segmented sum), set: last write wins
+ * in index order like NumPy. y_stride0 = 0 broadcasts a single row. */
+size_t pthip_scatter_rows_workspace(int64_t n_idx, int64_t n_rows, int64_t inner);
+int pthip_scatter_rows(int dtype, int inc, int64_t n_idx, int64_t inner, void* out, int64_t n_rows,
+                       const int64_t* idx, const void* y, int64_t y_stride0, void* ws,
+                       size_t ws_bytes);
+/* device-side error flag raised by kernels (index out of bounds ...); sync + read + clear */
+int pthip_check_status(int* status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTHIP_H */

@@ -1,0 +1,630 @@
+"""Fused ``Elemwise``/``Composite`` → HIP kernel source for gfx950.
+
+The reference emits the fused body with ``Composite.c_code_template``
+(pytensor/scalar/basic.py:4111-4170) by concatenating each scalar op's ``c_code``
+statement, and wraps it in the loop nest of ``Elemwise._c_all``
+(pytensor/tensor/elemwise.py:848-1167; contiguous fast path 1083-1166).  Here the
+same SSA walk emits a device expression per scalar op (same formulas as the
+reference ``c_code`` strings, cited below) and wraps it in one of three loop shapes
+designed for CDNA4 rather than for a CPU:
+
+``flat``    every operand is either fully contiguous (same shape) or a scalar
+            broadcast → grid-stride loop, 16-byte vector loads/stores per lane
+            (coalesced 1 KiB per wave instruction), ``UNROLL`` independent packs
+            in flight per thread;
+``nd``      general broadcasting / arbitrary strides → collapsed N-d index with
+            per-operand element strides (0 for broadcast dims);
+``reduce``  ``flat`` or ``nd`` loads fused with a full reduction of selected
+            outputs: per-thread accumulators (acc dtype) → wave64 butterfly →
+            LDS → one partial per workgroup; reduced outputs never touch HBM.
+
+Kernel parameters are all 8 bytes wide (pointers, ``long long``) so the host
+packs the argument buffer with plain ``struct.pack("<q...")``.
+"""
+
+from __future__ import annotations
+
+import hashlib
+import os
+
+import numpy as np
+
+CTYPE = {
+    "float64": "double",
+    "float32": "float",
+    "int64": "long long",
+    "int32": "int",
+    "int16": "short",
+    "int8": "signed char",
+    "uint8": "unsigned char",
+    "bool": "bool",
+}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_reduce_header_cache = None
+
+
+def reduce_header() -> str:
+    global _reduce_header_cache
+    if _reduce_header_cache is None:
+        src = open(os.path.join(_HERE, "csrc", "reduce_device.h")).read()
+        _reduce_header_cache = src.replace("#pragma once", "")
+    return _reduce_header_cache
+
+
+PRELUDE = r"""
+// ---- scalar helpers (formulas follow the reference c_code; citations in codegen.py) ----
+#define PT_DEV static __device__ __forceinline__
+template <class T> PT_DEV T pt_sqr(T x) { return x * x; }
+template <class T> PT_DEV T pt_max(T x, T y) { return (y > x) ? y : ((x >= y) ? x : (T)__builtin_nan("")); }
+template <class T> PT_DEV T pt_min(T x, T y) { return (y < x) ? y : ((x <= y) ? x : (T)__builtin_nan("")); }
+PT_DEV bool pt_max(bool x, bool y) { return x || y; }
+PT_DEV bool pt_min(bool x, bool y) { return x && y; }
+PT_DEV double pt_sign(double x) { return (x > 0) ? 1. : ((x < 0) ? -1. : (isnan(x) ? __builtin_nan("") : 0.)); }
+PT_DEV float pt_sign(float x) { return (x > 0) ? 1.f : ((x < 0) ? -1.f : (isnan(x) ? __builtin_nanf("") : 0.f)); }
+template <class T> PT_DEV T pt_sign(T x) { return (x >= 0) ? ((x == 0) ? 0 : 1) : -1; }
+// Python-style floor division / modulo for integers (IntDiv / Mod c_code, scalar/basic.py)
+template <class T> PT_DEV T pt_intdiv_i(T x, T y) {
+  if (y == 0) return 0;
+  T q = x / y;
+  if ((x % y != 0) && ((x < 0) != (y < 0))) q -= 1;
+  return q;
+}
+template <class T> PT_DEV T pt_mod_i(T x, T y) {
+  if (y == 0) return 0;
+  T r = x % y;
+  if (r != 0 && ((r < 0) != (y < 0))) r += y;
+  return r;
+}
+PT_DEV double pt_intdiv_f(double x, double y) { return floor(x / y); }
+PT_DEV float pt_intdiv_f(float x, float y) { return floorf(x / y); }
+PT_DEV double pt_mod_f(double x, double y) {
+  if (y == 0) return __builtin_nan("");
+  double r = fmod(x, y);
+  if (r != 0 && ((r < 0) != (y < 0))) r += y;
+  return r;
+}
+PT_DEV float pt_mod_f(float x, float y) {
+  if (y == 0) return __builtin_nanf("");
+  float r = fmodf(x, y);
+  if (r != 0 && ((r < 0) != (y < 0))) r += y;
+  return r;
+}
+PT_DEV double pt_sigmoid(double x) { return 1.0 / (1.0 + exp(-x)); }
+PT_DEV float pt_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+PT_DEV double pt_softplus(double x) {
+  return x < -37.0 ? exp(x) : x < 18.0 ? log1p(exp(x)) : x < 33.3 ? x + exp(-x) : x;
+}
+PT_DEV float pt_softplus(float x) {
+  return x < -37.0f ? expf(x) : x < 18.0f ? log1pf(expf(x)) : x < 33.3f ? x + expf(-x) : x;
+}
+PT_DEV double pt_log1mexp(double x) { return x < -0.6931471805599453 ? log1p(-exp(x)) : log(-expm1(x)); }
+PT_DEV float pt_log1mexp(float x) { return x < -0.6931471805599453f ? log1pf(-expf(x)) : logf(-expm1f(x)); }
+PT_DEV double pt_rint_even(double x) {
+  double y = floor(x), r = x - y;
+  if (r > 0.5) y += 1; else if (r == 0.5) { r = y - 2.0 * floor(0.5 * y); y += (int)r; }
+  return y;
+}
+PT_DEV float pt_rint_even(float x) {
+  float y = floorf(x), r = x - y;
+  if (r > 0.5f) y += 1; else if (r == 0.5f) { r = y - 2.0f * floorf(0.5f * y); y += (int)r; }
+  return y;
+}
+// digamma (Psi): asymptotic series with recurrence shift, as in the reference's
+// support code (scalar/math.py:403-470 `_psi`)
+PT_DEV double pt_psi(double x) {
+  const double S = 1.0e-5, C = 8.5, S3 = 8.333333333e-2, S4 = 8.333333333e-3, S5 = 3.968253968e-3,
+               D1 = -0.5772156649;
+  double y = x, psi = 0.0, R;
+  if (y <= 0.0) return psi;
+  if (y <= S) return D1 - 1.0 / y;
+  while (y < C) { psi = psi - 1.0 / y; y = y + 1; }
+  R = 1.0 / y;
+  psi = psi + log(y) - .5 * R;
+  R = R * R;
+  psi = psi - R * (S3 - R * (S4 - R * S5));
+  return psi;
+}
+PT_DEV float pt_psi(float x) { return (float)pt_psi((double)x); }
+"""
+
+
+class ScalarCodegenError(NotImplementedError):
+    pass
+
+
+def _lit(value, dtype: str) -> str:
+    dt = np.dtype(dtype)
+    if dt.kind == "f":
+        v = float.fromhex(value) if isinstance(value, str) else float(value)
+        if np.isnan(v):
+            return "__builtin_nan(\"\")" if dt == np.float64 else "__builtin_nanf(\"\")"
+        if np.isinf(v):
+            s = "__builtin_huge_val()" if dt == np.float64 else "__builtin_huge_valf()"
+            return s if v > 0 else f"(-{s})"
+        if dt == np.float64:
+            return f"{v.hex()}"  # C++17 hex float literal: bit exact
+        return f"{float(np.float32(v)).hex()}f"
+    if dt.kind == "b":
+        return "true" if value else "false"
+    v = int(value)
+    if dt == np.int64:
+        return f"({v}LL)" if v != -(2**63) else "(-9223372036854775807LL - 1)"
+    return f"(({CTYPE[str(dt)]}){v})"
+
+
+def _is_float(dt):
+    return np.dtype(dt).kind == "f"
+
+
+def _is_int(dt):
+    return np.dtype(dt).kind in "iu"
+
+
+def _f(name64, name32=None):
+    """libm-style unary: computed in the *output* dtype (upgrade_to_float ops)."""
+    name32 = name32 or name64 + "f"
+
+    def gen(args, in_dts, out_dt):
+        ct = CTYPE[out_dt]
+        fn = name64 if out_dt == "float64" else name32
+        return f"{fn}(({ct}){args[0]})"
+
+    return gen
+
+
+def _chain(op):
+    def gen(args, in_dts, out_dt):
+        ct = CTYPE[out_dt]
+        if out_dt == "bool":
+            sym = {"+": "||", "*": "&&"}[op]
+            return "(" + f" {sym} ".join(f"(bool){a}" for a in args) + ")"
+        return "(" + f" {op} ".join(f"({ct}){a}" for a in args) + ")"
+
+    return gen
+
+
+def _binop_upcast(op):
+    def gen(args, in_dts, out_dt):
+        ct = CTYPE[out_dt]
+        return f"(({ct}){args[0]} {op} ({ct}){args[1]})"
+
+    return gen
+
+
+def _cmp(op):
+    def gen(args, in_dts, out_dt):
+        # compare in the common type of the operands (C usual arithmetic conversions
+        # differ from NumPy only for mixed signed/unsigned, which we upcast explicitly)
+        common = str(np.result_type(*[np.dtype(d) for d in in_dts]))
+        ct = CTYPE.get(common, "double")
+        return f"(({ct}){args[0]} {op} ({ct}){args[1]})"
+
+    return gen
+
+
+def _bitop(op, boolop):
+    def gen(args, in_dts, out_dt):
+        if out_dt == "bool":
+            return "(" + f" {boolop} ".join(f"(bool){a}" for a in args) + ")"
+        ct = CTYPE[out_dt]
+        return "(" + f" {op} ".join(f"({ct}){a}" for a in args) + ")"
+
+    return gen
+
+
+def _truediv(args, in_dts, out_dt):
+    # TrueDiv.c_code (scalar/basic.py:1968+): discrete/discrete → (double)x / y
+    ct = CTYPE[out_dt]
+    return f"(({ct}){args[0]} / ({ct}){args[1]})"
+
+
+def _intdiv(args, in_dts, out_dt):
+    ct = CTYPE[out_dt]
+    fn = "pt_intdiv_f" if _is_float(out_dt) else "pt_intdiv_i"
+    return f"{fn}(({ct}){args[0]}, ({ct}){args[1]})"
+
+
+def _mod(args, in_dts, out_dt):
+    ct = CTYPE[out_dt]
+    fn = "pt_mod_f" if _is_float(out_dt) else "pt_mod_i"
+    return f"{fn}(({ct}){args[0]}, ({ct}){args[1]})"
+
+
+def _pow(args, in_dts, out_dt):
+    # Pow.c_code (scalar/basic.py:2250+): pow(x, y); integer outputs are cast back
+    if _is_float(out_dt):
+        ct = CTYPE[out_dt]
+        fn = "pow" if out_dt == "float64" else "powf"
+        return f"{fn}(({ct}){args[0]}, ({ct}){args[1]})"
+    return f"({CTYPE[out_dt]})pow((double){args[0]}, (double){args[1]})"
+
+
+def _abs(args, in_dts, out_dt):
+    dt = in_dts[0]
+    if _is_float(dt):
+        return f"fabs({args[0]})" if dt == "float64" else f"fabsf({args[0]})"
+    if dt in ("uint8", "bool"):
+        return args[0]
+    return f"(({args[0]}) < 0 ? -({args[0]}) : ({args[0]}))"
+
+
+def _switch(args, in_dts, out_dt):
+    ct = CTYPE[out_dt]
+    return f"(({args[0]}) ? ({ct}){args[1]} : ({ct}){args[2]})"
+
+
+def _clip(args, in_dts, out_dt):
+    ct = CTYPE[out_dt]
+    x, lo, hi = (f"({ct}){a}" for a in args)
+    return f"({x} < {lo} ? {lo} : ({x} > {hi} ? {hi} : {x}))"
+
+
+def _cast(args, in_dts, out_dt):
+    # Cast.c_code (scalar/basic.py:2435+)
+    if out_dt == "bool":
+        return f"(({args[0]}) ? true : false)"
+    return f"({CTYPE[out_dt]}){args[0]}"
+
+
+def _maxmin(fn):
+    def gen(args, in_dts, out_dt):
+        ct = CTYPE[out_dt]
+        e = f"({ct}){args[0]}"
+        for a in args[1:]:
+            e = f"{fn}({e}, ({ct}){a})"
+        return e
+
+    return gen
+
+
+def _isnan(args, in_dts, out_dt):
+    return f"isnan({args[0]})" if _is_float(in_dts[0]) else "false"
+
+
+def _isinf(args, in_dts, out_dt):
+    return f"isinf({args[0]})" if _is_float(in_dts[0]) else "false"
+
+
+def _invert(args, in_dts, out_dt):
+    return f"(!{args[0]})" if out_dt == "bool" else f"(({CTYPE[out_dt]})~{args[0]})"
+
+
+def _helper(fn):
+    def gen(args, in_dts, out_dt):
+        ct = CTYPE[out_dt]
+        return f"{fn}(" + ", ".join(f"({ct}){a}" for a in args) + ")"
+
+    return gen
+
+
+# op name (reference ScalarOp class) → expression generator
+SCALAR_EXPR = {
+    "Add": _chain("+"),  # scalar/basic.py:1835 Add.c_code
+    "Mul": _chain("*"),  # 1876
+    "Sub": _binop_upcast("-"),  # 1937
+    "TrueDiv": _truediv,  # 1968
+    "IntDiv": _intdiv,
+    "Mod": _mod,
+    "Pow": _pow,  # 2250
+    "Neg": lambda a, i, o: f"(-({CTYPE[o]}){a[0]})",
+    "Abs": _abs,  # 2524
+    "Sign": _helper("pt_sign"),  # 2575
+    "Sqr": _helper("pt_sqr"),  # 3202
+    "Sqrt": _f("sqrt"),  # 3231
+    "Exp": _f("exp"),  # 3085
+    "Exp2": _f("exp2"),
+    "Expm1": _f("expm1"),
+    "Log": _f("log"),  # 2907
+    "Log2": _f("log2"),
+    "Log10": _f("log10"),
+    "Log1p": _f("log1p"),  # 3042
+    "Sin": _f("sin"),
+    "Cos": _f("cos"),
+    "Tan": _f("tan"),
+    "ArcSin": _f("asin"),
+    "ArcCos": _f("acos"),
+    "ArcTan": _f("atan"),
+    "ArcTan2": lambda a, i, o: (
+        f"{'atan2' if o == 'float64' else 'atan2f'}(({CTYPE[o]}){a[0]}, ({CTYPE[o]}){a[1]})"
+    ),
+    "Sinh": _f("sinh"),
+    "Cosh": _f("cosh"),
+    "Tanh": _f("tanh"),  # 3702
+    "ArcSinh": _f("asinh"),
+    "ArcCosh": _f("acosh"),
+    "ArcTanh": _f("atanh"),
+    "Sigmoid": _helper("pt_sigmoid"),  # scalar/math.py:1187-1198
+    "Softplus": _helper("pt_softplus"),  # scalar/math.py:1250-1277
+    "Log1mexp": _helper("pt_log1mexp"),  # scalar/math.py:1295+
+    "Erf": _f("erf"),  # scalar/math.py:55
+    "Erfc": _f("erfc"),  # 91
+    "Erfinv": _f("erfinv"),
+    "Erfcinv": _f("erfcinv"),
+    "Erfcx": _f("erfcx"),
+    "GammaLn": _f("lgamma"),  # scalar/math.py:363
+    "Gamma": _f("tgamma"),
+    "Psi": _helper("pt_psi"),  # scalar/math.py:403
+    "Reciprocal": lambda a, i, o: f"(({CTYPE[o]})1 / ({CTYPE[o]}){a[0]})",
+    "Maximum": _maxmin("pt_max"),  # 1744
+    "Minimum": _maxmin("pt_min"),  # 1790
+    "ScalarMaximum": _maxmin("pt_max"),
+    "ScalarMinimum": _maxmin("pt_min"),
+    "EQ": _cmp("=="),  # 1411-1530
+    "NEQ": _cmp("!="),
+    "LT": _cmp("<"),
+    "GT": _cmp(">"),
+    "LE": _cmp("<="),
+    "GE": _cmp(">="),
+    "AND": _bitop("&", "&&"),
+    "OR": _bitop("|", "||"),
+    "XOR": _bitop("^", "!="),
+    "Invert": _invert,
+    "IsNan": _isnan,
+    "IsInf": _isinf,
+    "Switch": _switch,  # 1588
+    "Clip": _clip,  # 2335
+    "Identity": lambda a, i, o: f"({CTYPE[o]}){a[0]}",
+    "Second": lambda a, i, o: f"({CTYPE[o]}){a[1]}",
+    "Floor": _f("floor"),
+    "Ceil": _f("ceil"),
+    "Trunc": _f("trunc"),
+    "RoundHalfToEven": _helper("pt_rint_even"),
+    "RoundHalfAwayFromZero": _f("round"),
+    "Cast": _cast,  # 2435
+    "Deg2Rad": lambda a, i, o: f"(({CTYPE[o]}){a[0]} * ({CTYPE[o]})0.017453292519943295)",
+    "Rad2Deg": lambda a, i, o: f"(({CTYPE[o]}){a[0]} * ({CTYPE[o]})57.29577951308232)",
+}
+
+
+def supported(body: dict) -> bool:
+    return all(n["op"] in SCALAR_EXPR for n in body["body"]) and all(
+        d in CTYPE for d in body["in_dtypes"] + body["out_dtypes"]
+    )
+
+
+def emit_body(body: dict, in_names, out_names, indent="      ") -> str:
+    """SSA statements computing ``out_names`` from ``in_names`` (one element)."""
+    lines = []
+    tdt = []
+
+    def ref(r):
+        if r[0] == "i":
+            return in_names[r[1]], body["in_dtypes"][r[1]]
+        if r[0] == "t":
+            return f"t{r[1]}", tdt[r[1]]
+        return _lit(r[1], r[2]), r[2]
+
+    for k, n in enumerate(body["body"]):
+        gen = SCALAR_EXPR.get(n["op"])
+        if gen is None:
+            raise ScalarCodegenError(f"no device expression for scalar op {n['op']}")
+        pairs = [ref(r) for r in n["in"]]
+        expr = gen([p[0] for p in pairs], [p[1] for p in pairs], n["dtype"])
+        ct = CTYPE[n["dtype"]]
+        lines.append(f"{indent}const {ct} t{k} = ({ct})({expr});")
+        tdt.append(n["dtype"])
+    for name, r, dt in zip(out_names, body["outs"], body["out_dtypes"]):
+        e, _ = ref(r)
+        lines.append(f"{indent}{name} = ({CTYPE[dt]})({e});")
+    return "\n".join(lines)
+
+
+# ---------------------------------------------------------------------------
+# kernels
+# ---------------------------------------------------------------------------
+
+BLOCK = 256
+REDUCE_OPS = {"Add": "OpAdd", "Mul": "OpMul", "Maximum": "OpMax", "Minimum": "OpMin"}
+
+
+def _vec_width(dtypes) -> int:
+    """elements per 16-byte pack, limited by the widest participating dtype"""
+    w = max(np.dtype(d).itemsize for d in dtypes)
+    return max(1, 16 // w)
+
+
+def _vec_type(ctype: str, n: int) -> str:
+    return f"pt_vec<{ctype}, {n}>"
+
+
+VEC_HELPERS = r"""
+template <class T, int N> struct __attribute__((aligned(sizeof(T) * N))) pt_vec { T v[N]; };
+"""
+
+
+def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=None, unroll=2) -> str:
+    """``flat`` loop.  ``modes[k]`` ∈ {'V' contiguous vector, 'S' scalar broadcast} per input.
+
+    reduce_spec: None or list (per output) of None | (op_name, acc_dtype): reduced
+    outputs are accumulated instead of stored; the kernel then takes one partial
+    pointer per reduced output (laid out [gridDim.x]).
+    """
+    nin = len(body["in_dtypes"])
+    nout = len(body["out_dtypes"])
+    reduce_spec = reduce_spec or [None] * nout
+    params = ["long long n"]
+    for k, dt in enumerate(body["in_dtypes"]):
+        params.append(f"const {CTYPE[dt]}* __restrict__ in{k}")
+    for k, dt in enumerate(body["out_dtypes"]):
+        if reduce_spec[k] is None:
+            params.append(f"{CTYPE[dt]}* __restrict__ out{k}")
+        else:
+            params.append(f"{CTYPE[reduce_spec[k][1]]}* __restrict__ part{k}")
+    src = [reduce_header() if any(reduce_spec) else "", PRELUDE, VEC_HELPERS]
+    src.append(f'extern "C" __global__ __launch_bounds__({BLOCK}) void {name}({", ".join(params)}) {{')
+    # scalars
+    for k, m in enumerate(modes):
+        if m == "S":
+            src.append(f"  const {CTYPE[body['in_dtypes'][k]]} s{k} = in{k}[0];")
+    for k, rs in enumerate(reduce_spec):
+        if rs is not None:
+            act = CTYPE[rs[1]]
+            for u in range(unroll):
+                src.append(f"  {act} acc{k}_{u} = pthip_dev::{REDUCE_OPS[rs[0]]}::identity<{act}>();")
+    src.append(f"  const long long tid = (long long)blockIdx.x * {BLOCK} + threadIdx.x;")
+    src.append(f"  const long long nthreads = (long long)gridDim.x * {BLOCK};")
+    V = vec
+    if V > 1:
+        src.append(f"  const long long npack = n / {V};")
+        # main vector loop, `unroll` packs per iteration
+        src.append(f"  long long p = tid;")
+        src.append(f"  for (; p + {unroll - 1} * nthreads < npack; p += {unroll} * nthreads) {{")
+        for u in range(unroll):
+            for k, m in enumerate(modes):
+                if m == "V":
+                    ct = CTYPE[body["in_dtypes"][k]]
+                    src.append(f"    const {_vec_type(ct, V)} a{k}_{u} = reinterpret_cast<const {_vec_type(ct, V)}*>(in{k})[p + {u} * nthreads];")
+        for u in range(unroll):
+            for k, dt in enumerate(body["out_dtypes"]):
+                if reduce_spec[k] is None:
+                    src.append(f"    {_vec_type(CTYPE[dt], V)} r{k}_{u};")
+            src.append(f"#pragma unroll\n    for (int e = 0; e < {V}; e++) {{")
+            in_names = [(f"a{k}_{u}.v[e]" if m == "V" else f"s{k}") for k, m in enumerate(modes)]
+            out_names = []
+            for k, dt in enumerate(body["out_dtypes"]):
+                if reduce_spec[k] is None:
+                    out_names.append(f"r{k}_{u}.v[e]")
+                else:
+                    src.append(f"      {CTYPE[dt]} o{k};")
+                    out_names.append(f"o{k}")
+            src.append(emit_body(body, in_names, out_names))
+            for k, rs in enumerate(reduce_spec):
+                if rs is not None:
+                    src.append(f"      acc{k}_{u} = pthip_dev::{REDUCE_OPS[rs[0]]}::apply(acc{k}_{u}, ({CTYPE[rs[1]]})o{k});")
+            src.append("    }")
+            for k, dt in enumerate(body["out_dtypes"]):
+                if reduce_spec[k] is None:
+                    src.append(f"    reinterpret_cast<{_vec_type(CTYPE[dt], V)}*>(out{k})[p + {u} * nthreads] = r{k}_{u};")
+        src.append("  }")
+        # remaining packs one at a time, then the scalar tail
+        src.append(f"  for (; p < npack; p += nthreads) {{")
+        src.append(_flat_scalar_block(body, modes, reduce_spec, V, "p"))
+        src.append("  }")
+        src.append(f"  for (long long i = npack * {V} + tid; i < n; i += nthreads) {{")
+        src.append(_flat_elem(body, modes, reduce_spec, "i"))
+        src.append("  }")
+    else:
+        src.append(f"  for (long long i = tid; i < n; i += nthreads) {{")
+        src.append(_flat_elem(body, modes, reduce_spec, "i"))
+        src.append("  }")
+    src.append(_reduce_epilogue(reduce_spec, unroll))
+    src.append("}")
+    return "\n".join(src)
+
+
+def _flat_scalar_block(body, modes, reduce_spec, V, pvar):
+    lines = []
+    for k, m in enumerate(modes):
+        if m == "V":
+            ct = CTYPE[body["in_dtypes"][k]]
+            lines.append(f"    const {_vec_type(ct, V)} a{k} = reinterpret_cast<const {_vec_type(ct, V)}*>(in{k})[{pvar}];")
+    for k, dt in enumerate(body["out_dtypes"]):
+        if reduce_spec[k] is None:
+            lines.append(f"    {_vec_type(CTYPE[dt], V)} r{k};")
+    lines.append(f"#pragma unroll\n    for (int e = 0; e < {V}; e++) {{")
+    in_names = [(f"a{k}.v[e]" if m == "V" else f"s{k}") for k, m in enumerate(modes)]
+    out_names = []
+    for k, dt in enumerate(body["out_dtypes"]):
+        if reduce_spec[k] is None:
+            out_names.append(f"r{k}.v[e]")
+        else:
+            lines.append(f"      {CTYPE[dt]} o{k};")
+            out_names.append(f"o{k}")
+    lines.append(emit_body(body, in_names, out_names))
+    for k, rs in enumerate(reduce_spec):
+        if rs is not None:
+            lines.append(f"      acc{k}_0 = pthip_dev::{REDUCE_OPS[rs[0]]}::apply(acc{k}_0, ({CTYPE[rs[1]]})o{k});")
+    lines.append("    }")
+    for k, dt in enumerate(body["out_dtypes"]):
+        if reduce_spec[k] is None:
+            lines.append(f"    reinterpret_cast<{_vec_type(CTYPE[dt], V)}*>(out{k})[{pvar}] = r{k};")
+    return "\n".join(lines)
+
+
+def _flat_elem(body, modes, reduce_spec, ivar):
+    lines = []
+    in_names = [(f"in{k}[{ivar}]" if m == "V" else f"s{k}") for k, m in enumerate(modes)]
+    out_names = []
+    for k, dt in enumerate(body["out_dtypes"]):
+        lines.append(f"      {CTYPE[dt]} o{k};")
+        out_names.append(f"o{k}")
+    lines.append(emit_body(body, in_names, out_names))
+    for k, rs in enumerate(reduce_spec):
+        if rs is None:
+            lines.append(f"      out{k}[{ivar}] = o{k};")
+        else:
+            lines.append(f"      acc{k}_0 = pthip_dev::{REDUCE_OPS[rs[0]]}::apply(acc{k}_0, ({CTYPE[rs[1]]})o{k});")
+    return "\n".join(lines)
+
+
+def _reduce_epilogue(reduce_spec, unroll):
+    if not any(reduce_spec):
+        return ""
+    lines = []
+    for k, rs in enumerate(reduce_spec):
+        if rs is None:
+            continue
+        act = CTYPE[rs[1]]
+        op = f"pthip_dev::{REDUCE_OPS[rs[0]]}"
+        lines.append(f"  __shared__ {act} smem{k}[{BLOCK // 64}];")
+        e = f"acc{k}_0"
+        for u in range(1, unroll):
+            e = f"{op}::apply({e}, acc{k}_{u})"
+        lines.append(f"  {act} tot{k} = pthip_dev::block_reduce<{op}, {act}, {BLOCK}>({e}, smem{k});")
+        lines.append(f"  if (threadIdx.x == 0) part{k}[blockIdx.x] = tot{k};")
+    return "\n".join(lines)
+
+
+MAX_ND = 5
+
+
+def nd_kernel_source(name: str, body: dict, ndim: int, reduce_spec=None) -> str:
+    """General broadcasting loop: collapsed ``ndim``-d index (row-major over the output
+    shape), per-operand element strides (0 on broadcast dims); outputs contiguous."""
+    nin = len(body["in_dtypes"])
+    nout = len(body["out_dtypes"])
+    reduce_spec = reduce_spec or [None] * nout
+    params = ["long long n"]
+    params += [f"long long d{j}" for j in range(ndim)]
+    for k, dt in enumerate(body["in_dtypes"]):
+        params.append(f"const {CTYPE[dt]}* __restrict__ in{k}")
+        params += [f"long long s{k}_{j}" for j in range(ndim)]
+    for k, dt in enumerate(body["out_dtypes"]):
+        if reduce_spec[k] is None:
+            params.append(f"{CTYPE[dt]}* __restrict__ out{k}")
+        else:
+            params.append(f"{CTYPE[reduce_spec[k][1]]}* __restrict__ part{k}")
+    src = [reduce_header() if any(reduce_spec) else "", PRELUDE]
+    src.append(f'extern "C" __global__ __launch_bounds__({BLOCK}) void {name}({", ".join(params)}) {{')
+    for k, rs in enumerate(reduce_spec):
+        if rs is not None:
+            act = CTYPE[rs[1]]
+            src.append(f"  {act} acc{k}_0 = pthip_dev::{REDUCE_OPS[rs[0]]}::identity<{act}>();")
+    src.append(f"  for (long long i = (long long)blockIdx.x * {BLOCK} + threadIdx.x; i < n; i += (long long)gridDim.x * {BLOCK}) {{")
+    src.append("      long long rem = i;")
+    for j in range(ndim - 1, 0, -1):
+        src.append(f"      const long long c{j} = rem % d{j}; rem /= d{j};")
+    src.append("      const long long c0 = rem;")
+    in_names = []
+    for k in range(nin):
+        off = " + ".join(f"c{j} * s{k}_{j}" for j in range(ndim)) or "0"
+        in_names.append(f"in{k}[{off}]")
+    out_names = []
+    for k, dt in enumerate(body["out_dtypes"]):
+        src.append(f"      {CTYPE[dt]} o{k};")
+        out_names.append(f"o{k}")
+    src.append(emit_body(body, in_names, out_names))
+    for k, rs in enumerate(reduce_spec):
+        if rs is None:
+            src.append(f"      out{k}[i] = o{k};")
+        else:
+            src.append(f"      acc{k}_0 = pthip_dev::{REDUCE_OPS[rs[0]]}::apply(acc{k}_0, ({CTYPE[rs[1]]})o{k});")
+    src.append("  }")
+    src.append(_reduce_epilogue(reduce_spec, 1))
+    src.append("}")
+    return "\n".join(src)
+
+
+def source_key(src: str) -> str:
+    return hashlib.sha256(src.encode()).hexdigest()[:24]

@@ -1,0 +1,412 @@
+// gemm.hip — Gemm / Dot22 / Dot22Scalar / BatchedDot on MFMA tiles (gfx950).
+//
+// Reference: Gemm.perform z <- beta*z + alpha*x@y (pytensor/tensor/blas/gemm.py:183-216),
+// Dot22 (248-285), Dot22Scalar (298+), BatchedDot (batched.py:18-79); the C glue picks
+// N/T flags from strides (c_code/codegen.py:159-250) — here the same four layout cases
+// are template instances.
+//
+// fp64: v_mfma_f64_16x16x4_f64   (A: lane l -> A[l&15][l>>4]; B: B[l>>4][l&15];
+//                                 D reg r -> row (l>>4)+4r, col l&15)
+// fp32: v_mfma_f32_32x32x2_f32   (A: A[l&31][l>>5]; B: B[l>>5][l&31];
+//                                 D reg r -> row (r&3)+8(r>>2)+4(l>>5), col l&31)
+// Exact IEEE fma chains in both cases (no reduced-precision path exists on gfx950).
+//
+// Tiling: 256 threads = 4 waves (2x2), block tile 128x128, wave tile 64x64, BK = 16,
+// double-buffered LDS, next tile prefetched global->registers while the current one
+// is multiplied (one barrier per K step).  LDS images are chosen per operand layout so
+// that both the 16-byte staging writes and the fragment reads are bank-conflict free:
+//   K-contiguous operand  -> image [row][k], leading dimension 18 elements
+//   M/N-contiguous operand-> image [k][row], leading dimension 144 (f64) / 128 (f32)
+// Tile ids are remapped so that the 8 XCDs (block b runs on XCD b%8) each walk a
+// contiguous band of tile rows (L2 reuse of the A panel).
+#include "common.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int BM = 128, BN = 128, BK = 16;
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------
+// staging: global -> registers -> LDS
+// ---------------------------------------------------------------------------------
+// An operand tile is ROWS(=128) x BK(=16) elements, `row` along M (for A) or N (for B).
+// KC (K-contiguous in global memory): element (row, k) at base + row*ld + k.
+// else (row-contiguous):               element (row, k) at base + k*ld + row.
+template <class T, bool KC> struct Stage;
+
+template <bool KC> struct Stage<double, KC> {
+  static constexpr int NV = 4;                 // 16-byte vectors per thread per tile
+  static constexpr int LD = KC ? 18 : 144;     // LDS leading dimension (elements)
+  static constexpr int SIZE = KC ? 128 * 18 : 16 * 144;
+  double2 v[NV];
+  __device__ __forceinline__ void load(const double* __restrict__ base, long long ld,
+                                       long long row0, long long k0, long long rows,
+                                       long long K, bool vec_ok) {
+#pragma unroll
+    for (int p = 0; p < NV; p++) {
+      const int id = threadIdx.x + p * BLOCK;
+      if constexpr (KC) {
+        const int r = id >> 3, kv = (id & 7) * 2;
+        const long long row = row0 + r, k = k0 + kv;
+        const double* g = base + row * ld + k;
+        if (row < rows && k + 1 < K && vec_ok) v[p] = *(const double2*)g;
+        else {
+          v[p].x = (row < rows && k < K) ? g[0] : 0.0;
+          v[p].y = (row < rows && k + 1 < K) ? g[1] : 0.0;
+        }
+      } else {
+        const int kk = id >> 6, rv = (id & 63) * 2;
+        const long long row = row0 + rv, k = k0 + kk;
+        const double* g = base + k * ld + row;
+        if (k < K && row + 1 < rows && vec_ok) v[p] = *(const double2*)g;
+        else {
+          v[p].x = (k < K && row < rows) ? g[0] : 0.0;
+          v[p].y = (k < K && row + 1 < rows) ? g[1] : 0.0;
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void store(double* __restrict__ s) const {
+#pragma unroll
+    for (int p = 0; p < NV; p++) {
+      const int id = threadIdx.x + p * BLOCK;
+      if constexpr (KC) {
+        const int r = id >> 3, kv = (id & 7) * 2;
+        *(double2*)(s + r * LD + kv) = v[p];
+      } else {
+        const int kk = id >> 6, rv = (id & 63) * 2;
+        *(double2*)(s + kk * LD + rv) = v[p];
+      }
+    }
+  }
+  // fragment element for MFMA 16x16x4: row = r0 + (l&15), k = kk*4 + (l>>4)
+  static __device__ __forceinline__ double frag(const double* __restrict__ s, int r0, int kk,
+                                                int lane) {
+    if constexpr (KC) return s[(r0 + (lane & 15)) * LD + kk * 4 + (lane >> 4)];
+    else return s[(kk * 4 + (lane >> 4)) * LD + r0 + (lane & 15)];
+  }
+};
+
+template <bool KC> struct Stage<float, KC> {
+  static constexpr int NV = 2;
+  static constexpr int LD = KC ? 18 : 128;
+  static constexpr int SIZE = KC ? 128 * 18 : 16 * 128;
+  float4 v[NV];
+  __device__ __forceinline__ void load(const float* __restrict__ base, long long ld,
+                                       long long row0, long long k0, long long rows,
+                                       long long K, bool vec_ok) {
+#pragma unroll
+    for (int p = 0; p < NV; p++) {
+      const int id = threadIdx.x + p * BLOCK;
+      long long row, k, se;  // se: element stride between the 4 vector components
+      const float* g;
+      bool full;
+      if constexpr (KC) {
+        const int r = id >> 2, kv = (id & 3) * 4;
+        row = row0 + r; k = k0 + kv;
+        g = base + row * ld + k;
+        full = row < rows && k + 3 < K;
+        if (full && vec_ok) { v[p] = *(const float4*)g; continue; }
+        v[p].x = (row < rows && k < K) ? g[0] : 0.f;
+        v[p].y = (row < rows && k + 1 < K) ? g[1] : 0.f;
+        v[p].z = (row < rows && k + 2 < K) ? g[2] : 0.f;
+        v[p].w = (row < rows && k + 3 < K) ? g[3] : 0.f;
+      } else {
+        const int kk = id >> 5, rv = (id & 31) * 4;
+        row = row0 + rv; k = k0 + kk;
+        g = base + k * ld + row;
+        full = k < K && row + 3 < rows;
+        if (full && vec_ok) { v[p] = *(const float4*)g; continue; }
+        v[p].x = (k < K && row < rows) ? g[0] : 0.f;
+        v[p].y = (k < K && row + 1 < rows) ? g[1] : 0.f;
+        v[p].z = (k < K && row + 2 < rows) ? g[2] : 0.f;
+        v[p].w = (k < K && row + 3 < rows) ? g[3] : 0.f;
+      }
+      (void)se;
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ s) const {
+#pragma unroll
+    for (int p = 0; p < NV; p++) {
+      const int id = threadIdx.x + p * BLOCK;
+      if constexpr (KC) {
+        const int r = id >> 2, kv = (id & 3) * 4;
+        float2* d = (float2*)(s + r * LD + kv);  // LD=18: 8-byte aligned rows
+        d[0] = make_float2(v[p].x, v[p].y);
+        d[1] = make_float2(v[p].z, v[p].w);
+      } else {
+        const int kk = id >> 5, rv = (id & 31) * 4;
+        *(float4*)(s + kk * LD + rv) = v[p];
+      }
+    }
+  }
+  // two fragment elements for MFMA 32x32x2 pair s=0,1: row = r0 + (l&31),
+  // k = kk*4 + 2*(l>>5) + s   (same k assignment for A and B)
+  static __device__ __forceinline__ float2 frag2(const float* __restrict__ s, int r0, int kk,
+                                                 int lane) {
+    const int h = lane >> 5, i = lane & 31;
+    if constexpr (KC) return *(const float2*)(s + (r0 + i) * LD + kk * 4 + 2 * h);
+    else return make_float2(s[(kk * 4 + 2 * h) * LD + r0 + i], s[(kk * 4 + 2 * h + 1) * LD + r0 + i]);
+  }
+};
+
+__device__ __forceinline__ void tile_coords(long long tiles_m, long long tiles_n, long long& tm,
+                                            long long& tn) {
+  long long pid = blockIdx.x;
+  const long long nt = tiles_m * tiles_n;
+  if (nt % 8 == 0) {  // XCD-aware remap: XCD x gets the contiguous tile range [x*nt/8, (x+1)*nt/8)
+    const long long per = nt / 8;
+    pid = (pid % 8) * per + pid / 8;
+  }
+  tm = pid / tiles_n;
+  tn = pid % tiles_n;
+}
+
+// ---------------------------------------------------------------------------------
+// fp64 kernel
+// ---------------------------------------------------------------------------------
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(BLOCK, 2) void dgemm_kernel(
+    double* __restrict__ out, const double* __restrict__ A, const double* __restrict__ B,
+    const double* __restrict__ C, long long M, long long N, long long K, long long lda,
+    long long ldb, long long sAb, long long sBb, long long sCb, long long sC0, long long sC1,
+    double alpha, double beta, long long tiles_m, long long tiles_n, int vecA, int vecB) {
+  using SA = Stage<double, AKC>;
+  using SB = Stage<double, BKC>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* As = (double*)smem_raw;                // [2][SA::SIZE]
+  double* Bs = As + 2 * SA::SIZE;                // [2][SB::SIZE]
+  long long tm, tn;
+  tile_coords(tiles_m, tiles_n, tm, tn);
+  const long long m0 = tm * BM, n0 = tn * BN;
+  const long long bz = blockIdx.z;
+  A += bz * sAb;
+  B += bz * sBb;
+  out += bz * M * N;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm0 = (w >> 1) * 64, wn0 = (w & 1) * 64;
+  double4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  SA sa;
+  SB sb;
+  const long long nk = (K + BK - 1) / BK;
+  sa.load(A, lda, m0, 0, M, K, vecA);
+  sb.load(B, ldb, n0, 0, N, K, vecB);
+  sa.store(As);
+  sb.store(Bs);
+  __syncthreads();
+  for (long long kt = 0; kt < nk; kt++) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      sa.load(A, lda, m0, (kt + 1) * BK, M, K, vecA);
+      sb.load(B, ldb, n0, (kt + 1) * BK, N, K, vecB);
+    }
+    const double* as = As + cur * SA::SIZE;
+    const double* bs = Bs + cur * SB::SIZE;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; kk++) {
+      double af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) af[i] = SA::frag(as, wm0 + i * 16, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 4; j++) bf[j] = SB::frag(bs, wn0 + j * 16, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      sa.store(As + (cur ^ 1) * SA::SIZE);
+      sb.store(Bs + (cur ^ 1) * SB::SIZE);
+    }
+    __syncthreads();
+  }
+  // epilogue: D reg r -> row (l>>4) + 4r, col l&15
+  const bool has_c = (beta != 0.0) && C != nullptr;
+  if (has_c) C += bz * sCb;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const long long row = m0 + wm0 + i * 16 + (lane >> 4) + 4 * r;
+        const long long col = n0 + wn0 + j * 16 + (lane & 15);
+        if (row < M && col < N) {
+          double v = alpha * acc[i][j][r];
+          if (has_c) v += beta * C[row * sC0 + col * sC1];
+          out[row * N + col] = v;
+        }
+      }
+}
+
+// ---------------------------------------------------------------------------------
+// fp32 kernel
+// ---------------------------------------------------------------------------------
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(BLOCK, 2) void sgemm_kernel(
+    float* __restrict__ out, const float* __restrict__ A, const float* __restrict__ B,
+    const float* __restrict__ C, long long M, long long N, long long K, long long lda,
+    long long ldb, long long sAb, long long sBb, long long sCb, long long sC0, long long sC1,
+    float alpha, float beta, long long tiles_m, long long tiles_n, int vecA, int vecB) {
+  using SA = Stage<float, AKC>;
+  using SB = Stage<float, BKC>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* As = (float*)smem_raw;
+  float* Bs = As + 2 * SA::SIZE;
+  long long tm, tn;
+  tile_coords(tiles_m, tiles_n, tm, tn);
+  const long long m0 = tm * BM, n0 = tn * BN;
+  const long long bz = blockIdx.z;
+  A += bz * sAb;
+  B += bz * sBb;
+  out += bz * M * N;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm0 = (w >> 1) * 64, wn0 = (w & 1) * 64;
+  float16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  SA sa;
+  SB sb;
+  const long long nk = (K + BK - 1) / BK;
+  sa.load(A, lda, m0, 0, M, K, vecA);
+  sb.load(B, ldb, n0, 0, N, K, vecB);
+  sa.store(As);
+  sb.store(Bs);
+  __syncthreads();
+  for (long long kt = 0; kt < nk; kt++) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      sa.load(A, lda, m0, (kt + 1) * BK, M, K, vecA);
+      sb.load(B, ldb, n0, (kt + 1) * BK, N, K, vecB);
+    }
+    const float* as = As + cur * SA::SIZE;
+    const float* bs = Bs + cur * SB::SIZE;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; kk++) {
+      float2 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) af[i] = SA::frag2(as, wm0 + i * 32, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 2; j++) bf[j] = SB::frag2(bs, wn0 + j * 32, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) {
+      sa.store(As + (cur ^ 1) * SA::SIZE);
+      sb.store(Bs + (cur ^ 1) * SB::SIZE);
+    }
+    __syncthreads();
+  }
+  const bool has_c = (beta != 0.f) && C != nullptr;
+  if (has_c) C += bz * sCb;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const long long row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const long long col = n0 + wn0 + j * 32 + (lane & 31);
+        if (row < M && col < N) {
+          float v = alpha * acc[i][j][r];
+          if (has_c) v += beta * C[row * sC0 + col * sC1];
+          out[row * N + col] = v;
+        }
+      }
+}
+
+template <class T> struct KernelSel;
+template <> struct KernelSel<double> {
+  template <bool a, bool b> static auto get() { return dgemm_kernel<a, b>; }
+};
+template <> struct KernelSel<float> {
+  template <bool a, bool b> static auto get() { return sgemm_kernel<a, b>; }
+};
+
+template <class T, bool AKC, bool BKC>
+int launch(long long batch, long long M, long long N, long long K, T alpha, const T* A,
+           long long sAb, long long lda, const T* B, long long sBb, long long ldb, T beta,
+           const T* C, long long sCb, long long sC0, long long sC1, T* out) {
+  hipStream_t st = pthip::ctx().stream;
+  using SA = Stage<T, AKC>;
+  using SB = Stage<T, BKC>;
+  const size_t shmem = (size_t)(2 * SA::SIZE + 2 * SB::SIZE) * sizeof(T);
+  auto k = KernelSel<T>::template get<AKC, BKC>();
+  static bool attr_set = false;
+  if (!attr_set && shmem > 64 * 1024) {
+    PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    attr_set = true;
+  }
+  const long long tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  constexpr int VN = 16 / sizeof(T);
+  const int vecA = (lda % VN == 0) && (((uintptr_t)A) % 16 == 0) && (sAb % VN == 0);
+  const int vecB = (ldb % VN == 0) && (((uintptr_t)B) % 16 == 0) && (sBb % VN == 0);
+  dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)batch);
+  hipLaunchKernelGGL(k, grid, dim3(BLOCK), shmem, st, out, A, B, C, M, N, K, lda, ldb, sAb, sBb, sCb,
+                     sC0, sC1, alpha, beta, tiles_m, tiles_n, vecA, vecB);
+  return pthip::post_launch("gemm");
+}
+
+template <class T>
+int gemm_typed(long long batch, long long M, long long N, long long K, double alpha, const void* A,
+               long long sAb, long long sA0, long long sA1, const void* B, long long sBb,
+               long long sB0, long long sB1, double beta, const void* C, long long sCb,
+               long long sC0, long long sC1, void* out) {
+  if (batch == 0 || M == 0 || N == 0) return 0;
+  // Normalise the strides of degenerate (length-1) dims, then classify:
+  //   A (m,k) at m*sA0 + k*sA1 : K-contiguous iff sA1 == 1 (lda = sA0), else M-contiguous (lda = sA1)
+  //   B (k,n) at k*sB0 + n*sB1 : N-contiguous iff sB1 == 1 (ldb = sB0), else K-contiguous (ldb = sB1)
+  if (K == 1) sA1 = 1;
+  if (M == 1) { if (sA1 == 1) sA0 = K; else sA0 = 1; }
+  if (N == 1) sB1 = 1;
+  if (K == 1) { if (sB1 == 1) sB0 = N; else sB0 = 1; }
+  bool akc, bkc;
+  long long lda, ldb;
+  if (sA1 == 1) { akc = true; lda = sA0; }
+  else if (sA0 == 1) { akc = false; lda = sA1; }
+  else return pthip::set_error("pthip_gemm: A has no unit stride (%lld, %lld)", (long long)sA0, (long long)sA1);
+  if (sB1 == 1) { bkc = false; ldb = sB0; }
+  else if (sB0 == 1) { bkc = true; ldb = sB1; }
+  else return pthip::set_error("pthip_gemm: B has no unit stride (%lld, %lld)", (long long)sB0, (long long)sB1);
+  const T* a = (const T*)A;
+  const T* b = (const T*)B;
+  const T* c = (const T*)C;
+  T* o = (T*)out;
+#define GO(X, Y) return launch<T, X, Y>(batch, M, N, K, (T)alpha, a, sAb, lda, b, sBb, ldb, (T)beta, c, sCb, sC0, sC1, o)
+  if (akc && bkc) GO(true, true);
+  if (akc && !bkc) GO(true, false);
+  if (!akc && bkc) GO(false, true);
+  GO(false, false);
+#undef GO
+}
+
+}  // namespace
+
+extern "C" int pthip_gemm(int dtype, int64_t batch, int64_t M, int64_t N, int64_t K, double alpha,
+                          const void* A, int64_t sAb, int64_t sA0, int64_t sA1, const void* B,
+                          int64_t sBb, int64_t sB0, int64_t sB1, double beta, const void* C,
+                          int64_t sCb, int64_t sC0, int64_t sC1, void* out) {
+  PTHIP_REQUIRE_INIT();
+  if (dtype == PTHIP_F64)
+    return gemm_typed<double>(batch, M, N, K, alpha, A, sAb, sA0, sA1, B, sBb, sB0, sB1, beta, C, sCb, sC0, sC1, out);
+  if (dtype == PTHIP_F32)
+    return gemm_typed<float>(batch, M, N, K, alpha, A, sAb, sA0, sA1, B, sBb, sB0, sB1, beta, C, sCb, sC0, sC1, out);
+  return pthip::set_error("pthip_gemm: dtype %d not supported (float32/float64 only)", dtype);
+}

@@ -1,0 +1,431 @@
+// runtime.hip — context, caching device pool, copies, hipGraph capture, events, hiprtc JIT.
+// MI355X-native: one process per GPU, one in-order stream per process, everything
+// stream-ordered; memory is pooled in power-of-two-ish buckets and never returned to the
+// driver on the hot path (288 GB of HBM3E: reuse, don't free).
+#include "common.h"
+
+#include <hip/hiprtc.h>
+
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+namespace pthip {
+
+static thread_local std::string g_err;
+static Context g_ctx;
+Context& ctx() { return g_ctx; }
+
+int set_error(const char* fmt, ...) {
+  char buf[2048];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return 1;
+}
+
+int check(hipError_t e, const char* what) {
+  return set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+}
+
+// ---------------------------------------------------------------------------------
+// caching pool
+// ---------------------------------------------------------------------------------
+struct Block {
+  void* ptr;
+  size_t size;
+};
+
+static size_t round_size(size_t n) {
+  if (n == 0) n = 1;
+  if (n <= 4096) return (n + 255) & ~size_t(255);
+  // buckets: 1/8-octave steps above 4 KiB keep internal fragmentation <= 12.5 %
+  size_t p = size_t(1) << (63 - __builtin_clzll(n));
+  size_t step = p >> 3;
+  return (n + step - 1) / step * step;
+}
+
+struct Arena {
+  std::multimap<size_t, void*> free_list;     // private free blocks
+  std::unordered_map<void*, size_t> live;     // blocks handed out
+  std::vector<Block> owned;                   // everything the arena owns
+};
+
+struct Pool {
+  std::mutex mu;
+  std::multimap<size_t, void*> free_list;
+  std::unordered_map<void*, size_t> live;  // ptr -> rounded size
+  std::unordered_map<void*, Arena*> arena_of;
+  Arena* active = nullptr;
+  size_t in_use = 0, reserved = 0, n_allocs = 0;
+};
+static Pool g_pool;
+
+static int pool_alloc(size_t bytes, void** out) {
+  size_t sz = round_size(bytes);
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  if (Arena* a = g_pool.active) {
+    auto it = a->free_list.lower_bound(sz);
+    if (it != a->free_list.end() && it->first == sz) {
+      *out = it->second;
+      a->free_list.erase(it);
+      a->live[*out] = sz;
+      return 0;
+    }
+    if (g_ctx.capturing)
+      return set_error("pool: allocation of %zu bytes during graph capture missed the arena "
+                       "(launch sequence differs from the warm-up run)", bytes);
+    void* p = nullptr;
+    PTHIP_CHECK(hipMalloc(&p, sz));
+    g_pool.reserved += sz;
+    g_pool.n_allocs++;
+    a->owned.push_back({p, sz});
+    a->live[p] = sz;
+    g_pool.arena_of[p] = a;
+    *out = p;
+    return 0;
+  }
+  auto it = g_pool.free_list.lower_bound(sz);
+  if (it != g_pool.free_list.end() && it->first == sz) {
+    *out = it->second;
+    g_pool.free_list.erase(it);
+  } else {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, sz);
+    if (e != hipSuccess) {
+      // release cached blocks and retry once
+      for (auto& kv : g_pool.free_list) {
+        (void)hipFree(kv.second);
+        g_pool.reserved -= kv.first;
+      }
+      g_pool.free_list.clear();
+      (void)hipGetLastError();
+      e = hipMalloc(&p, sz);
+      if (e != hipSuccess) return check(e, "hipMalloc");
+    }
+    g_pool.reserved += sz;
+    g_pool.n_allocs++;
+    *out = p;
+  }
+  g_pool.live[*out] = sz;
+  g_pool.in_use += sz;
+  return 0;
+}
+
+static int pool_free(void* p) {
+  if (!p) return 0;
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  auto ao = g_pool.arena_of.find(p);
+  if (ao != g_pool.arena_of.end()) {
+    Arena* a = ao->second;
+    auto it = a->live.find(p);
+    if (it == a->live.end()) return set_error("pool: double free of arena block %p", p);
+    a->free_list.emplace(it->second, p);
+    a->live.erase(it);
+    return 0;
+  }
+  auto it = g_pool.live.find(p);
+  if (it == g_pool.live.end()) return set_error("pool: free of unknown pointer %p", p);
+  // Stream-ordered reuse: the single in-order stream guarantees that any kernel
+  // enqueued later runs after every earlier user of this block.
+  g_pool.free_list.emplace(it->second, p);
+  g_pool.in_use -= it->second;
+  g_pool.live.erase(it);
+  return 0;
+}
+
+}  // namespace pthip
+
+using namespace pthip;
+
+extern "C" {
+
+int pthip_init(int device) {
+  if (g_ctx.device == device && g_ctx.stream) return 0;
+  int n = 0;
+  PTHIP_CHECK(hipGetDeviceCount(&n));
+  if (n <= 0) return set_error("pthip_init: no HIP device visible");
+  if (device < 0 || device >= n) return set_error("pthip_init: device %d out of range (%d visible)", device, n);
+  PTHIP_CHECK(hipSetDevice(device));
+  if (!g_ctx.stream) PTHIP_CHECK(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+  if (!g_ctx.status_dev) {
+    PTHIP_CHECK(hipMalloc((void**)&g_ctx.status_dev, 256));
+    PTHIP_CHECK(hipMemset(g_ctx.status_dev, 0, 256));
+  }
+  g_ctx.device = device;
+  return 0;
+}
+
+int pthip_device_count(int* n) {
+  hipError_t e = hipGetDeviceCount(n);
+  if (e != hipSuccess) {
+    *n = 0;
+    (void)hipGetLastError();
+  }
+  return 0;
+}
+
+int pthip_device_name(char* buf, size_t buflen) {
+  PTHIP_REQUIRE_INIT();
+  hipDeviceProp_t prop;
+  PTHIP_CHECK(hipGetDeviceProperties(&prop, g_ctx.device));
+  snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return 0;
+}
+
+const char* pthip_last_error(void) { return g_err.c_str(); }
+
+int pthip_synchronize(void) {
+  PTHIP_REQUIRE_INIT();
+  PTHIP_CHECK(hipStreamSynchronize(g_ctx.stream));
+  return 0;
+}
+
+void* pthip_stream(void) { return (void*)g_ctx.stream; }
+
+int pthip_alloc(size_t bytes, void** dptr) {
+  PTHIP_REQUIRE_INIT();
+  return pool_alloc(bytes, dptr);
+}
+
+int pthip_free(void* dptr) { return pool_free(dptr); }
+
+int pthip_pool_stats(size_t* in_use, size_t* reserved, size_t* n_allocs) {
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  if (in_use) *in_use = g_pool.in_use;
+  if (reserved) *reserved = g_pool.reserved;
+  if (n_allocs) *n_allocs = g_pool.n_allocs;
+  return 0;
+}
+
+int pthip_pool_trim(void) {
+  PTHIP_REQUIRE_INIT();
+  PTHIP_CHECK(hipStreamSynchronize(g_ctx.stream));
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  for (auto& kv : g_pool.free_list) {
+    (void)hipFree(kv.second);
+    g_pool.reserved -= kv.first;
+  }
+  g_pool.free_list.clear();
+  return 0;
+}
+
+int pthip_host_alloc(size_t bytes, void** hptr) {
+  PTHIP_REQUIRE_INIT();
+  PTHIP_CHECK(hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+  return 0;
+}
+
+int pthip_host_free(void* hptr) {
+  if (hptr) PTHIP_CHECK(hipHostFree(hptr));
+  return 0;
+}
+
+int pthip_h2d(void* dst, const void* src, size_t bytes) {
+  PTHIP_REQUIRE_INIT();
+  if (!bytes) return 0;
+  PTHIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_ctx.stream));
+  return 0;
+}
+
+int pthip_d2h(void* dst, const void* src, size_t bytes) {
+  PTHIP_REQUIRE_INIT();
+  if (!bytes) return 0;
+  PTHIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_ctx.stream));
+  return 0;
+}
+
+int pthip_d2d(void* dst, const void* src, size_t bytes) {
+  PTHIP_REQUIRE_INIT();
+  if (!bytes) return 0;
+  PTHIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_ctx.stream));
+  return 0;
+}
+
+int pthip_memset(void* dst, int byte, size_t bytes) {
+  PTHIP_REQUIRE_INIT();
+  if (!bytes) return 0;
+  PTHIP_CHECK(hipMemsetAsync(dst, byte, bytes, g_ctx.stream));
+  return 0;
+}
+
+// ---- arena --------------------------------------------------------------------
+int pthip_arena_begin(void** arena) {
+  PTHIP_REQUIRE_INIT();
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  if (g_pool.active) return set_error("pthip_arena_begin: an arena is already active");
+  Arena* a = (Arena*)*arena;
+  if (!a) {
+    a = new Arena();
+    *arena = a;
+  } else {
+    if (!a->live.empty())
+      return set_error("pthip_arena_begin: %zu blocks of the arena are still live", a->live.size());
+    // rewind: every owned block is free again, in deterministic (size, address) order
+    a->free_list.clear();
+    for (auto& b : a->owned) a->free_list.emplace(b.size, b.ptr);
+  }
+  g_pool.active = a;
+  return 0;
+}
+
+int pthip_arena_end(void) {
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  g_pool.active = nullptr;
+  return 0;
+}
+
+int pthip_arena_destroy(void* arena) {
+  if (!arena) return 0;
+  PTHIP_CHECK(hipStreamSynchronize(g_ctx.stream));
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  Arena* a = (Arena*)arena;
+  if (g_pool.active == a) g_pool.active = nullptr;
+  for (auto& b : a->owned) {
+    g_pool.arena_of.erase(b.ptr);
+    (void)hipFree(b.ptr);
+    g_pool.reserved -= b.size;
+  }
+  delete a;
+  return 0;
+}
+
+// ---- graph capture -----------------------------------------------------------
+int pthip_capture_begin(void) {
+  PTHIP_REQUIRE_INIT();
+  if (g_ctx.capturing) return set_error("pthip_capture_begin: already capturing");
+  PTHIP_CHECK(hipStreamBeginCapture(g_ctx.stream, hipStreamCaptureModeThreadLocal));
+  g_ctx.capturing = true;
+  return 0;
+}
+
+int pthip_capture_end(void** graph_exec) {
+  if (!g_ctx.capturing) return set_error("pthip_capture_end: not capturing");
+  g_ctx.capturing = false;
+  hipGraph_t graph = nullptr;
+  PTHIP_CHECK(hipStreamEndCapture(g_ctx.stream, &graph));
+  hipGraphExec_t exec = nullptr;
+  hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) return check(e, "hipGraphInstantiate");
+  *graph_exec = (void*)exec;
+  return 0;
+}
+
+int pthip_graph_launch(void* graph_exec) {
+  PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, g_ctx.stream));
+  return 0;
+}
+
+int pthip_graph_destroy(void* graph_exec) {
+  if (graph_exec) PTHIP_CHECK(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  return 0;
+}
+
+// ---- events -----------------------------------------------------------------
+int pthip_event_create(void** ev) {
+  PTHIP_REQUIRE_INIT();
+  hipEvent_t e;
+  PTHIP_CHECK(hipEventCreate(&e));
+  *ev = (void*)e;
+  return 0;
+}
+int pthip_event_record(void* ev) {
+  PTHIP_CHECK(hipEventRecord((hipEvent_t)ev, g_ctx.stream));
+  return 0;
+}
+int pthip_event_synchronize(void* ev) {
+  PTHIP_CHECK(hipEventSynchronize((hipEvent_t)ev));
+  return 0;
+}
+int pthip_event_elapsed_ms(void* a, void* b, float* ms) {
+  PTHIP_CHECK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+  return 0;
+}
+int pthip_event_destroy(void* ev) {
+  if (ev) PTHIP_CHECK(hipEventDestroy((hipEvent_t)ev));
+  return 0;
+}
+
+// ---- JIT ----------------------------------------------------------------------
+int pthip_jit_compile(const char* src, const char* name, const char* const* opts, int n_opts,
+                      void** code, size_t* code_size, char* log, size_t log_len) {
+  hiprtcProgram prog;
+  hiprtcResult r = hiprtcCreateProgram(&prog, src, name, 0, nullptr, nullptr);
+  if (r != HIPRTC_SUCCESS) return set_error("hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
+  std::vector<const char*> o;
+  o.push_back("--offload-arch=gfx950");
+  o.push_back("-O3");
+  o.push_back("-std=c++17");
+  for (int i = 0; i < n_opts; i++) o.push_back(opts[i]);
+  r = hiprtcCompileProgram(prog, (int)o.size(), o.data());
+  size_t ls = 0;
+  hiprtcGetProgramLogSize(prog, &ls);
+  std::string lg(ls + 1, '\0');
+  if (ls) hiprtcGetProgramLog(prog, lg.data());
+  if (log && log_len) {
+    strncpy(log, lg.c_str(), log_len - 1);
+    log[log_len - 1] = 0;
+  }
+  if (r != HIPRTC_SUCCESS) {
+    hiprtcDestroyProgram(&prog);
+    return set_error("hiprtc compile of %s failed: %s\n%s", name, hiprtcGetErrorString(r), lg.c_str());
+  }
+  size_t cs = 0;
+  hiprtcGetCodeSize(prog, &cs);
+  void* buf = malloc(cs);
+  hiprtcGetCode(prog, (char*)buf);
+  hiprtcDestroyProgram(&prog);
+  *code = buf;
+  *code_size = cs;
+  return 0;
+}
+
+void pthip_buffer_free(void* p) { free(p); }
+
+int pthip_module_load(const void* code, size_t code_size, void** module) {
+  PTHIP_REQUIRE_INIT();
+  (void)code_size;
+  hipModule_t m;
+  PTHIP_CHECK(hipModuleLoadData(&m, code));
+  *module = (void*)m;
+  return 0;
+}
+
+int pthip_module_unload(void* module) {
+  if (module) PTHIP_CHECK(hipModuleUnload((hipModule_t)module));
+  return 0;
+}
+
+int pthip_module_get_function(void* module, const char* name, void** fn) {
+  hipFunction_t f;
+  PTHIP_CHECK(hipModuleGetFunction(&f, (hipModule_t)module, name));
+  *fn = (void*)f;
+  return 0;
+}
+
+int pthip_launch(void* fn, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t bx, uint32_t by,
+                 uint32_t bz, uint32_t shmem, const void* argbuf, size_t argbuf_bytes) {
+  PTHIP_REQUIRE_INIT();
+  size_t sz = argbuf_bytes;
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, (void*)argbuf, HIP_LAUNCH_PARAM_BUFFER_SIZE,
+                    &sz, HIP_LAUNCH_PARAM_END};
+  PTHIP_CHECK(hipModuleLaunchKernel((hipFunction_t)fn, gx, gy, gz, bx, by, bz, shmem, g_ctx.stream,
+                                    nullptr, config));
+  return 0;
+}
+
+int pthip_check_status(int* status) {
+  PTHIP_REQUIRE_INIT();
+  int h = 0;
+  PTHIP_CHECK(hipMemcpyAsync(&h, g_ctx.status_dev, sizeof(int), hipMemcpyDeviceToHost, g_ctx.stream));
+  PTHIP_CHECK(hipStreamSynchronize(g_ctx.stream));
+  if (h) PTHIP_CHECK(hipMemsetAsync(g_ctx.status_dev, 0, sizeof(int), g_ctx.stream));
+  *status = h;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,178 @@
+"""BLAS-family ops: ``Gemv``, ``Ger``, ``Dot22``, ``Dot22Scalar``, ``Gemm``, ``BatchedDot``, ``Dot``.
+
+Reference: pytensor/tensor/blas/ (gemv.py:16, ger.py:8, gemm.py:76,248,298,
+batched.py:18) and ``Dot`` (pytensor/tensor/math.py:3041).  The stride→layout
+decisions made by the reference's C glue (c_code/codegen.py:159-250: pick N/T flags
+from strides, copy when no unit stride 111-157) are made here on the host and passed
+to the kernels as element strides.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from pytensor_amd import ffi
+from pytensor_amd.device import DeviceArray
+from pytensor_amd.dispatch import handler
+from pytensor_amd.executor import HostValue
+
+
+def _scalar(env, v) -> float:
+    return float(env.to_host(v))
+
+
+def _dt(x) -> int:
+    return ffi.np_dtype_code(x.dtype)
+
+
+def _unit_stride_2d(x: DeviceArray) -> DeviceArray:
+    """Like the reference's C glue (codegen.py:111-157): copy operands that have no
+    unit stride (or negative strides) into a fresh row-major buffer."""
+    ok = all(s >= 0 for s in x.strides) and (1 in x.strides or x.size <= 1 or min(x.shape) == 1)
+    return x if ok else x.contiguous()
+
+
+def gemv_device(env, alpha, A, x, beta, y):
+    lib = env.lib
+    M, N = A.shape
+    if x.shape[0] != N:
+        raise ValueError(f"Shape mismatch: A.shape[1] != x.shape[0] ({A.shape}, {x.shape})")
+    A = _unit_stride_2d(A)
+    out = DeviceArray.empty((M,), A.dtype)
+    if y is not None and y.shape[0] != M:
+        raise ValueError(f"Shape mismatch: y.shape[0] != A.shape[0] ({y.shape}, {A.shape})")
+    sA0, sA1 = A.strides
+    if N == 1:
+        sA1 = 1
+    if M == 1 and sA1 != 1:
+        sA0 = 1
+    ws_bytes = lib.pthip_gemv_workspace(_dt(A), M, N, sA0, sA1)
+    ws = DeviceArray.empty((ws_bytes,), "uint8") if ws_bytes else None
+    ffi.check(
+        lib.pthip_gemv(
+            _dt(A), M, N, float(alpha), A.ptr, sA0, sA1, x.ptr, x.strides[0] if x.shape[0] > 1 else 1,
+            float(beta), y.ptr if y is not None else None, (y.strides[0] if y.shape[0] > 1 else 1) if y is not None else 0,
+            out.ptr, ws.ptr if ws is not None else None, ws_bytes,
+        )
+    )
+    return out
+
+
+@handler("Gemv")
+def gemv(node, inputs, env):
+    y, alpha, A, x, beta = inputs
+    alpha, beta = _scalar(env, alpha), _scalar(env, beta)
+    A, x = env.to_device(A), env.to_device(x)
+    y = env.to_device(y)
+    return [gemv_device(env, alpha, A, x, beta, None if beta == 0.0 else y)]
+
+
+@handler("Ger")
+def ger(node, inputs, env):
+    A, alpha, x, y = inputs
+    alpha = _scalar(env, alpha)
+    A, x, y = env.to_device(A), env.to_device(x), env.to_device(y)
+    M, N = A.shape
+    if x.shape[0] != M or y.shape[0] != N:
+        raise ValueError("Ger: shape mismatch")
+    out = DeviceArray.empty((M, N), A.dtype)
+    ffi.check(
+        env.lib.pthip_ger(_dt(A), M, N, alpha, A.ptr, A.strides[0], A.strides[1], x.ptr, x.strides[0], y.ptr, y.strides[0], out.ptr)
+    )
+    return [out]
+
+
+def gemm_device(env, alpha, A, B, beta=0.0, Cm=None, batch=None):
+    """out = beta*C + alpha*A@B on MFMA tiles; A (.., M, K), B (.., K, N)."""
+    lib = env.lib
+    if batch is None:
+        M, K = A.shape
+        K2, N = B.shape
+        nb = 1
+        sAb = sBb = 0
+        sA, sB = A.strides, B.strides
+    else:
+        nb, M, K = A.shape
+        nb2, K2, N = B.shape
+        if nb != nb2:
+            raise TypeError(f"Inputs [{A.shape}, {B.shape}] must have the same size in axis 0")
+        sAb, sBb = A.strides[0], B.strides[0]
+        sA, sB = A.strides[1:], B.strides[1:]
+    if K != K2:
+        raise ValueError(f"Shape mismatch: x has {K} cols but y has {K2} rows")
+    shape = (M, N) if batch is None else (nb, M, N)
+    out = DeviceArray.empty(shape, A.dtype)
+    if out.size == 0:
+        return out
+    if Cm is not None and beta != 0.0:
+        cs = Cm.strides
+        cshape = Cm.shape
+        sC0 = 0 if cshape[-2] == 1 and M != 1 else cs[-2]
+        sC1 = 0 if cshape[-1] == 1 and N != 1 else cs[-1]
+        sCb = cs[0] if batch is not None else 0
+        cptr = Cm.ptr
+    else:
+        sC0 = sC1 = sCb = 0
+        cptr = None
+        beta = 0.0
+    ffi.check(
+        lib.pthip_gemm(
+            _dt(A), nb, M, N, K, float(alpha), A.ptr, sAb, sA[0], sA[1], B.ptr, sBb, sB[0], sB[1],
+            float(beta), cptr, sCb, sC0, sC1, out.ptr,
+        )
+    )
+    return out
+
+
+def _prep2d(x):
+    return _unit_stride_2d(x)
+
+
+@handler("Dot22")
+def dot22(node, inputs, env):
+    x, y = (env.to_device(i) for i in inputs)
+    return [gemm_device(env, 1.0, _prep2d(x), _prep2d(y))]
+
+
+@handler("Dot22Scalar")
+def dot22scalar(node, inputs, env):
+    x, y, a = inputs
+    x, y = env.to_device(x), env.to_device(y)
+    return [gemm_device(env, _scalar(env, a), _prep2d(x), _prep2d(y))]
+
+
+@handler("Gemm")
+def gemm(node, inputs, env):
+    z, a, x, y, b = inputs
+    z, x, y = env.to_device(z), env.to_device(x), env.to_device(y)
+    return [gemm_device(env, _scalar(env, a), _prep2d(x), _prep2d(y), _scalar(env, b), z)]
+
+
+def _prep3d(x):
+    ok = all(s >= 0 for s in x.strides) and (1 in x.strides[1:] or x.size <= 1)
+    return x if ok else x.contiguous()
+
+
+@handler("BatchedDot")
+def batched_dot(node, inputs, env):
+    x, y = (env.to_device(i) for i in inputs)
+    return [gemm_device(env, 1.0, _prep3d(x), _prep3d(y), batch=True)]
+
+
+@handler("Dot")
+def dot(node, inputs, env):
+    x, y = (env.to_device(i) for i in inputs)
+    if x.ndim == 2 and y.ndim == 2:
+        return [gemm_device(env, 1.0, _prep2d(x), _prep2d(y))]
+    if x.ndim == 2 and y.ndim == 1:
+        return [gemv_device(env, 1.0, x, y, 0.0, None)]
+    if x.ndim == 1 and y.ndim == 2:
+        yt = y.view((y.shape[1], y.shape[0]), (y.strides[1], y.strides[0]))
+        return [gemv_device(env, 1.0, yt, x, 0.0, None)]
+    if x.ndim == 1 and y.ndim == 1:
+        if x.shape != y.shape:
+            raise ValueError(f"shapes {x.shape} and {y.shape} not aligned")
+        A = x.view((1, x.shape[0]), (0, x.strides[0]))
+        r = gemv_device(env, 1.0, A if x.strides[0] == 1 or x.shape[0] <= 1 else A.contiguous(), y, 0.0, None)
+        return [r.view((), ())]
+    raise NotImplementedError("Dot with ndim > 2")

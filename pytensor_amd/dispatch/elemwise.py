@@ -1,0 +1,401 @@
+"""``Elemwise`` / ``CAReduce`` / ``DimShuffle`` and the fused ``ElemwiseReduce``.
+
+Reference: pytensor/tensor/elemwise.py — ``Elemwise`` 375 (perform 755-823,
+``_check_runtime_broadcast`` 825-840), ``CAReduce`` 1233 (perform 1493-1511,
+``_acc_dtype`` 1383-1417), ``DimShuffle`` 41 (view, 186-256).
+"""
+
+from __future__ import annotations
+
+import hashlib
+import json
+import struct
+
+import numpy as np
+
+from pytensor_amd import codegen, ffi, kernel_cache
+from pytensor_amd.device import DeviceArray
+from pytensor_amd.dispatch import handler
+from pytensor_amd.executor import HOST_MAX, HostValue
+
+BLOCK = codegen.BLOCK
+MAX_GRID = 256 * 8  # ≫256 workgroups, grid-stride beyond (cdna guide G11)
+
+_body_key_cache = {}
+
+
+def _body_key(body) -> str:
+    k = id(body)
+    v = _body_key_cache.get(k)
+    if v is None:
+        v = hashlib.sha256(json.dumps(body, sort_keys=True).encode()).hexdigest()[:16]
+        _body_key_cache[k] = (v, body)
+        return v
+    return v[0]
+
+
+# ---------------------------------------------------------------------------
+# host evaluation of *shape arithmetic* (tiny integer/bool values only)
+# ---------------------------------------------------------------------------
+
+_HOST_OPS = {
+    "Add": lambda *a: sum(a[1:], a[0]),
+    "Mul": lambda *a: np.prod(np.broadcast_arrays(*a), axis=0) if len(a) > 2 else a[0] * a[1],
+    "Sub": lambda a, b: a - b,
+    "Neg": lambda a: -a,
+    "IntDiv": lambda a, b: a // b,
+    "Mod": lambda a, b: a % b,
+    "Abs": abs,
+    "EQ": lambda a, b: a == b,
+    "NEQ": lambda a, b: a != b,
+    "LT": lambda a, b: a < b,
+    "GT": lambda a, b: a > b,
+    "LE": lambda a, b: a <= b,
+    "GE": lambda a, b: a >= b,
+    "AND": lambda *a: np.bitwise_and.reduce(np.broadcast_arrays(*a)),
+    "OR": lambda *a: np.bitwise_or.reduce(np.broadcast_arrays(*a)),
+    "Invert": lambda a: ~a,
+    "Maximum": np.maximum,
+    "Minimum": np.minimum,
+    "Switch": np.where,
+    "Cast": lambda a: a,
+    "Identity": lambda a: a,
+    "Sign": np.sign,
+    "Sqr": lambda a: a * a,
+}
+
+
+def _host_evaluable(body, inputs):
+    if not all(isinstance(i, HostValue) for i in inputs):
+        return False
+    if any(np.dtype(d).kind not in "iub" for d in body["in_dtypes"] + body["out_dtypes"]):
+        return False
+    if any(np.dtype(n["dtype"]).kind not in "iub" for n in body["body"]):
+        return False
+    return all(n["op"] in _HOST_OPS for n in body["body"])
+
+
+def _host_eval(body, inputs):
+    vals = []
+
+    def get(r):
+        if r[0] == "i":
+            return inputs[r[1]].a
+        if r[0] == "t":
+            return vals[r[1]]
+        return np.asarray(r[1], dtype=r[2])
+
+    for n in body["body"]:
+        out = _HOST_OPS[n["op"]](*[get(r) for r in n["in"]])
+        vals.append(np.asarray(out).astype(n["dtype"]))
+    shape = np.broadcast_shapes(*[i.a.shape for i in inputs]) if inputs else ()
+    return [
+        HostValue(np.broadcast_to(np.asarray(get(r)).astype(dt), shape).copy())
+        for r, dt in zip(body["outs"], body["out_dtypes"])
+    ]
+
+
+# ---------------------------------------------------------------------------
+# launch planning
+# ---------------------------------------------------------------------------
+
+
+def _broadcast_shape(node, graph, ins):
+    nd = max((i.ndim for i in ins), default=0)
+    shape = [1] * nd
+    for d in range(nd):
+        lens = {i.shape[d] for i in ins}
+        big = [l for l in lens if l != 1]
+        if len(set(big)) > 1:
+            raise ValueError(f"Incompatible Elemwise input shapes {[i.shape for i in ins]}")
+        shape[d] = big[0] if big else (1 if lens else 1)
+        if big and 1 in lens:
+            # Elemwise._check_runtime_broadcast (elemwise.py:825-840)
+            for vid, arr in zip(node.inputs, ins):
+                static = graph.vars[vid].shape
+                if arr.shape[d] == 1 and static[d] != 1:
+                    raise ValueError(
+                        f"Runtime broadcasting not allowed. One input had a distinct dimension length of 1 along axis {d}, "
+                        "but the static type does not mark it as broadcastable"
+                    )
+    return tuple(shape)
+
+
+def _collapse(shape, strides_list):
+    """Merge adjacent dims that are jointly contiguous for every operand."""
+    dims = [(s, [st[k] for st in strides_list]) for k, s in enumerate(shape) if s != 1]
+    if not dims:
+        return (1,), [[0] for _ in strides_list]
+    out = [dims[0]]
+    for s, sts in dims[1:]:
+        ps, psts = out[-1]
+        if all(p == s * c for p, c in zip(psts, sts)):
+            out[-1] = (ps * s, sts)
+        else:
+            out.append((s, sts))
+    shp = tuple(d[0] for d in out)
+    per_op = [[d[1][k] for d in out] for k in range(len(strides_list))]
+    return shp, per_op
+
+
+def _grid(n_units):
+    g = (n_units + BLOCK - 1) // BLOCK
+    return max(1, min(g, MAX_GRID))
+
+
+def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env):
+    """Launch the fused kernel.  Returns (stored outputs or None per output,
+    partial buffers or None per output, grid)."""
+    lib = env.lib
+    n = int(np.prod(out_shape)) if out_shape else 1
+    nout = len(out_dtypes)
+    reduce_spec = reduce_spec or [None] * nout
+    outs = [None if reduce_spec[k] else DeviceArray.empty(out_shape, out_dtypes[k]) for k in range(nout)]
+    if n == 0:
+        return outs, [None] * nout, 0
+    nd = len(out_shape)
+    modes = []
+    flat = True
+    for a in ins:
+        if a.size == 1:
+            modes.append("S")
+        elif a.shape == tuple(out_shape) and a.is_contiguous():
+            modes.append("V")
+        else:
+            flat = False
+            break
+    bkey = _body_key(body)
+    rkey = "".join("-" if r is None else r["op"][0] + r["acc_dtype"][0] + r["acc_dtype"][-1] for r in reduce_spec)
+    rs = [None if r is None else (r["op"], r["acc_dtype"]) for r in reduce_spec]
+    if flat:
+        dts = [body["in_dtypes"][k] for k, m in enumerate(modes) if m == "V"] + [
+            d for k, d in enumerate(out_dtypes) if reduce_spec[k] is None
+        ]
+        vec = codegen._vec_width(dts) if dts else 1
+        if vec > 1:
+            ptrs = [a.ptr for a, m in zip(ins, modes) if m == "V"] + [o.ptr for o in outs if o is not None]
+            if any(p % 16 for p in ptrs) or n < vec:
+                vec = 1
+        unroll = 2
+        name = f"ew_{bkey}_{''.join(modes)}_v{vec}_{rkey}".replace("-", "x")
+        src = codegen.flat_kernel_source(name, body, "".join(modes), vec, rs, unroll)
+        fn = kernel_cache.get_function(src, name)
+        units = (n // vec + unroll - 1) // unroll if vec > 1 else n
+        grid = _grid(max(units, 1))
+        args = [n] + [a.ptr for a in ins]
+    else:
+        sshape = tuple(out_shape)
+        strides = []
+        for a in ins:
+            st = tuple(0 if a.shape[d] == 1 and sshape[d] != 1 else a.strides[d] for d in range(nd))
+            strides.append(st)
+        cshape, cstr = _collapse(sshape, strides + [_cstrides(sshape)])
+        cstr = cstr[:-1]
+        ndc = len(cshape)
+        if ndc > codegen.MAX_ND:
+            # materialise the worst operand and retry (rare: >5 non-mergeable dims)
+            ins = [a.contiguous() if not a.is_contiguous() else a for a in ins]
+            return launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env)
+        name = f"ewnd_{bkey}_d{ndc}_{rkey}".replace("-", "x")
+        src = codegen.nd_kernel_source(name, body, ndc, rs)
+        fn = kernel_cache.get_function(src, name)
+        grid = _grid(n)
+        args = [n] + list(cshape)
+        for a, st in zip(ins, cstr):
+            args.append(a.ptr)
+            args += list(st)
+    parts = [None] * nout
+    for k in range(nout):
+        if reduce_spec[k] is None:
+            args.append(outs[k].ptr)
+        else:
+            parts[k] = DeviceArray.empty((grid,), reduce_spec[k]["acc_dtype"])
+            args.append(parts[k].ptr)
+    buf = struct.pack(f"<{len(args)}q", *args)
+    ffi.check(lib.pthip_launch(fn, grid, 1, 1, BLOCK, 1, 1, 0, buf, len(buf)))
+    return outs, parts, grid
+
+
+def _cstrides(shape):
+    st = []
+    acc = 1
+    for s in reversed(shape):
+        st.append(acc)
+        acc *= max(int(s), 1)
+    return tuple(reversed(st))
+
+
+def device_reduce(env, op, x: DeviceArray, A, R, B, sA, sR, sB, acc_dtype, out_dtype, out_shape):
+    lib = env.lib
+    acc_code = ffi.np_dtype_code(acc_dtype)
+    out = DeviceArray.empty(out_shape, out_dtype)
+    ws_bytes = lib.pthip_reduce_workspace(acc_code, A, R, B)
+    ws = DeviceArray.empty((ws_bytes,), "uint8") if ws_bytes else None
+    ffi.check(
+        lib.pthip_reduce(
+            ffi.REDUCE_CODE[op],
+            ffi.np_dtype_code(x.dtype),
+            acc_code,
+            ffi.np_dtype_code(out_dtype),
+            x.ptr,
+            out.ptr,
+            A,
+            R,
+            B,
+            sA,
+            sR,
+            sB,
+            ws.ptr if ws is not None else None,
+            ws_bytes,
+        )
+    )
+    return out
+
+
+# ---------------------------------------------------------------------------
+# handlers
+# ---------------------------------------------------------------------------
+
+
+@handler("Elemwise")
+def elemwise(node, inputs, env):
+    body = node.params["scalar"]
+    g = env.exe.graph
+    if _host_evaluable(body, inputs) and all(i.a.size <= HOST_MAX for i in inputs):
+        return _host_eval(body, inputs)
+    ins = [env.to_device(i) for i in inputs]
+    shape = _broadcast_shape(node, g, ins)
+    outs, _, _ = launch_elemwise(body, ins, shape, body["out_dtypes"], None, env)
+    return outs
+
+
+@handler("ElemwiseReduce")
+def elemwise_reduce(node, inputs, env):
+    body = node.params["scalar"]
+    spec = node.params["reduce"]
+    g = env.exe.graph
+    ins = [env.to_device(i) for i in inputs]
+    shape = _broadcast_shape(node, g, ins)
+    outs, parts, grid = launch_elemwise(body, ins, shape, body["out_dtypes"], spec, env)
+    res = []
+    for k, r in enumerate(spec):
+        if r is None:
+            res.append(outs[k])
+        elif grid == 0:
+            # empty input: identity of the reduction (elemwise.py:1607-1625)
+            ident = {"Add": 0, "Mul": 1}.get(r["op"])
+            if ident is None:
+                raise ValueError(f"zero-size array to reduction operation {r['op'].lower()} which has no identity")
+            res.append(env.to_device(HostValue(np.asarray(ident, dtype=r["dtype"]))))
+        else:
+            res.append(device_reduce(env, r["op"], parts[k], 1, grid, 1, 0, 1, 0, r["acc_dtype"], r["dtype"], ()))
+    return res
+
+
+@handler("CAReduce")
+def careduce(node, inputs, env):
+    p = node.params
+    (x,) = inputs
+    if isinstance(x, HostValue):
+        x = env.to_device(x)
+    axes = sorted(int(a) for a in p["axis"])
+    op = p["scalar_op"]
+    acc, outdt = p["acc_dtype"], p["dtype"]
+    if op in ("AND", "OR", "XOR") or op in ("Maximum", "Minimum", "ScalarMaximum", "ScalarMinimum"):
+        acc = str(x.dtype)  # accumulate in the input dtype (elemwise.py:1383-1417)
+    keep = [d for d in range(x.ndim) if d not in axes]
+    out_shape = tuple(x.shape[d] for d in keep)
+    if not axes:
+        return [x if str(x.dtype) == outdt else _cast(env, x, outdt)]
+    if any(x.shape[d] == 0 for d in axes) and op not in ("Add", "Mul", "AND", "OR", "XOR"):
+        raise ValueError(f"zero-size array to reduction operation {op.lower()} which has no identity")
+    # split the reduced axes into runs of adjacent dims; reduce the last run first
+    runs = []
+    for a in axes:
+        if runs and runs[-1][-1] == a - 1:
+            runs[-1].append(a)
+        else:
+            runs.append([a])
+    cur = x
+    cur_dims = list(range(x.ndim))  # original dim ids still present in `cur`
+    for ri, run in enumerate(reversed(runs)):
+        last = ri == len(runs) - 1
+        pos = [cur_dims.index(d) for d in run]
+        lo, hi = pos[0], pos[-1]
+        groupA = list(range(0, lo))
+        groupR = list(range(lo, hi + 1))
+        groupB = list(range(hi + 1, cur.ndim))
+        merged = _merge3(cur, groupA, groupR, groupB)
+        if merged is None:
+            cur = cur.contiguous()
+            merged = _merge3(cur, groupA, groupR, groupB)
+        (A, sA), (R, sR), (B, sB) = merged
+        oshape = tuple(cur.shape[k] for k in groupA + groupB)
+        odt = outdt if last else acc
+        if last and odt == "bool" and acc != "bool":
+            odt = acc
+        cur = device_reduce(env, op, cur, A, R, B, sA, sR, sB, acc, odt, oshape)
+        cur_dims = [d for d in cur_dims if d not in run]
+    if str(cur.dtype) != outdt:
+        cur = _cast(env, cur, outdt)
+    return [cur.view(out_shape, _cstrides(out_shape))]
+
+
+def _merge_group(arr, dims):
+    """(extent, stride) of a group of adjacent dims if it is a single strided run."""
+    dims = [d for d in dims if arr.shape[d] != 1]
+    if not dims:
+        return 1, 0
+    ext, st = arr.shape[dims[-1]], arr.strides[dims[-1]]
+    for d in reversed(dims[:-1]):
+        if arr.strides[d] != ext * st:
+            return None
+        ext *= arr.shape[d]
+    return ext, st
+
+
+def _merge3(arr, gA, gR, gB):
+    if arr.size == 0:
+        ext = lambda g: int(np.prod([arr.shape[d] for d in g])) if g else 1
+        return (ext(gA), 0), (ext(gR), 0), (ext(gB), 0)
+    res = [_merge_group(arr, g) for g in (gA, gR, gB)]
+    if any(r is None for r in res):
+        return None
+    return res
+
+
+def _cast(env, x, dtype):
+    body = {
+        "in_dtypes": [str(x.dtype)],
+        "out_dtypes": [str(dtype)],
+        "body": [{"op": "Cast", "in": [["i", 0]], "dtype": str(dtype)}],
+        "outs": [["t", 0]],
+    }
+    outs, _, _ = launch_elemwise(body, [x], x.shape, [str(dtype)], None, env)
+    return outs[0]
+
+
+@handler("DimShuffle")
+def dimshuffle(node, inputs, env):
+    (x,) = inputs
+    order = node.params["new_order"]
+    if isinstance(x, HostValue):
+        a = x.a
+        keep = [o for o in order if o != "x"]
+        drop = [d for d in range(a.ndim) if d not in keep]
+        t = a.transpose(keep + drop).reshape([a.shape[d] for d in keep])
+        idx = tuple(None if o == "x" else slice(None) for o in order)
+        return [HostValue(t[idx])]
+    keep = [o for o in order if o != "x"]
+    for d in range(x.ndim):
+        if d not in keep and x.shape[d] != 1:
+            raise ValueError(f"DimShuffle: cannot drop dimension {d} of length {x.shape[d]}")
+    shape, strides = [], []
+    for o in order:
+        if o == "x":
+            shape.append(1)
+            strides.append(0)
+        else:
+            shape.append(x.shape[o])
+            strides.append(x.strides[o])
+    return [x.view(shape, strides)]

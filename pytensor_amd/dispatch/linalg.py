@@ -1,0 +1,130 @@
+"""``Cholesky`` / ``SolveTriangular`` / ``CholeskySolve`` and their ``Blockwise`` batching.
+
+Reference: pytensor/tensor/linalg/decomposition/cholesky.py:18-83,
+solvers/triangular.py:13-71, solvers/psd.py:14-53, pytensor/tensor/blockwise.py:153
+(batch dims → grid dimension here instead of a Python loop).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from pytensor_amd import ffi
+from pytensor_amd.device import DeviceArray, copy_into
+from pytensor_amd.dispatch import handler
+
+
+def _dt(x):
+    return ffi.np_dtype_code(x.dtype)
+
+
+def _require_float(x, what):
+    if x.dtype.kind != "f":
+        raise NotImplementedError(f"{what}: only float32/float64 on the device")
+
+
+def _batchify(x: DeviceArray, core_ndim: int, bshape):
+    """Broadcast leading dims to ``bshape`` and return a contiguous (batch, *core) array."""
+    core = x.shape[x.ndim - core_ndim :]
+    lead = x.shape[: x.ndim - core_ndim]
+    lead = (1,) * (len(bshape) - len(lead)) + lead
+    nb = int(np.prod(bshape)) if bshape else 1
+    if lead == tuple(bshape) and x.is_contiguous():
+        return x.view((nb, *core), _cs((nb, *core)))
+    out = DeviceArray.empty((*bshape, *core), x.dtype)
+    copy_into(out, x.view((*lead, *core), (0,) * (len(lead) - (x.ndim - core_ndim)) + x.strides))
+    return out.view((nb, *core), _cs((nb, *core)))
+
+
+def _cs(shape):
+    st, acc = [], 1
+    for s in reversed(shape):
+        st.append(acc)
+        acc *= max(int(s), 1)
+    return tuple(reversed(st))
+
+
+def cholesky_device(env, a: DeviceArray, lower: bool) -> DeviceArray:
+    _require_float(a, "Cholesky")
+    if a.shape[-1] != a.shape[-2]:
+        raise ValueError("Cholesky: matrix must be square")
+    n = a.shape[-1]
+    bshape = a.shape[:-2]
+    ab = _batchify(a, 2, bshape)
+    out = DeviceArray.empty(a.shape, a.dtype)
+    if out.size:
+        ffi.check(env.lib.pthip_potrf(_dt(a), int(lower), ab.shape[0], n, ab.ptr, out.ptr))
+    return out
+
+
+def trsm_device(env, T: DeviceArray, b: DeviceArray, lower, unit, b_ndim, trans=False) -> DeviceArray:
+    _require_float(T, "SolveTriangular")
+    n = T.shape[-1]
+    if T.shape[-2] != n:
+        raise ValueError("SolveTriangular: matrix must be square")
+    if b.shape[b.ndim - b_ndim] != n:
+        raise ValueError(f"SolveTriangular: incompatible shapes {T.shape} and {b.shape}")
+    if str(b.dtype) != str(T.dtype):
+        raise TypeError("SolveTriangular: dtype mismatch")
+    bT, bb = T.shape[:-2], b.shape[: b.ndim - b_ndim]
+    bshape = tuple(np.broadcast_shapes(bT, bb))
+    nb = int(np.prod(bshape)) if bshape else 1
+    nrhs = 1 if b_ndim == 1 else b.shape[-1]
+    core_b = b.shape[b.ndim - b_ndim :]
+    out = DeviceArray.empty((*bshape, *core_b), b.dtype)
+    if out.size == 0:
+        return out
+    if not bshape:
+        Tm, sTb, sT0, sT1 = T, 0, T.strides[0], T.strides[1]
+        if any(s < 0 for s in T.strides):
+            Tm = T.contiguous()
+            sT0, sT1 = Tm.strides
+        bm = b.contiguous()
+        sBb = 0
+    else:
+        Tm = _batchify(T, 2, bshape)
+        sTb, sT0, sT1 = Tm.strides
+        bm = _batchify(b, b_ndim, bshape)
+        sBb = bm.strides[0]
+    ffi.check(
+        env.lib.pthip_trsm(_dt(T), int(lower), int(trans), int(unit), nb, n, nrhs, Tm.ptr, sTb, sT0, sT1, bm.ptr, sBb, out.ptr)
+    )
+    return out
+
+
+@handler("Cholesky")
+def cholesky(node, inputs, env):
+    return [cholesky_device(env, env.to_device(inputs[0]), node.params["lower"])]
+
+
+@handler("SolveTriangular")
+def solve_triangular(node, inputs, env):
+    p = node.params
+    A, b = (env.to_device(i) for i in inputs)
+    return [trsm_device(env, A, b, p["lower"], p["unit_diagonal"], p["b_ndim"])]
+
+
+def cho_solve_device(env, c, b, lower, b_ndim):
+    # potrs (psd.py:35-53): lower: L y = b, L^T x = y ; upper: U^T y = b, U x = y
+    y = trsm_device(env, c, b, lower, False, b_ndim, trans=not lower)
+    return trsm_device(env, c, y, lower, False, b_ndim, trans=lower)
+
+
+@handler("CholeskySolve")
+def cholesky_solve(node, inputs, env):
+    c, b = (env.to_device(i) for i in inputs)
+    return [cho_solve_device(env, c, b, node.params["lower"], node.params["b_ndim"])]
+
+
+@handler("Blockwise")
+def blockwise(node, inputs, env):
+    p = node.params
+    cp = p["core_params"]
+    ins = [env.to_device(i) for i in inputs]
+    if p["core_op"] == "Cholesky":
+        return [cholesky_device(env, ins[0], cp["lower"])]
+    if p["core_op"] == "SolveTriangular":
+        return [trsm_device(env, ins[0], ins[1], cp["lower"], cp["unit_diagonal"], cp["b_ndim"])]
+    if p["core_op"] == "CholeskySolve":
+        return [cho_solve_device(env, ins[0], ins[1], cp["lower"], cp["b_ndim"])]
+    raise NotImplementedError(f"Blockwise({p['core_op']})")

@@ -1,0 +1,127 @@
+"""``Scan`` — host-side step driver enqueuing the inner graph's kernels on one stream.
+
+Reference: pytensor/scan/op.py:839 (``Scan``; ``perform`` 1827; buffer conventions
+322-635) and the Cython loop pytensor/scan/scan_perform.pyx:74-603.  The JAX
+lowering (pytensor/link/jax/dispatch/scan.py:11-247) is the functional precedent.
+
+Outer inputs: ``[n_steps, seqs…, mit_mot…, mit_sot…, sit_sot…, untraced_sit_sot…,
+nit_sot lengths…, non_seqs…]``.  Recurrent buffers hold the initial taps first; step
+``t`` reads ``buf[(t + mintap + tap) % L]`` and writes ``buf[(t + mintap) % L]``.
+Everything stays in HBM: taps are strided views of the trace buffers, the inner
+graph's kernels are enqueued back-to-back on the context stream, and there is no
+host synchronisation inside the loop (unless ``as_while``, whose condition must be
+read back each step).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from pytensor_amd.device import DeviceArray, copy_into
+from pytensor_amd.dispatch import handler
+from pytensor_amd.executor import HipExecutable, HostValue
+
+_inner_cache = {}
+
+
+def _inner_executable(node, env) -> HipExecutable:
+    key = id(node.params["inner"])
+    exe = _inner_cache.get(key)
+    if exe is None:
+        exe = HipExecutable(node.params["inner"], device=env.exe._device)
+        _inner_cache[key] = (exe, node.params["inner"])
+        return exe
+    return exe[0]
+
+
+def _roll_to_front(buf: DeviceArray, start: int) -> DeviceArray:
+    """np.concatenate([buf[start:], buf[:start]]) on the device."""
+    L = buf.shape[0]
+    out = DeviceArray.empty(buf.shape, buf.dtype)
+    tail = L - start
+    copy_into(out.view((tail, *buf.shape[1:]), out.strides), buf.view((tail, *buf.shape[1:]), buf.strides, start * buf.strides[0]))
+    copy_into(
+        out.view((start, *buf.shape[1:]), out.strides, tail * out.strides[0]),
+        buf.view((start, *buf.shape[1:]), buf.strides),
+    )
+    return out
+
+
+@handler("Scan")
+def scan(node, inputs, env):
+    info = node.params["info"]
+    if info["mit_mot_in_slices"]:
+        raise NotImplementedError("hip linker: mit-mot Scan (gradient of Scan) is not lowered yet")
+    inner = _inner_executable(node, env)
+    ig = inner.graph
+    n_steps = int(env.to_host(inputs[0]))
+    k = 1
+    seqs = [env.to_device(s) for s in inputs[k : k + info["n_seqs"]]]
+    k += info["n_seqs"]
+    taps = [list(t) for t in info["mit_sot_in_slices"]] + [list(t) for t in info["sit_sot_in_slices"]]
+    n_rec = len(taps)
+    rec_bufs = []
+    for b in inputs[k : k + n_rec]:
+        b = env.to_device(b)
+        own = DeviceArray.empty(b.shape, b.dtype)  # Scan must not mutate its inputs
+        copy_into(own, b)
+        rec_bufs.append(own)
+    k += n_rec
+    untraced = list(inputs[k : k + info["n_untraced_sit_sot"]])
+    k += info["n_untraced_sit_sot"]
+    nit_lens = [int(env.to_host(x)) for x in inputs[k : k + info["n_nit_sot"]]]
+    k += info["n_nit_sot"]
+    non_seqs = list(inputs[k:])
+    mintaps = [-min(t) for t in taps]
+    for s in seqs:
+        if s.shape[0] < n_steps:
+            raise ValueError(f"Scan: sequence of length {s.shape[0]} is shorter than n_steps={n_steps}")
+    nit_bufs = [None] * info["n_nit_sot"]
+    steps_done = 0
+    for t in range(n_steps):
+        step_in = [s.view(s.shape[1:], s.strides[1:], t * s.strides[0]) for s in seqs]
+        for buf, tp, mt in zip(rec_bufs, taps, mintaps):
+            L = buf.shape[0]
+            for tap in tp:
+                step_in.append(buf.view(buf.shape[1:], buf.strides[1:], ((t + mt + tap) % L) * buf.strides[0]))
+        step_in += untraced
+        step_in += non_seqs
+        outs, _ = inner.run_device(step_in, env)
+        o = 0
+        for buf, mt in zip(rec_bufs, mintaps):
+            slot = buf.view(buf.shape[1:], buf.strides[1:], ((t + mt) % buf.shape[0]) * buf.strides[0])
+            copy_into(slot, env.to_device(outs[o]))
+            o += 1
+        for j in range(info["n_nit_sot"]):
+            v = env.to_device(outs[o])
+            if nit_bufs[j] is None:
+                nit_bufs[j] = DeviceArray.empty((nit_lens[j], *v.shape), v.dtype)
+            nb = nit_bufs[j]
+            copy_into(nb.view(nb.shape[1:], nb.strides[1:], (t % nit_lens[j]) * nb.strides[0]), v)
+            o += 1
+        for j in range(info["n_untraced_sit_sot"]):
+            untraced[j] = outs[o]
+            o += 1
+        steps_done = t + 1
+        if info["as_while"] and bool(env.to_host(outs[o])):
+            break
+    res = []
+    for buf, mt in zip(rec_bufs, mintaps):
+        L = buf.shape[0]
+        end = (steps_done + mt) % L
+        if steps_done + mt > L and end != 0:
+            buf = _roll_to_front(buf, end)
+        if info["as_while"]:
+            buf = buf.view((min(L, steps_done + mt), *buf.shape[1:]), buf.strides)
+        res.append(buf)
+    for j, buf in enumerate(nit_bufs):
+        if buf is None:
+            ov = ig.vars[ig.outputs[n_rec + j]]
+            buf = DeviceArray.empty((0,) * (ov.ndim + 1), ov.dtype)
+        elif steps_done > nit_lens[j] and steps_done % nit_lens[j]:
+            buf = _roll_to_front(buf, steps_done % nit_lens[j])
+        if info["as_while"]:
+            buf = buf.view((min(buf.shape[0], steps_done), *buf.shape[1:]), buf.strides)
+        res.append(buf)
+    res += untraced
+    return res

@@ -1,0 +1,231 @@
+"""Indexing ops (bit-exact tier): ``Subtensor``, ``IncSubtensor``, ``AdvancedSubtensor``,
+``AdvancedIncSubtensor``.
+
+Reference: pytensor/tensor/subtensor.py — Subtensor 868 (perform 912-917: a NumPy
+view), IncSubtensor 1441, AdvancedSubtensor 1932, AdvancedIncSubtensor 2275
+(``np.add.at`` semantics for ``inc``).  Basic indexing is descriptor arithmetic on
+the host (no kernel); integer-array indexing on one axis maps to the row
+gather/scatter kernels.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from pytensor_amd import ffi
+from pytensor_amd.device import DeviceArray, contiguous_strides, copy_into
+from pytensor_amd.dispatch import handler
+from pytensor_amd.executor import HostValue
+
+
+def _resolve(idx_list, index_inputs, env):
+    """idx_list with input positions → concrete Python ints / slices (host)."""
+
+    def val(e):
+        if e is None:
+            return None
+        v = index_inputs[e]
+        a = env.to_host(v)
+        return int(a)
+
+    out = []
+    for e in idx_list:
+        if isinstance(e, slice):
+            out.append(slice(val(e.start), val(e.stop), val(e.step)))
+        else:
+            out.append(val(e))
+    return out
+
+
+def basic_view(x: DeviceArray, index) -> DeviceArray:
+    """NumPy basic indexing as a strided view."""
+    if len(index) > x.ndim:
+        raise IndexError("too many indices for array")
+    off = 0
+    shape, strides = [], []
+    for d in range(x.ndim):
+        n, st = x.shape[d], x.strides[d]
+        e = index[d] if d < len(index) else slice(None)
+        if isinstance(e, slice):
+            start, stop, step = e.indices(n)
+            ln = len(range(start, stop, step))
+            off += start * st if ln else 0
+            shape.append(ln)
+            strides.append(st * step)
+        else:
+            i = int(e)
+            if i < -n or i >= n:
+                raise IndexError(f"index {i} is out of bounds for axis {d} with size {n}")
+            if i < 0:
+                i += n
+            off += i * st
+    return x.view(shape, strides, off)
+
+
+@handler("Subtensor")
+def subtensor(node, inputs, env):
+    x, *idx = inputs
+    index = _resolve(node.params["idx_list"], idx, env)
+    if isinstance(x, HostValue):
+        return [HostValue(np.asarray(x.a[tuple(index)]))]
+    return [basic_view(x, index)]
+
+
+def _add_into(env, view: DeviceArray, y: DeviceArray):
+    """view[...] += broadcast(y) through a fused add + strided write-back."""
+    from pytensor_amd.dispatch.elemwise import launch_elemwise
+
+    dt = str(view.dtype)
+    body = {
+        "in_dtypes": [dt, str(y.dtype)],
+        "out_dtypes": [dt],
+        "body": [{"op": "Add", "in": [["i", 0], ["i", 1]], "dtype": dt}],
+        "outs": [["t", 0]],
+    }
+    nd = view.ndim
+    yv = y.view((1,) * (nd - y.ndim) + y.shape, (0,) * (nd - y.ndim) + y.strides)
+    for d in range(nd):
+        if yv.shape[d] != view.shape[d] and yv.shape[d] != 1:
+            raise ValueError(f"shape mismatch: value array of shape {y.shape} could not be broadcast to {view.shape}")
+    outs, _, _ = launch_elemwise(body, [view, yv], view.shape, [dt], None, env)
+    copy_into(view, outs[0])
+
+
+@handler("IncSubtensor")
+def inc_subtensor(node, inputs, env):
+    x, y, *idx = inputs
+    x, y = env.to_device(x), env.to_device(y)
+    index = _resolve(node.params["idx_list"], idx, env)
+    out = DeviceArray.empty(x.shape, x.dtype)
+    copy_into(out, x)
+    view = basic_view(out, index)
+    if y.ndim > view.ndim:
+        raise ValueError("IncSubtensor: value has more dimensions than the indexed region")
+    if view.size == 0:
+        return [out]
+    if node.params["set_instead_of_inc"]:
+        if str(y.dtype) != str(out.dtype):
+            from pytensor_amd.dispatch.elemwise import _cast
+
+            y = _cast(env, y, out.dtype)
+        copy_into(view, y)
+    else:
+        _add_into(env, view, y)
+    return [out]
+
+
+def _single_axis_index(idx_list, index_inputs, x_ndim):
+    """Supported advanced pattern: exactly one integer-array index, all other
+    positions full slices.  Returns (axis, index value)."""
+    axis = None
+    for d, e in enumerate(idx_list):
+        if isinstance(e, slice):
+            if (e.start, e.stop, e.step) != (None, None, None):
+                raise NotImplementedError("hip linker: advanced indexing mixed with non-trivial slices")
+            continue
+        if axis is not None:
+            raise NotImplementedError("hip linker: more than one advanced index")
+        axis = d
+    if axis is None:
+        raise NotImplementedError("hip linker: advanced indexing without an integer index")
+    return axis, index_inputs[idx_list[axis]]
+
+
+def _index_on_device(env, iv):
+    iv = env.to_device(iv)
+    if iv.dtype.kind == "b":
+        raise NotImplementedError("hip linker: boolean mask indexing")
+    if str(iv.dtype) != "int64":
+        from pytensor_amd.dispatch.elemwise import _cast
+
+        iv = _cast(env, iv, "int64")
+    return iv.contiguous()
+
+
+def _axis_to_front(x: DeviceArray, axis: int) -> DeviceArray:
+    if axis == 0:
+        return x
+    order = [axis] + [d for d in range(x.ndim) if d != axis]
+    return x.view([x.shape[d] for d in order], [x.strides[d] for d in order])
+
+
+@handler("AdvancedSubtensor")
+def advanced_subtensor(node, inputs, env):
+    x, *idx = inputs
+    x = env.to_device(x)
+    axis, iv = _single_axis_index(node.params["idx_list"], idx, x.ndim)
+    iv = _index_on_device(env, iv)
+    xf = _axis_to_front(x, axis)
+    inner_shape = xf.shape[1:]
+    inner = int(np.prod(inner_shape)) if inner_shape else 1
+    # rows must be contiguous runs of `inner` elements
+    if inner > 1 and not xf.view(inner_shape, xf.strides[1:]).is_contiguous():
+        xf = xf.contiguous()
+    n_idx = iv.size
+    out = DeviceArray.empty((n_idx, *inner_shape), x.dtype)
+    if out.size:
+        ffi.check(
+            env.lib.pthip_take_rows(x.itemsize, n_idx, inner, xf.ptr, xf.shape[0], xf.strides[0] if xf.shape[0] > 1 else inner, iv.ptr, out.ptr)
+        )
+    elif n_idx and xf.shape[0] == 0:
+        raise IndexError("index out of bounds for axis with size 0")
+    res_shape = (*iv.shape, *inner_shape)
+    res = out.view(res_shape, contiguous_strides(res_shape))
+    if axis != 0:
+        # NumPy places the broadcast index dims where the indexed axis was
+        k = len(iv.shape)
+        order = list(range(k, k + axis)) + list(range(k)) + list(range(k + axis, len(res_shape)))
+        res = res.view([res.shape[d] for d in order], [res.strides[d] for d in order])
+    return [res]
+
+
+@handler("AdvancedIncSubtensor")
+def advanced_inc_subtensor(node, inputs, env):
+    p = node.params
+    x, y, *idx = inputs
+    x, y = env.to_device(x), env.to_device(y)
+    axis, iv = _single_axis_index(p["idx_list"], idx, x.ndim)
+    if axis != 0:
+        raise NotImplementedError("hip linker: AdvancedIncSubtensor on axis != 0")
+    iv = _index_on_device(env, iv)
+    if iv.ndim != 1:
+        raise NotImplementedError("hip linker: AdvancedIncSubtensor with a multi-dimensional index")
+    out = DeviceArray.empty(x.shape, x.dtype)
+    copy_into(out, x)
+    inner_shape = x.shape[1:]
+    inner = int(np.prod(inner_shape)) if inner_shape else 1
+    n_idx = iv.size
+    if n_idx == 0 or inner == 0:
+        return [out]
+    if str(y.dtype) != str(x.dtype):
+        from pytensor_amd.dispatch.elemwise import _cast
+
+        y = _cast(env, y, x.dtype)
+    # y broadcasts against (n_idx, *inner_shape)
+    tgt = (n_idx, *inner_shape)
+    yv = y.view((1,) * (len(tgt) - y.ndim) + y.shape, (0,) * (len(tgt) - y.ndim) + y.strides)
+    for d in range(len(tgt)):
+        if yv.shape[d] not in (1, tgt[d]):
+            raise ValueError(f"shape mismatch: value array of shape {y.shape} could not be broadcast to indexing result of shape {tgt}")
+    row_bcast = yv.shape[0] == 1 and n_idx != 1
+    inner_view = yv.view(yv.shape[1:], yv.strides[1:])
+    if inner_view.shape == tuple(inner_shape) and inner_view.is_contiguous() and (row_bcast or inner == 1 or yv.strides[0] == inner or n_idx == 1):
+        ysrc = yv
+        ys0 = 0 if row_bcast else (yv.strides[0] if n_idx > 1 else inner)
+    else:
+        ysrc = DeviceArray.empty(tgt, x.dtype)
+        copy_into(ysrc, yv)
+        ys0 = inner
+    lib = env.lib
+    ws_bytes = lib.pthip_scatter_rows_workspace(n_idx, x.shape[0], inner)
+    ws = DeviceArray.empty((ws_bytes,), "uint8") if ws_bytes else None
+    inc = 0 if p["set_instead_of_inc"] else 1
+    if inc and p.get("ignore_duplicates"):
+        raise NotImplementedError("hip linker: AdvancedIncSubtensor(ignore_duplicates=True)")
+    ffi.check(
+        lib.pthip_scatter_rows(
+            ffi.np_dtype_code(x.dtype), inc, n_idx, inner, out.ptr, x.shape[0], iv.ptr, ysrc.ptr, ys0,
+            ws.ptr if ws is not None else None, ws_bytes,
+        )
+    )
+    return [out]

@@ -1,5 +1,228 @@
+"""``HipExecutable`` — runs a lowered graph (``pytensor_amd.ir.Graph``) on the device.
+
+This is the callable ``HipLinker.jit_compile`` returns: positional host
+``ndarray``s in (all ``fgraph.inputs``, shared variables included), a tuple of
+freshly-owned host ``ndarray``s out — the contract of the thunk built in
+pytensor/link/basic.py:670-684 (cf. pytorch/linker.py:81-88).
+
+Execution model (MI355X-first, no tracing compiler):
+
+* every node maps to zero or more launches on ONE in-order HIP stream through the
+  C-ABI (``include/pthip.h``); views launch nothing;
+* shape arithmetic (``Shape_i``, ``MakeVector``, integer ``Elemwise`` on shapes,
+  ``ScalarFromTensor`` of those) stays on the host, as control plane — tensor
+  data never does: there is NO CPU fallback for data ops, the module raises if
+  ``libpthip.so`` or the GPU is missing;
+* inputs marked resident (shared variables) are uploaded once and cached by array
+  identity;
+* the only host↔device crossings are H2D of non-resident inputs at entry and D2H
+  of outputs at exit, followed by the single stream synchronisation of the call;
+* ``freeze()`` captures the whole launch sequence of one call signature into a
+  hipGraph (arena-backed buffers, pinned staging) so that subsequent calls cost
+  one native call instead of one Python dispatch per node — the analogue of the
+  reference's CVM (pytensor/link/c/c_code/lazylinker_c.c:749).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from pytensor_amd import ffi
+from pytensor_amd.device import DeviceArray
+from pytensor_amd.ir import Graph
+
+HOST_MAX = 64  # host-resident values are tiny integer/bool arrays (shape math)
+
+
+class HostValue:
+    """A small host-resident value (shape arithmetic / scalar indices)."""
+
+    __slots__ = ("a",)
+
+    def __init__(self, a):
+        self.a = np.asarray(a)
+
+    @property
+    def shape(self):
+        return self.a.shape
+
+    @property
+    def dtype(self):
+        return self.a.dtype
+
+    def __repr__(self):
+        return f"HostValue({self.a!r})"
+
+
+class Env:
+    """Per-call state handed to the node handlers."""
+
+    def __init__(self, exe: "HipExecutable"):
+        self.exe = exe
+        self.lib = ffi.lib()
+        self.keepalive = []  # host arrays whose async H2D may still be in flight
+
+    def to_device(self, v) -> DeviceArray:
+        if isinstance(v, DeviceArray):
+            return v
+        if isinstance(v, HostValue):
+            a = np.ascontiguousarray(v.a)
+            self.keepalive.append(a)
+            return DeviceArray.from_host(a)
+        raise TypeError(f"cannot move {type(v)} to the device")
+
+    def to_host(self, v) -> np.ndarray:
+        """Value of a (small) variable on the host — a synchronisation point when
+        the value lives on the device."""
+        if isinstance(v, HostValue):
+            return v.a
+        if isinstance(v, DeviceArray):
+            if self.exe._capturing:
+                raise ffi.HipError("data-dependent host read inside a frozen (hipGraph) plan")
+            return v.to_host(sync=True)
+        return np.asarray(v)
+
+
 class HipExecutable:
-    def __init__(self, graph):
-        self.graph = graph
-    def __call__(self, *a):
-        raise RuntimeError("stub")
+    def __init__(self, graph: Graph, resident=(), device: int | None = None, fuse=True):
+        from pytensor_amd import dispatch  # registers handlers
+        from pytensor_amd.fusion import fuse_elemwise_reduce
+
+        self.source_graph = graph
+        self.graph = fuse_elemwise_reduce(graph) if fuse else graph
+        self.resident = set(resident)
+        self._handlers = dispatch.HANDLERS
+        self._resident_cache = {}  # input position -> (key, DeviceArray)
+        self._const_cache = {}
+        self._device = device
+        self._capturing = False
+        self._plans = {}
+        self._last_use = self._compute_last_use()
+        # fail loudly and early if the library / device is unusable
+        ffi.lib()
+
+    # ------------------------------------------------------------------
+    def _compute_last_use(self):
+        last = {}
+        for k, n in enumerate(self.graph.nodes):
+            for i in n.inputs:
+                last[i] = k
+        keep = set(self.graph.outputs)
+        free_after = [[] for _ in self.graph.nodes]
+        for vid, k in last.items():
+            if vid not in keep and self.graph.vars[vid].const is None:
+                free_after[k].append(vid)
+        return free_after
+
+    def _ensure_device(self):
+        if ffi.device_count() <= 0:
+            raise ffi.HipError("no HIP device visible: the hip linker has no CPU fallback")
+        ffi.init(self._device if self._device is not None else 0)
+
+    def _const(self, vid, env):
+        v = self.graph.vars[vid]
+        if vid in self._const_cache:
+            return self._const_cache[vid]
+        a = np.asarray(v.const)
+        if v.kind != "tensor" or (a.dtype.kind in "iub" and a.size <= HOST_MAX):
+            val = HostValue(a)
+        else:
+            val = DeviceArray.from_host(a)
+            env.keepalive.append(a)
+        self._const_cache[vid] = val
+        return val
+
+    def _input(self, pos, vid, value, env):
+        var = self.graph.vars[vid]
+        if isinstance(value, (DeviceArray, HostValue)):
+            return value
+        if var.kind != "tensor":
+            return HostValue(np.asarray(value))
+        a = np.asarray(value)
+        if str(a.dtype) != var.dtype:
+            raise TypeError(f"input {pos} ({var.name}): expected dtype {var.dtype}, got {a.dtype}")
+        if a.ndim != var.ndim:
+            raise TypeError(f"input {pos} ({var.name}): expected {var.ndim} dimensions, got {a.ndim}")
+        for d, s in enumerate(var.shape):
+            if s is not None and a.shape[d] != s:
+                raise TypeError(f"input {pos} ({var.name}): static shape {var.shape} violated by {a.shape}")
+        if pos in self.resident:
+            key = (id(value), a.ctypes.data, a.shape, a.strides, str(a.dtype))
+            hit = self._resident_cache.get(pos)
+            if hit is not None and hit[0] == key:
+                return hit[1]
+            dev = DeviceArray.from_host(a)
+            env.keepalive.append(a)
+            # hold a reference to the host array so that `id` stays unique
+            self._resident_cache[pos] = (key, dev, value)
+            return dev
+        if a.dtype.kind in "iub" and a.ndim == 0:
+            return HostValue(a)
+        dev = DeviceArray.from_host(a)
+        env.keepalive.append(a)
+        return dev
+
+    # ------------------------------------------------------------------
+    def run_device(self, inputs, env=None):
+        """Run the graph; returns the list of output values (DeviceArray/HostValue)."""
+        g = self.graph
+        if len(inputs) != len(g.inputs):
+            raise TypeError(f"expected {len(g.inputs)} inputs, got {len(inputs)}")
+        env = env or Env(self)
+        vals = {}
+        for pos, (vid, value) in enumerate(zip(g.inputs, inputs)):
+            vals[vid] = self._input(pos, vid, value, env)
+        handlers = self._handlers
+        for k, node in enumerate(g.nodes):
+            ins = []
+            for i in node.inputs:
+                v = vals.get(i)
+                if v is None:
+                    v = self._const(i, env)
+                ins.append(v)
+            h = handlers.get(node.op)
+            if h is None:
+                raise NotImplementedError(f"hip linker: no device handler for {node.op}")
+            outs = h(node, ins, env)
+            for o, val in zip(node.outputs, outs):
+                vals[o] = val
+            for dead in self._last_use[k]:
+                vals.pop(dead, None)
+        outs = []
+        for o in g.outputs:
+            v = vals.get(o)
+            if v is None:
+                v = self._const(o, env)
+            outs.append(v)
+        return outs, env
+
+    def __call__(self, *inputs):
+        self._ensure_device()
+        outs, env = self.run_device(inputs)
+        lib = ffi.lib()
+        host = []
+        for o, vid in zip(outs, self.graph.outputs):
+            var = self.graph.vars[vid]
+            if isinstance(o, HostValue):
+                host.append(np.array(o.a, dtype=var.dtype if var.kind == "tensor" else o.a.dtype, copy=True))
+            else:
+                host.append(o.to_host(sync=False))
+        ffi.check(lib.pthip_synchronize())
+        st = C.c_int(0)
+        ffi.check(lib.pthip_check_status(C.byref(st)))
+        if st.value:
+            raise IndexError("index out of bounds (device-side check)")
+        env.keepalive.clear()
+        return tuple(host)
+
+    # ------------------------------------------------------------------
+    def freeze(self, *inputs):
+        """Capture the launch sequence for this input signature into a hipGraph and
+        return a :class:`FrozenPlan` (see ``pytensor_amd/plan.py``)."""
+        from pytensor_amd.plan import FrozenPlan
+
+        self._ensure_device()
+        return FrozenPlan(self, inputs)

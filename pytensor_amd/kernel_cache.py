@@ -1,0 +1,64 @@
+"""JIT cache for generated kernels: source → gfx950 code object → loaded function.
+
+Analogue of the reference's C-module cache (pytensor/link/c/cmodule.py:612
+``ModuleCache``): keyed by a hash of the generated source; code objects persist
+in-tree under ``pytensor_amd/_kcache/`` (git-ignored ``*.hsaco``), so kernels
+compiled by ``build()`` without a GPU are reused on the GPU box.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from pytensor_amd import ffi
+from pytensor_amd.codegen import source_key
+
+CACHE_DIR = os.environ.get("PTHIP_KCACHE", os.path.join(os.path.dirname(os.path.abspath(__file__)), "_kcache"))
+
+_code = {}  # key -> bytes
+_funcs = {}  # (key, name) -> function handle
+_modules = {}
+
+
+def compile_source(src: str, name: str) -> str:
+    """Compile (or fetch) ``src``; returns the cache key.  Needs no GPU."""
+    key = source_key(src)
+    if key in _code:
+        return key
+    path = os.path.join(CACHE_DIR, f"{key}.hsaco")
+    if os.path.exists(path):
+        with open(path, "rb") as fh:
+            _code[key] = fh.read()
+        return key
+    code = ffi.jit_compile(src, name + ".hip")
+    _code[key] = code
+    try:
+        os.makedirs(CACHE_DIR, exist_ok=True)
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as fh:
+            fh.write(code)
+        os.replace(tmp, path)
+    except OSError:
+        pass
+    return key
+
+
+def get_function(src: str, name: str) -> int:
+    key = compile_source(src, name)
+    f = _funcs.get((key, name))
+    if f is not None:
+        return f
+    lib = ffi.lib()
+    mod = _modules.get(key)
+    if mod is None:
+        m = C.c_void_p()
+        code = _code[key]
+        buf = C.create_string_buffer(code, len(code))
+        ffi.check(lib.pthip_module_load(buf, len(code), C.byref(m)))
+        _modules[key] = (m, buf)
+        mod = _modules[key]
+    fn = C.c_void_p()
+    ffi.check(lib.pthip_module_get_function(mod[0], name.encode(), C.byref(fn)))
+    _funcs[(key, name)] = fn.value
+    return fn.value
