@@ -71,7 +71,9 @@ class DeviceArray:
 
     @classmethod
     def from_host(cls, a: np.ndarray) -> "DeviceArray":
-        a = np.ascontiguousarray(a)
+        a = np.asarray(a)
+        if not a.flags.c_contiguous:
+            a = np.ascontiguousarray(a)  # (never for 0-d: ascontiguousarray would make it 1-d)
         out = cls.empty(a.shape, a.dtype)
         if a.size:
             ffi.check(ffi.lib().pthip_h2d(out.ptr, a.ctypes.data, a.nbytes))

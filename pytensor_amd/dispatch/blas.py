@@ -18,7 +18,7 @@ from pytensor_amd.executor import HostValue
 
 
 def _scalar(env, v) -> float:
-    return float(env.to_host(v))
+    return float(np.asarray(env.to_host(v)).reshape(-1)[0])
 
 
 def _dt(x) -> int:

@@ -260,7 +260,7 @@ def device_reduce(env, op, x: DeviceArray, A, R, B, sA, sR, sB, acc_dtype, out_d
 @handler("Elemwise")
 def elemwise(node, inputs, env):
     body = node.params["scalar"]
-    g = env.exe.graph
+    g = env.graph
     if _host_evaluable(body, inputs) and all(i.a.size <= HOST_MAX for i in inputs):
         return _host_eval(body, inputs)
     ins = [env.to_device(i) for i in inputs]
@@ -273,7 +273,7 @@ def elemwise(node, inputs, env):
 def elemwise_reduce(node, inputs, env):
     body = node.params["scalar"]
     spec = node.params["reduce"]
-    g = env.exe.graph
+    g = env.graph
     ins = [env.to_device(i) for i in inputs]
     shape = _broadcast_shape(node, g, ins)
     outs, parts, grid = launch_elemwise(body, ins, shape, body["out_dtypes"], spec, env)

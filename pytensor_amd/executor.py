@@ -40,10 +40,11 @@ HOST_MAX = 64  # host-resident values are tiny integer/bool arrays (shape math)
 class HostValue:
     """A small host-resident value (shape arithmetic / scalar indices)."""
 
-    __slots__ = ("a",)
+    __slots__ = ("a", "dev")
 
     def __init__(self, a):
         self.a = np.asarray(a)
+        self.dev = None  # cached device copy (constants are uploaded once)
 
     @property
     def shape(self):
@@ -64,14 +65,17 @@ class Env:
         self.exe = exe
         self.lib = ffi.lib()
         self.keepalive = []  # host arrays whose async H2D may still be in flight
+        self.graph = exe.graph  # graph whose node is currently running (inner graphs swap it)
 
     def to_device(self, v) -> DeviceArray:
         if isinstance(v, DeviceArray):
             return v
         if isinstance(v, HostValue):
-            a = np.ascontiguousarray(v.a)
-            self.keepalive.append(a)
-            return DeviceArray.from_host(a)
+            if v.dev is None:
+                a = v.a if v.a.flags.c_contiguous else np.ascontiguousarray(v.a)
+                self.keepalive.append(a)
+                v.dev = DeviceArray.from_host(a)
+            return v.dev
         raise TypeError(f"cannot move {type(v)} to the device")
 
     def to_host(self, v) -> np.ndarray:
@@ -127,7 +131,9 @@ class HipExecutable:
         if vid in self._const_cache:
             return self._const_cache[vid]
         a = np.asarray(v.const)
-        if v.kind != "tensor" or (a.dtype.kind in "iub" and a.size <= HOST_MAX):
+        if v.kind != "tensor" or a.size <= HOST_MAX:
+            # small constants (alpha/beta of Gemv, fill values, shapes) stay on the host and
+            # are uploaded lazily, once, when a kernel needs them as an operand
             val = HostValue(a)
         else:
             val = DeviceArray.from_host(a)
@@ -172,6 +178,13 @@ class HipExecutable:
         if len(inputs) != len(g.inputs):
             raise TypeError(f"expected {len(g.inputs)} inputs, got {len(inputs)}")
         env = env or Env(self)
+        outer_graph, env.graph = env.graph, g
+        try:
+            return self._run_nodes(g, inputs, env), env
+        finally:
+            env.graph = outer_graph
+
+    def _run_nodes(self, g, inputs, env):
         vals = {}
         for pos, (vid, value) in enumerate(zip(g.inputs, inputs)):
             vals[vid] = self._input(pos, vid, value, env)
@@ -186,7 +199,17 @@ class HipExecutable:
             h = handlers.get(node.op)
             if h is None:
                 raise NotImplementedError(f"hip linker: no device handler for {node.op}")
-            outs = h(node, ins, env)
+            try:
+                outs = h(node, ins, env)
+            except Exception as e:
+                # the analogue of raise_with_op (pytensor/link/utils.py:271): say which Apply failed
+                desc = ", ".join(
+                    f"{type(v).__name__}{getattr(v, 'shape', '')}:{getattr(v, 'dtype', '')}" for v in ins
+                )
+                msg = f"\nhip linker: while running node {k} {node.op}({desc})"
+                if e.args and isinstance(e.args[0], str):
+                    e.args = (e.args[0] + msg, *e.args[1:])
+                raise
             for o, val in zip(node.outputs, outs):
                 vals[o] = val
             for dead in self._last_use[k]:
@@ -197,7 +220,7 @@ class HipExecutable:
             if v is None:
                 v = self._const(o, env)
             outs.append(v)
-        return outs, env
+        return outs
 
     def __call__(self, *inputs):
         self._ensure_device()
