@@ -167,6 +167,10 @@ size_t pthip_scatter_rows_workspace(int64_t n_idx, int64_t n_rows, int64_t inner
 int pthip_scatter_rows(int dtype, int inc, int64_t n_idx, int64_t inner, void* out, int64_t n_rows,
                        const int64_t* idx, const void* y, int64_t y_stride0, void* ws,
                        size_t ws_bytes);
+/* gather up to 16 small contiguous device buffers into one staging buffer (one launch instead of
+ * one D2H copy per Function output; cf. the output loop of pytensor/link/basic.py:683-684) */
+int pthip_pack(int n, const void* const* srcs, const int64_t* nbytes, const int64_t* dst_offsets,
+               void* dst);
 /* device-side error flag raised by kernels (index out of bounds ...); sync + read + clear */
 int pthip_check_status(int* status);
 

@@ -174,26 +174,41 @@ __global__ __launch_bounds__(BLOCK) void gemv_col_kernel(
 }
 
 // out[i] = beta*y[i] + alpha * sum_p part[p][i]   (fixed order → deterministic)
+// Block = 16 outputs x 16 slices of the partial rows: 128-byte coalesced reads per slice,
+// slices combined through LDS in slice order.
 template <class T>
 __global__ __launch_bounds__(BLOCK) void gemv_finish_kernel(T* __restrict__ out,
                                                            const T* __restrict__ part,
                                                            const T* __restrict__ y, long long M,
                                                            long long nparts, long long sy, T alpha,
                                                            T beta) {
-  const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= M) return;
+  __shared__ T red[16][17];
+  const int oi = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long long i = (long long)blockIdx.x * 16 + oi;
+  const long long per = (nparts + 15) / 16;
+  long long p0 = sl * per, p1 = p0 + per;
+  if (p1 > nparts) p1 = nparts;
   T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
-  long long p = 0;
-  for (; p + 3 < nparts; p += 4) {
-    a0 += part[p * M + i];
-    a1 += part[(p + 1) * M + i];
-    a2 += part[(p + 2) * M + i];
-    a3 += part[(p + 3) * M + i];
+  if (i < M) {
+    long long p = p0;
+    for (; p + 3 < p1; p += 4) {
+      a0 += part[p * M + i];
+      a1 += part[(p + 1) * M + i];
+      a2 += part[(p + 2) * M + i];
+      a3 += part[(p + 3) * M + i];
+    }
+    for (; p < p1; p++) a0 += part[p * M + i];
   }
-  for (; p < nparts; p++) a0 += part[p * M + i];
-  T res = alpha * ((a0 + a1) + (a2 + a3));
-  if (beta != T(0)) res += beta * y[i * sy];
-  out[i] = res;
+  red[sl][oi] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (sl == 0 && i < M) {
+    T v = red[0][oi];
+#pragma unroll
+    for (int k = 1; k < 16; k++) v += red[k][oi];
+    T res = alpha * v;
+    if (beta != T(0)) res += beta * y[i * sy];
+    out[i] = res;
+  }
 }
 
 // ---- generic strided fallback: wave per row, scalar loads ----------------------------------
@@ -301,7 +316,7 @@ int gemv_typed(long long M, long long N, double alpha_d, const void* Av, long lo
                          dim3(BLOCK), 0, st, part, A, x, M, N, sA1, sx, p.chunk);
     int r = pthip::post_launch("gemv_col");
     if (r) return r;
-    hipLaunchKernelGGL((gemv_finish_kernel<T>), dim3((unsigned)((M + BLOCK - 1) / BLOCK)),
+    hipLaunchKernelGGL((gemv_finish_kernel<T>), dim3((unsigned)((M + 15) / 16)),
                        dim3(BLOCK), 0, st, out, part, y, M, nparts, sy, alpha, beta);
     return pthip::post_launch("gemv_finish");
   }

@@ -166,24 +166,37 @@ __global__ __launch_bounds__(BLOCK) void scatter_add_scan_kernel(
   if (bin < n_bins) part[((long long)blockIdx.x * parts + slice) * n_bins + bin] = acc;
 }
 
+// out[b] += sum_k part[k][b] in k order: 16 bins x 16 slices per block, combined in LDS
 template <class T>
 __global__ __launch_bounds__(BLOCK) void scatter_add_finish_kernel(T* __restrict__ out,
                                                                   const T* __restrict__ part,
                                                                   long long n_bins,
                                                                   long long nblk) {
-  const long long b = (long long)blockIdx.x * BLOCK + threadIdx.x;
-  if (b >= n_bins) return;
-  // pairwise-in-order: 4 interleaved accumulators combined in a fixed order
+  __shared__ T red[16][17];
+  const int oi = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long long b = (long long)blockIdx.x * 16 + oi;
+  const long long per = (nblk + 15) / 16;
+  long long k0 = sl * per, k1 = k0 + per;
+  if (k1 > nblk) k1 = nblk;
   T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
-  long long k = 0;
-  for (; k + 3 < nblk; k += 4) {
-    a0 += part[k * n_bins + b];
-    a1 += part[(k + 1) * n_bins + b];
-    a2 += part[(k + 2) * n_bins + b];
-    a3 += part[(k + 3) * n_bins + b];
+  if (b < n_bins) {
+    long long k = k0;
+    for (; k + 3 < k1; k += 4) {
+      a0 += part[k * n_bins + b];
+      a1 += part[(k + 1) * n_bins + b];
+      a2 += part[(k + 2) * n_bins + b];
+      a3 += part[(k + 3) * n_bins + b];
+    }
+    for (; k < k1; k++) a0 += part[k * n_bins + b];
   }
-  for (; k < nblk; k++) a0 += part[k * n_bins + b];
-  out[b] += (a0 + a1) + (a2 + a3);
+  red[sl][oi] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (sl == 0 && b < n_bins) {
+    T v = red[0][oi];
+#pragma unroll
+    for (int k = 1; k < 16; k++) v += red[k][oi];
+    out[b] += v;
+  }
 }
 
 // many bins: native fp atomics (order not reproducible in the last bits; documented)
@@ -209,6 +222,30 @@ __global__ __launch_bounds__(BLOCK) void scatter_add_atomic_kernel(
       atomicAdd((unsigned long long*)&out[j * inner + c], (unsigned long long)y[r * ys0 + c]);
     else
       atomicAdd((int*)&out[j * inner + c], (int)y[r * ys0 + c]);
+  }
+}
+
+// ---- pack: gather up to 16 small contiguous buffers into one staging buffer -----------------
+struct PackDesc {
+  const unsigned char* src[16];
+  long long nbytes[16];
+  long long dst_off[16];
+};
+
+__global__ __launch_bounds__(BLOCK) void pack_kernel(unsigned char* __restrict__ dst, PackDesc d) {
+  const int e = blockIdx.y;
+  const long long nb = d.nbytes[e];
+  const unsigned char* s = d.src[e];
+  unsigned char* o = dst + d.dst_off[e];
+  const long long tid = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  const long long nth = (long long)gridDim.x * BLOCK;
+  if ((((uintptr_t)s | (uintptr_t)o) & 7) == 0) {
+    const long long nw = nb >> 3;
+    for (long long i = tid; i < nw; i += nth)
+      ((unsigned long long*)o)[i] = ((const unsigned long long*)s)[i];
+    for (long long i = (nw << 3) + tid; i < nb; i += nth) o[i] = s[i];
+  } else {
+    for (long long i = tid; i < nb; i += nth) o[i] = s[i];
   }
 }
 
@@ -366,7 +403,7 @@ int pthip_scatter_rows(int dtype, int inc, int64_t n_idx, int64_t inner, void* o
                        (long long)inner, (long long)n_rows, (long long)ys0, n_bins, nb_pad,       \
                        per_block, status);                                                        \
     hipLaunchKernelGGL((scatter_add_finish_kernel<T>),                                            \
-                       dim3((unsigned)((n_bins + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st,        \
+                       dim3((unsigned)((n_bins + 15) / 16)), dim3(BLOCK), 0, st,                  \
                        (T*)out, (const T*)ws, n_bins, nblk * parts);                              \
   } while (0)
     if (dtype == PTHIP_F64) LAUNCH(double);
@@ -388,6 +425,27 @@ int pthip_scatter_rows(int dtype, int inc, int64_t n_idx, int64_t inner, void* o
   }
 #undef LAUNCH
   return pthip::post_launch("scatter_add_atomic");
+}
+
+int pthip_pack(int n, const void* const* srcs, const int64_t* nbytes, const int64_t* dst_offsets,
+               void* dst) {
+  PTHIP_REQUIRE_INIT();
+  if (n <= 0) return 0;
+  if (n > 16) return pthip::set_error("pthip_pack: at most 16 buffers per call");
+  PackDesc d{};
+  long long mx = 0;
+  for (int i = 0; i < n; i++) {
+    d.src[i] = (const unsigned char*)srcs[i];
+    d.nbytes[i] = nbytes[i];
+    d.dst_off[i] = dst_offsets[i];
+    if (nbytes[i] > mx) mx = nbytes[i];
+  }
+  long long bx = (mx / 8 + BLOCK - 1) / BLOCK;
+  if (bx < 1) bx = 1;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)bx, (unsigned)n), dim3(BLOCK), 0,
+                     pthip::ctx().stream, (unsigned char*)dst, d);
+  return pthip::post_launch("pack");
 }
 
 }  // extern "C"

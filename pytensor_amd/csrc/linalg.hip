@@ -5,133 +5,351 @@
 // SolveTriangular.perform (solvers/triangular.py:32-71, trtrs, NaN on info != 0);
 // CholeskySolve.perform (solvers/psd.py:35-53, potrs = two triangular solves).
 //
-// MI355X mapping: these are latency-bound on the hot path (n = 128: 0.7 MFLOP), so the
-// design goal is "one launch, everything on-chip": a 128x128 fp64 matrix is 128 KiB and
-// fits the 160 KiB LDS of one CU, so one workgroup factors it entirely in LDS
-// (right-looking, column-at-a-time, two barriers per column).  Larger matrices fall
-// back to the same algorithm on global memory (correct, not fast).  Batches
-// (Blockwise) map to grid.x.
+// MI355X mapping: on the hot path these are latency-bound (n = 128: 0.7 MFLOP), so the
+// design goal is "one launch, everything on-chip".  A 128x128 fp64 matrix (128 KiB)
+// fits the 160 KiB LDS of one CU:
+//   potrf : one workgroup, blocked right-looking with 16-column panels:
+//           (a) the 16x16 diagonal block is factored in REGISTERS by every wave
+//               redundantly (lane i holds row i; cross-lane reads are v_readlane), so no
+//               barrier or LDS round trip separates it from
+//           (b) the panel solve X = A21 L11^-T, one matrix row per thread, L11 entries
+//               broadcast from the wave's own registers, and
+//           (c) the trailing update A22 -= X X^T with 4x4 register tiles read from LDS.
+//           Two barriers per panel (8 panels at n = 128) instead of three per column.
+//   trsv  : matrix staged to LDS by the whole workgroup (coalesced), then ONE wave does the
+//           substitution wave-synchronously (two rows per lane, pivots via v_readlane):
+//           no barriers inside the n-step dependency chain.
+// Larger matrices fall back to simple global-memory kernels (correct, not fast).
+// Batches (Blockwise) map to grid.x.
 #include "common.h"
 
 namespace {
 
 constexpr int BLOCK = 256;
+constexpr int NB = 16;  // panel width
 
-// A: row-major n×n (contiguous). L: row-major n×n.  lower: L L^T = A, else U^T U = A
-// with U returned (upper).  We always factor the lower triangle of the symmetric
-// matrix in "lower" form internally: for upper we read A transposed (A is symmetric
-// in the referenced triangle only: LAPACK reads the `uplo` triangle) and write L^T.
-template <class T, bool LDS>
-__global__ __launch_bounds__(BLOCK) void potrf_kernel(T* __restrict__ Lout,
-                                                     const T* __restrict__ Ain, int n, int lower,
-                                                     T* __restrict__ scratch) {
+template <class T> __device__ __forceinline__ T bcast_lane(T v, int src) {
+  // wave-uniform broadcast of lane `src` (compile-time constant after unrolling)
+  if constexpr (sizeof(T) == 8) {
+    union { T t; int i[2]; } u;
+    u.t = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], src);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
+    return u.t;
+  } else {
+    union { T t; int i; } u;
+    u.t = v;
+    u.i = __builtin_amdgcn_readlane(u.i, src);
+    return u.t;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// blocked LDS-resident Cholesky
+// ---------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(BLOCK) void potrf_lds_kernel(T* __restrict__ Lout,
+                                                         const T* __restrict__ Ain, int n,
+                                                         int lower) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ int s_fail;
+  T* W = (T*)smem_raw;
+  const int ld = n | 1;  // odd leading dimension: column walks are bank-conflict free
   const long long mat = blockIdx.x;
   const T* A = Ain + mat * (long long)n * n;
   T* Lo = Lout + mat * (long long)n * n;
-  T* W = LDS ? (T*)smem_raw : scratch + mat * (long long)n * n;
-  const int ld = LDS ? (n | 1) : n;  // odd leading dimension: conflict-free column walks
-  if (threadIdx.x == 0) s_fail = 0;
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) s_fail = 0;
   // load the referenced triangle as a lower-triangular working matrix W[i][j], i >= j
-  for (int e = threadIdx.x; e < n * n; e += BLOCK) {
-    const int i = e / n, j = e - i * n;
-    if (i >= j) W[i * ld + j] = lower ? A[i * n + j] : A[j * n + i];
+  // (for `upper` the strict upper triangle is read transposed: LAPACK reads only `uplo`)
+  // (8 independent loads in flight per thread: an un-unrolled loop would serialise the
+  //  HBM/L2 latency 64 times)
+  for (int e0 = 0; e0 < n * n; e0 += BLOCK * 8) {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int e = e0 + u * BLOCK + tid;
+      v[u] = e < n * n ? A[e] : T(0);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int e = e0 + u * BLOCK + tid;
+      if (e < n * n) {
+        const int i = e / n, j = e - i * n;
+        if (lower) { if (i >= j) W[i * ld + j] = v[u]; }
+        else { if (j >= i) W[j * ld + i] = v[u]; }
+      }
+    }
   }
   __syncthreads();
-  for (int k = 0; k < n; k++) {
-    const T akk = W[k * ld + k];
-    // LAPACK dpotf2: fail if akk <= 0 or NaN
-    if (!(akk > T(0))) {
-      if (threadIdx.x == 0) s_fail = 1;
-      break;  // uniform: every thread reads the same akk
+  bool fail = false;
+  for (int j0 = 0; j0 < n; j0 += NB) {
+    const int jb = (n - j0) < NB ? (n - j0) : NB;
+    // ---- (a) diagonal block in registers: lane r (< NB) of EVERY wave holds row j0+r ----
+    T d[NB], rdiag[NB];
+    {
+      const int r = lane < NB ? lane : NB - 1;
+      const int row = (j0 + r) < n ? (j0 + r) : (n - 1);
+#pragma unroll
+      for (int c = 0; c < NB; c++) d[c] = (c < jb && c <= r) ? W[row * ld + j0 + c] : T(0);
     }
-    const T piv = sqrt(akk);
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      if (k < jb) {
+        const T akk = bcast_lane(d[k], k);
+        if (!(akk > T(0))) fail = true;  // dpotf2: non-positive or NaN pivot (wave-uniform)
+        // one wave-uniform reciprocal square root per column (dpotf2 itself scales the
+        // column by 1/ajj via dscal); piv = akk * rsqrt(akk) is within 2 ulp of sqrt(akk)
+        rdiag[k] = rsqrt(akk);
+        const T piv = akk * rdiag[k];
+        // column k: rows > k scaled, row k gets the pivot
+        d[k] = (lane == k) ? piv : d[k] * rdiag[k];
+#pragma unroll
+        for (int c = k + 1; c < NB; c++) {
+          // a[r][c] -= a[r][k] * a[c][k] ; a[c][k] lives in lane c
+          const T ack = bcast_lane(d[k], c);
+          d[c] -= d[k] * ack;
+        }
+      }
+    }
+    // (rows r < k were also "updated" above; only the lower triangle c <= r is meaningful)
+    const int m = n - j0 - jb;  // rows below the panel
+    // ---- (b) panel solve: thread t owns row i = j0+jb+t; x = a L11^-T ----
+    for (int t = tid; t < m; t += BLOCK) {
+      // (m <= 112 < BLOCK at n = 128: a single pass, threads of all four waves busy)
+      const int i = j0 + jb + t;
+      T x[NB];
+#pragma unroll
+      for (int c = 0; c < NB; c++) x[c] = (c < jb) ? W[i * ld + j0 + c] : T(0);
+#pragma unroll
+      for (int k = 0; k < NB; k++) {
+        if (k < jb) {
+          T s = x[k];
+#pragma unroll
+          for (int c = 0; c < k; c++) s -= x[c] * bcast_lane(d[c], k);  // L11[k][c]
+          x[k] = s * rdiag[k];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < NB; c++)
+        if (c < jb) W[i * ld + j0 + c] = x[c];
+    }
+    // the readlane broadcasts above must be executed by all lanes of a wave, including
+    // lanes without a row: handle waves whose lanes all have t >= m uniformly
+    // (bcast_lane is only reached inside the t-loop by waves with at least one row;
+    //  v_readlane ignores EXEC for the source lane, so partial waves are fine).
+    // wave 0 writes the factored diagonal block back
+    if (tid < NB && tid < jb) {
+#pragma unroll
+      for (int c = 0; c < NB; c++)
+        if (c <= tid) W[(j0 + tid) * ld + j0 + c] = d[c];
+    }
     __syncthreads();
-    // scale column k
-    for (int i = k + threadIdx.x; i < n; i += BLOCK)
-      W[i * ld + k] = (i == k) ? piv : W[i * ld + k] / piv;
-    __syncthreads();
-    // trailing update: W[i][j] -= W[i][k]*W[j][k], k < j <= i < n
-    const int m = n - k - 1;
-    const long long tot = (long long)m * m;
-    for (long long e = threadIdx.x; e < tot; e += BLOCK) {
-      const int ii = (int)(e / m), jj = (int)(e - (long long)ii * m);
-      if (jj <= ii) {
-        const int i = k + 1 + ii, j = k + 1 + jj;
-        W[i * ld + j] -= W[i * ld + k] * W[j * ld + k];
+    // ---- (c) trailing update A22 -= X X^T, 4x4 register tiles over the lower triangle ----
+    if (m > 0) {
+      const int mt = (m + 3) >> 2;            // tiles per side
+      const int ntiles = mt * (mt + 1) / 2;   // lower-triangular tile count
+      const int base = j0 + jb;
+      for (int tt = tid; tt < ntiles; tt += BLOCK) {
+        // unrank tt -> (ti >= tj)
+        int ti = (int)((sqrtf(8.0f * tt + 1.0f) - 1.0f) * 0.5f);
+        while ((ti + 1) * (ti + 2) / 2 <= tt) ti++;
+        while (ti * (ti + 1) / 2 > tt) ti--;
+        const int tj = tt - ti * (ti + 1) / 2;
+        const int i0 = base + ti * 4, c0 = base + tj * 4;
+        T acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int b = 0; b < 4; b++) acc[a][b] = T(0);
+#pragma unroll 4
+        for (int k = 0; k < NB; k++) {
+          if (k < jb) {
+            T xi[4], xj[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+              const int ri = (i0 + a) < n ? (i0 + a) : (n - 1);
+              const int rj = (c0 + a) < n ? (c0 + a) : (n - 1);
+              xi[a] = W[ri * ld + j0 + k];
+              xj[a] = W[rj * ld + j0 + k];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+              for (int b = 0; b < 4; b++) acc[a][b] += xi[a] * xj[b];
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            const int i = i0 + a, j = c0 + b;
+            if (i < n && j < n && j <= i) W[i * ld + j] -= acc[a][b];
+          }
       }
     }
     __syncthreads();
   }
+  if (fail) s_fail = 1;  // benign race: every writer stores 1
   __syncthreads();
-  const bool fail = s_fail != 0;
-  const T nanv = __builtin_nan("");
-  for (int e = threadIdx.x; e < n * n; e += BLOCK) {
+  const bool failed = s_fail != 0;
+  const T nanv = (T)__builtin_nan("");
+#pragma unroll 8
+  for (int e = tid; e < n * n; e += BLOCK) {
     const int i = e / n, j = e - i * n;
     T v;
-    if (fail) v = nanv;
+    if (failed) v = nanv;
     else if (lower) v = (i >= j) ? W[i * ld + j] : T(0);
     else v = (j >= i) ? W[j * ld + i] : T(0);
     Lo[e] = v;
   }
 }
 
-// Solve T X = B for one right-hand side per workgroup-column-group.
-// T is accessed through element strides (sT0, sT1), so a transposed solve is just
-// swapped strides + flipped `lower`.  B, X: n×nrhs row-major contiguous.
-// nrhs == 1: cooperative column-oriented substitution with T staged in LDS.
-template <class T, bool LDS>
-__global__ __launch_bounds__(BLOCK) void trsv_kernel(T* __restrict__ Xout,
-                                                    const T* __restrict__ Tm, long long sTb,
-                                                    long long sT0, long long sT1,
-                                                    const T* __restrict__ B, long long sBb, int n,
-                                                    int lower, int unit) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+// global-memory fallback (n too large for LDS): unblocked right-looking, one workgroup
+template <class T>
+__global__ __launch_bounds__(BLOCK) void potrf_global_kernel(T* __restrict__ Lout,
+                                                            const T* __restrict__ Ain, int n,
+                                                            int lower, T* __restrict__ scratch) {
   __shared__ int s_fail;
   const long long mat = blockIdx.x;
-  const T* Tg = Tm + mat * sTb;
-  const T* b = B + mat * sBb;
-  T* x = Xout + mat * (long long)n;
-  const int ld = n | 1;
-  T* W = (T*)smem_raw;               // LDS: n*ld (if LDS) + n for the rhs
-  T* xs = LDS ? W + (long long)n * ld : W;
+  const T* A = Ain + mat * (long long)n * n;
+  T* Lo = Lout + mat * (long long)n * n;
+  T* W = scratch + mat * (long long)n * n;
+  const int ld = n;
   if (threadIdx.x == 0) s_fail = 0;
-  if constexpr (LDS) {
-    for (int e = threadIdx.x; e < n * n; e += BLOCK) {
-      const int i = e / n, j = e - i * n;
-      W[i * ld + j] = Tg[i * sT0 + j * sT1];
-    }
+  for (long long e = threadIdx.x; e < (long long)n * n; e += BLOCK) {
+    const int i = (int)(e / n), j = (int)(e - (long long)i * n);
+    if (i >= j) W[(long long)i * ld + j] = lower ? A[(long long)i * n + j] : A[(long long)j * n + i];
   }
-  for (int i = threadIdx.x; i < n; i += BLOCK) xs[i] = b[i];
   __syncthreads();
-  for (int s = 0; s < n; s++) {
-    const int k = lower ? s : n - 1 - s;
-    const T d = unit ? T(1) : (LDS ? W[k * ld + k] : Tg[k * sT0 + k * sT1]);
-    if (d == T(0)) {  // trtrs: exact singularity => info > 0
+  for (int k = 0; k < n; k++) {
+    const T akk = W[(long long)k * ld + k];
+    if (!(akk > T(0))) {
       if (threadIdx.x == 0) s_fail = 1;
       break;
     }
-    const T xk = xs[k] / d;
+    const T piv = sqrt(akk);
     __syncthreads();
-    if (threadIdx.x == 0) xs[k] = xk;
-    // eliminate from the remaining rows
-    if (lower) {
-      for (int i = k + 1 + threadIdx.x; i < n; i += BLOCK)
-        xs[i] -= (LDS ? W[i * ld + k] : Tg[i * sT0 + k * sT1]) * xk;
-    } else {
-      for (int i = threadIdx.x; i < k; i += BLOCK)
-        xs[i] -= (LDS ? W[i * ld + k] : Tg[i * sT0 + k * sT1]) * xk;
+    for (int i = k + threadIdx.x; i < n; i += BLOCK)
+      W[(long long)i * ld + k] = (i == k) ? piv : W[(long long)i * ld + k] / piv;
+    __syncthreads();
+    for (int i = k + 1 + (threadIdx.x >> 6); i < n; i += BLOCK / 64) {
+      const T lik = W[(long long)i * ld + k];
+      for (int j = k + 1 + (threadIdx.x & 63); j <= i; j += 64)
+        W[(long long)i * ld + j] -= lik * W[(long long)j * ld + k];
     }
     __syncthreads();
   }
   __syncthreads();
   const bool fail = s_fail != 0;
-  for (int i = threadIdx.x; i < n; i += BLOCK) x[i] = fail ? (T)__builtin_nan("") : xs[i];
+  const T nanv = (T)__builtin_nan("");
+  for (long long e = threadIdx.x; e < (long long)n * n; e += BLOCK) {
+    const int i = (int)(e / n), j = (int)(e - (long long)i * n);
+    T v;
+    if (fail) v = nanv;
+    else if (lower) v = (i >= j) ? W[(long long)i * ld + j] : T(0);
+    else v = (j >= i) ? W[(long long)j * ld + i] : T(0);
+    Lo[e] = v;
+  }
 }
 
-// nrhs > 1: one thread per right-hand-side column, row-oriented substitution.
-// X (output) doubles as the working vector; accesses X[i*nrhs + c] are coalesced over c.
+// ---------------------------------------------------------------------------------
+// triangular solve, one right-hand side: wave-synchronous substitution from LDS
+// ---------------------------------------------------------------------------------
+// T accessed through element strides (sT0, sT1): a transposed solve = swapped strides +
+// flipped `lower`.  RPL rows per lane (n <= 64*RPL).
+template <class T, int RPL>
+__global__ __launch_bounds__(BLOCK) void trsv_lds_kernel(T* __restrict__ Xout,
+                                                        const T* __restrict__ Tm, long long sTb,
+                                                        long long sT0, long long sT1,
+                                                        const T* __restrict__ B, long long sBb,
+                                                        int n, int lower, int unit) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* W = (T*)smem_raw;
+  const int ld = n | 1;
+  const long long mat = blockIdx.x;
+  const T* Tg = Tm + mat * sTb;
+  const T* b = B + mat * sBb;
+  T* x = Xout + mat * (long long)n;
+  // stage T with the unit-stride axis across lanes (coalesced for either orientation)
+  const bool rowmaj = (sT1 == 1 || sT0 != 1);
+  for (int e0 = 0; e0 < n * n; e0 += BLOCK * 8) {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int e = e0 + u * BLOCK + threadIdx.x;
+      const int a = e / n, c = e - a * n;  // a: slow index, c: fast (unit-stride) index
+      const int i = rowmaj ? a : c, j = rowmaj ? c : a;
+      v[u] = e < n * n ? Tg[i * sT0 + j * sT1] : T(0);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int e = e0 + u * BLOCK + threadIdx.x;
+      const int a = e / n, c = e - a * n;
+      const int i = rowmaj ? a : c, j = rowmaj ? c : a;
+      if (e < n * n) W[i * ld + j] = v[u];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) return;  // one wave solves; no barriers below
+  const int lane = threadIdx.x;
+  T r[RPL];  // rows lane + 64*q
+#pragma unroll
+  for (int q = 0; q < RPL; q++) {
+    const int i = lane + 64 * q;
+    r[q] = i < n ? b[i] : T(0);
+  }
+  // The dependency chain per step is only  broadcast(r_k) -> divide -> fma:
+  // the matrix column k+1 is prefetched from LDS while step k's chain resolves.
+  bool fail = false;
+  T col[RPL], dkk;
+  {
+    const int k0 = lower ? 0 : n - 1;
+    dkk = unit ? T(1) : W[k0 * ld + k0];
+#pragma unroll
+    for (int q = 0; q < RPL; q++) {
+      const int i = lane + 64 * q;
+      col[q] = i < n ? W[i * ld + k0] : T(0);
+    }
+  }
+  for (int s = 0; s < n; s++) {
+    const int k = lower ? s : n - 1 - s;
+    // prefetch the next column (independent of the chain)
+    T ncol[RPL], ndkk = T(1);
+    if (s + 1 < n) {
+      const int kn = lower ? k + 1 : k - 1;
+      ndkk = unit ? T(1) : W[kn * ld + kn];
+#pragma unroll
+      for (int q = 0; q < RPL; q++) {
+        const int i = lane + 64 * q;
+        ncol[q] = i < n ? W[i * ld + kn] : T(0);
+      }
+    }
+    if (dkk == T(0)) fail = true;  // trtrs: exact singularity
+    T rk = T(0);
+#pragma unroll
+    for (int q = 0; q < RPL; q++)
+      if ((k >> 6) == q) rk = r[q];
+    const T xk = bcast_lane(rk, k & 63) / dkk;  // k is wave-uniform: v_readlane
+#pragma unroll
+    for (int q = 0; q < RPL; q++) {
+      const int i = lane + 64 * q;
+      if (i == k) r[q] = xk;
+      else if (lower ? i > k : i < k) r[q] -= col[q] * xk;
+    }
+    dkk = ndkk;
+#pragma unroll
+    for (int q = 0; q < RPL; q++) col[q] = ncol[q];
+  }
+  const T nanv = (T)__builtin_nan("");
+#pragma unroll
+  for (int q = 0; q < RPL; q++) {
+    const int i = lane + 64 * q;
+    if (i < n) x[i] = fail ? nanv : r[q];
+  }
+}
+
+// generic (any n, nrhs): one thread per right-hand-side column, row-oriented substitution.
 template <class T>
 __global__ __launch_bounds__(BLOCK) void trsm_kernel(T* __restrict__ Xout,
                                                     const T* __restrict__ Tm, long long sTb,
@@ -157,7 +375,7 @@ __global__ __launch_bounds__(BLOCK) void trsm_kernel(T* __restrict__ Xout,
     if (d == T(0)) fail = true;
     x[(long long)i * nrhs + c] = acc / d;
   }
-  // any zero pivot poisons the whole system (all columns share T): NaN-fill like the reference
+  // a zero pivot poisons the whole system (all columns share T): NaN-fill like the reference
   if (fail)
     for (int i = 0; i < n; i++) x[(long long)i * nrhs + c] = (T)__builtin_nan("");
 }
@@ -168,20 +386,17 @@ int potrf_typed(int lower, long long batch, long long n, const void* A, void* L)
   if (batch == 0 || n == 0) return 0;
   const size_t ld = (size_t)(n | 1);
   const size_t need = (size_t)n * ld * sizeof(T);
-  if (need <= 160 * 1024 - 64) {
-    auto k = potrf_kernel<T, true>;
+  if (need <= 160 * 1024 - 256) {
+    auto k = potrf_lds_kernel<T>;
     if (need > 64 * 1024)
       PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-    hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(BLOCK), need, st, (T*)L, (const T*)A, (int)n,
-                       lower, (T*)nullptr);
+    hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(BLOCK), need, st, (T*)L, (const T*)A, (int)n, lower);
     return pthip::post_launch("potrf_lds");
   }
-  // global-memory fallback: L doubles as scratch? no — L's upper triangle is written at
-  // the end; use a pooled scratch buffer.
   void* scratch = nullptr;
   int r = pthip_alloc((size_t)batch * n * n * sizeof(T), &scratch);
   if (r) return r;
-  hipLaunchKernelGGL((potrf_kernel<T, false>), dim3((unsigned)batch), dim3(BLOCK), 0, st, (T*)L,
+  hipLaunchKernelGGL((potrf_global_kernel<T>), dim3((unsigned)batch), dim3(BLOCK), 0, st, (T*)L,
                      (const T*)A, (int)n, lower, (T*)scratch);
   r = pthip::post_launch("potrf_global");
   pthip_free(scratch);  // stream-ordered reuse keeps this safe
@@ -194,25 +409,23 @@ int trsm_typed(int lower, int unit, long long batch, long long n, long long nrhs
                void* out) {
   hipStream_t st = pthip::ctx().stream;
   if (batch == 0 || n == 0 || nrhs == 0) return 0;
-  if (nrhs == 1) {
+  if (nrhs == 1 && n <= 256) {
     const size_t ld = (size_t)(n | 1);
-    const size_t full = ((size_t)n * ld + n) * sizeof(T);
-    if (full <= 160 * 1024 - 64) {
-      auto k = trsv_kernel<T, true>;
-      if (full > 64 * 1024)
-        PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)full));
-      hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(BLOCK), full, st, (T*)out, (const T*)Tm,
-                         sTb, sT0, sT1, (const T*)B, sBb, (int)n, lower, unit);
+    const size_t need = (size_t)n * ld * sizeof(T);
+    if (need <= 160 * 1024 - 256) {
+#define LAUNCH_TRSV(RPL)                                                                         \
+  do {                                                                                           \
+    auto k = trsv_lds_kernel<T, RPL>;                                                            \
+    if (need > 64 * 1024)                                                                        \
+      PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need)); \
+    hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(BLOCK), need, st, (T*)out, (const T*)Tm,   \
+                       sTb, sT0, sT1, (const T*)B, sBb, (int)n, lower, unit);                    \
+  } while (0)
+      if (n <= 64) LAUNCH_TRSV(1);
+      else if (n <= 128) LAUNCH_TRSV(2);
+      else LAUNCH_TRSV(4);
+#undef LAUNCH_TRSV
       return pthip::post_launch("trsv_lds");
-    }
-    const size_t small = (size_t)n * sizeof(T);
-    if (small <= 160 * 1024 - 64) {
-      auto k = trsv_kernel<T, false>;
-      if (small > 64 * 1024)
-        PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small));
-      hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(BLOCK), small, st, (T*)out, (const T*)Tm,
-                         sTb, sT0, sT1, (const T*)B, sBb, (int)n, lower, unit);
-      return pthip::post_launch("trsv_global");
     }
   }
   hipLaunchKernelGGL((trsm_kernel<T>), dim3((unsigned)((nrhs + BLOCK - 1) / BLOCK), (unsigned)batch),

@@ -10,9 +10,10 @@ frozen once and replayed with a single ``hipGraphLaunch``.
 How: (1) a warm-up run inside a private pool *arena* discovers every allocation;
 (2) the arena is rewound and the same sequence is run again under stream capture —
 allocations are now served from the arena's free lists (no ``hipMalloc`` while
-capturing), non-resident inputs arrive through pinned staging buffers, outputs leave
-through pinned buffers; (3) replays copy the small parameter arrays into the staging
-buffers, launch the graph, synchronise once and copy the outputs out.
+capturing); all non-resident inputs travel in ONE pinned staging block (one H2D
+node), all outputs are gathered by one ``pthip_pack`` launch into one block (one
+D2H node); (3) replays copy the small parameter arrays into the staging block,
+launch the graph, synchronise once and copy the outputs out.
 
 Data-dependent host reads (a ``ScalarFromTensor`` of a computed value used as a
 shape) cannot be frozen; ``freeze`` raises and the caller keeps the eager path.
@@ -25,25 +26,39 @@ import ctypes as C
 import numpy as np
 
 from pytensor_amd import ffi
-from pytensor_amd.device import DeviceArray
+from pytensor_amd.device import Buffer, DeviceArray, contiguous_strides
 from pytensor_amd.executor import Env, HostValue
 
+_ALIGN = 256
 
-class _Pinned:
-    def __init__(self, shape, dtype):
-        self.shape = tuple(shape)
-        self.dtype = np.dtype(dtype)
-        n = int(np.prod(self.shape)) if self.shape else 1
-        self.nbytes = n * self.dtype.itemsize
+
+def _round(n):
+    return (n + _ALIGN - 1) // _ALIGN * _ALIGN
+
+
+class _PinnedBlock:
+    """One pinned host allocation carved into aligned NumPy views."""
+
+    def __init__(self, specs):
+        self.offsets = []
+        off = 0
+        for shape, dtype in specs:
+            self.offsets.append(off)
+            n = int(np.prod(shape)) if len(shape) else 1
+            off += _round(max(n * np.dtype(dtype).itemsize, 1))
+        self.nbytes = max(off, _ALIGN)
         p = C.c_void_p()
-        ffi.check(ffi.lib().pthip_host_alloc(max(self.nbytes, 1), C.byref(p)))
+        ffi.check(ffi.lib().pthip_host_alloc(self.nbytes, C.byref(p)))
         self.ptr = p.value
-        buf = (C.c_char * max(self.nbytes, 1)).from_address(self.ptr)
-        self.array = np.frombuffer(buf, dtype=self.dtype, count=n).reshape(self.shape)
+        raw = (C.c_char * self.nbytes).from_address(self.ptr)
+        self.views = []
+        for (shape, dtype), o in zip(specs, self.offsets):
+            n = int(np.prod(shape)) if len(shape) else 1
+            self.views.append(np.frombuffer(raw, dtype=dtype, count=n, offset=o).reshape(shape))
 
     def free(self):
         if self.ptr:
-            self.array = None
+            self.views = []
             ffi.lib().pthip_host_free(self.ptr)
             self.ptr = 0
 
@@ -57,10 +72,11 @@ class FrozenPlan:
             raise TypeError(f"expected {len(g.inputs)} inputs, got {len(inputs)}")
         self._arena = C.c_void_p()
         self._graph_exec = C.c_void_p()
-        self._in_stage = {}  # position -> _Pinned
+        self._staged = []  # input positions travelling through the staging block
         self._baked = {}  # position -> host value baked into the plan (int scalars)
         self._resident_keys = {}
         self._sig = []
+        specs = []
         for pos, (vid, value) in enumerate(zip(g.inputs, inputs)):
             var = g.vars[vid]
             a = np.asarray(value)
@@ -73,8 +89,11 @@ class FrozenPlan:
             elif var.kind != "tensor" or (a.dtype.kind in "iub" and a.ndim == 0):
                 self._baked[pos] = a.copy()
             else:
-                self._in_stage[pos] = _Pinned(a.shape, a.dtype)
-        self._out_stage = None
+                self._staged.append(pos)
+                specs.append((a.shape, a.dtype))
+        self._in_block = _PinnedBlock(specs)
+        self._in_view = {pos: k for k, pos in enumerate(self._staged)}
+        self._out_block = None
         self._out_meta = None
         self._keep = []
         try:
@@ -87,45 +106,55 @@ class FrozenPlan:
     def _run_once(self, inputs, capture):
         exe, lib = self.exe, self.lib
         env = Env(exe)
+        blk = self._in_block
+        dev_in = None
+        if self._staged:
+            dev_in = Buffer(blk.nbytes)
+            ffi.check(lib.pthip_h2d(dev_in.ptr, blk.ptr, blk.nbytes))
         dev_inputs = []
         for pos, value in enumerate(inputs):
-            if pos in self._in_stage:
-                st = self._in_stage[pos]
-                d = DeviceArray.empty(st.shape, st.dtype)
-                if st.nbytes:
-                    ffi.check(lib.pthip_h2d(d.ptr, st.ptr, st.nbytes))
-                dev_inputs.append(d)
+            k = self._in_view.get(pos)
+            if k is not None:
+                v = blk.views[k]
+                dev_inputs.append(DeviceArray(dev_in, blk.offsets[k], v.shape, contiguous_strides(v.shape), v.dtype))
             elif pos in self._baked:
                 dev_inputs.append(HostValue(self._baked[pos]))
             else:
                 dev_inputs.append(exe._resident_cache[pos][1])
         outs, env = exe.run_device(dev_inputs, env)
-        if self._out_stage is None:
-            self._out_stage = []
+        if self._out_block is None:
+            specs = []
             self._out_meta = []
-            for o, vid in zip(outs, exe.graph.outputs):
+            for o in outs:
                 if isinstance(o, HostValue):
-                    self._out_stage.append(None)
                     self._out_meta.append(np.array(o.a, copy=True))
                 else:
-                    self._out_stage.append(_Pinned(o.shape, o.dtype))
                     self._out_meta.append(None)
-        for o, st in zip(outs, self._out_stage):
-            if st is None:
-                continue
-            src = o.contiguous()
-            if st.nbytes:
-                ffi.check(lib.pthip_d2h(st.ptr, src.ptr, st.nbytes))
+                    specs.append((o.shape, o.dtype))
+            self._out_block = _PinnedBlock(specs)
+        ob = self._out_block
+        dev_outs = [o.contiguous() for o in outs if not isinstance(o, HostValue)]
+        if dev_outs:
+            dev_out = Buffer(ob.nbytes)
+            # gather every output into one block: chunks of <= 16 buffers per launch
+            for c0 in range(0, len(dev_outs), 16):
+                chunk = dev_outs[c0 : c0 + 16]
+                n = len(chunk)
+                srcs = (C.c_void_p * n)(*[o.ptr for o in chunk])
+                nb = (C.c_int64 * n)(*[o.nbytes for o in chunk])
+                offs = (C.c_int64 * n)(*ob.offsets[c0 : c0 + n])
+                ffi.check(lib.pthip_pack(n, srcs, nb, offs, dev_out.ptr))
+            ffi.check(lib.pthip_d2h(ob.ptr, dev_out.ptr, ob.nbytes))
             if capture:
-                self._keep.append(src)
+                self._keep += [dev_out, dev_outs]
         if capture:
-            self._keep.append(env.keepalive)
+            self._keep += [dev_in, env.keepalive]
         return outs
 
     def _build(self, inputs):
         lib = self.lib
-        for pos, st in self._in_stage.items():
-            np.copyto(st.array, np.asarray(inputs[pos]))
+        for pos, k in self._in_view.items():
+            np.copyto(self._in_block.views[k], np.asarray(inputs[pos]))
         # (1) warm-up inside the arena
         ffi.check(lib.pthip_arena_begin(C.byref(self._arena)))
         try:
@@ -154,13 +183,15 @@ class FrozenPlan:
         lib = self.lib
         if len(inputs) != len(self._sig):
             raise TypeError(f"expected {len(self._sig)} inputs, got {len(inputs)}")
+        views = self._in_block.views
         for pos, value in enumerate(inputs):
-            st = self._in_stage.get(pos)
-            if st is not None:
+            k = self._in_view.get(pos)
+            if k is not None:
                 a = np.asarray(value)
-                if a.shape != st.shape or a.dtype != st.dtype:
+                v = views[k]
+                if a.shape != v.shape or a.dtype != v.dtype:
                     raise TypeError(f"frozen plan: input {pos} changed signature {self._sig[pos]} -> {(a.shape, str(a.dtype))}")
-                np.copyto(st.array, a)
+                np.copyto(v, a)
             elif pos in self._baked:
                 if not np.array_equal(np.asarray(value), self._baked[pos]):
                     raise ValueError(f"frozen plan: scalar input {pos} is baked into the plan and changed")
@@ -169,8 +200,13 @@ class FrozenPlan:
         ffi.check(lib.pthip_graph_launch(self._graph_exec))
         ffi.check(lib.pthip_synchronize())
         res = []
-        for st, meta in zip(self._out_stage, self._out_meta):
-            res.append(meta.copy() if st is None else st.array.copy())
+        k = 0
+        for meta in self._out_meta:
+            if meta is not None:
+                res.append(meta.copy())
+            else:
+                res.append(self._out_block.views[k].copy())
+                k += 1
         return tuple(res)
 
     def launch_async(self):
@@ -187,8 +223,9 @@ class FrozenPlan:
             if self._arena:
                 lib.pthip_arena_destroy(self._arena)
                 self._arena = C.c_void_p()
-            for st in list(self._in_stage.values()) + [s for s in (self._out_stage or []) if s is not None]:
-                st.free()
+            for blk in (self._in_block, self._out_block):
+                if blk is not None:
+                    blk.free()
         except Exception:
             pass
 

@@ -1,0 +1,77 @@
+"""Replica sharding of independent ``Function`` calls over the GPUs of one node.
+
+The reference has no distributed layer: MCMC chains are independent
+evaluations.  One process per GPU (``torch.distributed.run`` sets RANK / LOCAL_RANK /
+WORLD_SIZE); each rank owns one device, one resident copy of the data and its own
+chains.  There is no data-path collective — ``torch.distributed`` (RCCL on ROCm, gloo in
+the CPU tests) is used only for the barrier and for max-over-ranks timing.
+"""
+
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+
+
+@dataclass
+class RankInfo:
+    rank: int
+    local_rank: int
+    world: int
+
+
+def rank_info() -> RankInfo:
+    return RankInfo(
+        int(os.environ.get("RANK", "0")),
+        int(os.environ.get("LOCAL_RANK", "0")),
+        int(os.environ.get("WORLD_SIZE", "1")),
+    )
+
+
+def chains_for_rank(n_chains: int, info: RankInfo):
+    """Round-robin assignment chain i → rank i % world (chain i → GPU i mod 8)."""
+    return [c for c in range(n_chains) if c % info.world == info.rank]
+
+
+def init_process_group(info: RankInfo, backend: str | None = None):
+    """Returns the torch.distributed module (or None when world == 1)."""
+    if info.world <= 1:
+        return None
+    import torch
+    import torch.distributed as dist
+
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(info.local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", info.local_rank))
+    else:
+        dist.init_process_group(backend)
+    return dist
+
+
+def barrier(dist):
+    if dist is not None:
+        dist.barrier()
+
+
+def max_over_ranks(dist, value: float) -> float:
+    if dist is None:
+        return float(value)
+    import torch
+
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(dist, value: float) -> float:
+    if dist is None:
+        return float(value)
+    import torch
+
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

@@ -1,0 +1,87 @@
+"""CPU, build container only: the HipLinker boundary against the live reference."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import make_ref
+
+pytestmark = pytest.mark.skipif(not make_ref.available(), reason="/root/reference not present (GPU box)")
+
+
+@pytest.fixture(scope="module")
+def pt():
+    make_ref.activate()
+    import pytensor
+    import pytensor.tensor as ptt
+
+    import pytensor_amd
+
+    pytensor_amd.register()
+    return pytensor, ptt
+
+
+def test_mode_hip_is_registered_and_lowers(pt):
+    pytensor, ptt = pt
+    from pytensor.compile.mode import get_mode, predefined_linkers
+
+    from pytensor_amd.linker import HipLinker
+
+    assert isinstance(get_mode("hip").linker, HipLinker)
+    assert "hip" in predefined_linkers
+    x = ptt.dvector("x")
+    mu = ptt.dscalar("mu")
+    y = ptt.exp(-0.5 * (x - mu) ** 2).sum()
+    f = pytensor.function([x, mu], [y, pytensor.grad(y, x)], mode="hip")
+    g = f.maker.linker.last_ir
+    assert [n.op for n in g.nodes].count("Elemwise") == 1 and "CAReduce" in [n.op for n in g.nodes]
+    assert not any(n.op == "HostPerform" for n in g.nodes)
+    # the committed fixture is exactly what the linker produces today
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "c1_gauss.json")))
+    assert g.to_dict()["nodes"] == d["nodes"]
+
+
+def test_thunk_fails_loudly_without_gpu(pt):
+    pytensor, ptt = pt
+    from pytensor_amd import ffi
+
+    if ffi.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    x = ptt.dvector("x")
+    f = pytensor.function([x], [ptt.tanh(x).sum()], mode="hip")
+    with pytest.raises(Exception) as ei:
+        f(np.ones(4))
+    assert "no HIP device" in str(ei.value) or "HipError" in repr(ei.type)
+
+
+def test_linker_is_copyable_and_reusable(pt):
+    # FunctionMaker does copy(mode.linker) and accept() on a linker bound to another fgraph
+    # (pytensor/compile/maker.py:600-609, link/basic.py:308-317)
+    import copy
+
+    pytensor, ptt = pt
+    from pytensor_amd.linker import HipLinker
+
+    l = HipLinker()
+    l2 = copy.copy(l)
+    assert repr(l2) == "HipLinker()"
+    x = ptt.fmatrix("x")
+    f1 = pytensor.function([x], [x.sum(axis=0)], mode="hip")
+    f2 = pytensor.function([x], [ptt.dot(x, x.T)], mode="hip")
+    assert f1.maker.linker.last_ir.nodes[0].op == "CAReduce"
+    assert any(n.op in ("Dot22", "Dot") for n in f2.maker.linker.last_ir.nodes)
+
+
+def test_scan_and_ofg_inner_graphs_compile(pt):
+    pytensor, ptt = pt
+    xs = ptt.dmatrix("xs")
+    s0 = ptt.dvector("s0")
+    out = pytensor.scan(lambda x, s: ptt.tanh(s + x), sequences=[xs], outputs_info=[s0], return_updates=False)
+    f = pytensor.function([xs, s0], [out[-1]], mode="hip")
+    ops = [n.op for n in f.maker.linker.last_ir.nodes]
+    assert "Scan" in ops
+    from pytensor.tensor.special import softmax
+
+    f = pytensor.function([xs], [softmax(xs, axis=-1)], mode="hip")  # SymbolicOp / OpFromGraph path
+    assert not any(n.op == "HostPerform" for n in f.maker.linker.last_ir.nodes)
