@@ -37,9 +37,9 @@ template <> __device__ __forceinline__ float vget<float>(const float4& v, int k)
 // ---- row kernel ------------------------------------------------------------------------
 // VEC: 16-byte vector loads (requires N % VN == 0, sA0 % VN == 0, aligned base).
 // x is staged in LDS when it fits (XLDS), else read through L1/L2.
-constexpr int ROWS = 4;  // rows in flight per wave
+// ROWS rows in flight per wave (4 when there are plenty of rows, 1 for short-and-wide matrices)
 
-template <class T, bool VEC, bool XLDS>
+template <class T, bool VEC, bool XLDS, int ROWS>
 __global__ __launch_bounds__(BLOCK) void gemv_row_kernel(
     T* __restrict__ out, const T* __restrict__ A, const T* __restrict__ x,
     const T* __restrict__ y, long long M, long long N, long long sA0, long long sx, long long sy,
@@ -286,14 +286,23 @@ int gemv_typed(long long M, long long N, double alpha_d, const void* Av, long lo
     const bool vec = (N % VN == 0) && (sA0 % VN == 0) && (((uintptr_t)A) % 16 == 0);
     const bool xlds = (size_t)N * sizeof(T) <= 64 * 1024;
     const bool vec_ok = vec && (xlds || (sx == 1 && ((uintptr_t)x) % 16 == 0));
-    long long waves = (M + ROWS - 1) / ROWS;
+    // plenty of rows: 4 rows in flight per wave; short-and-wide (e.g. 4096 x 4096): one row
+    // per wave so that >= 2048 workgroups exist to fill 256 CUs
+    const int rows = (M / (4 * WAVES) >= (long long)pthip::kNumCU * 4) ? 4 : 1;
+    long long waves = (M + rows - 1) / rows;
     long long blocks = (waves + WAVES - 1) / WAVES;
     long long cap = (long long)pthip::kNumCU * 8;
     if (blocks > cap) blocks = cap;
     size_t shmem = xlds ? (size_t)N * sizeof(T) : 0;
-#define LAUNCH(V, X)                                                                             \
-  hipLaunchKernelGGL((gemv_row_kernel<T, V, X>), dim3((unsigned)blocks), dim3(BLOCK), shmem, st, \
-                     out, A, x, y, M, N, sA0, sx, sy, alpha, beta)
+#define LAUNCH(V, X)                                                                              \
+  do {                                                                                            \
+    if (rows == 4)                                                                                \
+      hipLaunchKernelGGL((gemv_row_kernel<T, V, X, 4>), dim3((unsigned)blocks), dim3(BLOCK),      \
+                         shmem, st, out, A, x, y, M, N, sA0, sx, sy, alpha, beta);                \
+    else                                                                                          \
+      hipLaunchKernelGGL((gemv_row_kernel<T, V, X, 1>), dim3((unsigned)blocks), dim3(BLOCK),      \
+                         shmem, st, out, A, x, y, M, N, sA0, sx, sy, alpha, beta);                \
+  } while (0)
     if (vec_ok && xlds) LAUNCH(true, true);
     else if (vec_ok) LAUNCH(true, false);
     else if (xlds) LAUNCH(false, true);

@@ -19,7 +19,10 @@ from pytensor_amd.dispatch import handler
 from pytensor_amd.executor import HOST_MAX, HostValue
 
 BLOCK = codegen.BLOCK
-MAX_GRID = 256 * 8  # ≫256 workgroups, grid-stride beyond (cdna guide G11)
+import os as _os
+
+MAX_GRID = int(_os.environ.get("PTHIP_EW_MAXGRID", 256 * 8))  # ≫256 workgroups, grid-stride beyond (cdna guide G11)
+EW_UNROLL = int(_os.environ.get("PTHIP_EW_UNROLL", 2))
 
 _body_key_cache = {}
 
@@ -176,7 +179,7 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env):
             ptrs = [a.ptr for a, m in zip(ins, modes) if m == "V"] + [o.ptr for o in outs if o is not None]
             if any(p % 16 for p in ptrs) or n < vec:
                 vec = 1
-        unroll = 2
+        unroll = EW_UNROLL
         name = f"ew_{bkey}_{''.join(modes)}_v{vec}_{rkey}".replace("-", "x")
         src = codegen.flat_kernel_source(name, body, "".join(modes), vec, rs, unroll)
         fn = kernel_cache.get_function(src, name)

@@ -242,10 +242,10 @@ class HipExecutable:
         return tuple(host)
 
     # ------------------------------------------------------------------
-    def freeze(self, *inputs):
+    def freeze(self, *inputs, fetch_outputs=True):
         """Capture the launch sequence for this input signature into a hipGraph and
         return a :class:`FrozenPlan` (see ``pytensor_amd/plan.py``)."""
         from pytensor_amd.plan import FrozenPlan
 
         self._ensure_device()
-        return FrozenPlan(self, inputs)
+        return FrozenPlan(self, inputs, fetch_outputs=fetch_outputs)

@@ -64,8 +64,9 @@ class _PinnedBlock:
 
 
 class FrozenPlan:
-    def __init__(self, exe, inputs):
+    def __init__(self, exe, inputs, fetch_outputs=True):
         self.exe = exe
+        self.fetch_outputs = fetch_outputs  # False: device-side timing only (no pack/D2H node)
         self.lib = ffi.lib()
         g = exe.graph
         if len(inputs) != len(g.inputs):
@@ -134,7 +135,9 @@ class FrozenPlan:
             self._out_block = _PinnedBlock(specs)
         ob = self._out_block
         dev_outs = [o.contiguous() for o in outs if not isinstance(o, HostValue)]
-        if dev_outs:
+        if dev_outs and not self.fetch_outputs and capture:
+            self._keep += [dev_outs]
+        elif dev_outs:
             dev_out = Buffer(ob.nbytes)
             # gather every output into one block: chunks of <= 16 buffers per launch
             for c0 in range(0, len(dev_outs), 16):

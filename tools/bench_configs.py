@@ -1,0 +1,124 @@
+"""Per-config measurements for BASELINE.json configs #1, #2, #3, #5 on one MI355X
+(config #4 is bench.py).  Prints one JSON line per config: device time per evaluation
+(HIP events around hipGraph replays, inputs resident in HBM), achieved GB/s or TFLOP/s
+against the roofline that bounds it, and a parity check against the CPU oracle at the
+full size (or a reduced size where the oracle would take minutes).
+
+usage: python tools/bench_configs.py [c1 c2 c3 c5] [--reps R]
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+from pytensor_amd import configs, ffi  # noqa: E402
+from pytensor_amd.executor import HipExecutable  # noqa: E402
+from pytensor_amd.ir import Graph  # noqa: E402
+
+HBM_PEAK = 8000.0  # GB/s
+F64_MFMA_PEAK = 78.6  # TFLOP/s
+F32_MFMA_PEAK = 157.3
+
+
+def load(name):
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", f"{name}.json")))
+    return Graph.from_dict(d), d["input_names"]
+
+
+def device_time_ms(plan, reps):
+    lib = ffi.lib()
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    ffi.check(lib.pthip_event_create(C.byref(e0)))
+    ffi.check(lib.pthip_event_create(C.byref(e1)))
+    for _ in range(3):
+        plan.launch_async()
+    ffi.check(lib.pthip_event_record(e0))
+    for _ in range(reps):
+        plan.launch_async()
+    ffi.check(lib.pthip_event_record(e1))
+    ffi.check(lib.pthip_event_synchronize(e1))
+    ms = C.c_float()
+    ffi.check(lib.pthip_event_elapsed_ms(e0, e1, C.byref(ms)))
+    return ms.value / reps
+
+
+def run_case(name, vals, reps, check=True, rtol=1e-10, oracle_vals=None):
+    import np_graph
+
+    g, names = load(name)
+    inputs = [vals[n] for n in names]
+    exe = HipExecutable(g, resident=range(len(inputs)))
+    out = exe(*inputs)
+    if check:
+        ov = oracle_vals or vals
+        oin = [ov[n] for n in names]
+        ref = np_graph.run_graph(g, oin)
+        got = out if oracle_vals is None else HipExecutable(g)(*oin)
+        for k, (a, b) in enumerate(zip(got, ref)):
+            np.testing.assert_allclose(a, b, rtol=rtol, atol=rtol * max(1.0, float(np.max(np.abs(b)))), err_msg=f"{name} out{k}")
+    dplan = exe.freeze(*inputs, fetch_outputs=False)  # kernels only: no output D2H node
+    t_dev = device_time_ms(dplan, reps)
+    dplan.close()
+    plan = exe.freeze(*inputs)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        plan(*inputs)
+    t_wall = (time.perf_counter() - t0) / reps * 1e3
+    return t_dev, t_wall
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    reps = 20
+    if "--reps" in sys.argv:
+        reps = int(sys.argv[sys.argv.index("--reps") + 1])
+    which = args or ["c1", "c2", "c3", "c5"]
+    ffi.init(0)
+    res = []
+    if "c1" in which:
+        v = configs.c1_inputs()
+        td, tw = run_case("c1_gauss", v, reps)
+        b = 1.6e6
+        res.append({"config": "C1 exp(-0.5(x-mu)^2).sum()+grad N=1e5 f64", "ms_device": td, "ms_call": tw, "GBs": b / td / 1e6, "bound": "launch latency"})
+    if "c2" in which:
+        v = configs.c2_inputs()
+        small = configs.c2_inputs(N=1_000_000)
+        for nm, label in (("c2_cheap", "C2 cheap 52-op Composite+Sum N=1e7 f64"), ("c2_transc", "C2 transcendental (10 tanh + 10 exp) Composite+Sum N=1e7 f64")):
+            td, tw = run_case(nm, v, reps, oracle_vals=small)
+            b = 160e6
+            res.append({"config": label, "ms_device": td, "ms_call": tw, "GBs": b / td / 1e6, "frac_hbm": b / td / 1e6 / HBM_PEAK, "bound": "hbm"})
+    if "c3" in which:
+        v = configs.c3_inputs()
+        small = configs.c3_inputs(M=512, B=8, Bn=64)
+        td, tw = run_case("c3_dot22", v, max(3, reps // 4), oracle_vals=small)
+        fl = 2 * 4096**3
+        res.append({"config": "C3 Dot22 4096^3 f64", "ms_device": td, "ms_call": tw, "TFLOPs": fl / td / 1e9, "frac_mfma": fl / td / 1e9 / F64_MFMA_PEAK, "bound": "mfma f64"})
+        td, tw = run_case("c3_gemv", v, reps, oracle_vals=small)
+        b = 4096 * 4096 * 8
+        res.append({"config": "C3 Gemv 4096^2 f64", "ms_device": td, "ms_call": tw, "GBs": b / td / 1e6, "frac_hbm": b / td / 1e6 / HBM_PEAK, "bound": "hbm"})
+        td, tw = run_case("c3_bdot", v, reps, rtol=1e-4, oracle_vals=small)
+        fl = 2 * 512 * 256**3
+        res.append({"config": "C3 BatchedDot 512x(256x256) f32", "ms_device": td, "ms_call": tw, "TFLOPs": fl / td / 1e9, "frac_mfma": fl / td / 1e9 / F32_MFMA_PEAK, "bound": "mfma f32"})
+    if "c5" in which:
+        T, B, H = 1000, 64, 1024
+        v = configs.c5_inputs(T=T, B=B, H=H)
+        small = configs.c5_inputs(T=5, B=8, H=64)
+        td, tw = run_case("c5_gru", v, 3, rtol=2e-4, oracle_vals=small)
+        fl = 6 * 2 * B * H * H * T
+        res.append({"config": f"C5 GRU Scan T={T} B={B} H={H} f32", "ms_device": td, "ms_call": tw, "ms_per_step": td / T, "TFLOPs": fl / td / 1e9, "frac_mfma": fl / td / 1e9 / F32_MFMA_PEAK, "bound": "mfma f32 (skinny M)"})
+    for r in res:
+        print(json.dumps(r))
+
+
+if __name__ == "__main__":
+    main()
