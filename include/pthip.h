@@ -131,6 +131,11 @@ size_t pthip_gemv_workspace(int dtype, int64_t M, int64_t N, int64_t sA0, int64_
 int pthip_gemv(int dtype, int64_t M, int64_t N, double alpha, const void* A, int64_t sA0,
                int64_t sA1, const void* x, int64_t sx, double beta, const void* y, int64_t sy,
                void* out, void* ws, size_t ws_bytes);
+/* out[i] = beta*y[i*sy] + alpha * sum_{p<nparts} part[p*M + i], summed in a fixed order:
+ * second stage of the column-layout Gemv and of the fused one-pass GemvChain kernel
+ * (generated by pytensor_amd/codegen.py:gemv_chain_source). */
+int pthip_gemv_finish(int dtype, int64_t M, int64_t nparts, const void* part, double alpha,
+                      double beta, const void* y, int64_t sy, void* out);
 /* out[b] (M×N, contiguous) = beta*C[b] + alpha * A[b] (M×K) @ B[b] (K×N); batch stride 0 = shared.
  * beta==0 => C not read (gemm.py:183-216; codegen.py:159-250). MFMA tiles. */
 int pthip_gemm(int dtype, int64_t batch, int64_t M, int64_t N, int64_t K, double alpha,

@@ -626,5 +626,138 @@ def nd_kernel_source(name: str, body: dict, ndim: int, reduce_spec=None) -> str:
     return "\n".join(src)
 
 
+def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, has_y1) -> str:
+    """One-pass ``r = b1*y1 + a1*A@x ; outs = body(.., r, ..) ; partial += A.T@w`` (fp64).
+
+    Work decomposition (wave64): a wave owns groups of ``RG`` consecutive rows.  Lane l
+    holds columns {2l, 2l+1} + 128c (c < C) of every row of the group in registers
+    (16-byte coalesced loads: one wave instruction = one 1 KiB row chunk), so the
+    matrix is read from HBM exactly once and used twice:
+
+    1. per-row partial dot products (2C FMAs per row per lane);
+    2. a *transposing* butterfly: log2(RG) exchange steps in which every lane gives away
+       half of its rows (RG-1 exchanges instead of 6 per row), then 6-log2(RG) plain
+       steps — lanes (row << s .. ) end up owning one finished row each;
+    3. the scalar graph runs once per row on the owning lanes (other row inputs are
+       coalesced loads), reductions accumulate per lane, vector outputs are stored;
+    4. w[row] is broadcast back with ``v_readlane`` (compile-time lane) and multiplied
+       into the still-resident row registers: acc[c] += row * w.
+
+    ``e_modes[k]`` ∈ {'R' the Gemv result, 'V' N-vector, 'S' scalar} per elementwise input.
+    Kernel params (all 8 bytes): N, K, A, lda, x, y1, alpha1, beta1, <elementwise inputs
+    except R>, [r_out], <outputs: stored ptr | partial ptr>, partT.
+    """
+    import math
+
+    nout = len(body["out_dtypes"])
+    lg = int(math.log2(RG))
+    assert 1 << lg == RG and 2 <= RG <= 32
+    rest = 6 - lg  # plain butterfly steps after the transposing ones
+    params = [
+        "long long N", "long long K", "const double* __restrict__ A", "long long lda",
+        "const double* __restrict__ x", "const double* __restrict__ y1", "double alpha1", "double beta1",
+    ]
+    k_in = 0
+    for k, m in enumerate(e_modes):
+        if m != "R":
+            params.append(f"const {CTYPE[body['in_dtypes'][k]]}* __restrict__ in{k}")
+    if store_r:
+        params.append("double* __restrict__ r_out")
+    for k, dt in enumerate(body["out_dtypes"]):
+        if reduce_spec[k] is None:
+            params.append(f"{CTYPE[dt]}* __restrict__ out{k}")
+        else:
+            params.append(f"{CTYPE[reduce_spec[k][1]]}* __restrict__ part{k}")
+    params.append("double* __restrict__ partT")
+    L = [reduce_header(), PRELUDE]
+    L.append("typedef double pt_d2 __attribute__((ext_vector_type(2)));")
+    L.append("static __device__ __forceinline__ double pt_shfl_xor(double v, int m) { return pthip_dev::shfl_xor_any(v, m); }")
+    L.append("static __device__ __forceinline__ double pt_readlane(double v, int l) {")
+    L.append("  union { double d; int i[2]; } u; u.d = v;")
+    L.append("  u.i[0] = __builtin_amdgcn_readlane(u.i[0], l); u.i[1] = __builtin_amdgcn_readlane(u.i[1], l); return u.d; }")
+    L.append(f'extern "C" __global__ __launch_bounds__({BLOCK}) void {name}({", ".join(params)}) {{')
+    L.append(f"  constexpr int C = {C}, RG = {RG};")
+    L.append("  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;")
+    L.append("  pt_d2 b[C], accT[C];")
+    L.append("#pragma unroll\n  for (int c = 0; c < C; c++) {")
+    L.append("    const long long col = c * 128 + 2 * lane;")
+    L.append("    b[c] = (col < K) ? *(const pt_d2*)(x + col) : (pt_d2){0.0, 0.0};")
+    L.append("    accT[c] = (pt_d2){0.0, 0.0};\n  }")
+    for k, m in enumerate(e_modes):
+        if m == "S":
+            L.append(f"  const {CTYPE[body['in_dtypes'][k]]} s{k} = in{k}[0];")
+    for k, rs in enumerate(reduce_spec):
+        if rs is not None:
+            act = CTYPE[rs[1]]
+            L.append(f"  {act} acc{k}_0 = pthip_dev::{REDUCE_OPS[rs[0]]}::identity<{act}>();")
+    L.append(f"  const int myrow = (lane >> {rest}) & (RG - 1);   // row of the group this lane finishes")
+    L.append(f"  const bool owner = (lane & {(1 << rest) - 1}) == 0;")
+    L.append("  const long long ngroups = (N + RG - 1) / RG;")
+    L.append(f"  for (long long g = (long long)blockIdx.x * {BLOCK // 64} + wid; g < ngroups; g += (long long)gridDim.x * {BLOCK // 64}) {{")
+    L.append("    const long long row0 = g * RG;")
+    L.append("    pt_d2 xr[RG][C];")
+    L.append("#pragma unroll\n    for (int r = 0; r < RG; r++) {")
+    L.append("      const long long row = (row0 + r < N) ? row0 + r : N - 1;")
+    L.append("#pragma unroll\n      for (int c = 0; c < C; c++) {")
+    L.append("        const long long col = c * 128 + 2 * lane;")
+    L.append("        xr[r][c] = (col < K) ? *(const pt_d2*)(A + row * lda + col) : (pt_d2){0.0, 0.0};\n      }\n    }")
+    L.append("    double p[RG];")
+    L.append("#pragma unroll\n    for (int r = 0; r < RG; r++) {")
+    L.append("      double s = 0.0;")
+    L.append("#pragma unroll\n      for (int c = 0; c < C; c++) s += xr[r][c].x * b[c].x + xr[r][c].y * b[c].y;")
+    L.append("      p[r] = s;\n    }")
+    # transposing butterfly
+    half = RG // 2
+    mask = 32
+    while half >= 1:
+        L.append(f"    {{ const bool up = (lane & {mask}) != 0;")
+        L.append(f"#pragma unroll\n      for (int i = 0; i < {half}; i++) {{")
+        L.append(f"        const double send = up ? p[i] : p[i + {half}];")
+        L.append(f"        const double keep = up ? p[i + {half}] : p[i];")
+        L.append(f"        p[i] = keep + pt_shfl_xor(send, {mask});\n      }} }}")
+        half //= 2
+        mask //= 2
+    while mask >= 1:
+        L.append(f"    p[0] += pt_shfl_xor(p[0], {mask});")
+        mask //= 2
+    L.append("    const long long row = row0 + myrow;")
+    L.append("    const bool valid = row < N;")
+    L.append("    const long long rowc = valid ? row : N - 1;")
+    L.append("    double res = alpha1 * p[0];")
+    if has_y1:
+        L.append("    if (beta1 != 0.0) res += beta1 * y1[rowc];")
+    if store_r:
+        L.append("    if (valid && owner) r_out[row] = res;")
+    in_names = []
+    for k, m in enumerate(e_modes):
+        in_names.append("res" if m == "R" else (f"s{k}" if m == "S" else f"in{k}[rowc]"))
+    out_names = []
+    for k, dt in enumerate(body["out_dtypes"]):
+        L.append(f"    {CTYPE[dt]} o{k};")
+        out_names.append(f"o{k}")
+    L.append(emit_body(body, in_names, out_names, indent="    "))
+    for k, rs in enumerate(reduce_spec):
+        if rs is None:
+            L.append(f"    if (valid && owner) out{k}[row] = o{k};")
+        else:
+            L.append(f"    if (valid && owner) acc{k}_0 = pthip_dev::{REDUCE_OPS[rs[0]]}::apply(acc{k}_0, ({CTYPE[rs[1]]})o{k});")
+    L.append(f"    const double w = valid ? (double)o{w_out} : 0.0;")
+    L.append("#pragma unroll\n    for (int r = 0; r < RG; r++) {")
+    L.append(f"      const double wr = pt_readlane(w, r << {rest});")
+    L.append("#pragma unroll\n      for (int c = 0; c < C; c++) { accT[c].x += xr[r][c].x * wr; accT[c].y += xr[r][c].y * wr; }\n    }")
+    L.append("  }")
+    # block combine of accT (fixed wave order) and of the reductions
+    L.append(f"  __shared__ double redT[{BLOCK // 64}][128 * C];")
+    L.append("#pragma unroll\n  for (int c = 0; c < C; c++) { redT[wid][c * 128 + 2 * lane] = accT[c].x; redT[wid][c * 128 + 2 * lane + 1] = accT[c].y; }")
+    L.append("  __syncthreads();")
+    L.append(f"  for (int j = threadIdx.x; j < 128 * C; j += {BLOCK}) {{")
+    L.append("    double v = redT[0][j];")
+    L.append(f"#pragma unroll\n    for (int q = 1; q < {BLOCK // 64}; q++) v += redT[q][j];")
+    L.append("    if (j < K) partT[(long long)blockIdx.x * K + j] = v;\n  }")
+    L.append(_reduce_epilogue(reduce_spec, 1))
+    L.append("}")
+    return "\n".join(L)
+
+
 def source_key(src: str) -> str:
     return hashlib.sha256(src.encode()).hexdigest()[:24]

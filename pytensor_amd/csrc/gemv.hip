@@ -363,6 +363,24 @@ int pthip_gemv(int dtype, int64_t M, int64_t N, double alpha, const void* A, int
   return pthip::set_error("pthip_gemv: dtype %d not supported (float32/float64 only)", dtype);
 }
 
+int pthip_gemv_finish(int dtype, int64_t M, int64_t nparts, const void* part, double alpha,
+                      double beta, const void* y, int64_t sy, void* out) {
+  PTHIP_REQUIRE_INIT();
+  hipStream_t st = pthip::ctx().stream;
+  if (M == 0) return 0;
+  if (dtype == PTHIP_F64)
+    hipLaunchKernelGGL((gemv_finish_kernel<double>), dim3((unsigned)((M + 15) / 16)), dim3(BLOCK), 0,
+                       st, (double*)out, (const double*)part, (const double*)y, (long long)M,
+                       (long long)nparts, (long long)sy, alpha, beta);
+  else if (dtype == PTHIP_F32)
+    hipLaunchKernelGGL((gemv_finish_kernel<float>), dim3((unsigned)((M + 15) / 16)), dim3(BLOCK), 0,
+                       st, (float*)out, (const float*)part, (const float*)y, (long long)M,
+                       (long long)nparts, (long long)sy, (float)alpha, (float)beta);
+  else
+    return pthip::set_error("pthip_gemv_finish: dtype %d not supported", dtype);
+  return pthip::post_launch("gemv_finish");
+}
+
 int pthip_ger(int dtype, int64_t M, int64_t N, double alpha, const void* A, int64_t sA0,
               int64_t sA1, const void* x, int64_t sx, const void* y, int64_t sy, void* out) {
   PTHIP_REQUIRE_INIT();

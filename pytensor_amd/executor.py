@@ -58,6 +58,41 @@ class HostValue:
         return f"HostValue({self.a!r})"
 
 
+class KernelTimer:
+    """HIP-event brackets around individual generated-kernel launches (profiling only)."""
+
+    def __init__(self):
+        self.lib = ffi.lib()
+        self.pending = []
+        self.totals = {}
+
+    def begin(self):
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        ffi.check(self.lib.pthip_event_create(C.byref(e0)))
+        ffi.check(self.lib.pthip_event_create(C.byref(e1)))
+        ffi.check(self.lib.pthip_event_record(e0))
+        return e0, e1
+
+    def end(self, name, tok):
+        ffi.check(self.lib.pthip_event_record(tok[1]))
+        self.pending.append((name, tok))
+
+    def resolve(self):
+        for name, (e0, e1) in self.pending:
+            ms = C.c_float()
+            ffi.check(self.lib.pthip_event_synchronize(e1))
+            ffi.check(self.lib.pthip_event_elapsed_ms(e0, e1, C.byref(ms)))
+            t = self.totals.setdefault(name, [0.0, 0])
+            t[0] += ms.value
+            t[1] += 1
+            self.lib.pthip_event_destroy(e0)
+            self.lib.pthip_event_destroy(e1)
+        self.pending = []
+
+    def mean_ms(self):
+        return {k: v[0] / v[1] for k, v in self.totals.items()}
+
+
 class Env:
     """Per-call state handed to the node handlers."""
 
@@ -66,6 +101,8 @@ class Env:
         self.lib = ffi.lib()
         self.keepalive = []  # host arrays whose async H2D may still be in flight
         self.graph = exe.graph  # graph whose node is currently running (inner graphs swap it)
+        self.node_events = None  # set by HipExecutable.profile_nodes
+        self.kernel_timer = None  # KernelTimer: brackets individual generated-kernel launches
 
     def to_device(self, v) -> DeviceArray:
         if isinstance(v, DeviceArray):
@@ -93,10 +130,12 @@ class Env:
 class HipExecutable:
     def __init__(self, graph: Graph, resident=(), device: int | None = None, fuse=True):
         from pytensor_amd import dispatch  # registers handlers
-        from pytensor_amd.fusion import fuse_elemwise_reduce
+        from pytensor_amd.fusion import fuse_elemwise_reduce, fuse_gemv_chain
 
         self.source_graph = graph
         self.graph = fuse_elemwise_reduce(graph) if fuse else graph
+        if fuse and fuse != "elemwise":
+            self.graph = fuse_gemv_chain(self.graph)
         self.resident = set(resident)
         self._handlers = dispatch.HANDLERS
         self._resident_cache = {}  # input position -> (key, DeviceArray)
@@ -189,6 +228,7 @@ class HipExecutable:
         for pos, (vid, value) in enumerate(zip(g.inputs, inputs)):
             vals[vid] = self._input(pos, vid, value, env)
         handlers = self._handlers
+        evs = env.node_events if env.exe is self else None  # inner graphs are not itemised
         for k, node in enumerate(g.nodes):
             ins = []
             for i in node.inputs:
@@ -200,7 +240,11 @@ class HipExecutable:
             if h is None:
                 raise NotImplementedError(f"hip linker: no device handler for {node.op}")
             try:
+                if evs is not None:
+                    ffi.check(env.lib.pthip_event_record(evs[2 * k]))
                 outs = h(node, ins, env)
+                if evs is not None:
+                    ffi.check(env.lib.pthip_event_record(evs[2 * k + 1]))
             except Exception as e:
                 # the analogue of raise_with_op (pytensor/link/utils.py:271): say which Apply failed
                 desc = ", ".join(
@@ -240,6 +284,40 @@ class HipExecutable:
             raise IndexError("index out of bounds (device-side check)")
         env.keepalive.clear()
         return tuple(host)
+
+    # ------------------------------------------------------------------
+    def profile_nodes(self, inputs, reps=10):
+        """Device time of every node (HIP events on the context stream around each
+        handler, eager mode, averaged over ``reps`` runs): ``[(k, op, ms), ...]``."""
+        self._ensure_device()
+        lib = ffi.lib()
+        n = len(self.graph.nodes)
+        evs = []
+        for _ in range(2 * n):
+            e = C.c_void_p()
+            ffi.check(lib.pthip_event_create(C.byref(e)))
+            evs.append(e)
+        tot = [0.0] * n
+        self.last_kernel_times = {}
+        kt = KernelTimer()
+        try:
+            self(*inputs)  # warm: kernels compiled, residents uploaded
+            for _ in range(reps):
+                env = Env(self)
+                env.node_events = evs
+                env.kernel_timer = kt
+                self.run_device(inputs, env)
+                ffi.check(lib.pthip_synchronize())
+                for k in range(n):
+                    ms = C.c_float()
+                    ffi.check(lib.pthip_event_elapsed_ms(evs[2 * k], evs[2 * k + 1], C.byref(ms)))
+                    tot[k] += ms.value
+                kt.resolve()
+            self.last_kernel_times = kt.mean_ms()
+        finally:
+            for e in evs:
+                lib.pthip_event_destroy(e)
+        return [(k, self.graph.nodes[k].op, tot[k] / reps) for k in range(n)]
 
     # ------------------------------------------------------------------
     def freeze(self, *inputs, fetch_outputs=True):

@@ -82,6 +82,7 @@ SIGNATURES = {
     "pthip_reduce": (_int, [_int, _int, _int, _int, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _sz]),
     "pthip_gemv_workspace": (_sz, [_int, _i64, _i64, _i64, _i64]),
     "pthip_gemv": (_int, [_int, _i64, _i64, _dbl, _vp, _i64, _i64, _vp, _i64, _dbl, _vp, _i64, _vp, _vp, _sz]),
+    "pthip_gemv_finish": (_int, [_int, _i64, _i64, _vp, _dbl, _dbl, _vp, _i64, _vp]),
     "pthip_gemm": (
         _int,
         [_int, _i64, _i64, _i64, _i64, _dbl, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _dbl, _vp, _i64, _i64, _i64, _vp],

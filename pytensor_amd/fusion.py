@@ -74,3 +74,101 @@ def fuse_elemwise_reduce(g: Graph) -> Graph:
             continue
         out.nodes.append(new_nodes.get(k, n))
     return out
+
+
+# ---------------------------------------------------------------------------
+# Gemv(row) -> Elemwise -> Gemv(col) over the SAME matrix: read it once
+# ---------------------------------------------------------------------------
+
+
+def fuse_gemv_chain(g: Graph) -> Graph:
+    """``r = b1*y1 + a1*A@x1 ; (…, w, …) = Elemwise(…, r, …) ; out = b2*y2 + a2*A.T@w``
+
+    is the forward/backward pair of every regression-style logp+grad graph
+    (``X@beta`` forward, ``X.T@residual`` backward).  The
+    reference runs it as three nodes that stream the N×K matrix twice
+    (pytensor/tensor/blas/gemv.py:64-108 twice + elemwise.py:755); on MI355X the matrix
+    is the dominant HBM traffic, so the three are rewritten into
+
+    * ``GemvChain``  (placed where the Elemwise was): one kernel that loads a block of
+      rows once, forms the dot products, applies the scalar graph to them and
+      accumulates ``A.T@w`` from the same registers → per-workgroup partials;
+    * ``GemvFinish`` (placed where the second Gemv was): fixed-order sum of the
+      partials with the ``alpha2/beta2/y2`` epilogue.
+    """
+    producer = {}
+    for k, n in enumerate(g.nodes):
+        for o in n.outputs:
+            producer[o] = k
+    consumers = {}
+    for k, n in enumerate(g.nodes):
+        for i in n.inputs:
+            consumers.setdefault(i, []).append(k)
+    out_set = set(g.outputs)
+    replace = {}  # node index -> new Node or None (removed)
+    used = set()
+    new_vars = []
+    for k2, n2 in enumerate(g.nodes):
+        if n2.op != "Gemv":
+            continue
+        y2, a2, At, w, b2 = n2.inputs
+        kt = producer.get(At)
+        if kt is None or g.nodes[kt].op != "DimShuffle" or g.nodes[kt].params["new_order"] != [1, 0]:
+            continue
+        A = g.nodes[kt].inputs[0]
+        ke = producer.get(w)
+        if ke is None or ke in used or g.nodes[ke].op not in ("Elemwise", "ElemwiseReduce"):
+            continue
+        ne = g.nodes[ke]
+        if g.vars[w].ndim != 1 or g.vars[w].dtype != "float64":
+            continue
+        # find the forward Gemv feeding the elementwise node
+        r_pos = None
+        for pos, i in enumerate(ne.inputs):
+            k1 = producer.get(i)
+            if k1 is not None and g.nodes[k1].op == "Gemv" and g.nodes[k1].inputs[2] == A and k1 not in used:
+                r_pos = pos
+                break
+        if r_pos is None:
+            continue
+        r = ne.inputs[r_pos]
+        k1 = producer[r]
+        n1 = g.nodes[k1]
+        if ne.inputs.count(r) != 1:
+            continue
+        store_r = (r in out_set) or len(consumers.get(r, [])) != 1
+        spec = ne.params.get("reduce") or [None] * len(ne.outputs)
+        w_out = ne.outputs.index(w)
+        if spec[w_out] is not None:
+            continue
+        e_ins = [i for pos, i in enumerate(ne.inputs) if pos != r_pos]
+        part = max(g.vars) + 1 + len(new_vars)
+        new_vars.append((part, "float64"))
+        chain = Node(
+            "GemvChain",
+            {"scalar": ne.params["scalar"], "reduce": spec, "r_pos": r_pos, "w_out": w_out, "store_r": store_r},
+            list(n1.inputs) + e_ins,
+            ([r] if store_r else []) + list(ne.outputs) + [part],
+        )
+        finish = Node("GemvFinish", {}, [part, y2, a2, b2], list(n2.outputs))
+        replace[k1] = None
+        replace[ke] = chain
+        replace[k2] = finish
+        used.update((k1, ke, k2))
+    if not replace:
+        return g
+    from pytensor_amd.ir import Var
+
+    out = Graph(name=g.name)
+    out.vars = dict(g.vars)
+    for vid, dt in new_vars:
+        out.vars[vid] = Var(vid, dt, (None, None), "tensor", None, "gemv_chain_partials")
+    out.inputs = list(g.inputs)
+    out.outputs = list(g.outputs)
+    for k, n in enumerate(g.nodes):
+        if k in replace:
+            if replace[k] is not None:
+                out.nodes.append(replace[k])
+        else:
+            out.nodes.append(n)
+    return out
