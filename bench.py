@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="per-node dispatch instead of the frozen hipGraph plan")
+    ap.add_argument("--single-stream", action="store_true", help="frozen plan without the two-stream fork")
     args = ap.parse_args()
 
     from pytensor_amd import configs, ffi, replicas
@@ -93,7 +94,7 @@ def main():
     out = exe(*inputs)  # uploads the resident data; result is parity-gated below
     plan = None
     if not args.eager:
-        plan = exe.freeze(*inputs)
+        plan = exe.freeze(*inputs, multi_stream=not args.single_stream)
         for a, b in zip(out, plan(*inputs)):
             np.testing.assert_array_equal(a, b)
     call = plan if plan is not None else exe

@@ -58,6 +58,14 @@ int pthip_device_count(int* n);
 int pthip_device_name(char* buf, size_t buflen);
 const char* pthip_last_error(void);
 int pthip_synchronize(void);
+/* Multi-stream plans: the eager path uses stream 0 only.  A frozen plan may fork
+ * independent branches of the graph (e.g. the single-CU Cholesky/solve chain next to the
+ * HBM-streaming kernels) onto up to 4 streams; cross-stream dependencies become event
+ * edges of the captured hipGraph.  `select` makes stream i the target of every
+ * subsequent launch/copy; `wait(waiter, signaler)` orders waiter after everything
+ * enqueued so far on signaler. */
+int pthip_stream_select(int i);
+int pthip_stream_wait(int waiter, int signaler);
 /* raw hipStream_t of the context (for interop / event timing on the right stream) */
 void* pthip_stream(void);
 
@@ -80,6 +88,8 @@ int pthip_memset(void* dst, int byte, size_t bytes);
  * the same pointers.  Used to freeze a plan into a hipGraph. */
 int pthip_arena_begin(void** arena); /* *arena == NULL → create; else re-enter and rewind */
 int pthip_arena_end(void);
+/* blocks freed inside the arena are not reused before the next rewind (multi-stream plans) */
+int pthip_arena_set_no_reuse(void* arena, int no_reuse);
 int pthip_arena_destroy(void* arena);
 
 /* ---- hipGraph capture of the launch sequence of one Function call
@@ -88,6 +98,8 @@ int pthip_arena_destroy(void* arena);
 int pthip_capture_begin(void);
 int pthip_capture_end(void** graph_exec);
 int pthip_graph_launch(void* graph_exec);
+/* launch into stream `stream` (segmented plans: independent segments on different streams) */
+int pthip_graph_launch_on(void* graph_exec, int stream);
 int pthip_graph_destroy(void* graph_exec);
 
 /* ---- events (HIP events on the context stream) ---- */

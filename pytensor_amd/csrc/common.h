@@ -11,9 +11,13 @@
 
 namespace pthip {
 
+constexpr int kMaxStreams = 4;
+
 struct Context {
   int device = -1;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;               // CURRENT stream: every launch/copy goes here
+  hipStream_t streams[kMaxStreams] = {};      // streams[0] = origin (the eager path never leaves it)
+  int current = 0;
   int* status_dev = nullptr;  // device-side error flag
   bool capturing = false;
 };

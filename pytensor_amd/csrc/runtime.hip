@@ -52,6 +52,9 @@ struct Arena {
   std::multimap<size_t, void*> free_list;     // private free blocks
   std::unordered_map<void*, size_t> live;     // blocks handed out
   std::vector<Block> owned;                   // everything the arena owns
+  // no_reuse: a freed block is not handed out again before the next rewind.  Needed when a
+  // plan runs on several streams: stream order no longer serialises all users of a block.
+  bool no_reuse = false;
 };
 
 struct Pool {
@@ -123,7 +126,7 @@ static int pool_free(void* p) {
     Arena* a = ao->second;
     auto it = a->live.find(p);
     if (it == a->live.end()) return set_error("pool: double free of arena block %p", p);
-    a->free_list.emplace(it->second, p);
+    if (!a->no_reuse) a->free_list.emplace(it->second, p);
     a->live.erase(it);
     return 0;
   }
@@ -150,7 +153,11 @@ int pthip_init(int device) {
   if (n <= 0) return set_error("pthip_init: no HIP device visible");
   if (device < 0 || device >= n) return set_error("pthip_init: device %d out of range (%d visible)", device, n);
   PTHIP_CHECK(hipSetDevice(device));
-  if (!g_ctx.stream) PTHIP_CHECK(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+  if (!g_ctx.streams[0]) {
+    PTHIP_CHECK(hipStreamCreateWithFlags(&g_ctx.streams[0], hipStreamNonBlocking));
+    g_ctx.stream = g_ctx.streams[0];
+    g_ctx.current = 0;
+  }
   if (!g_ctx.status_dev) {
     PTHIP_CHECK(hipMalloc((void**)&g_ctx.status_dev, 256));
     PTHIP_CHECK(hipMemset(g_ctx.status_dev, 0, 256));
@@ -180,7 +187,32 @@ const char* pthip_last_error(void) { return g_err.c_str(); }
 
 int pthip_synchronize(void) {
   PTHIP_REQUIRE_INIT();
-  PTHIP_CHECK(hipStreamSynchronize(g_ctx.stream));
+  for (int i = 0; i < kMaxStreams; i++)
+    if (g_ctx.streams[i]) PTHIP_CHECK(hipStreamSynchronize(g_ctx.streams[i]));
+  return 0;
+}
+
+int pthip_stream_select(int i) {
+  PTHIP_REQUIRE_INIT();
+  if (i < 0 || i >= kMaxStreams) return set_error("pthip_stream_select: stream %d out of range", i);
+  if (!g_ctx.streams[i]) PTHIP_CHECK(hipStreamCreateWithFlags(&g_ctx.streams[i], hipStreamNonBlocking));
+  g_ctx.stream = g_ctx.streams[i];
+  g_ctx.current = i;
+  return 0;
+}
+
+int pthip_stream_wait(int waiter, int signaler) {
+  PTHIP_REQUIRE_INIT();
+  if (waiter < 0 || waiter >= kMaxStreams || signaler < 0 || signaler >= kMaxStreams)
+    return set_error("pthip_stream_wait: stream out of range");
+  if (waiter == signaler) return 0;
+  for (int i : {waiter, signaler})
+    if (!g_ctx.streams[i]) PTHIP_CHECK(hipStreamCreateWithFlags(&g_ctx.streams[i], hipStreamNonBlocking));
+  hipEvent_t ev;
+  PTHIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  PTHIP_CHECK(hipEventRecord(ev, g_ctx.streams[signaler]));
+  PTHIP_CHECK(hipStreamWaitEvent(g_ctx.streams[waiter], ev, 0));
+  PTHIP_CHECK(hipEventDestroy(ev));  // released once the recorded work completes / captured as an edge
   return 0;
 }
 
@@ -253,6 +285,13 @@ int pthip_memset(void* dst, int byte, size_t bytes) {
 }
 
 // ---- arena --------------------------------------------------------------------
+int pthip_arena_set_no_reuse(void* arena, int no_reuse) {
+  if (!arena) return set_error("pthip_arena_set_no_reuse: null arena");
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  ((Arena*)arena)->no_reuse = no_reuse != 0;
+  return 0;
+}
+
 int pthip_arena_begin(void** arena) {
   PTHIP_REQUIRE_INIT();
   std::lock_guard<std::mutex> lk(g_pool.mu);
@@ -297,7 +336,8 @@ int pthip_arena_destroy(void* arena) {
 int pthip_capture_begin(void) {
   PTHIP_REQUIRE_INIT();
   if (g_ctx.capturing) return set_error("pthip_capture_begin: already capturing");
-  PTHIP_CHECK(hipStreamBeginCapture(g_ctx.stream, hipStreamCaptureModeThreadLocal));
+  if (g_ctx.current != 0) return set_error("pthip_capture_begin: select stream 0 first");
+  PTHIP_CHECK(hipStreamBeginCapture(g_ctx.streams[0], hipStreamCaptureModeThreadLocal));
   g_ctx.capturing = true;
   return 0;
 }
@@ -306,7 +346,9 @@ int pthip_capture_end(void** graph_exec) {
   if (!g_ctx.capturing) return set_error("pthip_capture_end: not capturing");
   g_ctx.capturing = false;
   hipGraph_t graph = nullptr;
-  PTHIP_CHECK(hipStreamEndCapture(g_ctx.stream, &graph));
+  g_ctx.stream = g_ctx.streams[0];
+  g_ctx.current = 0;
+  PTHIP_CHECK(hipStreamEndCapture(g_ctx.streams[0], &graph));
   hipGraphExec_t exec = nullptr;
   hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
   (void)hipGraphDestroy(graph);
@@ -316,7 +358,15 @@ int pthip_capture_end(void** graph_exec) {
 }
 
 int pthip_graph_launch(void* graph_exec) {
-  PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, g_ctx.stream));
+  PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, g_ctx.streams[0]));
+  return 0;
+}
+
+int pthip_graph_launch_on(void* graph_exec, int stream) {
+  if (stream < 0 || stream >= kMaxStreams) return set_error("pthip_graph_launch_on: bad stream");
+  if (!g_ctx.streams[stream])
+    PTHIP_CHECK(hipStreamCreateWithFlags(&g_ctx.streams[stream], hipStreamNonBlocking));
+  PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, g_ctx.streams[stream]));
   return 0;
 }
 

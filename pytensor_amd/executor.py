@@ -103,6 +103,7 @@ class Env:
         self.graph = exe.graph  # graph whose node is currently running (inner graphs swap it)
         self.node_events = None  # set by HipExecutable.profile_nodes
         self.kernel_timer = None  # KernelTimer: brackets individual generated-kernel launches
+        self.scheduler = None  # StreamScheduler of a multi-stream frozen plan
 
     def to_device(self, v) -> DeviceArray:
         if isinstance(v, DeviceArray):
@@ -133,9 +134,12 @@ class HipExecutable:
         from pytensor_amd.fusion import fuse_elemwise_reduce, fuse_gemv_chain
 
         self.source_graph = graph
+        self.segments = None  # per-node segment ids for multi-stream plans (fusion.segment_graph)
         self.graph = fuse_elemwise_reduce(graph) if fuse else graph
         if fuse and fuse != "elemwise":
-            self.graph = fuse_gemv_chain(self.graph)
+            from pytensor_amd.fusion import segment_graph
+
+            self.graph, self.segments = segment_graph(fuse_gemv_chain(self.graph))
         self.resident = set(resident)
         self._handlers = dispatch.HANDLERS
         self._resident_cache = {}  # input position -> (key, DeviceArray)
@@ -229,6 +233,7 @@ class HipExecutable:
             vals[vid] = self._input(pos, vid, value, env)
         handlers = self._handlers
         evs = env.node_events if env.exe is self else None  # inner graphs are not itemised
+        sched = env.scheduler if env.exe is self else None  # multi-stream plans (plan.py)
         for k, node in enumerate(g.nodes):
             ins = []
             for i in node.inputs:
@@ -242,6 +247,8 @@ class HipExecutable:
             try:
                 if evs is not None:
                     ffi.check(env.lib.pthip_event_record(evs[2 * k]))
+                if sched is not None:
+                    sched.before_node(k, node)
                 outs = h(node, ins, env)
                 if evs is not None:
                     ffi.check(env.lib.pthip_event_record(evs[2 * k + 1]))
@@ -320,10 +327,10 @@ class HipExecutable:
         return [(k, self.graph.nodes[k].op, tot[k] / reps) for k in range(n)]
 
     # ------------------------------------------------------------------
-    def freeze(self, *inputs, fetch_outputs=True):
+    def freeze(self, *inputs, fetch_outputs=True, multi_stream=True):
         """Capture the launch sequence for this input signature into a hipGraph and
         return a :class:`FrozenPlan` (see ``pytensor_amd/plan.py``)."""
         from pytensor_amd.plan import FrozenPlan
 
         self._ensure_device()
-        return FrozenPlan(self, inputs, fetch_outputs=fetch_outputs)
+        return FrozenPlan(self, inputs, fetch_outputs=fetch_outputs, multi_stream=multi_stream)

@@ -47,6 +47,9 @@ SIGNATURES = {
     "pthip_last_error": (C.c_char_p, []),
     "pthip_synchronize": (_int, []),
     "pthip_stream": (_vp, []),
+    "pthip_stream_select": (_int, [_int]),
+    "pthip_stream_wait": (_int, [_int, _int]),
+    "pthip_arena_set_no_reuse": (_int, [_vp, _int]),
     "pthip_alloc": (_int, [_sz, C.POINTER(_vp)]),
     "pthip_free": (_int, [_vp]),
     "pthip_pool_stats": (_int, [C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
@@ -63,6 +66,7 @@ SIGNATURES = {
     "pthip_capture_begin": (_int, []),
     "pthip_capture_end": (_int, [C.POINTER(_vp)]),
     "pthip_graph_launch": (_int, [_vp]),
+    "pthip_graph_launch_on": (_int, [_vp, _int]),
     "pthip_graph_destroy": (_int, [_vp]),
     "pthip_event_create": (_int, [C.POINTER(_vp)]),
     "pthip_event_record": (_int, [_vp]),

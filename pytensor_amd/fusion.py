@@ -76,6 +76,98 @@ def fuse_elemwise_reduce(g: Graph) -> Graph:
     return out
 
 
+LATENCY_OPS = {"Cholesky", "SolveTriangular", "CholeskySolve", "Blockwise"}
+
+
+def stream_classes(g: Graph, staged_inputs=()):
+    """0 = HBM-streaming work, 1 = the single-CU dense-linear-algebra chain and the
+    scalar work hanging off it (see ``plan.StreamScheduler``)."""
+    cls = []
+    var_cls = {}
+    for n in g.nodes:
+        parents = [var_cls[v] for v in n.inputs if v in var_cls]
+        c = 1 if (n.op in LATENCY_OPS or (parents and all(p == 1 for p in parents))) else 0
+        cls.append(c)
+        for o in n.outputs:
+            var_cls[o] = c
+    return cls
+
+
+def schedule_latency_chain_first(g: Graph) -> Graph:
+    """Topological re-ordering that issues the latency-bound chain (class 1) as early as
+    its inputs allow, so that in a multi-stream plan it is enqueued — and starts — before
+    the long HBM-streaming kernels it overlaps with.  Pure re-ordering: same nodes."""
+    cls = stream_classes(g)
+    if not any(cls):
+        return g
+    produced_by = {}
+    for k, n in enumerate(g.nodes):
+        for o in n.outputs:
+            produced_by[o] = k
+    deps = [set(produced_by[v] for v in n.inputs if v in produced_by) for n in g.nodes]
+    done, order = set(), []
+    remaining = list(range(len(g.nodes)))
+    while remaining:
+        ready = [k for k in remaining if deps[k] <= done]
+        pick = next((k for k in ready if cls[k] == 1), ready[0])
+        order.append(pick)
+        done.add(pick)
+        remaining.remove(pick)
+    out = Graph(name=g.name)
+    out.vars, out.inputs, out.outputs = g.vars, list(g.inputs), list(g.outputs)
+    out.nodes = [g.nodes[k] for k in order]
+    return out
+
+
+def segment_graph(g: Graph):
+    """Split the node list into three consecutive segments for a multi-stream plan:
+
+    * ``A`` — the latency chain: class-1 nodes with no class-0 ancestor
+      (Cholesky → solves → the scalar work on their results);
+    * ``B`` — class-0 nodes with no class-1 ancestor (the HBM-streaming work);
+    * ``C`` — the rest (whatever combines the two).
+
+    A and B are mutually independent, so a frozen plan captures them as two hipGraphs and
+    launches them on two streams; C follows both.  Returns ``(reordered graph, seg)``
+    with ``seg[k] ∈ {0: A, 1: B, 2: C}``; ``seg`` is ``None`` when there is nothing to
+    overlap (ROCm 7.2 serialises the branches of a *single* captured graph, so the
+    overlap has to come from separate graphs on separate streams).
+    """
+    cls = stream_classes(g)
+    if not any(cls):
+        return g, None
+    produced_by = {}
+    for k, n in enumerate(g.nodes):
+        for o in n.outputs:
+            produced_by[o] = k
+    anc0 = [False] * len(g.nodes)  # has a class-0 ancestor
+    anc1 = [False] * len(g.nodes)  # has a class-1 ancestor
+    for k, n in enumerate(g.nodes):
+        for v in n.inputs:
+            p = produced_by.get(v)
+            if p is None:
+                continue
+            anc0[k] = anc0[k] or anc0[p] or cls[p] == 0
+            anc1[k] = anc1[k] or anc1[p] or cls[p] == 1
+    seg = []
+    for k in range(len(g.nodes)):
+        if cls[k] == 1 and not anc0[k]:
+            seg.append(0)
+        elif cls[k] == 0 and not anc1[k]:
+            seg.append(1)
+        else:
+            seg.append(2)
+    if 0 not in seg or 1 not in seg:
+        return g, None
+    order = [k for k in range(len(g.nodes)) if seg[k] == 0]
+    order += [k for k in range(len(g.nodes)) if seg[k] == 1]
+    order += [k for k in range(len(g.nodes)) if seg[k] == 2]
+    out = Graph(name=g.name)
+    out.vars, out.inputs, out.outputs = g.vars, list(g.inputs), list(g.outputs)
+    out.nodes = [g.nodes[k] for k in order]
+    return out, [seg[k] for k in order]
+
+
 # ---------------------------------------------------------------------------
 # Gemv(row) -> Elemwise -> Gemv(col) over the SAME matrix: read it once
 # ---------------------------------------------------------------------------

@@ -1,19 +1,27 @@
-"""``FrozenPlan`` — one ``Function`` call as one hipGraph launch.
+"""``FrozenPlan`` — one ``Function`` call as one (or three) hipGraph launches.
 
 The reference's fastest runtime is the CVM (pytensor/link/c/c_code/lazylinker_c.c:749
 ``CLazyLinker_call``): one native call per ``Function.__call__`` that walks
 pre-resolved node tables instead of dispatching from Python.  The MI355X-native
 analogue is a captured hipGraph: for a fixed input signature (shapes/dtypes, resident
 arrays) the launch sequence, every intermediate buffer and both PCIe staging copies are
-frozen once and replayed with a single ``hipGraphLaunch``.
+frozen once and replayed.
 
 How: (1) a warm-up run inside a private pool *arena* discovers every allocation;
 (2) the arena is rewound and the same sequence is run again under stream capture —
 allocations are now served from the arena's free lists (no ``hipMalloc`` while
-capturing); all non-resident inputs travel in ONE pinned staging block (one H2D
-node), all outputs are gathered by one ``pthip_pack`` launch into one block (one
-D2H node); (3) replays copy the small parameter arrays into the staging block,
-launch the graph, synchronise once and copy the outputs out.
+capturing); all non-resident inputs travel in ONE pinned staging block (one H2D), all
+outputs are gathered by one ``pthip_pack`` launch into one block (one D2H);
+(3) replays copy the small parameter arrays into the staging block, launch, synchronise
+once and copy the outputs out.
+
+**Segmented plans.**  ``fusion.segment_graph`` splits the nodes into A (the single-CU,
+latency-bound Cholesky/solve chain), B (the HBM-streaming work, independent of A) and
+C (what combines them).  ROCm 7.2 executes the branches of one captured graph one after
+the other (measured: profiles/r1f_*), so A, B and C are captured as three graphs and
+replayed as  ``H2D → [A on stream 1 ‖ B on stream 0] → C on stream 0``: the ≈0.25 ms
+latency chain hides under the streaming kernels.  Segmented plans run with the arena in
+no-reuse mode (stream order no longer serialises all users of a block).
 
 Data-dependent host reads (a ``ScalarFromTensor`` of a computed value used as a
 shape) cannot be frozen; ``freeze`` raises and the caller keeps the eager path.
@@ -63,8 +71,23 @@ class _PinnedBlock:
             self.ptr = 0
 
 
+class _SegmentSwitch:
+    """Scheduler hook: closes the running capture and opens the next one when the
+    executor crosses a segment boundary (A → B → C)."""
+
+    def __init__(self, plan, seg):
+        self.plan = plan
+        self.seg = seg
+        self.capturing = False
+
+    def before_node(self, k, node):
+        if self.capturing and k > 0 and self.seg[k] != self.seg[k - 1]:
+            self.plan._end_segment()
+            self.plan._begin_segment()
+
+
 class FrozenPlan:
-    def __init__(self, exe, inputs, fetch_outputs=True):
+    def __init__(self, exe, inputs, fetch_outputs=True, multi_stream=True):
         self.exe = exe
         self.fetch_outputs = fetch_outputs  # False: device-side timing only (no pack/D2H node)
         self.lib = ffi.lib()
@@ -72,7 +95,7 @@ class FrozenPlan:
         if len(inputs) != len(g.inputs):
             raise TypeError(f"expected {len(g.inputs)} inputs, got {len(inputs)}")
         self._arena = C.c_void_p()
-        self._graph_exec = C.c_void_p()
+        self._graphs = []  # captured hipGraphExec handles, in segment order
         self._staged = []  # input positions travelling through the staging block
         self._baked = {}  # position -> host value baked into the plan (int scalars)
         self._resident_keys = {}
@@ -94,6 +117,10 @@ class FrozenPlan:
                 specs.append((a.shape, a.dtype))
         self._in_block = _PinnedBlock(specs)
         self._in_view = {pos: k for k, pos in enumerate(self._staged)}
+        self._dev_in = Buffer(self._in_block.nbytes) if self._staged else None  # outside the arena
+        seg = exe.segments if multi_stream else None
+        self.segmented = seg is not None and len(set(seg)) == 3 and seg[0] == 0
+        self._switch = _SegmentSwitch(self, seg) if self.segmented else None
         self._out_block = None
         self._out_meta = None
         self._keep = []
@@ -104,84 +131,127 @@ class FrozenPlan:
             raise
 
     # ------------------------------------------------------------------
+    def _begin_segment(self):
+        ffi.check(self.lib.pthip_capture_begin())
+        self.exe._capturing = True
+        if self._switch is not None:
+            self._switch.capturing = True
+
+    def _end_segment(self):
+        self.exe._capturing = False
+        if self._switch is not None:
+            self._switch.capturing = False
+        ge = C.c_void_p()
+        ffi.check(self.lib.pthip_capture_end(C.byref(ge)))
+        self._graphs.append(ge)
+
+    def _upload_params(self):
+        if self._dev_in is not None:
+            ffi.check(self.lib.pthip_h2d(self._dev_in.ptr, self._in_block.ptr, self._in_block.nbytes))
+
     def _run_once(self, inputs, capture):
         exe, lib = self.exe, self.lib
         env = Env(exe)
         blk = self._in_block
-        dev_in = None
-        if self._staged:
-            dev_in = Buffer(blk.nbytes)
-            ffi.check(lib.pthip_h2d(dev_in.ptr, blk.ptr, blk.nbytes))
+        # the parameter H2D is a plain async copy issued before the graphs (both A and B
+        # read the parameters; it is not part of any captured segment)
+        if not capture:
+            self._upload_params()
         dev_inputs = []
         for pos, value in enumerate(inputs):
             k = self._in_view.get(pos)
             if k is not None:
                 v = blk.views[k]
-                dev_inputs.append(DeviceArray(dev_in, blk.offsets[k], v.shape, contiguous_strides(v.shape), v.dtype))
+                dev_inputs.append(DeviceArray(self._dev_in, blk.offsets[k], v.shape, contiguous_strides(v.shape), v.dtype))
             elif pos in self._baked:
                 dev_inputs.append(HostValue(self._baked[pos]))
             else:
                 dev_inputs.append(exe._resident_cache[pos][1])
-        outs, env = exe.run_device(dev_inputs, env)
-        if self._out_block is None:
-            specs = []
-            self._out_meta = []
-            for o in outs:
-                if isinstance(o, HostValue):
-                    self._out_meta.append(np.array(o.a, copy=True))
-                else:
-                    self._out_meta.append(None)
-                    specs.append((o.shape, o.dtype))
-            self._out_block = _PinnedBlock(specs)
-        ob = self._out_block
-        dev_outs = [o.contiguous() for o in outs if not isinstance(o, HostValue)]
-        if dev_outs and not self.fetch_outputs and capture:
-            self._keep += [dev_outs]
-        elif dev_outs:
-            dev_out = Buffer(ob.nbytes)
-            # gather every output into one block: chunks of <= 16 buffers per launch
-            for c0 in range(0, len(dev_outs), 16):
-                chunk = dev_outs[c0 : c0 + 16]
-                n = len(chunk)
-                srcs = (C.c_void_p * n)(*[o.ptr for o in chunk])
-                nb = (C.c_int64 * n)(*[o.nbytes for o in chunk])
-                offs = (C.c_int64 * n)(*ob.offsets[c0 : c0 + n])
-                ffi.check(lib.pthip_pack(n, srcs, nb, offs, dev_out.ptr))
-            ffi.check(lib.pthip_d2h(ob.ptr, dev_out.ptr, ob.nbytes))
-            if capture:
-                self._keep += [dev_out, dev_outs]
         if capture:
-            self._keep += [dev_in, env.keepalive]
+            env.scheduler = self._switch
+            self._begin_segment()
+        ok = False
+        try:
+            outs, env = exe.run_device(dev_inputs, env)
+            if self._out_block is None:
+                specs = []
+                self._out_meta = []
+                for o in outs:
+                    if isinstance(o, HostValue):
+                        self._out_meta.append(np.array(o.a, copy=True))
+                    else:
+                        self._out_meta.append(None)
+                        specs.append((o.shape, o.dtype))
+                self._out_block = _PinnedBlock(specs)
+            ob = self._out_block
+            dev_outs = [o.contiguous() for o in outs if not isinstance(o, HostValue)]
+            if dev_outs and self.fetch_outputs:
+                dev_out = Buffer(ob.nbytes)
+                # gather every output into one block: chunks of <= 16 buffers per launch
+                for c0 in range(0, len(dev_outs), 16):
+                    chunk = dev_outs[c0 : c0 + 16]
+                    n = len(chunk)
+                    srcs = (C.c_void_p * n)(*[o.ptr for o in chunk])
+                    nb = (C.c_int64 * n)(*[o.nbytes for o in chunk])
+                    offs = (C.c_int64 * n)(*ob.offsets[c0 : c0 + n])
+                    ffi.check(lib.pthip_pack(n, srcs, nb, offs, dev_out.ptr))
+                ffi.check(lib.pthip_d2h(ob.ptr, dev_out.ptr, ob.nbytes))
+                if capture:
+                    self._keep.append(dev_out)
+            if capture:
+                self._keep += [dev_outs, env.keepalive]
+            ok = True
+        finally:
+            if capture:
+                if ok:
+                    self._end_segment()
+                else:  # abort the capture cleanly
+                    self.exe._capturing = False
+                    ge = C.c_void_p()
+                    lib.pthip_capture_end(C.byref(ge))
+                    if ge:
+                        lib.pthip_graph_destroy(ge)
         return outs
 
     def _build(self, inputs):
         lib = self.lib
         for pos, k in self._in_view.items():
             np.copyto(self._in_block.views[k], np.asarray(inputs[pos]))
-        # (1) warm-up inside the arena
+        # (1) warm-up inside the arena (single stream; discovers every allocation)
         ffi.check(lib.pthip_arena_begin(C.byref(self._arena)))
+        if self.segmented:
+            ffi.check(lib.pthip_arena_set_no_reuse(self._arena, 1))
         try:
             outs = self._run_once(inputs, capture=False)
             del outs
             ffi.check(lib.pthip_synchronize())
         finally:
             ffi.check(lib.pthip_arena_end())
-        # (2) rewind + capture
+        # (2) rewind + capture (one graph, or one per segment)
         ffi.check(lib.pthip_arena_begin(C.byref(self._arena)))
         try:
-            ffi.check(lib.pthip_capture_begin())
-            self.exe._capturing = True
-            try:
-                outs = self._run_once(inputs, capture=True)
-                del outs
-            finally:
-                self.exe._capturing = False
-                rc = lib.pthip_capture_end(C.byref(self._graph_exec))
-            ffi.check(rc)
+            outs = self._run_once(inputs, capture=True)
+            del outs
         finally:
             ffi.check(lib.pthip_arena_end())
+        if self.segmented and len(self._graphs) != 3:
+            raise ffi.HipError(f"segmented plan captured {len(self._graphs)} graphs instead of 3")
 
     # ------------------------------------------------------------------
+    def launch_async(self):
+        """Enqueue one replay (parameters already in the staging block); no host sync."""
+        lib = self.lib
+        self._upload_params()
+        if self.segmented:
+            ga, gb, gc = self._graphs
+            ffi.check(lib.pthip_stream_wait(1, 0))  # A needs the parameters
+            ffi.check(lib.pthip_graph_launch_on(ga, 1))
+            ffi.check(lib.pthip_graph_launch_on(gb, 0))
+            ffi.check(lib.pthip_stream_wait(0, 1))  # C needs A and B
+            ffi.check(lib.pthip_graph_launch_on(gc, 0))
+        else:
+            ffi.check(lib.pthip_graph_launch_on(self._graphs[0], 0))
+
     def __call__(self, *inputs):
         lib = self.lib
         if len(inputs) != len(self._sig):
@@ -200,7 +270,7 @@ class FrozenPlan:
                     raise ValueError(f"frozen plan: scalar input {pos} is baked into the plan and changed")
             elif self._resident_keys[pos] != id(value):
                 raise ValueError(f"frozen plan: resident input {pos} was replaced; re-freeze")
-        ffi.check(lib.pthip_graph_launch(self._graph_exec))
+        self.launch_async()
         ffi.check(lib.pthip_synchronize())
         res = []
         k = 0
@@ -212,20 +282,18 @@ class FrozenPlan:
                 k += 1
         return tuple(res)
 
-    def launch_async(self):
-        """Replay without touching inputs/outputs (for timing the device side alone)."""
-        ffi.check(self.lib.pthip_graph_launch(self._graph_exec))
-
     def close(self):
         lib = self.lib
         try:
-            if self._graph_exec:
-                lib.pthip_graph_destroy(self._graph_exec)
-                self._graph_exec = C.c_void_p()
+            lib.pthip_synchronize()
+            for ge in self._graphs:
+                lib.pthip_graph_destroy(ge)
+            self._graphs = []
             self._keep.clear()
             if self._arena:
                 lib.pthip_arena_destroy(self._arena)
                 self._arena = C.c_void_p()
+            self._dev_in = None
             for blk in (self._in_block, self._out_block):
                 if blk is not None:
                     blk.free()
