@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--rows", dest="n", type=int, default=1_000_000, help="observations N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="per-node dispatch instead of the frozen hipGraph plan")
     ap.add_argument("--single-stream", action="store_true", help="frozen plan without the two-stream fork")
@@ -82,14 +82,15 @@ def main():
     from pytensor_amd.executor import HipExecutable
 
     info = replicas.rank_info()
+    lib = ffi.lib()  # load the HIP runtime of /opt/rocm before torch brings its own copy
+    dev = replicas.device_for_rank(info, ffi.device_count())
+    ffi.init(dev)
     dist = replicas.init_process_group(info)
-    ffi.init(info.local_rank)
-    lib = ffi.lib()
     graph, names = _load_graph("c4_hier")
     vals = configs.c4_inputs(N=args.n, chain=info.rank)  # same data, one parameter draw per rank
     inputs = [vals[n] for n in names]
     resident = [k for k, n in enumerate(names) if n in configs.C4_DATA]
-    exe = HipExecutable(graph, resident=resident, device=info.local_rank)
+    exe = HipExecutable(graph, resident=resident, device=dev)
 
     out = exe(*inputs)  # uploads the resident data; result is parity-gated below
     plan = None

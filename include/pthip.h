@@ -100,6 +100,12 @@ int pthip_capture_end(void** graph_exec);
 int pthip_graph_launch(void* graph_exec);
 /* launch into stream `stream` (segmented plans: independent segments on different streams) */
 int pthip_graph_launch_on(void* graph_exec, int stream);
+/* One native call per Function.__call__ (what CLazyLinker_call is to the CVM,
+ * lazylinker_c.c:749): upload the staged parameters, replay the captured segment(s)
+ * — ga (latency chain, stream 1) may be NULL for an unsegmented plan — and, if `sync`,
+ * wait for the result. */
+int pthip_plan_replay(void* ga, void* gb, void* gc, void* dev_in, const void* host_in,
+                      size_t in_bytes, int sync);
 int pthip_graph_destroy(void* graph_exec);
 
 /* ---- events (HIP events on the context stream) ---- */

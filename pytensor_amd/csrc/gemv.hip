@@ -174,18 +174,19 @@ __global__ __launch_bounds__(BLOCK) void gemv_col_kernel(
 }
 
 // out[i] = beta*y[i] + alpha * sum_p part[p][i]   (fixed order → deterministic)
-// Block = 16 outputs x 16 slices of the partial rows: 128-byte coalesced reads per slice,
-// slices combined through LDS in slice order.
+// Block = 4 outputs x 64 slices of the partial rows (M/4 workgroups: with M = 128 and 2048
+// partial rows every thread sums 32 values), slices combined through LDS in slice order.
 template <class T>
 __global__ __launch_bounds__(BLOCK) void gemv_finish_kernel(T* __restrict__ out,
                                                            const T* __restrict__ part,
                                                            const T* __restrict__ y, long long M,
                                                            long long nparts, long long sy, T alpha,
                                                            T beta) {
-  __shared__ T red[16][17];
-  const int oi = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const long long i = (long long)blockIdx.x * 16 + oi;
-  const long long per = (nparts + 15) / 16;
+  constexpr int NO = 4, NS = BLOCK / NO;
+  __shared__ T red[NS][NO + 1];
+  const int oi = threadIdx.x & (NO - 1), sl = threadIdx.x / NO;
+  const long long i = (long long)blockIdx.x * NO + oi;
+  const long long per = (nparts + NS - 1) / NS;
   long long p0 = sl * per, p1 = p0 + per;
   if (p1 > nparts) p1 = nparts;
   T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
@@ -203,8 +204,8 @@ __global__ __launch_bounds__(BLOCK) void gemv_finish_kernel(T* __restrict__ out,
   __syncthreads();
   if (sl == 0 && i < M) {
     T v = red[0][oi];
-#pragma unroll
-    for (int k = 1; k < 16; k++) v += red[k][oi];
+#pragma unroll 8
+    for (int k = 1; k < NS; k++) v += red[k][oi];
     T res = alpha * v;
     if (beta != T(0)) res += beta * y[i * sy];
     out[i] = res;
@@ -325,7 +326,7 @@ int gemv_typed(long long M, long long N, double alpha_d, const void* Av, long lo
                          dim3(BLOCK), 0, st, part, A, x, M, N, sA1, sx, p.chunk);
     int r = pthip::post_launch("gemv_col");
     if (r) return r;
-    hipLaunchKernelGGL((gemv_finish_kernel<T>), dim3((unsigned)((M + 15) / 16)),
+    hipLaunchKernelGGL((gemv_finish_kernel<T>), dim3((unsigned)((M + 3) / 4)),
                        dim3(BLOCK), 0, st, out, part, y, M, nparts, sy, alpha, beta);
     return pthip::post_launch("gemv_finish");
   }
@@ -369,11 +370,11 @@ int pthip_gemv_finish(int dtype, int64_t M, int64_t nparts, const void* part, do
   hipStream_t st = pthip::ctx().stream;
   if (M == 0) return 0;
   if (dtype == PTHIP_F64)
-    hipLaunchKernelGGL((gemv_finish_kernel<double>), dim3((unsigned)((M + 15) / 16)), dim3(BLOCK), 0,
+    hipLaunchKernelGGL((gemv_finish_kernel<double>), dim3((unsigned)((M + 3) / 4)), dim3(BLOCK), 0,
                        st, (double*)out, (const double*)part, (const double*)y, (long long)M,
                        (long long)nparts, (long long)sy, alpha, beta);
   else if (dtype == PTHIP_F32)
-    hipLaunchKernelGGL((gemv_finish_kernel<float>), dim3((unsigned)((M + 15) / 16)), dim3(BLOCK), 0,
+    hipLaunchKernelGGL((gemv_finish_kernel<float>), dim3((unsigned)((M + 3) / 4)), dim3(BLOCK), 0,
                        st, (float*)out, (const float*)part, (const float*)y, (long long)M,
                        (long long)nparts, (long long)sy, (float)alpha, (float)beta);
   else

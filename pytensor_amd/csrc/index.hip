@@ -135,7 +135,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_add_scan_kernel(
   const int bin = threadIdx.x & (nb_pad - 1), slice = threadIdx.x / nb_pad;
   const int jb = (int)(bin / inner), cb = (int)(bin % inner);
   const int per_slice = SC_CHUNK / parts;
-  T acc = T(0);
+  T acc = T(0), acc1 = T(0), acc2 = T(0), acc3 = T(0);
   for (long long base = i0; base < i1; base += SC_CHUNK) {
     const int m = (int)((i1 - base) < SC_CHUNK ? (i1 - base) : SC_CHUNK);
     __syncthreads();
@@ -154,7 +154,27 @@ __global__ __launch_bounds__(BLOCK) void scatter_add_scan_kernel(
     int k1 = k0 + per_slice;
     if (k1 > m) k1 = m;
     if (inner == 1) {
-      for (int k = k0; k < k1; k++) {
+      // 8 staged entries per step: the LDS reads (wave-uniform addresses -> broadcast) are
+      // issued together, so their latency is paid once per 8 entries instead of per entry;
+      // the adds stay in index order (acc is a single in-order chain: bit-reproducible).
+      int k = k0;
+      for (; k + 7 < k1; k += 8) {
+        int id[8];
+        T v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          id[u] = s_idx[k + u];
+          v[u] = s_y[k + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u += 4) {  // four fixed interleaved chains (deterministic order)
+          acc += (id[u] == jb) ? v[u] : T(0);
+          acc1 += (id[u + 1] == jb) ? v[u + 1] : T(0);
+          acc2 += (id[u + 2] == jb) ? v[u + 2] : T(0);
+          acc3 += (id[u + 3] == jb) ? v[u + 3] : T(0);
+        }
+      }
+      for (; k < k1; k++) {
         const T v = s_y[k];
         acc += (s_idx[k] == jb) ? v : T(0);
       }
@@ -163,7 +183,8 @@ __global__ __launch_bounds__(BLOCK) void scatter_add_scan_kernel(
         if (s_idx[k] == jb) acc += y[(base + k) * ys0 + cb];
     }
   }
-  if (bin < n_bins) part[((long long)blockIdx.x * parts + slice) * n_bins + bin] = acc;
+  if (bin < n_bins)
+    part[((long long)blockIdx.x * parts + slice) * n_bins + bin] = (acc + acc1) + (acc2 + acc3);
 }
 
 // out[b] += sum_k part[k][b] in k order: 16 bins x 16 slices per block, combined in LDS

@@ -370,6 +370,38 @@ int pthip_graph_launch_on(void* graph_exec, int stream) {
   return 0;
 }
 
+// One native call per Function call (the CVM analogue): parameter upload, the captured
+// segments on their streams, and the single synchronisation of the call.
+//   segmented (ga, gb, gc != NULL): H2D -> [gb on stream 0 || ga on stream 1] -> gc on stream 0
+//   single    (only gb != NULL)   : H2D -> gb on stream 0
+// The streaming segment gb is enqueued first: it is the critical path.
+int pthip_plan_replay(void* ga, void* gb, void* gc, void* dev_in, const void* host_in,
+                      size_t in_bytes, int sync) {
+  PTHIP_REQUIRE_INIT();
+  static hipEvent_t ev_in = nullptr, ev_a = nullptr;
+  hipStream_t s0 = g_ctx.streams[0];
+  if (in_bytes) PTHIP_CHECK(hipMemcpyAsync(dev_in, host_in, in_bytes, hipMemcpyHostToDevice, s0));
+  if (ga && gc) {
+    if (!g_ctx.streams[1]) PTHIP_CHECK(hipStreamCreateWithFlags(&g_ctx.streams[1], hipStreamNonBlocking));
+    hipStream_t s1 = g_ctx.streams[1];
+    if (!ev_in) {
+      PTHIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+      PTHIP_CHECK(hipEventCreateWithFlags(&ev_a, hipEventDisableTiming));
+    }
+    PTHIP_CHECK(hipEventRecord(ev_in, s0));
+    PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)gb, s0));
+    PTHIP_CHECK(hipStreamWaitEvent(s1, ev_in, 0));
+    PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)ga, s1));
+    PTHIP_CHECK(hipEventRecord(ev_a, s1));
+    PTHIP_CHECK(hipStreamWaitEvent(s0, ev_a, 0));
+    PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)gc, s0));
+  } else {
+    PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)gb, s0));
+  }
+  if (sync) PTHIP_CHECK(hipStreamSynchronize(s0));
+  return 0;
+}
+
 int pthip_graph_destroy(void* graph_exec) {
   if (graph_exec) PTHIP_CHECK(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
   return 0;

@@ -61,10 +61,13 @@ def scan(node, inputs, env):
     taps = [list(t) for t in info["mit_sot_in_slices"]] + [list(t) for t in info["sit_sot_in_slices"]]
     n_rec = len(taps)
     rec_bufs = []
-    for b in inputs[k : k + n_rec]:
+    for j, b in enumerate(inputs[k : k + n_rec]):
         b = env.to_device(b)
-        own = DeviceArray.empty(b.shape, b.dtype)  # Scan must not mutate its inputs
-        copy_into(own, b)
+        if (k + j) in env.donated and b.is_contiguous() and b.offset == 0:
+            own = b  # donated by the executor: fresh buffer, this Scan is its only consumer
+        else:
+            own = DeviceArray.empty(b.shape, b.dtype)  # Scan must not mutate its inputs
+            copy_into(own, b)
         rec_bufs.append(own)
     k += n_rec
     untraced = list(inputs[k : k + info["n_untraced_sit_sot"]])

@@ -71,6 +71,16 @@ def subtensor(node, inputs, env):
     return [basic_view(x, index)]
 
 
+def _own_copy(env, x: DeviceArray, pos: int) -> DeviceArray:
+    """A buffer this node may overwrite: ``x`` itself when the executor donated it
+    (fresh, single consumer — executor._compute_donations), else a copy."""
+    if pos in env.donated and x.is_contiguous() and x.offset == 0:
+        return x
+    out = DeviceArray.empty(x.shape, x.dtype)
+    copy_into(out, x)
+    return out
+
+
 def _add_into(env, view: DeviceArray, y: DeviceArray):
     """view[...] += broadcast(y) through a fused add + strided write-back."""
     from pytensor_amd.dispatch.elemwise import launch_elemwise
@@ -96,8 +106,7 @@ def inc_subtensor(node, inputs, env):
     x, y, *idx = inputs
     x, y = env.to_device(x), env.to_device(y)
     index = _resolve(node.params["idx_list"], idx, env)
-    out = DeviceArray.empty(x.shape, x.dtype)
-    copy_into(out, x)
+    out = _own_copy(env, x, 0)
     view = basic_view(out, index)
     if y.ndim > view.ndim:
         raise ValueError("IncSubtensor: value has more dimensions than the indexed region")
@@ -190,8 +199,7 @@ def advanced_inc_subtensor(node, inputs, env):
     iv = _index_on_device(env, iv)
     if iv.ndim != 1:
         raise NotImplementedError("hip linker: AdvancedIncSubtensor with a multi-dimensional index")
-    out = DeviceArray.empty(x.shape, x.dtype)
-    copy_into(out, x)
+    out = _own_copy(env, x, 0)
     inner_shape = x.shape[1:]
     inner = int(np.prod(inner_shape)) if inner_shape else 1
     n_idx = iv.size

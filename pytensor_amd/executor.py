@@ -104,6 +104,7 @@ class Env:
         self.node_events = None  # set by HipExecutable.profile_nodes
         self.kernel_timer = None  # KernelTimer: brackets individual generated-kernel launches
         self.scheduler = None  # StreamScheduler of a multi-stream frozen plan
+        self.donated = frozenset()  # input positions of the running node that may be overwritten
 
     def to_device(self, v) -> DeviceArray:
         if isinstance(v, DeviceArray):
@@ -148,6 +149,7 @@ class HipExecutable:
         self._capturing = False
         self._plans = {}
         self._last_use = self._compute_last_use()
+        self._donations = self._compute_donations()
         # fail loudly and early if the library / device is unusable
         ffi.lib()
 
@@ -163,6 +165,35 @@ class HipExecutable:
             if vid not in keep and self.graph.vars[vid].const is None:
                 free_after[k].append(vid)
         return free_after
+
+    # ops whose outputs are freshly allocated, exclusively owned buffers (never views)
+    _FRESH_OPS = frozenset(
+        ["Alloc", "AllocEmpty", "Elemwise", "ElemwiseReduce", "GemvChain", "AdvancedSubtensor", "Gemv", "Gemm", "Dot22",
+         "Dot22Scalar", "BatchedDot", "Ger", "Join", "DeepCopyOp", "IncSubtensor", "AdvancedIncSubtensor",
+         "Cholesky", "SolveTriangular", "CholeskySolve", "Blockwise", "GemvFinish"]
+    )
+
+    def _compute_donations(self):
+        """Per node: input positions whose buffer the node may overwrite in place — the
+        value is produced by a fresh-buffer op, this node is its only consumer and it is not
+        a graph output.  The functional replacement for the reference's ``inplace`` rewrites
+        (``destroy_map``), decided on the lowered graph instead of by graph rewriting."""
+        g = self.graph
+        producer, consumers = {}, {}
+        for k, n in enumerate(g.nodes):
+            for o in n.outputs:
+                producer[o] = n.op
+            for i in n.inputs:
+                consumers[i] = consumers.get(i, 0) + 1
+        outs = set(g.outputs)
+        res = []
+        for n in g.nodes:
+            d = set()
+            for pos, v in enumerate(n.inputs):
+                if producer.get(v) in self._FRESH_OPS and consumers.get(v) == 1 and v not in outs:
+                    d.add(pos)
+            res.append(d)
+        return res
 
     def _ensure_device(self):
         if ffi.device_count() <= 0:
@@ -249,6 +280,7 @@ class HipExecutable:
                     ffi.check(env.lib.pthip_event_record(evs[2 * k]))
                 if sched is not None:
                     sched.before_node(k, node)
+                env.donated = self._donations[k]
                 outs = h(node, ins, env)
                 if evs is not None:
                     ffi.check(env.lib.pthip_event_record(evs[2 * k + 1]))

@@ -67,6 +67,7 @@ SIGNATURES = {
     "pthip_capture_end": (_int, [C.POINTER(_vp)]),
     "pthip_graph_launch": (_int, [_vp]),
     "pthip_graph_launch_on": (_int, [_vp, _int]),
+    "pthip_plan_replay": (_int, [_vp, _vp, _vp, _vp, _vp, _sz, _int]),
     "pthip_graph_destroy": (_int, [_vp]),
     "pthip_event_create": (_int, [C.POINTER(_vp)]),
     "pthip_event_record": (_int, [_vp]),

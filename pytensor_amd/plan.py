@@ -238,40 +238,42 @@ class FrozenPlan:
             raise ffi.HipError(f"segmented plan captured {len(self._graphs)} graphs instead of 3")
 
     # ------------------------------------------------------------------
-    def launch_async(self):
-        """Enqueue one replay (parameters already in the staging block); no host sync."""
-        lib = self.lib
-        self._upload_params()
+    def _replay(self, sync):
         if self.segmented:
             ga, gb, gc = self._graphs
-            ffi.check(lib.pthip_stream_wait(1, 0))  # A needs the parameters
-            ffi.check(lib.pthip_graph_launch_on(ga, 1))
-            ffi.check(lib.pthip_graph_launch_on(gb, 0))
-            ffi.check(lib.pthip_stream_wait(0, 1))  # C needs A and B
-            ffi.check(lib.pthip_graph_launch_on(gc, 0))
         else:
-            ffi.check(lib.pthip_graph_launch_on(self._graphs[0], 0))
+            ga, gb, gc = None, self._graphs[0], None
+        nb = self._in_block.nbytes if self._dev_in is not None else 0
+        rc = self.lib.pthip_plan_replay(
+            ga, gb, gc, self._dev_in.ptr if nb else None, self._in_block.ptr if nb else None, nb, int(sync)
+        )
+        if rc:
+            ffi.check(rc)
+
+    def launch_async(self):
+        """Enqueue one replay (parameters already in the staging block); no host sync."""
+        self._replay(False)
 
     def __call__(self, *inputs):
         lib = self.lib
         if len(inputs) != len(self._sig):
             raise TypeError(f"expected {len(self._sig)} inputs, got {len(inputs)}")
         views = self._in_block.views
-        for pos, value in enumerate(inputs):
-            k = self._in_view.get(pos)
-            if k is not None:
-                a = np.asarray(value)
-                v = views[k]
+        for pos, k in self._in_view.items():
+            v = views[k]
+            a = inputs[pos]
+            if getattr(a, "shape", None) != v.shape or getattr(a, "dtype", None) != v.dtype:
+                a = np.asarray(a)
                 if a.shape != v.shape or a.dtype != v.dtype:
                     raise TypeError(f"frozen plan: input {pos} changed signature {self._sig[pos]} -> {(a.shape, str(a.dtype))}")
-                np.copyto(v, a)
-            elif pos in self._baked:
-                if not np.array_equal(np.asarray(value), self._baked[pos]):
-                    raise ValueError(f"frozen plan: scalar input {pos} is baked into the plan and changed")
-            elif self._resident_keys[pos] != id(value):
+            v[...] = a
+        for pos, key in self._resident_keys.items():
+            if key != id(inputs[pos]):
                 raise ValueError(f"frozen plan: resident input {pos} was replaced; re-freeze")
-        self.launch_async()
-        ffi.check(lib.pthip_synchronize())
+        for pos, b in self._baked.items():
+            if not np.array_equal(np.asarray(inputs[pos]), b):
+                raise ValueError(f"frozen plan: scalar input {pos} is baked into the plan and changed")
+        self._replay(True)  # one native call: H2D, graphs, stream synchronisation
         res = []
         k = 0
         for meta in self._out_meta:

@@ -28,6 +28,12 @@ def rank_info() -> RankInfo:
     )
 
 
+def device_for_rank(info: RankInfo, n_devices: int) -> int:
+    """LOCAL_RANK → device index (one process per GPU; wraps only when ranks outnumber
+    devices, which happens in the single-GPU CI test of the multi-rank path)."""
+    return info.local_rank % max(n_devices, 1)
+
+
 def chains_for_rank(n_chains: int, info: RankInfo):
     """Round-robin assignment chain i → rank i % world (chain i → GPU i mod 8)."""
     return [c for c in range(n_chains) if c % info.world == info.rank]
@@ -41,7 +47,7 @@ def init_process_group(info: RankInfo, backend: str | None = None):
     import torch.distributed as dist
 
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("PTHIP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(info.local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", info.local_rank))

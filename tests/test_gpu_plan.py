@@ -62,3 +62,43 @@ def test_plan_new_parameters_same_signature(hip):
         for k, (a, b) in enumerate(zip(got, ref)):
             assert_parity(a, b, 1e-12, f"chain {chain} out{k}")
     plan.close()
+
+
+def test_bench_multi_rank_flow_on_one_gpu(hip, tmp_path):
+    """The N>1 launch contract (torch.distributed.run, barrier, max-over-ranks) end to end,
+    with two ranks sharing GPU 0 over gloo (RCCL refuses two ranks on one device)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PTHIP_DIST_BACKEND="gloo")
+    cmd = [
+        sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+        "--master-addr", "127.0.0.1", "--master-port", "29581",
+        os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--rows", "20000",
+    ]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
+
+
+def test_coexists_with_torch_hip_runtime(hip):
+    """bench.py's multi-rank path imports torch (which bundles its own libamdhip64):
+    our library must keep working next to it."""
+    import torch
+
+    from pytensor_amd.executor import HipExecutable
+
+    g, ins, cvm, py, meta = load_case("c1_gauss")
+    a = HipExecutable(g)(*ins)
+    if torch.cuda.is_available():
+        t = torch.ones(1024, device="cuda").sum().item()
+        assert t == 1024.0
+    b = HipExecutable(g)(*ins)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
