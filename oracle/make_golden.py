@@ -405,6 +405,100 @@ def scan_taps():
     }
 
 
+@case("edge_empty")
+def edge_empty():
+    # empty dims: tests/tensor/test_elemwise.py:446-462 (TestCAReduce), test_cholesky.py empty case
+    x = pt.dmatrix("x")
+    v = pt.dvector("v")
+    A = pt.dmatrix("A")
+    outs = [
+        pt.exp(x) + 1.0,
+        x.sum(),
+        x.sum(axis=0),
+        x.sum(axis=1),
+        x.prod(),
+        pt.exp(v).sum(),
+        pt.dot(A, v),
+        pt.dot(x.T, x),
+        cholesky(pt.dot(x.T, x)[:0, :0]),
+    ]
+    return [x, v, A], outs, {"x": np.zeros((0, 5)), "v": np.zeros((0,)), "A": np.zeros((4, 0))}
+
+
+@case("edge_nan_reduce")
+def edge_nan_reduce():
+    # NaN handling of max/min reductions: tests/tensor/test_elemwise.py:611,677
+    rng = np.random.default_rng(30)
+    x = pt.dmatrix("x")
+    xv = rng.normal(size=(6, 70))
+    xv[1, 3] = np.nan
+    xv[4, 69] = np.inf
+    xv[5, 0] = -np.inf
+    return [x], [x.max(axis=1), x.min(axis=0), x.max(), x.min(), x.sum(axis=1), pt.isnan(x).any(axis=1), pt.maximum(x, 0.5), pt.switch(pt.isnan(x), 0.0, x).sum()], {"x": xv}
+
+
+@case("edge_noncontig")
+def edge_noncontig():
+    # non-contiguous operands: tests/tensor/test_blas.py:344 (TestGemm non-contiguous),
+    # TestBlasStrides 1943-2327, test_elemwise.py TestBroadcast with transposes
+    rng = np.random.default_rng(31)
+    A = pt.dmatrix("A")
+    B = pt.dmatrix("B")
+    v = pt.dvector("v")
+    outs = [
+        pt.exp(A.T) + B[::2, ::-1][: A.shape[1], : A.shape[0]],
+        A[::2].sum(axis=0),
+        A[:, ::3].sum(axis=1),
+        A.T[1:].sum(),
+        pt.dot(A[::2], B[:, ::2].T[: A.shape[1]]),
+        pt.dot(A.T, A[:, ::-1]),
+        pt.dot(A[::-1], v[::2]),
+        pt.dot(A.T[:, ::2], v[1::4][: (A.shape[0] + 1) // 2]),
+        (A[1:, 1:] * B[:-1, :-1][: A.shape[0] - 1, : A.shape[1] - 1]).max(axis=0),
+    ]
+    return [A, B, v], outs, {"A": rng.normal(size=(10, 14)), "B": rng.normal(size=(28, 30)), "v": rng.normal(size=28)}
+
+
+@case("edge_odd_sizes")
+def edge_odd_sizes():
+    # sizes that are not multiples of the 16-byte vector width / wave / tile sizes
+    rng = np.random.default_rng(32)
+    x = pt.dvector("x")
+    y = pt.fvector("y")
+    A = pt.dmatrix("A")
+    F = pt.fmatrix("F")
+    outs = [
+        pt.tanh(x[1:]) * x[:-1],
+        (x * 2.0).sum(),
+        pt.exp(y)[1:].sum(),
+        y[3:] + y[:-3],
+        pt.dot(A, A.T),
+        pt.dot(F.T, F),
+        pt.dot(A, x[: A.shape[1]]),
+        pt.dot(F.T, y[: F.shape[0]]),
+        x[:1] ** 2,
+    ]
+    return [x, y, A, F], outs, {
+        "x": rng.normal(size=131),
+        "y": rng.normal(size=67).astype("float32"),
+        "A": rng.normal(size=(33, 17)),
+        "F": rng.normal(size=(19, 35)).astype("float32"),
+    }
+
+
+@case("careduce_int_bool")
+def careduce_int_bool():
+    rng = np.random.default_rng(33)
+    i = pt.lmatrix("i")
+    s = pt.tensor("s", dtype="int8", shape=(None, None))
+    b = pt.tensor("b", dtype="bool", shape=(None, None))
+    return [i, s, b], [i.sum(axis=0), i.prod(axis=1), i.max(), i.min(axis=0), s.sum(), s.max(axis=1), b.all(), b.any(axis=0), b.sum(axis=1)], {
+        "i": rng.integers(-9, 9, size=(7, 11)),
+        "s": rng.integers(-100, 100, size=(5, 9)).astype("int8"),
+        "b": rng.random(size=(4, 6)) > 0.5,
+    }
+
+
 # ---------------------------------------------------------------------------
 
 
