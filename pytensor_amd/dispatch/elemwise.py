@@ -207,16 +207,53 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env):
         for a, st in zip(ins, cstr):
             args.append(a.ptr)
             args += list(st)
-    parts = [None] * nout
+    parts = alloc_partials(reduce_spec, grid)
     for k in range(nout):
-        if reduce_spec[k] is None:
-            args.append(outs[k].ptr)
-        else:
-            parts[k] = DeviceArray.empty((grid,), reduce_spec[k]["acc_dtype"])
-            args.append(parts[k].ptr)
+        args.append(outs[k].ptr if reduce_spec[k] is None else parts[k].ptr)
     buf = struct.pack(f"<{len(args)}q", *args)
     ffi.check(lib.pthip_launch(fn, grid, 1, 1, BLOCK, 1, 1, 0, buf, len(buf)))
     return outs, parts, grid
+
+
+def _homogeneous(spec):
+    red = [r for r in spec if r is not None]
+    return len(red) > 1 and all((r["op"], r["acc_dtype"], r["dtype"]) == (red[0]["op"], red[0]["acc_dtype"], red[0]["dtype"]) for r in red)
+
+
+def alloc_partials(spec, grid):
+    """One [n_reduced][grid] slab when every reduced output shares (op, acc, dtype), so that
+    ONE second-stage launch finishes them all; separate buffers otherwise."""
+    parts = [None] * len(spec)
+    red = [k for k, r in enumerate(spec) if r is not None]
+    if not red:
+        return parts
+    if _homogeneous(spec):
+        slab = DeviceArray.empty((len(red), grid), spec[red[0]]["acc_dtype"])
+        for j, k in enumerate(red):
+            parts[k] = slab.view((grid,), (1,), j * grid)
+    else:
+        for k in red:
+            parts[k] = DeviceArray.empty((grid,), spec[k]["acc_dtype"])
+    return parts
+
+
+def finish_partials(env, spec, parts, grid):
+    """Second stage: per-workgroup partials -> final 0-d values (fixed order, deterministic)."""
+    res = [None] * len(spec)
+    red = [k for k, r in enumerate(spec) if r is not None]
+    if not red:
+        return res
+    if _homogeneous(spec):
+        r = spec[red[0]]
+        slab = parts[red[0]]  # first view starts at the slab base
+        out = device_reduce(env, r["op"], slab, len(red), grid, 1, grid, 1, 0, r["acc_dtype"], r["dtype"], (len(red),))
+        for j, k in enumerate(red):
+            res[k] = out.view((), (), j)
+    else:
+        for k in red:
+            r = spec[k]
+            res[k] = device_reduce(env, r["op"], parts[k], 1, grid, 1, 0, 1, 0, r["acc_dtype"], r["dtype"], ())
+    return res
 
 
 def _cstrides(shape):
@@ -280,6 +317,7 @@ def elemwise_reduce(node, inputs, env):
     ins = [env.to_device(i) for i in inputs]
     shape = _broadcast_shape(node, g, ins)
     outs, parts, grid = launch_elemwise(body, ins, shape, body["out_dtypes"], spec, env)
+    finals = finish_partials(env, spec, parts, grid) if grid else [None] * len(spec)
     res = []
     for k, r in enumerate(spec):
         if r is None:
@@ -291,7 +329,7 @@ def elemwise_reduce(node, inputs, env):
                 raise ValueError(f"zero-size array to reduction operation {r['op'].lower()} which has no identity")
             res.append(env.to_device(HostValue(np.asarray(ident, dtype=r["dtype"]))))
         else:
-            res.append(device_reduce(env, r["op"], parts[k], 1, grid, 1, 0, 1, 0, r["acc_dtype"], r["dtype"], ()))
+            res.append(finals[k])
     return res
 
 

@@ -19,7 +19,7 @@ from pytensor_amd import codegen, ffi, kernel_cache
 from pytensor_amd.device import DeviceArray
 from pytensor_amd.dispatch import handler
 from pytensor_amd.dispatch.blas import _scalar, gemv_device
-from pytensor_amd.dispatch.elemwise import BLOCK, MAX_GRID, _body_key, device_reduce, launch_elemwise
+from pytensor_amd.dispatch.elemwise import BLOCK, MAX_GRID, _body_key, alloc_partials, finish_partials, launch_elemwise
 from pytensor_amd.executor import HostValue
 
 CHAIN_RG = int(os.environ.get("PTHIP_CHAIN_RG", 0))  # 0 = auto
@@ -88,14 +88,13 @@ def gemv_chain(node, inputs, env):
     if store_r:
         r_out = DeviceArray.empty((N,), "float64")
         args.append(("q", r_out.ptr))
-    parts = [None] * nout
+    parts = alloc_partials(spec, grid)
     stored = [None] * nout
     for k in range(nout):
         if spec[k] is None:
             stored[k] = DeviceArray.empty((N,), body["out_dtypes"][k])
             args.append(("q", stored[k].ptr))
         else:
-            parts[k] = DeviceArray.empty((grid,), spec[k]["acc_dtype"])
             args.append(("q", parts[k].ptr))
     partT = DeviceArray.empty((grid, K), "float64")
     args.append(("q", partT.ptr))
@@ -105,13 +104,10 @@ def gemv_chain(node, inputs, env):
     ffi.check(env.lib.pthip_launch(fn, grid, 1, 1, BLOCK, 1, 1, 0, buf, len(buf)))
     if kt is not None:
         kt.end(name, tok)
+    finals = finish_partials(env, spec, parts, grid)
     res = [r_out] if store_r else []
     for k in range(nout):
-        if spec[k] is None:
-            res.append(stored[k])
-        else:
-            r = spec[k]
-            res.append(device_reduce(env, r["op"], parts[k], 1, grid, 1, 0, 1, 0, r["acc_dtype"], r["dtype"], ()))
+        res.append(stored[k] if spec[k] is None else finals[k])
     res.append(partT)
     return res
 
@@ -126,6 +122,7 @@ def _fallback(node, env, alpha1, A, x1, beta1, y1d, e_ins):
     ins.insert(r_pos, r)
     shape = (N,)
     outs, parts, grid = launch_elemwise(body, ins, shape, body["out_dtypes"], spec, env)
+    finals = finish_partials(env, spec, parts, grid) if grid else [None] * len(spec)
     res = [r] if store_r else []
     for k, sp in enumerate(spec):
         if sp is None:
@@ -133,7 +130,7 @@ def _fallback(node, env, alpha1, A, x1, beta1, y1d, e_ins):
         elif grid == 0:
             res.append(env.to_device(HostValue(np.asarray({"Add": 0, "Mul": 1}[sp["op"]], dtype=sp["dtype"]))))
         else:
-            res.append(device_reduce(env, sp["op"], parts[k], 1, grid, 1, 0, 1, 0, sp["acc_dtype"], sp["dtype"], ()))
+            res.append(finals[k])
     w = outs[w_out]
     At = A.view((K, N), (A.strides[1], A.strides[0]))
     t = gemv_device(env, 1.0, At, w, 0.0, None)

@@ -105,6 +105,7 @@ class Env:
         self.kernel_timer = None  # KernelTimer: brackets individual generated-kernel launches
         self.scheduler = None  # StreamScheduler of a multi-stream frozen plan
         self.donated = frozenset()  # input positions of the running node that may be overwritten
+        self.node_key = None  # (executable id, node index) of the running node
 
     def to_device(self, v) -> DeviceArray:
         if isinstance(v, DeviceArray):
@@ -281,6 +282,7 @@ class HipExecutable:
                 if sched is not None:
                     sched.before_node(k, node)
                 env.donated = self._donations[k]
+                env.node_key = (id(self), k)
                 outs = h(node, ins, env)
                 if evs is not None:
                     ffi.check(env.lib.pthip_event_record(evs[2 * k + 1]))
