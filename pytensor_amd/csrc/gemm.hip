@@ -168,12 +168,16 @@ __device__ __forceinline__ void tile_coords(long long tiles_m, long long tiles_n
 // ---------------------------------------------------------------------------------
 // fp64 kernel
 // ---------------------------------------------------------------------------------
-template <bool AKC, bool BKC>
+// SKINNY (M <= 64): the four waves split N (wave tile 64 x 32) so no MFMA is spent on
+// padding rows.  gridDim.y > 1 = split-K: block y covers K range [y*kchunk, (y+1)*kchunk) and
+// writes its raw accumulators to partial slab y of `out` (combined by splitk_finish_kernel).
+template <bool AKC, bool BKC, bool SKINNY>
 __global__ __launch_bounds__(BLOCK, 2) void dgemm_kernel(
     double* __restrict__ out, const double* __restrict__ A, const double* __restrict__ B,
     const double* __restrict__ C, long long M, long long N, long long K, long long lda,
     long long ldb, long long sAb, long long sBb, long long sCb, long long sC0, long long sC1,
-    double alpha, double beta, long long tiles_m, long long tiles_n, int vecA, int vecB) {
+    double alpha, double beta, long long tiles_m, long long tiles_n, int vecA, int vecB,
+    long long kchunk) {
   using SA = Stage<double, AKC>;
   using SB = Stage<double, BKC>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -185,41 +189,45 @@ __global__ __launch_bounds__(BLOCK, 2) void dgemm_kernel(
   const long long bz = blockIdx.z;
   A += bz * sAb;
   B += bz * sBb;
-  out += bz * M * N;
+  const bool split = gridDim.y > 1;
+  out += ((long long)blockIdx.y * gridDim.z + bz) * M * N;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int wm0 = (w >> 1) * 64, wn0 = (w & 1) * 64;
-  double4_t acc[4][4];
+  constexpr int NJ = SKINNY ? 2 : 4;
+  const int wm0 = SKINNY ? 0 : (w >> 1) * 64, wn0 = SKINNY ? w * 32 : (w & 1) * 64;
+  double4_t acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < NJ; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
   SA sa;
   SB sb;
-  const long long nk = (K + BK - 1) / BK;
-  sa.load(A, lda, m0, 0, M, K, vecA);
-  sb.load(B, ldb, n0, 0, N, K, vecB);
+  const long long kb = (long long)blockIdx.y * kchunk;
+  const long long Kend = (kb + kchunk < K) ? kb + kchunk : K;
+  const long long nk = (Kend - kb + BK - 1) / BK;
+  sa.load(A, lda, m0, kb, M, Kend, vecA);
+  sb.load(B, ldb, n0, kb, N, Kend, vecB);
   sa.store(As);
   sb.store(Bs);
   __syncthreads();
   for (long long kt = 0; kt < nk; kt++) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      sa.load(A, lda, m0, (kt + 1) * BK, M, K, vecA);
-      sb.load(B, ldb, n0, (kt + 1) * BK, N, K, vecB);
+      sa.load(A, lda, m0, kb + (kt + 1) * BK, M, Kend, vecA);
+      sb.load(B, ldb, n0, kb + (kt + 1) * BK, N, Kend, vecB);
     }
     const double* as = As + cur * SA::SIZE;
     const double* bs = Bs + cur * SB::SIZE;
 #pragma unroll
     for (int kk = 0; kk < BK / 4; kk++) {
-      double af[4], bf[4];
+      double af[4], bf[NJ];
 #pragma unroll
       for (int i = 0; i < 4; i++) af[i] = SA::frag(as, wm0 + i * 16, kk, lane);
 #pragma unroll
-      for (int j = 0; j < 4; j++) bf[j] = SB::frag(bs, wn0 + j * 16, kk, lane);
+      for (int j = 0; j < NJ; j++) bf[j] = SB::frag(bs, wn0 + j * 16, kk, lane);
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < NJ; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) {
@@ -229,12 +237,13 @@ __global__ __launch_bounds__(BLOCK, 2) void dgemm_kernel(
     __syncthreads();
   }
   // epilogue: D reg r -> row (l>>4) + 4r, col l&15
-  const bool has_c = (beta != 0.0) && C != nullptr;
+  const bool has_c = !split && (beta != 0.0) && C != nullptr;
   if (has_c) C += bz * sCb;
+  if (split) alpha = 1.0;
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++)
+    for (int j = 0; j < NJ; j++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const long long row = m0 + wm0 + i * 16 + (lane >> 4) + 4 * r;
@@ -250,12 +259,13 @@ __global__ __launch_bounds__(BLOCK, 2) void dgemm_kernel(
 // ---------------------------------------------------------------------------------
 // fp32 kernel
 // ---------------------------------------------------------------------------------
-template <bool AKC, bool BKC>
+template <bool AKC, bool BKC, bool SKINNY>
 __global__ __launch_bounds__(BLOCK, 2) void sgemm_kernel(
     float* __restrict__ out, const float* __restrict__ A, const float* __restrict__ B,
     const float* __restrict__ C, long long M, long long N, long long K, long long lda,
     long long ldb, long long sAb, long long sBb, long long sCb, long long sC0, long long sC1,
-    float alpha, float beta, long long tiles_m, long long tiles_n, int vecA, int vecB) {
+    float alpha, float beta, long long tiles_m, long long tiles_n, int vecA, int vecB,
+    long long kchunk) {
   using SA = Stage<float, AKC>;
   using SB = Stage<float, BKC>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -267,43 +277,47 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_kernel(
   const long long bz = blockIdx.z;
   A += bz * sAb;
   B += bz * sBb;
-  out += bz * M * N;
+  const bool split = gridDim.y > 1;
+  out += ((long long)blockIdx.y * gridDim.z + bz) * M * N;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int wm0 = (w >> 1) * 64, wn0 = (w & 1) * 64;
-  float16_t acc[2][2];
+  constexpr int NJ = SKINNY ? 1 : 2;
+  const int wm0 = SKINNY ? 0 : (w >> 1) * 64, wn0 = SKINNY ? w * 32 : (w & 1) * 64;
+  float16_t acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < NJ; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
   SA sa;
   SB sb;
-  const long long nk = (K + BK - 1) / BK;
-  sa.load(A, lda, m0, 0, M, K, vecA);
-  sb.load(B, ldb, n0, 0, N, K, vecB);
+  const long long kb = (long long)blockIdx.y * kchunk;
+  const long long Kend = (kb + kchunk < K) ? kb + kchunk : K;
+  const long long nk = (Kend - kb + BK - 1) / BK;
+  sa.load(A, lda, m0, kb, M, Kend, vecA);
+  sb.load(B, ldb, n0, kb, N, Kend, vecB);
   sa.store(As);
   sb.store(Bs);
   __syncthreads();
   for (long long kt = 0; kt < nk; kt++) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      sa.load(A, lda, m0, (kt + 1) * BK, M, K, vecA);
-      sb.load(B, ldb, n0, (kt + 1) * BK, N, K, vecB);
+      sa.load(A, lda, m0, kb + (kt + 1) * BK, M, Kend, vecA);
+      sb.load(B, ldb, n0, kb + (kt + 1) * BK, N, Kend, vecB);
     }
     const float* as = As + cur * SA::SIZE;
     const float* bs = Bs + cur * SB::SIZE;
 #pragma unroll
     for (int kk = 0; kk < BK / 4; kk++) {
-      float2 af[2], bf[2];
+      float2 af[2], bf[NJ];
 #pragma unroll
       for (int i = 0; i < 2; i++) af[i] = SA::frag2(as, wm0 + i * 32, kk, lane);
 #pragma unroll
-      for (int j = 0; j < 2; j++) bf[j] = SB::frag2(bs, wn0 + j * 32, kk, lane);
+      for (int j = 0; j < NJ; j++) bf[j] = SB::frag2(bs, wn0 + j * 32, kk, lane);
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < NJ; j++) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
         }
@@ -314,12 +328,13 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_kernel(
     }
     __syncthreads();
   }
-  const bool has_c = (beta != 0.f) && C != nullptr;
+  const bool has_c = !split && (beta != 0.f) && C != nullptr;
   if (has_c) C += bz * sCb;
+  if (split) alpha = 1.f;
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < NJ; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const long long row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -332,15 +347,35 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_kernel(
       }
 }
 
+// out[b][m][n] = alpha * sum_s part[s][b][m][n] + beta * C[b][m][n]   (fixed order over s)
+template <class T>
+__global__ __launch_bounds__(BLOCK) void splitk_finish_kernel(
+    T* __restrict__ out, const T* __restrict__ part, const T* __restrict__ C, long long M,
+    long long N, long long total, int nsplit, long long sCb, long long sC0, long long sC1, T alpha,
+    T beta) {
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < total;
+       i += (long long)gridDim.x * BLOCK) {
+    T v = part[i];
+    for (int s = 1; s < nsplit; s++) v += part[(long long)s * total + i];
+    v *= alpha;
+    if (beta != T(0) && C != nullptr) {
+      const long long b = i / (M * N), r = i - b * M * N;
+      const long long m = r / N, n = r - m * N;
+      v += beta * C[b * sCb + m * sC0 + n * sC1];
+    }
+    out[i] = v;
+  }
+}
+
 template <class T> struct KernelSel;
 template <> struct KernelSel<double> {
-  template <bool a, bool b> static auto get() { return dgemm_kernel<a, b>; }
+  template <bool a, bool b, bool s> static auto get() { return dgemm_kernel<a, b, s>; }
 };
 template <> struct KernelSel<float> {
-  template <bool a, bool b> static auto get() { return sgemm_kernel<a, b>; }
+  template <bool a, bool b, bool s> static auto get() { return sgemm_kernel<a, b, s>; }
 };
 
-template <class T, bool AKC, bool BKC>
+template <class T, bool AKC, bool BKC, bool SKINNY>
 int launch(long long batch, long long M, long long N, long long K, T alpha, const T* A,
            long long sAb, long long lda, const T* B, long long sBb, long long ldb, T beta,
            const T* C, long long sCb, long long sC0, long long sC1, T* out) {
@@ -348,7 +383,7 @@ int launch(long long batch, long long M, long long N, long long K, T alpha, cons
   using SA = Stage<T, AKC>;
   using SB = Stage<T, BKC>;
   const size_t shmem = (size_t)(2 * SA::SIZE + 2 * SB::SIZE) * sizeof(T);
-  auto k = KernelSel<T>::template get<AKC, BKC>();
+  auto k = KernelSel<T>::template get<AKC, BKC, SKINNY>();
   static bool attr_set = false;
   if (!attr_set && shmem > 64 * 1024) {
     PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -358,10 +393,43 @@ int launch(long long batch, long long M, long long N, long long K, T alpha, cons
   constexpr int VN = 16 / sizeof(T);
   const int vecA = (lda % VN == 0) && (((uintptr_t)A) % 16 == 0) && (sAb % VN == 0);
   const int vecB = (ldb % VN == 0) && (((uintptr_t)B) % 16 == 0) && (sBb % VN == 0);
-  dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)batch);
-  hipLaunchKernelGGL(k, grid, dim3(BLOCK), shmem, st, out, A, B, C, M, N, K, lda, ldb, sAb, sBb, sCb,
-                     sC0, sC1, alpha, beta, tiles_m, tiles_n, vecA, vecB);
-  return pthip::post_launch("gemm");
+  // split-K when the tile grid cannot fill the chip (skinny / small GEMMs, e.g. the
+  // (B x H)@(H x H) products of a Scan step): aim for >= 256 workgroups, >= 64 k per split
+  const long long tiles = tiles_m * tiles_n * batch;
+  long long nsplit = 1;
+  if (tiles < 128 && K >= 128) {
+    nsplit = (256 + tiles - 1) / tiles;
+    if (nsplit > K / 64) nsplit = K / 64;
+    if (nsplit > 64) nsplit = 64;
+    if (nsplit < 1) nsplit = 1;
+  }
+  long long kchunk = (K + nsplit - 1) / nsplit;
+  kchunk = (kchunk + BK - 1) / BK * BK;
+  if (kchunk < BK) kchunk = BK;
+  nsplit = (K + kchunk - 1) / kchunk;
+  if (nsplit < 1) nsplit = 1;
+  dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)nsplit, (unsigned)batch);
+  if (nsplit == 1) {
+    hipLaunchKernelGGL(k, grid, dim3(BLOCK), shmem, st, out, A, B, C, M, N, K, lda, ldb, sAb, sBb,
+                       sCb, sC0, sC1, alpha, beta, tiles_m, tiles_n, vecA, vecB, kchunk);
+    return pthip::post_launch("gemm");
+  }
+  const long long total = batch * M * N;
+  void* part = nullptr;
+  int r = pthip_alloc((size_t)nsplit * total * sizeof(T), &part);
+  if (r) return r;
+  hipLaunchKernelGGL(k, grid, dim3(BLOCK), shmem, st, (T*)part, A, B, C, M, N, K, lda, ldb, sAb, sBb,
+                     sCb, sC0, sC1, alpha, beta, tiles_m, tiles_n, vecA, vecB, kchunk);
+  r = pthip::post_launch("gemm(split-K)");
+  if (!r) {
+    long long blocks = (total + BLOCK - 1) / BLOCK;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL((splitk_finish_kernel<T>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, out,
+                       (const T*)part, C, M, N, total, (int)nsplit, sCb, sC0, sC1, alpha, beta);
+    r = pthip::post_launch("gemm splitk_finish");
+  }
+  pthip_free(part);  // stream-ordered reuse keeps this safe
+  return r;
 }
 
 template <class T>
@@ -389,7 +457,15 @@ int gemm_typed(long long batch, long long M, long long N, long long K, double al
   const T* b = (const T*)B;
   const T* c = (const T*)C;
   T* o = (T*)out;
-#define GO(X, Y) return launch<T, X, Y>(batch, M, N, K, (T)alpha, a, sAb, lda, b, sBb, ldb, (T)beta, c, sCb, sC0, sC1, o)
+  const bool skinny = M <= 64;
+#define GO(X, Y)                                                                                   \
+  do {                                                                                             \
+    if (skinny)                                                                                    \
+      return launch<T, X, Y, true>(batch, M, N, K, (T)alpha, a, sAb, lda, b, sBb, ldb, (T)beta, c, \
+                                   sCb, sC0, sC1, o);                                              \
+    return launch<T, X, Y, false>(batch, M, N, K, (T)alpha, a, sAb, lda, b, sBb, ldb, (T)beta, c,  \
+                                  sCb, sC0, sC1, o);                                               \
+  } while (0)
   if (akc && bkc) GO(true, true);
   if (akc && !bkc) GO(true, false);
   if (!akc && bkc) GO(false, true);

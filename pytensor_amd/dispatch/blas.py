@@ -176,3 +176,20 @@ def dot(node, inputs, env):
         r = gemv_device(env, 1.0, A if x.strides[0] == 1 or x.shape[0] <= 1 else A.contiguous(), y, 0.0, None)
         return [r.view((), ())]
     raise NotImplementedError("Dot with ndim > 2")
+
+
+@handler("SeqDot22")
+def seq_dot22(node, inputs, env):
+    """``out[t] = seq[t] @ W`` for every step of a Scan at once (fusion.hoist_scan_seq_dots):
+    one (T·B × K)@(K × N) MFMA GEMM instead of T skinny ones."""
+    seq, W = (env.to_device(i) for i in inputs)
+    T, B, K = seq.shape
+    if W.shape[0] != K:
+        raise ValueError(f"Shape mismatch: x has {K} cols but y has {W.shape[0]} rows")
+    # (T, B, K) -> (T*B, K) needs the first two dims to be mergeable
+    if seq.strides[0] != B * seq.strides[1] or seq.strides[2] != 1:
+        seq = seq.contiguous()
+    flat = seq.view((T * B, K), (seq.strides[1], seq.strides[2]))
+    out = gemm_device(env, 1.0, flat, _prep2d(W))
+    N = W.shape[1]
+    return [out.view((T, B, N), (B * N, N, 1))]

@@ -139,6 +139,9 @@ class HipExecutable:
         self.segments = None  # per-node segment ids for multi-stream plans (fusion.segment_graph)
         self.graph = fuse_elemwise_reduce(graph) if fuse else graph
         if fuse and fuse != "elemwise":
+            from pytensor_amd.fusion import hoist_scan_seq_dots
+
+            self.graph = hoist_scan_seq_dots(self.graph)
             from pytensor_amd.fusion import segment_graph
 
             self.graph, self.segments = segment_graph(fuse_gemv_chain(self.graph))
@@ -171,7 +174,7 @@ class HipExecutable:
     _FRESH_OPS = frozenset(
         ["Alloc", "AllocEmpty", "Elemwise", "ElemwiseReduce", "GemvChain", "AdvancedSubtensor", "Gemv", "Gemm", "Dot22",
          "Dot22Scalar", "BatchedDot", "Ger", "Join", "DeepCopyOp", "IncSubtensor", "AdvancedIncSubtensor",
-         "Cholesky", "SolveTriangular", "CholeskySolve", "Blockwise", "GemvFinish"]
+         "Cholesky", "SolveTriangular", "CholeskySolve", "Blockwise", "GemvFinish", "SeqDot22"]
     )
 
     def _compute_donations(self):

@@ -264,3 +264,79 @@ def fuse_gemv_chain(g: Graph) -> Graph:
         else:
             out.nodes.append(n)
     return out
+
+
+# ---------------------------------------------------------------------------
+# Scan: hoist sequence-only matrix products out of the loop
+# ---------------------------------------------------------------------------
+
+
+def hoist_scan_seq_dots(g: Graph) -> Graph:
+    """``Dot22(x_t, W)`` inside a ``Scan`` step, with ``x_t`` a slice of a sequence and ``W``
+    a non-sequence, does not depend on the recurrence: the T products
+    ``(B×K)@(K×N)`` become ONE ``(T·B×K)@(K×N)`` MFMA GEMM before the loop
+    (``SeqDot22``), whose result is fed back as an extra sequence.  The reference has the
+    same idea as a graph rewrite (``scan_pushout_seq_operation``,
+    pytensor/scan/rewriting/__init__.py) but it does not fire once ``BlasOpt`` has turned
+    the inner ``dot + add`` into ``Dot22``/``Gemm``; on MI355X it is the difference
+    between T skinny launches that cannot fill 256 CUs and one full-rate GEMM.
+    """
+    import copy
+
+    from pytensor_amd.ir import Var
+
+    if not any(n.op == "Scan" for n in g.nodes):
+        return g
+    out = Graph(name=g.name)
+    out.vars = dict(g.vars)
+    out.inputs, out.outputs = list(g.inputs), list(g.outputs)
+    next_id = max(out.vars) + 1
+    changed = False
+    for n in g.nodes:
+        if n.op != "Scan":
+            out.nodes.append(n)
+            continue
+        info = dict(n.params["info"])
+        inner: Graph = n.params["inner"]
+        if info["mit_mot_in_slices"] or info["as_while"]:
+            out.nodes.append(n)
+            continue
+        n_seqs = info["n_seqs"]
+        n_inner_in = len(inner.inputs)
+        n_non = info["n_non_seqs"]
+        seq_in = inner.inputs[:n_seqs]
+        non_in = inner.inputs[n_inner_in - n_non :]
+        outer_seqs = n.inputs[1 : 1 + n_seqs]
+        outer_non = n.inputs[len(n.inputs) - n_non :]
+        hoist = []
+        for k, m in enumerate(inner.nodes):
+            if m.op == "Dot22" and m.inputs[0] in seq_in and m.inputs[1] in non_in and m.outputs[0] not in inner.outputs:
+                hoist.append(k)
+        if not hoist:
+            out.nodes.append(n)
+            continue
+        new_inner = Graph(name=inner.name)
+        new_inner.vars = dict(inner.vars)
+        new_inner.outputs = list(inner.outputs)
+        new_outer_seqs, new_inner_seqs = [], []
+        pre_nodes = []
+        for k in hoist:
+            m = inner.nodes[k]
+            s_pos = seq_in.index(m.inputs[0])
+            w_pos = non_in.index(m.inputs[1])
+            ov = inner.vars[m.outputs[0]]
+            # outer result (T, B, N) and the SeqDot22 node producing it
+            vid = next_id
+            next_id += 1
+            out.vars[vid] = Var(vid, ov.dtype, (None, *ov.shape), "tensor", None, "scan_hoisted_dot")
+            pre_nodes.append(Node("SeqDot22", {}, [outer_seqs[s_pos], outer_non[w_pos]], [vid]))
+            new_outer_seqs.append(vid)
+            new_inner_seqs.append(m.outputs[0])  # the inner var now arrives as a sequence slice
+        new_inner.nodes = [m for k, m in enumerate(inner.nodes) if k not in hoist]
+        new_inner.inputs = list(seq_in) + new_inner_seqs + list(inner.inputs[n_seqs:])
+        info["n_seqs"] = n_seqs + len(hoist)
+        new_inputs = [n.inputs[0]] + list(outer_seqs) + new_outer_seqs + list(n.inputs[1 + n_seqs :])
+        out.nodes.extend(pre_nodes)
+        out.nodes.append(Node("Scan", {"info": info, "inner": new_inner}, new_inputs, list(n.outputs)))
+        changed = True
+    return out if changed else g

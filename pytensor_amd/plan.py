@@ -86,8 +86,19 @@ class _SegmentSwitch:
             self.plan._begin_segment()
 
 
+_CAPTURE_ACTIVE = [None]  # the plan currently inside warm-up/capture, if any
+_DEFERRED = []  # plans whose release was requested during somebody else's capture
+
+
+def _drain_deferred():
+    while _DEFERRED and _CAPTURE_ACTIVE[0] is None:
+        _DEFERRED.pop().close()
+
+
 class FrozenPlan:
     def __init__(self, exe, inputs, fetch_outputs=True, multi_stream=True):
+        self._closed = False
+        _drain_deferred()
         self.exe = exe
         self.fetch_outputs = fetch_outputs  # False: device-side timing only (no pack/D2H node)
         self.lib = ffi.lib()
@@ -124,11 +135,15 @@ class FrozenPlan:
         self._out_block = None
         self._out_meta = None
         self._keep = []
+        _CAPTURE_ACTIVE[0] = self
         try:
             self._build(inputs)
         except Exception:
+            _CAPTURE_ACTIVE[0] = None
             self.close()
             raise
+        finally:
+            _CAPTURE_ACTIVE[0] = None
 
     # ------------------------------------------------------------------
     def _begin_segment(self):
@@ -285,6 +300,16 @@ class FrozenPlan:
         return tuple(res)
 
     def close(self):
+        """Release the graphs, the arena and the staging blocks.  Idempotent.  When called
+        (e.g. by the garbage collector through ``__del__``) while ANOTHER plan is being
+        captured, the release is deferred: a stream synchronisation would invalidate the
+        running capture."""
+        if self._closed:
+            return
+        if _CAPTURE_ACTIVE[0] and _CAPTURE_ACTIVE[0] is not self:
+            _DEFERRED.append(self)  # keeps the object alive until it is safe to free
+            return
+        self._closed = True
         lib = self.lib
         try:
             lib.pthip_synchronize()
