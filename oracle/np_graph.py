@@ -692,3 +692,49 @@ def run_graph(graph, inputs):
         for vid, val in zip(node.outputs, outs):
             env[vid] = val
     return [env[o] for o in graph.outputs]
+
+
+# ---------------------------------------------------------------------------
+# fused IR nodes (pytensor_amd/fusion.py) restated from their unfused parts, so that the
+# IR passes themselves can be checked on the CPU: oracle(pass(graph)) == oracle(graph)
+# ---------------------------------------------------------------------------
+
+
+@op("ElemwiseReduce")
+def _elemwise_reduce(p, inputs, node, graph):
+    outs = eval_scalar_body(p["scalar"], inputs)
+    shape = np.broadcast(*inputs).shape if inputs else ()
+    res = []
+    for o, spec, dt in zip(outs, p["reduce"], p["scalar"]["out_dtypes"]):
+        full = np.array(np.broadcast_to(o, shape), dtype=dt, order="C")
+        if spec is None:
+            res.append(full)
+        else:
+            uf = _REDUCE[spec["op"]]
+            res.append(np.asarray(uf.reduce(full.ravel(), dtype=np.dtype(spec["acc_dtype"]))).astype(spec["dtype"]))
+    return res
+
+
+@op("GemvChain")
+def _gemv_chain(p, inputs, node, graph):
+    y1, a1, A, x1, b1, *e_rest = inputs
+    r = _gemv({}, [y1, a1, A, x1, b1], node, graph)[0]
+    e_in = list(e_rest)
+    e_in.insert(p["r_pos"], r)
+    outs = _elemwise_reduce({"scalar": p["scalar"], "reduce": p["reduce"]}, e_in, node, graph)
+    w = outs[p["w_out"]]
+    part = np.dot(A.T, w)[None, :]
+    return ([r] if p["store_r"] else []) + outs + [part]
+
+
+@op("GemvFinish")
+def _gemv_finish(p, inputs, node, graph):
+    part, y2, a2, b2 = inputs
+    s = part.sum(axis=0)
+    return [np.asarray((a2 * s if b2 == 0.0 else b2 * y2 + a2 * s), dtype=part.dtype)]
+
+
+@op("SeqDot22")
+def _seq_dot22(p, inputs, node, graph):
+    seq, W = inputs
+    return [np.matmul(seq, W)]
