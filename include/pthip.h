@@ -196,6 +196,8 @@ int pthip_pack(int n, const void* const* srcs, const int64_t* nbytes, const int6
                void* dst);
 /* device-side error flag raised by kernels (index out of bounds ...); sync + read + clear */
 int pthip_check_status(int* status);
+/* device address of that flag, for generated (JIT) kernels that bounds-check indices */
+void* pthip_status_ptr(void);
 
 #ifdef __cplusplus
 }

@@ -717,14 +717,29 @@ def _elemwise_reduce(p, inputs, node, graph):
 
 @op("GemvChain")
 def _gemv_chain(p, inputs, node, graph):
-    y1, a1, A, x1, b1, *e_rest = inputs
+    y1, a1, A, x1, b1, *rest = inputs
     r = _gemv({}, [y1, a1, A, x1, b1], node, graph)[0]
-    e_in = list(e_rest)
-    e_in.insert(p["r_pos"], r)
+    gather = set(p.get("gather") or [])
+    it = iter(rest)
+    e_in = []
+    for pos in range(len(p["scalar"]["in_dtypes"])):
+        if pos == p["r_pos"]:
+            e_in.append(r)
+        elif pos in gather:
+            table, idx = next(it), next(it)
+            e_in.append(table[idx])  # AdvancedSubtensor on axis 0
+        else:
+            e_in.append(next(it))
     outs = _elemwise_reduce({"scalar": p["scalar"], "reduce": p["reduce"]}, e_in, node, graph)
     w = outs[p["w_out"]]
     part = np.dot(A.T, w)[None, :]
-    return ([r] if p["store_r"] else []) + outs + [part]
+    res = ([r] if p["store_r"] else []) + outs + [part]
+    if p.get("scatter_out") is not None:
+        sidx, base = next(it), next(it)
+        acc = np.zeros(base.shape[0], dtype="float64")
+        np.add.at(acc, sidx, outs[p["scatter_out"]])  # AdvancedIncSubtensor(inc) on zeros
+        res.append(acc[None, :])
+    return res
 
 
 @op("GemvFinish")

@@ -626,7 +626,8 @@ def nd_kernel_source(name: str, body: dict, ndim: int, reduce_spec=None) -> str:
     return "\n".join(src)
 
 
-def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, has_y1) -> str:
+def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, has_y1,
+                      out_store=None, scatter_out=None) -> str:
     """One-pass ``r = b1*y1 + a1*A@x ; outs = body(.., r, ..) ; partial += A.T@w`` (fp64).
 
     Work decomposition (wave64): a wave owns groups of ``RG`` consecutive rows.  Lane l
@@ -639,17 +640,25 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
        half of its rows (RG-1 exchanges instead of 6 per row), then 6-log2(RG) plain
        steps — lanes (row << s .. ) end up owning one finished row each;
     3. the scalar graph runs once per row on the owning lanes (other row inputs are
-       coalesced loads), reductions accumulate per lane, vector outputs are stored;
+       coalesced loads or table gathers), reductions accumulate per lane, vector outputs
+       are stored only if something outside the fused node reads them;
     4. w[row] is broadcast back with ``v_readlane`` (compile-time lane) and multiplied
-       into the still-resident row registers: acc[c] += row * w.
+       into the still-resident row registers: acc[c] += row * w;
+    5. optionally the scatter-add ``out[sidx[row]] += o[row]`` (gradient of a gather) is
+       accumulated in the same pass: lane b owns bins b and b+64 (<= 128 bins), rows are
+       visited in order, per-workgroup partials are combined in a fixed order afterwards
+       (deterministic, like every other reduction here).
 
-    ``e_modes[k]`` ∈ {'R' the Gemv result, 'V' N-vector, 'S' scalar} per elementwise input.
-    Kernel params (all 8 bytes): N, K, A, lda, x, y1, alpha1, beta1, <elementwise inputs
-    except R>, [r_out], <outputs: stored ptr | partial ptr>, partT.
+    ``e_modes[k]`` ∈ {'R' the Gemv result, 'V' N-vector, 'S' scalar, 'G' gather
+    ``table[gidx[row]]``} per elementwise input.
+    Kernel params (all 8 bytes): N, K, A, lda, x, y1, alpha1, beta1, <per elementwise input
+    except R: ptr (and for 'G': index ptr, table length)>, [r_out], <per output: stored ptr
+    (if stored) | partial ptr (if reduced)>, partT, [sidx, sbins, partS], status.
     """
     import math
 
     nout = len(body["out_dtypes"])
+    out_store = list(out_store) if out_store is not None else [True] * nout
     lg = int(math.log2(RG))
     assert 1 << lg == RG and 2 <= RG <= 32
     rest = 6 - lg  # plain butterfly steps after the transposing ones
@@ -657,18 +666,23 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
         "long long N", "long long K", "const double* __restrict__ A", "long long lda",
         "const double* __restrict__ x", "const double* __restrict__ y1", "double alpha1", "double beta1",
     ]
-    k_in = 0
     for k, m in enumerate(e_modes):
-        if m != "R":
-            params.append(f"const {CTYPE[body['in_dtypes'][k]]}* __restrict__ in{k}")
+        if m == "R":
+            continue
+        params.append(f"const {CTYPE[body['in_dtypes'][k]]}* __restrict__ in{k}")
+        if m == "G":
+            params += [f"const long long* __restrict__ gidx{k}", f"long long glen{k}"]
     if store_r:
         params.append("double* __restrict__ r_out")
     for k, dt in enumerate(body["out_dtypes"]):
-        if reduce_spec[k] is None:
-            params.append(f"{CTYPE[dt]}* __restrict__ out{k}")
-        else:
+        if reduce_spec[k] is not None:
             params.append(f"{CTYPE[reduce_spec[k][1]]}* __restrict__ part{k}")
+        elif out_store[k]:
+            params.append(f"{CTYPE[dt]}* __restrict__ out{k}")
     params.append("double* __restrict__ partT")
+    if scatter_out is not None:
+        params += ["const long long* __restrict__ sidx", "long long sbins", "double* __restrict__ partS"]
+    params.append("int* __restrict__ status")
     L = [reduce_header(), PRELUDE]
     L.append("typedef double pt_d2 __attribute__((ext_vector_type(2)));")
     L.append("static __device__ __forceinline__ double pt_shfl_xor(double v, int m) { return pthip_dev::shfl_xor_any(v, m); }")
@@ -683,6 +697,8 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
     L.append("    const long long col = c * 128 + 2 * lane;")
     L.append("    b[c] = (col < K) ? *(const pt_d2*)(x + col) : (pt_d2){0.0, 0.0};")
     L.append("    accT[c] = (pt_d2){0.0, 0.0};\n  }")
+    if scatter_out is not None:
+        L.append("  double accS0 = 0.0, accS1 = 0.0;  // bins lane and lane + 64")
     for k, m in enumerate(e_modes):
         if m == "S":
             L.append(f"  const {CTYPE[body['in_dtypes'][k]]} s{k} = in{k}[0];")
@@ -706,7 +722,6 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
     L.append("      double s = 0.0;")
     L.append("#pragma unroll\n      for (int c = 0; c < C; c++) s += xr[r][c].x * b[c].x + xr[r][c].y * b[c].y;")
     L.append("      p[r] = s;\n    }")
-    # transposing butterfly
     half = RG // 2
     mask = 32
     while half >= 1:
@@ -730,23 +745,47 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
         L.append("    if (valid && owner) r_out[row] = res;")
     in_names = []
     for k, m in enumerate(e_modes):
-        in_names.append("res" if m == "R" else (f"s{k}" if m == "S" else f"in{k}[rowc]"))
+        if m == "R":
+            in_names.append("res")
+        elif m == "S":
+            in_names.append(f"s{k}")
+        elif m == "G":
+            L.append(f"    long long gi{k} = gidx{k}[rowc];")
+            L.append(f"    if (gi{k} < 0) gi{k} += glen{k};")
+            L.append(f"    if (gi{k} < 0 || gi{k} >= glen{k}) {{ *status = 1; gi{k} = 0; }}  // IndexError, reported by the host")
+            in_names.append(f"in{k}[gi{k}]")
+        else:
+            in_names.append(f"in{k}[rowc]")
     out_names = []
     for k, dt in enumerate(body["out_dtypes"]):
         L.append(f"    {CTYPE[dt]} o{k};")
         out_names.append(f"o{k}")
     L.append(emit_body(body, in_names, out_names, indent="    "))
     for k, rs in enumerate(reduce_spec):
-        if rs is None:
-            L.append(f"    if (valid && owner) out{k}[row] = o{k};")
-        else:
+        if rs is not None:
             L.append(f"    if (valid && owner) acc{k}_0 = pthip_dev::{REDUCE_OPS[rs[0]]}::apply(acc{k}_0, ({CTYPE[rs[1]]})o{k});")
+        elif out_store[k]:
+            L.append(f"    if (valid && owner) out{k}[row] = o{k};")
     L.append(f"    const double w = valid ? (double)o{w_out} : 0.0;")
+    if scatter_out is not None:
+        if scatter_out != w_out:
+            L.append(f"    const double sv = valid ? (double)o{scatter_out} : 0.0;")
+        L.append("    long long si_ = sidx[rowc];")
+        L.append("    if (si_ < 0) si_ += sbins;")
+        L.append("    if (valid && (si_ < 0 || si_ >= sbins)) { *status = 1; }")
+        L.append("    const int si = (valid && si_ >= 0 && si_ < sbins) ? (int)si_ : -1;")
     L.append("#pragma unroll\n    for (int r = 0; r < RG; r++) {")
     L.append(f"      const double wr = pt_readlane(w, r << {rest});")
-    L.append("#pragma unroll\n      for (int c = 0; c < C; c++) { accT[c].x += xr[r][c].x * wr; accT[c].y += xr[r][c].y * wr; }\n    }")
+    L.append("#pragma unroll\n      for (int c = 0; c < C; c++) { accT[c].x += xr[r][c].x * wr; accT[c].y += xr[r][c].y * wr; }")
+    if scatter_out is not None:
+        sval = "wr" if scatter_out == w_out else f"pt_readlane(sv, r << {rest})"
+        L.append(f"      const int ir = __builtin_amdgcn_readlane(si, r << {rest});")
+        L.append(f"      const double svr = {sval};")
+        L.append("      accS0 += (ir == lane) ? svr : 0.0;")
+        L.append("      accS1 += (ir == lane + 64) ? svr : 0.0;")
+    L.append("    }")
     L.append("  }")
-    # block combine of accT (fixed wave order) and of the reductions
+    # block combine of accT (fixed wave order), of the scatter bins and of the reductions
     L.append(f"  __shared__ double redT[{BLOCK // 64}][128 * C];")
     L.append("#pragma unroll\n  for (int c = 0; c < C; c++) { redT[wid][c * 128 + 2 * lane] = accT[c].x; redT[wid][c * 128 + 2 * lane + 1] = accT[c].y; }")
     L.append("  __syncthreads();")
@@ -754,6 +793,14 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
     L.append("    double v = redT[0][j];")
     L.append(f"#pragma unroll\n    for (int q = 1; q < {BLOCK // 64}; q++) v += redT[q][j];")
     L.append("    if (j < K) partT[(long long)blockIdx.x * K + j] = v;\n  }")
+    if scatter_out is not None:
+        L.append("  __syncthreads();")
+        L.append("  redT[wid][lane] = accS0; redT[wid][lane + 64] = accS1;")
+        L.append("  __syncthreads();")
+        L.append("  if (threadIdx.x < 128) {")
+        L.append("    double v = redT[0][threadIdx.x];")
+        L.append(f"#pragma unroll\n    for (int q = 1; q < {BLOCK // 64}; q++) v += redT[q][threadIdx.x];")
+        L.append("    if (threadIdx.x < sbins) partS[(long long)blockIdx.x * sbins + threadIdx.x] = v;\n  }")
     L.append(_reduce_epilogue(reduce_spec, 1))
     L.append("}")
     return "\n".join(L)

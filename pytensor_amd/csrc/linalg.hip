@@ -299,13 +299,16 @@ __global__ __launch_bounds__(BLOCK) void trsv_lds_kernel(T* __restrict__ Xout,
     const int i = lane + 64 * q;
     r[q] = i < n ? b[i] : T(0);
   }
-  // The dependency chain per step is only  broadcast(r_k) -> divide -> fma:
-  // the matrix column k+1 is prefetched from LDS while step k's chain resolves.
+  // The dependency chain per step is only  broadcast(r_k) -> multiply -> fma: the matrix
+  // column k+1 AND the reciprocal of its pivot are fetched/computed while step k's chain
+  // resolves (the fp64 divide is a ~100-cycle sequence; as 1/d it leaves the chain;
+  // x*(1/d) is within 1 ulp of x/d).
   bool fail = false;
-  T col[RPL], dkk;
+  T col[RPL], dkk, rd;
   {
     const int k0 = lower ? 0 : n - 1;
     dkk = unit ? T(1) : W[k0 * ld + k0];
+    rd = T(1) / dkk;
 #pragma unroll
     for (int q = 0; q < RPL; q++) {
       const int i = lane + 64 * q;
@@ -315,10 +318,11 @@ __global__ __launch_bounds__(BLOCK) void trsv_lds_kernel(T* __restrict__ Xout,
   for (int s = 0; s < n; s++) {
     const int k = lower ? s : n - 1 - s;
     // prefetch the next column (independent of the chain)
-    T ncol[RPL], ndkk = T(1);
+    T ncol[RPL], ndkk = T(1), nrd = T(1);
     if (s + 1 < n) {
       const int kn = lower ? k + 1 : k - 1;
       ndkk = unit ? T(1) : W[kn * ld + kn];
+      nrd = T(1) / ndkk;
 #pragma unroll
       for (int q = 0; q < RPL; q++) {
         const int i = lane + 64 * q;
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(BLOCK) void trsv_lds_kernel(T* __restrict__ Xout,
 #pragma unroll
     for (int q = 0; q < RPL; q++)
       if ((k >> 6) == q) rk = r[q];
-    const T xk = bcast_lane(rk, k & 63) / dkk;  // k is wave-uniform: v_readlane
+    const T xk = bcast_lane(rk, k & 63) * rd;  // k is wave-uniform: v_readlane
 #pragma unroll
     for (int q = 0; q < RPL; q++) {
       const int i = lane + 64 * q;
@@ -338,6 +342,7 @@ __global__ __launch_bounds__(BLOCK) void trsv_lds_kernel(T* __restrict__ Xout,
       else if (lower ? i > k : i < k) r[q] -= col[q] * xk;
     }
     dkk = ndkk;
+    rd = nrd;
 #pragma unroll
     for (int q = 0; q < RPL; q++) col[q] = ncol[q];
   }

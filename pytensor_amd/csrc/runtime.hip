@@ -153,6 +153,13 @@ int pthip_init(int device) {
   if (n <= 0) return set_error("pthip_init: no HIP device visible");
   if (device < 0 || device >= n) return set_error("pthip_init: device %d out of range (%d visible)", device, n);
   PTHIP_CHECK(hipSetDevice(device));
+  // One process per GPU and a latency-critical host loop (one synchronisation per Function
+  // call): spin on completion instead of sleeping on an interrupt.  Best effort — the flag
+  // is rejected once the primary context is active (e.g. torch initialised HIP first).
+  if (getenv("PTHIP_NO_SPIN") == nullptr) {
+    (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
+    (void)hipGetLastError();
+  }
   if (!g_ctx.streams[0]) {
     PTHIP_CHECK(hipStreamCreateWithFlags(&g_ctx.streams[0], hipStreamNonBlocking));
     g_ctx.stream = g_ctx.streams[0];
@@ -498,6 +505,11 @@ int pthip_launch(void* fn, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t bx, u
   PTHIP_CHECK(hipModuleLaunchKernel((hipFunction_t)fn, gx, gy, gz, bx, by, bz, shmem, g_ctx.stream,
                                     nullptr, config));
   return 0;
+}
+
+void* pthip_status_ptr(void) {
+  if (g_ctx.device < 0 && pthip_init(0)) return nullptr;
+  return (void*)g_ctx.status_dev;
 }
 
 int pthip_check_status(int* status) {

@@ -3,9 +3,11 @@
 
 ``GemvChain`` reads the matrix once for the forward ``A@x`` and the backward ``A.T@w``
 (reference: two ``Gemv.perform`` calls, pytensor/tensor/blas/gemv.py:64-108, with an
-``Elemwise.perform`` between them).  When the operands do not meet the fast kernel's
-layout requirements the handler falls back to the three unfused launches — same
-results, two passes over the matrix.
+``Elemwise.perform`` between them), optionally gathering ``table[idx]`` inputs
+(``AdvancedSubtensor``, subtensor.py:1932) and scatter-adding one output
+(``AdvancedIncSubtensor``, subtensor.py:2275) in the same pass.  When the operands do
+not meet the fast kernel's layout requirements the handler falls back to the unfused
+launches — same results, two passes over the matrix.
 """
 
 from __future__ import annotations
@@ -16,16 +18,42 @@ import struct
 import numpy as np
 
 from pytensor_amd import codegen, ffi, kernel_cache
-from pytensor_amd.device import DeviceArray
+from pytensor_amd.device import DeviceArray, copy_into
 from pytensor_amd.dispatch import handler
 from pytensor_amd.dispatch.blas import _scalar, gemv_device
 from pytensor_amd.dispatch.elemwise import BLOCK, MAX_GRID, _body_key, alloc_partials, finish_partials, launch_elemwise
 from pytensor_amd.executor import HostValue
 
 CHAIN_RG = int(os.environ.get("PTHIP_CHAIN_RG", 0))  # 0 = auto
+# Workgroups of the one-pass kernel (230 VGPRs -> 2 workgroups per CU resident).  Measured
+# on C4 (evals/s): 448: 3252, 480: 3220, 512: 3209, 1024: 3274, 2048: 3331, 4096: 3282 —
+# a persistent grid that leaves CUs free for the overlapped latency chain does not pay.
+CHAIN_GRID = int(os.environ.get("PTHIP_CHAIN_GRID", 2048))
+MAX_SCATTER_BINS = 128
 
 
-def _fast_ok(A, x1, y1, e_ins, N, K):
+def _unpack(node, inputs, env):
+    """Split the flat input list of a GemvChain node into its parts."""
+    p = node.params
+    body = p["scalar"]
+    gather = set(p.get("gather") or [])
+    it = iter(inputs[5:])
+    e_vals = []  # per elementwise input position != r_pos: DeviceArray | (table, idx)
+    for pos in range(len(body["in_dtypes"])):
+        if pos == p["r_pos"]:
+            e_vals.append(None)
+        elif pos in gather:
+            e_vals.append((env.to_device(next(it)), env.to_device(next(it))))
+        else:
+            e_vals.append(env.to_device(next(it)))
+    sidx = base = None
+    if p.get("scatter_out") is not None:
+        sidx = env.to_device(next(it))
+        base = env.to_device(next(it))
+    return e_vals, sidx, base
+
+
+def _fast_ok(A, x1, y1, e_vals, sidx, base, N, K):
     if str(A.dtype) != "float64" or A.ndim != 2 or A.strides[1] != 1 or A.strides[0] % 2 or A.ptr % 16:
         return False
     if K % 2 or K > 1024 or N == 0:
@@ -34,10 +62,19 @@ def _fast_ok(A, x1, y1, e_ins, N, K):
         return False
     if y1 is not None and (not y1.is_contiguous() or y1.shape != (N,)):
         return False
-    for a in e_ins:
-        if a.size == 1:
+    for v in e_vals:
+        if v is None:
             continue
-        if a.shape != (N,) or not a.is_contiguous():
+        if isinstance(v, tuple):
+            table, idx = v
+            if not table.is_contiguous() or table.ndim != 1 or idx.shape != (N,) or not idx.is_contiguous():
+                return False
+            if table.shape[0] == 0:
+                return False
+        elif v.size != 1 and (v.shape != (N,) or not v.is_contiguous()):
+            return False
+    if sidx is not None:
+        if sidx.shape != (N,) or not sidx.is_contiguous() or base.ndim != 1 or not (0 < base.shape[0] <= MAX_SCATTER_BINS):
             return False
     return True
 
@@ -46,44 +83,50 @@ def _fast_ok(A, x1, y1, e_ins, N, K):
 def gemv_chain(node, inputs, env):
     p = node.params
     body, spec, r_pos, w_out, store_r = p["scalar"], p["reduce"], p["r_pos"], p["w_out"], p["store_r"]
-    y1, alpha1, A, x1, beta1, *e_rest = inputs
+    nout = len(body["out_dtypes"])
+    out_store = p.get("out_store") or [s is None for s in spec]
+    scatter_out = p.get("scatter_out")
+    y1, alpha1, A, x1, beta1 = inputs[:5]
     alpha1, beta1 = _scalar(env, alpha1), _scalar(env, beta1)
     A, x1 = env.to_device(A), env.to_device(x1)
     y1d = None if beta1 == 0.0 else env.to_device(y1)
-    e_ins = [env.to_device(v) for v in e_rest]
+    e_vals, sidx, base = _unpack(node, inputs, env)
     N, K = A.shape
-    nout = len(body["out_dtypes"])
     if x1.shape != (K,):
         raise ValueError(f"Shape mismatch: A.shape[1] != x.shape[0] ({A.shape}, {x1.shape})")
-    if not _fast_ok(A, x1, y1d, e_ins, N, K):
-        return _fallback(node, env, alpha1, A, x1, beta1, y1d, e_ins)
-    # runtime broadcast rule of Elemwise (elemwise.py:825-840) for the vector inputs
-    g = env.graph
-    for vid, a in zip(node.inputs[5:], e_ins):
-        if a.size == 1 and a.ndim == 1 and N != 1 and g.vars[vid].shape[0] != 1:
-            raise ValueError("Runtime broadcasting not allowed (GemvChain elementwise input)")
+    if not _fast_ok(A, x1, y1d, e_vals, sidx, base, N, K):
+        return _fallback(node, env, alpha1, A, x1, beta1, y1d, e_vals, sidx, base)
     C = (K + 127) // 128
     RG = CHAIN_RG or max(4, 32 // C)
     while RG * C > 32 and RG > 4:
         RG //= 2
     e_modes = []
-    it = iter(e_ins)
-    for pos in range(len(body["in_dtypes"])):
-        if pos == r_pos:
+    for pos, v in enumerate(e_vals):
+        if v is None:
             e_modes.append("R")
+        elif isinstance(v, tuple):
+            e_modes.append("G")
         else:
-            a = next(it)
-            e_modes.append("S" if a.size == 1 else "V")
+            e_modes.append("S" if v.size == 1 else "V")
     rs = [None if r is None else (r["op"], r["acc_dtype"]) for r in spec]
     rkey = "".join("-" if r is None else r["op"][0] + r["acc_dtype"][0] + r["acc_dtype"][-1] for r in spec)
-    name = f"gchain_{_body_key(body)}_{''.join(e_modes)}_{rkey}_w{w_out}_c{C}_g{RG}_{int(store_r)}{int(y1d is not None)}".replace("-", "x")
-    src = codegen.gemv_chain_source(name, body, e_modes, rs, w_out, C, RG, store_r, y1d is not None)
+    skey = "".join("1" if s else "0" for s in out_store)
+    name = (
+        f"gchain_{_body_key(body)}_{''.join(e_modes)}_{rkey}_w{w_out}_c{C}_g{RG}_{int(store_r)}{int(y1d is not None)}"
+        f"_s{skey}_{'n' if scatter_out is None else scatter_out}"
+    ).replace("-", "x")
+    src = codegen.gemv_chain_source(name, body, e_modes, rs, w_out, C, RG, store_r, y1d is not None, out_store, scatter_out)
     fn = kernel_cache.get_function(src, name)
     ngroups = (N + RG - 1) // RG
-    grid = max(1, min((ngroups + 3) // 4, MAX_GRID))
+    grid = max(1, min((ngroups + 3) // 4, CHAIN_GRID))
     args = [("q", N), ("q", K), ("q", A.ptr), ("q", A.strides[0]), ("q", x1.ptr), ("q", y1d.ptr if y1d is not None else 0), ("d", alpha1), ("d", beta1)]
-    args += [("q", a.ptr) for a in e_ins]
-    outs = []
+    for v in e_vals:
+        if v is None:
+            continue
+        if isinstance(v, tuple):
+            args += [("q", v[0].ptr), ("q", v[1].ptr), ("q", v[0].shape[0])]
+        else:
+            args.append(("q", v.ptr))
     r_out = None
     if store_r:
         r_out = DeviceArray.empty((N,), "float64")
@@ -91,13 +134,19 @@ def gemv_chain(node, inputs, env):
     parts = alloc_partials(spec, grid)
     stored = [None] * nout
     for k in range(nout):
-        if spec[k] is None:
+        if spec[k] is not None:
+            args.append(("q", parts[k].ptr))
+        elif out_store[k]:
             stored[k] = DeviceArray.empty((N,), body["out_dtypes"][k])
             args.append(("q", stored[k].ptr))
-        else:
-            args.append(("q", parts[k].ptr))
     partT = DeviceArray.empty((grid, K), "float64")
     args.append(("q", partT.ptr))
+    partS = None
+    if scatter_out is not None:
+        bins = base.shape[0]
+        partS = DeviceArray.empty((grid, bins), "float64")
+        args += [("q", sidx.ptr), ("q", bins), ("q", partS.ptr)]
+    args.append(("q", _status_ptr(env)))
     buf = struct.pack("<" + "".join(a[0] for a in args), *[a[1] for a in args])
     kt = env.kernel_timer
     tok = kt.begin() if kt is not None else None
@@ -107,21 +156,44 @@ def gemv_chain(node, inputs, env):
     finals = finish_partials(env, spec, parts, grid)
     res = [r_out] if store_r else []
     for k in range(nout):
-        res.append(stored[k] if spec[k] is None else finals[k])
+        res.append(finals[k] if spec[k] is not None else stored[k])
     res.append(partT)
+    if scatter_out is not None:
+        res.append(partS)
     return res
 
 
-def _fallback(node, env, alpha1, A, x1, beta1, y1d, e_ins):
-    """Three launches, two passes over A (exactly the unfused graph)."""
+_STATUS = [None]
+
+
+def _status_ptr(env) -> int:
+    """device address of the runtime's error flag (read + cleared by pthip_check_status)"""
+    if _STATUS[0] is None:
+        _STATUS[0] = env.lib.pthip_status_ptr()
+    return _STATUS[0]
+
+
+def _fallback(node, env, alpha1, A, x1, beta1, y1d, e_vals, sidx, base):
+    """Unfused launches, two passes over A (exactly the original graph)."""
     p = node.params
     body, spec, r_pos, w_out, store_r = p["scalar"], p["reduce"], p["r_pos"], p["w_out"], p["store_r"]
+    scatter_out = p.get("scatter_out")
     N, K = A.shape
     r = gemv_device(env, alpha1, A, x1, beta1, y1d)
-    ins = list(e_ins)
-    ins.insert(r_pos, r)
-    shape = (N,)
-    outs, parts, grid = launch_elemwise(body, ins, shape, body["out_dtypes"], spec, env)
+    ins = []
+    for v in e_vals:
+        if v is None:
+            ins.append(r)
+        elif isinstance(v, tuple):
+            table, idx = v
+            g = DeviceArray.empty((idx.shape[0],), table.dtype)
+            if g.size:
+                tc = table.contiguous()
+                ffi.check(env.lib.pthip_take_rows(table.itemsize, idx.shape[0], 1, tc.ptr, tc.shape[0], 1, idx.contiguous().ptr, g.ptr))
+            ins.append(g)
+        else:
+            ins.append(v)
+    outs, parts, grid = launch_elemwise(body, ins, (N,), body["out_dtypes"], spec, env)
     finals = finish_partials(env, spec, parts, grid) if grid else [None] * len(spec)
     res = [r] if store_r else []
     for k, sp in enumerate(spec):
@@ -135,6 +207,21 @@ def _fallback(node, env, alpha1, A, x1, beta1, y1d, e_ins):
     At = A.view((K, N), (A.strides[1], A.strides[0]))
     t = gemv_device(env, 1.0, At, w, 0.0, None)
     res.append(t.view((1, K), (K, 1)))
+    if scatter_out is not None:
+        bins = base.shape[0]
+        acc = DeviceArray.empty((bins,), "float64")
+        ffi.check(env.lib.pthip_memset(acc.ptr, 0, acc.nbytes))
+        n_idx = sidx.shape[0]
+        if n_idx and bins:
+            lib = env.lib
+            ws_bytes = lib.pthip_scatter_rows_workspace(n_idx, bins, 1)
+            ws = DeviceArray.empty((ws_bytes,), "uint8") if ws_bytes else None
+            sv = outs[scatter_out].contiguous()
+            ffi.check(
+                lib.pthip_scatter_rows(ffi.np_dtype_code("float64"), 1, n_idx, 1, acc.ptr, bins, sidx.contiguous().ptr, sv.ptr, 1,
+                                       ws.ptr if ws is not None else None, ws_bytes)
+            )
+        res.append(acc.view((1, bins), (bins, 1)))
     return res
 
 

@@ -187,7 +187,19 @@ def fuse_gemv_chain(g: Graph) -> Graph:
       accumulates ``A.T@w`` from the same registers → per-workgroup partials;
     * ``GemvFinish`` (placed where the second Gemv was): fixed-order sum of the
       partials with the ``alpha2/beta2/y2`` epilogue.
+
+    Two neighbours are absorbed as well when present (the reference's
+    numba-only ``FusedElemwise`` idea, tensor/rewriting/fused_elemwise.py):
+
+    * a gather feeding the scalar graph, ``table[idx]`` (``AdvancedSubtensor`` on axis 0 of
+      a vector, sole consumer) is read inside the kernel (input mode ``G``);
+    * the scatter-add of one of its vector outputs, ``inc_subtensor(base[idx], o)``
+      (``AdvancedIncSubtensor``, the gradient of such a gather), is accumulated in the
+      same pass into per-workgroup bin partials and finished by a second ``GemvFinish``
+      (``out = base + Σ partials``) where the scatter node was.
     """
+    from pytensor_amd.ir import Var
+
     producer = {}
     for k, n in enumerate(g.nodes):
         for o in n.outputs:
@@ -199,7 +211,15 @@ def fuse_gemv_chain(g: Graph) -> Graph:
     out_set = set(g.outputs)
     replace = {}  # node index -> new Node or None (removed)
     used = set()
-    new_vars = []
+    new_vars = {}
+    next_id = [max(g.vars) + 1]
+
+    def fresh(dtype, shape, const=None, name=None):
+        vid = next_id[0]
+        next_id[0] += 1
+        new_vars[vid] = Var(vid, dtype, shape, "tensor", const, name)
+        return vid
+
     for k2, n2 in enumerate(g.nodes):
         if n2.op != "Gemv":
             continue
@@ -233,28 +253,95 @@ def fuse_gemv_chain(g: Graph) -> Graph:
         w_out = ne.outputs.index(w)
         if spec[w_out] is not None:
             continue
-        e_ins = [i for pos, i in enumerate(ne.inputs) if pos != r_pos]
-        part = max(g.vars) + 1 + len(new_vars)
-        new_vars.append((part, "float64"))
-        chain = Node(
-            "GemvChain",
-            {"scalar": ne.params["scalar"], "reduce": spec, "r_pos": r_pos, "w_out": w_out, "store_r": store_r},
-            list(n1.inputs) + e_ins,
-            ([r] if store_r else []) + list(ne.outputs) + [part],
-        )
-        finish = Node("GemvFinish", {}, [part, y2, a2, b2], list(n2.outputs))
+        # ---- gathers feeding the scalar graph --------------------------------------
+        gather = []  # positions (in the elementwise input numbering) read as table[idx]
+        e_ins = []
+        removed = []
+        for pos, v in enumerate(ne.inputs):
+            if pos == r_pos:
+                continue
+            kp = producer.get(v)
+            P = g.nodes[kp] if kp is not None else None
+            if (
+                P is not None
+                and P.op == "AdvancedSubtensor"
+                and P.params["idx_list"] == [0]
+                and len(P.inputs) == 2
+                and g.vars[P.inputs[0]].ndim == 1
+                and g.vars[P.inputs[1]].ndim == 1
+                and g.vars[P.inputs[1]].dtype == "int64"
+                and consumers.get(v, []) == [ke]
+                and v not in out_set
+                and kp not in used
+            ):
+                gather.append(pos)
+                e_ins += [P.inputs[0], P.inputs[1]]
+                removed.append(kp)
+            else:
+                e_ins.append(v)
+        # ---- scatter-add of a stored vector output -----------------------------------
+        scatter = None
+        for pos_o, o in enumerate(ne.outputs):
+            if spec[pos_o] is not None or g.vars[o].ndim != 1 or g.vars[o].dtype != "float64":
+                continue
+            for ks in consumers.get(o, []):
+                S = g.nodes[ks]
+                if (
+                    S.op == "AdvancedIncSubtensor"
+                    and ks not in used
+                    and S.params["idx_list"] == [0]
+                    and not S.params["set_instead_of_inc"]
+                    and not S.params.get("ignore_duplicates")
+                    and len(S.inputs) == 3
+                    and S.inputs[1] == o
+                    and g.vars[S.inputs[0]].ndim == 1
+                    and g.vars[S.inputs[0]].dtype == "float64"
+                    and g.vars[S.inputs[2]].dtype == "int64"
+                    and producer.get(S.inputs[2], -1) < ke
+                ):
+                    scatter = (pos_o, ks, S)
+                    break
+            if scatter:
+                break
+        # which vector outputs must still be written to HBM
+        fused_consumers = {k2} | ({scatter[1]} if scatter else set())
+        out_store = []
+        for pos_o, o in enumerate(ne.outputs):
+            if spec[pos_o] is not None:
+                out_store.append(False)
+            else:
+                out_store.append(o in out_set or any(c not in fused_consumers for c in consumers.get(o, [])))
+        part = fresh("float64", (None, None), name="gemv_chain_partials")
+        chain_inputs = list(n1.inputs) + e_ins
+        chain_outputs = ([r] if store_r else []) + list(ne.outputs) + [part]
+        params = {
+            "scalar": ne.params["scalar"], "reduce": spec, "r_pos": r_pos, "w_out": w_out,
+            "store_r": store_r, "gather": gather, "out_store": out_store, "scatter_out": None,
+        }
+        if scatter:
+            pos_o, ks, S = scatter
+            partS = fresh("float64", (None, None), name="gemv_chain_scatter_partials")
+            chain_inputs.append(S.inputs[2])  # the scatter index vector (last input)
+            chain_inputs.append(S.inputs[0])  # base: only its length is used by the chain
+            chain_outputs.append(partS)
+            params["scatter_out"] = pos_o
+            import numpy as _np
+
+            one = fresh("float64", (), const=_np.asarray(1.0), name="one")
+            replace[ks] = Node("GemvFinish", {}, [partS, S.inputs[0], one, one], list(S.outputs))
+            used.add(ks)
         replace[k1] = None
-        replace[ke] = chain
-        replace[k2] = finish
+        for kp in removed:
+            replace[kp] = None
+            used.add(kp)
+        replace[ke] = Node("GemvChain", params, chain_inputs, chain_outputs)
+        replace[k2] = Node("GemvFinish", {}, [part, y2, a2, b2], list(n2.outputs))
         used.update((k1, ke, k2))
     if not replace:
         return g
-    from pytensor_amd.ir import Var
-
     out = Graph(name=g.name)
     out.vars = dict(g.vars)
-    for vid, dt in new_vars:
-        out.vars[vid] = Var(vid, dt, (None, None), "tensor", None, "gemv_chain_partials")
+    out.vars.update(new_vars)
     out.inputs = list(g.inputs)
     out.outputs = list(g.outputs)
     for k, n in enumerate(g.nodes):
@@ -263,7 +350,31 @@ def fuse_gemv_chain(g: Graph) -> Graph:
                 out.nodes.append(replace[k])
         else:
             out.nodes.append(n)
+    # the fused node may now depend on values produced after the elementwise node's old
+    # position (the base of the absorbed scatter): restore a valid order
+    out.nodes = _stable_toposort(out.nodes)
     return out
+
+
+def _stable_toposort(nodes):
+    """Kahn's algorithm that keeps the given order wherever dependencies allow."""
+    produced_by = {}
+    for k, n in enumerate(nodes):
+        for o in n.outputs:
+            produced_by[o] = k
+    deps = [set(produced_by[v] for v in n.inputs if v in produced_by) - {k} for k, n in enumerate(nodes)]
+    done, order = set(), []
+    pending = list(range(len(nodes)))
+    while pending:
+        for k in pending:
+            if deps[k] <= done:
+                order.append(k)
+                done.add(k)
+                pending.remove(k)
+                break
+        else:  # pragma: no cover
+            raise RuntimeError("cycle in lowered graph")
+    return [nodes[k] for k in order]
 
 
 # ---------------------------------------------------------------------------

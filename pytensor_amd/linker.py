@@ -51,7 +51,11 @@ class HipLinker(JITLinker):
     def fgraph_convert(self, fgraph, input_storage=None, storage_map=None, **kwargs):
         from pytensor_amd.lower import lower_fgraph
 
-        graph = lower_fgraph(fgraph)
+        # No silent CPU fallback: an Op without a device lowering is an error unless the user
+        # opts in to the D2H -> Op.perform -> H2D detour (PTHIP_ALLOW_HOST_PERFORM=1).
+        import os
+
+        graph = lower_fgraph(fgraph, allow_host_fallback=os.environ.get("PTHIP_ALLOW_HOST_PERFORM") == "1")
         self.last_ir = graph
         return graph
 

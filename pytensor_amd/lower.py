@@ -7,10 +7,11 @@ emitting Python source it records, per ``Apply`` node in toposort order, the
 reference ``Op`` class name and its ``__props__`` so the executor / oracle can
 interpret them without PyTensor.
 
-Needs PyTensor importable.  Ops without a device handler lower to a
-``HostPerform`` node that carries the live ``Op`` (not serialisable): the
-executor then does D2H → ``Op.perform`` → H2D for that node, mirroring numba's
-object-mode fallback (pytensor/link/numba/dispatch/basic.py:228-263).
+Needs PyTensor importable.  Ops without a device lowering raise
+``NotImplementedError`` at compile time.  Only with ``PTHIP_ALLOW_HOST_PERFORM=1``
+do they lower to a ``HostPerform`` node carrying the live ``Op`` (not serialisable;
+D2H → ``Op.perform`` → H2D, like numba's object-mode fallback,
+pytensor/link/numba/dispatch/basic.py:228-263) — never on the measured paths.
 """
 
 from __future__ import annotations
@@ -355,7 +356,7 @@ def _var_spec(v):
     raise NotImplementedError(f"unsupported variable type {t!r} for the hip linker")
 
 
-def lower_fgraph(fgraph, name="graph", allow_host_fallback=True) -> Graph:
+def lower_fgraph(fgraph, name="graph", allow_host_fallback=False) -> Graph:
     g = Graph(name=name)
     vid = {}
 
@@ -381,7 +382,10 @@ def lower_fgraph(fgraph, name="graph", allow_host_fallback=True) -> Graph:
         lowered = hip_funcify(node.op, node, g)
         if lowered is None:
             if not allow_host_fallback:
-                raise NotImplementedError(f"no hip lowering for {node.op}")
+                raise NotImplementedError(
+                    f"hip linker: no device lowering for {node.op} (set PTHIP_ALLOW_HOST_PERFORM=1 to run it "
+                    "through Op.perform on the host)"
+                )
             g.add_node("HostPerform", {"op": node.op, "node": node, "name": str(node.op)}, ins, outs)
         else:
             g.add_node(lowered[0], lowered[1], ins, outs)
