@@ -169,6 +169,12 @@ int pthip_ger(int dtype, int64_t M, int64_t N, double alpha, const void* A, int6
  *      CholeskySolve potrs solvers/psd.py:35-53).  Row-major n×n per batch item, contiguous.
  *      Failure (non-PD / singular) => the item's result is NaN-filled. ---- */
 int pthip_potrf(int dtype, int lower, int64_t batch, int64_t n, const void* A, void* L);
+/* Cholesky(lower) fused with its first triangular solve, x = L^-1 b (b, x: batch x n): the
+ * factor stays in LDS between the two (Cholesky -> SolveTriangular(L, b) of a Gaussian logp).
+ * Only the LDS-resident size class (n <= ~140 fp64 / ~200 fp32); callers fall back to
+ * pthip_potrf + pthip_trsm otherwise. */
+int pthip_potrf_trsv(int dtype, int64_t batch, int64_t n, const void* A, const void* b, void* L,
+                     void* x);
 /* solve op(T) X = B, T triangular n×n (strided), B n×nrhs (contiguous row-major), out contiguous */
 int pthip_trsm(int dtype, int lower, int trans, int unit_diag, int64_t batch, int64_t n,
                int64_t nrhs, const void* T, int64_t sTb, int64_t sT0, int64_t sT1, const void* B,

@@ -753,3 +753,11 @@ def _gemv_finish(p, inputs, node, graph):
 def _seq_dot22(p, inputs, node, graph):
     seq, W = inputs
     return [np.matmul(seq, W)]
+
+
+@op("CholeskyTrsv")
+def _cholesky_trsv(p, inputs, node, graph):
+    S, b = inputs
+    L = _cholesky({"lower": True}, [S], node, graph)[0]
+    x = _solve_tri({"lower": True, "unit_diagonal": False, "b_ndim": 1}, [L, b], node, graph)[0]
+    return [L, x]

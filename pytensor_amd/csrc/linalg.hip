@@ -44,13 +44,80 @@ template <class T> __device__ __forceinline__ T bcast_lane(T v, int src) {
   }
 }
 
+// Wave-synchronous substitution T x = b with T resident in LDS (W, leading dimension ld).
+// Called by ONE wave (64 lanes, RPL rows per lane, n <= 64*RPL); no barriers.  The chain per
+// step is broadcast(r_k) -> multiply by the prefetched 1/t_kk -> fma; column k+1 and its
+// pivot reciprocal are fetched while step k resolves.
+template <class T, int RPL>
+__device__ __forceinline__ void wave_trsv(const T* __restrict__ W, int ld, int n,
+                                          const T* __restrict__ b, T* __restrict__ x, int lower,
+                                          int unit, bool poisoned) {
+  const int lane = threadIdx.x & 63;
+  T r[RPL];
+#pragma unroll
+  for (int q = 0; q < RPL; q++) {
+    const int i = lane + 64 * q;
+    r[q] = i < n ? b[i] : T(0);
+  }
+  bool fail = poisoned;
+  T col[RPL], dkk, rd;
+  {
+    const int k0 = lower ? 0 : n - 1;
+    dkk = unit ? T(1) : W[k0 * ld + k0];
+    rd = T(1) / dkk;
+#pragma unroll
+    for (int q = 0; q < RPL; q++) {
+      const int i = lane + 64 * q;
+      col[q] = i < n ? W[i * ld + k0] : T(0);
+    }
+  }
+  for (int s = 0; s < n; s++) {
+    const int k = lower ? s : n - 1 - s;
+    T ncol[RPL], ndkk = T(1), nrd = T(1);
+    if (s + 1 < n) {
+      const int kn = lower ? k + 1 : k - 1;
+      ndkk = unit ? T(1) : W[kn * ld + kn];
+      nrd = T(1) / ndkk;
+#pragma unroll
+      for (int q = 0; q < RPL; q++) {
+        const int i = lane + 64 * q;
+        ncol[q] = i < n ? W[i * ld + kn] : T(0);
+      }
+    }
+    if (dkk == T(0)) fail = true;  // trtrs: exact singularity
+    T rk = T(0);
+#pragma unroll
+    for (int q = 0; q < RPL; q++)
+      if ((k >> 6) == q) rk = r[q];
+    const T xk = bcast_lane(rk, k & 63) * rd;  // k is wave-uniform: v_readlane
+#pragma unroll
+    for (int q = 0; q < RPL; q++) {
+      const int i = lane + 64 * q;
+      if (i == k) r[q] = xk;
+      else if (lower ? i > k : i < k) r[q] -= col[q] * xk;
+    }
+    dkk = ndkk;
+    rd = nrd;
+#pragma unroll
+    for (int q = 0; q < RPL; q++) col[q] = ncol[q];
+  }
+  const T nanv = (T)__builtin_nan("");
+#pragma unroll
+  for (int q = 0; q < RPL; q++) {
+    const int i = lane + 64 * q;
+    if (i < n) x[i] = fail ? nanv : r[q];
+  }
+}
+
 // ---------------------------------------------------------------------------------
-// blocked LDS-resident Cholesky
+// blocked LDS-resident Cholesky (optionally followed by the first triangular solve with
+// the factor still in LDS: rhs != NULL  =>  xout = L^-1 rhs, lower factor only)
 // ---------------------------------------------------------------------------------
 template <class T>
 __global__ __launch_bounds__(BLOCK) void potrf_lds_kernel(T* __restrict__ Lout,
                                                          const T* __restrict__ Ain, int n,
-                                                         int lower) {
+                                                         int lower, const T* __restrict__ rhs,
+                                                         T* __restrict__ xout) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ int s_fail;
   T* W = (T*)smem_raw;
@@ -203,6 +270,10 @@ __global__ __launch_bounds__(BLOCK) void potrf_lds_kernel(T* __restrict__ Lout,
     else v = (j >= i) ? W[j * ld + i] : T(0);
     Lo[e] = v;
   }
+  // fused SolveTriangular(L, b): the lower factor is still in LDS — no second launch, no
+  // re-staging of the 128 KiB matrix (the solve alone is ~5 us of a ~50-70 us trsv launch)
+  if (rhs != nullptr && tid < 64)
+    wave_trsv<T, 4>(W, ld, n, rhs + mat * (long long)n, xout + mat * (long long)n, 1, 0, failed);
 }
 
 // global-memory fallback (n too large for LDS): unblocked right-looking, one workgroup
@@ -292,66 +363,7 @@ __global__ __launch_bounds__(BLOCK) void trsv_lds_kernel(T* __restrict__ Xout,
   }
   __syncthreads();
   if (threadIdx.x >= 64) return;  // one wave solves; no barriers below
-  const int lane = threadIdx.x;
-  T r[RPL];  // rows lane + 64*q
-#pragma unroll
-  for (int q = 0; q < RPL; q++) {
-    const int i = lane + 64 * q;
-    r[q] = i < n ? b[i] : T(0);
-  }
-  // The dependency chain per step is only  broadcast(r_k) -> multiply -> fma: the matrix
-  // column k+1 AND the reciprocal of its pivot are fetched/computed while step k's chain
-  // resolves (the fp64 divide is a ~100-cycle sequence; as 1/d it leaves the chain;
-  // x*(1/d) is within 1 ulp of x/d).
-  bool fail = false;
-  T col[RPL], dkk, rd;
-  {
-    const int k0 = lower ? 0 : n - 1;
-    dkk = unit ? T(1) : W[k0 * ld + k0];
-    rd = T(1) / dkk;
-#pragma unroll
-    for (int q = 0; q < RPL; q++) {
-      const int i = lane + 64 * q;
-      col[q] = i < n ? W[i * ld + k0] : T(0);
-    }
-  }
-  for (int s = 0; s < n; s++) {
-    const int k = lower ? s : n - 1 - s;
-    // prefetch the next column (independent of the chain)
-    T ncol[RPL], ndkk = T(1), nrd = T(1);
-    if (s + 1 < n) {
-      const int kn = lower ? k + 1 : k - 1;
-      ndkk = unit ? T(1) : W[kn * ld + kn];
-      nrd = T(1) / ndkk;
-#pragma unroll
-      for (int q = 0; q < RPL; q++) {
-        const int i = lane + 64 * q;
-        ncol[q] = i < n ? W[i * ld + kn] : T(0);
-      }
-    }
-    if (dkk == T(0)) fail = true;  // trtrs: exact singularity
-    T rk = T(0);
-#pragma unroll
-    for (int q = 0; q < RPL; q++)
-      if ((k >> 6) == q) rk = r[q];
-    const T xk = bcast_lane(rk, k & 63) * rd;  // k is wave-uniform: v_readlane
-#pragma unroll
-    for (int q = 0; q < RPL; q++) {
-      const int i = lane + 64 * q;
-      if (i == k) r[q] = xk;
-      else if (lower ? i > k : i < k) r[q] -= col[q] * xk;
-    }
-    dkk = ndkk;
-    rd = nrd;
-#pragma unroll
-    for (int q = 0; q < RPL; q++) col[q] = ncol[q];
-  }
-  const T nanv = (T)__builtin_nan("");
-#pragma unroll
-  for (int q = 0; q < RPL; q++) {
-    const int i = lane + 64 * q;
-    if (i < n) x[i] = fail ? nanv : r[q];
-  }
+  wave_trsv<T, RPL>(W, ld, n, b, x, lower, unit, false);
 }
 
 // generic (any n, nrhs): one thread per right-hand-side column, row-oriented substitution.
@@ -386,18 +398,23 @@ __global__ __launch_bounds__(BLOCK) void trsm_kernel(T* __restrict__ Xout,
 }
 
 template <class T>
-int potrf_typed(int lower, long long batch, long long n, const void* A, void* L) {
+int potrf_typed(int lower, long long batch, long long n, const void* A, void* L,
+                const void* rhs = nullptr, void* xout = nullptr) {
   hipStream_t st = pthip::ctx().stream;
   if (batch == 0 || n == 0) return 0;
+  if (rhs != nullptr && (!lower || n > 256))
+    return pthip::set_error("pthip_potrf_trsv: fused solve needs the lower factor and n <= 256");
   const size_t ld = (size_t)(n | 1);
   const size_t need = (size_t)n * ld * sizeof(T);
   if (need <= 160 * 1024 - 256) {
     auto k = potrf_lds_kernel<T>;
     if (need > 64 * 1024)
       PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-    hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(BLOCK), need, st, (T*)L, (const T*)A, (int)n, lower);
+    hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(BLOCK), need, st, (T*)L, (const T*)A, (int)n, lower,
+                       (const T*)rhs, (T*)xout);
     return pthip::post_launch("potrf_lds");
   }
+  if (rhs != nullptr) return pthip::set_error("pthip_potrf_trsv: matrix does not fit the LDS-resident kernel");
   void* scratch = nullptr;
   int r = pthip_alloc((size_t)batch * n * n * sizeof(T), &scratch);
   if (r) return r;
@@ -449,6 +466,14 @@ int pthip_potrf(int dtype, int lower, int64_t batch, int64_t n, const void* A, v
   if (dtype == PTHIP_F64) return potrf_typed<double>(lower, batch, n, A, L);
   if (dtype == PTHIP_F32) return potrf_typed<float>(lower, batch, n, A, L);
   return pthip::set_error("pthip_potrf: dtype %d not supported", dtype);
+}
+
+int pthip_potrf_trsv(int dtype, int64_t batch, int64_t n, const void* A, const void* b, void* L,
+                     void* x) {
+  PTHIP_REQUIRE_INIT();
+  if (dtype == PTHIP_F64) return potrf_typed<double>(1, batch, n, A, L, b, x);
+  if (dtype == PTHIP_F32) return potrf_typed<float>(1, batch, n, A, L, b, x);
+  return pthip::set_error("pthip_potrf_trsv: dtype %d not supported", dtype);
 }
 
 int pthip_trsm(int dtype, int lower, int trans, int unit_diag, int64_t batch, int64_t n,

@@ -97,6 +97,28 @@ def cholesky(node, inputs, env):
     return [cholesky_device(env, env.to_device(inputs[0]), node.params["lower"])]
 
 
+@handler("CholeskyTrsv")
+def cholesky_trsv(node, inputs, env):
+    """``L = cholesky(S, lower); x = L^-1 b`` in one launch (fusion.fuse_cholesky_solve); falls
+    back to the two separate kernels when the matrix does not fit the LDS-resident one."""
+    S, b = (env.to_device(i) for i in inputs)
+    _require_float(S, "Cholesky")
+    n = S.shape[-1]
+    if S.shape[0] != n:
+        raise ValueError("Cholesky: matrix must be square")
+    if b.shape != (n,):
+        raise ValueError(f"SolveTriangular: incompatible shapes {S.shape} and {b.shape}")
+    fits = 0 < n <= 256 and n * (n | 1) * S.itemsize <= 160 * 1024 - 256 and str(b.dtype) == str(S.dtype)
+    if not fits:
+        L = cholesky_device(env, S, True)
+        return [L, trsm_device(env, L, b, True, False, 1)]
+    Sc, bc = S.contiguous(), b.contiguous()
+    L = DeviceArray.empty((n, n), S.dtype)
+    x = DeviceArray.empty((n,), S.dtype)
+    ffi.check(env.lib.pthip_potrf_trsv(_dt(S), 1, n, Sc.ptr, bc.ptr, L.ptr, x.ptr))
+    return [L, x]
+
+
 @handler("SolveTriangular")
 def solve_triangular(node, inputs, env):
     p = node.params

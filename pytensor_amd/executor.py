@@ -142,6 +142,9 @@ class HipExecutable:
             from pytensor_amd.fusion import hoist_scan_seq_dots
 
             self.graph = hoist_scan_seq_dots(self.graph)
+            from pytensor_amd.fusion import fuse_cholesky_solve
+
+            self.graph = fuse_cholesky_solve(self.graph)
             from pytensor_amd.fusion import segment_graph
 
             self.graph, self.segments = segment_graph(fuse_gemv_chain(self.graph))
@@ -174,7 +177,7 @@ class HipExecutable:
     _FRESH_OPS = frozenset(
         ["Alloc", "AllocEmpty", "Elemwise", "ElemwiseReduce", "GemvChain", "AdvancedSubtensor", "Gemv", "Gemm", "Dot22",
          "Dot22Scalar", "BatchedDot", "Ger", "Join", "DeepCopyOp", "IncSubtensor", "AdvancedIncSubtensor",
-         "Cholesky", "SolveTriangular", "CholeskySolve", "Blockwise", "GemvFinish", "SeqDot22"]
+         "Cholesky", "SolveTriangular", "CholeskySolve", "Blockwise", "GemvFinish", "SeqDot22", "CholeskyTrsv"]
     )
 
     def _compute_donations(self):

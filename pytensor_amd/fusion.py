@@ -76,7 +76,7 @@ def fuse_elemwise_reduce(g: Graph) -> Graph:
     return out
 
 
-LATENCY_OPS = {"Cholesky", "SolveTriangular", "CholeskySolve", "Blockwise"}
+LATENCY_OPS = {"Cholesky", "SolveTriangular", "CholeskySolve", "Blockwise", "CholeskyTrsv"}
 
 
 def stream_classes(g: Graph, staged_inputs=()):
@@ -451,3 +451,48 @@ def hoist_scan_seq_dots(g: Graph) -> Graph:
         out.nodes.append(Node("Scan", {"info": info, "inner": new_inner}, new_inputs, list(n.outputs)))
         changed = True
     return out if changed else g
+
+
+# ---------------------------------------------------------------------------
+# Cholesky followed by its first triangular solve: keep the factor in LDS
+# ---------------------------------------------------------------------------
+
+
+def fuse_cholesky_solve(g: Graph) -> Graph:
+    """``L = cholesky(S); x = solve_triangular(L, b, lower=True)`` (the whitening step of a
+    multivariate-normal logp) → one ``CholeskyTrsv`` node: the 128 KiB factor is still in
+    the CU's LDS when the substitution runs, so the second launch and its re-staging of
+    the matrix disappear (reference: two LAPACK calls, cholesky.py:52-83 + triangular.py:41-71).
+    ``L`` is still written out for its other consumers."""
+    producer = {}
+    for k, n in enumerate(g.nodes):
+        for o in n.outputs:
+            producer[o] = k
+    replace = {}
+    for ks, ns in enumerate(g.nodes):
+        if ns.op != "SolveTriangular":
+            continue
+        p = ns.params
+        if not p["lower"] or p["unit_diagonal"] or p["b_ndim"] != 1:
+            continue
+        kc = producer.get(ns.inputs[0])
+        if kc is None or kc in replace or g.nodes[kc].op != "Cholesky" or not g.nodes[kc].params["lower"]:
+            continue
+        nc = g.nodes[kc]
+        if g.vars[nc.inputs[0]].ndim != 2 or g.vars[ns.inputs[1]].ndim != 1:
+            continue
+        replace[kc] = Node("CholeskyTrsv", {}, [nc.inputs[0], ns.inputs[1]], [nc.outputs[0], ns.outputs[0]])
+        replace[ks] = None
+    if not replace:
+        return g
+    out = Graph(name=g.name)
+    out.vars, out.inputs, out.outputs = g.vars, list(g.inputs), list(g.outputs)
+    nodes = []
+    for k, n in enumerate(g.nodes):
+        if k in replace:
+            if replace[k] is not None:
+                nodes.append(replace[k])
+        else:
+            nodes.append(n)
+    out.nodes = _stable_toposort(nodes)
+    return out

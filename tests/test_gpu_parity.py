@@ -44,3 +44,31 @@ def test_unfused_equals_fused(hip, name):
     b = HipExecutable(g, fuse=False)(*ins)
     for k, (x, y) in enumerate(zip(a, b)):
         assert_parity(x, y, meta["rtol"], f"{name} out{k} fused vs unfused")
+
+
+@pytest.mark.parametrize("dtype,n", [("float64", 1), ("float64", 7), ("float64", 64), ("float64", 128), ("float64", 141),
+                                     ("float32", 33), ("float32", 200)])
+def test_potrf_trsv_fused_kernel(hip, dtype, n):
+    """The fused Cholesky + forward-substitution launch against LAPACK potrf/trtrs."""
+    import scipy.linalg
+
+    from pytensor_amd.device import DeviceArray
+
+    rng = np.random.default_rng(n)
+    A = rng.normal(size=(n, n + 3))
+    S = (A @ A.T / n + np.eye(n)).astype(dtype)
+    b = rng.normal(size=n).astype(dtype)
+    dS, db = DeviceArray.from_host(S), DeviceArray.from_host(b)
+    L, x = DeviceArray.empty((n, n), dtype), DeviceArray.empty((n,), dtype)
+    lib = hip.lib()
+    hip.check(lib.pthip_potrf_trsv(hip.np_dtype_code(dtype), 1, n, dS.ptr, db.ptr, L.ptr, x.ptr))
+    Lr = scipy.linalg.cholesky(S, lower=True)
+    xr = scipy.linalg.solve_triangular(Lr, b, lower=True)
+    rtol = 1e-11 if dtype == "float64" else 2e-4
+    np.testing.assert_allclose(L.to_host(), Lr, rtol=rtol, atol=rtol)
+    np.testing.assert_allclose(x.to_host(), xr, rtol=rtol, atol=rtol)
+    # not positive definite: the factor and the solve are NaN (reference on_error="nan", cholesky.py:76-83)
+    S[n // 2, n // 2] = -1.0
+    dS = DeviceArray.from_host(S)
+    hip.check(lib.pthip_potrf_trsv(hip.np_dtype_code(dtype), 1, n, dS.ptr, db.ptr, L.ptr, x.ptr))
+    assert np.isnan(L.to_host()).all() and np.isnan(x.to_host()).all()

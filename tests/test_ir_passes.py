@@ -8,6 +8,7 @@ import pytest
 
 import np_graph
 from pytensor_amd.fusion import (
+    fuse_cholesky_solve,
     fuse_elemwise_reduce,
     fuse_gemv_chain,
     hoist_scan_seq_dots,
@@ -19,6 +20,7 @@ from util import assert_parity, golden_cases, load_case
 def _pipeline(g):
     g = fuse_elemwise_reduce(g)
     g = hoist_scan_seq_dots(g)
+    g = fuse_cholesky_solve(g)
     g = fuse_gemv_chain(g)
     g, seg = segment_graph(g)
     return g, seg
@@ -45,7 +47,7 @@ def test_c4_gets_the_one_pass_gemv_chain_and_two_segments():
     assert seg is not None and seg[0] == 0 and set(seg) == {0, 1, 2} and seg == sorted(seg)
     a_ops = {n.op for n, s in zip(g2.nodes, seg) if s == 0}
     b_ops = {n.op for n, s in zip(g2.nodes, seg) if s == 1}
-    assert {"Cholesky", "SolveTriangular"} <= a_ops and "GemvChain" in b_ops
+    assert {"CholeskyTrsv", "SolveTriangular"} <= a_ops and "GemvChain" in b_ops and "Cholesky" not in ops
     # nothing in A or B consumes a value produced in the other
     prod = {}
     for n, s in zip(g2.nodes, seg):
