@@ -45,61 +45,75 @@ template <class T> __device__ __forceinline__ T bcast_lane(T v, int src) {
 }
 
 // Wave-synchronous substitution T x = b with T resident in LDS (W, leading dimension ld).
-// Called by ONE wave (64 lanes, RPL rows per lane, n <= 64*RPL); no barriers.  The chain per
-// step is broadcast(r_k) -> multiply by the prefetched 1/t_kk -> fma; column k+1 and its
-// pivot reciprocal are fetched while step k resolves.
-template <class T, int RPL>
-__device__ __forceinline__ void wave_trsv(const T* __restrict__ W, int ld, int n,
-                                          const T* __restrict__ b, T* __restrict__ x, int lower,
-                                          int unit, bool poisoned) {
+// Called by ONE wave (64 lanes, RPL rows per lane, n <= 64*RPL); no barriers, no branches in
+// the step.  The system is row-scaled once, in parallel (r'_i = b_i / t_ii, t'_ik = t_ik / t_ii),
+// so the serial chain per column is only  v_readlane(r'_k) -> fma : x_k IS the scaled residual
+// of row k.  Columns are fetched from LDS eight at a time, one block ahead of the block being
+// eliminated, already masked to the strict triangle (select, not multiply: the unreferenced
+// triangle may hold anything).
+template <class T, int RPL, bool LOWER>
+__device__ __forceinline__ void wave_trsv_dir(const T* __restrict__ W, int ld, int n,
+                                              const T* __restrict__ b, T* __restrict__ x, int unit,
+                                              bool poisoned) {
+  constexpr int U = 8;
   const int lane = threadIdx.x & 63;
-  T r[RPL];
+  T r[RPL], rd[RPL];
+  bool sing = false;
 #pragma unroll
   for (int q = 0; q < RPL; q++) {
     const int i = lane + 64 * q;
-    r[q] = i < n ? b[i] : T(0);
+    const int ic = i < n ? i : n - 1;
+    const T d = unit ? T(1) : W[ic * ld + ic];
+    if (i < n && d == T(0)) sing = true;  // trtrs: exact singularity
+    rd[q] = i < n ? T(1) / d : T(0);
+    r[q] = i < n ? b[i] * rd[q] : T(0);
   }
-  bool fail = poisoned;
-  T col[RPL], dkk, rd;
-  {
-    const int k0 = lower ? 0 : n - 1;
-    dkk = unit ? T(1) : W[k0 * ld + k0];
-    rd = T(1) / dkk;
+  const bool fail = poisoned || __ballot(sing) != 0ull;
 #pragma unroll
-    for (int q = 0; q < RPL; q++) {
-      const int i = lane + 64 * q;
-      col[q] = i < n ? W[i * ld + k0] : T(0);
-    }
-  }
-  for (int s = 0; s < n; s++) {
-    const int k = lower ? s : n - 1 - s;
-    T ncol[RPL], ndkk = T(1), nrd = T(1);
-    if (s + 1 < n) {
-      const int kn = lower ? k + 1 : k - 1;
-      ndkk = unit ? T(1) : W[kn * ld + kn];
-      nrd = T(1) / ndkk;
+  for (int qq = 0; qq < RPL; qq++) {
+    const int qb = LOWER ? qq : RPL - 1 - qq;  // 64-row block holding the pivots (compile time)
+    const int kbeg = 64 * qb;
+    const int kend = (kbeg + 64) < n ? (kbeg + 64) : n;
+    const int cnt = kend - kbeg;  // pivots in this block (wave-uniform)
+    if (cnt <= 0) continue;
+    T cur[U][RPL], nxt[U][RPL];
+    auto fetch = [&](T (&dst)[U][RPL], int kk0) {
 #pragma unroll
-      for (int q = 0; q < RPL; q++) {
-        const int i = lane + 64 * q;
-        ncol[q] = i < n ? W[i * ld + kn] : T(0);
+      for (int u = 0; u < U; u++) {
+        const int kk = kk0 + u;
+        const int kkc = kk < cnt ? kk : cnt - 1;
+        const int k = LOWER ? kbeg + kkc : kend - 1 - kkc;
+#pragma unroll
+        for (int q = 0; q < RPL; q++) {
+          if (LOWER ? q < qb : q > qb) { dst[u][q] = T(0); continue; }
+          const int i = lane + 64 * q;
+          const int ic = i < n ? i : n - 1;
+          const T v = W[ic * ld + k] * rd[q];
+          // only the pivot block straddles the diagonal; rows >= n hold rd = 0 and are never
+          // broadcast or stored; pivots past the end of the block broadcast x_k = 0 instead
+          dst[u][q] = (q != qb || (LOWER ? i > k : i < k)) ? v : T(0);
+        }
       }
+    };
+    fetch(cur, 0);
+    for (int kk0 = 0; kk0 < cnt; kk0 += U) {
+      fetch(nxt, kk0 + U);  // (clamped and fully masked past the end of the block)
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int kk = kk0 + u;
+        const int kkc = kk < cnt ? kk : cnt - 1;
+        const int kl = LOWER ? kkc : cnt - 1 - kkc;  // pivot lane within the block
+        T xk = bcast_lane(r[qb], kl);                 // wave-uniform lane: v_readlane
+        if (kk >= cnt) xk = T(0);                      // (scalar select)
+#pragma unroll
+        for (int q = 0; q < RPL; q++)
+          if (LOWER ? q >= qb : q <= qb) r[q] -= cur[u][q] * xk;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int q = 0; q < RPL; q++) cur[u][q] = nxt[u][q];
     }
-    if (dkk == T(0)) fail = true;  // trtrs: exact singularity
-    T rk = T(0);
-#pragma unroll
-    for (int q = 0; q < RPL; q++)
-      if ((k >> 6) == q) rk = r[q];
-    const T xk = bcast_lane(rk, k & 63) * rd;  // k is wave-uniform: v_readlane
-#pragma unroll
-    for (int q = 0; q < RPL; q++) {
-      const int i = lane + 64 * q;
-      if (i == k) r[q] = xk;
-      else if (lower ? i > k : i < k) r[q] -= col[q] * xk;
-    }
-    dkk = ndkk;
-    rd = nrd;
-#pragma unroll
-    for (int q = 0; q < RPL; q++) col[q] = ncol[q];
   }
   const T nanv = (T)__builtin_nan("");
 #pragma unroll
@@ -107,6 +121,14 @@ __device__ __forceinline__ void wave_trsv(const T* __restrict__ W, int ld, int n
     const int i = lane + 64 * q;
     if (i < n) x[i] = fail ? nanv : r[q];
   }
+}
+
+template <class T, int RPL>
+__device__ __forceinline__ void wave_trsv(const T* __restrict__ W, int ld, int n,
+                                          const T* __restrict__ b, T* __restrict__ x, int lower,
+                                          int unit, bool poisoned) {
+  if (lower) wave_trsv_dir<T, RPL, true>(W, ld, n, b, x, unit, poisoned);
+  else wave_trsv_dir<T, RPL, false>(W, ld, n, b, x, unit, poisoned);
 }
 
 // ---------------------------------------------------------------------------------

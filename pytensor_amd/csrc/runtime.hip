@@ -173,6 +173,17 @@ int pthip_init(int device) {
   return 0;
 }
 
+// Stream 1 carries the latency-bound chain of a segmented plan (single-workgroup Cholesky /
+// triangular solves): create it at the highest queue priority so that its dispatches are not
+// queued behind the streaming kernels of stream 0.
+static hipError_t create_stream(int i) {
+  int lo = 0, hi = 0;
+  if (i == 1 && getenv("PTHIP_NO_STREAM_PRIORITY") == nullptr &&
+      hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+    return hipStreamCreateWithPriority(&g_ctx.streams[i], hipStreamNonBlocking, hi);
+  return hipStreamCreateWithFlags(&g_ctx.streams[i], hipStreamNonBlocking);
+}
+
 int pthip_device_count(int* n) {
   hipError_t e = hipGetDeviceCount(n);
   if (e != hipSuccess) {
@@ -202,7 +213,7 @@ int pthip_synchronize(void) {
 int pthip_stream_select(int i) {
   PTHIP_REQUIRE_INIT();
   if (i < 0 || i >= kMaxStreams) return set_error("pthip_stream_select: stream %d out of range", i);
-  if (!g_ctx.streams[i]) PTHIP_CHECK(hipStreamCreateWithFlags(&g_ctx.streams[i], hipStreamNonBlocking));
+  if (!g_ctx.streams[i]) PTHIP_CHECK(create_stream(i));
   g_ctx.stream = g_ctx.streams[i];
   g_ctx.current = i;
   return 0;
@@ -214,7 +225,7 @@ int pthip_stream_wait(int waiter, int signaler) {
     return set_error("pthip_stream_wait: stream out of range");
   if (waiter == signaler) return 0;
   for (int i : {waiter, signaler})
-    if (!g_ctx.streams[i]) PTHIP_CHECK(hipStreamCreateWithFlags(&g_ctx.streams[i], hipStreamNonBlocking));
+    if (!g_ctx.streams[i]) PTHIP_CHECK(create_stream(i));
   hipEvent_t ev;
   PTHIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   PTHIP_CHECK(hipEventRecord(ev, g_ctx.streams[signaler]));
@@ -371,8 +382,7 @@ int pthip_graph_launch(void* graph_exec) {
 
 int pthip_graph_launch_on(void* graph_exec, int stream) {
   if (stream < 0 || stream >= kMaxStreams) return set_error("pthip_graph_launch_on: bad stream");
-  if (!g_ctx.streams[stream])
-    PTHIP_CHECK(hipStreamCreateWithFlags(&g_ctx.streams[stream], hipStreamNonBlocking));
+  if (!g_ctx.streams[stream]) PTHIP_CHECK(create_stream(stream));
   PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, g_ctx.streams[stream]));
   return 0;
 }
@@ -381,7 +391,8 @@ int pthip_graph_launch_on(void* graph_exec, int stream) {
 // segments on their streams, and the single synchronisation of the call.
 //   segmented (ga, gb, gc != NULL): H2D -> [gb on stream 0 || ga on stream 1] -> gc on stream 0
 //   single    (only gb != NULL)   : H2D -> gb on stream 0
-// The streaming segment gb is enqueued first: it is the critical path.
+// The latency chain ga is enqueued first (its single-workgroup kernels are the critical
+// path once the streaming segment runs at HBM speed); PTHIP_PLAN_B_FIRST=1 swaps the order.
 int pthip_plan_replay(void* ga, void* gb, void* gc, void* dev_in, const void* host_in,
                       size_t in_bytes, int sync) {
   PTHIP_REQUIRE_INIT();
@@ -389,16 +400,18 @@ int pthip_plan_replay(void* ga, void* gb, void* gc, void* dev_in, const void* ho
   hipStream_t s0 = g_ctx.streams[0];
   if (in_bytes) PTHIP_CHECK(hipMemcpyAsync(dev_in, host_in, in_bytes, hipMemcpyHostToDevice, s0));
   if (ga && gc) {
-    if (!g_ctx.streams[1]) PTHIP_CHECK(hipStreamCreateWithFlags(&g_ctx.streams[1], hipStreamNonBlocking));
+    if (!g_ctx.streams[1]) PTHIP_CHECK(create_stream(1));
     hipStream_t s1 = g_ctx.streams[1];
     if (!ev_in) {
       PTHIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
       PTHIP_CHECK(hipEventCreateWithFlags(&ev_a, hipEventDisableTiming));
     }
+    static const bool a_first = getenv("PTHIP_PLAN_B_FIRST") == nullptr;
     PTHIP_CHECK(hipEventRecord(ev_in, s0));
-    PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)gb, s0));
+    if (!a_first) PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)gb, s0));
     PTHIP_CHECK(hipStreamWaitEvent(s1, ev_in, 0));
     PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)ga, s1));
+    if (a_first) PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)gb, s0));
     PTHIP_CHECK(hipEventRecord(ev_a, s1));
     PTHIP_CHECK(hipStreamWaitEvent(s0, ev_a, 0));
     PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)gc, s0));
