@@ -736,7 +736,8 @@ def _gemv_chain(p, inputs, node, graph):
     res = ([r] if p["store_r"] else []) + outs + [part]
     if p.get("scatter_out") is not None:
         sidx, base = next(it), next(it)
-        acc = np.zeros(base.shape[0], dtype="float64")
+        nbins = int(np.asarray(base).reshape(-1)[0]) if p.get("scatter_len_input") else base.shape[0]
+        acc = np.zeros(nbins, dtype="float64")
         np.add.at(acc, sidx, outs[p["scatter_out"]])  # AdvancedIncSubtensor(inc) on zeros
         res.append(acc[None, :])
     return res

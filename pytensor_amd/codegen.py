@@ -445,7 +445,10 @@ def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=
     reduce_spec = reduce_spec or [None] * nout
     params = ["long long n"]
     for k, dt in enumerate(body["in_dtypes"]):
-        params.append(f"const {CTYPE[dt]}* __restrict__ in{k}")
+        if modes[k] == "C":  # host-known scalar: travels by value in the argument block
+            params.append(f"const long long in{k}")
+        else:
+            params.append(f"const {CTYPE[dt]}* __restrict__ in{k}")
     for k, dt in enumerate(body["out_dtypes"]):
         if reduce_spec[k] is None:
             params.append(f"{CTYPE[dt]}* __restrict__ out{k}")
@@ -457,6 +460,9 @@ def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=
     for k, m in enumerate(modes):
         if m == "S":
             src.append(f"  const {CTYPE[body['in_dtypes'][k]]} s{k} = in{k}[0];")
+        elif m == "C":
+            ct = CTYPE[body["in_dtypes"][k]]
+            src.append(f"  {ct} s{k}; {{ const long long b = in{k}; __builtin_memcpy(&s{k}, &b, sizeof({ct})); }}")
     for k, rs in enumerate(reduce_spec):
         if rs is not None:
             act = CTYPE[rs[1]]

@@ -44,6 +44,59 @@ template <class T> __device__ __forceinline__ T bcast_lane(T v, int src) {
   }
 }
 
+// Stage a dense n x n matrix (fast axis contiguous, slow stride n) from HBM into LDS through
+// `put(a, c, v)` (a = slow index, c = fast index).  One workgroup cannot hide HBM latency with
+// occupancy, so it keeps 16 x 16-byte loads per thread in flight: 64 KiB per round trip, two
+// round trips for a 128 x 128 fp64 matrix (8-byte loads, 8 deep, needed eight and took ~40 us
+// next to a kernel that saturates HBM).  `wide` = 16-byte path usable (n % VEC == 0, aligned).
+template <class T, class F>
+__device__ __forceinline__ void stage_dense(const T* __restrict__ src, int n, bool wide, F&& put) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int UN = 16;
+  typedef T vec_t __attribute__((ext_vector_type(VEC)));
+  const int tid = threadIdx.x;
+  const int total = n * n;
+  if (wide) {
+    const int nv = total / VEC;
+    const vec_t* s = (const vec_t*)src;
+    for (int v0 = 0; v0 < nv; v0 += BLOCK * UN) {
+      vec_t v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; u++) {
+        const int idx = v0 + u * BLOCK + tid;
+        v[u] = s[idx < nv ? idx : nv - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < UN; u++) {
+        const int idx = v0 + u * BLOCK + tid;
+        if (idx < nv) {
+          const int e = idx * VEC;
+          const int a = e / n, c = e - a * n;
+#pragma unroll
+          for (int w = 0; w < VEC; w++) put(a, c + w, v[u][w]);
+        }
+      }
+    }
+  } else {
+    for (int e0 = 0; e0 < total; e0 += BLOCK * 8) {
+      T v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int e = e0 + u * BLOCK + tid;
+        v[u] = src[e < total ? e : total - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int e = e0 + u * BLOCK + tid;
+        if (e < total) {
+          const int a = e / n, c = e - a * n;
+          put(a, c, v[u]);
+        }
+      }
+    }
+  }
+}
+
 // Wave-synchronous substitution T x = b with T resident in LDS (W, leading dimension ld).
 // Called by ONE wave (64 lanes, RPL rows per lane, n <= 64*RPL); no barriers, no branches in
 // the step.  The system is row-scaled once, in parallel (r'_i = b_i / t_ii, t'_ik = t_ik / t_ii),
@@ -151,24 +204,12 @@ __global__ __launch_bounds__(BLOCK) void potrf_lds_kernel(T* __restrict__ Lout,
   if (tid == 0) s_fail = 0;
   // load the referenced triangle as a lower-triangular working matrix W[i][j], i >= j
   // (for `upper` the strict upper triangle is read transposed: LAPACK reads only `uplo`)
-  // (8 independent loads in flight per thread: an un-unrolled loop would serialise the
-  //  HBM/L2 latency 64 times)
-  for (int e0 = 0; e0 < n * n; e0 += BLOCK * 8) {
-    T v[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int e = e0 + u * BLOCK + tid;
-      v[u] = e < n * n ? A[e] : T(0);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int e = e0 + u * BLOCK + tid;
-      if (e < n * n) {
-        const int i = e / n, j = e - i * n;
-        if (lower) { if (i >= j) W[i * ld + j] = v[u]; }
-        else { if (j >= i) W[j * ld + i] = v[u]; }
-      }
-    }
+  {
+    const bool wide = (n % (16 / (int)sizeof(T))) == 0 && (((size_t)A) & 15) == 0;
+    if (lower)
+      stage_dense<T>(A, n, wide, [&](int i, int j, T v) { if (i >= j) W[i * ld + j] = v; });
+    else
+      stage_dense<T>(A, n, wide, [&](int i, int j, T v) { if (j >= i) W[j * ld + i] = v; });
   }
   __syncthreads();
   bool fail = false;
@@ -366,21 +407,28 @@ __global__ __launch_bounds__(BLOCK) void trsv_lds_kernel(T* __restrict__ Xout,
   T* x = Xout + mat * (long long)n;
   // stage T with the unit-stride axis across lanes (coalesced for either orientation)
   const bool rowmaj = (sT1 == 1 || sT0 != 1);
-  for (int e0 = 0; e0 < n * n; e0 += BLOCK * 8) {
-    T v[8];
+  const bool dense = rowmaj ? (sT1 == 1 && sT0 == n) : (sT0 == 1 && sT1 == n);
+  if (dense || n == 1) {
+    const bool wide = (n % (16 / (int)sizeof(T))) == 0 && (((size_t)Tg) & 15) == 0;
+    if (rowmaj) stage_dense<T>(Tg, n, wide, [&](int i, int j, T v) { W[i * ld + j] = v; });
+    else stage_dense<T>(Tg, n, wide, [&](int j, int i, T v) { W[i * ld + j] = v; });
+  } else {
+    for (int e0 = 0; e0 < n * n; e0 += BLOCK * 8) {
+      T v[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int e = e0 + u * BLOCK + threadIdx.x;
-      const int a = e / n, c = e - a * n;  // a: slow index, c: fast (unit-stride) index
-      const int i = rowmaj ? a : c, j = rowmaj ? c : a;
-      v[u] = e < n * n ? Tg[i * sT0 + j * sT1] : T(0);
-    }
+      for (int u = 0; u < 8; u++) {
+        const int e = e0 + u * BLOCK + threadIdx.x;
+        const int a = e / n, c = e - a * n;  // a: slow index, c: fast (unit-stride) index
+        const int i = rowmaj ? a : c, j = rowmaj ? c : a;
+        v[u] = e < n * n ? Tg[i * sT0 + j * sT1] : T(0);
+      }
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int e = e0 + u * BLOCK + threadIdx.x;
-      const int a = e / n, c = e - a * n;
-      const int i = rowmaj ? a : c, j = rowmaj ? c : a;
-      if (e < n * n) W[i * ld + j] = v[u];
+      for (int u = 0; u < 8; u++) {
+        const int e = e0 + u * BLOCK + threadIdx.x;
+        const int a = e / n, c = e - a * n;
+        const int i = rowmaj ? a : c, j = rowmaj ? c : a;
+        if (e < n * n) W[i * ld + j] = v[u];
+      }
     }
   }
   __syncthreads();

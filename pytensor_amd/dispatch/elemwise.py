@@ -146,6 +146,16 @@ def _grid(n_units):
     return max(1, min(g, MAX_GRID))
 
 
+def _scalar_bits(h, dtype) -> int:
+    """The bytes of a host scalar, zero-extended to the 8-byte argument slot."""
+    raw = np.asarray(h.a, dtype=dtype).reshape(()).tobytes()
+    return int.from_bytes(raw.ljust(8, b"\0"), "little", signed=True)
+
+
+def _scalar_or_device(env, i):
+    return i if isinstance(i, HostValue) and i.a.size == 1 else env.to_device(i)
+
+
 def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env):
     """Launch the fused kernel.  Returns (stored outputs or None per output,
     partial buffers or None per output, grid)."""
@@ -160,13 +170,17 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env):
     modes = []
     flat = True
     for a in ins:
-        if a.size == 1:
+        if isinstance(a, HostValue):
+            modes.append("C")  # host-known scalar: by value, no upload node in a captured plan
+        elif a.size == 1:
             modes.append("S")
         elif a.shape == tuple(out_shape) and a.is_contiguous():
             modes.append("V")
         else:
             flat = False
             break
+    if not flat:
+        ins = [env.to_device(a) for a in ins]
     bkey = _body_key(body)
     rkey = "".join("-" if r is None else r["op"][0] + r["acc_dtype"][0] + r["acc_dtype"][-1] for r in reduce_spec)
     rs = [None if r is None else (r["op"], r["acc_dtype"]) for r in reduce_spec]
@@ -185,7 +199,7 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env):
         fn = kernel_cache.get_function(src, name)
         units = (n // vec + unroll - 1) // unroll if vec > 1 else n
         grid = _grid(max(units, 1))
-        args = [n] + [a.ptr for a in ins]
+        args = [n] + [_scalar_bits(a, body["in_dtypes"][k]) if m == "C" else a.ptr for k, (a, m) in enumerate(zip(ins, modes))]
     else:
         sshape = tuple(out_shape)
         strides = []
@@ -242,6 +256,15 @@ def finish_partials(env, spec, parts, grid):
     res = [None] * len(spec)
     red = [k for k, r in enumerate(spec) if r is not None]
     if not red:
+        return res
+    if grid == 1:
+        # a single workgroup already produced the final value: no second-stage launch
+        for k in red:
+            r = spec[k]
+            if r["acc_dtype"] == r["dtype"]:
+                res[k] = parts[k].view((), (), 0)
+            else:
+                res[k] = device_reduce(env, r["op"], parts[k], 1, 1, 1, 0, 1, 0, r["acc_dtype"], r["dtype"], ())
         return res
     if _homogeneous(spec):
         r = spec[red[0]]
@@ -303,7 +326,7 @@ def elemwise(node, inputs, env):
     g = env.graph
     if _host_evaluable(body, inputs) and all(i.a.size <= HOST_MAX for i in inputs):
         return _host_eval(body, inputs)
-    ins = [env.to_device(i) for i in inputs]
+    ins = [_scalar_or_device(env, i) for i in inputs]
     shape = _broadcast_shape(node, g, ins)
     outs, _, _ = launch_elemwise(body, ins, shape, body["out_dtypes"], None, env)
     return outs
@@ -314,7 +337,7 @@ def elemwise_reduce(node, inputs, env):
     body = node.params["scalar"]
     spec = node.params["reduce"]
     g = env.graph
-    ins = [env.to_device(i) for i in inputs]
+    ins = [_scalar_or_device(env, i) for i in inputs]
     shape = _broadcast_shape(node, g, ins)
     outs, parts, grid = launch_elemwise(body, ins, shape, body["out_dtypes"], spec, env)
     finals = finish_partials(env, spec, parts, grid) if grid else [None] * len(spec)

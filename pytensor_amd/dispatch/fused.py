@@ -49,8 +49,21 @@ def _unpack(node, inputs, env):
     sidx = base = None
     if p.get("scatter_out") is not None:
         sidx = env.to_device(next(it))
-        base = env.to_device(next(it))
+        base = next(it)
+        if p.get("scatter_len_input"):
+            base = _Bins(int(np.asarray(env.to_host(base)).reshape(-1)[0]))  # zeros(n): only n exists
+        else:
+            base = env.to_device(base)
     return e_vals, sidx, base
+
+
+class _Bins:
+    """Stand-in for a never-materialised ``zeros(n)`` scatter base: just its shape."""
+
+    ndim = 1
+
+    def __init__(self, n):
+        self.shape = (n,)
 
 
 def _fast_ok(A, x1, y1, e_vals, sidx, base, N, K):

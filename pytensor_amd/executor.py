@@ -54,6 +54,14 @@ class HostValue:
     def dtype(self):
         return self.a.dtype
 
+    @property
+    def ndim(self):
+        return self.a.ndim
+
+    @property
+    def size(self):
+        return self.a.size
+
     def __repr__(self):
         return f"HostValue({self.a!r})"
 
@@ -133,21 +141,11 @@ class Env:
 class HipExecutable:
     def __init__(self, graph: Graph, resident=(), device: int | None = None, fuse=True):
         from pytensor_amd import dispatch  # registers handlers
-        from pytensor_amd.fusion import fuse_elemwise_reduce, fuse_gemv_chain
+        from pytensor_amd.passes import run_pipeline
 
         self.source_graph = graph
-        self.segments = None  # per-node segment ids for multi-stream plans (fusion.segment_graph)
-        self.graph = fuse_elemwise_reduce(graph) if fuse else graph
-        if fuse and fuse != "elemwise":
-            from pytensor_amd.fusion import hoist_scan_seq_dots
-
-            self.graph = hoist_scan_seq_dots(self.graph)
-            from pytensor_amd.fusion import fuse_cholesky_solve
-
-            self.graph = fuse_cholesky_solve(self.graph)
-            from pytensor_amd.fusion import segment_graph
-
-            self.graph, self.segments = segment_graph(fuse_gemv_chain(self.graph))
+        # per-node segment ids for multi-stream plans (fusion.segment_graph), or None
+        self.graph, self.segments = run_pipeline(graph, fuse)
         self.resident = set(resident)
         self._handlers = dispatch.HANDLERS
         self._resident_cache = {}  # input position -> (key, DeviceArray)

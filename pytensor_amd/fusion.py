@@ -321,14 +321,32 @@ def fuse_gemv_chain(g: Graph) -> Graph:
         if scatter:
             pos_o, ks, S = scatter
             partS = fresh("float64", (None, None), name="gemv_chain_scatter_partials")
-            chain_inputs.append(S.inputs[2])  # the scatter index vector (last input)
-            chain_inputs.append(S.inputs[0])  # base: only its length is used by the chain
-            chain_outputs.append(partS)
-            params["scatter_out"] = pos_o
             import numpy as _np
 
+            chain_inputs.append(S.inputs[2])  # the scatter index vector
+            chain_outputs.append(partS)
+            params["scatter_out"] = pos_o
             one = fresh("float64", (), const=_np.asarray(1.0), name="one")
-            replace[ks] = Node("GemvFinish", {}, [partS, S.inputs[0], one, one], list(S.outputs))
+            base = S.inputs[0]
+            kb = producer.get(base)
+            B = g.nodes[kb] if kb is not None else None
+            zero_base = (
+                B is not None
+                and B.op == "Alloc"
+                and len(B.inputs) == 2
+                and g.vars[B.inputs[0]].const is not None
+                and not _np.any(_np.asarray(g.vars[B.inputs[0]].const))
+            )
+            if zero_base:
+                # inc_subtensor(zeros(n)[idx], o): only n is needed — the zero fill is never
+                # launched (the length scalar doubles as the unread `y` of the finish node)
+                chain_inputs.append(B.inputs[1])
+                params["scatter_len_input"] = True
+                zero = fresh("float64", (), const=_np.asarray(0.0), name="zero")
+                replace[ks] = Node("GemvFinish", {}, [partS, B.inputs[1], one, zero], list(S.outputs))
+            else:
+                chain_inputs.append(base)  # base: only its length is used by the chain
+                replace[ks] = Node("GemvFinish", {}, [partS, base, one, one], list(S.outputs))
             used.add(ks)
         replace[k1] = None
         for kp in removed:

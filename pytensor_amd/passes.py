@@ -1,0 +1,49 @@
+"""The IR pass pipeline of the ``hip`` linker (one place, used by the executor and the tests).
+
+Order matters:
+
+1. ``push_gather_through_elemwise`` / ``inline_elemwise_producers`` (inline.py) — finish the
+   elementwise fusion the reference's ``FusionOptimizer`` stops short of;
+2. ``fuse_elemwise_reduce`` (fusion.py) — full reductions folded into the producing kernel;
+3. ``merge_sibling_reductions`` (inline.py);
+4. ``hoist_scan_seq_dots`` — sequence-only products out of ``Scan``;
+5. ``fuse_cholesky_solve`` — Cholesky + its first triangular solve, factor kept in LDS;
+6. ``fuse_gemv_chain`` — ``X@b → Composite → X.T@w`` (+ gathers, + scatter-add) in one pass;
+7. ``dead_code_elimination``;
+8. ``segment_graph`` — latency chain / streaming / combine segments for multi-stream plans.
+
+``fuse=False`` leaves the lowered graph untouched (one launch per reference ``Apply``: the
+parity tests compare the two); ``fuse="elemwise"`` stops after step 2.
+"""
+
+from __future__ import annotations
+
+from pytensor_amd.fusion import (
+    fuse_cholesky_solve,
+    fuse_elemwise_reduce,
+    fuse_gemv_chain,
+    hoist_scan_seq_dots,
+    segment_graph,
+)
+from pytensor_amd.inline import (
+    dead_code_elimination,
+    inline_elemwise_producers,
+    merge_sibling_reductions,
+    push_gather_through_elemwise,
+)
+from pytensor_amd.ir import Graph
+
+
+def run_pipeline(graph: Graph, fuse=True):
+    """Returns ``(graph, segments)``; ``segments`` is ``None`` when there is nothing to overlap."""
+    if not fuse:
+        return graph, None
+    if fuse == "elemwise":
+        return fuse_elemwise_reduce(graph), None
+    g = inline_elemwise_producers(push_gather_through_elemwise(graph))
+    g = fuse_elemwise_reduce(g)
+    g = merge_sibling_reductions(g)
+    g = hoist_scan_seq_dots(g)
+    g = fuse_cholesky_solve(g)
+    g = dead_code_elimination(fuse_gemv_chain(g))
+    return segment_graph(g)

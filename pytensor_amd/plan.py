@@ -30,6 +30,7 @@ shape) cannot be frozen; ``freeze`` raises and the caller keeps the eager path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -85,6 +86,9 @@ class _SegmentSwitch:
             self.plan._end_segment()
             self.plan._begin_segment()
 
+
+# results up to this size are written by the pack kernel directly into pinned host memory
+_ZEROCOPY_MAX = int(os.environ.get("PTHIP_ZEROCOPY_MAX", 1 << 16))
 
 _CAPTURE_ACTIVE = [None]  # the plan currently inside warm-up/capture, if any
 _DEFERRED = []  # plans whose release was requested during somebody else's capture
@@ -200,7 +204,17 @@ class FrozenPlan:
                 self._out_block = _PinnedBlock(specs)
             ob = self._out_block
             dev_outs = [o.contiguous() for o in outs if not isinstance(o, HostValue)]
-            if dev_outs and self.fetch_outputs:
+            if dev_outs and self.fetch_outputs and ob.nbytes <= _ZEROCOPY_MAX:
+                # small results: the pack kernel stores straight into the pinned (device-visible,
+                # coherent) host block — no copy node after it
+                for c0 in range(0, len(dev_outs), 16):
+                    chunk = dev_outs[c0 : c0 + 16]
+                    n = len(chunk)
+                    srcs = (C.c_void_p * n)(*[o.ptr for o in chunk])
+                    nb = (C.c_int64 * n)(*[o.nbytes for o in chunk])
+                    offs = (C.c_int64 * n)(*ob.offsets[c0 : c0 + n])
+                    ffi.check(lib.pthip_pack(n, srcs, nb, offs, ob.ptr))
+            elif dev_outs and self.fetch_outputs:
                 dev_out = Buffer(ob.nbytes)
                 # gather every output into one block: chunks of <= 16 buffers per launch
                 for c0 in range(0, len(dev_outs), 16):

@@ -7,23 +7,8 @@ import numpy as np
 import pytest
 
 import np_graph
-from pytensor_amd.fusion import (
-    fuse_cholesky_solve,
-    fuse_elemwise_reduce,
-    fuse_gemv_chain,
-    hoist_scan_seq_dots,
-    segment_graph,
-)
+from pytensor_amd.passes import run_pipeline as _pipeline
 from util import assert_parity, golden_cases, load_case
-
-
-def _pipeline(g):
-    g = fuse_elemwise_reduce(g)
-    g = hoist_scan_seq_dots(g)
-    g = fuse_cholesky_solve(g)
-    g = fuse_gemv_chain(g)
-    g, seg = segment_graph(g)
-    return g, seg
 
 
 @pytest.mark.parametrize("name", golden_cases())
@@ -43,6 +28,15 @@ def test_c4_gets_the_one_pass_gemv_chain_and_two_segments():
     # the gather a[gidx] and the scatter-add of its gradient are absorbed into the chain
     assert "AdvancedSubtensor" not in ops and "AdvancedIncSubtensor" not in ops
     assert ops.count("ElemwiseReduce") >= 3
+    # exp(log_sigma), mu + sigma*z and the zero fill no longer launch anything before the chain;
+    # the CAReduce of the scatter result rides on the node that reads it anyway
+    # (the two bool Elemwise nodes are shape checks evaluated on the host)
+    b_kernels = [
+        n.op for n, s in zip(g2.nodes, seg)
+        if s == 1 and n.op in ("Elemwise", "ElemwiseReduce", "Alloc", "CAReduce", "GemvChain", "GemvFinish")
+        and g2.vars[n.outputs[0]].dtype != "bool"
+    ]
+    assert b_kernels == ["GemvChain", "GemvFinish", "ElemwiseReduce"]
     # segment A = Cholesky/solve chain first, B = streaming, C = combine
     assert seg is not None and seg[0] == 0 and set(seg) == {0, 1, 2} and seg == sorted(seg)
     a_ops = {n.op for n, s in zip(g2.nodes, seg) if s == 0}
@@ -88,3 +82,63 @@ def test_donations_only_fresh_single_consumer_values():
             assert consumers[v] == 1 and v not in exe.graph.outputs and v not in exe.graph.inputs
             seen += 1
     assert seen > 0  # the trace buffer (AllocEmpty -> IncSubtensor -> Scan) is donated
+
+
+def test_inline_passes_units():
+    """push-gather, producer inlining, sibling reductions and DCE on a hand-built graph."""
+    from pytensor_amd.inline import (
+        dead_code_elimination,
+        inline_elemwise_producers,
+        merge_sibling_reductions,
+        push_gather_through_elemwise,
+    )
+    from pytensor_amd.fusion import fuse_elemwise_reduce
+    from pytensor_amd.ir import Graph
+
+    def body(ops, nin, outs=None):
+        return {"in_dtypes": ["float64"] * nin, "out_dtypes": ["float64"] * len(outs or [0]), "body": ops,
+                "outs": outs or [["t", len(ops) - 1]]}
+
+    g = Graph(name="unit")
+    s = g.new_var("float64", (), name="s")
+    z = g.new_var("float64", (None,), name="z")
+    idx = g.new_var("int64", (None,), name="idx")
+    y = g.new_var("float64", (None,), name="y")
+    g.inputs = [s, z, idx, y]
+    es = g.new_var("float64", ())
+    g.add_node("Elemwise", {"scalar": body([{"op": "Exp", "in": [["i", 0]], "dtype": "float64"}], 1)}, [s], [es])
+    es1 = g.new_var("float64", (1,))
+    g.add_node("DimShuffle", {"new_order": ["x"]}, [es], [es1])
+    t = g.new_var("float64", (None,))
+    g.add_node("Elemwise", {"scalar": body([{"op": "Mul", "in": [["i", 0], ["i", 1]], "dtype": "float64"}], 2)}, [es1, z], [t])
+    tg = g.new_var("float64", (None,))
+    g.add_node("AdvancedSubtensor", {"idx_list": [0]}, [t, idx], [tg])
+    d = g.new_var("float64", (None,))
+    g.add_node("Elemwise", {"scalar": body([{"op": "Sub", "in": [["i", 0], ["i", 1]], "dtype": "float64"}], 2)}, [y, tg], [d])
+    tot = g.new_var("float64", ())
+    g.add_node("CAReduce", {"scalar_op": "Add", "axis": [0], "acc_dtype": "float64", "dtype": "float64"}, [y], [tot])
+    unused = g.new_var("float64", (None,))
+    g.add_node("Elemwise", {"scalar": body([{"op": "Neg", "in": [["i", 0]], "dtype": "float64"}], 1)}, [y], [unused])
+    g.outputs = [d, tot, es]
+
+    rng = np.random.default_rng(0)
+    ins = [np.asarray(0.3), rng.normal(size=7), rng.integers(0, 7, size=20), rng.normal(size=20)]
+    want = np_graph.run_graph(g, ins)
+
+    g1 = dead_code_elimination(g)
+    assert len(g1.nodes) == len(g.nodes) - 1
+    g2 = push_gather_through_elemwise(g1)
+    ops = [n.op for n in g2.nodes]
+    assert ops.index("AdvancedSubtensor") < ops.index("Elemwise", ops.index("AdvancedSubtensor"))
+    gather = next(n for n in g2.nodes if n.op == "AdvancedSubtensor")
+    assert gather.inputs == [z, idx]
+    g3 = inline_elemwise_producers(g2)
+    ew = [n for n in g3.nodes if n.op == "Elemwise"]
+    # exp(s) stays (it is a graph output) but is also recomputed inside the one vector kernel
+    assert len(ew) == 2 and sorted(len(n.params["scalar"]["body"]) for n in ew) == [1, 3]
+    g4 = merge_sibling_reductions(fuse_elemwise_reduce(g3))
+    assert "CAReduce" not in [n.op for n in g4.nodes]
+    for gg in (g1, g2, g3, g4):
+        got = np_graph.run_graph(gg, ins)
+        for a, b in zip(got, want):
+            np.testing.assert_allclose(a, b, rtol=1e-14)
