@@ -14,7 +14,11 @@
 //               barrier or LDS round trip separates it from
 //           (b) the panel solve X = A21 L11^-T, one matrix row per thread, L11 entries
 //               broadcast from the wave's own registers, and
-//           (c) the trailing update A22 -= X X^T with 4x4 register tiles read from LDS.
+//           (c) the trailing update A22 -= X X^T as 16x16 tiles on the matrix cores
+//               (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32), operands read from LDS.
+//           (A variant that moved the L11 broadcasts of (a)/(b) from v_readlane to LDS was
+//            3% faster alone and 2x slower next to the streaming kernel, whose butterfly
+//            reductions keep the CU's LDS crossbar busy: the register broadcasts stay.)
 //           Two barriers per panel (8 panels at n = 128) instead of three per column.
 //   trsv  : matrix staged to LDS by the whole workgroup (coalesced), then ONE wave does the
 //           substitution wave-synchronously (two rows per lane, pivots via v_readlane):
@@ -27,6 +31,24 @@ namespace {
 
 constexpr int BLOCK = 256;
 constexpr int NB = 16;  // panel width
+
+// 16x16x4 matrix-core step, D += A B.  Operands: lane l supplies A[l&15][l>>4] and
+// B[l>>4][l&15]; result register r of lane l is D[drow(l, r)][l&15].
+template <class T> struct Mfma16;
+template <> struct Mfma16<double> {
+  typedef double v4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ v4 run(double a, double b, v4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int drow(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <> struct Mfma16<float> {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ v4 run(float a, float b, v4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int drow(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
 
 template <class T> __device__ __forceinline__ T bcast_lane(T v, int src) {
   // wave-uniform broadcast of lane `src` (compile-time constant after unrolling)
@@ -275,47 +297,37 @@ __global__ __launch_bounds__(BLOCK) void potrf_lds_kernel(T* __restrict__ Lout,
         if (c <= tid) W[(j0 + tid) * ld + j0 + c] = d[c];
     }
     __syncthreads();
-    // ---- (c) trailing update A22 -= X X^T, 4x4 register tiles over the lower triangle ----
+    // ---- (c) trailing update A22 -= X X^T on the matrix cores: one 16x16 output tile of
+    //      the lower triangle per wave and step, K = 16 = four 16x16x4 MFMAs.  (m > 0 only
+    //      after a full panel, so K is always NB.)  Both operands are rows of the panel X.
     if (m > 0) {
-      const int mt = (m + 3) >> 2;            // tiles per side
+      const int mt = (m + 15) >> 4;           // 16-row tiles per side
       const int ntiles = mt * (mt + 1) / 2;   // lower-triangular tile count
       const int base = j0 + jb;
-      for (int tt = tid; tt < ntiles; tt += BLOCK) {
-        // unrank tt -> (ti >= tj)
+      const int wave = tid >> 6;
+      for (int tt = wave; tt < ntiles; tt += BLOCK / 64) {
+        // unrank tt -> (ti >= tj)   (wave-uniform)
         int ti = (int)((sqrtf(8.0f * tt + 1.0f) - 1.0f) * 0.5f);
         while ((ti + 1) * (ti + 2) / 2 <= tt) ti++;
         while (ti * (ti + 1) / 2 > tt) ti--;
         const int tj = tt - ti * (ti + 1) / 2;
-        const int i0 = base + ti * 4, c0 = base + tj * 4;
-        T acc[4][4];
+        const int i0 = base + ti * 16, c0 = base + tj * 16;
+        const int ri = (i0 + (lane & 15)) < n ? (i0 + (lane & 15)) : (n - 1);
+        const int rj = (c0 + (lane & 15)) < n ? (c0 + (lane & 15)) : (n - 1);
+        T af[4], bf[4];
 #pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-          for (int b = 0; b < 4; b++) acc[a][b] = T(0);
-#pragma unroll 4
-        for (int k = 0; k < NB; k++) {
-          if (k < jb) {
-            T xi[4], xj[4];
-#pragma unroll
-            for (int a = 0; a < 4; a++) {
-              const int ri = (i0 + a) < n ? (i0 + a) : (n - 1);
-              const int rj = (c0 + a) < n ? (c0 + a) : (n - 1);
-              xi[a] = W[ri * ld + j0 + k];
-              xj[a] = W[rj * ld + j0 + k];
-            }
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-              for (int b = 0; b < 4; b++) acc[a][b] += xi[a] * xj[b];
-          }
+        for (int kk = 0; kk < 4; kk++) {
+          af[kk] = W[ri * ld + j0 + kk * 4 + (lane >> 4)];
+          bf[kk] = W[rj * ld + j0 + kk * 4 + (lane >> 4)];
         }
+        typename Mfma16<T>::v4 acc = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+        for (int kk = 0; kk < 4; kk++) acc = Mfma16<T>::run(af[kk], bf[kk], acc);
 #pragma unroll
-          for (int b = 0; b < 4; b++) {
-            const int i = i0 + a, j = c0 + b;
-            if (i < n && j < n && j <= i) W[i * ld + j] -= acc[a][b];
-          }
+        for (int r = 0; r < 4; r++) {
+          const int i = i0 + Mfma16<T>::drow(lane, r), j = c0 + (lane & 15);
+          if (i < n && j < n && j <= i) W[i * ld + j] -= acc[r];
+        }
       }
     }
     __syncthreads();

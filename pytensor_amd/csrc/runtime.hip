@@ -5,6 +5,7 @@
 #include "common.h"
 
 #include <hip/hiprtc.h>
+#include <time.h>
 
 #include <map>
 #include <mutex>
@@ -391,14 +392,40 @@ int pthip_graph_launch_on(void* graph_exec, int stream) {
 // segments on their streams, and the single synchronisation of the call.
 //   segmented (ga, gb, gc != NULL): H2D -> [gb on stream 0 || ga on stream 1] -> gc on stream 0
 //   single    (only gb != NULL)   : H2D -> gb on stream 0
-// The latency chain ga is enqueued first (its single-workgroup kernels are the critical
-// path once the streaming segment runs at HBM speed); PTHIP_PLAN_B_FIRST=1 swaps the order.
+// The streaming segment gb is enqueued first (each hipGraphLaunch costs ~6-11 us of host time
+// and gb is the critical path: 4.03k vs 3.95k evals/s on C4); PTHIP_PLAN_A_FIRST=1 swaps.
+// PTHIP_PLAN_TRACE=1: host-side cost of each step of a replay, averaged over 100 calls (stderr)
+struct ReplayTrace {
+  bool on = getenv("PTHIP_PLAN_TRACE") != nullptr;
+  double acc[8] = {0};
+  int n = 0;
+  timespec t{};
+  void start() { if (on) clock_gettime(CLOCK_MONOTONIC, &t); }
+  void lap(int k) {
+    if (!on) return;
+    timespec u;
+    clock_gettime(CLOCK_MONOTONIC, &u);
+    acc[k] += (u.tv_sec - t.tv_sec) * 1e6 + (u.tv_nsec - t.tv_nsec) * 1e-3;
+    t = u;
+  }
+  void done() {
+    if (!on || ++n < 100) return;
+    fprintf(stderr, "[pthip plan] us/call: h2d %.1f  A %.1f  B %.1f  evA+C %.1f  sync %.1f\n",
+            acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n);
+    for (double& a : acc) a = 0;
+    n = 0;
+  }
+};
+
 int pthip_plan_replay(void* ga, void* gb, void* gc, void* dev_in, const void* host_in,
                       size_t in_bytes, int sync) {
   PTHIP_REQUIRE_INIT();
   static hipEvent_t ev_in = nullptr, ev_a = nullptr;
+  static ReplayTrace tr;
   hipStream_t s0 = g_ctx.streams[0];
+  tr.start();
   if (in_bytes) PTHIP_CHECK(hipMemcpyAsync(dev_in, host_in, in_bytes, hipMemcpyHostToDevice, s0));
+  tr.lap(0);
   if (ga && gc) {
     if (!g_ctx.streams[1]) PTHIP_CHECK(create_stream(1));
     hipStream_t s1 = g_ctx.streams[1];
@@ -406,19 +433,25 @@ int pthip_plan_replay(void* ga, void* gb, void* gc, void* dev_in, const void* ho
       PTHIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
       PTHIP_CHECK(hipEventCreateWithFlags(&ev_a, hipEventDisableTiming));
     }
-    static const bool a_first = getenv("PTHIP_PLAN_B_FIRST") == nullptr;
+    static const bool b_first = getenv("PTHIP_PLAN_A_FIRST") == nullptr;
     PTHIP_CHECK(hipEventRecord(ev_in, s0));
-    if (!a_first) PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)gb, s0));
+    if (b_first) PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)gb, s0));
     PTHIP_CHECK(hipStreamWaitEvent(s1, ev_in, 0));
     PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)ga, s1));
-    if (a_first) PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)gb, s0));
+    tr.lap(1);
+    if (!b_first) PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)gb, s0));
+    tr.lap(2);
     PTHIP_CHECK(hipEventRecord(ev_a, s1));
     PTHIP_CHECK(hipStreamWaitEvent(s0, ev_a, 0));
     PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)gc, s0));
+    tr.lap(3);
   } else {
     PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)gb, s0));
+    tr.lap(2);
   }
   if (sync) PTHIP_CHECK(hipStreamSynchronize(s0));
+  tr.lap(4);
+  tr.done();
   return 0;
 }
 

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpthip.so")
+LIB_PATH = os.environ.get("PTHIP_LIB") or os.path.join(_HERE, "libpthip.so")  # (override: A/B builds)
 
 DTYPE_CODE = {
     "bool": 0,
