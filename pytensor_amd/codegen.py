@@ -100,24 +100,26 @@ PT_DEV float pt_softplus(float x) {
 }
 PT_DEV double pt_log1mexp(double x) { return x < -0.6931471805599453 ? log1p(-exp(x)) : log(-expm1(x)); }
 PT_DEV float pt_log1mexp(float x) { return x < -0.6931471805599453f ? log1pf(-expf(x)) : logf(-expm1f(x)); }
-PT_DEV double pt_rint_even(double x) {
-  double y = floor(x), r = x - y;
-  if (r > 0.5) y += 1; else if (r == 0.5) { r = y - 2.0 * floor(0.5 * y); y += (int)r; }
-  return y;
-}
-PT_DEV float pt_rint_even(float x) {
-  float y = floorf(x), r = x - y;
-  if (r > 0.5f) y += 1; else if (r == 0.5f) { r = y - 2.0f * floorf(0.5f * y); y += (int)r; }
-  return y;
-}
+// RoundHalfToEven (scalar/basic.py:2737-2766 restates npy_rint with floor arithmetic): the
+// hardware's v_rndne is that function exactly, and — unlike `x - floor(x)` — cannot have the
+// producer of x contracted into it (x = a*b fused into an fma changes which side of a tie
+// the value lands on: found by the golden vectors, 2.5 rounded to 3).
+PT_DEV double pt_rint_even(double x) { return __builtin_rint(x); }
+PT_DEV float pt_rint_even(float x) { return __builtin_rintf(x); }
 // digamma (Psi): asymptotic series with recurrence shift, as in the reference's
 // support code (scalar/math.py:403-470 `_psi`)
 PT_DEV double pt_psi(double x) {
   const double S = 1.0e-5, C = 8.5, S3 = 8.333333333e-2, S4 = 8.333333333e-3, S5 = 3.968253968e-3,
                D1 = -0.5772156649;
   double y = x, psi = 0.0, R;
-  if (y <= 0.0) return psi;
-  if (y <= S) return D1 - 1.0 / y;
+  if (y <= 0.0) {
+    // poles at 0, -1, -2, ...: +inf (the reference's choice); elsewhere the reflection formula
+    if (y == floor(y)) return __builtin_inf();
+    const double pix = 3.14159265358979323846 * y;
+    psi = -3.14159265358979323846 * (cos(pix) / sin(pix));
+    y = 1.0 - y;
+  }
+  if (y <= S) return psi + D1 - 1.0 / y;
   while (y < C) { psi = psi - 1.0 / y; y = y + 1; }
   R = 1.0 / y;
   psi = psi + log(y) - .5 * R;
