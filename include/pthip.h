@@ -200,6 +200,18 @@ int pthip_scatter_rows(int dtype, int inc, int64_t n_idx, int64_t inner, void* o
  * one D2H copy per Function output; cf. the output loop of pytensor/link/basic.py:683-684) */
 int pthip_pack(int n, const void* const* srcs, const int64_t* nbytes, const int64_t* dst_offsets,
                void* dst);
+/* ---- order-defined scans (pytensor/tensor/extra_ops.py CumOp.perform = np.cumsum/np.cumprod;
+ *      pytensor/tensor/math.py Argmax.perform = np.argmax over the flattened trailing axes) ---- */
+/* dst[o, k, i] = fold_{j<=k} src[o, j, i] (mul = 0: +, 1: *), strictly left to right; src and
+ * dst contiguous (outer, n, inner) */
+int pthip_cumulative(int dtype, int mul, int64_t outer, int64_t n, int64_t inner, const void* src,
+                     void* dst);
+/* integer Dot (pytensor/tensor/math.py Dot.perform = np.dot without BLAS): out (M x N, contiguous)
+ * = A (M x K, strided) @ B (K x N, strided) with wrap-around arithmetic in `dtype` */
+int pthip_imatmul(int dtype, int64_t M, int64_t N, int64_t K, const void* A, int64_t sA0,
+                  int64_t sA1, const void* B, int64_t sB0, int64_t sB1, void* out);
+/* out[row] (int64) = index of the first maximum of src[row, 0:R] (a NaN is the maximum) */
+int pthip_argmax(int dtype, int64_t rows, int64_t R, const void* src, void* out);
 /* device-side error flag raised by kernels (index out of bounds ...); sync + read + clear */
 int pthip_check_status(int* status);
 /* device address of that flag, for generated (JIT) kernels that bounds-check indices */

@@ -1,0 +1,119 @@
+"""More golden cases (imported by ``make_golden.py``): ops and variants the first batch did not
+reach.  TEST INFRASTRUCTURE.  Shapes follow the reference's own tests where cited."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytensor
+import pytensor.tensor as pt
+from pytensor.tensor.linalg import cho_solve, cholesky
+
+from make_golden import case
+
+
+@case("dot_shapes")
+def dot_shapes():
+    # tests/tensor/test_math.py TestDot: every rank combination; integer dots have no BLAS
+    # path and stay ``Dot`` (bit-exact tier)
+    rng = np.random.default_rng(40)
+    a, b, c = pt.dvector("a"), pt.dvector("b"), pt.dvector("c")
+    A, B = pt.dmatrix("A"), pt.dmatrix("B")
+    iA, iB = pt.lmatrix("iA"), pt.lmatrix("iB")
+    iv = pt.lvector("iv")
+    outs = [pt.dot(a, c), pt.dot(A, a), pt.dot(b, A), pt.dot(A, B.T), pt.dot(iA, iB), pt.dot(iA, iv), pt.dot(iv, iv),
+            pt.dot(A.T, A) + pt.outer(a, a)]
+    vals = {"a": rng.normal(size=7), "b": rng.normal(size=5), "c": rng.normal(size=7), "A": rng.normal(size=(5, 7)), "B": rng.normal(size=(9, 7)),
+            "iA": rng.integers(-9, 9, size=(4, 6)), "iB": rng.integers(-9, 9, size=(6, 3)), "iv": rng.integers(-9, 9, size=6)}
+    return [a, b, c, A, B, iA, iB, iv], outs, vals
+
+
+@case("shape_ops")
+def shape_ops():
+    rng = np.random.default_rng(41)
+    x = pt.dmatrix("x")
+    s = pt.dscalar("s")
+    k = pt.lscalar("k")
+    outs = [
+        x.shape, pt.shape(x)[0] * pt.shape(x)[1], pt.specify_shape(x, (None, 5)) * 2.0, pt.tensor_from_scalar(pt.scalar_from_tensor(s) * 2.0),
+        x.copy(), pt.zeros_like(x) + s, pt.ones((k, 3), dtype="float32"), pt.full((2, k), s), pt.arange(k) * 2,
+        pt.eye(4, 5, 1) + x[:4], pt.tril(x[:5, :5]), pt.repeat(x[0], 2), pt.tile(x[:2, :2], (2, 2)), pt.flatten(x, 1),
+        pt.expand_dims(x, 1).sum(axis=1), pt.squeeze(x[:, :1], axis=1), pt.swapaxes(x, 0, 1) * 1.0, pt.stack([x[0], x[1]], axis=1),
+    ]
+    return [x, s, k], outs, {"x": rng.normal(size=(6, 5)), "s": np.asarray(1.25), "k": np.asarray(4)}
+
+
+@case("indexing_more")
+def indexing_more():
+    # tests/tensor/test_subtensor.py: stepped / negative slices, take along axis 1, matrix rows
+    # with duplicate indices (inc accumulates, set keeps the last writer)
+    rng = np.random.default_rng(42)
+    x = pt.dmatrix("x")
+    y = pt.dmatrix("y")
+    v = pt.dvector("v")
+    idx = pt.lvector("idx")
+    jdx = pt.lvector("jdx")
+    t3 = pt.dtensor3("t3")
+    outs = [
+        x[::-1, ::2], x[-2:0:-1], x[1:-1:3, -1], t3[1, :, ::-2], t3[:, 2], x[:, jdx], pt.take(x, jdx, axis=1), x[idx][:, jdx],
+        pt.inc_subtensor(x[idx], y[: idx.shape[0]]), pt.set_subtensor(x[idx], y[: idx.shape[0]]),
+        pt.inc_subtensor(x[1:6:2, ::3], 2.5), pt.set_subtensor(x[::-2], x[:4] * 0 + v[:7]), pt.inc_subtensor(t3[0, 1:3], 1.0),
+        x[idx, jdx[: idx.shape[0]]], pt.set_subtensor(v[-3:], 0.0), pt.inc_subtensor(v[::4], v[:3]),
+    ]
+    return [x, y, v, idx, jdx, t3], outs, {
+        "x": rng.normal(size=(8, 7)), "y": rng.normal(size=(6, 7)), "v": rng.normal(size=9),
+        "idx": np.array([5, 0, 5, 2, 7]), "jdx": np.array([6, 1, 1, 0, 3, 6]), "t3": rng.normal(size=(3, 4, 5)),
+    }
+
+
+@case("scan_variants")
+def scan_variants():
+    # tests/scan/test_basic.py: map (nit-sot only), two recurrent states with a shared
+    # non-sequence, n_steps shorter than the sequence, reversed sequence
+    rng = np.random.default_rng(43)
+    xs = pt.dmatrix("xs")
+    ys = pt.dmatrix("ys")
+    a0 = pt.dvector("a0")
+    b0 = pt.dvector("b0")
+    W = pt.dmatrix("W")
+    sq = pytensor.scan(lambda x, y: x * y + 1.0, sequences=[xs, ys], return_updates=False)
+
+    def step(x, a, b, W):
+        a_new = pt.tanh(a @ W + x)
+        b_new = b * 0.5 + a_new
+        return a_new, b_new
+
+    aa, bb = pytensor.scan(step, sequences=[xs], outputs_info=[a0, b0], non_sequences=[W], n_steps=5, return_updates=False)
+    rr = pytensor.scan(lambda x, acc: acc + x, sequences=[xs], outputs_info=[pt.zeros_like(a0)], go_backwards=True, return_updates=False)
+    return [xs, ys, a0, b0, W], [sq, aa, bb[-1], rr], {
+        "xs": rng.normal(size=(7, 4)), "ys": rng.normal(size=(7, 4)), "a0": rng.normal(size=4), "b0": rng.normal(size=4),
+        "W": rng.normal(size=(4, 4)) * 0.5,
+    }
+
+
+@case("blockwise_linalg")
+def blockwise_linalg():
+    # tests/tensor/test_blockwise.py: batched cho_solve and a broadcast (one matrix, many rhs) solve
+    rng = np.random.default_rng(44)
+    S = pt.dtensor3("S")
+    b = pt.dmatrix("b")
+    B = pt.dtensor3("B")
+    L = cholesky(S)
+    outs = [cho_solve((L, True), b, b_ndim=1), cho_solve((L, True), B), pt.linalg.solve_triangular(L[0], B, lower=True, b_ndim=2)]
+    A = rng.normal(size=(3, 6, 9))
+    Sv = A @ A.transpose(0, 2, 1) / 9 + np.eye(6)
+    return [S, b, B], outs, {"S": Sv, "b": rng.normal(size=(3, 6)), "B": rng.normal(size=(3, 6, 2))}
+
+
+@case("careduce_more")
+def careduce_more():
+    # elemwise.py:1233 CAReduce: every scalar op x axis pattern on a 4-d tensor, keepdims, mean/var
+    rng = np.random.default_rng(45)
+    t = pt.dtensor4("t")
+    i3 = pt.ltensor3("i3")
+    outs = [
+        t.sum(axis=(0, 2)), t.prod(axis=3), t.max(axis=(1, 3)), t.min(axis=0), t.sum(axis=(1, 2, 3)), t.mean(axis=2),
+        t.var(axis=(0, 1)), t.sum(axis=1, keepdims=True), t.max(), pt.argmax(t[0, 0], axis=1),
+        i3.sum(axis=(0, 2)), i3.max(axis=1), i3.prod(axis=2), pt.all(i3 > -8, axis=0), pt.any(i3 > 7, axis=(1, 2)),
+        pt.logsumexp(t, axis=(2, 3)), pt.cumsum(t[0, 0], axis=1),
+    ]
+    return [t, i3], outs, {"t": rng.normal(size=(3, 4, 5, 6)), "i3": rng.integers(-9, 9, size=(4, 3, 5))}

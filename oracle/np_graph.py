@@ -716,6 +716,8 @@ def run_graph(graph, inputs):
     for vid, v in graph.vars.items():
         if v.const is not None:
             env[vid] = v.const
+        elif v.kind == "none":
+            env[vid] = None  # NoneConst (an unspecified SpecifyShape entry)
     if len(inputs) != len(graph.inputs):
         raise TypeError(f"expected {len(graph.inputs)} inputs, got {len(inputs)}")
     for vid, val in zip(graph.inputs, inputs):
@@ -798,3 +800,37 @@ def _cholesky_trsv(p, inputs, node, graph):
     L = _cholesky({"lower": True}, [S], node, graph)[0]
     x = _solve_tri({"lower": True, "unit_diagonal": False, "b_ndim": 1}, [L, b], node, graph)[0]
     return [L, x]
+
+
+@op("ARange")
+def _arange(p, inputs, node, graph):
+    # pytensor/tensor/basic.py:3139 ARange.perform
+    start, stop, step = (np.asarray(i).reshape(()) for i in inputs)
+    return [np.arange(start, stop, step, dtype=p["dtype"])]
+
+
+@op("Eye")
+def _eye(p, inputs, node, graph):
+    # pytensor/tensor/basic.py:1351 Eye.perform
+    n, m, k = (int(np.asarray(i).reshape(())) for i in inputs)
+    return [np.eye(n, m, k, dtype=p["dtype"])]
+
+
+@op("CumOp")
+def _cumop(p, inputs, node, graph):
+    # pytensor/tensor/extra_ops.py:281 CumOp.perform
+    (x,) = inputs
+    f = np.cumsum if p["mode"] == "add" else np.cumprod
+    return [f(x, axis=p["axis"])]
+
+
+@op("Argmax")
+def _argmax(p, inputs, node, graph):
+    # pytensor/tensor/math.py:188-206 Argmax.perform: kept axes first, reduced axes flattened last
+    (x,) = inputs
+    axes = list(p["axis"])
+    keep = [d for d in range(x.ndim) if d not in axes]
+    xt = np.transpose(x, keep + axes)
+    kept_shape = xt.shape[: len(keep)]
+    r = xt.reshape((*kept_shape, int(np.prod(xt.shape[len(keep) :], dtype="int64"))))
+    return [np.asarray(np.argmax(r, axis=-1), dtype="int64")]

@@ -159,9 +159,39 @@ def batched_dot(node, inputs, env):
     return [gemm_device(env, 1.0, _prep3d(x), _prep3d(y), batch=True)]
 
 
+def _int_dot(env, x, y, out_dtype):
+    """Integer ``Dot`` (no BLAS in the reference either: ``np.dot`` on integer arrays): operands
+    cast to the result dtype, wrap-around arithmetic, bit-exact."""
+    from pytensor_amd.dispatch.elemwise import _cast
+
+    if x.ndim > 2 or y.ndim > 2:
+        raise NotImplementedError("Dot with ndim > 2")
+    K = x.shape[-1]
+    if K != y.shape[0]:
+        raise ValueError(f"shapes {x.shape} and {y.shape} not aligned: {K} (dim {x.ndim - 1}) != {y.shape[0]} (dim 0)")
+    x = x if str(x.dtype) == out_dtype else _cast(env, x, out_dtype)
+    y = y if str(y.dtype) == out_dtype else _cast(env, y, out_dtype)
+    xm = x if x.ndim == 2 else x.view((1, K), (0, x.strides[0]))
+    ym = y if y.ndim == 2 else y.view((K, 1), (y.strides[0], 0))
+    M, N = xm.shape[0], ym.shape[1]
+    out_shape = (() if x.ndim == 1 else (M,)) + (() if y.ndim == 1 else (N,))
+    out = DeviceArray.empty(out_shape, out_dtype)
+    if K == 0:
+        ffi.check(env.lib.pthip_memset(out.ptr, 0, out.nbytes))
+    elif out.size:
+        ffi.check(
+            env.lib.pthip_imatmul(ffi.np_dtype_code(out_dtype), M, N, K, xm.ptr, xm.strides[0], xm.strides[1],
+                                  ym.ptr, ym.strides[0], ym.strides[1], out.ptr)
+        )
+    return out
+
+
 @handler("Dot")
 def dot(node, inputs, env):
     x, y = (env.to_device(i) for i in inputs)
+    out_dtype = str(env.graph.vars[node.outputs[0]].dtype)
+    if np.dtype(out_dtype).kind in "iu":
+        return [_int_dot(env, x, y, out_dtype)]
     if x.ndim == 2 and y.ndim == 2:
         return [gemm_device(env, 1.0, _prep2d(x), _prep2d(y))]
     if x.ndim == 2 and y.ndim == 1:

@@ -1,0 +1,72 @@
+"""``ARange`` / ``Eye`` (index helpers built from host-known scalars) and the order-defined
+scans ``CumOp`` / ``Argmax``.
+
+Reference: pytensor/tensor/basic.py ``ARange`` 3139 (perform: ``np.arange``), ``Eye`` 1351
+(``np.eye``); pytensor/tensor/extra_ops.py ``CumOp`` 281 (``np.cumsum``/``np.cumprod``);
+pytensor/tensor/math.py ``Argmax`` 142 (reduced axes moved last and flattened, ``np.argmax``).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from pytensor_amd import ffi
+from pytensor_amd.device import DeviceArray, contiguous_strides
+from pytensor_amd.dispatch import handler
+from pytensor_amd.executor import HOST_MAX, HostValue
+
+
+def _host_or_device(env, a: np.ndarray):
+    h = HostValue(a)
+    return h if a.size <= HOST_MAX else env.to_device(h)
+
+
+@handler("ARange")
+def arange(node, inputs, env):
+    # start/stop/step are scalars whose *values* fix the output length: host reads, like the
+    # shape arithmetic of Alloc/Reshape (data-dependent in a frozen plan -> the plan refuses)
+    start, stop, step = (np.asarray(env.to_host(i)).reshape(()) for i in inputs)
+    return [_host_or_device(env, np.arange(start, stop, step, dtype=node.params["dtype"]))]
+
+
+@handler("Eye")
+def eye(node, inputs, env):
+    n, m, k = (int(np.asarray(env.to_host(i)).reshape(())) for i in inputs)
+    return [_host_or_device(env, np.eye(n, m, k, dtype=node.params["dtype"]))]
+
+
+@handler("CumOp")
+def cumop(node, inputs, env):
+    x = env.to_device(inputs[0]).contiguous()
+    axis = node.params["axis"]
+    if axis >= x.ndim:
+        raise ValueError(f"axis(={axis}) out of bounds")
+    out = DeviceArray.empty(x.shape, x.dtype)
+    if x.size == 0:
+        return [out]
+    if str(x.dtype) not in ("float64", "float32", "int64", "int32"):
+        raise NotImplementedError(f"CumOp: dtype {x.dtype} on the device")
+    outer = int(np.prod(x.shape[:axis], dtype=np.int64))
+    inner = int(np.prod(x.shape[axis + 1 :], dtype=np.int64))
+    ffi.check(env.lib.pthip_cumulative(ffi.np_dtype_code(x.dtype), int(node.params["mode"] == "mul"), outer, x.shape[axis], inner, x.ptr, out.ptr))
+    return [out]
+
+
+@handler("Argmax")
+def argmax(node, inputs, env):
+    x = env.to_device(inputs[0])
+    axes = list(node.params["axis"])
+    keep = [d for d in range(x.ndim) if d not in axes]
+    perm = keep + axes
+    xt = x.view([x.shape[d] for d in perm], [x.strides[d] for d in perm]).contiguous()
+    kept = tuple(x.shape[d] for d in keep)
+    R = int(np.prod([x.shape[d] for d in axes], dtype=np.int64))
+    rows = int(np.prod(kept, dtype=np.int64))
+    out = DeviceArray.empty(kept, "int64")
+    if R == 0:
+        raise ValueError("attempt to get argmax of an empty sequence")
+    if rows:
+        if str(x.dtype) == "bool":
+            raise NotImplementedError("Argmax: bool input on the device")
+        ffi.check(env.lib.pthip_argmax(ffi.np_dtype_code(x.dtype), rows, R, xt.ptr, out.ptr))
+    return [out]

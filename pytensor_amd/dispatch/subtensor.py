@@ -140,6 +140,58 @@ def _single_axis_index(idx_list, index_inputs, x_ndim):
     return axis, index_inputs[idx_list[axis]]
 
 
+def _leading_multi_index(idx_list, index_inputs):
+    """``x[i0, i1, ..., :, :]`` — k >= 2 integer-array indices on the k leading axes, full slices
+    after them.  Returns the list of index values or None."""
+    k = 0
+    while k < len(idx_list) and not isinstance(idx_list[k], slice):
+        k += 1
+    if k < 2:
+        return None
+    for e in idx_list[k:]:
+        if not isinstance(e, slice) or (e.start, e.stop, e.step) != (None, None, None):
+            return None
+    return [index_inputs[idx_list[d]] for d in range(k)]
+
+
+def _combine_indices(env, ivs, dims):
+    """Row-major linear index of pointwise index vectors over the leading ``dims`` (negative
+    entries wrap like NumPy; any out-of-range component poisons the row so that the gather /
+    scatter kernel raises the device error flag -> IndexError)."""
+    from pytensor_amd.dispatch.elemwise import launch_elemwise
+    from pytensor_amd.executor import HostValue
+
+    ivs = [_index_on_device(env, iv) for iv in ivs]
+    shape = np.broadcast_shapes(*[iv.shape for iv in ivs])
+    if len(shape) != 1:
+        raise NotImplementedError("hip linker: multi-dimensional index arrays in a multi-index")
+    ins = []
+    for iv in ivs:
+        if iv.shape != tuple(shape) and iv.size != 1:
+            raise IndexError(f"shape mismatch: indexing arrays could not be broadcast together with shapes {[i.shape for i in ivs]}")
+        ins.append(iv if iv.ndim == 1 else iv.view((1,), (0,)))
+    k = len(ivs)
+    ins += [HostValue(np.asarray(int(n), dtype="int64")) for n in dims]
+    body = []
+
+    def emit(op, args, dt="int64"):
+        body.append({"op": op, "in": args, "dtype": dt})
+        return ["t", len(body) - 1]
+
+    zero = ["c", 0, "int64"]
+    lin = valid = None
+    for d in range(k):
+        i, n = ["i", d], ["i", k + d]
+        w = emit("Switch", [emit("LT", [i, zero], "bool"), emit("Add", [i, n]), i])
+        ok = emit("AND", [emit("GE", [w, zero], "bool"), emit("LT", [w, n], "bool")], "bool")
+        valid = ok if valid is None else emit("AND", [valid, ok], "bool")
+        lin = w if lin is None else emit("Add", [emit("Mul", [lin, n]), w])
+    out = emit("Switch", [valid, lin, ["c", -(1 << 62), "int64"]])
+    sb = {"in_dtypes": ["int64"] * (2 * k), "out_dtypes": ["int64"], "body": body, "outs": [out]}
+    outs, _, _ = launch_elemwise(sb, ins, tuple(shape), ["int64"], None, env)
+    return outs[0]
+
+
 def _index_on_device(env, iv):
     iv = env.to_device(iv)
     if iv.dtype.kind == "b":
@@ -162,9 +214,20 @@ def _axis_to_front(x: DeviceArray, axis: int) -> DeviceArray:
 def advanced_subtensor(node, inputs, env):
     x, *idx = inputs
     x = env.to_device(x)
-    axis, iv = _single_axis_index(node.params["idx_list"], idx, x.ndim)
-    iv = _index_on_device(env, iv)
-    xf = _axis_to_front(x, axis)
+    multi = _leading_multi_index(node.params["idx_list"], idx)
+    if multi is not None:
+        # pointwise multi-index: the k leading axes are flattened and gathered with one
+        # combined row index (subtensor.py:1932 AdvancedSubtensor.perform = x[i0, i1, ...])
+        k = len(multi)
+        xc = x.contiguous()
+        iv = _combine_indices(env, multi, x.shape[:k])
+        rows = int(np.prod(x.shape[:k], dtype=np.int64))
+        xf = xc.view((rows, *x.shape[k:]), contiguous_strides((rows, *x.shape[k:])))
+        axis = 0
+    else:
+        axis, iv = _single_axis_index(node.params["idx_list"], idx, x.ndim)
+        iv = _index_on_device(env, iv)
+        xf = _axis_to_front(x, axis)
     inner_shape = xf.shape[1:]
     inner = int(np.prod(inner_shape)) if inner_shape else 1
     # rows must be contiguous runs of `inner` elements
@@ -193,18 +256,33 @@ def advanced_inc_subtensor(node, inputs, env):
     p = node.params
     x, y, *idx = inputs
     x, y = env.to_device(x), env.to_device(y)
+    multi = _leading_multi_index(p["idx_list"], idx)
+    if multi is not None:
+        k = len(multi)
+        iv = _combine_indices(env, multi, x.shape[:k])
+        full_shape = x.shape
+        rows = int(np.prod(x.shape[:k], dtype=np.int64))
+        own = _own_copy(env, x, 0)
+        flat = own.view((rows, *x.shape[k:]), contiguous_strides((rows, *x.shape[k:])))
+        res = _scatter_rows(env, p, flat, y, iv)
+        return [res.view(full_shape, contiguous_strides(full_shape))]
     axis, iv = _single_axis_index(p["idx_list"], idx, x.ndim)
     if axis != 0:
         raise NotImplementedError("hip linker: AdvancedIncSubtensor on axis != 0")
     iv = _index_on_device(env, iv)
     if iv.ndim != 1:
         raise NotImplementedError("hip linker: AdvancedIncSubtensor with a multi-dimensional index")
-    out = _own_copy(env, x, 0)
+    return [_scatter_rows(env, p, _own_copy(env, x, 0), y, iv)]
+
+
+def _scatter_rows(env, p, out, y, iv):
+    """``out[iv] (+)= y`` on the leading axis of the (owned, contiguous) ``out``."""
+    x = out
     inner_shape = x.shape[1:]
     inner = int(np.prod(inner_shape)) if inner_shape else 1
     n_idx = iv.size
     if n_idx == 0 or inner == 0:
-        return [out]
+        return out
     if str(y.dtype) != str(x.dtype):
         from pytensor_amd.dispatch.elemwise import _cast
 
@@ -236,4 +314,4 @@ def advanced_inc_subtensor(node, inputs, env):
             ws.ptr if ws is not None else None, ws_bytes,
         )
     )
-    return [out]
+    return out

@@ -184,6 +184,14 @@ def _(op, node, ctx):
     return "Elemwise", {"scalar": body}
 
 
+@hip_funcify.register(ScalarOp)
+def _(op, node, ctx):
+    # a ScalarOp applied directly to ScalarType variables (between ScalarFromTensor and
+    # TensorFromScalar): the same scalar graph on 0-d values
+    body = lower_scalar_op(op, [i.type.dtype for i in node.inputs], [o.type.dtype for o in node.outputs])
+    return "Elemwise", {"scalar": body}
+
+
 @hip_funcify.register(CAReduce)
 def _(op, node, ctx):
     # Sum/Prod/Max/Min/All/Any are subclasses (pytensor/tensor/math.py:3498...)
@@ -217,6 +225,30 @@ for _cls in (Dot22, Dot22Scalar, BatchedDot, Dot, Shape, Reshape, ScalarFromTens
 @hip_funcify.register(TypeCastingOp)
 def _(op, node, ctx):
     return "ViewOp", {}
+
+
+def _register_extra_ops():
+    # ops next to the hot path that model graphs routinely carry along (index helpers, scans)
+    from pytensor.tensor.basic import ARange, Eye
+    from pytensor.tensor.extra_ops import CumOp
+    from pytensor.tensor.math import Argmax
+
+    @hip_funcify.register(ARange)
+    @hip_funcify.register(Eye)
+    def _(op, node, ctx):
+        return type(op).__name__, {"dtype": str(op.dtype)}
+
+    @hip_funcify.register(CumOp)
+    def _(op, node, ctx):
+        return "CumOp", {"axis": int(op.axis), "mode": str(op.mode)}
+
+    @hip_funcify.register(Argmax)
+    def _(op, node, ctx):
+        axis = op.axis if op.axis is not None else tuple(range(node.inputs[0].type.ndim))
+        return "Argmax", {"axis": [int(a) for a in axis]}
+
+
+_register_extra_ops()
 
 
 @hip_funcify.register(Gemm)
