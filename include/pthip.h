@@ -160,6 +160,14 @@ int pthip_gemm(int dtype, int64_t batch, int64_t M, int64_t N, int64_t K, double
                const void* A, int64_t sAb, int64_t sA0, int64_t sA1, const void* B, int64_t sBb,
                int64_t sB0, int64_t sB1, double beta, const void* C, int64_t sCb, int64_t sC0,
                int64_t sC1, void* out);
+/* Split-K products left unfinished for a consumer that folds the sum into its own kernel (the
+ * Gemm -> Elemwise pairs of a Scan step: gemm.py:183-216 followed by elemwise.py:755):
+ * part[s][b][m][n], s < pthip_gemm_nslabs(batch, M, N, K); the consumer adds the slabs in
+ * ascending s and applies alpha/beta itself.  nslabs == 1: slab 0 is the plain product. */
+int64_t pthip_gemm_nslabs(int64_t batch, int64_t M, int64_t N, int64_t K);
+int pthip_gemm_partials(int dtype, int64_t batch, int64_t M, int64_t N, int64_t K, const void* A,
+                        int64_t sAb, int64_t sA0, int64_t sA1, const void* B, int64_t sBb,
+                        int64_t sB0, int64_t sB1, void* part, int64_t nslabs);
 /* out (M×N contiguous) = A + alpha * x y^T  (ger.py) */
 int pthip_ger(int dtype, int64_t M, int64_t N, double alpha, const void* A, int64_t sA0,
               int64_t sA1, const void* x, int64_t sx, const void* y, int64_t sy, void* out);

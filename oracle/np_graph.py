@@ -263,7 +263,9 @@ def _check_runtime_broadcast(node, graph, inputs):
 @op("Elemwise")
 def _elemwise(p, inputs, node, graph):
     # pytensor/tensor/elemwise.py:755-823 (Elemwise.perform)
-    _check_runtime_broadcast(node, graph, inputs)
+    inputs = _sum_partial_inputs(p, inputs)
+    if not p.get("partial_inputs"):
+        _check_runtime_broadcast(node, graph, inputs)
     outs = eval_scalar_body(p["scalar"], inputs)
     shape = np.broadcast(*inputs).shape if inputs else ()
     res = []
@@ -738,8 +740,18 @@ def run_graph(graph, inputs):
 # ---------------------------------------------------------------------------
 
 
+def _sum_partial_inputs(p, inputs):
+    """Inputs listed in ``partial_inputs`` are split-K slabs (S, *shape) of a ``GemmPartials``
+    node (fusion.defer_gemm_finish): their value is the sum over the slab axis."""
+    pi = p.get("partial_inputs")
+    if not pi:
+        return inputs
+    return [np.sum(x, axis=0) if k in pi else x for k, x in enumerate(inputs)]
+
+
 @op("ElemwiseReduce")
 def _elemwise_reduce(p, inputs, node, graph):
+    inputs = _sum_partial_inputs(p, inputs)
     outs = eval_scalar_body(p["scalar"], inputs)
     shape = np.broadcast(*inputs).shape if inputs else ()
     res = []
@@ -834,3 +846,10 @@ def _argmax(p, inputs, node, graph):
     kept_shape = xt.shape[: len(keep)]
     r = xt.reshape((*kept_shape, int(np.prod(xt.shape[len(keep) :], dtype="int64"))))
     return [np.asarray(np.argmax(r, axis=-1), dtype="int64")]
+
+
+@op("GemmPartials")
+def _gemm_partials(p, inputs, node, graph):
+    # one slab = the whole product; the consumer's "partial_inputs" sum over the slab axis
+    A, B = inputs
+    return [np.dot(A, B)[None]]

@@ -587,17 +587,29 @@ def _reduce_epilogue(reduce_spec, unroll):
 MAX_ND = 5
 
 
-def nd_kernel_source(name: str, body: dict, ndim: int, reduce_spec=None) -> str:
+def nd_kernel_source(name: str, body: dict, ndim: int, reduce_spec=None, partial=(), byvalue=()) -> str:
     """General broadcasting loop: collapsed ``ndim``-d index (row-major over the output
-    shape), per-operand element strides (0 on broadcast dims); outputs contiguous."""
+    shape), per-operand element strides (0 on broadcast dims); outputs contiguous.
+
+    ``partial``: input positions that arrive as unfinished split-K slabs ``[np][n]`` (contiguous,
+    same iteration space as the output): the value is their sum in ascending slab order — the
+    order ``splitk_finish_kernel`` uses — folded into this kernel instead of a launch of its own."""
     nin = len(body["in_dtypes"])
     nout = len(body["out_dtypes"])
     reduce_spec = reduce_spec or [None] * nout
+    partial = set(partial)
+    byvalue = set(byvalue)
     params = ["long long n"]
     params += [f"long long d{j}" for j in range(ndim)]
     for k, dt in enumerate(body["in_dtypes"]):
+        if k in byvalue:  # host-known scalar: travels in the argument block
+            params.append(f"const long long in{k}")
+            continue
         params.append(f"const {CTYPE[dt]}* __restrict__ in{k}")
-        params += [f"long long s{k}_{j}" for j in range(ndim)]
+        if k in partial:
+            params += [f"long long np{k}", f"long long ps{k}"]
+        else:
+            params += [f"long long s{k}_{j}" for j in range(ndim)]
     for k, dt in enumerate(body["out_dtypes"]):
         if reduce_spec[k] is None:
             params.append(f"{CTYPE[dt]}* __restrict__ out{k}")
@@ -609,6 +621,9 @@ def nd_kernel_source(name: str, body: dict, ndim: int, reduce_spec=None) -> str:
         if rs is not None:
             act = CTYPE[rs[1]]
             src.append(f"  {act} acc{k}_0 = pthip_dev::{REDUCE_OPS[rs[0]]}::identity<{act}>();")
+    for k in sorted(byvalue):
+        ct = CTYPE[body["in_dtypes"][k]]
+        src.append(f"  {ct} bv{k}; {{ const long long b = in{k}; __builtin_memcpy(&bv{k}, &b, sizeof({ct})); }}")
     src.append(f"  for (long long i = (long long)blockIdx.x * {BLOCK} + threadIdx.x; i < n; i += (long long)gridDim.x * {BLOCK}) {{")
     src.append("      long long rem = i;")
     for j in range(ndim - 1, 0, -1):
@@ -616,6 +631,22 @@ def nd_kernel_source(name: str, body: dict, ndim: int, reduce_spec=None) -> str:
     src.append("      const long long c0 = rem;")
     in_names = []
     for k in range(nin):
+        if k in byvalue:
+            in_names.append(f"bv{k}")
+            continue
+        if k in partial:
+            ct = CTYPE[body["in_dtypes"][k]]
+            # eight independent loads in flight, added in ascending slab order (deterministic)
+            src.append(f"      {ct} p{k} = in{k}[i];")
+            src.append(f"      long long sl{k} = 1;")
+            src.append(f"      for (; sl{k} + 7 < np{k}; sl{k} += 8) {{")
+            src.append(f"        {ct} q{k}[8];")
+            src.append(f"#pragma unroll\n        for (int u = 0; u < 8; u++) q{k}[u] = in{k}[(sl{k} + u) * ps{k} + i];")
+            src.append(f"#pragma unroll\n        for (int u = 0; u < 8; u++) p{k} += q{k}[u];")
+            src.append("      }")
+            src.append(f"      for (; sl{k} < np{k}; sl{k}++) p{k} += in{k}[sl{k} * ps{k} + i];")
+            in_names.append(f"p{k}")
+            continue
         off = " + ".join(f"c{j} * s{k}_{j}" for j in range(ndim)) or "0"
         in_names.append(f"in{k}[{off}]")
     out_names = []

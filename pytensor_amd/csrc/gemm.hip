@@ -375,10 +375,39 @@ template <> struct KernelSel<float> {
   template <bool a, bool b, bool s> static auto get() { return sgemm_kernel<a, b, s>; }
 };
 
+// split-K when the tile grid cannot fill the chip (skinny / small GEMMs, e.g. the
+// (B x H)@(H x H) products of a Scan step): aim for >= 256 workgroups, >= 64 k per split.
+// A pure function of the shape: pthip_gemm_nslabs() promises the same count to callers that
+// consume the raw partial slabs themselves (pthip_gemm_partials).
+struct SplitPlan {
+  long long nsplit, kchunk;
+};
+inline SplitPlan split_plan(long long batch, long long M, long long N, long long K) {
+  const long long tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const long long tiles = tiles_m * tiles_n * batch;
+  long long nsplit = 1;
+  if (tiles < 128 && K >= 128) {
+    static const long long cap = getenv("PTHIP_GEMM_MAXSPLIT") ? atoll(getenv("PTHIP_GEMM_MAXSPLIT")) : 64;
+    nsplit = (256 + tiles - 1) / tiles;
+    if (nsplit > K / 64) nsplit = K / 64;
+    if (nsplit > cap) nsplit = cap;
+    if (nsplit < 1) nsplit = 1;
+  }
+  long long kchunk = (K + nsplit - 1) / nsplit;
+  kchunk = (kchunk + BK - 1) / BK * BK;
+  if (kchunk < BK) kchunk = BK;
+  nsplit = (K + kchunk - 1) / kchunk;
+  if (nsplit < 1) nsplit = 1;
+  return {nsplit, kchunk};
+}
+
+// `partials` != nullptr: write the raw products into partials[nsplit][batch][M][N] and stop
+// (no finish launch: the consumer folds the fixed-order sum and the alpha/beta epilogue in)
 template <class T, bool AKC, bool BKC, bool SKINNY>
 int launch(long long batch, long long M, long long N, long long K, T alpha, const T* A,
            long long sAb, long long lda, const T* B, long long sBb, long long ldb, T beta,
-           const T* C, long long sCb, long long sC0, long long sC1, T* out) {
+           const T* C, long long sCb, long long sC0, long long sC1, T* out,
+           T* partials = nullptr) {
   hipStream_t st = pthip::ctx().stream;
   using SA = Stage<T, AKC>;
   using SB = Stage<T, BKC>;
@@ -393,22 +422,16 @@ int launch(long long batch, long long M, long long N, long long K, T alpha, cons
   constexpr int VN = 16 / sizeof(T);
   const int vecA = (lda % VN == 0) && (((uintptr_t)A) % 16 == 0) && (sAb % VN == 0);
   const int vecB = (ldb % VN == 0) && (((uintptr_t)B) % 16 == 0) && (sBb % VN == 0);
-  // split-K when the tile grid cannot fill the chip (skinny / small GEMMs, e.g. the
-  // (B x H)@(H x H) products of a Scan step): aim for >= 256 workgroups, >= 64 k per split
-  const long long tiles = tiles_m * tiles_n * batch;
-  long long nsplit = 1;
-  if (tiles < 128 && K >= 128) {
-    nsplit = (256 + tiles - 1) / tiles;
-    if (nsplit > K / 64) nsplit = K / 64;
-    if (nsplit > 64) nsplit = 64;
-    if (nsplit < 1) nsplit = 1;
-  }
-  long long kchunk = (K + nsplit - 1) / nsplit;
-  kchunk = (kchunk + BK - 1) / BK * BK;
-  if (kchunk < BK) kchunk = BK;
-  nsplit = (K + kchunk - 1) / kchunk;
-  if (nsplit < 1) nsplit = 1;
+  const SplitPlan sp = split_plan(batch, M, N, K);
+  const long long nsplit = sp.nsplit, kchunk = sp.kchunk;
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)nsplit, (unsigned)batch);
+  if (partials != nullptr) {
+    // nsplit == 1: the epilogue with alpha = 1, beta = 0 stores the plain product in slab 0
+    hipLaunchKernelGGL(k, grid, dim3(BLOCK), shmem, st, partials, A, B, (const T*)nullptr, M, N, K,
+                       lda, ldb, sAb, sBb, (long long)(M * N), N, 1LL, T(1), T(0), tiles_m, tiles_n,
+                       vecA, vecB, kchunk);
+    return pthip::post_launch("gemm(partials)");
+  }
   if (nsplit == 1) {
     hipLaunchKernelGGL(k, grid, dim3(BLOCK), shmem, st, out, A, B, C, M, N, K, lda, ldb, sAb, sBb,
                        sCb, sC0, sC1, alpha, beta, tiles_m, tiles_n, vecA, vecB, kchunk);
@@ -436,7 +459,7 @@ template <class T>
 int gemm_typed(long long batch, long long M, long long N, long long K, double alpha, const void* A,
                long long sAb, long long sA0, long long sA1, const void* B, long long sBb,
                long long sB0, long long sB1, double beta, const void* C, long long sCb,
-               long long sC0, long long sC1, void* out) {
+               long long sC0, long long sC1, void* out, void* partials = nullptr) {
   if (batch == 0 || M == 0 || N == 0) return 0;
   // Normalise the strides of degenerate (length-1) dims, then classify:
   //   A (m,k) at m*sA0 + k*sA1 : K-contiguous iff sA1 == 1 (lda = sA0), else M-contiguous (lda = sA1)
@@ -462,9 +485,9 @@ int gemm_typed(long long batch, long long M, long long N, long long K, double al
   do {                                                                                             \
     if (skinny)                                                                                    \
       return launch<T, X, Y, true>(batch, M, N, K, (T)alpha, a, sAb, lda, b, sBb, ldb, (T)beta, c, \
-                                   sCb, sC0, sC1, o);                                              \
+                                   sCb, sC0, sC1, o, (T*)partials);                                \
     return launch<T, X, Y, false>(batch, M, N, K, (T)alpha, a, sAb, lda, b, sBb, ldb, (T)beta, c,  \
-                                  sCb, sC0, sC1, o);                                               \
+                                  sCb, sC0, sC1, o, (T*)partials);                                 \
   } while (0)
   if (akc && bkc) GO(true, true);
   if (akc && !bkc) GO(true, false);
@@ -485,4 +508,29 @@ extern "C" int pthip_gemm(int dtype, int64_t batch, int64_t M, int64_t N, int64_
   if (dtype == PTHIP_F32)
     return gemm_typed<float>(batch, M, N, K, alpha, A, sAb, sA0, sA1, B, sBb, sB0, sB1, beta, C, sCb, sC0, sC1, out);
   return pthip::set_error("pthip_gemm: dtype %d not supported (float32/float64 only)", dtype);
+}
+
+// Number of partial slabs pthip_gemm_partials writes for this shape (1 = no split-K).
+extern "C" int64_t pthip_gemm_nslabs(int64_t batch, int64_t M, int64_t N, int64_t K) {
+  if (batch <= 0 || M <= 0 || N <= 0) return 1;
+  return split_plan(batch, M, N, K).nsplit;
+}
+
+// Raw products for a consumer that folds the split-K sum into its own kernel:
+// part[s][b][m][n] = sum over the s-th K range of A[b][m][k] * B[b][k][n]; the caller adds the
+// slabs in ascending s (the order splitk_finish_kernel uses) and applies alpha/beta itself.
+// `nslabs` must equal pthip_gemm_nslabs(batch, M, N, K).
+extern "C" int pthip_gemm_partials(int dtype, int64_t batch, int64_t M, int64_t N, int64_t K,
+                                   const void* A, int64_t sAb, int64_t sA0, int64_t sA1,
+                                   const void* B, int64_t sBb, int64_t sB0, int64_t sB1, void* part,
+                                   int64_t nslabs) {
+  PTHIP_REQUIRE_INIT();
+  if (nslabs != pthip_gemm_nslabs(batch, M, N, K))
+    return pthip::set_error("pthip_gemm_partials: slab count %lld does not match the plan", (long long)nslabs);
+  if (K == 0) return pthip_memset(part, 0, (size_t)(batch * M * N) * (dtype == PTHIP_F64 ? 8 : 4));
+  if (dtype == PTHIP_F64)
+    return gemm_typed<double>(batch, M, N, K, 1.0, A, sAb, sA0, sA1, B, sBb, sB0, sB1, 0.0, nullptr, 0, 0, 0, part, part);
+  if (dtype == PTHIP_F32)
+    return gemm_typed<float>(batch, M, N, K, 1.0, A, sAb, sA0, sA1, B, sBb, sB0, sB1, 0.0, nullptr, 0, 0, 0, part, part);
+  return pthip::set_error("pthip_gemm_partials: dtype %d not supported (float32/float64 only)", dtype);
 }

@@ -223,3 +223,24 @@ def seq_dot22(node, inputs, env):
     out = gemm_device(env, 1.0, flat, _prep2d(W))
     N = W.shape[1]
     return [out.view((T, B, N), (B * N, N, 1))]
+
+
+@handler("GemmPartials")
+def gemm_partials(node, inputs, env):
+    """``A @ B`` left as split-K slabs ``(S, M, N)`` for the Elemwise node that consumes it
+    (fusion.defer_gemm_finish): that kernel adds the slabs in order and applies the Gemm's
+    alpha/beta, so the separate finish launch of ``pthip_gemm`` disappears."""
+    A, B = (_prep2d(env.to_device(i)) for i in inputs)
+    M, K = A.shape
+    K2, N = B.shape
+    if K != K2:
+        raise ValueError(f"Shape mismatch: x has {K} cols but y has {K2} rows")
+    if str(A.dtype) != str(B.dtype):
+        raise TypeError("GemmPartials: dtype mismatch")
+    S = int(env.lib.pthip_gemm_nslabs(1, M, N, K)) if M and N else 1
+    part = DeviceArray.empty((S, M, N), A.dtype)
+    if part.size:
+        ffi.check(
+            env.lib.pthip_gemm_partials(_dt(A), 1, M, N, K, A.ptr, 0, A.strides[0], A.strides[1], B.ptr, 0, B.strides[0], B.strides[1], part.ptr, S)
+        )
+    return [part]

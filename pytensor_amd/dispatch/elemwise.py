@@ -103,7 +103,17 @@ def _host_eval(body, inputs):
 # ---------------------------------------------------------------------------
 
 
-def _broadcast_shape(node, graph, ins):
+def _broadcast_shape(node, graph, ins, skip=()):
+    """Elemwise output shape; ``skip`` = positions of split-K slab inputs (one extra leading
+    dim, they do not take part in broadcasting)."""
+    if skip:
+        keep = [k for k in range(len(ins)) if k not in skip]
+        sel = type("_Sel", (), {"inputs": [node.inputs[k] for k in keep]})
+        shape = _broadcast_shape(sel, graph, [ins[k] for k in keep])
+        for k in skip:
+            if tuple(ins[k].shape[1:]) != shape:
+                raise ValueError(f"Incompatible Elemwise input shapes {[i.shape for i in ins]}")
+        return shape
     nd = max((i.ndim for i in ins), default=0)
     shape = [1] * nd
     for d in range(nd):
@@ -156,9 +166,12 @@ def _scalar_or_device(env, i):
     return i if isinstance(i, HostValue) and i.a.size == 1 else env.to_device(i)
 
 
-def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env):
+def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=()):
     """Launch the fused kernel.  Returns (stored outputs or None per output,
-    partial buffers or None per output, grid)."""
+    partial buffers or None per output, grid).
+
+    ``partial``: positions of inputs that are unfinished split-K slabs ``(S, *out_shape)``
+    (``GemmPartials``): summed inside the kernel, in slab order."""
     lib = env.lib
     n = int(np.prod(out_shape)) if out_shape else 1
     nout = len(out_dtypes)
@@ -167,9 +180,10 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env):
     if n == 0:
         return outs, [None] * nout, 0
     nd = len(out_shape)
+    partial = set(partial)
     modes = []
-    flat = True
-    for a in ins:
+    flat = not partial
+    for a in ins if flat else ():
         if isinstance(a, HostValue):
             modes.append("C")  # host-known scalar: by value, no upload node in a captured plan
         elif a.size == 1:
@@ -179,8 +193,11 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env):
         else:
             flat = False
             break
+    byvalue = set()
     if not flat:
-        ins = [env.to_device(a) for a in ins]
+        # host-known scalars travel by value here too (no upload node per replay)
+        byvalue = {k for k, a in enumerate(ins) if isinstance(a, HostValue) and a.a.size == 1}
+        ins = [a if k in byvalue else env.to_device(a) for k, a in enumerate(ins)]
     bkey = _body_key(body)
     rkey = "".join("-" if r is None else r["op"][0] + r["acc_dtype"][0] + r["acc_dtype"][-1] for r in reduce_spec)
     rs = [None if r is None else (r["op"], r["acc_dtype"]) for r in reduce_spec]
@@ -203,7 +220,13 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env):
     else:
         sshape = tuple(out_shape)
         strides = []
-        for a in ins:
+        for k, a in enumerate(ins):
+            if k in byvalue:
+                continue
+            if k in partial:
+                if a.shape[1:] != sshape or not a.is_contiguous():
+                    raise ValueError(f"split-K slabs of shape {a.shape} do not match the Elemwise shape {sshape}")
+                continue
             st = tuple(0 if a.shape[d] == 1 and sshape[d] != 1 else a.strides[d] for d in range(nd))
             strides.append(st)
         cshape, cstr = _collapse(sshape, strides + [_cstrides(sshape)])
@@ -211,16 +234,25 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env):
         ndc = len(cshape)
         if ndc > codegen.MAX_ND:
             # materialise the worst operand and retry (rare: >5 non-mergeable dims)
-            ins = [a.contiguous() if not a.is_contiguous() else a for a in ins]
-            return launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env)
-        name = f"ewnd_{bkey}_d{ndc}_{rkey}".replace("-", "x")
-        src = codegen.nd_kernel_source(name, body, ndc, rs)
+            ins = [a if isinstance(a, HostValue) or a.is_contiguous() else a.contiguous() for a in ins]
+            return launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial)
+        pkey = ("_p" + "".join(str(k) + "." for k in sorted(partial))) if partial else ""
+        pkey += ("_c" + "".join(str(k) + "." for k in sorted(byvalue))) if byvalue else ""
+        name = f"ewnd_{bkey}_d{ndc}_{rkey}{pkey}".replace("-", "x").replace(".", "_")
+        src = codegen.nd_kernel_source(name, body, ndc, rs, partial, byvalue)
         fn = kernel_cache.get_function(src, name)
         grid = _grid(n)
         args = [n] + list(cshape)
-        for a, st in zip(ins, cstr):
+        it = iter(cstr)
+        for k, a in enumerate(ins):
+            if k in byvalue:
+                args.append(_scalar_bits(a, body["in_dtypes"][k]))
+                continue
             args.append(a.ptr)
-            args += list(st)
+            if k in partial:
+                args += [a.shape[0], n]
+            else:
+                args += list(next(it))
     parts = alloc_partials(reduce_spec, grid)
     for k in range(nout):
         args.append(outs[k].ptr if reduce_spec[k] is None else parts[k].ptr)
@@ -327,8 +359,9 @@ def elemwise(node, inputs, env):
     if _host_evaluable(body, inputs) and all(i.a.size <= HOST_MAX for i in inputs):
         return _host_eval(body, inputs)
     ins = [_scalar_or_device(env, i) for i in inputs]
-    shape = _broadcast_shape(node, g, ins)
-    outs, _, _ = launch_elemwise(body, ins, shape, body["out_dtypes"], None, env)
+    pi = tuple(node.params.get("partial_inputs") or ())
+    shape = _broadcast_shape(node, g, ins, pi)
+    outs, _, _ = launch_elemwise(body, ins, shape, body["out_dtypes"], None, env, pi)
     return outs
 
 
@@ -338,8 +371,9 @@ def elemwise_reduce(node, inputs, env):
     spec = node.params["reduce"]
     g = env.graph
     ins = [_scalar_or_device(env, i) for i in inputs]
-    shape = _broadcast_shape(node, g, ins)
-    outs, parts, grid = launch_elemwise(body, ins, shape, body["out_dtypes"], spec, env)
+    pi = tuple(node.params.get("partial_inputs") or ())
+    shape = _broadcast_shape(node, g, ins, pi)
+    outs, parts, grid = launch_elemwise(body, ins, shape, body["out_dtypes"], spec, env, pi)
     finals = finish_partials(env, spec, parts, grid) if grid else [None] * len(spec)
     res = []
     for k, r in enumerate(spec):

@@ -8,6 +8,8 @@ Order matters:
 3. ``merge_sibling_reductions`` (inline.py);
 4. ``hoist_scan_seq_dots`` — sequence-only products out of ``Scan``;
 5. ``fuse_cholesky_solve`` — Cholesky + its first triangular solve, factor kept in LDS;
+   ``defer_gemm_finish`` (gemmfuse.py) — split-K finish + Gemm epilogue folded into the
+   consuming elementwise kernel (also inside Scan inner graphs);
 6. ``fuse_gemv_chain`` — ``X@b → Composite → X.T@w`` (+ gathers, + scatter-add) in one pass;
 7. ``dead_code_elimination``;
 8. ``segment_graph`` — latency chain / streaming / combine segments for multi-stream plans.
@@ -25,6 +27,7 @@ from pytensor_amd.fusion import (
     hoist_scan_seq_dots,
     segment_graph,
 )
+from pytensor_amd.gemmfuse import defer_gemm_finish
 from pytensor_amd.inline import (
     dead_code_elimination,
     inline_elemwise_producers,
@@ -45,5 +48,6 @@ def run_pipeline(graph: Graph, fuse=True):
     g = merge_sibling_reductions(g)
     g = hoist_scan_seq_dots(g)
     g = fuse_cholesky_solve(g)
+    g = defer_gemm_finish(g)
     g = dead_code_elimination(fuse_gemv_chain(g))
     return segment_graph(g)

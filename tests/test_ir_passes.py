@@ -59,7 +59,11 @@ def test_c5_scan_dots_are_hoisted():
     assert ops.count("SeqDot22") == 3
     scan = next(n for n in g2.nodes if n.op == "Scan")
     inner_ops = [m.op for m in scan.params["inner"].nodes]
-    assert "Dot22" not in inner_ops and inner_ops.count("Gemm") == 3
+    # the three recurrent products stay in the loop, as split-K slabs whose finish (and the
+    # Gemm's b*y + a*(.) epilogue) is folded into the two gate kernels (gemmfuse.py)
+    assert "Dot22" not in inner_ops and "Gemm" not in inner_ops and inner_ops.count("GemmPartials") == 3
+    ew = [m for m in scan.params["inner"].nodes if m.op == "Elemwise"]
+    assert sorted(len(m.params["partial_inputs"]) for m in ew) == [1, 2]
     assert scan.params["info"]["n_seqs"] == 4
     # the original graph object is untouched (passes are functional)
     g_again, *_ = load_case("c5_gru")
