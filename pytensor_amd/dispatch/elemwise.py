@@ -166,7 +166,19 @@ def _scalar_or_device(env, i):
     return i if isinstance(i, HostValue) and i.a.size == 1 else env.to_device(i)
 
 
-def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=()):
+def _placed(env, node, shape, out_dtypes):
+    """Pre-assigned destinations (``env.placement``) for this node's outputs, where they fit."""
+    if not env.placement:
+        return None
+    res = []
+    for o, dt in zip(node.outputs, out_dtypes):
+        b = env.placement.get(o)
+        ok = b is not None and b.shape == tuple(shape) and str(b.dtype) == str(dt) and b.is_contiguous()
+        res.append(b if ok else None)
+    return res if any(r is not None for r in res) else None
+
+
+def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=(), out_bufs=None):
     """Launch the fused kernel.  Returns (stored outputs or None per output,
     partial buffers or None per output, grid).
 
@@ -176,7 +188,10 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=
     n = int(np.prod(out_shape)) if out_shape else 1
     nout = len(out_dtypes)
     reduce_spec = reduce_spec or [None] * nout
-    outs = [None if reduce_spec[k] else DeviceArray.empty(out_shape, out_dtypes[k]) for k in range(nout)]
+    outs = [
+        None if reduce_spec[k] else (out_bufs[k] if out_bufs and out_bufs[k] is not None else DeviceArray.empty(out_shape, out_dtypes[k]))
+        for k in range(nout)
+    ]
     if n == 0:
         return outs, [None] * nout, 0
     nd = len(out_shape)
@@ -235,7 +250,7 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=
         if ndc > codegen.MAX_ND:
             # materialise the worst operand and retry (rare: >5 non-mergeable dims)
             ins = [a if isinstance(a, HostValue) or a.is_contiguous() else a.contiguous() for a in ins]
-            return launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial)
+            return launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial, out_bufs)
         pkey = ("_p" + "".join(str(k) + "." for k in sorted(partial))) if partial else ""
         pkey += ("_c" + "".join(str(k) + "." for k in sorted(byvalue))) if byvalue else ""
         name = f"ewnd_{bkey}_d{ndc}_{rkey}{pkey}".replace("-", "x").replace(".", "_")
@@ -361,7 +376,7 @@ def elemwise(node, inputs, env):
     ins = [_scalar_or_device(env, i) for i in inputs]
     pi = tuple(node.params.get("partial_inputs") or ())
     shape = _broadcast_shape(node, g, ins, pi)
-    outs, _, _ = launch_elemwise(body, ins, shape, body["out_dtypes"], None, env, pi)
+    outs, _, _ = launch_elemwise(body, ins, shape, body["out_dtypes"], None, env, pi, _placed(env, node, shape, body["out_dtypes"]))
     return outs
 
 
@@ -373,7 +388,7 @@ def elemwise_reduce(node, inputs, env):
     ins = [_scalar_or_device(env, i) for i in inputs]
     pi = tuple(node.params.get("partial_inputs") or ())
     shape = _broadcast_shape(node, g, ins, pi)
-    outs, parts, grid = launch_elemwise(body, ins, shape, body["out_dtypes"], spec, env, pi)
+    outs, parts, grid = launch_elemwise(body, ins, shape, body["out_dtypes"], spec, env, pi, _placed(env, node, shape, body["out_dtypes"]))
     finals = finish_partials(env, spec, parts, grid) if grid else [None] * len(spec)
     res = []
     for k, r in enumerate(spec):

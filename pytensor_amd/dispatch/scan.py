@@ -89,11 +89,26 @@ def scan(node, inputs, env):
                 step_in.append(buf.view(buf.shape[1:], buf.strides[1:], ((t + mt + tap) % L) * buf.strides[0]))
         step_in += untraced
         step_in += non_seqs
-        outs, _ = inner.run_device(step_in, env)
-        o = 0
-        for buf, mt in zip(rec_bufs, mintaps):
+        # the kernel that produces a recurrent output writes it straight into its trace slot
+        # (no copy launch per step) — unless that slot is also one of this step's taps
+        tap_ptrs = {v.ptr for v in step_in if isinstance(v, DeviceArray)}
+        slots, placement = [], {}
+        for j, (buf, mt) in enumerate(zip(rec_bufs, mintaps)):
             slot = buf.view(buf.shape[1:], buf.strides[1:], ((t + mt) % buf.shape[0]) * buf.strides[0])
-            copy_into(slot, env.to_device(outs[o]))
+            slots.append(slot)
+            if slot.ptr not in tap_ptrs and slot.is_contiguous():
+                placement[ig.outputs[j]] = slot
+        saved = env.placement
+        env.placement = placement
+        try:
+            outs, _ = inner.run_device(step_in, env)
+        finally:
+            env.placement = saved
+        o = 0
+        for slot in slots:
+            v = env.to_device(outs[o])
+            if not (v.ptr == slot.ptr and v.shape == slot.shape and v.strides == slot.strides):
+                copy_into(slot, v)
             o += 1
         for j in range(info["n_nit_sot"]):
             v = env.to_device(outs[o])

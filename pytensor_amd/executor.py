@@ -114,6 +114,9 @@ class Env:
         self.scheduler = None  # StreamScheduler of a multi-stream frozen plan
         self.donated = frozenset()  # input positions of the running node that may be overwritten
         self.node_key = None  # (executable id, node index) of the running node
+        # var id -> DeviceArray the producing kernel should write into directly (a Scan's trace
+        # slot): handlers that support it skip their own allocation, the caller skips the copy
+        self.placement = {}
 
     def to_device(self, v) -> DeviceArray:
         if isinstance(v, DeviceArray):
