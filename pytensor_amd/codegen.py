@@ -607,7 +607,8 @@ def nd_kernel_source(name: str, body: dict, ndim: int, reduce_spec=None, partial
             continue
         params.append(f"const {CTYPE[dt]}* __restrict__ in{k}")
         if k in partial:
-            params += [f"long long np{k}", f"long long ps{k}"]
+            # np slabs, slab stride ps; rows of pn elements, pld apart (a column block of wider slabs)
+            params += [f"long long np{k}", f"long long ps{k}", f"long long pn{k}", f"long long pld{k}"]
         else:
             params += [f"long long s{k}_{j}" for j in range(ndim)]
     for k, dt in enumerate(body["out_dtypes"]):
@@ -637,14 +638,15 @@ def nd_kernel_source(name: str, body: dict, ndim: int, reduce_spec=None, partial
         if k in partial:
             ct = CTYPE[body["in_dtypes"][k]]
             # eight independent loads in flight, added in ascending slab order (deterministic)
-            src.append(f"      {ct} p{k} = in{k}[i];")
+            src.append(f"      const long long pi{k} = (pld{k} == pn{k}) ? i : (i / pn{k}) * pld{k} + (i % pn{k});")
+            src.append(f"      {ct} p{k} = in{k}[pi{k}];")
             src.append(f"      long long sl{k} = 1;")
             src.append(f"      for (; sl{k} + 7 < np{k}; sl{k} += 8) {{")
             src.append(f"        {ct} q{k}[8];")
-            src.append(f"#pragma unroll\n        for (int u = 0; u < 8; u++) q{k}[u] = in{k}[(sl{k} + u) * ps{k} + i];")
+            src.append(f"#pragma unroll\n        for (int u = 0; u < 8; u++) q{k}[u] = in{k}[(sl{k} + u) * ps{k} + pi{k}];")
             src.append(f"#pragma unroll\n        for (int u = 0; u < 8; u++) p{k} += q{k}[u];")
             src.append("      }")
-            src.append(f"      for (; sl{k} < np{k}; sl{k}++) p{k} += in{k}[sl{k} * ps{k} + i];")
+            src.append(f"      for (; sl{k} < np{k}; sl{k}++) p{k} += in{k}[sl{k} * ps{k} + pi{k}];")
             in_names.append(f"p{k}")
             continue
         off = " + ".join(f"c{j} * s{k}_{j}" for j in range(ndim)) or "0"

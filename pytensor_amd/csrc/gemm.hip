@@ -388,8 +388,10 @@ inline SplitPlan split_plan(long long batch, long long M, long long N, long long
   long long nsplit = 1;
   if (tiles < 128 && K >= 128) {
     static const long long cap = getenv("PTHIP_GEMM_MAXSPLIT") ? atoll(getenv("PTHIP_GEMM_MAXSPLIT")) : 64;
-    nsplit = (256 + tiles - 1) / tiles;
-    if (nsplit > K / 64) nsplit = K / 64;
+    static const long long mink = getenv("PTHIP_GEMM_MINK") ? atoll(getenv("PTHIP_GEMM_MINK")) : 64;
+    static const long long wgs = getenv("PTHIP_GEMM_WGS") ? atoll(getenv("PTHIP_GEMM_WGS")) : 256;
+    nsplit = (wgs + tiles - 1) / tiles;
+    if (nsplit > K / mink) nsplit = K / mink;
     if (nsplit > cap) nsplit = cap;
     if (nsplit < 1) nsplit = 1;
   }

@@ -239,8 +239,13 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=
             if k in byvalue:
                 continue
             if k in partial:
-                if a.shape[1:] != sshape or not a.is_contiguous():
-                    raise ValueError(f"split-K slabs of shape {a.shape} do not match the Elemwise shape {sshape}")
+                # slabs (S, *shape): rows of shape[-1] contiguous elements, uniformly spaced
+                # (a column block of wider slabs is fine: merge_sibling_gemms)
+                ok = a.shape[1:] == sshape and (sshape[-1] == 1 or a.strides[-1] == 1)
+                for d in range(1, nd - 1):
+                    ok = ok and (a.shape[d] == 1 or a.strides[d] == a.strides[d + 1] * a.shape[d + 1])
+                if not ok:
+                    raise ValueError(f"split-K slabs of shape {a.shape}/strides {a.strides} do not match the Elemwise shape {sshape}")
                 continue
             st = tuple(0 if a.shape[d] == 1 and sshape[d] != 1 else a.strides[d] for d in range(nd))
             strides.append(st)
@@ -265,7 +270,9 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=
                 continue
             args.append(a.ptr)
             if k in partial:
-                args += [a.shape[0], n]
+                pn = sshape[-1] if nd else 1
+                pld = a.strides[-2] if nd >= 2 and n > pn else pn
+                args += [a.shape[0], a.strides[0] if a.shape[0] > 1 else 0, pn, pld]
             else:
                 args += list(next(it))
     parts = alloc_partials(reduce_spec, grid)

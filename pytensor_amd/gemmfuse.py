@@ -135,3 +135,94 @@ def defer_gemm_finish(g: Graph) -> Graph:
                 nodes.append(n)
         g = _copy(g, nodes)
         g.vars.update(new_vars)
+
+
+def merge_sibling_gemms(g: Graph) -> Graph:
+    """``h @ U_r`` and ``h @ U_z`` of one Scan step → ``h @ [U_r | U_z]``.
+
+    Two ``GemmPartials`` nodes of a Scan's inner graph that share the left operand and whose
+    right operands are loop constants (non-sequences) become one product against the
+    concatenated weights; the concatenation (``Join`` on axis 1) is hoisted into the outer
+    graph — once per evaluation, not per step — and travels as one more non-sequence.  The
+    consumers read column blocks of the shared slabs (strided views, no copy).  One launch
+    instead of two per step; the merged GEMM is still far too small to notice the wider N."""
+    out_nodes, new_vars, changed = [], {}, False
+    for n in g.nodes:
+        if n.op != "Scan":
+            out_nodes.append(n)
+            continue
+        res = _merge_in_scan(g, n, new_vars)
+        if res is None:
+            out_nodes.append(n)
+        else:
+            pre, scan = res
+            out_nodes += pre + [scan]
+            changed = True
+    if not changed:
+        return g
+    g2 = _copy(g, out_nodes)
+    g2.vars.update(new_vars)
+    return merge_sibling_gemms(g2)  # further pairs / other Scan nodes
+
+
+def _merge_in_scan(g: Graph, scan: Node, new_vars: dict):
+    info = scan.params["info"]
+    inner: Graph = scan.params["inner"]
+    nns = info["n_non_seqs"]
+    if nns < 2:
+        return None
+    n_in = len(inner.inputs)
+    non_seq_pos = {v: p for p, v in enumerate(inner.inputs) if p >= n_in - nns}
+    gp = [(k, m) for k, m in enumerate(inner.nodes) if m.op == "GemmPartials"]
+    pair = None
+    for a in range(len(gp)):
+        for b in range(a + 1, len(gp)):
+            (k1, P1), (k2, P2) = gp[a], gp[b]
+            if P1.inputs[0] != P2.inputs[0] or P1.inputs[1] == P2.inputs[1]:
+                continue
+            if P1.inputs[1] not in non_seq_pos or P2.inputs[1] not in non_seq_pos:
+                continue
+            v1, v2 = inner.vars[P1.inputs[1]], inner.vars[P2.inputs[1]]
+            if v1.dtype != v2.dtype or v1.ndim != 2 or v2.ndim != 2:
+                continue
+            pair = (k1, k2)
+            break
+        if pair:
+            break
+    if pair is None:
+        return None
+    k1, k2 = pair
+    P1, P2 = inner.nodes[k1], inner.nodes[k2]
+    A, B1, B2 = P1.inputs[0], P1.inputs[1], P2.inputs[1]
+    dt = inner.vars[B1].dtype
+    # ---- outer graph: Bcat = Join(axis=1)(B1, B2), one more non-sequence of the Scan ----
+    o1 = scan.inputs[len(scan.inputs) - n_in + non_seq_pos[B1]]
+    o2 = scan.inputs[len(scan.inputs) - n_in + non_seq_pos[B2]]
+    bcat_o = _fresh(g, new_vars, dt, (None, None), name="scan_gemm_weights_cat")
+    join = Node("Join", {"axis": 1}, [o1, o2], [bcat_o])
+    # ---- inner graph ----
+    ivars = {}
+    bcat_i = _fresh(inner, ivars, dt, (None, None), name="weights_cat")
+    pvc = _fresh(inner, ivars, dt, (None, None, None), name="gemm_partials_cat")
+    n1 = _fresh(inner, ivars, "int64", ())
+    full = slice(None, None, None)
+    new_nodes = []
+    for k, m in enumerate(inner.nodes):
+        if k == k1:
+            new_nodes.append(Node("GemmPartials", {}, [A, bcat_i], [pvc]))
+            new_nodes.append(Node("Shape_i", {"i": 1}, [B1], [n1]))
+            new_nodes.append(Node("Subtensor", {"idx_list": [full, full, slice(None, 0, None)]}, [pvc, n1], [P1.outputs[0]]))
+            new_nodes.append(Node("Subtensor", {"idx_list": [full, full, slice(0, None, None)]}, [pvc, n1], [P2.outputs[0]]))
+        elif k == k2:
+            continue
+        else:
+            new_nodes.append(m)
+    new_inner = _copy(inner, new_nodes)
+    new_inner.vars.update(ivars)
+    new_inner.inputs = list(inner.inputs) + [bcat_i]
+    new_info = dict(info)
+    new_info["n_non_seqs"] = nns + 1
+    params = dict(scan.params)
+    params["inner"] = new_inner
+    params["info"] = new_info
+    return [join], Node("Scan", params, list(scan.inputs) + [bcat_o], list(scan.outputs))

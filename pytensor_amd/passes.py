@@ -27,7 +27,7 @@ from pytensor_amd.fusion import (
     hoist_scan_seq_dots,
     segment_graph,
 )
-from pytensor_amd.gemmfuse import defer_gemm_finish
+from pytensor_amd.gemmfuse import defer_gemm_finish, merge_sibling_gemms
 from pytensor_amd.inline import (
     dead_code_elimination,
     inline_elemwise_producers,
@@ -48,6 +48,6 @@ def run_pipeline(graph: Graph, fuse=True):
     g = merge_sibling_reductions(g)
     g = hoist_scan_seq_dots(g)
     g = fuse_cholesky_solve(g)
-    g = defer_gemm_finish(g)
+    g = merge_sibling_gemms(defer_gemm_finish(g))
     g = dead_code_elimination(fuse_gemv_chain(g))
     return segment_graph(g)

@@ -61,7 +61,10 @@ def test_c5_scan_dots_are_hoisted():
     inner_ops = [m.op for m in scan.params["inner"].nodes]
     # the three recurrent products stay in the loop, as split-K slabs whose finish (and the
     # Gemm's b*y + a*(.) epilogue) is folded into the two gate kernels (gemmfuse.py)
-    assert "Dot22" not in inner_ops and "Gemm" not in inner_ops and inner_ops.count("GemmPartials") == 3
+    # h@U_r and h@U_z share h: one product against the concatenated weights (Join hoisted out)
+    assert "Dot22" not in inner_ops and "Gemm" not in inner_ops and inner_ops.count("GemmPartials") == 2
+    assert ops.count("Join") == 1 and ops.index("Join") < ops.index("Scan")
+    assert scan.params["info"]["n_non_seqs"] == 10
     ew = [m for m in scan.params["inner"].nodes if m.op == "Elemwise"]
     assert sorted(len(m.params["partial_inputs"]) for m in ew) == [1, 2]
     assert scan.params["info"]["n_seqs"] == 4
