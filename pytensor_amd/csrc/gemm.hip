@@ -294,19 +294,7 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_kernel(
   const long long kb = (long long)blockIdx.y * kchunk;
   const long long Kend = (kb + kchunk < K) ? kb + kchunk : K;
   const long long nk = (Kend - kb + BK - 1) / BK;
-  sa.load(A, lda, m0, kb, M, Kend, vecA);
-  sb.load(B, ldb, n0, kb, N, Kend, vecB);
-  sa.store(As);
-  sb.store(Bs);
-  __syncthreads();
-  for (long long kt = 0; kt < nk; kt++) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      sa.load(A, lda, m0, kb + (kt + 1) * BK, M, Kend, vecA);
-      sb.load(B, ldb, n0, kb + (kt + 1) * BK, N, Kend, vecB);
-    }
-    const float* as = As + cur * SA::SIZE;
-    const float* bs = Bs + cur * SB::SIZE;
+  auto compute = [&](const float* as, const float* bs) {
 #pragma unroll
     for (int kk = 0; kk < BK / 4; kk++) {
       float2 af[2], bf[NJ];
@@ -322,11 +310,53 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_kernel(
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
         }
     }
-    if (kt + 1 < nk) {
-      sa.store(As + (cur ^ 1) * SA::SIZE);
-      sb.store(Bs + (cur ^ 1) * SB::SIZE);
-    }
+  };
+  constexpr int PRE = 4;
+  if (SKINNY && nk <= PRE) {
+    // a split-K slice of a skinny product is a few BK steps long: every step's global loads
+    // are issued up front (one HBM/L2 latency for the whole workgroup instead of one per
+    // step — there is almost no MFMA work per step to hide them behind)
+    SA sap[PRE];
+    SB sbp[PRE];
+#pragma unroll
+    for (int t = 0; t < PRE; t++)
+      if (t < nk) {
+        sap[t].load(A, lda, m0, kb + t * BK, M, Kend, vecA);
+        sbp[t].load(B, ldb, n0, kb + t * BK, N, Kend, vecB);
+      }
+    sap[0].store(As);
+    sbp[0].store(Bs);
     __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < PRE; kt++)
+      if (kt < nk) {
+        const int cur = kt & 1;
+        compute(As + cur * SA::SIZE, Bs + cur * SB::SIZE);
+        if (kt + 1 < PRE && kt + 1 < nk) {
+          sap[kt + 1 < PRE ? kt + 1 : 0].store(As + (cur ^ 1) * SA::SIZE);
+          sbp[kt + 1 < PRE ? kt + 1 : 0].store(Bs + (cur ^ 1) * SB::SIZE);
+        }
+        __syncthreads();
+      }
+  } else {
+    sa.load(A, lda, m0, kb, M, Kend, vecA);
+    sb.load(B, ldb, n0, kb, N, Kend, vecB);
+    sa.store(As);
+    sb.store(Bs);
+    __syncthreads();
+    for (long long kt = 0; kt < nk; kt++) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) {
+        sa.load(A, lda, m0, kb + (kt + 1) * BK, M, Kend, vecA);
+        sb.load(B, ldb, n0, kb + (kt + 1) * BK, N, Kend, vecB);
+      }
+      compute(As + cur * SA::SIZE, Bs + cur * SB::SIZE);
+      if (kt + 1 < nk) {
+        sa.store(As + (cur ^ 1) * SA::SIZE);
+        sb.store(Bs + (cur ^ 1) * SB::SIZE);
+      }
+      __syncthreads();
+    }
   }
   const bool has_c = !split && (beta != 0.f) && C != nullptr;
   if (has_c) C += bz * sCb;
