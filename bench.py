@@ -119,8 +119,10 @@ def main():
     k_dom, op_dom, ms_dom = max(prof, key=lambda t: t[2])
     N, K = vals["X"].shape
     if op_dom == "GemvChain":
-        # X once + the three N-vectors the fused scalar graph touches (y, a[gidx] in; w out)
-        bytes_per_launch = N * K * 8 + 3 * N * 8
+        # X once + the two N-vectors the kernel streams: y and gidx (int64; read for the gather
+        # a[gidx] and again, from cache, for the scatter-add).  w and a[gidx] never touch HBM;
+        # the G-entry table and the per-workgroup partials (4 MB) are not counted.
+        bytes_per_launch = N * K * 8 + 2 * N * 8
         kernel_name = "gchain_* (fused Gemv(row) -> Composite -> Gemv(col), one pass over X)"
     else:
         bytes_per_launch = N * K * 8

@@ -1,0 +1,58 @@
+"""Device time of pthip_gemm for a few shapes (HIP events around back-to-back launches).
+
+usage: python tools/bench_gemm.py
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pytensor_amd import ffi  # noqa: E402
+from pytensor_amd.device import DeviceArray  # noqa: E402
+
+PEAK = {"float64": 78.6, "float32": 157.3}
+
+
+def timed(lib, fn, reps):
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    ffi.check(lib.pthip_event_create(C.byref(e0)))
+    ffi.check(lib.pthip_event_create(C.byref(e1)))
+    for _ in range(3):
+        fn()
+    ffi.check(lib.pthip_event_record(e0))
+    for _ in range(reps):
+        fn()
+    ffi.check(lib.pthip_event_record(e1))
+    ffi.check(lib.pthip_event_synchronize(e1))
+    ms = C.c_float()
+    ffi.check(lib.pthip_event_elapsed_ms(e0, e1, C.byref(ms)))
+    return ms.value / reps
+
+
+def main():
+    ffi.init(0)
+    lib = ffi.lib()
+    for dtype, batch, M, N, K in [
+        ("float32", 1, 4096, 4096, 4096), ("float32", 1, 8192, 8192, 1024), ("float32", 512, 256, 256, 256),
+        ("float32", 64, 1024, 1024, 256), ("float64", 1, 4096, 4096, 4096), ("float32", 1, 64, 2048, 1024),
+    ]:
+        A = DeviceArray.empty((batch, M, K), dtype)
+        B = DeviceArray.empty((batch, K, N), dtype)
+        out = DeviceArray.empty((batch, M, N), dtype)
+        for x in (A, B):
+            ffi.check(lib.pthip_memset(x.ptr, 0, x.nbytes))
+        dt = ffi.np_dtype_code(dtype)
+
+        def run():
+            ffi.check(lib.pthip_gemm(dt, batch, M, N, K, 1.0, A.ptr, M * K, K, 1, B.ptr, K * N, N, 1, 0.0, None, 0, 0, 0, out.ptr))
+
+        ms = timed(lib, run, 10)
+        tf = 2.0 * batch * M * N * K / ms / 1e9
+        print(json.dumps({"dtype": dtype, "batch": batch, "M": M, "N": N, "K": K, "ms": round(ms, 4), "TFLOPs": round(tf, 1), "frac": round(tf / PEAK[dtype], 3)}))
+
+
+if __name__ == "__main__":
+    main()
