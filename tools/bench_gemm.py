@@ -35,10 +35,13 @@ def timed(lib, fn, reps):
 def main():
     ffi.init(0)
     lib = ffi.lib()
-    for dtype, batch, M, N, K in [
+    shapes = [
         ("float32", 1, 4096, 4096, 4096), ("float32", 1, 8192, 8192, 1024), ("float32", 512, 256, 256, 256),
         ("float32", 64, 1024, 1024, 256), ("float64", 1, 4096, 4096, 4096), ("float32", 1, 64, 2048, 1024),
-    ]:
+    ]
+    if len(sys.argv) > 1:  # indices of the shapes to run (profiling one kernel at a time)
+        shapes = [shapes[int(a)] for a in sys.argv[1:]]
+    for dtype, batch, M, N, K in shapes:
         A = DeviceArray.empty((batch, M, K), dtype)
         B = DeviceArray.empty((batch, K, N), dtype)
         out = DeviceArray.empty((batch, M, N), dtype)
