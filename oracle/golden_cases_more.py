@@ -104,6 +104,42 @@ def blockwise_linalg():
     return [S, b, B], outs, {"S": Sv, "b": rng.normal(size=(3, 6)), "B": rng.normal(size=(3, 6, 2))}
 
 
+@case("hier_nodesign")
+def hier_nodesign():
+    # the C4 model without a design matrix — the gather a[gidx] feeds the likelihood
+    # Composite directly (fused_elemwise.py:107 FusedElemwise is the reference's numba-only rewrite)
+    rng = np.random.default_rng(46)
+    N, G = 4001, 37
+    gv = rng.integers(0, G, size=N)
+    yv = rng.normal(size=N) + 0.3 * gv / G
+    y = pytensor.shared(yv, name="y")
+    gidx = pytensor.shared(gv, name="gidx")
+    mu_g, log_tau, log_sigma = pt.dscalar("mu_g"), pt.dscalar("log_tau"), pt.dscalar("log_sigma")
+    z = pt.dvector("z")
+    a = mu_g + pt.exp(log_tau) * z
+    r = (y - a[gidx]) / pt.exp(log_sigma)
+    logp = pt.sum(-0.5 * r**2 - log_sigma) + pt.sum(-0.5 * z**2) - 0.5 * (mu_g**2 + log_tau**2 + log_sigma**2)
+    params = [mu_g, log_tau, z, log_sigma]
+    vals = {"mu_g": np.asarray(0.2), "log_tau": np.asarray(-0.4), "z": rng.normal(size=G), "log_sigma": np.asarray(0.1)}
+    return params, [logp, *pytensor.grad(logp, params)], vals
+
+
+@case("gather_elemwise")
+def gather_elemwise():
+    # several gathers (two tables, two index vectors, negative indices) into one Composite,
+    # stored and reduced outputs
+    rng = np.random.default_rng(47)
+    t1, t2, v = pt.dvector("t1"), pt.dvector("t2"), pt.dvector("v")
+    idx, jdx = pt.lvector("idx"), pt.lvector("jdx")
+    e = pt.exp(t1[idx]) * v + t2[jdx] - t1[jdx]
+    outs = [e, e.sum(), (t2[idx] * v).max(), pt.tanh(t1[idx] + 1.0)]
+    n = 513
+    return [t1, t2, v, idx, jdx], outs, {
+        "t1": rng.normal(size=19), "t2": rng.normal(size=19), "v": rng.normal(size=n),
+        "idx": rng.integers(-19, 19, size=n), "jdx": rng.integers(0, 19, size=n),
+    }
+
+
 @case("careduce_more")
 def careduce_more():
     # elemwise.py:1233 CAReduce: every scalar op x axis pattern on a 4-d tensor, keepdims, mean/var

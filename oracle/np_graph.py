@@ -264,7 +264,7 @@ def _check_runtime_broadcast(node, graph, inputs):
 def _elemwise(p, inputs, node, graph):
     # pytensor/tensor/elemwise.py:755-823 (Elemwise.perform)
     inputs = _sum_partial_inputs(p, inputs)
-    if not p.get("partial_inputs"):
+    if not p.get("partial_inputs") and not p.get("gather"):
         _check_runtime_broadcast(node, graph, inputs)
     outs = eval_scalar_body(p["scalar"], inputs)
     shape = np.broadcast(*inputs).shape if inputs else ()
@@ -743,6 +743,15 @@ def run_graph(graph, inputs):
 def _sum_partial_inputs(p, inputs):
     """Inputs listed in ``partial_inputs`` are split-K slabs (S, *shape) of a ``GemmPartials``
     node (fusion.defer_gemm_finish): their value is the sum over the slab axis."""
+    gspec = p.get("gather")
+    if gspec:
+        # gatherfuse.absorb_gathers: body input `pos` is a table read as table[idx], the index
+        # vectors follow the body inputs (AdvancedSubtensor on axis 0: subtensor.py:1932)
+        nbody = len(p["scalar"]["in_dtypes"])
+        body_in = list(inputs[:nbody])
+        for pos, extra in gspec:
+            body_in[pos] = np.asarray(body_in[pos])[np.asarray(inputs[nbody + extra])]
+        inputs = body_in
     pi = p.get("partial_inputs")
     if not pi:
         return inputs

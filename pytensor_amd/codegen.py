@@ -449,6 +449,8 @@ def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=
     for k, dt in enumerate(body["in_dtypes"]):
         if modes[k] == "C":  # host-known scalar: travels by value in the argument block
             params.append(f"const long long in{k}")
+        elif modes[k] == "G":  # in{k}[gx{k}[i]]: a gather (AdvancedSubtensor on axis 0) read in the loop
+            params += [f"const {CTYPE[dt]}* __restrict__ in{k}", f"const long long* __restrict__ gx{k}", f"long long gn{k}"]
         else:
             params.append(f"const {CTYPE[dt]}* __restrict__ in{k}")
     for k, dt in enumerate(body["out_dtypes"]):
@@ -456,6 +458,9 @@ def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=
             params.append(f"{CTYPE[dt]}* __restrict__ out{k}")
         else:
             params.append(f"{CTYPE[reduce_spec[k][1]]}* __restrict__ part{k}")
+    if "G" in modes:
+        assert vec == 1, "gather inputs use the scalar loop"
+        params.append("int* __restrict__ status")
     src = [reduce_header() if any(reduce_spec) else "", PRELUDE, VEC_HELPERS]
     src.append(f'extern "C" __global__ __launch_bounds__({BLOCK}) void {name}({", ".join(params)}) {{')
     # scalars
@@ -552,7 +557,19 @@ def _flat_scalar_block(body, modes, reduce_spec, V, pvar):
 
 def _flat_elem(body, modes, reduce_spec, ivar):
     lines = []
-    in_names = [(f"in{k}[{ivar}]" if m == "V" else f"s{k}") for k, m in enumerate(modes)]
+    in_names = []
+    for k, m in enumerate(modes):
+        if m == "V":
+            in_names.append(f"in{k}[{ivar}]")
+        elif m == "G":
+            # NumPy index semantics: negative wraps once, out of range is an IndexError (raised
+            # by the host from the device flag; the lane reads entry 0 meanwhile)
+            lines.append(f"      long long gi{k} = gx{k}[{ivar}];")
+            lines.append(f"      if (gi{k} < 0) gi{k} += gn{k};")
+            lines.append(f"      if (gi{k} < 0 || gi{k} >= gn{k}) {{ *status = 1; gi{k} = 0; }}")
+            in_names.append(f"in{k}[gi{k}]")
+        else:
+            in_names.append(f"s{k}")
     out_names = []
     for k, dt in enumerate(body["out_dtypes"]):
         lines.append(f"      {CTYPE[dt]} o{k};")

@@ -178,7 +178,16 @@ def _placed(env, node, shape, out_dtypes):
     return res if any(r is not None for r in res) else None
 
 
-def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=(), out_bufs=None):
+def _take(env, table: DeviceArray, idx: DeviceArray) -> DeviceArray:
+    """table[idx] for a 1-d table (the unfused form of a gather input)."""
+    out = DeviceArray.empty(idx.shape, table.dtype)
+    if out.size:
+        tc = table.contiguous()
+        ffi.check(env.lib.pthip_take_rows(table.itemsize, idx.size, 1, tc.ptr, tc.shape[0], 1, idx.contiguous().ptr, out.ptr))
+    return out
+
+
+def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=(), out_bufs=None, gather=None):
     """Launch the fused kernel.  Returns (stored outputs or None per output,
     partial buffers or None per output, grid).
 
@@ -196,10 +205,13 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=
         return outs, [None] * nout, 0
     nd = len(out_shape)
     partial = set(partial)
+    gather = gather or {}
     modes = []
     flat = not partial
-    for a in ins if flat else ():
-        if isinstance(a, HostValue):
+    for k, a in enumerate(ins) if flat else ():
+        if k in gather:
+            modes.append("G")  # table[idx[i]] read inside the loop (gatherfuse.py)
+        elif isinstance(a, HostValue):
             modes.append("C")  # host-known scalar: by value, no upload node in a captured plan
         elif a.size == 1:
             modes.append("S")
@@ -208,6 +220,16 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=
         else:
             flat = False
             break
+    if gather:
+        for k, idx in gather.items():
+            t = ins[k]
+            if not (flat and isinstance(t, DeviceArray) and t.ndim == 1 and t.is_contiguous() and t.shape[0] > 0
+                    and idx.shape == tuple(out_shape) and idx.is_contiguous() and str(idx.dtype) == "int64"):
+                flat = False
+        if not flat:
+            # layouts the in-loop gather does not cover: gather first, then the ordinary kernel
+            ins = [_take(env, env.to_device(a), gather[k]) if k in gather else a for k, a in enumerate(ins)]
+            return launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial, out_bufs)
     byvalue = set()
     if not flat:
         # host-known scalars travel by value here too (no upload node per replay)
@@ -223,7 +245,7 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=
         vec = codegen._vec_width(dts) if dts else 1
         if vec > 1:
             ptrs = [a.ptr for a, m in zip(ins, modes) if m == "V"] + [o.ptr for o in outs if o is not None]
-            if any(p % 16 for p in ptrs) or n < vec:
+            if any(p % 16 for p in ptrs) or n < vec or "G" in modes:
                 vec = 1
         unroll = EW_UNROLL
         name = f"ew_{bkey}_{''.join(modes)}_v{vec}_{rkey}".replace("-", "x")
@@ -231,7 +253,14 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=
         fn = kernel_cache.get_function(src, name)
         units = (n // vec + unroll - 1) // unroll if vec > 1 else n
         grid = _grid(max(units, 1))
-        args = [n] + [_scalar_bits(a, body["in_dtypes"][k]) if m == "C" else a.ptr for k, (a, m) in enumerate(zip(ins, modes))]
+        args = [n]
+        for k, (a, m) in enumerate(zip(ins, modes)):
+            if m == "C":
+                args.append(_scalar_bits(a, body["in_dtypes"][k]))
+            elif m == "G":
+                args += [a.ptr, gather[k].ptr, a.shape[0]]
+            else:
+                args.append(a.ptr)
     else:
         sshape = tuple(out_shape)
         strides = []
@@ -278,6 +307,8 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=
     parts = alloc_partials(reduce_spec, grid)
     for k in range(nout):
         args.append(outs[k].ptr if reduce_spec[k] is None else parts[k].ptr)
+    if flat and "G" in modes:
+        args.append(env.lib.pthip_status_ptr())  # device error flag: out-of-range index
     buf = struct.pack(f"<{len(args)}q", *args)
     ffi.check(lib.pthip_launch(fn, grid, 1, 1, BLOCK, 1, 1, 0, buf, len(buf)))
     return outs, parts, grid
@@ -374,16 +405,37 @@ def device_reduce(env, op, x: DeviceArray, A, R, B, sA, sR, sB, acc_dtype, out_d
 # ---------------------------------------------------------------------------
 
 
+def _prepare(node, inputs, env):
+    """Handler inputs → (kernel inputs, iteration shape, split-K slab positions, gather map).
+
+    ``params["gather"] = [[pos, extra], …]`` (gatherfuse.py): body input ``pos`` is a 1-d table
+    read as ``table[idx]`` with ``idx = inputs[n_body + extra]``; for the shape rules the
+    gathered operand has the index's shape."""
+    body = node.params["scalar"]
+    nbody = len(body["in_dtypes"])
+    ins = [_scalar_or_device(env, i) for i in inputs[:nbody]]
+    pi = tuple(node.params.get("partial_inputs") or ())
+    gather = {}
+    shape_ins = list(ins)
+    for pos, extra in node.params.get("gather") or []:
+        from pytensor_amd.dispatch.subtensor import _index_on_device
+
+        idx = _index_on_device(env, inputs[nbody + extra])
+        gather[pos] = idx
+        ins[pos] = env.to_device(ins[pos])
+        shape_ins[pos] = idx
+    shape = _broadcast_shape(node, env.graph, shape_ins, pi)
+    return ins, shape, pi, gather
+
+
 @handler("Elemwise")
 def elemwise(node, inputs, env):
     body = node.params["scalar"]
     g = env.graph
-    if _host_evaluable(body, inputs) and all(i.a.size <= HOST_MAX for i in inputs):
+    if not node.params.get("gather") and _host_evaluable(body, inputs) and all(i.a.size <= HOST_MAX for i in inputs):
         return _host_eval(body, inputs)
-    ins = [_scalar_or_device(env, i) for i in inputs]
-    pi = tuple(node.params.get("partial_inputs") or ())
-    shape = _broadcast_shape(node, g, ins, pi)
-    outs, _, _ = launch_elemwise(body, ins, shape, body["out_dtypes"], None, env, pi, _placed(env, node, shape, body["out_dtypes"]))
+    ins, shape, pi, gather = _prepare(node, inputs, env)
+    outs, _, _ = launch_elemwise(body, ins, shape, body["out_dtypes"], None, env, pi, _placed(env, node, shape, body["out_dtypes"]), gather)
     return outs
 
 
@@ -392,10 +444,8 @@ def elemwise_reduce(node, inputs, env):
     body = node.params["scalar"]
     spec = node.params["reduce"]
     g = env.graph
-    ins = [_scalar_or_device(env, i) for i in inputs]
-    pi = tuple(node.params.get("partial_inputs") or ())
-    shape = _broadcast_shape(node, g, ins, pi)
-    outs, parts, grid = launch_elemwise(body, ins, shape, body["out_dtypes"], spec, env, pi, _placed(env, node, shape, body["out_dtypes"]))
+    ins, shape, pi, gather = _prepare(node, inputs, env)
+    outs, parts, grid = launch_elemwise(body, ins, shape, body["out_dtypes"], spec, env, pi, _placed(env, node, shape, body["out_dtypes"]), gather)
     finals = finish_partials(env, spec, parts, grid) if grid else [None] * len(spec)
     res = []
     for k, r in enumerate(spec):

@@ -27,6 +27,7 @@ from pytensor_amd.fusion import (
     hoist_scan_seq_dots,
     segment_graph,
 )
+from pytensor_amd.gatherfuse import absorb_gathers
 from pytensor_amd.gemmfuse import defer_gemm_finish, merge_sibling_gemms
 from pytensor_amd.inline import (
     dead_code_elimination,
@@ -49,5 +50,6 @@ def run_pipeline(graph: Graph, fuse=True):
     g = hoist_scan_seq_dots(g)
     g = fuse_cholesky_solve(g)
     g = merge_sibling_gemms(defer_gemm_finish(g))
-    g = dead_code_elimination(fuse_gemv_chain(g))
+    g = absorb_gathers(fuse_gemv_chain(g))  # gchain takes the gathers it can use first
+    g = dead_code_elimination(g)
     return segment_graph(g)

@@ -68,6 +68,23 @@ def test_out_of_range_index_is_index_error(hip):
     _both_raise(g, bad, IndexError)
 
 
+def test_out_of_range_index_inside_fused_gather_is_index_error(hip):
+    # the gather is read inside the generated elementwise kernel (gatherfuse.py): the bounds
+    # check is the device error flag, surfaced as IndexError by the executor
+    from pytensor_amd.executor import HipExecutable
+
+    g, ins, cvm, *_ = load_case("gather_elemwise")
+    assert any(n.params.get("gather") for n in HipExecutable(g).graph.nodes)
+    bad = list(ins)
+    k = [i for i, a in enumerate(ins) if a.dtype.kind == "i"][0]
+    idx = ins[k].copy()
+    idx[7] = 19  # table length is 19: one past the end
+    bad[k] = idx
+    exe = _both_raise(g, bad, IndexError)
+    for a, b in zip(exe(*ins), cvm):  # the flag was cleared: the next valid call is clean
+        np.testing.assert_allclose(a, b, rtol=1e-12)
+
+
 def test_check_and_raise_type(hip):
     # C4 asserts y.shape[0] == X.shape[0] (CheckAndRaise nodes of the Gemv shape checks)
     from pytensor_amd.executor import HipExecutable
