@@ -208,6 +208,11 @@ int pthip_scatter_rows(int dtype, int inc, int64_t n_idx, int64_t inner, void* o
  * one D2H copy per Function output; cf. the output loop of pytensor/link/basic.py:683-684) */
 int pthip_pack(int n, const void* const* srcs, const int64_t* nbytes, const int64_t* dst_offsets,
                void* dst);
+/* ---- Softmax / LogSoftmax over the last axis (pytensor/tensor/special.py:26,67; the reference
+ *      inlines them into Max + Composite + Sum + Composite before fusing, rewriting/ofg.py:46-70;
+ *      here one kernel, one HBM read + one write).  x, out: contiguous rows x cols; log_ = 1 for
+ *      LogSoftmax.  float32 sums accumulate in double like the reference's Sum. ---- */
+int pthip_softmax(int dtype, int log_, int64_t rows, int64_t cols, const void* x, void* out);
 /* ---- order-defined scans (pytensor/tensor/extra_ops.py CumOp.perform = np.cumsum/np.cumprod;
  *      pytensor/tensor/math.py Argmax.perform = np.argmax over the flattened trailing axes) ---- */
 /* dst[o, k, i] = fold_{j<=k} src[o, j, i] (mul = 0: +, 1: *), strictly left to right; src and

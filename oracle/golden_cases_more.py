@@ -140,6 +140,45 @@ def gather_elemwise():
     }
 
 
+@case("softmax_shapes", rtol=1e-11)
+def softmax_shapes():
+    # tests/tensor/test_special.py TestSoftmax/TestLogSoftmax axis matrix + the cross-entropy
+    # gradient (Softmax.pullback, special.py:49-53); narrow rows (<= 16) and wide rows take
+    # different kernels
+    rng = np.random.default_rng(48)
+    a = pt.dmatrix("a")
+    b = pt.dmatrix("b")
+    t3 = pt.dtensor3("t3")
+    lab = pt.lvector("lab")
+    sm = pt.special.softmax(a, axis=-1)
+    lsm = pt.special.log_softmax(b, axis=1)
+    nll = -lsm[pt.arange(b.shape[0]), lab].mean()
+    outs = [sm, pt.special.softmax(a, axis=0), pt.special.log_softmax(a, axis=-1), lsm, pt.special.softmax(t3, axis=(0, 2)),
+            pt.special.softmax(t3, axis=None), nll, pytensor.grad(nll, b), pytensor.grad((sm * sm).sum(), a)]
+    bv = rng.normal(size=(29, 5)) * 3
+    bv[3] = [700.0, -700.0, 0.0, 1.0, 2.0]  # overflow-safe thanks to the max subtraction
+    return [a, b, t3, lab], outs, {"a": rng.normal(size=(37, 300)) * 4, "b": bv, "t3": rng.normal(size=(4, 6, 9)),
+                                   "lab": rng.integers(0, 5, size=29)}
+
+
+@case("softmax_f32", rtol=2e-5)
+def softmax_f32():
+    rng = np.random.default_rng(49)
+    a = pt.fmatrix("a")
+    return [a], [pt.special.softmax(a, axis=1), pt.special.log_softmax(a, axis=1), pt.special.softmax(a[:, :7], axis=1)], {
+        "a": (rng.normal(size=(11, 1000)) * 5).astype("float32")}
+
+
+@case("softmax_long_rows", rtol=1e-11)
+def softmax_long_rows():
+    # few, long rows take the workgroup-per-row kernel (cols >= 4096)
+    rng = np.random.default_rng(50)
+    a = pt.dmatrix("a")
+    c = pt.dmatrix("c")
+    return [a, c], [pt.special.softmax(a, axis=1), pt.special.log_softmax(a, axis=1), pt.special.softmax(c, axis=None)], {
+        "a": rng.normal(size=(3, 5000)) * 3, "c": rng.normal(size=(70, 70))}
+
+
 @case("careduce_more")
 def careduce_more():
     # elemwise.py:1233 CAReduce: every scalar op x axis pattern on a 4-d tensor, keepdims, mean/var

@@ -857,6 +857,21 @@ def _argmax(p, inputs, node, graph):
     return [np.asarray(np.argmax(r, axis=-1), dtype="int64")]
 
 
+@op("Softmax")
+def _softmax(p, inputs, node, graph):
+    # pytensor/tensor/special.py:44-47 (Softmax.build_inner_graph) / 85-87 (LogSoftmax): the
+    # inner graph the reference inlines, evaluated as written (float32 sums accumulate in
+    # float64 like Sum's acc_dtype, elemwise.py:1383-1417)
+    (x,) = inputs
+    axis = tuple(p["axis"])
+    with np.errstate(all="ignore"):
+        xs = x - x.max(axis=axis, keepdims=True)
+        e = np.exp(xs)
+        acc = np.float64 if x.dtype == np.float32 else x.dtype
+        s = e.sum(axis=axis, keepdims=True, dtype=acc).astype(x.dtype)
+        return [(xs - np.log(s)) if p["log"] else (e / s)]
+
+
 @op("GemmPartials")
 def _gemm_partials(p, inputs, node, graph):
     # one slab = the whole product; the consumer's "partial_inputs" sum over the slab axis

@@ -1,0 +1,217 @@
+// softmax.hip — Softmax / LogSoftmax over the last axis of a (rows x cols) matrix.
+//
+// Reference: pytensor/tensor/special.py Softmax 26 (build_inner_graph 44-47:
+// e = exp(x - max(x)); e / sum(e)), LogSoftmax 67 (85-87: (x - max) - log(sum(exp(x - max)))).
+// The reference inlines these into Max + Composite + Sum + Composite nodes before its fusion
+// pass (rewriting/ofg.py:46-70) — five launches and four reads + two writes of the matrix on
+// a GPU.  The hip linker keeps the op whole (like the JAX/PyTorch/MLX linkers, which dispatch
+// their own softmax) and runs one kernel: the row is read from HBM once, the second and third
+// sweep hit L1/L2, one write.
+//
+// wave-per-row: 64 lanes stride along the row (coalesced), wave64 butterflies for max and sum;
+// four rows per workgroup.  Rows of <= 16 elements use thread-per-row with the row in registers.
+// float32 sums accumulate in double, as the reference's Sum does (elemwise.py:1383-1417).
+#include "common.h"
+#include "reduce_device.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+template <class T> struct Acc { typedef T type; };
+template <> struct Acc<float> { typedef double type; };
+
+template <class T> __device__ __forceinline__ T dev_exp(T x);
+template <> __device__ __forceinline__ double dev_exp(double x) { return exp(x); }
+template <> __device__ __forceinline__ float dev_exp(float x) { return expf(x); }
+template <class T> __device__ __forceinline__ T dev_log(T x);
+template <> __device__ __forceinline__ double dev_log(double x) { return log(x); }
+template <> __device__ __forceinline__ float dev_log(float x) { return logf(x); }
+
+// NaN-propagating max like the reference's Maximum (scalar/basic.py:1744)
+template <class T> __device__ __forceinline__ T nan_max(T a, T b) {
+  return (b > a) ? b : ((a >= b) ? a : (T)__builtin_nan(""));
+}
+
+template <class T, bool LOG>
+__global__ __launch_bounds__(BLOCK) void softmax_wave_kernel(T* __restrict__ out,
+                                                            const T* __restrict__ x,
+                                                            long long rows, long long cols) {
+  typedef typename Acc<T>::type A;
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * (BLOCK / 64);
+  for (long long r = wave; r < rows; r += nwaves) {
+    const T* xr = x + r * cols;
+    T* orow = out + r * cols;
+    T m = -__builtin_huge_val();
+    for (long long j = lane; j < cols; j += 64) m = nan_max(m, xr[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = nan_max(m, __shfl_xor(m, o));
+    A s = A(0);
+    for (long long j = lane; j < cols; j += 64) s += (A)dev_exp<T>(xr[j] - m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (LOG) {
+      const T ls = dev_log<T>((T)s);
+      for (long long j = lane; j < cols; j += 64) orow[j] = (xr[j] - m) - ls;
+    } else {
+      const T st = (T)s;
+      for (long long j = lane; j < cols; j += 64) orow[j] = dev_exp<T>(xr[j] - m) / st;
+    }
+  }
+}
+
+// rows of up to 64*VPL elements: the row lives in registers (VPL values per lane) — one read,
+// one exp per element, one write
+template <class T, bool LOG, int VPL>
+__global__ __launch_bounds__(BLOCK) void softmax_wave_reg_kernel(T* __restrict__ out,
+                                                                const T* __restrict__ x,
+                                                                long long rows, int cols) {
+  typedef typename Acc<T>::type A;
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * (BLOCK / 64);
+  for (long long r = wave; r < rows; r += nwaves) {
+    const T* xr = x + r * cols;
+    T* orow = out + r * cols;
+    T v[VPL];
+    T m = -__builtin_huge_val();
+#pragma unroll
+    for (int u = 0; u < VPL; u++) {
+      const int j = lane + 64 * u;
+      if (j < cols) { v[u] = xr[j]; m = nan_max(m, v[u]); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = nan_max(m, __shfl_xor(m, o));
+    A s = A(0);
+#pragma unroll
+    for (int u = 0; u < VPL; u++) {
+      const int j = lane + 64 * u;
+      if (j < cols) {
+        v[u] = v[u] - m;
+        const T e = dev_exp<T>(v[u]);
+        s += (A)e;
+        if (!LOG) v[u] = e;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const T st = (T)s;
+    const T ls = LOG ? dev_log<T>(st) : T(0);
+#pragma unroll
+    for (int u = 0; u < VPL; u++) {
+      const int j = lane + 64 * u;
+      if (j < cols) orow[j] = LOG ? (v[u] - ls) : (v[u] / st);
+    }
+  }
+}
+
+// few, long rows: a whole workgroup per row (a wave per row would leave most of the chip idle)
+template <class T, bool LOG>
+__global__ __launch_bounds__(BLOCK) void softmax_block_kernel(T* __restrict__ out,
+                                                             const T* __restrict__ x,
+                                                             long long rows, long long cols) {
+  typedef typename Acc<T>::type A;
+  __shared__ T smt[BLOCK / 64];
+  __shared__ A sma[BLOCK / 64];
+  for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+    const T* xr = x + r * cols;
+    T* orow = out + r * cols;
+    T m = -__builtin_huge_val();
+    for (long long j = threadIdx.x; j < cols; j += BLOCK) m = nan_max(m, xr[j]);
+    m = pthip_dev::block_reduce<pthip_dev::OpMax, T, BLOCK, true>(m, smt);
+    A s = A(0);
+    for (long long j = threadIdx.x; j < cols; j += BLOCK) s += (A)dev_exp<T>(xr[j] - m);
+    s = pthip_dev::block_reduce<pthip_dev::OpAdd, A, BLOCK, true>(s, sma);
+    if (LOG) {
+      const T ls = dev_log<T>((T)s);
+      for (long long j = threadIdx.x; j < cols; j += BLOCK) orow[j] = (xr[j] - m) - ls;
+    } else {
+      const T st = (T)s;
+      for (long long j = threadIdx.x; j < cols; j += BLOCK) orow[j] = dev_exp<T>(xr[j] - m) / st;
+    }
+  }
+}
+
+template <class T, bool LOG, int MAXC>
+__global__ __launch_bounds__(BLOCK) void softmax_thread_kernel(T* __restrict__ out,
+                                                              const T* __restrict__ x,
+                                                              long long rows, int cols) {
+  typedef typename Acc<T>::type A;
+  const long long r = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (r >= rows) return;
+  T v[MAXC];
+  T m = -__builtin_huge_val();
+#pragma unroll
+  for (int j = 0; j < MAXC; j++)
+    if (j < cols) { v[j] = x[r * cols + j]; m = nan_max(m, v[j]); }
+  A s = A(0);
+#pragma unroll
+  for (int j = 0; j < MAXC; j++)
+    if (j < cols) { v[j] = v[j] - m; s += (A)dev_exp<T>(v[j]); }
+  if (LOG) {
+    const T ls = dev_log<T>((T)s);
+#pragma unroll
+    for (int j = 0; j < MAXC; j++)
+      if (j < cols) out[r * cols + j] = v[j] - ls;
+  } else {
+    const T st = (T)s;
+#pragma unroll
+    for (int j = 0; j < MAXC; j++)
+      if (j < cols) out[r * cols + j] = dev_exp<T>(v[j]) / st;
+  }
+}
+
+template <class T>
+int softmax_typed(int log_, long long rows, long long cols, const void* x, void* out) {
+  if (rows == 0 || cols == 0) return 0;
+  hipStream_t st = pthip::ctx().stream;
+  if (cols <= 16) {
+    const unsigned grid = (unsigned)((rows + BLOCK - 1) / BLOCK);
+    if (log_)
+      hipLaunchKernelGGL((softmax_thread_kernel<T, true, 16>), dim3(grid), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, (int)cols);
+    else
+      hipLaunchKernelGGL((softmax_thread_kernel<T, false, 16>), dim3(grid), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, (int)cols);
+    return pthip::post_launch("softmax(thread per row)");
+  }
+  if (rows < 2 * (long long)pthip::kNumCU && cols >= 4096) {
+    const unsigned grid = (unsigned)rows;
+    if (log_)
+      hipLaunchKernelGGL((softmax_block_kernel<T, true>), dim3(grid), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, cols);
+    else
+      hipLaunchKernelGGL((softmax_block_kernel<T, false>), dim3(grid), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, cols);
+    return pthip::post_launch("softmax(workgroup per row)");
+  }
+  long long blocks = (rows + 3) / 4;
+  const long long cap = (long long)pthip::kNumCU * 16;
+  if (blocks > cap) blocks = cap;
+#define LAUNCH_REG(VPL)                                                                          \
+  do {                                                                                           \
+    if (log_)                                                                                    \
+      hipLaunchKernelGGL((softmax_wave_reg_kernel<T, true, VPL>), dim3((unsigned)blocks),        \
+                         dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, (int)cols);             \
+    else                                                                                         \
+      hipLaunchKernelGGL((softmax_wave_reg_kernel<T, false, VPL>), dim3((unsigned)blocks),       \
+                         dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, (int)cols);             \
+    return pthip::post_launch("softmax(wave per row, registers)");                               \
+  } while (0)
+  if (cols <= 64 * 4) LAUNCH_REG(4);
+  if (cols <= 64 * 16) LAUNCH_REG(16);
+  if (cols <= 64 * 32) LAUNCH_REG(32);
+#undef LAUNCH_REG
+  if (log_)
+    hipLaunchKernelGGL((softmax_wave_kernel<T, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, cols);
+  else
+    hipLaunchKernelGGL((softmax_wave_kernel<T, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, cols);
+  return pthip::post_launch("softmax(wave per row)");
+}
+
+}  // namespace
+
+extern "C" int pthip_softmax(int dtype, int log_, int64_t rows, int64_t cols, const void* x, void* out) {
+  PTHIP_REQUIRE_INIT();
+  if (dtype == PTHIP_F64) return softmax_typed<double>(log_, rows, cols, x, out);
+  if (dtype == PTHIP_F32) return softmax_typed<float>(log_, rows, cols, x, out);
+  return pthip::set_error("pthip_softmax: dtype %d not supported (float32/float64 only)", dtype);
+}

@@ -52,6 +52,28 @@ def cumop(node, inputs, env):
     return [out]
 
 
+@handler("Softmax")
+def softmax(node, inputs, env):
+    """``Softmax`` / ``LogSoftmax`` (pytensor/tensor/special.py:26,67) over ``axis``: the reduced
+    axes are moved last (a view when they already are), one launch for all rows."""
+    x = env.to_device(inputs[0])
+    if x.dtype.kind != "f":
+        raise NotImplementedError("Softmax: float32/float64 only on the device")
+    axes = list(node.params["axis"])
+    keep = [d for d in range(x.ndim) if d not in axes]
+    perm = keep + axes
+    xt = x.view([x.shape[d] for d in perm], [x.strides[d] for d in perm]).contiguous()
+    rows = int(np.prod([x.shape[d] for d in keep], dtype=np.int64))
+    cols = int(np.prod([x.shape[d] for d in axes], dtype=np.int64))
+    out = DeviceArray.empty(xt.shape, x.dtype)
+    if out.size:
+        ffi.check(env.lib.pthip_softmax(ffi.np_dtype_code(x.dtype), int(bool(node.params["log"])), rows, cols, xt.ptr, out.ptr))
+    if perm != list(range(x.ndim)):
+        inv = [perm.index(d) for d in range(x.ndim)]
+        out = out.view([out.shape[d] for d in inv], [out.strides[d] for d in inv])
+    return [out]
+
+
 @handler("Argmax")
 def argmax(node, inputs, env):
     x = env.to_device(inputs[0])

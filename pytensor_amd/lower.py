@@ -247,6 +247,16 @@ def _register_extra_ops():
         axis = op.axis if op.axis is not None else tuple(range(node.inputs[0].type.ndim))
         return "Argmax", {"axis": [int(a) for a in axis]}
 
+    # kept whole (HipLinker excludes the reference's inline_symbolic_for_fusion): one kernel
+    from pytensor.tensor.special import LogSoftmax, Softmax
+
+    @hip_funcify.register(Softmax)
+    @hip_funcify.register(LogSoftmax)
+    def _(op, node, ctx):
+        nd = node.inputs[0].type.ndim
+        axis = tuple(range(nd)) if op.axis is None else tuple(int(a) % nd for a in op.axis)
+        return "Softmax", {"axis": sorted(axis), "log": isinstance(op, LogSoftmax)}
+
 
 _register_extra_ops()
 
