@@ -183,6 +183,14 @@ int pthip_potrf(int dtype, int lower, int64_t batch, int64_t n, const void* A, v
  * pthip_potrf + pthip_trsm otherwise. */
 int pthip_potrf_trsv(int dtype, int64_t batch, int64_t n, const void* A, const void* b, void* L,
                      void* x);
+/* LU with partial pivoting (LAPACK getrf behind scipy.linalg.solve(assume_a="gen"), np.linalg.det /
+ * slogdet / inv: solvers/general.py Solve.perform, linalg/summary.py, linalg/inverse.py).
+ * A, LU: batch x n x n row-major; perm (int64, batch x n): row i of P*A is row perm[i] of A;
+ * sign, logabsdet (dtype, batch): of det(A) (0 and -inf when exactly singular; with
+ * flag_singular that also raises bit 1 (value 2) of the device error word -> the LinAlgError of
+ * np.linalg.inv at the caller's next sync; Solve NaN-fills and det returns 0 instead). */
+int pthip_getrf(int dtype, int64_t batch, int64_t n, const void* A, void* LU, void* perm, void* sign,
+                void* logabsdet, int flag_singular);
 /* solve op(T) X = B, T triangular n×n (strided), B n×nrhs (contiguous row-major), out contiguous */
 int pthip_trsm(int dtype, int lower, int trans, int unit_diag, int64_t batch, int64_t n,
                int64_t nrhs, const void* T, int64_t sTb, int64_t sT0, int64_t sT1, const void* B,

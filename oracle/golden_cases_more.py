@@ -179,6 +179,34 @@ def softmax_long_rows():
         "a": rng.normal(size=(3, 5000)) * 3, "c": rng.normal(size=(70, 70))}
 
 
+@case("general_solve_det", rtol=1e-10)
+def general_solve_det():
+    # tests/tensor/linalg/test_solvers/test_general.py, test_summary.py: Solve (gen / pos, vector
+    # and matrix rhs), Det, SLogDet, MatrixInverse and the gradient of log|det| (a MatrixInverse)
+    # (the solves and the determinants use different matrices: with a shared one the reference's
+    #  C-mode pipeline computes det from the LU factors it introduces for the solves and returned
+    #  +7.1e9 where np.linalg.det, its own NumPy mode and its unshared graph all give -7.1e9)
+    rng = np.random.default_rng(51)
+    A = pt.dmatrix("A")
+    A2 = pt.dmatrix("A2")
+    S = pt.dmatrix("S")
+    b = pt.dvector("b")
+    B = pt.dmatrix("B")
+    T3 = pt.dtensor3("T3")
+    U3 = pt.dtensor3("U3")
+    sl = pt.linalg.slogdet(A)
+    outs = [
+        pt.linalg.solve(A2, b), pt.linalg.solve(A2.T, B), pt.linalg.solve(S, b, assume_a="pos"), pt.linalg.solve(S, B, assume_a="pos"),
+        pt.linalg.det(A), sl[0], sl[1], pt.linalg.inv(A), pytensor.grad(sl[1], A), pt.linalg.det(T3), pt.linalg.solve(U3, B[:5]),
+    ]
+    n = 23
+    Av = rng.normal(size=(n, n)) + np.eye(n) * 0.5
+    M = rng.normal(size=(n, n + 4))
+    return [A, A2, S, b, B, T3, U3], outs, {
+        "A": Av, "A2": rng.normal(size=(n, n)) + np.eye(n), "S": M @ M.T / n + np.eye(n), "b": rng.normal(size=n),
+        "B": rng.normal(size=(n, 3)), "T3": rng.normal(size=(4, 5, 5)) + np.eye(5), "U3": rng.normal(size=(4, 5, 5)) + 2 * np.eye(5)}
+
+
 @case("careduce_more")
 def careduce_more():
     # elemwise.py:1233 CAReduce: every scalar op x axis pattern on a 4-d tensor, keepdims, mean/var

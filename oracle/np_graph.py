@@ -446,17 +446,18 @@ def _blockwise(p, inputs, node, graph):
     bcast = [
         np.broadcast_to(i, bshape + np.shape(i)[np.ndim(i) - c :]) for i, c in zip(inputs, core_ndims)
     ]
-    out = None
+    outs = None
     for idx in np.ndindex(*bshape):
-        (r,) = core(p["core_params"], [b[idx] for b in bcast], node, graph)
-        if out is None:
-            out = np.empty(bshape + r.shape, dtype=r.dtype)
-        out[idx] = r
-    if out is None:  # empty batch
+        rs = [np.asarray(r) for r in core(p["core_params"], [b[idx] for b in bcast], node, graph)]
+        if outs is None:
+            outs = [np.empty(bshape + r.shape, dtype=r.dtype) for r in rs]
+        for o, r in zip(outs, rs):
+            o[idx] = r
+    if outs is None:  # empty batch
         dt = graph.vars[node.outputs[0]].dtype
         core_shape = np.shape(inputs[-1])[np.ndim(inputs[-1]) - core_ndims[-1] :]
-        out = np.empty(bshape + core_shape, dtype=dt)
-    return [out]
+        outs = [np.empty(bshape + core_shape, dtype=dt)]
+    return outs
 
 
 def unflatten_index(idx_list, index_values):
@@ -855,6 +856,44 @@ def _argmax(p, inputs, node, graph):
     kept_shape = xt.shape[: len(keep)]
     r = xt.reshape((*kept_shape, int(np.prod(xt.shape[len(keep) :], dtype="int64"))))
     return [np.asarray(np.argmax(r, axis=-1), dtype="int64")]
+
+
+@op("Solve")
+def _solve_general(p, inputs, node, graph):
+    # pytensor/tensor/linalg/solvers/general.py:62-75 (Solve.perform): scipy.linalg.solve; a
+    # singular system is NaN-filled (the reference fills a.shape — we fill the solution's shape)
+    a, b = inputs
+    if a.ndim > 2 or b.ndim > p["b_ndim"]:  # Blockwise batching
+        bshape = np.broadcast_shapes(a.shape[:-2], b.shape[: b.ndim - p["b_ndim"]])
+        ab = np.broadcast_to(a, (*bshape, *a.shape[-2:]))
+        bb = np.broadcast_to(b, (*bshape, *b.shape[b.ndim - p["b_ndim"] :]))
+        out = np.empty(bb.shape, dtype=b.dtype)
+        for idx in np.ndindex(*bshape):
+            out[idx] = _solve_general(p, [ab[idx], bb[idx]], node, graph)[0]
+        return [out]
+    try:
+        return [scipy.linalg.solve(a, b, lower=p["lower"], check_finite=False, assume_a=p["assume_a"])]
+    except np.linalg.LinAlgError:
+        return [np.full(b.shape, np.nan, dtype=b.dtype)]
+
+
+@op("Det")
+def _det(p, inputs, node, graph):
+    # pytensor/tensor/linalg/summary.py:59-65 (Det.perform): np.linalg.det
+    return [np.asarray(np.linalg.det(inputs[0]))]
+
+
+@op("SLogDet")
+def _slogdet(p, inputs, node, graph):
+    # pytensor/tensor/linalg/summary.py:101-107 (SLogDet.perform): np.linalg.slogdet
+    s, l = np.linalg.slogdet(inputs[0])
+    return [np.asarray(s), np.asarray(l)]
+
+
+@op("MatrixInverse")
+def _matrix_inverse(p, inputs, node, graph):
+    # pytensor/tensor/linalg/inverse.py:114-117 (MatrixInverse.perform): np.linalg.inv
+    return [np.linalg.inv(inputs[0])]
 
 
 @op("Softmax")

@@ -149,4 +149,11 @@ def blockwise(node, inputs, env):
         return [trsm_device(env, ins[0], ins[1], cp["lower"], cp["unit_diagonal"], cp["b_ndim"])]
     if p["core_op"] == "CholeskySolve":
         return [cho_solve_device(env, ins[0], ins[1], cp["lower"], cp["b_ndim"])]
+    if p["core_op"] in ("Solve", "Det", "SLogDet"):
+        from pytensor_amd.dispatch import lu
+
+        if p["core_op"] == "Solve":
+            return [lu._solve(env, cp, ins[0], ins[1])]
+        fake = type("_N", (), {"params": cp})
+        return (lu.det if p["core_op"] == "Det" else lu.slogdet)(fake, ins, env)
     raise NotImplementedError(f"Blockwise({p['core_op']})")

@@ -101,6 +101,16 @@ class KernelTimer:
         return {k: v[0] / v[1] for k, v in self.totals.items()}
 
 
+def raise_device_status(word: int):
+    """The device error word (kernels cannot raise): bit 0 = an index was out of range
+    (IndexError, like the reference's take/inc_subtensor), bit 1 = np.linalg.inv met an exactly
+    singular matrix (LinAlgError)."""
+    if word & 2:
+        raise np.linalg.LinAlgError("Singular matrix")
+    if word & 1:
+        raise IndexError("index out of bounds (device-side check)")
+
+
 class Env:
     """Per-call state handed to the node handlers."""
 
@@ -328,8 +338,7 @@ class HipExecutable:
         ffi.check(lib.pthip_synchronize())
         st = C.c_int(0)
         ffi.check(lib.pthip_check_status(C.byref(st)))
-        if st.value:
-            raise IndexError("index out of bounds (device-side check)")
+        raise_device_status(st.value)
         env.keepalive.clear()
         return tuple(host)
 

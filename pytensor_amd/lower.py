@@ -247,6 +247,23 @@ def _register_extra_ops():
         axis = op.axis if op.axis is not None else tuple(range(node.inputs[0].type.ndim))
         return "Argmax", {"axis": [int(a) for a in axis]}
 
+    # general dense solves on LU with partial pivoting (csrc/lu.hip)
+    from pytensor.tensor.linalg.inverse import MatrixInverse
+    from pytensor.tensor.linalg.solvers.general import Solve
+    from pytensor.tensor.linalg.summary import Det, SLogDet
+
+    @hip_funcify.register(Solve)
+    def _(op, node, ctx):
+        if op.assume_a not in ("gen", "pos"):
+            return None
+        return "Solve", {"assume_a": str(op.assume_a), "lower": bool(op.lower), "b_ndim": int(op.b_ndim)}
+
+    @hip_funcify.register(Det)
+    @hip_funcify.register(SLogDet)
+    @hip_funcify.register(MatrixInverse)
+    def _(op, node, ctx):
+        return type(op).__name__, {}
+
     # kept whole (HipLinker excludes the reference's inline_symbolic_for_fusion): one kernel
     from pytensor.tensor.special import LogSoftmax, Softmax
 
@@ -316,7 +333,7 @@ def _(op, node, ctx):
 @hip_funcify.register(Blockwise)
 def _(op, node, ctx):
     core = hip_funcify(op.core_op, None, ctx)
-    if core is None or core[0] not in ("Cholesky", "SolveTriangular", "CholeskySolve"):
+    if core is None or core[0] not in ("Cholesky", "SolveTriangular", "CholeskySolve", "Solve", "Det", "SLogDet"):
         return None
     name, params = core
     return "Blockwise", {"core_op": name, "core_params": params, "signature": op.signature}

@@ -85,6 +85,40 @@ def test_out_of_range_index_inside_fused_gather_is_index_error(hip):
         np.testing.assert_allclose(a, b, rtol=1e-12)
 
 
+def test_singular_matrix_conventions(hip):
+    # np.linalg.inv raises LinAlgError; Solve NaN-fills (general.py:74-75); det is exactly 0
+    from pytensor_amd.executor import HipExecutable
+    from pytensor_amd.ir import Graph
+
+    def unary(op, nout=1):
+        g = Graph(name=op)
+        a = g.new_var("float64", (None, None), name="A")
+        outs = [g.new_var("float64", (None, None) if op == "MatrixInverse" else ()) for _ in range(nout)]
+        g.add_node(op, {}, [a], outs)
+        g.inputs, g.outputs = [a], outs
+        return g
+
+    S = np.array([[1.0, 2.0, 3.0], [2.0, 4.0, 6.0], [0.5, -1.0, 2.0]])
+    with pytest.raises(np.linalg.LinAlgError):
+        np_graph.run_graph(unary("MatrixInverse"), [S])
+    exe = HipExecutable(unary("MatrixInverse"))
+    with pytest.raises(np.linalg.LinAlgError):
+        exe(S)
+    good = S + np.eye(3)
+    np.testing.assert_allclose(exe(good)[0], np.linalg.inv(good), rtol=1e-12)  # flag cleared
+    assert HipExecutable(unary("Det"))(S)[0] == 0.0
+    sign, logabs = HipExecutable(unary("SLogDet", 2))(S)
+    assert sign == 0.0 and logabs == -np.inf
+    g = Graph(name="solve")
+    a = g.new_var("float64", (None, None), name="A")
+    b = g.new_var("float64", (None,), name="b")
+    x = g.new_var("float64", (None,))
+    g.add_node("Solve", {"assume_a": "gen", "lower": False, "b_ndim": 1}, [a, b], [x])
+    g.inputs, g.outputs = [a, b], [x]
+    assert np.isnan(HipExecutable(g)(S, np.ones(3))[0]).all()
+    assert np.isnan(np_graph.run_graph(g, [S, np.ones(3)])[0]).all()
+
+
 def test_check_and_raise_type(hip):
     # C4 asserts y.shape[0] == X.shape[0] (CheckAndRaise nodes of the Gemv shape checks)
     from pytensor_amd.executor import HipExecutable
