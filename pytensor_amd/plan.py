@@ -72,6 +72,13 @@ class _PinnedBlock:
             self.ptr = 0
 
 
+class _Src:
+    """A raw device range handed to the pack kernel (the error word)."""
+
+    def __init__(self, ptr, nbytes):
+        self.ptr, self.nbytes = ptr, nbytes
+
+
 class _SegmentSwitch:
     """Scheduler hook: closes the running capture and opens the next one when the
     executor crosses a segment boundary (A → B → C)."""
@@ -201,9 +208,15 @@ class FrozenPlan:
                     else:
                         self._out_meta.append(None)
                         specs.append((o.shape, o.dtype))
+                # last slot: the device error word (index out of range / singular inverse) rides
+                # along with the results — a replay costs no extra sync to learn about it
+                specs.append(((1,), np.dtype("int32")))
                 self._out_block = _PinnedBlock(specs)
+                self._out_block.views[-1][0] = 0
             ob = self._out_block
             dev_outs = [o.contiguous() for o in outs if not isinstance(o, HostValue)]
+            if dev_outs and self.fetch_outputs:
+                dev_outs = dev_outs + [_Src(lib.pthip_status_ptr(), 4)]
             if dev_outs and self.fetch_outputs and ob.nbytes <= _ZEROCOPY_MAX:
                 # small results: the pack kernel stores straight into the pinned (device-visible,
                 # coherent) host block — no copy node after it
@@ -303,6 +316,14 @@ class FrozenPlan:
             if not np.array_equal(np.asarray(inputs[pos]), b):
                 raise ValueError(f"frozen plan: scalar input {pos} is baked into the plan and changed")
         self._replay(True)  # one native call: H2D, graphs, stream synchronisation
+        if self.fetch_outputs and self._out_block is not None and self._out_block.views[-1][0]:
+            from pytensor_amd.executor import raise_device_status
+
+            word = int(self._out_block.views[-1][0])
+            st = C.c_int(0)
+            ffi.check(lib.pthip_check_status(C.byref(st)))  # clears the device word
+            self._out_block.views[-1][0] = 0
+            raise_device_status(word)
         res = []
         k = 0
         for meta in self._out_meta:

@@ -83,6 +83,13 @@ def test_out_of_range_index_inside_fused_gather_is_index_error(hip):
     exe = _both_raise(g, bad, IndexError)
     for a, b in zip(exe(*ins), cvm):  # the flag was cleared: the next valid call is clean
         np.testing.assert_allclose(a, b, rtol=1e-12)
+    # a frozen plan learns about it from the error word packed next to its results
+    plan = exe.freeze(*ins)
+    with pytest.raises(IndexError):
+        plan(*bad)
+    for a, b in zip(plan(*ins), cvm):
+        np.testing.assert_allclose(a, b, rtol=1e-12)
+    plan.close()
 
 
 def test_singular_matrix_conventions(hip):
