@@ -49,10 +49,25 @@ def init_process_group(info: RankInfo, backend: str | None = None):
     if backend is None:
         backend = os.environ.get("PTHIP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
-        torch.cuda.set_device(info.local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", info.local_rank))
-    else:
-        dist.init_process_group(backend)
+        try:
+            torch.cuda.set_device(info.local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", info.local_rank))
+            # one tiny collective now: a broken RCCL setup must show up here, not inside the bench
+            t = torch.zeros(1, device="cuda")
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+            return dist
+        except Exception as e:  # control plane only (barrier + max): fall back rather than fail
+            import sys
+
+            print(f"[pytensor_amd.replicas] RCCL init failed on rank {info.rank} ({e!r}); using gloo", file=sys.stderr)
+            try:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+            except Exception:
+                pass
+            backend = "gloo"
+    dist.init_process_group(backend)
     return dist
 
 
