@@ -207,6 +207,29 @@ def general_solve_det():
         "B": rng.normal(size=(n, 3)), "T3": rng.normal(size=(4, 5, 5)) + np.eye(5), "U3": rng.normal(size=(4, 5, 5)) + 2 * np.eye(5)}
 
 
+@case("scan_grad", rtol=1e-10)
+def scan_grad():
+    # the gradient of a Scan is a Scan with mit-mot states (Scan.pullback, op.py:2955+;
+    # tests/scan/test_basic.py TestGradScan patterns): an RNN-like recurrence with a
+    # non-sequence weight, and a two-tap recurrence
+    rng = np.random.default_rng(52)
+    xs = pt.dmatrix("xs")
+    h0 = pt.dvector("h0")
+    W = pt.dmatrix("W")
+    f0 = pt.dmatrix("f0")
+
+    def step(x, h, W):
+        return pt.tanh(h @ W + x)
+
+    hs = pytensor.scan(step, sequences=[xs], outputs_info=[h0], non_sequences=[W], return_updates=False)
+    loss = (hs[-1] ** 2).sum() + 0.1 * hs.sum()
+    fs = pytensor.scan(lambda fm2, fm1: fm1 * 0.6 + pt.sin(fm2), outputs_info=[dict(initial=f0, taps=[-2, -1])],
+                       n_steps=6, return_updates=False)
+    loss2 = (fs[-1] * fs[2]).sum()
+    return [xs, h0, W, f0], [loss, *pytensor.grad(loss, [xs, h0, W]), loss2, pytensor.grad(loss2, f0)], {
+        "xs": rng.normal(size=(8, 5)), "h0": rng.normal(size=5), "W": rng.normal(size=(5, 5)) * 0.4, "f0": rng.normal(size=(2, 3))}
+
+
 @case("careduce_more")
 def careduce_more():
     # elemwise.py:1233 CAReduce: every scalar op x axis pattern on a 4-d tensor, keepdims, mean/var

@@ -640,13 +640,16 @@ def _scan(p, inputs, node, graph):
     """
     info = p["info"]
     inner: "Graph" = p["inner"]
-    if info["mit_mot_in_slices"]:
-        raise NotImplementedError("mit-mot scans are outside the oracle's scope")
     n_steps = int(inputs[0])
     k = 1
     seqs = inputs[k : k + info["n_seqs"]]
     k += info["n_seqs"]
-    mit_sot_taps = [list(t) for t in info["mit_sot_in_slices"]]
+    # mit-mot (op.py:2091-2140): inputs read at the `in` taps, the first inner outputs written
+    # back at the `out` taps of the same buffer: buf[out_tap + pos], pos = step - min(in taps)
+    mm_in = [list(t) for t in info["mit_mot_in_slices"]]
+    mm_out = [list(t) for t in info["mit_mot_out_slices"]]
+    n_mm = len(mm_in)
+    mit_sot_taps = mm_in + [list(t) for t in info["mit_sot_in_slices"]]
     sit_sot_taps = [list(t) for t in info["sit_sot_in_slices"]]
     n_ms, n_ss = len(mit_sot_taps), len(sit_sot_taps)
     rec_bufs = [np.array(b, copy=True) for b in inputs[k : k + n_ms + n_ss]]
@@ -668,9 +671,14 @@ def _scan(p, inputs, node, graph):
                 inner_in.append(buf[(t + mt + tap) % L])
         inner_in += untraced
         inner_in += non_seqs
-        outs = run_graph(inner, inner_in)
+        outs = [np.array(v, copy=True) for v in run_graph(inner, inner_in)]
         o = 0
-        for buf, mt in zip(rec_bufs, mintaps):
+        for j, (buf, mt) in enumerate(zip(rec_bufs, mintaps)):
+            if j < n_mm:
+                for tap in mm_out[j]:
+                    buf[(t + mt + tap) % buf.shape[0]] = outs[o]
+                    o += 1
+                continue
             buf[(t + mt) % buf.shape[0]] = outs[o]
             o += 1
         for j in range(info["n_nit_sot"]):
@@ -696,7 +704,7 @@ def _scan(p, inputs, node, graph):
         res.append(buf)
     for j, buf in enumerate(nit_bufs):
         if buf is None:
-            ov = inner.vars[inner.outputs[n_ms + n_ss + j]]
+            ov = inner.vars[inner.outputs[sum(len(t) for t in mm_out) + (n_ms - n_mm) + n_ss + j]]
             buf = np.zeros((0,) * (ov.ndim + 1), dtype=ov.dtype)
         elif steps_done > nit_lens[j] and steps_done % nit_lens[j]:
             e = steps_done % nit_lens[j]

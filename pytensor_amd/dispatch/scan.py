@@ -50,15 +50,20 @@ def _roll_to_front(buf: DeviceArray, start: int) -> DeviceArray:
 @handler("Scan")
 def scan(node, inputs, env):
     info = node.params["info"]
-    if info["mit_mot_in_slices"]:
-        raise NotImplementedError("hip linker: mit-mot Scan (gradient of Scan) is not lowered yet")
     inner = _inner_executable(node, env)
     ig = inner.graph
     n_steps = int(env.to_host(inputs[0]))
     k = 1
     seqs = [env.to_device(s) for s in inputs[k : k + info["n_seqs"]]]
     k += info["n_seqs"]
-    taps = [list(t) for t in info["mit_sot_in_slices"]] + [list(t) for t in info["sit_sot_in_slices"]]
+    # mit-mot states (what Scan.pullback builds, op.py:2955+): read at `in` taps, written at
+    # `out` taps of the same buffer (several per step; an out tap may coincide with an in tap =
+    # accumulate in place).  mit-sot / sit-sot are the special case "write at tap 0".
+    mm_in = [list(t) for t in info["mit_mot_in_slices"]]
+    mm_out = [list(t) for t in info["mit_mot_out_slices"]]
+    n_mm = len(mm_in)
+    n_mm_outs = sum(len(t) for t in mm_out)
+    taps = mm_in + [list(t) for t in info["mit_sot_in_slices"]] + [list(t) for t in info["sit_sot_in_slices"]]
     n_rec = len(taps)
     rec_bufs = []
     for j, b in enumerate(inputs[k : k + n_rec]):
@@ -94,10 +99,15 @@ def scan(node, inputs, env):
         tap_ptrs = {v.ptr for v in step_in if isinstance(v, DeviceArray)}
         slots, placement = [], {}
         for j, (buf, mt) in enumerate(zip(rec_bufs, mintaps)):
-            slot = buf.view(buf.shape[1:], buf.strides[1:], ((t + mt) % buf.shape[0]) * buf.strides[0])
-            slots.append(slot)
+            L = buf.shape[0]
+            if j < n_mm:
+                for tap in mm_out[j]:
+                    slots.append(buf.view(buf.shape[1:], buf.strides[1:], ((t + mt + tap) % L) * buf.strides[0]))
+                continue
+            slot = buf.view(buf.shape[1:], buf.strides[1:], ((t + mt) % L) * buf.strides[0])
             if slot.ptr not in tap_ptrs and slot.is_contiguous():
-                placement[ig.outputs[j]] = slot
+                placement[ig.outputs[len(slots)]] = slot
+            slots.append(slot)
         saved = env.placement
         env.placement = placement
         try:
@@ -105,11 +115,22 @@ def scan(node, inputs, env):
         finally:
             env.placement = saved
         o = 0
+        # (mit-mot outputs of one step may alias each other's taps only through the buffer:
+        #  all of them are read from the inner graph's own results before any slot is written)
+        vals = []
         for slot in slots:
             v = env.to_device(outs[o])
+            if v.buf is slot.buf and v.ptr != slot.ptr:
+                # an output that is a view of another slot of the same trace buffer: detach it
+                # before any slot of this step is overwritten
+                tmp = DeviceArray.empty(v.shape, v.dtype)
+                copy_into(tmp, v)
+                v = tmp
+            vals.append(v)
+            o += 1
+        for slot, v in zip(slots, vals):
             if not (v.ptr == slot.ptr and v.shape == slot.shape and v.strides == slot.strides):
                 copy_into(slot, v)
-            o += 1
         for j in range(info["n_nit_sot"]):
             v = env.to_device(outs[o])
             if nit_bufs[j] is None:
@@ -134,7 +155,7 @@ def scan(node, inputs, env):
         res.append(buf)
     for j, buf in enumerate(nit_bufs):
         if buf is None:
-            ov = ig.vars[ig.outputs[n_rec + j]]
+            ov = ig.vars[ig.outputs[n_mm_outs + (n_rec - n_mm) + j]]
             buf = DeviceArray.empty((0,) * (ov.ndim + 1), ov.dtype)
         elif steps_done > nit_lens[j] and steps_done % nit_lens[j]:
             buf = _roll_to_front(buf, steps_done % nit_lens[j])
