@@ -26,6 +26,7 @@ Execution model (MI355X-first, no tracing compiler):
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 
 import numpy as np
@@ -152,10 +153,22 @@ class Env:
 
 
 class HipExecutable:
-    def __init__(self, graph: Graph, resident=(), device: int | None = None, fuse=True):
+    """``auto_freeze``: after one eager call, a second call with the same input signature
+    (shapes/dtypes, resident array identities, integer scalar values) captures the launch
+    sequence into a :class:`~pytensor_amd.plan.FrozenPlan`; later calls with that signature
+    replay it (one native call).  A different signature runs eagerly and re-arms the capture;
+    graphs that cannot be frozen (data-dependent host reads) stay eager.  This is what
+    ``pytensor.function(..., mode="hip")`` gets (``HipLinker.jit_compile``); direct users of
+    the class opt in."""
+
+    def __init__(self, graph: Graph, resident=(), device: int | None = None, fuse=True, auto_freeze=False):
         from pytensor_amd import dispatch  # registers handlers
         from pytensor_amd.passes import run_pipeline
 
+        self.auto_freeze = bool(auto_freeze) and os.environ.get("PTHIP_AUTO_FREEZE", "1") != "0"
+        self._auto_plan = None
+        self._auto_sig = None  # signature seen on the previous eager call
+        self._auto_failed = False
         self.source_graph = graph
         # per-node segment ids for multi-stream plans (fusion.segment_graph), or None
         self.graph, self.segments = run_pipeline(graph, fuse)
@@ -324,7 +337,40 @@ class HipExecutable:
             outs.append(v)
         return outs
 
+    def _signature(self, inputs):
+        sig = []
+        for pos, (vid, v) in enumerate(zip(self.graph.inputs, inputs)):
+            if pos in self.resident:
+                sig.append(("r", id(v)))
+                continue
+            a = v if isinstance(v, np.ndarray) else np.asarray(v)
+            if self.graph.vars[vid].kind != "tensor" or (a.dtype.kind in "iub" and a.ndim == 0):
+                sig.append(("b", a.dtype.str, a.tolist()))  # baked into a plan
+            else:
+                sig.append((a.shape, a.dtype.str))
+        return tuple(sig)
+
     def __call__(self, *inputs):
+        if self.auto_freeze:
+            sig = self._signature(inputs)
+            if self._auto_plan is not None:
+                if sig == self._auto_plan_sig:
+                    return self._auto_plan(*inputs)
+                self._auto_plan.close()  # the signature moved on: capture again later
+                self._auto_plan = None
+            elif sig == self._auto_sig and not self._auto_failed:
+                try:
+                    self._auto_plan = self.freeze(*inputs)
+                    self._auto_plan_sig = sig
+                    return self._auto_plan(*inputs)
+                except ffi.HipError as e:
+                    if "data-dependent host read" not in str(e):
+                        raise
+                    self._auto_failed = True  # this graph reads device data on the host: stay eager
+            self._auto_sig = sig
+        return self._call_eager(*inputs)
+
+    def _call_eager(self, *inputs):
         self._ensure_device()
         outs, env = self.run_device(inputs)
         lib = ffi.lib()

@@ -102,3 +102,50 @@ def test_coexists_with_torch_hip_runtime(hip):
     b = HipExecutable(g)(*ins)
     for x, y in zip(a, b):
         np.testing.assert_array_equal(x, y)
+
+
+def test_auto_freeze_is_what_the_linker_path_gets(hip):
+    """``HipLinker.jit_compile`` builds ``HipExecutable(..., auto_freeze=True)``: call 1 eager,
+    call 2 captures, later calls replay; a new signature falls back to eager and re-arms; a
+    graph that reads device data on the host stays eager."""
+    from pytensor_amd.executor import HipExecutable
+
+    g, ins, cvm, py, meta = load_case("c4_hier_small")
+    names = [g.vars[v].name for v in g.inputs]
+    resident = [k for k, n in enumerate(names) if n in ("y", "X", "gidx", "Sigma")]
+    exe = HipExecutable(g, resident=resident, auto_freeze=True)
+    first = exe(*ins)
+    assert exe._auto_plan is None
+    second = exe(*ins)
+    assert exe._auto_plan is not None
+    third = exe(*ins)
+    for a, b, c, ref in zip(first, second, third, cvm):
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(a, c)
+        np.testing.assert_allclose(a, ref, rtol=meta["rtol"], atol=meta["rtol"] * np.max(np.abs(ref)))
+    # new parameter values, same signature: still the plan, new results
+    ins2 = [a if k in resident else (a * 1.01 if a.dtype.kind == "f" else a) for k, a in enumerate(ins)]
+    plan = exe._auto_plan
+    got = exe(*ins2)
+    assert exe._auto_plan is plan
+    want = HipExecutable(g, resident=resident)(*ins2)
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, b)
+    # a resident array replaced by a new object (shared.set_value): eager again, then re-captured
+    ins3 = list(ins)
+    ins3[resident[0]] = ins[resident[0]].copy()
+    got3 = exe(*ins3)
+    assert exe._auto_plan is None
+    for a, b in zip(got3, first):
+        np.testing.assert_array_equal(a, b)
+    exe(*ins3)
+    assert exe._auto_plan is not None and exe._auto_plan is not plan
+
+    # not freezable: stays eager, still correct
+    g, ins, cvm, py, meta = load_case("softmax_shapes")
+    exe = HipExecutable(g, auto_freeze=True)
+    for _ in range(3):
+        out = exe(*ins)
+    assert exe._auto_plan is None and exe._auto_failed
+    for a, ref in zip(out, cvm):
+        np.testing.assert_allclose(a, ref, rtol=meta["rtol"], atol=meta["rtol"] * max(1.0, float(np.max(np.abs(ref)))))
