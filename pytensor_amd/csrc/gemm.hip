@@ -45,6 +45,16 @@ template <bool KC> struct Stage<double, KC> {
   __device__ __forceinline__ void load(const double* __restrict__ base, long long ld,
                                        long long row0, long long k0, long long rows,
                                        long long K, bool vec_ok) {
+    if (vec_ok && row0 + 128 <= rows && k0 + BK <= K) {
+      // interior tile (workgroup-uniform test): straight 16-byte loads, no per-vector branches
+#pragma unroll
+      for (int p = 0; p < NV; p++) {
+        const int id = threadIdx.x + p * BLOCK;
+        if constexpr (KC) v[p] = *(const double2*)(base + (row0 + (id >> 3)) * ld + k0 + (id & 7) * 2);
+        else v[p] = *(const double2*)(base + (k0 + (id >> 6)) * ld + row0 + (id & 63) * 2);
+      }
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < NV; p++) {
       const int id = threadIdx.x + p * BLOCK;
@@ -98,6 +108,16 @@ template <bool KC> struct Stage<float, KC> {
   __device__ __forceinline__ void load(const float* __restrict__ base, long long ld,
                                        long long row0, long long k0, long long rows,
                                        long long K, bool vec_ok) {
+    if (vec_ok && row0 + 128 <= rows && k0 + BK <= K) {
+      // interior tile (workgroup-uniform test): straight 16-byte loads, no per-vector branches
+#pragma unroll
+      for (int p = 0; p < NV; p++) {
+        const int id = threadIdx.x + p * BLOCK;
+        if constexpr (KC) v[p] = *(const float4*)(base + (row0 + (id >> 2)) * ld + k0 + (id & 3) * 4);
+        else v[p] = *(const float4*)(base + (k0 + (id >> 5)) * ld + row0 + (id & 31) * 4);
+      }
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < NV; p++) {
       const int id = threadIdx.x + p * BLOCK;
