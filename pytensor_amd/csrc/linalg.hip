@@ -256,12 +256,14 @@ __global__ __launch_bounds__(BLOCK) void potrf_lds_kernel(T* __restrict__ Lout,
         const T piv = akk * rdiag[k];
         // column k: rows > k scaled, row k gets the pivot
         d[k] = (lane == k) ? piv : d[k] * rdiag[k];
+        // a[r][c] -= a[r][k] * a[c][k] ; a[c][k] lives in lane c.  All broadcasts first (distinct
+        // SGPR pairs), then the FMAs: interleaved, every v_readlane -> v_fma pair pays the
+        // VALU-writes-SGPR wait states and reuses one SGPR pair serially
+        T ack[NB];
 #pragma unroll
-        for (int c = k + 1; c < NB; c++) {
-          // a[r][c] -= a[r][k] * a[c][k] ; a[c][k] lives in lane c
-          const T ack = bcast_lane(d[k], c);
-          d[c] -= d[k] * ack;
-        }
+        for (int c = k + 1; c < NB; c++) ack[c] = bcast_lane(d[k], c);
+#pragma unroll
+        for (int c = k + 1; c < NB; c++) d[c] -= d[k] * ack[c];
       }
     }
     // (rows r < k were also "updated" above; only the lower triangle c <= r is meaningful)
@@ -277,8 +279,11 @@ __global__ __launch_bounds__(BLOCK) void potrf_lds_kernel(T* __restrict__ Lout,
       for (int k = 0; k < NB; k++) {
         if (k < jb) {
           T s = x[k];
+          T lk[NB];  // row k of L11, broadcast first (see (a))
 #pragma unroll
-          for (int c = 0; c < k; c++) s -= x[c] * bcast_lane(d[c], k);  // L11[k][c]
+          for (int c = 0; c < k; c++) lk[c] = bcast_lane(d[c], k);
+#pragma unroll
+          for (int c = 0; c < k; c++) s -= x[c] * lk[c];
           x[k] = s * rdiag[k];
         }
       }
