@@ -360,7 +360,7 @@ class HipExecutable:
                 self._auto_plan = None
             elif sig == self._auto_sig and not self._auto_failed:
                 try:
-                    self._auto_plan = self.freeze(*inputs)
+                    self._auto_plan = self.freeze(*inputs, multi_stream="auto")
                     self._auto_plan_sig = sig
                     return self._auto_plan(*inputs)
                 except ffi.HipError as e:
@@ -425,8 +425,36 @@ class HipExecutable:
     # ------------------------------------------------------------------
     def freeze(self, *inputs, fetch_outputs=True, multi_stream=True):
         """Capture the launch sequence for this input signature into a hipGraph and
-        return a :class:`FrozenPlan` (see ``pytensor_amd/plan.py``)."""
+        return a :class:`FrozenPlan` (see ``pytensor_amd/plan.py``).
+
+        ``multi_stream="auto"`` (what the linker path uses): when the graph has a latency
+        chain to overlap, capture both the one-graph and the three-graph/two-stream form, time
+        a few replays of each and keep the faster — the two extra ``hipGraphLaunch`` calls cost
+        ≈20 µs of host time, more than the overlap saves on small problems (measured,
+        tools/bench_small.py: N=3000: 142 vs 162 µs per call; N=1e6: 300 vs 249 µs)."""
         from pytensor_amd.plan import FrozenPlan
 
         self._ensure_device()
-        return FrozenPlan(self, inputs, fetch_outputs=fetch_outputs, multi_stream=multi_stream)
+        if multi_stream != "auto":
+            return FrozenPlan(self, inputs, fetch_outputs=fetch_outputs, multi_stream=bool(multi_stream))
+        single = FrozenPlan(self, inputs, fetch_outputs=fetch_outputs, multi_stream=False)
+        if self.segments is None:
+            return single
+        multi = FrozenPlan(self, inputs, fetch_outputs=fetch_outputs, multi_stream=True)
+        if not multi.segmented:
+            multi.close()
+            return single
+        import time
+
+        def wall(plan, reps=12):
+            for _ in range(3):
+                plan._replay(True)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                plan._replay(True)
+            return time.perf_counter() - t0
+
+        t_single, t_multi = wall(single), wall(multi)
+        keep, drop = (single, multi) if t_single <= t_multi else (multi, single)
+        drop.close()
+        return keep

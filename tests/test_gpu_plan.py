@@ -149,3 +149,20 @@ def test_auto_freeze_is_what_the_linker_path_gets(hip):
     assert exe._auto_plan is None and exe._auto_failed
     for a, ref in zip(out, cvm):
         np.testing.assert_allclose(a, ref, rtol=meta["rtol"], atol=meta["rtol"] * max(1.0, float(np.max(np.abs(ref)))))
+
+
+def test_auto_multi_stream_picks_a_plan_and_matches_eager(hip):
+    """freeze(multi_stream="auto") times the one- and the two-stream capture and keeps one;
+    either way the replay is bit-identical to the eager run."""
+    from pytensor_amd.executor import HipExecutable
+
+    for name in ("c4_hier_small", "c1_gauss"):
+        g, ins, cvm, py, meta = load_case(name)
+        exe = HipExecutable(g)
+        want = exe(*ins)
+        plan = exe.freeze(*ins, multi_stream="auto")
+        for a, b in zip(plan(*ins), want):
+            np.testing.assert_array_equal(a, b)
+        if exe.segments is None:
+            assert not plan.segmented
+        plan.close()
