@@ -453,6 +453,65 @@ __global__ __launch_bounds__(BLOCK) void trsv_lds_kernel(T* __restrict__ Xout,
   wave_trsv<T, RPL>(W, ld, n, b, x, lower, unit, false);
 }
 
+// many right-hand sides, triangle resident in LDS: one thread per rhs column, eight rows of the
+// solution at a time in registers.  The triangle entries are uniform-address (broadcast) LDS
+// reads, the already-solved x_j are coalesced loads across the columns and are reused for eight
+// rows; the 8x8 diagonal block is substituted in registers.  (MatrixInverse / Solve with a
+// matrix rhs: the generic kernel below re-read T and x from global memory for every term.)
+template <class T>
+__global__ __launch_bounds__(BLOCK) void trsm_lds_kernel(T* __restrict__ Xout,
+                                                        const T* __restrict__ Tm, long long sTb,
+                                                        long long sT0, long long sT1,
+                                                        const T* __restrict__ B, long long sBb,
+                                                        int n, int nrhs, int lower, int unit) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* W = (T*)smem_raw;
+  const int ld = n | 1;
+  const long long mat = blockIdx.y;
+  const T* Tg = Tm + mat * sTb;
+  const T* b = B + mat * sBb;
+  T* x = Xout + mat * (long long)n * nrhs;
+  for (int e = threadIdx.x; e < n * n; e += BLOCK) {
+    const int i = e / n, j = e - i * n;
+    W[i * ld + j] = Tg[i * sT0 + j * sT1];
+  }
+  __syncthreads();
+  const int c = blockIdx.x * BLOCK + threadIdx.x;
+  if (c >= nrhs) return;
+  constexpr int RB = 8;
+  bool fail = false;
+  for (int s0 = 0; s0 < n; s0 += RB) {
+    T acc[RB];
+    int row[RB];
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+      const int p = (s0 + r) < n ? (s0 + r) : (n - 1);
+      row[r] = lower ? p : n - 1 - p;
+      acc[r] = b[(long long)row[r] * nrhs + c];
+    }
+    for (int q = 0; q < s0; q++) {
+      const int j = lower ? q : n - 1 - q;
+      const T xj = x[(long long)j * nrhs + c];
+#pragma unroll
+      for (int r = 0; r < RB; r++) acc[r] -= W[row[r] * ld + j] * xj;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+      if (s0 + r < n) {
+#pragma unroll
+        for (int r2 = 0; r2 < r; r2++) acc[r] -= W[row[r] * ld + row[r2]] * acc[r2];
+        const T d = unit ? T(1) : W[row[r] * ld + row[r]];
+        if (d == T(0)) fail = true;
+        acc[r] = acc[r] / d;
+        x[(long long)row[r] * nrhs + c] = acc[r];
+      }
+    }
+  }
+  // a zero pivot poisons the whole system (all columns share T): NaN-fill like the reference
+  if (fail)
+    for (int i = 0; i < n; i++) x[(long long)i * nrhs + c] = (T)__builtin_nan("");
+}
+
 // generic (any n, nrhs): one thread per right-hand-side column, row-oriented substitution.
 template <class T>
 __global__ __launch_bounds__(BLOCK) void trsm_kernel(T* __restrict__ Xout,
@@ -535,6 +594,17 @@ int trsm_typed(int lower, int unit, long long batch, long long n, long long nrhs
       else LAUNCH_TRSV(4);
 #undef LAUNCH_TRSV
       return pthip::post_launch("trsv_lds");
+    }
+  }
+  {
+    const size_t need = (size_t)n * (size_t)(n | 1) * sizeof(T);
+    if (need <= 160 * 1024 - 256) {
+      auto k = trsm_lds_kernel<T>;
+      if (need > 64 * 1024)
+        PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+      hipLaunchKernelGGL(k, dim3((unsigned)((nrhs + BLOCK - 1) / BLOCK), (unsigned)batch), dim3(BLOCK), need,
+                         st, (T*)out, (const T*)Tm, sTb, sT0, sT1, (const T*)B, sBb, (int)n, (int)nrhs, lower, unit);
+      return pthip::post_launch("trsm_lds");
     }
   }
   hipLaunchKernelGGL((trsm_kernel<T>), dim3((unsigned)((nrhs + BLOCK - 1) / BLOCK), (unsigned)batch),

@@ -31,7 +31,6 @@ __global__ __launch_bounds__(BLOCK) void getrf_kernel(T* __restrict__ LUout,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ T s_val[BLOCK / 64];
   __shared__ int s_idx[BLOCK / 64];
-  __shared__ int s_piv;
   __shared__ int s_perm[512];
   const long long mat = blockIdx.x;
   const T* A = Ain + mat * (long long)n * n;
@@ -61,17 +60,16 @@ __global__ __launch_bounds__(BLOCK) void getrf_kernel(T* __restrict__ LUout,
       const int oi = __shfl_xor(bi, o);
       if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
     }
+    // (every thread folds the per-wave candidates itself: three barriers per column, not five;
+    //  the slots are rewritten only after the two barriers below)
     if (lane == 0) { s_val[wid] = best; s_idx[wid] = bi; }
     __syncthreads();
-    if (tid == 0) {
-      T b = s_val[0];
-      int p = s_idx[0];
+    int p = s_idx[0];
+    {
+      T bv = s_val[0];
       for (int w = 1; w < BLOCK / 64; w++)
-        if (s_val[w] > b || (s_val[w] == b && s_idx[w] < p)) { b = s_val[w]; p = s_idx[w]; }
-      s_piv = p;
+        if (s_val[w] > bv || (s_val[w] == bv && s_idx[w] < p)) { bv = s_val[w]; p = s_idx[w]; }
     }
-    __syncthreads();
-    const int p = s_piv;
     if (p != k) {
       for (int j = tid; j < n; j += BLOCK) {
         const T t = W[k * ld + j];
@@ -83,18 +81,15 @@ __global__ __launch_bounds__(BLOCK) void getrf_kernel(T* __restrict__ LUout,
     }
     __syncthreads();
     const T piv = W[k * ld + k];
-    if (piv == T(0)) {
-      singular = true;  // dgetf2: info = k+1, no scaling, elimination continues
-    } else {
-      const T rp = T(1) / piv;
-      for (int i = k + 1 + tid; i < n; i += BLOCK) W[i * ld + k] *= rp;
-    }
-    __syncthreads();
-    // ---- rank-1 update of the trailing block ----
-    const int m = n - k - 1;
-    for (int e = tid; e < m * m; e += BLOCK) {
-      const int i = k + 1 + e / m, j = k + 1 + e % m;
-      W[i * ld + j] -= W[i * ld + k] * W[k * ld + j];
+    if (piv == T(0)) singular = true;  // dgetf2: info = k+1, no scaling, elimination continues
+    const T rp = piv == T(0) ? T(1) : T(1) / piv;
+    // ---- scale column k and rank-1 update of the trailing block, one phase ----
+    // (16 x 16 thread tiles: no index division; the threads of tile column 0 store the
+    //  multipliers, which only their own tile row reads)
+    for (int i = k + 1 + (tid >> 4); i < n; i += BLOCK / 16) {
+      const T lik = W[i * ld + k] * rp;
+      for (int j = k + 1 + (tid & 15); j < n; j += 16) W[i * ld + j] -= lik * W[k * ld + j];
+      if ((tid & 15) == 0) W[i * ld + k] = lik;
     }
     __syncthreads();
   }
