@@ -243,3 +243,43 @@ def careduce_more():
         pt.logsumexp(t, axis=(2, 3)), pt.cumsum(t[0, 0], axis=1),
     ]
     return [t, i3], outs, {"t": rng.normal(size=(3, 4, 5, 6)), "i3": rng.integers(-9, 9, size=(4, 3, 5))}
+
+
+@case("scalar_incomplete_f64", rtol=1e-11, py_rtol=1e-6)
+def scalar_incomplete_f64():
+    # scalar/math.py: TriGamma 502, GammaInc 627, GammaIncC 674, BetaInc 1342 — their C support
+    # code (c_code/gamma.c, c_code/incbet.c): series and continued-fraction branches, the
+    # (half-)integer table of logGamma, the symmetry flip and the logarithmic fallback of incbet
+    rng = np.random.default_rng(46)
+    k = pt.dvector("k")  # shape parameters, some integers and half-integers
+    x = pt.dvector("x")
+    a = pt.dvector("a")
+    b = pt.dvector("b")
+    u = pt.dvector("u")  # (0, 1)
+    outs = [pt.gammainc(k, x), pt.gammaincc(k, x), pt.gammainc(k * 30, x * 30), pt.gammaincc(k * 30, x * 35),
+            pt.betainc(a, b, u), pt.betainc(a * 40, b * 55, u), pt.betainc(b, a, u * u), pt.tri_gamma(k), pt.tri_gamma(x * 1e-4 + 1e-6),
+            pt.exp(-x) * pt.gammaincc(k, x) + pt.betainc(a, b, u) ** 2]
+    n = 211
+    kv = rng.uniform(0.1, 9, size=n)
+    kv[::7] = np.round(kv[::7]) + 1.0
+    kv[3::7] = np.round(kv[3::7]) + 0.5
+    uv = rng.uniform(0.001, 0.999, size=n)
+    uv[:4] = [0.0, 1.0, 0.96, 0.5]
+    xv = rng.uniform(0.0, 14, size=n)
+    xv[5] = 0.0
+    vals = {"k": kv, "x": xv, "a": rng.uniform(0.2, 6, size=n), "b": rng.uniform(0.2, 6, size=n), "u": uv}
+    return [k, x, a, b, u], outs, vals
+
+
+@case("scalar_incomplete_f32", rtol=2e-6, py_rtol=1e-4)
+def scalar_incomplete_f32():
+    # float32 storage: the C code evaluates in double and casts (math.py:651-655)
+    rng = np.random.default_rng(47)
+    k = pt.fvector("k")
+    x = pt.fvector("x")
+    u = pt.fvector("u")
+    outs = [pt.gammainc(k, x), pt.gammaincc(k, x), pt.betainc(k, k * 0.5 + 1.0, u), pt.tri_gamma(k)]
+    n = 97
+    vals = {"k": rng.uniform(0.2, 7, size=n).astype("float32"), "x": rng.uniform(0.01, 12, size=n).astype("float32"),
+            "u": rng.uniform(0.01, 0.99, size=n).astype("float32")}
+    return [k, x, u], outs, vals

@@ -642,6 +642,8 @@ def generate(name):
     d = graph.to_dict()
     d["input_names"] = names
     d["rtol"] = tol
+    if name in PY_RTOL:
+        d["py_rtol"] = PY_RTOL[name]
     with open(os.path.join(GOLDEN, f"{name}.json"), "w") as fh:
         json.dump(d, fh, separators=(",", ":"))
     arrays = {f"in{k}": v for k, v in enumerate(in_vals)}

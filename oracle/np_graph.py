@@ -26,6 +26,8 @@ import numpy as np
 import scipy.linalg
 import scipy.special
 
+import special_c
+
 # ---------------------------------------------------------------------------
 # scalar ops — reference: pytensor/scalar/basic.py, pytensor/scalar/math.py
 # (``impl`` / ``nfunc_spec`` of each ScalarOp = what the NumPy linker runs)
@@ -174,6 +176,10 @@ SCALAR = {
     "GammaLn": scipy.special.gammaln,
     "Gamma": scipy.special.gamma,
     "Psi": _psi_as103,
+    "TriGamma": special_c.TriGamma,
+    "GammaInc": special_c.GammaInc,
+    "GammaIncC": special_c.GammaIncC,
+    "BetaInc": special_c.BetaInc,
     "Reciprocal": np.reciprocal,
     "Maximum": _variadic(np.maximum),
     "Minimum": _variadic(np.minimum),

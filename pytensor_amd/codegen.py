@@ -25,6 +25,7 @@ packs the argument buffer with plain ``struct.pack("<q...")``.
 from __future__ import annotations
 
 import hashlib
+import math
 import os
 
 import numpy as np
@@ -128,7 +129,229 @@ PT_DEV double pt_psi(double x) {
   return psi;
 }
 PT_DEV float pt_psi(float x) { return (float)pt_psi((double)x); }
+// trigamma: AS 121 with the 10-digit constants of TriGamma.c_support_code (scalar/math.py:518-567)
+PT_DEV double pt_trigamma(double x) {
+  const double b2 = 0.1666666667, b4 = -0.03333333333, b6 = 0.02380952381, b8 = -0.03333333333;
+  if (x <= 0) return 0.0;  // (NaN compares false and runs through the series: NaN out)
+  if (x <= 0.0001) return 1.0 / x / x;
+  double value = 0.0, z = x;
+  while (z < 5.0) { value += 1.0 / z / z; z += 1.0; }
+  const double y = 1.0 / z / z;
+  value += 0.5 * y + (1.0 + y * (b2 + y * (b4 + y * (b6 + y * b8)))) / z;
+  return value;
+}
+PT_DEV float pt_trigamma(float x) { return (float)pt_trigamma((double)x); }
 """
+
+# ---- incomplete gamma / beta: emitted only into kernels that use them ----
+
+
+def _gamma_tables():
+    """log(i!) and log(Gamma(i+1/2)) by the running products of the reference's support code
+    (scalar/c_code/gamma.c:62-80; the last half-integer slot stays 0 there)."""
+    logfs = [0.0] * 171
+    loghs = [0.0] * 171
+    x = 1.0
+    for i in range(2, 171):
+        x *= i
+        logfs[i] = math.log(x)
+    x = 1.77245385090551602729816748334
+    loghs[0] = 0.5 * 1.14472988584940017414342735135
+    for i in range(1, 170):
+        x *= i - 0.5
+        loghs[i] = math.log(x)
+    return logfs, loghs
+
+
+def _c_table(name, vals):
+    return f"static __device__ const double {name}[{len(vals)}] = {{" + ", ".join(repr(float(v)) for v in vals) + "};\n"
+
+
+_GAMMAINC_SRC = r"""
+// regularised incomplete gamma P / Q as the reference's C backend computes them
+// (scalar/c_code/gamma.c: logGamma 83-106, _series 143-155, _cfrac 172-189, GammaP 207-218,
+//  GammaQ 222-233; called from GammaInc/GammaIncC.c_code, scalar/math.py:648-655, 695-702)
+#define PT_G_EPS 2.2204460492503131e-16
+#define PT_G_TINY (PT_G_EPS * PT_G_EPS * PT_G_EPS)
+PT_DEV double pt_g_loggamma(double n) {
+  if (n <= 0) return __builtin_nan("");
+  if (n < 171 + 4 * PT_G_EPS) {
+    if (fabs(n - floor(n)) < 4 * PT_G_EPS) { const int i = (int)floor(n) - 1; return pt_g_logfs[i < 0 ? 0 : i]; }
+    if (fabs(2 * n - floor(2 * n)) < 4 * PT_G_EPS) return pt_g_loghs[(int)floor(n)];
+  }
+  double s = 0.99999999999980993227684700473478;
+  s += 676.520368121885098567009190444019 / (n + 1);
+  s += -1259.13921672240287047156078755283 / (n + 2);
+  s += 771.3234287776530788486528258894 / (n + 3);
+  s += -176.61502916214059906584551354 / (n + 4);
+  s += 12.507343278686904814458936853 / (n + 5);
+  s += -0.13857109526572011689554707 / (n + 6);
+  s += 9.984369578019570859563e-6 / (n + 7);
+  s += 1.50563273514931155834e-7 / (n + 8);
+  return (n + 0.5) * log((n + 7.5) / 2.71828182845904523536028747135) + (0.918938533204672741780329736406 + log(s / n) - 7.0);
+}
+PT_DEV double pt_g_series(double n, double x) {
+  double t = 1.0 / n, sum = t;
+  for (int i = 0; i < 1024; i++) {
+    n += 1.0;
+    t *= x / n;
+    sum += t;
+    if (fabs(t) < fabs(sum) * PT_G_EPS) break;
+  }
+  return sum;
+}
+PT_DEV double pt_g_cfrac(double n, double x) {
+  double b = x + 1 - n, c = 1 / PT_G_TINY, d = 1 / b, f = d;
+  for (int i = 1; i < 1024; i++) {
+    const double a = i * (n - i);
+    b += 2;
+    d = a * d + b;
+    if (fabs(d) < PT_G_TINY) d = PT_G_TINY;
+    c = b + a / c;
+    if (fabs(c) < PT_G_TINY) c = PT_G_TINY;
+    d = 1 / d;
+    const double e = d * c;
+    f *= e;
+    if (fabs(e - 1) < PT_G_EPS) break;
+  }
+  return f;
+}
+PT_DEV double pt_gammainc(double n, double x) {
+  if (isnan(n) || isnan(x)) return __builtin_nan("");
+  if ((n <= 0) || (x < 0)) return __builtin_nan("");
+  if (x <= 0) return 0;
+  if (isinf(n)) return isinf(x) ? __builtin_nan("") : 0.0;
+  if (isinf(x)) return 1;
+  const double sc = exp(n * log(x) - x - pt_g_loggamma(n));
+  if (x < n + 1) return pt_g_series(n, x) * sc;
+  return 1 - pt_g_cfrac(n, x) * sc;
+}
+PT_DEV double pt_gammaincc(double n, double x) {
+  if (isnan(n) || isnan(x)) return __builtin_nan("");
+  if ((n <= 0) || (x < 0)) return __builtin_nan("");
+  if (x <= 0) return 1;
+  if (isinf(n)) return isinf(x) ? __builtin_nan("") : 1.0;
+  if (isinf(x)) return 0;
+  const double sc = exp(n * log(x) - x - pt_g_loggamma(n));
+  if (x < n + 1) return 1 - pt_g_series(n, x) * sc;
+  return pt_g_cfrac(n, x) * sc;
+}
+PT_DEV float pt_gammainc(float n, float x) { return (float)pt_gammainc((double)n, (double)x); }
+PT_DEV float pt_gammaincc(float n, float x) { return (float)pt_gammaincc((double)n, (double)x); }
+"""
+
+_BETAINC_SRC = r"""
+// regularised incomplete beta (Cephes incbet) as the reference's C backend computes it
+// (scalar/c_code/incbet.c: BetaInc 33-90, incbcf 96-178, incbd 184-268, pseries 274-311;
+//  called from BetaInc.c_code, scalar/math.py:1371-1381).  The reference flips (a, b, x) by
+//  calling itself once; here the flipped evaluation is a second call of the same body.
+#define PT_B_MINLOG -7.451332191019412076235E2
+#define PT_B_MAXLOG 7.09782712893383996732E2
+#define PT_B_MAXGAM 171.624376956302725
+#define PT_B_EPS 1.11022302462515654042e-16
+#define PT_B_BIG 4.503599627370496e15
+#define PT_B_BIGINV 2.22044604925031308085e-16
+// both continued fractions share one three-term recurrence: k1..k8 and their increments differ
+PT_DEV double pt_b_cf(double xz, double k1, double k2, double k3, double k4, double k5, double k6,
+                      double k7, double k8, double d2, double d6) {
+  double pkm2 = 0.0, qkm2 = 1.0, pkm1 = 1.0, qkm1 = 1.0, ans = 1.0, r = 1.0, t;
+  const double thresh = 3.0 * PT_B_EPS;
+  int n = 0;
+  do {
+    double xk = -(xz * k1 * k2) / (k3 * k4);
+    double pk = pkm1 + pkm2 * xk, qk = qkm1 + qkm2 * xk;
+    pkm2 = pkm1; pkm1 = pk; qkm2 = qkm1; qkm1 = qk;
+    xk = (xz * k5 * k6) / (k7 * k8);
+    pk = pkm1 + pkm2 * xk; qk = qkm1 + qkm2 * xk;
+    pkm2 = pkm1; pkm1 = pk; qkm2 = qkm1; qkm1 = qk;
+    if (qk != 0.0) r = pk / qk;
+    if (r != 0.0) { t = fabs((ans - r) / r); ans = r; } else t = 1.0;
+    if (t < thresh) break;
+    k1 += 1.0; k2 += d2; k3 += 2.0; k4 += 2.0; k5 += 1.0; k6 += d6; k7 += 2.0; k8 += 2.0;
+    if ((fabs(qk) + fabs(pk)) > PT_B_BIG) { pkm2 *= PT_B_BIGINV; pkm1 *= PT_B_BIGINV; qkm2 *= PT_B_BIGINV; qkm1 *= PT_B_BIGINV; }
+    if ((fabs(qk) < PT_B_BIGINV) || (fabs(pk) < PT_B_BIGINV)) { pkm2 *= PT_B_BIG; pkm1 *= PT_B_BIG; qkm2 *= PT_B_BIG; qkm1 *= PT_B_BIG; }
+  } while (++n < 300);
+  return ans;
+}
+PT_DEV double pt_b_pseries(double a, double b, double x) {
+  const double ai = 1.0 / a;
+  double u = (1.0 - b) * x, v = u / (a + 1.0), t = u, n = 2.0, s = 0.0;
+  const double t1 = v, z = PT_B_EPS * ai;
+  while (fabs(v) > z) {
+    u = (n - b) * x / n;
+    t *= u;
+    v = t / (a + n);
+    s += v;
+    n += 1.0;
+  }
+  s += t1;
+  s += ai;
+  u = a * log(x);
+  if ((a + b) < PT_B_MAXGAM && fabs(u) < PT_B_MAXLOG) {
+    t = tgamma(a + b) / (tgamma(a) * tgamma(b));
+    s = s * t * pow(x, a);
+  } else {
+    t = lgamma(a + b) - lgamma(a) - lgamma(b) + u + log(s);
+    s = t < PT_B_MINLOG ? 0.0 : exp(t);
+  }
+  return s;
+}
+// everything of BetaInc() except the symmetry flip; *flip is set when the caller has to flip
+PT_DEV double pt_b_body(double a, double b, double x, bool may_flip, bool* flip) {
+  *flip = false;
+  if (x == 0.0) return 0.0;
+  if (x == 1.0) return 1.0;
+  if ((b * x) <= 1.0 && x <= 0.95) return pt_b_pseries(a, b, x);
+  const double xc = 1.0 - x;
+  if (may_flip && x > (a / (a + b))) { *flip = true; return 0.0; }
+  double y = x * (a + b - 2.0) - (a - 1.0), w, t;
+  if (y < 0.0) w = pt_b_cf(x, a, a + b, a, a + 1.0, 1.0, b - 1.0, a + 1.0, a + 2.0, 1.0, -1.0);
+  else w = pt_b_cf(x / (1.0 - x), a, b - 1.0, a, a + 1.0, 1.0, a + b, a + 1.0, a + 2.0, -1.0, 1.0) / xc;
+  y = a * log(x);
+  t = b * log(xc);
+  if ((a + b) < PT_B_MAXGAM && fabs(y) < PT_B_MAXLOG && fabs(t) < PT_B_MAXLOG) {
+    t = pow(xc, b);
+    t *= pow(x, a);
+    t /= a;
+    t *= w;
+    t *= tgamma(a + b) / (tgamma(a) * tgamma(b));
+    return t;
+  }
+  y += t + lgamma(a + b) - lgamma(a) - lgamma(b);
+  y += log(w / a);
+  return y < PT_B_MINLOG ? 0.0 : exp(y);
+}
+PT_DEV double pt_betainc(double a, double b, double x) {
+  if (isnan(a) || isnan(b) || isnan(x)) return __builtin_nan("");
+  if (a <= 0.0 || b <= 0.0 || x < 0.0 || 1.0 < x) return __builtin_nan("");
+  bool flip;
+  double t = pt_b_body(a, b, x, true, &flip);
+  if (!flip) return t;
+  t = pt_b_body(b, a, 1.0 - x, false, &flip);
+  return t <= PT_B_EPS ? 1.0 - PT_B_EPS : 1.0 - t;
+}
+PT_DEV float pt_betainc(float a, float b, float x) { return (float)pt_betainc((double)a, (double)b, (double)x); }
+"""
+
+_OPTIONAL_HELPERS = {"GammaInc": "gammainc", "GammaIncC": "gammainc", "BetaInc": "betainc"}
+_optional_src_cache = {}
+
+
+def _optional_src(key: str) -> str:
+    if key not in _optional_src_cache:
+        if key == "gammainc":
+            logfs, loghs = _gamma_tables()
+            _optional_src_cache[key] = _c_table("pt_g_logfs", logfs) + _c_table("pt_g_loghs", loghs) + _GAMMAINC_SRC
+        else:
+            _optional_src_cache[key] = _BETAINC_SRC
+    return _optional_src_cache[key]
+
+
+def prelude_for(*bodies) -> str:
+    """PRELUDE plus the long helpers only the given scalar bodies need."""
+    keys = sorted({_OPTIONAL_HELPERS[n["op"]] for b in bodies if b for n in b["body"] if n["op"] in _OPTIONAL_HELPERS})
+    return PRELUDE + "".join(_optional_src(k) for k in keys)
+
 
 
 class ScalarCodegenError(NotImplementedError):
@@ -347,6 +570,10 @@ SCALAR_EXPR = {
     "GammaLn": _f("lgamma"),  # scalar/math.py:363
     "Gamma": _f("tgamma"),
     "Psi": _helper("pt_psi"),  # scalar/math.py:403
+    "TriGamma": _helper("pt_trigamma"),  # scalar/math.py:502
+    "GammaInc": _helper("pt_gammainc"),  # scalar/math.py:627
+    "GammaIncC": _helper("pt_gammaincc"),  # scalar/math.py:674
+    "BetaInc": _helper("pt_betainc"),  # scalar/math.py:1342
     "Reciprocal": lambda a, i, o: f"(({CTYPE[o]})1 / ({CTYPE[o]}){a[0]})",
     "Maximum": _maxmin("pt_max"),  # 1744
     "Minimum": _maxmin("pt_min"),  # 1790
@@ -461,7 +688,7 @@ def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=
     if "G" in modes:
         assert vec == 1, "gather inputs use the scalar loop"
         params.append("int* __restrict__ status")
-    src = [reduce_header() if any(reduce_spec) else "", PRELUDE, VEC_HELPERS]
+    src = [reduce_header() if any(reduce_spec) else "", prelude_for(body), VEC_HELPERS]
     src.append(f'extern "C" __global__ __launch_bounds__({BLOCK}) void {name}({", ".join(params)}) {{')
     # scalars
     for k, m in enumerate(modes):
@@ -633,7 +860,7 @@ def nd_kernel_source(name: str, body: dict, ndim: int, reduce_spec=None, partial
             params.append(f"{CTYPE[dt]}* __restrict__ out{k}")
         else:
             params.append(f"{CTYPE[reduce_spec[k][1]]}* __restrict__ part{k}")
-    src = [reduce_header() if any(reduce_spec) else "", PRELUDE]
+    src = [reduce_header() if any(reduce_spec) else "", prelude_for(body)]
     src.append(f'extern "C" __global__ __launch_bounds__({BLOCK}) void {name}({", ".join(params)}) {{')
     for k, rs in enumerate(reduce_spec):
         if rs is not None:
@@ -741,7 +968,7 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
     if scatter_out is not None:
         params += ["const long long* __restrict__ sidx", "long long sbins", "double* __restrict__ partS"]
     params.append("int* __restrict__ status")
-    L = [reduce_header(), PRELUDE]
+    L = [reduce_header(), prelude_for(body)]
     L.append("typedef double pt_d2 __attribute__((ext_vector_type(2)));")
     L.append("static __device__ __forceinline__ double pt_shfl_xor(double v, int m) { return pthip_dev::shfl_xor_any(v, m); }")
     L.append("static __device__ __forceinline__ double pt_readlane(double v, int l) {")

@@ -19,7 +19,9 @@ def test_reference_py_and_c_linkers_agree(name):
     # sanity of the fixtures themselves: NumPy linker vs C linker of the reference
     g, ins, cvm, py, meta = load_case(name)
     for k, (a, b) in enumerate(zip(py, cvm)):
-        assert_parity(a, b, max(meta["rtol"], 1e-10), f"{name} out{k} (reference py vs C)")
+        # (py_rtol: cases where the reference's SciPy-backed impl and its C support code are
+        #  different algorithms — the C values are the parity target, this is only a sanity check)
+        assert_parity(a, b, meta.get("py_rtol", max(meta["rtol"], 1e-10)), f"{name} out{k} (reference py vs C)")
 
 
 def test_ir_roundtrip():
