@@ -283,3 +283,23 @@ def scalar_incomplete_f32():
     vals = {"k": rng.uniform(0.2, 7, size=n).astype("float32"), "x": rng.uniform(0.01, 12, size=n).astype("float32"),
             "u": rng.uniform(0.01, 0.99, size=n).astype("float32")}
     return [k, x, u], outs, vals
+
+
+@case("scalar_loop_grads", rtol=1e-9, py_rtol=1e-6)
+def scalar_loop_grads():
+    # scalar/loop.py:10 ScalarLoop inside Elemwise: the shape-parameter gradients of the incomplete
+    # gamma / beta functions (math.py gammainc_grad 772+, gammaincc_grad, betainc_grad 1386+) are
+    # while-loops over series / continued fractions, fused with the surrounding scalar ops
+    rng = np.random.default_rng(48)
+    k = pt.dvector("k")
+    x = pt.dvector("x")
+    a = pt.dvector("a")
+    b = pt.dvector("b")
+    u = pt.dvector("u")
+    gk = pytensor.grad(pt.gammainc(k, x).sum(), [k, x])
+    gkc = pytensor.grad((pt.gammaincc(k, x) * x).sum(), k)
+    gab = pytensor.grad(pt.betainc(a, b, u).sum(), [a, b, u])
+    n = 61
+    vals = {"k": rng.uniform(0.3, 7, size=n), "x": rng.uniform(0.1, 12, size=n), "a": rng.uniform(0.4, 5, size=n),
+            "b": rng.uniform(0.4, 5, size=n), "u": rng.uniform(0.02, 0.98, size=n)}
+    return [k, x, a, b, u], [*gk, gkc, *gab], vals

@@ -228,9 +228,43 @@ def eval_scalar_body(body: dict, inputs):
     with np.errstate(all="ignore"):
         for n in body["body"]:
             args = [get(r) for r in n["in"]]
+            if n["op"] == "ScalarLoop":
+                vals.append(_eval_scalar_loop(n["loop"], args))  # a tuple of final states (+ until)
+                continue
+            if n["op"] == "LoopOut":
+                vals.append(np.asarray(args[0][n["k"]]).astype(n["dtype"], copy=False))
+                continue
             out = SCALAR[n["op"]](*args)
             vals.append(np.asarray(out).astype(n["dtype"], copy=False))
     return [get(r) for r in body["outs"]]
+
+
+def _eval_scalar_loop(loop: dict, args):
+    """``ScalarLoop`` the way its C code runs it (pytensor/scalar/loop.py:181-290), lane-wise over
+    arrays: each element iterates ``n_steps`` times or until its ``until`` turns true (the flag
+    starts true, so zero steps report "done"); finished elements keep their state."""
+    inner = loop["body"]
+    S = loop["n_state"]
+    n_steps = np.asarray(args[0])
+    shape = np.broadcast_shapes(*[np.shape(a) for a in args])
+    state = [np.broadcast_to(np.asarray(a).astype(dt, copy=False), shape).copy() for a, dt in zip(args[1 : 1 + S], inner["in_dtypes"][:S])]
+    consts = [np.broadcast_to(np.asarray(a).astype(dt, copy=False), shape) for a, dt in zip(args[1 + S :], inner["in_dtypes"][S:])]
+    done = np.ones(shape, dtype=bool)
+    active = np.broadcast_to(n_steps > 0, shape).copy()
+    it = 0
+    while active.any():
+        outs = eval_scalar_body(inner, state + consts)
+        for j in range(S):
+            state[j] = np.where(active, np.broadcast_to(outs[j], shape), state[j]).astype(inner["in_dtypes"][j], copy=False)
+        if loop["is_while"]:
+            done = np.where(active, np.broadcast_to(outs[S], shape).astype(bool), done)
+        else:
+            done = np.where(active, False, done)
+        it += 1
+        active = active & (it < n_steps)
+        if loop["is_while"]:
+            active = active & ~done
+    return tuple(state) + ((done,) if loop["is_while"] else ())
 
 
 # ---------------------------------------------------------------------------

@@ -349,8 +349,17 @@ def _optional_src(key: str) -> str:
 
 def prelude_for(*bodies) -> str:
     """PRELUDE plus the long helpers only the given scalar bodies need."""
-    keys = sorted({_OPTIONAL_HELPERS[n["op"]] for b in bodies if b for n in b["body"] if n["op"] in _OPTIONAL_HELPERS})
+    keys = sorted({_OPTIONAL_HELPERS[op] for b in bodies if b for op in body_ops(b) if op in _OPTIONAL_HELPERS})
     return PRELUDE + "".join(_optional_src(k) for k in keys)
+
+
+def body_ops(body: dict):
+    """every scalar op name of a body, the inner bodies of its ``ScalarLoop`` nodes included"""
+    for n in body["body"]:
+        if n["op"] == "ScalarLoop":
+            yield from body_ops(n["loop"]["body"])
+        elif n["op"] != "LoopOut":
+            yield n["op"]
 
 
 
@@ -607,13 +616,18 @@ SCALAR_EXPR = {
 
 
 def supported(body: dict) -> bool:
-    return all(n["op"] in SCALAR_EXPR for n in body["body"]) and all(
-        d in CTYPE for d in body["in_dtypes"] + body["out_dtypes"]
-    )
+    def dtypes(b):
+        yield from b["in_dtypes"] + b["out_dtypes"]
+        for n in b["body"]:
+            if n["op"] == "ScalarLoop":
+                yield from dtypes(n["loop"]["body"])
+
+    return all(op in SCALAR_EXPR for op in body_ops(body)) and all(d in CTYPE for d in dtypes(body))
 
 
-def emit_body(body: dict, in_names, out_names, indent="      ") -> str:
-    """SSA statements computing ``out_names`` from ``in_names`` (one element)."""
+def emit_body(body: dict, in_names, out_names, indent="      ", tp="t") -> str:
+    """SSA statements computing ``out_names`` from ``in_names`` (one element).  ``tp`` prefixes
+    the temporaries (the inner body of a loop lives in a nested scope with its own prefix)."""
     lines = []
     tdt = []
 
@@ -621,22 +635,65 @@ def emit_body(body: dict, in_names, out_names, indent="      ") -> str:
         if r[0] == "i":
             return in_names[r[1]], body["in_dtypes"][r[1]]
         if r[0] == "t":
-            return f"t{r[1]}", tdt[r[1]]
+            return f"{tp}{r[1]}", tdt[r[1]]
         return _lit(r[1], r[2]), r[2]
 
     for k, n in enumerate(body["body"]):
-        gen = SCALAR_EXPR.get(n["op"])
-        if gen is None:
-            raise ScalarCodegenError(f"no device expression for scalar op {n['op']}")
-        pairs = [ref(r) for r in n["in"]]
-        expr = gen([p[0] for p in pairs], [p[1] for p in pairs], n["dtype"])
         ct = CTYPE[n["dtype"]]
-        lines.append(f"{indent}const {ct} t{k} = ({ct})({expr});")
+        if n["op"] == "ScalarLoop":
+            lines.append(_emit_loop(n, [ref(r) for r in n["in"]], f"{tp}{k}_", indent))
+            lines.append(f"{indent}const {ct} {tp}{k} = {tp}{k}_s0;")
+        elif n["op"] == "LoopOut":
+            assert n["in"][0][0] == "t" and body["body"][n["in"][0][1]]["op"] == "ScalarLoop"
+            loop = body["body"][n["in"][0][1]]["loop"]
+            which = "done" if (loop["is_while"] and n["k"] == loop["n_state"]) else f"s{n['k']}"
+            lines.append(f"{indent}const {ct} {tp}{k} = ({ct}){tp}{n['in'][0][1]}_{which};")
+        else:
+            gen = SCALAR_EXPR.get(n["op"])
+            if gen is None:
+                raise ScalarCodegenError(f"no device expression for scalar op {n['op']}")
+            pairs = [ref(r) for r in n["in"]]
+            expr = gen([p[0] for p in pairs], [p[1] for p in pairs], n["dtype"])
+            lines.append(f"{indent}const {ct} {tp}{k} = ({ct})({expr});")
         tdt.append(n["dtype"])
     for name, r, dt in zip(out_names, body["outs"], body["out_dtypes"]):
         e, _ = ref(r)
         lines.append(f"{indent}{name} = ({CTYPE[dt]})({e});")
     return "\n".join(lines)
+
+
+def _emit_loop(n: dict, pairs, P: str, indent: str) -> str:
+    """``ScalarLoop.c_code_template`` (pytensor/scalar/loop.py:181-290) restated: carried
+    copies of the initial states, ``for (i < n_steps)`` around the inner body, the carries
+    overwritten after the whole body ran, ``until`` starting true and breaking after the update."""
+    loop = n["loop"]
+    inner = loop["body"]
+    S = loop["n_state"]
+    L = []
+    for j in range(S):
+        ct = CTYPE[inner["in_dtypes"][j]]
+        L.append(f"{indent}{ct} {P}s{j} = ({ct})({pairs[1 + j][0]});")
+    names = [f"{P}s{j}" for j in range(S)]
+    for j in range(S, len(inner["in_dtypes"])):
+        ct = CTYPE[inner["in_dtypes"][j]]
+        L.append(f"{indent}const {ct} {P}c{j} = ({ct})({pairs[1 + j][0]});")
+        names.append(f"{P}c{j}")
+    if loop["is_while"]:
+        L.append(f"{indent}bool {P}done = true;")
+    L.append(f"{indent}for (long long {P}it = 0, {P}n = (long long)({pairs[0][0]}); {P}it < {P}n; ++{P}it) {{")
+    ind2 = indent + "  "
+    outs = []
+    for j, dt in enumerate(inner["out_dtypes"]):
+        L.append(f"{ind2}{CTYPE[dt]} {P}n{j};")
+        outs.append(f"{P}n{j}")
+    L.append(emit_body(inner, names, outs, ind2, tp=P + "t"))
+    for j in range(S):
+        L.append(f"{ind2}{P}s{j} = {P}n{j};")
+    if loop["is_while"]:
+        L.append(f"{ind2}{P}done = {P}n{S};")
+        L.append(f"{ind2}if ({P}done) break;")
+    L.append(f"{indent}}}")
+    return "\n".join(L)
 
 
 # ---------------------------------------------------------------------------

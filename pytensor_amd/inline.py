@@ -97,8 +97,9 @@ def _inline_at(cb: dict, q: int, pb: dict) -> dict:
             return ["t", r[1] + n_p]
         return list(r)
 
-    body = [{"op": b["op"], "in": [pref(r) for r in b["in"]], "dtype": b["dtype"]} for b in pb["body"]]
-    body += [{"op": b["op"], "in": [cref(r) for r in b["in"]], "dtype": b["dtype"]} for b in cb["body"]]
+    # ({**b}: loop nodes carry their inner body along)
+    body = [{**b, "in": [pref(r) for r in b["in"]]} for b in pb["body"]]
+    body += [{**b, "in": [cref(r) for r in b["in"]]} for b in cb["body"]]
     return {
         "in_dtypes": [d for pos, d in enumerate(cb["in_dtypes"]) if pos != q] + list(pb["in_dtypes"]),
         "out_dtypes": list(cb["out_dtypes"]),
@@ -126,7 +127,7 @@ def _dedupe_inputs(node: Node) -> Node:
     nb = {
         "in_dtypes": [b["in_dtypes"][p] for p in keep],
         "out_dtypes": list(b["out_dtypes"]),
-        "body": [{"op": e["op"], "in": [ref(r) for r in e["in"]], "dtype": e["dtype"]} for e in b["body"]],
+        "body": [{**e, "in": [ref(r) for r in e["in"]]} for e in b["body"]],
         "outs": [ref(r) for r in b["outs"]],
     }
     params = dict(node.params)

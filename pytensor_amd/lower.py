@@ -24,6 +24,7 @@ from pytensor.compile.ops import DeepCopyOp, TypeCastingOp, ViewOp
 from pytensor.graph.basic import Constant
 from pytensor.raise_op import CheckAndRaise
 from pytensor.scalar.basic import Cast, Composite, ScalarOp, ScalarType
+from pytensor.scalar.loop import ScalarLoop
 from pytensor.scan.op import Scan
 from pytensor.tensor.basic import (
     Alloc,
@@ -63,70 +64,100 @@ def _scalar_op_name(op) -> str:
 
 
 def lower_scalar_op(op: ScalarOp, in_dtypes, out_dtypes) -> dict:
-    """Scalar op or ``Composite`` → SSA body.
+    """Scalar op, ``Composite`` or ``ScalarLoop`` → SSA body.
 
     Follows the walk of ``Composite.c_code_template``
     (pytensor/scalar/basic.py:4111-4170): inner nodes in toposort order,
     constants inlined as literals.
     refs: ["i", k] input k · ["t", k] k-th body value · ["c", value, dtype] literal.
+
+    A ``ScalarLoop`` (pytensor/scalar/loop.py:10; the gradients of the incomplete gamma / beta
+    functions and of hyp2f1 are built from it) becomes one body node carrying its inner SSA
+    body under ``"loop"``, followed by one ``LoopOut`` node per output selecting a final state
+    (or the ``until`` flag).
     """
     if isinstance(op, Composite):
-        fg = op.fgraph
-        ref = {}
-        for k, v in enumerate(fg.inputs):
-            ref[v] = ["i", k]
+        return _lower_scalar_fgraph(op.fgraph, in_dtypes, out_dtypes)
+    args = [["i", k] for k in range(len(in_dtypes))]
+    if isinstance(op, ScalarLoop):
         body = []
-        for node in fg.toposort():
-            args = []
-            for inp in node.inputs:
-                if inp in ref:
-                    args.append(ref[inp])
-                elif isinstance(inp, Constant):
-                    args.append(_const_ref(inp))
-                else:  # pragma: no cover
-                    raise NotImplementedError(f"dangling scalar input {inp}")
-            if isinstance(node.op, Composite):  # nested composite: flatten
-                sub = lower_scalar_op(
-                    node.op,
-                    [i.type.dtype for i in node.inputs],
-                    [o.type.dtype for o in node.outputs],
-                )
-                base = len(body)
-
-                def fix(r, base=base, args=args):
-                    if r[0] == "i":
-                        return args[r[1]]
-                    if r[0] == "t":
-                        return ["t", base + r[1]]
-                    return r
-
-                for sn in sub["body"]:
-                    body.append({**sn, "in": [fix(r) for r in sn["in"]]})
-                for out, r in zip(node.outputs, sub["outs"]):
-                    ref[out] = fix(r)
-                continue
-            if len(node.outputs) != 1:
-                raise NotImplementedError(f"multi-output scalar op {node.op}")
-            body.append(_scalar_node(node.op, args, node.outputs[0].type.dtype))
-            ref[node.outputs[0]] = ["t", len(body) - 1]
-        outs = []
-        for o in fg.outputs:
-            if o in ref:
-                outs.append(ref[o])
-            elif isinstance(o, Constant):
-                outs.append(_const_ref(o))
-            else:  # pragma: no cover
-                raise NotImplementedError
+        outs = _append_loop(body, op, args, out_dtypes)
         return {"in_dtypes": list(in_dtypes), "out_dtypes": list(out_dtypes), "body": body, "outs": outs}
     if len(out_dtypes) != 1:
         raise NotImplementedError(f"multi-output scalar op {op}")
-    args = [["i", k] for k in range(len(in_dtypes))]
     return {
         "in_dtypes": list(in_dtypes),
         "out_dtypes": list(out_dtypes),
         "body": [_scalar_node(op, args, out_dtypes[0])],
         "outs": [["t", 0]],
     }
+
+
+def _append_loop(body, op, args, out_dtypes):
+    """append the loop node and its ``LoopOut`` selectors to ``body``; returns the output refs"""
+    n_state = len(op.outputs) - (1 if op.is_while else 0)
+    inner = _lower_scalar_fgraph(op.fgraph, [i.type.dtype for i in op.fgraph.inputs], [o.type.dtype for o in op.fgraph.outputs])
+    k = len(body)
+    body.append({"op": "ScalarLoop", "in": args, "dtype": str(out_dtypes[0]),
+                 "loop": {"n_state": n_state, "is_while": bool(op.is_while), "body": inner}})
+    refs = []
+    for j, dt in enumerate(out_dtypes):
+        body.append({"op": "LoopOut", "in": [["t", k]], "dtype": str(dt), "k": j})
+        refs.append(["t", len(body) - 1])
+    return refs
+
+
+def _lower_scalar_fgraph(fg, in_dtypes, out_dtypes) -> dict:
+    ref = {}
+    for k, v in enumerate(fg.inputs):
+        ref[v] = ["i", k]
+    body = []
+    for node in fg.toposort():
+        args = []
+        for inp in node.inputs:
+            if inp in ref:
+                args.append(ref[inp])
+            elif isinstance(inp, Constant):
+                args.append(_const_ref(inp))
+            else:  # pragma: no cover
+                raise NotImplementedError(f"dangling scalar input {inp}")
+        if isinstance(node.op, Composite):  # nested composite: flatten
+            sub = lower_scalar_op(
+                node.op,
+                [i.type.dtype for i in node.inputs],
+                [o.type.dtype for o in node.outputs],
+            )
+            base = len(body)
+
+            def fix(r, base=base, args=args):
+                if r[0] == "i":
+                    return args[r[1]]
+                if r[0] == "t":
+                    return ["t", base + r[1]]
+                return r
+
+            for sn in sub["body"]:
+                body.append({**sn, "in": [fix(r) for r in sn["in"]]})
+            for out, r in zip(node.outputs, sub["outs"]):
+                ref[out] = fix(r)
+            continue
+        if isinstance(node.op, ScalarLoop):
+            for out, r in zip(node.outputs, _append_loop(body, node.op, args, [o.type.dtype for o in node.outputs])):
+                ref[out] = r
+            continue
+        if len(node.outputs) != 1:
+            raise NotImplementedError(f"multi-output scalar op {node.op}")
+        body.append(_scalar_node(node.op, args, node.outputs[0].type.dtype))
+        ref[node.outputs[0]] = ["t", len(body) - 1]
+    outs = []
+    for o in fg.outputs:
+        if o in ref:
+            outs.append(ref[o])
+        elif isinstance(o, Constant):
+            outs.append(_const_ref(o))
+        else:  # pragma: no cover
+            raise NotImplementedError
+    return {"in_dtypes": list(in_dtypes), "out_dtypes": list(out_dtypes), "body": body, "outs": outs}
 
 
 def _const_ref(c: Constant):
