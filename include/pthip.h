@@ -191,6 +191,12 @@ int pthip_potrf_trsv(int dtype, int64_t batch, int64_t n, const void* A, const v
  * np.linalg.inv at the caller's next sync; Solve NaN-fills and det returns 0 instead). */
 int pthip_getrf(int dtype, int64_t batch, int64_t n, const void* A, void* LU, void* perm, void* sign,
                 void* logabsdet, int flag_singular);
+/* Eigh.perform (pytensor/tensor/linalg/decomposition/eigen.py:177-195, scipy.linalg.eigh of the
+ * standard problem): batch x (n, n) symmetric matrices of which only the lower (or upper)
+ * triangle is read -> eigenvalues W (batch, n) ascending and eigenvectors as the columns of V
+ * (batch, n, n).  Parallel cyclic Jacobi; no convergence raises bit 1 of the device error word
+ * (scipy: LinAlgError).  n <= 512. */
+int pthip_eigh(int dtype, int64_t batch, int64_t n, int lower, const void* A, void* W, void* V);
 /* solve op(T) X = B, T triangular n×n (strided), B n×nrhs (contiguous row-major), out contiguous */
 int pthip_trsm(int dtype, int lower, int trans, int unit_diag, int64_t batch, int64_t n,
                int64_t nrhs, const void* T, int64_t sTb, int64_t sT0, int64_t sT1, const void* B,

@@ -303,3 +303,45 @@ def scalar_loop_grads():
     vals = {"k": rng.uniform(0.3, 7, size=n), "x": rng.uniform(0.1, 12, size=n), "a": rng.uniform(0.4, 5, size=n),
             "b": rng.uniform(0.4, 5, size=n), "u": rng.uniform(0.02, 0.98, size=n)}
     return [k, x, a, b, u], [*gk, gkc, *gab], vals
+
+
+@case("scalar_bessel", rtol=1e-10)
+def scalar_bessel():
+    # scalar/math.py: J1 1011, J0 1039 (libm through c_code), I1 1066, I0 1090 (SciPy, no C code)
+    rng = np.random.default_rng(49)
+    x = pt.dvector("x")
+    f = pt.fvector("f")
+    outs = [pt.j0(x), pt.j1(x), pt.i0(x), pt.i1(x), pt.j0(x * 4) + pt.i0(x * 0.25), pt.j1(f), pt.i0(f)]
+    return [x, f], outs, {"x": rng.uniform(-7, 7, size=173), "f": rng.uniform(-5, 5, size=64).astype("float32")}
+
+
+@case("eigh_symmetric", rtol=1e-9)
+def eigh_symmetric():
+    # linalg/decomposition/eigen.py:102 Eigh (standard problem) and its pullback 214-300.  An
+    # eigenvector's sign is arbitrary (LAPACK's and the Jacobi kernel's differ), so every output
+    # is a sign-free function: w, |v|, V f(w) V^T, and gradients of sign-free losses.
+    rng = np.random.default_rng(50)
+    A = pt.dmatrix("A")
+    B = pt.dtensor3("B")
+    w, v = pt.linalg.eigh(A)
+    wu, vu = pt.linalg.eigh(A, lower=False)
+    wb, vb = pt.linalg.eigh(B)
+    loss = (pt.log(w) * w).sum() + ((v * v) * A).sum()
+    outs = [w, pt.abs(v), (v * pt.exp(-w)[None, :]) @ v.T, wu, pt.abs(vu), wb, pt.abs(vb), pytensor.grad(loss, A)]
+    n = 24
+    M = rng.normal(size=(n, n))
+    S = M @ M.T / n + np.diag(np.linspace(0.5, 3.0, n))
+    T = rng.normal(size=(n, n))  # not symmetric: lower and upper triangles are different problems
+    Bv = rng.normal(size=(3, 9, 9))
+    Bv = Bv @ Bv.transpose(0, 2, 1) + np.eye(9) * np.arange(1, 10)
+    return [A, B], outs, {"A": S + np.triu(T, 1), "B": Bv}
+
+
+@case("eigh_f32", rtol=2e-5)
+def eigh_f32():
+    rng = np.random.default_rng(51)
+    F = pt.fmatrix("F")
+    wf, vf = pt.linalg.eigh(F)
+    Fv = rng.normal(size=(17, 17)).astype("float32")
+    Fv = (Fv + Fv.T) / 2
+    return [F], [wf, (vf * wf[None, :]) @ vf.T, pt.abs(vf)], {"F": Fv}

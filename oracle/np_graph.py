@@ -180,6 +180,10 @@ SCALAR = {
     "GammaInc": special_c.GammaInc,
     "GammaIncC": special_c.GammaIncC,
     "BetaInc": special_c.BetaInc,
+    "J0": scipy.special.j0,
+    "J1": scipy.special.j1,
+    "I0": scipy.special.i0,
+    "I1": scipy.special.i1,
     "Reciprocal": np.reciprocal,
     "Maximum": _variadic(np.maximum),
     "Minimum": _variadic(np.minimum),
@@ -936,6 +940,13 @@ def _slogdet(p, inputs, node, graph):
     # pytensor/tensor/linalg/summary.py:101-107 (SLogDet.perform): np.linalg.slogdet
     s, l = np.linalg.slogdet(inputs[0])
     return [np.asarray(s), np.asarray(l)]
+
+
+@op("Eigh")
+def _eigh(p, inputs, node, graph):
+    # pytensor/tensor/linalg/decomposition/eigen.py:177-195 (Eigh.perform, standard problem)
+    w, v = scipy.linalg.eigh(inputs[0], lower=p["lower"])
+    return [w, v]
 
 
 @op("MatrixInverse")

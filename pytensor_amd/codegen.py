@@ -583,6 +583,12 @@ SCALAR_EXPR = {
     "GammaInc": _helper("pt_gammainc"),  # scalar/math.py:627
     "GammaIncC": _helper("pt_gammaincc"),  # scalar/math.py:674
     "BetaInc": _helper("pt_betainc"),  # scalar/math.py:1342
+    # Bessel functions: J0/J1.c_code call libm's j0/j1 in double (scalar/math.py:1011-1064);
+    # I0/I1 have no C code, the reference evaluates scipy.special.i0/i1 (1066-1110)
+    "J0": lambda a, i, o: f"({CTYPE[o]})j0((double){a[0]})",
+    "J1": lambda a, i, o: f"({CTYPE[o]})j1((double){a[0]})",
+    "I0": lambda a, i, o: f"({CTYPE[o]})cyl_bessel_i0((double){a[0]})",
+    "I1": lambda a, i, o: f"({CTYPE[o]})cyl_bessel_i1((double){a[0]})",
     "Reciprocal": lambda a, i, o: f"(({CTYPE[o]})1 / ({CTYPE[o]}){a[0]})",
     "Maximum": _maxmin("pt_max"),  # 1744
     "Minimum": _maxmin("pt_min"),  # 1790

@@ -1,0 +1,185 @@
+// eigh.hip — symmetric eigendecomposition by parallel cyclic Jacobi rotations.
+//
+// Reference: Eigh.perform (pytensor/tensor/linalg/decomposition/eigen.py:177-195:
+// scipy.linalg.eigh(a, lower=..., driver=evr|evd) — LAPACK syevr/syevd): eigenvalues ascending,
+// eigenvectors as columns, only the `lower` (or upper) triangle of the input is read.  The sign
+// of an eigenvector is not defined by the reference either; parity is checked on sign-free
+// quantities (w, |v|, V f(w) V^T, gradients).
+//
+// correct first.  LAPACK's tridiagonalisation + MRRR is a chain of
+// short dependent steps; on a GPU the two-sided Jacobi method is the natural small-matrix
+// algorithm: a round-robin ordering gives n/2 disjoint (p, q) pairs per round whose rotations
+// are applied together, every phase is a conflict-free LDS sweep (leading dimension n|1), and
+// the result has high relative accuracy.  One workgroup per matrix (batches on grid.x); A and
+// the accumulated V live in LDS when they fit (n <= 96 fp64 / 136 fp32), otherwise V (then A)
+// moves to an L2-resident global scratch.  A round is three phases: rotation angles (one thread
+// per pair), column update of A and V, row update of A.  Sweeps repeat until one passes without
+// a rotation; no convergence within MAX_SWEEPS raises bit 1 of the device error word
+// (scipy raises LinAlgError when LAPACK reports non-convergence).
+#include "common.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int MAX_SWEEPS = 60;
+constexpr int MAX_N = 512;
+
+template <class T> struct Eps;
+template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; };
+template <> struct Eps<float> { static constexpr float v = 1.1920929e-07f; };
+
+template <class T>
+__global__ __launch_bounds__(BLOCK) void eigh_jacobi_kernel(const T* __restrict__ Ain, T* __restrict__ Wout,
+                                                           T* __restrict__ Vout, int n, int lower, int a_lds,
+                                                           int v_lds, T* scratchA, T* scratchV,
+                                                           int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ T s_c[MAX_N / 2], s_s[MAX_N / 2];
+  __shared__ short s_p[MAX_N / 2], s_q[MAX_N / 2], s_rank[MAX_N];
+  __shared__ T s_red[BLOCK / 64];
+  __shared__ int s_rot;
+  const long long mat = blockIdx.x;
+  const int ld = n | 1;
+  T* A = a_lds ? (T*)smem_raw : scratchA + mat * (long long)n * ld;
+  T* V = v_lds ? (T*)smem_raw + (a_lds ? (size_t)n * ld : 0) : scratchV + mat * (long long)n * ld;
+  const T* Ag = Ain + mat * (long long)n * n;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+
+  // symmetric load from the chosen triangle; V = I; Frobenius norm for the absolute threshold
+  T fro = T(0);
+  for (int i = wid; i < n; i += BLOCK / 64)
+    for (int j = lane; j < n; j += 64) {
+      const int r = lower ? (i > j ? i : j) : (i < j ? i : j);
+      const int c = lower ? (i > j ? j : i) : (i < j ? j : i);
+      const T a = Ag[(long long)r * n + c];
+      A[i * ld + j] = a;
+      V[i * ld + j] = i == j ? T(1) : T(0);
+      fro += a * a;
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) fro += __shfl_xor(fro, o);
+  if (lane == 0) s_red[wid] = fro;
+  if (tid == 0) s_rot = 0;
+  __syncthreads();
+  fro = T(0);
+  for (int w = 0; w < BLOCK / 64; w++) fro += s_red[w];
+  // below this, a rotation changes nothing at working precision relative to ||A||
+  const T tiny_abs = Eps<T>::v * T(1.0 / 1024) * sqrt(fro);
+
+  const int m = (n + 1) & ~1, half = m >> 1;
+  bool converged = n < 2;
+  for (int sweep = 0; sweep < MAX_SWEEPS && !converged; sweep++) {
+    for (int r = 0; r < m - 1; r++) {
+      // ---- phase 1: one thread per pair computes its rotation ----
+      for (int i = tid; i < half; i += BLOCK) {
+        int p, q;
+        if (i == 0) { p = r; q = m - 1; }
+        else { p = r + i; if (p >= m - 1) p -= m - 1; q = r - i; if (q < 0) q += m - 1; }
+        if (p > q) { const int t = p; p = q; q = t; }
+        T c = T(1), s = T(0);
+        if (q < n) {
+          const T app = A[p * ld + p], aqq = A[q * ld + q], apq = A[p * ld + q];
+          const T mag = apq < T(0) ? -apq : apq;
+          const T dd = app * aqq;
+          if (mag > tiny_abs && mag > Eps<T>::v * sqrt(dd < T(0) ? -dd : dd)) {
+            const T theta = (aqq - app) / (T(2) * apq);
+            const T at = theta < T(0) ? -theta : theta;
+            T t = T(1) / (at + sqrt(theta * theta + T(1)));
+            if (theta < T(0)) t = -t;
+            c = T(1) / sqrt(t * t + T(1));
+            s = t * c;
+            s_rot = 1;
+          }
+        }
+        s_c[i] = c; s_s[i] = s; s_p[i] = (short)p; s_q[i] = (short)q;
+      }
+      __syncthreads();
+      // ---- phase 2: columns p, q of A and of V (a wave per pair, lanes down the rows) ----
+      for (int i = wid; i < half; i += BLOCK / 64) {
+        const T s = s_s[i];
+        if (s == T(0)) continue;
+        const T c = s_c[i];
+        const int p = s_p[i], q = s_q[i];
+        for (int k = lane; k < n; k += 64) {
+          const T x = A[k * ld + p], y = A[k * ld + q];
+          A[k * ld + p] = c * x - s * y;
+          A[k * ld + q] = s * x + c * y;
+          const T vx = V[k * ld + p], vy = V[k * ld + q];
+          V[k * ld + p] = c * vx - s * vy;
+          V[k * ld + q] = s * vx + c * vy;
+        }
+      }
+      __syncthreads();
+      // ---- phase 3: rows p, q of A; the annihilated pair is stored as an exact zero ----
+      for (int i = wid; i < half; i += BLOCK / 64) {
+        const T s = s_s[i];
+        if (s == T(0)) continue;
+        const T c = s_c[i];
+        const int p = s_p[i], q = s_q[i];
+        for (int k = lane; k < n; k += 64) {
+          const T x = A[p * ld + k], y = A[q * ld + k];
+          A[p * ld + k] = k == q ? T(0) : c * x - s * y;
+          A[q * ld + k] = k == p ? T(0) : s * x + c * y;
+        }
+      }
+      __syncthreads();
+    }
+    const int rot = s_rot;
+    __syncthreads();
+    if (tid == 0) s_rot = 0;
+    converged = rot == 0;
+    __syncthreads();
+  }
+  if (!converged && tid == 0 && status != nullptr) atomicOr(status, 2);
+
+  // ascending order: rank of each eigenvalue (ties by index), then the permuted write
+  T* Wg = Wout + mat * (long long)n;
+  T* Vg = Vout + mat * (long long)n * n;
+  for (int i = tid; i < n; i += BLOCK) {
+    const T wi = A[i * ld + i];
+    int rank = 0;
+    for (int j = 0; j < n; j++) {
+      const T wj = A[j * ld + j];
+      rank += (wj < wi || (wj == wi && j < i)) ? 1 : 0;
+    }
+    if (wi != wi) rank = i;  // NaN input: every slot still gets written
+    Wg[rank] = wi;
+    s_rank[i] = (short)rank;
+  }
+  __syncthreads();
+  for (int k = wid; k < n; k += BLOCK / 64)
+    for (int i = lane; i < n; i += 64) Vg[(long long)k * n + s_rank[i]] = V[k * ld + i];
+}
+
+template <class T>
+int eigh_typed(long long batch, long long n, int lower, const void* A, void* W, void* V) {
+  if (batch == 0 || n == 0) return 0;
+  if (n > MAX_N) return pthip::set_error("pthip_eigh: n = %lld > %d is not supported yet", n, MAX_N);
+  hipStream_t st = pthip::ctx().stream;
+  const size_t one = (size_t)n * (size_t)(n | 1) * sizeof(T);
+  const size_t budget = 160 * 1024 - 12 * 1024;  // static scratch of the kernel + slack
+  const bool a_lds = one <= budget;
+  const bool v_lds = a_lds && 2 * one <= budget;
+  const size_t dyn = (a_lds ? one : 0) + (v_lds ? one : 0);
+  auto k = eigh_jacobi_kernel<T>;
+  if (dyn > 48 * 1024)
+    PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+  void *sa = nullptr, *sv = nullptr;
+  if (!a_lds) { int r = pthip_alloc((size_t)batch * one, &sa); if (r) return r; }
+  if (!v_lds) { int r = pthip_alloc((size_t)batch * one, &sv); if (r) { if (sa) pthip_free(sa); return r; } }
+  hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(BLOCK), dyn, st, (const T*)A, (T*)W, (T*)V, (int)n, lower,
+                     a_lds ? 1 : 0, v_lds ? 1 : 0, (T*)sa, (T*)sv, (int*)pthip_status_ptr());
+  int r = pthip::post_launch("eigh");
+  if (sa) pthip_free(sa);  // stream-ordered reuse keeps this safe
+  if (sv) pthip_free(sv);
+  return r;
+}
+
+}  // namespace
+
+extern "C" int pthip_eigh(int dtype, int64_t batch, int64_t n, int lower, const void* A, void* W, void* V) {
+  PTHIP_REQUIRE_INIT();
+  if (dtype == PTHIP_F64) return eigh_typed<double>(batch, n, lower, A, W, V);
+  if (dtype == PTHIP_F32) return eigh_typed<float>(batch, n, lower, A, W, V);
+  return pthip::set_error("pthip_eigh: dtype %d not supported (float32/float64 only)", dtype);
+}

@@ -156,4 +156,8 @@ def blockwise(node, inputs, env):
             return [lu._solve(env, cp, ins[0], ins[1])]
         fake = type("_N", (), {"params": cp})
         return (lu.det if p["core_op"] == "Det" else lu.slogdet)(fake, ins, env)
+    if p["core_op"] == "Eigh":
+        from pytensor_amd.dispatch import lu
+
+        return lu.eigh(type("_N", (), {"params": cp}), ins, env)
     raise NotImplementedError(f"Blockwise({p['core_op']})")

@@ -141,3 +141,23 @@ def matrix_inverse(node, inputs, env):
     pb = _permute_rows(env, eye, perm.view((n,), (1,)))
     y = trsm_device(env, lu, pb, True, True, 2)
     return [trsm_device(env, lu, y, False, False, 2)]
+
+
+@handler("Eigh")
+def eigh(node, inputs, env):
+    """``Eigh`` of the standard problem (linalg/decomposition/eigen.py:102; perform 177-195):
+    eigenvalues ascending, eigenvectors as columns, the chosen triangle only (csrc/eigh.hip).
+    Leading dims are a batch (``Blockwise``)."""
+    a = env.to_device(inputs[0])
+    _require_float(a, "Eigh")
+    n = a.shape[-1]
+    if a.shape[-2] != n:
+        raise ValueError("Eigh: expected a square matrix")
+    bshape = a.shape[:-2]
+    ab = _batchify(a, 2, bshape)
+    nb = ab.shape[0]
+    w = DeviceArray.empty((nb, n), a.dtype)
+    v = DeviceArray.empty((nb, n, n), a.dtype)
+    if nb and n:
+        ffi.check(env.lib.pthip_eigh(_dt(a), nb, n, int(node.params["lower"]), ab.ptr, w.ptr, v.ptr))
+    return [w.view((*bshape, n), contiguous_strides((*bshape, n))), v.view((*bshape, n, n), contiguous_strides((*bshape, n, n)))]

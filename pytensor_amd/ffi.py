@@ -98,6 +98,7 @@ SIGNATURES = {
     "pthip_potrf": (_int, [_int, _int, _i64, _i64, _vp, _vp]),
     "pthip_potrf_trsv": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _vp]),
     "pthip_getrf": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _int]),
+    "pthip_eigh": (_int, [_int, _i64, _i64, _int, _vp, _vp, _vp]),
     "pthip_trsm": (_int, [_int, _int, _int, _int, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "pthip_copy_strided": (_int, [_int, _int, C.POINTER(_i64), _vp, C.POINTER(_i64), _vp, C.POINTER(_i64)]),
     "pthip_take_rows": (_int, [_int, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),

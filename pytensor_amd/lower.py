@@ -295,6 +295,14 @@ def _register_extra_ops():
     def _(op, node, ctx):
         return type(op).__name__, {}
 
+    from pytensor.tensor.linalg.decomposition.eigen import Eigh
+
+    @hip_funcify.register(Eigh)
+    def _(op, node, ctx):
+        if node is not None and len(node.inputs) != 1:
+            return None  # the generalised problem A v = w B v is not lowered
+        return "Eigh", {"lower": bool(op.lower)}
+
     # kept whole (HipLinker excludes the reference's inline_symbolic_for_fusion): one kernel
     from pytensor.tensor.special import LogSoftmax, Softmax
 
@@ -364,7 +372,9 @@ def _(op, node, ctx):
 @hip_funcify.register(Blockwise)
 def _(op, node, ctx):
     core = hip_funcify(op.core_op, None, ctx)
-    if core is None or core[0] not in ("Cholesky", "SolveTriangular", "CholeskySolve", "Solve", "Det", "SLogDet"):
+    if core is None or core[0] not in ("Cholesky", "SolveTriangular", "CholeskySolve", "Solve", "Det", "SLogDet", "Eigh"):
+        return None
+    if core[0] == "Eigh" and len(node.inputs) != 1:
         return None
     name, params = core
     return "Blockwise", {"core_op": name, "core_params": params, "signature": op.signature}
@@ -446,38 +456,74 @@ def _var_spec(v):
     raise NotImplementedError(f"unsupported variable type {t!r} for the hip linker")
 
 
+_INLINE = ("__inline__", {})
+
+
+def _register_ofg():
+    from pytensor.compile.builders import OpFromGraph
+
+    @hip_funcify.register(OpFromGraph)
+    def _(op, node, ctx):
+        # OpFromGraph / SymbolicOp without a kernel of its own (AllocDiag, KroneckerProduct, user
+        # OpFromGraphs, ...): the reference runs the inner function from ``perform``
+        # (compile/builders.py); here the inner graph is lowered in place.  Ops registered on
+        # their own class (Softmax, LogSoftmax) take precedence in the dispatch.
+        return _INLINE
+
+
+_register_ofg()
+
+
 def lower_fgraph(fgraph, name="graph", allow_host_fallback=False) -> Graph:
     g = Graph(name=name)
-    vid = {}
 
-    def get(v):
-        if v in vid:
-            return vid[v]
-        dtype, shape, kind = _var_spec(v)
-        const = None
-        if isinstance(v, Constant):
-            if kind in ("tensor", "scalar"):
-                const = np.asarray(v.data)
-                shape = const.shape
-            elif kind == "slice":
-                const = v.data
-        i = g.new_var(dtype, shape, kind=kind, const=const, name=getattr(v, "name", None))
-        vid[v] = i
-        return i
+    def getter(scope):
+        def get(v):
+            if v in scope:
+                return scope[v]
+            dtype, shape, kind = _var_spec(v)
+            const = None
+            if isinstance(v, Constant):
+                if kind in ("tensor", "scalar"):
+                    const = np.asarray(v.data)
+                    shape = const.shape
+                elif kind == "slice":
+                    const = v.data
+            i = g.new_var(dtype, shape, kind=kind, const=const, name=getattr(v, "name", None))
+            scope[v] = i
+            return i
 
+        return get
+
+    def lower_nodes(fg, scope):
+        get = getter(scope)
+        for node in fg.toposort():
+            lowered = hip_funcify(node.op, node, g)
+            if lowered is _INLINE:
+                # a fresh scope per application: the (interned) inner variables of one op are
+                # shared by every node that applies it
+                inner = node.op.fgraph
+                iscope = {iv: get(ov) for iv, ov in zip(inner.inputs, node.inputs)}
+                lower_nodes(inner, iscope)
+                iget = getter(iscope)
+                for ov, iv in zip(node.outputs, inner.outputs):
+                    scope[ov] = iget(iv)
+                continue
+            ins = [get(v) for v in node.inputs]
+            outs = [get(v) for v in node.outputs]
+            if lowered is None:
+                if not allow_host_fallback:
+                    raise NotImplementedError(
+                        f"hip linker: no device lowering for {node.op} (set PTHIP_ALLOW_HOST_PERFORM=1 to run it "
+                        "through Op.perform on the host)"
+                    )
+                g.add_node("HostPerform", {"op": node.op, "node": node, "name": str(node.op)}, ins, outs)
+            else:
+                g.add_node(lowered[0], lowered[1], ins, outs)
+
+    top = {}
+    get = getter(top)
     g.inputs = [get(v) for v in fgraph.inputs]
-    for node in fgraph.toposort():
-        ins = [get(v) for v in node.inputs]
-        outs = [get(v) for v in node.outputs]
-        lowered = hip_funcify(node.op, node, g)
-        if lowered is None:
-            if not allow_host_fallback:
-                raise NotImplementedError(
-                    f"hip linker: no device lowering for {node.op} (set PTHIP_ALLOW_HOST_PERFORM=1 to run it "
-                    "through Op.perform on the host)"
-                )
-            g.add_node("HostPerform", {"op": node.op, "node": node, "name": str(node.op)}, ins, outs)
-        else:
-            g.add_node(lowered[0], lowered[1], ins, outs)
+    lower_nodes(fgraph, top)
     g.outputs = [get(v) for v in fgraph.outputs]
     return g

@@ -72,3 +72,33 @@ def test_potrf_trsv_fused_kernel(hip, dtype, n):
     dS = DeviceArray.from_host(S)
     hip.check(lib.pthip_potrf_trsv(hip.np_dtype_code(dtype), 1, n, dS.ptr, db.ptr, L.ptr, x.ptr))
     assert np.isnan(L.to_host()).all() and np.isnan(x.to_host()).all()
+
+
+@pytest.mark.parametrize("dtype,n,batch", [("float64", 1, 1), ("float64", 2, 3), ("float64", 5, 2), ("float64", 64, 2), ("float64", 96, 1),
+                                           ("float64", 100, 1), ("float64", 141, 2), ("float32", 33, 2), ("float32", 150, 1)])
+def test_eigh_jacobi_kernel(hip, dtype, n, batch):
+    """pthip_eigh against LAPACK (eigenvalues) and the defining properties (A V = V diag(w),
+    V^T V = I, ascending order) — the sizes walk the three storage layouts (A and V in LDS; V in
+    the global scratch; both), odd n exercises the padded round-robin."""
+    from pytensor_amd.device import DeviceArray
+
+    rng = np.random.default_rng(100 + n)
+    M = rng.normal(size=(batch, n, n))
+    S = ((M + M.transpose(0, 2, 1)) / 2).astype(dtype)
+    if n > 3:
+        S[0, 1, 1] = S[0, 2, 2] = 0.75  # a repeated diagonal entry, an exactly zero coupling
+        S[0, 1, 2] = S[0, 2, 1] = 0.0
+    junk = np.triu(rng.normal(size=(n, n)), 1).astype(dtype)  # the upper triangle must not be read
+    dS = DeviceArray.from_host(np.ascontiguousarray(np.tril(S) + junk))
+    w, v = DeviceArray.empty((batch, n), dtype), DeviceArray.empty((batch, n, n), dtype)
+    hip.check(hip.lib().pthip_eigh(hip.np_dtype_code(dtype), batch, n, 1, dS.ptr, w.ptr, v.ptr))
+    w, v = w.to_host(), v.to_host()
+    tol = 1e-12 if dtype == "float64" else 5e-6
+    for b in range(batch):
+        wr = np.linalg.eigvalsh(S[b].astype("float64"))
+        scale = max(1.0, float(np.abs(wr).max()))
+        np.testing.assert_allclose(w[b], wr, rtol=0, atol=tol * scale * n)
+        assert (np.diff(w[b]) >= 0).all()
+        V = v[b].astype("float64")
+        np.testing.assert_allclose(V.T @ V, np.eye(n), atol=tol * n)
+        np.testing.assert_allclose(S[b].astype("float64") @ V, V * w[b][None, :], atol=tol * scale * n)
