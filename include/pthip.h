@@ -197,6 +197,24 @@ int pthip_getrf(int dtype, int64_t batch, int64_t n, const void* A, void* LU, vo
  * (batch, n, n).  Parallel cyclic Jacobi; no convergence raises bit 1 of the device error word
  * (scipy: LinAlgError).  n <= 512. */
 int pthip_eigh(int dtype, int64_t batch, int64_t n, int lower, const void* A, void* W, void* V);
+/* RandomVariable.perform (pytensor/tensor/random/op.py; distributions: random/basic.py) — n draws
+ * of distribution `dist` from the Philox4x64-10 stream (key[2], counter[4]) of a
+ * numpy.random.Generator(Philox): uniform output i is word i%4 of block counter+1+i/4 (the
+ * numbers Generator.random(n) returns), every other distribution gives element i the block
+ * counter+1+i.  The caller advances the counter by ceil(n/4) (uniform) or n blocks.
+ * dist: 0 uniform(low,high) 1 normal(loc,scale) 2 halfnormal 3 lognormal 4 exponential(scale)
+ * 5 laplace 6 logistic 7 cauchy 8 halfcauchy 9 gumbel 10 weibull(shape) 11 pareto(b,scale)
+ * 12 triangular(left,mode,right) 13 gamma(shape,scale) 14 beta(a,b) 15 invgamma(shape,scale)
+ * 16 t(df,loc,scale) 17 bernoulli(p) 18 geometric(p) 19 poisson(lam) 20 integers(low,high).
+ * params[j]: contiguous array broadcast to the output (stride 1) or one element (stride 0),
+ * any numeric dtype.  out: float64 / float32 / int64, contiguous. */
+int pthip_random(int dist, int out_dtype, int64_t n, const uint64_t* key, const uint64_t* counter,
+                 int nparams, const void* const* params, const int* param_dtypes,
+                 const int64_t* param_strides, void* out);
+/* CategoricalRV (random/basic.py:1821): one draw per row of p (rows x k, row_stride elements
+ * apart, 0 = the same vector for every row) by inversion of the running sum; int64 out */
+int pthip_random_categorical(int p_dtype, int64_t rows, int64_t k, const uint64_t* key,
+                             const uint64_t* counter, const void* p, int64_t row_stride, void* out);
 /* solve op(T) X = B, T triangular n×n (strided), B n×nrhs (contiguous row-major), out contiguous */
 int pthip_trsm(int dtype, int lower, int trans, int unit_diag, int64_t batch, int64_t n,
                int64_t nrhs, const void* T, int64_t sTb, int64_t sT0, int64_t sT1, const void* B,

@@ -942,6 +942,17 @@ def _slogdet(p, inputs, node, graph):
     return [np.asarray(s), np.asarray(l)]
 
 
+@op("RandomVariable")
+def _random_variable(p, inputs, node, graph):
+    # RandomVariable.perform (pytensor/tensor/random/op.py) with the hip linker's own stream: the
+    # restatement of csrc/random.hip in philox_ref.py (the reference's draws cannot be matched)
+    import philox_ref
+
+    gen, size, *params = inputs
+    size = None if p["size_is_none"] else [int(v) for v in np.asarray(size).ravel()]
+    return list(philox_ref.draw(p["name"], gen, size, params, p["dtype"]))
+
+
 @op("Eigh")
 def _eigh(p, inputs, node, graph):
     # pytensor/tensor/linalg/decomposition/eigen.py:177-195 (Eigh.perform, standard problem)

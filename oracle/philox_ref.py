@@ -1,0 +1,234 @@
+"""TEST INFRASTRUCTURE ONLY — CPU restatement of the device samplers (pytensor_amd/csrc/random.hip).
+
+The reference draws from ``numpy.random.Generator`` methods (RandomVariable.perform,
+pytensor/tensor/random/op.py; rng_fn of the classes in random/basic.py); those samplers are
+sequential (ziggurat / rejection loops on one stream) and cannot be matched by a parallel device
+sampler, so for this row the oracle restates the *device* algorithm, and is
+pinned two ways: ``philox_block`` against ``numpy.random.Philox().random_raw`` and the uniform
+draws against ``Generator(Philox).random`` bit for bit; every sampler's output against the
+distribution the reference draws from (Kolmogorov–Smirnov / moment tests in tests/test_random.py).
+Plain Python integers and floats; small sizes only.
+"""
+import math
+
+import numpy as np
+
+MASK = (1 << 64) - 1
+M0, M1 = 0xD2E7470EE14C6C93, 0xCA5A826395121157
+W0, W1 = 0x9E3779B97F4A7C15, 0xBB67AE8584CAA73B
+
+
+def philox_block(counter: int, k0: int, k1: int):
+    """Philox4x64-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
+    SC'11) of a 256-bit counter under a 128-bit key, the variant numpy.random.Philox implements."""
+    c = [(counter >> (64 * j)) & MASK for j in range(4)]
+    for r in range(10):
+        if r:
+            k0 = (k0 + W0) & MASK
+            k1 = (k1 + W1) & MASK
+        p0 = M0 * c[0]
+        p1 = M1 * c[2]
+        c = [(p1 >> 64) ^ c[1] ^ k0, p1 & MASK, (p0 >> 64) ^ c[3] ^ k1, p0 & MASK]
+    return c
+
+
+def generator_state(gen):
+    st = gen.bit_generator.state
+    assert st["bit_generator"] == "Philox", "the oracle takes the Philox generators the boundary produces"
+    key = [int(w) for w in st["state"]["key"]]
+    ctr = 0
+    for j, w in enumerate(st["state"]["counter"]):
+        ctr |= int(w) << (64 * j)
+    return key, ctr
+
+
+def make_generator(key, counter: int):
+    words = np.array([(counter >> (64 * j)) & MASK for j in range(4)], dtype=np.uint64)
+    return np.random.Generator(np.random.Philox(key=np.array(key, dtype=np.uint64), counter=words))
+
+
+class Stream:
+    """blocks of element ``i``: counter + 1 + i under key (k0 ^ W0*substream, k1 + attempt)"""
+
+    def __init__(self, key, counter):
+        self.key, self.counter = key, counter
+
+    def block(self, i, sub=0, attempt=0):
+        ctr = (self.counter + 1 + i) & ((1 << 256) - 1)
+        return philox_block(ctr, self.key[0] ^ ((W0 * sub) & MASK), (self.key[1] + attempt) & MASK)
+
+
+def u53(w):
+    return (w >> 11) * (1.0 / 9007199254740992.0)
+
+
+def uopen(w):
+    return ((w >> 12) + 0.5) * (1.0 / 4503599627370496.0)
+
+
+def box_muller(w0, w1):
+    return math.sqrt(-2.0 * math.log(uopen(w0))) * math.cos(6.283185307179586 * uopen(w1))
+
+
+def gamma_mt(s: Stream, i, sub, shape):
+    if not shape > 0.0:
+        return 0.0 if shape == 0.0 else math.nan
+    w = s.block(i, sub, 0)
+    boost = 1.0
+    if shape < 1.0:
+        boost = math.pow(uopen(w[3]), 1.0 / shape)
+        shape += 1.0
+    d = shape - 1.0 / 3.0
+    c = 1.0 / math.sqrt(9.0 * d)
+    for attempt in range(64):
+        if attempt:
+            w = s.block(i, sub, attempt)
+        z = box_muller(w[0], w[1])
+        v = 1.0 + c * z
+        if v <= 0.0:
+            continue
+        v = v * v * v
+        u = uopen(w[2])
+        if math.log(u) < 0.5 * z * z + d - d * v + d * math.log(v):
+            return d * v * boost
+    return d * boost
+
+
+def poisson_draw(s: Stream, i, lam):
+    if not lam >= 0.0:
+        return math.nan
+    if lam == 0.0:
+        return 0.0
+    if lam < 10.0:
+        L = math.exp(-lam)
+        p = 1.0
+        k = 0
+        for attempt in range(64):
+            w = s.block(i, 0, attempt)
+            for j in range(4):
+                p *= uopen(w[j])
+                if p <= L:
+                    return float(k)
+                k += 1
+        return float(k)
+    slam, loglam = math.sqrt(lam), math.log(lam)
+    b = 0.931 + 2.53 * slam
+    al = -0.059 + 0.02483 * b
+    invalpha = 1.1239 + 1.1328 / (b - 3.4)
+    vr = 0.9277 - 3.6224 / (b - 2.0)
+    for attempt in range(256):
+        w = s.block(i, 0, attempt)
+        U = uopen(w[0]) - 0.5
+        V = uopen(w[1])
+        us = 0.5 - abs(U)
+        k = math.floor((2.0 * al / us + b) * U + lam + 0.43)
+        if us >= 0.07 and V <= vr:
+            return float(k)
+        if k < 0 or (us < 0.013 and V > us):
+            continue
+        if math.log(V) + math.log(invalpha) - math.log(al / (us * us) + b) <= -lam + k * loglam - math.lgamma(k + 1.0):
+            return float(k)
+    return float(math.floor(lam))
+
+
+def _element(name, s: Stream, i, p):
+    """one draw of a per-element distribution; ``p`` are this element's (float) parameters"""
+    if name in ("normal", "halfnormal", "lognormal"):
+        w = s.block(i)
+        z = box_muller(w[0], w[1])
+        if name == "halfnormal":
+            z = abs(z)
+        r = p[0] + p[1] * z
+        return math.exp(r) if name == "lognormal" else r
+    if name == "gamma":
+        return gamma_mt(s, i, 0, p[0]) * p[1]
+    if name == "beta":
+        x, y = gamma_mt(s, i, 0, p[0]), gamma_mt(s, i, 1, p[1])
+        return x / (x + y)
+    if name == "invgamma":
+        return p[1] / gamma_mt(s, i, 0, p[0])
+    if name == "t":
+        g = gamma_mt(s, i, 0, 0.5 * p[0])
+        w = s.block(i, 1, 0)
+        return p[1] + p[2] * (math.sqrt(0.5 * p[0]) * box_muller(w[0], w[1]) / math.sqrt(g))
+    if name == "poisson":
+        return poisson_draw(s, i, p[0])
+    w = s.block(i)
+    u = uopen(w[0])
+    if name == "exponential":
+        return -p[0] * math.log(u)
+    if name == "laplace":
+        e = -math.log(u)
+        return p[0] + p[1] * (e if (w[1] >> 63) else -e)
+    if name == "logistic":
+        return p[0] + p[1] * math.log(u / (1.0 - u))
+    if name == "cauchy":
+        return p[0] + p[1] * math.tan(3.141592653589793 * (u - 0.5))
+    if name == "halfcauchy":
+        return p[0] + p[1] * math.tan(1.5707963267948966 * u)
+    if name == "gumbel":
+        return p[0] - p[1] * math.log(-math.log(u))
+    if name == "weibull":
+        return math.pow(-math.log(u), 1.0 / p[0])
+    if name == "pareto":
+        return p[1] * math.exp(-math.log(u) / p[0])
+    if name == "triangular":
+        l, m, h = p
+        fc = (m - l) / (h - l)
+        return l + math.sqrt(u * (h - l) * (m - l)) if u < fc else h - math.sqrt((1.0 - u) * (h - l) * (h - m))
+    if name == "bernoulli":
+        return 1.0 if u < p[0] else 0.0
+    if name == "geometric":
+        r = 1.0 if p[0] >= 1.0 else math.ceil(math.log(u) / math.log1p(-p[0]))
+        return max(r, 1.0)
+    raise NotImplementedError(name)
+
+
+def draw(name, gen, size, params, dtype):
+    """(advanced generator, draws) — what the ``RandomVariable`` node of the hip linker returns"""
+    key, ctr = generator_state(gen)
+    s = Stream(key, ctr)
+    dtype = np.dtype(dtype)
+    if name == "categorical":
+        (pr,) = params
+        pr = np.asarray(pr)
+        batch = pr.shape[:-1]
+        shape = tuple(batch) if size is None else tuple(size)
+        prb = np.broadcast_to(pr, (*shape, pr.shape[-1])).reshape(-1, pr.shape[-1])
+        out = np.empty(len(prb), dtype=np.int64)
+        for i, row in enumerate(prb):
+            u = uopen(s.block(i)[0])
+            acc, pick = 0.0, len(row) - 1
+            for j, pj in enumerate(row):
+                acc += float(pj)
+                if u < acc:
+                    pick = j
+                    break
+            out[i] = pick
+        return make_generator(key, ctr + len(prb)), out.reshape(shape).astype(dtype)
+    params = [np.asarray(p) for p in params]
+    bshape = np.broadcast_shapes(*[p.shape for p in params]) if params else ()
+    shape = tuple(bshape) if size is None else tuple(int(v) for v in size)
+    n = int(np.prod(shape)) if shape else 1
+    flat = [np.broadcast_to(p, shape).reshape(-1) for p in params]
+    if name == "uniform":
+        u = np.empty(n)
+        for b in range((n + 3) // 4):
+            w = s.block(b)
+            for j in range(4):
+                if 4 * b + j < n:
+                    u[4 * b + j] = u53(w[j])
+        lo, hi = flat[0].astype(np.float64), flat[1].astype(np.float64)
+        out = lo + (hi - lo) * u
+        return make_generator(key, ctr + (n + 3) // 4), out.reshape(shape).astype(dtype)
+    if name == "integers":
+        out = np.empty(n, dtype=np.int64)
+        for i in range(n):
+            lo, hi = int(flat[0][i]), int(flat[1][i])
+            rng_ = (hi - lo) & MASK
+            out[i] = lo + ((s.block(i)[0] * rng_) >> 64)
+        return make_generator(key, ctr + n), out.reshape(shape).astype(dtype)
+    out = np.empty(n, dtype=np.float64)
+    for i in range(n):
+        out[i] = _element(name, s, i, [float(f[i]) for f in flat])
+    return make_generator(key, ctr + n), out.reshape(shape).astype(dtype)

@@ -1,0 +1,123 @@
+"""``RandomVariable`` nodes: draws from the device Philox stream (csrc/random.hip).
+
+Reference: RandomVariable.perform (pytensor/tensor/random/op.py: ``rng_fn(rng, *params, size)``,
+outputs ``(advanced rng, draws)``), size / parameter broadcasting as ``_infer_shape`` does it
+(op.py), the distribution classes of random/basic.py.  The streams are this backend's own (see
+``pytensor_amd/rng.py`` and SURVEY §8f row 4): what is reproduced is the distribution, the
+output shape / dtype, and the threading of the generator through the graph.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from pytensor_amd import ffi
+from pytensor_amd.device import DeviceArray, contiguous_strides, copy_into
+from pytensor_amd.dispatch import handler
+from pytensor_amd.executor import HostValue
+from pytensor_amd.rng import RngState
+
+# distribution name (RandomVariable.name) -> (code of csrc/random.hip, number of parameters)
+DISTRIBUTIONS = {
+    "uniform": (0, 2), "normal": (1, 2), "halfnormal": (2, 2), "lognormal": (3, 2), "exponential": (4, 1),
+    "laplace": (5, 2), "logistic": (6, 2), "cauchy": (7, 2), "halfcauchy": (8, 2), "gumbel": (9, 2),
+    "weibull": (10, 1), "pareto": (11, 2), "triangular": (12, 3), "gamma": (13, 2), "beta": (14, 2),
+    "invgamma": (15, 2), "t": (16, 3), "bernoulli": (17, 1), "geometric": (18, 1), "poisson": (19, 1),
+    "integers": (20, 2),
+}
+
+
+def _size_tuple(env, size, size_is_none):
+    if size_is_none:
+        return None
+    return tuple(int(s) for s in np.asarray(env.to_host(size)).ravel())
+
+
+def _param_operand(x: DeviceArray, shape):
+    """(array kept alive, pointer, dtype code, stride): one element broadcast (stride 0) or a
+    contiguous array of the output shape (stride 1)"""
+    if x.size == 1:
+        return x, x.ptr, ffi.np_dtype_code(x.dtype), 0
+    if tuple(x.shape) == tuple(shape) and x.is_contiguous():
+        return x, x.ptr, ffi.np_dtype_code(x.dtype), 1
+    full = DeviceArray.empty(shape, x.dtype)
+    copy_into(full, x)
+    return full, full.ptr, ffi.np_dtype_code(full.dtype), 1
+
+
+def _words(a):
+    arr = np.ascontiguousarray(a, dtype=np.uint64)
+    return arr, arr.ctypes.data_as(C.c_void_p)
+
+
+@handler("RandomVariable")
+def random_variable(node, inputs, env):
+    p = node.params
+    rng, size, *params = inputs
+    if not isinstance(rng, RngState):
+        rng = RngState.from_generator(rng.a.item() if isinstance(rng, HostValue) else rng)
+    name = p["name"]
+    out_dtype = np.dtype(p["dtype"])
+    size = _size_tuple(env, size, p["size_is_none"])
+    devs = [env.to_device(x) for x in params]
+    key_arr, key_ptr = _words(rng.key_words())
+    ctr_arr, ctr_ptr = _words(rng.counter_words())
+
+    if name == "categorical":
+        (pr,) = devs
+        k = pr.shape[-1]
+        batch = tuple(pr.shape[:-1])
+        shape = batch if size is None else size
+        rows = int(np.prod(shape)) if shape else 1
+        out = DeviceArray.empty(shape, "int64")
+        if rows:
+            if pr.ndim == 1 or int(np.prod(batch)) == 1:
+                prc, stride = pr.contiguous(), 0
+            else:
+                if tuple(batch) != tuple(shape):
+                    full = DeviceArray.empty((*shape, k), pr.dtype)
+                    copy_into(full, pr)
+                    pr = full
+                prc, stride = pr.contiguous(), k
+            ffi.check(env.lib.pthip_random_categorical(ffi.np_dtype_code(prc.dtype), rows, k, key_ptr, ctr_ptr, prc.ptr, stride, out.ptr))
+        out = out if out_dtype == np.dtype("int64") else _cast(env, out, out_dtype)
+        return [rng.advanced(rows), out]
+
+    if name not in DISTRIBUTIONS:
+        raise NotImplementedError(f"hip linker: no device sampler for the {name!r} RandomVariable")
+    code, nparams = DISTRIBUTIONS[name]
+    if len(devs) != nparams:
+        raise TypeError(f"{name}: expected {nparams} parameters, got {len(devs)}")
+    bshape = np.broadcast_shapes(*[tuple(d.shape) for d in devs]) if devs else ()
+    if size is None:
+        shape = tuple(bshape)
+    else:
+        shape = size
+        if np.broadcast_shapes(bshape, shape) != tuple(shape):
+            raise ValueError(f"{name}: size {shape} does not match the parameter batch shape {tuple(bshape)}")
+    n = int(np.prod(shape)) if shape else 1
+    kernel_dtype = out_dtype if out_dtype.name in ("float64", "float32", "int64") else np.dtype("int64" if out_dtype.kind in "iub" else "float64")
+    out = DeviceArray.empty(shape, kernel_dtype)
+    if n:
+        ops = [_param_operand(d, shape) for d in devs]
+        ptrs = (C.c_void_p * 3)(*[o[1] for o in ops], *([None] * (3 - len(ops))))
+        dts = (C.c_int * 3)(*[o[2] for o in ops], *([0] * (3 - len(ops))))
+        sts = (C.c_int64 * 3)(*[o[3] for o in ops], *([0] * (3 - len(ops))))
+        ffi.check(env.lib.pthip_random(code, ffi.np_dtype_code(kernel_dtype), n, key_ptr, ctr_ptr, len(ops),
+                                       C.cast(ptrs, C.c_void_p), C.cast(dts, C.c_void_p), C.cast(sts, C.c_void_p), out.ptr))
+        env.keepalive.extend(o[0] for o in ops)
+    if kernel_dtype != out_dtype:
+        out = _cast(env, out, out_dtype)
+    blocks = (n + 3) // 4 if name == "uniform" else n
+    return [rng.advanced(blocks), out]
+
+
+def _cast(env, x: DeviceArray, dtype) -> DeviceArray:
+    from pytensor_amd.dispatch.elemwise import launch_elemwise
+
+    body = {"in_dtypes": [str(x.dtype)], "out_dtypes": [str(dtype)],
+            "body": [{"op": "Cast", "in": [["i", 0]], "dtype": str(dtype)}], "outs": [["t", 0]]}
+    outs, _, _ = launch_elemwise(body, [x], x.shape, [str(dtype)], None, env)
+    return outs[0].view(x.shape, contiguous_strides(x.shape))

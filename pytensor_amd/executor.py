@@ -173,6 +173,11 @@ class HipExecutable:
         # per-node segment ids for multi-stream plans (fusion.segment_graph), or None
         self.graph, self.segments = run_pipeline(graph, fuse)
         self.resident = set(resident)
+        # a captured launch sequence would replay the same Philox counters: graphs that draw
+        # random numbers run eagerly (sampling graphs are not the logp+grad hot path)
+        self.has_rng = any(v.kind == "rng" for v in self.graph.vars.values())
+        if self.has_rng:
+            self.auto_freeze = False
         self._handlers = dispatch.HANDLERS
         self._resident_cache = {}  # input position -> (key, DeviceArray)
         self._const_cache = {}
@@ -250,6 +255,10 @@ class HipExecutable:
         var = self.graph.vars[vid]
         if isinstance(value, (DeviceArray, HostValue)):
             return value
+        if var.kind == "rng":  # numpy Generator (or its state dict) -> Philox key + counter
+            from pytensor_amd.rng import RngState
+
+            return RngState.from_generator(value)
         if var.kind != "tensor":
             return HostValue(np.asarray(value))
         a = np.asarray(value)
@@ -377,7 +386,9 @@ class HipExecutable:
         host = []
         for o, vid in zip(outs, self.graph.outputs):
             var = self.graph.vars[vid]
-            if isinstance(o, HostValue):
+            if var.kind == "rng":  # the advanced generator, as a numpy Generator(Philox) again
+                host.append(o.to_generator())
+            elif isinstance(o, HostValue):
                 host.append(np.array(o.a, dtype=var.dtype if var.kind == "tensor" else o.a.dtype, copy=True))
             else:
                 host.append(o.to_host(sync=False))
@@ -434,6 +445,9 @@ class HipExecutable:
         tools/bench_small.py: N=3000: 142 vs 162 µs per call; N=1e6: 300 vs 249 µs)."""
         from pytensor_amd.plan import FrozenPlan
 
+        if self.has_rng:
+            raise NotImplementedError("hip linker: a graph that draws random numbers cannot be frozen "
+                                      "(a replay would repeat the captured Philox counters)")
         self._ensure_device()
         if multi_stream != "auto":
             return FrozenPlan(self, inputs, fetch_outputs=fetch_outputs, multi_stream=bool(multi_stream))

@@ -49,6 +49,8 @@ from pytensor.tensor.subtensor import (
     IncSubtensor,
     Subtensor,
 )
+from pytensor.tensor.random.op import RandomVariable
+from pytensor.tensor.random.type import RandomType
 from pytensor.tensor.type import TensorType
 from pytensor.tensor.type_other import NoneTypeT, SliceType
 
@@ -453,10 +455,28 @@ def _var_spec(v):
         return "object", (), "slice"
     if isinstance(t, NoneTypeT):
         return "object", (), "none"
+    if isinstance(t, RandomType):
+        return "object", (), "rng"
     raise NotImplementedError(f"unsupported variable type {t!r} for the hip linker")
 
 
 _INLINE = ("__inline__", {})
+
+
+@hip_funcify.register(RandomVariable)
+def _(op, node, ctx):
+    # inputs (rng, size, *dist_params) -> outputs (advanced rng, draws), random/op.py make_node;
+    # samplers and their stream: csrc/random.hip, pytensor_amd/rng.py
+    from pytensor_amd.dispatch.random import DISTRIBUTIONS
+
+    name = str(op.name)
+    if name not in DISTRIBUTIONS and name != "categorical":
+        return None
+    return "RandomVariable", {
+        "name": name,
+        "dtype": str(node.outputs[1].type.dtype),
+        "size_is_none": isinstance(node.inputs[1].type, NoneTypeT),
+    }
 
 
 def _register_ofg():
