@@ -345,3 +345,19 @@ def eigh_f32():
     Fv = rng.normal(size=(17, 17)).astype("float32")
     Fv = (Fv + Fv.T) / 2
     return [F], [wf, (vf * wf[None, :]) @ vf.T, pt.abs(vf)], {"F": Fv}
+
+
+@case("random_uniform_philox")
+def random_uniform_philox():
+    # RandomVariable (tensor/random/op.py) with a shared Generator(Philox): uniform draws in whole
+    # 4-word blocks are the one case where the reference's numbers can be reproduced bit for bit
+    # (Generator.uniform = low + (high - low) * random()); every other sampler of NumPy consumes a
+    # data-dependent number of raw words and is pinned distributionally (tests/test_random.py).
+    rng = pytensor.shared(np.random.Generator(np.random.Philox(key=[20260924, 7], counter=[5, 0, 0, 0])), name="rng")
+    lo = pt.dvector("lo")
+    s = pt.dscalar("s")
+    r1, u1 = pt.random.uniform(-1.0, 2.0, size=(8, 4), rng=rng).owner.outputs
+    r2, u2 = pt.random.uniform(lo, lo + s, size=(3, 4), rng=r1).owner.outputs
+    r3, u3 = pt.random.uniform(0.0, 1.0, size=(16,), rng=r2).owner.outputs
+    outs = [u1, u2, pt.exp(u1).sum(axis=0) + u2.mean(axis=0), u3.reshape((4, 4)) @ u1.T]
+    return [lo, s], outs, {"lo": np.array([-3.0, 0.0, 10.0, 0.5]), "s": np.asarray(2.5)}

@@ -616,6 +616,8 @@ def generate(name):
         names.append(nm)
         if nm in vals:
             in_vals.append(np.asarray(vals[nm], dtype=v.type.dtype))
+        elif isinstance(cont.storage[0], np.random.Generator):
+            in_vals.append(cont.storage[0])  # a shared RNG: stored as its Philox key + counter words
         else:
             in_vals.append(np.asarray(cont.storage[0]))
     explicit = [np.asarray(vals[v.name], dtype=v.type.dtype) for v in ins]
@@ -646,7 +648,15 @@ def generate(name):
         d["py_rtol"] = PY_RTOL[name]
     with open(os.path.join(GOLDEN, f"{name}.json"), "w") as fh:
         json.dump(d, fh, separators=(",", ":"))
-    arrays = {f"in{k}": v for k, v in enumerate(in_vals)}
+    import philox_ref
+
+    def storable(v):
+        if isinstance(v, np.random.Generator):
+            key, ctr = philox_ref.generator_state(v)
+            return np.array([*key, *[(ctr >> (64 * j)) & philox_ref.MASK for j in range(4)]], dtype=np.uint64)
+        return v
+
+    arrays = {f"in{k}": storable(v) for k, v in enumerate(in_vals)}
     arrays.update({f"cvm{k}": v for k, v in enumerate(out_c)})
     arrays.update({f"py{k}": v for k, v in enumerate(out_py)})
     np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **arrays)

@@ -17,6 +17,10 @@ def load_case(name):
     g = Graph.from_dict(d)
     z = np.load(os.path.join(GOLDEN, f"{name}.npz"))
     ins = [z[f"in{k}"] for k in range(len(g.inputs))]
+    for k, vid in enumerate(g.inputs):
+        if g.vars[vid].kind == "rng":  # stored as Philox key (2 words) + counter (4 words)
+            w = ins[k]
+            ins[k] = np.random.Generator(np.random.Philox(key=w[:2], counter=w[2:]))
     cvm = [z[f"cvm{k}"] for k in range(len(g.outputs))]
     py = [z[f"py{k}"] for k in range(len(g.outputs))]
     return g, ins, cvm, py, d
