@@ -197,6 +197,12 @@ int pthip_getrf(int dtype, int64_t batch, int64_t n, const void* A, void* LU, vo
  * (batch, n, n).  Parallel cyclic Jacobi; no convergence raises bit 1 of the device error word
  * (scipy: LinAlgError).  n <= 512. */
 int pthip_eigh(int dtype, int64_t batch, int64_t n, int lower, const void* A, void* W, void* V);
+/* Ordered stream compaction for boolean-mask indexing (AdvancedSubtensor / AdvancedIncSubtensor
+ * with a bool index, pytensor/tensor/subtensor.py:1932, 2275: x[mask] == x[mask.nonzero()]) and
+ * the Nonzero op (tensor/basic.py): ascending C-order flat indices of the non-zero bytes of the
+ * contiguous `mask` (n bytes) into idx_out (room for n int64), their number into count_out
+ * (device int64) — the caller reads it back, the output length is data dependent. */
+int pthip_nonzero(int64_t n, const void* mask, void* idx_out, void* count_out);
 /* RandomVariable.perform (pytensor/tensor/random/op.py; distributions: random/basic.py) — n draws
  * of distribution `dist` from the Philox4x64-10 stream (key[2], counter[4]) of a
  * numpy.random.Generator(Philox): uniform output i is word i%4 of block counter+1+i/4 (the

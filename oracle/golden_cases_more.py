@@ -361,3 +361,25 @@ def random_uniform_philox():
     r3, u3 = pt.random.uniform(0.0, 1.0, size=(16,), rng=r2).owner.outputs
     outs = [u1, u2, pt.exp(u1).sum(axis=0) + u2.mean(axis=0), u3.reshape((4, 4)) @ u1.T]
     return [lo, s], outs, {"lo": np.array([-3.0, 0.0, 10.0, 0.5]), "s": np.asarray(2.5)}
+
+
+@case("bool_mask_split")
+def bool_mask_split():
+    # boolean-mask indexing (subtensor.py:1932, 2275: x[mask] == x[mask.nonzero()]), Nonzero
+    # (basic.py), Split (basic.py:2203 — the gradient of Join / stack); index tier: bit-exact
+    rng = np.random.default_rng(52)
+    x = pt.dvector("x")
+    y = pt.dvector("y")
+    M = pt.dmatrix("M")
+    iM = pt.lmatrix("iM")
+    cat = pt.concatenate([x, y * 2.0, x[:3]])
+    stk = pt.stack([x[:5], y[:5], x[2:7]])
+    outs = [
+        x[x > 0], M[M[:, 0] > 0], M[M > 0.5], M[:, M[0] < 0], (x[x > 0] ** 2).sum(),
+        pt.set_subtensor(x[x > 0], 1.0), pt.inc_subtensor(M[M[:, 1] > 0], 10.0), pt.set_subtensor(M[M < 0], 0.0),
+        pt.where(x > 0)[0], pt.nonzero(iM)[0], pt.nonzero(iM)[1], x[x > 100.0],
+        *pytensor.grad((cat ** 2).sum() + (stk[0] * stk[1] * stk[2]).sum(), [x, y]),
+        *pt.split(M, [2, 0, 5], n_splits=3, axis=1),
+    ]
+    vals = {"x": rng.normal(size=4500), "y": rng.normal(size=9), "M": rng.normal(size=(6, 7)), "iM": rng.integers(-1, 2, size=(5, 4))}
+    return [x, y, M, iM], outs, vals

@@ -942,6 +942,26 @@ def _slogdet(p, inputs, node, graph):
     return [np.asarray(s), np.asarray(l)]
 
 
+@op("Nonzero")
+def _nonzero(p, inputs, node, graph):
+    # pytensor/tensor/basic.py Nonzero.perform: np.nonzero, int64 vectors
+    return [np.asarray(r, dtype=np.int64) for r in np.nonzero(inputs[0])]
+
+
+@op("Split")
+def _split(p, inputs, node, graph):
+    # pytensor/tensor/basic.py:2268-2283 (Split.perform)
+    x, splits = inputs
+    splits = np.asarray(splits)
+    if len(splits) != p["len_splits"]:
+        raise ValueError("Length of splits is not equal to n_splits")
+    if splits.sum() != x.shape[p["axis"]]:
+        raise ValueError(f"Split sizes sum to {splits.sum()}; expected {x.shape[p['axis']]}")
+    if (splits < 0).any():
+        raise ValueError("Split sizes cannot be negative")
+    return list(np.split(x, np.cumsum(splits[:-1]), axis=p["axis"]))
+
+
 @op("RandomVariable")
 def _random_variable(p, inputs, node, graph):
     # RandomVariable.perform (pytensor/tensor/random/op.py) with the hip linker's own stream: the

@@ -166,6 +166,29 @@ def join(node, inputs, env):
     return [out]
 
 
+@handler("Split")
+def split(node, inputs, env):
+    # Split.perform (pytensor/tensor/basic.py:2268-2283): np.split at the running sums of
+    # `splits` — views of the input (view_map 2237), no data moves
+    x, splits = inputs
+    axis = node.params["axis"]
+    sizes = [int(v) for v in np.asarray(env.to_host(splits)).ravel()]
+    if len(sizes) != node.params["len_splits"]:
+        raise ValueError("Length of splits is not equal to n_splits")
+    x = env.to_device(x)
+    if sum(sizes) != x.shape[axis]:
+        raise ValueError(f"Split sizes sum to {sum(sizes)}; expected {x.shape[axis]}")
+    if any(v < 0 for v in sizes):
+        raise ValueError("Split sizes cannot be negative")
+    outs, off = [], 0
+    for v in sizes:
+        shape = list(x.shape)
+        shape[axis] = v
+        outs.append(x.view(shape, x.strides, off * x.strides[axis] if v else 0))
+        off += v
+    return outs
+
+
 @handler("CheckAndRaise")
 def check_and_raise(node, inputs, env):
     x, *conds = inputs

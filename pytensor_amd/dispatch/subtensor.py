@@ -192,10 +192,97 @@ def _combine_indices(env, ivs, dims):
     return outs[0]
 
 
+def nonzero_flat(env, mask) -> DeviceArray:
+    """Ascending flat (C-order) int64 indices of the non-zero elements of ``mask``
+    (csrc/nonzero.hip).  The length is data dependent: one host read of the count."""
+    m = env.to_device(mask)
+    if m.dtype.kind != "b":
+        from pytensor_amd.dispatch.elemwise import launch_elemwise
+
+        dt = str(m.dtype)
+        body = {"in_dtypes": [dt], "out_dtypes": ["bool"],
+                "body": [{"op": "NEQ", "in": [["i", 0], ["c", 0 if m.dtype.kind in "iu" else (0.0).hex(), dt]], "dtype": "bool"}],
+                "outs": [["t", 0]]}
+        outs, _, _ = launch_elemwise(body, [m], m.shape, ["bool"], None, env)
+        m = outs[0]
+    mc = m.contiguous()
+    n = mc.size
+    idx = DeviceArray.empty((max(n, 1),), "int64")
+    cnt = DeviceArray.empty((1,), "int64")
+    ffi.check(env.lib.pthip_nonzero(n, mc.ptr, idx.ptr, cnt.ptr))
+    k = int(np.asarray(env.to_host(cnt)).ravel()[0])
+    return idx.view((k,), (1,))
+
+
+def unravel_flat(env, flat: DeviceArray, shape):
+    """the per-axis components of C-order flat indices (np.unravel_index), on the device"""
+    if len(shape) == 1:
+        return [flat]
+    from pytensor_amd.dispatch.elemwise import launch_elemwise
+
+    comps, stride = [None] * len(shape), 1
+    for d in range(len(shape) - 1, -1, -1):
+        body = {"in_dtypes": ["int64"], "out_dtypes": ["int64"],
+                "body": [{"op": "IntDiv", "in": [["i", 0], ["c", int(stride), "int64"]], "dtype": "int64"},
+                         {"op": "Mod", "in": [["t", 0], ["c", max(int(shape[d]), 1), "int64"]], "dtype": "int64"}],
+                "outs": [["t", 1]]}
+        if flat.size:
+            outs, _, _ = launch_elemwise(body, [flat], flat.shape, ["int64"], None, env)
+            comps[d] = outs[0]
+        else:
+            comps[d] = flat
+        stride *= int(shape[d])
+    return comps
+
+
+def _is_bool_index(v):
+    return getattr(v, "dtype", None) is not None and np.dtype(v.dtype).kind == "b"
+
+
+def _expand_bool_masks(env, idx_list, idx, x_shape):
+    """NumPy semantics: a boolean index over m axes stands for the m integer vectors of its
+    ``nonzero()``.  Returns an (idx_list, index values) pair without boolean entries."""
+    if not any((not isinstance(e, slice)) and _is_bool_index(idx[e]) for e in idx_list):
+        return idx_list, idx
+    new_list, new_idx, d = [], [], 0
+    for e in idx_list:
+        if isinstance(e, slice):
+            new_list.append(e)
+            d += 1
+            continue
+        v = idx[e]
+        if _is_bool_index(v):
+            mv = env.to_device(v)
+            m = mv.ndim
+            if m == 0:
+                raise NotImplementedError("hip linker: 0-d boolean index")
+            if tuple(mv.shape) != tuple(x_shape[d : d + m]):
+                raise IndexError(f"boolean index did not match indexed array along axis {d}; size of axis is "
+                                 f"{tuple(x_shape[d:d + m])} but size of corresponding boolean axis is {tuple(mv.shape)}")
+            for c in unravel_flat(env, nonzero_flat(env, mv), mv.shape):
+                new_list.append(len(new_idx))
+                new_idx.append(c)
+            d += m
+        else:
+            new_list.append(len(new_idx))
+            new_idx.append(v)
+            d += 1
+    return new_list, new_idx
+
+
+@handler("Nonzero")
+def nonzero(node, inputs, env):
+    # Nonzero.perform (pytensor/tensor/basic.py): np.nonzero -> one int64 vector per axis
+    x = env.to_device(inputs[0])
+    if x.ndim == 0:
+        raise ValueError("Nonzero only supports non-scalar arrays.")
+    return unravel_flat(env, nonzero_flat(env, x), x.shape)
+
+
 def _index_on_device(env, iv):
     iv = env.to_device(iv)
     if iv.dtype.kind == "b":
-        raise NotImplementedError("hip linker: boolean mask indexing")
+        raise NotImplementedError("hip linker: boolean index outside AdvancedSubtensor/AdvancedIncSubtensor")
     if str(iv.dtype) != "int64":
         from pytensor_amd.dispatch.elemwise import _cast
 
@@ -214,7 +301,8 @@ def _axis_to_front(x: DeviceArray, axis: int) -> DeviceArray:
 def advanced_subtensor(node, inputs, env):
     x, *idx = inputs
     x = env.to_device(x)
-    multi = _leading_multi_index(node.params["idx_list"], idx)
+    idx_list, idx = _expand_bool_masks(env, node.params["idx_list"], idx, x.shape)
+    multi = _leading_multi_index(idx_list, idx)
     if multi is not None:
         # pointwise multi-index: the k leading axes are flattened and gathered with one
         # combined row index (subtensor.py:1932 AdvancedSubtensor.perform = x[i0, i1, ...])
@@ -225,7 +313,7 @@ def advanced_subtensor(node, inputs, env):
         xf = xc.view((rows, *x.shape[k:]), contiguous_strides((rows, *x.shape[k:])))
         axis = 0
     else:
-        axis, iv = _single_axis_index(node.params["idx_list"], idx, x.ndim)
+        axis, iv = _single_axis_index(idx_list, idx, x.ndim)
         iv = _index_on_device(env, iv)
         xf = _axis_to_front(x, axis)
     inner_shape = xf.shape[1:]
@@ -256,7 +344,8 @@ def advanced_inc_subtensor(node, inputs, env):
     p = node.params
     x, y, *idx = inputs
     x, y = env.to_device(x), env.to_device(y)
-    multi = _leading_multi_index(p["idx_list"], idx)
+    idx_list, idx = _expand_bool_masks(env, p["idx_list"], idx, x.shape)
+    multi = _leading_multi_index(idx_list, idx)
     if multi is not None:
         k = len(multi)
         iv = _combine_indices(env, multi, x.shape[:k])
@@ -266,7 +355,7 @@ def advanced_inc_subtensor(node, inputs, env):
         flat = own.view((rows, *x.shape[k:]), contiguous_strides((rows, *x.shape[k:])))
         res = _scatter_rows(env, p, flat, y, iv)
         return [res.view(full_shape, contiguous_strides(full_shape))]
-    axis, iv = _single_axis_index(p["idx_list"], idx, x.ndim)
+    axis, iv = _single_axis_index(idx_list, idx, x.ndim)
     if axis != 0:
         raise NotImplementedError("hip linker: AdvancedIncSubtensor on axis != 0")
     iv = _index_on_device(env, iv)

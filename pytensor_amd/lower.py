@@ -33,6 +33,7 @@ from pytensor.tensor.basic import (
     Join,
     MakeVector,
     ScalarFromTensor,
+    Split,
     TensorFromScalar,
 )
 from pytensor.tensor.blas import BatchedDot, Dot22, Dot22Scalar, Gemm, Gemv, Ger
@@ -214,7 +215,20 @@ def _(op, node, ctx):
         [i.type.dtype for i in node.inputs],
         [o.type.dtype for o in node.outputs],
     )
+    _require_device_body(body, op)
     return "Elemwise", {"scalar": body}
+
+
+def _require_device_body(body, op):
+    """fail at compile time, not at the first call: every scalar op and dtype of the fused body
+    must have a device expression (codegen.SCALAR_EXPR)"""
+    from pytensor_amd import codegen
+
+    if not codegen.supported(body):
+        missing = sorted({o for o in codegen.body_ops(body) if o not in codegen.SCALAR_EXPR})
+        dts = sorted({d for d in body["in_dtypes"] + body["out_dtypes"] if d not in codegen.CTYPE})
+        what = ", ".join([*(f"scalar op {m}" for m in missing), *(f"dtype {d}" for d in dts)]) or "an inner loop dtype"
+        raise NotImplementedError(f"hip linker: no device code for {what} (in {op})")
 
 
 @hip_funcify.register(ScalarOp)
@@ -222,6 +236,7 @@ def _(op, node, ctx):
     # a ScalarOp applied directly to ScalarType variables (between ScalarFromTensor and
     # TensorFromScalar): the same scalar graph on 0-d values
     body = lower_scalar_op(op, [i.type.dtype for i in node.inputs], [o.type.dtype for o in node.outputs])
+    _require_device_body(body, op)
     return "Elemwise", {"scalar": body}
 
 
@@ -253,6 +268,22 @@ for _cls in (Dot22, Dot22Scalar, BatchedDot, Dot, Shape, Reshape, ScalarFromTens
     @hip_funcify.register(_cls)
     def _(op, node, ctx, _name=_cls.__name__):
         return _name, {}
+
+
+def _register_nonzero():
+    from pytensor.tensor.basic import Nonzero
+
+    @hip_funcify.register(Nonzero)
+    def _(op, node, ctx):
+        return "Nonzero", {}
+
+
+_register_nonzero()
+
+
+@hip_funcify.register(Split)
+def _(op, node, ctx):
+    return "Split", {"len_splits": int(op.len_splits), "axis": int(op.axis)}
 
 
 @hip_funcify.register(TypeCastingOp)
