@@ -239,7 +239,13 @@ void* pthip_stream(void) { return (void*)g_ctx.stream; }
 
 int pthip_alloc(size_t bytes, void** dptr) {
   PTHIP_REQUIRE_INIT();
-  return pool_alloc(bytes, dptr);
+  int r = pool_alloc(bytes, dptr);
+  // debugging aid: PTHIP_POISON=1 fills every block handed out with 0xFF bytes (NaN as a
+  // float, -1 as an integer) on the current stream, so that a read of never-written memory
+  // shows up in the results instead of depending on what the pool happened to hold
+  static const bool poison = getenv("PTHIP_POISON") != nullptr;
+  if (r == 0 && poison && bytes) PTHIP_CHECK(hipMemsetAsync(*dptr, 0xFF, bytes, g_ctx.stream));
+  return r;
 }
 
 int pthip_free(void* dptr) { return pool_free(dptr); }
