@@ -114,10 +114,213 @@ __global__ __launch_bounds__(BLOCK) void getrf_kernel(T* __restrict__ LUout,
   }
 }
 
+// ---- n <= 128: the matrix lives in registers, pivoting is implicit --------------------------
+// 256 threads as a 16 x 16 grid, thread (ty, tx) owns the NB x NB elements (ty + 16 r, tx + 16 c).
+// Rows are never moved: a pivoted row just stops taking part (a bit of `active`); its position in
+// P*A is tracked in LDS (s_pos / s_cur, updated exactly like LAPACK's explicit swaps would move
+// it, so that ties in the pivot search resolve to the row LAPACK would pick: the first in the
+// *current* order) and applied once, when the factors are written out.  Per column: every wave
+// finds the pivot itself from the column copy in LDS (DPP arg-max, no cross-wave step), the
+// owners of the pivot row publish it, one barrier, a rank-1 update out of registers (the
+// multipliers go to a staging matrix in global memory, so the update needs no per-element
+// tests), the owners of the next column publish that, one barrier.  Two barriers and ~3 LDS
+// reads per thread-row and column instead of a read-modify-write sweep of the trailing block.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_or_own(int own) {
+  return __builtin_amdgcn_update_dpp(own, own, CTRL, ROW_MASK, 0xf, false);
+}
+
+// wave-wide arg-max of (v, key): larger v wins, ties go to the smaller key; result in lane 63
+template <class T, int CTRL, int ROW_MASK>
+__device__ __forceinline__ void argmax_step(T& v, int& key) {
+  T ov;
+  if constexpr (sizeof(T) == 8) {
+    const int lo = dpp_or_own<CTRL, ROW_MASK>(__double2loint(v));
+    const int hi = dpp_or_own<CTRL, ROW_MASK>(__double2hiint(v));
+    ov = __hiloint2double(hi, lo);
+  } else {
+    ov = __int_as_float(dpp_or_own<CTRL, ROW_MASK>(__float_as_int(v)));
+  }
+  const int ok = dpp_or_own<CTRL, ROW_MASK>(key);
+  if (ov > v || (ov == v && ok < key)) { v = ov; key = ok; }
+}
+
+template <class T, int NB>
+__global__ __launch_bounds__(BLOCK) void getrf_reg_kernel(T* __restrict__ LUout, const T* __restrict__ Ain,
+                                                         long long* __restrict__ perm_out,
+                                                         T* __restrict__ sign_out, T* __restrict__ logabs_out,
+                                                         int n, T* __restrict__ Lstage, int* __restrict__ status) {
+  __shared__ T s_col[2][128], s_row[128], s_piv[128];
+  __shared__ int s_pos[128], s_cur[128];
+  __shared__ T s_sum[BLOCK / 64];
+  __shared__ int s_neg[BLOCK / 64];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4, lane = tid & 63, wid = tid >> 6;
+  const long long mat = blockIdx.x;
+  const T* A = Ain + mat * (long long)n * n;
+  T* Lg = Lstage + mat * (long long)n * n;
+  T a[NB][NB];
+  unsigned active = 0;
+#pragma unroll
+  for (int r = 0; r < NB; r++) {
+    const int i = ty + 16 * r;
+    if (i < n) active |= 1u << r;
+#pragma unroll
+    for (int c = 0; c < NB; c++) {
+      const int j = tx + 16 * c;
+      a[r][c] = (i < n && j < n) ? A[(long long)i * n + j] : T(0);
+    }
+  }
+  if (tid < 128) { s_pos[tid] = tid; s_cur[tid] = tid; }
+  if (tx == 0) {
+#pragma unroll
+    for (int r = 0; r < NB; r++) s_col[0][ty + 16 * r] = a[r][0];
+  }
+  int flips = 0;
+  bool singular = false;
+  __syncthreads();
+  for (int k = 0; k < n; k++) {
+    const T* col = s_col[k & 1];
+    // ---- pivot: among the rows not pivoted yet, largest |a_ik|, first in the current order ----
+    T v = T(-1);
+    int key = 0x7fffffff;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int rho = lane + 64 * h;
+      if (rho < n) {
+        const int p = s_pos[rho];
+        if (p >= k) {
+          const T x = dev_abs(col[rho]);
+          const int ky = p * 256 + rho;
+          if (x > v || (x == v && ky < key)) { v = x; key = ky; }
+        }
+      }
+    }
+    argmax_step<T, 0x111, 0xf>(v, key);  // row_shr:1
+    argmax_step<T, 0x112, 0xf>(v, key);  // row_shr:2
+    argmax_step<T, 0x114, 0xf>(v, key);  // row_shr:4
+    argmax_step<T, 0x118, 0xf>(v, key);  // row_shr:8
+    argmax_step<T, 0x142, 0xa>(v, key);  // row_bcast:15 into rows 1, 3
+    argmax_step<T, 0x143, 0xc>(v, key);  // row_bcast:31 into rows 2, 3
+    key = __builtin_amdgcn_readlane(key, 63);
+    const int rho = key & 255, q = key >> 8;
+    const T piv = col[rho];
+    if (piv == T(0)) singular = true;  // dgetf2: info = k+1, no scaling, elimination continues
+    const T rp = piv == T(0) ? T(1) : T(1) / piv;
+    // ---- the owners of the pivot row publish it; that row is done ----
+    if (ty == (rho & 15)) {
+#pragma unroll
+      for (int r = 0; r < NB; r++)
+        if (r == (rho >> 4)) {
+#pragma unroll
+          for (int c = 0; c < NB; c++) s_row[tx + 16 * c] = a[r][c];
+          active &= ~(1u << r);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {  // the bookkeeping of LAPACK's row interchange k <-> q
+      const int sigma = s_cur[k];
+      s_cur[q] = sigma; s_pos[sigma] = q;
+      s_cur[k] = rho; s_pos[rho] = k;
+      s_piv[k] = piv;
+      flips += q != k;
+    }
+    // ---- rank-1 update out of registers ----
+    // The multipliers of this column go to the staging matrix Lg (physical row order), so the
+    // register entries at or left of column k of a still-active row are dead from here on and
+    // the update needs no per-element tests: a frozen row gets l = 0 (a - 0 * row = a), whole
+    // column blocks left of k are skipped by a wave-uniform branch.
+    const int cb = k >> 4;
+    T l[NB];
+#pragma unroll
+    for (int r = 0; r < NB; r++) {
+      const bool on = (active >> r) & 1u;
+      l[r] = on ? col[ty + 16 * r] * rp : T(0);
+      if (on && tx == (k & 15)) Lg[(long long)(ty + 16 * r) * n + k] = l[r];
+    }
+#pragma unroll
+    for (int c = 0; c < NB; c++) {
+      if (c >= cb) {
+        const T rv = s_row[tx + 16 * c];
+#pragma unroll
+        for (int r = 0; r < NB; r++) a[r][c] -= l[r] * rv;
+      }
+    }
+    // ---- the owners of column k+1 publish it ----
+    if (k + 1 < n && tx == ((k + 1) & 15)) {
+#pragma unroll
+      for (int c = 0; c < NB; c++)
+        if (c == ((k + 1) >> 4)) {
+#pragma unroll
+          for (int r = 0; r < NB; r++) s_col[(k + 1) & 1][ty + 16 * r] = a[r][c];
+        }
+    }
+    __syncthreads();
+  }
+  // ---- write out: physical row i goes to row s_pos[i] of P*A = L*U ----
+  T* Lo = LUout + mat * (long long)n * n;
+#pragma unroll
+  for (int r = 0; r < NB; r++) {
+    const int i = ty + 16 * r;
+    if (i < n) {
+      const int p = s_pos[i];  // = the column at which row i was pivoted
+      const long long orow = (long long)p * n;
+#pragma unroll
+      for (int c = 0; c < NB; c++) {
+        const int j = tx + 16 * c;
+        // left of the diagonal the multipliers (written by this very thread), U from registers
+        if (j < n) Lo[orow + j] = j < p ? Lg[(long long)i * n + j] : a[r][c];
+      }
+    }
+  }
+  for (int i = tid; i < n; i += BLOCK) perm_out[mat * n + i] = s_cur[i];
+  // slogdet: sign of the permutation times the signs of the pivots, sum of log|pivot|
+  T la = T(0);
+  int neg = 0;
+  for (int i = tid; i < n; i += BLOCK) {
+    const T d = s_piv[i];
+    neg += d < T(0);
+    la += log(dev_abs(d));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { la += __shfl_xor(la, o); neg += __shfl_xor(neg, o); }
+  if (lane == 0) { s_sum[wid] = la; s_neg[wid] = neg; }
+  __syncthreads();
+  if (tid == 0) {
+    la = T(0); neg = 0;
+    for (int w = 0; w < BLOCK / 64; w++) { la += s_sum[w]; neg += s_neg[w]; }
+    T sg = ((flips + neg) & 1) ? T(-1) : T(1);
+    if (singular) { sg = T(0); la = -__builtin_huge_val(); }
+    sign_out[mat] = sg;
+    logabs_out[mat] = la;
+    if (singular && status != nullptr) atomicOr(status, 2);
+  }
+}
+
+template <class T, int NB>
+int launch_getrf_reg(long long batch, long long n, const void* A, void* LU, void* perm, void* sign, void* logabs,
+                     int flag_singular) {
+  void* stage = nullptr;  // multipliers in physical row order until the permutation is known
+  int r = pthip_alloc((size_t)batch * n * n * sizeof(T), &stage);
+  if (r) return r;
+  hipLaunchKernelGGL((getrf_reg_kernel<T, NB>), dim3((unsigned)batch), dim3(BLOCK), 0, pthip::ctx().stream, (T*)LU,
+                     (const T*)A, (long long*)perm, (T*)sign, (T*)logabs, (int)n, (T*)stage,
+                     flag_singular ? (int*)pthip_status_ptr() : (int*)nullptr);
+  r = pthip::post_launch("getrf_reg");
+  pthip_free(stage);  // stream-ordered reuse keeps this safe
+  return r;
+}
+
 template <class T>
 int getrf_typed(long long batch, long long n, const void* A, void* LU, void* perm, void* sign,
                 void* logabs, int flag_singular) {
   if (batch == 0) return 0;
+  static const bool no_reg = getenv("PTHIP_LU_NO_REG") != nullptr;
+  if (n <= 128 && !no_reg) {
+    if (n <= 16) return launch_getrf_reg<T, 1>(batch, n, A, LU, perm, sign, logabs, flag_singular);
+    if (n <= 32) return launch_getrf_reg<T, 2>(batch, n, A, LU, perm, sign, logabs, flag_singular);
+    if (n <= 64) return launch_getrf_reg<T, 4>(batch, n, A, LU, perm, sign, logabs, flag_singular);
+    return launch_getrf_reg<T, 8>(batch, n, A, LU, perm, sign, logabs, flag_singular);
+  }
   if (n > 512) return pthip::set_error("pthip_getrf: n = %lld > 512 is not supported yet", n);
   hipStream_t st = pthip::ctx().stream;
   const size_t need = (size_t)n * (size_t)(n | 1) * sizeof(T);
