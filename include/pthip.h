@@ -197,6 +197,11 @@ int pthip_getrf(int dtype, int64_t batch, int64_t n, const void* A, void* LU, vo
  * (batch, n, n).  Parallel cyclic Jacobi; no convergence raises bit 1 of the device error word
  * (scipy: LinAlgError).  n <= 512. */
 int pthip_eigh(int dtype, int64_t batch, int64_t n, int lower, const void* A, void* W, void* V);
+/* SortOp / ArgSortOp (pytensor/tensor/sort.py:31, 156: np.sort / np.argsort along an axis):
+ * `rows` contiguous rows of n elements sorted ascending along the row, NaNs last, ties in
+ * position order (stable).  out_vals (same dtype) and/or out_idx (int64 positions within the
+ * row) — either may be NULL.  Bitonic network; rows up to 4096 elements in one LDS pass. */
+int pthip_sort(int dtype, int64_t rows, int64_t n, const void* in, void* out_vals, void* out_idx);
 /* Ordered stream compaction for boolean-mask indexing (AdvancedSubtensor / AdvancedIncSubtensor
  * with a bool index, pytensor/tensor/subtensor.py:1932, 2275: x[mask] == x[mask.nonzero()]) and
  * the Nonzero op (tensor/basic.py): ascending C-order flat indices of the non-zero bytes of the

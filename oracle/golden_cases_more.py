@@ -383,3 +383,27 @@ def bool_mask_split():
     ]
     vals = {"x": rng.normal(size=4500), "y": rng.normal(size=9), "M": rng.normal(size=(6, 7)), "iM": rng.integers(-1, 2, size=(5, 4))}
     return [x, y, M, iM], outs, vals
+
+
+@case("sort_argsort")
+def sort_argsort():
+    # tensor/sort.py:31 SortOp, 156 ArgSortOp: every axis, NaNs last, ties (sorted values are
+    # unaffected; argsort only on inputs without ties, where every algorithm agrees), a row longer
+    # than one LDS tile (4096), integer and float32 keys, median through sort
+    rng = np.random.default_rng(53)
+    x = pt.dvector("x")
+    M = pt.dmatrix("M")
+    T3 = pt.ftensor3("T3")
+    iv = pt.lvector("iv")
+    big = pt.dvector("big")
+    outs = [pt.sort(x), pt.argsort(x), pt.sort(M, axis=0), pt.sort(M, axis=1), pt.argsort(M, axis=0), pt.argsort(M, axis=-1),
+            pt.sort(T3, axis=1), pt.argsort(T3, axis=2), pt.sort(iv), pt.sort(big), pt.argsort(big), pt.sort(pt.round(big))[::97],
+            x[pt.argsort(x)][:5]]
+    xv = rng.normal(size=301)
+    xv[[5, 77]] = np.nan
+    xv[100] = -np.inf
+    xv[200] = np.inf
+    bigv = rng.normal(size=10007) * 3
+    vals = {"x": xv, "M": rng.normal(size=(37, 19)), "T3": rng.normal(size=(3, 9, 130)).astype("float32"),
+            "iv": rng.integers(-5, 5, size=64), "big": bigv}
+    return [x, M, T3, iv, big], outs, vals

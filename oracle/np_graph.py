@@ -942,6 +942,19 @@ def _slogdet(p, inputs, node, graph):
     return [np.asarray(s), np.asarray(l)]
 
 
+@op("SortOp")
+def _sort_op(p, inputs, node, graph):
+    # pytensor/tensor/sort.py:52-55 (SortOp.perform)
+    return [np.sort(inputs[0], int(inputs[1]), p["kind"])]
+
+
+@op("ArgSortOp")
+def _argsort_op(p, inputs, node, graph):
+    # pytensor/tensor/sort.py:180-186 (ArgSortOp.perform); a stable kind is used whatever the op
+    # says so that ties have one defined answer (the one the device kernel gives)
+    return [np.asarray(np.argsort(inputs[0], int(inputs[1]), "stable"), dtype=p.get("dtype", "int64"))]
+
+
 @op("Nonzero")
 def _nonzero(p, inputs, node, graph):
     # pytensor/tensor/basic.py Nonzero.perform: np.nonzero, int64 vectors

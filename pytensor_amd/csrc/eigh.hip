@@ -104,9 +104,11 @@ __global__ __launch_bounds__(BLOCK) void eigh_jacobi_kernel(const T* __restrict_
           const T x = A[k * ld + p], y = A[k * ld + q];
           A[k * ld + p] = c * x - s * y;
           A[k * ld + q] = s * x + c * y;
-          const T vx = V[k * ld + p], vy = V[k * ld + q];
-          V[k * ld + p] = c * vx - s * vy;
-          V[k * ld + q] = s * vx + c * vy;
+          // (V is kept transposed: eigenvector p is row p — contiguous in k, which is what the
+          //  global-scratch case needs to stay coalesced)
+          const T vx = V[p * ld + k], vy = V[q * ld + k];
+          V[p * ld + k] = c * vx - s * vy;
+          V[q * ld + k] = s * vx + c * vy;
         }
       }
       __syncthreads();
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(BLOCK) void eigh_jacobi_kernel(const T* __restrict_
   }
   __syncthreads();
   for (int k = wid; k < n; k += BLOCK / 64)
-    for (int i = lane; i < n; i += 64) Vg[(long long)k * n + s_rank[i]] = V[k * ld + i];
+    for (int i = lane; i < n; i += 64) Vg[(long long)k * n + s_rank[i]] = V[i * ld + k];
 }
 
 template <class T>

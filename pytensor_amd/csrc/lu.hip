@@ -7,10 +7,12 @@
 // only np.linalg.inv raises LinAlgError — with flag_singular the kernel raises bit 1 of the
 // device error word and the executor raises that exception at its next synchronisation.
 //
-// correct first.  One workgroup per matrix (batches on grid.x),
-// the matrix resident in LDS when it fits (n <= ~140 fp64), unblocked right-looking
-// elimination: per column one block-wide arg-max (first maximum, like idamax), a row swap,
-// a scale by the reciprocal pivot (dgetf2 does the same above sfmin) and a rank-1 update.
+// SURVEY §8f row 3 (widening).  One workgroup per matrix (batches on grid.x).  Up to n = 128
+// the matrix lives in registers and pivoting is implicit (getrf_reg_kernel below: two barriers
+// per column); larger matrices are swept in LDS (n <= ~140 fp64) or in an L2-resident global
+// scratch (getrf_kernel: unblocked right-looking elimination, per column one block-wide
+// arg-max — first maximum, like idamax —, a row swap, a scale by the reciprocal pivot as dgetf2
+// does above sfmin, and a rank-1 update).
 // Outputs: the packed factors, the row permutation as a gather vector (row i of P*A is row
 // perm[i] of A), its sign (0 when singular) and log|det|.
 #include "common.h"

@@ -92,3 +92,41 @@ def argmax(node, inputs, env):
             raise NotImplementedError("Argmax: bool input on the device")
         ffi.check(env.lib.pthip_argmax(ffi.np_dtype_code(x.dtype), rows, R, xt.ptr, out.ptr))
     return [out]
+
+
+def _sort(node, inputs, env, want_idx):
+    """SortOp / ArgSortOp (pytensor/tensor/sort.py:31, 156): np.sort / np.argsort along ``axis``
+    (a runtime scalar input).  ``kind`` does not matter for the values; index ties come out in
+    position order (NumPy's stable answer), csrc/sort.hip."""
+    x = env.to_device(inputs[0])
+    axis = int(np.asarray(env.to_host(inputs[1])))
+    if x.ndim == 0:
+        raise np.exceptions.AxisError(axis, 0)
+    if not -x.ndim <= axis < x.ndim:
+        raise np.exceptions.AxisError(axis, x.ndim)
+    axis %= x.ndim
+    order = [d for d in range(x.ndim) if d != axis] + [axis]
+    xt = x.view([x.shape[d] for d in order], [x.strides[d] for d in order]).contiguous()
+    n = xt.shape[-1]
+    rows = xt.size // n if n else 0
+    out = DeviceArray.empty(xt.shape, "int64" if want_idx else x.dtype)
+    if rows and n:
+        ffi.check(env.lib.pthip_sort(ffi.np_dtype_code(x.dtype), rows, n, xt.ptr, None if want_idx else out.ptr,
+                                     out.ptr if want_idx else None))
+    inv = [order.index(d) for d in range(x.ndim)]
+    res = out.view([out.shape[d] for d in inv], [out.strides[d] for d in inv])
+    if want_idx and node.params.get("dtype", "int64") != "int64":
+        from pytensor_amd.dispatch.elemwise import _cast
+
+        res = _cast(env, res.contiguous(), node.params["dtype"])
+    return [res]
+
+
+@handler("SortOp")
+def sort_op(node, inputs, env):
+    return _sort(node, inputs, env, False)
+
+
+@handler("ArgSortOp")
+def argsort_op(node, inputs, env):
+    return _sort(node, inputs, env, True)

@@ -99,6 +99,7 @@ SIGNATURES = {
     "pthip_potrf_trsv": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _vp]),
     "pthip_getrf": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _int]),
     "pthip_eigh": (_int, [_int, _i64, _i64, _int, _vp, _vp, _vp]),
+    "pthip_sort": (_int, [_int, _i64, _i64, _vp, _vp, _vp]),
     "pthip_nonzero": (_int, [_i64, _vp, _vp, _vp]),
     "pthip_random": (_int, [_int, _int, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     "pthip_random_categorical": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),

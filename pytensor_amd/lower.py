@@ -270,6 +270,21 @@ for _cls in (Dot22, Dot22Scalar, BatchedDot, Dot, Shape, Reshape, ScalarFromTens
         return _name, {}
 
 
+def _register_sort():
+    from pytensor.tensor.sort import ArgSortOp, SortOp
+
+    @hip_funcify.register(SortOp)
+    def _(op, node, ctx):
+        return "SortOp", {"kind": str(op.kind)}
+
+    @hip_funcify.register(ArgSortOp)
+    def _(op, node, ctx):
+        return "ArgSortOp", {"kind": str(op.kind), "dtype": str(node.outputs[0].type.dtype)}
+
+
+_register_sort()
+
+
 def _register_nonzero():
     from pytensor.tensor.basic import Nonzero
 

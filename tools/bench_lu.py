@@ -1,4 +1,4 @@
-"""Device time of the LU-based ops at n = 128 (eager handler launches between HIP events).
+"""Device time of the LU-based ops and of Eigh at n = 128 (eager handler launches between HIP events).
 usage: python tools/bench_lu.py [n]"""
 import ctypes as C
 import json
@@ -13,11 +13,11 @@ from pytensor_amd.executor import HipExecutable  # noqa: E402
 from pytensor_amd.ir import Graph  # noqa: E402
 
 
-def unary(op, n_out_dims):
+def unary(op, n_out_dims, params=None):
     g = Graph(name=op)
     a = g.new_var("float64", (None, None), name="A")
     outs = [g.new_var("float64", (None,) * d) for d in n_out_dims]
-    g.add_node(op, {}, [a], outs)
+    g.add_node(op, params or {}, [a], outs)
     g.inputs, g.outputs = [a], outs
     return g
 
@@ -27,7 +27,10 @@ def main(n=128):
     rng = np.random.default_rng(0)
     A = rng.normal(size=(n, n)) + np.eye(n) * 2
     res = {"n": n}
-    for name, g in (("MatrixInverse", unary("MatrixInverse", [2])), ("Det", unary("Det", [0])), ("SLogDet", unary("SLogDet", [0, 0]))):
+    for name, g in (("MatrixInverse", unary("MatrixInverse", [2])), ("Det", unary("Det", [0])), ("SLogDet", unary("SLogDet", [0, 0])),
+                    ("Eigh", unary("Eigh", [1, 2], {"lower": True}))):
+        if name == "Eigh":
+            A = (A + A.T) / 2
         exe = HipExecutable(g, resident=[0])
         exe(A)
         plan = exe.freeze(A, fetch_outputs=False)
