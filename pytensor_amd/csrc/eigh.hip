@@ -94,34 +94,52 @@ __global__ __launch_bounds__(BLOCK) void eigh_jacobi_kernel(const T* __restrict_
         s_c[i] = c; s_s[i] = s; s_p[i] = (short)p; s_q[i] = (short)q;
       }
       __syncthreads();
-      // ---- phase 2: columns p, q of A and of V (a wave per pair, lanes down the rows) ----
-      for (int i = wid; i < half; i += BLOCK / 64) {
-        const T s = s_s[i];
-        if (s == T(0)) continue;
-        const T c = s_c[i];
-        const int p = s_p[i], q = s_q[i];
+      // ---- phase 2: columns p, q of A and of V (lanes down the rows; each wave works on two
+      //      pairs at a time so that their LDS round trips overlap) ----
+      constexpr int NW = BLOCK / 64;
+      for (int i0 = wid; i0 < half; i0 += 2 * NW) {
+        const int i1 = i0 + NW < half ? i0 + NW : i0;  // (odd tail: the second slot idles)
+        const bool two = i1 != i0;
+        const T s0 = s_s[i0], c0 = s_c[i0], s1 = two ? s_s[i1] : T(0), c1 = two ? s_c[i1] : T(1);
+        if (s0 == T(0) && s1 == T(0)) continue;
+        const int p0 = s_p[i0], q0 = s_q[i0], p1 = s_p[i1], q1 = s_q[i1];
         for (int k = lane; k < n; k += 64) {
-          const T x = A[k * ld + p], y = A[k * ld + q];
-          A[k * ld + p] = c * x - s * y;
-          A[k * ld + q] = s * x + c * y;
+          const T x0 = A[k * ld + p0], y0 = A[k * ld + q0], x1 = A[k * ld + p1], y1 = A[k * ld + q1];
           // (V is kept transposed: eigenvector p is row p — contiguous in k, which is what the
           //  global-scratch case needs to stay coalesced)
-          const T vx = V[p * ld + k], vy = V[q * ld + k];
-          V[p * ld + k] = c * vx - s * vy;
-          V[q * ld + k] = s * vx + c * vy;
+          const T vx0 = V[p0 * ld + k], vy0 = V[q0 * ld + k], vx1 = V[p1 * ld + k], vy1 = V[q1 * ld + k];
+          if (s0 != T(0)) {
+            A[k * ld + p0] = c0 * x0 - s0 * y0;
+            A[k * ld + q0] = s0 * x0 + c0 * y0;
+            V[p0 * ld + k] = c0 * vx0 - s0 * vy0;
+            V[q0 * ld + k] = s0 * vx0 + c0 * vy0;
+          }
+          if (s1 != T(0)) {
+            A[k * ld + p1] = c1 * x1 - s1 * y1;
+            A[k * ld + q1] = s1 * x1 + c1 * y1;
+            V[p1 * ld + k] = c1 * vx1 - s1 * vy1;
+            V[q1 * ld + k] = s1 * vx1 + c1 * vy1;
+          }
         }
       }
       __syncthreads();
       // ---- phase 3: rows p, q of A; the annihilated pair is stored as an exact zero ----
-      for (int i = wid; i < half; i += BLOCK / 64) {
-        const T s = s_s[i];
-        if (s == T(0)) continue;
-        const T c = s_c[i];
-        const int p = s_p[i], q = s_q[i];
+      for (int i0 = wid; i0 < half; i0 += 2 * NW) {
+        const int i1 = i0 + NW < half ? i0 + NW : i0;
+        const bool two = i1 != i0;
+        const T s0 = s_s[i0], c0 = s_c[i0], s1 = two ? s_s[i1] : T(0), c1 = two ? s_c[i1] : T(1);
+        if (s0 == T(0) && s1 == T(0)) continue;
+        const int p0 = s_p[i0], q0 = s_q[i0], p1 = s_p[i1], q1 = s_q[i1];
         for (int k = lane; k < n; k += 64) {
-          const T x = A[p * ld + k], y = A[q * ld + k];
-          A[p * ld + k] = k == q ? T(0) : c * x - s * y;
-          A[q * ld + k] = k == p ? T(0) : s * x + c * y;
+          const T x0 = A[p0 * ld + k], y0 = A[q0 * ld + k], x1 = A[p1 * ld + k], y1 = A[q1 * ld + k];
+          if (s0 != T(0)) {
+            A[p0 * ld + k] = k == q0 ? T(0) : c0 * x0 - s0 * y0;
+            A[q0 * ld + k] = k == p0 ? T(0) : s0 * x0 + c0 * y0;
+          }
+          if (s1 != T(0)) {
+            A[p1 * ld + k] = k == q1 ? T(0) : c1 * x1 - s1 * y1;
+            A[q1 * ld + k] = k == p1 ? T(0) : s1 * x1 + c1 * y1;
+          }
         }
       }
       __syncthreads();
