@@ -471,6 +471,9 @@ def _(op, node, ctx):
 def _(op, node, ctx):
     info = op.info
     inner = lower_fgraph(op.fgraph, name="scan_inner")
+    if any(v.kind == "rng" for v in inner.vars.values()):
+        raise NotImplementedError("hip linker: random draws inside a Scan are not lowered "
+                                  "(the generator would have to be carried as a Scan state)")
     return "Scan", {
         "info": {
             "n_seqs": info.n_seqs,
