@@ -226,6 +226,9 @@ int pthip_random(int dist, int out_dtype, int64_t n, const uint64_t* key, const 
  * apart, 0 = the same vector for every row) by inversion of the running sum; int64 out */
 int pthip_random_categorical(int p_dtype, int64_t rows, int64_t k, const uint64_t* key,
                              const uint64_t* counter, const void* p, int64_t row_stride, void* out);
+/* out (n, n) = P * I for the gather vector perm of pthip_getrf (row i = unit vector e_perm[i]):
+ * the right-hand side of MatrixInverse (pytensor/tensor/linalg/inverse.py:87), built on the device */
+int pthip_permuted_identity(int dtype, int64_t n, const void* perm, void* out);
 /* solve op(T) X = B, T triangular n×n (strided), B n×nrhs (contiguous row-major), out contiguous */
 int pthip_trsm(int dtype, int lower, int trans, int unit_diag, int64_t batch, int64_t n,
                int64_t nrhs, const void* T, int64_t sTb, int64_t sT0, int64_t sT1, const void* B,

@@ -344,7 +344,30 @@ int getrf_typed(long long batch, long long n, const void* A, void* LU, void* per
   return r;
 }
 
+// P * I for the inverse: row i of the result is the unit vector e_perm[i]
+template <class T>
+__global__ __launch_bounds__(BLOCK) void permuted_identity_kernel(T* __restrict__ out, const long long* __restrict__ perm,
+                                                                 long long n) {
+  const long long total = n * n;
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (long long)gridDim.x * BLOCK) {
+    const long long i = e / n, j = e - i * n;
+    out[e] = j == perm[i] ? T(1) : T(0);
+  }
+}
+
 }  // namespace
+
+extern "C" int pthip_permuted_identity(int dtype, int64_t n, const void* perm, void* out) {
+  PTHIP_REQUIRE_INIT();
+  if (n <= 0) return 0;
+  long long g = (n * n + BLOCK - 1) / BLOCK;
+  if (g > 4096) g = 4096;
+  hipStream_t st = pthip::ctx().stream;
+  if (dtype == PTHIP_F64) hipLaunchKernelGGL(permuted_identity_kernel<double>, dim3((unsigned)g), dim3(BLOCK), 0, st, (double*)out, (const long long*)perm, (long long)n);
+  else if (dtype == PTHIP_F32) hipLaunchKernelGGL(permuted_identity_kernel<float>, dim3((unsigned)g), dim3(BLOCK), 0, st, (float*)out, (const long long*)perm, (long long)n);
+  else return pthip::set_error("pthip_permuted_identity: dtype %d not supported (float32/float64 only)", dtype);
+  return pthip::post_launch("permuted_identity");
+}
 
 extern "C" int pthip_getrf(int dtype, int64_t batch, int64_t n, const void* A, void* LU, void* perm,
                            void* sign, void* logabsdet, int flag_singular) {

@@ -135,10 +135,9 @@ def matrix_inverse(node, inputs, env):
         raise NotImplementedError("hip linker: batched MatrixInverse")
     LU, perm, _, _, _ = getrf_device(env, x, flag_singular=True)  # np.linalg.inv raises when singular
     lu = LU.view((n, n), (n, 1))
-    from pytensor_amd.executor import HostValue
-
-    eye = env.to_device(HostValue(np.eye(n, dtype=x.dtype)))  # (kept alive for captured replays)
-    pb = _permute_rows(env, eye, perm.view((n,), (1,)))
+    pb = DeviceArray.empty((n, n), x.dtype)  # P * I, built on the device (no upload per call)
+    if n:
+        ffi.check(env.lib.pthip_permuted_identity(_dt(x), n, perm.ptr, pb.ptr))
     y = trsm_device(env, lu, pb, True, True, 2)
     return [trsm_device(env, lu, y, False, False, 2)]
 

@@ -98,6 +98,7 @@ SIGNATURES = {
     "pthip_potrf": (_int, [_int, _int, _i64, _i64, _vp, _vp]),
     "pthip_potrf_trsv": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _vp]),
     "pthip_getrf": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _int]),
+    "pthip_permuted_identity": (_int, [_int, _i64, _vp, _vp]),
     "pthip_eigh": (_int, [_int, _i64, _i64, _int, _vp, _vp, _vp]),
     "pthip_sort": (_int, [_int, _i64, _i64, _vp, _vp, _vp]),
     "pthip_nonzero": (_int, [_i64, _vp, _vp, _vp]),
