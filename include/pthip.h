@@ -197,6 +197,12 @@ int pthip_getrf(int dtype, int64_t batch, int64_t n, const void* A, void* LU, vo
  * (batch, n, n).  Parallel cyclic Jacobi; no convergence raises bit 1 of the device error word
  * (scipy: LinAlgError).  n <= 512. */
 int pthip_eigh(int dtype, int64_t batch, int64_t n, int lower, const void* A, void* W, void* V);
+/* ARange.perform (pytensor/tensor/basic.py: np.arange(start, stop, step, dtype)) for a length n
+ * the host has computed: integers istart + i*istep, floating point fstart + i*delta with
+ * delta = (fstart + fstep) - fstart in the output type (NumPy's fill loop). */
+int pthip_arange(int dtype, int64_t n, double fstart, double fstep, int64_t istart, int64_t istep, void* out);
+/* Eye.perform (np.eye(n, m, k, dtype)): out (n, m), ones on the k-th diagonal */
+int pthip_eye(int dtype, int64_t n, int64_t m, int64_t k, void* out);
 /* SortOp / ArgSortOp (pytensor/tensor/sort.py:31, 156: np.sort / np.argsort along an axis):
  * `rows` contiguous rows of n elements sorted ascending along the row, NaNs last, ties in
  * position order (stable).  out_vals (same dtype) and/or out_idx (int64 positions within the

@@ -407,3 +407,15 @@ def sort_argsort():
     vals = {"x": xv, "M": rng.normal(size=(37, 19)), "T3": rng.normal(size=(3, 9, 130)).astype("float32"),
             "iv": rng.integers(-5, 5, size=64), "big": bigv}
     return [x, M, T3, iv, big], outs, vals
+
+
+@case("fill_long")
+def fill_long():
+    # ARange / Eye (tensor/basic.py) beyond the host-resident size: generated by a kernel.
+    # Float ranges follow NumPy's fill loop (start + i * ((start + step) - start)).
+    s = pt.dscalar("s")
+    k = pt.lscalar("k")
+    x = pt.dvector("x")
+    outs = [pt.arange(0.25, s, 0.125) * 2.0, pt.arange(k) * 3, pt.arange(5, k, 7), pt.arange(0.1, s, 0.3, dtype="float32"),
+            pt.eye(70, 90, 3) * s, pt.eye(k, k, -2, dtype="int32")[:5, :9], x[pt.arange(k)[::-1]][:4], pt.arange(10.0, -s, -0.7)]
+    return [s, k, x], outs, {"s": np.asarray(60.0), "k": np.asarray(500), "x": np.random.default_rng(54).normal(size=600)}

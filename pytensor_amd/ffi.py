@@ -100,6 +100,8 @@ SIGNATURES = {
     "pthip_getrf": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _int]),
     "pthip_permuted_identity": (_int, [_int, _i64, _vp, _vp]),
     "pthip_eigh": (_int, [_int, _i64, _i64, _int, _vp, _vp, _vp]),
+    "pthip_arange": (_int, [_int, _i64, _dbl, _dbl, _i64, _i64, _vp]),
+    "pthip_eye": (_int, [_int, _i64, _i64, _i64, _vp]),
     "pthip_sort": (_int, [_int, _i64, _i64, _vp, _vp, _vp]),
     "pthip_nonzero": (_int, [_i64, _vp, _vp, _vp]),
     "pthip_random": (_int, [_int, _int, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
