@@ -222,7 +222,8 @@ int pthip_nonzero(int64_t n, const void* mask, void* idx_out, void* count_out);
  * dist: 0 uniform(low,high) 1 normal(loc,scale) 2 halfnormal 3 lognormal 4 exponential(scale)
  * 5 laplace 6 logistic 7 cauchy 8 halfcauchy 9 gumbel 10 weibull(shape) 11 pareto(b,scale)
  * 12 triangular(left,mode,right) 13 gamma(shape,scale) 14 beta(a,b) 15 invgamma(shape,scale)
- * 16 t(df,loc,scale) 17 bernoulli(p) 18 geometric(p) 19 poisson(lam) 20 integers(low,high).
+ * 16 t(df,loc,scale) 17 bernoulli(p) 18 geometric(p) 19 poisson(lam) 20 integers(low,high)
+ * 21 binomial(n,p) 22 negative_binomial(n,p).
  * params[j]: contiguous array broadcast to the output (stride 1) or one element (stride 0),
  * any numeric dtype.  out: float64 / float32 / int64, contiguous. */
 int pthip_random(int dist, int out_dtype, int64_t n, const uint64_t* key, const uint64_t* counter,

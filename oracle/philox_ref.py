@@ -94,7 +94,7 @@ def gamma_mt(s: Stream, i, sub, shape):
     return d * boost
 
 
-def poisson_draw(s: Stream, i, lam):
+def poisson_draw(s: Stream, i, lam, sub=0):
     if not lam >= 0.0:
         return math.nan
     if lam == 0.0:
@@ -104,7 +104,7 @@ def poisson_draw(s: Stream, i, lam):
         p = 1.0
         k = 0
         for attempt in range(64):
-            w = s.block(i, 0, attempt)
+            w = s.block(i, sub, attempt)
             for j in range(4):
                 p *= uopen(w[j])
                 if p <= L:
@@ -117,7 +117,7 @@ def poisson_draw(s: Stream, i, lam):
     invalpha = 1.1239 + 1.1328 / (b - 3.4)
     vr = 0.9277 - 3.6224 / (b - 2.0)
     for attempt in range(256):
-        w = s.block(i, 0, attempt)
+        w = s.block(i, sub, attempt)
         U = uopen(w[0]) - 0.5
         V = uopen(w[1])
         us = 0.5 - abs(U)
@@ -129,6 +129,68 @@ def poisson_draw(s: Stream, i, lam):
         if math.log(V) + math.log(invalpha) - math.log(al / (us * us) + b) <= -lam + k * loglam - math.lgamma(k + 1.0):
             return float(k)
     return float(math.floor(lam))
+
+
+def binomial_draw(s: Stream, i, n, p):
+    if not (0.0 <= p <= 1.0) or not n >= 0.0:
+        return math.nan
+    n = math.floor(n)
+    flip = p > 0.5
+    q = 1.0 - p if flip else p
+    if q == 0.0 or n == 0.0:
+        return n if flip else 0.0
+    x = -1.0
+    if n * q < 10.0:
+        qn = math.exp(n * math.log1p(-q))
+        odds = q / (1.0 - q)
+        bound = min(n, n * q + 10.0 * math.sqrt(n * q * (1.0 - q) + 1.0))
+        for attempt in range(64):
+            if x >= 0.0:
+                break
+            w = s.block(i, 0, attempt)
+            for j in range(4):
+                if x >= 0.0:
+                    break
+                u, px, k, ok = uopen(w[j]), qn, 0.0, True
+                while u > px:
+                    k += 1.0
+                    if k > bound:
+                        ok = False
+                        break
+                    u -= px
+                    px *= (n - k + 1.0) * odds / k
+                if ok:
+                    x = k
+        if x < 0.0:
+            x = math.floor(n * q)
+    else:
+        spq = math.sqrt(n * q * (1.0 - q))
+        b = 1.15 + 2.53 * spq
+        al = -0.0873 + 0.0248 * b + 0.01 * q
+        c = n * q + 0.5
+        vr = 0.92 - 4.2 / b
+        alpha = (2.83 + 5.1 / b) * spq
+        lpq = math.log(q / (1.0 - q))
+        m = math.floor((n + 1.0) * q)
+        h = math.lgamma(m + 1.0) + math.lgamma(n - m + 1.0)
+        for attempt in range(256):
+            w = s.block(i, 0, attempt)
+            u = uopen(w[0]) - 0.5
+            v = uopen(w[1])
+            us = 0.5 - abs(u)
+            k = math.floor((2.0 * al / us + b) * u + c)
+            if k < 0.0 or k > n:
+                continue
+            if us >= 0.07 and v <= vr:
+                x = k
+                break
+            v = math.log(v * alpha / (al / (us * us) + b))
+            if v <= h - math.lgamma(k + 1.0) - math.lgamma(n - k + 1.0) + (k - m) * lpq:
+                x = k
+                break
+        if x < 0.0:
+            x = m
+    return n - x if flip else x
 
 
 def _element(name, s: Stream, i, p):
@@ -153,6 +215,10 @@ def _element(name, s: Stream, i, p):
         return p[1] + p[2] * (math.sqrt(0.5 * p[0]) * box_muller(w[0], w[1]) / math.sqrt(g))
     if name == "poisson":
         return poisson_draw(s, i, p[0])
+    if name == "binomial":
+        return binomial_draw(s, i, p[0], p[1])
+    if name == "negative_binomial":
+        return poisson_draw(s, i, gamma_mt(s, i, 0, p[0]) * ((1.0 - p[1]) / p[1]), 1)
     w = s.block(i)
     u = uopen(w[0])
     if name == "exponential":

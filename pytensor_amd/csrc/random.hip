@@ -28,7 +28,7 @@ constexpr int BLOCK = 256;
 enum Dist {
   D_UNIFORM = 0, D_NORMAL, D_HALFNORMAL, D_LOGNORMAL, D_EXPONENTIAL, D_LAPLACE, D_LOGISTIC, D_CAUCHY,
   D_HALFCAUCHY, D_GUMBEL, D_WEIBULL, D_PARETO, D_TRIANGULAR, D_GAMMA, D_BETA, D_INVGAMMA, D_STUDENT_T,
-  D_BERNOULLI, D_GEOMETRIC, D_POISSON, D_INTEGERS, D_COUNT
+  D_BERNOULLI, D_GEOMETRIC, D_POISSON, D_INTEGERS, D_BINOMIAL, D_NEGBINOMIAL, D_COUNT
 };
 
 struct RandArgs {
@@ -121,7 +121,7 @@ __device__ double gamma_mt(const RandArgs& a, u64 i, unsigned sub, double shape)
 }
 
 // Knuth's product method below lambda = 10, Hoermann's PTRS (1993) above
-__device__ double poisson_draw(const RandArgs& a, u64 i, double lam) {
+__device__ double poisson_draw(const RandArgs& a, u64 i, unsigned sub, double lam) {
   if (!(lam >= 0.0)) return __builtin_nan("");
   if (lam == 0.0) return 0.0;
   u64 w[4];
@@ -130,7 +130,7 @@ __device__ double poisson_draw(const RandArgs& a, u64 i, double lam) {
     double p = 1.0;
     long long k = 0;
     for (unsigned attempt = 0; attempt < 64; attempt++) {
-      draw_block(a, i, 0, attempt, w);
+      draw_block(a, i, sub, attempt, w);
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         p *= uopen(w[j]);
@@ -143,7 +143,7 @@ __device__ double poisson_draw(const RandArgs& a, u64 i, double lam) {
   const double slam = sqrt(lam), loglam = log(lam), b = 0.931 + 2.53 * slam, al = -0.059 + 0.02483 * b;
   const double invalpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2.0);
   for (unsigned attempt = 0; attempt < 256; attempt++) {
-    draw_block(a, i, 0, attempt, w);
+    draw_block(a, i, sub, attempt, w);
     const double U = uopen(w[0]) - 0.5, V = uopen(w[1]);
     const double us = 0.5 - fabs(U);
     const double k = floor((2.0 * al / us + b) * U + lam + 0.43);
@@ -152,6 +152,55 @@ __device__ double poisson_draw(const RandArgs& a, u64 i, double lam) {
     if (log(V) + log(invalpha) - log(al / (us * us) + b) <= -lam + k * loglam - lgamma(k + 1.0)) return k;
   }
   return floor(lam);
+}
+
+// binomial(n, p): sequential inversion while n*min(p,1-p) < 10, Hoermann's BTRS (1993) above
+__device__ double binomial_draw(const RandArgs& a, u64 i, double n, double p) {
+  if (!(p >= 0.0 && p <= 1.0) || !(n >= 0.0)) return __builtin_nan("");
+  n = floor(n);
+  const bool flip = p > 0.5;
+  const double q = flip ? 1.0 - p : p;
+  if (q == 0.0 || n == 0.0) return flip ? n : 0.0;
+  u64 w[4];
+  double x = -1.0;
+  if (n * q < 10.0) {
+    const double qn = exp(n * log1p(-q)), odds = q / (1.0 - q);
+    const double bound = fmin(n, n * q + 10.0 * sqrt(n * q * (1.0 - q) + 1.0));
+    for (unsigned attempt = 0; attempt < 64 && x < 0.0; attempt++) {
+      draw_block(a, i, 0, attempt, w);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (x >= 0.0) break;
+        double u = uopen(w[j]), px = qn, k = 0.0;
+        bool ok = true;
+        while (u > px) {
+          k += 1.0;
+          if (k > bound) { ok = false; break; }
+          u -= px;
+          px *= (n - k + 1.0) * odds / k;
+        }
+        if (ok) x = k;
+      }
+    }
+    if (x < 0.0) x = floor(n * q);
+  } else {
+    const double spq = sqrt(n * q * (1.0 - q)), b = 1.15 + 2.53 * spq, al = -0.0873 + 0.0248 * b + 0.01 * q;
+    const double c = n * q + 0.5, vr = 0.92 - 4.2 / b, alpha = (2.83 + 5.1 / b) * spq, lpq = log(q / (1.0 - q));
+    const double m = floor((n + 1.0) * q), h = lgamma(m + 1.0) + lgamma(n - m + 1.0);
+    for (unsigned attempt = 0; attempt < 256 && x < 0.0; attempt++) {
+      draw_block(a, i, 0, attempt, w);
+      const double u = uopen(w[0]) - 0.5;
+      double v = uopen(w[1]);
+      const double us = 0.5 - fabs(u);
+      const double k = floor((2.0 * al / us + b) * u + c);
+      if (k < 0.0 || k > n) continue;
+      if (us >= 0.07 && v <= vr) { x = k; break; }
+      v = log(v * alpha / (al / (us * us) + b));
+      if (v <= h - lgamma(k + 1.0) - lgamma(n - k + 1.0) + (k - m) * lpq) x = k;
+    }
+    if (x < 0.0) x = m;
+  }
+  return flip ? n - x : x;
 }
 
 template <class T>
@@ -228,7 +277,13 @@ __global__ __launch_bounds__(BLOCK) void random_kernel(int dist, long long n, Ra
         r = p >= 1.0 ? 1.0 : ceil(log(uopen(w[0])) / log1p(-p));
         if (r < 1.0) r = 1.0;
       } break;
-      case D_POISSON: r = poisson_draw(a, (u64)i, load_f(a, 0, i)); break;
+      case D_POISSON: r = poisson_draw(a, (u64)i, 0, load_f(a, 0, i)); break;
+      case D_BINOMIAL: r = binomial_draw(a, (u64)i, load_f(a, 0, i), load_f(a, 1, i)); break;
+      case D_NEGBINOMIAL: {
+        // gamma-Poisson mixture: lambda ~ Gamma(n, (1-p)/p), X ~ Poisson(lambda)
+        const double nn = load_f(a, 0, i), p = load_f(a, 1, i);
+        r = poisson_draw(a, (u64)i, 1, gamma_mt(a, (u64)i, 0, nn) * ((1.0 - p) / p));
+      } break;
       default: r = __builtin_nan(""); break;
     }
     out[i] = (T)r;

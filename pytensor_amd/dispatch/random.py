@@ -25,7 +25,7 @@ DISTRIBUTIONS = {
     "laplace": (5, 2), "logistic": (6, 2), "cauchy": (7, 2), "halfcauchy": (8, 2), "gumbel": (9, 2),
     "weibull": (10, 1), "pareto": (11, 2), "triangular": (12, 3), "gamma": (13, 2), "beta": (14, 2),
     "invgamma": (15, 2), "t": (16, 3), "bernoulli": (17, 1), "geometric": (18, 1), "poisson": (19, 1),
-    "integers": (20, 2),
+    "integers": (20, 2), "binomial": (21, 2), "negative_binomial": (22, 2),
 }
 
 

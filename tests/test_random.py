@@ -61,11 +61,15 @@ CASES = {
     "poisson": ([3.6], st.poisson(3.6), True),
     "poisson_large": ([47.5], st.poisson(47.5), True),
     "integers": ([-3, 9], st.randint(-3, 9), True),
+    "binomial": ([12, 0.3], st.binom(12, 0.3), True),
+    "binomial_large": ([400, 0.35], st.binom(400, 0.35), True),
+    "binomial_flip": ([60, 0.85], st.binom(60, 0.85), True),
+    "negative_binomial": ([5.0, 0.4], st.nbinom(5.0, 0.4), True),
 }
 
 
 def _name(case):
-    return case.split("_")[0]
+    return "negative_binomial" if case.startswith("negative_binomial") else case.split("_")[0]
 
 
 def _params(case):
