@@ -272,6 +272,20 @@ def draw(name, gen, size, params, dtype):
                     break
             out[i] = pick
         return make_generator(key, ctr + len(prb)), out.reshape(shape).astype(dtype)
+    if name == "dirichlet":
+        al = np.asarray(params[0], dtype=np.float64)
+        shape = (*(al.shape[:-1] if size is None else tuple(size)), al.shape[-1])
+        flat = np.broadcast_to(al, shape).reshape(-1)
+        g = np.array([gamma_mt(s, i, 0, float(a)) for i, a in enumerate(flat)]).reshape(shape)
+        return make_generator(key, ctr + g.size), (g / g.sum(axis=-1, keepdims=True)).astype(dtype)
+    if name == "multivariate_normal":
+        mean, cov = (np.asarray(p, dtype=np.float64) for p in params)
+        k = mean.shape[0]
+        lead = () if size is None else tuple(int(v) for v in size)
+        rows = int(np.prod(lead)) if lead else 1
+        z = np.array([box_muller(*s.block(i)[:2]) for i in range(rows * k)]).reshape(rows, k)
+        out = z @ np.linalg.cholesky(cov).T + mean
+        return make_generator(key, ctr + rows * k), out.reshape(*lead, k).astype(dtype)
     params = [np.asarray(p) for p in params]
     bshape = np.broadcast_shapes(*[p.shape for p in params]) if params else ()
     shape = tuple(bshape) if size is None else tuple(int(v) for v in size)

@@ -85,6 +85,37 @@ def random_variable(node, inputs, env):
         out = out if out_dtype == np.dtype("int64") else _cast(env, out, out_dtype)
         return [rng.advanced(rows), out]
 
+    if name == "dirichlet":
+        # DirichletRV (random/basic.py:942): unit-scale gammas normalised along the last axis
+        (al,) = devs
+        k = al.shape[-1]
+        shape = (*(tuple(al.shape[:-1]) if size is None else size), k)
+        n = int(np.prod(shape))
+        g = _draw(env, "gamma", [al, env.to_device(HostValue(np.asarray(1.0)))], shape, np.dtype("float64"), key_ptr, ctr_ptr)
+        return [rng.advanced(n), _normalise_rows(env, g, out_dtype)]
+
+    if name == "multivariate_normal":
+        # MvNormalRV.rng_fn (random/basic.py:914-936, method="cholesky"): mean + L z, z ~ N(0, I)
+        mean, cov = devs
+        if p.get("method", "cholesky") != "cholesky":
+            raise NotImplementedError("hip linker: multivariate_normal is lowered for method='cholesky' only")
+        if mean.ndim != 1 or cov.ndim != 2:
+            raise NotImplementedError("hip linker: multivariate_normal with batched mean / cov")
+        from pytensor_amd.dispatch.blas import gemm_device
+        from pytensor_amd.dispatch.linalg import cholesky_device
+
+        k = mean.shape[0]
+        lead = () if size is None else size
+        rows = int(np.prod(lead)) if lead else 1
+        fdt = np.dtype(cov.dtype)
+        zero, one = (env.to_device(HostValue(np.asarray(v, dtype=fdt))) for v in (0.0, 1.0))
+        z = _draw(env, "normal", [zero, one], (rows, k), fdt, key_ptr, ctr_ptr)
+        L = cholesky_device(env, cov, True)
+        m2 = mean if str(mean.dtype) == str(fdt) else _cast(env, mean, fdt)
+        out = gemm_device(env, 1.0, z, L.view((k, k), (L.strides[1], L.strides[0])), 1.0, m2.view((1, k), (0, m2.strides[0])))
+        out = out.view((*lead, k), contiguous_strides((*lead, k)))
+        return [rng.advanced(rows * k), out if out_dtype == fdt else _cast(env, out, out_dtype)]
+
     if name not in DISTRIBUTIONS:
         raise NotImplementedError(f"hip linker: no device sampler for the {name!r} RandomVariable")
     code, nparams = DISTRIBUTIONS[name]
@@ -112,6 +143,40 @@ def random_variable(node, inputs, env):
         out = _cast(env, out, out_dtype)
     blocks = (n + 3) // 4 if name == "uniform" else n
     return [rng.advanced(blocks), out]
+
+
+def _draw(env, name, devs, shape, kernel_dtype, key_ptr, ctr_ptr) -> DeviceArray:
+    """one pthip_random launch: per-element draws of ``name`` into a fresh contiguous array"""
+    code, _ = DISTRIBUTIONS[name]
+    n = int(np.prod(shape)) if shape else 1
+    out = DeviceArray.empty(shape, kernel_dtype)
+    if n:
+        ops = [_param_operand(d, shape) for d in devs]
+        ptrs = (C.c_void_p * 3)(*[o[1] for o in ops], *([None] * (3 - len(ops))))
+        dts = (C.c_int * 3)(*[o[2] for o in ops], *([0] * (3 - len(ops))))
+        sts = (C.c_int64 * 3)(*[o[3] for o in ops], *([0] * (3 - len(ops))))
+        ffi.check(env.lib.pthip_random(code, ffi.np_dtype_code(kernel_dtype), n, key_ptr, ctr_ptr, len(ops),
+                                       C.cast(ptrs, C.c_void_p), C.cast(dts, C.c_void_p), C.cast(sts, C.c_void_p), out.ptr))
+        env.keepalive.extend(o[0] for o in ops)
+    return out
+
+
+def _normalise_rows(env, g: DeviceArray, out_dtype) -> DeviceArray:
+    """g / g.sum(-1, keepdims=True) of a contiguous array"""
+    from pytensor_amd.dispatch.elemwise import device_reduce, launch_elemwise
+
+    k = g.shape[-1]
+    rows = g.size // k if k else 0
+    dt = str(g.dtype)
+    if not g.size:
+        return DeviceArray.empty(g.shape, out_dtype)
+    sums = device_reduce(env, "Add", g, rows, k, 1, k, 1, 0, dt, dt, (rows,))
+    body = {"in_dtypes": [dt, dt], "out_dtypes": [str(out_dtype)],
+            "body": [{"op": "TrueDiv", "in": [["i", 0], ["i", 1]], "dtype": dt}, {"op": "Cast", "in": [["t", 0]], "dtype": str(out_dtype)}],
+            "outs": [["t", 1]]}
+    g2 = g.view((rows, k), (k, 1))
+    outs, _, _ = launch_elemwise(body, [g2, sums.view((rows, 1), (1, 0))], (rows, k), [str(out_dtype)], None, env)
+    return outs[0].view(g.shape, contiguous_strides(g.shape))
 
 
 def _cast(env, x: DeviceArray, dtype) -> DeviceArray:

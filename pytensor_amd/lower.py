@@ -519,7 +519,9 @@ def _(op, node, ctx):
     from pytensor_amd.dispatch.random import DISTRIBUTIONS
 
     name = str(op.name)
-    if name not in DISTRIBUTIONS and name != "categorical":
+    if name not in DISTRIBUTIONS and name not in ("categorical", "dirichlet", "multivariate_normal"):
+        return None
+    if name == "multivariate_normal" and getattr(op, "method", "cholesky") != "cholesky":
         return None
     return "RandomVariable", {
         "name": name,

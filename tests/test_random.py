@@ -142,6 +142,29 @@ def test_categorical_and_broadcast_parameters():
     assert y.shape == (500, 3) and np.abs(y.mean(axis=0) - [0.0, 100.0, -100.0]).max() < 0.1
 
 
+def _mv_cases():
+    rng = np.random.default_rng(3)
+    B = rng.normal(size=(4, 4))
+    return np.array([0.5, 2.0, 1.0, 4.0]), np.array([1.0, -2.0, 0.5, 3.0]), B @ B.T + np.eye(4)
+
+
+def test_dirichlet_and_multivariate_normal_moments():
+    alpha, mean, cov = _mv_cases()
+    g = rv_graph("dirichlet", "float64", (5000,), [("float64", 1)])
+    g.vars[g.outputs[1]].shape = (None, None)
+    g2, x = np_graph.run_graph(g, [gen(2), alpha])
+    assert x.shape == (5000, 4) and np.allclose(x.sum(axis=1), 1.0)
+    assert np.abs(x.mean(axis=0) - alpha / alpha.sum()).max() < 0.01
+    a0 = alpha.sum()
+    assert np.abs(x.var(axis=0) - alpha * (a0 - alpha) / (a0 * a0 * (a0 + 1))).max() < 0.003
+    assert philox_ref.generator_state(g2)[1] == 2 + 20000
+    g = rv_graph("multivariate_normal", "float64", (6000,), [("float64", 1), ("float64", 2)])
+    g.vars[g.outputs[1]].shape = (None, None)
+    _, y = np_graph.run_graph(g, [gen(2), mean, cov])
+    assert y.shape == (6000, 4)
+    assert np.abs(y.mean(axis=0) - mean).max() < 0.12 and np.abs(np.cov(y.T) - cov).max() < 0.35
+
+
 def test_successive_nodes_draw_disjoint_blocks():
     _, a = philox_ref.draw("normal", gen(0), (64,), [np.asarray(0.0), np.asarray(1.0)], "float64")
     g1, _ = philox_ref.draw("normal", gen(0), (32,), [np.asarray(0.0), np.asarray(1.0)], "float64")
@@ -213,6 +236,19 @@ def test_device_categorical_float32_and_broadcast(hip):
     got = HipExecutable(g)(gen(5), *ins)
     assert got[1].dtype == np.float32 and got[1].shape == (257, 3)
     np.testing.assert_allclose(got[1], want[1], rtol=1e-6, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_device_dirichlet_and_multivariate_normal(hip):
+    from pytensor_amd.executor import HipExecutable
+
+    alpha, mean, cov = _mv_cases()
+    for name, ins, size in (("dirichlet", [alpha], (1000,)), ("multivariate_normal", [mean, cov], (1500,)), ("multivariate_normal", [mean, cov], None)):
+        g = rv_graph(name, "float64", size, [("float64", a.ndim) for a in ins])
+        want = np_graph.run_graph(g, [gen(4), *ins])
+        got = HipExecutable(g)(gen(4), *ins)
+        assert philox_ref.generator_state(got[0]) == philox_ref.generator_state(want[0])
+        np.testing.assert_allclose(got[1], want[1], rtol=1e-11, atol=1e-11)
 
 
 @pytest.mark.gpu
