@@ -350,6 +350,16 @@ int pthip_arena_destroy(void* arena) {
   if (g_pool.active == a) g_pool.active = nullptr;
   for (auto& b : a->owned) {
     g_pool.arena_of.erase(b.ptr);
+    if (a->live.count(b.ptr)) {
+      // Still referenced by the caller — e.g. arrays in frames that a stored exception
+      // traceback keeps alive after the plan that owned the arena was closed.  Releasing the
+      // memory here would leave those owners with a dangling pointer whose late pthip_free hits
+      // whatever the address has become by then (observed: two live arrays sharing one block).
+      // The block is adopted by the general pool instead; its owner frees it as usual.
+      g_pool.live[b.ptr] = b.size;
+      g_pool.in_use += b.size;
+      continue;
+    }
     (void)hipFree(b.ptr);
     g_pool.reserved -= b.size;
   }
