@@ -176,3 +176,25 @@ def test_auto_multi_stream_picks_a_plan_and_matches_eager(hip):
         if exe.segments is None:
             assert not plan.segmented
         plan.close()
+
+
+def test_arena_destroy_adopts_blocks_that_are_still_referenced(hip):
+    """A block handed out inside a plan's arena may outlive the plan (arrays in frames that a
+    stored exception traceback keeps alive).  Destroying the arena must not release it: its owner
+    would free a dangling pointer later, and the pool would hand a live block out twice."""
+    import ctypes as C
+
+    from pytensor_amd.device import Buffer
+
+    lib = hip.lib()
+    arena = C.c_void_p()
+    hip.check(lib.pthip_arena_begin(C.byref(arena)))
+    held = Buffer(4096)  # allocated inside the arena, outlives it
+    hip.check(lib.pthip_arena_end())
+    hip.check(lib.pthip_arena_destroy(arena))
+    others = [Buffer(4096) for _ in range(64)]
+    assert held.ptr not in {b.ptr for b in others}
+    del held  # the late free returns a block the pool knows about
+    more = [Buffer(4096) for _ in range(64)]
+    ptrs = [b.ptr for b in others + more]
+    assert len(set(ptrs)) == len(ptrs)
