@@ -85,3 +85,27 @@ def test_scan_and_ofg_inner_graphs_compile(pt):
 
     f = pytensor.function([xs], [softmax(xs, axis=-1)], mode="hip")  # SymbolicOp / OpFromGraph path
     assert not any(n.op == "HostPerform" for n in f.maker.linker.last_ir.nodes)
+
+
+def test_widening_rows_lower_to_their_own_nodes(pt):
+    """SURVEY §8f rows 3/4 and the index tier: each op keeps a node of its own in the IR (no
+    HostPerform), OpFromGraph/SymbolicOps are inlined, unsupported scalar ops fail at compile
+    time with the op's name."""
+    pytensor, ptt = pt
+    x, y = ptt.dvector("x"), ptt.dvector("y")
+    M = ptt.dmatrix("M")
+    rng = pytensor.shared(np.random.default_rng(3), name="rng")
+    nr, u = ptt.random.uniform(0.0, 1.0, size=(8,), rng=rng).owner.outputs
+    w, v = ptt.linalg.eigh(M)
+    outs = [ptt.sort(x), ptt.argsort(x), x[x > 0], ptt.nonzero(x)[0], *pytensor.grad((ptt.concatenate([x, y]) ** 2).sum(), [x, y]),
+            ptt.gammainc(ptt.abs(x) + 1, ptt.abs(y[: x.shape[0]])), u + x[:8], pytensor.grad((w * w).sum(), M), ptt.linalg.det(M),
+            pytensor.grad(ptt.gammainc(ptt.abs(x) + 1.0, 2.0).sum(), x)]
+    f = pytensor.function([x, y, M], outs, updates={rng: nr}, mode="hip", on_unused_input="ignore")
+    ops = [n.op for n in f.maker.linker.last_ir.nodes]
+    for name in ("SortOp", "ArgSortOp", "Nonzero", "Split", "RandomVariable", "Eigh", "Det"):
+        assert name in ops, (name, ops)
+    assert "HostPerform" not in ops and "OpFromGraph" not in ops and "AllocDiag" not in ops
+    loops = [b for n in f.maker.linker.last_ir.nodes if "scalar" in n.params for b in n.params["scalar"]["body"] if b["op"] == "ScalarLoop"]
+    assert loops, "the gradient of gammainc wrt its shape parameter is a ScalarLoop inside the fused kernel"
+    with pytest.raises(NotImplementedError, match="Hyp2F1"):
+        pytensor.function([x], ptt.hyp2f1(0.5, 1.0, 1.5, ptt.sigmoid(x)), mode="hip")
