@@ -2,9 +2,12 @@
 
 TEST INFRASTRUCTURE.  The reference (``/root/reference``, requires-python >=3.12,
 pyproject.toml:13) does not import under this image's Python 3.10.12.  This
-recipe copies ``pytensor/`` into ``oracle/_ref/`` (git-ignored AND
-gpurun-ignored: a Python reference does not travel) and applies the three
-mechanical shims from SURVEY.md §8c / Appendix A:
+recipe copies ``pytensor/`` and the reference's own ``tests/`` into ``oracle/_ref/``
+(git-ignored: no reference source enters the history; NOT gpurun-ignored since round 2, so the
+built copy travels to the GPU box like any other built artefact and the drop-in can be
+exercised end to end there — ``tests/test_gpu_e2e.py``, ``tests/test_gpu_refsuite.py``, the
+``cpu_baseline`` leg of ``bench.py``) and applies the three mechanical shims from SURVEY.md
+§8c / Appendix A:
 
 1. PEP 695/646 syntax in 11 files (``type X = ...``, ``def f[T](``, ``*tuple[...]``);
 2. hashable ``slice`` in ``MetaType``'s generated ``__hash__`` (graph/utils.py:217-219);
@@ -85,6 +88,19 @@ def build(force: bool = False) -> str:
         assert old in s
         var = old.split(".")[0]
         open(p, "w").write(s.replace(old, f'getattr({var}, "add_note", lambda *_a: None)('))
+    # the reference's own test-suite (subclassed under mode="hip" by tests/test_gpu_refsuite.py)
+    tdst = os.path.join(DST, "tests")
+    shutil.copytree(os.path.join(REF, "tests"), tdst)
+    os.system(f"chmod -R u+w {tdst}")
+    for root, _, files in os.walk(tdst):
+        for f in files:
+            if f.endswith(".py"):
+                p = os.path.join(root, f)
+                s = open(p).read()
+                s2 = re.sub(r"^type (\w+) = ", r"\1 = ", s, flags=re.M)
+                s2 = re.sub(r"^(\s*def \w+)\[[^\]]*\]\(", r"\1(", s2, flags=re.M)
+                if s2 != s:
+                    open(p, "w").write(s2)
     bad = []
     for root, _, files in os.walk(pkg):
         for f in files:
@@ -111,7 +127,13 @@ def activate() -> None:
 
 
 def available() -> bool:
+    """The pristine reference is present (build container): fixtures can be regenerated."""
     return os.path.isdir(os.path.join(REF, "pytensor"))
+
+
+def importable() -> bool:
+    """A built copy exists (build container, or the GPU box where ``oracle/_ref`` travelled)."""
+    return os.path.exists(os.path.join(DST, ".built")) or available()
 
 
 if __name__ == "__main__":

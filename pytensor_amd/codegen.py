@@ -856,7 +856,7 @@ def _flat_elem(body, modes, reduce_spec, ivar):
             # by the host from the device flag; the lane reads entry 0 meanwhile)
             lines.append(f"      long long gi{k} = gx{k}[{ivar}];")
             lines.append(f"      if (gi{k} < 0) gi{k} += gn{k};")
-            lines.append(f"      if (gi{k} < 0 || gi{k} >= gn{k}) {{ *status = 1; gi{k} = 0; }}")
+            lines.append(f"      if (gi{k} < 0 || gi{k} >= gn{k}) {{ atomicOr(status, 1); gi{k} = 0; }}")
             in_names.append(f"in{k}[gi{k}]")
         else:
             in_names.append(f"s{k}")
@@ -1100,7 +1100,7 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
         elif m == "G":
             L.append(f"    long long gi{k} = gidx{k}[rowc];")
             L.append(f"    if (gi{k} < 0) gi{k} += glen{k};")
-            L.append(f"    if (gi{k} < 0 || gi{k} >= glen{k}) {{ *status = 1; gi{k} = 0; }}  // IndexError, reported by the host")
+            L.append(f"    if (gi{k} < 0 || gi{k} >= glen{k}) {{ atomicOr(status, 1); gi{k} = 0; }}  // IndexError, reported by the host")
             in_names.append(f"in{k}[gi{k}]")
         else:
             in_names.append(f"in{k}[rowc]")
@@ -1120,7 +1120,7 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
             L.append(f"    const double sv = valid ? (double)o{scatter_out} : 0.0;")
         L.append("    long long si_ = sidx[rowc];")
         L.append("    if (si_ < 0) si_ += sbins;")
-        L.append("    if (valid && (si_ < 0 || si_ >= sbins)) { *status = 1; }")
+        L.append("    if (valid && (si_ < 0 || si_ >= sbins)) { atomicOr(status, 1); }")
         L.append("    const int si = (valid && si_ >= 0 && si_ < sbins) ? (int)si_ : -1;")
     L.append("#pragma unroll\n    for (int r = 0; r < RG; r++) {")
     L.append(f"      const double wr = pt_readlane(w, r << {rest});")

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(BLOCK) void take_rows_kernel(T* __restrict__ out,
     long long j = idx[r];
     if (j < 0) j += n_rows;
     if (j < 0 || j >= n_rows) {
-      *status = 1;  // IndexError
+      atomicOr(status, 1);  // IndexError
       continue;
     }
     out[i] = x[j * sx0 + c];
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_winner_kernel(long long* __rest
     long long j = idx[i];
     if (j < 0) j += n_rows;
     if (j < 0 || j >= n_rows) {
-      *status = 1;
+      atomicOr(status, 1);
       continue;
     }
     atomicMax((long long*)&winner[j], i);
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_add_scan_kernel(
       long long j = idx[base + k];
       if (j < 0) j += n_rows;
       if (j < 0 || j >= n_rows) {
-        *status = 1;
+        atomicOr(status, 1);
         j = -1;
       }
       s_idx[k] = (int)j;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_add_atomic_kernel(
     long long j = idx[r];
     if (j < 0) j += n_rows;
     if (j < 0 || j >= n_rows) {
-      *status = 1;
+      atomicOr(status, 1);
       continue;
     }
     if constexpr (sizeof(T) == 8 && !__is_integral(T))

@@ -120,6 +120,12 @@ class DeviceArray:
         copy_into(out, self)
         return out
 
+    def contiguous_copy(self) -> "DeviceArray":
+        """A fresh contiguous copy (always a new buffer)."""
+        out = DeviceArray.empty(self.shape, self.dtype)
+        copy_into(out, self)
+        return out
+
     def to_host(self, sync=True) -> np.ndarray:
         src = self.contiguous()
         out = np.empty(self.shape, dtype=self.dtype)

@@ -192,6 +192,12 @@ def dot(node, inputs, env):
     out_dtype = str(env.graph.vars[node.outputs[0]].dtype)
     if np.dtype(out_dtype).kind in "iu":
         return [_int_dot(env, x, y, out_dtype)]
+    # Dot.make_node accepts mixed operand dtypes and upcasts (tensor/math.py Dot; np.dot does the
+    # same): f32 @ f64, int64 @ f64 reach this handler unchanged — cast to the result dtype first
+    from pytensor_amd.dispatch.elemwise import _cast
+
+    x = x if str(x.dtype) == out_dtype else _cast(env, x, out_dtype)
+    y = y if str(y.dtype) == out_dtype else _cast(env, y, out_dtype)
     if x.ndim == 2 and y.ndim == 2:
         return [gemm_device(env, 1.0, _prep2d(x), _prep2d(y))]
     if x.ndim == 2 and y.ndim == 1:

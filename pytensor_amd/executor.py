@@ -67,6 +67,62 @@ class HostValue:
         return f"HostValue({self.a!r})"
 
 
+# ---------------------------------------------------------------------------------------
+# Resident (shared-variable) inputs: coherence between the host array and its HBM copy
+# ---------------------------------------------------------------------------------------
+# The reference backends read a shared variable's storage cell on every call, so an in-place
+# edit of a borrowed value (`get_value(borrow=True)[...] = v`, `set_value(x, borrow=True)` then
+# `x *= 2`; pytensor/compile/sharedvalue.py:97-130) is seen by the next call.  A device-resident
+# copy needs to notice such edits without re-reading gigabytes per call:
+#   * arrays <= 64 KiB: a 64-bit hash of the whole content on every call (sound);
+#   * larger arrays: a fingerprint of 256 evenly spaced elements incl. the first and the last
+#     (catches bulk overwrites and scaling, the usual borrow patterns; a single-element edit
+#     between the sample points is NOT seen — `PTHIP_RESIDENT=strict` hashes everything on
+#     every call, `HipExecutable.invalidate_resident()` forces a re-upload);
+#   * `PTHIP_RESIDENT=trust`: identity only (round-1 behaviour).
+_FULL_HASH_MAX = 64 << 10
+_NSAMPLE = 256
+_sample_cache = {}
+
+try:  # xxh3: ~10 GB/s; zlib.crc32 as the always-present fallback
+    from xxhash import xxh3_64_intdigest as _hash64
+except Exception:  # pragma: no cover
+    import zlib
+
+    def _hash64(buf):
+        return zlib.crc32(buf)
+
+
+def _fingerprint(a: np.ndarray):
+    mode = os.environ.get("PTHIP_RESIDENT", "sampled")
+    if mode == "trust":
+        return None
+    if a.nbytes <= _FULL_HASH_MAX or mode == "strict":
+        if a.size == 0:
+            return 0
+        c = a if a.flags.c_contiguous else np.ascontiguousarray(a)
+        return _hash64(c.reshape(-1).view(np.uint8).data)
+    idx = _sample_cache.get(a.size)
+    if idx is None:
+        idx = _sample_cache[a.size] = np.linspace(0, a.size - 1, _NSAMPLE).astype(np.int64)
+    return a.flat[idx].tobytes()
+
+
+class ResidentEntry:
+    """One shared-variable input kept in HBM: a *stable* device buffer (frozen plans capture its
+    address; a new host value of the same shape is copied into it in place), the host array it
+    mirrors (strong reference: keeps `id` unique) and the fingerprint of that array's content."""
+
+    __slots__ = ("key", "dev", "host", "fp")
+
+    def __init__(self, key, dev, host, fp):
+        self.key, self.dev, self.host, self.fp = key, dev, host, fp
+
+
+def _resident_key(value, a):
+    return (id(value), a.ctypes.data, a.shape, a.strides, a.dtype.str)
+
+
 class KernelTimer:
     """HIP-event brackets around individual generated-kernel launches (profiling only)."""
 
@@ -161,7 +217,8 @@ class HipExecutable:
     ``pytensor.function(..., mode="hip")`` gets (``HipLinker.jit_compile``); direct users of
     the class opt in."""
 
-    def __init__(self, graph: Graph, resident=(), device: int | None = None, fuse=True, auto_freeze=False):
+    def __init__(self, graph: Graph, resident=(), device: int | None = None, fuse=True, auto_freeze=False,
+                 update_map=None):
         from pytensor_amd import dispatch  # registers handlers
         from pytensor_amd.passes import run_pipeline
 
@@ -179,7 +236,14 @@ class HipExecutable:
         if self.has_rng:
             self.auto_freeze = False
         self._handlers = dispatch.HANDLERS
-        self._resident_cache = {}  # input position -> (key, DeviceArray)
+        self._resident_cache = {}  # input position -> ResidentEntry
+        # update feedback (compile/executor.py:712-716 stores output i into the storage cell of
+        # input j after every call): {output index: resident input position}.  The new value is
+        # copied device-to-device into the resident buffer at the end of the call, so the next
+        # call neither uploads it nor leaves the captured plan (an SGD-style `updates=` loop).
+        self.update_map = {int(o): int(i) for o, i in (update_map or {}).items() if int(i) in self.resident}
+        self.stats = {"resident_uploads": 0, "eager_calls": 0, "captures": 0, "replays": 0, "capture_failures": 0}
+        self._warm = False
         self._const_cache = {}
         self._device = device
         self._capturing = False
@@ -270,20 +334,70 @@ class HipExecutable:
             if s is not None and a.shape[d] != s:
                 raise TypeError(f"input {pos} ({var.name}): static shape {var.shape} violated by {a.shape}")
         if pos in self.resident:
-            key = (id(value), a.ctypes.data, a.shape, a.strides, str(a.dtype))
-            hit = self._resident_cache.get(pos)
-            if hit is not None and hit[0] == key:
-                return hit[1]
-            dev = DeviceArray.from_host(a)
-            env.keepalive.append(a)
-            # hold a reference to the host array so that `id` stays unique
-            self._resident_cache[pos] = (key, dev, value)
-            return dev
+            return self._refresh_resident(pos, value, a, env)
         if a.dtype.kind in "iub" and a.ndim == 0:
             return HostValue(a)
         dev = DeviceArray.from_host(a)
         env.keepalive.append(a)
         return dev
+
+    def _refresh_resident(self, pos, value, a=None, env=None) -> DeviceArray:
+        """Device copy of resident input ``pos`` for the host value in the storage cell: reused
+        when the cell still holds the array that was uploaded (same object, same memory, same
+        content fingerprint); otherwise uploaded again — *into the same device buffer* when
+        shape and dtype are unchanged, so captured plans stay valid across ``set_value``."""
+        if a is None:
+            a = np.asarray(value)
+        key = _resident_key(value, a)
+        ent = self._resident_cache.get(pos)
+        if ent is not None and ent.key == key and (ent.fp is None or ent.fp == _fingerprint(a)):
+            return ent.dev
+        self.stats["resident_uploads"] += 1
+        if ent is not None and ent.dev.shape == a.shape and ent.dev.dtype == a.dtype:
+            if a.size:
+                c = a if a.flags.c_contiguous else np.ascontiguousarray(a)
+                ffi.check(ffi.lib().pthip_h2d(ent.dev.ptr, c.ctypes.data, c.nbytes))
+                if env is not None:
+                    env.keepalive.append(c)
+            ent.key, ent.host, ent.fp = key, value, _fingerprint(a)
+            return ent.dev
+        dev = DeviceArray.from_host(a)
+        if env is not None:
+            env.keepalive.append(a)
+        self._resident_cache[pos] = ResidentEntry(key, dev, value, _fingerprint(a))
+        return dev
+
+    def invalidate_resident(self, pos=None):
+        """Forget what is known about the host side of resident inputs (all, or one position):
+        the next call uploads them again.  For in-place edits the sampled fingerprint can miss."""
+        for p, ent in self._resident_cache.items():
+            if pos is None or p == pos:
+                ent.key = None
+
+    # -- update feedback -------------------------------------------------------------------
+    def _feed_updates_device(self, outs):
+        """Enqueue ``resident[pos] <- outs[o]`` (device to device, after every read of the old
+        value on the stream).  Returns the (pos, o) pairs that were fed."""
+        from pytensor_amd.device import copy_into
+
+        fed = []
+        for o, pos in self.update_map.items():
+            ent = self._resident_cache.get(pos)
+            src = outs[o]
+            if ent is None or not isinstance(src, DeviceArray) or src.shape != ent.dev.shape or src.dtype != ent.dev.dtype:
+                continue  # (shape changed: the next call uploads the new host value)
+            if not (src.buf is ent.dev.buf and src.offset == ent.dev.offset and src.strides == ent.dev.strides):
+                copy_into(ent.dev, src)
+            fed.append((pos, o))
+        return fed
+
+    def _feed_updates_host(self, fed, host):
+        """The arrays just returned are what ``Function`` installs in the storage cells: record
+        them as the host mirrors of the (already updated) resident buffers."""
+        for pos, o in fed:
+            ent = self._resident_cache[pos]
+            h = host[o]
+            ent.key, ent.host, ent.fp = _resident_key(h, h), h, _fingerprint(h)
 
     # ------------------------------------------------------------------
     def run_device(self, inputs, env=None):
@@ -349,10 +463,11 @@ class HipExecutable:
     def _signature(self, inputs):
         sig = []
         for pos, (vid, v) in enumerate(zip(self.graph.inputs, inputs)):
-            if pos in self.resident:
-                sig.append(("r", id(v)))
-                continue
             a = v if isinstance(v, np.ndarray) else np.asarray(v)
+            if pos in self.resident and self.graph.vars[vid].kind == "tensor":
+                # content changes are absorbed by an in-place re-upload; only the geometry matters
+                sig.append(("r", a.shape, a.dtype.str))
+                continue
             if self.graph.vars[vid].kind != "tensor" or (a.dtype.kind in "iub" and a.ndim == 0):
                 sig.append(("b", a.dtype.str, a.tolist()))  # baked into a plan
             else:
@@ -364,24 +479,39 @@ class HipExecutable:
             sig = self._signature(inputs)
             if self._auto_plan is not None:
                 if sig == self._auto_plan_sig:
+                    self.stats["replays"] += 1
                     return self._auto_plan(*inputs)
                 self._auto_plan.close()  # the signature moved on: capture again later
                 self._auto_plan = None
             elif sig == self._auto_sig and not self._auto_failed:
+                plan = None
                 try:
-                    self._auto_plan = self.freeze(*inputs, multi_stream="auto")
-                    self._auto_plan_sig = sig
-                    return self._auto_plan(*inputs)
-                except ffi.HipError as e:
-                    if "data-dependent host read" not in str(e):
-                        raise
-                    self._auto_failed = True  # this graph reads device data on the host: stay eager
+                    plan = self.freeze(*inputs, multi_stream="auto")
+                except Exception as e:  # noqa: BLE001 — *any* capture-time failure means "not freezable":
+                    # data-dependent host reads, an allocation that missed the arena, a HIP call that
+                    # stream capture does not support, a handler's NotImplementedError under capture.
+                    # Eager execution is unaffected; explicit freeze() calls still raise.
+                    self._auto_failed = True
+                    self.stats["capture_failures"] += 1
+                    if "data-dependent host read" not in str(e) and os.environ.get("PTHIP_WARN_CAPTURE", "1") != "0":
+                        import warnings
+
+                        warnings.warn(f"hip linker: hipGraph capture failed, staying on the eager path: {type(e).__name__}: {e}",
+                                      RuntimeWarning, stacklevel=2)
+                if plan is not None:
+                    self._auto_plan, self._auto_plan_sig = plan, sig
+                    self.stats["captures"] += 1
+                    self.stats["replays"] += 1
+                    return plan(*inputs)
             self._auto_sig = sig
         return self._call_eager(*inputs)
 
     def _call_eager(self, *inputs):
         self._ensure_device()
+        self.stats["eager_calls"] += 1
         outs, env = self.run_device(inputs)
+        self._warm = True
+        fed = self._feed_updates_device(outs) if self.update_map else ()
         lib = ffi.lib()
         host = []
         for o, vid in zip(outs, self.graph.outputs):
@@ -397,6 +527,10 @@ class HipExecutable:
         ffi.check(lib.pthip_check_status(C.byref(st)))
         raise_device_status(st.value)
         env.keepalive.clear()
+        if fed:
+            self._feed_updates_host(fed, host)
+        if not self.graph.outputs:
+            return None  # link/basic.py:690-699: a function without outputs must return None
         return tuple(host)
 
     # ------------------------------------------------------------------
@@ -449,6 +583,13 @@ class HipExecutable:
             raise NotImplementedError("hip linker: a graph that draws random numbers cannot be frozen "
                                       "(a replay would repeat the captured Philox counters)")
         self._ensure_device()
+        if not self._warm:
+            # never run before: constants are uploaded lazily and would otherwise be allocated
+            # inside the plan's arena: one plain device pass first (no update feedback)
+            _, env = self.run_device(inputs)
+            ffi.check(ffi.lib().pthip_synchronize())
+            env.keepalive.clear()
+            self._warm = True
         if multi_stream != "auto":
             return FrozenPlan(self, inputs, fetch_outputs=fetch_outputs, multi_stream=bool(multi_stream))
         single = FrozenPlan(self, inputs, fetch_outputs=fetch_outputs, multi_stream=False)
@@ -468,7 +609,15 @@ class HipExecutable:
                 plan._replay(True)
             return time.perf_counter() - t0
 
+        # the contest replays the plans for real: with update feedback that would advance the
+        # shared state, so it is snapshotted and put back
+        saved = [(pos, self._resident_cache[pos].dev, self._resident_cache[pos].dev.contiguous_copy())
+                 for pos in set(self.update_map.values()) if pos in self._resident_cache]
         t_single, t_multi = wall(single), wall(multi)
+        from pytensor_amd.device import copy_into
+
+        for _pos, dev, snap in saved:
+            copy_into(dev, snap)
         keep, drop = (single, multi) if t_single <= t_multi else (multi, single)
         drop.close()
         return keep

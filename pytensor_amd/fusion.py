@@ -248,6 +248,11 @@ def fuse_gemv_chain(g: Graph) -> Graph:
         n1 = g.nodes[k1]
         if ne.inputs.count(r) != 1:
             continue
+        # every other operand of the scalar graph must be available before the chain starts: a
+        # value that itself depends on r (e.g. the 2/N·r of a *mean* squared error, whose scale
+        # comes after a full reduction of r) would make the fused node its own ancestor
+        if any(_depends_on(g, producer, v, k1) for pos, v in enumerate(ne.inputs) if pos != r_pos):
+            continue
         store_r = (r in out_set) or len(consumers.get(r, [])) != 1
         spec = ne.params.get("reduce") or [None] * len(ne.outputs)
         w_out = ne.outputs.index(w)
@@ -298,6 +303,7 @@ def fuse_gemv_chain(g: Graph) -> Graph:
                     and g.vars[S.inputs[0]].dtype == "float64"
                     and g.vars[S.inputs[2]].dtype == "int64"
                     and producer.get(S.inputs[2], -1) < ke
+                    and not any(_depends_on(g, producer, u, kk) for u in (S.inputs[0], S.inputs[2]) for kk in (k1, ke))
                 ):
                     scatter = (pos_o, ks, S)
                     break
@@ -372,6 +378,25 @@ def fuse_gemv_chain(g: Graph) -> Graph:
     # position (the base of the absorbed scatter): restore a valid order
     out.nodes = _stable_toposort(out.nodes)
     return out
+
+
+def _depends_on(g, producer, v, k_anc, _memo=None):
+    """True when variable ``v`` is computed (transitively) from an output of node ``k_anc``."""
+    memo = {} if _memo is None else _memo
+    stack = [v]
+    seen = set()
+    while stack:
+        u = stack.pop()
+        if u in seen:
+            continue
+        seen.add(u)
+        k = producer.get(u)
+        if k is None:
+            continue
+        if k == k_anc:
+            return True
+        stack.extend(g.nodes[k].inputs)
+    return False
 
 
 def _stable_toposort(nodes):

@@ -65,18 +65,22 @@ class HipLinker(JITLinker):
 
         graph = lower_fgraph(fgraph, allow_host_fallback=os.environ.get("PTHIP_ALLOW_HOST_PERFORM") == "1")
         self.last_ir = graph
-        # shared variables = data: uploaded once and kept in HBM (re-uploaded only when the
-        # storage cell holds a different array object, i.e. after set_value)
+        # shared variables = data: uploaded once and kept in HBM (re-uploaded when the storage cell
+        # holds a different array or the array's content fingerprint changed: executor._refresh_resident)
         from pytensor.compile.sharedvalue import SharedVariable
 
         self._resident = [k for k, v in enumerate(fgraph.inputs) if isinstance(v, SharedVariable)]
+        # `updates=`: output i is stored into the storage cell of input j after every call
+        # (compile/executor.py:712-716); the executor keeps that value in HBM (fg.py:188)
+        self._update_map = dict(getattr(fgraph, "update_mapping", None) or {})
         return graph
 
     def jit_compile(self, graph):
         from pytensor_amd.executor import HipExecutable
 
         # repeated calls with one input signature replay a captured hipGraph (the CVM analogue)
-        return HipExecutable(graph, resident=getattr(self, "_resident", ()), auto_freeze=True)
+        return HipExecutable(graph, resident=getattr(self, "_resident", ()), auto_freeze=True,
+                             update_map=getattr(self, "_update_map", None))
 
     def create_thunk_inputs(self, storage_map):
         # cf. pytensor/link/pytorch/linker.py:97-104: every fgraph input,

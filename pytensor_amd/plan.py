@@ -120,18 +120,18 @@ class FrozenPlan:
         self._graphs = []  # captured hipGraphExec handles, in segment order
         self._staged = []  # input positions travelling through the staging block
         self._baked = {}  # position -> host value baked into the plan (int scalars)
-        self._resident_keys = {}
+        self._resident_devs = {}  # position -> DeviceArray (kept alive: its address is in the graphs)
+        self._fed = []  # (resident position, output index) pairs written back inside the graph
         self._sig = []
         specs = []
         for pos, (vid, value) in enumerate(zip(g.inputs, inputs)):
             var = g.vars[vid]
             a = np.asarray(value)
             self._sig.append((a.shape, str(a.dtype)))
-            if pos in exe.resident:
-                hit = exe._resident_cache.get(pos)
-                if hit is None or hit[0][0] != id(value):
-                    raise ffi.HipError("freeze(): run the executable once on these inputs first (resident upload)")
-                self._resident_keys[pos] = id(value)
+            if pos in exe.resident and var.kind == "tensor":
+                # the plan captures the address of the executable's stable resident buffer; new
+                # host values of the same geometry are copied into it (executor._refresh_resident)
+                self._resident_devs[pos] = exe._refresh_resident(pos, value, a)
             elif var.kind != "tensor" or (a.dtype.kind in "iub" and a.ndim == 0):
                 self._baked[pos] = a.copy()
             else:
@@ -191,8 +191,10 @@ class FrozenPlan:
                 dev_inputs.append(DeviceArray(self._dev_in, blk.offsets[k], v.shape, contiguous_strides(v.shape), v.dtype))
             elif pos in self._baked:
                 dev_inputs.append(HostValue(self._baked[pos]))
-            else:
-                dev_inputs.append(exe._resident_cache[pos][1])
+            elif pos in self._resident_devs:
+                dev_inputs.append(self._resident_devs[pos])
+            else:  # non-tensor shared input (cannot happen for freezable graphs: rng graphs stay eager)
+                dev_inputs.append(value)
         if capture:
             env.scheduler = self._switch
             self._begin_segment()
@@ -242,6 +244,10 @@ class FrozenPlan:
                     self._keep.append(dev_out)
             if capture:
                 self._keep += [dev_outs, env.keepalive]
+                if exe.update_map:
+                    # update feedback inside the graph: resident[pos] <- outs[o] after every read
+                    # of the old value (the warm-up pass must NOT do this: it runs for real)
+                    self._fed = exe._feed_updates_device(outs)
             ok = True
         finally:
             if capture:
@@ -309,9 +315,9 @@ class FrozenPlan:
                 if a.shape != v.shape or a.dtype != v.dtype:
                     raise TypeError(f"frozen plan: input {pos} changed signature {self._sig[pos]} -> {(a.shape, str(a.dtype))}")
             v[...] = a
-        for pos, key in self._resident_keys.items():
-            if key != id(inputs[pos]):
-                raise ValueError(f"frozen plan: resident input {pos} was replaced; re-freeze")
+        for pos, dev in self._resident_devs.items():
+            if self.exe._refresh_resident(pos, inputs[pos]) is not dev:
+                raise ValueError(f"frozen plan: resident input {pos} changed shape or dtype; re-freeze")
         for pos, b in self._baked.items():
             if not np.array_equal(np.asarray(inputs[pos]), b):
                 raise ValueError(f"frozen plan: scalar input {pos} is baked into the plan and changed")
@@ -332,6 +338,10 @@ class FrozenPlan:
             else:
                 res.append(self._out_block.views[k].copy())
                 k += 1
+        if self._fed:
+            self.exe._feed_updates_host(self._fed, res)
+        if not res and not self._out_meta:
+            return None  # a function without outputs returns None (link/basic.py:690-699)
         return tuple(res)
 
     def close(self):

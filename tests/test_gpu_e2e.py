@@ -1,0 +1,410 @@
+"""GPU, end to end: ``pytensor.function(..., mode="hip")`` against the reference's C linker
+(``mode="CVM"``) in the same process, on the MI355X box.
+
+This is the drop-in boundary itself: ``FunctionMaker`` → rewrites → ``HipLinker`` →
+``JITLinker`` thunk (link/basic.py:670-684) → ``Function.__call__`` (compile/executor.py:651-744)
+with its real storage cells, shared variables and update feedback.  Every function is called at
+least three times (eager → hipGraph capture → replay).  Helper shaped after
+tests/link/pytorch/test_basic.py:41-87 of the reference.
+"""
+import numpy as np
+import pytest
+
+import e2e_util as E
+from e2e_util import assert_close, compare_hip_and_cvm, hip_executable
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pt():
+    pytensor = E.activate()
+    if not E.have_gpu():
+        pytest.fail("no HIP device visible: GPU tests must run on the MI355X box")
+    import pytensor.tensor as ptt
+
+    return pytensor, ptt
+
+
+def test_native_library_is_what_runs(pt):
+    """The thunk of a ``mode="hip"`` function is a HipExecutable bound to libpthip.so."""
+    pytensor, ptt = pt
+    from pytensor_amd import ffi
+
+    x = ptt.dvector("x")
+    f = pytensor.function([x], ptt.exp(x).sum(), mode="hip")
+    exe = hip_executable(f)
+    assert ffi.lib()._name.endswith("pytensor_amd/libpthip.so")
+    r = f(np.linspace(0, 1, 1000))
+    assert isinstance(r, np.ndarray) and r.shape == () and r.dtype == np.float64
+    assert exe.graph.nodes, "lowered graph is empty"
+
+
+def test_c1_gauss_sum_and_grad(pt):
+    pytensor, ptt = pt
+    x, mu = ptt.dvector("x"), ptt.dscalar("mu")
+    y = ptt.exp(-0.5 * (x - mu) ** 2).sum()
+    rng = np.random.default_rng(1)
+    # y is a sum of 1e5 positive terms: no cancellation, plain rtol
+    compare_hip_and_cvm([x, mu], [y, pytensor.grad(y, x)], [rng.normal(size=100_000), 0.3], must_freeze=True)
+
+
+def test_elemwise_broadcast_and_mixed_dtypes(pt):
+    pytensor, ptt = pt
+    a = ptt.tensor("a", shape=(None, 1, None), dtype="float64")
+    b = ptt.tensor("b", shape=(1, None, None), dtype="float32")
+    i = ptt.lvector("i")
+    rng = np.random.default_rng(2)
+    outs = [ptt.tanh(a) * b + ptt.sqrt(ptt.abs(a)), (a > b) & (b < 0.5), ptt.switch(a > 0, i, -i) // 3, ptt.cast(i, "int8") * 2,
+            ptt.log1p(ptt.exp(b))]
+    compare_hip_and_cvm([a, b, i], outs, [rng.normal(size=(7, 1, 5)), rng.normal(size=(1, 6, 5)).astype("float32"),
+                                          rng.integers(-50, 50, size=5)])
+
+
+def test_runtime_broadcast_error_is_a_valueerror(pt):
+    pytensor, ptt = pt
+    x, y = ptt.dmatrix("x"), ptt.dmatrix("y")
+    f = pytensor.function([x, y], x + y, mode="hip")
+    f(np.ones((3, 4)), np.ones((3, 4)))
+    with pytest.raises(ValueError):  # elemwise.py:825-840
+        f(np.ones((3, 4)), np.ones((1, 4)))
+    with pytest.raises(TypeError):  # TensorType.filter (type.py:162): wrong ndim never reaches the thunk
+        f(np.ones(3), np.ones((3, 4)))
+
+
+@pytest.mark.parametrize("axis", [None, 0, 1, (0, 2), -1])
+def test_careduce_axes(pt, axis):
+    pytensor, ptt = pt
+    x = ptt.dtensor3("x")
+    xi = ptt.ltensor3("xi")
+    rng = np.random.default_rng(3)
+    xv = rng.normal(size=(9, 17, 33))
+    # sums of N(0,1) values cancel: |error| is relative to sum|x_i|, not to |sum x_i|
+    compare_hip_and_cvm([x], [x.sum(axis=axis)], [xv], atol=1e-12 * np.abs(xv).sum() / 10)
+    compare_hip_and_cvm([x, xi], [x.max(axis=axis), x.min(axis=axis), ptt.abs(x).prod(axis=axis) if axis != None else x.max(),
+                                  xi.sum(axis=axis), (xi > 0).all(axis=axis), (xi > 90).any(axis=axis)],
+                        [xv, rng.integers(-100, 100, size=(9, 17, 33))])
+
+
+def test_softmax_family(pt):
+    pytensor, ptt = pt
+    from pytensor.tensor.special import log_softmax, softmax
+
+    x = ptt.dmatrix("x")
+    rng = np.random.default_rng(4)
+    xv = rng.normal(size=(64, 300)) * 3
+    compare_hip_and_cvm([x], [softmax(x, axis=-1), log_softmax(x, axis=-1), ptt.logsumexp(x, axis=1), softmax(x, axis=0)], [xv],
+                        atol=1e-15)  # log_softmax entries near 0 (max element of a peaked row)
+
+
+def test_blas_family(pt):
+    pytensor, ptt = pt
+    A, B, Cm = ptt.dmatrix("A"), ptt.dmatrix("B"), ptt.dmatrix("C")
+    v, w = ptt.dvector("v"), ptt.dvector("w")
+    rng = np.random.default_rng(5)
+    Av, Bv, Cv = rng.normal(size=(130, 70)), rng.normal(size=(70, 90)), rng.normal(size=(130, 90))
+    vv, wv = rng.normal(size=70), rng.normal(size=130)
+    outs = [ptt.dot(A, B), 0.5 * ptt.dot(A, B) + 2.0 * Cm, ptt.dot(A, v), wv.mean() * w + 3.0 * ptt.dot(A, v), ptt.dot(w, A),
+            ptt.dot(A.T, Cm), ptt.outer(w, v) + A]
+    # dot products of N(0,1) vectors cancel: bound by K * eps * |a||b| ~ 70 * 1e-16 * 10
+    f, _ = compare_hip_and_cvm([A, B, Cm, v, w], outs, [Av, Bv, Cv, vv, wv], atol=2e-13)
+    ops = [n.op for n in hip_executable(f).source_graph.nodes]
+    assert any(o in ops for o in ("Dot22", "Gemm")) and "Gemv" in ops, ops
+
+
+def test_blas_mixed_dtypes(pt):
+    """Dot.make_node upcasts mixed operands (dispatch/blas.py): f32 @ f64, int64 @ f64."""
+    pytensor, ptt = pt
+    X32, Xi = ptt.fmatrix("X32"), ptt.lmatrix("Xi")
+    w = ptt.dvector("w")
+    W = ptt.dmatrix("W")
+    rng = np.random.default_rng(6)
+    compare_hip_and_cvm([X32, Xi, w, W], [ptt.dot(X32, w), ptt.dot(Xi, w), ptt.dot(X32, W), ptt.dot(Xi, W)],
+                        [rng.normal(size=(40, 30)).astype("float32"), rng.integers(-5, 5, size=(40, 30)), rng.normal(size=30),
+                         rng.normal(size=(30, 20))], atol=1e-13)
+
+
+def test_batched_dot_f32(pt):
+    pytensor, ptt = pt
+    X, Y = ptt.ftensor3("X"), ptt.ftensor3("Y")
+    rng = np.random.default_rng(7)
+    f, _ = compare_hip_and_cvm([X, Y], [ptt.matmul(X, Y)], [rng.normal(size=(6, 40, 24)).astype("float32"),
+                                                          rng.normal(size=(6, 24, 56)).astype("float32")], atol=2e-5)
+    assert "BatchedDot" in [n.op for n in hip_executable(f).source_graph.nodes]
+
+
+def test_cholesky_solves_and_nan_on_failure(pt):
+    pytensor, ptt = pt
+    S, b = ptt.dmatrix("S"), ptt.dvector("b")
+    L = ptt.linalg.cholesky(S)
+    rng = np.random.default_rng(8)
+    A = rng.normal(size=(48, 48))
+    Sv = A @ A.T + 48 * np.eye(48)
+    outs = [L, ptt.linalg.solve_triangular(L, b, lower=True), ptt.linalg.solve(S, b, assume_a="pos"), ptt.log(ptt.diagonal(L)).sum()]
+    f, _ = compare_hip_and_cvm([S, b], outs, [Sv, rng.normal(size=48)], rtol=1e-11, atol=1e-13)
+    Sv[20, 20] = -1.0  # not positive definite: NaN, not an exception (cholesky.py:78-80)
+    r = f(Sv, np.ones(48))
+    assert np.isnan(r[0]).all()
+
+
+def _hier(ptt, pytensor, N, K, G, seed=0):
+    rng = np.random.default_rng(seed)
+    y = pytensor.shared(rng.normal(size=N), name="y")
+    X = pytensor.shared(rng.normal(size=(N, K)), name="X")
+    gidx = pytensor.shared(rng.integers(0, G, size=N), name="gidx")
+    A = rng.normal(size=(K, K))
+    Sigma = pytensor.shared(A @ A.T + K * np.eye(K), name="Sigma")
+    mu_g, log_tau, log_sigma = ptt.dscalar("mu_g"), ptt.dscalar("log_tau"), ptt.dscalar("log_sigma")
+    z, beta = ptt.dvector("z"), ptt.dvector("beta")
+    tau, sigma = ptt.exp(log_tau), ptt.exp(log_sigma)
+    a = mu_g + tau * z
+    L = ptt.linalg.cholesky(Sigma)
+    alpha = ptt.linalg.solve_triangular(L, beta, lower=True)
+    logp_beta = -0.5 * (alpha**2).sum() - ptt.log(ptt.diagonal(L)).sum() - 0.5 * K * np.log(2 * np.pi)
+    eta = a[gidx] + ptt.dot(X, beta)
+    r = (y - eta) / sigma
+    logp_y = (-0.5 * r**2 - log_sigma - 0.5 * np.log(2 * np.pi)).sum()
+    logp_z = (-0.5 * z**2 - 0.5 * np.log(2 * np.pi)).sum()
+    logp = logp_y + logp_z + logp_beta - 0.5 * (mu_g**2 + log_tau**2 + log_sigma**2)
+    params = [mu_g, log_tau, z, beta, log_sigma]
+    vals = [np.float64(0.1), np.float64(-0.2), rng.normal(size=G), 0.1 * rng.normal(size=K), np.float64(0.3)]
+    return params, [logp, *pytensor.grad(logp, params)], vals, dict(y=y, X=X, gidx=gidx, Sigma=Sigma)
+
+
+def test_c4_hierarchical_logp_grad_with_shared_data(pt):
+    """BASELINE configs[3] through the real Function: data as shared
+    variables (device resident), parameters per call; `set_value` between calls re-uploads."""
+    pytensor, ptt = pt
+    N, K, G = 20_000, 32, 16
+    params, outs, vals, sh = _hier(ptt, pytensor, N, K, G)
+    # logp ~ -1e5 is a sum of same-sign terms; the gradients are sums of N mixed-sign terms:
+    # error relative to sum|terms| ~ N * 1 -> atol 1e-12 * N * 0.1
+    f, r0 = compare_hip_and_cvm(params, outs, vals, calls=4, atol=1e-12 * N * 0.1, must_freeze=True)
+    exe = hip_executable(f)
+    assert exe.resident, "shared variables should be device resident"
+    # new data through set_value (compile/sharedvalue.py:97-130): both backends see it
+    rng = np.random.default_rng(99)
+    f_ref = pytensor.function(params, outs, mode=E.reference_mode())
+    sh["y"].set_value(rng.normal(size=N))
+    want = f_ref(*vals)
+    for c in range(3):
+        got = f(*vals)
+        for k, (a, b) in enumerate(zip(got, want)):
+            assert_close(a, b, f"after set_value: output {k}, call {c}", atol=1e-12 * N * 0.1)
+    assert abs(float(got[0]) - float(r0[0])) > 1.0, "set_value had no effect"
+    # other parameter values, same signature: replay path
+    vals2 = [v * 1.5 for v in vals]
+    want = f_ref(*vals2)
+    for k, (a, b) in enumerate(zip(f(*vals2), want)):
+        assert_close(a, b, f"other parameters: output {k}", atol=1e-12 * N * 0.1)
+    assert exe._auto_plan is not None, "the call after a parameter change must stay on the replay path"
+
+
+def test_borrowed_shared_value_mutated_in_place(pt):
+    """`get_value(borrow=True)[...] = v` and `set_value(x, borrow=True)` + in-place edits
+    (compile/sharedvalue.py:97-130): the reference backends read the storage cell's memory on
+    every call, so the new contents must be seen (VERDICT r1 missing-5)."""
+    pytensor, ptt = pt
+    rng = np.random.default_rng(10)
+    d = pytensor.shared(rng.normal(size=50_000), name="d", borrow=True)
+    s = ptt.dscalar("s")
+    out = [(d * s).sum(), ptt.exp(-d * d).sum()]
+    f = pytensor.function([s], out, mode="hip")
+    f_ref = pytensor.function([s], out, mode=E.reference_mode())
+    for step in range(3):
+        for c in range(3):
+            for k, (a, b) in enumerate(zip(f(1.5), f_ref(1.5))):
+                assert_close(a, b, f"step {step} call {c} output {k}", atol=1e-10)
+        buf = d.get_value(borrow=True)
+        buf[...] = rng.normal(size=buf.shape)  # bulk overwrite in place
+    # an array handed over with borrow=True and edited afterwards
+    mine = rng.normal(size=50_000)
+    d.set_value(mine, borrow=True)
+    f(1.5)
+    f(1.5)
+    mine *= 2.0
+    for k, (a, b) in enumerate(zip(f(1.5), f_ref(1.5))):
+        assert_close(a, b, f"borrowed set_value then in-place edit: output {k}", atol=1e-10)
+
+
+def test_updates_sgd_loop_stays_on_device_and_replays(pt):
+    """An SGD-style ``updates=`` function (compile/executor.py:712-728 update feedback): same
+    trajectory as the reference C linker, the weight stays in HBM between calls and the calls
+    after the second run on the captured plan."""
+    pytensor, ptt = pt
+    rng = np.random.default_rng(11)
+    Xv, yv = rng.normal(size=(4096, 64)), rng.normal(size=4096)
+    w0 = rng.normal(size=64) * 0.1
+
+    def build(mode):
+        X, y = pytensor.shared(Xv, name="X"), pytensor.shared(yv, name="y")
+        w = pytensor.shared(w0.copy(), name="w")
+        lr = ptt.dscalar("lr")
+        loss = ((ptt.dot(X, w) - y) ** 2).mean()
+        g = pytensor.grad(loss, w)
+        return pytensor.function([lr], loss, updates={w: w - lr * g}, mode=mode), w
+
+    f_hip, w_hip = build("hip")
+    f_ref, w_ref = build(E.reference_mode())
+    for step in range(8):
+        a, b = f_hip(0.05), f_ref(0.05)
+        assert_close(a, b, f"loss at step {step}", rtol=1e-11)
+        assert_close(w_hip.get_value(), w_ref.get_value(), f"weights after step {step}", rtol=1e-10, atol=1e-13)
+    exe = hip_executable(f_hip)
+    assert exe._auto_plan is not None, "the update loop never reached the replay path"
+    assert exe.stats["resident_uploads"] <= 4, exe.stats  # X, y, w once (+1 slack); not once per step
+    # the user resets the weight: honoured, trajectory restarts identically
+    w_hip.set_value(w0.copy())
+    w_ref.set_value(w0.copy())
+    for step in range(3):
+        assert_close(f_hip(0.05), f_ref(0.05), f"loss after reset, step {step}", rtol=1e-11)
+    assert_close(w_hip.get_value(), w_ref.get_value(), "weights after reset", rtol=1e-10, atol=1e-13)
+
+
+def test_function_without_outputs_only_updates(pt):
+    pytensor, ptt = pt
+    c = pytensor.shared(np.zeros(5), name="c")
+    inc = ptt.dvector("inc")
+    f = pytensor.function([inc], [], updates={c: c + inc}, mode="hip")
+    for _ in range(4):
+        assert f(np.arange(5.0)) == []
+    np.testing.assert_array_equal(c.get_value(), 4 * np.arange(5.0))
+    g = pytensor.function([inc], None, updates={c: c * 0 + inc}, mode="hip")
+    g_ref = pytensor.function([inc], None, updates={c: c * 0 + inc}, mode=E.reference_mode())
+    assert g(np.ones(5)) == g_ref(np.ones(5))
+    np.testing.assert_array_equal(c.get_value(), np.ones(5))
+    # no fgraph outputs at all: the JITLinker thunk asserts the callable returned None (link/basic.py:690-699)
+    h = pytensor.function([inc], [], mode="hip", on_unused_input="ignore")
+    assert h(np.ones(5)) == []
+
+
+def test_scan_gru_small(pt):
+    """BASELINE configs[4] shape at T=20, B=8, H=64 fp32."""
+    pytensor, ptt = pt
+    T, B, H = 20, 8, 64
+    rng = np.random.default_rng(12)
+    mats = [pytensor.shared((rng.normal(size=(H, H)) * 0.1).astype("float32"), name=f"W{k}") for k in range(6)]
+    bias = [pytensor.shared((rng.normal(size=(1, H)) * 0.1).astype("float32"), name=f"b{k}", shape=(1, H)) for k in range(3)]
+    Wz, Wr, Wh, Uz, Ur, Uh = mats
+    bz, br, bh = bias
+    xs, h0 = ptt.ftensor3("xs"), ptt.fmatrix("h0")
+
+    def step(x, h):
+        z = ptt.sigmoid(ptt.dot(x, Wz) + ptt.dot(h, Uz) + bz)
+        r = ptt.sigmoid(ptt.dot(x, Wr) + ptt.dot(h, Ur) + br)
+        hh = ptt.tanh(ptt.dot(x, Wh) + ptt.dot(r * h, Uh) + bh)
+        return (1 - z) * h + z * hh
+
+    hs = pytensor.scan(step, sequences=[xs], outputs_info=[h0], return_updates=False)
+    f, _ = compare_hip_and_cvm([xs, h0], [hs[-1].sum(), hs], [rng.normal(size=(T, B, H)).astype("float32"),
+                                                            np.zeros((B, H), dtype="float32")], rtol=2e-5, atol=2e-5)
+    assert "Scan" in [n.op for n in hip_executable(f).source_graph.nodes]
+
+
+def test_scan_cumulative_with_until_and_grad(pt):
+    pytensor, ptt = pt
+    xs, s0 = ptt.dmatrix("xs"), ptt.dvector("s0")
+    out = pytensor.scan(lambda x, s: ptt.tanh(s + x), sequences=[xs], outputs_info=[s0], return_updates=False)
+    cost = (out[-1] ** 2).sum()
+    rng = np.random.default_rng(13)
+    compare_hip_and_cvm([xs, s0], [cost, *pytensor.grad(cost, [xs, s0])], [rng.normal(size=(12, 5)), rng.normal(size=5)], rtol=1e-11,
+                        atol=1e-14)
+
+
+def test_indexing_tier_is_bit_exact(pt):
+    pytensor, ptt = pt
+    x, M = ptt.dvector("x"), ptt.dmatrix("M")
+    idx = ptt.lvector("idx")
+    rng = np.random.default_rng(14)
+    outs = [x[idx], M[idx], M[:, ::-2], M[1:-1, 3], ptt.set_subtensor(x[2:5], 7.0), ptt.inc_subtensor(ptt.zeros(11)[idx], x[idx]),
+            ptt.concatenate([x, x[::-1]]), M.T.reshape((-1,))[:9], ptt.alloc(x[0], 3, 4), M.shape[0] * 2 + x.shape[0], ptt.argmax(M, axis=1),
+            ptt.diagonal(M), ptt.cumsum(x), ptt.sort(x), ptt.argsort(x)]
+    f, got = compare_hip_and_cvm([x, M, idx], outs, [rng.normal(size=11), rng.normal(size=(11, 13)), rng.integers(-11, 11, size=20)], rtol=0)
+    with pytest.raises(IndexError):
+        f(np.ones(11), np.ones((11, 13)), np.array([0, 11]))
+
+
+def test_random_uniform_with_rng_update(pt):
+    """A shared Generator advanced through ``updates=`` (tensor/random/op.py): three calls give
+    the three blocks the reference's C linker gives (uniform is the bit-exact sampler)."""
+    pytensor, ptt = pt
+
+    def build(mode):
+        rng = pytensor.shared(np.random.Generator(np.random.Philox(key=7)), name="rng")
+        nr, u = ptt.random.uniform(-1.0, 2.0, size=(1000,), rng=rng).owner.outputs
+        return pytensor.function([], u, updates={rng: nr}, mode=mode)
+
+    f_hip, f_ref = build("hip"), build(E.reference_mode())
+    for c in range(3):
+        a, b = f_hip(), f_ref()
+        np.testing.assert_array_equal(a, b, err_msg=f"draw {c}")
+
+
+def test_function_copy_givens_and_trust_input(pt):
+    pytensor, ptt = pt
+    x = ptt.dvector("x")
+    s = pytensor.shared(np.arange(4.0), name="s")
+    f = pytensor.function([x], (x * s).sum(), mode="hip")
+    assert float(f(np.ones(4))) == 6.0
+    s2 = pytensor.shared(np.ones(4) * 2, name="s2")
+    f2 = f.copy(swap={s: s2})  # compile/executor.py Function.copy: re-links with the same linker class
+    assert float(f2(np.ones(4))) == 8.0 and float(f(np.ones(4))) == 6.0
+    f.trust_input = True
+    for _ in range(3):
+        assert float(f(np.ones(4))) == 6.0
+    y = ptt.dvector("y")
+    g = pytensor.function([y], ptt.exp(x), givens={x: y * 0}, mode="hip")
+    np.testing.assert_array_equal(g(np.ones(3)), np.ones(3))
+
+
+def test_outputs_are_fresh_and_do_not_alias_inputs(pt):
+    """link/vm.py:860-880 no_recycling semantics + aliasing.py:165-260 (DeepCopyOp)."""
+    pytensor, ptt = pt
+    x = ptt.dvector("x")
+    f = pytensor.function([x], [x, x[::2], ptt.exp(x)], mode="hip")
+    xv = np.arange(6.0)
+    a1 = f(xv)
+    a2 = f(xv)
+    a3 = f(xv)
+    for r in (a1, a2, a3):
+        assert not np.shares_memory(r[0], xv)
+    keep = [r.copy() for r in a1]
+    a3[2][...] = -1.0  # scribbling over a later result must not change an earlier one
+    a2[0][...] = -1.0
+    for k, r in zip(keep, a1):
+        np.testing.assert_array_equal(k, r)
+
+
+def test_wide_model_many_fused_kernels(pt):
+    """north_star's "~200 fused Elemwise" scale: 40 independent likelihood terms in one graph."""
+    pytensor, ptt = pt
+    rng = np.random.default_rng(15)
+    N = 4000
+    mu, ls = ptt.dvector("mu"), ptt.dvector("ls")
+    terms = []
+    for k in range(40):
+        yk = pytensor.shared(rng.normal(size=N) + 0.1 * k, name=f"y{k}")
+        r = (yk - mu[k]) * ptt.exp(-ls[k])
+        fam = k % 4
+        if fam == 0:
+            terms.append((-0.5 * r**2 - ls[k]).sum())
+        elif fam == 1:
+            terms.append((-ptt.log1p(r**2 / 3.0) * 2.0 - ls[k]).sum())
+        elif fam == 2:
+            terms.append((-ptt.abs(r) - ls[k]).sum())
+        else:
+            terms.append((-r - 2.0 * ptt.softplus(-r) - ls[k]).sum())
+    logp = ptt.add(*terms)
+    compare_hip_and_cvm([mu, ls], [logp, *pytensor.grad(logp, [mu, ls])], [rng.normal(size=40) * 0.1, rng.normal(size=40) * 0.1],
+                        atol=1e-12 * N, must_freeze=True)
+
+
+def test_profile_flag_reports_device_time(pt):
+    """``pytensor.function(profile=True)``: the hip thunk feeds ``vm_call_time`` like
+    any VM and exposes per-node device time through ``update_profile``."""
+    pytensor, ptt = pt
+    x = ptt.dvector("x")
+    f = pytensor.function([x], [ptt.tanh(x).sum(), ptt.exp(x)], mode="hip", profile=True)
+    for _ in range(4):
+        f(np.ones(10_000))
+    assert f.profile.fct_callcount >= 3 and f.profile.vm_call_time > 0
