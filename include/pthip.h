@@ -37,7 +37,11 @@ enum pthip_dtype {
   PTHIP_I64 = 4,
   PTHIP_U8 = 5,
   PTHIP_F32 = 6,
-  PTHIP_F64 = 7
+  PTHIP_F64 = 7,
+  PTHIP_U16 = 8,
+  PTHIP_U32 = 9,
+  PTHIP_U64 = 10,
+  PTHIP_F16 = 11 /* storage type; arithmetic rounds to half after every scalar op, as NumPy does */
 };
 
 /* CAReduce scalar ops (pytensor/tensor/elemwise.py:1233; subclasses tensor/math.py:3498,3587,468,475,3438,3468) */

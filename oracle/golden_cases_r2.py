@@ -1,0 +1,138 @@
+"""Golden cases added in round 2 (imported by ``make_golden.py``).  TEST INFRASTRUCTURE.
+
+What they pin: mixed-dtype ``Dot``, BLAS nodes whose alpha/beta are computed on the
+device, the SGD/mean-squared-error graph that made ``fuse_gemv_chain`` produce a cycle, the
+boundary dtypes ``TensorType`` carries beyond round 1 (pytensor/tensor/type.py:40-57:
+uint16/32/64 on the bit-exact tier, float16 as a storage type) and raw ``CAReduce`` nodes that
+accumulate wide and store narrow (tests/tensor/test_elemwise.py:444 ``TestCAReduce``).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytensor
+import pytensor.scalar as ps
+import pytensor.tensor as pt
+from pytensor.tensor.elemwise import CAReduce
+
+from make_golden import case
+
+
+@case("dot_mixed_dtypes")
+def dot_mixed_dtypes():
+    # Dot.make_node upcasts mixed operands (tensor/math.py Dot; np.dot does the same)
+    rng = np.random.default_rng(60)
+    X32, Xi = pt.fmatrix("X32"), pt.lmatrix("Xi")
+    w, W = pt.dvector("w"), pt.dmatrix("W")
+    v32 = pt.fvector("v32")
+    outs = [pt.dot(X32, w), pt.dot(Xi, w), pt.dot(X32, W), pt.dot(Xi, W), pt.dot(w, W), pt.dot(v32, W), pt.dot(v32, w)]
+    vals = {"X32": rng.normal(size=(9, 11)).astype("float32"), "Xi": rng.integers(-5, 5, size=(9, 11)), "w": rng.normal(size=11),
+            "W": rng.normal(size=(11, 6)), "v32": rng.normal(size=11).astype("float32")}
+    return [X32, Xi, w, W, v32], outs, vals
+
+
+@case("blas_device_alpha")
+def blas_device_alpha():
+    # alpha / beta that are functions of an *input* scalar (an SGD step size): the rewritten graph
+    # holds Gemv / Gemm / Dot22Scalar / Ger nodes whose scalars live on the device
+    rng = np.random.default_rng(61)
+    A, B, Cm = pt.dmatrix("A"), pt.dmatrix("B"), pt.dmatrix("C")
+    x, y = pt.dvector("x"), pt.dvector("y")
+    lr, mom = pt.dscalar("lr"), pt.dscalar("mom")
+    outs = [
+        y - lr * pt.dot(A, x),  # Gemv(y, -lr, A, x, 1)
+        mom * y + lr * pt.dot(A, x),  # Gemv with both scalars computed
+        Cm - lr * pt.dot(A, B),  # Gemm(C, -lr, A, B, 1)
+        mom * Cm + (lr * 2.0) * pt.dot(A, B),
+        lr * pt.dot(A, B),  # Dot22Scalar
+        A + lr * pt.outer(y, x),  # Ger
+    ]
+    vals = {"A": rng.normal(size=(13, 9)), "B": rng.normal(size=(9, 7)), "C": rng.normal(size=(13, 7)), "x": rng.normal(size=9),
+            "y": rng.normal(size=13), "lr": np.asarray(0.05), "mom": np.asarray(0.9)}
+    return [A, B, Cm, x, y, lr, mom], outs, vals
+
+
+@case("sgd_mse_update")
+def sgd_mse_update():
+    # mean squared error + one gradient step: the backward Gemv's vector is scaled by 2/N where N
+    # reaches the graph through a *reduction of the forward Gemv's output*; fusing forward and
+    # backward Gemv into one GemvChain would make the chain its own ancestor (round-2 regression)
+    rng = np.random.default_rng(62)
+    X, y, w = pt.dmatrix("X"), pt.dvector("y"), pt.dvector("w")
+    lr = pt.dscalar("lr")
+    loss = ((pt.dot(X, w) - y) ** 2).mean()
+    g = pytensor.grad(loss, w)
+    return [X, y, w, lr], [loss, w - lr * g], {"X": rng.normal(size=(300, 17)), "y": rng.normal(size=300), "w": rng.normal(size=17) * 0.1,
+                                                "lr": np.asarray(0.05)}
+
+
+@case("unsigned_ints")
+def unsigned_ints():
+    # bit-exact tier on the unsigned dtypes: arithmetic wraps, Sum accumulates in uint64
+    # (elemwise.py:1383-1417), comparisons between signed and unsigned go through the common type
+    rng = np.random.default_rng(63)
+    a8, a16, a32, a64 = (pt.vector(n, dtype=d) for n, d in (("a8", "uint8"), ("a16", "uint16"), ("a32", "uint32"), ("a64", "uint64")))
+    M16 = pt.matrix("M16", dtype="uint16")
+    i = pt.lvector("i")
+    idx = pt.lvector("idx")
+    u = lambda v, d: np.asarray(v, dtype=d)  # same-dtype constants: a Python int constant would be int8 and
+    # upcast the result to int64, where the reference's C code multiplies in 32 bits (C promotion
+    # of uint32 * int8) but its NumPy linker in int64 — not pinnable, the two disagree
+    outs = [
+        a8 + a8, a16 * a16, a32 - a32[::-1], a64 // u(3, "uint64") + a64 % u(7, "uint64"), a16 + a8, a32 * u(3, "uint32"),
+        pt.cast(a64 % u(1000, "uint64"), "uint16"), pt.cast(abs(i), "uint32"),
+        pt.cast(a32, "float64") / 7.0, a8 < a16, pt.eq(a32, a32[::-1]), pt.maximum(a16, a16[::-1]), a16 & u(0xFF, "uint16"),
+        a32 | u(1, "uint32"), a64 ^ a64[::-1],
+        ~a16, a8.sum(), a16.sum(), a32.sum(), a64.sum(), a16.prod(), M16.sum(axis=0), M16.sum(axis=1), M16.max(axis=1), M16.max(axis=0),
+        a32.max(), a64.max(), a16[idx], M16[idx], pt.set_subtensor(a32[1:4], u(7, "uint32")), pt.inc_subtensor(a64[idx], a64[idx]), pt.sort(a16),
+        pt.argsort(a32), pt.cumsum(a64), pt.argmax(M16, axis=1), pt.concatenate([a16, a16[::-1]]), pt.switch(a8 > u(100, "uint8"), a16, a16 + a16),
+        abs(a32),
+    ]
+    n = 37
+    vals = {"a8": rng.integers(0, 256, size=n).astype("uint8"), "a16": rng.integers(0, 65536, size=n).astype("uint16"),
+            "a32": rng.integers(0, 2**32, size=n).astype("uint32"), "a64": rng.integers(0, 2**52, size=n).astype("uint64") * 2 + 1,  # (< 2^53: Maximum.c_code's `nan("")` arm makes
+            # the C ternary a double, so the reference's C linker rounds 64-bit integer maxima above 2^53 — not pinnable)
+            "M16": rng.integers(0, 65536, size=(n, 11)).astype("uint16"), "i": rng.integers(-50, 50, size=n), "idx": np.array([3, 0, 36, 3, 11])}
+    return [a8, a16, a32, a64, M16, i, idx], outs, vals
+
+
+@case("careduce_narrow_out")
+def careduce_narrow_out():
+    # a raw CAReduce keeps the input dtype on the output and accumulates wide (TestCAReduce cases)
+    rng = np.random.default_rng(64)
+    xi8, xu8 = pt.matrix("xi8", dtype="int8"), pt.matrix("xu8", dtype="uint8")
+    xi16, xb = pt.matrix("xi16", dtype="int16"), pt.matrix("xb", dtype="bool")
+    # NOT pinned here: Minimum over an unsigned dtype.  The reference's C code seeds the
+    # accumulator with the literal 1 for every `uint*` input (elemwise.py:1609-1611), so its C
+    # linker returns min(1, true minimum) while its NumPy linker returns the true minimum; the hip
+    # linker follows NumPy (tests/test_gpu_dtypes.py checks that against np.minimum.reduce).
+    outs = []
+    for x in (xi8, xu8, xi16):
+        for axis in (None, (0,), (1,)):
+            outs += [CAReduce(ps.add, axis=axis)(x), CAReduce(ps.mul, axis=axis)(x), CAReduce(ps.maximum, axis=axis)(x),
+                     CAReduce(ps.or_, axis=axis)(x), CAReduce(ps.and_, axis=axis)(x), CAReduce(ps.xor, axis=axis)(x)]
+            if x is not xu8:
+                outs.append(CAReduce(ps.minimum, axis=axis)(x))
+    outs += [CAReduce(ps.add, axis=None)(xb), CAReduce(ps.mul, axis=(0,))(xb), CAReduce(ps.or_, axis=(1,))(xb), CAReduce(ps.xor, axis=None)(xb)]
+    vals = {"xi8": rng.integers(-128, 128, size=(5, 6)).astype("int8"), "xu8": rng.integers(0, 256, size=(5, 6)).astype("uint8"),
+            "xi16": rng.integers(-3000, 3000, size=(5, 6)).astype("int16"), "xb": rng.integers(0, 2, size=(5, 6)).astype("bool")}
+    return [xi8, xu8, xi16, xb], outs, vals
+
+
+@case("float16_storage", rtol=1e-3, py_rtol=1e-3)
+def float16_storage():
+    # float16 is a storage type: the reference has no C code for it (Elemwise falls back to
+    # `perform`: NumPy ufuncs, one rounding to half per scalar op); Sum accumulates in float32.
+    # rtol 1e-3 = one half ulp (2^-10): +,-,*,/ are reproduced exactly, libm-style ops may differ
+    # from NumPy's float32 kernels by one float32 ulp before the rounding to half
+    rng = np.random.default_rng(65)
+    h, k = pt.vector("h", dtype="float16"), pt.vector("k", dtype="float16")
+    H = pt.matrix("H", dtype="float16")
+    f = pt.fvector("f")
+    outs = [h + k, h * k - h, h / (abs(k) + 1), pt.exp(h * 0.5), pt.tanh(h) * k + pt.sqrt(abs(h)), pt.cast(h, "float32") * f, pt.cast(f, "float16"),
+            h.sum(), H.sum(axis=0), H.sum(axis=1), H.max(axis=1), pt.maximum(h, k), h > k, pt.switch(h > 0, h, k), H[1:, ::2], H.T * 2,
+            pt.cast(h * 100, "int16")]
+    n = 41
+    vals = {"h": rng.normal(size=n).astype("float16"), "k": rng.normal(size=n).astype("float16"), "H": rng.normal(size=(7, n)).astype("float16"),
+            "f": rng.normal(size=n).astype("float32")}
+    return [h, k, H, f], outs, vals

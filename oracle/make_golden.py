@@ -667,6 +667,7 @@ if __name__ == "__main__":
     sys.modules.setdefault("make_golden", sys.modules["__main__"])  # one CASES registry
     import golden_cases_fuzz  # noqa: F401
     import golden_cases_more  # noqa: F401  (registers its cases)
+    import golden_cases_r2  # noqa: F401
 
     names = sys.argv[1:] or list(CASES)
     for n in names:

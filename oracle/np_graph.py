@@ -895,7 +895,10 @@ def _cumop(p, inputs, node, graph):
     # pytensor/tensor/extra_ops.py:281 CumOp.perform
     (x,) = inputs
     f = np.cumsum if p["mode"] == "add" else np.cumprod
-    return [f(x, axis=p["axis"])]
+    # accumulate in the declared output dtype (= the input dtype, extra_ops.py:302 make_node):
+    # NumPy alone would widen small integers to the platform integer; the reference's C code
+    # (extra_ops.py c_code) accumulates in the output type and wraps, and the C linker wins
+    return [f(x, axis=p["axis"], dtype=x.dtype)]
 
 
 @op("Argmax")

@@ -38,6 +38,14 @@ CTYPE = {
     "int16": "short",
     "int8": "signed char",
     "uint8": "unsigned char",
+    "uint16": "unsigned short",
+    "uint32": "unsigned int",
+    "uint64": "unsigned long long",
+    # storage type with per-op rounding: every SSA temporary of dtype float16 is a `_Float16`, so
+    # +,-,*,/ are IEEE half operations and libm-style ops are evaluated in float and rounded —
+    # what NumPy does for float16 scalars (the reference has no C code for float16:
+    # Elemwise runs `perform`, tensor/elemwise.py:755-823)
+    "float16": "_Float16",
     "bool": "bool",
 }
 
@@ -382,6 +390,8 @@ def _lit(value, dtype: str) -> str:
     if dt.kind == "b":
         return "true" if value else "false"
     v = int(value)
+    if dt == np.uint64:
+        return f"({v}ULL)"
     if dt == np.int64:
         return f"({v}LL)" if v != -(2**63) else "(-9223372036854775807LL - 1)"
     return f"(({CTYPE[str(dt)]}){v})"
@@ -478,7 +488,7 @@ def _abs(args, in_dts, out_dt):
     dt = in_dts[0]
     if _is_float(dt):
         return f"fabs({args[0]})" if dt == "float64" else f"fabsf({args[0]})"
-    if dt in ("uint8", "bool"):
+    if dt in ("uint8", "uint16", "uint32", "uint64", "bool"):
         return args[0]
     return f"(({args[0]}) < 0 ? -({args[0]}) : ({args[0]}))"
 
@@ -659,7 +669,15 @@ def emit_body(body: dict, in_names, out_names, indent="      ", tp="t") -> str:
             if gen is None:
                 raise ScalarCodegenError(f"no device expression for scalar op {n['op']}")
             pairs = [ref(r) for r in n["in"]]
-            expr = gen([p[0] for p in pairs], [p[1] for p in pairs], n["dtype"])
+            odt = n["dtype"]
+            if odt == "float16" or any(p[1] == "float16" for p in pairs):
+                # half is a storage type: operands widen to float, the op runs in float and the
+                # assignment below rounds to half — bit-identical to IEEE half +,-,*,/ (float has
+                # 24 >= 2*11+2 significand bits, so the double rounding is innocuous) and what
+                # NumPy does for every float16 ufunc
+                pairs = [(f"(float){a}", "float32") if d == "float16" else (a, d) for a, d in pairs]
+                odt = "float32" if odt == "float16" else odt
+            expr = gen([p[0] for p in pairs], [p[1] for p in pairs], odt)
             lines.append(f"{indent}const {ct} {tp}{k} = ({ct})({expr});")
         tdt.append(n["dtype"])
     for name, r, dt in zip(out_names, body["outs"], body["out_dtypes"]):

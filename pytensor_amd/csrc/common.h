@@ -43,9 +43,9 @@ int check(hipError_t e, const char* what);
 inline int dtype_size(int dt) {
   switch (dt) {
     case PTHIP_BOOL: case PTHIP_I8: case PTHIP_U8: return 1;
-    case PTHIP_I16: return 2;
-    case PTHIP_I32: case PTHIP_F32: return 4;
-    case PTHIP_I64: case PTHIP_F64: return 8;
+    case PTHIP_I16: case PTHIP_U16: case PTHIP_F16: return 2;
+    case PTHIP_I32: case PTHIP_U32: case PTHIP_F32: return 4;
+    case PTHIP_I64: case PTHIP_U64: case PTHIP_F64: return 8;
   }
   return 0;
 }

@@ -442,6 +442,8 @@ int pthip_scatter_rows(int dtype, int inc, int64_t n_idx, int64_t inner, void* o
     case PTHIP_F32: LAUNCH(float); break;
     case PTHIP_I64: LAUNCH(long long); break;
     case PTHIP_I32: LAUNCH(int); break;
+    case PTHIP_U64: LAUNCH(unsigned long long); break;  // wrap-around add: same bits as the signed one
+    case PTHIP_U32: LAUNCH(unsigned int); break;
     default: return pthip::set_error("pthip_scatter_rows: unsupported dtype %d for inc", dtype);
   }
 #undef LAUNCH

@@ -81,6 +81,10 @@ __device__ __forceinline__ double load_f(const RandArgs& a, int j, long long i) 
     case PTHIP_I16: return (double)((const short*)a.p[j])[e];
     case PTHIP_I8: return (double)((const signed char*)a.p[j])[e];
     case PTHIP_U8: return (double)((const unsigned char*)a.p[j])[e];
+    case PTHIP_U16: return (double)((const unsigned short*)a.p[j])[e];
+    case PTHIP_U32: return (double)((const unsigned int*)a.p[j])[e];
+    case PTHIP_U64: return (double)((const unsigned long long*)a.p[j])[e];
+    case PTHIP_F16: return (double)((const _Float16*)a.p[j])[e];
     default: return (double)((const bool*)a.p[j])[e];
   }
 }
@@ -92,6 +96,9 @@ __device__ __forceinline__ long long load_i(const RandArgs& a, int j, long long 
     case PTHIP_I16: return ((const short*)a.p[j])[e];
     case PTHIP_I8: return ((const signed char*)a.p[j])[e];
     case PTHIP_U8: return ((const unsigned char*)a.p[j])[e];
+    case PTHIP_U16: return ((const unsigned short*)a.p[j])[e];
+    case PTHIP_U32: return ((const unsigned int*)a.p[j])[e];
+    case PTHIP_U64: return (long long)((const unsigned long long*)a.p[j])[e];
     case PTHIP_F64: return (long long)((const double*)a.p[j])[e];
     case PTHIP_F32: return (long long)((const float*)a.p[j])[e];
     default: return ((const bool*)a.p[j])[e];

@@ -183,30 +183,92 @@ int run(const void* xv, void* outv, long long A, long long R, long long B, long 
   return launch_strided<Op, Tacc, Tacc, Tout>(st, part, out, n_out, p.nsplit, n_out, 0, n_out, 1, 1, p.nsplit);
 }
 
+// (input, accumulator, output) dtype triples the reference can produce (elemwise.py:1383-1417
+// `_acc_dtype`: signed -> int64, unsigned -> uint64, bool -> int64, float16 -> float32,
+// float32 -> float64; output = the accumulator dtype for Sum/Prod, the input dtype for a raw
+// CAReduce, or whatever `dtype=` asked for among the float types).
+#define PTHIP_RUN(TIN, TACC, TOUT) return run<Op, TIN, TACC, TOUT>(x, out, A, R, B, sA, sR, sB, ws)
+#define PTHIP_CASE(IN, ACC, OUT, TIN, TACC, TOUT) \
+  if (in == IN && acc == ACC && outd == OUT) PTHIP_RUN(TIN, TACC, TOUT);
+
+// Add / Mul: accumulate wide, store wide or narrow (wrap-around cast, like the C backend's
+// final `(out_dtype)acc`, elemwise.py:1668-1676)
 template <class Op>
 int dispatch_types(int in, int acc, int outd, const void* x, void* out, long long A, long long R,
                    long long B, long long sA, long long sR, long long sB, void* ws) {
-#define CASE(IN, ACC, OUT, TIN, TACC, TOUT)                 \
-  if (in == IN && acc == ACC && outd == OUT)                \
-    return run<Op, TIN, TACC, TOUT>(x, out, A, R, B, sA, sR, sB, ws);
-  CASE(PTHIP_F64, PTHIP_F64, PTHIP_F64, double, double, double)
-  CASE(PTHIP_F32, PTHIP_F64, PTHIP_F32, float, double, float)
-  CASE(PTHIP_F64, PTHIP_F64, PTHIP_F32, double, double, float)
-  CASE(PTHIP_F32, PTHIP_F64, PTHIP_F64, float, double, double)
-  CASE(PTHIP_F32, PTHIP_F32, PTHIP_F32, float, float, float)
-  CASE(PTHIP_I64, PTHIP_I64, PTHIP_I64, long long, long long, long long)
-  CASE(PTHIP_I32, PTHIP_I64, PTHIP_I64, int, long long, long long)
-  CASE(PTHIP_I16, PTHIP_I64, PTHIP_I64, short, long long, long long)
-  CASE(PTHIP_I8, PTHIP_I64, PTHIP_I64, signed char, long long, long long)
-  CASE(PTHIP_U8, PTHIP_I64, PTHIP_I64, unsigned char, long long, long long)
-  CASE(PTHIP_BOOL, PTHIP_I64, PTHIP_I64, unsigned char, long long, long long)
-  CASE(PTHIP_I32, PTHIP_I32, PTHIP_I32, int, int, int)
-  CASE(PTHIP_I16, PTHIP_I16, PTHIP_I16, short, short, short)
-  CASE(PTHIP_I8, PTHIP_I8, PTHIP_I8, signed char, signed char, signed char)
-  CASE(PTHIP_U8, PTHIP_U8, PTHIP_U8, unsigned char, unsigned char, unsigned char)
-#undef CASE
+  PTHIP_CASE(PTHIP_F64, PTHIP_F64, PTHIP_F64, double, double, double)
+  PTHIP_CASE(PTHIP_F32, PTHIP_F64, PTHIP_F32, float, double, float)
+  PTHIP_CASE(PTHIP_F64, PTHIP_F64, PTHIP_F32, double, double, float)
+  PTHIP_CASE(PTHIP_F32, PTHIP_F64, PTHIP_F64, float, double, double)
+  PTHIP_CASE(PTHIP_F32, PTHIP_F32, PTHIP_F32, float, float, float)
+  PTHIP_CASE(PTHIP_F16, PTHIP_F32, PTHIP_F16, _Float16, float, _Float16)
+  PTHIP_CASE(PTHIP_F16, PTHIP_F32, PTHIP_F32, _Float16, float, float)
+  PTHIP_CASE(PTHIP_I64, PTHIP_I64, PTHIP_I64, long long, long long, long long)
+  PTHIP_CASE(PTHIP_I32, PTHIP_I64, PTHIP_I64, int, long long, long long)
+  PTHIP_CASE(PTHIP_I16, PTHIP_I64, PTHIP_I64, short, long long, long long)
+  PTHIP_CASE(PTHIP_I8, PTHIP_I64, PTHIP_I64, signed char, long long, long long)
+  PTHIP_CASE(PTHIP_BOOL, PTHIP_I64, PTHIP_I64, unsigned char, long long, long long)
+  PTHIP_CASE(PTHIP_U8, PTHIP_I64, PTHIP_I64, unsigned char, long long, long long)
+  PTHIP_CASE(PTHIP_I32, PTHIP_I64, PTHIP_I32, int, long long, int)
+  PTHIP_CASE(PTHIP_I16, PTHIP_I64, PTHIP_I16, short, long long, short)
+  PTHIP_CASE(PTHIP_I8, PTHIP_I64, PTHIP_I8, signed char, long long, signed char)
+  PTHIP_CASE(PTHIP_U64, PTHIP_U64, PTHIP_U64, unsigned long long, unsigned long long, unsigned long long)
+  PTHIP_CASE(PTHIP_U32, PTHIP_U64, PTHIP_U64, unsigned int, unsigned long long, unsigned long long)
+  PTHIP_CASE(PTHIP_U16, PTHIP_U64, PTHIP_U64, unsigned short, unsigned long long, unsigned long long)
+  PTHIP_CASE(PTHIP_U8, PTHIP_U64, PTHIP_U64, unsigned char, unsigned long long, unsigned long long)
+  PTHIP_CASE(PTHIP_U32, PTHIP_U64, PTHIP_U32, unsigned int, unsigned long long, unsigned int)
+  PTHIP_CASE(PTHIP_U16, PTHIP_U64, PTHIP_U16, unsigned short, unsigned long long, unsigned short)
+  PTHIP_CASE(PTHIP_U8, PTHIP_U64, PTHIP_U8, unsigned char, unsigned long long, unsigned char)
+  PTHIP_CASE(PTHIP_I32, PTHIP_I32, PTHIP_I32, int, int, int)
+  PTHIP_CASE(PTHIP_I16, PTHIP_I16, PTHIP_I16, short, short, short)
+  PTHIP_CASE(PTHIP_I8, PTHIP_I8, PTHIP_I8, signed char, signed char, signed char)
+  PTHIP_CASE(PTHIP_U8, PTHIP_U8, PTHIP_U8, unsigned char, unsigned char, unsigned char)
+  // second stage over accumulator-typed partials of a fused Elemwise+reduce kernel
+  PTHIP_CASE(PTHIP_I64, PTHIP_I64, PTHIP_I32, long long, long long, int)
+  PTHIP_CASE(PTHIP_I64, PTHIP_I64, PTHIP_I16, long long, long long, short)
+  PTHIP_CASE(PTHIP_I64, PTHIP_I64, PTHIP_I8, long long, long long, signed char)
+  PTHIP_CASE(PTHIP_U64, PTHIP_U64, PTHIP_U32, unsigned long long, unsigned long long, unsigned int)
+  PTHIP_CASE(PTHIP_U64, PTHIP_U64, PTHIP_U16, unsigned long long, unsigned long long, unsigned short)
+  PTHIP_CASE(PTHIP_U64, PTHIP_U64, PTHIP_U8, unsigned long long, unsigned long long, unsigned char)
+  PTHIP_CASE(PTHIP_F32, PTHIP_F32, PTHIP_F16, float, float, _Float16)
   return pthip::set_error("pthip_reduce: unsupported dtype combination in=%d acc=%d out=%d", in, acc, outd);
 }
+
+// Maximum / Minimum: no widening is ever needed; the accumulator dtype the graph names is
+// honoured for the float pairs, every other type reduces in itself
+template <class Op>
+int dispatch_minmax(int in, int acc, int outd, const void* x, void* out, long long A, long long R,
+                    long long B, long long sA, long long sR, long long sB, void* ws) {
+  PTHIP_CASE(PTHIP_F64, PTHIP_F64, PTHIP_F64, double, double, double)
+  PTHIP_CASE(PTHIP_F32, PTHIP_F32, PTHIP_F32, float, float, float)
+  PTHIP_CASE(PTHIP_F32, PTHIP_F64, PTHIP_F32, float, float, float)
+  PTHIP_CASE(PTHIP_F16, PTHIP_F16, PTHIP_F16, _Float16, _Float16, _Float16)
+  PTHIP_CASE(PTHIP_F16, PTHIP_F32, PTHIP_F16, _Float16, _Float16, _Float16)
+  PTHIP_CASE(PTHIP_F64, PTHIP_F64, PTHIP_F32, double, double, float)
+  // second stage over accumulator-typed partials of a fused Elemwise+reduce kernel
+  PTHIP_CASE(PTHIP_I64, PTHIP_I64, PTHIP_I32, long long, long long, int)
+  PTHIP_CASE(PTHIP_I64, PTHIP_I64, PTHIP_I16, long long, long long, short)
+  PTHIP_CASE(PTHIP_I64, PTHIP_I64, PTHIP_I8, long long, long long, signed char)
+  PTHIP_CASE(PTHIP_U64, PTHIP_U64, PTHIP_U32, unsigned long long, unsigned long long, unsigned int)
+  PTHIP_CASE(PTHIP_U64, PTHIP_U64, PTHIP_U16, unsigned long long, unsigned long long, unsigned short)
+  PTHIP_CASE(PTHIP_U64, PTHIP_U64, PTHIP_U8, unsigned long long, unsigned long long, unsigned char)
+  PTHIP_CASE(PTHIP_F32, PTHIP_F32, PTHIP_F16, float, float, _Float16)
+  if (in == outd) {
+    switch (in) {
+      case PTHIP_I64: PTHIP_RUN(long long, long long, long long);
+      case PTHIP_I32: PTHIP_RUN(int, int, int);
+      case PTHIP_I16: PTHIP_RUN(short, short, short);
+      case PTHIP_I8: PTHIP_RUN(signed char, signed char, signed char);
+      case PTHIP_U64: PTHIP_RUN(unsigned long long, unsigned long long, unsigned long long);
+      case PTHIP_U32: PTHIP_RUN(unsigned int, unsigned int, unsigned int);
+      case PTHIP_U16: PTHIP_RUN(unsigned short, unsigned short, unsigned short);
+      case PTHIP_U8: PTHIP_RUN(unsigned char, unsigned char, unsigned char);
+      default: break;
+    }
+  }
+  return pthip::set_error("pthip_reduce: unsupported dtype combination in=%d acc=%d out=%d", in, acc, outd);
+}
+#undef PTHIP_CASE
 
 template <class Op>
 int dispatch_bool(int in, int acc, int outd, const void* x, void* out, long long A, long long R,
@@ -220,9 +282,13 @@ int dispatch_bool(int in, int acc, int outd, const void* x, void* out, long long
   CASE(PTHIP_I16, short)
   CASE(PTHIP_I8, signed char)
   CASE(PTHIP_U8, unsigned char)
+  CASE(PTHIP_U16, unsigned short)
+  CASE(PTHIP_U32, unsigned int)
+  CASE(PTHIP_U64, unsigned long long)
 #undef CASE
   return pthip::set_error("pthip_reduce: unsupported dtype combination in=%d acc=%d out=%d", in, acc, outd);
 }
+#undef PTHIP_RUN
 
 }  // namespace
 
@@ -252,11 +318,11 @@ int pthip_reduce(int op, int in_dtype, int acc_dtype, int out_dtype, const void*
     case PTHIP_RED_MAX:
       if (R == 0) return pthip::set_error("zero-size array to reduction operation maximum which has no identity");
       if (in_dtype == PTHIP_BOOL) return dispatch_bool<OpOr>(in_dtype, acc_dtype, out_dtype, x, out, A, R, B, sA, sR, sB, ws);
-      return dispatch_types<OpMax>(in_dtype, acc_dtype, out_dtype, x, out, A, R, B, sA, sR, sB, ws);
+      return dispatch_minmax<OpMax>(in_dtype, acc_dtype, out_dtype, x, out, A, R, B, sA, sR, sB, ws);
     case PTHIP_RED_MIN:
       if (R == 0) return pthip::set_error("zero-size array to reduction operation minimum which has no identity");
       if (in_dtype == PTHIP_BOOL) return dispatch_bool<OpAnd>(in_dtype, acc_dtype, out_dtype, x, out, A, R, B, sA, sR, sB, ws);
-      return dispatch_types<OpMin>(in_dtype, acc_dtype, out_dtype, x, out, A, R, B, sA, sR, sB, ws);
+      return dispatch_minmax<OpMin>(in_dtype, acc_dtype, out_dtype, x, out, A, R, B, sA, sR, sB, ws);
     case PTHIP_RED_AND: return dispatch_bool<OpAnd>(in_dtype, acc_dtype, out_dtype, x, out, A, R, B, sA, sR, sB, ws);
     case PTHIP_RED_OR: return dispatch_bool<OpOr>(in_dtype, acc_dtype, out_dtype, x, out, A, R, B, sA, sR, sB, ws);
     case PTHIP_RED_XOR: return dispatch_bool<OpXor>(in_dtype, acc_dtype, out_dtype, x, out, A, R, B, sA, sR, sB, ws);

@@ -48,6 +48,22 @@ template <> struct Limits<unsigned char> {
   static __device__ __forceinline__ unsigned char lowest() { return 0; }
   static __device__ __forceinline__ unsigned char highest() { return 255; }
 };
+template <> struct Limits<unsigned short> {
+  static __device__ __forceinline__ unsigned short lowest() { return 0; }
+  static __device__ __forceinline__ unsigned short highest() { return 65535; }
+};
+template <> struct Limits<unsigned int> {
+  static __device__ __forceinline__ unsigned int lowest() { return 0u; }
+  static __device__ __forceinline__ unsigned int highest() { return 0xffffffffu; }
+};
+template <> struct Limits<unsigned long long> {
+  static __device__ __forceinline__ unsigned long long lowest() { return 0ull; }
+  static __device__ __forceinline__ unsigned long long highest() { return 0xffffffffffffffffull; }
+};
+template <> struct Limits<_Float16> {
+  static __device__ __forceinline__ _Float16 lowest() { return (_Float16)(-__builtin_huge_valf()); }
+  static __device__ __forceinline__ _Float16 highest() { return (_Float16)__builtin_huge_valf(); }
+};
 template <> struct Limits<bool> {
   static __device__ __forceinline__ bool lowest() { return false; }
   static __device__ __forceinline__ bool highest() { return true; }

@@ -117,6 +117,12 @@ int pthip_cumulative(int dtype, int mul, int64_t outer, int64_t n, int64_t inner
     case PTHIP_F32: return cumulative_typed<float>(mul, outer, n, inner, src, dst);
     case PTHIP_I64: return cumulative_typed<long long>(mul, outer, n, inner, src, dst);
     case PTHIP_I32: return cumulative_typed<int>(mul, outer, n, inner, src, dst);
+    case PTHIP_I16: return cumulative_typed<short>(mul, outer, n, inner, src, dst);
+    case PTHIP_I8: return cumulative_typed<signed char>(mul, outer, n, inner, src, dst);
+    case PTHIP_U8: return cumulative_typed<unsigned char>(mul, outer, n, inner, src, dst);
+    case PTHIP_U16: return cumulative_typed<unsigned short>(mul, outer, n, inner, src, dst);
+    case PTHIP_U32: return cumulative_typed<unsigned int>(mul, outer, n, inner, src, dst);
+    case PTHIP_U64: return cumulative_typed<unsigned long long>(mul, outer, n, inner, src, dst);
     default: return pthip::set_error("pthip_cumulative: unsupported dtype %d", dtype);
   }
 }
@@ -130,6 +136,9 @@ int pthip_imatmul(int dtype, int64_t M, int64_t N, int64_t K, const void* A, int
     case PTHIP_I16: return imatmul_typed<short>(M, N, K, A, sA0, sA1, B, sB0, sB1, out);
     case PTHIP_I8: return imatmul_typed<signed char>(M, N, K, A, sA0, sA1, B, sB0, sB1, out);
     case PTHIP_U8: return imatmul_typed<unsigned char>(M, N, K, A, sA0, sA1, B, sB0, sB1, out);
+    case PTHIP_U16: return imatmul_typed<unsigned short>(M, N, K, A, sA0, sA1, B, sB0, sB1, out);
+    case PTHIP_U32: return imatmul_typed<unsigned int>(M, N, K, A, sA0, sA1, B, sB0, sB1, out);
+    case PTHIP_U64: return imatmul_typed<unsigned long long>(M, N, K, A, sA0, sA1, B, sB0, sB1, out);
     default: return pthip::set_error("pthip_imatmul: integer dtypes only (got %d)", dtype);
   }
 }
@@ -145,6 +154,9 @@ int pthip_argmax(int dtype, int64_t rows, int64_t R, const void* src, void* out)
     case PTHIP_I16: return argmax_typed<short>(rows, R, src, out);
     case PTHIP_I8: return argmax_typed<signed char>(rows, R, src, out);
     case PTHIP_U8: return argmax_typed<unsigned char>(rows, R, src, out);
+    case PTHIP_U16: return argmax_typed<unsigned short>(rows, R, src, out);
+    case PTHIP_U32: return argmax_typed<unsigned int>(rows, R, src, out);
+    case PTHIP_U64: return argmax_typed<unsigned long long>(rows, R, src, out);
     default: return pthip::set_error("pthip_argmax: unsupported dtype %d", dtype);
   }
 }

@@ -171,6 +171,9 @@ extern "C" int pthip_sort(int dtype, int64_t rows, int64_t n, const void* in, vo
     case PTHIP_I16: return sort_typed<short>(rows, n, in, out_vals, out_idx);
     case PTHIP_I8: return sort_typed<signed char>(rows, n, in, out_vals, out_idx);
     case PTHIP_U8: case PTHIP_BOOL: return sort_typed<unsigned char>(rows, n, in, out_vals, out_idx);
+    case PTHIP_U16: return sort_typed<unsigned short>(rows, n, in, out_vals, out_idx);
+    case PTHIP_U32: return sort_typed<unsigned int>(rows, n, in, out_vals, out_idx);
+    case PTHIP_U64: return sort_typed<unsigned long long>(rows, n, in, out_vals, out_idx);
     default: return pthip::set_error("pthip_sort: unsupported dtype %d", dtype);
   }
 }

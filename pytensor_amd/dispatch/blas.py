@@ -21,6 +21,61 @@ def _scalar(env, v) -> float:
     return float(np.asarray(env.to_host(v)).reshape(-1)[0])
 
 
+def _host_scalar(v):
+    """The value of alpha/beta when the host knows it (a constant or shape arithmetic); ``None``
+    when it is *computed on the device* (e.g. ``-lr`` of an SGD update, ``lr`` a function input):
+    reading it back would be a host synchronisation per call and cannot be captured in a hipGraph,
+    so those cases run the product with alpha=1, beta=0 and a fused ``beta*y + alpha*t`` epilogue
+    kernel that takes the scalars as device operands (`_axpby`)."""
+    if isinstance(v, HostValue):
+        return float(np.asarray(v.a).reshape(-1)[0])
+    if isinstance(v, DeviceArray):
+        return None
+    return float(np.asarray(v).reshape(-1)[0])
+
+
+def _axpby(env, alpha, t, beta, y):
+    """``beta*y + alpha*t`` (``y`` broadcast to ``t``; ``beta == 0`` never reads ``y``, as
+    gemv.py:79-86 / gemm.py:183-216 do) with alpha / beta as host floats or device scalars."""
+    from pytensor_amd.dispatch.elemwise import launch_elemwise
+
+    dt = str(t.dtype)
+
+    def operand(v):
+        h = _host_scalar(v) if not isinstance(v, float) else v
+        if h is not None:
+            return HostValue(np.asarray(h, dtype=dt))
+        v = env.to_device(v)
+        return v.view((1,) * t.ndim, (0,) * t.ndim) if t.ndim else v
+
+    a_op, b_op = operand(alpha), operand(beta)
+    bh = _host_scalar(beta) if not isinstance(beta, float) else beta
+    if y is None or bh == 0.0:
+        body = {"in_dtypes": [dt, dt], "out_dtypes": [dt],
+                "body": [{"op": "Mul", "in": [["i", 1], ["i", 0]], "dtype": dt}], "outs": [["t", 0]]}
+        outs, _, _ = launch_elemwise(body, [t, a_op], t.shape, [dt], None, env)
+        return outs[0]
+    yb = y
+    if y.shape != t.shape:  # Gemm: z may be broadcast along a static length-1 axis (gemm.py:194-198)
+        ysh = (1,) * (t.ndim - y.ndim) + y.shape
+        yst = (0,) * (t.ndim - y.ndim) + y.strides
+        yb = y.view(ysh, tuple(0 if s == 1 and d != 1 else st for s, d, st in zip(ysh, t.shape, yst)))
+    zero = ["c", "0x0.0p+0", dt]
+    body = {
+        "in_dtypes": [dt, dt, dt, dt], "out_dtypes": [dt],
+        "body": [
+            {"op": "Mul", "in": [["i", 1], ["i", 0]], "dtype": dt},  # alpha * t
+            {"op": "Mul", "in": [["i", 2], ["i", 3]], "dtype": dt},  # beta * y
+            {"op": "EQ", "in": [["i", 2], zero], "dtype": "bool"},
+            {"op": "Switch", "in": [["t", 2], zero, ["t", 1]], "dtype": dt},  # beta == 0: y is not used
+            {"op": "Add", "in": [["t", 3], ["t", 0]], "dtype": dt},
+        ],
+        "outs": [["t", 4]],
+    }
+    outs, _, _ = launch_elemwise(body, [t, a_op, b_op, yb], t.shape, [dt], None, env)
+    return outs[0]
+
+
 def _dt(x) -> int:
     return ffi.np_dtype_code(x.dtype)
 
@@ -61,17 +116,25 @@ def gemv_device(env, alpha, A, x, beta, y):
 @handler("Gemv")
 def gemv(node, inputs, env):
     y, alpha, A, x, beta = inputs
-    alpha, beta = _scalar(env, alpha), _scalar(env, beta)
+    ah, bh = _host_scalar(alpha), _host_scalar(beta)
     A, x = env.to_device(A), env.to_device(x)
     y = env.to_device(y)
-    return [gemv_device(env, alpha, A, x, beta, None if beta == 0.0 else y)]
+    if ah is None or bh is None:  # alpha/beta computed on the device
+        if y.shape[0] != A.shape[0]:
+            raise ValueError(f"Shape mismatch: y.shape[0] != A.shape[0] ({y.shape}, {A.shape})")
+        return [_axpby(env, alpha, gemv_device(env, 1.0, A, x, 0.0, None), beta, y)]
+    return [gemv_device(env, ah, A, x, bh, None if bh == 0.0 else y)]
 
 
 @handler("Ger")
 def ger(node, inputs, env):
     A, alpha, x, y = inputs
-    alpha = _scalar(env, alpha)
+    ah = _host_scalar(alpha)
     A, x, y = env.to_device(A), env.to_device(x), env.to_device(y)
+    if ah is None:  # device alpha: A + (alpha*x) y^T
+        x, alpha = _axpby(env, alpha, x, 0.0, None), 1.0
+    else:
+        alpha = ah
     M, N = A.shape
     if x.shape[0] != M or y.shape[0] != N:
         raise ValueError("Ger: shape mismatch")
@@ -138,14 +201,20 @@ def dot22(node, inputs, env):
 def dot22scalar(node, inputs, env):
     x, y, a = inputs
     x, y = env.to_device(x), env.to_device(y)
-    return [gemm_device(env, _scalar(env, a), _prep2d(x), _prep2d(y))]
+    ah = _host_scalar(a)
+    if ah is None:
+        return [_axpby(env, a, gemm_device(env, 1.0, _prep2d(x), _prep2d(y)), 0.0, None)]
+    return [gemm_device(env, ah, _prep2d(x), _prep2d(y))]
 
 
 @handler("Gemm")
 def gemm(node, inputs, env):
     z, a, x, y, b = inputs
     z, x, y = env.to_device(z), env.to_device(x), env.to_device(y)
-    return [gemm_device(env, _scalar(env, a), _prep2d(x), _prep2d(y), _scalar(env, b), z)]
+    ah, bh = _host_scalar(a), _host_scalar(b)
+    if ah is None or bh is None:
+        return [_axpby(env, a, gemm_device(env, 1.0, _prep2d(x), _prep2d(y)), b, z)]
+    return [gemm_device(env, ah, _prep2d(x), _prep2d(y), bh, z)]
 
 
 def _prep3d(x):

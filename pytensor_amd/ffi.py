@@ -24,6 +24,10 @@ DTYPE_CODE = {
     "uint8": 5,
     "float32": 6,
     "float64": 7,
+    "uint16": 8,
+    "uint32": 9,
+    "uint64": 10,
+    "float16": 11,
 }
 REDUCE_CODE = {
     "Add": 0,

@@ -248,6 +248,9 @@ def fuse_gemv_chain(g: Graph) -> Graph:
         n1 = g.nodes[k1]
         if ne.inputs.count(r) != 1:
             continue
+        # the chain / finish kernels take alpha and beta by value: they must be constants
+        if any(g.vars[v].const is None for v in (n1.inputs[1], n1.inputs[4], a2, b2)):
+            continue
         # every other operand of the scalar graph must be available before the chain starts: a
         # value that itself depends on r (e.g. the 2/N·r of a *mean* squared error, whose scale
         # comes after a full reduction of r) would make the fused node its own ancestor
