@@ -23,6 +23,11 @@ _modules = {}
 
 def compile_source(src: str, name: str) -> str:
     """Compile (or fetch) ``src``; returns the cache key.  Needs no GPU."""
+    if "_Float16" in src:
+        # float16 is rounded after every scalar op (NumPy semantics, what the reference's Elemwise
+        # `perform` does): HIP's default -ffp-contract=fast would turn `half(a*b) - c` into one
+        # v_fma_f16 and skip the intermediate rounding
+        src = "#pragma clang fp contract(off)\n" + src
     key = source_key(src)
     if key in _code:
         return key

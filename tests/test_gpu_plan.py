@@ -141,14 +141,30 @@ def test_auto_freeze_is_what_the_linker_path_gets(hip):
     want = HipExecutable(g, resident=resident)(*ins2)
     for a, b in zip(got, want):
         np.testing.assert_array_equal(a, b)
-    # a resident array replaced by a new object (shared.set_value): eager again, then re-captured
+    # a resident array replaced by a new object of the same geometry (shared.set_value): copied
+    # into the SAME device buffer, so the captured plan stays valid (round 2; it used to drop
+    # back to eager and capture again)
+    ups = exe.stats["resident_uploads"]
     ins3 = list(ins)
     ins3[resident[0]] = ins[resident[0]].copy()
     got3 = exe(*ins3)
-    assert exe._auto_plan is None
+    assert exe._auto_plan is plan and exe.stats["resident_uploads"] == ups + 1
     for a, b in zip(got3, first):
         np.testing.assert_array_equal(a, b)
-    exe(*ins3)
+    # new CONTENT (in-place edit of the borrowed array): seen, re-uploaded, still the plan
+    ins3[resident[0]][...] = ins3[resident[0]] * 2.0
+    got4 = exe(*ins3)
+    assert exe._auto_plan is plan and exe.stats["resident_uploads"] == ups + 2
+    want4 = HipExecutable(g, resident=resident)(*ins3)
+    for a, b in zip(got4, want4):
+        np.testing.assert_array_equal(a, b)
+    assert not np.array_equal(got4[0], got3[0])
+    # a new SHAPE is a new signature: eager, then captured again
+    n_old = ins[resident[0]].shape[0]
+    ins5 = [a[: n_old - 7] if (k in resident and a.shape[:1] == (n_old,)) else a for k, a in enumerate(ins)]
+    exe(*ins5)
+    assert exe._auto_plan is None
+    exe(*ins5)
     assert exe._auto_plan is not None and exe._auto_plan is not plan
 
     # not freezable: stays eager, still correct
