@@ -13,14 +13,22 @@ evaluates an independent chain (weak scaling, no data-path collective: "replicas
 SURVEY.md §8e) and ``value`` = total evals / max-over-ranks time.
 
 The JSON line also carries
-  roofline      the dominant kernel (Gemv over X; the slower orientation): algorithmic
-                bytes (N*K*8 per launch) / mean launch duration measured live with HIP
-                events on the context stream; ``traffic`` = HBM bytes per launch from the
-                committed PMC passes (profiles/r1_pmc_c4.json, FETCH_SIZE corrected x2 +
-                WRITE_SIZE) when that file matches the workload, else null;
-  cpu_baseline  the CPU oracle (oracle/np_graph.py: NumPy/SciPy restatement of the
-                reference's perform methods) timed on the host cores on a bounded sample
-                (N=1e5), scaled linearly to N — kind "port".
+  roofline      the dominant kernel (gchain_*: one pass over X for X@beta and X.T@w): algorithmic
+                bytes (N*K*8 + 2*N*8 per launch) / mean launch duration measured live with HIP
+                events on the context stream; ``traffic`` = HBM bytes per launch from the committed
+                PMC passes (FETCH_SIZE corrected x2 + WRITE_SIZE, ``traffic_source`` names the
+                file — PMC counters cannot be collected inside the driver's plain run);
+  cpu_baseline  the REFERENCE ITSELF on the host cores of this box: the same graph compiled by
+                the reference's C linker (``mode="CVM"``, ``trust_input=True``) from the importable
+                copy ``oracle/_ref`` (a built artefact that travels with the snapshot; test
+                infrastructure), at the full N, 1 warm-up + median of 5 evals — kind
+                "reference-cvm" (SURVEY §8d).  Its outputs gate the HIP outputs at
+                rtol 1e-12 + 8*eps*sum|term| (oracle/bounds.py).  ``port`` inside it keeps the
+                NumPy/SciPy oracle timing (kind "port") at the full N as a second number.  When
+                ``oracle/_ref`` is absent the port is the baseline and says so;
+  configs       BASELINE configs #1, #2 (cheap / transcendental), #3 (Dot22, Gemv, BatchedDot), #5
+                at their stated sizes: device-event timed hipGraph replays, achieved GB/s or
+                TFLOP/s and the fraction of the roofline that bounds each (tools/bench_configs.py).
 """
 
 from __future__ import annotations
@@ -67,6 +75,79 @@ def _time_launches(lib, fn, reps=20):
     return ms.value / reps
 
 
+def cpu_baseline(graph, names, vals, inputs, out_hip, args):
+    """The reference C linker (or, without ``oracle/_ref``, the NumPy port) on this host."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import bounds
+    import np_graph
+
+    cores = os.cpu_count()
+    try:
+        from threadpoolctl import threadpool_info
+
+        blas = "; ".join(f"{d.get('internal_api')} {d.get('version')} x{d.get('num_threads')}" for d in threadpool_info())
+    except Exception:  # pragma: no cover
+        blas = "unknown"
+
+    # -- the NumPy/SciPy restatement at the full N (second number; also a parity gate) ----------
+    np_graph.run_graph(graph, inputs)
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        ref_full = np_graph.run_graph(graph, inputs)
+        ts.append(time.perf_counter() - t0)
+    port = {"value": 1.0 / float(np.median(ts)), "unit": "graph evals/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle/np_graph.py at N={args.n} (no scaling), 1 warm-up + median of 5; BLAS: {blas}; elementwise single-threaded"}
+    used_port = bounds.check_c4(out_hip, ref_full, vals, what="bench parity vs oracle")
+
+    import make_ref
+
+    if not make_ref.importable():
+        port["parity_err_over_bound"] = max(used_port)
+        port["note"] = "oracle/_ref absent on this box: the reference C linker could not be timed"
+        return port
+    make_ref.activate()
+    import pytensor
+    from pytensor.compile.mode import Mode
+
+    import ref_graphs
+
+    have_cxx = bool(pytensor.config.cxx)
+    mode = Mode(linker="cvm" if have_cxx else "py", optimizer="fast_run")
+    params, outs = ref_graphs.build_c4(vals)
+    t0 = time.perf_counter()
+    f = pytensor.function(params, outs, mode=mode)
+    t_compile = time.perf_counter() - t0
+    f.trust_input = True
+    pv = [np.asarray(vals[n]) for n in configs_params()]
+    ref_out = f(*pv)  # warm-up
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        ref_out = f(*pv)
+        ts.append(time.perf_counter() - t0)
+    used = bounds.check_c4(out_hip, ref_out, vals, what="bench parity vs the reference C linker")
+    return {
+        "value": 1.0 / float(np.median(ts)),
+        "unit": "graph evals/sec",
+        "cores": cores,
+        "kind": "reference-cvm" if have_cxx else "reference-py (no g++ on this box)",
+        "sample": (f"pytensor.function(mode=Mode('cvm','fast_run')) from oracle/_ref, trust_input=True, N={args.n} (full size), "
+                   f"1 warm-up + median of 5 evals (min {min(ts) * 1e3:.0f} ms, max {max(ts) * 1e3:.0f} ms; compile {t_compile:.1f} s); "
+                   f"nproc={cores}, OMP_NUM_THREADS={os.environ.get('OMP_NUM_THREADS', 'unset')}, BLAS: {blas}; "
+                   "C Elemwise loops single-threaded (config.openmp=False)"),
+        "ms_per_eval": float(np.median(ts)) * 1e3,
+        "parity_err_over_bound": max(used),
+        "port": port,
+    }
+
+
+def configs_params():
+    from pytensor_amd import configs
+
+    return configs.C4_PARAMS
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +155,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows", dest="n", type=int, default=1_000_000, help="observations N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-config measurements (configs #1, #2, #3, #5)")
     ap.add_argument("--eager", action="store_true", help="per-node dispatch instead of the frozen hipGraph plan")
     ap.add_argument("--single-stream", action="store_true", help="frozen plan without the two-stream fork")
     args = ap.parse_args()
@@ -149,32 +231,14 @@ def main():
 
     cpu = None
     if not args.no_cpu_baseline and info.world == 1:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import np_graph
+        cpu = cpu_baseline(graph, names, vals, inputs, out, args)
 
-        n_s = min(args.n, 100_000)
-        sv = configs.c4_inputs(N=n_s, chain=0)
-        sin = [sv[n] for n in names]
-        np_graph.run_graph(graph, sin)
-        reps = 0
-        tc0 = time.perf_counter()
-        while True:
-            np_graph.run_graph(graph, sin)
-            reps += 1
-            if time.perf_counter() - tc0 > 10.0 or reps >= 50:
-                break
-        per_eval = (time.perf_counter() - tc0) / reps * (args.n / n_s)
-        if args.n <= 2_000_000:  # full-size parity gate against the oracle
-            ref_full = np_graph.run_graph(graph, inputs)
-            for k, (a, b) in enumerate(zip(out, ref_full)):
-                np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-10, err_msg=f"bench parity output {k}")
-        cpu = {
-            "value": 1.0 / per_eval,
-            "unit": "graph evals/sec",
-            "cores": os.cpu_count(),
-            "kind": "port",
-            "sample": f"oracle/np_graph.py (NumPy/SciPy perform semantics; BLAS threads = host cores, elementwise single-threaded) at N={n_s}, {reps} evals, scaled x{args.n // n_s} to N={args.n}",
-        }
+    cfgs = None
+    if not args.no_configs and info.world == 1:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_configs
+
+        cfgs = bench_configs.measure(reps=10, check=False)  # (parity at these sizes: tests/test_gpu_fullsize.py)
 
     line = {
         "metric": "graph evals/sec (logp+grad, N=1e6 fp64)",
@@ -202,6 +266,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_source": "profiles/pmc_c4_current.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None,
             "detail": {
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "kernel_ms": ms_kernel,
@@ -210,6 +275,7 @@ def main():
             },
         },
         "cpu_baseline": cpu,
+        "configs": cfgs,
     }
     print(json.dumps(line))
 

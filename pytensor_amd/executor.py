@@ -346,12 +346,19 @@ class HipExecutable:
         when the cell still holds the array that was uploaded (same object, same memory, same
         content fingerprint); otherwise uploaded again — *into the same device buffer* when
         shape and dtype are unchanged, so captured plans stay valid across ``set_value``."""
-        if a is None:
-            a = np.asarray(value)
-        key = _resident_key(value, a)
         ent = self._resident_cache.get(pos)
-        if ent is not None and ent.key == key and (ent.fp is None or ent.fp == _fingerprint(a)):
-            return ent.dev
+        if ent is not None and value is ent.host and ent.key is not None:
+            # the very object that was uploaded (an ndarray cannot move its memory): only the
+            # content can have changed
+            if ent.fp is None or ent.fp == _fingerprint(value):
+                return ent.dev
+            a, key = value, ent.key
+        else:
+            if a is None:
+                a = np.asarray(value)
+            key = _resident_key(value, a)
+            if ent is not None and ent.key == key and (ent.fp is None or ent.fp == _fingerprint(a)):
+                return ent.dev
         self.stats["resident_uploads"] += 1
         if ent is not None and ent.dev.shape == a.shape and ent.dev.dtype == a.dtype:
             if a.size:

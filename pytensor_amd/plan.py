@@ -315,13 +315,37 @@ class FrozenPlan:
                 if a.shape != v.shape or a.dtype != v.dtype:
                     raise TypeError(f"frozen plan: input {pos} changed signature {self._sig[pos]} -> {(a.shape, str(a.dtype))}")
             v[...] = a
+        exe = self.exe
+        late = []  # residents still held by the object that was uploaded: content check deferred
         for pos, dev in self._resident_devs.items():
-            if self.exe._refresh_resident(pos, inputs[pos]) is not dev:
+            v = inputs[pos]
+            ent = exe._resident_cache[pos]
+            if v is ent.host and ent.key is not None:
+                if ent.fp is not None:
+                    late.append((pos, ent, v))
+            elif exe._refresh_resident(pos, v) is not dev:
                 raise ValueError(f"frozen plan: resident input {pos} changed shape or dtype; re-freeze")
         for pos, b in self._baked.items():
             if not np.array_equal(np.asarray(inputs[pos]), b):
                 raise ValueError(f"frozen plan: scalar input {pos} is baked into the plan and changed")
-        self._replay(True)  # one native call: H2D, graphs, stream synchronisation
+        if not late:
+            self._replay(True)  # one native call: H2D, graphs, stream synchronisation
+        else:
+            # launch first, fingerprint the resident host arrays while the GPU works (a borrowed
+            # shared value edited in place, executor._fingerprint): the check costs the call nothing
+            self._replay(False)
+            from pytensor_amd.executor import _fingerprint
+
+            dirty = [pos for pos, ent, v in late if _fingerprint(v) != ent.fp]
+            if dirty:
+                # the replay in flight read stale data: discard it, upload what changed (and put
+                # back every update-fed resident, which that replay advanced), run again
+                ffi.check(lib.pthip_synchronize())
+                for pos in set(dirty) | {p for p, _ in self._fed}:
+                    exe._resident_cache[pos].key = None
+                    exe._refresh_resident(pos, inputs[pos])
+                self._replay(False)
+            ffi.check(lib.pthip_synchronize())
         if self.fetch_outputs and self._out_block is not None and self._out_block.views[-1][0]:
             from pytensor_amd.executor import raise_device_status
 

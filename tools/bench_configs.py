@@ -77,47 +77,62 @@ def run_case(name, vals, reps, check=True, rtol=1e-10, oracle_vals=None):
     return t_dev, t_wall
 
 
+def measure(which=("c1", "c2", "c3", "c5"), reps=20, check=True):
+    """Device-event timed replays of BASELINE configs #1, #2, #3, #5 at their stated sizes
+    (inputs resident in HBM).  Returns ``{key: {...}}``; imported by ``bench.py`` for the
+    ``configs`` field of its JSON line."""
+    res = {}
+    if "c1" in which:
+        v = configs.c1_inputs()
+        td, tw = run_case("c1_gauss", v, reps, check=check)
+        b = 1.6e6
+        res["c1"] = {"config": "C1 exp(-0.5(x-mu)^2).sum()+grad N=1e5 f64", "ms_device": td, "ms_call": tw, "achieved": b / td / 1e6,
+                     "unit": "GB/s", "peak": HBM_PEAK, "frac": b / td / 1e6 / HBM_PEAK, "bound": "launch latency (1.6 MB/eval)"}
+    if "c2" in which:
+        v = configs.c2_inputs()
+        small = configs.c2_inputs(N=1_000_000)
+        for key, nm, label in (("c2_cheap", "c2_cheap", "C2 cheap 52-op Composite+Sum N=1e7 f64"),
+                               ("c2_transc", "c2_transc", "C2 transcendental (10 tanh + 10 exp) Composite+Sum N=1e7 f64")):
+            td, tw = run_case(nm, v, reps, check=check, oracle_vals=small)
+            b = 160e6
+            res[key] = {"config": label, "ms_device": td, "ms_call": tw, "achieved": b / td / 1e6, "unit": "GB/s", "peak": HBM_PEAK,
+                        "frac": b / td / 1e6 / HBM_PEAK, "bound": "hbm" if key == "c2_cheap" else "alu (transcendentals), hbm fraction shown"}
+    if "c3" in which:
+        v = configs.c3_inputs()
+        small = configs.c3_inputs(M=512, B=8, Bn=64)
+        td, tw = run_case("c3_dot22", v, max(3, reps // 4), check=check, oracle_vals=small)
+        fl = 2 * 4096**3
+        res["c3_dot22"] = {"config": "C3 Dot22 4096^3 f64", "ms_device": td, "ms_call": tw, "achieved": fl / td / 1e9, "unit": "TFLOP/s",
+                           "peak": F64_MFMA_PEAK, "frac": fl / td / 1e9 / F64_MFMA_PEAK, "bound": "mfma f64"}
+        td, tw = run_case("c3_gemv", v, reps, check=check, oracle_vals=small)
+        b = 4096 * 4096 * 8
+        res["c3_gemv"] = {"config": "C3 Gemv 4096^2 f64", "ms_device": td, "ms_call": tw, "achieved": b / td / 1e6, "unit": "GB/s",
+                          "peak": HBM_PEAK, "frac": b / td / 1e6 / HBM_PEAK, "bound": "hbm"}
+        td, tw = run_case("c3_bdot", v, reps, check=check, rtol=1e-4, oracle_vals=small)
+        fl = 2 * 512 * 256**3
+        res["c3_bdot"] = {"config": "C3 BatchedDot 512x(256x256) f32", "ms_device": td, "ms_call": tw, "achieved": fl / td / 1e9,
+                          "unit": "TFLOP/s", "peak": F32_MFMA_PEAK, "frac": fl / td / 1e9 / F32_MFMA_PEAK, "bound": "mfma f32"}
+    if "c5" in which:
+        T, B, H = 1000, 64, 1024
+        v = configs.c5_inputs(T=T, B=B, H=H)
+        small = configs.c5_inputs(T=5, B=8, H=64)
+        td, tw = run_case("c5_gru", v, 3, check=check, rtol=2e-4, oracle_vals=small)
+        fl = 6 * 2 * B * H * H * T
+        res["c5"] = {"config": f"C5 GRU Scan T={T} B={B} H={H} f32", "ms_device": td, "ms_call": tw, "us_per_step": td / T * 1e3,
+                     "achieved": fl / td / 1e9, "unit": "TFLOP/s", "peak": F32_MFMA_PEAK, "frac": fl / td / 1e9 / F32_MFMA_PEAK,
+                     "bound": "mfma f32 (skinny M=64, dependent steps)"}
+    return res
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     reps = 20
     if "--reps" in sys.argv:
         reps = int(sys.argv[sys.argv.index("--reps") + 1])
-    which = args or ["c1", "c2", "c3", "c5"]
+    which = [a for a in args if not a.isdigit()] or ["c1", "c2", "c3", "c5"]
     ffi.init(0)
-    res = []
-    if "c1" in which:
-        v = configs.c1_inputs()
-        td, tw = run_case("c1_gauss", v, reps)
-        b = 1.6e6
-        res.append({"config": "C1 exp(-0.5(x-mu)^2).sum()+grad N=1e5 f64", "ms_device": td, "ms_call": tw, "GBs": b / td / 1e6, "bound": "launch latency"})
-    if "c2" in which:
-        v = configs.c2_inputs()
-        small = configs.c2_inputs(N=1_000_000)
-        for nm, label in (("c2_cheap", "C2 cheap 52-op Composite+Sum N=1e7 f64"), ("c2_transc", "C2 transcendental (10 tanh + 10 exp) Composite+Sum N=1e7 f64")):
-            td, tw = run_case(nm, v, reps, oracle_vals=small)
-            b = 160e6
-            res.append({"config": label, "ms_device": td, "ms_call": tw, "GBs": b / td / 1e6, "frac_hbm": b / td / 1e6 / HBM_PEAK, "bound": "hbm"})
-    if "c3" in which:
-        v = configs.c3_inputs()
-        small = configs.c3_inputs(M=512, B=8, Bn=64)
-        td, tw = run_case("c3_dot22", v, max(3, reps // 4), oracle_vals=small)
-        fl = 2 * 4096**3
-        res.append({"config": "C3 Dot22 4096^3 f64", "ms_device": td, "ms_call": tw, "TFLOPs": fl / td / 1e9, "frac_mfma": fl / td / 1e9 / F64_MFMA_PEAK, "bound": "mfma f64"})
-        td, tw = run_case("c3_gemv", v, reps, oracle_vals=small)
-        b = 4096 * 4096 * 8
-        res.append({"config": "C3 Gemv 4096^2 f64", "ms_device": td, "ms_call": tw, "GBs": b / td / 1e6, "frac_hbm": b / td / 1e6 / HBM_PEAK, "bound": "hbm"})
-        td, tw = run_case("c3_bdot", v, reps, rtol=1e-4, oracle_vals=small)
-        fl = 2 * 512 * 256**3
-        res.append({"config": "C3 BatchedDot 512x(256x256) f32", "ms_device": td, "ms_call": tw, "TFLOPs": fl / td / 1e9, "frac_mfma": fl / td / 1e9 / F32_MFMA_PEAK, "bound": "mfma f32"})
-    if "c5" in which:
-        T, B, H = 1000, 64, 1024
-        v = configs.c5_inputs(T=T, B=B, H=H)
-        small = configs.c5_inputs(T=5, B=8, H=64)
-        td, tw = run_case("c5_gru", v, 3, rtol=2e-4, oracle_vals=small)
-        fl = 6 * 2 * B * H * H * T
-        res.append({"config": f"C5 GRU Scan T={T} B={B} H={H} f32", "ms_device": td, "ms_call": tw, "ms_per_step": td / T, "TFLOPs": fl / td / 1e9, "frac_mfma": fl / td / 1e9 / F32_MFMA_PEAK, "bound": "mfma f32 (skinny M)"})
-    for r in res:
-        print(json.dumps(r))
+    for k, r in measure(which, reps).items():
+        print(json.dumps({"key": k, **r}))
 
 
 if __name__ == "__main__":
