@@ -261,6 +261,13 @@ size_t pthip_scatter_rows_workspace(int64_t n_idx, int64_t n_rows, int64_t inner
 int pthip_scatter_rows(int dtype, int inc, int64_t n_idx, int64_t inner, void* out, int64_t n_rows,
                        const int64_t* idx, const void* y, int64_t y_stride0, void* ws,
                        size_t ws_bytes);
+/* Second stages in one launch: up to 16 row-major partial slabs parts[k] of shape [nparts[k], M[k]]
+ * (per-workgroup partials of a split Gemv / scatter-add — pytensor/tensor/blas/gemv.py:64-108 —
+ * or of a CAReduce, elemwise.py:1233) are reduced with ops[k] (pthip_reduce_op ADD/MUL/MAX/MIN)
+ * to outs[k] of shape [S[k], M[k]]; row chunk s covers rows [s*ceil(nparts/S), ...).  Fixed
+ * order, deterministic.  The tail kernel of the executor adds the S rows. */
+int pthip_multi_finish(int dtype, int n_tasks, const int* ops, const void* const* parts,
+                       const int64_t* nparts, const int64_t* M, const int* S, void* const* outs);
 /* gather up to 16 small contiguous device buffers into one staging buffer (one launch instead of
  * one D2H copy per Function output; cf. the output loop of pytensor/link/basic.py:683-684) */
 int pthip_pack(int n, const void* const* srcs, const int64_t* nbytes, const int64_t* dst_offsets,

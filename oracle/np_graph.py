@@ -1022,3 +1022,16 @@ def _gemm_partials(p, inputs, node, graph):
     # one slab = the whole product; the consumer's "partial_inputs" sum over the slab axis
     A, B = inputs
     return [np.dot(A, B)[None]]
+
+
+@op("Tail")
+def _tail(p, inputs, node, graph):
+    # tailfuse.fuse_tail: the member nodes in their original order (the fusion changes how many
+    # launches they cost on the device, not what they compute)
+    env = dict(zip(node.inputs, inputs))
+    for sub in p["nodes"]:
+        ins = [env[i] if i in env else graph.vars[i].const for i in sub.inputs]
+        outs = OPS[sub.op](sub.params, ins, sub, graph)
+        for vid, val in zip(sub.outputs, outs):
+            env[vid] = val
+    return [env[o] for o in node.outputs]

@@ -1174,3 +1174,139 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
 
 def source_key(src: str) -> str:
     return hashlib.sha256(src.encode()).hexdigest()[:24]
+
+
+# ---------------------------------------------------------------------------
+# Tail kernel: a chain of small nodes in ONE single-workgroup launch (tailfuse.py)
+# ---------------------------------------------------------------------------
+
+TAIL_BLOCK = 256
+
+
+def tail_chain_source(name: str, spec: dict) -> str:
+    """One workgroup runs ``spec["steps"]`` in order, intermediates in LDS.
+
+    ``spec`` is purely structural (extents are kernel arguments, so one code object serves every
+    size):
+
+    * ``ext``   — external operands: ``{"kind": "V" (vector: pointer + element stride) | "S"
+      (device scalar) | "C" (host scalar by value) | "P" (row-major partial slab / partials),
+      "dtype"}``;
+    * ``slots`` — LDS values ``{"dtype"}`` (byte offset and length arrive as arguments);
+    * ``steps`` — ``finish``: ``out[i] = beta*y[i] + alpha*sum_s src[s*M+i]`` (the second stage +
+      epilogue of a split Gemv / scatter-add, blas/gemv.py:64-108; ``y`` optional),
+      ``rsum``: a deferred full reduction over ``rows`` partials (elemwise.py:1233 second stage),
+      ``ew``: an ``Elemwise`` / ``ElemwiseReduce`` over ``n`` elements with per-operand modes;
+    * ``outs``  — LDS slots copied to their destinations at the end; optional status-word copy.
+
+    Operand references are ``("e", k)`` (external) or ("l", k) (LDS slot).  Argument order =
+    the order of ``tail_chain_args``.
+    """
+    ext, slots, steps = spec["ext"], spec["slots"], spec["steps"]
+    P = []
+    for k, e in enumerate(ext):
+        ct = CTYPE[e["dtype"]]
+        if e["kind"] == "C":
+            P.append(f"const long long ec{k}")
+        elif e["kind"] == "V":
+            P += [f"const {ct}* __restrict__ e{k}", f"const long long es{k}"]
+        else:
+            P.append(f"const {ct}* __restrict__ e{k}")
+    for k in range(len(slots)):
+        P += [f"const long long off{k}"]
+    for j, st in enumerate(steps):
+        if st["op"] == "finish":
+            P += [f"const long long rows{j}", f"const long long M{j}", f"const double alpha{j}", f"const double beta{j}"]
+        elif st["op"] == "rsum":
+            P += [f"const long long rows{j}"]
+        else:
+            P += [f"const long long n{j}"]
+    for k, o in enumerate(spec["outs"]):
+        P += [f"{CTYPE[slots[o]['dtype']]}* __restrict__ dst{k}", f"const long long len{k}"]
+    P += ["const int* status_src", "int* status_dst"]
+    bodies = [st["body"] for st in steps if st["op"] == "ew"]
+    L = [reduce_header(), prelude_for(*bodies)]
+    L.append(f'extern "C" __global__ __launch_bounds__({TAIL_BLOCK}) void {name}({", ".join(P)}) {{')
+    L.append("  extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];")
+    L.append("  __shared__ double red_[8];")
+    L.append("  const int tid = threadIdx.x;")
+    for k, e in enumerate(ext):
+        if e["kind"] == "C":
+            ct = CTYPE[e["dtype"]]
+            L.append(f"  {ct} c{k}; {{ const long long b = ec{k}; __builtin_memcpy(&c{k}, &b, sizeof({ct})); }}")
+    for k, s in enumerate(slots):
+        ct = CTYPE[s["dtype"]]
+        L.append(f"  {ct}* const l{k} = ({ct}*)(lds_ + off{k});")
+
+    def operand(ref, mode, i="i"):
+        kind, k = ref
+        if kind == "e":
+            e = ext[k]
+            if e["kind"] == "C":
+                return f"c{k}"
+            if e["kind"] == "V":
+                return f"e{k}[{i} * es{k}]" if mode == "V" else f"e{k}[0]"
+            return f"e{k}[0]"
+        return f"l{k}[{i}]" if mode == "V" else f"l{k}[0]"
+
+    for j, st in enumerate(steps):
+        if st["op"] == "finish":
+            ct = CTYPE[st["dtype"]]
+            src = f"e{st['src'][1]}"
+            L.append(f"  // step {j}: second stage + epilogue of a split Gemv / scatter-add")
+            L.append(f"  for (long long i = tid; i < M{j}; i += {TAIL_BLOCK}) {{")
+            L.append(f"    {ct} a0 = 0, a1 = 0;")
+            L.append(f"    long long s = 0;")
+            L.append(f"    for (; s + 1 < rows{j}; s += 2) {{ a0 += {src}[s * M{j} + i]; a1 += {src}[(s + 1) * M{j} + i]; }}")
+            L.append(f"    if (s < rows{j}) a0 += {src}[s * M{j} + i];")
+            L.append(f"    {ct} r = ({ct})alpha{j} * (a0 + a1);")
+            if st.get("y") is not None:
+                L.append(f"    if (beta{j} != 0.0) r += ({ct})beta{j} * ({ct}){operand(st['y'], st['ymode'])};")
+            L.append(f"    l{st['out']}[i] = r;")
+            L.append("  }")
+            L.append("  __syncthreads();")
+        elif st["op"] == "rsum":
+            act, oct_ = CTYPE[st["acc_dtype"]], CTYPE[st["dtype"]]
+            op = REDUCE_OPS[st["red"]]
+            src = f"e{st['src'][1]}"
+            L.append(f"  // step {j}: deferred second stage of a fused Elemwise+reduce kernel")
+            L.append("  {")
+            L.append(f"    {act} a = pthip_dev::{op}::identity<{act}>();")
+            L.append(f"    for (long long p = tid; p < rows{j}; p += {TAIL_BLOCK}) a = pthip_dev::{op}::apply(a, ({act}){src}[p]);")
+            L.append(f"    a = pthip_dev::block_reduce<pthip_dev::{op}, {act}, {TAIL_BLOCK}, true>(a, ({act}*)red_);")
+            L.append(f"    if (tid == 0) l{st['out']}[0] = ({oct_})a;")
+            L.append("  }")
+            L.append("  __syncthreads();")
+        else:
+            body, modes, red = st["body"], st["modes"], st["reduce"]
+            L.append(f"  // step {j}: Elemwise over n{j} elements, operand modes {modes}")
+            L.append("  {")
+            for q, r in enumerate(red):
+                if r is not None:
+                    act = CTYPE[r[1]]
+                    L.append(f"    {act} acc{q} = pthip_dev::{REDUCE_OPS[r[0]]}::identity<{act}>();")
+            L.append(f"    for (long long i = tid; i < n{j}; i += {TAIL_BLOCK}) {{")
+            in_names = [operand(ref, m) for ref, m in zip(st["ins"], modes)]
+            out_names = []
+            for q, dt in enumerate(body["out_dtypes"]):
+                L.append(f"      {CTYPE[dt]} o{q};")
+                out_names.append(f"o{q}")
+            L.append(emit_body(body, in_names, out_names, indent="      "))
+            for q, r in enumerate(red):
+                if r is None:
+                    L.append(f"      l{st['outs'][q]}[i] = o{q};")
+                else:
+                    L.append(f"      acc{q} = pthip_dev::{REDUCE_OPS[r[0]]}::apply(acc{q}, ({CTYPE[r[1]]})o{q});")
+            L.append("    }")
+            for q, r in enumerate(red):
+                if r is not None:
+                    act = CTYPE[r[1]]
+                    L.append(f"    acc{q} = pthip_dev::block_reduce<pthip_dev::{REDUCE_OPS[r[0]]}, {act}, {TAIL_BLOCK}, true>(acc{q}, ({act}*)red_);")
+                    L.append(f"    if (tid == 0) l{st['outs'][q]}[0] = ({CTYPE[r[2]]})acc{q};")
+            L.append("  }")
+            L.append("  __syncthreads();")
+    for k, o in enumerate(spec["outs"]):
+        L.append(f"  for (long long i = tid; i < len{k}; i += {TAIL_BLOCK}) dst{k}[i] = l{o}[i];")
+    L.append("  if (tid == 0 && status_dst != nullptr) *status_dst = __hip_atomic_load(status_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);")
+    L.append("}")
+    return "\n".join(L)

@@ -336,11 +336,26 @@ def alloc_partials(spec, grid):
     return parts
 
 
-def finish_partials(env, spec, parts, grid):
-    """Second stage: per-workgroup partials -> final 0-d values (fixed order, deterministic)."""
+def finish_partials(env, spec, parts, grid, defer=()):
+    """Second stage: per-workgroup partials -> final 0-d values (fixed order, deterministic).
+    ``defer``: output positions whose only consumer is a ``Tail`` node — left as
+    :class:`~pytensor_amd.executor.DeferredReduce` (no launch here)."""
     res = [None] * len(spec)
     red = [k for k, r in enumerate(spec) if r is not None]
     if not red:
+        return res
+    if defer and grid > 1:
+        from pytensor_amd.executor import DeferredReduce
+
+        rest = [None if (k in defer or r is None) else r for k, r in enumerate(spec)]
+        for k in red:
+            if k in defer:
+                res[k] = DeferredReduce(parts[k], grid, spec[k])
+        if any(r is not None for r in rest):
+            # (the non-deferred ones keep their own second stage; a shared slab is then read per output)
+            for k, r in enumerate(rest):
+                if r is not None:
+                    res[k] = device_reduce(env, r["op"], parts[k], 1, grid, 1, 0, 1, 0, r["acc_dtype"], r["dtype"], ())
         return res
     if grid == 1:
         # a single workgroup already produced the final value: no second-stage launch
@@ -446,7 +461,7 @@ def elemwise_reduce(node, inputs, env):
     g = env.graph
     ins, shape, pi, gather = _prepare(node, inputs, env)
     outs, parts, grid = launch_elemwise(body, ins, shape, body["out_dtypes"], spec, env, pi, _placed(env, node, shape, body["out_dtypes"]), gather)
-    finals = finish_partials(env, spec, parts, grid) if grid else [None] * len(spec)
+    finals = finish_partials(env, spec, parts, grid, node.params.get("defer_reduce") or ()) if grid else [None] * len(spec)
     res = []
     for k, r in enumerate(spec):
         if r is None:

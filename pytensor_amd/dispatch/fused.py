@@ -166,7 +166,7 @@ def gemv_chain(node, inputs, env):
     ffi.check(env.lib.pthip_launch(fn, grid, 1, 1, BLOCK, 1, 1, 0, buf, len(buf)))
     if kt is not None:
         kt.end(name, tok)
-    finals = finish_partials(env, spec, parts, grid)
+    finals = finish_partials(env, spec, parts, grid, p.get("defer_reduce") or ())
     res = [r_out] if store_r else []
     for k in range(nout):
         res.append(finals[k] if spec[k] is not None else stored[k])

@@ -28,7 +28,7 @@ def _inner_executable(node, env) -> HipExecutable:
     key = id(node.params["inner"])
     exe = _inner_cache.get(key)
     if exe is None:
-        exe = HipExecutable(node.params["inner"], device=env.exe._device)
+        exe = HipExecutable(node.params["inner"], device=env.exe._device, tail=False)
         _inner_cache[key] = (exe, node.params["inner"])
         return exe
     return exe[0]

@@ -1,0 +1,310 @@
+"""``Tail`` — the small nodes at the end of an evaluation in two launches (tailfuse.py).
+
+The member nodes keep their reference meaning (``GemvFinish`` = second stage + epilogue of
+pytensor/tensor/blas/gemv.py:64-108, ``Elemwise`` / ``ElemwiseReduce`` = elemwise.py:375 /
+1233, ``DimShuffle`` = a view, elemwise.py:41); this handler only decides *how many launches*
+they cost.  Extents are checked at run time: when every operand is a scalar or a short vector,
+``pthip_multi_finish`` shrinks the large partial slabs and ONE generated single-workgroup kernel
+does the rest (``codegen.tail_chain_source``); otherwise the members run through their own
+handlers, exactly as before the fusion.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import struct
+
+import numpy as np
+
+from pytensor_amd import codegen, ffi, kernel_cache
+from pytensor_amd.device import DeviceArray
+from pytensor_amd.dispatch import HANDLERS, handler
+from pytensor_amd.dispatch.elemwise import _body_key, _scalar_bits
+from pytensor_amd.executor import DeferredReduce, HostValue
+
+MAX_LEN = 4096  # elements per vector the single workgroup loops over
+MAX_LDS = 48 << 10
+SHRINK_MIN = 8192  # slabs below this many elements are summed by the tail kernel directly
+SHRINK_ROWS = 16
+_FLOAT = ("float64", "float32")
+
+
+class _Infeasible(Exception):
+    pass
+
+
+class _Val:
+    """What the planner knows about a value: where it lives and its shape."""
+
+    __slots__ = ("ref", "shape", "dtype", "host", "dev")
+
+    def __init__(self, ref, shape, dtype, host=None, dev=None):
+        self.ref, self.shape, self.dtype, self.host, self.dev = ref, tuple(shape), str(dtype), host, dev
+
+    @property
+    def size(self):
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+
+def _vec_len(shape):
+    """length of a value that is a scalar or a vector up to size-1 dims; None otherwise"""
+    big = [s for s in shape if s != 1]
+    if len(big) > 1:
+        return None
+    return big[0] if big else 1
+
+
+class _Planner:
+    def __init__(self, env):
+        self.env = env
+        self.ext, self.ext_args = [], []  # structural descriptors / runtime arguments
+        self.slots, self.slot_len = [], []
+        self.steps, self.step_args = [], []
+        self.keep = []
+        self.shrink = []  # (op code, slab, nparts, M, S, out buffer)
+
+    def add_ext(self, v) -> _Val:
+        if isinstance(v, HostValue):
+            if v.a.size != 1:
+                raise _Infeasible("host array operand")
+            dt = str(v.a.dtype)
+            if dt not in codegen.CTYPE:
+                raise _Infeasible(dt)
+            self.ext.append({"kind": "C", "dtype": dt})
+            self.ext_args.append([("q", _scalar_bits(v, dt))])
+            return _Val(("e", len(self.ext) - 1), v.a.shape, dt, host=v)
+        if isinstance(v, DeferredReduce):
+            return _Val(None, (), v.spec["dtype"], dev=v)  # consumed through an `rsum` step
+        if not isinstance(v, DeviceArray):
+            raise _Infeasible(type(v).__name__)
+        dt = str(v.dtype)
+        if dt not in codegen.CTYPE:
+            raise _Infeasible(dt)
+        n = _vec_len(v.shape)
+        if n is None or n > MAX_LEN:
+            return _Val(None, v.shape, dt, dev=v)  # only usable as a partial slab
+        if n == 1:
+            self.ext.append({"kind": "S", "dtype": dt})
+            self.ext_args.append([("q", v.ptr)])
+        else:
+            stride = [st for s, st in zip(v.shape, v.strides) if s != 1][0]
+            self.ext.append({"kind": "V", "dtype": dt})
+            self.ext_args.append([("q", v.ptr), ("q", stride)])
+        self.keep.append(v)
+        return _Val(("e", len(self.ext) - 1), v.shape, dt, dev=v)
+
+    def add_slab(self, arr: DeviceArray) -> tuple:
+        self.ext.append({"kind": "P", "dtype": str(arr.dtype)})
+        self.ext_args.append([("q", arr.ptr)])
+        self.keep.append(arr)
+        return ("e", len(self.ext) - 1)
+
+    def new_slot(self, shape, dtype) -> _Val:
+        n = 1
+        for s in shape:
+            n *= s
+        if n > MAX_LEN or _vec_len(shape) is None:
+            raise _Infeasible("large intermediate")
+        self.slots.append({"dtype": str(dtype)})
+        self.slot_len.append(n)
+        return _Val(("l", len(self.slots) - 1), shape, dtype)
+
+    def materialise(self, val: _Val) -> _Val:
+        """A deferred reduction becomes an LDS scalar through an `rsum` step (once)."""
+        if val.ref is not None:
+            return val
+        d = val.dev
+        if not isinstance(d, DeferredReduce):
+            raise _Infeasible("large operand")
+        if d.spec["op"] not in codegen.REDUCE_OPS or d.spec["acc_dtype"] not in codegen.CTYPE:
+            raise _Infeasible("reduction op")
+        out = self.new_slot((), d.spec["dtype"])
+        src = self.add_slab(d.parts)
+        self.steps.append({"op": "rsum", "src": src, "red": d.spec["op"], "acc_dtype": d.spec["acc_dtype"], "dtype": d.spec["dtype"],
+                           "out": out.ref[1]})
+        self.step_args.append([("q", d.grid)])
+        val.ref, val.shape = out.ref, ()
+        return val
+
+
+def _plan(node, inputs, env):
+    P = _Planner(env)
+    vals = {vid: P.add_ext(v) for vid, v in zip(node.inputs, inputs)}
+    g = env.graph
+
+    def const_scalar(vid):
+        v = vals.get(vid)
+        if v is None:
+            c = g.vars[vid].const
+            if c is None:
+                raise _Infeasible("unbound operand")
+            v = vals[vid] = P.add_ext(HostValue(np.asarray(c)) if np.asarray(c).size == 1 else env.exe._const(vid, env))
+        return v
+
+    for sub in node.params["nodes"]:
+        for vid in sub.inputs:
+            if vid not in vals:
+                const_scalar(vid)
+        if sub.op == "DimShuffle":
+            x = vals[sub.inputs[0]]
+            if x.ref is None and not isinstance(x.dev, DeferredReduce):
+                raise _Infeasible("view of a large operand")
+            x = P.materialise(x)
+            order = sub.params["new_order"]
+            shape = tuple(1 if o == "x" else x.shape[o] for o in order)
+            if _vec_len(shape) is None:
+                raise _Infeasible("view shape")
+            vals[sub.outputs[0]] = _Val(x.ref, shape, x.dtype, host=x.host, dev=x.dev)
+        elif sub.op == "GemvFinish":
+            part, y, a, b = (vals[v] for v in sub.inputs)
+            slab = part.dev
+            if not isinstance(slab, DeviceArray) or slab.ndim != 2 or not slab.is_contiguous() or str(slab.dtype) not in _FLOAT:
+                raise _Infeasible("partial slab layout")
+            if a.host is None or b.host is None:
+                raise _Infeasible("device alpha/beta")
+            alpha, beta = float(a.host.a.reshape(-1)[0]), float(b.host.a.reshape(-1)[0])
+            rows, M = slab.shape
+            if M > MAX_LEN:
+                raise _Infeasible("long finish")
+            if rows * M >= SHRINK_MIN and rows > SHRINK_ROWS:
+                S = SHRINK_ROWS
+                small = DeviceArray.empty((S, M), slab.dtype)
+                P.shrink.append((ffi.REDUCE_CODE["Add"], slab, rows, M, S, small))
+                slab, rows = small, S
+            src = P.add_slab(slab)
+            out = P.new_slot((M,), slab.dtype)
+            st = {"op": "finish", "src": src, "dtype": str(slab.dtype), "y": None, "ymode": "V", "out": out.ref[1]}
+            if beta != 0.0:
+                y = P.materialise(y)
+                n = _vec_len(y.shape)
+                if n not in (1, M):
+                    raise ValueError(f"Shape mismatch: y.shape[0] != A.shape[0] ({y.shape}, {M})")
+                st["y"], st["ymode"] = y.ref, ("V" if n == M and M > 1 else "S")
+            P.steps.append(st)
+            P.step_args.append([("q", rows), ("q", M), ("d", alpha), ("d", beta)])
+            vals[sub.outputs[0]] = out
+        else:  # Elemwise / ElemwiseReduce
+            body = sub.params["scalar"]
+            if not codegen.supported(body):
+                raise _Infeasible("scalar op")
+            ins = [P.materialise(vals[v]) for v in sub.inputs]
+            nd = max((len(v.shape) for v in ins), default=0)
+            shape = [1] * nd
+            for v in ins:
+                sh = (1,) * (nd - len(v.shape)) + v.shape
+                for d, s in enumerate(sh):
+                    if s != 1:
+                        if shape[d] not in (1, s):
+                            raise ValueError(f"Runtime broadcasting not allowed: operand shapes {[i.shape for i in ins]}")
+                        shape[d] = s
+            n = _vec_len(shape)
+            if n is None or n > MAX_LEN:
+                raise _Infeasible("large elementwise")
+            modes = "".join("C" if (v.ref[0] == "e" and P.ext[v.ref[1]]["kind"] == "C") else ("V" if (v.size == n and n > 1) else "S") for v in ins)
+            for pos, (v, m) in enumerate(zip(ins, modes)):
+                # the reference forbids broadcasting a runtime length-1 dim that is not statically 1
+                # (elemwise.py:825-840); the member's own handler raises the exact message: let it
+                if m == "S" and n > 1 and any(s is None for s in g.vars[sub.inputs[pos]].shape):
+                    raise _Infeasible("runtime broadcast check")
+            spec = sub.params.get("reduce") or [None] * len(body["out_dtypes"])
+            outs, red = [], []
+            for q, (r, dt) in enumerate(zip(spec, body["out_dtypes"])):
+                if r is None:
+                    o = P.new_slot(tuple(shape), dt)
+                    red.append(None)
+                else:
+                    if r["op"] not in codegen.REDUCE_OPS:
+                        raise _Infeasible("reduction op")
+                    o = P.new_slot((), r["dtype"])
+                    red.append((r["op"], r["acc_dtype"], r["dtype"]))
+                outs.append(o)
+                vals[sub.outputs[q]] = o
+            P.steps.append({"op": "ew", "body": body, "ins": [v.ref for v in ins], "modes": modes, "outs": [o.ref[1] for o in outs], "reduce": red})
+            P.step_args.append([("q", n)])
+    results = []
+    for vid in node.outputs:
+        v = vals[vid]
+        if v.ref is None or v.ref[0] != "l":
+            raise _Infeasible("pass-through output")
+        results.append(v)
+    return P, results
+
+
+def _run_fused(node, P, results, env):
+    lib = env.lib
+    # launch 1: every large slab -> <= 16 rows
+    by_dt = {}
+    for t in P.shrink:
+        by_dt.setdefault(str(t[1].dtype), []).append(t)
+    for dt, ts in by_dt.items():
+        for c0 in range(0, len(ts), 16):
+            chunk = ts[c0 : c0 + 16]
+            n = len(chunk)
+            ffi.check(lib.pthip_multi_finish(
+                ffi.np_dtype_code(dt), n, (C.c_int * n)(*[t[0] for t in chunk]), (C.c_void_p * n)(*[t[1].ptr for t in chunk]),
+                (C.c_int64 * n)(*[t[2] for t in chunk]), (C.c_int64 * n)(*[t[3] for t in chunk]), (C.c_int * n)(*[t[4] for t in chunk]),
+                (C.c_void_p * n)(*[t[5].ptr for t in chunk])))
+    # launch 2: the chain
+    off, offs = 0, []
+    for s, n in zip(P.slots, P.slot_len):
+        offs.append(off)
+        off += (max(n, 1) * np.dtype(s["dtype"]).itemsize + 15) // 16 * 16
+    if off > MAX_LDS:
+        raise _Infeasible("LDS")
+    outs, out_args = [], []
+    for vid, v in zip(node.outputs, results):
+        dst = env.placement.get(vid) if env.placement else None
+        if not (dst is not None and dst.shape == v.shape and str(dst.dtype) == v.dtype and dst.is_contiguous()):
+            dst = DeviceArray.empty(v.shape, v.dtype)
+        outs.append(dst)
+        out_args += [("q", dst.ptr), ("q", v.size)]
+    spec = {"ext": P.ext, "slots": P.slots, "steps": P.steps, "outs": [v.ref[1] for v in results]}
+    key = repr([[(e["kind"], e["dtype"]) for e in P.ext], [s["dtype"] for s in P.slots],
+                [{k: (_body_key(v) if k == "body" else v) for k, v in st.items()} for st in P.steps], spec["outs"]])
+    name = "tail_" + codegen.source_key(key)[:16]
+    src = codegen.tail_chain_source(name, spec)
+    fn = kernel_cache.get_function(src, name)
+    args = [a for e in P.ext_args for a in e] + [("q", o) for o in offs] + [a for s in P.step_args for a in s] + out_args
+    status = getattr(env, "tail_status", None) or (0, 0)
+    args += [("q", status[0]), ("q", status[1])]
+    buf = struct.pack("<" + "".join(a[0] for a in args), *[a[1] for a in args])
+    kt = env.kernel_timer
+    tok = kt.begin() if kt is not None else None
+    ffi.check(lib.pthip_launch(fn, 1, 1, 1, codegen.TAIL_BLOCK, 1, 1, max(off, 16), buf, len(buf)))
+    if kt is not None:
+        kt.end(name, tok)
+    if status[1]:
+        env.tail_status_done = True
+    return outs
+
+
+def _run_members(node, inputs, env):
+    """The members one by one through their own handlers (what the graph was before the fusion)."""
+    vals = dict(zip(node.inputs, inputs))
+    env.donated = frozenset()  # (positions refer to the Tail node, not to its members)
+    for sub in node.params["nodes"]:
+        ins = []
+        for vid in sub.inputs:
+            v = vals.get(vid)
+            if v is None:
+                v = env.exe._const(vid, env)
+            if isinstance(v, DeferredReduce):
+                v = v.force(env)
+                vals[vid] = v
+            ins.append(v)
+        outs = HANDLERS[sub.op](sub, ins, env)
+        for o, val in zip(sub.outputs, outs):
+            vals[o] = val
+    return [vals[o] for o in node.outputs]
+
+
+@handler("Tail")
+def tail(node, inputs, env):
+    try:
+        P, results = _plan(node, inputs, env)
+        return _run_fused(node, P, results, env)
+    except _Infeasible:
+        return _run_members(node, inputs, env)

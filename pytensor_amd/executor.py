@@ -123,6 +123,31 @@ def _resident_key(value, a):
     return (id(value), a.ctypes.data, a.shape, a.strides, a.dtype.str)
 
 
+class DeferredReduce:
+    """A 0-d value whose second-stage reduction has not run yet: the per-workgroup partials of a
+    fused Elemwise+reduce kernel (``parts``: ``[grid]`` in the accumulator dtype).  Produced only
+    for outputs whose every consumer is a ``Tail`` node (tailfuse.py), which folds the sum into
+    its one kernel; anything else that touches the value forces it (``Env.to_device``)."""
+
+    __slots__ = ("parts", "grid", "spec", "_forced")
+    ndim, shape, size = 0, (), 1
+
+    def __init__(self, parts, grid, spec):
+        self.parts, self.grid, self.spec, self._forced = parts, int(grid), spec, None
+
+    @property
+    def dtype(self):
+        return np.dtype(self.spec["dtype"])
+
+    def force(self, env) -> DeviceArray:
+        if self._forced is None:
+            from pytensor_amd.dispatch.elemwise import device_reduce
+
+            r = self.spec
+            self._forced = device_reduce(env, r["op"], self.parts, 1, self.grid, 1, 0, 1, 0, r["acc_dtype"], r["dtype"], ())
+        return self._forced
+
+
 class KernelTimer:
     """HIP-event brackets around individual generated-kernel launches (profiling only)."""
 
@@ -184,10 +209,16 @@ class Env:
         # var id -> DeviceArray the producing kernel should write into directly (a Scan's trace
         # slot): handlers that support it skip their own allocation, the caller skips the copy
         self.placement = {}
+        # frozen plans: (device status word, pinned destination) — the Tail kernel, being the last
+        # launch, carries the error word to the host along with its results
+        self.tail_status = None
+        self.tail_status_done = False
 
     def to_device(self, v) -> DeviceArray:
         if isinstance(v, DeviceArray):
             return v
+        if isinstance(v, DeferredReduce):
+            return v.force(self)
         if isinstance(v, HostValue):
             if v.dev is None:
                 a = v.a if v.a.flags.c_contiguous else np.ascontiguousarray(v.a)
@@ -201,6 +232,8 @@ class Env:
         the value lives on the device."""
         if isinstance(v, HostValue):
             return v.a
+        if isinstance(v, DeferredReduce):
+            v = v.force(self)
         if isinstance(v, DeviceArray):
             if self.exe._capturing:
                 raise ffi.HipError("data-dependent host read inside a frozen (hipGraph) plan")
@@ -218,7 +251,7 @@ class HipExecutable:
     the class opt in."""
 
     def __init__(self, graph: Graph, resident=(), device: int | None = None, fuse=True, auto_freeze=False,
-                 update_map=None):
+                 update_map=None, tail=True):
         from pytensor_amd import dispatch  # registers handlers
         from pytensor_amd.passes import run_pipeline
 
@@ -228,7 +261,7 @@ class HipExecutable:
         self._auto_failed = False
         self.source_graph = graph
         # per-node segment ids for multi-stream plans (fusion.segment_graph), or None
-        self.graph, self.segments = run_pipeline(graph, fuse)
+        self.graph, self.segments = run_pipeline(graph, fuse, tail=tail)
         self.resident = set(resident)
         # a captured launch sequence would replay the same Philox counters: graphs that draw
         # random numbers run eagerly (sampling graphs are not the logp+grad hot path)

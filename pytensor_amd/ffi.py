@@ -116,6 +116,7 @@ SIGNATURES = {
     "pthip_scatter_rows_workspace": (_sz, [_i64, _i64, _i64]),
     "pthip_scatter_rows": (_int, [_int, _int, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _sz]),
     "pthip_pack": (_int, [_int, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_i64), _vp]),
+    "pthip_multi_finish": (_int, [_int, _int, C.POINTER(_int), C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_int), C.POINTER(_vp)]),
     "pthip_softmax": (_int, [_int, _int, _i64, _i64, _vp, _vp]),
     "pthip_cumulative": (_int, [_int, _int, _i64, _i64, _i64, _vp, _vp]),
     "pthip_imatmul": (_int, [_int, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp]),

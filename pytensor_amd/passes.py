@@ -11,7 +11,8 @@ Order matters:
    ``defer_gemm_finish`` (gemmfuse.py) — split-K finish + Gemm epilogue folded into the
    consuming elementwise kernel (also inside Scan inner graphs);
 6. ``fuse_gemv_chain`` — ``X@b → Composite → X.T@w`` (+ gathers, + scatter-add) in one pass;
-7. ``dead_code_elimination``;
+7. ``dead_code_elimination``; ``fuse_tail`` (tailfuse.py) — the small nodes at the end of the
+   graph in two launches;
 8. ``segment_graph`` — latency chain / streaming / combine segments for multi-stream plans.
 
 ``fuse=False`` leaves the lowered graph untouched (one launch per reference ``Apply``: the
@@ -19,6 +20,8 @@ parity tests compare the two); ``fuse="elemwise"`` stops after step 2.
 """
 
 from __future__ import annotations
+
+import os
 
 from pytensor_amd.fusion import (
     fuse_cholesky_solve,
@@ -36,10 +39,13 @@ from pytensor_amd.inline import (
     push_gather_through_elemwise,
 )
 from pytensor_amd.ir import Graph
+from pytensor_amd.tailfuse import fuse_tail
 
 
-def run_pipeline(graph: Graph, fuse=True):
-    """Returns ``(graph, segments)``; ``segments`` is ``None`` when there is nothing to overlap."""
+def run_pipeline(graph: Graph, fuse=True, tail=True):
+    """Returns ``(graph, segments)``; ``segments`` is ``None`` when there is nothing to overlap.
+    ``tail=False`` (Scan inner graphs: run once per step, nothing small enough to matter) skips
+    the tail fusion."""
     if not fuse:
         return graph, None
     if fuse == "elemwise":
@@ -52,4 +58,6 @@ def run_pipeline(graph: Graph, fuse=True):
     g = merge_sibling_gemms(defer_gemm_finish(g))
     g = absorb_gathers(fuse_gemv_chain(g))  # gchain takes the gathers it can use first
     g = dead_code_elimination(g)
+    if tail and os.environ.get("PTHIP_TAIL", "1") != "0":
+        g = fuse_tail(g)
     return segment_graph(g)

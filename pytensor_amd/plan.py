@@ -79,6 +79,16 @@ class _Src:
         self.ptr, self.nbytes = ptr, nbytes
 
 
+class _PinnedAsBuffer:
+    """The pinned (device-visible) output block seen as a buffer, so that a ``DeviceArray`` can
+    name a slot of it: the Tail kernel stores its results there directly (no pack launch)."""
+
+    __slots__ = ("ptr", "nbytes")
+
+    def __init__(self, ptr, nbytes):
+        self.ptr, self.nbytes = ptr, nbytes
+
+
 class _SegmentSwitch:
     """Scheduler hook: closes the running capture and opens the next one when the
     executor crosses a segment boundary (A → B → C)."""
@@ -195,6 +205,24 @@ class FrozenPlan:
                 dev_inputs.append(self._resident_devs[pos])
             else:  # non-tensor shared input (cannot happen for freezable graphs: rng graphs stay eager)
                 dev_inputs.append(value)
+        placed = {}
+        if capture and self.fetch_outputs and self._out_block is not None and self._out_block.nbytes <= _ZEROCOPY_MAX:
+            # results of the Tail node (the last launch) go straight into the pinned block
+            ob = self._out_block
+            g = exe.graph
+            tail_outs = {o for n in g.nodes if n.op == "Tail" for o in n.outputs}
+            pin = _PinnedAsBuffer(ob.ptr, ob.nbytes)
+            k = 0
+            for vid, meta in zip(g.outputs, self._out_meta):
+                if meta is not None:
+                    continue
+                v = ob.views[k]
+                if vid in tail_outs and g.outputs.count(vid) == 1:
+                    placed[vid] = DeviceArray(pin, ob.offsets[k], v.shape, contiguous_strides(v.shape), v.dtype)
+                k += 1
+            if placed:
+                env.placement.update(placed)
+                env.tail_status = (lib.pthip_status_ptr(), ob.ptr + ob.offsets[-1])
         if capture:
             env.scheduler = self._switch
             self._begin_segment()
@@ -221,13 +249,16 @@ class FrozenPlan:
                 dev_outs = dev_outs + [_Src(lib.pthip_status_ptr(), 4)]
             if dev_outs and self.fetch_outputs and ob.nbytes <= _ZEROCOPY_MAX:
                 # small results: the pack kernel stores straight into the pinned (device-visible,
-                # coherent) host block — no copy node after it
-                for c0 in range(0, len(dev_outs), 16):
-                    chunk = dev_outs[c0 : c0 + 16]
+                # coherent) host block — no copy node after it; what the Tail kernel already wrote
+                # there (results, error word) is skipped
+                todo = [(o, off) for o, off in zip(dev_outs, ob.offsets)
+                        if not (isinstance(getattr(o, "buf", None), _PinnedAsBuffer) or (isinstance(o, _Src) and env.tail_status_done))]
+                for c0 in range(0, len(todo), 16):
+                    chunk = todo[c0 : c0 + 16]
                     n = len(chunk)
-                    srcs = (C.c_void_p * n)(*[o.ptr for o in chunk])
-                    nb = (C.c_int64 * n)(*[o.nbytes for o in chunk])
-                    offs = (C.c_int64 * n)(*ob.offsets[c0 : c0 + n])
+                    srcs = (C.c_void_p * n)(*[o.ptr for o, _ in chunk])
+                    nb = (C.c_int64 * n)(*[o.nbytes for o, _ in chunk])
+                    offs = (C.c_int64 * n)(*[off for _, off in chunk])
                     ffi.check(lib.pthip_pack(n, srcs, nb, offs, ob.ptr))
             elif dev_outs and self.fetch_outputs:
                 dev_out = Buffer(ob.nbytes)
