@@ -172,6 +172,13 @@ int64_t pthip_gemm_nslabs(int64_t batch, int64_t M, int64_t N, int64_t K);
 int pthip_gemm_partials(int dtype, int64_t batch, int64_t M, int64_t N, int64_t K, const void* A,
                         int64_t sAb, int64_t sA0, int64_t sA1, const void* B, int64_t sBb,
                         int64_t sB0, int64_t sB1, void* part, int64_t nslabs);
+/* Loop-constant right operand of a skinny product (the recurrent weights of a Scan step:
+ * Dot22/Gemm, blas/gemm.py:76,248, whose left operand has a few hundred rows at most), repacked
+ * once per evaluation into the MFMA operand order the generated product+epilogue kernels stream:
+ * Bp[ceil(N/16)][ceil(K/16)*4][16][4], Bp[ct][k4][j][q] = B[4*k4+q][16*ct+j], zero padded.
+ * itemsize 4 or 8; B element strides sB0, sB1. */
+int pthip_pack_b16(int itemsize, int64_t K, int64_t N, const void* B, int64_t sB0, int64_t sB1,
+                   void* Bp);
 /* out (M×N contiguous) = A + alpha * x y^T  (ger.py) */
 int pthip_ger(int dtype, int64_t M, int64_t N, double alpha, const void* A, int64_t sA0,
               int64_t sA1, const void* x, int64_t sx, const void* y, int64_t sy, void* out);

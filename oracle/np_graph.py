@@ -1024,6 +1024,31 @@ def _gemm_partials(p, inputs, node, graph):
     return [np.dot(A, B)[None]]
 
 
+@op("PackB16")
+def _pack_b16(p, inputs, node, graph):
+    # gemmfuse.fuse_dot_epilogue: the right operand in the device kernel's operand order,
+    # Bp[ct][k4][j][q] = B[4*k4+q][16*ct+j] zero padded (include/pthip.h pthip_pack_b16); only
+    # the device reads it — DotEpilogue below takes the plain matrix
+    (B,) = inputs
+    K, N = B.shape
+    Kp, Np = (K + 15) // 16 * 16, (N + 15) // 16 * 16
+    pad = np.zeros((Kp, Np), dtype=B.dtype)
+    pad[:K, :N] = B
+    return [np.ascontiguousarray(pad.reshape(Kp // 4, 4, Np // 16, 16).transpose(2, 0, 3, 1)).reshape(-1)]
+
+
+@op("DotEpilogue")
+def _dot_epilogue(p, inputs, node, graph):
+    # Dot22 (blas/gemm.py:248-275) per product, then Elemwise.perform (elemwise.py:755-823)
+    nb = len(p["scalar"]["in_dtypes"])
+    body_in = list(inputs[:nb])
+    for j, q in enumerate(p["dot_inputs"]):
+        body_in[q] = np.dot(body_in[q], inputs[nb + 2 * j])
+    outs = eval_scalar_body(p["scalar"], body_in)
+    shape = np.broadcast(*body_in).shape
+    return [np.array(np.broadcast_to(o, shape), dtype=graph.vars[vid].dtype, order="C") for o, vid in zip(outs, node.outputs)]
+
+
 @op("Tail")
 def _tail(p, inputs, node, graph):
     # tailfuse.fuse_tail: the member nodes in their original order (the fusion changes how many

@@ -740,7 +740,27 @@ def _vec_type(ctype: str, n: int) -> str:
 
 VEC_HELPERS = r"""
 template <class T, int N> struct __attribute__((aligned(sizeof(T) * N))) pt_vec { T v[N]; };
+template <class P> static __device__ __forceinline__ P pthip_nt_pack(const P* p) {
+  typedef unsigned int pt_u4 __attribute__((ext_vector_type(4)));
+  P o;
+  if constexpr (sizeof(P) == 16) { const pt_u4 r = __builtin_nontemporal_load((const pt_u4*)p); __builtin_memcpy(&o, &r, 16); }
+  else if constexpr (sizeof(P) == 8) { const unsigned long long r = __builtin_nontemporal_load((const unsigned long long*)p); __builtin_memcpy(&o, &r, 8); }
+  else if constexpr (sizeof(P) == 4) { const unsigned int r = __builtin_nontemporal_load((const unsigned int*)p); __builtin_memcpy(&o, &r, 4); }
+  else o = *p;
+  return o;
+}
 """
+
+
+def _stream_load(ptr_expr: str, struct=False) -> str:
+    """Load of a streamed-once operand.  ``PTHIP_NT_LOADS=1`` marks it non-temporal (``nt``: the
+    line is not retained in L2/MALL — MI355X_MICROARCH.md price list, nt-weights row); the
+    default stays a plain load until the A/B measurement in profiles/ says otherwise."""
+    if os.environ.get("PTHIP_NT_LOADS", "0") == "1":
+        if struct:  # the pack types are structs of a 16-byte vector member `q`
+            return f"pthip_nt_pack({ptr_expr})"
+        return f"__builtin_nontemporal_load({ptr_expr})"
+    return f"*({ptr_expr})"
 
 
 def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=None, unroll=2) -> str:
@@ -795,7 +815,7 @@ def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=
             for k, m in enumerate(modes):
                 if m == "V":
                     ct = CTYPE[body["in_dtypes"][k]]
-                    src.append(f"    const {_vec_type(ct, V)} a{k}_{u} = reinterpret_cast<const {_vec_type(ct, V)}*>(in{k})[p + {u} * nthreads];")
+                    src.append(f"    const {_vec_type(ct, V)} a{k}_{u} = {_stream_load(f'reinterpret_cast<const {_vec_type(ct, V)}*>(in{k}) + (p + {u} * nthreads)', struct=True)};")
         for u in range(unroll):
             for k, dt in enumerate(body["out_dtypes"]):
                 if reduce_spec[k] is None:
@@ -1082,7 +1102,7 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
     L.append("      const long long row = (row0 + r < N) ? row0 + r : N - 1;")
     L.append("#pragma unroll\n      for (int c = 0; c < C; c++) {")
     L.append("        const long long col = c * 128 + 2 * lane;")
-    L.append("        xr[r][c] = (col < K) ? *(const pt_d2*)(A + row * lda + col) : (pt_d2){0.0, 0.0};\n      }\n    }")
+    L.append("        xr[r][c] = (col < K) ? " + _stream_load("(const pt_d2*)(A + row * lda + col)") + " : (pt_d2){0.0, 0.0};\n      }\n    }")
     L.append("    double p[RG];")
     L.append("#pragma unroll\n    for (int r = 0; r < RG; r++) {")
     L.append("      double s = 0.0;")
@@ -1174,6 +1194,141 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
 
 def source_key(src: str) -> str:
     return hashlib.sha256(src.encode()).hexdigest()[:24]
+
+
+# ---------------------------------------------------------------------------
+# Skinny product + epilogue (gemmfuse.fuse_dot_epilogue): out = body(.., A@B, ..)
+# ---------------------------------------------------------------------------
+
+DOTEW_CHUNK = 8  # k-groups (16 k each) per register buffer; two buffers in flight
+DOTEW_MAX_K = 16384
+_MFMA16 = {"float32": "__builtin_amdgcn_mfma_f32_16x16x4f32", "float64": "__builtin_amdgcn_mfma_f64_16x16x4f64"}
+
+
+def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chunk: int = DOTEW_CHUNK) -> str:
+    """One 16x16 output tile per workgroup of ``out = body(.., A_d @ B_d, ..)``, full K.
+
+    The recurrent products of a Scan step (``h @ U``: M = batch <= a few hundred rows, K = N =
+    hidden) followed by their gate ``Composite``: reference ``Dot22``/``Gemm`` (blas/gemm.py:
+    76, 248) + ``Elemwise`` (elemwise.py:755) of one step in ONE launch, no split-K slabs through
+    HBM, no finish pass.  MI355X mapping: 256 tiles for (64, 1024) = one per CU; the four waves
+    split K, each lane streams its operands with 16-byte loads straight into the MFMA operand
+    registers (``v_mfma_*_16x16x4``: lane (i = l%16, q = l/16) supplies A[i][k] and B[k][i] for
+    k = 16g + 4q + j, j = 0..3 — one 4-vector load per operand feeds four MFMAs).  ``B`` arrives
+    packed by ``pthip_pack_b16`` as ``[N/16][K/4][16][4]`` so that a wave's load is 1 KiB
+    contiguous; A is row-major (16 rows x 64 B per instruction).  The wave partials are added in
+    wave order through LDS (deterministic), then thread t owns element (t/16, t%16) of the tile
+    and runs the scalar graph; operands of the epilogue are requested before the K loop.
+
+    Arguments: M, N, then per body input — dot: (A, lda, Bp) | by value: bits | other:
+    (ptr, stride0, stride1) — then per output (ptr, row stride)."""
+    dot_pos = list(dot_pos)
+    byvalue = set(byvalue)
+    T = body["in_dtypes"][dot_pos[0]]
+    assert T in _MFMA16 and all(body["in_dtypes"][p] == T for p in dot_pos)
+    assert K % 16 == 0 and 0 < K <= DOTEW_MAX_K
+    ct = CTYPE[T]
+    G = K // 16
+    GW = (G + 3) // 4
+    guard = G % 4 != 0
+    nd = len(dot_pos)
+    P = ["long long M", "long long N"]
+    for k, dt in enumerate(body["in_dtypes"]):
+        if k in dot_pos:
+            P += [f"const {ct}* __restrict__ A{k}", f"long long lda{k}", f"const {ct}* __restrict__ Bp{k}"]
+        elif k in byvalue:
+            P.append(f"const long long in{k}")
+        else:
+            P += [f"const {CTYPE[dt]}* __restrict__ in{k}", f"long long s{k}_0", f"long long s{k}_1"]
+    for k, dt in enumerate(body["out_dtypes"]):
+        P += [f"{CTYPE[dt]}* __restrict__ out{k}", f"long long ldo{k}"]
+    L = [prelude_for(body)]
+    L.append(f"typedef {ct} __attribute__((ext_vector_type(4))) dvec4;")
+    L.append(f'extern "C" __global__ __launch_bounds__({BLOCK}) void {name}({", ".join(P)}) {{')
+    L.append(f"  __shared__ {ct} red_[{nd}][4][256];")
+    L.append("  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;")
+    L.append("  const long long ctile = blockIdx.x, r0 = (long long)blockIdx.y * 16;")
+    L.append("  const long long er = r0 + (tid >> 4), ec = ctile * 16 + (tid & 15);")
+    L.append("  const bool live = er < M && ec < N;")
+    L.append("  const long long err = live ? er : 0, ecc = live ? ec : 0;")
+    in_names, early, ew_loads = [], [], []
+    for k, dt in enumerate(body["in_dtypes"]):
+        if k in dot_pos:
+            in_names.append(f"dot{k}")
+        elif k in byvalue:
+            c = CTYPE[dt]
+            L.append(f"  {c} bv{k}; {{ const long long b = in{k}; __builtin_memcpy(&bv{k}, &b, sizeof({c})); }}")
+            in_names.append(f"bv{k}")
+        else:
+            ew_loads.append(f"  {CTYPE[dt]} e{k} = in{k}[err * s{k}_0 + ecc * s{k}_1];")
+            in_names.append(f"e{k}")
+            if dt in ("float32", "float64", "int32", "int64", "uint32", "uint64"):
+                early.append(f"e{k}")
+    # (the machine scheduler otherwise sinks every load next to its use: 48 VGPRs, one load in
+    #  flight per MFMA group, and the epilogue operands requested after the barrier)
+    SB = "  __builtin_amdgcn_sched_barrier(0);"
+    L.append("  long long arow = r0 + li; if (arow >= M) arow = M - 1;")
+    for p in dot_pos:
+        L.append(f"  dvec4 acc{p} = {{0, 0, 0, 0}};")
+        L.append(f"  const dvec4* ap{p} = (const dvec4*)(A{p} + arow * lda{p}) + ((long long)wave * {GW * 4} + kq);")
+        L.append(f"  const dvec4* bp{p} = (const dvec4*)Bp{p} + ((ctile * {K // 4} + (long long)wave * {GW * 4} + kq) * 16 + li);")
+    # the stream of (dot, chunk) register buffers, double-buffered
+    chunks = []
+    for p in dot_pos:
+        for c0 in range(0, GW, chunk):
+            chunks.append((p, c0, min(chunk, GW - c0)))
+    L.append(f"  dvec4 ra_[2][{chunk}], rb_[2][{chunk}];")
+
+    def loads(s):
+        p, c0, n = chunks[s]
+        out = []
+        for u in range(n):
+            g = c0 + u
+            la = f"ra_[{s & 1}][{u}] = ap{p}[{g * 4}]; rb_[{s & 1}][{u}] = bp{p}[{g * 64}];"
+            if guard:
+                la = f"if (wave * {GW} + {g} < {G}) {{ {la} }} else {{ ra_[{s & 1}][{u}] = dvec4{{0, 0, 0, 0}}; rb_[{s & 1}][{u}] = dvec4{{0, 0, 0, 0}}; }}"
+            out.append("  " + la)
+        return out
+
+    def mfmas(s):
+        p, c0, n = chunks[s]
+        out = []
+        for u in range(n):
+            for j in range(4):
+                out.append(f"  acc{p} = {_MFMA16[T]}(ra_[{s & 1}][{u}][{j}], rb_[{s & 1}][{u}][{j}], acc{p}, 0, 0, 0);")
+        return out
+
+    # issue order: operand chunks 0 and 1, then the epilogue operands (vmcnt retires in order:
+    # requested first, a load from HBM would hold up the first MFMA group), then the MFMA stream
+    L += loads(0) + [SB]
+    for s in range(len(chunks)):
+        if s + 1 < len(chunks):
+            L += loads(s + 1) + [SB]
+        if s == 0:
+            L += ew_loads + [SB]
+        L += mfmas(s) + [SB]
+    # pin the epilogue operands here: without a use in this block the whole scalar graph, loads
+    # included, is sunk into `if (live)` behind the barrier
+    for e in early:
+        L.append(f'  asm volatile("" : "+v"({e}));')
+    for d, p in enumerate(dot_pos):
+        # accumulator register v of lane (li, kq): f32 16x16x4 -> row 4*kq + v; f64 -> row kq + 4*v
+        row = "4 * kq + v" if T == "float32" else "kq + 4 * v"
+        L.append(f"#pragma unroll\n  for (int v = 0; v < 4; v++) red_[{d}][wave][({row}) * 16 + li] = acc{p}[v];")
+    L.append("  __syncthreads();")
+    for d, p in enumerate(dot_pos):
+        L.append(f"  const {ct} dot{p} = ((red_[{d}][0][tid] + red_[{d}][1][tid]) + red_[{d}][2][tid]) + red_[{d}][3][tid];")
+    out_names = []
+    for k, dt in enumerate(body["out_dtypes"]):
+        L.append(f"  {CTYPE[dt]} o{k};")
+        out_names.append(f"o{k}")
+    L.append(emit_body(body, in_names, out_names, indent="  "))
+    L.append("  if (live) {")
+    for k in range(len(body["out_dtypes"])):
+        L.append(f"    out{k}[er * ldo{k} + ec] = o{k};")
+    L.append("  }")
+    L.append("}")
+    return "\n".join(L)
 
 
 # ---------------------------------------------------------------------------

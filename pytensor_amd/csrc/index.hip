@@ -52,6 +52,22 @@ __global__ __launch_bounds__(BLOCK) void fill_kernel(T* __restrict__ dst, const 
     dst[i] = v;
 }
 
+// B (K x N, any strides) -> the MFMA-operand order of the generated skinny-product kernels
+// (codegen.dot_epilogue_source): Bp[N/16][K/4][16][4], Bp[ct][k4][j][q] = B[4*k4 + q][16*ct + j],
+// zero-padded to multiples of 16 in both extents.  One thread per destination element: writes
+// fully coalesced, reads 16-element row segments (a once-per-evaluation repack of a loop constant).
+template <typename T>
+__global__ void pack_b16_kernel(T* __restrict__ out, const T* __restrict__ B, long long K,
+                                long long N, long long Kp, long long n, long long s0, long long s1) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long q = i & 3, j = (i >> 2) & 15, r = i >> 6;
+    const long long k4 = r % (Kp >> 2), ct = r / (Kp >> 2);
+    const long long k = 4 * k4 + q, c = 16 * ct + j;
+    out[i] = (k < K && c < N) ? B[k * s0 + c * s1] : (T)0;
+  }
+}
+
 template <class T>
 __global__ __launch_bounds__(BLOCK) void take_rows_kernel(T* __restrict__ out,
                                                          const T* __restrict__ x,
@@ -341,6 +357,25 @@ int pthip_copy_strided(int itemsize, int ndim, const int64_t* shape, void* dst,
     case 8: return copy_typed<unsigned long long>(ndim, shape, dst, dst_strides, src, src_strides);
   }
   return pthip::set_error("pthip_copy_strided: unsupported itemsize %d", itemsize);
+}
+
+int pthip_pack_b16(int itemsize, int64_t K, int64_t N, const void* B, int64_t sB0, int64_t sB1,
+                   void* Bp) {
+  PTHIP_REQUIRE_INIT();
+  hipStream_t st = pthip::ctx().stream;
+  const long long Kp = (K + 15) / 16 * 16, Np = (N + 15) / 16 * 16;
+  const long long n = Kp * Np;
+  if (n == 0) return 0;
+#define LAUNCH(T)                                                                                  \
+  hipLaunchKernelGGL((pack_b16_kernel<T>), dim3(grid_for(n)), dim3(BLOCK), 0, st, (T*)Bp,           \
+                     (const T*)B, (long long)K, (long long)N, Kp, n, (long long)sB0, (long long)sB1)
+  switch (itemsize) {
+    case 4: LAUNCH(unsigned int); break;
+    case 8: LAUNCH(unsigned long long); break;
+    default: return pthip::set_error("pthip_pack_b16: unsupported itemsize %d", itemsize);
+  }
+#undef LAUNCH
+  return pthip::post_launch("pack_b16");
 }
 
 int pthip_take_rows(int itemsize, int64_t n_idx, int64_t inner, const void* x, int64_t n_rows,

@@ -1,0 +1,118 @@
+"""``DotEpilogue`` / ``PackB16`` — a skinny product and the ``Composite`` that consumes it, one launch.
+
+Produced by ``gemmfuse.fuse_dot_epilogue`` inside ``Scan`` steps: ``out = body(.., A_d @ W_d, ..)``
+with ``W_d`` loop constants.  Reference ops restated: ``Dot22``/``Gemm`` (pytensor/tensor/blas/
+gemm.py:76,248 — the alpha/beta epilogue already lives in ``body``) followed by ``Elemwise``
+(pytensor/tensor/elemwise.py:755).  The generated kernel (codegen.dot_epilogue_source) covers
+``K % 16 == 0``, rows of A 16-byte aligned, M up to ``MAX_ROWS``; anything else runs the plain
+MFMA GEMM followed by the ordinary elementwise kernel — same values, two launches per product.
+"""
+
+from __future__ import annotations
+
+import os
+import struct
+
+from pytensor_amd import codegen, ffi, kernel_cache
+from pytensor_amd.device import DeviceArray
+from pytensor_amd.dispatch import handler
+from pytensor_amd.dispatch.blas import _prep2d, gemm_device
+from pytensor_amd.dispatch.elemwise import _body_key, _placed, _scalar_bits, _scalar_or_device, launch_elemwise
+from pytensor_amd.executor import HostValue
+
+NUM_CU = 256
+MAX_ROWS = 1024  # above this the 16x16-tile/full-K scheme re-reads too much; GEMM + Elemwise
+
+
+def _ceil16(n: int) -> int:
+    return (n + 15) // 16 * 16
+
+
+@handler("PackB16")
+def pack_b16(node, inputs, env):
+    B = env.to_device(inputs[0])
+    if B.ndim != 2 or B.itemsize not in (4, 8):
+        raise TypeError(f"PackB16: expected a float32/float64 matrix, got {B.dtype} with {B.ndim} dims")
+    K, N = B.shape
+    out = DeviceArray.empty((_ceil16(K) * _ceil16(N),), B.dtype)
+    if out.size:
+        ffi.check(env.lib.pthip_pack_b16(B.itemsize, K, N, B.ptr, B.strides[0], B.strides[1], out.ptr))
+    return [out]
+
+
+@handler("DotEpilogue")
+def dot_epilogue(node, inputs, env):
+    body = node.params["scalar"]
+    dpos = list(node.params["dot_inputs"])
+    nb = len(body["in_dtypes"])
+    ins = [_scalar_or_device(env, i) for i in inputs[:nb]]
+    extra = inputs[nb:]
+    dots = {}
+    shape = None
+    for j, q in enumerate(dpos):
+        A, B, Bp = (env.to_device(v) for v in (ins[q], extra[2 * j], extra[2 * j + 1]))
+        if A.ndim != 2 or B.ndim != 2:
+            raise TypeError("DotEpilogue: operands of a product must be matrices")
+        if A.shape[1] != B.shape[0]:
+            raise ValueError(f"Shape mismatch: x has {A.shape[1]} cols but y has {B.shape[0]} rows")
+        if shape is not None and shape != (A.shape[0], B.shape[1]):
+            raise ValueError(f"Incompatible Elemwise input shapes {[shape, (A.shape[0], B.shape[1])]}")
+        shape = (A.shape[0], B.shape[1])
+        dots[q] = (A, B, Bp)
+    M, N = shape
+    for k, a in enumerate(ins):
+        if k in dots or (isinstance(a, HostValue) and a.a.size == 1):
+            continue
+        if a.ndim != 2 or any(a.shape[d] not in (1, shape[d]) for d in range(2)):
+            raise ValueError(f"Incompatible Elemwise input shapes {[shape] + [tuple(i.shape) for i in ins if not isinstance(i, HostValue)]}")
+        static = env.graph.vars[node.inputs[k]].shape
+        for d in range(2):
+            if a.shape[d] == 1 and shape[d] != 1 and static[d] != 1:
+                raise ValueError(
+                    f"Runtime broadcasting not allowed. One input had a distinct dimension length of 1 along axis {d}, "
+                    "but the static type does not mark it as broadcastable"
+                )
+    out_dtypes = body["out_dtypes"]
+    placed = _placed(env, node, shape, out_dtypes)
+    T = body["in_dtypes"][dpos[0]]
+    K = dots[dpos[0]][0].shape[1]
+    fast = (
+        M > 0 and N > 0 and 0 < K <= codegen.DOTEW_MAX_K and K % 16 == 0 and M <= MAX_ROWS
+        and T in ("float32", "float64") and all(body["in_dtypes"][q] == T for q in dpos)
+    )
+    for q in dpos:
+        A, B, Bp = dots[q]
+        fast = fast and A.shape[1] == K and str(A.dtype) == T and str(B.dtype) == T
+        fast = fast and A.strides[1] == 1 and (A.strides[0] * A.itemsize) % 16 == 0 and A.ptr % 16 == 0
+        fast = fast and Bp.size == _ceil16(K) * _ceil16(N) and Bp.is_contiguous() and Bp.ptr % 16 == 0
+    if not fast:
+        # shapes/layouts the generated kernel does not cover: MFMA GEMM, then the Elemwise kernel
+        ins2 = [gemm_device(env, 1.0, _prep2d(dots[k][0]), _prep2d(dots[k][1])) if k in dots else a for k, a in enumerate(ins)]
+        outs, _, _ = launch_elemwise(body, ins2, shape, out_dtypes, None, env, (), placed)
+        return outs
+    outs = [
+        placed[k] if placed and placed[k] is not None else DeviceArray.empty(shape, out_dtypes[k])
+        for k in range(len(out_dtypes))
+    ]
+    byvalue = {k for k, a in enumerate(ins) if isinstance(a, HostValue)}
+    # few tiles (one per CU or less): latency-bound, every operand load of two products in flight
+    # (~300 VGPRs, one workgroup per CU); many tiles: smaller register buffers, 3 workgroups per CU
+    tiles = ((N + 15) // 16) * ((M + 15) // 16)
+    chunk = int(os.environ.get("PTHIP_DOTEW_CHUNK", 0)) or (16 if tiles <= 2 * NUM_CU else 8)
+    name = f"dotew_{_body_key(body)}_k{K}_d{'_'.join(map(str, dpos))}_u{chunk}" + ("_c" + "_".join(map(str, sorted(byvalue))) if byvalue else "")
+    src = codegen.dot_epilogue_source(name, body, dpos, K, byvalue, chunk)
+    fn = kernel_cache.get_function(src, name)
+    args = [M, N]
+    for k, a in enumerate(ins):
+        if k in dots:
+            A, _, Bp = dots[k]
+            args += [A.ptr, A.strides[0], Bp.ptr]
+        elif k in byvalue:
+            args.append(_scalar_bits(a, body["in_dtypes"][k]))
+        else:
+            args += [a.ptr, 0 if a.shape[0] == 1 and M != 1 else a.strides[0], 0 if a.shape[1] == 1 and N != 1 else a.strides[1]]
+    for o in outs:
+        args += [o.ptr, o.strides[0]]
+    buf = struct.pack(f"<{len(args)}q", *args)
+    ffi.check(env.lib.pthip_launch(fn, (N + 15) // 16, (M + 15) // 16, 1, codegen.BLOCK, 1, 1, 0, buf, len(buf)))
+    return outs

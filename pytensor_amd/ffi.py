@@ -98,6 +98,7 @@ SIGNATURES = {
     ),
     "pthip_gemm_nslabs": (_i64, [_i64, _i64, _i64, _i64]),
     "pthip_gemm_partials": (_int, [_int, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64]),
+    "pthip_pack_b16": (_int, [_int, _i64, _i64, _vp, _i64, _i64, _vp]),
     "pthip_ger": (_int, [_int, _i64, _i64, _dbl, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "pthip_potrf": (_int, [_int, _int, _i64, _i64, _vp, _vp]),
     "pthip_potrf_trsv": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _vp]),

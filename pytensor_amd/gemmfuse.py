@@ -226,3 +226,105 @@ def _merge_in_scan(g: Graph, scan: Node, new_vars: dict):
     params["inner"] = new_inner
     params["info"] = new_info
     return [join], Node("Scan", params, list(scan.inputs) + [bcat_o], list(scan.outputs))
+
+
+def fuse_dot_epilogue(g: Graph) -> Graph:
+    """``GemmPartials(A, W) → Elemwise`` inside a Scan step → one ``DotEpilogue`` launch.
+
+    A recurrent product ``h @ U`` has M = batch rows (64 in BASELINE config #5): split-K slabs
+    through HBM plus a generic N-d gate kernel cost 11 µs + 5-8 µs per pair on MI355X.  When the
+    right operand is a loop constant (a non-sequence of the Scan) it is repacked once per
+    evaluation (``PackB16``, hoisted into the outer graph like ``merge_sibling_gemms`` hoists
+    its ``Join``) and the product, its slab sum and the consuming ``Composite`` become one
+    generated kernel (codegen.dot_epilogue_source): a GRU step is two dependent launches.
+    Several products feeding one ``Elemwise`` (``rh@U_h`` and ``h@U_z`` of the update gate) are
+    accumulated in the same launch.  Shapes the kernel does not cover are decided at run time
+    by the handler (dispatch/blas.py: plain GEMM + elementwise kernel).
+    Reference ops: ``Dot22``/``Gemm`` blas/gemm.py:76,248; ``Elemwise`` elemwise.py:375;
+    loop semantics scan/op.py:1827."""
+    out_nodes, new_vars, changed = [], {}, False
+    for n in g.nodes:
+        res = _dot_epilogue_in_scan(g, n, new_vars) if n.op == "Scan" else None
+        if res is None:
+            out_nodes.append(n)
+        else:
+            pre, scan = res
+            out_nodes += pre + [scan]
+            changed = True
+    if not changed:
+        return g
+    g2 = _copy(g, out_nodes)
+    g2.vars.update(new_vars)
+    return g2
+
+
+def _dot_epilogue_in_scan(g: Graph, scan: Node, new_vars: dict):
+    info = scan.params["info"]
+    inner: Graph = scan.params["inner"]
+    nns = info["n_non_seqs"]
+    n_in = len(inner.inputs)
+    non_seq_pos = {v: p for p, v in enumerate(inner.inputs) if p >= n_in - nns}
+    producer, consumers = _index(inner)
+    out_set = set(inner.outputs)
+    hits = {}  # index of the Elemwise -> [(pos, A, B, index of the GemmPartials)]
+    for ke, E in enumerate(inner.nodes):
+        pi = E.params.get("partial_inputs") if E.op == "Elemwise" else None
+        if not pi or E.params.get("gather") or inner.vars[E.outputs[0]].ndim != 2:
+            continue
+        dots = []
+        for q in sorted(pi):
+            v = E.inputs[q]
+            kp = producer.get(v)
+            P = inner.nodes[kp] if kp is not None else None
+            if P is None or P.op != "GemmPartials" or consumers.get(v) != [ke] or v in out_set:
+                break
+            A, B = P.inputs
+            va, vb = inner.vars[A], inner.vars[B]
+            if B not in non_seq_pos or va.ndim != 2 or vb.ndim != 2:
+                break
+            if va.dtype != vb.dtype or va.dtype not in ("float32", "float64"):
+                break
+            if inner.vars[v].dtype != va.dtype:
+                break
+            dots.append((q, A, B, kp))
+        else:
+            hits[ke] = dots
+    if not hits:
+        return None
+    ivars, pre, packed = {}, [], {}  # packed: inner B -> inner packed var
+    new_inner_inputs, new_outer_inputs = [], []
+    for dots in hits.values():
+        for _, _, B, _ in dots:
+            if B in packed:
+                continue
+            dt = inner.vars[B].dtype
+            packed[B] = _fresh(inner, ivars, dt, (None,), name="weights_packed16")
+            ob = scan.inputs[len(scan.inputs) - n_in + non_seq_pos[B]]
+            op_ = _fresh(g, new_vars, dt, (None,), name="scan_weights_packed16")
+            pre.append(Node("PackB16", {}, [ob], [op_]))
+            new_inner_inputs.append(packed[B])
+            new_outer_inputs.append(op_)
+    dead = {kp for dots in hits.values() for _, _, _, kp in dots}
+    nodes = []
+    for k, m in enumerate(inner.nodes):
+        if k in dead:
+            continue
+        if k in hits:
+            dots = hits[k]
+            ins = list(m.inputs)
+            extra = []
+            for q, A, B, _ in dots:
+                ins[q] = A
+                extra += [B, packed[B]]
+            params = {"scalar": m.params["scalar"], "dot_inputs": [q for q, *_ in dots]}
+            m = Node("DotEpilogue", params, ins + extra, list(m.outputs))
+        nodes.append(m)
+    new_inner = _copy(inner, nodes)
+    new_inner.vars.update(ivars)
+    new_inner.inputs = list(inner.inputs) + new_inner_inputs
+    new_info = dict(info)
+    new_info["n_non_seqs"] = nns + len(new_inner_inputs)
+    params = dict(scan.params)
+    params["inner"] = new_inner
+    params["info"] = new_info
+    return pre, Node("Scan", params, list(scan.inputs) + new_outer_inputs, list(scan.outputs))

@@ -9,7 +9,9 @@ Order matters:
 4. ``hoist_scan_seq_dots`` — sequence-only products out of ``Scan``;
 5. ``fuse_cholesky_solve`` — Cholesky + its first triangular solve, factor kept in LDS;
    ``defer_gemm_finish`` (gemmfuse.py) — split-K finish + Gemm epilogue folded into the
-   consuming elementwise kernel (also inside Scan inner graphs);
+   consuming elementwise kernel (also inside Scan inner graphs); ``fuse_dot_epilogue`` —
+   inside a Scan step, product against a loop-constant matrix + consuming ``Composite`` in one
+   generated kernel (``DotEpilogue``; weights repacked once outside the loop);
 6. ``fuse_gemv_chain`` — ``X@b → Composite → X.T@w`` (+ gathers, + scatter-add) in one pass;
 7. ``dead_code_elimination``; ``fuse_tail`` (tailfuse.py) — the small nodes at the end of the
    graph in two launches;
@@ -31,7 +33,7 @@ from pytensor_amd.fusion import (
     segment_graph,
 )
 from pytensor_amd.gatherfuse import absorb_gathers
-from pytensor_amd.gemmfuse import defer_gemm_finish, merge_sibling_gemms
+from pytensor_amd.gemmfuse import defer_gemm_finish, fuse_dot_epilogue, merge_sibling_gemms
 from pytensor_amd.inline import (
     dead_code_elimination,
     inline_elemwise_producers,
@@ -55,7 +57,10 @@ def run_pipeline(graph: Graph, fuse=True, tail=True):
     g = merge_sibling_reductions(g)
     g = hoist_scan_seq_dots(g)
     g = fuse_cholesky_solve(g)
-    g = merge_sibling_gemms(defer_gemm_finish(g))
+    g = defer_gemm_finish(g)
+    if os.environ.get("PTHIP_DOT_EPILOGUE", "1") != "0":
+        g = fuse_dot_epilogue(g)
+    g = merge_sibling_gemms(g)  # what is left as split-K slabs
     g = absorb_gathers(fuse_gemv_chain(g))  # gchain takes the gathers it can use first
     g = dead_code_elimination(g)
     if tail and os.environ.get("PTHIP_TAIL", "1") != "0":

@@ -66,19 +66,40 @@ def test_c5_scan_dots_are_hoisted():
     ops = [n.op for n in g2.nodes]
     assert ops.count("SeqDot22") == 3
     scan = next(n for n in g2.nodes if n.op == "Scan")
+    inner = scan.params["inner"]
+    inner_ops = [m.op for m in inner.nodes]
+    # the three recurrent products stay in the loop; each runs inside the generated kernel of the
+    # gate that consumes it (gemmfuse.fuse_dot_epilogue): two launches per step, the weights
+    # repacked once per evaluation outside the loop
+    assert not {"Dot22", "Gemm", "GemmPartials", "Elemwise"} & set(inner_ops)
+    de = [m for m in inner.nodes if m.op == "DotEpilogue"]
+    assert sorted(len(m.params["dot_inputs"]) for m in de) == [1, 2]
+    assert ops.count("PackB16") == 3 and max(k for k, o in enumerate(ops) if o == "PackB16") < ops.index("Scan")
+    assert scan.params["info"]["n_non_seqs"] == 12 and len(inner.inputs) == 17
+    for m in de:
+        nb = len(m.params["scalar"]["in_dtypes"])
+        # every packed operand is a non-sequence of the step function
+        assert all(v in inner.inputs[-12:] for v in m.inputs[nb:])
+    assert scan.params["info"]["n_seqs"] == 4
+    # the original graph object is untouched (passes are functional)
+    g_again, *_ = load_case("c5_gru")
+    assert [n.op for n in g.nodes] == [n.op for n in g_again.nodes]
+
+
+def test_c5_split_k_form_without_dot_epilogue(monkeypatch):
+    """``PTHIP_DOT_EPILOGUE=0``: the round-1 form (split-K slabs folded into the gate kernels,
+    sibling products merged) — still what runs when the right operand is not a loop constant."""
+    monkeypatch.setenv("PTHIP_DOT_EPILOGUE", "0")
+    g, *_ = load_case("c5_gru")
+    g2, _ = _pipeline(g)
+    ops = [n.op for n in g2.nodes]
+    scan = next(n for n in g2.nodes if n.op == "Scan")
     inner_ops = [m.op for m in scan.params["inner"].nodes]
-    # the three recurrent products stay in the loop, as split-K slabs whose finish (and the
-    # Gemm's b*y + a*(.) epilogue) is folded into the two gate kernels (gemmfuse.py)
-    # h@U_r and h@U_z share h: one product against the concatenated weights (Join hoisted out)
     assert "Dot22" not in inner_ops and "Gemm" not in inner_ops and inner_ops.count("GemmPartials") == 2
     assert ops.count("Join") == 1 and ops.index("Join") < ops.index("Scan")
     assert scan.params["info"]["n_non_seqs"] == 10
     ew = [m for m in scan.params["inner"].nodes if m.op == "Elemwise"]
     assert sorted(len(m.params["partial_inputs"]) for m in ew) == [1, 2]
-    assert scan.params["info"]["n_seqs"] == 4
-    # the original graph object is untouched (passes are functional)
-    g_again, *_ = load_case("c5_gru")
-    assert [n.op for n in g.nodes] == [n.op for n in g_again.nodes]
 
 
 def test_donations_only_fresh_single_consumer_values():
@@ -157,3 +178,40 @@ def test_inline_passes_units():
         got = np_graph.run_graph(gg, ins)
         for a, b in zip(got, want):
             np.testing.assert_allclose(a, b, rtol=1e-14)
+
+
+def test_dot_epilogue_source_compiles_for_both_dtypes():
+    """The generated product+epilogue kernel builds for gfx950 without a GPU (hiprtc), with the
+    operand loads of both register buffers issued ahead of the first MFMA."""
+    from pytensor_amd import codegen, ffi
+
+    for dt, K in (("float32", 1024), ("float64", 48), ("float32", 16)):
+        body = {
+            "in_dtypes": [dt, dt, dt], "out_dtypes": [dt],
+            "body": [{"op": "Add", "in": [["i", 0], ["i", 1]], "dtype": dt}, {"op": "Tanh", "in": [["t", 0]], "dtype": dt},
+                     {"op": "Mul", "in": [["t", 1], ["i", 2]], "dtype": dt}],
+            "outs": [["t", 2]],
+        }
+        src = codegen.dot_epilogue_source("dotew_probe", body, [1], K, byvalue=(2,))
+        assert src.count("= __builtin_amdgcn_mfma") == (K // 16 + 3) // 4 * 4  # per wave: K/64 groups x 4
+        assert len(ffi.jit_compile(src, "dotew_probe.hip")) > 1000
+
+
+def test_pack_b16_oracle_layout():
+    import np_graph
+    from pytensor_amd.ir import Graph
+
+    g = Graph(name="pack")
+    W = g.new_var("float64", (None, None))
+    Wp = g.new_var("float64", (None,))
+    g.add_node("PackB16", {}, [W], [Wp])
+    g.inputs, g.outputs = [W], [Wp]
+    K, N = 21, 35
+    w = np.arange(K * N, dtype="float64").reshape(K, N) + 1
+    (p,) = np_graph.run_graph(g, [w])
+    Kp, Np = 32, 48
+    assert p.shape == (Kp * Np,)
+    p4 = p.reshape(Np // 16, Kp // 4, 16, 4)
+    for ct, k4, j, q in ((0, 0, 0, 0), (2, 5, 2, 0), (1, 3, 15, 3), (2, 5, 3, 0), (0, 7, 0, 3)):
+        k, c = 4 * k4 + q, 16 * ct + j
+        assert p4[ct, k4, j, q] == (w[k, c] if k < K and c < N else 0.0)
