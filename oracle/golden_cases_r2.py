@@ -136,3 +136,40 @@ def float16_storage():
     vals = {"h": rng.normal(size=n).astype("float16"), "k": rng.normal(size=n).astype("float16"), "H": rng.normal(size=(7, n)).astype("float16"),
             "f": rng.normal(size=n).astype("float32")}
     return [h, k, H, f], outs, vals
+
+
+@case("indexing_nd")
+def indexing_nd():
+    # tests/tensor/test_subtensor.py (TestAdvancedSubtensor: test_index_w_int_and_vec, test_adv_sub_3d,
+    # test_advanced_indexing, multi-dimensional index arrays): N-d index arrays, advanced indices
+    # mixed with slices, non-adjacent advanced axes (broadcast dims go first), scatter on axis != 0
+    rng = np.random.default_rng(70)
+    x = pt.dmatrix("x")
+    t3 = pt.dtensor3("t3")
+    t4 = pt.dtensor4("t4")
+    I = pt.lmatrix("I")
+    J = pt.lmatrix("J")
+    iv = pt.lvector("iv")
+    jv = pt.lvector("jv")
+    y = pt.dmatrix("y")
+    outs = [
+        x[I],  # 2-d index array on axis 0: (2, 3, 7)
+        x[:, I],  # on axis 1: (8, 2, 3)
+        x[I, J],  # pointwise pair of 2-d index arrays: (2, 3)
+        x[I, jv[:3]],  # broadcast (2,3) with (3,)
+        t3[1:, iv],  # slice then vector on axis 1
+        t3[iv, :, jv[: iv.shape[0]]],  # non-adjacent advanced axes: broadcast dim first
+        t3[:, iv[:2], jv[:2]],  # adjacent advanced axes in the middle/back
+        t4[::2, I, :, 1:3],  # mixed stepped slice, 2-d index, full, slice
+        pt.inc_subtensor(x[:, jv], y[:, : jv.shape[0]]),  # scatter on axis 1 with duplicates
+        pt.set_subtensor(x[I], 1.5),  # N-d index on axis 0 (last writer wins per duplicate: same value)
+        pt.inc_subtensor(x[I, J], y[:2, :3]),  # pointwise scatter-add with duplicates
+        pt.inc_subtensor(t3[:, iv[:2], jv[:2]], 2.0),
+        pt.inc_subtensor(t3[1:, iv], t3[1:, iv] * 0 + 1.0),
+    ]
+    vals = {
+        "x": rng.normal(size=(8, 7)), "t3": rng.normal(size=(4, 5, 6)), "t4": rng.normal(size=(4, 5, 3, 4)),
+        "I": np.array([[0, 4, 4], [2, 0, 3]]), "J": np.array([[6, 1, 1], [0, 1, 6]]), "iv": np.array([3, 0, 3, 1]),
+        "jv": np.array([5, 0, 5, 2, 1]), "y": rng.normal(size=(8, 7)),
+    }
+    return [x, t3, t4, I, J, iv, jv, y], outs, vals

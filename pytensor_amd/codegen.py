@@ -753,11 +753,14 @@ template <class P> static __device__ __forceinline__ P pthip_nt_pack(const P* p)
 
 
 def _stream_load(ptr_expr: str, struct=False) -> str:
-    """Load of a streamed-once operand.  ``PTHIP_NT_LOADS=1`` marks it non-temporal (``nt``: the
-    line is not retained in L2/MALL — MI355X_MICROARCH.md price list, nt-weights row); the
-    default stays a plain load until the A/B measurement in profiles/ says otherwise."""
-    if os.environ.get("PTHIP_NT_LOADS", "0") == "1":
-        if struct:  # the pack types are structs of a 16-byte vector member `q`
+    """Load of an operand that is streamed once (the vector inputs of a flat fused kernel, the
+    matrix of ``gchain``): non-temporal (``nt``) — the line is not retained in L2/MALL, which is
+    what a pass over 0.16-1 GB wants (MI355X_MICROARCH.md price list, nt-weights row).  Measured
+    (profiles/r2f_nt_loads.txt): ``gchain`` 184.5 -> 171.2 us (5.64 -> 6.08 TB/s), config #4
+    4072 -> 4366 evals/s; 52-op Composite+Sum at N=1e7 39.9 -> 38.1 us.  ``PTHIP_NT_LOADS=0``
+    restores plain loads."""
+    if os.environ.get("PTHIP_NT_LOADS", "1") != "0":
+        if struct:  # the pack types are structs: reinterpret as one 16/8/4-byte word
             return f"pthip_nt_pack({ptr_expr})"
         return f"__builtin_nontemporal_load({ptr_expr})"
     return f"*({ptr_expr})"
@@ -1338,7 +1341,7 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
 TAIL_BLOCK = 256
 
 
-def tail_chain_source(name: str, spec: dict) -> str:
+def tail_chain_source(name: str, spec: dict, sizes: dict | None = None) -> str:
     """One workgroup runs ``spec["steps"]`` in order, intermediates in LDS.
 
     ``spec`` is purely structural (extents are kernel arguments, so one code object serves every
@@ -1380,6 +1383,8 @@ def tail_chain_source(name: str, spec: dict) -> str:
         P += [f"{CTYPE[slots[o]['dtype']]}* __restrict__ dst{k}", f"const long long len{k}"]
     P += ["const int* status_src", "int* status_dst"]
     bodies = [st["body"] for st in steps if st["op"] == "ew"]
+    if sizes is not None:
+        return _tail_preload_source(name, spec, sizes, P, bodies)
     L = [reduce_header(), prelude_for(*bodies)]
     L.append(f'extern "C" __global__ __launch_bounds__({TAIL_BLOCK}) void {name}({", ".join(P)}) {{')
     L.append("  extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];")
@@ -1453,6 +1458,173 @@ def tail_chain_source(name: str, spec: dict) -> str:
                 else:
                     L.append(f"      acc{q} = pthip_dev::{REDUCE_OPS[r[0]]}::apply(acc{q}, ({CTYPE[r[1]]})o{q});")
             L.append("    }")
+            for q, r in enumerate(red):
+                if r is not None:
+                    act = CTYPE[r[1]]
+                    L.append(f"    acc{q} = pthip_dev::block_reduce<pthip_dev::{REDUCE_OPS[r[0]]}, {act}, {TAIL_BLOCK}, true>(acc{q}, ({act}*)red_);")
+                    L.append(f"    if (tid == 0) l{st['outs'][q]}[0] = ({CTYPE[r[2]]})acc{q};")
+            L.append("  }")
+            L.append("  __syncthreads();")
+    for k, o in enumerate(spec["outs"]):
+        L.append(f"  for (long long i = tid; i < len{k}; i += {TAIL_BLOCK}) dst{k}[i] = l{o}[i];")
+    L.append("  if (tid == 0 && status_dst != nullptr) *status_dst = __hip_atomic_load(status_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);")
+    L.append("}")
+    return "\n".join(L)
+
+
+TAIL_PRELOAD_MAX_REGS = 160  # 8-byte values a thread may hold in flight in the preloading form
+
+
+def tail_preload_sizes(spec: dict, ext_len, step_n):
+    """Static size classes for ``tail_chain_source(..., sizes=)`` or ``None`` when the operands
+    are too long to sit in registers.  ``ext_len[k]``: elements of external ``k`` ("V"), rows of
+    a partial array; ``step_n[j]``: ``(rows, M)`` of a finish step, ``rows`` of an rsum step,
+    ``n`` of an elementwise step."""
+    ext, steps = spec["ext"], spec["steps"]
+    cl = lambda n: max(1, (int(n) + TAIL_BLOCK - 1) // TAIL_BLOCK)
+    eu = [cl(ext_len[k]) if e["kind"] == "V" else 0 for k, e in enumerate(ext)]
+    su, regs = [], sum(eu) + sum(1 for e in ext if e["kind"] in ("S", "V"))
+    for st, n in zip(steps, step_n):
+        if st["op"] == "finish":
+            rows, M = n
+            R = (int(rows) + 3) // 4 * 4
+            su.append((R, cl(M)))
+            regs += R * cl(M)
+        elif st["op"] == "rsum":
+            su.append(cl(n))
+            regs += cl(n)
+        else:
+            su.append(cl(n))
+    if regs > TAIL_PRELOAD_MAX_REGS or any((u[0] > 64 or u[1] > 4) if isinstance(u, tuple) else u > 16 for u in su) or any(u > 16 for u in eu):
+        return None
+    return {"ext_u": eu, "step_u": su}
+
+
+def _tail_preload_source(name: str, spec: dict, sizes: dict, P, bodies) -> str:
+    """The chain with every *global* operand requested up front (one memory latency for the whole
+    kernel instead of one per step — a single workgroup cannot hide it with occupancy): partial
+    slabs and partial arrays are summed in registers as they arrive, vectors stay in registers;
+    the steps then run out of registers and LDS.  Loop trip counts are static (``sizes``)."""
+    ext, slots, steps = spec["ext"], spec["slots"], spec["steps"]
+    eu, su = sizes["ext_u"], sizes["step_u"]
+    L = [reduce_header(), prelude_for(*bodies)]
+    L.append(f'extern "C" __global__ __launch_bounds__({TAIL_BLOCK}) void {name}({", ".join(P)}) {{')
+    L.append("  extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];")
+    L.append("  __shared__ double red_[8];")
+    L.append("  const int tid = threadIdx.x;")
+    for k, e in enumerate(ext):
+        ct = CTYPE[e["dtype"]]
+        if e["kind"] == "C":
+            L.append(f"  {ct} c{k}; {{ const long long b = ec{k}; __builtin_memcpy(&c{k}, &b, sizeof({ct})); }}")
+    for k, s in enumerate(slots):
+        ct = CTYPE[s["dtype"]]
+        L.append(f"  {ct}* const l{k} = ({ct}*)(lds_ + off{k});")
+    # ---- phase 0: every global operand in flight ------------------------------------------
+    used_len = {}  # V external -> name of its length (first elementwise step reading it as a vector)
+    for j, st in enumerate(steps):
+        if st["op"] == "ew":
+            for ref, m in zip(st["ins"], st["modes"]):
+                if ref[0] == "e" and ext[ref[1]]["kind"] == "V" and m == "V":
+                    used_len.setdefault(ref[1], f"n{j}")
+        elif st["op"] == "finish" and st.get("y") is not None and st["y"][0] == "e" and st["ymode"] == "V":
+            used_len.setdefault(st["y"][1], f"M{j}")
+    for k, e in enumerate(ext):
+        ct = CTYPE[e["dtype"]]
+        if e["kind"] == "S":
+            L.append(f"  const {ct} s{k} = e{k}[0];")
+        elif e["kind"] == "V":
+            L.append(f"  const {ct} s{k} = e{k}[0];")
+            if k in used_len:
+                for u in range(eu[k]):
+                    # clamped, unconditional (a predicated load becomes an exec-masked branch with its own wait)
+                    L.append(f"  const {ct} v{k}_{u} = e{k}[(tid + {u * TAIL_BLOCK} < {used_len[k]} ? (long long)(tid + {u * TAIL_BLOCK}) : {used_len[k]} - 1) * es{k}];")
+    for j, st in enumerate(steps):
+        if st["op"] == "finish":
+            ct = CTYPE[st["dtype"]]
+            src = f"e{st['src'][1]}"
+            R, U = su[j]
+            for u in range(U):
+                for r in range(R):
+                    L.append(f"  {ct} f{j}_{u}_{r} = {src}[({r} < rows{j} ? {r} : rows{j} - 1) * M{j} + (tid + {u * TAIL_BLOCK} < M{j} ? tid + {u * TAIL_BLOCK} : M{j} - 1)];")
+        elif st["op"] == "rsum":
+            act = CTYPE[st["acc_dtype"]]
+            op = REDUCE_OPS[st["red"]]
+            src = f"e{st['src'][1]}"
+            for u in range(su[j]):
+                L.append(f"  {act} p{j}_{u} = ({act}){src}[tid + {u * TAIL_BLOCK} < rows{j} ? tid + {u * TAIL_BLOCK} : rows{j} - 1];")
+    L.append("  __builtin_amdgcn_sched_barrier(0);")
+    for j, st in enumerate(steps):
+        if st["op"] == "finish":
+            R, U = su[j]
+            for u in range(U):
+                for r in range(R):
+                    L.append(f"  if ({r} >= rows{j}) f{j}_{u}_{r} = 0;")
+        elif st["op"] == "rsum":
+            act = CTYPE[st["acc_dtype"]]
+            for u in range(su[j]):
+                L.append(f"  if (tid + {u * TAIL_BLOCK} >= rows{j}) p{j}_{u} = pthip_dev::{REDUCE_OPS[st['red']]}::identity<{act}>();")
+
+    def operand(ref, mode, u):
+        kind, k = ref
+        if kind == "e":
+            e = ext[k]
+            if e["kind"] == "C":
+                return f"c{k}"
+            if e["kind"] == "V" and mode == "V":
+                return f"v{k}_{u}"
+            return f"s{k}"
+        return f"l{k}[tid + {u * TAIL_BLOCK}]" if mode == "V" else f"l{k}[0]"
+
+    for j, st in enumerate(steps):
+        if st["op"] == "finish":
+            ct = CTYPE[st["dtype"]]
+            R, U = su[j]
+            L.append(f"  // step {j}: second stage + epilogue of a split Gemv / scatter-add (rows even/odd, then the pair: the order of the looping form)")
+            for u in range(U):
+                L.append(f"  if (tid + {u * TAIL_BLOCK} < M{j}) {{")
+                L.append(f"    {ct} a0 = 0, a1 = 0;")
+                for r in range(0, R, 2):
+                    L.append(f"    a0 += f{j}_{u}_{r}; a1 += f{j}_{u}_{r + 1};")
+                L.append(f"    {ct} r = ({ct})alpha{j} * (a0 + a1);")
+                if st.get("y") is not None:
+                    L.append(f"    if (beta{j} != 0.0) r += ({ct})beta{j} * ({ct}){operand(st['y'], st['ymode'], u)};")
+                L.append(f"    l{st['out']}[tid + {u * TAIL_BLOCK}] = r;")
+                L.append("  }")
+            L.append("  __syncthreads();")
+        elif st["op"] == "rsum":
+            act, oct_ = CTYPE[st["acc_dtype"]], CTYPE[st["dtype"]]
+            op = REDUCE_OPS[st["red"]]
+            L.append(f"  // step {j}: deferred second stage of a fused Elemwise+reduce kernel")
+            L.append("  {")
+            L.append(f"    {act} a = pthip_dev::{op}::identity<{act}>();")
+            for u in range(su[j]):
+                L.append(f"    a = pthip_dev::{op}::apply(a, p{j}_{u});")
+            L.append(f"    a = pthip_dev::block_reduce<pthip_dev::{op}, {act}, {TAIL_BLOCK}, true>(a, ({act}*)red_);")
+            L.append(f"    if (tid == 0) l{st['out']}[0] = ({oct_})a;")
+            L.append("  }")
+            L.append("  __syncthreads();")
+        else:
+            body, modes, red = st["body"], st["modes"], st["reduce"]
+            L.append(f"  // step {j}: Elemwise over n{j} elements, operand modes {modes}")
+            L.append("  {")
+            for q, r in enumerate(red):
+                if r is not None:
+                    act = CTYPE[r[1]]
+                    L.append(f"    {act} acc{q} = pthip_dev::{REDUCE_OPS[r[0]]}::identity<{act}>();")
+            for u in range(su[j]):
+                L.append(f"    if (tid + {u * TAIL_BLOCK} < n{j}) {{")
+                in_names = [operand(ref, m, u) for ref, m in zip(st["ins"], modes)]
+                out_names = []
+                for q, dt in enumerate(body["out_dtypes"]):
+                    L.append(f"      {CTYPE[dt]} o{q};")
+                    out_names.append(f"o{q}")
+                L.append(emit_body(body, in_names, out_names, indent="      "))
+                for q, r in enumerate(red):
+                    if r is None:
+                        L.append(f"      l{st['outs'][q]}[tid + {u * TAIL_BLOCK}] = o{q};")
+                    else:
+                        L.append(f"      acc{q} = pthip_dev::{REDUCE_OPS[r[0]]}::apply(acc{q}, ({CTYPE[r[1]]})o{q});")
+                L.append("    }")
             for q, r in enumerate(red):
                 if r is not None:
                     act = CTYPE[r[1]]

@@ -34,6 +34,17 @@ template <> __device__ __forceinline__ float vget<float>(const float4& v, int k)
   return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w));
 }
 
+// The matrix is read exactly once: non-temporal loads (`nt`: the line is not kept in L2/MALL)
+// — the generated streaming kernels measured +7 % with them (codegen._stream_load).
+template <class V> __device__ __forceinline__ V nt_load16(const V* p) {
+  typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+  static_assert(sizeof(V) == 16, "16-byte pack");
+  const u4_t r = __builtin_nontemporal_load((const u4_t*)p);
+  V o;
+  __builtin_memcpy(&o, &r, 16);
+  return o;
+}
+
 // ---- row kernel ------------------------------------------------------------------------
 // VEC: 16-byte vector loads (requires N % VN == 0, sA0 % VN == 0, aligned base).
 // x is staged in LDS when it fits (XLDS), else read through L1/L2.
@@ -73,7 +84,7 @@ __global__ __launch_bounds__(BLOCK) void gemv_row_kernel(
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
           const long long row = row0 + r < M ? row0 + r : M - 1;
-          av[r] = *(const V*)(A + row * sA0 + j);
+          av[r] = nt_load16((const V*)(A + row * sA0 + j));
         }
 #pragma unroll
         for (int r = 0; r < ROWS; r++)
@@ -86,7 +97,7 @@ __global__ __launch_bounds__(BLOCK) void gemv_row_kernel(
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
           const long long row = row0 + r < M ? row0 + r : M - 1;
-          acc[r] += A[row * sA0 + j] * xv;
+          acc[r] += __builtin_nontemporal_load(A + row * sA0 + j) * xv;
         }
       }
     }
@@ -135,11 +146,11 @@ __global__ __launch_bounds__(BLOCK) void gemv_col_kernel(
         const T xj = __shfl(xl, jj, 64);  // wave-uniform broadcast (v_readlane)
         if (in) {
           if constexpr (VEC) {
-            V av = *(const V*)(A + i0 + (j0 + jj) * sA1);
+            V av = nt_load16((const V*)(A + i0 + (j0 + jj) * sA1));
 #pragma unroll
             for (int k = 0; k < VN; k++) acc[k] += vget<T>(av, k) * xj;
           } else {
-            acc[0] += A[i0 + (j0 + jj) * sA1] * xj;
+            acc[0] += __builtin_nontemporal_load(A + i0 + (j0 + jj) * sA1) * xj;
           }
         }
       }
@@ -148,11 +159,11 @@ __global__ __launch_bounds__(BLOCK) void gemv_col_kernel(
         const T xj = __shfl(xl, jj, 64);
         if (in) {
           if constexpr (VEC) {
-            V av = *(const V*)(A + i0 + (j0 + jj) * sA1);
+            V av = nt_load16((const V*)(A + i0 + (j0 + jj) * sA1));
 #pragma unroll
             for (int k = 0; k < VN; k++) acc[k] += vget<T>(av, k) * xj;
           } else {
-            acc[0] += A[i0 + (j0 + jj) * sA1] * xj;
+            acc[0] += __builtin_nontemporal_load(A + i0 + (j0 + jj) * sA1) * xj;
           }
         }
       }

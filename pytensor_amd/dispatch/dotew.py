@@ -20,7 +20,6 @@ from pytensor_amd.dispatch.blas import _prep2d, gemm_device
 from pytensor_amd.dispatch.elemwise import _body_key, _placed, _scalar_bits, _scalar_or_device, launch_elemwise
 from pytensor_amd.executor import HostValue
 
-NUM_CU = 256
 MAX_ROWS = 1024  # above this the 16x16-tile/full-K scheme re-reads too much; GEMM + Elemwise
 
 
@@ -95,10 +94,10 @@ def dot_epilogue(node, inputs, env):
         for k in range(len(out_dtypes))
     ]
     byvalue = {k for k, a in enumerate(ins) if isinstance(a, HostValue)}
-    # few tiles (one per CU or less): latency-bound, every operand load of two products in flight
-    # (~300 VGPRs, one workgroup per CU); many tiles: smaller register buffers, 3 workgroups per CU
-    tiles = ((N + 15) // 16) * ((M + 15) // 16)
-    chunk = int(os.environ.get("PTHIP_DOTEW_CHUNK", 0)) or (16 if tiles <= 2 * NUM_CU else 8)
+    # register buffers of 8 k-groups (two in flight = every load of a K=1024 product): 16.0 us per
+    # GRU step; 16 (both products of the update gate in flight, ~300 VGPRs) measured 17.4
+    # (profiles/r2f_c5_chunk.txt)
+    chunk = int(os.environ.get("PTHIP_DOTEW_CHUNK", 0)) or codegen.DOTEW_CHUNK
     name = f"dotew_{_body_key(body)}_k{K}_d{'_'.join(map(str, dpos))}_u{chunk}" + ("_c" + "_".join(map(str, sorted(byvalue))) if byvalue else "")
     src = codegen.dot_epilogue_source(name, body, dpos, K, byvalue, chunk)
     fn = kernel_cache.get_function(src, name)

@@ -123,37 +123,6 @@ def inc_subtensor(node, inputs, env):
     return [out]
 
 
-def _single_axis_index(idx_list, index_inputs, x_ndim):
-    """Supported advanced pattern: exactly one integer-array index, all other
-    positions full slices.  Returns (axis, index value)."""
-    axis = None
-    for d, e in enumerate(idx_list):
-        if isinstance(e, slice):
-            if (e.start, e.stop, e.step) != (None, None, None):
-                raise NotImplementedError("hip linker: advanced indexing mixed with non-trivial slices")
-            continue
-        if axis is not None:
-            raise NotImplementedError("hip linker: more than one advanced index")
-        axis = d
-    if axis is None:
-        raise NotImplementedError("hip linker: advanced indexing without an integer index")
-    return axis, index_inputs[idx_list[axis]]
-
-
-def _leading_multi_index(idx_list, index_inputs):
-    """``x[i0, i1, ..., :, :]`` — k >= 2 integer-array indices on the k leading axes, full slices
-    after them.  Returns the list of index values or None."""
-    k = 0
-    while k < len(idx_list) and not isinstance(idx_list[k], slice):
-        k += 1
-    if k < 2:
-        return None
-    for e in idx_list[k:]:
-        if not isinstance(e, slice) or (e.start, e.stop, e.step) != (None, None, None):
-            return None
-    return [index_inputs[idx_list[d]] for d in range(k)]
-
-
 def _combine_indices(env, ivs, dims):
     """Row-major linear index of pointwise index vectors over the leading ``dims`` (negative
     entries wrap like NumPy; any out-of-range component poisons the row so that the gather /
@@ -162,14 +131,13 @@ def _combine_indices(env, ivs, dims):
     from pytensor_amd.executor import HostValue
 
     ivs = [_index_on_device(env, iv) for iv in ivs]
-    shape = np.broadcast_shapes(*[iv.shape for iv in ivs])
-    if len(shape) != 1:
-        raise NotImplementedError("hip linker: multi-dimensional index arrays in a multi-index")
-    ins = []
-    for iv in ivs:
-        if iv.shape != tuple(shape) and iv.size != 1:
-            raise IndexError(f"shape mismatch: indexing arrays could not be broadcast together with shapes {[i.shape for i in ivs]}")
-        ins.append(iv if iv.ndim == 1 else iv.view((1,), (0,)))
+    try:
+        shape = np.broadcast_shapes(*[iv.shape for iv in ivs])
+    except ValueError:
+        raise IndexError(f"shape mismatch: indexing arrays could not be broadcast together with shapes {[i.shape for i in ivs]}") from None
+    nd = len(shape)
+    # NumPy broadcasting of the index arrays: left-pad to the common rank, stride 0 on length-1 dims
+    ins = [iv.view((1,) * (nd - iv.ndim) + tuple(iv.shape), (0,) * (nd - iv.ndim) + tuple(iv.strides)) for iv in ivs]
     k = len(ivs)
     ins += [HostValue(np.asarray(int(n), dtype="int64")) for n in dims]
     body = []
@@ -290,11 +258,39 @@ def _index_on_device(env, iv):
     return iv.contiguous()
 
 
-def _axis_to_front(x: DeviceArray, axis: int) -> DeviceArray:
-    if axis == 0:
-        return x
-    order = [axis] + [d for d in range(x.ndim) if d != axis]
-    return x.view([x.shape[d] for d in order], [x.strides[d] for d in order])
+def _simple_axis0(idx_list):
+    """``x[iv]`` / ``x[iv, :, ...]`` with full slices — the row gather/scatter kernels apply directly."""
+    return (len(idx_list) >= 1 and not isinstance(idx_list[0], slice)
+            and all(isinstance(e, slice) and (e.start, e.stop, e.step) == (None, None, None) for e in idx_list[1:]))
+
+
+def _general_plan(env, x: DeviceArray, idx_list, idx):
+    """NumPy advanced indexing in general (subtensor.py:1932 ``x.__getitem__(tuple(indices))``):
+    basic slices are applied first as a view; the advanced axes are then moved to the front,
+    flattened, and addressed with ONE combined row index (N-d index arrays broadcast against each
+    other).  Returns (view with the advanced axes leading, number k of advanced axes, combined
+    index of the broadcast shape, position at which NumPy places the broadcast dims — 0 when the
+    advanced axes are separated by a slice — and the axis order used)."""
+    basic, adv = [], []
+    for d, e in enumerate(idx_list):
+        if isinstance(e, slice):
+            basic.append(slice(*(None if v is None else int(env.to_host(idx[v])) for v in (e.start, e.stop, e.step))))
+        else:
+            basic.append(slice(None))
+            adv.append(d)
+    if not adv:
+        raise NotImplementedError("hip linker: advanced indexing without an integer index")
+    xv = basic_view(x, basic)
+    order = adv + [d for d in range(xv.ndim) if d not in adv]
+    xt = xv.view([xv.shape[d] for d in order], [xv.strides[d] for d in order])
+    k = len(adv)
+    ivs = [idx[idx_list[d]] for d in adv]
+    if k == 1:
+        iv = _index_on_device(env, ivs[0])
+    else:
+        iv = _combine_indices(env, ivs, xt.shape[:k])
+    adjacent = adv == list(range(adv[0], adv[0] + k))
+    return xt, k, iv, (adv[0] if adjacent else 0), order
 
 
 @handler("AdvancedSubtensor")
@@ -302,39 +298,33 @@ def advanced_subtensor(node, inputs, env):
     x, *idx = inputs
     x = env.to_device(x)
     idx_list, idx = _expand_bool_masks(env, node.params["idx_list"], idx, x.shape)
-    multi = _leading_multi_index(idx_list, idx)
-    if multi is not None:
-        # pointwise multi-index: the k leading axes are flattened and gathered with one
-        # combined row index (subtensor.py:1932 AdvancedSubtensor.perform = x[i0, i1, ...])
-        k = len(multi)
-        xc = x.contiguous()
-        iv = _combine_indices(env, multi, x.shape[:k])
-        rows = int(np.prod(x.shape[:k], dtype=np.int64))
-        xf = xc.view((rows, *x.shape[k:]), contiguous_strides((rows, *x.shape[k:])))
-        axis = 0
+    xt, k, iv, place, _ = _general_plan(env, x, idx_list, idx)
+    rest = tuple(xt.shape[k:])
+    rows = int(np.prod(xt.shape[:k], dtype=np.int64))
+    if k > 1:
+        # flatten the k leading axes: they must be jointly contiguous
+        xt = xt.contiguous()
+        xf = xt.view((rows, *rest), contiguous_strides((rows, *rest)))
     else:
-        axis, iv = _single_axis_index(idx_list, idx, x.ndim)
-        iv = _index_on_device(env, iv)
-        xf = _axis_to_front(x, axis)
-    inner_shape = xf.shape[1:]
-    inner = int(np.prod(inner_shape)) if inner_shape else 1
+        xf = xt
+    inner = int(np.prod(rest)) if rest else 1
     # rows must be contiguous runs of `inner` elements
-    if inner > 1 and not xf.view(inner_shape, xf.strides[1:]).is_contiguous():
+    if inner > 1 and not xf.view(rest, xf.strides[1:]).is_contiguous():
         xf = xf.contiguous()
     n_idx = iv.size
-    out = DeviceArray.empty((n_idx, *inner_shape), x.dtype)
+    out = DeviceArray.empty((n_idx, *rest), x.dtype)
     if out.size:
         ffi.check(
             env.lib.pthip_take_rows(x.itemsize, n_idx, inner, xf.ptr, xf.shape[0], xf.strides[0] if xf.shape[0] > 1 else inner, iv.ptr, out.ptr)
         )
     elif n_idx and xf.shape[0] == 0:
         raise IndexError("index out of bounds for axis with size 0")
-    res_shape = (*iv.shape, *inner_shape)
+    res_shape = (*iv.shape, *rest)
     res = out.view(res_shape, contiguous_strides(res_shape))
-    if axis != 0:
-        # NumPy places the broadcast index dims where the indexed axis was
-        k = len(iv.shape)
-        order = list(range(k, k + axis)) + list(range(k)) + list(range(k + axis, len(res_shape)))
+    if place != 0:
+        # NumPy places the broadcast index dims where the (adjacent) advanced axes were
+        nb = len(iv.shape)
+        order = list(range(nb, nb + place)) + list(range(nb)) + list(range(nb + place, len(res_shape)))
         res = res.view([res.shape[d] for d in order], [res.strides[d] for d in order])
     return [res]
 
@@ -345,23 +335,45 @@ def advanced_inc_subtensor(node, inputs, env):
     x, y, *idx = inputs
     x, y = env.to_device(x), env.to_device(y)
     idx_list, idx = _expand_bool_masks(env, p["idx_list"], idx, x.shape)
-    multi = _leading_multi_index(idx_list, idx)
-    if multi is not None:
-        k = len(multi)
-        iv = _combine_indices(env, multi, x.shape[:k])
-        full_shape = x.shape
-        rows = int(np.prod(x.shape[:k], dtype=np.int64))
-        own = _own_copy(env, x, 0)
-        flat = own.view((rows, *x.shape[k:]), contiguous_strides((rows, *x.shape[k:])))
-        res = _scatter_rows(env, p, flat, y, iv)
-        return [res.view(full_shape, contiguous_strides(full_shape))]
-    axis, iv = _single_axis_index(idx_list, idx, x.ndim)
-    if axis != 0:
-        raise NotImplementedError("hip linker: AdvancedIncSubtensor on axis != 0")
-    iv = _index_on_device(env, iv)
-    if iv.ndim != 1:
-        raise NotImplementedError("hip linker: AdvancedIncSubtensor with a multi-dimensional index")
-    return [_scatter_rows(env, p, _own_copy(env, x, 0), y, iv)]
+    own = _own_copy(env, x, 0)
+    if _simple_axis0(idx_list):
+        iv = _index_on_device(env, idx[idx_list[0]])
+        if iv.ndim == 1:
+            return [_scatter_rows(env, p, own, y, iv)]
+    xt, k, iv, place, _ = _general_plan(env, own, idx_list, idx)
+    rest = tuple(xt.shape[k:])
+    rows = int(np.prod(xt.shape[:k], dtype=np.int64))
+    flat_shape = (rows, *rest)
+    direct = xt.is_contiguous()
+    work = xt if direct else xt.contiguous_copy()
+    flat = work.view(flat_shape, contiguous_strides(flat_shape))
+    # y broadcasts against NumPy's result shape; bring it to (index dims..., remaining dims...)
+    nb = len(iv.shape)
+    res_shape = (*rest[:place], *iv.shape, *rest[place:]) if place else (*iv.shape, *rest)
+    if y.ndim > len(res_shape):
+        raise ValueError(f"shape mismatch: value array of shape {y.shape} could not be broadcast to indexing result of shape {res_shape}")
+    yv = y.view((1,) * (len(res_shape) - y.ndim) + tuple(y.shape), (0,) * (len(res_shape) - y.ndim) + tuple(y.strides))
+    for d in range(len(res_shape)):
+        if yv.shape[d] not in (1, res_shape[d]):
+            raise ValueError(f"shape mismatch: value array of shape {y.shape} could not be broadcast to indexing result of shape {res_shape}")
+    yb = yv.view(res_shape, [0 if yv.shape[d] == 1 and res_shape[d] != 1 else yv.strides[d] for d in range(len(res_shape))])
+    if place:
+        order = list(range(place, place + nb)) + list(range(place)) + list(range(place + nb, len(res_shape)))
+        yb = yb.view([yb.shape[d] for d in order], [yb.strides[d] for d in order])
+    n_idx = iv.size
+    if n_idx and flat.size:
+        ydt = yb
+        if str(ydt.dtype) != str(own.dtype):
+            from pytensor_amd.dispatch.elemwise import _cast
+
+            ydt = _cast(env, ydt.contiguous(), own.dtype)
+        yfull = DeviceArray.empty((*iv.shape, *rest), own.dtype)
+        copy_into(yfull, ydt)
+        y2 = yfull.view((n_idx, *rest), contiguous_strides((n_idx, *rest)))
+        _scatter_rows(env, p, flat, y2, iv.view((n_idx,), (1,)))
+        if not direct:
+            copy_into(xt, work)
+    return [own]
 
 
 def _scatter_rows(env, p, out, y, iv):

@@ -12,6 +12,7 @@ handlers, exactly as before the fusion.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import struct
 
 import numpy as np
@@ -61,6 +62,7 @@ class _Planner:
     def __init__(self, env):
         self.env = env
         self.ext, self.ext_args = [], []  # structural descriptors / runtime arguments
+        self.ext_len, self.step_n = [], []  # actual extents (size classes of the preloading kernel)
         self.slots, self.slot_len = [], []
         self.steps, self.step_args = [], []
         self.keep = []
@@ -74,6 +76,7 @@ class _Planner:
             if dt not in codegen.CTYPE:
                 raise _Infeasible(dt)
             self.ext.append({"kind": "C", "dtype": dt})
+            self.ext_len.append(1)
             self.ext_args.append([("q", _scalar_bits(v, dt))])
             return _Val(("e", len(self.ext) - 1), v.a.shape, dt, host=v)
         if isinstance(v, DeferredReduce):
@@ -86,6 +89,7 @@ class _Planner:
         n = _vec_len(v.shape)
         if n is None or n > MAX_LEN:
             return _Val(None, v.shape, dt, dev=v)  # only usable as a partial slab
+        self.ext_len.append(n)
         if n == 1:
             self.ext.append({"kind": "S", "dtype": dt})
             self.ext_args.append([("q", v.ptr)])
@@ -98,6 +102,7 @@ class _Planner:
 
     def add_slab(self, arr: DeviceArray) -> tuple:
         self.ext.append({"kind": "P", "dtype": str(arr.dtype)})
+        self.ext_len.append(arr.size)
         self.ext_args.append([("q", arr.ptr)])
         self.keep.append(arr)
         return ("e", len(self.ext) - 1)
@@ -126,6 +131,7 @@ class _Planner:
         self.steps.append({"op": "rsum", "src": src, "red": d.spec["op"], "acc_dtype": d.spec["acc_dtype"], "dtype": d.spec["dtype"],
                            "out": out.ref[1]})
         self.step_args.append([("q", d.grid)])
+        self.step_n.append(int(d.grid))
         val.ref, val.shape = out.ref, ()
         return val
 
@@ -185,6 +191,7 @@ def _plan(node, inputs, env):
                 st["y"], st["ymode"] = y.ref, ("V" if n == M and M > 1 else "S")
             P.steps.append(st)
             P.step_args.append([("q", rows), ("q", M), ("d", alpha), ("d", beta)])
+            P.step_n.append((int(rows), int(M)))
             vals[sub.outputs[0]] = out
         else:  # Elemwise / ElemwiseReduce
             body = sub.params["scalar"]
@@ -224,6 +231,7 @@ def _plan(node, inputs, env):
                 vals[sub.outputs[q]] = o
             P.steps.append({"op": "ew", "body": body, "ins": [v.ref for v in ins], "modes": modes, "outs": [o.ref[1] for o in outs], "reduce": red})
             P.step_args.append([("q", n)])
+            P.step_n.append(int(n))
     results = []
     for vid in node.outputs:
         v = vals[vid]
@@ -264,8 +272,11 @@ def _run_fused(node, P, results, env):
     spec = {"ext": P.ext, "slots": P.slots, "steps": P.steps, "outs": [v.ref[1] for v in results]}
     key = repr([[(e["kind"], e["dtype"]) for e in P.ext], [s["dtype"] for s in P.slots],
                 [{k: (_body_key(v) if k == "body" else v) for k, v in st.items()} for st in P.steps], spec["outs"]])
-    name = "tail_" + codegen.source_key(key)[:16]
-    src = codegen.tail_chain_source(name, spec)
+    # short operands (the usual case: K- and G-vectors, <= 16-row slabs): the form that requests
+    # every global operand before the first step; size classes are part of the kernel identity
+    sizes = codegen.tail_preload_sizes(spec, P.ext_len, P.step_n) if os.environ.get("PTHIP_TAIL_PRELOAD", "1") != "0" else None
+    name = "tail_" + codegen.source_key(key + repr(sizes))[:16]
+    src = codegen.tail_chain_source(name, spec, sizes)
     fn = kernel_cache.get_function(src, name)
     args = [a for e in P.ext_args for a in e] + [("q", o) for o in offs] + [a for s in P.step_args for a in s] + out_args
     status = getattr(env, "tail_status", None) or (0, 0)
