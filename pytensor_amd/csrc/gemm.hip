@@ -35,9 +35,9 @@ typedef float float16_t __attribute__((ext_vector_type(16)));
 // An operand tile is ROWS(=128) x BK(=16) elements, `row` along M (for A) or N (for B).
 // KC (K-contiguous in global memory): element (row, k) at base + row*ld + k.
 // else (row-contiguous):               element (row, k) at base + k*ld + row.
-template <class T, bool KC> struct Stage;
+template <class T, bool KC, int BKT = 16> struct Stage;  // BKT: K extent of a staged tile
 
-template <bool KC> struct Stage<double, KC> {
+template <bool KC> struct Stage<double, KC, 16> {
   static constexpr int NV = 4;                 // 16-byte vectors per thread per tile
   static constexpr int LD = KC ? 18 : 144;     // LDS leading dimension (elements)
   static constexpr int SIZE = KC ? 128 * 18 : 16 * 144;
@@ -100,20 +100,21 @@ template <bool KC> struct Stage<double, KC> {
   }
 };
 
-template <bool KC> struct Stage<float, KC> {
-  static constexpr int NV = 2;
-  static constexpr int LD = KC ? 18 : 128;
-  static constexpr int SIZE = KC ? 128 * 18 : 16 * 128;
+template <bool KC, int BKT> struct Stage<float, KC, BKT> {
+  static constexpr int VPR = BKT / 4;          // 16-byte vectors per tile row (K-contiguous image)
+  static constexpr int NV = BKT / 8;
+  static constexpr int LD = KC ? BKT + 2 : 128;  // 18 / 34: float2 fragment reads hit 32 distinct banks per 16 lanes
+  static constexpr int SIZE = KC ? 128 * (BKT + 2) : BKT * 128;
   float4 v[NV];
   __device__ __forceinline__ void load(const float* __restrict__ base, long long ld,
                                        long long row0, long long k0, long long rows,
                                        long long K, bool vec_ok) {
-    if (vec_ok && row0 + 128 <= rows && k0 + BK <= K) {
+    if (vec_ok && row0 + 128 <= rows && k0 + BKT <= K) {
       // interior tile (workgroup-uniform test): straight 16-byte loads, no per-vector branches
 #pragma unroll
       for (int p = 0; p < NV; p++) {
         const int id = threadIdx.x + p * BLOCK;
-        if constexpr (KC) v[p] = *(const float4*)(base + (row0 + (id >> 2)) * ld + k0 + (id & 3) * 4);
+        if constexpr (KC) v[p] = *(const float4*)(base + (row0 + (id / VPR)) * ld + k0 + (id % VPR) * 4);
         else v[p] = *(const float4*)(base + (k0 + (id >> 5)) * ld + row0 + (id & 31) * 4);
       }
       return;
@@ -125,7 +126,7 @@ template <bool KC> struct Stage<float, KC> {
       const float* g;
       bool full;
       if constexpr (KC) {
-        const int r = id >> 2, kv = (id & 3) * 4;
+        const int r = id / VPR, kv = (id % VPR) * 4;
         row = row0 + r; k = k0 + kv;
         g = base + row * ld + k;
         full = row < rows && k + 3 < K;
@@ -153,7 +154,7 @@ template <bool KC> struct Stage<float, KC> {
     for (int p = 0; p < NV; p++) {
       const int id = threadIdx.x + p * BLOCK;
       if constexpr (KC) {
-        const int r = id >> 2, kv = (id & 3) * 4;
+        const int r = id / VPR, kv = (id % VPR) * 4;
         float2* d = (float2*)(s + r * LD + kv);  // LD=18: 8-byte aligned rows
         d[0] = make_float2(v[p].x, v[p].y);
         d[1] = make_float2(v[p].z, v[p].w);
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(BLOCK, 2) void dgemm_kernel(
 // ---------------------------------------------------------------------------------
 // fp32 kernel
 // ---------------------------------------------------------------------------------
-template <bool AKC, bool BKC, bool SKINNY>
+template <bool AKC, bool BKC, bool SKINNY, int BKT>
 // (PMC, 4096^3: waves parked at barriers / s_waitcnt 37 % of their cycles vs 11 % in the fp64
 //  kernel — an fp32 step has half the MFMA time to hide the same latencies.  Tried, measured,
 //  rejected: three workgroups per CU (same 101 TFLOP/s); two BK steps per barrier interval
@@ -290,8 +291,8 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_kernel(
     long long ldb, long long sAb, long long sBb, long long sCb, long long sC0, long long sC1,
     float alpha, float beta, long long tiles_m, long long tiles_n, int vecA, int vecB,
     long long kchunk) {
-  using SA = Stage<float, AKC>;
-  using SB = Stage<float, BKC>;
+  using SA = Stage<float, AKC, BKT>;
+  using SB = Stage<float, BKC, BKT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* As = (float*)smem_raw;
   float* Bs = As + 2 * SA::SIZE;
@@ -317,10 +318,10 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_kernel(
   SB sb;
   const long long kb = (long long)blockIdx.y * kchunk;
   const long long Kend = (kb + kchunk < K) ? kb + kchunk : K;
-  const long long nk = (Kend - kb + BK - 1) / BK;
+  const long long nk = (Kend - kb + BKT - 1) / BKT;
   auto compute = [&](const float* as, const float* bs) {
 #pragma unroll
-    for (int kk = 0; kk < BK / 4; kk++) {
+    for (int kk = 0; kk < BKT / 4; kk++) {
       float2 af[2], bf[NJ];
 #pragma unroll
       for (int i = 0; i < 2; i++) af[i] = SA::frag2(as, wm0 + i * 32, kk, lane);
@@ -350,8 +351,8 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_kernel(
 #pragma unroll
     for (int t = 0; t < PRE; t++)
       if (t < nk) {
-        sap[t].load(A, lda, m0, kb + t * BK, M, Kend, vecA);
-        sbp[t].load(B, ldb, n0, kb + t * BK, N, Kend, vecB);
+        sap[t].load(A, lda, m0, kb + t * BKT, M, Kend, vecA);
+        sbp[t].load(B, ldb, n0, kb + t * BKT, N, Kend, vecB);
       }
     sap[0].store(As);
     sbp[0].store(Bs);
@@ -376,8 +377,8 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_kernel(
     for (long long kt = 0; kt < nk; kt++) {
       const int cur = kt & 1;
       if (kt + 1 < nk) {
-        sa.load(A, lda, m0, kb + (kt + 1) * BK, M, Kend, vecA);
-        sb.load(B, ldb, n0, kb + (kt + 1) * BK, N, Kend, vecB);
+        sa.load(A, lda, m0, kb + (kt + 1) * BKT, M, Kend, vecA);
+        sb.load(B, ldb, n0, kb + (kt + 1) * BKT, N, Kend, vecB);
       }
       compute(As + cur * SA::SIZE, Bs + cur * SB::SIZE);
       if (kt + 1 < nk) {
@@ -428,10 +429,10 @@ __global__ __launch_bounds__(BLOCK) void splitk_finish_kernel(
 
 template <class T> struct KernelSel;
 template <> struct KernelSel<double> {
-  template <bool a, bool b, bool s> static auto get() { return dgemm_kernel<a, b, s>; }
+  template <bool a, bool b, bool s, int bk> static auto get() { return dgemm_kernel<a, b, s>; }
 };
 template <> struct KernelSel<float> {
-  template <bool a, bool b, bool s> static auto get() { return sgemm_kernel<a, b, s>; }
+  template <bool a, bool b, bool s, int bk> static auto get() { return sgemm_kernel<a, b, s, bk>; }
 };
 
 // split-K when the tile grid cannot fill the chip (skinny / small GEMMs, e.g. the
@@ -464,16 +465,16 @@ inline SplitPlan split_plan(long long batch, long long M, long long N, long long
 
 // `partials` != nullptr: write the raw products into partials[nsplit][batch][M][N] and stop
 // (no finish launch: the consumer folds the fixed-order sum and the alpha/beta epilogue in)
-template <class T, bool AKC, bool BKC, bool SKINNY>
+template <class T, bool AKC, bool BKC, bool SKINNY, int BKT = 16>
 int launch(long long batch, long long M, long long N, long long K, T alpha, const T* A,
            long long sAb, long long lda, const T* B, long long sBb, long long ldb, T beta,
            const T* C, long long sCb, long long sC0, long long sC1, T* out,
            T* partials = nullptr) {
   hipStream_t st = pthip::ctx().stream;
-  using SA = Stage<T, AKC>;
-  using SB = Stage<T, BKC>;
+  using SA = Stage<T, AKC, BKT>;
+  using SB = Stage<T, BKC, BKT>;
   const size_t shmem = (size_t)(2 * SA::SIZE + 2 * SB::SIZE) * sizeof(T);
-  auto k = KernelSel<T>::template get<AKC, BKC, SKINNY>();
+  auto k = KernelSel<T>::template get<AKC, BKC, SKINNY, BKT>();
   static bool attr_set = false;
   if (!attr_set && shmem > 64 * 1024) {
     PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -516,6 +517,14 @@ int launch(long long batch, long long M, long long N, long long K, T alpha, cons
   return r;
 }
 
+// fp32, M > 64: K extent of the staged tiles.  32 = half as many barrier intervals per tile (the
+// fp32 MFMA step is half as long as the fp64 one for the same latencies); PTHIP_SGEMM_BK=16
+// selects the round-1 kernel for A/B measurements.
+inline bool sgemm_bk32() {
+  static const bool v = !(getenv("PTHIP_SGEMM_BK") && atoi(getenv("PTHIP_SGEMM_BK")) == 16);
+  return v;
+}
+
 template <class T>
 int gemm_typed(long long batch, long long M, long long N, long long K, double alpha, const void* A,
                long long sAb, long long sA0, long long sA1, const void* B, long long sBb,
@@ -547,6 +556,11 @@ int gemm_typed(long long batch, long long M, long long N, long long K, double al
     if (skinny)                                                                                    \
       return launch<T, X, Y, true>(batch, M, N, K, (T)alpha, a, sAb, lda, b, sBb, ldb, (T)beta, c, \
                                    sCb, sC0, sC1, o, (T*)partials);                                \
+    if constexpr (sizeof(T) == 4) {                                                                \
+      if (sgemm_bk32())                                                                            \
+        return launch<T, X, Y, false, 32>(batch, M, N, K, (T)alpha, a, sAb, lda, b, sBb, ldb,      \
+                                          (T)beta, c, sCb, sC0, sC1, o, (T*)partials);             \
+    }                                                                                              \
     return launch<T, X, Y, false>(batch, M, N, K, (T)alpha, a, sAb, lda, b, sBb, ldb, (T)beta, c,  \
                                   sCb, sC0, sC1, o, (T*)partials);                                 \
   } while (0)

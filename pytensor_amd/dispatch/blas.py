@@ -103,12 +103,16 @@ def gemv_device(env, alpha, A, x, beta, y):
         sA0 = 1
     ws_bytes = lib.pthip_gemv_workspace(_dt(A), M, N, sA0, sA1)
     ws = DeviceArray.empty((ws_bytes,), "uint8") if ws_bytes else None
-    ffi.check(
-        lib.pthip_gemv(
-            _dt(A), M, N, float(alpha), A.ptr, sA0, sA1, x.ptr, x.strides[0] if x.shape[0] > 1 else 1,
-            float(beta), y.ptr if y is not None else None, (y.strides[0] if y.shape[0] > 1 else 1) if y is not None else 0,
-            out.ptr, ws.ptr if ws is not None else None, ws_bytes,
-        )
+    # (row layout: one kernel; column layout: the streaming kernel plus its fixed-order finish)
+    env.timed(
+        f"gemv_{A.dtype}_{M}x{N}_{'row' if sA1 == 1 else 'col'}",
+        lambda: ffi.check(
+            lib.pthip_gemv(
+                _dt(A), M, N, float(alpha), A.ptr, sA0, sA1, x.ptr, x.strides[0] if x.shape[0] > 1 else 1,
+                float(beta), y.ptr if y is not None else None, (y.strides[0] if y.shape[0] > 1 else 1) if y is not None else 0,
+                out.ptr, ws.ptr if ws is not None else None, ws_bytes,
+            )
+        ),
     )
     return out
 
@@ -178,11 +182,14 @@ def gemm_device(env, alpha, A, B, beta=0.0, Cm=None, batch=None):
         sC0 = sC1 = sCb = 0
         cptr = None
         beta = 0.0
-    ffi.check(
-        lib.pthip_gemm(
-            _dt(A), nb, M, N, K, float(alpha), A.ptr, sAb, sA[0], sA[1], B.ptr, sBb, sB[0], sB[1],
-            float(beta), cptr, sCb, sC0, sC1, out.ptr,
-        )
+    env.timed(
+        f"gemm_{A.dtype}_b{nb}_{M}x{N}x{K}",
+        lambda: ffi.check(
+            lib.pthip_gemm(
+                _dt(A), nb, M, N, K, float(alpha), A.ptr, sAb, sA[0], sA[1], B.ptr, sBb, sB[0], sB[1],
+                float(beta), cptr, sCb, sC0, sC1, out.ptr,
+            )
+        ),
     )
     return out
 

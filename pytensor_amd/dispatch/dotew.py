@@ -113,5 +113,5 @@ def dot_epilogue(node, inputs, env):
     for o in outs:
         args += [o.ptr, o.strides[0]]
     buf = struct.pack(f"<{len(args)}q", *args)
-    ffi.check(env.lib.pthip_launch(fn, (N + 15) // 16, (M + 15) // 16, 1, codegen.BLOCK, 1, 1, 0, buf, len(buf)))
+    env.timed(name, lambda: ffi.check(env.lib.pthip_launch(fn, (N + 15) // 16, (M + 15) // 16, 1, codegen.BLOCK, 1, 1, 0, buf, len(buf))))
     return outs

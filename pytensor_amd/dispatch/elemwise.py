@@ -310,7 +310,7 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=
     if flat and "G" in modes:
         args.append(env.lib.pthip_status_ptr())  # device error flag: out-of-range index
     buf = struct.pack(f"<{len(args)}q", *args)
-    ffi.check(lib.pthip_launch(fn, grid, 1, 1, BLOCK, 1, 1, 0, buf, len(buf)))
+    env.timed(name, lambda: ffi.check(lib.pthip_launch(fn, grid, 1, 1, BLOCK, 1, 1, 0, buf, len(buf))))
     return outs, parts, grid
 
 

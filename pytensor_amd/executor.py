@@ -214,6 +214,17 @@ class Env:
         self.tail_status = None
         self.tail_status_done = False
 
+    def timed(self, name, launch):
+        """Run ``launch()`` (ONE kernel launch) between two HIP events when a KernelTimer is
+        attached (HipExecutable.profile_nodes); plain call otherwise."""
+        kt = self.kernel_timer
+        if kt is None:
+            return launch()
+        tok = kt.begin()
+        r = launch()
+        kt.end(name, tok)
+        return r
+
     def to_device(self, v) -> DeviceArray:
         if isinstance(v, DeviceArray):
             return v

@@ -52,7 +52,7 @@ def device_time_ms(plan, reps):
     return ms.value / reps
 
 
-def run_case(name, vals, reps, check=True, rtol=1e-10, oracle_vals=None):
+def run_case(name, vals, reps, check=True, rtol=1e-10, oracle_vals=None, kernel_reps=10):
     import np_graph
 
     g, names = load(name)
@@ -74,7 +74,32 @@ def run_case(name, vals, reps, check=True, rtol=1e-10, oracle_vals=None):
     for _ in range(reps):
         plan(*inputs)
     t_wall = (time.perf_counter() - t0) / reps * 1e3
+    plan.close()
+    # per-kernel launch durations (HIP events bracketing each launch, eager pass): what the
+    # roofline fraction of the dominant kernel is computed from — a replay additionally carries
+    # the graph-launch floor (~8-10 us: config #1 is two ~2 us kernels and replays in 12 us)
+    exe.profile_nodes(inputs, reps=kernel_reps)
+    KERNELS[name] = dict(exe.last_kernel_times)
     return t_dev, t_wall
+
+
+KERNELS = {}
+
+
+def _dominant(name, prefix=None):
+    kt = {k: v for k, v in KERNELS.get(name, {}).items() if prefix is None or k.startswith(prefix)}
+    if not kt:
+        return None, None
+    k = max(kt, key=kt.get)
+    return k, kt[k]
+
+
+def _with_kernel(entry, name, work, peak, prefix=None, scale=1e6):
+    """adds the dominant kernel's own roofline: ``work`` (bytes or flops) / its launch duration"""
+    k, ms = _dominant(name, prefix)
+    if k is not None:
+        entry.update({"kernel": k, "kernel_ms": ms, "kernel_achieved": work / ms / scale, "kernel_frac": work / ms / scale / peak})
+    return entry
 
 
 def measure(which=("c1", "c2", "c3", "c5"), reps=20, check=True):
@@ -86,8 +111,8 @@ def measure(which=("c1", "c2", "c3", "c5"), reps=20, check=True):
         v = configs.c1_inputs()
         td, tw = run_case("c1_gauss", v, reps, check=check)
         b = 1.6e6
-        res["c1"] = {"config": "C1 exp(-0.5(x-mu)^2).sum()+grad N=1e5 f64", "ms_device": td, "ms_call": tw, "achieved": b / td / 1e6,
-                     "unit": "GB/s", "peak": HBM_PEAK, "frac": b / td / 1e6 / HBM_PEAK, "bound": "launch latency (1.6 MB/eval)"}
+        res["c1"] = _with_kernel({"config": "C1 exp(-0.5(x-mu)^2).sum()+grad N=1e5 f64", "ms_device": td, "ms_call": tw, "achieved": b / td / 1e6,
+                     "unit": "GB/s", "peak": HBM_PEAK, "frac": b / td / 1e6 / HBM_PEAK, "bound": "launch latency (1.6 MB/eval)"}, "c1_gauss", b, HBM_PEAK)
     if "c2" in which:
         v = configs.c2_inputs()
         small = configs.c2_inputs(N=1_000_000)
@@ -95,32 +120,33 @@ def measure(which=("c1", "c2", "c3", "c5"), reps=20, check=True):
                                ("c2_transc", "c2_transc", "C2 transcendental (10 tanh + 10 exp) Composite+Sum N=1e7 f64")):
             td, tw = run_case(nm, v, reps, check=check, oracle_vals=small)
             b = 160e6
-            res[key] = {"config": label, "ms_device": td, "ms_call": tw, "achieved": b / td / 1e6, "unit": "GB/s", "peak": HBM_PEAK,
-                        "frac": b / td / 1e6 / HBM_PEAK, "bound": "hbm" if key == "c2_cheap" else "alu (transcendentals), hbm fraction shown"}
+            res[key] = _with_kernel({"config": label, "ms_device": td, "ms_call": tw, "achieved": b / td / 1e6, "unit": "GB/s", "peak": HBM_PEAK,
+                        "frac": b / td / 1e6 / HBM_PEAK, "bound": "hbm" if key == "c2_cheap" else "alu (transcendentals), hbm fraction shown"}, nm, b, HBM_PEAK)
     if "c3" in which:
         v = configs.c3_inputs()
         small = configs.c3_inputs(M=512, B=8, Bn=64)
         td, tw = run_case("c3_dot22", v, max(3, reps // 4), check=check, oracle_vals=small)
         fl = 2 * 4096**3
-        res["c3_dot22"] = {"config": "C3 Dot22 4096^3 f64", "ms_device": td, "ms_call": tw, "achieved": fl / td / 1e9, "unit": "TFLOP/s",
-                           "peak": F64_MFMA_PEAK, "frac": fl / td / 1e9 / F64_MFMA_PEAK, "bound": "mfma f64"}
+        res["c3_dot22"] = _with_kernel({"config": "C3 Dot22 4096^3 f64", "ms_device": td, "ms_call": tw, "achieved": fl / td / 1e9, "unit": "TFLOP/s",
+                           "peak": F64_MFMA_PEAK, "frac": fl / td / 1e9 / F64_MFMA_PEAK, "bound": "mfma f64"}, "c3_dot22", fl, F64_MFMA_PEAK, "gemm_", 1e9)
         td, tw = run_case("c3_gemv", v, reps, check=check, oracle_vals=small)
         b = 4096 * 4096 * 8
-        res["c3_gemv"] = {"config": "C3 Gemv 4096^2 f64", "ms_device": td, "ms_call": tw, "achieved": b / td / 1e6, "unit": "GB/s",
-                          "peak": HBM_PEAK, "frac": b / td / 1e6 / HBM_PEAK, "bound": "hbm"}
+        res["c3_gemv"] = _with_kernel({"config": "C3 Gemv 4096^2 f64", "ms_device": td, "ms_call": tw, "achieved": b / td / 1e6, "unit": "GB/s",
+                          "peak": HBM_PEAK, "frac": b / td / 1e6 / HBM_PEAK, "bound": "hbm"}, "c3_gemv", b, HBM_PEAK, "gemv_")
         td, tw = run_case("c3_bdot", v, reps, check=check, rtol=1e-4, oracle_vals=small)
         fl = 2 * 512 * 256**3
-        res["c3_bdot"] = {"config": "C3 BatchedDot 512x(256x256) f32", "ms_device": td, "ms_call": tw, "achieved": fl / td / 1e9,
-                          "unit": "TFLOP/s", "peak": F32_MFMA_PEAK, "frac": fl / td / 1e9 / F32_MFMA_PEAK, "bound": "mfma f32"}
+        res["c3_bdot"] = _with_kernel({"config": "C3 BatchedDot 512x(256x256) f32", "ms_device": td, "ms_call": tw, "achieved": fl / td / 1e9,
+                          "unit": "TFLOP/s", "peak": F32_MFMA_PEAK, "frac": fl / td / 1e9 / F32_MFMA_PEAK, "bound": "mfma f32"}, "c3_bdot", fl, F32_MFMA_PEAK, "gemm_", 1e9)
     if "c5" in which:
         T, B, H = 1000, 64, 1024
         v = configs.c5_inputs(T=T, B=B, H=H)
         small = configs.c5_inputs(T=5, B=8, H=64)
-        td, tw = run_case("c5_gru", v, 3, check=check, rtol=2e-4, oracle_vals=small)
+        td, tw = run_case("c5_gru", v, 3, check=check, rtol=2e-4, oracle_vals=small, kernel_reps=1)
         fl = 6 * 2 * B * H * H * T
         res["c5"] = {"config": f"C5 GRU Scan T={T} B={B} H={H} f32", "ms_device": td, "ms_call": tw, "us_per_step": td / T * 1e3,
                      "achieved": fl / td / 1e9, "unit": "TFLOP/s", "peak": F32_MFMA_PEAK, "frac": fl / td / 1e9 / F32_MFMA_PEAK,
-                     "bound": "mfma f32 (skinny M=64, dependent steps)"}
+                     "bound": "mfma f32 (skinny M=64, dependent steps)",
+                     "kernels_us": {k: round(ms * 1e3, 2) for k, ms in sorted(KERNELS.get("c5_gru", {}).items(), key=lambda t: -t[1])[:4]}}
     return res
 
 
