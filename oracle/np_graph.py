@@ -1049,6 +1049,16 @@ def _dot_epilogue(p, inputs, node, graph):
     return [np.array(np.broadcast_to(o, shape), dtype=graph.vars[vid].dtype, order="C") for o, vid in zip(outs, node.outputs)]
 
 
+@op("AllReduce")
+def _all_reduce(p, inputs, node, graph):
+    # pytensor_amd/collective.py AllReduce.perform: element-wise reduction over the ranks of the
+    # job (identity in a single process) — no reference Op exists; semantics = NumPy's
+    # sum/prod/max/min over the stacked per-rank arrays
+    from pytensor_amd import comm
+
+    return [comm.all_reduce_host(inputs[0], p["op"])]
+
+
 @op("Tail")
 def _tail(p, inputs, node, graph):
     # tailfuse.fuse_tail: the member nodes in their original order (the fusion changes how many

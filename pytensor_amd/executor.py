@@ -183,6 +183,19 @@ class KernelTimer:
         return {k: v[0] / v[1] for k, v in self.totals.items()}
 
 
+def _has_op(graph, name: str) -> bool:
+    """``name`` anywhere in the graph, inner graphs of Scan / Tail nodes included."""
+    for n in graph.nodes:
+        if n.op == name:
+            return True
+        inner = n.params.get("inner") if isinstance(n.params, dict) else None
+        if inner is not None and _has_op(inner, name):
+            return True
+        if n.op == "Tail" and any(m.op == name for m in n.params.get("nodes", ())):
+            return True
+    return False
+
+
 def raise_device_status(word: int):
     """The device error word (kernels cannot raise): bit 0 = an index was out of range
     (IndexError, like the reference's take/inc_subtensor), bit 1 = np.linalg.inv met an exactly
@@ -277,7 +290,9 @@ class HipExecutable:
         # a captured launch sequence would replay the same Philox counters: graphs that draw
         # random numbers run eagerly (sampling graphs are not the logp+grad hot path)
         self.has_rng = any(v.kind == "rng" for v in self.graph.vars.values())
-        if self.has_rng:
+        # an all-reduce drains the stream and runs on RCCL's: not capturable either
+        self.has_collective = _has_op(self.graph, "AllReduce")
+        if self.has_rng or self.has_collective:
             self.auto_freeze = False
         self._handlers = dispatch.HANDLERS
         self._resident_cache = {}  # input position -> ResidentEntry
@@ -633,6 +648,9 @@ class HipExecutable:
         if self.has_rng:
             raise NotImplementedError("hip linker: a graph that draws random numbers cannot be frozen "
                                       "(a replay would repeat the captured Philox counters)")
+        if self.has_collective:
+            raise NotImplementedError("hip linker: a graph with an all-reduce cannot be frozen "
+                                      "(the collective runs outside the captured stream)")
         self._ensure_device()
         if not self._warm:
             # never run before: constants are uploaded lazily and would otherwise be allocated

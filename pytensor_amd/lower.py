@@ -365,6 +365,18 @@ def _register_extra_ops():
 _register_extra_ops()
 
 
+def _register_collective():
+    # the one explicit collective (pytensor_amd/collective.py; north_star: RCCL over xGMI)
+    from pytensor_amd.collective import AllReduce
+
+    @hip_funcify.register(AllReduce)
+    def _(op, node, ctx):
+        return "AllReduce", {"op": str(op.op)}
+
+
+_register_collective()
+
+
 @hip_funcify.register(Gemm)
 @hip_funcify.register(Gemv)
 @hip_funcify.register(Ger)

@@ -33,3 +33,46 @@ def test_single_rank_defaults():
     assert replicas.chains_for_rank(3, info) == [0, 1, 2]
     assert replicas.init_process_group(info) is None
     assert replicas.max_over_ranks(None, 1.5) == 1.5
+
+
+def test_all_reduce_world2_gloo(tmp_path):
+    """The explicit all-reduce (pytensor_amd/comm.py + the ``AllReduce`` IR node) on two ranks."""
+    import numpy as np
+
+    env = dict(os.environ, DIST_OUT=str(tmp_path), OMP_NUM_THREADS="1")
+    cmd = [
+        sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+        "--master-addr", "127.0.0.1", "--master-port", "29578",
+        os.path.join(ROOT, "tests", "_allreduce_worker.py"),
+    ]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = (json.load(open(tmp_path / f"ar{k}.json")) for k in range(2))
+    xa, xb = np.array(a["x"]), np.array(b["x"])
+    want = {"sum": xa + xb, "prod": xa * xb, "max": np.maximum(xa, xb), "min": np.minimum(xa, xb)}
+    for op, w in want.items():
+        # bit-identical on both ranks, equal to NumPy's reduction of the stacked shards
+        assert a[op] == b[op]
+        np.testing.assert_array_equal(np.array(a[op]), w)
+    assert a["int_sum"] == b["int_sum"] == [0, 3, 6, 9]
+    assert a["bool_max"] == b["bool_max"] == [True, False, True]
+    tot = xa.sum() + xb.sum()
+    assert a["graph"] == b["graph"]
+    np.testing.assert_allclose(a["graph"], [tot, np.exp(tot)], rtol=1e-13)
+
+
+def test_all_reduce_single_process_is_identity():
+    import numpy as np
+
+    from pytensor_amd import comm
+
+    x = np.arange(6.0).reshape(2, 3)
+    for op in comm.OPS:
+        y = comm.all_reduce_host(x, op)
+        assert y is not x
+        np.testing.assert_array_equal(y, x)
+    assert comm.world_size() == 1
+    import pytest
+
+    with pytest.raises(ValueError):
+        comm.all_reduce_host(x, "mean")

@@ -28,7 +28,8 @@ def test_golden_case(hip, name):
     assert len(out) == len(cvm)
     for k, (a, b) in enumerate(zip(out, cvm)):
         assert isinstance(a, np.ndarray)
-        assert_parity(a, b, meta["rtol"], f"{name} out{k} (hip vs reference C linker)")
+        # element-wise at north_star's rtol, no atol; exceptions per output in tests/tolerances.json
+        assert_parity(a, b, None, f"{name} out{k} (hip vs reference C linker)", case=name, k=k, py=py[k])
     # second call: cached kernels, pooled buffers — same answer, bit for bit
     out2 = exe(*ins)
     for a, b in zip(out, out2):
@@ -43,7 +44,7 @@ def test_unfused_equals_fused(hip, name):
     a = HipExecutable(g, fuse=True)(*ins)
     b = HipExecutable(g, fuse=False)(*ins)
     for k, (x, y) in enumerate(zip(a, b)):
-        assert_parity(x, y, meta["rtol"], f"{name} out{k} fused vs unfused")
+        assert_parity(x, y, None, f"{name} out{k} fused vs unfused", case=name, k=k, py=py[k], slack=2.0)
 
 
 @pytest.mark.parametrize("dtype,n", [("float64", 1), ("float64", 7), ("float64", 64), ("float64", 128), ("float64", 141),

@@ -132,7 +132,7 @@ def test_auto_freeze_is_what_the_linker_path_gets(hip):
     for a, b, c, ref in zip(first, second, third, cvm):
         np.testing.assert_array_equal(a, b)
         np.testing.assert_array_equal(a, c)
-        np.testing.assert_allclose(a, ref, rtol=meta["rtol"], atol=meta["rtol"] * np.max(np.abs(ref)))
+        np.testing.assert_allclose(a, ref, rtol=1e-12)  # north_star, element-wise
     # new parameter values, same signature: still the plan, new results
     ins2 = [a if k in resident else (a * 1.01 if a.dtype.kind == "f" else a) for k, a in enumerate(ins)]
     plan = exe._auto_plan
@@ -173,8 +173,10 @@ def test_auto_freeze_is_what_the_linker_path_gets(hip):
     for _ in range(3):
         out = exe(*ins)
     assert exe._auto_plan is None and exe._auto_failed
-    for a, ref in zip(out, cvm):
-        np.testing.assert_allclose(a, ref, rtol=meta["rtol"], atol=meta["rtol"] * max(1.0, float(np.max(np.abs(ref)))))
+    from util import assert_parity
+
+    for k, (a, ref) in enumerate(zip(out, cvm)):
+        assert_parity(a, ref, None, f"softmax_shapes out{k}", case="softmax_shapes", k=k, py=py[k])
 
 
 def test_auto_multi_stream_picks_a_plan_and_matches_eager(hip):

@@ -17,7 +17,7 @@ def test_passes_preserve_results(name):
     g2, seg = _pipeline(g)
     out = np_graph.run_graph(g2, ins)
     for k, (a, b) in enumerate(zip(out, cvm)):
-        assert_parity(a, b, max(meta["rtol"], 1e-11), f"{name} out{k} after IR passes")
+        assert_parity(a, b, None, f"{name} out{k} after IR passes", case=name, k=k, py=py[k], slack=2.0)
 
 
 def test_c4_gets_the_one_pass_gemv_chain_and_two_segments():

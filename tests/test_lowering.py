@@ -109,3 +109,35 @@ def test_widening_rows_lower_to_their_own_nodes(pt):
     assert loops, "the gradient of gammainc wrt its shape parameter is a ScalarLoop inside the fused kernel"
     with pytest.raises(NotImplementedError, match="Hyp2F1"):
         pytensor.function([x], ptt.hyp2f1(0.5, 1.0, 1.5, ptt.sigmoid(x)), mode="hip")
+
+
+def test_all_reduce_op_lowers_and_differentiates(pt):
+    """The explicit collective (north_star: "the rare explicit all-reduce Op"): an ordinary Op for
+    every linker (perform = the host reduction, identity on one rank), an ``AllReduce`` IR node
+    under ``mode="hip"``, with a gradient."""
+    pytensor, ptt = pt
+    from pytensor_amd.collective import AllReduce, all_reduce
+
+    x = ptt.dvector("x")
+    logp_shard = -0.5 * (x**2).sum()
+    total = all_reduce(logp_shard)  # sum of the per-rank shards
+    cost = ptt.exp(0.1 * total)
+    gx = pytensor.grad(cost, x)
+    assert any(isinstance(n.op, AllReduce) for n in pytensor.graph.traversal.applys_between([x], [gx]))
+    xv = np.linspace(-1, 1, 7)
+    f_py = pytensor.function([x], [total, cost, gx], mode=pytensor.compile.mode.Mode("py", "fast_run"))
+    t, c, g = f_py(xv)
+    np.testing.assert_allclose(t, -0.5 * (xv**2).sum(), rtol=1e-14)  # one rank: identity
+    np.testing.assert_allclose(g, np.exp(0.1 * t) * 0.1 * (-xv), rtol=1e-13)
+    f = pytensor.function([x], [total, cost, gx], mode="hip")
+    ir = f.maker.linker.last_ir
+    ops = [n.op for n in ir.nodes]
+    assert ops.count("AllReduce") == 2 and "HostPerform" not in ops  # forward + the gradient's
+    assert all(n.params == {"op": "sum"} for n in ir.nodes if n.op == "AllReduce")
+    # the oracle interprets the lowered graph (single process: identity) like the py linker
+    import np_graph
+
+    for a, b in zip(np_graph.run_graph(ir, [xv]), (t, c, g)):
+        np.testing.assert_allclose(a, b, rtol=1e-13)
+    with pytest.raises(ValueError):
+        all_reduce(x, "mean")

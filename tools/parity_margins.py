@@ -2,9 +2,9 @@
 fp32 1e-5, no atol): for the device executor (on a GPU) and — always — for the reference's own
 NumPy linker against its C linker (both stored in the fixtures).  An output whose two *reference*
 backends already differ by more than the tolerance cannot be held to it; the table this prints is
-where tests/golden/tolerances.json comes from.
+where tests/tests/tolerances.json comes from.
 
-usage: python tools/parity_margins.py [--device] > margins.json
+usage: python tools/parity_margins.py [--device] [--oracle] > margins.json
 """
 import json, os, sys
 import numpy as np
@@ -44,6 +44,9 @@ def main():
     for name in golden_cases():
         g, ins, cvm, py, d = load_case(name)
         rec = {"py_vs_cvm": [margin(a, b) for a, b in zip(py, cvm)]}
+        if "--oracle" in sys.argv:
+            import np_graph
+            rec["oracle_vs_cvm"] = [margin(a, b) for a, b in zip(np_graph.run_graph(g, ins), cvm)]
         if device:
             try:
                 got = HipExecutable(g)(*ins)
