@@ -301,6 +301,20 @@ int pthip_check_status(int* status);
 /* device address of that flag, for generated (JIT) kernels that bounds-check indices */
 void* pthip_status_ptr(void);
 
+/* ---- the one data-path collective -----------------------------------------------------------
+ * north_star: "RCCL over xGMI only for the rare explicit all-reduce Op" — the Op is
+ * pytensor_amd/collective.py (the reference has no distributed layer: SURVEY.md §5 last row, §8e;
+ * closest reference interface: Op.perform of an ordinary Apply, pytensor/graph/op.py).  One process
+ * per GPU.  Rank 0 calls pthip_comm_unique_id and ships the 128 bytes to its peers over the control
+ * plane; every rank then calls pthip_comm_init.  pthip_all_reduce reduces `n` elements in place over
+ * all ranks on the context stream (stream-ordered, no device synchronisation): op 0 sum, 1 prod,
+ * 2 max, 3 min.  Without a communicator it is the identity.  librccl.so is loaded on first use. */
+int pthip_comm_unique_id(void* id128);
+int pthip_comm_init(int nranks, int rank, const void* id128);
+int pthip_comm_size(int* nranks, int* rank);
+int pthip_comm_destroy(void);
+int pthip_all_reduce(int dtype, int op, int64_t n, void* buf);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,7 +34,7 @@ class AllReduce(Op):
     def perform(self, node, inputs, output_storage):
         output_storage[0][0] = comm.all_reduce_host(inputs[0], self.op)
 
-    def infer_shape(self, fgraph, node, input_shapes):
+    def infer_shape(self, node, input_shapes):
         return [input_shapes[0]]
 
     def L_op(self, inputs, outputs, output_grads):

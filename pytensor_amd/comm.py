@@ -5,10 +5,12 @@ distributed layer (SURVEY.md §5 last row, §8e): independent ``Function`` calls
 replicas (``replicas.py``) and never communicate; a user who wants, say, the sum of per-shard
 log-likelihoods inserts ``pytensor_amd.collective.all_reduce`` into the graph.
 
-One process per GPU, ``torch.distributed`` as the transport: backend ``"nccl"`` IS RCCL on ROCm —
-the reduction runs on the device buffer itself over xGMI (ring per link, 7 links x ~153 GB/s per
-GPU); with ``gloo`` (CPU tests, ranks sharing one GPU) the value is staged through the host.
-World size 1 is the identity.  The result is bit-identical on every rank (RCCL/gloo reduce in a
+One process per GPU.  Device values are reduced by RCCL itself, called through the C-ABI
+(``pthip_all_reduce``, csrc/comm.hip) on the executor's own stream: over xGMI (ring per link, 7 links
+x ~153 GB/s per GPU), no torch tensors, no host staging.  ``torch.distributed`` is only the control
+plane (rendezvous, the broadcast of RCCL's 128-byte unique id, host-side values); with ranks sharing
+one GPU (which RCCL refuses) or on CPU the value goes through the host over gloo.  World size 1 is
+the identity.  The result is bit-identical on every rank (RCCL/gloo reduce in a
 fixed rank order), so replicated downstream computations stay in lock step.
 """
 
@@ -62,21 +64,72 @@ def all_reduce_host(a: np.ndarray, op: str = "sum") -> np.ndarray:
     return (out != 0) if was_bool else out.astype(a.dtype, copy=False).reshape(a.shape)
 
 
-class _Aliased:
-    """A device range exposed through ``__cuda_array_interface__`` so that torch (and through it
-    RCCL) operates on the executor's own HBM buffer — no copy, no torch allocator."""
-
-    def __init__(self, ptr: int, shape, dtype):
-        self.__cuda_array_interface__ = {
-            "shape": tuple(int(s) for s in shape), "typestr": np.dtype(dtype).str, "data": (int(ptr), False),
-            "version": 2, "strides": None,
-        }
+_OP_CODE = {"sum": 0, "prod": 1, "max": 2, "min": 3}
+_rccl_ready = False
 
 
-def all_reduce_device(x, op: str = "sum", device_index: int = 0):
-    """``x``: contiguous ``DeviceArray``.  Returns a fresh ``DeviceArray`` holding the reduction.
-    RCCL reduces in place on a private copy; both streams are drained around the collective
-    (the executor's stream is not torch's): a rare, explicit synchronisation point."""
+def _local_ranks_share_a_device() -> bool:
+    import os
+
+    from pytensor_amd import ffi
+
+    lws = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    return lws > max(ffi.device_count(), 1)
+
+
+def transport() -> str:
+    """``"rccl"`` (device buffers reduced over xGMI on the executor's stream) or ``"gloo"`` (staged
+    through the host: CPU tests, several ranks sharing one GPU — RCCL refuses that).
+    ``PTHIP_COMM=rccl|gloo`` overrides the choice."""
+    import os
+
+    forced = os.environ.get("PTHIP_COMM", "auto").lower()
+    if forced in ("rccl", "gloo"):
+        return forced
+    return "gloo" if _local_ranks_share_a_device() else "rccl"
+
+
+def _ensure_rccl(dist):
+    """One RCCL communicator per process: rank 0 draws the unique id (C-ABI ``pthip_comm_unique_id``),
+    the control plane (whatever backend ``torch.distributed`` runs on) broadcasts its 128 bytes,
+    every rank joins (``pthip_comm_init``)."""
+    global _rccl_ready
+    if _rccl_ready:
+        return
+    import ctypes as C
+
+    import torch
+
+    from pytensor_amd import ffi
+
+    lib = ffi.lib()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ident = (C.c_ubyte * 128)()
+    if rank == 0:
+        ffi.check(lib.pthip_comm_unique_id(ident))
+    t = torch.tensor(list(ident), dtype=torch.uint8)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.broadcast(t, src=0)
+    ident = (C.c_ubyte * 128)(*t.cpu().tolist())
+    ffi.check(lib.pthip_comm_init(world, rank, ident))
+    _rccl_ready = True
+
+
+def shutdown():
+    """Destroy the RCCL communicator (before ``torch.distributed.destroy_process_group``)."""
+    global _rccl_ready
+    if _rccl_ready:
+        from pytensor_amd import ffi
+
+        ffi.check(ffi.lib().pthip_comm_destroy())
+        _rccl_ready = False
+
+
+def all_reduce_device(x, op: str = "sum"):
+    """``x``: ``DeviceArray``.  Returns a fresh contiguous ``DeviceArray`` holding the reduction
+    over all ranks.  RCCL path: ``ncclAllReduce`` in place on a private copy, enqueued on the
+    executor's own stream (csrc/comm.hip) — stream-ordered, no synchronisation, no host copy."""
     from pytensor_amd import ffi
     from pytensor_amd.device import DeviceArray, copy_into
 
@@ -88,17 +141,12 @@ def all_reduce_device(x, op: str = "sum", device_index: int = 0):
     if dist is None or out.size == 0:
         return out
     lib = ffi.lib()
-    ffi.check(lib.pthip_synchronize())
-    if dist.get_backend() != "nccl":
-        host = all_reduce_host(out.to_host(), op)
-        ffi.check(lib.pthip_h2d(out.ptr, host.ctypes.data, host.nbytes))
-        ffi.check(lib.pthip_synchronize())
+    if transport() == "rccl":
+        _ensure_rccl(dist)
+        ffi.check(lib.pthip_all_reduce(ffi.np_dtype_code(out.dtype), _OP_CODE[op], out.size, out.ptr))
         return out
-    import torch
-
-    if str(out.dtype) not in _TORCH_DTYPES or str(out.dtype) == "bool":
-        raise TypeError(f"all_reduce: dtype {out.dtype} has no RCCL collective")
-    t = torch.as_tensor(_Aliased(out.ptr, (out.size,), out.dtype), device=torch.device("cuda", device_index))
-    dist.all_reduce(t, op=_reduce_op(dist, op))
-    torch.cuda.synchronize(device_index)
+    ffi.check(lib.pthip_synchronize())
+    host = all_reduce_host(out.to_host(), op)
+    ffi.check(lib.pthip_h2d(out.ptr, host.ctypes.data, host.nbytes))
+    ffi.check(lib.pthip_synchronize())
     return out

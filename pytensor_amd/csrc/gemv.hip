@@ -298,11 +298,24 @@ int gemv_typed(long long M, long long N, double alpha_d, const void* Av, long lo
   if (N == 0 || sA1 == 1 || (sA0 != 1 && N == 1)) {
     if (sA1 != 1 && N > 1) return pthip::set_error("gemv: internal layout error");
     const bool vec = (N % VN == 0) && (sA0 % VN == 0) && (((uintptr_t)A) % 16 == 0);
-    const bool xlds = (size_t)N * sizeof(T) <= 64 * 1024;
+    // tuning knobs for A/B runs (tools/bench_gemv.py): PTHIP_GEMV_XLDS=0 reads x through L1/L2
+    // instead of staging it in LDS, PTHIP_GEMV_ROWS=1|2|4 fixes the rows in flight per wave
+    static const int knob_xlds = getenv("PTHIP_GEMV_XLDS") ? atoi(getenv("PTHIP_GEMV_XLDS")) : -1;
+    static const int knob_rows = getenv("PTHIP_GEMV_ROWS") ? atoi(getenv("PTHIP_GEMV_ROWS")) : 0;
+    // x in LDS only while staging it is cheap next to the rows a workgroup streams (x <= 4 KB:
+    // the tall-skinny case, +2.6 % at 1e6 x 128); a longer x costs every workgroup a 32 KB copy and
+    // a barrier before its first matrix load — read through L1/L2 instead (the matrix loads are
+    // non-temporal and leave it cached): 4096^2 f64 24.0 -> 22.2 us, 8192^2 f32 54.1 -> 45.2 us
+    // (profiles/r2k_gemv_sweep.txt)
+    bool xlds = (size_t)N * sizeof(T) <= 64 * 1024;
+    const bool x_direct_ok = sx == 1 && ((uintptr_t)x) % 16 == 0;
+    if (x_direct_ok && (size_t)N * sizeof(T) > 4 * 1024 && knob_xlds != 1) xlds = false;
+    if (knob_xlds == 0 && x_direct_ok) xlds = false;
     const bool vec_ok = vec && (xlds || (sx == 1 && ((uintptr_t)x) % 16 == 0));
     // plenty of rows: 4 rows in flight per wave; short-and-wide (e.g. 4096 x 4096): one row
     // per wave so that >= 2048 workgroups exist to fill 256 CUs
-    const int rows = (M / (4 * WAVES) >= (long long)pthip::kNumCU * 4) ? 4 : 1;
+    int rows = (M / (4 * WAVES) >= (long long)pthip::kNumCU * 4) ? 4 : 1;
+    if (knob_rows == 1 || knob_rows == 2 || knob_rows == 4) rows = knob_rows;
     long long waves = (M + rows - 1) / rows;
     long long blocks = (waves + WAVES - 1) / WAVES;
     long long cap = (long long)pthip::kNumCU * 8;
@@ -312,6 +325,9 @@ int gemv_typed(long long M, long long N, double alpha_d, const void* Av, long lo
   do {                                                                                            \
     if (rows == 4)                                                                                \
       hipLaunchKernelGGL((gemv_row_kernel<T, V, X, 4>), dim3((unsigned)blocks), dim3(BLOCK),      \
+                         shmem, st, out, A, x, y, M, N, sA0, sx, sy, alpha, beta);                \
+    else if (rows == 2)                                                                           \
+      hipLaunchKernelGGL((gemv_row_kernel<T, V, X, 2>), dim3((unsigned)blocks), dim3(BLOCK),      \
                          shmem, st, out, A, x, y, M, N, sA0, sx, sy, alpha, beta);                \
     else                                                                                          \
       hipLaunchKernelGGL((gemv_row_kernel<T, V, X, 1>), dim3((unsigned)blocks), dim3(BLOCK),      \

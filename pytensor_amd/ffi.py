@@ -122,6 +122,11 @@ SIGNATURES = {
     "pthip_cumulative": (_int, [_int, _int, _i64, _i64, _i64, _vp, _vp]),
     "pthip_imatmul": (_int, [_int, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp]),
     "pthip_argmax": (_int, [_int, _i64, _i64, _vp, _vp]),
+    "pthip_comm_unique_id": (_int, [_vp]),
+    "pthip_comm_init": (_int, [_int, _int, _vp]),
+    "pthip_comm_size": (_int, [C.POINTER(_int), C.POINTER(_int)]),
+    "pthip_comm_destroy": (_int, []),
+    "pthip_all_reduce": (_int, [_int, _int, _i64, _vp]),
     "pthip_check_status": (_int, [C.POINTER(_int)]),
     "pthip_status_ptr": (_vp, []),
 }

@@ -1,7 +1,7 @@
 """GPU: the explicit all-reduce node through the HIP executor (north_star: "RCCL over xGMI only
 for the rare explicit all-reduce Op").  One GPU is what the test box has: world size 1 (identity)
-and two ranks sharing GPU 0 over gloo; the 8-GPU RCCL path is the same ``comm.all_reduce_device``
-with ``backend == "nccl"`` operating on the aliased device buffer."""
+two ranks sharing GPU 0 (host staging over gloo: RCCL refuses two ranks on one device), and the
+RCCL leg itself with a communicator of one rank — the 8-GPU path is that same ``pthip_all_reduce``."""
 import json
 import os
 import subprocess
@@ -57,7 +57,7 @@ def test_single_rank_is_identity_and_stays_eager(hip, op):
 
 
 def test_two_ranks_on_one_gpu_gloo(hip, tmp_path):
-    env = dict(os.environ, DIST_OUT=str(tmp_path), OMP_NUM_THREADS="1")
+    env = dict(os.environ, DIST_OUT=str(tmp_path), OMP_NUM_THREADS="1", PTHIP_COMM="gloo")
     cmd = [
         sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
         "--master-addr", "127.0.0.1", "--master-port", "29583",
@@ -74,3 +74,33 @@ def test_two_ranks_on_one_gpu_gloo(hip, tmp_path):
     assert a["reduced"] == b["reduced"] and a["tanh"] == b["tanh"]
     np.testing.assert_array_equal(np.array(a["reduced"]), np.array(a["local"]) + np.array(b["local"]))
     np.testing.assert_allclose(a["tanh"], np.tanh(a["reduced"]), rtol=1e-12)
+
+
+def test_rccl_single_rank_communicator_through_the_c_abi(hip):
+    """The RCCL leg itself on the one GPU the box has: unique id -> communicator of one rank ->
+    ``pthip_all_reduce`` on the executor's stream (identity for one rank) -> destroy.  Loads
+    librccl.so through the C-ABI exactly as the 8-GPU path does."""
+    import ctypes as C
+
+    from pytensor_amd.device import DeviceArray
+
+    lib = hip.lib()
+    ident = (C.c_ubyte * 128)()
+    hip.check(lib.pthip_comm_unique_id(ident))
+    assert any(ident)
+    hip.check(lib.pthip_comm_init(1, 0, ident))
+    try:
+        n, r = C.c_int(-1), C.c_int(-1)
+        hip.check(lib.pthip_comm_size(C.byref(n), C.byref(r)))
+        assert (n.value, r.value) == (1, 0)
+        for dt, code in (("float64", hip.np_dtype_code("float64")), ("float32", hip.np_dtype_code("float32")), ("int64", hip.np_dtype_code("int64"))):
+            x = (np.arange(5000) % 97 - 40).astype(dt)
+            d = DeviceArray.empty(x.shape, dt)
+            hip.check(lib.pthip_h2d(d.ptr, x.ctypes.data, x.nbytes))
+            for op in range(4):
+                hip.check(lib.pthip_all_reduce(code, op, d.size, d.ptr))
+            np.testing.assert_array_equal(d.to_host(), x)
+        assert lib.pthip_all_reduce(hip.np_dtype_code("int16"), 0, 4, d.ptr) != 0  # no RCCL type
+        assert lib.pthip_comm_init(1, 0, ident) != 0  # one communicator per process
+    finally:
+        hip.check(lib.pthip_comm_destroy())
