@@ -301,6 +301,17 @@ int pthip_check_status(int* status);
 /* device address of that flag, for generated (JIT) kernels that bounds-check indices */
 void* pthip_status_ptr(void);
 
+/* out[b] (n x n contiguous) = the symmetric matrix defined by the lower (or upper) triangle of A[b]:
+ * the operand convention of scipy.linalg.eigh(a, b, lower=...) (Eigh.perform, eigen.py:177-186),
+ * used by the device reduction of the generalised problem to a standard one. */
+int pthip_symmetrize(int dtype, int64_t batch, int64_t n, int lower, const void* A, void* out);
+/* LUFactor (pytensor/tensor/linalg/decomposition/lu.py:239-300: scipy getrf -> (LU, pivots), LU
+ * NaN-filled when a pivot is exactly zero) = pthip_getrf + this finish: the 0-based LAPACK
+ * interchange vector piv[batch][n] (int32) from the row order perm[batch][n] (int64), and the NaN
+ * fill.  PivotToPermutations (lu.py:206-231): out[batch][n] (int64) from pivots (int32/int64). */
+int pthip_lu_factor_finish(int dtype, int64_t batch, int64_t n, void* LU, const void* perm, void* piv);
+int pthip_pivots_to_perm(int itemsize, int inverse, int64_t batch, int64_t n, const void* piv, void* out);
+
 /* ---- the one data-path collective -----------------------------------------------------------
  * north_star: "RCCL over xGMI only for the rare explicit all-reduce Op" — the Op is
  * pytensor_amd/collective.py (the reference has no distributed layer: SURVEY.md §5 last row, §8e;

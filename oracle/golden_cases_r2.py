@@ -173,3 +173,62 @@ def indexing_nd():
         "jv": np.array([5, 0, 5, 2, 1]), "y": rng.normal(size=(8, 7)),
     }
     return [x, t3, t4, I, J, iv, jv, y], outs, vals
+
+
+@case("lu_reuse")
+def lu_reuse():
+    # rewriting/linalg/solvers.py:615-632 (reuse_decomposition_multiple_solves): several Solve nodes
+    # against one matrix (and its transpose) factor it ONCE — LUFactor + PivotToPermutations +
+    # SolveTriangular pairs; tests/tensor/linalg/test_rewriting (test_lu_decomposition_reused_*).
+    # A batched matrix goes through Blockwise(LUFactor); a singular one NaN-fills (perform, lu.py:293).
+    rng = np.random.default_rng(71)
+    A, b1, B2 = pt.dmatrix("A"), pt.dvector("b1"), pt.dmatrix("B2")
+    A3, b3 = pt.dtensor3("A3"), pt.dmatrix("b3")
+    S = pt.dmatrix("S")
+    from pytensor.tensor.linalg.decomposition.lu import lu_factor, pivot_to_permutation
+
+    LU, piv = lu_factor(A)
+    outs = [
+        pt.linalg.solve(A, b1), pt.linalg.solve(A, B2), pt.linalg.solve(A.T, b1),
+        LU, piv, pivot_to_permutation(piv, inverse=False), pivot_to_permutation(piv, inverse=True),
+        pt.linalg.solve(A3, b3[None, :, :] * 1.0)[:, :, 0], pt.linalg.solve(A3, b3[None, :, :] * 2.0)[:, :, 1],
+        lu_factor(S)[0],
+    ]
+    n = 23
+    Sv = rng.normal(size=(6, 6))
+    Sv[:, 3] = 0.0  # exactly singular: a zero pivot
+    vals = {"A": rng.normal(size=(n, n)) + 0.5 * np.eye(n), "b1": rng.normal(size=n), "B2": rng.normal(size=(n, 4)),
+            "A3": rng.normal(size=(3, 9, 9)) + 2 * np.eye(9), "b3": rng.normal(size=(9, 2)), "S": Sv}
+    return [A, b1, B2, A3, b3, S], outs, vals
+
+
+@case("solve_sym_eigh_generalised")
+def solve_sym_eigh_generalised():
+    # linalg/solvers/general.py:17 Solve(assume_a="sym") — scipy sysv reads ONE triangle of A;
+    # linalg/decomposition/eigen.py:177-186 Eigh(a, b): the generalised problem A v = w B v
+    # (scipy.linalg.eigh(a, b=b, lower=)).  Eigenvector signs are arbitrary: sign-free outputs.
+    rng = np.random.default_rng(72)
+    A, Bm, b = pt.dmatrix("A"), pt.dmatrix("B"), pt.dvector("b")
+    R = pt.dmatrix("R")
+    from pytensor.tensor.linalg.decomposition.eigen import Eigh
+
+    w, v = Eigh(lower=True)(A, Bm)
+    wu, vu = Eigh(lower=False)(A, Bm)
+    outs = [
+        pt.linalg.solve(A, b, assume_a="sym"), pt.linalg.solve(A, R, assume_a="sym", lower=True),
+        w, pt.abs(v), (v * pt.exp(-w)[None, :]) @ v.T, wu, pt.abs(vu),
+    ]
+    n = 19
+
+    def sym():
+        M = rng.normal(size=(n, n))
+        return M + M.T + np.diag(np.linspace(3.0, 9.0, n))  # symmetric, indefinite-ish, well conditioned
+
+    def spd():
+        Q = rng.normal(size=(n, n))
+        return Q @ Q.T / n + np.eye(n)
+
+    # the two triangles hold DIFFERENT symmetric problems: `lower` decides which one is solved
+    Av = np.triu(sym()) + np.tril(sym(), -1)
+    Bv = np.triu(spd()) + np.tril(spd(), -1)
+    return [A, Bm, b, R], outs, {"A": Av, "B": Bv, "b": rng.normal(size=n), "R": rng.normal(size=(n, 3))}

@@ -992,7 +992,10 @@ def _random_variable(p, inputs, node, graph):
 @op("Eigh")
 def _eigh(p, inputs, node, graph):
     # pytensor/tensor/linalg/decomposition/eigen.py:177-195 (Eigh.perform, standard problem)
-    w, v = scipy.linalg.eigh(inputs[0], lower=p["lower"])
+    if len(inputs) == 2:  # generalised problem A v = w B v (perform 179-186)
+        w, v = scipy.linalg.eigh(inputs[0], b=inputs[1], lower=p["lower"])
+    else:
+        w, v = scipy.linalg.eigh(inputs[0], lower=p["lower"])
     return [w, v]
 
 
@@ -1047,6 +1050,40 @@ def _dot_epilogue(p, inputs, node, graph):
     outs = eval_scalar_body(p["scalar"], body_in)
     shape = np.broadcast(*body_in).shape
     return [np.array(np.broadcast_to(o, shape), dtype=graph.vars[vid].dtype, order="C") for o, vid in zip(outs, node.outputs)]
+
+
+@op("LUFactor")
+def _lu_factor(p, inputs, node, graph):
+    # pytensor/tensor/linalg/decomposition/lu.py:279-299 (LUFactor.perform): scipy getrf; a zero
+    # pivot (info != 0) NaN-fills the factors.  Leading dims are a batch (Blockwise).
+    import scipy.linalg
+
+    (A,) = inputs
+    n = A.shape[-1]
+    LU = np.empty_like(A)
+    piv = np.empty(A.shape[:-1], dtype=np.int32)
+    if A.size:
+        (getrf,) = scipy.linalg.get_lapack_funcs(("getrf",), (A,))
+        for idx in np.ndindex(A.shape[:-2]):
+            lu, pv, info = getrf(A[idx])
+            if info != 0:
+                lu[...] = np.nan
+            LU[idx], piv[idx] = lu, pv
+    return [LU, piv]
+
+
+@op("PivotToPermutations")
+def _pivot_to_permutations(p, inputs, node, graph):
+    # lu.py:220-231 (PivotToPermutations.perform)
+    (pivots,) = inputs
+    out = np.empty(pivots.shape, dtype=np.int64)
+    for idx in np.ndindex(pivots.shape[:-1]):
+        pv = pivots[idx]
+        p_inv = np.arange(len(pv), dtype="int64")
+        for i in range(len(pv)):
+            p_inv[i], p_inv[pv[i]] = p_inv[pv[i]], p_inv[i]
+        out[idx] = p_inv if p["inverse"] else np.argsort(p_inv)
+    return [out]
 
 
 @op("AllReduce")

@@ -197,6 +197,38 @@ int eigh_typed(long long batch, long long n, int lower, const void* A, void* W, 
 
 }  // namespace
 
+// out = the symmetric matrix whose `lower` (or upper) triangle is A's: what LAPACK's sy* routines
+// read.  The generalised problem A v = w B v (Eigh with two inputs, eigen.py:177-186) is reduced on
+// the full matrices (Cholesky of B, two triangular solves), so the unread triangle must not leak in.
+namespace {
+template <class T>
+__global__ __launch_bounds__(256) void symmetrize_kernel(T* __restrict__ out, const T* __restrict__ A, long long n,
+                                                         long long total, int lower) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long b = e / (n * n), r = e - b * n * n;
+    const long long i = r / n, j = r - i * n;
+    const bool take = lower ? (i >= j) : (i <= j);
+    out[e] = take ? A[e] : A[b * n * n + j * n + i];
+  }
+}
+}  // namespace
+
+extern "C" int pthip_symmetrize(int dtype, int64_t batch, int64_t n, int lower, const void* A, void* out) {
+  PTHIP_REQUIRE_INIT();
+  const long long total = (long long)batch * n * n;
+  if (total == 0) return 0;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipStream_t st = pthip::ctx().stream;
+  if (dtype == PTHIP_F64)
+    hipLaunchKernelGGL((symmetrize_kernel<double>), dim3((unsigned)blocks), dim3(256), 0, st, (double*)out, (const double*)A, (long long)n, total, lower);
+  else if (dtype == PTHIP_F32)
+    hipLaunchKernelGGL((symmetrize_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, (float*)out, (const float*)A, (long long)n, total, lower);
+  else
+    return pthip::set_error("pthip_symmetrize: dtype %d not supported (float32/float64 only)", dtype);
+  return pthip::post_launch("symmetrize");
+}
+
 extern "C" int pthip_eigh(int dtype, int64_t batch, int64_t n, int lower, const void* A, void* W, void* V) {
   PTHIP_REQUIRE_INIT();
   if (dtype == PTHIP_F64) return eigh_typed<double>(batch, n, lower, A, W, V);

@@ -369,6 +369,101 @@ extern "C" int pthip_permuted_identity(int dtype, int64_t n, const void* perm, v
   return pthip::post_launch("permuted_identity");
 }
 
+// ---- LAPACK's pivot vector from the row order, and back ------------------------------------------
+// getrf above returns the row ORDER (LU rows = A[perm]); scipy's getrf — what LUFactor.perform
+// returns (linalg/decomposition/lu.py:239-300) — reports the interchanges: row i was swapped with
+// row piv[i] (0-based).  One thread replays the swaps (n sequential steps on <= a few hundred
+// rows); the workgroup NaN-fills a factor with an exactly zero pivot (perform: `info != 0`).
+namespace {
+template <class T>
+__global__ __launch_bounds__(256) void lu_factor_finish_kernel(T* __restrict__ LU, const long long* __restrict__ perm,
+                                                               int* __restrict__ piv, int n) {
+  extern __shared__ int sm_[];  // cur[n]: original row at each position, inv[n]: position of each row
+  __shared__ int singular;
+  const long long b = blockIdx.x;
+  T* lu = LU + b * (long long)n * n;
+  perm += b * n;
+  piv += b * n;
+  int* cur = sm_;
+  int* inv = sm_ + n;
+  if (threadIdx.x == 0) singular = 0;
+  for (int i = threadIdx.x; i < n; i += 256) { cur[i] = i; inv[i] = i; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256)
+    if (lu[(long long)i * n + i] == T(0)) singular = 1;
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < n; i++) {
+      const int r = (int)perm[i], j = inv[r], ri = cur[i];
+      piv[i] = j;
+      cur[i] = r; cur[j] = ri;
+      inv[r] = i; inv[ri] = j;
+    }
+  }
+  __syncthreads();
+  if (singular) {
+    const T nan = T(NAN);
+    for (long long i = threadIdx.x; i < (long long)n * n; i += 256) lu[i] = nan;
+  }
+}
+
+// PivotToPermutations.perform (lu.py:206-231): p = arange(n); for i: swap(p[i], p[piv[i]]);
+// inverse -> p, else argsort(p) (p is a permutation: its inverse).
+template <class I>
+__global__ __launch_bounds__(256) void pivots_to_perm_kernel(const I* __restrict__ piv, long long* __restrict__ out,
+                                                             int n, int inverse, int* status) {
+  extern __shared__ int sm_[];
+  const long long b = blockIdx.x;
+  piv += b * n;
+  out += b * n;
+  int* p = sm_;
+  for (int i = threadIdx.x; i < n; i += 256) p[i] = i;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < n; i++) {
+      long long j = (long long)piv[i];
+      if (j < 0 || j >= n) { atomicOr(status, 1); j = i; }  // IndexError, like the NumPy loop
+      const int t = p[i]; p[i] = p[j]; p[j] = t;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    if (inverse) out[i] = p[i];
+    else out[p[i]] = i;
+  }
+}
+}  // namespace
+
+extern "C" int pthip_lu_factor_finish(int dtype, int64_t batch, int64_t n, void* LU, const void* perm, void* piv) {
+  PTHIP_REQUIRE_INIT();
+  if (n == 0 || batch == 0) return 0;
+  if (n > 8000) return pthip::set_error("pthip_lu_factor_finish: n = %lld exceeds the LDS bookkeeping", (long long)n);
+  hipStream_t st = pthip::ctx().stream;
+  const size_t sh = (size_t)n * 2 * sizeof(int);
+  if (dtype == PTHIP_F64)
+    hipLaunchKernelGGL((lu_factor_finish_kernel<double>), dim3((unsigned)batch), dim3(256), sh, st, (double*)LU, (const long long*)perm, (int*)piv, (int)n);
+  else if (dtype == PTHIP_F32)
+    hipLaunchKernelGGL((lu_factor_finish_kernel<float>), dim3((unsigned)batch), dim3(256), sh, st, (float*)LU, (const long long*)perm, (int*)piv, (int)n);
+  else
+    return pthip::set_error("pthip_lu_factor_finish: dtype %d not supported (float32/float64 only)", dtype);
+  return pthip::post_launch("lu_factor_finish");
+}
+
+extern "C" int pthip_pivots_to_perm(int itemsize, int inverse, int64_t batch, int64_t n, const void* piv, void* out) {
+  PTHIP_REQUIRE_INIT();
+  if (n == 0 || batch == 0) return 0;
+  if (n > 16000) return pthip::set_error("pthip_pivots_to_perm: n = %lld exceeds the LDS bookkeeping", (long long)n);
+  hipStream_t st = pthip::ctx().stream;
+  int* status = (int*)pthip_status_ptr();
+  const size_t sh = (size_t)n * sizeof(int);
+  if (itemsize == 4)
+    hipLaunchKernelGGL((pivots_to_perm_kernel<int>), dim3((unsigned)batch), dim3(256), sh, st, (const int*)piv, (long long*)out, (int)n, inverse, status);
+  else if (itemsize == 8)
+    hipLaunchKernelGGL((pivots_to_perm_kernel<long long>), dim3((unsigned)batch), dim3(256), sh, st, (const long long*)piv, (long long*)out, (int)n, inverse, status);
+  else
+    return pthip::set_error("pthip_pivots_to_perm: pivots must be int32 or int64");
+  return pthip::post_launch("pivots_to_perm");
+}
+
 extern "C" int pthip_getrf(int dtype, int64_t batch, int64_t n, const void* A, void* LU, void* perm,
                            void* sign, void* logabsdet, int flag_singular) {
   PTHIP_REQUIRE_INIT();

@@ -156,8 +156,60 @@ def blockwise(node, inputs, env):
             return [lu._solve(env, cp, ins[0], ins[1])]
         fake = type("_N", (), {"params": cp})
         return (lu.det if p["core_op"] == "Det" else lu.slogdet)(fake, ins, env)
+    if p["core_op"] == "LUFactor":
+        from pytensor_amd.dispatch import lu
+
+        return list(lu.lu_factor_device(env, ins[0]))
+    if p["core_op"] == "PivotToPermutations":
+        from pytensor_amd.dispatch import lu
+
+        return lu.pivot_to_permutations(type("_N", (), {"params": cp}), ins, env)
     if p["core_op"] == "Eigh":
         from pytensor_amd.dispatch import lu
 
         return lu.eigh(type("_N", (), {"params": cp}), ins, env)
-    raise NotImplementedError(f"Blockwise({p['core_op']})")
+    return _blockwise_loop(node, ins, env)
+
+
+def _blockwise_loop(node, ins, env):
+    """Any other core op with a device handler: loop the broadcast batch on the host, one core
+    call per item on views of the operands (``Blockwise.perform``, pytensor/tensor/blockwise.py:
+    542: gufunc semantics).  What ``vectorize`` makes of small helper ops — the row gather
+    ``b[perm]`` and the pivot bookkeeping of a batched ``lu_solve`` — not a hot path."""
+    from pytensor_amd.device import copy_into
+    from pytensor_amd.dispatch import HANDLERS
+
+    p = node.params
+    core = HANDLERS.get(p["core_op"])
+    if core is None:
+        raise NotImplementedError(f"Blockwise({p['core_op']})")
+    sig_in = p["signature"].split("->")[0]
+    core_ndims = [t.count(",") + 1 if t.strip("()") else 0 for t in sig_in.split("),(")]
+    if len(core_ndims) != len(ins):
+        raise NotImplementedError(f"Blockwise({p['core_op']}): signature {p['signature']!r} does not match {len(ins)} operands")
+    batch_shapes = [a.shape[: a.ndim - c] for a, c in zip(ins, core_ndims)]
+    bshape = tuple(np.broadcast_shapes(*batch_shapes))
+    views = []
+    for a, c in zip(ins, core_ndims):
+        lead = a.shape[: a.ndim - c]
+        pad = len(bshape) - len(lead)
+        strides = (0,) * pad + tuple(0 if (s == 1 and bshape[pad + d] != 1) else st for d, (s, st) in enumerate(zip(lead, a.strides[: len(lead)])))
+        views.append((a, strides, a.shape[a.ndim - c :], a.strides[a.ndim - c :]))
+    fake = type("_Core", (), {"params": p["core_params"], "inputs": list(node.inputs), "outputs": list(node.outputs)})
+    outs = None
+    saved = env.donated
+    env.donated = frozenset()
+    try:
+        for idx in np.ndindex(*bshape):
+            item = [a.view(cs, cst, sum(i * st for i, st in zip(idx, bst))) for a, bst, cs, cst in views]
+            rs = [env.to_device(r) for r in core(fake, item, env)]
+            if outs is None:
+                outs = [DeviceArray.empty((*bshape, *r.shape), r.dtype) for r in rs]
+            for o, r in zip(outs, rs):
+                core_shape = o.shape[len(bshape):]
+                copy_into(o.view(core_shape, o.strides[len(bshape):], sum(i * st for i, st in zip(idx, o.strides[: len(bshape)]))), r)
+    finally:
+        env.donated = saved
+    if outs is None:
+        raise NotImplementedError(f"Blockwise({p['core_op']}) over an empty batch")
+    return outs

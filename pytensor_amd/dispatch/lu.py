@@ -89,9 +89,47 @@ def _solve(env, p, A, b):
         # scipy posv reads the triangle named by `lower` (default: upper)
         c = cholesky_device(env, A, bool(p["lower"]))
         return cho_solve_device(env, c, b, bool(p["lower"]), p["b_ndim"])
-    if assume == "gen":
+    if assume in ("gen", "sym", "her"):
+        if assume != "gen":
+            # scipy sysv reads only the triangle named by `lower`
+            A = _symmetrize(env, A, bool(p["lower"]))
         return solve_general(env, A, b, p["b_ndim"])
     raise NotImplementedError(f"hip linker: Solve(assume_a={assume!r}) is not lowered (gen and pos are)")
+
+
+def lu_factor_device(env, a: DeviceArray):
+    """``LUFactor`` (linalg/decomposition/lu.py:239; perform 279-299: scipy ``getrf``): the packed
+    factors and LAPACK's 0-based interchange vector (int32); an exactly zero pivot NaN-fills LU.
+    Leading dims are a batch (``Blockwise``).  What the reference's decomposition-reuse rewrites
+    (rewriting/linalg/solvers.py:615-632) factor once for several ``Solve`` nodes."""
+    LU, perm, _, _, bshape = getrf_device(env, a)
+    nb, n = perm.shape
+    piv = DeviceArray.empty((nb, n), "int32")
+    if nb and n:
+        ffi.check(env.lib.pthip_lu_factor_finish(_dt(a), nb, n, LU.ptr, perm.ptr, piv.ptr))
+    return (LU.view((*bshape, n, n), contiguous_strides((*bshape, n, n))),
+            piv.view((*bshape, n), contiguous_strides((*bshape, n))))
+
+
+@handler("LUFactor")
+def lu_factor(node, inputs, env):
+    return list(lu_factor_device(env, env.to_device(inputs[0])))
+
+
+@handler("PivotToPermutations")
+def pivot_to_permutations(node, inputs, env):
+    """lu.py:206-231: the permutation (or its inverse) LAPACK's sequential row interchanges amount to."""
+    piv = env.to_device(inputs[0])
+    if piv.dtype.kind not in "iu" or piv.itemsize not in (4, 8):
+        raise TypeError(f"PivotToPermutations: integer pivots expected, got {piv.dtype}")
+    n = piv.shape[-1]
+    bshape = piv.shape[:-1]
+    pc = piv.contiguous()
+    nb = int(np.prod(bshape)) if bshape else 1
+    out = DeviceArray.empty(piv.shape, "int64")
+    if nb and n:
+        ffi.check(env.lib.pthip_pivots_to_perm(pc.itemsize, int(bool(node.params["inverse"])), nb, n, pc.ptr, out.ptr))
+    return [out]
 
 
 @handler("Solve")
@@ -147,6 +185,8 @@ def eigh(node, inputs, env):
     """``Eigh`` of the standard problem (linalg/decomposition/eigen.py:102; perform 177-195):
     eigenvalues ascending, eigenvectors as columns, the chosen triangle only (csrc/eigh.hip).
     Leading dims are a batch (``Blockwise``)."""
+    if len(inputs) == 2:
+        return _eigh_generalised(node, inputs, env)
     a = env.to_device(inputs[0])
     _require_float(a, "Eigh")
     n = a.shape[-1]
@@ -160,3 +200,41 @@ def eigh(node, inputs, env):
     if nb and n:
         ffi.check(env.lib.pthip_eigh(_dt(a), nb, n, int(node.params["lower"]), ab.ptr, w.ptr, v.ptr))
     return [w.view((*bshape, n), contiguous_strides((*bshape, n))), v.view((*bshape, n, n), contiguous_strides((*bshape, n, n)))]
+
+
+
+def _symmetrize(env, x: DeviceArray, lower: bool) -> DeviceArray:
+    n = x.shape[-1]
+    bshape = x.shape[:-2]
+    xb = _batchify(x, 2, bshape)
+    out = DeviceArray.empty(xb.shape, x.dtype)
+    if out.size:
+        ffi.check(env.lib.pthip_symmetrize(_dt(x), xb.shape[0], n, int(lower), xb.ptr, out.ptr))
+    return out.view((*bshape, n, n), contiguous_strides((*bshape, n, n)))
+
+
+def _eigh_generalised(node, inputs, env):
+    """``A v = w B v`` (Eigh with two inputs; perform = ``scipy.linalg.eigh(a, b, lower=)``, LAPACK
+    sygvd): the same reduction LAPACK's ``sygst`` does, out of kernels that exist — ``B = L L^T``
+    (potrf), ``C = L^-1 A L^-T`` (two multi-rhs triangular solves), the standard problem for C
+    (Jacobi), ``v = L^-T y``.  Eigenvectors come out B-orthonormal (``v^T B v = I``) like scipy's."""
+    a, b = (env.to_device(i) for i in inputs)
+    _require_float(a, "Eigh")
+    n = a.shape[-1]
+    if a.shape[-2] != n or b.shape[-2:] != (n, n):
+        raise ValueError(f"Eigh: incompatible shapes {a.shape} and {b.shape}")
+    if str(a.dtype) != str(b.dtype):
+        raise TypeError("Eigh: dtype mismatch")
+    if a.ndim != 2 or b.ndim != 2:
+        raise NotImplementedError("hip linker: batched generalised Eigh")
+    lower = bool(node.params["lower"])
+    A = _symmetrize(env, a, lower)
+    B = _symmetrize(env, b, lower)
+    L = cholesky_device(env, B, True)
+    Y = trsm_device(env, L, A, True, False, 2)  # L Y = A
+    Yt = Y.view((n, n), (Y.strides[1], Y.strides[0])).contiguous()
+    Cm = trsm_device(env, L, Yt, True, False, 2)  # L C = Y^T  ->  C = L^-1 A L^-T (symmetric)
+    fake = type("_N", (), {"params": {"lower": True}})
+    w, y = eigh(fake, [Cm], env)
+    v = trsm_device(env, L, y, True, False, 2, trans=True)  # L^T v = y
+    return [w, v]

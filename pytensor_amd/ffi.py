@@ -103,8 +103,11 @@ SIGNATURES = {
     "pthip_potrf": (_int, [_int, _int, _i64, _i64, _vp, _vp]),
     "pthip_potrf_trsv": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _vp]),
     "pthip_getrf": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _int]),
+    "pthip_lu_factor_finish": (_int, [_int, _i64, _i64, _vp, _vp, _vp]),
+    "pthip_pivots_to_perm": (_int, [_int, _int, _i64, _i64, _vp, _vp]),
     "pthip_permuted_identity": (_int, [_int, _i64, _vp, _vp]),
     "pthip_eigh": (_int, [_int, _i64, _i64, _int, _vp, _vp, _vp]),
+    "pthip_symmetrize": (_int, [_int, _i64, _i64, _int, _vp, _vp]),
     "pthip_arange": (_int, [_int, _i64, _dbl, _dbl, _i64, _i64, _vp]),
     "pthip_eye": (_int, [_int, _i64, _i64, _i64, _vp]),
     "pthip_sort": (_int, [_int, _i64, _i64, _vp, _vp, _vp]),

@@ -40,12 +40,6 @@ class HipLinker(JITLinker):
         "cxx_only",
         "inplace",
         "scan_reduce_trace_prealloc",
-        "reuse_lu_decomposition_multiple_solves",
-        "scan_split_non_sequence_lu_decomposition_solve",
-        # (current names of the two rewrites above, rewriting/linalg/solvers.py:615-632: they
-        #  split Solve into LUFactor + LUSolve nodes; Solve is lowered whole, csrc/lu.hip)
-        "reuse_decomposition_multiple_solves",
-        "scan_split_non_sequence_decomposition_and_solve",
         # Softmax / LogSoftmax stay whole and run as one kernel (csrc/softmax.hip), like the
         # JAX / PyTorch / MLX linkers that dispatch their own softmax (rewriting/ofg.py:46-62).
         # XLogY, XLog1PY, LogSumExp, LogAddExp are still inlined at specialize (ofg.py:16-17).

@@ -333,7 +333,9 @@ def _register_extra_ops():
 
     @hip_funcify.register(Solve)
     def _(op, node, ctx):
-        if op.assume_a not in ("gen", "pos"):
+        # "sym"/"her" (real dtypes: the same thing) run on the general LU — LAPACK's sysv
+        # (Bunch-Kaufman) is a different but equally backward-stable factorisation
+        if op.assume_a not in ("gen", "pos", "sym", "her"):
             return None
         return "Solve", {"assume_a": str(op.assume_a), "lower": bool(op.lower), "b_ndim": int(op.b_ndim)}
 
@@ -343,12 +345,21 @@ def _register_extra_ops():
     def _(op, node, ctx):
         return type(op).__name__, {}
 
+    from pytensor.tensor.linalg.decomposition.lu import LUFactor, PivotToPermutations
+
+    @hip_funcify.register(LUFactor)
+    def _(op, node, ctx):
+        return "LUFactor", {}
+
+    @hip_funcify.register(PivotToPermutations)
+    def _(op, node, ctx):
+        return "PivotToPermutations", {"inverse": bool(op.inverse)}
+
     from pytensor.tensor.linalg.decomposition.eigen import Eigh
 
     @hip_funcify.register(Eigh)
     def _(op, node, ctx):
-        if node is not None and len(node.inputs) != 1:
-            return None  # the generalised problem A v = w B v is not lowered
+        # one input: the standard problem; two: A v = w B v (dispatch/lu.py::_eigh_generalised)
         return "Eigh", {"lower": bool(op.lower)}
 
     # kept whole (HipLinker excludes the reference's inline_symbolic_for_fusion): one kernel
@@ -432,10 +443,12 @@ def _(op, node, ctx):
 @hip_funcify.register(Blockwise)
 def _(op, node, ctx):
     core = hip_funcify(op.core_op, None, ctx)
-    if core is None or core[0] not in ("Cholesky", "SolveTriangular", "CholeskySolve", "Solve", "Det", "SLogDet", "Eigh"):
+    # (batched kernels exist for the linalg family; any other lowered core op runs as a host loop
+    #  over the batch of single-item device calls — dispatch/linalg.py::_blockwise_loop)
+    if core is None or core[0] in ("Scan", "Blockwise", "HostPerform"):
         return None
     if core[0] == "Eigh" and len(node.inputs) != 1:
-        return None
+        return None  # (batched generalised problem: not lowered)
     name, params = core
     return "Blockwise", {"core_op": name, "core_params": params, "signature": op.signature}
 

@@ -4,7 +4,7 @@ NumPy linker against its C linker (both stored in the fixtures).  An output whos
 backends already differ by more than the tolerance cannot be held to it; the table this prints is
 where tests/tests/tolerances.json comes from.
 
-usage: python tools/parity_margins.py [--device] [--oracle] > margins.json
+usage: python tools/parity_margins.py [--device] [--oracle] [case ...] > margins.json
 """
 import json, os, sys
 import numpy as np
@@ -41,7 +41,10 @@ def main():
         from pytensor_amd.executor import HipExecutable
         ffi.init(0)
     out = {}
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]
     for name in golden_cases():
+        if only and name not in only:
+            continue
         g, ins, cvm, py, d = load_case(name)
         rec = {"py_vs_cvm": [margin(a, b) for a, b in zip(py, cvm)]}
         if "--oracle" in sys.argv:
