@@ -1016,7 +1016,7 @@ def nd_kernel_source(name: str, body: dict, ndim: int, reduce_spec=None, partial
 
 
 def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, has_y1,
-                      out_store=None, scatter_out=None) -> str:
+                      out_store=None, scatter_out=None, scatter_groups=2) -> str:
     """One-pass ``r = b1*y1 + a1*A@x ; outs = body(.., r, ..) ; partial += A.T@w`` (fp64).
 
     Work decomposition (wave64): a wave owns groups of ``RG`` consecutive rows.  Lane l
@@ -1034,7 +1034,7 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
     4. w[row] is broadcast back with ``v_readlane`` (compile-time lane) and multiplied
        into the still-resident row registers: acc[c] += row * w;
     5. optionally the scatter-add ``out[sidx[row]] += o[row]`` (gradient of a gather) is
-       accumulated in the same pass: lane b owns bins b and b+64 (<= 128 bins), rows are
+       accumulated in the same pass: lane b owns bins b, b+64, ... (``scatter_groups`` x 64 <= 256 bins), rows are
        visited in order, per-workgroup partials are combined in a fixed order afterwards
        (deterministic, like every other reduction here).
 
@@ -1087,7 +1087,9 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
     L.append("    b[c] = (col < K) ? *(const pt_d2*)(x + col) : (pt_d2){0.0, 0.0};")
     L.append("    accT[c] = (pt_d2){0.0, 0.0};\n  }")
     if scatter_out is not None:
-        L.append("  double accS0 = 0.0, accS1 = 0.0;  // bins lane and lane + 64")
+        SG = int(scatter_groups)
+        assert 1 <= SG <= 4
+        L.append("  double " + ", ".join(f"accS{q} = 0.0" for q in range(SG)) + ";  // bins lane, lane + 64, ...")
     for k, m in enumerate(e_modes):
         if m == "S":
             L.append(f"  const {CTYPE[body['in_dtypes'][k]]} s{k} = in{k}[0];")
@@ -1170,12 +1172,13 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
         sval = "wr" if scatter_out == w_out else f"pt_readlane(sv, r << {rest})"
         L.append(f"      const int ir = __builtin_amdgcn_readlane(si, r << {rest});")
         L.append(f"      const double svr = {sval};")
-        L.append("      accS0 += (ir == lane) ? svr : 0.0;")
-        L.append("      accS1 += (ir == lane + 64) ? svr : 0.0;")
+        for q in range(SG):
+            L.append(f"      accS{q} += (ir == lane + {64 * q}) ? svr : 0.0;")
     L.append("    }")
     L.append("  }")
     # block combine of accT (fixed wave order), of the scatter bins and of the reductions
-    L.append(f"  __shared__ double redT[{BLOCK // 64}][128 * C];")
+    red_w = f"(128 * C > {64 * int(scatter_groups)} ? 128 * C : {64 * int(scatter_groups)})" if scatter_out is not None else "128 * C"
+    L.append(f"  __shared__ double redT[{BLOCK // 64}][{red_w}];")
     L.append("#pragma unroll\n  for (int c = 0; c < C; c++) { redT[wid][c * 128 + 2 * lane] = accT[c].x; redT[wid][c * 128 + 2 * lane + 1] = accT[c].y; }")
     L.append("  __syncthreads();")
     L.append(f"  for (int j = threadIdx.x; j < 128 * C; j += {BLOCK}) {{")
@@ -1184,9 +1187,9 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
     L.append("    if (j < K) partT[(long long)blockIdx.x * K + j] = v;\n  }")
     if scatter_out is not None:
         L.append("  __syncthreads();")
-        L.append("  redT[wid][lane] = accS0; redT[wid][lane + 64] = accS1;")
+        L.append("  " + " ".join(f"redT[wid][lane + {64 * q}] = accS{q};" for q in range(SG)))
         L.append("  __syncthreads();")
-        L.append("  if (threadIdx.x < 128) {")
+        L.append(f"  if (threadIdx.x < {64 * SG}) {{")
         L.append("    double v = redT[0][threadIdx.x];")
         L.append(f"#pragma unroll\n    for (int q = 1; q < {BLOCK // 64}; q++) v += redT[q][threadIdx.x];")
         L.append("    if (threadIdx.x < sbins) partS[(long long)blockIdx.x * sbins + threadIdx.x] = v;\n  }")

@@ -29,7 +29,7 @@ CHAIN_RG = int(os.environ.get("PTHIP_CHAIN_RG", 0))  # 0 = auto
 # on C4 (evals/s): 448: 3252, 480: 3220, 512: 3209, 1024: 3274, 2048: 3331, 4096: 3282 —
 # a persistent grid that leaves CUs free for the overlapped latency chain does not pay.
 CHAIN_GRID = int(os.environ.get("PTHIP_CHAIN_GRID", 2048))
-MAX_SCATTER_BINS = 128
+MAX_SCATTER_BINS = 256  # 64 bins per accumulator register of a lane, up to four (codegen.gemv_chain_source)
 
 
 def _unpack(node, inputs, env):
@@ -128,7 +128,11 @@ def gemv_chain(node, inputs, env):
         f"gchain_{_body_key(body)}_{''.join(e_modes)}_{rkey}_w{w_out}_c{C}_g{RG}_{int(store_r)}{int(y1d is not None)}"
         f"_s{skey}_{'n' if scatter_out is None else scatter_out}"
     ).replace("-", "x")
-    src = codegen.gemv_chain_source(name, body, e_modes, rs, w_out, C, RG, store_r, y1d is not None, out_store, scatter_out)
+    sgroups = 2
+    if scatter_out is not None:
+        sgroups = max(1, (base.shape[0] + 63) // 64)
+        name += f"_b{sgroups}"
+    src = codegen.gemv_chain_source(name, body, e_modes, rs, w_out, C, RG, store_r, y1d is not None, out_store, scatter_out, sgroups)
     fn = kernel_cache.get_function(src, name)
     ngroups = (N + RG - 1) // RG
     grid = max(1, min((ngroups + 3) // 4, CHAIN_GRID))

@@ -113,3 +113,31 @@ def test_c3_gemm_gemv_associativity(hip):
     # spot-check rows of A@B against NumPy
     rows = [0, 1234, 4095]
     np.testing.assert_allclose(AB[rows], A[rows] @ B, rtol=1e-11, atol=1e-9)
+
+
+@pytest.mark.parametrize("G", [1, 64, 129, 200, 256, 300])
+def test_c4_group_counts_across_the_scatter_bin_limit(hip, G):
+    """The gradient of ``a[gidx]`` rides inside ``gchain`` up to 256 groups (64 bins per accumulator
+    register of a lane, up to four) and falls back to the standalone scatter kernel beyond; every
+    count agrees with the oracle and fused == unfused (r1 verdict: G = 129 silently took the
+    two-pass path)."""
+    import np_graph
+    from pytensor_amd import configs
+    from pytensor_amd.executor import HipExecutable
+
+    g, ins, cvm, py, meta = load_case("c4_hier")
+    names = meta["input_names"]
+    vals = configs.c4_inputs(N=20011, K=128, G=G)
+    inputs = [vals[k] for k in names]
+    exe = HipExecutable(g)
+    got = exe(*inputs)
+    want = np_graph.run_graph(g, inputs)
+    raw = HipExecutable(g, fuse=False)(*inputs)
+    for k, (a, b, c) in enumerate(zip(got, want, raw)):
+        scale = max(1.0, float(np.max(np.abs(b))))
+        # sums over 20011 mixed-sign terms: order-independent bound c*eps*sum|term| <~ 1e-12*scale*20
+        np.testing.assert_allclose(a, b, rtol=1e-11, atol=2e-11 * scale, err_msg=f"G={G} out{k} vs oracle")
+        np.testing.assert_allclose(a, c, rtol=1e-11, atol=2e-11 * scale, err_msg=f"G={G} out{k} fused vs unfused")
+    chain = [n for n in exe.graph.nodes if n.op == "GemvChain"]
+    assert len(chain) == 1
+    assert (chain[0].params.get("scatter_out") is not None)
