@@ -110,6 +110,22 @@ int pthip_graph_launch_on(void* graph_exec, int stream);
  * wait for the result. */
 int pthip_plan_replay(void* ga, void* gb, void* gc, void* dev_in, const void* host_in,
                       size_t in_bytes, int sync);
+/* Launch lists: the C++ launch-plan executor (the reference's analogue is the CVM's
+ * pre-resolved thunk walk, link/c/c_code/lazylinker_c.c:749).  Between pthip_record_begin and
+ * pthip_record_end every kernel launch and async copy the library issues on stream 0 is executed AND
+ * kept with its arguments resolved; pthip_list_launch repeats the sequence as direct launches on a
+ * stream.  For a few kernels this beats a hipGraph replay (no graph-launch floor, no graph-to-graph
+ * boundary behind an event wait).  A sequence that contains a host-to-device copy cannot be
+ * recorded (pthip_record_end fails, *list = NULL).  pthip_launch_count: kernel launches + async
+ * copies issued so far (used to size plan segments).  pthip_plan_replay2 = pthip_plan_replay with
+ * each segment given either as a graph (g*) or as a list (l*). */
+int pthip_record_begin(void);
+int pthip_record_end(void** list, int64_t* n_ops);
+int pthip_list_launch(void* list, int stream);
+int pthip_list_destroy(void* list);
+int64_t pthip_launch_count(void);
+int pthip_plan_replay2(void* ga, void* la, void* gb, void* lb, void* gc, void* lc, void* dev_in,
+                       const void* host_in, size_t in_bytes, int sync);
 int pthip_graph_destroy(void* graph_exec);
 
 /* ---- events (HIP events on the context stream) ---- */

@@ -5,13 +5,28 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
+#include <vector>
 
 #include "../../include/pthip.h"
 
 namespace pthip {
 
 constexpr int kMaxStreams = 4;
+
+// A recorded launch sequence (the C++ launch-plan executor of SURVEY §8f row 2, the analogue of
+// the reference's lazylinker_c.c thunk walk): every kernel launch / async copy issued while a
+// recorder is attached is kept as a closure with its arguments resolved, and replayed as DIRECT
+// launches.  For a handful of kernels that beats a hipGraph: no graph-launch floor on the host
+// (≈8 µs per hipGraphLaunch) and no graph-to-graph boundary on the device (≈14 µs behind an event
+// wait, profiles/r2n_c4_timeline.md) — a direct launch behind a stream wait starts ≈2 µs after its
+// predecessor ends.
+struct LaunchList {
+  std::vector<std::function<hipError_t(hipStream_t)>> ops;
+  bool ok = true;        // false: something was issued that a replay cannot repeat
+  std::string why;
+};
 
 struct Context {
   int device = -1;
@@ -20,6 +35,8 @@ struct Context {
   int current = 0;
   int* status_dev = nullptr;  // device-side error flag
   bool capturing = false;
+  LaunchList* recorder = nullptr;  // attached between pthip_record_begin / pthip_record_end
+  long long launch_count = 0;      // kernel launches + async copies issued so far (plan sizing)
 };
 
 Context& ctx();
@@ -58,4 +75,35 @@ inline int post_launch(const char* what) {
 
 constexpr int kNumCU = 256;  // MI355X
 
+// async copies / fills issued by the library: performed now and, while a recorder is attached,
+// kept for replay (host memory involved must outlive the list: the plan's pinned blocks do)
+inline hipError_t memcpy_async(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
+  Context& c = ctx();
+  c.launch_count++;
+  if (c.recorder)
+    c.recorder->ops.emplace_back([=](hipStream_t s) { return hipMemcpyAsync(dst, src, bytes, kind, s); });
+  return hipMemcpyAsync(dst, src, bytes, kind, st);
+}
+inline hipError_t memset_async(void* dst, int byte, size_t bytes, hipStream_t st) {
+  Context& c = ctx();
+  c.launch_count++;
+  if (c.recorder)
+    c.recorder->ops.emplace_back([=](hipStream_t s) { return hipMemsetAsync(dst, byte, bytes, s); });
+  return hipMemsetAsync(dst, byte, bytes, st);
+}
+
 }  // namespace pthip
+
+// Every kernel launch of the library goes through this macro: launch now, and — while a recorder is
+// attached — keep a closure that repeats the launch on a given stream (arguments captured by value).
+#define PTHIP_KLAUNCH(kernel, grid, block, shmem, stream, ...)                                    \
+  do {                                                                                            \
+    ::pthip::Context& pk_ctx_ = ::pthip::ctx();                                                   \
+    pk_ctx_.launch_count++;                                                                       \
+    if (pk_ctx_.recorder)                                                                         \
+      pk_ctx_.recorder->ops.emplace_back([=](hipStream_t pk_s_) -> hipError_t {                   \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, pk_s_, __VA_ARGS__);                       \
+        return hipGetLastError();                                                                 \
+      });                                                                                         \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                          \
+  } while (0)

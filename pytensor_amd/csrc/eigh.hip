@@ -187,7 +187,7 @@ int eigh_typed(long long batch, long long n, int lower, const void* A, void* W, 
   void *sa = nullptr, *sv = nullptr;
   if (!a_lds) { int r = pthip_alloc((size_t)batch * one, &sa); if (r) return r; }
   if (!v_lds) { int r = pthip_alloc((size_t)batch * one, &sv); if (r) { if (sa) pthip_free(sa); return r; } }
-  hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(BLOCK), dyn, st, (const T*)A, (T*)W, (T*)V, (int)n, lower,
+  PTHIP_KLAUNCH(k, dim3((unsigned)batch), dim3(BLOCK), dyn, st, (const T*)A, (T*)W, (T*)V, (int)n, lower,
                      a_lds ? 1 : 0, v_lds ? 1 : 0, (T*)sa, (T*)sv, (int*)pthip_status_ptr());
   int r = pthip::post_launch("eigh");
   if (sa) pthip_free(sa);  // stream-ordered reuse keeps this safe
@@ -221,9 +221,9 @@ extern "C" int pthip_symmetrize(int dtype, int64_t batch, int64_t n, int lower, 
   if (blocks > 2048) blocks = 2048;
   hipStream_t st = pthip::ctx().stream;
   if (dtype == PTHIP_F64)
-    hipLaunchKernelGGL((symmetrize_kernel<double>), dim3((unsigned)blocks), dim3(256), 0, st, (double*)out, (const double*)A, (long long)n, total, lower);
+    PTHIP_KLAUNCH((symmetrize_kernel<double>), dim3((unsigned)blocks), dim3(256), 0, st, (double*)out, (const double*)A, (long long)n, total, lower);
   else if (dtype == PTHIP_F32)
-    hipLaunchKernelGGL((symmetrize_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, (float*)out, (const float*)A, (long long)n, total, lower);
+    PTHIP_KLAUNCH((symmetrize_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, (float*)out, (const float*)A, (long long)n, total, lower);
   else
     return pthip::set_error("pthip_symmetrize: dtype %d not supported (float32/float64 only)", dtype);
   return pthip::post_launch("symmetrize");

@@ -51,16 +51,16 @@ extern "C" int pthip_arange(int dtype, int64_t n, double fstart, double fstep, i
   hipStream_t st = pthip::ctx().stream;
   const dim3 g(grid_for(n)), b(BLOCK);
   switch (dtype) {
-    case PTHIP_F64: hipLaunchKernelGGL(arange_float_kernel<double>, g, b, 0, st, (double*)out, (long long)n, fstart, fstep); break;
-    case PTHIP_F32: hipLaunchKernelGGL(arange_float_kernel<float>, g, b, 0, st, (float*)out, (long long)n, fstart, fstep); break;
-    case PTHIP_I64: hipLaunchKernelGGL(arange_int_kernel<long long>, g, b, 0, st, (long long*)out, (long long)n, (long long)istart, (long long)istep); break;
-    case PTHIP_I32: hipLaunchKernelGGL(arange_int_kernel<int>, g, b, 0, st, (int*)out, (long long)n, (long long)istart, (long long)istep); break;
-    case PTHIP_I16: hipLaunchKernelGGL(arange_int_kernel<short>, g, b, 0, st, (short*)out, (long long)n, (long long)istart, (long long)istep); break;
-    case PTHIP_I8: hipLaunchKernelGGL(arange_int_kernel<signed char>, g, b, 0, st, (signed char*)out, (long long)n, (long long)istart, (long long)istep); break;
-    case PTHIP_U8: hipLaunchKernelGGL(arange_int_kernel<unsigned char>, g, b, 0, st, (unsigned char*)out, (long long)n, (long long)istart, (long long)istep); break;
-    case PTHIP_U16: hipLaunchKernelGGL(arange_int_kernel<unsigned short>, g, b, 0, st, (unsigned short*)out, (long long)n, (long long)istart, (long long)istep); break;
-    case PTHIP_U32: hipLaunchKernelGGL(arange_int_kernel<unsigned int>, g, b, 0, st, (unsigned int*)out, (long long)n, (long long)istart, (long long)istep); break;
-    case PTHIP_U64: hipLaunchKernelGGL(arange_int_kernel<unsigned long long>, g, b, 0, st, (unsigned long long*)out, (long long)n, (long long)istart, (long long)istep); break;
+    case PTHIP_F64: PTHIP_KLAUNCH(arange_float_kernel<double>, g, b, 0, st, (double*)out, (long long)n, fstart, fstep); break;
+    case PTHIP_F32: PTHIP_KLAUNCH(arange_float_kernel<float>, g, b, 0, st, (float*)out, (long long)n, fstart, fstep); break;
+    case PTHIP_I64: PTHIP_KLAUNCH(arange_int_kernel<long long>, g, b, 0, st, (long long*)out, (long long)n, (long long)istart, (long long)istep); break;
+    case PTHIP_I32: PTHIP_KLAUNCH(arange_int_kernel<int>, g, b, 0, st, (int*)out, (long long)n, (long long)istart, (long long)istep); break;
+    case PTHIP_I16: PTHIP_KLAUNCH(arange_int_kernel<short>, g, b, 0, st, (short*)out, (long long)n, (long long)istart, (long long)istep); break;
+    case PTHIP_I8: PTHIP_KLAUNCH(arange_int_kernel<signed char>, g, b, 0, st, (signed char*)out, (long long)n, (long long)istart, (long long)istep); break;
+    case PTHIP_U8: PTHIP_KLAUNCH(arange_int_kernel<unsigned char>, g, b, 0, st, (unsigned char*)out, (long long)n, (long long)istart, (long long)istep); break;
+    case PTHIP_U16: PTHIP_KLAUNCH(arange_int_kernel<unsigned short>, g, b, 0, st, (unsigned short*)out, (long long)n, (long long)istart, (long long)istep); break;
+    case PTHIP_U32: PTHIP_KLAUNCH(arange_int_kernel<unsigned int>, g, b, 0, st, (unsigned int*)out, (long long)n, (long long)istart, (long long)istep); break;
+    case PTHIP_U64: PTHIP_KLAUNCH(arange_int_kernel<unsigned long long>, g, b, 0, st, (unsigned long long*)out, (long long)n, (long long)istart, (long long)istep); break;
     default: return pthip::set_error("pthip_arange: unsupported dtype %d", dtype);
   }
   return pthip::post_launch("arange");
@@ -72,17 +72,17 @@ extern "C" int pthip_eye(int dtype, int64_t n, int64_t m, int64_t k, void* out) 
   hipStream_t st = pthip::ctx().stream;
   const dim3 g(grid_for(n * m)), b(BLOCK);
   switch (dtype) {
-    case PTHIP_F64: hipLaunchKernelGGL(eye_kernel<double>, g, b, 0, st, (double*)out, (long long)n, (long long)m, (long long)k); break;
-    case PTHIP_F32: hipLaunchKernelGGL(eye_kernel<float>, g, b, 0, st, (float*)out, (long long)n, (long long)m, (long long)k); break;
-    case PTHIP_I64: hipLaunchKernelGGL(eye_kernel<long long>, g, b, 0, st, (long long*)out, (long long)n, (long long)m, (long long)k); break;
-    case PTHIP_I32: hipLaunchKernelGGL(eye_kernel<int>, g, b, 0, st, (int*)out, (long long)n, (long long)m, (long long)k); break;
-    case PTHIP_I16: hipLaunchKernelGGL(eye_kernel<short>, g, b, 0, st, (short*)out, (long long)n, (long long)m, (long long)k); break;
-    case PTHIP_I8: hipLaunchKernelGGL(eye_kernel<signed char>, g, b, 0, st, (signed char*)out, (long long)n, (long long)m, (long long)k); break;
-    case PTHIP_U8: case PTHIP_BOOL: hipLaunchKernelGGL(eye_kernel<unsigned char>, g, b, 0, st, (unsigned char*)out, (long long)n, (long long)m, (long long)k); break;
-    case PTHIP_U16: hipLaunchKernelGGL(eye_kernel<unsigned short>, g, b, 0, st, (unsigned short*)out, (long long)n, (long long)m, (long long)k); break;
-    case PTHIP_U32: hipLaunchKernelGGL(eye_kernel<unsigned int>, g, b, 0, st, (unsigned int*)out, (long long)n, (long long)m, (long long)k); break;
-    case PTHIP_U64: hipLaunchKernelGGL(eye_kernel<unsigned long long>, g, b, 0, st, (unsigned long long*)out, (long long)n, (long long)m, (long long)k); break;
-    case PTHIP_F16: hipLaunchKernelGGL(eye_kernel<_Float16>, g, b, 0, st, (_Float16*)out, (long long)n, (long long)m, (long long)k); break;
+    case PTHIP_F64: PTHIP_KLAUNCH(eye_kernel<double>, g, b, 0, st, (double*)out, (long long)n, (long long)m, (long long)k); break;
+    case PTHIP_F32: PTHIP_KLAUNCH(eye_kernel<float>, g, b, 0, st, (float*)out, (long long)n, (long long)m, (long long)k); break;
+    case PTHIP_I64: PTHIP_KLAUNCH(eye_kernel<long long>, g, b, 0, st, (long long*)out, (long long)n, (long long)m, (long long)k); break;
+    case PTHIP_I32: PTHIP_KLAUNCH(eye_kernel<int>, g, b, 0, st, (int*)out, (long long)n, (long long)m, (long long)k); break;
+    case PTHIP_I16: PTHIP_KLAUNCH(eye_kernel<short>, g, b, 0, st, (short*)out, (long long)n, (long long)m, (long long)k); break;
+    case PTHIP_I8: PTHIP_KLAUNCH(eye_kernel<signed char>, g, b, 0, st, (signed char*)out, (long long)n, (long long)m, (long long)k); break;
+    case PTHIP_U8: case PTHIP_BOOL: PTHIP_KLAUNCH(eye_kernel<unsigned char>, g, b, 0, st, (unsigned char*)out, (long long)n, (long long)m, (long long)k); break;
+    case PTHIP_U16: PTHIP_KLAUNCH(eye_kernel<unsigned short>, g, b, 0, st, (unsigned short*)out, (long long)n, (long long)m, (long long)k); break;
+    case PTHIP_U32: PTHIP_KLAUNCH(eye_kernel<unsigned int>, g, b, 0, st, (unsigned int*)out, (long long)n, (long long)m, (long long)k); break;
+    case PTHIP_U64: PTHIP_KLAUNCH(eye_kernel<unsigned long long>, g, b, 0, st, (unsigned long long*)out, (long long)n, (long long)m, (long long)k); break;
+    case PTHIP_F16: PTHIP_KLAUNCH(eye_kernel<_Float16>, g, b, 0, st, (_Float16*)out, (long long)n, (long long)m, (long long)k); break;
     default: return pthip::set_error("pthip_eye: unsupported dtype %d", dtype);
   }
   return pthip::post_launch("eye");

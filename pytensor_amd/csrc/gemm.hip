@@ -489,13 +489,13 @@ int launch(long long batch, long long M, long long N, long long K, T alpha, cons
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)nsplit, (unsigned)batch);
   if (partials != nullptr) {
     // nsplit == 1: the epilogue with alpha = 1, beta = 0 stores the plain product in slab 0
-    hipLaunchKernelGGL(k, grid, dim3(BLOCK), shmem, st, partials, A, B, (const T*)nullptr, M, N, K,
+    PTHIP_KLAUNCH(k, grid, dim3(BLOCK), shmem, st, partials, A, B, (const T*)nullptr, M, N, K,
                        lda, ldb, sAb, sBb, (long long)(M * N), N, 1LL, T(1), T(0), tiles_m, tiles_n,
                        vecA, vecB, kchunk);
     return pthip::post_launch("gemm(partials)");
   }
   if (nsplit == 1) {
-    hipLaunchKernelGGL(k, grid, dim3(BLOCK), shmem, st, out, A, B, C, M, N, K, lda, ldb, sAb, sBb,
+    PTHIP_KLAUNCH(k, grid, dim3(BLOCK), shmem, st, out, A, B, C, M, N, K, lda, ldb, sAb, sBb,
                        sCb, sC0, sC1, alpha, beta, tiles_m, tiles_n, vecA, vecB, kchunk);
     return pthip::post_launch("gemm");
   }
@@ -503,13 +503,13 @@ int launch(long long batch, long long M, long long N, long long K, T alpha, cons
   void* part = nullptr;
   int r = pthip_alloc((size_t)nsplit * total * sizeof(T), &part);
   if (r) return r;
-  hipLaunchKernelGGL(k, grid, dim3(BLOCK), shmem, st, (T*)part, A, B, C, M, N, K, lda, ldb, sAb, sBb,
+  PTHIP_KLAUNCH(k, grid, dim3(BLOCK), shmem, st, (T*)part, A, B, C, M, N, K, lda, ldb, sAb, sBb,
                      sCb, sC0, sC1, alpha, beta, tiles_m, tiles_n, vecA, vecB, kchunk);
   r = pthip::post_launch("gemm(split-K)");
   if (!r) {
     long long blocks = (total + BLOCK - 1) / BLOCK;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL((splitk_finish_kernel<T>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, out,
+    PTHIP_KLAUNCH((splitk_finish_kernel<T>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, out,
                        (const T*)part, C, M, N, total, (int)nsplit, sCb, sC0, sC1, alpha, beta);
     r = pthip::post_launch("gemm splitk_finish");
   }

@@ -324,13 +324,13 @@ int gemv_typed(long long M, long long N, double alpha_d, const void* Av, long lo
 #define LAUNCH(V, X)                                                                              \
   do {                                                                                            \
     if (rows == 4)                                                                                \
-      hipLaunchKernelGGL((gemv_row_kernel<T, V, X, 4>), dim3((unsigned)blocks), dim3(BLOCK),      \
+      PTHIP_KLAUNCH((gemv_row_kernel<T, V, X, 4>), dim3((unsigned)blocks), dim3(BLOCK),      \
                          shmem, st, out, A, x, y, M, N, sA0, sx, sy, alpha, beta);                \
     else if (rows == 2)                                                                           \
-      hipLaunchKernelGGL((gemv_row_kernel<T, V, X, 2>), dim3((unsigned)blocks), dim3(BLOCK),      \
+      PTHIP_KLAUNCH((gemv_row_kernel<T, V, X, 2>), dim3((unsigned)blocks), dim3(BLOCK),      \
                          shmem, st, out, A, x, y, M, N, sA0, sx, sy, alpha, beta);                \
     else                                                                                          \
-      hipLaunchKernelGGL((gemv_row_kernel<T, V, X, 1>), dim3((unsigned)blocks), dim3(BLOCK),      \
+      PTHIP_KLAUNCH((gemv_row_kernel<T, V, X, 1>), dim3((unsigned)blocks), dim3(BLOCK),      \
                          shmem, st, out, A, x, y, M, N, sA0, sx, sy, alpha, beta);                \
   } while (0)
     if (vec_ok && xlds) LAUNCH(true, true);
@@ -348,21 +348,21 @@ int gemv_typed(long long M, long long N, double alpha_d, const void* Av, long lo
                               (size_t)nparts * (size_t)M * sizeof(T));
     T* part = (T*)ws;
     if (p.vec)
-      hipLaunchKernelGGL((gemv_col_kernel<T, true>), dim3((unsigned)p.nsplit, (unsigned)p.ytiles),
+      PTHIP_KLAUNCH((gemv_col_kernel<T, true>), dim3((unsigned)p.nsplit, (unsigned)p.ytiles),
                          dim3(BLOCK), 0, st, part, A, x, M, N, sA1, sx, p.chunk);
     else
-      hipLaunchKernelGGL((gemv_col_kernel<T, false>), dim3((unsigned)p.nsplit, (unsigned)p.ytiles),
+      PTHIP_KLAUNCH((gemv_col_kernel<T, false>), dim3((unsigned)p.nsplit, (unsigned)p.ytiles),
                          dim3(BLOCK), 0, st, part, A, x, M, N, sA1, sx, p.chunk);
     int r = pthip::post_launch("gemv_col");
     if (r) return r;
-    hipLaunchKernelGGL((gemv_finish_kernel<T>), dim3((unsigned)((M + 3) / 4)),
+    PTHIP_KLAUNCH((gemv_finish_kernel<T>), dim3((unsigned)((M + 3) / 4)),
                        dim3(BLOCK), 0, st, out, part, y, M, nparts, sy, alpha, beta);
     return pthip::post_launch("gemv_finish");
   }
   long long blocks = (M + WAVES - 1) / WAVES;
   long long cap = (long long)pthip::kNumCU * 8;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL((gemv_generic_kernel<T>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, out, A,
+  PTHIP_KLAUNCH((gemv_generic_kernel<T>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, out, A,
                      x, y, M, N, sA0, sA1, sx, sy, alpha, beta);
   return pthip::post_launch("gemv_generic");
 }
@@ -399,11 +399,11 @@ int pthip_gemv_finish(int dtype, int64_t M, int64_t nparts, const void* part, do
   hipStream_t st = pthip::ctx().stream;
   if (M == 0) return 0;
   if (dtype == PTHIP_F64)
-    hipLaunchKernelGGL((gemv_finish_kernel<double>), dim3((unsigned)((M + 3) / 4)), dim3(BLOCK), 0,
+    PTHIP_KLAUNCH((gemv_finish_kernel<double>), dim3((unsigned)((M + 3) / 4)), dim3(BLOCK), 0,
                        st, (double*)out, (const double*)part, (const double*)y, (long long)M,
                        (long long)nparts, (long long)sy, alpha, beta);
   else if (dtype == PTHIP_F32)
-    hipLaunchKernelGGL((gemv_finish_kernel<float>), dim3((unsigned)((M + 3) / 4)), dim3(BLOCK), 0,
+    PTHIP_KLAUNCH((gemv_finish_kernel<float>), dim3((unsigned)((M + 3) / 4)), dim3(BLOCK), 0,
                        st, (float*)out, (const float*)part, (const float*)y, (long long)M,
                        (long long)nparts, (long long)sy, (float)alpha, (float)beta);
   else
@@ -421,12 +421,12 @@ int pthip_ger(int dtype, int64_t M, int64_t N, double alpha, const void* A, int6
   long long cap = (long long)pthip::kNumCU * 8;
   if (blocks > cap) blocks = cap;
   if (dtype == PTHIP_F64)
-    hipLaunchKernelGGL((ger_kernel<double>), dim3((unsigned)blocks), dim3(BLOCK), 0, st,
+    PTHIP_KLAUNCH((ger_kernel<double>), dim3((unsigned)blocks), dim3(BLOCK), 0, st,
                        (double*)out, (const double*)A, (const double*)x, (const double*)y,
                        (long long)M, (long long)N, (long long)sA0, (long long)sA1, (long long)sx,
                        (long long)sy, alpha);
   else if (dtype == PTHIP_F32)
-    hipLaunchKernelGGL((ger_kernel<float>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, (float*)out,
+    PTHIP_KLAUNCH((ger_kernel<float>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, (float*)out,
                        (const float*)A, (const float*)x, (const float*)y, (long long)M,
                        (long long)N, (long long)sA0, (long long)sA1, (long long)sx, (long long)sy,
                        (float)alpha);

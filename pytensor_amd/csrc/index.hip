@@ -321,12 +321,12 @@ int copy_typed(int ndim, const int64_t* shape, void* dst, const int64_t* ds, con
     sh[0] = 1; d[0] = 1; s[0] = 1; nd = 1;
   }
   if (nd == 1 && d[0] == 1 && s[0] == 1) {
-    hipError_t e = hipMemcpyAsync(dst, src, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, st);
+    hipError_t e = pthip::memcpy_async(dst, src, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return pthip::check(e, "hipMemcpyAsync(copy_strided)");
     return 0;
   }
   if (nd == 1 && d[0] == 1 && s[0] == 0) {
-    hipLaunchKernelGGL((fill_kernel<T>), dim3(grid_for(n)), dim3(BLOCK), 0, st, (T*)dst, (const T*)src, n);
+    PTHIP_KLAUNCH((fill_kernel<T>), dim3(grid_for(n)), dim3(BLOCK), 0, st, (T*)dst, (const T*)src, n);
     return pthip::post_launch("fill");
   }
   if (nd > MAXD) return pthip::set_error("pthip_copy_strided: more than %d non-mergeable dims", MAXD);
@@ -337,7 +337,7 @@ int copy_typed(int ndim, const int64_t* shape, void* dst, const int64_t* ds, con
     cd.dstr[k] = d[k];
     cd.sstr[k] = s[k];
   }
-  hipLaunchKernelGGL((copy_strided_kernel<T>), dim3(grid_for(n)), dim3(BLOCK), 0, st, (T*)dst,
+  PTHIP_KLAUNCH((copy_strided_kernel<T>), dim3(grid_for(n)), dim3(BLOCK), 0, st, (T*)dst,
                      (const T*)src, cd, n);
   return pthip::post_launch("copy_strided");
 }
@@ -367,7 +367,7 @@ int pthip_pack_b16(int itemsize, int64_t K, int64_t N, const void* B, int64_t sB
   const long long n = Kp * Np;
   if (n == 0) return 0;
 #define LAUNCH(T)                                                                                  \
-  hipLaunchKernelGGL((pack_b16_kernel<T>), dim3(grid_for(n)), dim3(BLOCK), 0, st, (T*)Bp,           \
+  PTHIP_KLAUNCH((pack_b16_kernel<T>), dim3(grid_for(n)), dim3(BLOCK), 0, st, (T*)Bp,           \
                      (const T*)B, (long long)K, (long long)N, Kp, n, (long long)sB0, (long long)sB1)
   switch (itemsize) {
     case 4: LAUNCH(unsigned int); break;
@@ -386,7 +386,7 @@ int pthip_take_rows(int itemsize, int64_t n_idx, int64_t inner, const void* x, i
   if (n == 0) return 0;
   int* status = pthip::ctx().status_dev;
 #define LAUNCH(T)                                                                                  \
-  hipLaunchKernelGGL((take_rows_kernel<T>), dim3(grid_for(n)), dim3(BLOCK), 0, st, (T*)out,        \
+  PTHIP_KLAUNCH((take_rows_kernel<T>), dim3(grid_for(n)), dim3(BLOCK), 0, st, (T*)out,        \
                      (const T*)x, (const long long*)idx, (long long)n_idx, (long long)inner,       \
                      (long long)n_rows, (long long)sx0, status)
   switch (itemsize) {
@@ -425,11 +425,11 @@ int pthip_scatter_rows(int dtype, int inc, int64_t n_idx, int64_t inner, void* o
   const int isz = pthip::dtype_size(dtype);
   const long long n = n_idx * inner;
   if (!inc) {
-    PTHIP_CHECK(hipMemsetAsync(ws, 0xff, (size_t)n_rows * 8, st));  // winner = -1
-    hipLaunchKernelGGL(scatter_winner_kernel, dim3(grid_for(n_idx)), dim3(BLOCK), 0, st,
+    PTHIP_CHECK(pthip::memset_async(ws, 0xff, (size_t)n_rows * 8, st));  // winner = -1
+    PTHIP_KLAUNCH(scatter_winner_kernel, dim3(grid_for(n_idx)), dim3(BLOCK), 0, st,
                        (long long*)ws, (const long long*)idx, (long long)n_idx, (long long)n_rows, status);
 #define LAUNCH(T)                                                                               \
-  hipLaunchKernelGGL((scatter_set_kernel<T>), dim3(grid_for(n)), dim3(BLOCK), 0, st, (T*)out,   \
+  PTHIP_KLAUNCH((scatter_set_kernel<T>), dim3(grid_for(n)), dim3(BLOCK), 0, st, (T*)out,   \
                      (const long long*)ws, (const long long*)idx, (const T*)y, (long long)n_idx, \
                      (long long)inner, (long long)n_rows, (long long)ys0)
     switch (isz) {
@@ -454,11 +454,11 @@ int pthip_scatter_rows(int dtype, int inc, int64_t n_idx, int64_t inner, void* o
     nblk = (n_idx + per_block - 1) / per_block;
 #define LAUNCH(T)                                                                                 \
   do {                                                                                            \
-    hipLaunchKernelGGL((scatter_add_scan_kernel<T>), dim3((unsigned)nblk), dim3(BLOCK), 0, st,    \
+    PTHIP_KLAUNCH((scatter_add_scan_kernel<T>), dim3((unsigned)nblk), dim3(BLOCK), 0, st,    \
                        (T*)ws, (const long long*)idx, (const T*)y, (long long)n_idx,              \
                        (long long)inner, (long long)n_rows, (long long)ys0, n_bins, nb_pad,       \
                        per_block, status);                                                        \
-    hipLaunchKernelGGL((scatter_add_finish_kernel<T>),                                            \
+    PTHIP_KLAUNCH((scatter_add_finish_kernel<T>),                                            \
                        dim3((unsigned)((n_bins + 15) / 16)), dim3(BLOCK), 0, st,                  \
                        (T*)out, (const T*)ws, n_bins, nblk * parts);                              \
   } while (0)
@@ -469,7 +469,7 @@ int pthip_scatter_rows(int dtype, int inc, int64_t n_idx, int64_t inner, void* o
     return pthip::post_launch("scatter_add_scan");
   }
 #define LAUNCH(T)                                                                                  \
-  hipLaunchKernelGGL((scatter_add_atomic_kernel<T>), dim3(grid_for(n)), dim3(BLOCK), 0, st,        \
+  PTHIP_KLAUNCH((scatter_add_atomic_kernel<T>), dim3(grid_for(n)), dim3(BLOCK), 0, st,        \
                      (T*)out, (const long long*)idx, (const T*)y, (long long)n_idx,                \
                      (long long)inner, (long long)n_rows, (long long)ys0, status)
   switch (dtype) {
@@ -501,7 +501,7 @@ int pthip_pack(int n, const void* const* srcs, const int64_t* nbytes, const int6
   long long bx = (mx / 8 + BLOCK - 1) / BLOCK;
   if (bx < 1) bx = 1;
   if (bx > 64) bx = 64;
-  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)bx, (unsigned)n), dim3(BLOCK), 0,
+  PTHIP_KLAUNCH(pack_kernel, dim3((unsigned)bx, (unsigned)n), dim3(BLOCK), 0,
                      pthip::ctx().stream, (unsigned char*)dst, d);
   return pthip::post_launch("pack");
 }

@@ -556,7 +556,7 @@ int potrf_typed(int lower, long long batch, long long n, const void* A, void* L,
     auto k = potrf_lds_kernel<T>;
     if (need > 64 * 1024)
       PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-    hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(BLOCK), need, st, (T*)L, (const T*)A, (int)n, lower,
+    PTHIP_KLAUNCH(k, dim3((unsigned)batch), dim3(BLOCK), need, st, (T*)L, (const T*)A, (int)n, lower,
                        (const T*)rhs, (T*)xout);
     return pthip::post_launch("potrf_lds");
   }
@@ -564,7 +564,7 @@ int potrf_typed(int lower, long long batch, long long n, const void* A, void* L,
   void* scratch = nullptr;
   int r = pthip_alloc((size_t)batch * n * n * sizeof(T), &scratch);
   if (r) return r;
-  hipLaunchKernelGGL((potrf_global_kernel<T>), dim3((unsigned)batch), dim3(BLOCK), 0, st, (T*)L,
+  PTHIP_KLAUNCH((potrf_global_kernel<T>), dim3((unsigned)batch), dim3(BLOCK), 0, st, (T*)L,
                      (const T*)A, (int)n, lower, (T*)scratch);
   r = pthip::post_launch("potrf_global");
   pthip_free(scratch);  // stream-ordered reuse keeps this safe
@@ -586,7 +586,7 @@ int trsm_typed(int lower, int unit, long long batch, long long n, long long nrhs
     auto k = trsv_lds_kernel<T, RPL>;                                                            \
     if (need > 64 * 1024)                                                                        \
       PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need)); \
-    hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(BLOCK), need, st, (T*)out, (const T*)Tm,   \
+    PTHIP_KLAUNCH(k, dim3((unsigned)batch), dim3(BLOCK), need, st, (T*)out, (const T*)Tm,   \
                        sTb, sT0, sT1, (const T*)B, sBb, (int)n, lower, unit);                    \
   } while (0)
       if (n <= 64) LAUNCH_TRSV(1);
@@ -602,12 +602,12 @@ int trsm_typed(int lower, int unit, long long batch, long long n, long long nrhs
       auto k = trsm_lds_kernel<T>;
       if (need > 64 * 1024)
         PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-      hipLaunchKernelGGL(k, dim3((unsigned)((nrhs + BLOCK - 1) / BLOCK), (unsigned)batch), dim3(BLOCK), need,
+      PTHIP_KLAUNCH(k, dim3((unsigned)((nrhs + BLOCK - 1) / BLOCK), (unsigned)batch), dim3(BLOCK), need,
                          st, (T*)out, (const T*)Tm, sTb, sT0, sT1, (const T*)B, sBb, (int)n, (int)nrhs, lower, unit);
       return pthip::post_launch("trsm_lds");
     }
   }
-  hipLaunchKernelGGL((trsm_kernel<T>), dim3((unsigned)((nrhs + BLOCK - 1) / BLOCK), (unsigned)batch),
+  PTHIP_KLAUNCH((trsm_kernel<T>), dim3((unsigned)((nrhs + BLOCK - 1) / BLOCK), (unsigned)batch),
                      dim3(BLOCK), 0, st, (T*)out, (const T*)Tm, sTb, sT0, sT1, (const T*)B, sBb,
                      (int)n, (int)nrhs, lower, unit);
   return pthip::post_launch("trsm");

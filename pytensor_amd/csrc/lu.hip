@@ -304,7 +304,7 @@ int launch_getrf_reg(long long batch, long long n, const void* A, void* LU, void
   void* stage = nullptr;  // multipliers in physical row order until the permutation is known
   int r = pthip_alloc((size_t)batch * n * n * sizeof(T), &stage);
   if (r) return r;
-  hipLaunchKernelGGL((getrf_reg_kernel<T, NB>), dim3((unsigned)batch), dim3(BLOCK), 0, pthip::ctx().stream, (T*)LU,
+  PTHIP_KLAUNCH((getrf_reg_kernel<T, NB>), dim3((unsigned)batch), dim3(BLOCK), 0, pthip::ctx().stream, (T*)LU,
                      (const T*)A, (long long*)perm, (T*)sign, (T*)logabs, (int)n, (T*)stage,
                      flag_singular ? (int*)pthip_status_ptr() : (int*)nullptr);
   r = pthip::post_launch("getrf_reg");
@@ -336,7 +336,7 @@ int getrf_typed(long long batch, long long n, const void* A, void* LU, void* per
     int r = pthip_alloc((size_t)batch * n * n * sizeof(T), &scratch);
     if (r) return r;
   }
-  hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(BLOCK), lds ? need : 0, st, (T*)LU, (const T*)A,
+  PTHIP_KLAUNCH(k, dim3((unsigned)batch), dim3(BLOCK), lds ? need : 0, st, (T*)LU, (const T*)A,
                      (long long*)perm, (T*)sign, (T*)logabs, (int)n, lds ? 1 : 0, (T*)scratch,
                      flag_singular ? (int*)pthip_status_ptr() : (int*)nullptr);
   int r = pthip::post_launch("getrf");
@@ -363,8 +363,8 @@ extern "C" int pthip_permuted_identity(int dtype, int64_t n, const void* perm, v
   long long g = (n * n + BLOCK - 1) / BLOCK;
   if (g > 4096) g = 4096;
   hipStream_t st = pthip::ctx().stream;
-  if (dtype == PTHIP_F64) hipLaunchKernelGGL(permuted_identity_kernel<double>, dim3((unsigned)g), dim3(BLOCK), 0, st, (double*)out, (const long long*)perm, (long long)n);
-  else if (dtype == PTHIP_F32) hipLaunchKernelGGL(permuted_identity_kernel<float>, dim3((unsigned)g), dim3(BLOCK), 0, st, (float*)out, (const long long*)perm, (long long)n);
+  if (dtype == PTHIP_F64) PTHIP_KLAUNCH(permuted_identity_kernel<double>, dim3((unsigned)g), dim3(BLOCK), 0, st, (double*)out, (const long long*)perm, (long long)n);
+  else if (dtype == PTHIP_F32) PTHIP_KLAUNCH(permuted_identity_kernel<float>, dim3((unsigned)g), dim3(BLOCK), 0, st, (float*)out, (const long long*)perm, (long long)n);
   else return pthip::set_error("pthip_permuted_identity: dtype %d not supported (float32/float64 only)", dtype);
   return pthip::post_launch("permuted_identity");
 }
@@ -440,9 +440,9 @@ extern "C" int pthip_lu_factor_finish(int dtype, int64_t batch, int64_t n, void*
   hipStream_t st = pthip::ctx().stream;
   const size_t sh = (size_t)n * 2 * sizeof(int);
   if (dtype == PTHIP_F64)
-    hipLaunchKernelGGL((lu_factor_finish_kernel<double>), dim3((unsigned)batch), dim3(256), sh, st, (double*)LU, (const long long*)perm, (int*)piv, (int)n);
+    PTHIP_KLAUNCH((lu_factor_finish_kernel<double>), dim3((unsigned)batch), dim3(256), sh, st, (double*)LU, (const long long*)perm, (int*)piv, (int)n);
   else if (dtype == PTHIP_F32)
-    hipLaunchKernelGGL((lu_factor_finish_kernel<float>), dim3((unsigned)batch), dim3(256), sh, st, (float*)LU, (const long long*)perm, (int*)piv, (int)n);
+    PTHIP_KLAUNCH((lu_factor_finish_kernel<float>), dim3((unsigned)batch), dim3(256), sh, st, (float*)LU, (const long long*)perm, (int*)piv, (int)n);
   else
     return pthip::set_error("pthip_lu_factor_finish: dtype %d not supported (float32/float64 only)", dtype);
   return pthip::post_launch("lu_factor_finish");
@@ -456,9 +456,9 @@ extern "C" int pthip_pivots_to_perm(int itemsize, int inverse, int64_t batch, in
   int* status = (int*)pthip_status_ptr();
   const size_t sh = (size_t)n * sizeof(int);
   if (itemsize == 4)
-    hipLaunchKernelGGL((pivots_to_perm_kernel<int>), dim3((unsigned)batch), dim3(256), sh, st, (const int*)piv, (long long*)out, (int)n, inverse, status);
+    PTHIP_KLAUNCH((pivots_to_perm_kernel<int>), dim3((unsigned)batch), dim3(256), sh, st, (const int*)piv, (long long*)out, (int)n, inverse, status);
   else if (itemsize == 8)
-    hipLaunchKernelGGL((pivots_to_perm_kernel<long long>), dim3((unsigned)batch), dim3(256), sh, st, (const long long*)piv, (long long*)out, (int)n, inverse, status);
+    PTHIP_KLAUNCH((pivots_to_perm_kernel<long long>), dim3((unsigned)batch), dim3(256), sh, st, (const long long*)piv, (long long*)out, (int)n, inverse, status);
   else
     return pthip::set_error("pthip_pivots_to_perm: pivots must be int32 or int64");
   return pthip::post_launch("pivots_to_perm");

@@ -83,16 +83,16 @@ extern "C" int pthip_nonzero(int64_t n, const void* mask, void* idx_out, void* c
   PTHIP_REQUIRE_INIT();
   hipStream_t st = pthip::ctx().stream;
   if (n <= 0) {
-    PTHIP_CHECK(hipMemsetAsync(count_out, 0, sizeof(long long), st));
+    PTHIP_CHECK(pthip::memset_async(count_out, 0, sizeof(long long), st));
     return 0;
   }
   const long long nb = (n + TILE - 1) / TILE;
   void* counts = nullptr;
   int r = pthip_alloc((size_t)nb * sizeof(long long), &counts);
   if (r) return r;
-  hipLaunchKernelGGL(nz_count_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, st, (const unsigned char*)mask, (long long)n, (long long*)counts);
-  hipLaunchKernelGGL(nz_scan_kernel, dim3(1), dim3(BLOCK), 0, st, (long long*)counts, nb, (long long*)count_out);
-  hipLaunchKernelGGL(nz_write_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, st, (const unsigned char*)mask, (long long)n, (const long long*)counts, (long long*)idx_out);
+  PTHIP_KLAUNCH(nz_count_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, st, (const unsigned char*)mask, (long long)n, (long long*)counts);
+  PTHIP_KLAUNCH(nz_scan_kernel, dim3(1), dim3(BLOCK), 0, st, (long long*)counts, nb, (long long*)count_out);
+  PTHIP_KLAUNCH(nz_write_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, st, (const unsigned char*)mask, (long long)n, (const long long*)counts, (long long*)idx_out);
   r = pthip::post_launch("nonzero");
   pthip_free(counts);  // stream-ordered reuse keeps this safe
   return r;

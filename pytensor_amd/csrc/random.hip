@@ -356,13 +356,13 @@ extern "C" int pthip_random(int dist, int out_dtype, int64_t n, const uint64_t* 
   hipStream_t st = pthip::ctx().stream;
   if (dist == D_INTEGERS) {
     if (out_dtype != PTHIP_I64) return pthip::set_error("pthip_random: integers draws are int64");
-    hipLaunchKernelGGL(integers_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, st, (long long)n, a, (long long*)out);
+    PTHIP_KLAUNCH(integers_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, st, (long long)n, a, (long long*)out);
     return pthip::post_launch("random_integers");
   }
   const long long work = dist == D_UNIFORM ? (n + 3) / 4 : n;
-  if (out_dtype == PTHIP_F64) hipLaunchKernelGGL(random_kernel<double>, dim3(grid_for(work)), dim3(BLOCK), 0, st, dist, (long long)n, a, (double*)out);
-  else if (out_dtype == PTHIP_F32) hipLaunchKernelGGL(random_kernel<float>, dim3(grid_for(work)), dim3(BLOCK), 0, st, dist, (long long)n, a, (float*)out);
-  else if (out_dtype == PTHIP_I64) hipLaunchKernelGGL(random_kernel<long long>, dim3(grid_for(work)), dim3(BLOCK), 0, st, dist, (long long)n, a, (long long*)out);
+  if (out_dtype == PTHIP_F64) PTHIP_KLAUNCH(random_kernel<double>, dim3(grid_for(work)), dim3(BLOCK), 0, st, dist, (long long)n, a, (double*)out);
+  else if (out_dtype == PTHIP_F32) PTHIP_KLAUNCH(random_kernel<float>, dim3(grid_for(work)), dim3(BLOCK), 0, st, dist, (long long)n, a, (float*)out);
+  else if (out_dtype == PTHIP_I64) PTHIP_KLAUNCH(random_kernel<long long>, dim3(grid_for(work)), dim3(BLOCK), 0, st, dist, (long long)n, a, (long long*)out);
   else return pthip::set_error("pthip_random: output dtype %d not supported (float64/float32/int64)", out_dtype);
   return pthip::post_launch("random");
 }
@@ -376,8 +376,8 @@ extern "C" int pthip_random_categorical(int p_dtype, int64_t rows, int64_t k, co
   a.key[0] = key[0]; a.key[1] = key[1];
   for (int j = 0; j < 4; j++) a.ctr[j] = counter[j];
   hipStream_t st = pthip::ctx().stream;
-  if (p_dtype == PTHIP_F64) hipLaunchKernelGGL(categorical_kernel<double>, dim3(grid_for(rows)), dim3(BLOCK), 0, st, (long long)rows, (long long)k, a, (const double*)p, (long long)row_stride, (long long*)out);
-  else if (p_dtype == PTHIP_F32) hipLaunchKernelGGL(categorical_kernel<float>, dim3(grid_for(rows)), dim3(BLOCK), 0, st, (long long)rows, (long long)k, a, (const float*)p, (long long)row_stride, (long long*)out);
+  if (p_dtype == PTHIP_F64) PTHIP_KLAUNCH(categorical_kernel<double>, dim3(grid_for(rows)), dim3(BLOCK), 0, st, (long long)rows, (long long)k, a, (const double*)p, (long long)row_stride, (long long*)out);
+  else if (p_dtype == PTHIP_F32) PTHIP_KLAUNCH(categorical_kernel<float>, dim3(grid_for(rows)), dim3(BLOCK), 0, st, (long long)rows, (long long)k, a, (const float*)p, (long long)row_stride, (long long*)out);
   else return pthip::set_error("pthip_random_categorical: probabilities must be float32/float64");
   return pthip::post_launch("random_categorical");
 }

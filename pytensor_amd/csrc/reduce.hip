@@ -135,10 +135,10 @@ int launch_contig(hipStream_t st, int group, const Tin* x, Tout* out, long long 
   long long groups = n_out * nsplit;
   if (groups == 0) return 0;
   if (group == 256) {
-    hipLaunchKernelGGL((reduce_contig_kernel<Op, Tin, Tacc, Tout, 256>), dim3((unsigned)groups),
+    PTHIP_KLAUNCH((reduce_contig_kernel<Op, Tin, Tacc, Tout, 256>), dim3((unsigned)groups),
                        dim3(BLOCK), 0, st, x, out, n_out, R, B, sA, sR, sB, nsplit, chunk);
   } else {
-    hipLaunchKernelGGL((reduce_contig_kernel<Op, Tin, Tacc, Tout, 64>),
+    PTHIP_KLAUNCH((reduce_contig_kernel<Op, Tin, Tacc, Tout, 64>),
                        dim3((unsigned)((groups + 3) / 4)), dim3(BLOCK), 0, st, x, out, n_out, R, B,
                        sA, sR, sB, nsplit, chunk);
   }
@@ -150,7 +150,7 @@ int launch_strided(hipStream_t st, const Tin* x, Tout* out, long long n_out, lon
                    long long B, long long sA, long long sR, long long sB, long long nsplit,
                    long long chunk) {
   if (n_out == 0) return 0;
-  hipLaunchKernelGGL((reduce_strided_kernel<Op, Tin, Tacc, Tout>),
+  PTHIP_KLAUNCH((reduce_strided_kernel<Op, Tin, Tacc, Tout>),
                      dim3((unsigned)((n_out + BLOCK - 1) / BLOCK), (unsigned)nsplit), dim3(BLOCK), 0,
                      st, x, out, n_out, R, B, sA, sR, sB, chunk);
   return pthip::post_launch("reduce_strided");

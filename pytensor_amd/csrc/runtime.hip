@@ -284,6 +284,8 @@ int pthip_host_free(void* hptr) {
 int pthip_h2d(void* dst, const void* src, size_t bytes) {
   PTHIP_REQUIRE_INIT();
   if (!bytes) return 0;
+  // (a pageable source would be snapshotted at call time by the runtime, not at replay time)
+  if (g_ctx.recorder) { g_ctx.recorder->ok = false; g_ctx.recorder->why = "host-to-device copy"; }
   PTHIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_ctx.stream));
   return 0;
 }
@@ -291,21 +293,21 @@ int pthip_h2d(void* dst, const void* src, size_t bytes) {
 int pthip_d2h(void* dst, const void* src, size_t bytes) {
   PTHIP_REQUIRE_INIT();
   if (!bytes) return 0;
-  PTHIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_ctx.stream));
+  PTHIP_CHECK(memcpy_async(dst, src, bytes, hipMemcpyDeviceToHost, g_ctx.stream));
   return 0;
 }
 
 int pthip_d2d(void* dst, const void* src, size_t bytes) {
   PTHIP_REQUIRE_INIT();
   if (!bytes) return 0;
-  PTHIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_ctx.stream));
+  PTHIP_CHECK(memcpy_async(dst, src, bytes, hipMemcpyDeviceToDevice, g_ctx.stream));
   return 0;
 }
 
 int pthip_memset(void* dst, int byte, size_t bytes) {
   PTHIP_REQUIRE_INIT();
   if (!bytes) return 0;
-  PTHIP_CHECK(hipMemsetAsync(dst, byte, bytes, g_ctx.stream));
+  PTHIP_CHECK(memset_async(dst, byte, bytes, g_ctx.stream));
   return 0;
 }
 
@@ -433,8 +435,16 @@ struct ReplayTrace {
   }
 };
 
-int pthip_plan_replay(void* ga, void* gb, void* gc, void* dev_in, const void* host_in,
-                      size_t in_bytes, int sync) {
+// A segment is a captured hipGraph (g*) or a recorded launch list (l*), never both.
+static int run_segment(void* g, void* l, hipStream_t st) {
+  if (g) PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)g, st));
+  else if (l)
+    for (auto& op : ((LaunchList*)l)->ops) PTHIP_CHECK(op(st));
+  return 0;
+}
+
+int pthip_plan_replay2(void* ga, void* la, void* gb, void* lb, void* gc, void* lc, void* dev_in,
+                       const void* host_in, size_t in_bytes, int sync) {
   PTHIP_REQUIRE_INIT();
   static hipEvent_t ev_in = nullptr, ev_a = nullptr;
   static ReplayTrace tr;
@@ -442,7 +452,7 @@ int pthip_plan_replay(void* ga, void* gb, void* gc, void* dev_in, const void* ho
   tr.start();
   if (in_bytes) PTHIP_CHECK(hipMemcpyAsync(dev_in, host_in, in_bytes, hipMemcpyHostToDevice, s0));
   tr.lap(0);
-  if (ga && gc) {
+  if ((ga || la) && (gc || lc)) {
     if (!g_ctx.streams[1]) PTHIP_CHECK(create_stream(1));
     hipStream_t s1 = g_ctx.streams[1];
     if (!ev_in) {
@@ -451,24 +461,29 @@ int pthip_plan_replay(void* ga, void* gb, void* gc, void* dev_in, const void* ho
     }
     static const bool b_first = getenv("PTHIP_PLAN_A_FIRST") == nullptr;
     PTHIP_CHECK(hipEventRecord(ev_in, s0));
-    if (b_first) PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)gb, s0));
+    if (b_first) { if (int r = run_segment(gb, lb, s0)) return r; }
     PTHIP_CHECK(hipStreamWaitEvent(s1, ev_in, 0));
-    PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)ga, s1));
+    if (int r = run_segment(ga, la, s1)) return r;
     tr.lap(1);
-    if (!b_first) PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)gb, s0));
+    if (!b_first) { if (int r = run_segment(gb, lb, s0)) return r; }
     tr.lap(2);
     PTHIP_CHECK(hipEventRecord(ev_a, s1));
     PTHIP_CHECK(hipStreamWaitEvent(s0, ev_a, 0));
-    PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)gc, s0));
+    if (int r = run_segment(gc, lc, s0)) return r;
     tr.lap(3);
   } else {
-    PTHIP_CHECK(hipGraphLaunch((hipGraphExec_t)gb, s0));
+    if (int r = run_segment(gb, lb, s0)) return r;
     tr.lap(2);
   }
   if (sync) PTHIP_CHECK(hipStreamSynchronize(s0));
   tr.lap(4);
   tr.done();
   return 0;
+}
+
+int pthip_plan_replay(void* ga, void* gb, void* gc, void* dev_in, const void* host_in,
+                      size_t in_bytes, int sync) {
+  return pthip_plan_replay2(ga, nullptr, gb, nullptr, gc, nullptr, dev_in, host_in, in_bytes, sync);
 }
 
 int pthip_graph_destroy(void* graph_exec) {
@@ -564,10 +579,63 @@ int pthip_launch(void* fn, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t bx, u
   size_t sz = argbuf_bytes;
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, (void*)argbuf, HIP_LAUNCH_PARAM_BUFFER_SIZE,
                     &sz, HIP_LAUNCH_PARAM_END};
+  g_ctx.launch_count++;
+  if (g_ctx.recorder) {
+    // the argument block is copied: the caller's buffer does not outlive this call
+    std::vector<char> args((const char*)argbuf, (const char*)argbuf + argbuf_bytes);
+    g_ctx.recorder->ops.emplace_back([=](hipStream_t s) mutable {
+      size_t n = args.size();
+      void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, (void*)args.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &n, HIP_LAUNCH_PARAM_END};
+      return hipModuleLaunchKernel((hipFunction_t)fn, gx, gy, gz, bx, by, bz, shmem, s, nullptr, cfg);
+    });
+  }
   PTHIP_CHECK(hipModuleLaunchKernel((hipFunction_t)fn, gx, gy, gz, bx, by, bz, shmem, g_ctx.stream,
                                     nullptr, config));
   return 0;
 }
+
+// ---- launch lists (the C++ launch-plan executor; common.h LaunchList) ------------------------
+int pthip_record_begin(void) {
+  PTHIP_REQUIRE_INIT();
+  if (g_ctx.capturing || g_ctx.recorder) return set_error("pthip_record_begin: already capturing / recording");
+  if (g_ctx.current != 0) return set_error("pthip_record_begin: select stream 0 first");
+  g_ctx.recorder = new LaunchList();
+  g_ctx.capturing = true;  // same discipline as a hipGraph capture: no host reads, no syncs
+  return 0;
+}
+
+int pthip_record_end(void** list, int64_t* n_ops) {
+  if (!g_ctx.recorder) return set_error("pthip_record_end: not recording");
+  LaunchList* l = g_ctx.recorder;
+  g_ctx.recorder = nullptr;
+  g_ctx.capturing = false;
+  g_ctx.stream = g_ctx.streams[0];
+  g_ctx.current = 0;
+  if (n_ops) *n_ops = (int64_t)l->ops.size();
+  if (!l->ok) {
+    std::string why = l->why;
+    delete l;
+    *list = nullptr;
+    return set_error("pthip_record_end: the sequence cannot be replayed (%s)", why.c_str());
+  }
+  *list = (void*)l;
+  return 0;
+}
+
+int pthip_list_launch(void* list, int stream) {
+  if (!list) return set_error("pthip_list_launch: null list");
+  if (stream < 0 || stream >= kMaxStreams) return set_error("pthip_list_launch: bad stream");
+  if (!g_ctx.streams[stream]) PTHIP_CHECK(create_stream(stream));
+  for (auto& op : ((LaunchList*)list)->ops) PTHIP_CHECK(op(g_ctx.streams[stream]));
+  return 0;
+}
+
+int pthip_list_destroy(void* list) {
+  delete (LaunchList*)list;
+  return 0;
+}
+
+int64_t pthip_launch_count(void) { return (int64_t)g_ctx.launch_count; }
 
 void* pthip_status_ptr(void) {
   if (g_ctx.device < 0 && pthip_init(0)) return nullptr;

@@ -75,7 +75,7 @@ int imatmul_typed(long long M, long long N, long long K, const void* A, long lon
                   long long sA1, const void* B, long long sB0, long long sB1, void* out) {
   if (M * N == 0) return 0;
   const unsigned grid = (unsigned)((M * N + BLOCK - 1) / BLOCK);
-  hipLaunchKernelGGL((imatmul_kernel<T>), dim3(grid), dim3(BLOCK), 0, pthip::ctx().stream, (T*)out,
+  PTHIP_KLAUNCH((imatmul_kernel<T>), dim3(grid), dim3(BLOCK), 0, pthip::ctx().stream, (T*)out,
                      (const T*)A, sA0, sA1, (const T*)B, sB0, sB1, M, N, K);
   return pthip::post_launch("imatmul");
 }
@@ -88,10 +88,10 @@ int cumulative_typed(int mul, long long outer, long long n, long long inner, con
   const unsigned grid = (unsigned)((lines + BLOCK - 1) / BLOCK);
   hipStream_t st = pthip::ctx().stream;
   if (mul)
-    hipLaunchKernelGGL((cumulative_kernel<T, true>), dim3(grid), dim3(BLOCK), 0, st, (T*)dst,
+    PTHIP_KLAUNCH((cumulative_kernel<T, true>), dim3(grid), dim3(BLOCK), 0, st, (T*)dst,
                        (const T*)src, outer, n, inner);
   else
-    hipLaunchKernelGGL((cumulative_kernel<T, false>), dim3(grid), dim3(BLOCK), 0, st, (T*)dst,
+    PTHIP_KLAUNCH((cumulative_kernel<T, false>), dim3(grid), dim3(BLOCK), 0, st, (T*)dst,
                        (const T*)src, outer, n, inner);
   return pthip::post_launch("cumulative");
 }
@@ -100,7 +100,7 @@ template <class T>
 int argmax_typed(long long rows, long long R, const void* src, void* out) {
   if (rows == 0) return 0;
   const unsigned grid = (unsigned)((rows + BLOCK - 1) / BLOCK);
-  hipLaunchKernelGGL((argmax_kernel<T>), dim3(grid), dim3(BLOCK), 0, pthip::ctx().stream,
+  PTHIP_KLAUNCH((argmax_kernel<T>), dim3(grid), dim3(BLOCK), 0, pthip::ctx().stream,
                      (long long*)out, (const T*)src, rows, R);
   return pthip::post_launch("argmax");
 }

@@ -170,17 +170,17 @@ int softmax_typed(int log_, long long rows, long long cols, const void* x, void*
   if (cols <= 16) {
     const unsigned grid = (unsigned)((rows + BLOCK - 1) / BLOCK);
     if (log_)
-      hipLaunchKernelGGL((softmax_thread_kernel<T, true, 16>), dim3(grid), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, (int)cols);
+      PTHIP_KLAUNCH((softmax_thread_kernel<T, true, 16>), dim3(grid), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, (int)cols);
     else
-      hipLaunchKernelGGL((softmax_thread_kernel<T, false, 16>), dim3(grid), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, (int)cols);
+      PTHIP_KLAUNCH((softmax_thread_kernel<T, false, 16>), dim3(grid), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, (int)cols);
     return pthip::post_launch("softmax(thread per row)");
   }
   if (rows < 2 * (long long)pthip::kNumCU && cols >= 4096) {
     const unsigned grid = (unsigned)rows;
     if (log_)
-      hipLaunchKernelGGL((softmax_block_kernel<T, true>), dim3(grid), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, cols);
+      PTHIP_KLAUNCH((softmax_block_kernel<T, true>), dim3(grid), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, cols);
     else
-      hipLaunchKernelGGL((softmax_block_kernel<T, false>), dim3(grid), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, cols);
+      PTHIP_KLAUNCH((softmax_block_kernel<T, false>), dim3(grid), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, cols);
     return pthip::post_launch("softmax(workgroup per row)");
   }
   long long blocks = (rows + 3) / 4;
@@ -189,10 +189,10 @@ int softmax_typed(int log_, long long rows, long long cols, const void* x, void*
 #define LAUNCH_REG(VPL)                                                                          \
   do {                                                                                           \
     if (log_)                                                                                    \
-      hipLaunchKernelGGL((softmax_wave_reg_kernel<T, true, VPL>), dim3((unsigned)blocks),        \
+      PTHIP_KLAUNCH((softmax_wave_reg_kernel<T, true, VPL>), dim3((unsigned)blocks),        \
                          dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, (int)cols);             \
     else                                                                                         \
-      hipLaunchKernelGGL((softmax_wave_reg_kernel<T, false, VPL>), dim3((unsigned)blocks),       \
+      PTHIP_KLAUNCH((softmax_wave_reg_kernel<T, false, VPL>), dim3((unsigned)blocks),       \
                          dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, (int)cols);             \
     return pthip::post_launch("softmax(wave per row, registers)");                               \
   } while (0)
@@ -201,9 +201,9 @@ int softmax_typed(int log_, long long rows, long long cols, const void* x, void*
   if (cols <= 64 * 32) LAUNCH_REG(32);
 #undef LAUNCH_REG
   if (log_)
-    hipLaunchKernelGGL((softmax_wave_kernel<T, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, cols);
+    PTHIP_KLAUNCH((softmax_wave_kernel<T, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, cols);
   else
-    hipLaunchKernelGGL((softmax_wave_kernel<T, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, cols);
+    PTHIP_KLAUNCH((softmax_wave_kernel<T, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, cols);
   return pthip::post_launch("softmax(wave per row)");
 }
 

@@ -135,7 +135,7 @@ int sort_typed(long long rows, long long n, const void* in, void* out_vals, void
   int P = 2;
   while (P < n) P <<= 1;
   if (P <= TILE) {
-    hipLaunchKernelGGL(sort_lds_kernel<T>, dim3((unsigned)rows), dim3(BLOCK), 0, st, (const T*)in, (int)n, P,
+    PTHIP_KLAUNCH(sort_lds_kernel<T>, dim3((unsigned)rows), dim3(BLOCK), 0, st, (const T*)in, (int)n, P,
                        (T*)out_vals, (long long*)out_idx);
     return pthip::post_launch("sort_lds");
   }
@@ -145,14 +145,14 @@ int sort_typed(long long rows, long long n, const void* in, void* out_vals, void
   r = pthip_alloc((size_t)rows * P * sizeof(int), &idx);
   if (r) { pthip_free(keys); return r; }
   const unsigned tiles = (unsigned)(rows * (P / TILE));
-  hipLaunchKernelGGL(sort_init_kernel<T>, dim3(grid_for(rows * P)), dim3(BLOCK), 0, st, (const T*)in, rows, (int)n, P, (T*)keys, (int*)idx);
-  hipLaunchKernelGGL(sort_tile_kernel<T>, dim3(tiles), dim3(BLOCK), 0, st, (T*)keys, (int*)idx, (int)n, P, 0, 1);
+  PTHIP_KLAUNCH(sort_init_kernel<T>, dim3(grid_for(rows * P)), dim3(BLOCK), 0, st, (const T*)in, rows, (int)n, P, (T*)keys, (int*)idx);
+  PTHIP_KLAUNCH(sort_tile_kernel<T>, dim3(tiles), dim3(BLOCK), 0, st, (T*)keys, (int*)idx, (int)n, P, 0, 1);
   for (long long k = 2ll * TILE; k <= P; k <<= 1) {
     for (long long j = k >> 1; j >= TILE; j >>= 1)
-      hipLaunchKernelGGL(sort_far_step_kernel<T>, dim3(grid_for(rows * (P / 2))), dim3(BLOCK), 0, st, (T*)keys, (int*)idx, rows, (int)n, P, (int)k, (int)j);
-    hipLaunchKernelGGL(sort_tile_kernel<T>, dim3(tiles), dim3(BLOCK), 0, st, (T*)keys, (int*)idx, (int)n, P, (int)k, 0);
+      PTHIP_KLAUNCH(sort_far_step_kernel<T>, dim3(grid_for(rows * (P / 2))), dim3(BLOCK), 0, st, (T*)keys, (int*)idx, rows, (int)n, P, (int)k, (int)j);
+    PTHIP_KLAUNCH(sort_tile_kernel<T>, dim3(tiles), dim3(BLOCK), 0, st, (T*)keys, (int*)idx, (int)n, P, (int)k, 0);
   }
-  hipLaunchKernelGGL(sort_store_kernel<T>, dim3(grid_for(rows * n)), dim3(BLOCK), 0, st, (const T*)keys, (const int*)idx, rows, (int)n, P, (T*)out_vals, (long long*)out_idx);
+  PTHIP_KLAUNCH(sort_store_kernel<T>, dim3(grid_for(rows * n)), dim3(BLOCK), 0, st, (const T*)keys, (const int*)idx, rows, (int)n, P, (T*)out_vals, (long long*)out_idx);
   r = pthip::post_launch("sort");
   pthip_free(keys);  // stream-ordered reuse keeps this safe
   pthip_free(idx);

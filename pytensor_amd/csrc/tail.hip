@@ -113,9 +113,9 @@ extern "C" int pthip_multi_finish(int dtype, int n_tasks, const int* ops, const 
   t.blk0[n_tasks] = nb;
   hipStream_t st = pthip::ctx().stream;
   switch (dtype) {
-    case PTHIP_F64: hipLaunchKernelGGL(multi_finish_kernel<double>, dim3(nb), dim3(BLOCK), 0, st, t); break;
-    case PTHIP_F32: hipLaunchKernelGGL(multi_finish_kernel<float>, dim3(nb), dim3(BLOCK), 0, st, t); break;
-    case PTHIP_I64: hipLaunchKernelGGL(multi_finish_kernel<long long>, dim3(nb), dim3(BLOCK), 0, st, t); break;
+    case PTHIP_F64: PTHIP_KLAUNCH(multi_finish_kernel<double>, dim3(nb), dim3(BLOCK), 0, st, t); break;
+    case PTHIP_F32: PTHIP_KLAUNCH(multi_finish_kernel<float>, dim3(nb), dim3(BLOCK), 0, st, t); break;
+    case PTHIP_I64: PTHIP_KLAUNCH(multi_finish_kernel<long long>, dim3(nb), dim3(BLOCK), 0, st, t); break;
     default: return pthip::set_error("pthip_multi_finish: unsupported accumulator dtype %d", dtype);
   }
   return pthip::post_launch("multi_finish");

@@ -72,6 +72,12 @@ SIGNATURES = {
     "pthip_graph_launch": (_int, [_vp]),
     "pthip_graph_launch_on": (_int, [_vp, _int]),
     "pthip_plan_replay": (_int, [_vp, _vp, _vp, _vp, _vp, _sz, _int]),
+    "pthip_record_begin": (_int, []),
+    "pthip_record_end": (_int, [C.POINTER(_vp), C.POINTER(_i64)]),
+    "pthip_list_launch": (_int, [_vp, _int]),
+    "pthip_list_destroy": (_int, [_vp]),
+    "pthip_launch_count": (_i64, []),
+    "pthip_plan_replay2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _int]),
     "pthip_graph_destroy": (_int, [_vp]),
     "pthip_event_create": (_int, [C.POINTER(_vp)]),
     "pthip_event_record": (_int, [_vp]),

@@ -90,22 +90,31 @@ class _PinnedAsBuffer:
 
 
 class _SegmentSwitch:
-    """Scheduler hook: closes the running capture and opens the next one when the
-    executor crosses a segment boundary (A → B → C)."""
+    """Scheduler hook: tells the plan when the executor crosses a segment boundary (A → B → C) —
+    during the warm-up pass to size the segments, during the build pass to close the running
+    capture / recording and open the next one."""
 
     def __init__(self, plan, seg):
         self.plan = plan
         self.seg = seg
         self.capturing = False
+        self.sizing = False
 
     def before_node(self, k, node):
-        if self.capturing and k > 0 and self.seg[k] != self.seg[k - 1]:
-            self.plan._end_segment()
-            self.plan._begin_segment()
+        if k > 0 and self.seg[k] != self.seg[k - 1]:
+            if self.capturing:
+                self.plan._end_segment()
+                self.plan._begin_segment()
+            elif self.sizing:
+                self.plan._note_boundary()
 
 
 # results up to this size are written by the pack kernel directly into pinned host memory
 _ZEROCOPY_MAX = int(os.environ.get("PTHIP_ZEROCOPY_MAX", 1 << 16))
+
+# a segment of at most this many launches is replayed as a recorded launch list (direct launches:
+# no hipGraph launch floor, no graph-to-graph boundary); longer ones as captured hipGraphs
+_LIST_MAX = int(os.environ.get("PTHIP_LIST_MAX", 8))
 
 _CAPTURE_ACTIVE = [None]  # the plan currently inside warm-up/capture, if any
 _DEFERRED = []  # plans whose release was requested during somebody else's capture
@@ -127,7 +136,12 @@ class FrozenPlan:
         if len(inputs) != len(g.inputs):
             raise TypeError(f"expected {len(g.inputs)} inputs, got {len(inputs)}")
         self._arena = C.c_void_p()
-        self._graphs = []  # captured hipGraphExec handles, in segment order
+        self._graphs = []  # segments in order: ("graph", hipGraphExec handle) | ("list", LaunchList handle)
+        self._seg_sizes = []  # launches per segment, measured in the warm-up pass
+        self._mark = 0
+        # update feedback writes the resident buffers: a recording pass executes what it records,
+        # so such plans are captured (capture does not execute)
+        self._use_lists = _LIST_MAX > 0 and not exe.update_map
         self._staged = []  # input positions travelling through the staging block
         self._baked = {}  # position -> host value baked into the plan (int scalars)
         self._resident_devs = {}  # position -> DeviceArray (kept alive: its address is in the graphs)
@@ -167,8 +181,17 @@ class FrozenPlan:
             _CAPTURE_ACTIVE[0] = None
 
     # ------------------------------------------------------------------
+    def _note_boundary(self):
+        n = int(self.lib.pthip_launch_count())
+        self._seg_sizes.append(n - self._mark)
+        self._mark = n
+
+    def _segment_is_list(self, k):
+        return self._use_lists and k < len(self._seg_sizes) and 0 < self._seg_sizes[k] <= _LIST_MAX
+
     def _begin_segment(self):
-        ffi.check(self.lib.pthip_capture_begin())
+        self._cur_is_list = self._segment_is_list(len(self._graphs))
+        ffi.check(self.lib.pthip_record_begin() if self._cur_is_list else self.lib.pthip_capture_begin())
         self.exe._capturing = True
         if self._switch is not None:
             self._switch.capturing = True
@@ -177,9 +200,29 @@ class FrozenPlan:
         self.exe._capturing = False
         if self._switch is not None:
             self._switch.capturing = False
-        ge = C.c_void_p()
-        ffi.check(self.lib.pthip_capture_end(C.byref(ge)))
-        self._graphs.append(ge)
+        h = C.c_void_p()
+        if self._cur_is_list:
+            n = C.c_int64(0)
+            if self.lib.pthip_record_end(C.byref(h), C.byref(n)) != 0:
+                self._list_failed = True  # (no exception: a traceback would keep arena blocks alive)
+                h = C.c_void_p()
+            self._graphs.append(("list", h))
+        else:
+            ffi.check(self.lib.pthip_capture_end(C.byref(h)))
+            self._graphs.append(("graph", h))
+
+    def _abort_segment(self):
+        """close a running capture / recording after a failure, releasing what it produced"""
+        self.exe._capturing = False
+        h = C.c_void_p()
+        if getattr(self, "_cur_is_list", False):
+            self.lib.pthip_record_end(C.byref(h), None)
+            if h:
+                self.lib.pthip_list_destroy(h)
+        else:
+            self.lib.pthip_capture_end(C.byref(h))
+            if h:
+                self.lib.pthip_graph_destroy(h)
 
     def _upload_params(self):
         if self._dev_in is not None:
@@ -226,6 +269,12 @@ class FrozenPlan:
         if capture:
             env.scheduler = self._switch
             self._begin_segment()
+        elif self._switch is not None:
+            env.scheduler = self._switch
+            self._switch.sizing = True
+        if not capture:
+            self._seg_sizes = []
+            self._mark = int(lib.pthip_launch_count())
         ok = False
         try:
             outs, env = exe.run_device(dev_inputs, env)
@@ -281,15 +330,15 @@ class FrozenPlan:
                     self._fed = exe._feed_updates_device(outs)
             ok = True
         finally:
+            if self._switch is not None:
+                self._switch.sizing = False
             if capture:
                 if ok:
                     self._end_segment()
-                else:  # abort the capture cleanly
-                    self.exe._capturing = False
-                    ge = C.c_void_p()
-                    lib.pthip_capture_end(C.byref(ge))
-                    if ge:
-                        lib.pthip_graph_destroy(ge)
+                else:  # abort the capture / recording cleanly
+                    self._abort_segment()
+            elif ok:
+                self._note_boundary()  # the last (or only) segment, output packing included
         return outs
 
     def _build(self, inputs):
@@ -306,25 +355,37 @@ class FrozenPlan:
             ffi.check(lib.pthip_synchronize())
         finally:
             ffi.check(lib.pthip_arena_end())
-        # (2) rewind + capture (one graph, or one per segment)
-        ffi.check(lib.pthip_arena_begin(C.byref(self._arena)))
-        try:
-            outs = self._run_once(inputs, capture=True)
-            del outs
-        finally:
-            ffi.check(lib.pthip_arena_end())
+        # (2) rewind + capture / record (one segment, or three)
+        for attempt in (0, 1):
+            self._list_failed = False
+            ffi.check(lib.pthip_arena_begin(C.byref(self._arena)))
+            try:
+                outs = self._run_once(inputs, capture=True)
+                del outs
+            finally:
+                ffi.check(lib.pthip_arena_end())
+            if not self._list_failed:
+                break
+            # a sequence a launch list cannot repeat (an upload inside it): hipGraphs instead
+            ffi.check(lib.pthip_synchronize())
+            self._release_segments()
+            self._keep.clear()  # arrays of the discarded pass hold arena blocks: rewind needs them gone
+            self._fed = []
+            self._use_lists = False
         if self.segmented and len(self._graphs) != 3:
             raise ffi.HipError(f"segmented plan captured {len(self._graphs)} graphs instead of 3")
 
     # ------------------------------------------------------------------
     def _replay(self, sync):
         if self.segmented:
-            ga, gb, gc = self._graphs
+            sa, sb, sc = self._graphs
         else:
-            ga, gb, gc = None, self._graphs[0], None
+            sa, sb, sc = None, self._graphs[0], None
+        g = lambda seg: seg[1] if (seg is not None and seg[0] == "graph") else None
+        l = lambda seg: seg[1] if (seg is not None and seg[0] == "list") else None
         nb = self._in_block.nbytes if self._dev_in is not None else 0
-        rc = self.lib.pthip_plan_replay(
-            ga, gb, gc, self._dev_in.ptr if nb else None, self._in_block.ptr if nb else None, nb, int(sync)
+        rc = self.lib.pthip_plan_replay2(
+            g(sa), l(sa), g(sb), l(sb), g(sc), l(sc), self._dev_in.ptr if nb else None, self._in_block.ptr if nb else None, nb, int(sync)
         )
         if rc:
             ffi.check(rc)
@@ -413,9 +474,7 @@ class FrozenPlan:
         lib = self.lib
         try:
             lib.pthip_synchronize()
-            for ge in self._graphs:
-                lib.pthip_graph_destroy(ge)
-            self._graphs = []
+            self._release_segments()
             self._keep.clear()
             if self._arena:
                 lib.pthip_arena_destroy(self._arena)
@@ -426,6 +485,12 @@ class FrozenPlan:
                     blk.free()
         except Exception:
             pass
+
+    def _release_segments(self):
+        for kind, h in self._graphs:
+            if h:
+                (self.lib.pthip_graph_destroy if kind == "graph" else self.lib.pthip_list_destroy)(h)
+        self._graphs = []
 
     def __del__(self):
         self.close()
