@@ -1211,7 +1211,7 @@ DOTEW_MAX_K = 16384
 _MFMA16 = {"float32": "__builtin_amdgcn_mfma_f32_16x16x4f32", "float64": "__builtin_amdgcn_mfma_f64_16x16x4f64"}
 
 
-def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chunk: int = DOTEW_CHUNK) -> str:
+def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chunk: int = DOTEW_CHUNK, share=None) -> str:
     """One 16x16 output tile per workgroup of ``out = body(.., A_d @ B_d, ..)``, full K.
 
     The recurrent products of a Scan step (``h @ U``: M = batch <= a few hundred rows, K = N =
@@ -1225,6 +1225,10 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
     contiguous; A is row-major (16 rows x 64 B per instruction).  The wave partials are added in
     wave order through LDS (deterministic), then thread t owns element (t/16, t%16) of the tile
     and runs the scalar graph; operands of the epilogue are requested before the K loop.
+
+    ``share``: ``{follower dot position: leader dot position}`` — products with the SAME left
+    operand (``h @ U_r`` and ``h @ U_z``): the leader's A registers feed both MFMA chains, the
+    follower loads only its packed B (64 KB less per tile, and two independent accumulator chains).
 
     Arguments: M, N, then per body input — dot: (A, lda, Bp) | by value: bits | other:
     (ptr, stride0, stride1) — then per output (ptr, row stride)."""
@@ -1278,30 +1282,46 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
         L.append(f"  dvec4 acc{p} = {{0, 0, 0, 0}};")
         L.append(f"  const dvec4* ap{p} = (const dvec4*)(A{p} + arow * lda{p}) + ((long long)wave * {GW * 4} + kq);")
         L.append(f"  const dvec4* bp{p} = (const dvec4*)Bp{p} + ((ctile * {K // 4} + (long long)wave * {GW * 4} + kq) * 16 + li);")
-    # the stream of (dot, chunk) register buffers, double-buffered
-    chunks = []
+    # the stream of (dot group, chunk) register buffers, double-buffered; a group = a leader and
+    # the dots that share its left operand (at most one follower: register budget)
+    share = dict(share or {})
+    groups = []
     for p in dot_pos:
+        if p in share:
+            continue
+        fol = [f for f in dot_pos if share.get(f) == p][:1]
+        for f in [f for f in dot_pos if share.get(f) == p][1:]:
+            share.pop(f)  # further followers stream their own copy of A
+        groups.append([p] + fol)
+    groups += [[p] for p in dot_pos if p not in {q for g in groups for q in g}]
+    chunks = []
+    for gr in groups:
         for c0 in range(0, GW, chunk):
-            chunks.append((p, c0, min(chunk, GW - c0)))
+            chunks.append((gr, c0, min(chunk, GW - c0)))
     L.append(f"  dvec4 ra_[2][{chunk}], rb_[2][{chunk}];")
+    if any(len(gr) > 1 for gr in groups):
+        L.append(f"  dvec4 rc_[2][{chunk}];")
+    bufs = ["rb_", "rc_"]
 
     def loads(s):
-        p, c0, n = chunks[s]
+        gr, c0, n = chunks[s]
         out = []
         for u in range(n):
             g = c0 + u
-            la = f"ra_[{s & 1}][{u}] = ap{p}[{g * 4}]; rb_[{s & 1}][{u}] = bp{p}[{g * 64}];"
+            la = f"ra_[{s & 1}][{u}] = ap{gr[0]}[{g * 4}]; " + " ".join(f"{bufs[q]}[{s & 1}][{u}] = bp{p}[{g * 64}];" for q, p in enumerate(gr))
             if guard:
-                la = f"if (wave * {GW} + {g} < {G}) {{ {la} }} else {{ ra_[{s & 1}][{u}] = dvec4{{0, 0, 0, 0}}; rb_[{s & 1}][{u}] = dvec4{{0, 0, 0, 0}}; }}"
+                zero = f"ra_[{s & 1}][{u}] = dvec4{{0, 0, 0, 0}}; " + " ".join(f"{bufs[q]}[{s & 1}][{u}] = dvec4{{0, 0, 0, 0}};" for q in range(len(gr)))
+                la = f"if (wave * {GW} + {g} < {G}) {{ {la} }} else {{ {zero} }}"
             out.append("  " + la)
         return out
 
     def mfmas(s):
-        p, c0, n = chunks[s]
+        gr, c0, n = chunks[s]
         out = []
         for u in range(n):
             for j in range(4):
-                out.append(f"  acc{p} = {_MFMA16[T]}(ra_[{s & 1}][{u}][{j}], rb_[{s & 1}][{u}][{j}], acc{p}, 0, 0, 0);")
+                for q, p in enumerate(gr):
+                    out.append(f"  acc{p} = {_MFMA16[T]}(ra_[{s & 1}][{u}][{j}], {bufs[q]}[{s & 1}][{u}][{j}], acc{p}, 0, 0, 0);")
         return out
 
     # issue order: operand chunks 0 and 1, then the epilogue operands (vmcnt retires in order:

@@ -175,13 +175,21 @@ template <bool KC, int BKT> struct Stage<float, KC, BKT> {
 };
 
 __device__ __forceinline__ void tile_coords(long long tiles_m, long long tiles_n, long long& tm,
-                                            long long& tn) {
-  long long pid = blockIdx.x;
+                                            long long& tn, long long& bz) {
+  // XCD-aware remap over the whole (batch x tile) space: workgroups are dispatched x-fastest and
+  // block L runs on XCD L % 8, so XCD x gets the contiguous range [x*total/8, (x+1)*total/8) of
+  // (batch, tile) pairs — the tiles of one matrix, and the tiles of one band of a big matrix,
+  // share an L2.  (Round 1 remapped the tiles of one matrix only: the four 128x128 tiles of a
+  // 256x256 batch item landed on four XCDs and every operand was fetched from HBM twice.)
   const long long nt = tiles_m * tiles_n;
-  if (nt % 8 == 0) {  // XCD-aware remap: XCD x gets the contiguous tile range [x*nt/8, (x+1)*nt/8)
-    const long long per = nt / 8;
+  long long pid = blockIdx.x + nt * (long long)blockIdx.z;
+  const long long total = nt * (long long)gridDim.z;
+  if (total % 8 == 0) {
+    const long long per = total / 8;
     pid = (pid % 8) * per + pid / 8;
   }
+  bz = pid / nt;
+  pid -= bz * nt;
   tm = pid / tiles_n;
   tn = pid % tiles_n;
 }
@@ -205,9 +213,9 @@ __global__ __launch_bounds__(BLOCK, 2) void dgemm_kernel(
   double* As = (double*)smem_raw;                // [2][SA::SIZE]
   double* Bs = As + 2 * SA::SIZE;                // [2][SB::SIZE]
   long long tm, tn;
-  tile_coords(tiles_m, tiles_n, tm, tn);
+  long long bz;
+  tile_coords(tiles_m, tiles_n, tm, tn, bz);
   const long long m0 = tm * BM, n0 = tn * BN;
-  const long long bz = blockIdx.z;
   A += bz * sAb;
   B += bz * sBb;
   const bool split = gridDim.y > 1;
@@ -297,9 +305,9 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_kernel(
   float* As = (float*)smem_raw;
   float* Bs = As + 2 * SA::SIZE;
   long long tm, tn;
-  tile_coords(tiles_m, tiles_n, tm, tn);
+  long long bz;
+  tile_coords(tiles_m, tiles_n, tm, tn, bz);
   const long long m0 = tm * BM, n0 = tn * BN;
-  const long long bz = blockIdx.z;
   A += bz * sAb;
   B += bz * sBb;
   const bool split = gridDim.y > 1;

@@ -44,6 +44,22 @@ def dot_epilogue(node, inputs, env):
     body = node.params["scalar"]
     dpos = list(node.params["dot_inputs"])
     nb = len(body["in_dtypes"])
+    plain = node.params.get("plain")
+    if plain is not None:
+        # a product moved here because it shares this node's left operand (gemmfuse.
+        # _hoist_shared_left_operand): only when its shape equals the node's own can it ride in the
+        # same tiles; otherwise it is a plain GEMM and the node runs in its original form
+        q = plain["moved"][0]
+        Am, Bm = env.to_device(inputs[q]), env.to_device(inputs[nb + 2 * (len(dpos) - 1)])
+        q0 = plain["dot_inputs"][0]
+        A0, B0 = env.to_device(inputs[q0]), env.to_device(inputs[nb])
+        if (Am.shape[0], Bm.shape[1]) != (A0.shape[0], B0.shape[1]) or Am.shape[1] != A0.shape[1]:
+            nbp = len(plain["scalar"]["in_dtypes"])
+            sub = type("_Plain", (), {"params": {"scalar": plain["scalar"], "dot_inputs": plain["dot_inputs"]},
+                                      "inputs": list(node.inputs[:nbp]) + list(node.inputs[nb : nb + 2 * len(plain["dot_inputs"])]),
+                                      "outputs": list(node.outputs[: plain["moved"][1]])})
+            outs = dot_epilogue(sub, list(inputs[:nbp]) + list(inputs[nb : nb + 2 * len(plain["dot_inputs"])]), env)
+            return list(outs) + [gemm_device(env, 1.0, _prep2d(Am), _prep2d(Bm))]
     ins = [_scalar_or_device(env, i) for i in inputs[:nb]]
     extra = inputs[nb:]
     dots = {}
@@ -99,7 +115,17 @@ def dot_epilogue(node, inputs, env):
     # (profiles/r2f_c5_chunk.txt)
     chunk = int(os.environ.get("PTHIP_DOTEW_CHUNK", 0)) or codegen.DOTEW_CHUNK
     name = f"dotew_{_body_key(body)}_k{K}_d{'_'.join(map(str, dpos))}_u{chunk}" + ("_c" + "_".join(map(str, sorted(byvalue))) if byvalue else "")
-    src = codegen.dot_epilogue_source(name, body, dpos, K, byvalue, chunk)
+    # products with the very same left operand stream it once
+    share = {}
+    for t2, q2 in enumerate(dpos):
+        for q1 in dpos[:t2]:
+            a1, a2 = dots[q1][0], dots[q2][0]
+            if q1 not in share and a1.ptr == a2.ptr and a1.shape == a2.shape and a1.strides == a2.strides and q1 not in share.values():
+                share[q2] = q1
+                break
+    if share:
+        name += "_h" + "_".join(f"{a}.{b}" for a, b in sorted(share.items())).replace(".", "x")
+    src = codegen.dot_epilogue_source(name, body, dpos, K, byvalue, chunk, share)
     fn = kernel_cache.get_function(src, name)
     args = [M, N]
     for k, a in enumerate(ins):

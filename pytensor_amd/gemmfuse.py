@@ -319,6 +319,7 @@ def _dot_epilogue_in_scan(g: Graph, scan: Node, new_vars: dict):
             params = {"scalar": m.params["scalar"], "dot_inputs": [q for q, *_ in dots]}
             m = Node("DotEpilogue", params, ins + extra, list(m.outputs))
         nodes.append(m)
+    nodes = _hoist_shared_left_operand(inner, nodes, ivars)
     new_inner = _copy(inner, nodes)
     new_inner.vars.update(ivars)
     new_inner.inputs = list(inner.inputs) + new_inner_inputs
@@ -328,3 +329,56 @@ def _dot_epilogue_in_scan(g: Graph, scan: Node, new_vars: dict):
     params["inner"] = new_inner
     params["info"] = new_info
     return pre, Node("Scan", params, list(scan.inputs) + new_outer_inputs, list(scan.outputs))
+
+
+def _hoist_shared_left_operand(inner: Graph, nodes, ivars):
+    """``h @ U_z`` of a later ``DotEpilogue`` moves into the earlier one that already streams ``h``
+    (``h @ U_r``): the generated kernel loads the shared left operand once and runs two accumulator
+    chains (codegen.dot_epilogue_source ``share``); the moved product leaves as an extra raw output
+    and enters its old consumer as an ordinary elementwise operand.  Per GRU step: 64 KB less per
+    workgroup, and the second launch — the longer one — loses a whole product.
+
+    The earlier node keeps its original form in ``params["plain"]``: shapes are not known until
+    run time, and when the moved product's shape differs from the node's own the handler computes
+    it with a plain GEMM and runs the original body (dispatch/dotew.py)."""
+    nodes = list(nodes)
+    for j, D2 in enumerate(nodes):
+        if D2.op != "DotEpilogue" or len(D2.params["dot_inputs"]) < 2:
+            continue
+        nb2 = len(D2.params["scalar"]["in_dtypes"])
+        for i in range(j):
+            D1 = nodes[i]
+            if D1.op != "DotEpilogue" or len(D1.params["dot_inputs"]) != 1 or "plain" in D1.params:
+                continue
+            nb1 = len(D1.params["scalar"]["in_dtypes"])
+            a1 = D1.inputs[D1.params["dot_inputs"][0]]
+            hit = None
+            for t, q in enumerate(D2.params["dot_inputs"]):
+                if D2.inputs[q] == a1:
+                    hit = (t, q)
+                    break
+            if hit is None or len(D1.inputs) + 3 > MAX_INPUTS:
+                continue
+            # the operands of the moved product must exist before D1: A does (D1 reads it), its
+            # weights are loop constants (graph inputs)
+            t, q = hit
+            B, Bp = D2.inputs[nb2 + 2 * t], D2.inputs[nb2 + 2 * t + 1]
+            dt = D2.params["scalar"]["in_dtypes"][q]
+            if dt != D1.params["scalar"]["in_dtypes"][D1.params["dot_inputs"][0]]:
+                continue
+            raw = _fresh(inner, ivars, dt, (None, None), name="shared_left_product")
+            b1 = D1.params["scalar"]
+            body1 = {"in_dtypes": list(b1["in_dtypes"]) + [dt], "out_dtypes": list(b1["out_dtypes"]) + [dt],
+                     "body": b1["body"], "outs": list(b1["outs"]) + [["i", nb1]]}
+            ins1 = list(D1.inputs[:nb1]) + [a1] + list(D1.inputs[nb1:]) + [B, Bp]
+            p1 = {"scalar": body1, "dot_inputs": list(D1.params["dot_inputs"]) + [nb1],
+                  "plain": {"scalar": b1, "dot_inputs": list(D1.params["dot_inputs"]), "n_inputs": len(D1.inputs), "moved": [nb1, len(b1["out_dtypes"])]}}
+            nodes[i] = Node("DotEpilogue", p1, ins1, list(D1.outputs) + [raw])
+            # D2: the dot input becomes an elementwise operand; its (B, Bp) pair leaves
+            ins2 = list(D2.inputs)
+            ins2[q] = raw
+            del ins2[nb2 + 2 * t : nb2 + 2 * t + 2]
+            dots2 = [d for d in D2.params["dot_inputs"] if d != q]
+            nodes[j] = Node("DotEpilogue", {"scalar": D2.params["scalar"], "dot_inputs": dots2}, ins2, list(D2.outputs))
+            return _hoist_shared_left_operand(inner, nodes, ivars)  # further pairs
+    return nodes

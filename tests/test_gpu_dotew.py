@@ -49,7 +49,7 @@ def _gate_body(dt, two):
     return {"in_dtypes": [dt] * 5, "out_dtypes": [dt], "body": body, "outs": [["t", 7]]}
 
 
-def _graph(dt, two, bias_shape):
+def _graph(dt, two, bias_shape, same_left=False):
     g = Graph(name="dotew_unit")
     h = g.new_var(dt, (None, None), name="h")
     x = g.new_var(dt, (None, None), name="x")
@@ -61,12 +61,12 @@ def _graph(dt, two, bias_shape):
     ins, extra, dpos = [h, x, A, b], [W, Wp], [2]
     g.inputs = [h, x, A, b, W]
     if two:
-        A2 = g.new_var(dt, (None, None), name="A2")
+        A2 = A if same_left else g.new_var(dt, (None, None), name="A2")
         W2 = g.new_var(dt, (None, None), name="W2")
         W2p = g.new_var(dt, (None,))
         g.add_node("PackB16", {}, [W2], [W2p])
         ins, extra, dpos = ins + [A2], extra + [W2, W2p], [2, 4]
-        g.inputs += [A2, W2]
+        g.inputs += [W2] if same_left else [A2, W2]
     body = _gate_body(dt, two)
     outs = [g.new_var(dt, (None, None)) for _ in body["out_dtypes"]]
     g.add_node("DotEpilogue", {"scalar": body, "dot_inputs": dpos}, ins + extra, outs)
@@ -84,6 +84,8 @@ CASES = [
     ("float64", 33, 80, 17, False, (1, None), True),     # A rows 16-byte aligned inside a wider buffer
     ("float32", 7, 24, 9, False, (1, None), False),      # K % 16 != 0: GEMM + Elemwise path
     ("float64", 3, 37, 5, True, (1, None), False),       # same, two products
+    ("float32", 64, 1024, 1024, True, (1, None), "same_left"),  # h@U_r and h@U_z: the left operand streamed once
+    ("float64", 21, 48, 33, True, (1, None), "same_left"),
 ]
 
 
@@ -92,7 +94,9 @@ def test_dot_epilogue_matches_oracle(hip, dt, M, K, N, two, bshape, strided):
     from pytensor_amd.executor import HipExecutable
 
     rng = np.random.default_rng(M * 131 + K * 7 + N)
-    g = _graph(dt, two, bshape)
+    same_left = strided == "same_left"
+    strided = strided is True
+    g = _graph(dt, two, bshape, same_left)
     h = rng.normal(size=(M, N)).astype(dt)
     x = rng.normal(size=(M, N)).astype(dt)
     if strided:
@@ -102,7 +106,9 @@ def test_dot_epilogue_matches_oracle(hip, dt, M, K, N, two, bshape, strided):
     b = rng.normal(size=tuple(1 if s == 1 else (N if k == 1 else M) for k, s in enumerate(bshape))).astype(dt)
     W = (rng.normal(size=(K, N)) / np.sqrt(K)).astype(dt)
     ins = [h, x, A, b, W]
-    if two:
+    if two and same_left:
+        ins += [(rng.normal(size=(K, N)) / np.sqrt(K)).astype(dt)]
+    elif two:
         ins += [rng.normal(size=(M, K)).astype(dt), (rng.normal(size=(K, N)) / np.sqrt(K)).astype(dt)]
     want = np_graph.run_graph(g, ins)
     exe = HipExecutable(g, fuse=False)
@@ -113,7 +119,7 @@ def test_dot_epilogue_matches_oracle(hip, dt, M, K, N, two, bshape, strided):
     # up to the factor |h| <= ~5 of the final multiply
     absdot = np.abs(A) @ np.abs(W)
     if two:
-        absdot = absdot + np.abs(ins[5]) @ np.abs(ins[6])
+        absdot = absdot + (np.abs(A) @ np.abs(ins[5]) if same_left else np.abs(ins[5]) @ np.abs(ins[6]))
     atol = bounds.C_SUM * eps * absdot * (1.0 + np.abs(h))
     for a, w in zip(got, want):
         assert a.shape == w.shape and a.dtype == w.dtype
