@@ -415,6 +415,131 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_kernel(
       }
 }
 
+// ---------------------------------------------------------------------------------
+// fp32, persistent tiles
+// ---------------------------------------------------------------------------------
+// Two workgroups per CU walk the (batch x tile) space; the first K-tile of a workgroup's NEXT
+// output tile is requested during the last K-step of the current one, and the epilogue stores of a
+// tile overlap the first MFMA steps of the next.  With one launch-wide wave of identical
+// workgroups every prologue (two global-load latencies before the first MFMA) and every epilogue
+// (64 KB of stores) of the co-resident workgroups coincide — nothing to overlap them with; at
+// K = 256 (8 K-steps per tile) that is a quarter of a tile's life (config #3 BatchedDot:
+// 512 x 256^3).  No split-K, M > 64 only (the one-tile-per-workgroup kernel above keeps those).
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(BLOCK, 2) void sgemm_persistent_kernel(
+    float* __restrict__ out, const float* __restrict__ A, const float* __restrict__ B,
+    const float* __restrict__ C, long long M, long long N, long long K, long long lda,
+    long long ldb, long long sAb, long long sBb, long long sCb, long long sC0, long long sC1,
+    float alpha, float beta, long long tiles_m, long long tiles_n, int vecA, int vecB,
+    long long batch) {
+  constexpr int BKT = 32;
+  using SA = Stage<float, AKC, BKT>;
+  using SB = Stage<float, BKC, BKT>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* As = (float*)smem_raw;
+  float* Bs = As + 2 * SA::SIZE;
+  const long long nt = tiles_m * tiles_n, total = nt * batch;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wm0 = (w >> 1) * 64, wn0 = (w & 1) * 64;
+  const long long nk = (K + BKT - 1) / BKT;
+  auto coords = [&](long long L, long long& m0, long long& n0, long long& bz) {
+    long long pid = L;
+    if (total % 8 == 0) {  // XCD x walks the contiguous range [x*total/8, (x+1)*total/8)
+      const long long per = total / 8;
+      pid = (L % 8) * per + L / 8;
+    }
+    bz = pid / nt;
+    pid -= bz * nt;
+    m0 = (pid / tiles_n) * BM;
+    n0 = (pid % tiles_n) * BN;
+  };
+  long long L = blockIdx.x;
+  if (L >= total) return;
+  long long m0, n0, bz;
+  coords(L, m0, n0, bz);
+  SA sa;
+  SB sb;
+  sa.load(A + bz * sAb, lda, m0, 0, M, K, vecA);
+  sb.load(B + bz * sBb, ldb, n0, 0, N, K, vecB);
+  sa.store(As);
+  sb.store(Bs);
+  __syncthreads();
+  int buf = 0;
+  const bool has_c = (beta != 0.f) && C != nullptr;
+  for (;;) {
+    const long long Ln = L + gridDim.x;
+    const bool has_next = Ln < total;
+    long long m1 = 0, n1 = 0, b1 = 0;
+    if (has_next) coords(Ln, m1, n1, b1);
+    float16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    const float* Ab = A + bz * sAb;
+    const float* Bb = B + bz * sBb;
+    for (long long kt = 0; kt < nk; kt++) {
+      const bool more = kt + 1 < nk;
+      if (more) {
+        sa.load(Ab, lda, m0, (kt + 1) * BKT, M, K, vecA);
+        sb.load(Bb, ldb, n0, (kt + 1) * BKT, N, K, vecB);
+      } else if (has_next) {  // the next tile's first K-tile, behind this tile's last MFMA step
+        sa.load(A + b1 * sAb, lda, m1, 0, M, K, vecA);
+        sb.load(B + b1 * sBb, ldb, n1, 0, N, K, vecB);
+      }
+      const float* as = As + buf * SA::SIZE;
+      const float* bs = Bs + buf * SB::SIZE;
+#pragma unroll
+      for (int kk = 0; kk < BKT / 4; kk++) {
+        float2 af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) af[i] = SA::frag2(as, wm0 + i * 32, kk, lane);
+#pragma unroll
+        for (int j = 0; j < 2; j++) bf[j] = SB::frag2(bs, wn0 + j * 32, kk, lane);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+      }
+      if (more || has_next) {
+        sa.store(As + (buf ^ 1) * SA::SIZE);
+        sb.store(Bs + (buf ^ 1) * SB::SIZE);
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
+    float* ob = out + bz * M * N;
+    const float* Cb = has_c ? C + bz * sCb : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const long long row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const long long col = n0 + wn0 + j * 32 + (lane & 31);
+          if (row < M && col < N) {
+            float v = alpha * acc[i][j][r];
+            if (has_c) v += beta * Cb[row * sC0 + col * sC1];
+            ob[row * N + col] = v;
+          }
+        }
+    if (!has_next) break;
+    L = Ln;
+    m0 = m1;
+    n0 = n1;
+    bz = b1;
+  }
+}
+
 // out[b][m][n] = alpha * sum_s part[s][b][m][n] + beta * C[b][m][n]   (fixed order over s)
 template <class T>
 __global__ __launch_bounds__(BLOCK) void splitk_finish_kernel(
@@ -503,6 +628,24 @@ int launch(long long batch, long long M, long long N, long long K, T alpha, cons
     return pthip::post_launch("gemm(partials)");
   }
   if (nsplit == 1) {
+    if constexpr (sizeof(T) == 4 && !SKINNY && BKT == 32) {
+      // more tiles than resident workgroups: the persistent kernel (prologues / epilogues of
+      // consecutive tiles overlap).  PTHIP_SGEMM_PERSIST=0 keeps one tile per workgroup.
+      static const bool persist = !(getenv("PTHIP_SGEMM_PERSIST") && atoi(getenv("PTHIP_SGEMM_PERSIST")) == 0);
+      const long long total = tiles_m * tiles_n * batch, resident = (long long)pthip::kNumCU * 2;
+      if (persist && total > resident) {
+        static bool attr_p = false;
+        auto kp = sgemm_persistent_kernel<AKC, BKC>;
+        if (!attr_p && shmem > 64 * 1024) {
+          PTHIP_CHECK(hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+          attr_p = true;
+        }
+        PTHIP_KLAUNCH(kp, dim3((unsigned)resident), dim3(BLOCK), shmem, st, (float*)out, (const float*)A, (const float*)B,
+                      (const float*)C, M, N, K, lda, ldb, sAb, sBb, sCb, sC0, sC1, (float)alpha, (float)beta, tiles_m, tiles_n,
+                      vecA, vecB, batch);
+        return pthip::post_launch("gemm(persistent)");
+      }
+    }
     PTHIP_KLAUNCH(k, grid, dim3(BLOCK), shmem, st, out, A, B, C, M, N, K, lda, ldb, sAb, sBb,
                        sCb, sC0, sC1, alpha, beta, tiles_m, tiles_n, vecA, vecB, kchunk);
     return pthip::post_launch("gemm");
