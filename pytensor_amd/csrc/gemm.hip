@@ -425,7 +425,10 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_kernel(
 // (64 KB of stores) of the co-resident workgroups coincide — nothing to overlap them with; at
 // K = 256 (8 K-steps per tile) that is a quarter of a tile's life (config #3 BatchedDot:
 // 512 x 256^3).  No split-K, M > 64 only (the one-tile-per-workgroup kernel above keeps those).
-template <bool AKC, bool BKC>
+// DIAG (timing experiments only, results invalid when != 0; PTHIP_SGEMM_DIAG): 1 = no global loads
+// after the first K-tile, 2 = also no LDS staging stores, 3 = also no LDS fragment reads (operands
+// from registers) — what the MFMA loop sustains with each feeder removed.
+template <bool AKC, bool BKC, int DIAG = 0>
 __global__ __launch_bounds__(BLOCK, 2) void sgemm_persistent_kernel(
     float* __restrict__ out, const float* __restrict__ A, const float* __restrict__ B,
     const float* __restrict__ C, long long M, long long N, long long K, long long lda,
@@ -482,34 +485,60 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_persistent_kernel(
     const float* Bb = B + bz * sBb;
     for (long long kt = 0; kt < nk; kt++) {
       const bool more = kt + 1 < nk;
-      if (more) {
-        sa.load(Ab, lda, m0, (kt + 1) * BKT, M, K, vecA);
-        sb.load(Bb, ldb, n0, (kt + 1) * BKT, N, K, vecB);
-      } else if (has_next) {  // the next tile's first K-tile, behind this tile's last MFMA step
-        sa.load(A + b1 * sAb, lda, m1, 0, M, K, vecA);
-        sb.load(B + b1 * sBb, ldb, n1, 0, N, K, vecB);
+      if constexpr (DIAG == 0) {
+        if (more) {
+          sa.load(Ab, lda, m0, (kt + 1) * BKT, M, K, vecA);
+          sb.load(Bb, ldb, n0, (kt + 1) * BKT, N, K, vecB);
+        } else if (has_next) {  // the next tile's first K-tile, behind this tile's last MFMA step
+          sa.load(A + b1 * sAb, lda, m1, 0, M, K, vecA);
+          sb.load(B + b1 * sBb, ldb, n1, 0, N, K, vecB);
+        }
       }
       const float* as = As + buf * SA::SIZE;
       const float* bs = Bs + buf * SB::SIZE;
+      // fragment reads one kk step AHEAD of the MFMAs that use them (two register sets): the
+      // straightforward loop compiled to ds_read -> s_waitcnt lgkmcnt(0) -> MFMA for every group,
+      // ~100 exposed LDS-latency cycles per 2-4 MFMAs (r2t diagnostic: operands from registers
+      // instead of LDS ran 138 vs 107 TFLOP/s at 4096^3)
+      float2 af[2][2], bf[2][2];
+      if constexpr (DIAG >= 3) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) { af[0][i] = make_float2(sa.v[0].x + i, sa.v[0].y); bf[0][i] = make_float2(sb.v[0].x + i, sb.v[0].y); }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; i++) af[0][i] = SA::frag2(as, wm0 + i * 32, 0, lane);
+#pragma unroll
+        for (int j = 0; j < 2; j++) bf[0][j] = SB::frag2(bs, wn0 + j * 32, 0, lane);
+      }
 #pragma unroll
       for (int kk = 0; kk < BKT / 4; kk++) {
-        float2 af[2], bf[2];
+        const int cs = kk & 1, ns = cs ^ 1;
+        if (kk + 1 < BKT / 4) {
+          if constexpr (DIAG >= 3) {
 #pragma unroll
-        for (int i = 0; i < 2; i++) af[i] = SA::frag2(as, wm0 + i * 32, kk, lane);
+            for (int i = 0; i < 2; i++) { af[ns][i] = make_float2(af[cs][i].y, af[cs][i].x + kk); bf[ns][i] = make_float2(bf[cs][i].y, bf[cs][i].x - kk); }
+          } else {
 #pragma unroll
-        for (int j = 0; j < 2; j++) bf[j] = SB::frag2(bs, wn0 + j * 32, kk, lane);
+            for (int i = 0; i < 2; i++) af[ns][i] = SA::frag2(as, wm0 + i * 32, kk + 1, lane);
+#pragma unroll
+            for (int j = 0; j < 2; j++) bf[ns][j] = SB::frag2(bs, wn0 + j * 32, kk + 1, lane);
+          }
+        }
+        // (without the fences the machine scheduler sinks each read back next to its use)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
           for (int j = 0; j < 2; j++)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cs][i].x, bf[cs][j].x, acc[i][j], 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
           for (int j = 0; j < 2; j++)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cs][i].y, bf[cs][j].y, acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (more || has_next) {
+      if ((more || has_next) && DIAG < 2) {
         sa.store(As + (buf ^ 1) * SA::SIZE);
         sb.store(Bs + (buf ^ 1) * SB::SIZE);
       }
@@ -518,20 +547,35 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_persistent_kernel(
     }
     float* ob = out + bz * M * N;
     const float* Cb = has_c ? C + bz * sCb : nullptr;
+    if (!has_c && m0 + BM <= M && n0 + BN <= N) {
+      // interior tile, no C operand (workgroup-uniform test): 64 unconditional stores per lane
+      // instead of 64 exec-masked branches
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+      for (int i = 0; i < 2; i++)
 #pragma unroll
-      for (int j = 0; j < 2; j++)
+        for (int j = 0; j < 2; j++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const long long row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const long long col = n0 + wn0 + j * 32 + (lane & 31);
-          if (row < M && col < N) {
-            float v = alpha * acc[i][j][r];
-            if (has_c) v += beta * Cb[row * sC0 + col * sC1];
-            ob[row * N + col] = v;
+          for (int r = 0; r < 16; r++) {
+            const long long row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const long long col = n0 + wn0 + j * 32 + (lane & 31);
+            ob[row * N + col] = alpha * acc[i][j][r];
           }
-        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const long long row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const long long col = n0 + wn0 + j * 32 + (lane & 31);
+            if (row < M && col < N) {
+              float v = alpha * acc[i][j][r];
+              if (has_c) v += beta * Cb[row * sC0 + col * sC1];
+              ob[row * N + col] = v;
+            }
+          }
+    }
     if (!has_next) break;
     L = Ln;
     m0 = m1;
@@ -635,7 +679,9 @@ int launch(long long batch, long long M, long long N, long long K, T alpha, cons
       const long long total = tiles_m * tiles_n * batch, resident = (long long)pthip::kNumCU * 2;
       if (persist && total > resident) {
         static bool attr_p = false;
-        auto kp = sgemm_persistent_kernel<AKC, BKC>;
+        static const int diag = getenv("PTHIP_SGEMM_DIAG") ? atoi(getenv("PTHIP_SGEMM_DIAG")) : 0;
+        auto kp = diag == 1 ? sgemm_persistent_kernel<AKC, BKC, 1> : diag == 2 ? sgemm_persistent_kernel<AKC, BKC, 2>
+                  : diag == 3 ? sgemm_persistent_kernel<AKC, BKC, 3> : sgemm_persistent_kernel<AKC, BKC, 0>;
         if (!attr_p && shmem > 64 * 1024) {
           PTHIP_CHECK(hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
           attr_p = true;
