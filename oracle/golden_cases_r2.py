@@ -232,3 +232,31 @@ def solve_sym_eigh_generalised():
     Av = np.triu(sym()) + np.tril(sym(), -1)
     Bv = np.triu(spd()) + np.tril(spd(), -1)
     return [A, Bm, b, R], outs, {"A": Av, "B": Bv, "b": rng.normal(size=n), "R": rng.normal(size=(n, 3))}
+
+
+@case("wide_terms")
+def wide_terms():
+    # "the harness should also include a wide synthetic model" — north_star's
+    # "≈200 fused Elemwise" scale in miniature: 12 independent likelihood terms of four families,
+    # logp and its gradient wrt 24 parameters.  Per term one fused Elemwise+Sum kernel and scalar
+    # IncSubtensor bookkeeping (widefuse.py: one MultiElemwise launch + one tail kernel).
+    rng = np.random.default_rng(73)
+    T, N = 12, 301
+    mu, ls = pt.dvector("mu"), pt.dvector("ls")
+    ys = [pt.dvector(f"y{k}") for k in range(T)]
+    terms = []
+    for k in range(T):
+        r = (ys[k] - mu[k]) * pt.exp(-ls[k])
+        fam = k % 4
+        if fam == 0:
+            terms.append((-0.5 * r**2 - ls[k]).sum())
+        elif fam == 1:
+            terms.append((-pt.log1p(r**2 / 3.0) * 2.0 - ls[k]).sum())
+        elif fam == 2:
+            terms.append((-pt.abs(r) - ls[k]).sum())
+        else:
+            terms.append((-r - 2.0 * pt.softplus(-r) - ls[k]).sum())
+    logp = pt.add(*terms)
+    vals = {"mu": rng.normal(size=T) * 0.1, "ls": rng.normal(size=T) * 0.1}
+    vals.update({f"y{k}": rng.normal(size=N + 7 * k) + 0.1 * k for k in range(T)})  # ragged lengths
+    return [mu, ls, *ys], [logp, *pytensor.grad(logp, [mu, ls])], vals

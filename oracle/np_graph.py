@@ -1086,6 +1086,34 @@ def _pivot_to_permutations(p, inputs, node, graph):
     return [out]
 
 
+@op("ScatterScalars")
+def _scatter_scalars(p, inputs, node, graph):
+    # widefuse.collect_scalar_updates: a chain of IncSubtensor nodes (subtensor.py:1441 perform:
+    # x[idx] = y / x[idx] += y on a copy), one element each at a constant index, in chain order
+    if p.get("base_fill") is not None:  # base = alloc(fill, n), not materialised by the fused node
+        out = np.full((int(inputs[0]),), p["base_fill"], dtype=graph.vars[node.outputs[0]].dtype)
+    else:
+        out = np.array(inputs[0], copy=True)
+    for k, is_set, y in zip(p["indices"], p["set"], inputs[1:]):
+        if is_set:
+            out[k] = y
+        else:
+            out[k] += y
+    return [out]
+
+
+@op("MultiElemwise")
+def _multi_elemwise(p, inputs, node, graph):
+    # widefuse.fuse_independent_reductions: independent ElemwiseReduce nodes in one launch; the
+    # values are the members' own
+    res, pos = [], 0
+    for t in p["terms"]:
+        ins = inputs[pos : pos + t["n_inputs"]]
+        pos += t["n_inputs"]
+        res += _elemwise_reduce({"scalar": t["scalar"], "reduce": t["reduce"]}, list(ins), node, graph)
+    return res
+
+
 @op("AllReduce")
 def _all_reduce(p, inputs, node, graph):
     # pytensor_amd/collective.py AllReduce.perform: element-wise reduction over the ranks of the

@@ -766,16 +766,7 @@ def _stream_load(ptr_expr: str, struct=False) -> str:
     return f"*({ptr_expr})"
 
 
-def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=None, unroll=2) -> str:
-    """``flat`` loop.  ``modes[k]`` ∈ {'V' contiguous vector, 'S' scalar broadcast} per input.
-
-    reduce_spec: None or list (per output) of None | (op_name, acc_dtype): reduced
-    outputs are accumulated instead of stored; the kernel then takes one partial
-    pointer per reduced output (laid out [gridDim.x]).
-    """
-    nin = len(body["in_dtypes"])
-    nout = len(body["out_dtypes"])
-    reduce_spec = reduce_spec or [None] * nout
+def _flat_params(body: dict, modes: str, reduce_spec, vec: int):
     params = ["long long n"]
     for k, dt in enumerate(body["in_dtypes"]):
         if modes[k] == "C":  # host-known scalar: travels by value in the argument block
@@ -792,8 +783,29 @@ def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=
     if "G" in modes:
         assert vec == 1, "gather inputs use the scalar loop"
         params.append("int* __restrict__ status")
-    src = [reduce_header() if any(reduce_spec) else "", prelude_for(body), VEC_HELPERS]
-    src.append(f'extern "C" __global__ __launch_bounds__({BLOCK}) void {name}({", ".join(params)}) {{')
+    return params
+
+
+def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=None, unroll=2, device_fn=False) -> str:
+    """``flat`` loop.  ``modes[k]`` ∈ {'V' contiguous vector, 'S' scalar broadcast} per input.
+
+    reduce_spec: None or list (per output) of None | (op_name, acc_dtype): reduced
+    outputs are accumulated instead of stored; the kernel then takes one partial
+    pointer per reduced output (laid out [gridDim.x]).
+
+    ``device_fn``: emit the loop as a ``__device__`` function taking the workgroup index and count as
+    two trailing arguments, without the headers (``multi_flat_source`` dispatches several of them
+    from one launch).
+    """
+    nin = len(body["in_dtypes"])
+    nout = len(body["out_dtypes"])
+    reduce_spec = reduce_spec or [None] * nout
+    params = _flat_params(body, modes, reduce_spec, vec)
+    if device_fn:
+        src = [f"static __device__ __forceinline__ void {name}({', '.join(params)}, const unsigned pt_bidx, const unsigned pt_gdim) {{"]
+    else:
+        src = [reduce_header() if any(reduce_spec) else "", prelude_for(body), VEC_HELPERS]
+        src.append(f'extern "C" __global__ __launch_bounds__({BLOCK}) void {name}({", ".join(params)}) {{')
     # scalars
     for k, m in enumerate(modes):
         if m == "S":
@@ -854,7 +866,44 @@ def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=
         src.append("  }")
     src.append(_reduce_epilogue(reduce_spec, unroll))
     src.append("}")
-    return "\n".join(src)
+    text = "\n".join(src)
+    if device_fn:
+        text = text.replace("blockIdx.x", "pt_bidx").replace("gridDim.x", "pt_gdim")
+    return text
+
+
+def multi_flat_source(name: str, terms) -> str:
+    """Several independent flat kernels in ONE launch (widefuse.fuse_independent_reductions):
+    ``blockIdx.y`` selects the term, ``blockIdx.x`` / ``gridDim.x`` are the workgroup index / count
+    within it.  ``terms``: ``[{body, modes, vec, rs, unroll}]``; terms with the same (body, modes,
+    vec, reductions) share one device function.  Arguments: the terms' flat-kernel arguments, one
+    term after the other."""
+    bodies = [t["body"] for t in terms]
+    head = [reduce_header(), prelude_for(*bodies), VEC_HELPERS]
+    fns, fn_of = {}, []
+    for t in terms:
+        key = source_key(repr((t["body"], t["modes"], t["vec"], t["rs"], t["unroll"])))
+        if key not in fns:
+            fname = f"mt_{key[:12]}"
+            fns[key] = (fname, flat_kernel_source(fname, t["body"], t["modes"], t["vec"], t["rs"], t["unroll"], device_fn=True))
+        fn_of.append(fns[key][0])
+    P, calls = [], []
+    for ti, t in enumerate(terms):
+        ps = _flat_params(t["body"], t["modes"], t["rs"], t["vec"])
+        names = []
+        for q, prm in enumerate(ps):
+            decl, nm = prm.rsplit(" ", 1)
+            P.append(f"{decl} t{ti}_{nm}")
+            names.append(f"t{ti}_{nm}")
+        calls.append(f"    case {ti}: {fn_of[ti]}({', '.join(names)}, blockIdx.x, gridDim.x); break;")
+    L = head + [f for _, f in fns.values()]
+    L.append(f'extern "C" __global__ __launch_bounds__({BLOCK}) void {name}({", ".join(P)}) {{')
+    L.append("  switch (blockIdx.y) {")
+    L += calls
+    L.append("    default: break;")
+    L.append("  }")
+    L.append("}")
+    return "\n".join(L)
 
 
 def _flat_scalar_block(body, modes, reduce_spec, V, pvar):
@@ -1393,8 +1442,11 @@ def tail_chain_source(name: str, spec: dict, sizes: dict | None = None) -> str:
             P += [f"const {ct}* __restrict__ e{k}", f"const long long es{k}"]
         else:
             P.append(f"const {ct}* __restrict__ e{k}")
+    # one-element slots sit at static offsets (16 B apart, first in the LDS block): a wide graph has
+    # hundreds of them and the kernel-argument block is 4 KB; vector slots get run-time offsets
     for k in range(len(slots)):
-        P += [f"const long long off{k}"]
+        if not slots[k].get("scalar"):
+            P += [f"const long long off{k}"]
     for j, st in enumerate(steps):
         if st["op"] == "finish":
             P += [f"const long long rows{j}", f"const long long M{j}", f"const double alpha{j}", f"const double beta{j}"]
@@ -1417,9 +1469,14 @@ def tail_chain_source(name: str, spec: dict, sizes: dict | None = None) -> str:
         if e["kind"] == "C":
             ct = CTYPE[e["dtype"]]
             L.append(f"  {ct} c{k}; {{ const long long b = ec{k}; __builtin_memcpy(&c{k}, &b, sizeof({ct})); }}")
+    n_sc = 0
     for k, s in enumerate(slots):
         ct = CTYPE[s["dtype"]]
-        L.append(f"  {ct}* const l{k} = ({ct}*)(lds_ + off{k});")
+        if s.get("scalar"):
+            L.append(f"  {ct}* const l{k} = ({ct}*)(lds_ + {16 * n_sc});")
+            n_sc += 1
+        else:
+            L.append(f"  {ct}* const l{k} = ({ct}*)(lds_ + off{k});")
 
     def operand(ref, mode, i="i"):
         kind, k = ref
@@ -1458,6 +1515,16 @@ def tail_chain_source(name: str, spec: dict, sizes: dict | None = None) -> str:
             L.append(f"    for (long long p = tid; p < rows{j}; p += {TAIL_BLOCK}) a = pthip_dev::{op}::apply(a, ({act}){src}[p]);")
             L.append(f"    a = pthip_dev::block_reduce<pthip_dev::{op}, {act}, {TAIL_BLOCK}, true>(a, ({act}*)red_);")
             L.append(f"    if (tid == 0) l{st['out']}[0] = ({oct_})a;")
+            L.append("  }")
+            L.append("  __syncthreads();")
+        elif st["op"] == "scatter":
+            ct = CTYPE[st["dtype"]]
+            L.append(f"  // step {j}: a chain of one-element IncSubtensor updates (widefuse.collect_scalar_updates)")
+            L.append(f"  for (long long i = tid; i < n{j}; i += {TAIL_BLOCK}) l{st['out']}[i] = ({ct}){operand(st['base'], st['bmode'])};")
+            L.append("  __syncthreads();")
+            L.append("  if (tid == 0) {")
+            for k, is_set, y in zip(st["indices"], st["set"], st["ys"]):
+                L.append(f"    l{st['out']}[{k}] {'=' if is_set else '+='} ({ct}){operand(y, 'S')};")
             L.append("  }")
             L.append("  __syncthreads();")
         else:
@@ -1515,12 +1582,14 @@ def tail_preload_sizes(spec: dict, ext_len, step_n):
             regs += R * cl(M)
         elif st["op"] == "rsum":
             su.append(cl(n))
-            regs += cl(n)
+            regs += cl(n) if n > 64 else 0  # (<= 64 partials: one value in ONE wave's lanes, see "wave")
         else:
             su.append(cl(n))
     if regs > TAIL_PRELOAD_MAX_REGS or any((u[0] > 64 or u[1] > 4) if isinstance(u, tuple) else u > 16 for u in su) or any(u > 16 for u in eu):
         return None
-    return {"ext_u": eu, "step_u": su}
+    # deferred reductions over <= 64 partials are folded by single waves, four at a time
+    wave = [st["op"] == "rsum" and int(n) <= 64 for st, n in zip(steps, step_n)]
+    return {"ext_u": eu, "step_u": su, "wave": wave}
 
 
 def _tail_preload_source(name: str, spec: dict, sizes: dict, P, bodies) -> str:
@@ -1539,9 +1608,14 @@ def _tail_preload_source(name: str, spec: dict, sizes: dict, P, bodies) -> str:
         ct = CTYPE[e["dtype"]]
         if e["kind"] == "C":
             L.append(f"  {ct} c{k}; {{ const long long b = ec{k}; __builtin_memcpy(&c{k}, &b, sizeof({ct})); }}")
+    n_sc = 0
     for k, s in enumerate(slots):
         ct = CTYPE[s["dtype"]]
-        L.append(f"  {ct}* const l{k} = ({ct}*)(lds_ + off{k});")
+        if s.get("scalar"):
+            L.append(f"  {ct}* const l{k} = ({ct}*)(lds_ + {16 * n_sc});")
+            n_sc += 1
+        else:
+            L.append(f"  {ct}* const l{k} = ({ct}*)(lds_ + off{k});")
     # ---- phase 0: every global operand in flight ------------------------------------------
     used_len = {}  # V external -> name of its length (first elementwise step reading it as a vector)
     for j, st in enumerate(steps):
@@ -1551,6 +1625,8 @@ def _tail_preload_source(name: str, spec: dict, sizes: dict, P, bodies) -> str:
                     used_len.setdefault(ref[1], f"n{j}")
         elif st["op"] == "finish" and st.get("y") is not None and st["y"][0] == "e" and st["ymode"] == "V":
             used_len.setdefault(st["y"][1], f"M{j}")
+        elif st["op"] == "scatter" and st["base"][0] == "e" and st["bmode"] == "V" and ext[st["base"][1]]["kind"] == "V":
+            used_len.setdefault(st["base"][1], f"n{j}")
     for k, e in enumerate(ext):
         ct = CTYPE[e["dtype"]]
         if e["kind"] == "S":
@@ -1561,6 +1637,7 @@ def _tail_preload_source(name: str, spec: dict, sizes: dict, P, bodies) -> str:
                 for u in range(eu[k]):
                     # clamped, unconditional (a predicated load becomes an exec-masked branch with its own wait)
                     L.append(f"  const {ct} v{k}_{u} = e{k}[(tid + {u * TAIL_BLOCK} < {used_len[k]} ? (long long)(tid + {u * TAIL_BLOCK}) : {used_len[k]} - 1) * es{k}];")
+    wave = sizes.get("wave") or [False] * len(steps)
     for j, st in enumerate(steps):
         if st["op"] == "finish":
             ct = CTYPE[st["dtype"]]
@@ -1569,12 +1646,37 @@ def _tail_preload_source(name: str, spec: dict, sizes: dict, P, bodies) -> str:
             for u in range(U):
                 for r in range(R):
                     L.append(f"  {ct} f{j}_{u}_{r} = {src}[({r} < rows{j} ? {r} : rows{j} - 1) * M{j} + (tid + {u * TAIL_BLOCK} < M{j} ? tid + {u * TAIL_BLOCK} : M{j} - 1)];")
-        elif st["op"] == "rsum":
+        elif st["op"] == "rsum" and not wave[j]:
             act = CTYPE[st["acc_dtype"]]
             op = REDUCE_OPS[st["red"]]
             src = f"e{st['src'][1]}"
             for u in range(su[j]):
                 L.append(f"  {act} p{j}_{u} = ({act}){src}[tid + {u * TAIL_BLOCK} < rows{j} ? tid + {u * TAIL_BLOCK} : rows{j} - 1];")
+    # deferred second stages over <= 64 partials: wave w folds every fourth of them with shuffles —
+    # no LDS scratch, no barrier per reduction (a wide graph hands over ~3 per likelihood term)
+    wsteps = [j for j, st in enumerate(steps) if st["op"] == "rsum" and wave[j]]
+    if wsteps:
+        L.append("  {")
+        L.append("    const int wv_ = tid >> 6, ln_ = tid & 63;")
+        for w in range(TAIL_BLOCK // 64):
+            mine = wsteps[w :: TAIL_BLOCK // 64]
+            if not mine:
+                continue
+            L.append(f"    if (wv_ == {w}) {{")
+            for j in mine:
+                st = steps[j]
+                act = CTYPE[st["acc_dtype"]]
+                L.append(f"      {act} w{j} = ({act})e{st['src'][1]}[ln_ < rows{j} ? ln_ : rows{j} - 1];")
+            L.append("      __builtin_amdgcn_sched_barrier(0);")
+            for j in mine:
+                st = steps[j]
+                act, oct_ = CTYPE[st["acc_dtype"]], CTYPE[st["dtype"]]
+                op = REDUCE_OPS[st["red"]]
+                L.append(f"      if (ln_ >= rows{j}) w{j} = pthip_dev::{op}::identity<{act}>();")
+                L.append(f"      w{j} = pthip_dev::wave_reduce<pthip_dev::{op}>(w{j});")
+                L.append(f"      if (ln_ == 0) l{st['out']}[0] = ({oct_})w{j};")
+            L.append("    }")
+        L.append("  }")
     L.append("  __builtin_amdgcn_sched_barrier(0);")
     for j, st in enumerate(steps):
         if st["op"] == "finish":
@@ -1582,7 +1684,7 @@ def _tail_preload_source(name: str, spec: dict, sizes: dict, P, bodies) -> str:
             for u in range(U):
                 for r in range(R):
                     L.append(f"  if ({r} >= rows{j}) f{j}_{u}_{r} = 0;")
-        elif st["op"] == "rsum":
+        elif st["op"] == "rsum" and not wave[j]:
             act = CTYPE[st["acc_dtype"]]
             for u in range(su[j]):
                 L.append(f"  if (tid + {u * TAIL_BLOCK} >= rows{j}) p{j}_{u} = pthip_dev::{REDUCE_OPS[st['red']]}::identity<{act}>();")
@@ -1598,62 +1700,106 @@ def _tail_preload_source(name: str, spec: dict, sizes: dict, P, bodies) -> str:
             return f"s{k}"
         return f"l{k}[tid + {u * TAIL_BLOCK}]" if mode == "V" else f"l{k}[0]"
 
+    # phases: a step reads LDS slots written in earlier phases only, so the steps of one phase need
+    # no barrier between them (slots are written once); one __syncthreads() per phase instead of one
+    # per step — the scalar bookkeeping of a wide graph is dozens of independent one-element steps
+    def lds_reads(st):
+        refs = []
+        if st["op"] == "finish" and st.get("y") is not None:
+            refs.append(st["y"])
+        elif st["op"] == "ew":
+            refs += list(st["ins"])
+        elif st["op"] == "scatter":
+            refs += [st["base"], *st["ys"]]
+        return [r[1] for r in refs if r[0] == "l"]
+
+    def lds_writes(st):
+        return list(st["outs"]) if st["op"] == "ew" else [st["out"]]
+
+    writer, phase = {}, []
     for j, st in enumerate(steps):
-        if st["op"] == "finish":
-            ct = CTYPE[st["dtype"]]
-            R, U = su[j]
-            L.append(f"  // step {j}: second stage + epilogue of a split Gemv / scatter-add (rows even/odd, then the pair: the order of the looping form)")
-            for u in range(U):
-                L.append(f"  if (tid + {u * TAIL_BLOCK} < M{j}) {{")
-                L.append(f"    {ct} a0 = 0, a1 = 0;")
-                for r in range(0, R, 2):
-                    L.append(f"    a0 += f{j}_{u}_{r}; a1 += f{j}_{u}_{r + 1};")
-                L.append(f"    {ct} r = ({ct})alpha{j} * (a0 + a1);")
-                if st.get("y") is not None:
-                    L.append(f"    if (beta{j} != 0.0) r += ({ct})beta{j} * ({ct}){operand(st['y'], st['ymode'], u)};")
-                L.append(f"    l{st['out']}[tid + {u * TAIL_BLOCK}] = r;")
+        ph = 0
+        for k in lds_reads(st):
+            if k in writer:
+                ph = max(ph, phase[writer[k]] + 1)
+        if st["op"] == "rsum" and wave[j]:
+            ph = 0
+        phase.append(ph)
+        for k in lds_writes(st):
+            writer[k] = j
+    # the wave-folded reductions were emitted above: everything that reads them is in phase >= 1
+    if wsteps:
+        L.append("  __syncthreads();")
+    for ph in range(max(phase, default=-1) + 1):
+        emitted = False
+        for j, st in enumerate(steps):
+            if phase[j] != ph or (st["op"] == "rsum" and wave[j]):
+                continue
+            emitted = True
+            if st["op"] == "finish":
+                ct = CTYPE[st["dtype"]]
+                R, U = su[j]
+                L.append(f"  // step {j}: second stage + epilogue of a split Gemv / scatter-add (rows even/odd, then the pair: the order of the looping form)")
+                for u in range(U):
+                    L.append(f"  if (tid + {u * TAIL_BLOCK} < M{j}) {{")
+                    L.append(f"    {ct} a0 = 0, a1 = 0;")
+                    for r in range(0, R, 2):
+                        L.append(f"    a0 += f{j}_{u}_{r}; a1 += f{j}_{u}_{r + 1};")
+                    L.append(f"    {ct} r = ({ct})alpha{j} * (a0 + a1);")
+                    if st.get("y") is not None:
+                        L.append(f"    if (beta{j} != 0.0) r += ({ct})beta{j} * ({ct}){operand(st['y'], st['ymode'], u)};")
+                    L.append(f"    l{st['out']}[tid + {u * TAIL_BLOCK}] = r;")
+                    L.append("  }")
+            elif st["op"] == "rsum":
+                act, oct_ = CTYPE[st["acc_dtype"]], CTYPE[st["dtype"]]
+                op = REDUCE_OPS[st["red"]]
+                L.append(f"  // step {j}: deferred second stage of a fused Elemwise+reduce kernel")
+                L.append("  {")
+                L.append(f"    {act} a = pthip_dev::{op}::identity<{act}>();")
+                for u in range(su[j]):
+                    L.append(f"    a = pthip_dev::{op}::apply(a, p{j}_{u});")
+                L.append(f"    a = pthip_dev::block_reduce<pthip_dev::{op}, {act}, {TAIL_BLOCK}, true>(a, ({act}*)red_);")
+                L.append(f"    if (tid == 0) l{st['out']}[0] = ({oct_})a;")
                 L.append("  }")
-            L.append("  __syncthreads();")
-        elif st["op"] == "rsum":
-            act, oct_ = CTYPE[st["acc_dtype"]], CTYPE[st["dtype"]]
-            op = REDUCE_OPS[st["red"]]
-            L.append(f"  // step {j}: deferred second stage of a fused Elemwise+reduce kernel")
-            L.append("  {")
-            L.append(f"    {act} a = pthip_dev::{op}::identity<{act}>();")
-            for u in range(su[j]):
-                L.append(f"    a = pthip_dev::{op}::apply(a, p{j}_{u});")
-            L.append(f"    a = pthip_dev::block_reduce<pthip_dev::{op}, {act}, {TAIL_BLOCK}, true>(a, ({act}*)red_);")
-            L.append(f"    if (tid == 0) l{st['out']}[0] = ({oct_})a;")
-            L.append("  }")
-            L.append("  __syncthreads();")
-        else:
-            body, modes, red = st["body"], st["modes"], st["reduce"]
-            L.append(f"  // step {j}: Elemwise over n{j} elements, operand modes {modes}")
-            L.append("  {")
-            for q, r in enumerate(red):
-                if r is not None:
-                    act = CTYPE[r[1]]
-                    L.append(f"    {act} acc{q} = pthip_dev::{REDUCE_OPS[r[0]]}::identity<{act}>();")
-            for u in range(su[j]):
-                L.append(f"    if (tid + {u * TAIL_BLOCK} < n{j}) {{")
-                in_names = [operand(ref, m, u) for ref, m in zip(st["ins"], modes)]
-                out_names = []
-                for q, dt in enumerate(body["out_dtypes"]):
-                    L.append(f"      {CTYPE[dt]} o{q};")
-                    out_names.append(f"o{q}")
-                L.append(emit_body(body, in_names, out_names, indent="      "))
+            elif st["op"] == "scatter":
+                ct = CTYPE[st["dtype"]]
+                L.append(f"  // step {j}: a chain of one-element IncSubtensor updates (widefuse.collect_scalar_updates)")
+                for u in range(su[j]):
+                    L.append(f"  if (tid + {u * TAIL_BLOCK} < n{j}) l{st['out']}[tid + {u * TAIL_BLOCK}] = ({ct}){operand(st['base'], st['bmode'], u)};")
+                L.append("  __syncthreads();")
+                L.append("  if (tid == 0) {")
+                for k, is_set, y in zip(st["indices"], st["set"], st["ys"]):
+                    L.append(f"    l{st['out']}[{k}] {'=' if is_set else '+='} ({ct}){operand(y, 'S', 0)};")
+                L.append("  }")
+            else:
+                body, modes, red = st["body"], st["modes"], st["reduce"]
+                L.append(f"  // step {j}: Elemwise over n{j} elements, operand modes {modes}")
+                L.append("  {")
                 for q, r in enumerate(red):
-                    if r is None:
-                        L.append(f"      l{st['outs'][q]}[tid + {u * TAIL_BLOCK}] = o{q};")
-                    else:
-                        L.append(f"      acc{q} = pthip_dev::{REDUCE_OPS[r[0]]}::apply(acc{q}, ({CTYPE[r[1]]})o{q});")
-                L.append("    }")
-            for q, r in enumerate(red):
-                if r is not None:
-                    act = CTYPE[r[1]]
-                    L.append(f"    acc{q} = pthip_dev::block_reduce<pthip_dev::{REDUCE_OPS[r[0]]}, {act}, {TAIL_BLOCK}, true>(acc{q}, ({act}*)red_);")
-                    L.append(f"    if (tid == 0) l{st['outs'][q]}[0] = ({CTYPE[r[2]]})acc{q};")
-            L.append("  }")
+                    if r is not None:
+                        act = CTYPE[r[1]]
+                        L.append(f"    {act} acc{q} = pthip_dev::{REDUCE_OPS[r[0]]}::identity<{act}>();")
+                for u in range(su[j]):
+                    L.append(f"    if (tid + {u * TAIL_BLOCK} < n{j}) {{")
+                    in_names = [operand(ref, m, u) for ref, m in zip(st["ins"], modes)]
+                    out_names = []
+                    for q, dt in enumerate(body["out_dtypes"]):
+                        L.append(f"      {CTYPE[dt]} o{q};")
+                        out_names.append(f"o{q}")
+                    L.append(emit_body(body, in_names, out_names, indent="      "))
+                    for q, r in enumerate(red):
+                        if r is None:
+                            L.append(f"      l{st['outs'][q]}[tid + {u * TAIL_BLOCK}] = o{q};")
+                        else:
+                            L.append(f"      acc{q} = pthip_dev::{REDUCE_OPS[r[0]]}::apply(acc{q}, ({CTYPE[r[1]]})o{q});")
+                    L.append("    }")
+                for q, r in enumerate(red):
+                    if r is not None:
+                        act = CTYPE[r[1]]
+                        L.append(f"    acc{q} = pthip_dev::block_reduce<pthip_dev::{REDUCE_OPS[r[0]]}, {act}, {TAIL_BLOCK}, true>(acc{q}, ({act}*)red_);")
+                        L.append(f"    if (tid == 0) l{st['outs'][q]}[0] = ({CTYPE[r[2]]})acc{q};")
+                L.append("  }")
+        if emitted:
             L.append("  __syncthreads();")
     for k, o in enumerate(spec["outs"]):
         L.append(f"  for (long long i = tid; i < len{k}; i += {TAIL_BLOCK}) dst{k}[i] = l{o}[i];")

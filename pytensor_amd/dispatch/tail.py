@@ -113,7 +113,7 @@ class _Planner:
             n *= s
         if n > MAX_LEN or _vec_len(shape) is None:
             raise _Infeasible("large intermediate")
-        self.slots.append({"dtype": str(dtype)})
+        self.slots.append({"dtype": str(dtype), "scalar": n == 1})
         self.slot_len.append(n)
         return _Val(("l", len(self.slots) - 1), shape, dtype)
 
@@ -193,6 +193,39 @@ def _plan(node, inputs, env):
             P.step_args.append([("q", rows), ("q", M), ("d", alpha), ("d", beta)])
             P.step_n.append((int(rows), int(M)))
             vals[sub.outputs[0]] = out
+        elif sub.op == "ScatterScalars":
+            # widefuse.collect_scalar_updates: out = copy(base); out[k_j] (=|+=) y_j in chain order
+            fill = sub.params.get("base_fill")
+            out_dt = str(g.vars[sub.outputs[0]].dtype)
+            if fill is not None:
+                # base = alloc(fill, n): the length is host shape arithmetic, the value a constant
+                ln = vals[sub.inputs[0]]
+                if ln.host is None:
+                    raise _Infeasible("scatter length on the device")
+                n = int(np.asarray(ln.host.a).reshape(()))
+                base = P.add_ext(HostValue(np.asarray(fill, dtype=out_dt)))
+                base = _Val(base.ref, (n,), out_dt, host=base.host)
+                if n < 1 or n > MAX_LEN:
+                    raise _Infeasible("scatter base")
+            else:
+                base = P.materialise(vals[sub.inputs[0]])
+                n = _vec_len(base.shape)
+                if n is None or n > MAX_LEN or len(base.shape) != 1:
+                    raise _Infeasible("scatter base")
+            ys = [P.materialise(vals[v]) for v in sub.inputs[1:]]
+            if any(y.size != 1 for y in ys) or base.dtype not in codegen.CTYPE:
+                raise _Infeasible("scatter operand")
+            idx = []
+            for k in sub.params["indices"]:
+                if k < -n or k >= n:
+                    raise IndexError(f"index {k} is out of bounds for axis 0 with size {n}")
+                idx.append(k + n if k < 0 else k)
+            out = P.new_slot((n,), base.dtype)
+            P.steps.append({"op": "scatter", "base": base.ref, "bmode": "V" if (n > 1 and fill is None) else "S", "ys": [y.ref for y in ys],
+                            "indices": idx, "set": [bool(b) for b in sub.params["set"]], "out": out.ref[1], "dtype": base.dtype})
+            P.step_args.append([("q", n)])
+            P.step_n.append(int(n))
+            vals[sub.outputs[0]] = out
         else:  # Elemwise / ElemwiseReduce
             body = sub.params["scalar"]
             if not codegen.supported(body):
@@ -256,8 +289,12 @@ def _run_fused(node, P, results, env):
                 (C.c_int64 * n)(*[t[2] for t in chunk]), (C.c_int64 * n)(*[t[3] for t in chunk]), (C.c_int * n)(*[t[4] for t in chunk]),
                 (C.c_void_p * n)(*[t[5].ptr for t in chunk])))
     # launch 2: the chain
-    off, offs = 0, []
+    # one-element slots first, at static 16-byte cells; vector slots behind them at run-time offsets
+    off = 16 * sum(1 for s in P.slots if s["scalar"])
+    offs = []
     for s, n in zip(P.slots, P.slot_len):
+        if s["scalar"]:
+            continue
         offs.append(off)
         off += (max(n, 1) * np.dtype(s["dtype"]).itemsize + 15) // 16 * 16
     if off > MAX_LDS:
@@ -270,7 +307,7 @@ def _run_fused(node, P, results, env):
         outs.append(dst)
         out_args += [("q", dst.ptr), ("q", v.size)]
     spec = {"ext": P.ext, "slots": P.slots, "steps": P.steps, "outs": [v.ref[1] for v in results]}
-    key = repr([[(e["kind"], e["dtype"]) for e in P.ext], [s["dtype"] for s in P.slots],
+    key = repr([[(e["kind"], e["dtype"]) for e in P.ext], [(s["dtype"], s["scalar"]) for s in P.slots],
                 [{k: (_body_key(v) if k == "body" else v) for k, v in st.items()} for st in P.steps], spec["outs"]])
     # short operands (the usual case: K- and G-vectors, <= 16-row slabs): the form that requests
     # every global operand before the first step; size classes are part of the kernel identity
@@ -282,6 +319,8 @@ def _run_fused(node, P, results, env):
     status = getattr(env, "tail_status", None) or (0, 0)
     args += [("q", status[0]), ("q", status[1])]
     buf = struct.pack("<" + "".join(a[0] for a in args), *[a[1] for a in args])
+    if len(buf) > 4000:
+        raise _Infeasible("kernel argument block")  # (4 KB kernarg limit: run the members instead)
     kt = env.kernel_timer
     tok = kt.begin() if kt is not None else None
     ffi.check(lib.pthip_launch(fn, 1, 1, 1, codegen.TAIL_BLOCK, 1, 1, max(off, 16), buf, len(buf)))

@@ -1,0 +1,114 @@
+"""``MultiElemwise`` / ``ScatterScalars`` — wide graphs (widefuse.py): many independent terms.
+
+``MultiElemwise``: the member ``ElemwiseReduce`` nodes (reference: ``Elemwise`` +
+``CAReduce``, pytensor/tensor/elemwise.py:375, 1233) in ONE launch when every member is a flat,
+contiguous, fully reduced loop — ``blockIdx.y`` picks the term (codegen.multi_flat_source); each term
+gets the same number of workgroups, few enough that the per-output partials (handed to the ``Tail``
+kernel unfinished) are at most 64 values.  Anything else runs the members one by one through their
+own handler.  ``ScatterScalars`` outside a ``Tail`` is its member ``IncSubtensor`` chain.
+"""
+
+from __future__ import annotations
+
+import struct
+
+from pytensor_amd import codegen, ffi, kernel_cache
+from pytensor_amd.device import DeviceArray
+from pytensor_amd.dispatch import HANDLERS, handler
+from pytensor_amd.dispatch.elemwise import (
+    BLOCK, EW_UNROLL, _body_key, _scalar_bits, _scalar_or_device, alloc_partials, finish_partials,
+)
+from pytensor_amd.executor import HostValue
+
+MAX_ARG_BYTES = 3900
+TOTAL_GROUPS = 2048  # workgroups of one launch, shared among the terms
+
+
+def _run_members(node, inputs, env):
+    vals = dict(zip(node.inputs, inputs))
+    saved = env.donated
+    env.donated = frozenset()
+    try:
+        for sub in node.params["nodes"]:
+            ins = [vals[v] if v in vals else env.exe._const(v, env) for v in sub.inputs]
+            for o, val in zip(sub.outputs, HANDLERS[sub.op](sub, ins, env)):
+                vals[o] = val
+    finally:
+        env.donated = saved
+    return [vals[o] for o in node.outputs]
+
+
+@handler("ScatterScalars")
+def scatter_scalars(node, inputs, env):
+    # (with `base_fill` the first member is the Alloc the fused node absorbed: its fill value is a
+    #  constant of the graph, its length this node's first input)
+    return _run_members(node, inputs, env)
+
+
+def _flat_term(term, ins):
+    """(modes, n, vec) when the term is a flat loop over one contiguous extent, else None"""
+    body = term["scalar"]
+    n, modes = None, []
+    for a in ins:
+        if isinstance(a, HostValue):
+            if a.a.size != 1:
+                return None
+            modes.append("C")
+        elif a.size == 1:
+            modes.append("S")
+        else:
+            if not a.is_contiguous() or (n is not None and a.size != n):
+                return None
+            n = a.size
+            modes.append("V")
+    if n is None or n == 0:
+        return None
+    dts = [body["in_dtypes"][k] for k, m in enumerate(modes) if m == "V"]
+    vec = codegen._vec_width(dts) if dts else 1
+    if vec > 1 and (any(a.ptr % 16 for a, m in zip(ins, modes) if m == "V") or n < vec):
+        vec = 1
+    return "".join(modes), n, vec
+
+
+@handler("MultiElemwise")
+def multi_elemwise(node, inputs, env):
+    terms = node.params["terms"]
+    defer = set(node.params.get("defer_reduce") or ())
+    per_term, pos = [], 0
+    for t in terms:
+        ins = [_scalar_or_device(env, i) for i in inputs[pos : pos + t["n_inputs"]]]
+        pos += t["n_inputs"]
+        ft = _flat_term(t, ins)
+        if ft is None or not codegen.supported(t["scalar"]):
+            return _run_members(node, inputs, env)
+        per_term.append((t, ins, *ft))
+    nt = len(per_term)
+    # the same workgroup count for every term (gridDim.x), bounded so that a term's partials fit
+    # one pass of the tail kernel; at least enough to give each term a few waves per XCD
+    units = max((n // vec + EW_UNROLL - 1) // EW_UNROLL if vec > 1 else n for _, _, _, n, vec in per_term)
+    gx = max(1, min((units + BLOCK - 1) // BLOCK, max(8, TOTAL_GROUPS // nt), 64))
+    specs, args, out_pos, results, o0 = [], [], 0, [], 0
+    gen_terms = []
+    for t, ins, modes, n, vec in per_term:
+        body, spec = t["scalar"], t["reduce"]
+        rs = [(r["op"], r["acc_dtype"]) for r in spec]
+        gen_terms.append({"body": body, "modes": modes, "vec": vec, "rs": rs, "unroll": EW_UNROLL})
+        parts = alloc_partials(spec, gx)
+        args.append(n)
+        for k, (a, m) in enumerate(zip(ins, modes)):
+            args.append(_scalar_bits(a, body["in_dtypes"][k]) if m == "C" else a.ptr)
+        args += [p.ptr for p in parts]
+        specs.append((spec, parts))
+    buf = struct.pack(f"<{len(args)}q", *args)
+    if len(buf) > MAX_ARG_BYTES:
+        return _run_members(node, inputs, env)
+    key = codegen.source_key(repr([(_body_key(g["body"]), g["modes"], g["vec"], g["rs"]) for g in gen_terms]))
+    name = f"multi_{key[:16]}_t{nt}"
+    src = codegen.multi_flat_source(name, gen_terms)
+    fn = kernel_cache.get_function(src, name)
+    env.timed(name, lambda: ffi.check(env.lib.pthip_launch(fn, gx, nt, 1, BLOCK, 1, 1, 0, buf, len(buf))))
+    for spec, parts in specs:
+        d = {k - o0 for k in defer if o0 <= k < o0 + len(spec)}
+        results += finish_partials(env, spec, parts, gx, d)
+        o0 += len(spec)
+    return results

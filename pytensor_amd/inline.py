@@ -173,24 +173,32 @@ def inline_elemwise_producers(g: Graph) -> Graph:
                 if kp is None:
                     continue
                 P = g.nodes[kp]
-                if P.op != "Elemwise" or len(P.outputs) != 1:
+                if P.op != "Elemwise":
                     continue
                 pb = P.params["scalar"]
+                if len(P.outputs) != 1:
+                    # a multi-output producer is folded only as a size-1 value (below): the
+                    # consumer gets the producer's scalar graph with the one output it reads
+                    # (e.g. (-s, exp(-s)) of a scale parameter: two outputs, several clients)
+                    if not all(_scalar_like(g.vars[o]) for o in P.outputs):
+                        continue
+                    j = P.outputs.index(src)
+                    pb = {"in_dtypes": pb["in_dtypes"], "out_dtypes": [pb["out_dtypes"][j]], "body": pb["body"], "outs": [pb["outs"][j]]}
                 if len(nc.inputs) - 1 + len(P.inputs) > MAX_INPUTS:
                     continue
                 p_scalar = _scalar_like(g.vars[P.outputs[0]]) and all(_scalar_like(g.vars[u]) for u in P.inputs)
                 single = (not through) and consumers.get(v, []).count(kc) == len(consumers.get(v, [])) and v not in out_set
-                if single and g.vars[v].ndim == nd_c:
-                    target = (kc, q, kp, False)
+                if single and g.vars[v].ndim == nd_c and len(P.outputs) == 1:
+                    target = (kc, q, kp, False, pb)
                 elif p_scalar and len(pb["body"]) <= MAX_SCALAR_BODY:
-                    target = (kc, q, kp, True)
+                    target = (kc, q, kp, True, pb)
                 if target:
                     break
             if target:
                 break
         if target is None:
             break
-        kc, q, kp, expand = target
+        kc, q, kp, expand, pbody = target
         nc, P = g.nodes[kc], g.nodes[kp]
         nd_c = g.vars[nc.outputs[0]].ndim
         new_vars = {}
@@ -207,7 +215,7 @@ def inline_elemwise_producers(g: Graph) -> Graph:
             pre.append(Node("DimShuffle", {"new_order": ["x"] * nd_c}, [u], [vid]))
             p_inputs.append(vid)
         params = dict(nc.params)
-        params["scalar"] = _inline_at(nc.params["scalar"], q, P.params["scalar"])
+        params["scalar"] = _inline_at(nc.params["scalar"], q, pbody)
         merged = Node(nc.op, params, [i for pos, i in enumerate(nc.inputs) if pos != q] + p_inputs, list(nc.outputs))
         merged = _dedupe_inputs(merged)
         nodes = list(g.nodes[:kc]) + pre + [merged] + list(g.nodes[kc + 1 :])

@@ -13,8 +13,10 @@ Order matters:
    inside a Scan step, product against a loop-constant matrix + consuming ``Composite`` in one
    generated kernel (``DotEpilogue``; weights repacked once outside the loop);
 6. ``fuse_gemv_chain`` — ``X@b → Composite → X.T@w`` (+ gathers, + scatter-add) in one pass;
-7. ``dead_code_elimination``; ``fuse_tail`` (tailfuse.py) — the small nodes at the end of the
-   graph in two launches;
+7. ``dead_code_elimination``; ``collect_scalar_updates`` / ``fuse_independent_reductions``
+   (widefuse.py) — wide graphs: scalar ``IncSubtensor`` chains as one node, independent
+   ``ElemwiseReduce`` terms in one launch; ``fuse_tail`` (tailfuse.py) — the small nodes at the end
+   of the graph in two launches;
 8. ``segment_graph`` — latency chain / streaming / combine segments for multi-stream plans.
 
 ``fuse=False`` leaves the lowered graph untouched (one launch per reference ``Apply``: the
@@ -42,6 +44,7 @@ from pytensor_amd.inline import (
 )
 from pytensor_amd.ir import Graph
 from pytensor_amd.tailfuse import fuse_tail
+from pytensor_amd.widefuse import collect_scalar_updates, fuse_independent_reductions
 
 
 def run_pipeline(graph: Graph, fuse=True, tail=True):
@@ -63,6 +66,8 @@ def run_pipeline(graph: Graph, fuse=True, tail=True):
     g = merge_sibling_gemms(g)  # what is left as split-K slabs
     g = absorb_gathers(fuse_gemv_chain(g))  # gchain takes the gathers it can use first
     g = dead_code_elimination(g)
+    if os.environ.get("PTHIP_WIDE", "1") != "0":
+        g = fuse_independent_reductions(collect_scalar_updates(g))
     if tail and os.environ.get("PTHIP_TAIL", "1") != "0":
         g = fuse_tail(g)
     return segment_graph(g)

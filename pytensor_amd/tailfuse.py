@@ -25,9 +25,9 @@ from __future__ import annotations
 from pytensor_amd.ir import Graph, Node
 
 # ops the tail kernel can execute (DimShuffle: only as a view of a scalar / vector)
-_MEMBER_OPS = frozenset(["Elemwise", "ElemwiseReduce", "GemvFinish", "DimShuffle"])
+_MEMBER_OPS = frozenset(["Elemwise", "ElemwiseReduce", "GemvFinish", "DimShuffle", "ScatterScalars"])
 # producers whose reduced outputs can be handed over unfinished (DeferredReduce)
-_DEFER_OPS = frozenset(["ElemwiseReduce", "GemvChain"])
+_DEFER_OPS = frozenset(["ElemwiseReduce", "GemvChain", "MultiElemwise"])
 MIN_LAUNCHES = 3  # below this the two launches of the tail save nothing
 
 
