@@ -216,3 +216,47 @@ def test_arena_destroy_adopts_blocks_that_are_still_referenced(hip):
     more = [Buffer(4096) for _ in range(64)]
     ptrs = [b.ptr for b in others + more]
     assert len(set(ptrs)) == len(ptrs)
+
+
+def test_small_segments_replay_as_launch_lists(hip, monkeypatch):
+    """Plan segments of a few launches are recorded launch lists (direct launches at replay), long
+    ones captured hipGraphs; both forms give the eager path's bits."""
+    import pytensor_amd.plan as plan_mod
+    from pytensor_amd.executor import HipExecutable
+
+    g, ins, cvm, py, meta = load_case("c1_gauss")
+    exe = HipExecutable(g)
+    want = exe(*ins)
+    p = exe.freeze(*ins)
+    assert [k for k, _ in p._graphs] == ["list"] and p._seg_sizes[0] <= plan_mod._LIST_MAX
+    for _ in range(3):
+        for a, b in zip(p(*ins), want):
+            np.testing.assert_array_equal(a, b)
+    p.close()
+    # the same graph captured as a hipGraph
+    monkeypatch.setattr(plan_mod, "_LIST_MAX", 0)
+    q = exe.freeze(*ins)
+    assert [k for k, _ in q._graphs] == ["graph"]
+    for a, b in zip(q(*ins), want):
+        np.testing.assert_array_equal(a, b)
+    q.close()
+    monkeypatch.undo()
+    # a Scan unrolled into thousands of launches stays a hipGraph
+    g, ins, cvm, py, meta = load_case("c5_gru")
+    exe = HipExecutable(g)
+    want = exe(*ins)
+    p = exe.freeze(*ins)
+    assert "graph" in [k for k, _ in p._graphs]
+    for a, b in zip(p(*ins), want):
+        np.testing.assert_array_equal(a, b)
+    p.close()
+    # the segmented two-stream plan of config #4: three lists
+    g, ins, cvm, py, meta = load_case("c4_hier")
+    names = meta["input_names"]
+    exe = HipExecutable(g, resident=[k for k, n in enumerate(names) if n in ("y", "X", "gidx", "Sigma")])
+    want = exe(*ins)
+    p = exe.freeze(*ins)
+    assert p.segmented and [k for k, _ in p._graphs] == ["list", "list", "list"]
+    for a, b in zip(p(*ins), want):
+        np.testing.assert_array_equal(a, b)
+    p.close()

@@ -215,3 +215,49 @@ def test_pack_b16_oracle_layout():
     for ct, k4, j, q in ((0, 0, 0, 0), (2, 5, 2, 0), (1, 3, 15, 3), (2, 5, 3, 0), (0, 7, 0, 3)):
         k, c = 4 * k4 + q, 16 * ct + j
         assert p4[ct, k4, j, q] == (w[k, c] if k < K and c < N else 0.0)
+
+
+def test_wide_graph_becomes_two_launches():
+    """widefuse.py on the 12-term model (golden ``wide_terms``): ONE ``MultiElemwise`` for the
+    per-term Elemwise+Sum kernels (all reductions handed on unfinished), everything after it —
+    the scalar gradient algebra and both ``IncSubtensor`` chains (as ``ScatterScalars`` nodes, their
+    zeros bases absorbed) — inside ONE ``Tail`` node; nothing else launches."""
+    g, ins, cvm, py, meta = load_case("wide_terms")
+    g2, _ = _pipeline(g)
+    ops = [n.op for n in g2.nodes]
+    assert ops.count("MultiElemwise") == 1 and ops.count("Tail") == 1
+    assert not {"ElemwiseReduce", "IncSubtensor", "Alloc", "CAReduce"} & set(ops)
+    launching = [o for o in ops if o not in ("DimShuffle", "Subtensor", "Shape_i", "MultiElemwise", "Tail")]
+    assert [o for o in launching if o != "Elemwise"] == []  # (host shape arithmetic only)
+    multi = next(n for n in g2.nodes if n.op == "MultiElemwise")
+    assert len(multi.params["terms"]) == 12
+    assert sorted(multi.params["defer_reduce"]) == list(range(len(multi.outputs)))
+    tail = next(n for n in g2.nodes if n.op == "Tail")
+    members = [m.op for m in tail.params["nodes"]]
+    assert members.count("ScatterScalars") == 2
+    for m in tail.params["nodes"]:
+        if m.op == "ScatterScalars":
+            assert m.params["base_fill"] == 0.0 and sorted(m.params["indices"]) == list(range(12)) and not any(m.params["set"])
+    # with the passes switched off the graph keeps one kernel per term (and the same results:
+    # test_passes_preserve_results runs both forms through the oracle)
+    import os
+
+    os.environ["PTHIP_WIDE"] = "0"
+    try:
+        g3, _ = _pipeline(g)
+    finally:
+        del os.environ["PTHIP_WIDE"]
+    assert [n.op for n in g3.nodes].count("ElemwiseReduce") == 12
+
+
+def test_multi_flat_source_shares_bodies_and_compiles():
+    from pytensor_amd import codegen, ffi
+
+    dt = "float64"
+    b1 = {"in_dtypes": [dt, dt], "out_dtypes": [dt], "body": [{"op": "Sub", "in": [["i", 1], ["i", 0]], "dtype": dt}, {"op": "Sqr", "in": [["t", 0]], "dtype": dt}], "outs": [["t", 1]]}
+    b2 = {"in_dtypes": [dt, dt], "out_dtypes": [dt], "body": [{"op": "Sub", "in": [["i", 1], ["i", 0]], "dtype": dt}, {"op": "Abs", "in": [["t", 0]], "dtype": dt}], "outs": [["t", 1]]}
+    mk = lambda b, m: {"body": b, "modes": m, "vec": 2, "rs": [("Add", dt)], "unroll": 2}
+    src = codegen.multi_flat_source("multi_probe", [mk(b1, "SV"), mk(b2, "CV"), mk(b1, "SV"), mk(b1, "CV")])
+    assert src.count("static __device__ __forceinline__ void mt_") == 3  # (b1,SV) shared by two terms
+    assert "switch (blockIdx.y)" in src and src.count("case ") == 4
+    assert len(ffi.jit_compile(src, "multi_probe.hip")) > 1000
