@@ -425,6 +425,8 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_kernel(
 // (64 KB of stores) of the co-resident workgroups coincide — nothing to overlap them with; at
 // K = 256 (8 K-steps per tile) that is a quarter of a tile's life (config #3 BatchedDot:
 // 512 x 256^3).  No split-K, M > 64 only (the one-tile-per-workgroup kernel above keeps those).
+// Tried and rejected: global loads two K-steps ahead with a second staging register set — 256 VGPRs
+// with spills, 5-15 % slower on every shape (profiles/r2w_sgemm_pf2.txt).
 // DIAG (timing experiments only, results invalid when != 0; PTHIP_SGEMM_DIAG): 1 = no global loads
 // after the first K-tile, 2 = also no LDS staging stores, 3 = also no LDS fragment reads (operands
 // from registers) — what the MFMA loop sustains with each feeder removed.
