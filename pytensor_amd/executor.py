@@ -93,8 +93,11 @@ except Exception:  # pragma: no cover
         return zlib.crc32(buf)
 
 
+_RESIDENT_MODE = os.environ.get("PTHIP_RESIDENT", "sampled")  # sampled | strict | trust
+
+
 def _fingerprint(a: np.ndarray):
-    mode = os.environ.get("PTHIP_RESIDENT", "sampled")
+    mode = _RESIDENT_MODE
     if mode == "trust":
         return None
     if a.nbytes <= _FULL_HASH_MAX or mode == "strict":
@@ -542,14 +545,22 @@ class HipExecutable:
 
     def __call__(self, *inputs):
         if self.auto_freeze:
-            sig = self._signature(inputs)
             if self._auto_plan is not None:
-                if sig == self._auto_plan_sig:
+                # the plan checks the signature of what it is given itself (before launching
+                # anything): no second pass over the inputs on the replay path
+                from pytensor_amd.plan import SignatureChanged
+
+                try:
+                    res = self._auto_plan(*inputs)
                     self.stats["replays"] += 1
-                    return self._auto_plan(*inputs)
-                self._auto_plan.close()  # the signature moved on: capture again later
-                self._auto_plan = None
-            elif sig == self._auto_sig and not self._auto_failed:
+                    return res
+                except SignatureChanged:
+                    self._auto_plan.close()  # the signature moved on: capture again later
+                    self._auto_plan = None
+                sig = self._signature(inputs)
+            else:
+                sig = self._signature(inputs)
+            if self._auto_plan is None and sig == self._auto_sig and not self._auto_failed:
                 plan = None
                 try:
                     plan = self.freeze(*inputs, multi_stream="auto")

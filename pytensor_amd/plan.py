@@ -125,6 +125,12 @@ def _drain_deferred():
         _DEFERRED.pop().close()
 
 
+class SignatureChanged(TypeError, ValueError):
+    """A replay was asked for inputs of another signature (shape / dtype of a staged or resident
+    input, value of a baked scalar) than the plan was captured for.  Raised before anything is
+    launched; the auto-freeze path of ``HipExecutable`` answers it with an eager call."""
+
+
 class FrozenPlan:
     def __init__(self, exe, inputs, fetch_outputs=True, multi_stream=True):
         self._closed = False
@@ -405,7 +411,7 @@ class FrozenPlan:
             if getattr(a, "shape", None) != v.shape or getattr(a, "dtype", None) != v.dtype:
                 a = np.asarray(a)
                 if a.shape != v.shape or a.dtype != v.dtype:
-                    raise TypeError(f"frozen plan: input {pos} changed signature {self._sig[pos]} -> {(a.shape, str(a.dtype))}")
+                    raise SignatureChanged(f"frozen plan: input {pos} changed signature {self._sig[pos]} -> {(a.shape, str(a.dtype))}")
             v[...] = a
         exe = self.exe
         late = []  # residents still held by the object that was uploaded: content check deferred
@@ -416,10 +422,10 @@ class FrozenPlan:
                 if ent.fp is not None:
                     late.append((pos, ent, v))
             elif exe._refresh_resident(pos, v) is not dev:
-                raise ValueError(f"frozen plan: resident input {pos} changed shape or dtype; re-freeze")
+                raise SignatureChanged(f"frozen plan: resident input {pos} changed shape or dtype; re-freeze")
         for pos, b in self._baked.items():
             if not np.array_equal(np.asarray(inputs[pos]), b):
-                raise ValueError(f"frozen plan: scalar input {pos} is baked into the plan and changed")
+                raise SignatureChanged(f"frozen plan: scalar input {pos} is baked into the plan and changed")
         if not late:
             self._replay(True)  # one native call: H2D, graphs, stream synchronisation
         else:
