@@ -250,7 +250,9 @@ int pthip_nonzero(int64_t n, const void* mask, void* idx_out, void* count_out);
  * 5 laplace 6 logistic 7 cauchy 8 halfcauchy 9 gumbel 10 weibull(shape) 11 pareto(b,scale)
  * 12 triangular(left,mode,right) 13 gamma(shape,scale) 14 beta(a,b) 15 invgamma(shape,scale)
  * 16 t(df,loc,scale) 17 bernoulli(p) 18 geometric(p) 19 poisson(lam) 20 integers(low,high)
- * 21 binomial(n,p) 22 negative_binomial(n,p).
+ * 21 binomial(n,p) 22 negative_binomial(n,p) 23 wald(mean,scale) 24 truncexpon(b,loc,scale)
+ * 25 gengamma(alpha,p,lambd) 26 beta_binomial(n,a,b) 27 vonmises(mu,kappa)
+ * 28 hypergeometric(ngood,nbad,nsample).
  * params[j]: contiguous array broadcast to the output (stride 1) or one element (stride 0),
  * any numeric dtype.  out: float64 / float32 / int64, contiguous. */
 int pthip_random(int dist, int out_dtype, int64_t n, const uint64_t* key, const uint64_t* counter,
@@ -260,6 +262,12 @@ int pthip_random(int dist, int out_dtype, int64_t n, const uint64_t* key, const 
  * apart, 0 = the same vector for every row) by inversion of the running sum; int64 out */
 int pthip_random_categorical(int p_dtype, int64_t rows, int64_t k, const uint64_t* key,
                              const uint64_t* counter, const void* p, int64_t row_stride, void* out);
+/* MultinomialRV (random/basic.py:1748 signature "(),(p)->(p)"): rows x k int64 counts, row i from the
+ * conditional binomials of n[i * n_stride] trials over p (row_stride as above); category j of a
+ * row draws on substream j of that row's block */
+int pthip_random_multinomial(int p_dtype, int64_t rows, int64_t k, const uint64_t* key,
+                             const uint64_t* counter, const void* n, int n_dtype, int64_t n_stride,
+                             const void* p, int64_t row_stride, void* out);
 /* out (n, n) = P * I for the gather vector perm of pthip_getrf (row i = unit vector e_perm[i]):
  * the right-hand side of MatrixInverse (pytensor/tensor/linalg/inverse.py:87), built on the device */
 int pthip_permuted_identity(int dtype, int64_t n, const void* perm, void* out);

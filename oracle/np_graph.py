@@ -986,7 +986,7 @@ def _random_variable(p, inputs, node, graph):
 
     gen, size, *params = inputs
     size = None if p["size_is_none"] else [int(v) for v in np.asarray(size).ravel()]
-    return list(philox_ref.draw(p["name"], gen, size, params, p["dtype"]))
+    return list(philox_ref.draw(p["name"], gen, size, params, p["dtype"], p.get("ndims_params")))
 
 
 @op("Eigh")

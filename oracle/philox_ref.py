@@ -131,7 +131,7 @@ def poisson_draw(s: Stream, i, lam, sub=0):
     return float(math.floor(lam))
 
 
-def binomial_draw(s: Stream, i, n, p):
+def binomial_draw(s: Stream, i, n, p, sub=0):
     if not (0.0 <= p <= 1.0) or not n >= 0.0:
         return math.nan
     n = math.floor(n)
@@ -147,7 +147,7 @@ def binomial_draw(s: Stream, i, n, p):
         for attempt in range(64):
             if x >= 0.0:
                 break
-            w = s.block(i, 0, attempt)
+            w = s.block(i, sub, attempt)
             for j in range(4):
                 if x >= 0.0:
                     break
@@ -174,7 +174,7 @@ def binomial_draw(s: Stream, i, n, p):
         m = math.floor((n + 1.0) * q)
         h = math.lgamma(m + 1.0) + math.lgamma(n - m + 1.0)
         for attempt in range(256):
-            w = s.block(i, 0, attempt)
+            w = s.block(i, sub, attempt)
             u = uopen(w[0]) - 0.5
             v = uopen(w[1])
             us = 0.5 - abs(u)
@@ -191,6 +191,90 @@ def binomial_draw(s: Stream, i, n, p):
         if x < 0.0:
             x = m
     return n - x if flip else x
+
+
+def vonmises_draw(s: Stream, i, mu, kappa):
+    PI = 3.141592653589793
+    if not kappa >= 0.0:
+        return math.nan
+    w = s.block(i, 0, 0)
+    if kappa < 1e-8:
+        return PI * (2.0 * uopen(w[0]) - 1.0)
+    if kappa > 1e6:
+        res = mu + math.sqrt(1.0 / kappa) * box_muller(w[0], w[1])
+    else:
+        sh = 0.5 / kappa
+        r = sh + math.sqrt(1.0 + sh * sh)
+        W, sign = 1.0, w[2]
+        for attempt in range(256):
+            if attempt:
+                w = s.block(i, 0, attempt)
+            Z = math.cos(PI * uopen(w[0]))
+            W = (1.0 + r * Z) / (r + Z)
+            Y, V = kappa * (r - W), uopen(w[1])
+            sign = w[2]
+            if Y * (2.0 - Y) - V >= 0.0 or math.log(Y / V) + 1.0 - Y >= 0.0:
+                break
+        W = min(1.0, max(-1.0, W))
+        res = math.acos(W)
+        if sign >> 63:
+            res = -res
+        res += mu
+    m = math.fmod(abs(res) + PI, 2.0 * PI) - PI
+    return -m if res < 0.0 else m
+
+
+def hypergeometric_draw(s: Stream, i, good, bad, sample):
+    good, bad, sample = math.floor(good), math.floor(bad), math.floor(sample)
+    if not (good >= 0 and bad >= 0 and sample >= 0) or sample > good + bad:
+        return math.nan
+    good, bad, sample = float(good), float(bad), float(sample)
+    lo, hi = max(0.0, sample - bad), min(sample, good)
+    if lo == hi:
+        return lo
+    u = uopen(s.block(i, 0, 0)[0])
+    m = math.floor((sample + 1.0) * (good + 1.0) / (good + bad + 2.0))
+    m = min(hi, max(lo, float(m)))
+    lg = math.lgamma
+    lpm = (lg(good + 1.0) - lg(m + 1.0) - lg(good - m + 1.0) + lg(bad + 1.0) - lg(sample - m + 1.0)
+           - lg(bad - sample + m + 1.0) - lg(good + bad + 1.0) + lg(sample + 1.0) + lg(good + bad - sample + 1.0))
+    pm = math.exp(lpm)
+    u -= pm
+    if u <= 0.0:
+        return m
+    kd = ku = m
+    pd = pu = pm
+    while kd > lo or ku < hi:
+        if kd > lo:
+            pd *= kd * (bad - sample + kd) / ((good - kd + 1.0) * (sample - kd + 1.0))
+            kd -= 1.0
+            u -= pd
+            if u <= 0.0:
+                return kd
+        if ku < hi:
+            pu *= (good - ku) * (sample - ku) / ((ku + 1.0) * (bad - sample + ku + 1.0))
+            ku += 1.0
+            u -= pu
+            if u <= 0.0:
+                return ku
+    return m
+
+
+def multinomial_row(s: Stream, i, n, row):
+    k = len(row)
+    out = [0] * k
+    remaining, mass = float(n), 1.0
+    for j in range(k - 1):
+        pj = float(row[j])
+        x = 0.0
+        if remaining > 0.0:
+            q = min(1.0, max(0.0, pj / mass)) if mass > 0.0 else 1.0
+            x = binomial_draw(s, i, remaining, q, j)
+        out[j] = int(x)
+        remaining -= x
+        mass -= pj
+    out[k - 1] = int(remaining)
+    return out
 
 
 def _element(name, s: Stream, i, p):
@@ -217,12 +301,30 @@ def _element(name, s: Stream, i, p):
         return poisson_draw(s, i, p[0])
     if name == "binomial":
         return binomial_draw(s, i, p[0], p[1])
+    if name == "gengamma":
+        return p[2] * math.pow(gamma_mt(s, i, 0, p[0] / p[1]), 1.0 / p[1])
+    if name == "beta_binomial":
+        x, y = gamma_mt(s, i, 0, p[1]), gamma_mt(s, i, 1, p[2])
+        return binomial_draw(s, i, p[0], x / (x + y), 2)
+    if name == "vonmises":
+        return vonmises_draw(s, i, p[0], p[1])
+    if name == "hypergeometric":
+        return hypergeometric_draw(s, i, p[0], p[1], p[2])
+    if name == "wald":
+        w = s.block(i)
+        mu, lam = p
+        z = box_muller(w[0], w[1])
+        y, d = mu * z * z, 0.5 * mu / lam
+        x = mu + d * (y - math.sqrt(4.0 * lam * y + y * y))
+        return x if uopen(w[2]) <= mu / (mu + x) else mu * mu / x
     if name == "negative_binomial":
         return poisson_draw(s, i, gamma_mt(s, i, 0, p[0]) * ((1.0 - p[1]) / p[1]), 1)
     w = s.block(i)
     u = uopen(w[0])
     if name == "exponential":
         return -p[0] * math.log(u)
+    if name == "truncexpon":
+        return p[1] + p[2] * -math.log1p(u * math.expm1(-p[0]))
     if name == "laplace":
         e = -math.log(u)
         return p[0] + p[1] * (e if (w[1] >> 63) else -e)
@@ -250,11 +352,56 @@ def _element(name, s: Stream, i, p):
     raise NotImplementedError(name)
 
 
-def draw(name, gen, size, params, dtype):
+def random_order(s: Stream, n, weights=None):
+    """(stable argsort of n random keys, blocks consumed): uniform keys (Generator.random's numbers)
+    or Exp(1) / weight keys"""
+    if weights is None:
+        keys = np.empty(n)
+        for b in range((n + 3) // 4):
+            w = s.block(b)
+            for j in range(4):
+                if 4 * b + j < n:
+                    keys[4 * b + j] = u53(w[j])
+        return np.argsort(keys, kind="stable"), keys, (n + 3) // 4
+    e = np.array([-1.0 * math.log(uopen(s.block(i)[0])) for i in range(n)])
+    with np.errstate(divide="ignore"):
+        keys = e / np.asarray(weights, dtype=np.float64)
+    return np.argsort(keys, kind="stable"), keys, n
+
+
+def draw(name, gen, size, params, dtype, ndims_params=None):
     """(advanced generator, draws) — what the ``RandomVariable`` node of the hip linker returns"""
     key, ctr = generator_state(gen)
     s = Stream(key, ctr)
     dtype = np.dtype(dtype)
+    if name == "permutation":
+        x = np.asarray(params[0])
+        core = 1 if ndims_params is None else int(ndims_params[0])
+        if x.ndim != core:
+            raise NotImplementedError("permutation with batch dimensions")
+        n = int(x) if core == 0 else x.shape[0]
+        order, _, blocks = random_order(s, n)
+        return make_generator(key, ctr + blocks), (order if core == 0 else x[order]).astype(dtype)
+    if name == "choice_without_replacement":
+        a, *rest, core_shape = params
+        a = np.asarray(a)
+        pr = np.asarray(rest[0]) if rest else None
+        core = a.ndim if ndims_params is None else int(ndims_params[0])
+        if a.ndim != core:
+            raise NotImplementedError("choice without replacement with batch dimensions")
+        core_shape = tuple(int(v) for v in np.asarray(core_shape).ravel())
+        take = int(np.prod(core_shape)) if core_shape else 1
+        n = int(a) if core == 0 else a.shape[0]
+        if take > n:
+            raise ValueError("Cannot take a larger sample than population when replace is False")
+        if pr is not None and pr.shape[0] != n:
+            raise ValueError("a and p must have same size")
+        order, keys, blocks = random_order(s, n, pr)
+        if pr is not None and take and not np.isfinite(keys[order[take - 1]]):
+            raise ValueError("Fewer non-zero entries in p than size")
+        head = order[:take]
+        out = head if core == 0 else a[head]
+        return make_generator(key, ctr + blocks), out.reshape(*core_shape, *a.shape[1:]).astype(dtype)
     if name == "categorical":
         (pr,) = params
         pr = np.asarray(pr)
@@ -272,6 +419,15 @@ def draw(name, gen, size, params, dtype):
                     break
             out[i] = pick
         return make_generator(key, ctr + len(prb)), out.reshape(shape).astype(dtype)
+    if name == "multinomial":
+        nn, pr = (np.asarray(v) for v in params)
+        batch = np.broadcast_shapes(nn.shape, pr.shape[:-1])
+        shape = tuple(batch) if size is None else tuple(int(v) for v in size)
+        k = pr.shape[-1]
+        nb = np.broadcast_to(nn, shape).reshape(-1)
+        prb = np.broadcast_to(pr, (*shape, k)).reshape(-1, k)
+        out = np.array([multinomial_row(s, i, int(nb[i]), prb[i]) for i in range(len(prb))], dtype=np.int64).reshape(*shape, k)
+        return make_generator(key, ctr + len(prb)), out.astype(dtype)
     if name == "dirichlet":
         al = np.asarray(params[0], dtype=np.float64)
         shape = (*(al.shape[:-1] if size is None else tuple(size)), al.shape[-1])

@@ -28,7 +28,8 @@ constexpr int BLOCK = 256;
 enum Dist {
   D_UNIFORM = 0, D_NORMAL, D_HALFNORMAL, D_LOGNORMAL, D_EXPONENTIAL, D_LAPLACE, D_LOGISTIC, D_CAUCHY,
   D_HALFCAUCHY, D_GUMBEL, D_WEIBULL, D_PARETO, D_TRIANGULAR, D_GAMMA, D_BETA, D_INVGAMMA, D_STUDENT_T,
-  D_BERNOULLI, D_GEOMETRIC, D_POISSON, D_INTEGERS, D_BINOMIAL, D_NEGBINOMIAL, D_COUNT
+  D_BERNOULLI, D_GEOMETRIC, D_POISSON, D_INTEGERS, D_BINOMIAL, D_NEGBINOMIAL, D_WALD, D_TRUNCEXPON, D_GENGAMMA,
+  D_BETABINOMIAL, D_VONMISES, D_HYPERGEOMETRIC, D_COUNT
 };
 
 struct RandArgs {
@@ -162,7 +163,7 @@ __device__ double poisson_draw(const RandArgs& a, u64 i, unsigned sub, double la
 }
 
 // binomial(n, p): sequential inversion while n*min(p,1-p) < 10, Hoermann's BTRS (1993) above
-__device__ double binomial_draw(const RandArgs& a, u64 i, double n, double p) {
+__device__ double binomial_draw(const RandArgs& a, u64 i, unsigned sub, double n, double p) {
   if (!(p >= 0.0 && p <= 1.0) || !(n >= 0.0)) return __builtin_nan("");
   n = floor(n);
   const bool flip = p > 0.5;
@@ -174,7 +175,7 @@ __device__ double binomial_draw(const RandArgs& a, u64 i, double n, double p) {
     const double qn = exp(n * log1p(-q)), odds = q / (1.0 - q);
     const double bound = fmin(n, n * q + 10.0 * sqrt(n * q * (1.0 - q) + 1.0));
     for (unsigned attempt = 0; attempt < 64 && x < 0.0; attempt++) {
-      draw_block(a, i, 0, attempt, w);
+      draw_block(a, i, sub, attempt, w);
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         if (x >= 0.0) break;
@@ -195,7 +196,7 @@ __device__ double binomial_draw(const RandArgs& a, u64 i, double n, double p) {
     const double c = n * q + 0.5, vr = 0.92 - 4.2 / b, alpha = (2.83 + 5.1 / b) * spq, lpq = log(q / (1.0 - q));
     const double m = floor((n + 1.0) * q), h = lgamma(m + 1.0) + lgamma(n - m + 1.0);
     for (unsigned attempt = 0; attempt < 256 && x < 0.0; attempt++) {
-      draw_block(a, i, 0, attempt, w);
+      draw_block(a, i, sub, attempt, w);
       const double u = uopen(w[0]) - 0.5;
       double v = uopen(w[1]);
       const double us = 0.5 - fabs(u);
@@ -208,6 +209,77 @@ __device__ double binomial_draw(const RandArgs& a, u64 i, double n, double p) {
     if (x < 0.0) x = m;
   }
   return flip ? n - x : x;
+}
+
+// von Mises(mu, kappa): Best & Fisher (1979) wrapped-Cauchy rejection; uniform on the circle below
+// kappa = 1e-8, wrapped normal above 1e6 (where the envelope's r loses its digits); result in [-pi, pi]
+__device__ double vonmises_draw(const RandArgs& a, u64 i, double mu, double kappa) {
+  const double PI = 3.141592653589793;
+  if (!(kappa >= 0.0)) return __builtin_nan("");
+  u64 w[4];
+  draw_block(a, i, 0, 0, w);
+  if (kappa < 1e-8) return PI * (2.0 * uopen(w[0]) - 1.0);
+  double res;
+  if (kappa > 1e6) {
+    res = mu + sqrt(1.0 / kappa) * box_muller(w[0], w[1]);
+  } else {
+    const double s = 0.5 / kappa, r = s + sqrt(1.0 + s * s);
+    double W = 1.0;
+    u64 sign = w[2];
+    for (unsigned attempt = 0; attempt < 256; attempt++) {
+      if (attempt) draw_block(a, i, 0, attempt, w);
+      const double Z = cos(PI * uopen(w[0]));
+      W = (1.0 + r * Z) / (r + Z);
+      const double Y = kappa * (r - W), V = uopen(w[1]);
+      sign = w[2];
+      if (Y * (2.0 - Y) - V >= 0.0 || log(Y / V) + 1.0 - Y >= 0.0) break;
+    }
+    W = fmin(1.0, fmax(-1.0, W));
+    res = acos(W);
+    if (sign >> 63) res = -res;
+    res += mu;
+  }
+  const bool neg = res < 0.0;
+  double m = fmod(fabs(res) + PI, 2.0 * PI) - PI;
+  return neg ? -m : m;
+}
+
+// hypergeometric(ngood, nbad, nsample): inversion of one uniform by chop-down from the mode, the
+// pmf walked outwards with its two-term recurrences (expected steps: a few standard deviations)
+__device__ double hypergeometric_draw(const RandArgs& a, u64 i, double good, double bad, double sample) {
+  good = floor(good); bad = floor(bad); sample = floor(sample);
+  if (!(good >= 0.0 && bad >= 0.0 && sample >= 0.0) || sample > good + bad) return __builtin_nan("");
+  const double lo = fmax(0.0, sample - bad), hi = fmin(sample, good);
+  if (lo == hi) return lo;
+  u64 w[4];
+  draw_block(a, i, 0, 0, w);
+  double u = uopen(w[0]);
+  double m = floor((sample + 1.0) * (good + 1.0) / (good + bad + 2.0));
+  m = fmin(hi, fmax(lo, m));
+  const double lpm = lgamma(good + 1.0) - lgamma(m + 1.0) - lgamma(good - m + 1.0) + lgamma(bad + 1.0) -
+                     lgamma(sample - m + 1.0) - lgamma(bad - sample + m + 1.0) - lgamma(good + bad + 1.0) +
+                     lgamma(sample + 1.0) + lgamma(good + bad - sample + 1.0);
+  const double pm = exp(lpm);
+  u -= pm;
+  if (u <= 0.0) return m;
+  double kd = m, ku = m, pd = pm, pu = pm;
+  for (long long it = 0; it < (1ll << 40); it++) {
+    const bool can_d = kd > lo, can_u = ku < hi;
+    if (!can_d && !can_u) break;
+    if (can_d) {
+      pd *= kd * (bad - sample + kd) / ((good - kd + 1.0) * (sample - kd + 1.0));
+      kd -= 1.0;
+      u -= pd;
+      if (u <= 0.0) return kd;
+    }
+    if (can_u) {
+      pu *= (good - ku) * (sample - ku) / ((ku + 1.0) * (bad - sample + ku + 1.0));
+      ku += 1.0;
+      u -= pu;
+      if (u <= 0.0) return ku;
+    }
+  }
+  return m;  // (u fell in the rounding residue of the total mass)
 }
 
 template <class T>
@@ -285,12 +357,39 @@ __global__ __launch_bounds__(BLOCK) void random_kernel(int dist, long long n, Ra
         if (r < 1.0) r = 1.0;
       } break;
       case D_POISSON: r = poisson_draw(a, (u64)i, 0, load_f(a, 0, i)); break;
-      case D_BINOMIAL: r = binomial_draw(a, (u64)i, load_f(a, 0, i), load_f(a, 1, i)); break;
+      case D_BINOMIAL: r = binomial_draw(a, (u64)i, 0, load_f(a, 0, i), load_f(a, 1, i)); break;
       case D_NEGBINOMIAL: {
         // gamma-Poisson mixture: lambda ~ Gamma(n, (1-p)/p), X ~ Poisson(lambda)
         const double nn = load_f(a, 0, i), p = load_f(a, 1, i);
         r = poisson_draw(a, (u64)i, 1, gamma_mt(a, (u64)i, 0, nn) * ((1.0 - p) / p));
       } break;
+      case D_WALD: {
+        // Michael, Schucany & Haas (1976): one chi-square(1) root, chosen by one uniform
+        draw_block(a, (u64)i, 0, 0, w);
+        const double mu = load_f(a, 0, i), lam = load_f(a, 1, i);
+        const double z = box_muller(w[0], w[1]);
+        const double y = mu * z * z, d = 0.5 * mu / lam;
+        const double x = mu + d * (y - sqrt(4.0 * lam * y + y * y));
+        r = uopen(w[2]) <= mu / (mu + x) ? x : mu * mu / x;
+      } break;
+      case D_TRUNCEXPON: {
+        // inverse cdf on [0, b]: -log(1 - u (1 - e^-b)), then loc + scale x
+        draw_block(a, (u64)i, 0, 0, w);
+        const double b = load_f(a, 0, i);
+        r = load_f(a, 1, i) + load_f(a, 2, i) * -log1p(uopen(w[0]) * expm1(-b));
+      } break;
+      case D_GENGAMMA: {
+        // GenGammaRV.rng_fn_scipy (random/basic.py:1739): lambd * Gamma(alpha / p)^(1/p)
+        const double al = load_f(a, 0, i), pw = load_f(a, 1, i);
+        r = load_f(a, 2, i) * pow(gamma_mt(a, (u64)i, 0, al / pw), 1.0 / pw);
+      } break;
+      case D_BETABINOMIAL: {
+        const double nn = load_f(a, 0, i);
+        const double x = gamma_mt(a, (u64)i, 0, load_f(a, 1, i)), y = gamma_mt(a, (u64)i, 1, load_f(a, 2, i));
+        r = binomial_draw(a, (u64)i, 2, nn, x / (x + y));
+      } break;
+      case D_VONMISES: r = vonmises_draw(a, (u64)i, load_f(a, 0, i), load_f(a, 1, i)); break;
+      case D_HYPERGEOMETRIC: r = hypergeometric_draw(a, (u64)i, load_f(a, 0, i), load_f(a, 1, i), load_f(a, 2, i)); break;
       default: r = __builtin_nan(""); break;
     }
     out[i] = (T)r;
@@ -327,6 +426,32 @@ __global__ __launch_bounds__(BLOCK) void categorical_kernel(long long rows, long
       if (u < acc) { pick = j; break; }
     }
     out[i] = pick;
+  }
+}
+
+// multinomial(n, p[k]): the conditional binomials X_j | X_<j ~ Binomial(n - sum X_<j, p_j / (1 - sum p_<j)),
+// one row per thread, category j on substream j; the last category takes the remainder
+template <class P>
+__global__ __launch_bounds__(BLOCK) void multinomial_kernel(long long rows, long long k, RandArgs a,
+                                                           const P* __restrict__ p, long long row_stride,
+                                                           long long* __restrict__ out) {
+  const long long nth = (long long)gridDim.x * BLOCK;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < rows; i += nth) {
+    const P* row = p + i * row_stride;
+    double remaining = (double)load_i(a, 0, i), mass = 1.0;
+    long long* o = out + i * k;
+    for (long long j = 0; j + 1 < k; j++) {
+      const double pj = (double)row[j];
+      double x = 0.0;
+      if (remaining > 0.0) {
+        const double q = mass > 0.0 ? fmin(1.0, fmax(0.0, pj / mass)) : 1.0;
+        x = binomial_draw(a, (u64)i, (unsigned)j, remaining, q);
+      }
+      o[j] = (long long)x;
+      remaining -= x;
+      mass -= pj;
+    }
+    o[k - 1] = (long long)remaining;
   }
 }
 
@@ -380,4 +505,21 @@ extern "C" int pthip_random_categorical(int p_dtype, int64_t rows, int64_t k, co
   else if (p_dtype == PTHIP_F32) PTHIP_KLAUNCH(categorical_kernel<float>, dim3(grid_for(rows)), dim3(BLOCK), 0, st, (long long)rows, (long long)k, a, (const float*)p, (long long)row_stride, (long long*)out);
   else return pthip::set_error("pthip_random_categorical: probabilities must be float32/float64");
   return pthip::post_launch("random_categorical");
+}
+
+extern "C" int pthip_random_multinomial(int p_dtype, int64_t rows, int64_t k, const uint64_t* key,
+                                        const uint64_t* counter, const void* n, int n_dtype, int64_t n_stride,
+                                        const void* p, int64_t row_stride, void* out) {
+  PTHIP_REQUIRE_INIT();
+  if (rows <= 0) return 0;
+  if (k <= 0) return pthip::set_error("pthip_random_multinomial: empty probability vector");
+  RandArgs a = {};
+  a.p[0] = n; a.dt[0] = n_dtype; a.st[0] = n_stride;
+  a.key[0] = key[0]; a.key[1] = key[1];
+  for (int j = 0; j < 4; j++) a.ctr[j] = counter[j];
+  hipStream_t st = pthip::ctx().stream;
+  if (p_dtype == PTHIP_F64) PTHIP_KLAUNCH(multinomial_kernel<double>, dim3(grid_for(rows)), dim3(BLOCK), 0, st, (long long)rows, (long long)k, a, (const double*)p, (long long)row_stride, (long long*)out);
+  else if (p_dtype == PTHIP_F32) PTHIP_KLAUNCH(multinomial_kernel<float>, dim3(grid_for(rows)), dim3(BLOCK), 0, st, (long long)rows, (long long)k, a, (const float*)p, (long long)row_stride, (long long*)out);
+  else return pthip::set_error("pthip_random_multinomial: probabilities must be float32/float64");
+  return pthip::post_launch("random_multinomial");
 }

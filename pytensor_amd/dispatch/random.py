@@ -25,8 +25,12 @@ DISTRIBUTIONS = {
     "laplace": (5, 2), "logistic": (6, 2), "cauchy": (7, 2), "halfcauchy": (8, 2), "gumbel": (9, 2),
     "weibull": (10, 1), "pareto": (11, 2), "triangular": (12, 3), "gamma": (13, 2), "beta": (14, 2),
     "invgamma": (15, 2), "t": (16, 3), "bernoulli": (17, 1), "geometric": (18, 1), "poisson": (19, 1),
-    "integers": (20, 2), "binomial": (21, 2), "negative_binomial": (22, 2),
+    "integers": (20, 2), "binomial": (21, 2), "negative_binomial": (22, 2), "wald": (23, 2), "truncexpon": (24, 3),
+    "gengamma": (25, 3), "beta_binomial": (26, 3), "vonmises": (27, 2), "hypergeometric": (28, 3),
 }
+
+# vector-valued RandomVariables with a handler of their own below
+STRUCTURED = ("categorical", "dirichlet", "multivariate_normal", "multinomial", "permutation", "choice_without_replacement")
 
 
 def _size_tuple(env, size, size_is_none):
@@ -82,6 +86,69 @@ def random_variable(node, inputs, env):
                     pr = full
                 prc, stride = pr.contiguous(), k
             ffi.check(env.lib.pthip_random_categorical(ffi.np_dtype_code(prc.dtype), rows, k, key_ptr, ctr_ptr, prc.ptr, stride, out.ptr))
+        out = out if out_dtype == np.dtype("int64") else _cast(env, out, out_dtype)
+        return [rng.advanced(rows), out]
+
+    if name == "permutation":
+        # PermutationRV.rng_fn (random/basic.py:2143: rng.permutation(x), x an int = arange(x)): a
+        # uniformly random order = the argsort of n iid uniform keys (Generator.random's numbers)
+        (x,) = devs
+        core = int(p.get("ndims_params", [1])[0])
+        if x.ndim != core:
+            raise NotImplementedError("hip linker: permutation with batch dimensions")
+        n = int(np.asarray(env.to_host(params[0]))) if core == 0 else x.shape[0]
+        order, _ = _random_order(env, n, None, key_ptr, ctr_ptr)
+        out = order if core == 0 else _take_rows(env, x, order)
+        return [rng.advanced((n + 3) // 4), out if np.dtype(out.dtype) == out_dtype else _cast(env, out.contiguous(), out_dtype)]
+
+    if name == "choice_without_replacement":
+        # ChoiceWithoutReplacement.rng_fn (random/basic.py:2029: rng.choice(a, p=p, size=core_shape,
+        # replace=False)).  Without p: the head of a random permutation.  With p: the smallest
+        # exponential keys E_i / p_i (Efraimidis & Spirakis 2006) — successive sampling without
+        # replacement proportional to p, the distribution NumPy's renormalise-and-redraw loop has.
+        a, *rest = devs
+        pr = rest[0] if len(rest) == 2 else None
+        core = int(p.get("ndims_params", [a.ndim])[0])
+        if a.ndim != core or (pr is not None and pr.ndim != 1):
+            raise NotImplementedError("hip linker: choice without replacement with batch dimensions")
+        core_shape = tuple(int(v) for v in np.asarray(env.to_host(inputs[-1])).ravel())
+        take = int(np.prod(core_shape)) if core_shape else 1
+        n = int(np.asarray(env.to_host(params[0]))) if core == 0 else a.shape[0]
+        if take > n:
+            raise ValueError("Cannot take a larger sample than population when replace is False")
+        if pr is not None and pr.shape[0] != n:
+            raise ValueError("a and p must have same size")
+        order, keys = _random_order(env, n, pr, key_ptr, ctr_ptr)
+        if pr is not None and take and not np.isfinite(np.asarray(env.to_host(keys.view((1,), (1,), take - 1)))).all():
+            raise ValueError("Fewer non-zero entries in p than size")
+        head = order.view((take,), (1,))
+        out = head if core == 0 else _take_rows(env, a, head)
+        shape = (*core_shape, *tuple(a.shape[1:]))
+        out = out.contiguous().view(shape, contiguous_strides(shape))
+        blocks = n if pr is not None else (n + 3) // 4
+        return [rng.advanced(blocks), out if np.dtype(out.dtype) == out_dtype else _cast(env, out, out_dtype)]
+
+    if name == "multinomial":
+        # MultinomialRV.rng_fn (random/basic.py:1798-1812): n broadcast against p's batch dimensions
+        nn, pr = devs
+        k = pr.shape[-1]
+        batch = np.broadcast_shapes(tuple(nn.shape), tuple(pr.shape[:-1]))
+        shape = tuple(batch) if size is None else size
+        rows = int(np.prod(shape)) if shape else 1
+        out = DeviceArray.empty((*shape, k), "int64")
+        if rows and k:
+            nk, nptr, ndt, nst = _param_operand(nn, shape)
+            if pr.ndim == 1 or int(np.prod(pr.shape[:-1])) == 1:
+                prc, stride = pr.contiguous(), 0
+            else:
+                if tuple(pr.shape[:-1]) != tuple(shape):
+                    full = DeviceArray.empty((*shape, k), pr.dtype)
+                    copy_into(full, pr)
+                    pr = full
+                prc, stride = pr.contiguous(), k
+            ffi.check(env.lib.pthip_random_multinomial(ffi.np_dtype_code(prc.dtype), rows, k, key_ptr, ctr_ptr, nptr, ndt, nst,
+                                                       prc.ptr, stride, out.ptr))
+            env.keepalive.extend((nk, prc))
         out = out if out_dtype == np.dtype("int64") else _cast(env, out, out_dtype)
         return [rng.advanced(rows), out]
 
@@ -158,6 +225,39 @@ def _draw(env, name, devs, shape, kernel_dtype, key_ptr, ctr_ptr) -> DeviceArray
         ffi.check(env.lib.pthip_random(code, ffi.np_dtype_code(kernel_dtype), n, key_ptr, ctr_ptr, len(ops),
                                        C.cast(ptrs, C.c_void_p), C.cast(dts, C.c_void_p), C.cast(sts, C.c_void_p), out.ptr))
         env.keepalive.extend(o[0] for o in ops)
+    return out
+
+
+def _random_order(env, n, weights, key_ptr, ctr_ptr):
+    """(argsort of n random keys, the sorted keys): uniform keys, or Exp(1) / weight keys"""
+    from pytensor_amd.dispatch.elemwise import launch_elemwise
+
+    one = env.to_device(HostValue(np.asarray(1.0)))
+    if weights is None:
+        keys = _draw(env, "uniform", [env.to_device(HostValue(np.asarray(0.0))), one], (n,), np.dtype("float64"), key_ptr, ctr_ptr)
+    else:
+        e = _draw(env, "exponential", [one], (n,), np.dtype("float64"), key_ptr, ctr_ptr)
+        wdt = str(weights.dtype)
+        body = {"in_dtypes": ["float64", wdt], "out_dtypes": ["float64"],
+                "body": [{"op": "Cast", "in": [["i", 1]], "dtype": "float64"}, {"op": "TrueDiv", "in": [["i", 0], ["t", 0]], "dtype": "float64"}],
+                "outs": [["t", 1]]}
+        (keys,), _, _ = launch_elemwise(body, [e, weights], (n,), ["float64"], None, env)
+    order = DeviceArray.empty((n,), "int64")
+    vals = DeviceArray.empty((n,), "float64")
+    if n:
+        ffi.check(env.lib.pthip_sort(ffi.np_dtype_code(np.dtype("float64")), 1, n, keys.contiguous().ptr, vals.ptr, order.ptr))
+    env.keepalive.append(keys)
+    return order, vals
+
+
+def _take_rows(env, x: DeviceArray, order: DeviceArray) -> DeviceArray:
+    """x[order] along axis 0 (pthip_take_rows)"""
+    x = x.contiguous()
+    rest = tuple(x.shape[1:])
+    inner = int(np.prod(rest)) if rest else 1
+    out = DeviceArray.empty((order.size, *rest), x.dtype)
+    if out.size:
+        ffi.check(env.lib.pthip_take_rows(x.itemsize, order.size, inner, x.ptr, x.shape[0], inner, order.ptr, out.ptr))
     return out
 
 

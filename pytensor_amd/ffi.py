@@ -120,6 +120,7 @@ SIGNATURES = {
     "pthip_nonzero": (_int, [_i64, _vp, _vp, _vp]),
     "pthip_random": (_int, [_int, _int, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     "pthip_random_categorical": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "pthip_random_multinomial": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _int, _i64, _vp, _i64, _vp]),
     "pthip_trsm": (_int, [_int, _int, _int, _int, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "pthip_copy_strided": (_int, [_int, _int, C.POINTER(_i64), _vp, C.POINTER(_i64), _vp, C.POINTER(_i64)]),
     "pthip_take_rows": (_int, [_int, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),

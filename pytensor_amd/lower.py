@@ -541,18 +541,25 @@ _INLINE = ("__inline__", {})
 def _(op, node, ctx):
     # inputs (rng, size, *dist_params) -> outputs (advanced rng, draws), random/op.py make_node;
     # samplers and their stream: csrc/random.hip, pytensor_amd/rng.py
-    from pytensor_amd.dispatch.random import DISTRIBUTIONS
+    from pytensor_amd.dispatch.random import DISTRIBUTIONS, STRUCTURED
 
     name = str(op.name)
-    if name not in DISTRIBUTIONS and name not in ("categorical", "dirichlet", "multivariate_normal"):
+    if name not in DISTRIBUTIONS and name not in STRUCTURED:
         return None
     if name == "multivariate_normal" and getattr(op, "method", "cholesky") != "cholesky":
         return None
-    return "RandomVariable", {
+    params = {
         "name": name,
         "dtype": str(node.outputs[1].type.dtype),
         "size_is_none": isinstance(node.inputs[1].type, NoneTypeT),
     }
+    if name in ("permutation", "choice_without_replacement"):
+        # rng.permutation / rng.choice have no batch dimensions (the reference loops over them on the host)
+        core = int(op.ndims_params[0])
+        if node.inputs[2].type.ndim != core or not params["size_is_none"]:
+            return None
+        params["ndims_params"] = [int(v) for v in op.ndims_params]
+    return "RandomVariable", params
 
 
 def _register_ofg():

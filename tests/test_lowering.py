@@ -111,6 +111,34 @@ def test_widening_rows_lower_to_their_own_nodes(pt):
         pytensor.function([x], ptt.hyp2f1(0.5, 1.0, 1.5, ptt.sigmoid(x)), mode="hip")
 
 
+def test_every_random_variable_of_the_reference_lowers(pt):
+    """tensor/random/basic.py: each RandomVariable class has a device sampler (no HostPerform); batched
+    permutation / choice-without-replacement, which the reference loops over on the host, are refused."""
+    pytensor, ptt = pt
+    import re
+
+    import pytensor.tensor.random.basic as rb
+    from pytensor_amd.dispatch.random import DISTRIBUTIONS, STRUCTURED
+
+    names = set(re.findall(r'^    name = "(\w+)"', open(rb.__file__).read(), re.M))
+    assert names and names <= set(DISTRIBUTIONS) | set(STRUCTURED), names - set(DISTRIBUTIONS) - set(STRUCTURED)
+    rng = pytensor.shared(np.random.default_rng(3), name="rng")
+    x = ptt.dmatrix("x")
+    R = ptt.random
+    outs = [R.wald(1.5, 2.5, size=(5,), rng=rng), R.truncexpon(2.5, -0.5, 1.5, size=(5,), rng=rng), R.gengamma(3.0, 1.5, 0.8, size=(5,), rng=rng),
+            R.betabinom(25, 2.0, 3.5, size=(5,), rng=rng), R.vonmises(0.7, 2.5, size=(5,), rng=rng), R.hypergeometric(30, 45, 20, size=(5,), rng=rng),
+            R.multinomial(40, np.array([0.1, 0.2, 0.7]), size=(5,), rng=rng), R.permutation(10, rng=rng), R.permutation(x, rng=rng),
+            R.choice(x, size=(2,), replace=False, rng=rng), R.choice(10, size=(2, 2), replace=False, p=np.full(10, 0.1), rng=rng)]
+    f = pytensor.function([x], outs, mode="hip")
+    rvs = [n.params["name"] for n in f.maker.linker.last_ir.nodes if n.op == "RandomVariable"]
+    assert sorted(rvs) == sorted(["wald", "truncexpon", "gengamma", "beta_binomial", "vonmises", "hypergeometric", "multinomial",
+                                  "permutation", "permutation", "choice_without_replacement", "choice_without_replacement"])
+    assert not any(n.op == "HostPerform" for n in f.maker.linker.last_ir.nodes)
+    x3 = ptt.dtensor3("x3")
+    with pytest.raises(NotImplementedError, match="permutation"):
+        pytensor.function([x3], rb.PermutationRV(signature="(x)->(x)", dtype="float64")(x3[0], rng=rng, size=(2,), return_next_rng=True)[1], mode="hip")
+
+
 def test_all_reduce_op_lowers_and_differentiates(pt):
     """The explicit collective (north_star: "the rare explicit all-reduce Op"): an ordinary Op for
     every linker (perform = the host reduction, identity on one rank), an ``AllReduce`` IR node

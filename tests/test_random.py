@@ -29,7 +29,8 @@ def rv_graph(name, dtype, size, param_specs):
     sz = g.new_var("int64", (len(size),), const=np.asarray(size, dtype="int64")) if size is not None else g.new_var("object", (), kind="none")
     ps = [g.new_var(dt, (None,) * nd) for dt, nd in param_specs]
     r2 = g.new_var("object", (), kind="rng")
-    out_nd = len(size) if size is not None else max([nd for _, nd in param_specs] + [0]) - (1 if name == "categorical" else 0)
+    out_nd = len(size) if size is not None else max([nd for _, nd in param_specs] + [0]) - (1 if name in ("categorical", "multinomial") else 0)
+    out_nd += name == "multinomial"
     out = g.new_var(dtype, (None,) * out_nd)
     g.add_node("RandomVariable", {"name": name, "dtype": dtype, "size_is_none": size is None}, [r, sz, *ps], [r2, out])
     g.inputs, g.outputs = [r, *ps], [r2, out]
@@ -65,17 +66,36 @@ CASES = {
     "binomial_large": ([400, 0.35], st.binom(400, 0.35), True),
     "binomial_flip": ([60, 0.85], st.binom(60, 0.85), True),
     "negative_binomial": ([5.0, 0.4], st.nbinom(5.0, 0.4), True),
+    "wald": ([1.5, 2.5], st.invgauss(1.5 / 2.5, scale=2.5), False),
+    "truncexpon": ([2.5, -0.5, 1.5], st.truncexpon(2.5, loc=-0.5, scale=1.5), False),
+    "gengamma": ([3.0, 1.5, 0.8], st.gengamma(2.0, 1.5, scale=0.8), False),
+    "beta_binomial": ([25, 2.0, 3.5], st.betabinom(25, 2.0, 3.5), True),
+    "beta_binomial_large": ([300, 4.0, 1.5], st.betabinom(300, 4.0, 1.5), True),
+    "vonmises": ([0.7, 2.5], st.vonmises(2.5, loc=0.7), False),
+    "vonmises_wrapped": ([3.0, 0.6], None, False),
+    "hypergeometric": ([30, 45, 20], st.hypergeom(75, 30, 20), True),
+    "hypergeometric_large": ([4000, 9000, 2500], st.hypergeom(13000, 4000, 2500), True),
 }
+# von Mises on the circle: the draw lies in [-pi, pi] (wrapped around mu), scipy's cdf does not wrap
+_VM = st.vonmises(0.6)
+CASES["vonmises_wrapped"] = ([3.0, 0.6], None, False)
+_MULTIWORD = ("negative_binomial", "beta_binomial")
 
 
 def _name(case):
-    return "negative_binomial" if case.startswith("negative_binomial") else case.split("_")[0]
+    for nm in _MULTIWORD:
+        if case.startswith(nm):
+            return nm
+    return case.split("_")[0]
 
 
 def _params(case):
     vals = CASES[case][0]
-    dt = "int64" if _name(case) == "integers" else "float64"
-    return [np.asarray(v, dtype=dt) for v in vals]
+    dt = "int64" if _name(case) in ("integers", "hypergeometric") else "float64"
+    out = [np.asarray(v, dtype=dt) for v in vals]
+    if _name(case) == "beta_binomial":
+        out[0] = np.asarray(vals[0], dtype="int64")
+    return out
 
 
 def _dtype(case):
@@ -85,6 +105,11 @@ def _dtype(case):
 def check_distribution(case, x):
     vals, dist, discrete = CASES[case]
     x = np.asarray(x).ravel()
+    if case == "vonmises_wrapped":
+        assert x.min() >= -np.pi and x.max() <= np.pi
+        y = np.mod(x - vals[0] + np.pi, 2 * np.pi) - np.pi   # angle relative to mu, in [-pi, pi)
+        assert st.kstest(y, _VM.cdf).pvalue > 1e-4
+        return
     if discrete:
         lo, hi = int(x.min()), int(x.max())
         ks = np.arange(lo, hi + 1)
@@ -140,6 +165,95 @@ def test_categorical_and_broadcast_parameters():
     g = rv_graph("normal", "float64", None, [("float64", 1), ("float64", 2)])
     _, y = np_graph.run_graph(g, [gen(), np.array([0.0, 100.0, -100.0]), np.full((500, 1), 0.5)])
     assert y.shape == (500, 3) and np.abs(y.mean(axis=0) - [0.0, 100.0, -100.0]).max() < 0.1
+
+
+_MULTI_P = np.array([0.05, 0.4, 0.25, 0.3])
+
+
+def check_multinomial(x, n):
+    """counts sum to n; every marginal is Binomial(n, p_j) (exact pmf chi-square)"""
+    assert x.shape[-1] == 4 and (x >= 0).all() and (x.sum(axis=-1) == n).all()
+    for j, pj in enumerate(_MULTI_P):
+        col = x[..., j].ravel()
+        ks = np.arange(col.min(), col.max() + 1)
+        obs = np.array([(col == k).sum() for k in ks], dtype=float)
+        exp = st.binom(n, pj).pmf(ks) * len(col)
+        keep = exp >= 5
+        chi2 = ((obs[keep] - exp[keep]) ** 2 / exp[keep]).sum()
+        assert st.chi2.sf(chi2, max(int(keep.sum()) - 1, 1)) > 1e-4, (j, chi2)
+    # and the pairwise covariance -n p_i p_j
+    flat = x.reshape(-1, 4).astype(float)
+    c = np.cov(flat.T)
+    want = -n * np.outer(_MULTI_P, _MULTI_P) + np.diag(n * _MULTI_P)
+    assert np.abs(c - want).max() < 0.08 * n * 0.25 + 0.3
+
+
+def test_multinomial_counts():
+    g = rv_graph("multinomial", "int64", (5000,), [("int64", 0), ("float64", 1)])
+    g2, x = np_graph.run_graph(g, [gen(2), np.asarray(40), _MULTI_P])
+    assert x.shape == (5000, 4) and x.dtype == np.int64 and philox_ref.generator_state(g2)[1] == 2 + 5000
+    check_multinomial(x, 40)
+    # size=None: n broadcast against the batch dimensions of p; a zero-probability category stays empty
+    g = rv_graph("multinomial", "int64", None, [("int64", 1), ("float64", 2)])
+    p2 = np.array([[0.5, 0.0, 0.5], [0.2, 0.3, 0.5]])
+    _, y = np_graph.run_graph(g, [gen(2), np.array([7, 900]), p2])
+    assert y.shape == (2, 3) and list(y.sum(axis=-1)) == [7, 900] and y[0, 1] == 0
+
+
+def order_graph(name, dtype, specs, ndims_params, out_nd=None):
+    """permutation / choice_without_replacement node: (rng, *params) -> (next_rng, draws); size=None"""
+    g = Graph(name=f"rv_{name}")
+    r = g.new_var("object", (), kind="rng", name="rng")
+    sz = g.new_var("object", (), kind="none")
+    ps = [g.new_var(dt, (None,) * nd) for dt, nd in specs]
+    r2 = g.new_var("object", (), kind="rng")
+    if out_nd is None:
+        out_nd = max(specs[0][1], 1)
+    out = g.new_var(dtype, (None,) * out_nd)
+    g.add_node("RandomVariable", {"name": name, "dtype": dtype, "size_is_none": True, "ndims_params": ndims_params}, [r, sz, *ps], [r2, out])
+    g.inputs, g.outputs = [r, *ps], [r2, out]
+    return g
+
+
+def test_permutation_and_choice_without_replacement():
+    # permutation of arange(n): a permutation; position of every element uniform
+    g = order_graph("permutation", "int64", [("int64", 0)], [0])
+    first = []
+    gcur = gen(0)
+    for _ in range(1200):
+        gcur, x = np_graph.run_graph(g, [gcur, np.asarray(6)])
+        assert sorted(x) == list(range(6))
+        first.append(x[0] * 6 + x[5])
+    obs = np.bincount(first, minlength=36).astype(float)
+    obs = obs[[i * 6 + j for i in range(6) for j in range(6) if i != j]]
+    assert st.chisquare(obs).pvalue > 1e-4
+    assert philox_ref.generator_state(gcur)[1] == 1200 * 2
+    # rows of a matrix are moved whole
+    g = order_graph("permutation", "float64", [("float64", 2)], [2])
+    m = np.arange(21.0).reshape(7, 3)
+    _, y = np_graph.run_graph(g, [gen(3), m])
+    assert y.shape == (7, 3) and sorted(y[:, 0]) == list(m[:, 0]) and np.array_equal(y[:, 1], y[:, 0] + 1)
+    # weighted choice without replacement: ordered pairs follow successive sampling, p_i p_j / (1 - p_i)
+    pr = np.array([0.5, 0.3, 0.15, 0.05])
+    g = order_graph("choice_without_replacement", "int64", [("int64", 0), ("float64", 1), ("int64", 1)], [0, 1, 1])
+    gcur, pairs = gen(1), []
+    for _ in range(4000):
+        gcur, x = np_graph.run_graph(g, [gcur, np.asarray(4), pr, np.array([2])])
+        assert x.shape == (2,) and x[0] != x[1]
+        pairs.append(x[0] * 4 + x[1])
+    keep = [i * 4 + j for i in range(4) for j in range(4) if i != j]
+    exp = np.array([pr[i] * pr[j] / (1 - pr[i]) for i in range(4) for j in range(4) if i != j]) * 4000
+    assert st.chisquare(np.bincount(pairs, minlength=16)[keep], exp).pvalue > 1e-4
+    # unweighted: elements of an array, 2-d core shape; errors as Generator.choice raises them
+    g = order_graph("choice_without_replacement", "float64", [("float64", 1), ("int64", 1)], [1, 1], out_nd=2)
+    vals = np.linspace(0.0, 1.0, 12)
+    _, z = np_graph.run_graph(g, [gen(8), vals, np.array([2, 3])])
+    assert z.shape == (2, 3) and len(set(z.ravel())) == 6 and set(z.ravel()) <= set(vals)
+    with pytest.raises(ValueError, match="larger sample than population"):
+        np_graph.run_graph(g, [gen(8), vals, np.array([13])])
+    g = order_graph("choice_without_replacement", "int64", [("int64", 0), ("float64", 1), ("int64", 1)], [0, 1, 1])
+    with pytest.raises(ValueError, match="Fewer non-zero entries in p than size"):
+        np_graph.run_graph(g, [gen(8), np.asarray(3), np.array([0.5, 0.5, 0.0]), np.array([3])])
 
 
 def _mv_cases():
@@ -236,6 +350,63 @@ def test_device_categorical_float32_and_broadcast(hip):
     got = HipExecutable(g)(gen(5), *ins)
     assert got[1].dtype == np.float32 and got[1].shape == (257, 3)
     np.testing.assert_allclose(got[1], want[1], rtol=1e-6, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_device_multinomial(hip):
+    from pytensor_amd.executor import HipExecutable
+
+    g = rv_graph("multinomial", "int64", (3000,), [("int64", 0), ("float64", 1)])
+    want = np_graph.run_graph(g, [gen(6), np.asarray(40), _MULTI_P])
+    exe = HipExecutable(g, auto_freeze=True)
+    for _ in range(2):
+        got = exe(gen(6), np.asarray(40), _MULTI_P)
+        assert np.array_equal(got[1], want[1]) and philox_ref.generator_state(got[0]) == philox_ref.generator_state(want[0])
+    _, nxt = exe(got[0], np.asarray(40), _MULTI_P)
+    check_multinomial(nxt, 40)
+    # batched n and float32 p rows, size=None; large n takes the BTRS branch per category
+    g = rv_graph("multinomial", "int64", None, [("int64", 1), ("float32", 2)])
+    ins = [np.array([7, 900, 100000]), np.array([[0.5, 0.0, 0.5], [0.2, 0.3, 0.5], [0.25, 0.7, 0.05]], dtype="float32")]
+    want = np_graph.run_graph(g, [gen(6), *ins])
+    got = HipExecutable(g)(gen(6), *ins)
+    assert got[1].shape == (3, 3) and np.array_equal(got[1], want[1])
+
+
+@pytest.mark.gpu
+def test_device_permutation_and_choice_without_replacement(hip):
+    from pytensor_amd.executor import HipExecutable
+
+    g = order_graph("permutation", "int64", [("int64", 0)], [0])
+    want = np_graph.run_graph(g, [gen(5), np.asarray(5000)])
+    exe = HipExecutable(g, auto_freeze=True)
+    for _ in range(3):
+        got = exe(gen(5), np.asarray(5000))
+        assert np.array_equal(got[1], want[1]) and philox_ref.generator_state(got[0]) == philox_ref.generator_state(want[0])
+    assert sorted(got[1]) == list(range(5000))
+    g = order_graph("permutation", "float32", [("float32", 2)], [2])
+    m = np.arange(3000, dtype="float32").reshape(1000, 3)
+    want = np_graph.run_graph(g, [gen(5), m])
+    got = HipExecutable(g)(gen(5), m)
+    assert got[1].dtype == np.float32 and np.array_equal(got[1], want[1])
+    pr = np.random.default_rng(0).dirichlet(np.ones(300))
+    pr[::7] = 0.0
+    pr /= pr.sum()
+    g = order_graph("choice_without_replacement", "int64", [("int64", 0), ("float64", 1), ("int64", 1)], [0, 1, 1], out_nd=2)
+    ins = [np.asarray(300), pr, np.array([5, 20])]
+    want = np_graph.run_graph(g, [gen(9), *ins])
+    got = HipExecutable(g)(gen(9), *ins)
+    assert got[1].shape == (5, 20) and np.array_equal(got[1], want[1]) and (pr[got[1]] > 0).all()
+    assert philox_ref.generator_state(got[0]) == philox_ref.generator_state(want[0])
+    g = order_graph("choice_without_replacement", "float64", [("float64", 2), ("int64", 1)], [2, 1])
+    a = np.arange(80.0).reshape(40, 2)
+    want = np_graph.run_graph(g, [gen(9), a, np.array([7])])
+    got = HipExecutable(g)(gen(9), a, np.array([7]))
+    assert got[1].shape == (7, 2) and np.array_equal(got[1], want[1])
+    with pytest.raises(ValueError, match="larger sample than population"):
+        HipExecutable(g)(gen(9), a, np.array([41]))
+    g = order_graph("choice_without_replacement", "int64", [("int64", 0), ("float64", 1), ("int64", 1)], [0, 1, 1])
+    with pytest.raises(ValueError, match="Fewer non-zero entries in p than size"):
+        HipExecutable(g)(gen(8), np.asarray(3), np.array([0.5, 0.5, 0.0]), np.array([3]))
 
 
 @pytest.mark.gpu
