@@ -118,7 +118,11 @@ int pthip_plan_replay(void* ga, void* gb, void* gc, void* dev_in, const void* ho
  * boundary behind an event wait).  A sequence that contains a host-to-device copy cannot be
  * recorded (pthip_record_end fails, *list = NULL).  pthip_launch_count: kernel launches + async
  * copies issued so far (used to size plan segments).  pthip_plan_replay2 = pthip_plan_replay with
- * each segment given either as a graph (g*) or as a list (l*). */
+ * each segment given either as a graph (g*) or as a list (l*).  pthip_plan_replay3 additionally
+ * copies the packed results (out_bytes at dev_out) into host_out after the last segment: the
+ * destination is a parameter of the call, not of the plan, so every call can fill a pinned block
+ * of its own that the caller hands out as the result arrays (JITLinker thunks return fresh
+ * arrays, link/basic.py:670-684) without copying them. */
 int pthip_record_begin(void);
 int pthip_record_end(void** list, int64_t* n_ops);
 int pthip_list_launch(void* list, int stream);
@@ -126,6 +130,9 @@ int pthip_list_destroy(void* list);
 int64_t pthip_launch_count(void);
 int pthip_plan_replay2(void* ga, void* la, void* gb, void* lb, void* gc, void* lc, void* dev_in,
                        const void* host_in, size_t in_bytes, int sync);
+int pthip_plan_replay3(void* ga, void* la, void* gb, void* lb, void* gc, void* lc, void* dev_in,
+                       const void* host_in, size_t in_bytes, const void* dev_out, void* host_out,
+                       size_t out_bytes, int sync);
 int pthip_graph_destroy(void* graph_exec);
 
 /* ---- events (HIP events on the context stream) ---- */

@@ -443,8 +443,9 @@ static int run_segment(void* g, void* l, hipStream_t st) {
   return 0;
 }
 
-int pthip_plan_replay2(void* ga, void* la, void* gb, void* lb, void* gc, void* lc, void* dev_in,
-                       const void* host_in, size_t in_bytes, int sync) {
+int pthip_plan_replay3(void* ga, void* la, void* gb, void* lb, void* gc, void* lc, void* dev_in,
+                       const void* host_in, size_t in_bytes, const void* dev_out, void* host_out,
+                       size_t out_bytes, int sync) {
   PTHIP_REQUIRE_INIT();
   static hipEvent_t ev_in = nullptr, ev_a = nullptr;
   static ReplayTrace tr;
@@ -477,10 +478,18 @@ int pthip_plan_replay2(void* ga, void* la, void* gb, void* lb, void* gc, void* l
     if (int r = run_segment(gb, lb, s0)) return r;
     tr.lap(2);
   }
+  // results packed by the last segment: one D2H into the pinned block of THIS call (the caller
+  // hands the block to its user without a copy, so the destination changes from call to call)
+  if (out_bytes) PTHIP_CHECK(hipMemcpyAsync(host_out, dev_out, out_bytes, hipMemcpyDeviceToHost, s0));
   if (sync) PTHIP_CHECK(hipStreamSynchronize(s0));
   tr.lap(4);
   tr.done();
   return 0;
+}
+
+int pthip_plan_replay2(void* ga, void* la, void* gb, void* lb, void* gc, void* lc, void* dev_in,
+                       const void* host_in, size_t in_bytes, int sync) {
+  return pthip_plan_replay3(ga, la, gb, lb, gc, lc, dev_in, host_in, in_bytes, nullptr, nullptr, 0, sync);
 }
 
 int pthip_plan_replay(void* ga, void* gb, void* gc, void* dev_in, const void* host_in,

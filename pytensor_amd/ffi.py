@@ -78,6 +78,7 @@ SIGNATURES = {
     "pthip_list_destroy": (_int, [_vp]),
     "pthip_launch_count": (_i64, []),
     "pthip_plan_replay2": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _int]),
+    "pthip_plan_replay3": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _int]),
     "pthip_graph_destroy": (_int, [_vp]),
     "pthip_event_create": (_int, [C.POINTER(_vp)]),
     "pthip_event_record": (_int, [_vp]),

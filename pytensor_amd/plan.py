@@ -31,6 +31,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -72,6 +73,51 @@ class _PinnedBlock:
             self.ptr = 0
 
 
+class _ResultRing:
+    """Pinned result blocks that are handed to the caller as the output arrays themselves.
+
+    A replay's D2H lands in a block of this ring and the views on it are returned without a copy
+    (an 800 kB gradient costs ~40 us to copy — more than the evaluation).  The block comes back
+    when the last array on it is collected; while every block is still held by the caller, calls
+    fall back to the plan's fixed block and copy out of it (fresh arrays either way,
+    link/basic.py:670-684)."""
+
+    def __init__(self, specs, limit):
+        self.specs, self.limit = specs, limit
+        self.free, self.made, self.closed = [], 0, False
+        self._layout = None  # (dtype, count, shape) per result, offsets from the first block
+
+    def take(self):
+        if self.free:
+            return self.free.pop()
+        if self.made < self.limit:
+            self.made += 1
+            return _PinnedBlock(self.specs)
+        return None
+
+    def hand_out(self, blk):
+        """fresh views of ``blk`` whose collection returns it to the ring"""
+        if self._layout is None:
+            self._layout = [(np.dtype(dtype), int(np.prod(shape)) if len(shape) else 1, tuple(shape), o)
+                            for (shape, dtype), o in zip(self.specs[:-1], blk.offsets)]
+            self._ctype = C.c_char * blk.nbytes
+        raw = self._ctype.from_address(blk.ptr)
+        weakref.finalize(raw, self._give_back, blk).atexit = False
+        fb = np.frombuffer
+        return [fb(raw, dtype=dt, count=n, offset=o).reshape(shape) for dt, n, shape, o in self._layout]
+
+    def _give_back(self, blk):
+        if self.closed:
+            blk.free()
+        else:
+            self.free.append(blk)
+
+    def close(self):
+        self.closed = True
+        while self.free:
+            self.free.pop().free()
+
+
 class _Src:
     """A raw device range handed to the pack kernel (the error word)."""
 
@@ -111,6 +157,9 @@ class _SegmentSwitch:
 
 # results up to this size are written by the pack kernel directly into pinned host memory
 _ZEROCOPY_MAX = int(os.environ.get("PTHIP_ZEROCOPY_MAX", 1 << 16))
+
+# larger results: this many pinned blocks per plan are handed out as the result arrays (0: always copy)
+_OUT_RING = int(os.environ.get("PTHIP_OUT_RING", 4))
 
 # a segment of at most this many launches is replayed as a recorded launch list (direct launches:
 # no hipGraph launch floor, no graph-to-graph boundary); longer ones as captured hipGraphs
@@ -175,6 +224,8 @@ class FrozenPlan:
         self._switch = _SegmentSwitch(self, seg) if self.segmented else None
         self._out_block = None
         self._out_meta = None
+        self._dev_out = None  # packed results on the device, copied out by the replay call itself
+        self._ring = None
         self._keep = []
         _CAPTURE_ACTIVE[0] = self
         try:
@@ -298,6 +349,7 @@ class FrozenPlan:
                 specs.append(((1,), np.dtype("int32")))
                 self._out_block = _PinnedBlock(specs)
                 self._out_block.views[-1][0] = 0
+                self._out_specs = specs
             ob = self._out_block
             dev_outs = [o.contiguous() for o in outs if not isinstance(o, HostValue)]
             if dev_outs and self.fetch_outputs:
@@ -325,9 +377,12 @@ class FrozenPlan:
                     nb = (C.c_int64 * n)(*[o.nbytes for o in chunk])
                     offs = (C.c_int64 * n)(*ob.offsets[c0 : c0 + n])
                     ffi.check(lib.pthip_pack(n, srcs, nb, offs, dev_out.ptr))
-                ffi.check(lib.pthip_d2h(ob.ptr, dev_out.ptr, ob.nbytes))
+                # the D2H is not part of the plan: the replay call issues it into the block of that call
                 if capture:
                     self._keep.append(dev_out)
+                    self._dev_out = dev_out
+                    if self._ring is None and _OUT_RING > 0:
+                        self._ring = _ResultRing(self._out_specs, _OUT_RING)
             if capture:
                 self._keep += [dev_outs, env.keepalive]
                 if exe.update_map:
@@ -380,9 +435,17 @@ class FrozenPlan:
             self._use_lists = False
         if self.segmented and len(self._graphs) != 3:
             raise ffi.HipError(f"segmented plan captured {len(self._graphs)} graphs instead of 3")
+        if self._dev_out is not None:
+            # the result copy is issued per call (not captured): take the runtime's one-time set-up of
+            # that copy path (8 ms on the second large D2H of a process, measured) here
+            for _ in range(2):
+                ffi.check(lib.pthip_d2h(self._out_block.ptr, self._dev_out.ptr, self._out_block.nbytes))
+                ffi.check(lib.pthip_synchronize())
+            if self._ring is not None:
+                self._ring.free.append(self._ring.take())  # the first call's block (pinning memory is slow)
 
     # ------------------------------------------------------------------
-    def _replay(self, sync):
+    def _replay(self, sync, out_block=None):
         if self.segmented:
             sa, sb, sc = self._graphs
         else:
@@ -390,8 +453,11 @@ class FrozenPlan:
         g = lambda seg: seg[1] if (seg is not None and seg[0] == "graph") else None
         l = lambda seg: seg[1] if (seg is not None and seg[0] == "list") else None
         nb = self._in_block.nbytes if self._dev_in is not None else 0
-        rc = self.lib.pthip_plan_replay2(
-            g(sa), l(sa), g(sb), l(sb), g(sc), l(sc), self._dev_in.ptr if nb else None, self._in_block.ptr if nb else None, nb, int(sync)
+        do = self._dev_out
+        ob = (out_block or self._out_block) if do is not None else None
+        rc = self.lib.pthip_plan_replay3(
+            g(sa), l(sa), g(sb), l(sb), g(sc), l(sc), self._dev_in.ptr if nb else None, self._in_block.ptr if nb else None, nb,
+            do.ptr if ob is not None else None, ob.ptr if ob is not None else None, ob.nbytes if ob is not None else 0, int(sync)
         )
         if rc:
             ffi.check(rc)
@@ -426,12 +492,15 @@ class FrozenPlan:
         for pos, b in self._baked.items():
             if not np.array_equal(np.asarray(inputs[pos]), b):
                 raise SignatureChanged(f"frozen plan: scalar input {pos} is baked into the plan and changed")
+        ring = self._ring
+        mine = ring.take() if ring is not None else None  # the pinned block this call's results land in
+        ob = mine or self._out_block
         if not late:
-            self._replay(True)  # one native call: H2D, graphs, stream synchronisation
+            self._replay(True, mine)  # one native call: H2D, graphs, D2H, stream synchronisation
         else:
             # launch first, fingerprint the resident host arrays while the GPU works (a borrowed
             # shared value edited in place, executor._fingerprint): the check costs the call nothing
-            self._replay(False)
+            self._replay(False, mine)
             from pytensor_amd.executor import _fingerprint
 
             dirty = [pos for pos, ent, v in late if _fingerprint(v) != ent.fp]
@@ -442,23 +511,26 @@ class FrozenPlan:
                 for pos in set(dirty) | {p for p, _ in self._fed}:
                     exe._resident_cache[pos].key = None
                     exe._refresh_resident(pos, inputs[pos])
-                self._replay(False)
+                self._replay(False, mine)
             ffi.check(lib.pthip_synchronize())
-        if self.fetch_outputs and self._out_block is not None and self._out_block.views[-1][0]:
+        if self.fetch_outputs and ob is not None and ob.views[-1][0]:
             from pytensor_amd.executor import raise_device_status
 
-            word = int(self._out_block.views[-1][0])
+            word = int(ob.views[-1][0])
             st = C.c_int(0)
             ffi.check(lib.pthip_check_status(C.byref(st)))  # clears the device word
-            self._out_block.views[-1][0] = 0
+            ob.views[-1][0] = 0
+            if mine is not None:
+                ring.free.append(mine)
             raise_device_status(word)
+        fresh = ring.hand_out(mine) if mine is not None else None
         res = []
         k = 0
         for meta in self._out_meta:
             if meta is not None:
                 res.append(meta.copy())
             else:
-                res.append(self._out_block.views[k].copy())
+                res.append(fresh[k] if fresh is not None else ob.views[k].copy())
                 k += 1
         if self._fed:
             self.exe._feed_updates_host(self._fed, res)
@@ -486,6 +558,9 @@ class FrozenPlan:
                 lib.pthip_arena_destroy(self._arena)
                 self._arena = C.c_void_p()
             self._dev_in = None
+            self._dev_out = None
+            if self._ring is not None:
+                self._ring.close()
             for blk in (self._in_block, self._out_block):
                 if blk is not None:
                     blk.free()

@@ -260,3 +260,49 @@ def test_small_segments_replay_as_launch_lists(hip, monkeypatch):
     for a, b in zip(p(*ins), want):
         np.testing.assert_array_equal(a, b)
     p.close()
+
+
+def test_large_results_are_handed_out_without_a_copy_and_stay_valid(hip):
+    """Results above the zero-copy pack limit land in a pinned block of the call's own (plan.py
+    ``_ResultRing``) and are returned as views on it: every call's arrays are distinct and keep
+    their values while later calls run (link/basic.py:670-684: thunks return fresh arrays), also
+    when the caller holds more results than the ring has blocks, and the blocks come back."""
+    import gc
+
+    from pytensor_amd.executor import HipExecutable
+    from pytensor_amd.ir import Graph
+
+    n = 50_000
+    g = Graph(name="big_out")
+    x = g.new_var("float64", (None,), name="x")
+    s = g.new_var("float64", (None,), name="s")
+    y, z = g.new_var("float64", (None,)), g.new_var("float64", (None,))
+    body = lambda op: {"in_dtypes": ["float64", "float64"], "out_dtypes": ["float64"],
+                       "body": [{"op": op, "in": [["i", 0], ["i", 1]], "dtype": "float64"}], "outs": [["t", 0]]}
+    g.add_node("Elemwise", {"scalar": body("Mul")}, [x, s], [y])
+    g.add_node("Elemwise", {"scalar": body("Add")}, [x, s], [z])
+    g.inputs, g.outputs = [x, s], [y, z]
+    xv = np.random.default_rng(0).normal(size=n)
+    exe = HipExecutable(g, resident=[0])
+    full = lambda v: np.full(n, float(v))
+    exe(xv, full(1))
+    plan = exe.freeze(xv, full(1))
+    assert plan._ring is not None
+    held = [plan(xv, full(k)) for k in range(7)]  # more than the ring holds
+    assert plan._ring.made == plan._ring.limit and not plan._ring.free
+    for k, (a, b) in enumerate(held):
+        assert a.flags.writeable and np.array_equal(a, xv * k) and np.array_equal(b, xv + k)
+    ptrs = {a.ctypes.data for a, _ in held}
+    assert len(ptrs) == 7
+    del held, a, b
+    gc.collect()
+    assert len(plan._ring.free) == plan._ring.limit  # every block came back
+    first = plan(xv, full(2))
+    again = plan(xv, full(3))
+    assert np.array_equal(first[0], xv * 2.0) and np.array_equal(again[0], xv * 3.0)
+    keep = first[1]
+    del first, again
+    plan.close()  # the array still held keeps its block; it is released with the array
+    assert np.array_equal(keep, xv + 2.0)
+    del keep
+    gc.collect()

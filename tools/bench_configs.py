@@ -70,6 +70,8 @@ def run_case(name, vals, reps, check=True, rtol=1e-10, oracle_vals=None, kernel_
     t_dev = device_time_ms(dplan, reps)
     dplan.close()
     plan = exe.freeze(*inputs)
+    for _ in range(2):  # untimed: the result ring pins its second block
+        plan(*inputs)
     t0 = time.perf_counter()
     for _ in range(reps):
         plan(*inputs)
