@@ -275,6 +275,35 @@ int pthip_random_categorical(int p_dtype, int64_t rows, int64_t k, const uint64_
 int pthip_random_multinomial(int p_dtype, int64_t rows, int64_t k, const uint64_t* key,
                              const uint64_t* counter, const void* n, int n_dtype, int64_t n_stride,
                              const void* p, int64_t row_stride, void* out);
+/* ---- dense decompositions, correct-first tier (csrc/decomp.hip): one workgroup per matrix ---- */
+/* QR.perform (linalg/decomposition/qr.py:153-221): LAPACK geqrf in place on `batch` contiguous
+ * row-major m x n matrices — Householder vectors below the diagonal (v_k = 1 implicit), R on and
+ * above it with dlarfg's signs, tau[batch][min(m,n)] */
+int pthip_geqrf(int dtype, int64_t batch, int64_t m, int64_t n, void* A, void* tau);
+/* orgqr: Q (m x ncols, contiguous) = H_0 ... H_{k-1} applied to the leading columns of the identity;
+ * QR as pthip_geqrf left it (row stride ldqr, qr_stride elements between batch items) */
+int pthip_orgqr(int dtype, int64_t batch, int64_t m, int64_t ncols, int64_t k, const void* QR, int64_t ldqr,
+                int64_t qr_stride, const void* tau, void* Q);
+/* SVD.perform (linalg/decomposition/svd.py:85-93; np.linalg.svd): one-sided Jacobi on the rows of X
+ * (r x c contiguous, r <= c <= any, r <= 2048; destroyed): X = P diag(S) Wt, S descending.
+ * vectors != 0: Wt (r x c, orthonormal rows; zero rows where S is 0) and Pt = P^T (r x r);
+ * Pt_work: r x r scratch.  Non-convergence (60 sweeps) raises bit 2 of the device error word. */
+int pthip_svd_rows(int dtype, int64_t batch, int64_t r, int64_t c, int vectors, void* X, void* Pt_work, void* S,
+                   void* Wt, void* Pt);
+/* rows i of Wt (r x c) with i >= r_valid or S[i] == 0 (S: r_valid per item) are replaced by column
+ * i of Q (c x ldq): an orthonormal completion of a rank-deficient or economy-sized factor */
+int pthip_fill_null_rows(int dtype, int64_t batch, int64_t r, int64_t c, void* Wt, const void* S, int64_t r_valid,
+                         const void* Q, int64_t ldq);
+/* dst (rows x cols, contiguous) = upper triangle of the leading rows of src (row stride ld,
+ * src_stride between batch items), zeros below: the R of QR.perform (qr.py:171-174) */
+int pthip_triu(int dtype, int64_t batch, int64_t rows, int64_t cols, const void* src, int64_t ld,
+               int64_t src_stride, void* dst);
+/* LUFactorTridiagonal / SolveLUFactorTridiagonal.perform (linalg/solvers/tridiagonal.py:70-90,
+ * 170-180): LAPACK gttrf in place on (dl[n-1], d[n], du[n-1]) -> du2[n-2], ipiv[n] (int32, 1-based
+ * as LAPACK returns it); gttrs on B (n x nrhs row-major, in place), trans = 0 | 1 */
+int pthip_gttrf(int dtype, int64_t batch, int64_t n, void* dl, void* d, void* du, void* du2, void* ipiv);
+int pthip_gttrs(int dtype, int64_t batch, int64_t n, int64_t nrhs, int trans, const void* dl, const void* d,
+                const void* du, const void* du2, const void* ipiv, void* B);
 /* out (n, n) = P * I for the gather vector perm of pthip_getrf (row i = unit vector e_perm[i]):
  * the right-hand side of MatrixInverse (pytensor/tensor/linalg/inverse.py:87), built on the device */
 int pthip_permuted_identity(int dtype, int64_t n, const void* perm, void* out);

@@ -1,0 +1,133 @@
+"""Golden cases for the dense decompositions lowered late in round 2 (imported by ``make_golden.py``).
+TEST INFRASTRUCTURE.
+
+What they pin (SURVEY §8f row 3 leftovers): ``QR`` in its four modes on tall / wide / square inputs
+with its gradient, ``SVD`` / ``MatrixPinv`` / ``Lstsq`` (sign- and basis-free functions of the singular
+vectors, which LAPACK does not fix either), the tridiagonal LU pair and ``Solve(assume_a=
+"tridiagonal")``, ``Eigvalsh``, ``TensorInv`` / ``TensorSolve``, ``BlockDiagonal``.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytensor
+import pytensor.tensor as pt
+
+from make_golden import case
+
+
+@case("qr_modes")
+def qr_modes():
+    # linalg/decomposition/qr.py:153-221 (geqrf + orgqr): R's diagonal carries LAPACK's signs, so Q
+    # and R are compared entry by entry; pullback 223-318 (static shapes: no IfElse)
+    from pytensor.tensor.linalg.decomposition.qr import QR
+
+    rng = np.random.default_rng(81)
+    T, W, S = pt.dmatrix("T"), pt.dmatrix("W"), pt.dmatrix("S")
+    F = pt.fmatrix("F")
+    Ts = pt.tensor("Ts", shape=(13, 7), dtype="float64")
+    Ws = pt.tensor("Ws", shape=(6, 11), dtype="float64")
+    C1, C2 = pt.dmatrix("C1"), pt.dmatrix("C2")
+    Qe, Re = QR(mode="economic")(Ts)
+    Qw, Rw = QR(mode="economic")(Ws)
+    cost = (Qe * C1).sum() + (Re**2).sum() + (Qw**3).sum() + (Rw * pt.tanh(Rw)).sum()
+    outs = [
+        *QR(mode="full")(T), *QR(mode="economic")(T), QR(mode="r")(T), *QR(mode="raw")(T),
+        *QR(mode="full")(W), *QR(mode="economic")(W), QR(mode="r")(W),
+        *QR(mode="full")(S), *QR(mode="economic")(F),
+        *pytensor.grad(cost, [Ts, Ws]),
+    ]
+    Tv, Wv = rng.normal(size=(13, 7)), rng.normal(size=(6, 11))
+    vals = {"T": Tv, "W": Wv, "S": rng.normal(size=(9, 9)), "F": rng.normal(size=(8, 5)).astype("float32"),
+            "Ts": Tv + 0.1, "Ws": Wv - 0.1, "C1": rng.normal(size=(13, 7)), "C2": rng.normal(size=(7, 7))}
+    return [T, W, S, F, Ts, Ws, C1, C2], outs, vals
+
+
+@case("svd_pinv_lstsq")
+def svd_pinv_lstsq():
+    # linalg/decomposition/svd.py:19 (np.linalg.svd), inverse.py:14 MatrixPinv (np.linalg.pinv),
+    # solvers/lstsq.py:10 Lstsq (np.linalg.lstsq).  Singular vectors are unique up to a sign per pair
+    # (distinct singular values) and the complement of an economy factor up to a rotation: the
+    # outputs are |U|, |Vt|, reconstructions and projectors.
+    from pytensor.tensor.linalg.decomposition.svd import SVD
+    from pytensor.tensor.linalg.inverse import MatrixPinv
+    from pytensor.tensor.linalg.solvers.lstsq import Lstsq
+
+    rng = np.random.default_rng(82)
+    A, B, D = pt.dmatrix("A"), pt.dmatrix("B"), pt.dmatrix("D")
+    C = pt.fmatrix("C")
+    y, y1 = pt.dmatrix("y"), pt.dvector("y1")
+    U, s, Vt = SVD(full_matrices=False)(A)
+    Uf, sf, Vtf = SVD(full_matrices=True)(B)
+    Ua, sa, Vta = SVD(full_matrices=True)(A)
+    Uc, sc, Vtc = SVD(full_matrices=False)(C)
+    xs = Lstsq()(A, y, pt.constant(-1.0))
+    x1 = Lstsq()(A, y1, pt.constant(1e-3))
+    xw = Lstsq()(B, y[:5], pt.constant(-1.0))
+    outs = [
+        SVD(compute_uv=False)(A), s, pt.abs(U), pt.abs(Vt), (U * s[None, :]) @ Vt,
+        sf, pt.abs(Uf), pt.abs(Vtf[:5]), Vtf[5:].T @ Vtf[5:],
+        sa, Ua[:, 7:] @ Ua[:, 7:].T, pt.abs(Vta),
+        sc, pt.abs(Uc), pt.abs(Vtc),
+        MatrixPinv(hermitian=False)(A), MatrixPinv(hermitian=False)(B), MatrixPinv(hermitian=False)(D),
+        *xs, *x1, *xw,
+    ]
+    Av = rng.normal(size=(12, 7))
+    Dv = rng.normal(size=(6, 3)) @ rng.normal(size=(3, 8))  # rank 3: the cutoff zeroes three singular values
+    vals = {"A": Av, "B": rng.normal(size=(5, 9)), "D": Dv, "C": rng.normal(size=(6, 6)).astype("float32"),
+            "y": rng.normal(size=(12, 2)), "y1": rng.normal(size=12)}
+    return [A, B, D, C, y, y1], outs, vals
+
+
+@case("tridiagonal_solve")
+def tridiagonal_solve():
+    # linalg/solvers/tridiagonal.py:18, 92 (LAPACK gttrf / gttrs, ipiv 1-based) and
+    # Solve(assume_a="tridiagonal") (general.py:17; scipy.linalg.solve reads the three diagonals)
+    from pytensor.tensor.linalg.solvers.tridiagonal import LUFactorTridiagonal, SolveLUFactorTridiagonal
+
+    rng = np.random.default_rng(83)
+    dl, d, du = pt.dvector("dl"), pt.dvector("d"), pt.dvector("du")
+    b, Bm = pt.dvector("b"), pt.dmatrix("Bm")
+    Am = pt.dmatrix("Am")
+    f = LUFactorTridiagonal()(dl, d, du)
+    outs = [
+        *f,
+        SolveLUFactorTridiagonal(b_ndim=1, transposed=False)(*f, b),
+        SolveLUFactorTridiagonal(b_ndim=2, transposed=True)(*f, Bm),
+        SolveLUFactorTridiagonal(b_ndim=2, transposed=False)(*f, Bm),
+        pt.linalg.solve(Am, b, assume_a="tridiagonal"),
+        pt.linalg.solve(Am, Bm, assume_a="tridiagonal"),
+    ]
+    n = 17
+    dv = rng.normal(size=n) + np.where(np.arange(n) % 3 == 0, 0.0, 3.0)  # every third pivot is small: rows swap
+    dlv, duv = rng.normal(size=n - 1), rng.normal(size=n - 1)
+    Av = np.diag(dv) + np.diag(dlv, -1) + np.diag(duv, 1)
+    return [dl, d, du, b, Bm, Am], outs, {"dl": dlv, "d": dv, "du": duv, "b": rng.normal(size=n), "Bm": rng.normal(size=(n, 3)), "Am": Av}
+
+
+@case("linalg_misc")
+def linalg_misc():
+    # decomposition/eigen.py:363 Eigvalsh (scipy.linalg.eigvalsh, standard and generalised),
+    # inverse.py:169 TensorInv, solvers/lstsq.py:39 TensorSolve (np.linalg.tensorinv / tensorsolve),
+    # constructors.py:52 BlockDiagonal (scipy.linalg.block_diag, largest common dtype)
+    from pytensor.tensor.linalg.constructors import BlockDiagonal
+    from pytensor.tensor.linalg.decomposition.eigen import Eigvalsh
+    from pytensor.tensor.linalg.inverse import TensorInv
+    from pytensor.tensor.linalg.solvers.lstsq import TensorSolve
+
+    rng = np.random.default_rng(84)
+    A, Bm = pt.dmatrix("A"), pt.dmatrix("B")
+    t4, t3, tb = pt.dtensor4("t4"), pt.dtensor3("t3"), pt.dmatrix("tb")
+    m1, m2, m3 = pt.dmatrix("m1"), pt.fmatrix("m2"), pt.bmatrix("m3")
+    outs = [
+        Eigvalsh(lower=True)(A), Eigvalsh(lower=False)(A, Bm),
+        TensorInv(ind=2)(t4), TensorSolve()(t3, tb),
+        BlockDiagonal(n_inputs=3)(m1, m2, m3), BlockDiagonal(n_inputs=2)(m2, m2.T),
+    ]
+    n = 11
+    M = rng.normal(size=(n, n))
+    Q = rng.normal(size=(n, n))
+    vals = {"A": M + M.T, "B": Q @ Q.T / n + np.eye(n),
+            "t4": rng.normal(size=(4, 6, 8, 3)) + 0.0, "t3": rng.normal(size=(2, 3, 6)), "tb": rng.normal(size=(2, 3)),
+            "m1": rng.normal(size=(3, 2)), "m2": rng.normal(size=(2, 4)).astype("float32"), "m3": np.array([[7, -3]], dtype="int8")}
+    return [A, Bm, t4, t3, tb, m1, m2, m3], outs, vals

@@ -999,6 +999,98 @@ def _eigh(p, inputs, node, graph):
     return [w, v]
 
 
+@op("Eigvalsh")
+def _eigvalsh(p, inputs, node, graph):
+    # pytensor/tensor/linalg/decomposition/eigen.py:363 (Eigvalsh.perform): scipy.linalg.eigvalsh
+    ins = [i for i in inputs if i is not None]
+    return [scipy.linalg.eigvalsh(ins[0], b=ins[1] if len(ins) == 2 else None, lower=p["lower"])]
+
+
+@op("QR")
+def _qr(p, inputs, node, graph):
+    # pytensor/tensor/linalg/decomposition/qr.py:153-221 (QR.perform): LAPACK geqrf, R = its upper
+    # triangle (the leading n rows for economic / raw when m >= n), Q from orgqr
+    (x,) = inputs
+    M, N = x.shape
+    geqrf, orgqr = scipy.linalg.get_lapack_funcs(("geqrf", "orgqr"), (x,))
+    qr, tau, _w, _info = geqrf(x)
+    mode = p["mode"]
+    R = np.triu(qr) if (mode not in ("economic", "raw") or M < N) else np.triu(qr[:N, :])
+    if mode == "r":
+        return [R]
+    if mode == "raw":
+        return [qr, tau, R]
+    if M < N:
+        Q = orgqr(qr[:, :M], tau)[0]
+    elif mode == "economic":
+        Q = orgqr(qr, tau)[0]
+    else:
+        qqr = np.empty((M, M), dtype=qr.dtype)
+        qqr[:, :N] = qr
+        Q = orgqr(qqr, tau)[0]
+    return [Q, R]
+
+
+@op("SVD")
+def _svd(p, inputs, node, graph):
+    # pytensor/tensor/linalg/decomposition/svd.py:85-93 (SVD.perform): np.linalg.svd
+    (x,) = inputs
+    if p["compute_uv"]:
+        return list(np.linalg.svd(x, p["full_matrices"], True))
+    return [np.linalg.svd(x, p["full_matrices"], False)]
+
+
+@op("MatrixPinv")
+def _matrix_pinv(p, inputs, node, graph):
+    # pytensor/tensor/linalg/inverse.py:32-35 (MatrixPinv.perform): np.linalg.pinv
+    return [np.linalg.pinv(inputs[0], hermitian=p["hermitian"])]
+
+
+@op("Lstsq")
+def _lstsq(p, inputs, node, graph):
+    # pytensor/tensor/linalg/solvers/lstsq.py:29-34 (Lstsq.perform): np.linalg.lstsq; the outputs are
+    # typed dmatrix / dvector / iscalar / dvector by make_node
+    x, res, rank, s = np.linalg.lstsq(inputs[0], inputs[1], inputs[2])
+    return [np.asarray(x, dtype="float64"), np.asarray(res, dtype="float64"), np.asarray(rank, dtype="int32"), np.asarray(s, dtype="float64")]
+
+
+@op("TensorInv")
+def _tensor_inv(p, inputs, node, graph):
+    # pytensor/tensor/linalg/inverse.py:187-190 (TensorInv.perform): np.linalg.tensorinv
+    return [np.linalg.tensorinv(inputs[0], p["ind"])]
+
+
+@op("TensorSolve")
+def _tensor_solve(p, inputs, node, graph):
+    # pytensor/tensor/linalg/solvers/lstsq.py:58-65 (TensorSolve.perform): np.linalg.tensorsolve
+    return [np.linalg.tensorsolve(inputs[0], inputs[1], None if p.get("axes") is None else tuple(p["axes"]))]
+
+
+@op("LUFactorTridiagonal")
+def _lu_factor_tridiagonal(p, inputs, node, graph):
+    # pytensor/tensor/linalg/solvers/tridiagonal.py:70-90: LAPACK gttrf (ipiv 1-based, as returned)
+    dt = np.result_type(*[np.asarray(i).dtype for i in inputs])
+    gttrf = scipy.linalg.get_lapack_funcs("gttrf", dtype=dt)
+    dl, d, du, du2, ipiv, _info = gttrf(*[np.asarray(i, dtype=dt) for i in inputs])
+    return [dl, d, du, du2, ipiv]
+
+
+@op("SolveLUFactorTridiagonal")
+def _solve_lu_factor_tridiagonal(p, inputs, node, graph):
+    # pytensor/tensor/linalg/solvers/tridiagonal.py:170-180: LAPACK gttrs
+    dl, d, du, du2, ipiv, b = inputs
+    dt = np.result_type(dl.dtype, d.dtype, du.dtype, du2.dtype, b.dtype)
+    gttrs = scipy.linalg.get_lapack_funcs("gttrs", dtype=dt)
+    x, _info = gttrs(*[np.asarray(v, dtype=dt) for v in (dl, d, du, du2)], ipiv, np.asarray(b, dtype=dt), trans="T" if p["transposed"] else "N")
+    return [x]
+
+
+@op("BlockDiagonal")
+def _block_diagonal(p, inputs, node, graph):
+    # pytensor/tensor/linalg/constructors.py:73-75: scipy.linalg.block_diag cast to the output dtype
+    return [scipy.linalg.block_diag(*inputs).astype(p["dtype"])]
+
+
 @op("MatrixInverse")
 def _matrix_inverse(p, inputs, node, graph):
     # pytensor/tensor/linalg/inverse.py:114-117 (MatrixInverse.perform): np.linalg.inv

@@ -1,0 +1,408 @@
+// decomp.hip — Householder QR, one-sided Jacobi SVD, tridiagonal LU: the dense decompositions of
+// SURVEY §8f row 3 that round 1 left on the host.
+//
+// Reference: QR.perform (pytensor/tensor/linalg/decomposition/qr.py:153-221: LAPACK geqrf, then
+// orgqr for Q), SVD.perform (linalg/decomposition/svd.py: np.linalg.svd = gesdd),
+// LUFactorTridiagonal / SolveLUFactorTridiagonal.perform (linalg/solvers/tridiagonal.py:70-90,
+// 170-180: LAPACK gttrf / gttrs).
+//
+// "Correct first" tier: one workgroup per matrix (batches on grid.x), the matrix in global memory
+// (L2-resident at the sizes these ops see), every inner loop a row-contiguous sweep so that a wave
+// reads whole 512-byte rows.  Conventions are LAPACK's where the result depends on them:
+//  * geqrf: H_k = I - tau v v^T, v_k = 1 implicit, beta = -sign(alpha) ||x|| on the diagonal
+//    (dlarfg), so R's diagonal carries LAPACK's signs and Q, R match the reference entry by entry;
+//  * gttrf / gttrs: dgttrf's pivoting rule (|d_i| >= |dl_i| keeps the row), 1-based ipiv, the
+//    same operation order as dgtts2, no fp contraction — bit-for-bit the reference's numbers;
+//  * SVD: singular values descending; U / V are defined up to a sign per pair (and up to a basis
+//    of the null space / complement), which LAPACK does not fix either.
+#include "common.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int VMAX = 4096;  // reflector entries staged in LDS (longer ones are read from L2)
+
+template <class T> __device__ __forceinline__ T dabs(T x) { return x < T(0) ? -x : x; }
+
+template <class T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// sum over the block; every thread gets the result (two barriers)
+template <class T> __device__ T block_sum(T v, T* s_red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  T r = T(0);
+#pragma unroll
+  for (int w = 0; w < BLOCK / 64; w++) r += s_red[w];
+  return r;
+}
+
+// M[r0:m, c0:c1] -= tau * v (v^T M[r0:m, c0:c1]),  v = (1, V[r0+1, vc], ..., V[m-1, vc])
+// threads: 64 columns x 4 row slices per pass; s_v: VMAX, s_w: 4 x 64
+template <class T>
+__device__ void apply_reflector(T* __restrict__ M, long long ld, int r0, int m, int c0, int c1,
+                                const T* __restrict__ V, long long ldv, int vc, T tau, T* s_v, T* s_w) {
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  const int len = m - r0;
+  const bool staged = len <= VMAX;
+  __syncthreads();
+  if (staged)
+    for (int i = tid; i < len; i += BLOCK) s_v[i] = i == 0 ? T(1) : V[(long long)(r0 + i) * ldv + vc];
+  __syncthreads();
+  for (int cc = c0; cc < c1; cc += 64) {
+    const int col = cc + tx;
+    T acc = T(0);
+    if (col < c1)
+      for (int i = ty; i < len; i += 4) {
+        const T vi = staged ? s_v[i] : (i == 0 ? T(1) : V[(long long)(r0 + i) * ldv + vc]);
+        acc += vi * M[(long long)(r0 + i) * ld + col];
+      }
+    s_w[ty * 64 + tx] = acc;
+    __syncthreads();
+    const T w = tau * (s_w[tx] + s_w[64 + tx] + s_w[128 + tx] + s_w[192 + tx]);
+    if (col < c1)
+      for (int i = ty; i < len; i += 4) {
+        const T vi = staged ? s_v[i] : (i == 0 ? T(1) : V[(long long)(r0 + i) * ldv + vc]);
+        M[(long long)(r0 + i) * ld + col] -= vi * w;
+      }
+    __syncthreads();
+  }
+}
+
+// in place: reflectors below the diagonal, R on and above it, tau[min(m,n)]
+template <class T>
+__global__ __launch_bounds__(BLOCK) void geqrf_kernel(T* __restrict__ Aall, T* __restrict__ tauall, int m, int n) {
+  __shared__ T s_v[VMAX];
+  __shared__ T s_w[256];
+  __shared__ T s_red[BLOCK / 64];
+  T* A = Aall + (long long)blockIdx.x * m * n;
+  const int K = m < n ? m : n;
+  T* tau = tauall + (long long)blockIdx.x * K;
+  const int tid = threadIdx.x;
+  for (int k = 0; k < K; k++) {
+    T part = T(0);
+    for (int i = k + 1 + tid; i < m; i += BLOCK) {
+      const T x = A[(long long)i * n + k];
+      part += x * x;
+    }
+    const T xn2 = block_sum(part, s_red);
+    const T alpha = A[(long long)k * n + k];
+    if (xn2 == T(0)) {  // dlarfg: H = I
+      if (tid == 0) tau[k] = T(0);
+      continue;
+    }
+    const T nrm = hypot(alpha, sqrt(xn2));
+    const T beta = alpha >= T(0) ? -nrm : nrm;
+    const T tk = (beta - alpha) / beta;
+    const T scale = T(1) / (alpha - beta);
+    __syncthreads();  // (every thread has read alpha)
+    for (int i = k + 1 + tid; i < m; i += BLOCK) A[(long long)i * n + k] *= scale;
+    if (tid == 0) { A[(long long)k * n + k] = beta; tau[k] = tk; }
+    if (k + 1 < n) apply_reflector(A, n, k, m, k + 1, n, A, n, k, tk, s_v, s_w);
+    __syncthreads();
+  }
+}
+
+// Q (m x nc) = H_0 H_1 ... H_{k-1} applied to the first nc columns of the identity (dorg2r)
+template <class T>
+__global__ __launch_bounds__(BLOCK) void orgqr_kernel(const T* __restrict__ QRall, long long ldqr, long long qr_stride,
+                                                     const T* __restrict__ tauall, T* __restrict__ Qall, int m, int nc, int k) {
+  __shared__ T s_v[VMAX];
+  __shared__ T s_w[256];
+  const T* QR = QRall + (long long)blockIdx.x * qr_stride;
+  const T* tau = tauall + (long long)blockIdx.x * k;
+  T* Q = Qall + (long long)blockIdx.x * m * nc;
+  for (long long e = threadIdx.x; e < (long long)m * nc; e += BLOCK) Q[e] = (e / nc == e % nc) ? T(1) : T(0);
+  __syncthreads();
+  for (int j = k - 1; j >= 0; j--) {
+    const T tj = tau[j];
+    if (tj != T(0) && j < nc) apply_reflector(Q, nc, j, m, j, nc, QR, ldqr, j, tj, s_v, s_w);
+  }
+}
+
+// ---- one-sided Jacobi SVD on the rows of X (r x c, r <= c) ------------------------------------
+// X = P diag(s) Wt: rotations from the left orthogonalise the rows (Hestenes), Pt accumulates them.
+// Parallel order: round-robin tournament, one wave per pair, a barrier per round.
+template <class T>
+__global__ __launch_bounds__(BLOCK) void svd_rows_kernel(T* __restrict__ Xall, T* __restrict__ Ptall, T* __restrict__ Sall,
+                                                        T* __restrict__ Wtall, T* __restrict__ Poutall, int r, int c,
+                                                        int want_vectors, int* __restrict__ status) {
+  __shared__ int s_rot;
+  __shared__ T s_norm[2048];  // r <= 2048 (checked by the caller)
+  T* X = Xall + (long long)blockIdx.x * r * c;
+  T* Pt = Ptall + (long long)blockIdx.x * r * r;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const T eps = sizeof(T) == 8 ? T(2.220446049250313e-16) : T(1.1920929e-07);
+  if (want_vectors) {
+    for (long long e = tid; e < (long long)r * r; e += BLOCK) Pt[e] = (e / r == e % r) ? T(1) : T(0);
+  }
+  __syncthreads();
+  const int R = (r + 1) & ~1;  // players (one bye when r is odd)
+  bool converged = r < 2;
+  for (int sweep = 0; sweep < 60 && !converged; sweep++) {
+    if (tid == 0) s_rot = 0;
+    __syncthreads();
+    for (int step = 0; step < R - 1; step++) {
+      for (int idx = wid; idx < R / 2; idx += BLOCK / 64) {
+        int p, q;
+        if (idx == 0) { p = R - 1; q = step; }
+        else { p = (step + idx) % (R - 1); q = (step - idx + (R - 1)) % (R - 1); }
+        if (p >= r || q >= r) continue;
+        if (p > q) { const int t = p; p = q; q = t; }
+        T* xp = X + (long long)p * c;
+        T* xq = X + (long long)q * c;
+        T a = T(0), b = T(0), g = T(0);
+        for (int j = lane; j < c; j += 64) {
+          const T u = xp[j], v = xq[j];
+          a += u * u; b += v * v; g += u * v;
+        }
+        a = wave_sum(a); b = wave_sum(b); g = wave_sum(g);
+        if (g == T(0) || dabs(g) <= eps * sqrt(a) * sqrt(b)) continue;
+        const T zeta = (b - a) / (T(2) * g);
+        const T t = (zeta >= T(0) ? T(1) : T(-1)) / (dabs(zeta) + sqrt(T(1) + zeta * zeta));
+        const T cs = T(1) / sqrt(T(1) + t * t), sn = cs * t;
+        for (int j = lane; j < c; j += 64) {
+          const T u = xp[j], v = xq[j];
+          xp[j] = cs * u - sn * v;
+          xq[j] = sn * u + cs * v;
+        }
+        if (want_vectors) {
+          T* pp = Pt + (long long)p * r;
+          T* pq = Pt + (long long)q * r;
+          for (int j = lane; j < r; j += 64) {
+            const T u = pp[j], v = pq[j];
+            pp[j] = cs * u - sn * v;
+            pq[j] = sn * u + cs * v;
+          }
+        }
+        if (lane == 0) s_rot = 1;
+      }
+      __syncthreads();
+    }
+    converged = s_rot == 0;
+    __syncthreads();
+  }
+  if (!converged && tid == 0 && status) atomicOr(status, 4);
+  // singular values = row norms; rank them descending (ties by position)
+  for (int i = wid; i < r; i += BLOCK / 64) {
+    T a = T(0);
+    for (int j = lane; j < c; j += 64) { const T u = X[(long long)i * c + j]; a += u * u; }
+    a = wave_sum(a);
+    if (lane == 0) s_norm[i] = sqrt(a);
+  }
+  __syncthreads();
+  T* S = Sall + (long long)blockIdx.x * r;
+  T* Wt = Wtall + (long long)blockIdx.x * r * c;
+  T* Pout = Poutall + (long long)blockIdx.x * r * r;
+  for (int i = wid; i < r; i += BLOCK / 64) {
+    const T si = s_norm[i];
+    int rank = 0;
+    for (int j = lane; j < r; j += 64) rank += (s_norm[j] > si || (s_norm[j] == si && j < i)) ? 1 : 0;
+    rank = (int)wave_sum((T)rank);
+    if (lane == 0) S[rank] = si;
+    if (want_vectors) {
+      const T inv = si > T(0) ? T(1) / si : T(0);
+      for (int j = lane; j < c; j += 64) Wt[(long long)rank * c + j] = X[(long long)i * c + j] * inv;
+      for (int j = lane; j < r; j += 64) Pout[(long long)rank * r + j] = Pt[(long long)i * r + j];
+    }
+  }
+}
+
+// rows of Wt that came out zero (singular value 0) are replaced by the same rows of Qt, an
+// orthonormal completion (transposed Householder Q of Wt^T): rows stay orthonormal
+template <class T>
+__global__ void fill_null_rows_kernel(T* __restrict__ Wt, const T* __restrict__ S, int r_valid, const T* __restrict__ Q,
+                                      long long batch, int r, int c, int ldq) {
+  const long long total = batch * r * c;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long b = e / ((long long)r * c);
+    const int i = (int)((e / c) % r), j = (int)(e % c);
+    if (i >= r_valid || !(S[b * r_valid + i] > T(0))) Wt[e] = Q[b * (long long)c * ldq + (long long)j * ldq + i];  // Q is c x ldq, column i
+  }
+}
+
+// dst (rows x cols, contiguous) = upper triangle of src's leading rows (row stride ld), zeros below
+template <class T>
+__global__ void triu_kernel(T* __restrict__ dst, const T* __restrict__ src, long long batch, int rows, int cols, long long ld,
+                            long long src_stride) {
+  const long long total = batch * rows * cols;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long b = e / ((long long)rows * cols);
+    const int i = (int)((e / cols) % rows), j = (int)(e % cols);
+    dst[e] = j >= i ? src[b * src_stride + (long long)i * ld + j] : T(0);
+  }
+}
+
+// ---- tridiagonal LU (dgttrf) and its solves (dgtts2); one thread per system / right-hand side ----
+template <class T>
+__global__ void gttrf_kernel(long long batch, int n, T* __restrict__ dl, T* __restrict__ d, T* __restrict__ du,
+                             T* __restrict__ du2, int* __restrict__ ipiv) {
+#pragma clang fp contract(off)
+  const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= batch) return;
+  dl += s * (n - 1); du += s * (n - 1); d += s * n; ipiv += s * n;
+  if (n > 2) du2 += s * (n - 2);
+  for (int i = 0; i < n; i++) ipiv[i] = i + 1;
+  for (int i = 0; i < n - 2; i++) du2[i] = T(0);
+  for (int i = 0; i < n - 1; i++) {
+    const bool last = i == n - 2;
+    if (dabs(d[i]) >= dabs(dl[i])) {
+      if (d[i] != T(0)) {
+        const T fact = dl[i] / d[i];
+        dl[i] = fact;
+        d[i + 1] = d[i + 1] - fact * du[i];
+      }
+    } else {
+      const T fact = d[i] / dl[i];
+      d[i] = dl[i];
+      dl[i] = fact;
+      const T temp = du[i];
+      du[i] = d[i + 1];
+      d[i + 1] = temp - fact * d[i + 1];
+      if (!last) {
+        du2[i] = du[i + 1];
+        du[i + 1] = -fact * du[i + 1];
+      }
+      ipiv[i] = i + 2;
+    }
+  }
+}
+
+template <class T>
+__global__ void gttrs_kernel(long long batch, int n, int nrhs, int trans, const T* __restrict__ dl, const T* __restrict__ d,
+                             const T* __restrict__ du, const T* __restrict__ du2, const int* __restrict__ ipiv,
+                             T* __restrict__ B) {
+#pragma clang fp contract(off)
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= batch * nrhs) return;
+  const long long s = e / nrhs;
+  const int col = (int)(e % nrhs);
+  dl += s * (n - 1); du += s * (n - 1); d += s * n; ipiv += s * n;
+  if (n > 2) du2 += s * (n - 2);
+  T* b = B + s * (long long)n * nrhs + col;
+  const long long ld = nrhs;
+  if (!trans) {
+    for (int i = 0; i < n - 1; i++) {
+      const int ip = ipiv[i] - 1;
+      const T temp = b[(i + 1 - ip + i) * ld] - dl[i] * b[ip * ld];
+      b[i * ld] = b[ip * ld];
+      b[(i + 1) * ld] = temp;
+    }
+    b[(n - 1) * ld] = b[(n - 1) * ld] / d[n - 1];
+    if (n > 1) b[(n - 2) * ld] = (b[(n - 2) * ld] - du[n - 2] * b[(n - 1) * ld]) / d[n - 2];
+    for (int i = n - 3; i >= 0; i--) b[i * ld] = (b[i * ld] - du[i] * b[(i + 1) * ld] - du2[i] * b[(i + 2) * ld]) / d[i];
+  } else {
+    b[0] = b[0] / d[0];
+    if (n > 1) b[ld] = (b[ld] - du[0] * b[0]) / d[1];
+    for (int i = 2; i < n; i++) b[i * ld] = (b[i * ld] - du[i - 1] * b[(i - 1) * ld] - du2[i - 2] * b[(i - 2) * ld]) / d[i];
+    for (int i = n - 2; i >= 0; i--) {
+      const int ip = ipiv[i] - 1;
+      const T temp = b[i * ld] - dl[i] * b[(i + 1) * ld];
+      b[i * ld] = b[ip * ld];
+      b[ip * ld] = temp;
+    }
+  }
+}
+
+template <class T> int geqrf_typed(long long batch, int m, int n, void* A, void* tau) {
+  PTHIP_KLAUNCH(geqrf_kernel<T>, dim3((unsigned)batch), dim3(BLOCK), 0, pthip::ctx().stream, (T*)A, (T*)tau, m, n);
+  return pthip::post_launch("geqrf");
+}
+
+template <class T> int orgqr_typed(long long batch, int m, int nc, int k, const void* QR, long long ldqr, long long stride,
+                                   const void* tau, void* Q) {
+  PTHIP_KLAUNCH(orgqr_kernel<T>, dim3((unsigned)batch), dim3(BLOCK), 0, pthip::ctx().stream, (const T*)QR, ldqr, stride,
+                (const T*)tau, (T*)Q, m, nc, k);
+  return pthip::post_launch("orgqr");
+}
+
+template <class T> int svd_typed(long long batch, int r, int c, int vectors, void* X, void* Pt, void* S, void* Wt, void* Pout) {
+  PTHIP_KLAUNCH(svd_rows_kernel<T>, dim3((unsigned)batch), dim3(BLOCK), 0, pthip::ctx().stream, (T*)X, (T*)Pt, (T*)S, (T*)Wt,
+                (T*)Pout, r, c, vectors, pthip::ctx().status_dev);
+  return pthip::post_launch("svd_rows");
+}
+
+}  // namespace
+
+extern "C" int pthip_geqrf(int dtype, int64_t batch, int64_t m, int64_t n, void* A, void* tau) {
+  PTHIP_REQUIRE_INIT();
+  if (batch <= 0 || m <= 0 || n <= 0) return 0;
+  if (dtype == PTHIP_F64) return geqrf_typed<double>(batch, (int)m, (int)n, A, tau);
+  if (dtype == PTHIP_F32) return geqrf_typed<float>(batch, (int)m, (int)n, A, tau);
+  return pthip::set_error("pthip_geqrf: dtype %d not supported (float32/float64 only)", dtype);
+}
+
+extern "C" int pthip_orgqr(int dtype, int64_t batch, int64_t m, int64_t ncols, int64_t k, const void* QR, int64_t ldqr,
+                           int64_t qr_stride, const void* tau, void* Q) {
+  PTHIP_REQUIRE_INIT();
+  if (batch <= 0 || m <= 0 || ncols <= 0) return 0;
+  if (dtype == PTHIP_F64) return orgqr_typed<double>(batch, (int)m, (int)ncols, (int)k, QR, ldqr, qr_stride, tau, Q);
+  if (dtype == PTHIP_F32) return orgqr_typed<float>(batch, (int)m, (int)ncols, (int)k, QR, ldqr, qr_stride, tau, Q);
+  return pthip::set_error("pthip_orgqr: dtype %d not supported (float32/float64 only)", dtype);
+}
+
+extern "C" int pthip_svd_rows(int dtype, int64_t batch, int64_t r, int64_t c, int vectors, void* X, void* Pt_work, void* S,
+                              void* Wt, void* Pt) {
+  PTHIP_REQUIRE_INIT();
+  if (batch <= 0 || r <= 0) return 0;
+  if (r > c) return pthip::set_error("pthip_svd_rows: %lld rows > %lld columns (pass the transpose)", (long long)r, (long long)c);
+  if (r > 2048) return pthip::set_error("pthip_svd_rows: min(m, n) = %lld above 2048", (long long)r);
+  if (dtype == PTHIP_F64) return svd_typed<double>(batch, (int)r, (int)c, vectors, X, Pt_work, S, Wt, Pt);
+  if (dtype == PTHIP_F32) return svd_typed<float>(batch, (int)r, (int)c, vectors, X, Pt_work, S, Wt, Pt);
+  return pthip::set_error("pthip_svd_rows: dtype %d not supported (float32/float64 only)", dtype);
+}
+
+extern "C" int pthip_triu(int dtype, int64_t batch, int64_t rows, int64_t cols, const void* src, int64_t ld,
+                          int64_t src_stride, void* dst) {
+  PTHIP_REQUIRE_INIT();
+  const long long total = (long long)batch * rows * cols;
+  if (total <= 0) return 0;
+  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipStream_t st = pthip::ctx().stream;
+  if (dtype == PTHIP_F64) PTHIP_KLAUNCH(triu_kernel<double>, dim3(grid), dim3(256), 0, st, (double*)dst, (const double*)src, (long long)batch, (int)rows, (int)cols, (long long)ld, (long long)src_stride);
+  else if (dtype == PTHIP_F32) PTHIP_KLAUNCH(triu_kernel<float>, dim3(grid), dim3(256), 0, st, (float*)dst, (const float*)src, (long long)batch, (int)rows, (int)cols, (long long)ld, (long long)src_stride);
+  else return pthip::set_error("pthip_triu: dtype %d not supported", dtype);
+  return pthip::post_launch("triu");
+}
+
+extern "C" int pthip_fill_null_rows(int dtype, int64_t batch, int64_t r, int64_t c, void* Wt, const void* S, int64_t r_valid,
+                                    const void* Q, int64_t ldq) {
+  PTHIP_REQUIRE_INIT();
+  const long long total = (long long)batch * r * c;
+  if (total <= 0) return 0;
+  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipStream_t st = pthip::ctx().stream;
+  if (dtype == PTHIP_F64) PTHIP_KLAUNCH(fill_null_rows_kernel<double>, dim3(grid), dim3(256), 0, st, (double*)Wt, (const double*)S, (int)r_valid, (const double*)Q, (long long)batch, (int)r, (int)c, (int)ldq);
+  else if (dtype == PTHIP_F32) PTHIP_KLAUNCH(fill_null_rows_kernel<float>, dim3(grid), dim3(256), 0, st, (float*)Wt, (const float*)S, (int)r_valid, (const float*)Q, (long long)batch, (int)r, (int)c, (int)ldq);
+  else return pthip::set_error("pthip_fill_null_rows: dtype %d not supported", dtype);
+  return pthip::post_launch("fill_null_rows");
+}
+
+extern "C" int pthip_gttrf(int dtype, int64_t batch, int64_t n, void* dl, void* d, void* du, void* du2, void* ipiv) {
+  PTHIP_REQUIRE_INIT();
+  if (batch <= 0 || n <= 0) return 0;
+  const int grid = (int)((batch + 63) / 64);
+  hipStream_t st = pthip::ctx().stream;
+  if (dtype == PTHIP_F64) PTHIP_KLAUNCH(gttrf_kernel<double>, dim3(grid), dim3(64), 0, st, (long long)batch, (int)n, (double*)dl, (double*)d, (double*)du, (double*)du2, (int*)ipiv);
+  else if (dtype == PTHIP_F32) PTHIP_KLAUNCH(gttrf_kernel<float>, dim3(grid), dim3(64), 0, st, (long long)batch, (int)n, (float*)dl, (float*)d, (float*)du, (float*)du2, (int*)ipiv);
+  else return pthip::set_error("pthip_gttrf: dtype %d not supported (float32/float64 only)", dtype);
+  return pthip::post_launch("gttrf");
+}
+
+extern "C" int pthip_gttrs(int dtype, int64_t batch, int64_t n, int64_t nrhs, int trans, const void* dl, const void* d,
+                           const void* du, const void* du2, const void* ipiv, void* B) {
+  PTHIP_REQUIRE_INIT();
+  if (batch <= 0 || n <= 0 || nrhs <= 0) return 0;
+  const long long total = (long long)batch * nrhs;
+  const int grid = (int)((total + 63) / 64);
+  hipStream_t st = pthip::ctx().stream;
+  if (dtype == PTHIP_F64) PTHIP_KLAUNCH(gttrs_kernel<double>, dim3(grid), dim3(64), 0, st, (long long)batch, (int)n, (int)nrhs, trans, (const double*)dl, (const double*)d, (const double*)du, (const double*)du2, (const int*)ipiv, (double*)B);
+  else if (dtype == PTHIP_F32) PTHIP_KLAUNCH(gttrs_kernel<float>, dim3(grid), dim3(64), 0, st, (long long)batch, (int)n, (int)nrhs, trans, (const float*)dl, (const float*)d, (const float*)du, (const float*)du2, (const int*)ipiv, (float*)B);
+  else return pthip::set_error("pthip_gttrs: dtype %d not supported (float32/float64 only)", dtype);
+  return pthip::post_launch("gttrs");
+}

@@ -94,7 +94,11 @@ def _solve(env, p, A, b):
             # scipy sysv reads only the triangle named by `lower`
             A = _symmetrize(env, A, bool(p["lower"]))
         return solve_general(env, A, b, p["b_ndim"])
-    raise NotImplementedError(f"hip linker: Solve(assume_a={assume!r}) is not lowered (gen and pos are)")
+    if assume == "tridiagonal":
+        from pytensor_amd.dispatch.decomp import solve_tridiagonal
+
+        return solve_tridiagonal(env, A, b, p["b_ndim"])
+    raise NotImplementedError(f"hip linker: Solve(assume_a={assume!r}) is not lowered")
 
 
 def lu_factor_device(env, a: DeviceArray):

@@ -202,9 +202,12 @@ def _has_op(graph, name: str) -> bool:
 def raise_device_status(word: int):
     """The device error word (kernels cannot raise): bit 0 = an index was out of range
     (IndexError, like the reference's take/inc_subtensor), bit 1 = np.linalg.inv met an exactly
-    singular matrix (LinAlgError)."""
+    singular matrix (LinAlgError), bit 2 = the Jacobi SVD did not converge (LinAlgError, the message
+    of np.linalg.svd)."""
     if word & 2:
         raise np.linalg.LinAlgError("Singular matrix")
+    if word & 4:
+        raise np.linalg.LinAlgError("SVD did not converge")
     if word & 1:
         raise IndexError("index out of bounds (device-side check)")
 

@@ -335,7 +335,7 @@ def _register_extra_ops():
     def _(op, node, ctx):
         # "sym"/"her" (real dtypes: the same thing) run on the general LU — LAPACK's sysv
         # (Bunch-Kaufman) is a different but equally backward-stable factorisation
-        if op.assume_a not in ("gen", "pos", "sym", "her"):
+        if op.assume_a not in ("gen", "pos", "sym", "her", "tridiagonal"):
             return None
         return "Solve", {"assume_a": str(op.assume_a), "lower": bool(op.lower), "b_ndim": int(op.b_ndim)}
 
@@ -355,12 +355,64 @@ def _register_extra_ops():
     def _(op, node, ctx):
         return "PivotToPermutations", {"inverse": bool(op.inverse)}
 
-    from pytensor.tensor.linalg.decomposition.eigen import Eigh
+    from pytensor.tensor.linalg.decomposition.eigen import Eigh, Eigvalsh
 
     @hip_funcify.register(Eigh)
     def _(op, node, ctx):
         # one input: the standard problem; two: A v = w B v (dispatch/lu.py::_eigh_generalised)
         return "Eigh", {"lower": bool(op.lower)}
+
+    @hip_funcify.register(Eigvalsh)
+    def _(op, node, ctx):
+        return "Eigvalsh", {"lower": bool(op.lower)}
+
+    # dense decompositions of the correct-first tier (csrc/decomp.hip, dispatch/decomp.py)
+    from pytensor.tensor.linalg.constructors import BlockDiagonal
+    from pytensor.tensor.linalg.decomposition.qr import QR
+    from pytensor.tensor.linalg.decomposition.svd import SVD
+    from pytensor.tensor.linalg.inverse import MatrixPinv, TensorInv
+    from pytensor.tensor.linalg.solvers.lstsq import Lstsq, TensorSolve
+    from pytensor.tensor.linalg.solvers.tridiagonal import LUFactorTridiagonal, SolveLUFactorTridiagonal
+
+    @hip_funcify.register(QR)
+    def _(op, node, ctx):
+        if op.pivoting:
+            return None  # (geqp3's column pivoting: not lowered)
+        return "QR", {"mode": str(op.mode)}
+
+    @hip_funcify.register(SVD)
+    def _(op, node, ctx):
+        return "SVD", {"full_matrices": bool(op.full_matrices), "compute_uv": bool(op.compute_uv)}
+
+    @hip_funcify.register(MatrixPinv)
+    def _(op, node, ctx):
+        return "MatrixPinv", {"hermitian": bool(op.hermitian)}
+
+    @hip_funcify.register(Lstsq)
+    def _(op, node, ctx):
+        return "Lstsq", {}
+
+    @hip_funcify.register(TensorInv)
+    def _(op, node, ctx):
+        return "TensorInv", {"ind": int(op.ind)}
+
+    @hip_funcify.register(TensorSolve)
+    def _(op, node, ctx):
+        return "TensorSolve", {"axes": None if op.axes is None else [int(a) for a in op.axes]}
+
+    @hip_funcify.register(LUFactorTridiagonal)
+    def _(op, node, ctx):
+        return "LUFactorTridiagonal", {}
+
+    @hip_funcify.register(SolveLUFactorTridiagonal)
+    def _(op, node, ctx):
+        return "SolveLUFactorTridiagonal", {"b_ndim": int(op.b_ndim), "transposed": bool(op.transposed)}
+
+    @hip_funcify.register(BlockDiagonal)
+    def _(op, node, ctx):
+        if node is None:
+            return None  # (as the core of a Blockwise the output dtype is not known here)
+        return "BlockDiagonal", {"dtype": str(node.outputs[0].type.dtype)}
 
     # kept whole (HipLinker excludes the reference's inline_symbolic_for_fusion): one kernel
     from pytensor.tensor.special import LogSoftmax, Softmax
