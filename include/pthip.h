@@ -275,6 +275,15 @@ int pthip_random_categorical(int p_dtype, int64_t rows, int64_t k, const uint64_
 int pthip_random_multinomial(int p_dtype, int64_t rows, int64_t k, const uint64_t* key,
                              const uint64_t* counter, const void* n, int n_dtype, int64_t n_stride,
                              const void* p, int64_t row_stride, void* out);
+/* SearchsortedOp.perform (extra_ops.py:155-166: np.searchsorted): out[j] (int64) = insertion point of
+ * v[j] in the ascending x[n] (read through `sorter` (int64) if not NULL); right = side "right";
+ * any numeric dtypes (compared as int64 when both are integers, else as float64, NaN last) */
+int pthip_searchsorted(int x_dtype, int64_t n, const void* x, const void* sorter, int v_dtype, int64_t m,
+                       const void* v, int right, void* out);
+/* Convolve1d.perform (signal/conv.py:124-128: np.convolve): out = a * b, "full" (na + nb - 1 values)
+ * or "valid" (|na - nb| + 1); float32 / float64 / int64 */
+int pthip_convolve1d(int dtype, int64_t na, const void* a, int64_t nb, const void* b, int full, void* out);
+
 /* ---- dense decompositions, correct-first tier (csrc/decomp.hip): one workgroup per matrix ---- */
 /* QR.perform (linalg/decomposition/qr.py:153-221): LAPACK geqrf in place on `batch` contiguous
  * row-major m x n matrices — Householder vectors below the diagonal (v_k = 1 implicit), R on and
@@ -294,10 +303,11 @@ int pthip_svd_rows(int dtype, int64_t batch, int64_t r, int64_t c, int vectors, 
  * i of Q (c x ldq): an orthonormal completion of a rank-deficient or economy-sized factor */
 int pthip_fill_null_rows(int dtype, int64_t batch, int64_t r, int64_t c, void* Wt, const void* S, int64_t r_valid,
                          const void* Q, int64_t ldq);
-/* dst (rows x cols, contiguous) = upper triangle of the leading rows of src (row stride ld,
- * src_stride between batch items), zeros below: the R of QR.perform (qr.py:171-174) */
+/* dst (rows x cols, contiguous) = the upper (lower != 0: lower) triangle of the leading rows of src
+ * (row stride ld, src_stride between batch items), zeros elsewhere, the diagonal 1 if unit_diag:
+ * the R of QR.perform (qr.py:171-174), the L and U of LU.perform (lu.py:77-89) */
 int pthip_triu(int dtype, int64_t batch, int64_t rows, int64_t cols, const void* src, int64_t ld,
-               int64_t src_stride, void* dst);
+               int64_t src_stride, void* dst, int lower, int unit_diag);
 /* LUFactorTridiagonal / SolveLUFactorTridiagonal.perform (linalg/solvers/tridiagonal.py:70-90,
  * 170-180): LAPACK gttrf in place on (dl[n-1], d[n], du[n-1]) -> du2[n-2], ipiv[n] (int32, 1-based
  * as LAPACK returns it); gttrs on B (n x nrhs row-major, in place), trans = 0 | 1 */

@@ -131,3 +131,86 @@ def linalg_misc():
             "t4": rng.normal(size=(4, 6, 8, 3)) + 0.0, "t3": rng.normal(size=(2, 3, 6)), "tb": rng.normal(size=(2, 3)),
             "m1": rng.normal(size=(3, 2)), "m2": rng.normal(size=(2, 4)).astype("float32"), "m3": np.array([[7, -3]], dtype="int8")}
     return [A, Bm, t4, t3, tb, m1, m2, m3], outs, vals
+
+
+@case("ifelse_lazy", lazy=True)
+def ifelse_lazy():
+    # pytensor/ifelse.py:42 IfElse, evaluated lazily by the VM (thunk 300-345): only the branch taken
+    # runs — here the branch not taken would raise (a Solve / Dot with mismatched shapes).  Nested
+    # conditionals, several outputs per IfElse, a branch shared with an unconditional consumer.
+    from pytensor.ifelse import ifelse
+
+    rng = np.random.default_rng(85)
+    T, W = pt.dmatrix("T"), pt.dmatrix("W")
+    x, y = pt.dvector("x"), pt.dvector("y")
+    s = pt.dscalar("s")
+
+    a, b = ifelse(s > 0, (pt.exp(x), x.sum()), (y[:3] * 2.0, y.prod()))
+    shared = pt.log1p(x**2)
+    inner = ifelse(x[0] > 10.0, shared * 3.0, ifelse(s < 1.0, shared + y[: x.shape[0]], pt.cumsum(shared)))
+    outs = [
+        ifelse(pt.ge(T.shape[0], T.shape[1]), pt.linalg.solve(T.T @ T, T.T @ y[: T.shape[0]]), pt.linalg.solve(T @ T.T, x)),
+        ifelse(pt.ge(W.shape[0], W.shape[1]), pt.linalg.solve(W.T @ W, W.T @ y[: W.shape[0]]), pt.linalg.solve(W @ W.T, x)),
+        a, b, inner, shared.sum(),
+        ifelse(pt.eq(x.shape[0], 5), pt.dot(x, y[:5]), pt.as_tensor(np.float64(-1.0))),
+    ]
+    vals = {"T": rng.normal(size=(8, 6)), "W": rng.normal(size=(5, 9)), "x": rng.normal(size=5), "y": rng.normal(size=8), "s": 0.5}
+    return [T, W, x, y, s], outs, vals
+
+
+@case("index_layout_misc")
+def index_layout_misc():
+    # tensor/extra_ops.py: SearchsortedOp 111, Repeat 639, Bartlett 776, FillDiagonal 839,
+    # FillDiagonalOffset 943, Unique 1189, UnravelIndex 1287, RavelMultiIndex 1365, CpuContiguous 47;
+    # tensor/reshape.py JoinDims / SplitDims; linalg/decomposition/lu.py:22 LU; signal/conv.py Convolve1d
+    from pytensor.tensor.extra_ops import (
+        Bartlett, CpuContiguous, FillDiagonal, FillDiagonalOffset, RavelMultiIndex, Repeat, SearchsortedOp, Unique, UnravelIndex,
+    )
+    from pytensor.tensor.linalg.decomposition.lu import LU
+    from pytensor.tensor.reshape import JoinDims, SplitDims
+    from pytensor.tensor.signal.conv import Convolve1d
+
+    rng = np.random.default_rng(86)
+    xs, v = pt.dvector("xs"), pt.dmatrix("v")
+    xi, vi = pt.lvector("xi"), pt.ivector("vi")
+    perm = pt.lvector("perm")
+    M3 = pt.dtensor3("M3")
+    reps = pt.lvector("reps")
+    A, Tl, C3 = pt.dmatrix("A"), pt.dmatrix("Tl"), pt.dtensor3("C3")
+    val = pt.dscalar("val")
+    u = pt.lvector("u")
+    uf = pt.dmatrix("uf")
+    flat, dims3 = pt.lmatrix("flat"), pt.tensor("dims3", shape=(3,), dtype="int64")
+    i0, i1, i2 = pt.lvector("i0"), pt.lvector("i1"), pt.lvector("i2")
+    sig, ker = pt.dvector("sig"), pt.dvector("ker")
+    fs, fk = pt.fvector("fs"), pt.fvector("fk")
+    uniq_all = Unique(return_index=True, return_inverse=True, return_counts=True)(u)
+    outs = [
+        SearchsortedOp(side="left")(xs, v), SearchsortedOp(side="right")(xs, v), SearchsortedOp(side="left")(xi, vi),
+        SearchsortedOp(side="right")(xs[perm], v, pt.argsort(xs[perm])),
+        Repeat(axis=1)(M3, reps), Repeat(axis=0)(xs, pt.arange(xs.shape[0]) % 3),
+        Bartlett()(pt.as_tensor(np.int64(12))), Bartlett()(xi.shape[0]),
+        FillDiagonal()(A, val), FillDiagonal()(Tl, val * 2), FillDiagonal()(C3, val), 
+        FillDiagonalOffset()(A, val, pt.as_tensor(np.int64(2))), FillDiagonalOffset()(Tl, val, pt.as_tensor(np.int64(-3))),
+        *uniq_all, Unique()(uf), Unique(return_counts=True)(uf)[1],
+        *UnravelIndex(order="C")(flat, dims3), *UnravelIndex(order="F")(flat[0], dims3),
+        RavelMultiIndex(mode="raise", order="C")(i0, i1, i2, dims3), RavelMultiIndex(mode="wrap", order="F")(i0 - 7, i1 + 9, i2, dims3),
+        RavelMultiIndex(mode="clip", order="C")(i0 - 7, i1 + 9, i2, dims3),
+        CpuContiguous()(v.T), JoinDims(start_axis=0, n_axes=2)(M3), JoinDims(start_axis=1, n_axes=2)(M3.transpose(1, 0, 2)),
+        SplitDims(axis=0)(xs[:12], pt.as_tensor(np.array([3, 2, 2]))),
+        *LU()(A), *LU(permute_l=True)(A), *LU(p_indices=True)(A),
+        Convolve1d()(sig, ker, pt.as_tensor(np.array(True))), Convolve1d()(sig, ker, pt.as_tensor(np.array(False))), Convolve1d()(ker, sig, pt.as_tensor(np.array(False))),
+        Convolve1d()(fs, fk, pt.as_tensor(np.array(True))),
+    ]
+    xsv = np.sort(rng.normal(size=40))
+    xsv[7] = xsv[8] = xsv[9]  # ties: left and right differ
+    vv = rng.normal(size=(3, 5))
+    vv[0, 0], vv[1, 1] = xsv[8], np.nan
+    xiv = np.sort(rng.integers(-20, 20, size=25))
+    vals = {"xs": xsv, "v": vv, "xi": xiv, "vi": rng.integers(-25, 25, size=9).astype("int32"), "perm": rng.permutation(40),
+            "M3": rng.normal(size=(2, 3, 4)), "reps": np.array([2, 0, 3]), "A": rng.normal(size=(6, 6)), "Tl": rng.normal(size=(7, 4)),
+            "C3": rng.normal(size=(3, 3, 3)), "val": -1.25, "u": rng.integers(0, 9, size=50), "uf": np.round(rng.normal(size=(6, 5)), 1),
+            "flat": rng.integers(0, 4 * 5 * 3, size=(2, 6)), "dims3": np.array([4, 5, 3]),
+            "i0": rng.integers(0, 4, size=8), "i1": rng.integers(0, 5, size=8), "i2": rng.integers(0, 3, size=8),
+            "sig": rng.normal(size=50), "ker": rng.normal(size=7), "fs": rng.normal(size=20).astype("float32"), "fk": rng.normal(size=20).astype("float32")}
+    return [xs, v, xi, vi, perm, M3, reps, A, Tl, C3, val, u, uf, flat, dims3, i0, i1, i2, sig, ker, fs, fk], outs, vals

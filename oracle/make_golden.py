@@ -48,9 +48,10 @@ CASES = {}
 
 
 PY_RTOL = {}  # case -> tolerance of the reference's own NumPy backend against its C backend
+PY_LAZY = set()  # cases whose NumPy-backend run needs the lazy VM (IfElse): PerformLinker runs every node
 
 
-def case(name, rtol=None, py_rtol=None):
+def case(name, rtol=None, py_rtol=None, lazy=False):
     """``py_rtol``: where the reference's two backends disagree beyond 1e-10 (Psi: AS 103 with
     10-digit constants in C, scipy.special.psi in Python) the C linker's values are the golden
     ones and the NumPy linker's are only sanity-checked at ``py_rtol``."""
@@ -59,6 +60,8 @@ def case(name, rtol=None, py_rtol=None):
         CASES[name] = (f, rtol)
         if py_rtol is not None:
             PY_RTOL[name] = py_rtol
+        if lazy:
+            PY_LAZY.add(name)
         return f
 
     return deco
@@ -603,7 +606,13 @@ def generate(name):
 
     fn_c = pytensor.function(ins, outs, mode="CVM", on_unused_input="ignore")
     out_c = [np.asarray(o) for o in fn_c(*explicit)]
-    fn_py = pytensor.function(ins, outs, mode=Mode("py", optimizer=None), on_unused_input="ignore")
+    if name in PY_LAZY:
+        from pytensor.link.vm import VMLinker
+
+        py_mode = Mode(VMLinker(use_cloop=False, c_thunks=False), optimizer=None)  # Python thunks, lazy
+    else:
+        py_mode = Mode("py", optimizer=None)
+    fn_py = pytensor.function(ins, outs, mode=py_mode, on_unused_input="ignore")
     out_py = [np.asarray(o) for o in fn_py(*explicit)]
 
     out_or = np_graph.run_graph(graph, in_vals)

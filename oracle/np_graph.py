@@ -777,7 +777,28 @@ def run_graph(graph, inputs):
         raise TypeError(f"expected {len(graph.inputs)} inputs, got {len(inputs)}")
     for vid, val in zip(graph.inputs, inputs):
         env[vid] = val if graph.vars[vid].kind != "tensor" else np.asarray(val)
-    for node in graph.nodes:
+    guard, members = _branch_guards(graph)
+    open_branches, taken = set(), {}
+    todo = list(range(len(graph.nodes)))[::-1]
+    while todo:
+        k = todo.pop()
+        node = graph.nodes[k]
+        if guard[k] is not None and guard[k] not in open_branches:
+            continue
+        if node.op == "IfElse":
+            # pytensor/ifelse.py:300-345 (the lazy thunk): the condition, then only the branch taken
+            n_out = len(node.outputs)
+            if k not in taken:
+                b = 0 if np.asarray(env[node.inputs[0]]).item() != 0 else 1
+                taken[k] = b
+                open_branches.add((k, b))
+                todo.append(k)
+                todo.extend(reversed(members.get((k, b), ())))
+                continue
+            b = taken[k]
+            for vid, src in zip(node.outputs, node.inputs[1 + b * n_out : 1 + (b + 1) * n_out]):
+                env[vid] = np.array(env[src], copy=True)
+            continue
         f = OPS.get(node.op)
         if f is None:
             raise NotImplementedError(f"oracle has no handler for {node.op}")
@@ -785,6 +806,39 @@ def run_graph(graph, inputs):
         for vid, val in zip(node.outputs, outs):
             env[vid] = val
     return [env[o] for o in graph.outputs]
+
+
+def _branch_guards(graph):
+    """nodes whose values reach the outputs only through ONE branch of an IfElse run only when that
+    branch is taken (the reference's VM is lazy): guard[k] = (IfElse node, branch), innermost first"""
+    nodes = graph.nodes
+    guard, members = [None] * len(nodes), {}
+    if not any(n.op == "IfElse" for n in nodes):
+        return guard, members
+    uses = {}
+    for k, n in enumerate(nodes):
+        for pos, i in enumerate(n.inputs):
+            uses.setdefault(i, []).append((k, pos))
+    outs = set(graph.outputs)
+    for k, n in enumerate(nodes):
+        if n.op != "IfElse":
+            continue
+        n_out = len(n.outputs)
+        for b in (0, 1):
+            lo, hi = 1 + b * n_out, 1 + (b + 1) * n_out
+            inside = set()
+            for j in range(k - 1, -1, -1):
+                m = nodes[j]
+                if any(o in outs for o in m.outputs):
+                    continue
+                us = [u for o in m.outputs for u in uses.get(o, ())]
+                if us and all((uk == k and lo <= up < hi) or uk in inside for uk, up in us):
+                    inside.add(j)
+            mine = [j for j in sorted(inside) if guard[j] is None]
+            for j in mine:
+                guard[j] = (k, b)
+            members[(k, b)] = mine
+    return guard, members
 
 
 # ---------------------------------------------------------------------------
@@ -1089,6 +1143,110 @@ def _solve_lu_factor_tridiagonal(p, inputs, node, graph):
 def _block_diagonal(p, inputs, node, graph):
     # pytensor/tensor/linalg/constructors.py:73-75: scipy.linalg.block_diag cast to the output dtype
     return [scipy.linalg.block_diag(*inputs).astype(p["dtype"])]
+
+
+@op("CpuContiguous")
+def _cpu_contiguous(p, inputs, node, graph):
+    # pytensor/tensor/extra_ops.py:67-75
+    return [np.ascontiguousarray(inputs[0])]
+
+
+@op("JoinDims")
+def _join_dims(p, inputs, node, graph):
+    # pytensor/tensor/reshape.py:72-82
+    (x,) = inputs
+    a, n = p["start_axis"], p["n_axes"]
+    return [x.reshape((*x.shape[:a], -1, *x.shape[a + n :]))]
+
+
+@op("SplitDims")
+def _split_dims(p, inputs, node, graph):
+    # pytensor/tensor/reshape.py:197-203
+    x, shape = inputs
+    return [x.reshape((*x.shape[: p["axis"]], *[int(v) for v in np.asarray(shape).ravel()], *x.shape[p["axis"] + 1 :]))]
+
+
+@op("FillDiagonal")
+def _fill_diagonal(p, inputs, node, graph):
+    # pytensor/tensor/extra_ops.py:871-886: rectangular matrices accepted, no wrap
+    a, val = inputs[0].copy(), inputs[1]
+    if a.ndim == 2:
+        a.flat[: a.shape[1] * a.shape[1] : a.shape[1] + 1] = val
+    else:
+        np.fill_diagonal(a, val)
+    return [a]
+
+
+@op("FillDiagonalOffset")
+def _fill_diagonal_offset(p, inputs, node, graph):
+    # pytensor/tensor/extra_ops.py:971-1004
+    a, val, offset = inputs[0].copy(), inputs[1], int(inputs[2])
+    height, width = a.shape
+    if offset >= 0:
+        start, steps = offset, min(min(width, height), width - offset)
+    else:
+        start, steps = -offset * a.shape[1], min(min(width, height), height + offset)
+    step = a.shape[1] + 1
+    a.flat[start : start + step * steps : step] = val
+    return [a]
+
+
+@op("Bartlett")
+def _bartlett(p, inputs, node, graph):
+    # pytensor/tensor/extra_ops.py (Bartlett.perform): np.bartlett
+    return [np.bartlett(int(inputs[0]))]
+
+
+@op("SearchsortedOp")
+def _searchsorted(p, inputs, node, graph):
+    # pytensor/tensor/extra_ops.py:155-166
+    x, v = inputs[:2]
+    return [np.searchsorted(x, v, side=p["side"], sorter=inputs[2] if len(inputs) == 3 else None).astype("int64")]
+
+
+@op("Repeat")
+def _repeat(p, inputs, node, graph):
+    # pytensor/tensor/extra_ops.py:706-708
+    return [np.repeat(inputs[0], repeats=inputs[1], axis=p["axis"])]
+
+
+@op("UnravelIndex")
+def _unravel_index(p, inputs, node, graph):
+    # pytensor/tensor/extra_ops.py (UnravelIndex.perform): np.unravel_index, int64 copies
+    return [np.array(r, dtype="int64") for r in np.unravel_index(inputs[0], tuple(int(d) for d in inputs[1]), order=p["order"])]
+
+
+@op("RavelMultiIndex")
+def _ravel_multi_index(p, inputs, node, graph):
+    # pytensor/tensor/extra_ops.py (RavelMultiIndex.perform): np.ravel_multi_index
+    *mi, dims = inputs
+    return [np.asarray(np.ravel_multi_index(mi, tuple(int(d) for d in dims), mode=p["mode"], order=p["order"]), "int64")]
+
+
+@op("Unique")
+def _unique(p, inputs, node, graph):
+    # pytensor/tensor/extra_ops.py:1227-1240 (old_np_unique: the inverse of the flattened input is 1-d)
+    (x,) = inputs
+    outs = np.unique(x, return_index=p["return_index"], return_inverse=p["return_inverse"], return_counts=p["return_counts"], axis=p["axis"])
+    if not isinstance(outs, tuple):
+        return [outs]
+    outs = list(outs)
+    if p["return_inverse"] and p["axis"] is None:
+        k = 1 + int(p["return_index"])
+        outs[k] = outs[k].reshape(-1)
+    return outs
+
+
+@op("LU")
+def _lu(p, inputs, node, graph):
+    # pytensor/tensor/linalg/decomposition/lu.py:77-89: scipy.linalg.lu
+    return list(scipy.linalg.lu(inputs[0], permute_l=p["permute_l"], p_indices=p["p_indices"]))
+
+
+@op("Convolve1d")
+def _convolve1d(p, inputs, node, graph):
+    # pytensor/tensor/signal/conv.py:124-128: np.convolve, "full" if the third input is true
+    return [np.convolve(inputs[0], inputs[1], mode="full" if bool(inputs[2]) else "valid")]
 
 
 @op("MatrixInverse")

@@ -226,15 +226,19 @@ __global__ void fill_null_rows_kernel(T* __restrict__ Wt, const T* __restrict__ 
   }
 }
 
-// dst (rows x cols, contiguous) = upper triangle of src's leading rows (row stride ld), zeros below
+// dst (rows x cols, contiguous) = one triangle of src's leading rows (row stride ld), zeros in the
+// other; unit: the diagonal is 1 (the L of a packed LU)
 template <class T>
 __global__ void triu_kernel(T* __restrict__ dst, const T* __restrict__ src, long long batch, int rows, int cols, long long ld,
-                            long long src_stride) {
+                            long long src_stride, int lower, int unit) {
   const long long total = batch * rows * cols;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const long long b = e / ((long long)rows * cols);
     const int i = (int)((e / cols) % rows), j = (int)(e % cols);
-    dst[e] = j >= i ? src[b * src_stride + (long long)i * ld + j] : T(0);
+    const bool keep = lower ? j <= i : j >= i;
+    T v = keep ? src[b * src_stride + (long long)i * ld + j] : T(0);
+    if (unit && i == j) v = T(1);
+    dst[e] = v;
   }
 }
 
@@ -358,14 +362,14 @@ extern "C" int pthip_svd_rows(int dtype, int64_t batch, int64_t r, int64_t c, in
 }
 
 extern "C" int pthip_triu(int dtype, int64_t batch, int64_t rows, int64_t cols, const void* src, int64_t ld,
-                          int64_t src_stride, void* dst) {
+                          int64_t src_stride, void* dst, int lower, int unit_diag) {
   PTHIP_REQUIRE_INIT();
   const long long total = (long long)batch * rows * cols;
   if (total <= 0) return 0;
   const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipStream_t st = pthip::ctx().stream;
-  if (dtype == PTHIP_F64) PTHIP_KLAUNCH(triu_kernel<double>, dim3(grid), dim3(256), 0, st, (double*)dst, (const double*)src, (long long)batch, (int)rows, (int)cols, (long long)ld, (long long)src_stride);
-  else if (dtype == PTHIP_F32) PTHIP_KLAUNCH(triu_kernel<float>, dim3(grid), dim3(256), 0, st, (float*)dst, (const float*)src, (long long)batch, (int)rows, (int)cols, (long long)ld, (long long)src_stride);
+  if (dtype == PTHIP_F64) PTHIP_KLAUNCH(triu_kernel<double>, dim3(grid), dim3(256), 0, st, (double*)dst, (const double*)src, (long long)batch, (int)rows, (int)cols, (long long)ld, (long long)src_stride, lower, unit_diag);
+  else if (dtype == PTHIP_F32) PTHIP_KLAUNCH(triu_kernel<float>, dim3(grid), dim3(256), 0, st, (float*)dst, (const float*)src, (long long)batch, (int)rows, (int)cols, (long long)ld, (long long)src_stride, lower, unit_diag);
   else return pthip::set_error("pthip_triu: dtype %d not supported", dtype);
   return pthip::post_launch("triu");
 }

@@ -218,3 +218,12 @@ def host_perform(node, inputs, env):
         a = np.asarray(cell[0])
         outs.append(HostValue(a) if a.dtype.kind in "iub" and a.size <= HOST_MAX and a.ndim <= 1 else env.to_device(HostValue(a)))
     return outs
+
+
+@handler("IfElse")
+def ifelse(node, inputs, env):
+    """``IfElse`` (pytensor/ifelse.py:42): the executor has read the condition and run only the
+    branch taken (executor.py ``branch_guards``); what is left is handing that branch's values on."""
+    n_out = len(node.outputs)
+    b = env.branch
+    return list(inputs[1 + b * n_out : 1 + (b + 1) * n_out])

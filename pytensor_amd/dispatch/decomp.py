@@ -59,10 +59,10 @@ def orgqr_device(env, qr: DeviceArray, tau: DeviceArray, ncols: int) -> DeviceAr
     return q
 
 
-def _triu(env, qr: DeviceArray, rows: int) -> DeviceArray:
+def _triu(env, qr: DeviceArray, rows: int, lower=False, unit=False) -> DeviceArray:
     m, n = qr.shape
     r = DeviceArray.empty((rows, n), qr.dtype)
-    ffi.check(env.lib.pthip_triu(_dt(qr), 1, rows, n, qr.ptr, n, m * n, r.ptr))
+    ffi.check(env.lib.pthip_triu(_dt(qr), 1, rows, n, qr.ptr, n, m * n, r.ptr, int(lower), int(unit)))
     return r
 
 

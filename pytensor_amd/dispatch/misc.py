@@ -1,0 +1,357 @@
+"""Index / layout / signal ops of the widening tier: ``CpuContiguous``, ``JoinDims`` / ``SplitDims``,
+``FillDiagonal`` / ``FillDiagonalOffset``, ``Bartlett``, ``SearchsortedOp``, ``Repeat``,
+``UnravelIndex`` / ``RavelMultiIndex``, ``Unique``, ``LU``, ``Convolve1d``.
+
+Reference: pytensor/tensor/extra_ops.py (CpuContiguous 47, SearchsortedOp 111, Repeat 639, Bartlett 776,
+FillDiagonal 839, FillDiagonalOffset 943, Unique 1189, UnravelIndex 1287, RavelMultiIndex 1365),
+tensor/reshape.py (JoinDims 20, SplitDims 151), linalg/decomposition/lu.py:22 ``LU``
+(scipy.linalg.lu), signal/conv.py ``Convolve1d`` (np.convolve).  Data-dependent output shapes
+(``Repeat``, ``Unique``) cost one host read, like ``Nonzero``.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from pytensor_amd import ffi
+from pytensor_amd.device import DeviceArray, contiguous_strides, copy_into
+from pytensor_amd.dispatch import handler
+from pytensor_amd.executor import HostValue
+
+
+def _cs(shape):
+    return contiguous_strides(tuple(shape))
+
+
+def _reshaped(x: DeviceArray, shape) -> DeviceArray:
+    x = x.contiguous()
+    return x.view(tuple(shape), _cs(shape))
+
+
+def _ew(env, body_ops, ins, in_dtypes, out_dtype, shape):
+    from pytensor_amd.dispatch.elemwise import launch_elemwise
+
+    body = {"in_dtypes": list(in_dtypes), "out_dtypes": [out_dtype], "body": body_ops, "outs": [["t", len(body_ops) - 1]]}
+    (out,), _, _ = launch_elemwise(body, ins, tuple(shape), [out_dtype], None, env)
+    return out
+
+
+def _bview(d: DeviceArray, shape) -> DeviceArray:
+    """``d`` broadcast to ``shape`` as a strided view (stride 0 along broadcast axes)"""
+    lead = len(shape) - d.ndim
+    st = tuple(0 if (s == 1 and t != 1) else q for s, q, t in zip(d.shape, d.strides, shape[lead:]))
+    return d.view(tuple(shape), (0,) * lead + st)
+
+
+def _host_ints(env, v):
+    return [int(t) for t in np.asarray(env.to_host(v)).ravel()]
+
+
+def _as_int64(env, x: DeviceArray) -> DeviceArray:
+    if str(x.dtype) == "int64":
+        return x.contiguous()
+    from pytensor_amd.dispatch.elemwise import _cast
+
+    return _cast(env, x.contiguous(), "int64")
+
+
+@handler("CpuContiguous")
+def cpu_contiguous(node, inputs, env):
+    return [env.to_device(inputs[0]).contiguous()]
+
+
+@handler("JoinDims")
+def join_dims(node, inputs, env):
+    x = env.to_device(inputs[0])
+    a, n = int(node.params["start_axis"]), int(node.params["n_axes"])
+    merged = int(np.prod(x.shape[a : a + n], dtype=np.int64)) if n else 1
+    return [_reshaped(x, (*x.shape[:a], merged, *x.shape[a + n :]))]
+
+
+@handler("SplitDims")
+def split_dims(node, inputs, env):
+    x = env.to_device(inputs[0])
+    axis = int(node.params["axis"])
+    shape = _host_ints(env, inputs[1])
+    if int(np.prod(shape, dtype=np.int64)) != x.shape[axis]:
+        raise ValueError(f"cannot reshape array of size {x.size} into shape {(*x.shape[:axis], *shape, *x.shape[axis + 1:])}")
+    return [_reshaped(x, (*x.shape[:axis], *shape, *x.shape[axis + 1 :]))]
+
+
+def _fill_line(env, out: DeviceArray, start: int, step: int, count: int, val):
+    """out.flat[start : start + step * count : step] = val (a scalar)"""
+    if count <= 0:
+        return
+    v = env.to_device(val)
+    if str(v.dtype) != str(out.dtype):
+        from pytensor_amd.dispatch.elemwise import _cast
+
+        v = _cast(env, v.contiguous(), out.dtype)
+    copy_into(out.view((count,), (step,), start), v.view((count,), (0,)))
+
+
+@handler("FillDiagonal")
+def fill_diagonal(node, inputs, env):
+    a = env.to_device(inputs[0]).contiguous_copy()
+    if a.ndim < 2:
+        raise ValueError("array must be at least 2-d")
+    if a.ndim == 2:
+        # extra_ops.py:875-882: a.flat[: w * w : w + 1] = val (rectangular matrices accepted, no wrap)
+        h, w = a.shape
+        _fill_line(env, a, 0, w + 1, min(h, w), inputs[1])
+    else:
+        if len(set(a.shape)) != 1:
+            raise ValueError("All dimensions of input must be of equal length")
+        _fill_line(env, a, 0, sum(_cs(a.shape)), a.shape[0], inputs[1])
+    return [a]
+
+
+@handler("FillDiagonalOffset")
+def fill_diagonal_offset(node, inputs, env):
+    a = env.to_device(inputs[0]).contiguous_copy()
+    offset = int(np.asarray(env.to_host(inputs[2])).item())
+    h, w = a.shape
+    if offset >= 0:  # extra_ops.py:990-999
+        start, count = offset, min(min(w, h), w - offset)
+    else:
+        start, count = -offset * w, min(min(w, h), h + offset)
+    _fill_line(env, a, start, w + 1, count, inputs[1])
+    return [a]
+
+
+@handler("Bartlett")
+def bartlett(node, inputs, env):
+    # np.bartlett: n = arange(1 - M, M, 2); where(n <= 0, 1 + n / (M - 1), 1 - n / (M - 1))
+    M = int(np.asarray(env.to_host(inputs[0])).item())
+    if M < 1:
+        return [DeviceArray.empty((0,), "float64")]
+    if M == 1:
+        return [HostValue(np.ones(1, dtype="float64"))]
+    n = DeviceArray.empty((M,), "int64")
+    ffi.check(env.lib.pthip_arange(ffi.np_dtype_code(np.dtype("int64")), M, float(1 - M), 2.0, 1 - M, 2, n.ptr))
+    d = float(M - 1).hex()
+    ops = [{"op": "Cast", "in": [["i", 0]], "dtype": "float64"},
+           {"op": "TrueDiv", "in": [["t", 0], ["c", d, "float64"]], "dtype": "float64"},
+           {"op": "LE", "in": [["i", 0], ["c", 0, "int64"]], "dtype": "bool"},
+           {"op": "Add", "in": [["c", (1.0).hex(), "float64"], ["t", 1]], "dtype": "float64"},
+           {"op": "Sub", "in": [["c", (1.0).hex(), "float64"], ["t", 1]], "dtype": "float64"},
+           {"op": "Switch", "in": [["t", 2], ["t", 3], ["t", 4]], "dtype": "float64"}]
+    return [_ew(env, ops, [n], ["int64"], "float64", (M,))]
+
+
+@handler("SearchsortedOp")
+def searchsorted(node, inputs, env):
+    x = env.to_device(inputs[0]).contiguous()
+    v = env.to_device(inputs[1]).contiguous()
+    sorter = _as_int64(env, env.to_device(inputs[2])) if len(inputs) == 3 else None
+    if x.ndim != 1:
+        raise ValueError("object too deep for desired array")
+    out = DeviceArray.empty(v.shape, "int64")
+    if v.size:
+        ffi.check(env.lib.pthip_searchsorted(ffi.np_dtype_code(x.dtype), x.shape[0], x.ptr, sorter.ptr if sorter is not None else None,
+                                             ffi.np_dtype_code(v.dtype), v.size, v.ptr, int(node.params["side"] == "right"), out.ptr))
+    env.keepalive.extend(t for t in (x, v, sorter) if t is not None)
+    return [out]
+
+
+def _take_axis(env, x: DeviceArray, idx: DeviceArray, axis: int) -> DeviceArray:
+    """x.take(idx, axis) for an int64 device index vector"""
+    order = [axis] + [d for d in range(x.ndim) if d != axis]
+    xt = x.view([x.shape[d] for d in order], [x.strides[d] for d in order]).contiguous()
+    rest = tuple(xt.shape[1:])
+    inner = int(np.prod(rest, dtype=np.int64)) if rest else 1
+    out = DeviceArray.empty((idx.size, *rest), x.dtype)
+    if out.size:
+        ffi.check(env.lib.pthip_take_rows(x.itemsize, idx.size, inner, xt.ptr, xt.shape[0], inner, idx.ptr, out.ptr))
+    inv = [order.index(d) for d in range(x.ndim)]
+    return out.view([out.shape[d] for d in inv], [out.strides[d] for d in inv])
+
+
+@handler("Repeat")
+def repeat(node, inputs, env):
+    # extra_ops.py:706 (np.repeat(x, repeats, axis)): the gather index is the only data-dependent part
+    x = env.to_device(inputs[0])
+    axis = int(node.params["axis"])
+    reps = np.asarray(env.to_host(inputs[1]))
+    if (reps < 0).any():
+        raise ValueError("repeats may not contain negative values.")
+    n = x.shape[axis]
+    if reps.ndim == 0 or reps.size == 1 and n != 1:
+        reps = np.full(n, int(reps.ravel()[0]) if reps.size else 0)
+    if reps.shape != (n,):
+        raise ValueError(f"operands could not be broadcast together with shape ({n},) ({reps.size},)")
+    idx = env.to_device(HostValue(np.repeat(np.arange(n, dtype=np.int64), reps)))
+    return [_take_axis(env, x, idx.contiguous(), axis)]
+
+
+@handler("UnravelIndex")
+def unravel_index(node, inputs, env):
+    from pytensor_amd.dispatch.subtensor import unravel_flat
+
+    idx = _as_int64(env, env.to_device(inputs[0]))
+    dims = _host_ints(env, inputs[1])
+    if node.params["order"] == "F":
+        comps = unravel_flat(env, idx, dims[::-1])[::-1]
+    else:
+        comps = unravel_flat(env, idx, dims)
+    return [c if c is not idx else idx.contiguous_copy() for c in comps]
+
+
+@handler("RavelMultiIndex")
+def ravel_multi_index(node, inputs, env):
+    *multi, dims = inputs
+    dims = _host_ints(env, dims)
+    if len(multi) != len(dims):
+        raise ValueError(f"parameter multi_index must be a sequence of length {len(dims)}")
+    devs = [_as_int64(env, env.to_device(m)) for m in multi]
+    shape = np.broadcast_shapes(*[tuple(d.shape) for d in devs])
+    strides = [1] * len(dims)
+    if node.params["order"] == "F":
+        for k in range(1, len(dims)):
+            strides[k] = strides[k - 1] * dims[k - 1]
+    else:
+        for k in range(len(dims) - 2, -1, -1):
+            strides[k] = strides[k + 1] * dims[k + 1]
+    mode = node.params["mode"]
+    ops, acc = [], None
+    for k in range(len(dims)):
+        ref = ["i", k]
+        if mode == "wrap":
+            ops.append({"op": "Mod", "in": [ref, ["c", max(dims[k], 1), "int64"]], "dtype": "int64"})
+            ref = ["t", len(ops) - 1]
+        elif mode == "clip":
+            ops.append({"op": "Maximum", "in": [ref, ["c", 0, "int64"]], "dtype": "int64"})
+            ops.append({"op": "Minimum", "in": [["t", len(ops) - 1], ["c", dims[k] - 1, "int64"]], "dtype": "int64"})
+            ref = ["t", len(ops) - 1]
+        ops.append({"op": "Mul", "in": [ref, ["c", strides[k], "int64"]], "dtype": "int64"})
+        if acc is not None:
+            ops.append({"op": "Add", "in": [acc, ["t", len(ops) - 1]], "dtype": "int64"})
+        acc = ["t", len(ops) - 1]
+    bviews = [_bview(d, shape) for d in devs]
+    if mode == "raise":
+        for d, n in zip(devs, dims):
+            if d.size:
+                h = np.asarray(env.to_host(d))  # (np.ravel_multi_index checks its input: a host read in this mode)
+                if (h < 0).any() or (h >= n).any():
+                    raise ValueError("invalid entry in coordinates array")
+    return [_ew(env, ops, bviews, ["int64"] * len(devs), "int64", shape)]
+
+
+@handler("Unique")
+def unique(node, inputs, env):
+    """np.unique of the flattened input (extra_ops.py:1229 ``old_np_unique``: the inverse is 1-d):
+    sort, flag the first element of every run, compact (csrc/sort.hip, nonzero.hip)."""
+    from pytensor_amd.dispatch.subtensor import nonzero_flat
+
+    p = node.params
+    if p.get("axis") is not None:
+        raise NotImplementedError("hip linker: Unique along an axis")
+    x = env.to_device(inputs[0]).contiguous()
+    n = x.size
+    flat = x.view((n,), (1,))
+    want = [p["return_index"], p["return_inverse"], p["return_counts"]]
+    if n == 0:
+        return [flat] + [DeviceArray.empty((0,), "int64") for w in want if w]
+    vals = DeviceArray.empty((n,), x.dtype)
+    order = DeviceArray.empty((n,), "int64")
+    if x.dtype.kind == "b":
+        raise NotImplementedError("hip linker: Unique of a bool array")
+    ffi.check(env.lib.pthip_sort(ffi.np_dtype_code(x.dtype), 1, n, flat.ptr, vals.ptr, order.ptr))
+    dt = str(x.dtype)
+    # first[i] = i == 0 or vals[i] != vals[i-1]  (np.unique: NaNs are all different unless equal_nan... old numpy: each NaN unique)
+    first = DeviceArray.empty((n,), "bool")
+    ffi.check(env.lib.pthip_memset(first.ptr, 1, 1))
+    if n > 1:
+        neq = _ew(env, [{"op": "NEQ", "in": [["i", 0], ["i", 1]], "dtype": "bool"}], [vals.view((n - 1,), (1,), 1), vals.view((n - 1,), (1,))], [dt, dt], "bool", (n - 1,))
+        copy_into(first.view((n - 1,), (1,), 1), neq)
+    starts = nonzero_flat(env, first)  # positions (in sorted order) where a new value starts
+    k = starts.size
+    uniq = DeviceArray.empty((k,), x.dtype)
+    ffi.check(env.lib.pthip_take_rows(x.itemsize, k, 1, vals.ptr, n, 1, starts.ptr, uniq.ptr))
+    outs = [uniq]
+    if p["return_index"]:
+        # stable sort: the first element of a run is the first occurrence
+        idx = DeviceArray.empty((k,), "int64")
+        ffi.check(env.lib.pthip_take_rows(8, k, 1, order.ptr, n, 1, starts.ptr, idx.ptr))
+        outs.append(idx)
+    if p["return_inverse"]:
+        # rank of every sorted element = (number of run starts up to it) - 1, scattered back by `order`
+        from pytensor_amd.dispatch.elemwise import _cast
+        from pytensor_amd.dispatch.subtensor import _scatter_rows
+
+        f64 = _cast(env, first, "int64")
+        run = DeviceArray.empty((n,), "int64")
+        ffi.check(env.lib.pthip_cumulative(ffi.np_dtype_code(np.dtype("int64")), 0, 1, n, 1, f64.ptr, run.ptr))
+        rank = _ew(env, [{"op": "Sub", "in": [["i", 0], ["c", 1, "int64"]], "dtype": "int64"}], [run], ["int64"], "int64", (n,))
+        inv = DeviceArray.empty((n,), "int64")
+        _scatter_rows(env, {"set_instead_of_inc": True}, inv, rank, order)
+        outs.append(inv)
+    if p["return_counts"]:
+        nxt = DeviceArray.empty((k,), "int64")
+        if k > 1:
+            copy_into(nxt.view((k - 1,), (1,)), starts.view((k - 1,), (1,), 1))
+        copy_into(nxt.view((1,), (1,), k - 1), env.to_device(HostValue(np.asarray([n], dtype="int64"))))
+        outs.append(_ew(env, [{"op": "Sub", "in": [["i", 0], ["i", 1]], "dtype": "int64"}], [nxt, starts], ["int64", "int64"], "int64", (k,)))
+    env.keepalive.extend((vals, order, first))
+    return outs
+
+
+@handler("LU")
+def lu(node, inputs, env):
+    """scipy.linalg.lu (lu.py:77-89): A = P L U from the packed getrf factors; ``p_indices`` gives the
+    row order p with A = L[p] U, ``permute_l`` the product P L."""
+    from pytensor_amd.dispatch.decomp import _triu
+    from pytensor_amd.dispatch.lu import getrf_device
+
+    a = env.to_device(inputs[0])
+    if a.ndim != 2 or a.shape[0] != a.shape[1]:
+        raise NotImplementedError("hip linker: LU of a rectangular or batched matrix (Blockwise loops the items)")
+    n = a.shape[0]
+    LU, perm, _, _, _ = getrf_device(env, a)
+    packed = LU.view((n, n), (n, 1))
+    L = _triu(env, packed, n, lower=True, unit=True)
+    U = _triu(env, packed, n)
+    gather = perm.view((n,), (1,))  # row i of L U is row gather[i] of A
+    # scipy's p / P: the inverse of that order (A = (L U)[p])
+    inv = DeviceArray.empty((n,), "int64")
+    if n:
+        from pytensor_amd.dispatch.subtensor import _scatter_rows
+
+        ar = DeviceArray.empty((n,), "int64")
+        ffi.check(env.lib.pthip_arange(ffi.np_dtype_code(np.dtype("int64")), n, 0.0, 1.0, 0, 1, ar.ptr))
+        _scatter_rows(env, {"set_instead_of_inc": True}, inv, ar, gather.contiguous())
+    p = node.params
+    if p["permute_l"]:
+        return [_take_axis(env, L, inv, 0).contiguous(), U]
+    if p["p_indices"]:
+        from pytensor_amd.dispatch.elemwise import _cast
+
+        return [_cast(env, inv, "int32"), L, U]
+    eye = DeviceArray.empty((n, n), a.dtype)
+    if n:
+        ffi.check(env.lib.pthip_eye(ffi.np_dtype_code(a.dtype), n, n, 0, eye.ptr))
+    return [_take_axis(env, eye, inv, 0).contiguous(), L, U]
+
+
+@handler("Convolve1d")
+def convolve1d(node, inputs, env):
+    a, b = (env.to_device(i) for i in inputs[:2])
+    full = bool(np.asarray(env.to_host(inputs[2])).item())
+    if a.ndim != 1 or b.ndim != 1:
+        raise ValueError("object too deep for desired array")
+    if a.shape[0] == 0 or b.shape[0] == 0:
+        raise ValueError("v cannot be empty" if b.shape[0] == 0 else "a cannot be empty")
+    dt = np.result_type(np.dtype(a.dtype), np.dtype(b.dtype))
+    kdt = dt if dt.name in ("float64", "float32", "int64") else np.dtype("int64" if dt.kind in "iub" else "float64")
+    if dt.kind == "b":
+        raise NotImplementedError("hip linker: Convolve1d of bool arrays")
+    from pytensor_amd.dispatch.elemwise import _cast
+
+    a, b = (t.contiguous() if np.dtype(t.dtype) == kdt else _cast(env, t.contiguous(), kdt) for t in (a, b))
+    if b.shape[0] > a.shape[0]:
+        a, b = b, a  # np.convolve swaps so that the first operand is the longer one
+    na, nb = a.shape[0], b.shape[0]
+    out = DeviceArray.empty((na + nb - 1 if full else na - nb + 1,), kdt)
+    ffi.check(env.lib.pthip_convolve1d(ffi.np_dtype_code(kdt), na, a.ptr, nb, b.ptr, int(full), out.ptr))
+    env.keepalive.extend((a, b))
+    return [out if kdt == dt else _cast(env, out, dt)]

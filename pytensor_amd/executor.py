@@ -199,6 +199,42 @@ def _has_op(graph, name: str) -> bool:
     return False
 
 
+def branch_guards(g):
+    """Lazy ``IfElse`` (pytensor/ifelse.py:42; the VM evaluates the condition, then only the branch
+    taken): ``guard[k] = (IfElse node index, branch)`` for every node whose results reach the graph
+    outputs only through that branch's inputs — the innermost one when conditionals nest — and the
+    node lists per (IfElse, branch) in execution order."""
+    nodes = g.nodes
+    guard = [None] * len(nodes)
+    members = {}
+    if not any(n.op == "IfElse" for n in nodes):
+        return guard, members
+    uses = {}
+    for k, n in enumerate(nodes):
+        for pos, i in enumerate(n.inputs):
+            uses.setdefault(i, []).append((k, pos))
+    outs = set(g.outputs)
+    for k, n in enumerate(nodes):
+        if n.op != "IfElse":
+            continue
+        n_out = len(n.outputs)
+        for b in (0, 1):
+            lo, hi = 1 + b * n_out, 1 + (b + 1) * n_out
+            inside = set()
+            for j in range(k - 1, -1, -1):
+                m = nodes[j]
+                if any(o in outs for o in m.outputs):
+                    continue
+                us = [u for o in m.outputs for u in uses.get(o, ())]
+                if us and all((uk == k and lo <= up < hi) or uk in inside for uk, up in us):
+                    inside.add(j)
+            mine = [j for j in sorted(inside) if guard[j] is None]
+            for j in mine:
+                guard[j] = (k, b)
+            members[(k, b)] = mine
+    return guard, members
+
+
 def raise_device_status(word: int):
     """The device error word (kernels cannot raise): bit 0 = an index was out of range
     (IndexError, like the reference's take/inc_subtensor), bit 1 = np.linalg.inv met an exactly
@@ -223,6 +259,7 @@ class Env:
         self.node_events = None  # set by HipExecutable.profile_nodes
         self.kernel_timer = None  # KernelTimer: brackets individual generated-kernel launches
         self.scheduler = None  # StreamScheduler of a multi-stream frozen plan
+        self.branch = 0  # branch taken by the IfElse node that is running
         self.donated = frozenset()  # input positions of the running node that may be overwritten
         self.node_key = None  # (executable id, node index) of the running node
         # var id -> DeviceArray the producing kernel should write into directly (a Scan's trace
@@ -313,6 +350,10 @@ class HipExecutable:
         self._device = device
         self._capturing = False
         self._plans = {}
+        # lazy IfElse: nodes that only feed one branch run when (and if) that branch is taken
+        self._guard, self._branch_nodes = branch_guards(self.graph)
+        if self._branch_nodes:
+            self.auto_freeze = False  # the condition is read on the host: nothing to capture
         self._last_use = self._compute_last_use()
         self._donations = self._compute_donations()
         # fail loudly and early if the library / device is unusable
@@ -321,9 +362,16 @@ class HipExecutable:
     # ------------------------------------------------------------------
     def _compute_last_use(self):
         last = {}
+        guard = self._guard
+
+        def when(k):  # a guarded node runs when its (outermost) IfElse does
+            while guard[k] is not None:
+                k = guard[k][0]
+            return k
+
         for k, n in enumerate(self.graph.nodes):
             for i in n.inputs:
-                last[i] = k
+                last[i] = max(last.get(i, -1), when(k))
         keep = set(self.graph.outputs)
         free_after = [[] for _ in self.graph.nodes]
         for vid, k in last.items():
@@ -491,7 +539,25 @@ class HipExecutable:
         handlers = self._handlers
         evs = env.node_events if env.exe is self else None  # inner graphs are not itemised
         sched = env.scheduler if env.exe is self else None  # multi-stream plans (plan.py)
-        for k, node in enumerate(g.nodes):
+        guard = self._guard
+        open_branches, taken = set(), {}  # lazy IfElse: (node, branch) pairs whose nodes may run
+        todo = list(range(len(g.nodes)))[::-1]  # a stack: a taken branch pushes its nodes in front
+        while todo:
+            k = todo.pop()
+            node = g.nodes[k]
+            if guard[k] is not None and guard[k] not in open_branches:
+                continue
+            if node.op == "IfElse" and k not in taken:
+                # ifelse.py:300-345 (the lazy thunk): the condition first, then only the taken branch
+                cond = vals.get(node.inputs[0])
+                if cond is None:
+                    cond = self._const(node.inputs[0], env)
+                b = 0 if np.asarray(env.to_host(cond)).item() != 0 else 1
+                taken[k] = b
+                open_branches.add((k, b))
+                todo.append(k)
+                todo.extend(reversed(self._branch_nodes.get((k, b), ())))
+                continue
             ins = []
             for i in node.inputs:
                 v = vals.get(i)
@@ -501,6 +567,8 @@ class HipExecutable:
             h = handlers.get(node.op)
             if h is None:
                 raise NotImplementedError(f"hip linker: no device handler for {node.op}")
+            if node.op == "IfElse":
+                env.branch = taken[k]
             try:
                 if evs is not None:
                     ffi.check(env.lib.pthip_event_record(evs[2 * k]))

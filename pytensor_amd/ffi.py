@@ -121,11 +121,13 @@ SIGNATURES = {
     "pthip_nonzero": (_int, [_i64, _vp, _vp, _vp]),
     "pthip_random": (_int, [_int, _int, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     "pthip_random_categorical": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "pthip_searchsorted": (_int, [_int, _i64, _vp, _vp, _int, _i64, _vp, _int, _vp]),
+    "pthip_convolve1d": (_int, [_int, _i64, _vp, _i64, _vp, _int, _vp]),
     "pthip_geqrf": (_int, [_int, _i64, _i64, _i64, _vp, _vp]),
     "pthip_orgqr": (_int, [_int, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),
     "pthip_svd_rows": (_int, [_int, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "pthip_fill_null_rows": (_int, [_int, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _i64]),
-    "pthip_triu": (_int, [_int, _i64, _i64, _i64, _vp, _i64, _i64, _vp]),
+    "pthip_triu": (_int, [_int, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _int, _int]),
     "pthip_gttrf": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "pthip_gttrs": (_int, [_int, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pthip_random_multinomial": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _int, _i64, _vp, _i64, _vp]),

@@ -614,6 +614,77 @@ def _(op, node, ctx):
     return "RandomVariable", params
 
 
+def _register_misc():
+    # index / layout / signal ops of the widening tier (dispatch/misc.py)
+    from pytensor.tensor.extra_ops import (
+        Bartlett,
+        CpuContiguous,
+        FillDiagonal,
+        FillDiagonalOffset,
+        RavelMultiIndex,
+        Repeat,
+        SearchsortedOp,
+        Unique,
+        UnravelIndex,
+    )
+    from pytensor.tensor.linalg.decomposition.lu import LU
+    from pytensor.tensor.reshape import JoinDims, SplitDims
+    from pytensor.tensor.signal.conv import Convolve1d
+
+    for cls in (Bartlett, CpuContiguous, FillDiagonal, FillDiagonalOffset, Convolve1d):
+        hip_funcify.register(cls)(lambda op, node, ctx: (type(op).__name__, {}))
+
+    @hip_funcify.register(JoinDims)
+    def _(op, node, ctx):
+        return "JoinDims", {"start_axis": int(op.start_axis), "n_axes": int(op.n_axes)}
+
+    @hip_funcify.register(SplitDims)
+    def _(op, node, ctx):
+        return "SplitDims", {"axis": int(op.axis)}
+
+    @hip_funcify.register(SearchsortedOp)
+    def _(op, node, ctx):
+        return "SearchsortedOp", {"side": str(op.side)}
+
+    @hip_funcify.register(Repeat)
+    def _(op, node, ctx):
+        return "Repeat", {"axis": int(op.axis)}
+
+    @hip_funcify.register(UnravelIndex)
+    def _(op, node, ctx):
+        return "UnravelIndex", {"order": str(op.order)}
+
+    @hip_funcify.register(RavelMultiIndex)
+    def _(op, node, ctx):
+        return "RavelMultiIndex", {"mode": str(op.mode), "order": str(op.order)}
+
+    @hip_funcify.register(Unique)
+    def _(op, node, ctx):
+        if op.axis is not None:
+            return None
+        return "Unique", {"return_index": bool(op.return_index), "return_inverse": bool(op.return_inverse),
+                          "return_counts": bool(op.return_counts), "axis": None}
+
+    @hip_funcify.register(LU)
+    def _(op, node, ctx):
+        return "LU", {"permute_l": bool(op.permute_l), "p_indices": bool(op.p_indices)}
+
+
+_register_misc()
+
+
+def _register_ifelse():
+    from pytensor.ifelse import IfElse
+
+    @hip_funcify.register(IfElse)
+    def _(op, node, ctx):
+        # inputs (condition, n_outs "then" values, n_outs "else" values); lazily evaluated
+        return "IfElse", {"n_outs": int(op.n_outs)}
+
+
+_register_ifelse()
+
+
 def _register_ofg():
     from pytensor.compile.builders import OpFromGraph
 
