@@ -283,6 +283,10 @@ int pthip_searchsorted(int x_dtype, int64_t n, const void* x, const void* sorter
 /* Convolve1d.perform (signal/conv.py:124-128: np.convolve): out = a * b, "full" (na + nb - 1 values)
  * or "valid" (|na - nb| + 1); float32 / float64 / int64 */
 int pthip_convolve1d(int dtype, int64_t na, const void* a, int64_t nb, const void* b, int full, void* out);
+/* Convolve2d.perform (signal/conv.py:260-263: scipy.signal.convolve of two matrices, "full" or
+ * "valid"): direct sums, a (ha x wa) and b (hb x wb) contiguous */
+int pthip_convolve2d(int dtype, int64_t ha, int64_t wa, const void* a, int64_t hb, int64_t wb, const void* b, int full,
+                     void* out);
 
 /* ---- dense decompositions, correct-first tier (csrc/decomp.hip): one workgroup per matrix ---- */
 /* QR.perform (linalg/decomposition/qr.py:153-221): LAPACK geqrf in place on `batch` contiguous

@@ -214,3 +214,54 @@ def index_layout_misc():
             "i0": rng.integers(0, 4, size=8), "i1": rng.integers(0, 5, size=8), "i2": rng.integers(0, 3, size=8),
             "sig": rng.normal(size=50), "ker": rng.normal(size=7), "fs": rng.normal(size=20).astype("float32"), "fk": rng.normal(size=20).astype("float32")}
     return [xs, v, xi, vi, perm, M3, reps, A, Tl, C3, val, u, uf, flat, dims3, i0, i1, i2, sig, ker, fs, fk], outs, vals
+
+
+@case("expm_and_grad")
+def expm_and_grad():
+    # linalg/products.py:13 Expm (scipy.linalg.expm) and its pullback 48-77: the Frechet derivative as
+    # the upper-right block of expm([[A^T, G], [0, A^T]]).  Norms from 0.02 to 60: no scaling, and
+    # several squarings; a float32 input.
+    from pytensor.tensor.linalg.products import Expm
+
+    rng = np.random.default_rng(87)
+    A, B, Z = pt.dmatrix("A"), pt.dmatrix("B"), pt.dmatrix("Z")
+    F = pt.fmatrix("F")
+    Wt = pt.dmatrix("Wt")
+    cost = (Expm()(A) * Wt).sum()
+    outs = [Expm()(A), Expm()(B), Expm()(Z), Expm()(F), pytensor.grad(cost, A), Expm()(-B)]
+    n = 9
+    Av = rng.normal(size=(n, n)) * 0.4
+    Bv = rng.normal(size=(n, n)) * 4.0 - 6.0 * np.eye(n)  # norm ~ 60 with a decaying spectrum
+    vals = {"A": Av, "B": Bv, "Z": rng.normal(size=(5, 5)) * 0.004, "F": (rng.normal(size=(6, 6)) * 0.7).astype("float32"),
+            "Wt": rng.normal(size=(n, n))}
+    return [A, B, Z, F, Wt], outs, vals
+
+
+@case("choose_permute_conv2d")
+def choose_permute_conv2d():
+    # tensor/basic.py:4135 Choose (np.choose, tensor choices), 3426 PermuteRowElements (a permutation per
+    # row, forward and inverse, broadcast leading dims), signal/conv.py Convolve2d (scipy.signal.convolve)
+    from pytensor.tensor.basic import Choose, PermuteRowElements
+    from pytensor.tensor.signal.conv import Convolve2d
+
+    rng = np.random.default_rng(88)
+    a = pt.lmatrix("a")
+    ch = pt.dtensor3("ch")
+    chv = pt.dmatrix("chv")
+    x2, p2, p1 = pt.dmatrix("x2"), pt.lmatrix("p2"), pt.lvector("p1")
+    x1 = pt.dvector("x1")
+    img, ker = pt.dmatrix("img"), pt.dmatrix("ker")
+    fi, fk = pt.fmatrix("fi"), pt.fmatrix("fk")
+    T, F = pt.as_tensor(np.array(True)), pt.as_tensor(np.array(False))
+    outs = [
+        Choose("raise")(a, ch), Choose("wrap")(a - 5, ch), Choose("clip")(a * 3 - 2, ch), Choose("raise")(a[0], chv),
+        PermuteRowElements(inverse=False)(x2, p2), PermuteRowElements(inverse=True)(x2, p2),
+        PermuteRowElements(inverse=False)(x2, p1), PermuteRowElements(inverse=True)(x1, p2),
+        Convolve2d(method="direct")(img, ker, T), Convolve2d(method="direct")(img, ker, F), Convolve2d(method="auto")(ker, img, F),
+        Convolve2d(method="direct")(fi, fk, T),
+    ]
+    vals = {"a": rng.integers(0, 4, size=(3, 5)), "ch": rng.normal(size=(4, 3, 5)), "chv": rng.normal(size=(4, 5)),
+            "x2": rng.normal(size=(4, 6)), "p2": np.stack([rng.permutation(6) for _ in range(4)]), "p1": rng.permutation(6),
+            "x1": rng.normal(size=6), "img": rng.normal(size=(14, 11)), "ker": rng.normal(size=(3, 5)),
+            "fi": rng.normal(size=(9, 9)).astype("float32"), "fk": rng.normal(size=(4, 4)).astype("float32")}
+    return [a, ch, chv, x2, p2, p1, x1, img, ker, fi, fk], outs, vals

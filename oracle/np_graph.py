@@ -1145,6 +1145,44 @@ def _block_diagonal(p, inputs, node, graph):
     return [scipy.linalg.block_diag(*inputs).astype(p["dtype"])]
 
 
+@op("Convolve2d")
+def _convolve2d(p, inputs, node, graph):
+    # pytensor/tensor/signal/conv.py:260-263: scipy.signal.convolve (direct sums: the restated kernel)
+    import scipy.signal
+
+    return [scipy.signal.convolve(inputs[0], inputs[1], mode="full" if bool(inputs[2]) else "valid", method="direct")]
+
+
+@op("Choose")
+def _choose(p, inputs, node, graph):
+    # pytensor/tensor/basic.py (Choose.perform): np.choose
+    return [np.choose(inputs[0], inputs[1], mode=p["mode"])]
+
+
+@op("PermuteRowElements")
+def _permute_row_elements(p, inputs, node, graph):
+    # pytensor/tensor/basic.py:3500-3560 (_rec_perform): a permutation per row, leading dims broadcast
+    x, y = inputs
+    nd = max(x.ndim, y.ndim)
+    x = x.reshape((1,) * (nd - x.ndim) + x.shape)
+    y = y.reshape((1,) * (nd - y.ndim) + y.shape)
+    shape = np.broadcast_shapes(x.shape, y.shape)
+    xb, yb = np.broadcast_to(x, shape), np.broadcast_to(y, shape)
+    out = np.empty(shape, dtype=x.dtype)
+    for idx in np.ndindex(*shape[:-1]):
+        if p["inverse"]:
+            out[idx][yb[idx]] = xb[idx]
+        else:
+            out[idx] = xb[idx][yb[idx]]
+    return [out]
+
+
+@op("Expm")
+def _expm(p, inputs, node, graph):
+    # pytensor/tensor/linalg/products.py:35-38 (Expm.perform): scipy.linalg.expm
+    return [scipy.linalg.expm(inputs[0])]
+
+
 @op("CpuContiguous")
 def _cpu_contiguous(p, inputs, node, graph):
     # pytensor/tensor/extra_ops.py:67-75

@@ -1,9 +1,10 @@
 // misc.hip — small index / signal kernels of the widening tier: SearchsortedOp,
-// Convolve1d.
+// Convolve1d, Convolve2d.
 //
 // Reference: SearchsortedOp.perform (pytensor/tensor/extra_ops.py:155-166: np.searchsorted with
 // side / sorter), Convolve1d.perform (pytensor/tensor/signal/conv.py: np.convolve, "full" or
-// "valid").  Index tier for searchsorted (bit-exact); the convolution accumulates each output in
+// "valid"), Convolve2d.perform (conv.py:260-263: scipy.signal.convolve, direct sums here whatever
+// `method` says).  Index tier for searchsorted (bit-exact); the convolution accumulates each output in
 // increasing order of the first operand's index, like np.convolve's inner dot.
 #include "common.h"
 
@@ -81,6 +82,22 @@ __global__ void convolve1d_kernel(const T* __restrict__ a, long long na, const T
   }
 }
 
+// out[i][j] = sum_{p,q} a[p][q] * b[i + lo_r - p][j + lo_c - q] over the overlap
+template <class T>
+__global__ void convolve2d_kernel(const T* __restrict__ a, int ha, int wa, const T* __restrict__ b, int hb, int wb, int lo_r,
+                                  int lo_c, int ho, int wo, T* __restrict__ out) {
+  const long long total = (long long)ho * wo;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int fi = (int)(e / wo) + lo_r, fj = (int)(e % wo) + lo_c;
+    const int p0 = fi - (hb - 1) > 0 ? fi - (hb - 1) : 0, p1 = fi < ha - 1 ? fi : ha - 1;
+    const int q0 = fj - (wb - 1) > 0 ? fj - (wb - 1) : 0, q1 = fj < wa - 1 ? fj : wa - 1;
+    T acc = T(0);
+    for (int p = p0; p <= p1; p++)
+      for (int q = q0; q <= q1; q++) acc += a[(long long)p * wa + q] * b[(long long)(fi - p) * wb + (fj - q)];
+    out[e] = acc;
+  }
+}
+
 int grid_for(long long n) {
   long long g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -111,4 +128,24 @@ extern "C" int pthip_convolve1d(int dtype, int64_t na, const void* a, int64_t nb
   else if (dtype == PTHIP_I64) PTHIP_KLAUNCH(convolve1d_kernel<long long>, dim3(grid_for(nout)), dim3(256), 0, st, (const long long*)a, (long long)na, (const long long*)b, (long long)nb, lo, nout, (long long*)out);
   else return pthip::set_error("pthip_convolve1d: dtype %d not supported (float32/float64/int64)", dtype);
   return pthip::post_launch("convolve1d");
+}
+
+extern "C" int pthip_convolve2d(int dtype, int64_t ha, int64_t wa, const void* a, int64_t hb, int64_t wb, const void* b, int full,
+                                void* out) {
+  PTHIP_REQUIRE_INIT();
+  if (ha <= 0 || wa <= 0 || hb <= 0 || wb <= 0) return 0;
+  if (!full && !((ha >= hb && wa >= wb) || (hb >= ha && wb >= wa)))
+    return pthip::set_error("pthip_convolve2d: for 'valid' mode, one must be at least as large as the other in every dimension");
+  auto mn = [](long long x, long long y) { return x < y ? x : y; };
+  auto mx = [](long long x, long long y) { return x > y ? x : y; };
+  const int lo_r = full ? 0 : (int)mn(ha, hb) - 1, lo_c = full ? 0 : (int)mn(wa, wb) - 1;
+  const int ho = full ? (int)(ha + hb - 1) : (int)(mx(ha, hb) - mn(ha, hb) + 1);
+  const int wo = full ? (int)(wa + wb - 1) : (int)(mx(wa, wb) - mn(wa, wb) + 1);
+  hipStream_t st = pthip::ctx().stream;
+  const int g = grid_for((long long)ho * wo);
+  if (dtype == PTHIP_F64) PTHIP_KLAUNCH(convolve2d_kernel<double>, dim3(g), dim3(256), 0, st, (const double*)a, (int)ha, (int)wa, (const double*)b, (int)hb, (int)wb, lo_r, lo_c, ho, wo, (double*)out);
+  else if (dtype == PTHIP_F32) PTHIP_KLAUNCH(convolve2d_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)a, (int)ha, (int)wa, (const float*)b, (int)hb, (int)wb, lo_r, lo_c, ho, wo, (float*)out);
+  else if (dtype == PTHIP_I64) PTHIP_KLAUNCH(convolve2d_kernel<long long>, dim3(g), dim3(256), 0, st, (const long long*)a, (int)ha, (int)wa, (const long long*)b, (int)hb, (int)wb, lo_r, lo_c, ho, wo, (long long*)out);
+  else return pthip::set_error("pthip_convolve2d: dtype %d not supported (float32/float64/int64)", dtype);
+  return pthip::post_launch("convolve2d");
 }

@@ -350,3 +350,73 @@ def block_diagonal(node, inputs, env):
         r0 += m.shape[0]
         c0 += m.shape[1]
     return [out]
+
+
+# ---- matrix exponential ---------------------------------------------------------------------------
+_PADE13 = (64764752532480000.0, 32382376266240000.0, 7771770303897600.0, 1187353796428800.0, 129060195264000.0, 10559470521600.0,
+           670442572800.0, 33522128640.0, 1323241920.0, 40840800.0, 960960.0, 16380.0, 182.0, 1.0)
+_THETA13 = 5.371920351148152  # Higham (2005), Table 2.3: ||A||_1 up to which the [13/13] Pade approximant is exact to fp64
+
+
+@handler("Expm")
+def expm(node, inputs, env):
+    """``Expm`` (linalg/products.py:13; perform = scipy.linalg.expm): scaling and squaring with the
+    [13/13] Pade approximant (Higham 2005, the algorithm scipy's expm descends from) out of device
+    GEMMs, fused linear combinations and one LU solve.  The scaling power is chosen from ||A||_1 (one
+    host read of n column sums).  scipy additionally picks lower Pade orders for small norms; both are
+    backward stable to unit roundoff."""
+    from pytensor_amd.dispatch.blas import gemm_device
+    from pytensor_amd.dispatch.lu import solve_general
+
+    A = _matrix(env, inputs[0], "Expm")
+    n = A.shape[0]
+    if A.shape[1] != n:
+        raise ValueError("expected a square matrix")
+    if n == 0:
+        return [DeviceArray.empty((0, 0), A.dtype)]
+    dt = str(A.dtype)
+    A = A.contiguous()
+    absA = _ew1(env, [{"op": "Abs", "in": [["i", 0]], "dtype": dt}], [A], [dt], dt, (n, n))
+    norm1 = float(np.asarray(env.to_host(_column_sums(env, absA))).max())
+    if not np.isfinite(norm1):
+        return [env.to_device(HostValue(np.full((n, n), np.nan, dtype=A.dtype)))]
+    s = max(0, int(np.ceil(np.log2(norm1 / _THETA13)))) if norm1 > _THETA13 else 0
+    if s:
+        A = _ew1(env, [{"op": "Mul", "in": [["i", 0], ["c", float(2.0 ** -s).hex(), dt]], "dtype": dt}], [A], [dt], dt, (n, n))
+    eye = DeviceArray.empty((n, n), A.dtype)
+    ffi.check(env.lib.pthip_eye(ffi.np_dtype_code(A.dtype), n, n, 0, eye.ptr))
+    b = _PADE13
+    A2 = gemm_device(env, 1.0, A, A)
+    A4 = gemm_device(env, 1.0, A2, A2)
+    A6 = gemm_device(env, 1.0, A4, A2)
+
+    def comb(coefs, mats):
+        ops, acc = [], None
+        for k, c in enumerate(coefs):
+            ops.append({"op": "Mul", "in": [["i", k], ["c", float(c).hex(), dt]], "dtype": dt})
+            if acc is not None:
+                ops.append({"op": "Add", "in": [acc, ["t", len(ops) - 1]], "dtype": dt})
+            acc = ["t", len(ops) - 1]
+        return _ew1(env, ops, mats, [dt] * len(mats), dt, (n, n))
+
+    W1 = comb((b[13], b[11], b[9]), [A6, A4, A2])
+    W2 = comb((b[7], b[5], b[3], b[1]), [A6, A4, A2, eye])
+    Z1 = comb((b[12], b[10], b[8]), [A6, A4, A2])
+    Z2 = comb((b[6], b[4], b[2], b[0]), [A6, A4, A2, eye])
+    W = gemm_device(env, 1.0, A6, W1, 1.0, W2)  # A6 W1 + W2
+    U = gemm_device(env, 1.0, A, W)
+    V = gemm_device(env, 1.0, A6, Z1, 1.0, Z2)
+    P = comb((1.0, 1.0), [V, U])
+    Q = comb((1.0, -1.0), [V, U])
+    X = solve_general(env, Q, P, 2)
+    for _ in range(s):
+        X = gemm_device(env, 1.0, X, X)
+    return [X]
+
+
+def _ew1(env, body_ops, ins, in_dtypes, out_dtype, shape):
+    from pytensor_amd.dispatch.elemwise import launch_elemwise
+
+    body = {"in_dtypes": list(in_dtypes), "out_dtypes": [out_dtype], "body": body_ops, "outs": [["t", len(body_ops) - 1]]}
+    (out,), _, _ = launch_elemwise(body, ins, tuple(shape), [out_dtype], None, env)
+    return out

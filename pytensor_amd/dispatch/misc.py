@@ -1,6 +1,7 @@
 """Index / layout / signal ops of the widening tier: ``CpuContiguous``, ``JoinDims`` / ``SplitDims``,
 ``FillDiagonal`` / ``FillDiagonalOffset``, ``Bartlett``, ``SearchsortedOp``, ``Repeat``,
-``UnravelIndex`` / ``RavelMultiIndex``, ``Unique``, ``LU``, ``Convolve1d``.
+``UnravelIndex`` / ``RavelMultiIndex``, ``Unique``, ``LU``, ``Convolve1d`` / ``Convolve2d``, ``Choose``,
+``PermuteRowElements``.
 
 Reference: pytensor/tensor/extra_ops.py (CpuContiguous 47, SearchsortedOp 111, Repeat 639, Bartlett 776,
 FillDiagonal 839, FillDiagonalOffset 943, Unique 1189, UnravelIndex 1287, RavelMultiIndex 1365),
@@ -355,3 +356,119 @@ def convolve1d(node, inputs, env):
     ffi.check(env.lib.pthip_convolve1d(ffi.np_dtype_code(kdt), na, a.ptr, nb, b.ptr, int(full), out.ptr))
     env.keepalive.extend((a, b))
     return [out if kdt == dt else _cast(env, out, dt)]
+
+
+@handler("Convolve2d")
+def convolve2d(node, inputs, env):
+    # signal/conv.py:260-263: scipy.signal.convolve(in1, in2, "full" | "valid") — direct sums
+    a, b = (env.to_device(i) for i in inputs[:2])
+    full = bool(np.asarray(env.to_host(inputs[2])).item())
+    if a.ndim != 2 or b.ndim != 2:
+        raise ValueError("convolve2d inputs must both be 2-D arrays")
+    dt = np.result_type(np.dtype(a.dtype), np.dtype(b.dtype))
+    if dt.kind == "b":
+        raise NotImplementedError("hip linker: Convolve2d of bool arrays")
+    kdt = dt if dt.name in ("float64", "float32", "int64") else np.dtype("int64" if dt.kind in "iu" else "float64")
+    from pytensor_amd.dispatch.elemwise import _cast
+
+    a, b = (t.contiguous() if np.dtype(t.dtype) == kdt else _cast(env, t.contiguous(), kdt) for t in (a, b))
+    (ha, wa), (hb, wb) = a.shape, b.shape
+    if 0 in (ha, wa, hb, wb):
+        raise ValueError("convolve2d: empty input")
+    if full:
+        shape = (ha + hb - 1, wa + wb - 1)
+    else:
+        if not ((ha >= hb and wa >= wb) or (hb >= ha and wb >= wa)):
+            raise ValueError("For 'valid' mode, one must be at least as large as the other in every dimension")
+        shape = (abs(ha - hb) + 1, abs(wa - wb) + 1)
+    out = DeviceArray.empty(shape, kdt)
+    ffi.check(env.lib.pthip_convolve2d(ffi.np_dtype_code(kdt), ha, wa, a.ptr, hb, wb, b.ptr, int(full), out.ptr))
+    env.keepalive.extend((a, b))
+    return [out if kdt == dt else _cast(env, out, dt)]
+
+
+def _iota(env, n: int) -> DeviceArray:
+    out = DeviceArray.empty((n,), "int64")
+    if n:
+        ffi.check(env.lib.pthip_arange(ffi.np_dtype_code(np.dtype("int64")), n, 0.0, 1.0, 0, 1, out.ptr))
+    return out
+
+
+def _bcast_copy(env, x: DeviceArray, shape) -> DeviceArray:
+    if tuple(x.shape) == tuple(shape) and x.is_contiguous():
+        return x
+    out = DeviceArray.empty(tuple(shape), x.dtype)
+    if out.size:
+        copy_into(out, _bview(x, shape))
+    return out
+
+
+@handler("Choose")
+def choose(node, inputs, env):
+    """np.choose(a, choices, mode) with ``choices`` one tensor (K, ...): out[i] = choices[a[i]][i]
+    (tensor/basic.py:4135; typed-list choices are not lowered)"""
+    a = _as_int64(env, env.to_device(inputs[0]))
+    ch = env.to_device(inputs[1])
+    if ch.ndim < 1:
+        raise ValueError("choices must have at least one dimension")
+    K = ch.shape[0]
+    shape = tuple(np.broadcast_shapes(tuple(a.shape), tuple(ch.shape[1:])))
+    size = int(np.prod(shape, dtype=np.int64)) if shape else 1
+    ab = _bcast_copy(env, a, shape)
+    cb = _bcast_copy(env, ch, (K, *shape))
+    mode = node.params["mode"]
+    if mode == "raise" and ab.size:
+        h = np.asarray(env.to_host(ab))
+        if (h < 0).any() or (h >= K).any():
+            raise ValueError("invalid entry in choice array")
+    ops = []
+    ref = ["i", 0]
+    if mode == "wrap":
+        ops.append({"op": "Mod", "in": [ref, ["c", max(K, 1), "int64"]], "dtype": "int64"})
+        ref = ["t", 0]
+    elif mode == "clip":
+        ops.append({"op": "Maximum", "in": [ref, ["c", 0, "int64"]], "dtype": "int64"})
+        ops.append({"op": "Minimum", "in": [["t", 0], ["c", K - 1, "int64"]], "dtype": "int64"})
+        ref = ["t", 1]
+    ops.append({"op": "Mul", "in": [ref, ["c", size, "int64"]], "dtype": "int64"})
+    ops.append({"op": "Add", "in": [["t", len(ops) - 1], ["i", 1]], "dtype": "int64"})
+    out = DeviceArray.empty(shape, ch.dtype)
+    if size:
+        flat = _ew(env, ops, [ab.view((size,), (1,)), _iota(env, size)], ["int64", "int64"], "int64", (size,))
+        ffi.check(env.lib.pthip_take_rows(ch.itemsize, size, 1, cb.ptr, K * size, 1, flat.ptr, out.ptr))
+        env.keepalive.extend((cb, flat))
+    return [out]
+
+
+@handler("PermuteRowElements")
+def permute_row_elements(node, inputs, env):
+    """tensor/basic.py:3426: out[..., i] = x[..., y[..., i]] (inverse: out[..., y[..., i]] = x[..., i]),
+    the leading dimensions of x and y broadcast against each other"""
+    from pytensor_amd.dispatch.subtensor import _scatter_rows
+
+    x = env.to_device(inputs[0])
+    y = _as_int64(env, env.to_device(inputs[1]))
+    nd = max(x.ndim, y.ndim)
+    xs = (1,) * (nd - x.ndim) + tuple(x.shape)
+    ys = (1,) * (nd - y.ndim) + tuple(y.shape)
+    if xs[-1] != ys[-1]:
+        raise ValueError(f"Dimension mismatch: {xs[-1]}, {ys[-1]}")
+    shape = tuple(np.broadcast_shapes(xs, ys))
+    L = shape[-1]
+    size = int(np.prod(shape, dtype=np.int64))
+    xb = _bcast_copy(env, x.view(xs, (0,) * (nd - x.ndim) + tuple(x.strides)), shape)
+    yb = _bcast_copy(env, y.view(ys, (0,) * (nd - y.ndim) + tuple(y.strides)), shape)
+    out = DeviceArray.empty(shape, x.dtype)
+    if size == 0:
+        return [out]
+    # flat index of the addressed element: (position // L) * L + y
+    ops = [{"op": "IntDiv", "in": [["i", 1], ["c", L, "int64"]], "dtype": "int64"},
+           {"op": "Mul", "in": [["t", 0], ["c", L, "int64"]], "dtype": "int64"},
+           {"op": "Add", "in": [["t", 1], ["i", 0]], "dtype": "int64"}]
+    flat = _ew(env, ops, [yb.view((size,), (1,)), _iota(env, size)], ["int64", "int64"], "int64", (size,))
+    if node.params["inverse"]:
+        _scatter_rows(env, {"set_instead_of_inc": True}, out.view((size,), (1,)), xb.view((size,), (1,)), flat)
+    else:
+        ffi.check(env.lib.pthip_take_rows(x.itemsize, size, 1, xb.ptr, size, 1, flat.ptr, out.ptr))
+    env.keepalive.extend((xb, flat))
+    return [out]

@@ -123,6 +123,7 @@ SIGNATURES = {
     "pthip_random_categorical": (_int, [_int, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
     "pthip_searchsorted": (_int, [_int, _i64, _vp, _vp, _int, _i64, _vp, _int, _vp]),
     "pthip_convolve1d": (_int, [_int, _i64, _vp, _i64, _vp, _int, _vp]),
+    "pthip_convolve2d": (_int, [_int, _i64, _i64, _vp, _i64, _i64, _vp, _int, _vp]),
     "pthip_geqrf": (_int, [_int, _i64, _i64, _i64, _vp, _vp]),
     "pthip_orgqr": (_int, [_int, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),
     "pthip_svd_rows": (_int, [_int, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp]),

@@ -374,6 +374,12 @@ def _register_extra_ops():
     from pytensor.tensor.linalg.solvers.lstsq import Lstsq, TensorSolve
     from pytensor.tensor.linalg.solvers.tridiagonal import LUFactorTridiagonal, SolveLUFactorTridiagonal
 
+    from pytensor.tensor.linalg.products import Expm
+
+    @hip_funcify.register(Expm)
+    def _(op, node, ctx):
+        return "Expm", {}
+
     @hip_funcify.register(QR)
     def _(op, node, ctx):
         if op.pivoting:
@@ -629,9 +635,20 @@ def _register_misc():
     )
     from pytensor.tensor.linalg.decomposition.lu import LU
     from pytensor.tensor.reshape import JoinDims, SplitDims
-    from pytensor.tensor.signal.conv import Convolve1d
+    from pytensor.tensor.basic import Choose, PermuteRowElements
+    from pytensor.tensor.signal.conv import Convolve1d, Convolve2d
 
-    for cls in (Bartlett, CpuContiguous, FillDiagonal, FillDiagonalOffset, Convolve1d):
+    @hip_funcify.register(Choose)
+    def _(op, node, ctx):
+        if node is not None and not isinstance(node.inputs[1].type, TensorType):
+            return None  # (typed-list choices)
+        return "Choose", {"mode": str(op.mode)}
+
+    @hip_funcify.register(PermuteRowElements)
+    def _(op, node, ctx):
+        return "PermuteRowElements", {"inverse": bool(op.inverse)}
+
+    for cls in (Bartlett, CpuContiguous, FillDiagonal, FillDiagonalOffset, Convolve1d, Convolve2d):
         hip_funcify.register(cls)(lambda op, node, ctx: (type(op).__name__, {}))
 
     @hip_funcify.register(JoinDims)
