@@ -265,3 +265,27 @@ def choose_permute_conv2d():
             "x1": rng.normal(size=6), "img": rng.normal(size=(14, 11)), "ker": rng.normal(size=(3, 5)),
             "fi": rng.normal(size=(9, 9)).astype("float32"), "fk": rng.normal(size=(4, 4)).astype("float32")}
     return [a, ch, chv, x2, p2, p1, x1, img, ker, fi, fk], outs, vals
+
+
+@case("rfft_irfft")
+def rfft_irfft():
+    # tensor/fft.py:11 RFFTOp (np.fft.rfftn over the trailing axes of a batch, re/im stacked last),
+    # 76 IRFFTOp (np.fft.irfftn * prod(s)), their pullbacks (each is the other with the interior
+    # frequencies halved / doubled).  Even and odd lengths, a 2-d transform, zero padding through s.
+    from pytensor.tensor.fft import irfft, rfft
+
+    rng = np.random.default_rng(89)
+    x = pt.dmatrix("x")     # (3, 16)
+    xo = pt.dmatrix("xo")   # (2, 15)
+    x2 = pt.dtensor3("x2")  # (2, 6, 9)
+    xf = pt.fmatrix("xf")   # (4, 12)
+    w = pt.dtensor3("w")
+    X = rfft(x)
+    Xo = rfft(xo)
+    X2 = rfft(x2)
+    cost = (rfft(x, norm="ortho") * w).sum()
+    outs = [X, Xo, X2, rfft(xf), irfft(X), irfft(Xo, is_odd=True), irfft(X2, is_odd=True),
+            irfft(X * w), pytensor.grad(cost, x), pytensor.grad((irfft(X2, is_odd=True) ** 2).sum(), x2)]
+    vals = {"x": rng.normal(size=(3, 16)), "xo": rng.normal(size=(2, 15)), "x2": rng.normal(size=(2, 6, 9)),
+            "xf": rng.normal(size=(4, 12)).astype("float32"), "w": rng.normal(size=(3, 9, 2))}
+    return [x, xo, x2, xf, w], outs, vals

@@ -1145,6 +1145,27 @@ def _block_diagonal(p, inputs, node, graph):
     return [scipy.linalg.block_diag(*inputs).astype(p["dtype"])]
 
 
+@op("RFFTOp")
+def _rfft(p, inputs, node, graph):
+    # pytensor/tensor/fft.py:39-48 (RFFTOp.perform)
+    a, s = inputs
+    s = tuple(int(v) for v in s)
+    A = np.fft.rfftn(a, s=s, axes=tuple(range(a.ndim - len(s), a.ndim)))
+    out = np.zeros((*A.shape, 2), dtype=a.dtype)
+    out[..., 0], out[..., 1] = np.real(A), np.imag(A)
+    return [out]
+
+
+@op("IRFFTOp")
+def _irfft(p, inputs, node, graph):
+    # pytensor/tensor/fft.py:109-117 (IRFFTOp.perform): numpy's 1/n normalisation removed
+    a, s = inputs
+    s = np.asarray(s)
+    inp = a[..., 0] + 1j * a[..., 1]
+    out = np.fft.irfftn(inp, s=tuple(int(v) for v in s), axes=tuple(range(inp.ndim - len(s), inp.ndim)))
+    return [(out * s.prod()).astype(a.dtype)]
+
+
 @op("Convolve2d")
 def _convolve2d(p, inputs, node, graph):
     # pytensor/tensor/signal/conv.py:260-263: scipy.signal.convolve (direct sums: the restated kernel)

@@ -18,4 +18,4 @@ def handler(*names):
     return deco
 
 
-from pytensor_amd.dispatch import basic, blas, decomp, dotew, elemwise, extra, fused, linalg, lu, misc, random, scan, subtensor, tail, wide  # noqa: E402,F401
+from pytensor_amd.dispatch import basic, blas, decomp, dotew, elemwise, extra, fft, fused, linalg, lu, misc, random, scan, subtensor, tail, wide  # noqa: E402,F401

@@ -690,6 +690,21 @@ def _register_misc():
 _register_misc()
 
 
+def _register_fft():
+    from pytensor.tensor.fft import IRFFTOp, RFFTOp
+
+    @hip_funcify.register(RFFTOp)
+    def _(op, node, ctx):
+        return "RFFTOp", {}
+
+    @hip_funcify.register(IRFFTOp)
+    def _(op, node, ctx):
+        return "IRFFTOp", {}
+
+
+_register_fft()
+
+
 def _register_ifelse():
     from pytensor.ifelse import IfElse
 
