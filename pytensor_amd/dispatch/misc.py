@@ -113,10 +113,14 @@ def fill_diagonal_offset(node, inputs, env):
     offset = int(np.asarray(env.to_host(inputs[2])).item())
     h, w = a.shape
     if offset >= 0:  # extra_ops.py:990-999
-        start, count = offset, min(min(w, h), w - offset)
+        start, steps = offset, min(min(w, h), w - offset)
     else:
-        start, count = -offset * w, min(min(w, h), h + offset)
-    _fill_line(env, a, start, w + 1, count, inputs[1])
+        start, steps = -offset * w, min(min(w, h), h + offset)
+    # a.flat[start : start + (w + 1) * steps : w + 1] = val, with Python's slice rules (an offset
+    # beyond the matrix makes the end negative, which wraps — the reference inherits that)
+    line = range(*slice(start, start + (w + 1) * steps, w + 1).indices(a.size))
+    if len(line):
+        _fill_line(env, a, line[0], w + 1, len(line), inputs[1])
     return [a]
 
 
