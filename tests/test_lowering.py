@@ -139,6 +139,51 @@ def test_every_random_variable_of_the_reference_lowers(pt):
         pytensor.function([x3], rb.PermutationRV(signature="(x)->(x)", dtype="float64")(x3[0], rng=rng, size=(2,), return_next_rng=True)[1], mode="hip")
 
 
+def test_op_coverage_of_the_registry(pt):
+    """Every ``Op`` class of pytensor.tensor (+ ifelse, scan, compile.ops, raise_op) either has a
+    ``hip_funcify`` registration or is on this list with the reason it has none."""
+    import importlib
+    import pkgutil
+
+    import pytensor
+    from pytensor.graph.op import Op
+
+    from pytensor_amd.lower import hip_funcify
+
+    not_lowered = {
+        # abstract bases
+        "BaseBLAS", "GemmRelated", "BaseBlockDiagonal", "SolveBase", "ScipyWrapperOp", "ScipyScalarWrapperOp",
+        "ScipyVectorWrapperOp", "RNGConsumerOp", "AbstractRNGConstructor",
+        # complex-valued results (complex dtypes are a compile-time NotImplementedError)
+        "Eig", "Schur", "QZ", "TRSYL", "Fourier",
+        # call back into Python / construct host objects
+        "MinimizeScalarOp", "MinimizeOp", "RootScalarOp", "RootOp", "FromFunctionOp", "DefaultGeneratorMakerOp", "MakeSlice",
+    }
+    mods = []
+    for m in pkgutil.walk_packages(pytensor.tensor.__path__, "pytensor.tensor."):
+        if ".rewriting" in m.name or "xtensor" in m.name:
+            continue
+        try:
+            mods.append(importlib.import_module(m.name))
+        except Exception:
+            pass
+    mods += [importlib.import_module(n) for n in ("pytensor.ifelse", "pytensor.raise_op", "pytensor.compile.ops", "pytensor.scan.op", "pytensor.compile.builders")]
+    default = hip_funcify.dispatch(object)
+    seen, missing = set(), set()
+    for m in mods:
+        for name, c in list(vars(m).items()):
+            try:
+                is_op = isinstance(c, type) and issubclass(c, Op)
+            except TypeError:  # (typing generics)
+                is_op = False
+            if is_op and c.__module__ == m.__name__ and c not in seen:
+                seen.add(c)
+                if hip_funcify.dispatch(c) is default:
+                    missing.add(name)
+    assert len(seen) >= 160
+    assert missing == not_lowered, (sorted(missing - not_lowered), sorted(not_lowered - missing))
+
+
 def test_all_reduce_op_lowers_and_differentiates(pt):
     """The explicit collective (north_star: "the rare explicit all-reduce Op"): an ordinary Op for
     every linker (perform = the host reduction, identity on one rank), an ``AllReduce`` IR node
