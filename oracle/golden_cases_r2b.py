@@ -289,3 +289,28 @@ def rfft_irfft():
     vals = {"x": rng.normal(size=(3, 16)), "xo": rng.normal(size=(2, 15)), "x2": rng.normal(size=(2, 6, 9)),
             "xf": rng.normal(size=(4, 12)).astype("float32"), "w": rng.normal(size=(3, 9, 2))}
     return [x, xo, x2, xf, w], outs, vals
+
+
+@case("special_inverse_polygamma", rtol=1e-10)
+def special_inverse_polygamma():
+    # scalar/math.py:595 PolyGamma, 721 GammaIncInv, 746 GammaIncCInv, 1601 BetaIncInv: no C code in the
+    # reference — both of its linkers call scipy.special.  Inside fused Elemwise kernels here.
+    import pytensor.scalar as ps
+    from pytensor.scalar.math import BetaIncInv, GammaIncCInv, GammaIncInv, PolyGamma
+    from pytensor.tensor.elemwise import Elemwise
+
+    rng = np.random.default_rng(90)
+    x, a, b = pt.dvector("x"), pt.dvector("a"), pt.dvector("b")
+    p = pt.dvector("p")
+    n = pt.lvector("n")
+    pg = Elemwise(PolyGamma(ps.upgrade_to_float, name="polygamma"))
+    gi = Elemwise(GammaIncInv(ps.upgrade_to_float, name="gammaincinv"))
+    gci = Elemwise(GammaIncCInv(ps.upgrade_to_float, name="gammainccinv"))
+    bi = Elemwise(BetaIncInv(ps.upgrade_to_float, name="betaincinv"))
+    outs = [pg(n, x), pg(n[:, None], x[None, :5]) * 1e-3, gi(a, p), gci(a, p), bi(a, b, p),
+            pt.exp(-gi(a, p)) + pt.log1p(bi(a, b, p)),  # fused with neighbours
+            gi(a, pt.constant(np.array(1e-9))) , gci(a, pt.constant(np.array(1e-9))), bi(a, b, pt.constant(np.array(1.0 - 1e-9)))]
+    m = 60
+    vals = {"x": np.concatenate([rng.uniform(0.05, 30.0, size=m - 8), -rng.uniform(0.1, 4.9, size=8)]), "n": rng.integers(0, 6, size=m),
+            "a": 10 ** rng.uniform(-1, 2.5, size=m), "b": 10 ** rng.uniform(-1, 2.5, size=m), "p": rng.uniform(0.001, 0.999, size=m)}
+    return [x, a, b, p, n], outs, vals

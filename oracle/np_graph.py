@@ -180,6 +180,11 @@ SCALAR = {
     "GammaInc": special_c.GammaInc,
     "GammaIncC": special_c.GammaIncC,
     "BetaInc": special_c.BetaInc,
+    # (these four have no C code in the reference: both linkers evaluate them through SciPy)
+    "PolyGamma": scipy.special.polygamma,  # scalar/math.py:607
+    "GammaIncInv": scipy.special.gammaincinv,  # scalar/math.py:728
+    "GammaIncCInv": scipy.special.gammainccinv,  # scalar/math.py:753
+    "BetaIncInv": scipy.special.betaincinv,  # scalar/math.py:1608
     "J0": scipy.special.j0,
     "J1": scipy.special.j1,
     "I0": scipy.special.i0,

@@ -341,7 +341,201 @@ PT_DEV double pt_betainc(double a, double b, double x) {
 PT_DEV float pt_betainc(float a, float b, float x) { return (float)pt_betainc((double)a, (double)b, (double)x); }
 """
 
-_OPTIONAL_HELPERS = {"GammaInc": "gammainc", "GammaIncC": "gammainc", "BetaInc": "betainc"}
+
+_POLYGAMMA_SRC = r"""
+// polygamma(n, x) as scipy.special.polygamma computes it (PolyGamma.impl, scalar/math.py:607-608):
+// n = 0: digamma (reflection, recurrence to x >= 10, asymptotic series); n >= 1:
+// (-1)^(n+1) n! zeta(n + 1, x), the Hurwitz zeta function by Euler-Maclaurin summation
+// (Cephes zeta.c: direct terms until the argument exceeds 9, then 12 Bernoulli corrections)
+PT_DEV double pt_zeta(double x, double q) {
+  const double A[12] = {12.0, -720.0, 30240.0, -1209600.0, 47900160.0, -1.8924375803183791606e9, 7.47242496e10,
+                        -2.950130727918164224e12, 1.1646782814350067249e14, -4.5979787224074726105e15,
+                        1.8152105401943546773e17, -7.1661652561756670113e18};
+  const double MACHEP = 1.11022302462515654042e-16;
+  if (x == 1.0) return __builtin_inf();
+  if (!(x >= 1.0)) return __builtin_nan("");
+  if (q <= 0.0) {
+    if (q == floor(q)) return __builtin_inf();
+    if (x != floor(x)) return __builtin_nan("");
+  }
+  if (q > 1e8) return (1.0 / (x - 1.0) + 1.0 / (2.0 * q)) * pow(q, 1.0 - x);
+  double s = pow(q, -x), a = q, b = 0.0;
+  int i = 0;
+  while (i < 9 || a <= 9.0) {
+    i++;
+    a += 1.0;
+    b = pow(a, -x);
+    s += b;
+    if (fabs(b / s) < MACHEP) return s;
+  }
+  const double w = a;
+  s += b * w / (x - 1.0);
+  s -= 0.5 * b;
+  a = 1.0;
+  double k = 0.0;
+  for (i = 0; i < 12; i++) {
+    a *= x + k;
+    b /= w;
+    const double t = a * b / A[i];
+    s += t;
+    if (fabs(t / s) < MACHEP) return s;
+    k += 1.0;
+    a *= x + k;
+    b /= w;
+    k += 1.0;
+  }
+  return s;
+}
+PT_DEV double pt_digamma_acc(double x) {
+  if (x != x || x == __builtin_inf()) return x;
+  double nz = 0.0;
+  bool neg = false;
+  if (x <= 0.0) {
+    if (x == floor(x)) return __builtin_nan("");
+    neg = true;
+    const double q = x;
+    double p = floor(q);
+    nz = q - p;
+    if (nz != 0.5) {
+      if (nz > 0.5) { p += 1.0; nz = q - p; }
+      nz = 3.14159265358979323846 / tan(3.14159265358979323846 * nz);
+    } else {
+      nz = 0.0;
+    }
+    x = 1.0 - x;
+  }
+  double y;
+  if (x <= 10.0 && x == floor(x)) {
+    y = 0.0;
+    for (int i = 1; i < (int)x; i++) y += 1.0 / i;
+    y -= 0.57721566490153286061;
+  } else {
+    double s = x, w = 0.0;
+    while (s < 10.0) { w += 1.0 / s; s += 1.0; }
+    const double z = 1.0 / (s * s);
+    double yy = 8.33333333333333333333E-2;
+    yy = yy * z + -2.10927960927960927961E-2;
+    yy = yy * z + 7.57575757575757575758E-3;
+    yy = yy * z + -4.16666666666666666667E-3;
+    yy = yy * z + 3.96825396825396825397E-3;
+    yy = yy * z + -8.33333333333333333333E-3;
+    yy = yy * z + 8.33333333333333333333E-2;
+    yy *= z;
+    y = log(s) - 0.5 / s - yy - w;
+  }
+  return neg ? y - nz : y;
+}
+PT_DEV double pt_polygamma(double n, double x) {
+  if (n == 0.0) return pt_digamma_acc(x);
+  if (!(n > 0.0) || n != floor(n)) return __builtin_nan("");
+  const double sgn = (((long long)n) & 1) ? 1.0 : -1.0;
+  return sgn * tgamma(n + 1.0) * pt_zeta(n + 1.0, x);
+}
+PT_DEV float pt_polygamma(float n, float x) { return (float)pt_polygamma((double)n, (double)x); }
+"""
+
+_GAMMAINCINV_SRC = r"""
+// inverses of the regularised incomplete gamma functions (GammaIncInv / GammaIncCInv.impl,
+// scalar/math.py: scipy.special.gammaincinv / gammainccinv): the root of P(a, x) = p or Q(a, x) = q,
+// always posed on the smaller tail, by safeguarded Halley steps from a Wilson-Hilferty / power-law
+// starting point, iterated to the last bit of the forward function above
+PT_DEV double pt_gamma_tail_root(double a, double tail, bool is_upper) {
+  const double EPS = 2.220446049250313e-16;
+  const double lg = lgamma(a);
+  double z = -1.4142135623730951 * erfcinv(2.0 * tail);
+  if (is_upper) z = -z;
+  const double t = 1.0 - 1.0 / (9.0 * a) + z / (3.0 * sqrt(a));
+  double x = t > 0.0 ? a * t * t * t : 0.0;
+  if (!is_upper && (a < 1.0 || x <= 0.0 || tail < 1e-3)) {
+    const double x2 = exp((log(tail) + lg + log(a)) / a);
+    if (x <= 0.0 || x2 < x) x = x2;
+  }
+  if (is_upper && x <= 0.0) x = fmax(-log(tail) - lg, 1e-3);
+  if (!(x > 0.0) || isinf(x)) x = 1.0;
+  double lo = 0.0, hi = __builtin_inf();
+  for (int it = 0; it < 300; it++) {
+    const double f = (is_upper ? pt_gammaincc(a, x) : pt_gammainc(a, x)) - tail;
+    if (f == 0.0) return x;
+    const bool right = is_upper ? f > 0.0 : f < 0.0;
+    if (right) lo = fmax(lo, x); else hi = fmin(hi, x);
+    const double dens = exp((a - 1.0) * log(x) - x - lg);
+    double xn = -1.0;
+    if (dens > 0.0 && !isinf(dens)) {
+      const double r = f / (is_upper ? -dens : dens);
+      const double h = 1.0 - 0.5 * r * ((a - 1.0) / x - 1.0);
+      xn = x - (h > 0.5 ? r / h : r);
+    }
+    if (!(xn > lo && xn < hi)) xn = isinf(hi) ? 2.0 * x : (lo > 0.0 ? 0.5 * (lo + hi) : 0.5 * hi);
+    if (fabs(xn - x) <= 2.0 * EPS * xn) return xn;
+    x = xn;
+  }
+  return x;
+}
+PT_DEV double pt_gammaincinv(double a, double p) {
+  if (!(a > 0.0) || !(p >= 0.0 && p <= 1.0)) return __builtin_nan("");
+  if (p == 0.0) return 0.0;
+  if (p == 1.0) return __builtin_inf();
+  return p <= 0.5 ? pt_gamma_tail_root(a, p, false) : pt_gamma_tail_root(a, 1.0 - p, true);
+}
+PT_DEV double pt_gammainccinv(double a, double q) {
+  if (!(a > 0.0) || !(q >= 0.0 && q <= 1.0)) return __builtin_nan("");
+  if (q == 0.0) return __builtin_inf();
+  if (q == 1.0) return 0.0;
+  return q <= 0.5 ? pt_gamma_tail_root(a, q, true) : pt_gamma_tail_root(a, 1.0 - q, false);
+}
+PT_DEV float pt_gammaincinv(float a, float p) { return (float)pt_gammaincinv((double)a, (double)p); }
+PT_DEV float pt_gammainccinv(float a, float q) { return (float)pt_gammainccinv((double)a, (double)q); }
+"""
+
+_BETAINCINV_SRC = r"""
+// inverse of the regularised incomplete beta function (BetaIncInv.impl, scalar/math.py:
+// scipy.special.betaincinv): the root is sought on the half of (0, 1) it lies in (t = x or 1 - x,
+// decided by I_1/2), the residual is P - p or q - Q, whichever is known more precisely, and
+// safeguarded Halley steps run to the last bit of the forward function above
+PT_DEV double pt_betaincinv(double a, double b, double p) {
+  const double EPS = 2.220446049250313e-16;
+  if (!(a > 0.0 && b > 0.0) || !(p >= 0.0 && p <= 1.0)) return __builtin_nan("");
+  if (p == 0.0) return 0.0;
+  if (p == 1.0) return 1.0;
+  double q = 1.0 - p;
+  const bool flip = p > pt_betainc(a, b, 0.5);
+  if (flip) { double s = a; a = b; b = s; s = p; p = q; q = s; }
+  const double lbeta = lgamma(a) + lgamma(b) - lgamma(a + b);
+  double t = fmin(0.5, a / (a + b));
+  if (p <= 0.5) {
+    const double lt = (log(p) + log(a) + lbeta) / a;
+    if (lt < log(t)) t = fmax(exp(lt), 1e-300);
+  }
+  double lo = 0.0, hi = 1.0, res = t;
+  for (int it = 0; it < 300; it++) {
+    const double ld = (a - 1.0) * log(t) + (b - 1.0) * log1p(-t) - lbeta;
+    const double dens = exp(ld);
+    const double f = (p <= q + dens) ? pt_betainc(a, b, t) - p : q - pt_betainc(b, a, 1.0 - t);
+    if (f == 0.0) { res = t; break; }
+    if (f < 0.0) lo = fmax(lo, t); else hi = fmin(hi, t);
+    double tn = -1.0;
+    if (dens > 0.0 && !isinf(dens)) {
+      const double r = f / dens;
+      const double h = 1.0 - 0.5 * r * ((a - 1.0) / t - (b - 1.0) / (1.0 - t));
+      tn = t - (h > 0.5 ? r / h : r);
+    }
+    if (!(tn > lo && tn < hi)) {
+      tn = lo > 0.0 ? (hi > 4.0 * lo ? sqrt(lo * hi) : 0.5 * (lo + hi)) : 1e-3 * hi;
+      if (tn <= 0.0) { res = 0.0; break; }
+    }
+    res = tn;
+    if (fabs(tn - t) <= 2.0 * EPS * tn) break;
+    t = tn;
+  }
+  return flip ? 1.0 - res : res;
+}
+PT_DEV float pt_betaincinv(float a, float b, float p) { return (float)pt_betaincinv((double)a, (double)b, (double)p); }
+"""
+
+_OPTIONAL_HELPERS = {"GammaInc": ("gammainc",), "GammaIncC": ("gammainc",), "BetaInc": ("betainc",), "PolyGamma": ("polygamma",),
+                     "GammaIncInv": ("gammainc", "gammaincinv"), "GammaIncCInv": ("gammainc", "gammaincinv"),
+                     "BetaIncInv": ("betainc", "betaincinv")}
+_OPTIONAL_ORDER = ("gammainc", "betainc", "polygamma", "gammaincinv", "betaincinv")
 _optional_src_cache = {}
 
 
@@ -351,14 +545,15 @@ def _optional_src(key: str) -> str:
             logfs, loghs = _gamma_tables()
             _optional_src_cache[key] = _c_table("pt_g_logfs", logfs) + _c_table("pt_g_loghs", loghs) + _GAMMAINC_SRC
         else:
-            _optional_src_cache[key] = _BETAINC_SRC
+            _optional_src_cache[key] = {"betainc": _BETAINC_SRC, "polygamma": _POLYGAMMA_SRC, "gammaincinv": _GAMMAINCINV_SRC,
+                                        "betaincinv": _BETAINCINV_SRC}[key]
     return _optional_src_cache[key]
 
 
 def prelude_for(*bodies) -> str:
     """PRELUDE plus the long helpers only the given scalar bodies need."""
-    keys = sorted({_OPTIONAL_HELPERS[op] for b in bodies if b for op in body_ops(b) if op in _OPTIONAL_HELPERS})
-    return PRELUDE + "".join(_optional_src(k) for k in keys)
+    want = {k for b in bodies if b for op in body_ops(b) if op in _OPTIONAL_HELPERS for k in _OPTIONAL_HELPERS[op]}
+    return PRELUDE + "".join(_optional_src(k) for k in _OPTIONAL_ORDER if k in want)
 
 
 def body_ops(body: dict):
@@ -593,6 +788,10 @@ SCALAR_EXPR = {
     "GammaInc": _helper("pt_gammainc"),  # scalar/math.py:627
     "GammaIncC": _helper("pt_gammaincc"),  # scalar/math.py:674
     "BetaInc": _helper("pt_betainc"),  # scalar/math.py:1342
+    "PolyGamma": _helper("pt_polygamma"),  # scalar/math.py:595 (scipy.special.polygamma)
+    "GammaIncInv": _helper("pt_gammaincinv"),  # scipy.special.gammaincinv
+    "GammaIncCInv": _helper("pt_gammainccinv"),  # scipy.special.gammainccinv
+    "BetaIncInv": _helper("pt_betaincinv"),  # scipy.special.betaincinv
     # Bessel functions: J0/J1.c_code call libm's j0/j1 in double (scalar/math.py:1011-1064);
     # I0/I1 have no C code, the reference evaluates scipy.special.i0/i1 (1066-1110)
     "J0": lambda a, i, o: f"({CTYPE[o]})j0((double){a[0]})",

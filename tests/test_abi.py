@@ -49,3 +49,18 @@ def test_product_path_fails_loudly_without_gpu():
     exe = HipExecutable(g)
     with pytest.raises(ffi.HipError):
         exe(*ins)
+
+
+def test_optional_special_function_helpers_compile_without_gpu():
+    """the long scalar helpers (incomplete gamma / beta and their inverses, polygamma) are emitted only
+    into kernels that use them: each combination must pass hiprtc on its own"""
+    from pytensor_amd import codegen, ffi
+
+    for op, nin in (("PolyGamma", 2), ("GammaIncInv", 2), ("GammaIncCInv", 2), ("BetaIncInv", 3), ("GammaInc", 2), ("BetaInc", 3)):
+        body = {"in_dtypes": ["float64"] * nin, "out_dtypes": ["float64"],
+                "body": [{"op": op, "in": [["i", k] for k in range(nin)], "dtype": "float64"}], "outs": [["t", 0]]}
+        names = [f"v{k}" for k in range(nin)]
+        src = (codegen.prelude_for(body) + '\nextern "C" __global__ void probe(const double* a, double* o) {\n'
+               + "".join(f"  const double {nm} = a[{k}];\n" for k, nm in enumerate(names)) + "  double r;\n"
+               + codegen.emit_body(body, names, ["r"], indent="  ") + "\n  o[0] = r;\n}\n")
+        assert len(ffi.jit_compile(src, f"probe_{op}.hip")) > 1000, op
