@@ -1045,7 +1045,7 @@ def _random_variable(p, inputs, node, graph):
 
     gen, size, *params = inputs
     size = None if p["size_is_none"] else [int(v) for v in np.asarray(size).ravel()]
-    return list(philox_ref.draw(p["name"], gen, size, params, p["dtype"], p.get("ndims_params")))
+    return list(philox_ref.draw(p["name"], gen, size, params, p["dtype"], p.get("ndims_params"), p.get("method", "cholesky")))
 
 
 @op("Eigh")

@@ -369,7 +369,7 @@ def random_order(s: Stream, n, weights=None):
     return np.argsort(keys, kind="stable"), keys, n
 
 
-def draw(name, gen, size, params, dtype, ndims_params=None):
+def draw(name, gen, size, params, dtype, ndims_params=None, method="cholesky"):
     """(advanced generator, draws) — what the ``RandomVariable`` node of the hip linker returns"""
     key, ctr = generator_state(gen)
     s = Stream(key, ctr)
@@ -440,7 +440,15 @@ def draw(name, gen, size, params, dtype, ndims_params=None):
         lead = () if size is None else tuple(int(v) for v in size)
         rows = int(np.prod(lead)) if lead else 1
         z = np.array([box_muller(*s.block(i)[:2]) for i in range(rows * k)]).reshape(rows, k)
-        out = z @ np.linalg.cholesky(cov).T + mean
+        if method == "cholesky":
+            A = np.linalg.cholesky(cov)
+        elif method == "svd":  # (the signs of the columns are LAPACK's choice: only the distribution is pinned)
+            A, sv, _ = np.linalg.svd(cov)
+            A = A * np.sqrt(sv)[None, :]
+        else:
+            w, A = np.linalg.eigh(cov)
+            A = A * np.sqrt(w)[None, :]
+        out = z @ A.T + mean
         return make_generator(key, ctr + rows * k), out.reshape(*lead, k).astype(dtype)
     params = [np.asarray(p) for p in params]
     bshape = np.broadcast_shapes(*[p.shape for p in params]) if params else ()

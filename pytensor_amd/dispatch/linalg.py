@@ -164,7 +164,7 @@ def blockwise(node, inputs, env):
         from pytensor_amd.dispatch import lu
 
         return lu.pivot_to_permutations(type("_N", (), {"params": cp}), ins, env)
-    if p["core_op"] == "Eigh":
+    if p["core_op"] == "Eigh" and len(ins) == 1:  # (the generalised problem loops its items below)
         from pytensor_amd.dispatch import lu
 
         return lu.eigh(type("_N", (), {"params": cp}), ins, env)

@@ -162,10 +162,10 @@ def random_variable(node, inputs, env):
         return [rng.advanced(n), _normalise_rows(env, g, out_dtype)]
 
     if name == "multivariate_normal":
-        # MvNormalRV.rng_fn (random/basic.py:914-936, method="cholesky"): mean + L z, z ~ N(0, I)
+        # MvNormalRV.rng_fn (random/basic.py:914-936): mean + A z, z ~ N(0, I), A A^T = cov with A the
+        # Cholesky factor, U sqrt(s) (svd) or V sqrt(w) (eigh)
         mean, cov = devs
-        if p.get("method", "cholesky") != "cholesky":
-            raise NotImplementedError("hip linker: multivariate_normal is lowered for method='cholesky' only")
+        method = p.get("method", "cholesky")
         if mean.ndim != 1 or cov.ndim != 2:
             raise NotImplementedError("hip linker: multivariate_normal with batched mean / cov")
         from pytensor_amd.dispatch.blas import gemm_device
@@ -177,7 +177,23 @@ def random_variable(node, inputs, env):
         fdt = np.dtype(cov.dtype)
         zero, one = (env.to_device(HostValue(np.asarray(v, dtype=fdt))) for v in (0.0, 1.0))
         z = _draw(env, "normal", [zero, one], (rows, k), fdt, key_ptr, ctr_ptr)
-        L = cholesky_device(env, cov, True)
+        if method == "cholesky":
+            L = cholesky_device(env, cov, True)
+        else:
+            from pytensor_amd.dispatch.elemwise import launch_elemwise
+
+            if method == "svd":
+                from pytensor_amd.dispatch.decomp import svd_device
+
+                M, d, _ = svd_device(env, cov, True, True)
+            else:
+                from pytensor_amd.dispatch.lu import eigh as eigh_handler
+
+                d, M = eigh_handler(type("_N", (), {"params": {"lower": True}}), [cov], env)
+            dt = str(fdt)
+            body = {"in_dtypes": [dt, dt], "out_dtypes": [dt],
+                    "body": [{"op": "Sqrt", "in": [["i", 1]], "dtype": dt}, {"op": "Mul", "in": [["i", 0], ["t", 0]], "dtype": dt}], "outs": [["t", 1]]}
+            (L,), _, _ = launch_elemwise(body, [M, d.view((k, k), (0, d.strides[0]))], (k, k), [dt], None, env)
         m2 = mean if str(mean.dtype) == str(fdt) else _cast(env, mean, fdt)
         out = gemm_device(env, 1.0, z, L.view((k, k), (L.strides[1], L.strides[0])), 1.0, m2.view((1, k), (0, m2.strides[0])))
         out = out.view((*lead, k), contiguous_strides((*lead, k)))

@@ -505,8 +505,6 @@ def _(op, node, ctx):
     #  over the batch of single-item device calls — dispatch/linalg.py::_blockwise_loop)
     if core is None or core[0] in ("Scan", "Blockwise", "HostPerform"):
         return None
-    if core[0] == "Eigh" and len(node.inputs) != 1:
-        return None  # (batched generalised problem: not lowered)
     name, params = core
     return "Blockwise", {"core_op": name, "core_params": params, "signature": op.signature}
 
@@ -604,13 +602,13 @@ def _(op, node, ctx):
     name = str(op.name)
     if name not in DISTRIBUTIONS and name not in STRUCTURED:
         return None
-    if name == "multivariate_normal" and getattr(op, "method", "cholesky") != "cholesky":
-        return None
     params = {
         "name": name,
         "dtype": str(node.outputs[1].type.dtype),
         "size_is_none": isinstance(node.inputs[1].type, NoneTypeT),
     }
+    if name == "multivariate_normal":
+        params["method"] = str(getattr(op, "method", "cholesky"))
     if name in ("permutation", "choice_without_replacement"):
         # rng.permutation / rng.choice have no batch dimensions (the reference loops over them on the host)
         core = int(op.ndims_params[0])

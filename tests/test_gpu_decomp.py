@@ -205,6 +205,19 @@ def test_blockwise_batches_and_small_ops(hip):
                  [("float64", 4)], [("float64", 3)])
     (s,) = HipExecutable(g)(x)
     np.testing.assert_allclose(s, np.linalg.svd(x, compute_uv=False), rtol=1e-12)
+    # the generalised symmetric problem over a batch (Blockwise loops the items)
+    Ab = rng.normal(size=(3, 7, 7))
+    Ab = Ab + Ab.transpose(0, 2, 1)
+    Qb = rng.normal(size=(3, 7, 7))
+    Bb = Qb @ Qb.transpose(0, 2, 1) / 7 + np.eye(7)
+    g = one_node("Blockwise", {"core_op": "Eigh", "core_params": {"lower": True}, "signature": "(m,m),(m,m)->(m),(m,m)"},
+                 [("float64", 3), ("float64", 3)], [("float64", 2), ("float64", 3)])
+    w, v = HipExecutable(g)(Ab, Bb)
+    import scipy.linalg
+
+    for k in range(3):
+        np.testing.assert_allclose(w[k], scipy.linalg.eigh(Ab[k], Bb[k], eigvals_only=True), rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(Ab[k] @ v[k], Bb[k] @ v[k] * w[k], atol=1e-11)
     # Eigvalsh / TensorInv / TensorSolve / BlockDiagonal against the oracle restatement
     M = rng.normal(size=(14, 14))
     for g, vals in [

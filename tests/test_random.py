@@ -423,6 +423,24 @@ def test_device_dirichlet_and_multivariate_normal(hip):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("method", ["svd", "eigh"])
+def test_device_multivariate_normal_svd_and_eigh_factors(hip, method):
+    """MvNormalRV(method=...) (random/basic.py:918-926): A = U sqrt(s) or V sqrt(w) instead of the Cholesky
+    factor — the column signs are the decomposition's own, so the draws are pinned through their moments"""
+    from pytensor_amd.executor import HipExecutable
+
+    _, mean, cov = _mv_cases()
+    g = rv_graph("multivariate_normal", "float64", (40000,), [("float64", 1), ("float64", 2)])
+    g.nodes[0].params["method"] = method
+    _, x = HipExecutable(g)(gen(4), mean, cov)
+    assert x.shape == (40000, 4)
+    assert np.abs(x.mean(axis=0) - mean).max() < 5 * np.sqrt(np.diag(cov).max() / 40000)
+    assert np.abs(np.cov(x.T) - cov).max() < 0.05 * np.abs(cov).max()
+    _, y = np_graph.run_graph(g, [gen(4), mean, cov])  # the restatement with NumPy's factor: same law
+    assert np.abs(np.cov(y.T) - cov).max() < 0.05 * np.abs(cov).max()
+
+
+@pytest.mark.gpu
 def test_device_large_uniform_and_normal_moments(hip):
     from pytensor_amd.executor import HipExecutable
 
