@@ -314,3 +314,21 @@ def special_inverse_polygamma():
     vals = {"x": np.concatenate([rng.uniform(0.05, 30.0, size=m - 8), -rng.uniform(0.1, 4.9, size=8)]), "n": rng.integers(0, 6, size=m),
             "a": 10 ** rng.uniform(-1, 2.5, size=m), "b": 10 ** rng.uniform(-1, 2.5, size=m), "p": rng.uniform(0.001, 0.999, size=m)}
     return [x, a, b, p, n], outs, vals
+
+
+@case("sylvester_lyapunov", rtol=1e-10)
+def sylvester_lyapunov():
+    # linalg/solvers/linear_control.py: solve_sylvester 123 (Schur + TRSYL in the reference), the continuous
+    # Lyapunov equation 167, the discrete one by the bilinear transform 197 and directly (kron + solve),
+    # and the gradient of a Sylvester solve (another Sylvester solve, 100-115)
+    rng = np.random.default_rng(91)
+    A, B, C = pt.dmatrix("A"), pt.dmatrix("B"), pt.dmatrix("C")
+    S, Q = pt.dmatrix("S"), pt.dmatrix("Q")
+    X = pt.linalg.solve_sylvester(A, B, C)
+    outs = [X, pt.linalg.solve_continuous_lyapunov(S, Q), pt.linalg.solve_discrete_lyapunov(S * 0.2, Q, method="bilinear"),
+            pt.linalg.solve_discrete_lyapunov(S * 0.2, Q, method="direct"), *pytensor.grad((X**2).sum(), [A, C])]
+    m, n = 7, 5
+    Qv = rng.normal(size=(6, 6))
+    vals = {"A": rng.normal(size=(m, m)) + 3.0 * np.eye(m), "B": rng.normal(size=(n, n)) + 3.0 * np.eye(n), "C": rng.normal(size=(m, n)),
+            "S": rng.normal(size=(6, 6)) - 3.0 * np.eye(6), "Q": Qv @ Qv.T}
+    return [A, B, C, S, Q], outs, vals

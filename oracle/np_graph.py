@@ -1203,6 +1203,13 @@ def _permute_row_elements(p, inputs, node, graph):
     return [out]
 
 
+@op("SolveSylvester")
+def _solve_sylvester(p, inputs, node, graph):
+    # pytensor/tensor/linalg/solvers/linear_control.py:117-165: A X + X B = C through real Schur forms and
+    # trsyl — what scipy.linalg.solve_sylvester does
+    return [scipy.linalg.solve_sylvester(*inputs)]
+
+
 @op("Expm")
 def _expm(p, inputs, node, graph):
     # pytensor/tensor/linalg/products.py:35-38 (Expm.perform): scipy.linalg.expm

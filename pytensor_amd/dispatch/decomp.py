@@ -420,3 +420,38 @@ def _ew1(env, body_ops, ins, in_dtypes, out_dtype, shape):
     body = {"in_dtypes": list(in_dtypes), "out_dtypes": [out_dtype], "body": body_ops, "outs": [["t", len(body_ops) - 1]]}
     (out,), _, _ = launch_elemwise(body, ins, tuple(shape), [out_dtype], None, env)
     return out
+
+
+# ---- Sylvester equation -----------------------------------------------------------------------------
+MAX_SYLVESTER = 4096  # m * n: the Kronecker system is (m n) x (m n)
+
+
+@handler("SolveSylvester")
+def solve_sylvester(node, inputs, env):
+    """``A X + X B = C`` (linalg/solvers/linear_control.py:117 ``SolveSylvester``; the reference builds
+    it from real Schur forms and LAPACK ``trsyl``).  Here the equation is solved as the linear system it
+    is: (A (x) I_n + I_m (x) B^T) vec(X) = vec(C) with row-major vec, assembled by one generated kernel
+    and handed to the LU solver — O((m n)^3), for the m n <= 4096 of state-space models; the unique
+    solution whenever the spectra of A and -B are disjoint, like Bartels-Stewart's."""
+    from pytensor_amd.dispatch.lu import solve_general
+
+    A, B, Cm = _same_float(env, inputs, "SolveSylvester")
+    m, n = A.shape[0], B.shape[0]
+    if A.shape != (m, m) or B.shape != (n, n) or Cm.shape != (m, n):
+        raise ValueError(f"SolveSylvester: incompatible shapes {A.shape}, {B.shape}, {Cm.shape}")
+    if m * n == 0:
+        return [DeviceArray.empty((m, n), A.dtype)]
+    if m * n > MAX_SYLVESTER:
+        raise NotImplementedError(f"hip linker: SolveSylvester with m*n = {m * n} (Kronecker tier, up to {MAX_SYLVESTER})")
+    dt = str(A.dtype)
+    eye = lambda k: env.to_device(HostValue(np.eye(k, dtype=A.dtype)))
+    Im, In = eye(m), eye(n)
+    shape = (m, n, m, n)  # K[(i, j), (k, l)] = A[i, k] d_jl + d_ik B[l, j]
+    ops = [{"op": "Mul", "in": [["i", 0], ["i", 1]], "dtype": dt}, {"op": "Mul", "in": [["i", 2], ["i", 3]], "dtype": dt},
+           {"op": "Add", "in": [["t", 0], ["t", 1]], "dtype": dt}]
+    K = _ew1(env, ops, [A.view(shape, (A.strides[0], 0, A.strides[1], 0)), In.view(shape, (0, In.strides[0], 0, In.strides[1])),
+                        Im.view(shape, (Im.strides[0], 0, Im.strides[1], 0)), B.view(shape, (0, B.strides[1], 0, B.strides[0]))],
+             [dt] * 4, dt, shape)
+    mn = m * n
+    x = solve_general(env, K.view((mn, mn), (mn, 1)), _reshape(Cm, (mn,)), 1)
+    return [x.view((m, n), (n, 1))]

@@ -717,6 +717,12 @@ _register_ifelse()
 
 def _register_ofg():
     from pytensor.compile.builders import OpFromGraph
+    from pytensor.tensor.linalg.solvers.linear_control import SolveSylvester
+
+    @hip_funcify.register(SolveSylvester)
+    def _(op, node, ctx):
+        # (its inner graph is Schur + TRSYL, which have no lowering: the equation is solved directly)
+        return "SolveSylvester", {}
 
     @hip_funcify.register(OpFromGraph)
     def _(op, node, ctx):
