@@ -139,6 +139,37 @@ def test_every_random_variable_of_the_reference_lowers(pt):
         pytensor.function([x3], rb.PermutationRV(signature="(x)->(x)", dtype="float64")(x3[0], rng=rng, size=(2,), return_next_rng=True)[1], mode="hip")
 
 
+def test_library_functions_lower_whole_and_match_the_c_linker(pt):
+    """pt.einsum / pad / interpolate / the linalg helpers are graphs of Ops (or OpFromGraphs): they must
+    come through the hip linker without a host node, and the lowered graph — run by the oracle — must
+    reproduce the reference's C linker."""
+    pytensor, ptt = pt
+    import np_graph
+    from pytensor.tensor.interpolate import interp
+
+    x, y, v, t3 = ptt.dmatrix("x"), ptt.dmatrix("y"), ptt.dvector("v"), ptt.dtensor3("t3")
+    L = ptt.linalg
+    outs = [
+        ptt.einsum("ij,jk->ik", x, y), ptt.einsum("bij,jk->bik", t3, y), ptt.einsum("ij,ij->", x, x),
+        ptt.pad(x, ((1, 2), (0, 3)), mode="constant", constant_values=2.0), ptt.pad(x, 2, mode="edge"), ptt.pad(x, 1, mode="reflect"),
+        ptt.pad(x, 1, mode="wrap"), ptt.pad(x, 1, mode="mean"), interp(v, ptt.as_tensor(np.linspace(0, 1, 7)), ptt.as_tensor(np.linspace(0, 1, 7) ** 2)),
+        ptt.tril(x), ptt.diff(v), ptt.roll(x, 2, axis=1), ptt.median(v), ptt.logsumexp(x, axis=1), ptt.bincount(ptt.cast(ptt.abs(v) * 3, "int64")),
+        ptt.tile(v, (2, 3)), ptt.tensordot(x, y, axes=[[1], [0]]), ptt.ptp(x, axis=0), ptt.searchsorted(ptt.sort(v), v), ptt.unique(ptt.round(v)),
+        ptt.repeat(v, 2), L.kron(x[:2, :2], y[:2, :2]), L.norm(x), L.matrix_power(x, 3), L.pinv(y), L.svd(y)[1], L.qr(y)[1], L.lstsq(y, v[:5], -1.0)[0],
+        L.slogdet(x)[1], L.block_diag(x, y), L.lu_solve(L.lu_factor(x), v[:5]), L.expm(x * 0.1), L.solve_continuous_lyapunov(x - 4 * ptt.eye(5), x @ x.T),
+    ]
+    rng = np.random.default_rng(0)
+    vals = {"x": rng.normal(size=(5, 5)), "y": rng.normal(size=(5, 4)), "v": rng.normal(size=6), "t3": rng.normal(size=(2, 3, 5))}
+    ins = [x, y, v, t3]
+    f = pytensor.function(ins, outs, mode="hip", on_unused_input="ignore")
+    g = f.maker.linker.last_ir
+    assert not [n.params.get("name") for n in g.nodes if n.op == "HostPerform"]
+    want = pytensor.function(ins, outs, mode="CVM", on_unused_input="ignore")(*[vals[i.name] for i in ins])
+    got = np_graph.run_graph(g, [vals[i.name] for i in f.maker.fgraph.inputs])
+    for k, (a, b) in enumerate(zip(got, want)):
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-11, err_msg=f"output {k}")
+
+
 def test_op_coverage_of_the_registry(pt):
     """Every ``Op`` class of pytensor.tensor (+ ifelse, scan, compile.ops, raise_op) either has a
     ``hip_funcify`` registration or is on this list with the reason it has none."""
