@@ -408,3 +408,32 @@ def test_profile_flag_reports_device_time(pt):
     for _ in range(4):
         f(np.ones(10_000))
     assert f.profile.fct_callcount >= 3 and f.profile.vm_call_time > 0
+
+
+def test_library_functions_end_to_end(pt):
+    """einsum / pad / interpolate / the linalg helper functions / signal / fft, compiled by the real
+    ``pytensor.function(mode="hip")`` and run on the MI355X next to the C linker.  atol: eps-level
+    multiples of the largest entry for outputs that are differences of O(1) numbers (padding means,
+    decompositions); the integer-valued ones are bit-exact."""
+    pytensor, ptt = pt
+    from pytensor.tensor.fft import irfft, rfft
+    from pytensor.tensor.interpolate import interp
+    from pytensor.tensor.signal import convolve1d
+
+    x, y, v, t3 = ptt.dmatrix("x"), ptt.dmatrix("y"), ptt.dvector("v"), ptt.dtensor3("t3")
+    L = ptt.linalg
+    outs = [
+        ptt.einsum("ij,jk->ik", x, y), ptt.einsum("bij,jk->bik", t3, y), ptt.einsum("ij,ij->", x, x),
+        ptt.pad(x, ((1, 2), (0, 3)), mode="constant", constant_values=2.0), ptt.pad(x, 2, mode="edge"), ptt.pad(x, 1, mode="reflect"),
+        ptt.pad(x, 1, mode="wrap"), ptt.pad(x, 1, mode="mean"), interp(v, ptt.as_tensor(np.linspace(0, 1, 7)), ptt.as_tensor(np.linspace(0, 1, 7) ** 2)),
+        ptt.tril(x), ptt.diff(v), ptt.roll(x, 2, axis=1), ptt.median(v), ptt.logsumexp(x, axis=1), ptt.bincount(ptt.cast(ptt.abs(v) * 3, "int64")),
+        ptt.tile(v, (2, 3)), ptt.tensordot(x, y, axes=[[1], [0]]), ptt.ptp(x, axis=0), ptt.searchsorted(ptt.sort(v), v), ptt.unique(ptt.round(v)),
+        ptt.repeat(v, 2), L.kron(x[:2, :2], y[:2, :2]), L.norm(x), L.matrix_power(x, 3), L.pinv(y), L.svd(y)[1], L.qr(y)[1], L.lstsq(y, v[:5], -1.0)[0],
+        L.slogdet(x)[1], L.block_diag(x, y), L.lu_solve(L.lu_factor(x), v[:5]), L.expm(x * 0.1), L.solve_continuous_lyapunov(x - 4 * ptt.eye(5), x @ x.T),
+        convolve1d(v, v[:3], mode="full"), rfft(x), irfft(rfft(x), is_odd=True),
+    ]
+    rng = np.random.default_rng(0)
+    vals = [rng.normal(size=(5, 5)), rng.normal(size=(5, 4)), rng.normal(size=6), rng.normal(size=(2, 3, 5))]
+    f, _ = compare_hip_and_cvm([x, y, v, t3], outs, vals, rtol=1e-11, atol=2e-13, calls=2, on_unused_input="ignore")
+    ops = [n.op for n in f.maker.linker.last_ir.nodes]
+    assert "HostPerform" not in ops and {"SVD", "QR", "Expm", "SolveSylvester", "RFFTOp", "IRFFTOp", "Unique", "SearchsortedOp"} <= set(ops), sorted(set(ops))
