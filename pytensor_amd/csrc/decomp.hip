@@ -57,19 +57,23 @@ __device__ void apply_reflector(T* __restrict__ M, long long ld, int r0, int m, 
   for (int cc = c0; cc < c1; cc += 64) {
     const int col = cc + tx;
     T acc = T(0);
-    if (col < c1)
-      for (int i = ty; i < len; i += 4) {
+    if (col < c1) {
+#pragma unroll 8
+      for (int i = ty; i < len; i += 4) {  // (unrolled: the row loads of eight steps are in flight together)
         const T vi = staged ? s_v[i] : (i == 0 ? T(1) : V[(long long)(r0 + i) * ldv + vc]);
         acc += vi * M[(long long)(r0 + i) * ld + col];
       }
+    }
     s_w[ty * 64 + tx] = acc;
     __syncthreads();
     const T w = tau * (s_w[tx] + s_w[64 + tx] + s_w[128 + tx] + s_w[192 + tx]);
-    if (col < c1)
+    if (col < c1) {
+#pragma unroll 8
       for (int i = ty; i < len; i += 4) {
         const T vi = staged ? s_v[i] : (i == 0 ? T(1) : V[(long long)(r0 + i) * ldv + vc]);
         M[(long long)(r0 + i) * ld + col] -= vi * w;
       }
+    }
     __syncthreads();
   }
 }
@@ -128,8 +132,10 @@ __global__ __launch_bounds__(BLOCK) void orgqr_kernel(const T* __restrict__ QRal
 // ---- one-sided Jacobi SVD on the rows of X (r x c, r <= c) ------------------------------------
 // X = P diag(s) Wt: rotations from the left orthogonalise the rows (Hestenes), Pt accumulates them.
 // Parallel order: round-robin tournament, one wave per pair, a barrier per round.
+constexpr int SVD_BLOCK = 1024;  // 16 waves: a round of the tournament has r/2 independent pairs, each a chain of L2 round trips
+
 template <class T>
-__global__ __launch_bounds__(BLOCK) void svd_rows_kernel(T* __restrict__ Xall, T* __restrict__ Ptall, T* __restrict__ Sall,
+__global__ __launch_bounds__(SVD_BLOCK) void svd_rows_kernel(T* __restrict__ Xall, T* __restrict__ Ptall, T* __restrict__ Sall,
                                                         T* __restrict__ Wtall, T* __restrict__ Poutall, int r, int c,
                                                         int want_vectors, int* __restrict__ status) {
   __shared__ int s_rot;
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(BLOCK) void svd_rows_kernel(T* __restrict__ Xall, T
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const T eps = sizeof(T) == 8 ? T(2.220446049250313e-16) : T(1.1920929e-07);
   if (want_vectors) {
-    for (long long e = tid; e < (long long)r * r; e += BLOCK) Pt[e] = (e / r == e % r) ? T(1) : T(0);
+    for (long long e = tid; e < (long long)r * r; e += SVD_BLOCK) Pt[e] = (e / r == e % r) ? T(1) : T(0);
   }
   __syncthreads();
   const int R = (r + 1) & ~1;  // players (one bye when r is odd)
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(BLOCK) void svd_rows_kernel(T* __restrict__ Xall, T
     if (tid == 0) s_rot = 0;
     __syncthreads();
     for (int step = 0; step < R - 1; step++) {
-      for (int idx = wid; idx < R / 2; idx += BLOCK / 64) {
+      for (int idx = wid; idx < R / 2; idx += SVD_BLOCK / 64) {
         int p, q;
         if (idx == 0) { p = R - 1; q = step; }
         else { p = (step + idx) % (R - 1); q = (step - idx + (R - 1)) % (R - 1); }
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(BLOCK) void svd_rows_kernel(T* __restrict__ Xall, T
   }
   if (!converged && tid == 0 && status) atomicOr(status, 4);
   // singular values = row norms; rank them descending (ties by position)
-  for (int i = wid; i < r; i += BLOCK / 64) {
+  for (int i = wid; i < r; i += SVD_BLOCK / 64) {
     T a = T(0);
     for (int j = lane; j < c; j += 64) { const T u = X[(long long)i * c + j]; a += u * u; }
     a = wave_sum(a);
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(BLOCK) void svd_rows_kernel(T* __restrict__ Xall, T
   T* S = Sall + (long long)blockIdx.x * r;
   T* Wt = Wtall + (long long)blockIdx.x * r * c;
   T* Pout = Poutall + (long long)blockIdx.x * r * r;
-  for (int i = wid; i < r; i += BLOCK / 64) {
+  for (int i = wid; i < r; i += SVD_BLOCK / 64) {
     const T si = s_norm[i];
     int rank = 0;
     for (int j = lane; j < r; j += 64) rank += (s_norm[j] > si || (s_norm[j] == si && j < i)) ? 1 : 0;
@@ -326,7 +332,7 @@ template <class T> int orgqr_typed(long long batch, int m, int nc, int k, const 
 }
 
 template <class T> int svd_typed(long long batch, int r, int c, int vectors, void* X, void* Pt, void* S, void* Wt, void* Pout) {
-  PTHIP_KLAUNCH(svd_rows_kernel<T>, dim3((unsigned)batch), dim3(BLOCK), 0, pthip::ctx().stream, (T*)X, (T*)Pt, (T*)S, (T*)Wt,
+  PTHIP_KLAUNCH(svd_rows_kernel<T>, dim3((unsigned)batch), dim3(SVD_BLOCK), 0, pthip::ctx().stream, (T*)X, (T*)Pt, (T*)S, (T*)Wt,
                 (T*)Pout, r, c, vectors, pthip::ctx().status_dev);
   return pthip::post_launch("svd_rows");
 }

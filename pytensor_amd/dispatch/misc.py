@@ -263,11 +263,16 @@ def unique(node, inputs, env):
         raise NotImplementedError("hip linker: Unique of a bool array")
     ffi.check(env.lib.pthip_sort(ffi.np_dtype_code(x.dtype), 1, n, flat.ptr, vals.ptr, order.ptr))
     dt = str(x.dtype)
-    # first[i] = i == 0 or vals[i] != vals[i-1]  (np.unique: NaNs are all different unless equal_nan... old numpy: each NaN unique)
+    # first[i] = i == 0 or vals[i] differs from vals[i-1]
     first = DeviceArray.empty((n,), "bool")
     ffi.check(env.lib.pthip_memset(first.ptr, 1, 1))
     if n > 1:
-        neq = _ew(env, [{"op": "NEQ", "in": [["i", 0], ["i", 1]], "dtype": "bool"}], [vals.view((n - 1,), (1,), 1), vals.view((n - 1,), (1,))], [dt, dt], "bool", (n - 1,))
+        ops = [{"op": "NEQ", "in": [["i", 0], ["i", 1]], "dtype": "bool"}]
+        if x.dtype.kind == "f":  # np.unique(equal_nan=True): the NaNs (sorted last) are one value
+            ops += [{"op": "IsNan", "in": [["i", 0]], "dtype": "bool"}, {"op": "IsNan", "in": [["i", 1]], "dtype": "bool"},
+                    {"op": "AND", "in": [["t", 1], ["t", 2]], "dtype": "bool"}, {"op": "Invert", "in": [["t", 3]], "dtype": "bool"},
+                    {"op": "AND", "in": [["t", 0], ["t", 4]], "dtype": "bool"}]
+        neq = _ew(env, ops, [vals.view((n - 1,), (1,), 1), vals.view((n - 1,), (1,))], [dt, dt], "bool", (n - 1,))
         copy_into(first.view((n - 1,), (1,), 1), neq)
     starts = nonzero_flat(env, first)  # positions (in sorted order) where a new value starts
     k = starts.size

@@ -65,7 +65,9 @@ def test_searchsorted_dtypes_nan_and_empty(hip):
 
 def test_unique_repeat_ravel(hip):
     rng = np.random.default_rng(1)
-    for x in (rng.integers(0, 50, size=5000), np.round(rng.normal(size=(30, 40)), 1), np.array([3.0]), np.zeros(0), rng.integers(0, 3, size=7).astype("int8")):
+    with_nan = np.round(rng.normal(size=60), 1)
+    with_nan[[3, 17, 40]] = np.nan  # np.unique(equal_nan=True): one NaN in the result, counted three times
+    for x in (rng.integers(0, 50, size=5000), np.round(rng.normal(size=(30, 40)), 1), np.array([3.0]), np.zeros(0), rng.integers(0, 3, size=7).astype("int8"), with_nan):
         dt, nd = str(x.dtype), x.ndim
         check(one_node("Unique", {"return_index": True, "return_inverse": True, "return_counts": True, "axis": None},
                        [(dt, nd)], [(dt, 1), ("int64", 1), ("int64", 1), ("int64", 1)]), x)
