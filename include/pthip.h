@@ -228,7 +228,7 @@ int pthip_getrf(int dtype, int64_t batch, int64_t n, const void* A, void* LU, vo
 /* Eigh.perform (pytensor/tensor/linalg/decomposition/eigen.py:177-195, scipy.linalg.eigh of the
  * standard problem): batch x (n, n) symmetric matrices of which only the lower (or upper)
  * triangle is read -> eigenvalues W (batch, n) ascending and eigenvectors as the columns of V
- * (batch, n, n).  Parallel cyclic Jacobi; no convergence raises bit 1 of the device error word
+ * (batch, n, n).  Parallel cyclic Jacobi; no convergence raises bit 3 of the device error word
  * (scipy: LinAlgError).  n <= 512. */
 int pthip_eigh(int dtype, int64_t batch, int64_t n, int lower, const void* A, void* W, void* V);
 /* ARange.perform (pytensor/tensor/basic.py: np.arange(start, stop, step, dtype)) for a length n

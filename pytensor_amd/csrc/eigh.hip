@@ -150,7 +150,7 @@ __global__ __launch_bounds__(BLOCK) void eigh_jacobi_kernel(const T* __restrict_
     converged = rot == 0;
     __syncthreads();
   }
-  if (!converged && tid == 0 && status != nullptr) atomicOr(status, 2);
+  if (!converged && tid == 0 && status != nullptr) atomicOr(status, 8);  // bit 3: LinAlgError("Eigenvalues did not converge")
 
   // ascending order: rank of each eigenvalue (ties by index), then the permuted write
   T* Wg = Wout + mat * (long long)n;

@@ -238,12 +238,14 @@ def branch_guards(g):
 def raise_device_status(word: int):
     """The device error word (kernels cannot raise): bit 0 = an index was out of range
     (IndexError, like the reference's take/inc_subtensor), bit 1 = np.linalg.inv met an exactly
-    singular matrix (LinAlgError), bit 2 = the Jacobi SVD did not converge (LinAlgError, the message
-    of np.linalg.svd)."""
+    singular matrix (LinAlgError), bit 2 / bit 3 = the Jacobi SVD / eigensolver did not converge
+    (LinAlgError, the messages of np.linalg.svd / eigh)."""
     if word & 2:
         raise np.linalg.LinAlgError("Singular matrix")
     if word & 4:
         raise np.linalg.LinAlgError("SVD did not converge")
+    if word & 8:
+        raise np.linalg.LinAlgError("Eigenvalues did not converge")
     if word & 1:
         raise IndexError("index out of bounds (device-side check)")
 

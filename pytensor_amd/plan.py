@@ -91,8 +91,13 @@ class _ResultRing:
         if self.free:
             return self.free.pop()
         if self.made < self.limit:
+            try:
+                blk = _PinnedBlock(self.specs)
+            except ffi.HipError:  # no more pinnable memory: this ring stays at its current size
+                self.limit = self.made
+                return None
             self.made += 1
-            return _PinnedBlock(self.specs)
+            return blk
         return None
 
     def hand_out(self, blk):
@@ -442,7 +447,9 @@ class FrozenPlan:
                 ffi.check(lib.pthip_d2h(self._out_block.ptr, self._dev_out.ptr, self._out_block.nbytes))
                 ffi.check(lib.pthip_synchronize())
             if self._ring is not None:
-                self._ring.free.append(self._ring.take())  # the first call's block (pinning memory is slow)
+                first = self._ring.take()  # the first call's block (pinning memory is slow)
+                if first is not None:
+                    self._ring.free.append(first)
 
     # ------------------------------------------------------------------
     def _replay(self, sync, out_block=None):
