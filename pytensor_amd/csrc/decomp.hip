@@ -132,6 +132,7 @@ __global__ __launch_bounds__(BLOCK) void orgqr_kernel(const T* __restrict__ QRal
 // ---- one-sided Jacobi SVD on the rows of X (r x c, r <= c) ------------------------------------
 // X = P diag(s) Wt: rotations from the left orthogonalise the rows (Hestenes), Pt accumulates them.
 // Parallel order: round-robin tournament, one wave per pair, a barrier per round.
+constexpr int SVD_CACHE = 4;      // row values per lane kept in registers (rows up to 256 long)
 constexpr int SVD_BLOCK = 1024;  // 16 waves: a round of the tournament has r/2 independent pairs, each a chain of L2 round trips
 
 template <class T>
@@ -162,6 +163,37 @@ __global__ __launch_bounds__(SVD_BLOCK) void svd_rows_kernel(T* __restrict__ Xal
         if (p > q) { const int t = p; p = q; q = t; }
         T* xp = X + (long long)p * c;
         T* xq = X + (long long)q * c;
+        T* pp = Pt + (long long)p * r;
+        T* pq = Pt + (long long)q * r;
+        if (c <= 64 * SVD_CACHE) {
+          // short rows: one trip to memory per pair — both rows of X and of Pt are requested up front
+          // and stay in registers through the dot products and the rotation
+          T xu[SVD_CACHE], xv[SVD_CACHE], pu[SVD_CACHE], pv[SVD_CACHE];
+#pragma unroll
+          for (int t = 0; t < SVD_CACHE; t++) {
+            const int j = lane + 64 * t;
+            xu[t] = j < c ? xp[j] : T(0);
+            xv[t] = j < c ? xq[j] : T(0);
+            pu[t] = (want_vectors && j < r) ? pp[j] : T(0);
+            pv[t] = (want_vectors && j < r) ? pq[j] : T(0);
+          }
+          T a = T(0), b = T(0), g = T(0);
+#pragma unroll
+          for (int t = 0; t < SVD_CACHE; t++) { a += xu[t] * xu[t]; b += xv[t] * xv[t]; g += xu[t] * xv[t]; }
+          a = wave_sum(a); b = wave_sum(b); g = wave_sum(g);
+          if (g == T(0) || dabs(g) <= eps * sqrt(a) * sqrt(b)) continue;
+          const T zeta = (b - a) / (T(2) * g);
+          const T tt = (zeta >= T(0) ? T(1) : T(-1)) / (dabs(zeta) + sqrt(T(1) + zeta * zeta));
+          const T cs = T(1) / sqrt(T(1) + tt * tt), sn = cs * tt;
+#pragma unroll
+          for (int t = 0; t < SVD_CACHE; t++) {
+            const int j = lane + 64 * t;
+            if (j < c) { xp[j] = cs * xu[t] - sn * xv[t]; xq[j] = sn * xu[t] + cs * xv[t]; }
+            if (want_vectors && j < r) { pp[j] = cs * pu[t] - sn * pv[t]; pq[j] = sn * pu[t] + cs * pv[t]; }
+          }
+          if (lane == 0) s_rot = 1;
+          continue;
+        }
         T a = T(0), b = T(0), g = T(0);
         for (int j = lane; j < c; j += 64) {
           const T u = xp[j], v = xq[j];
@@ -178,8 +210,6 @@ __global__ __launch_bounds__(SVD_BLOCK) void svd_rows_kernel(T* __restrict__ Xal
           xq[j] = sn * u + cs * v;
         }
         if (want_vectors) {
-          T* pp = Pt + (long long)p * r;
-          T* pq = Pt + (long long)q * r;
           for (int j = lane; j < r; j += 64) {
             const T u = pp[j], v = pq[j];
             pp[j] = cs * u - sn * v;
