@@ -436,9 +436,10 @@ def draw(name, gen, size, params, dtype, ndims_params=None, method="cholesky"):
         return make_generator(key, ctr + g.size), (g / g.sum(axis=-1, keepdims=True)).astype(dtype)
     if name == "multivariate_normal":
         mean, cov = (np.asarray(p, dtype=np.float64) for p in params)
-        k = mean.shape[0]
-        lead = () if size is None else tuple(int(v) for v in size)
+        k = mean.shape[-1]
+        lead = tuple(mean.shape[:-1]) if size is None else tuple(int(v) for v in size)
         rows = int(np.prod(lead)) if lead else 1
+        mean = np.broadcast_to(mean, (*lead, k)).reshape(rows, k)
         z = np.array([box_muller(*s.block(i)[:2]) for i in range(rows * k)]).reshape(rows, k)
         if method == "cholesky":
             A = np.linalg.cholesky(cov)

@@ -166,13 +166,15 @@ def random_variable(node, inputs, env):
         # Cholesky factor, U sqrt(s) (svd) or V sqrt(w) (eigh)
         mean, cov = devs
         method = p.get("method", "cholesky")
-        if mean.ndim != 1 or cov.ndim != 2:
-            raise NotImplementedError("hip linker: multivariate_normal with batched mean / cov")
+        if cov.ndim != 2 or mean.ndim < 1:
+            raise NotImplementedError("hip linker: multivariate_normal with a batched covariance")
         from pytensor_amd.dispatch.blas import gemm_device
         from pytensor_amd.dispatch.linalg import cholesky_device
 
-        k = mean.shape[0]
-        lead = () if size is None else size
+        k = mean.shape[-1]
+        lead = tuple(mean.shape[:-1]) if size is None else size  # rng_fn 915-916: batch shape of the parameters
+        if np.broadcast_shapes(tuple(mean.shape[:-1]), lead) != tuple(lead):
+            raise ValueError(f"multivariate_normal: size {lead} does not match the batch shape of mean {tuple(mean.shape[:-1])}")
         rows = int(np.prod(lead)) if lead else 1
         fdt = np.dtype(cov.dtype)
         zero, one = (env.to_device(HostValue(np.asarray(v, dtype=fdt))) for v in (0.0, 1.0))
@@ -195,7 +197,14 @@ def random_variable(node, inputs, env):
                     "body": [{"op": "Sqrt", "in": [["i", 1]], "dtype": dt}, {"op": "Mul", "in": [["i", 0], ["t", 0]], "dtype": dt}], "outs": [["t", 1]]}
             (L,), _, _ = launch_elemwise(body, [M, d.view((k, k), (0, d.strides[0]))], (k, k), [dt], None, env)
         m2 = mean if str(mean.dtype) == str(fdt) else _cast(env, mean, fdt)
-        out = gemm_device(env, 1.0, z, L.view((k, k), (L.strides[1], L.strides[0])), 1.0, m2.view((1, k), (0, m2.strides[0])))
+        if m2.ndim == 1:
+            mrows = m2.view((1, k), (0, m2.strides[0]))
+        else:  # a mean per draw: broadcast to the batch shape, one row each
+            full = DeviceArray.empty((*lead, k), fdt)
+            lead_pad = len(lead) + 1 - m2.ndim
+            copy_into(full, m2.view((*lead, k), (0,) * lead_pad + tuple(0 if (sdim == 1 and t != 1) else st for sdim, st, t in zip(m2.shape, m2.strides, (*lead, k)[lead_pad:]))))
+            mrows = full.view((rows, k), (k, 1))
+        out = gemm_device(env, 1.0, z, L.view((k, k), (L.strides[1], L.strides[0])), 1.0, mrows)
         out = out.view((*lead, k), contiguous_strides((*lead, k)))
         return [rng.advanced(rows * k), out if out_dtype == fdt else _cast(env, out, out_dtype)]
 

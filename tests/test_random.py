@@ -422,6 +422,37 @@ def test_device_dirichlet_and_multivariate_normal(hip):
         np.testing.assert_allclose(got[1], want[1], rtol=1e-11, atol=1e-11)
 
 
+def test_multivariate_normal_with_a_mean_per_draw():
+    """MvNormalRV.rng_fn 915-916: without ``size`` the batch shape is the mean's leading shape"""
+    _, mean, cov = _mv_cases()
+    means = mean[None, :] + np.arange(3000)[:, None] * 0.0 + np.array([0.0, 10.0, -10.0])[np.arange(3000) % 3][:, None]
+    g = rv_graph("multivariate_normal", "float64", None, [("float64", 2), ("float64", 2)])
+    g2, x = np_graph.run_graph(g, [gen(4), means, cov])
+    assert x.shape == (3000, 4) and philox_ref.generator_state(g2)[1] == 4 + 3000 * 4
+    for k, off in enumerate((0.0, 10.0, -10.0)):
+        assert np.abs(x[k::3].mean(axis=0) - (mean + off)).max() < 6 * np.sqrt(np.diag(cov).max() / 1000)
+    assert np.abs(np.cov((x - means).T) - cov).max() < 0.12 * np.abs(cov).max()
+
+
+@pytest.mark.gpu
+def test_device_multivariate_normal_with_a_mean_per_draw(hip):
+    from pytensor_amd.executor import HipExecutable
+
+    _, mean, cov = _mv_cases()
+    means = mean[None, :] + np.random.default_rng(1).normal(size=(257, 1))
+    g = rv_graph("multivariate_normal", "float64", None, [("float64", 2), ("float64", 2)])
+    want = np_graph.run_graph(g, [gen(4), means, cov])
+    got = HipExecutable(g)(gen(4), means, cov)
+    assert philox_ref.generator_state(got[0]) == philox_ref.generator_state(want[0])
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-11, atol=1e-11)
+    # size given, a (1, k) mean broadcast against it
+    g = rv_graph("multivariate_normal", "float64", (5, 7), [("float64", 2), ("float64", 2)])
+    want = np_graph.run_graph(g, [gen(4), mean[None, :], cov])
+    got = HipExecutable(g)(gen(4), mean[None, :], cov)
+    assert got[1].shape == (5, 7, 4)
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-11, atol=1e-11)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("method", ["svd", "eigh"])
 def test_device_multivariate_normal_svd_and_eigh_factors(hip, method):
