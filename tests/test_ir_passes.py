@@ -261,3 +261,39 @@ def test_multi_flat_source_shares_bodies_and_compiles():
     assert src.count("static __device__ __forceinline__ void mt_") == 3  # (b1,SV) shared by two terms
     assert "switch (blockIdx.y)" in src and src.count("case ") == 4
     assert len(ffi.jit_compile(src, "multi_probe.hip")) > 1000
+
+
+def test_branch_guards_of_lazy_ifelse():
+    """executor.branch_guards: nodes that reach the outputs only through one branch of an IfElse are
+    guarded by it (innermost conditional when they nest); anything shared with an unconditional
+    consumer, the condition's own producers and graph outputs stay eager.  The oracle's interpreter
+    carries the same analysis (np_graph._branch_guards) and must agree."""
+    import np_graph
+    from pytensor_amd.executor import branch_guards
+    from pytensor_amd.ir import Graph
+
+    g = Graph(name="guards")
+    x = g.new_var("float64", (None,), name="x")
+    c1, c2 = g.new_var("bool", (), name="c1"), g.new_var("bool", (), name="c2")
+    v = {k: g.new_var("float64", (None,)) for k in "abcdefgho"}
+    ew = lambda op: {"scalar": {"in_dtypes": ["float64"], "out_dtypes": ["float64"], "body": [{"op": op, "in": [["i", 0]], "dtype": "float64"}], "outs": [["t", 0]]}}
+    g.add_node("Elemwise", ew("Exp"), [x], [v["a"]])        # 0: only the inner "then" branch
+    g.add_node("Elemwise", ew("Sqr"), [x], [v["b"]])        # 1: inner "else" branch AND an output -> eager
+    g.add_node("IfElse", {"n_outs": 1}, [c2, v["a"], v["b"]], [v["c"]])  # 2: itself inside the outer "then" branch
+    g.add_node("Elemwise", ew("Neg"), [v["c"]], [v["d"]])   # 3: outer "then"
+    g.add_node("Elemwise", ew("Abs"), [x], [v["e"]])        # 4: outer "else" ...
+    g.add_node("Elemwise", ew("Log1p"), [v["e"]], [v["f"]])  # 5: ... chain of two
+    g.add_node("IfElse", {"n_outs": 1}, [c1, v["d"], v["f"]], [v["o"]])  # 6
+    g.inputs, g.outputs = [x, c1, c2], [v["o"], v["b"]]
+    guard, members = branch_guards(g)
+    assert guard == [(2, 0), None, (6, 0), (6, 0), (6, 1), (6, 1), None]
+    assert members == {(2, 0): [0], (2, 1): [], (6, 0): [2, 3], (6, 1): [4, 5]}
+    g2, m2 = np_graph._branch_guards(g)
+    assert (g2, m2) == (guard, members)
+    xv = np.array([0.5, -2.0, 3.0])
+    for a in (True, False):
+        for b in (True, False):
+            out, sq = np_graph.run_graph(g, [xv, np.asarray(a), np.asarray(b)])
+            want = (-(np.exp(xv) if b else xv**2)) if a else np.log1p(np.abs(xv))
+            np.testing.assert_allclose(out, want, rtol=1e-15)
+            np.testing.assert_allclose(sq, xv**2, rtol=1e-15)
