@@ -172,21 +172,46 @@ def _take_axis(env, x: DeviceArray, idx: DeviceArray, axis: int) -> DeviceArray:
     return out.view([out.shape[d] for d in inv], [out.strides[d] for d in inv])
 
 
+def _any_outside(env, idx: DeviceArray, n: int) -> bool:
+    """any(idx < 0 or idx >= n), decided on the device (one host read of a count)"""
+    from pytensor_amd.dispatch.subtensor import nonzero_flat
+
+    if not idx.size:
+        return False
+    ops = [{"op": "LT", "in": [["i", 0], ["c", 0, "int64"]], "dtype": "bool"}, {"op": "GE", "in": [["i", 0], ["c", int(n), "int64"]], "dtype": "bool"},
+           {"op": "OR", "in": [["t", 0], ["t", 1]], "dtype": "bool"}]
+    flat = idx.contiguous().view((idx.size,), (1,))
+    return nonzero_flat(env, _ew(env, ops, [flat], ["int64"], "bool", (idx.size,))).size > 0
+
+
 @handler("Repeat")
 def repeat(node, inputs, env):
-    # extra_ops.py:706 (np.repeat(x, repeats, axis)): the gather index is the only data-dependent part
+    """np.repeat(x, repeats, axis) (extra_ops.py:706): output position j reads the source position
+    searchsorted(cumsum(repeats), j, "right") — cumulative sum, arange and binary search on the
+    device; the output length (the last cumulative value) is the one host read a data-dependent
+    shape costs."""
     x = env.to_device(inputs[0])
     axis = int(node.params["axis"])
-    reps = np.asarray(env.to_host(inputs[1]))
-    if (reps < 0).any():
-        raise ValueError("repeats may not contain negative values.")
+    reps = _as_int64(env, env.to_device(inputs[1]))
     n = x.shape[axis]
-    if reps.ndim == 0 or reps.size == 1 and n != 1:
-        reps = np.full(n, int(reps.ravel()[0]) if reps.size else 0)
-    if reps.shape != (n,):
+    if reps.ndim == 0 or (reps.size == 1 and n != 1):
+        reps = _bcast_copy(env, reps.view((1,), (0,)) if reps.ndim == 0 else reps, (n,))
+    if tuple(reps.shape) != (n,):
         raise ValueError(f"operands could not be broadcast together with shape ({n},) ({reps.size},)")
-    idx = env.to_device(HostValue(np.repeat(np.arange(n, dtype=np.int64), reps)))
-    return [_take_axis(env, x, idx.contiguous(), axis)]
+    if n == 0:
+        return [x.contiguous_copy()]
+    if _any_outside(env, reps, 1 << 62):
+        raise ValueError("repeats may not contain negative values.")
+    ends = DeviceArray.empty((n,), "int64")
+    ffi.check(env.lib.pthip_cumulative(ffi.np_dtype_code(np.dtype("int64")), 0, 1, n, 1, reps.contiguous().ptr, ends.ptr))
+    total = int(np.asarray(env.to_host(ends.view((1,), (1,), n - 1))).item())
+    idx = DeviceArray.empty((total,), "int64")
+    if total:
+        pos = _iota(env, total)
+        ffi.check(env.lib.pthip_searchsorted(ffi.np_dtype_code(np.dtype("int64")), n, ends.ptr, None, ffi.np_dtype_code(np.dtype("int64")),
+                                             total, pos.ptr, 1, idx.ptr))
+        env.keepalive.extend((ends, pos))
+    return [_take_axis(env, x, idx, axis)]
 
 
 @handler("UnravelIndex")
@@ -235,10 +260,8 @@ def ravel_multi_index(node, inputs, env):
     bviews = [_bview(d, shape) for d in devs]
     if mode == "raise":
         for d, n in zip(devs, dims):
-            if d.size:
-                h = np.asarray(env.to_host(d))  # (np.ravel_multi_index checks its input: a host read in this mode)
-                if (h < 0).any() or (h >= n).any():
-                    raise ValueError("invalid entry in coordinates array")
+            if _any_outside(env, d, n):  # (np.ravel_multi_index checks its input)
+                raise ValueError("invalid entry in coordinates array")
     return [_ew(env, ops, bviews, ["int64"] * len(devs), "int64", shape)]
 
 
@@ -426,10 +449,8 @@ def choose(node, inputs, env):
     ab = _bcast_copy(env, a, shape)
     cb = _bcast_copy(env, ch, (K, *shape))
     mode = node.params["mode"]
-    if mode == "raise" and ab.size:
-        h = np.asarray(env.to_host(ab))
-        if (h < 0).any() or (h >= K).any():
-            raise ValueError("invalid entry in choice array")
+    if mode == "raise" and _any_outside(env, ab, K):
+        raise ValueError("invalid entry in choice array")
     ops = []
     ref = ["i", 0]
     if mode == "wrap":
