@@ -296,7 +296,7 @@ def special_inverse_polygamma():
     # scalar/math.py:595 PolyGamma, 721 GammaIncInv, 746 GammaIncCInv, 1601 BetaIncInv: no C code in the
     # reference — both of its linkers call scipy.special.  Inside fused Elemwise kernels here.
     import pytensor.scalar as ps
-    from pytensor.scalar.math import BetaIncInv, GammaIncCInv, GammaIncInv, PolyGamma
+    from pytensor.scalar.math import BetaIncInv, GammaIncCInv, GammaIncInv, NdtriExp, PolyGamma
     from pytensor.tensor.elemwise import Elemwise
 
     rng = np.random.default_rng(90)
@@ -307,13 +307,20 @@ def special_inverse_polygamma():
     gi = Elemwise(GammaIncInv(ps.upgrade_to_float, name="gammaincinv"))
     gci = Elemwise(GammaIncCInv(ps.upgrade_to_float, name="gammainccinv"))
     bi = Elemwise(BetaIncInv(ps.upgrade_to_float, name="betaincinv"))
-    outs = [pg(n, x), pg(n[:, None], x[None, :5]) * 1e-3, gi(a, p), gci(a, p), bi(a, b, p),
+    nde = Elemwise(NdtriExp(ps.upgrade_to_float, name="ndtri_exp"))
+    ly, lyg = pt.dvector("ly"), pt.dvector("lyg")
+    # (the gradient sqrt(2 pi) exp(y + z^2 / 2) magnifies an error of z by z^2: it is pinned where scipy's own
+    #  ndtri_exp is accurate to the last bits, y >= -40; far in the tail log_ndtr(scipy's z) misses y by 3e-7)
+    outs = [pg(n, x), pg(n[:, None], x[None, :5]) * 1e-3, gi(a, p), gci(a, p), bi(a, b, p), nde(ly), pytensor.grad(nde(lyg).sum(), lyg),
             pt.exp(-gi(a, p)) + pt.log1p(bi(a, b, p)),  # fused with neighbours
             gi(a, pt.constant(np.array(1e-9))) , gci(a, pt.constant(np.array(1e-9))), bi(a, b, pt.constant(np.array(1.0 - 1e-9)))]
     m = 60
     vals = {"x": np.concatenate([rng.uniform(0.05, 30.0, size=m - 8), -rng.uniform(0.1, 4.9, size=8)]), "n": rng.integers(0, 6, size=m),
-            "a": 10 ** rng.uniform(-1, 2.5, size=m), "b": 10 ** rng.uniform(-1, 2.5, size=m), "p": rng.uniform(0.001, 0.999, size=m)}
-    return [x, a, b, p, n], outs, vals
+            "a": 10 ** rng.uniform(-1, 2.5, size=m), "b": 10 ** rng.uniform(-1, 2.5, size=m), "p": rng.uniform(0.001, 0.999, size=m),
+            # log-probabilities from 1 - 1e-9 down to where exp underflows (not within 0.05 of log 1/2, where the quantile crosses 0)
+            "ly": np.concatenate([-10 ** rng.uniform(-9, -1.5, size=15), -rng.uniform(0.75, 2.0, size=10), -rng.uniform(2.0, 700.0, size=25), -10 ** rng.uniform(3, 4, size=10)])}
+    vals["lyg"] = -rng.uniform(0.75, 40.0, size=30)
+    return [x, a, b, p, n, ly, lyg], outs, vals
 
 
 @case("sylvester_lyapunov", rtol=1e-10)

@@ -182,6 +182,7 @@ SCALAR = {
     "BetaInc": special_c.BetaInc,
     # (these four have no C code in the reference: both linkers evaluate them through SciPy)
     "PolyGamma": scipy.special.polygamma,  # scalar/math.py:607
+    "NdtriExp": scipy.special.ndtri_exp,  # scalar/math.py:281
     "GammaIncInv": scipy.special.gammaincinv,  # scalar/math.py:728
     "GammaIncCInv": scipy.special.gammainccinv,  # scalar/math.py:753
     "BetaIncInv": scipy.special.betaincinv,  # scalar/math.py:1608

@@ -434,6 +434,31 @@ PT_DEV double pt_polygamma(double n, double x) {
 PT_DEV float pt_polygamma(float n, float x) { return (float)pt_polygamma((double)n, (double)x); }
 """
 
+_NDTRIEXP_SRC = r"""
+// ndtri(exp(y)) without forming exp(y) where it underflows (NdtriExp.impl, scalar/math.py:281:
+// scipy.special.ndtri_exp): the upper tail through erfcinv(2 (1 - e^y)) near y = 0, erfcinv(2 e^y) down
+// to y = -2, below that Newton steps on log Phi(x) = log(erfcx(-x / sqrt 2) / 2) - x^2 / 2 = y from the
+// asymptotic root — quadratic, 3-5 steps
+PT_DEV double pt_ndtri_exp(double y) {
+  if (y != y || y > 0.0) return __builtin_nan("");
+  if (y == 0.0) return __builtin_inf();
+  if (y == -__builtin_inf()) return y;
+  const double SQ2 = 1.4142135623730951;
+  if (y >= -0.6931471805599453) return SQ2 * erfcinv(2.0 * (-expm1(y)));
+  if (y >= -2.0) return -SQ2 * erfcinv(2.0 * exp(y));
+  const double t = -2.0 * y;
+  double x = -sqrt(t - log(6.283185307179586 * t));
+  for (int it = 0; it < 8; it++) {
+    const double r = erfcx(-x / SQ2);  // Phi(x) / phi(x) = r sqrt(pi / 2)
+    const double dx = (log(0.5 * r) - 0.5 * x * x - y) * r * 1.2533141373155003;
+    x -= dx;
+    if (fabs(dx) <= 1e-16 * fabs(x)) break;
+  }
+  return x;
+}
+PT_DEV float pt_ndtri_exp(float y) { return (float)pt_ndtri_exp((double)y); }
+"""
+
 _GAMMAINCINV_SRC = r"""
 // inverses of the regularised incomplete gamma functions (GammaIncInv / GammaIncCInv.impl,
 // scalar/math.py: scipy.special.gammaincinv / gammainccinv): the root of P(a, x) = p or Q(a, x) = q,
@@ -532,10 +557,10 @@ PT_DEV double pt_betaincinv(double a, double b, double p) {
 PT_DEV float pt_betaincinv(float a, float b, float p) { return (float)pt_betaincinv((double)a, (double)b, (double)p); }
 """
 
-_OPTIONAL_HELPERS = {"GammaInc": ("gammainc",), "GammaIncC": ("gammainc",), "BetaInc": ("betainc",), "PolyGamma": ("polygamma",),
+_OPTIONAL_HELPERS = {"NdtriExp": ("ndtriexp",), "GammaInc": ("gammainc",), "GammaIncC": ("gammainc",), "BetaInc": ("betainc",), "PolyGamma": ("polygamma",),
                      "GammaIncInv": ("gammainc", "gammaincinv"), "GammaIncCInv": ("gammainc", "gammaincinv"),
                      "BetaIncInv": ("betainc", "betaincinv")}
-_OPTIONAL_ORDER = ("gammainc", "betainc", "polygamma", "gammaincinv", "betaincinv")
+_OPTIONAL_ORDER = ("gammainc", "betainc", "polygamma", "ndtriexp", "gammaincinv", "betaincinv")
 _optional_src_cache = {}
 
 
@@ -545,7 +570,7 @@ def _optional_src(key: str) -> str:
             logfs, loghs = _gamma_tables()
             _optional_src_cache[key] = _c_table("pt_g_logfs", logfs) + _c_table("pt_g_loghs", loghs) + _GAMMAINC_SRC
         else:
-            _optional_src_cache[key] = {"betainc": _BETAINC_SRC, "polygamma": _POLYGAMMA_SRC, "gammaincinv": _GAMMAINCINV_SRC,
+            _optional_src_cache[key] = {"betainc": _BETAINC_SRC, "polygamma": _POLYGAMMA_SRC, "ndtriexp": _NDTRIEXP_SRC, "gammaincinv": _GAMMAINCINV_SRC,
                                         "betaincinv": _BETAINCINV_SRC}[key]
     return _optional_src_cache[key]
 
@@ -789,6 +814,7 @@ SCALAR_EXPR = {
     "GammaIncC": _helper("pt_gammaincc"),  # scalar/math.py:674
     "BetaInc": _helper("pt_betainc"),  # scalar/math.py:1342
     "PolyGamma": _helper("pt_polygamma"),  # scalar/math.py:595 (scipy.special.polygamma)
+    "NdtriExp": _helper("pt_ndtri_exp"),  # scalar/math.py:271 (scipy.special.ndtri_exp)
     "GammaIncInv": _helper("pt_gammaincinv"),  # scipy.special.gammaincinv
     "GammaIncCInv": _helper("pt_gammainccinv"),  # scipy.special.gammainccinv
     "BetaIncInv": _helper("pt_betaincinv"),  # scipy.special.betaincinv

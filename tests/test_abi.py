@@ -56,7 +56,7 @@ def test_optional_special_function_helpers_compile_without_gpu():
     into kernels that use them: each combination must pass hiprtc on its own"""
     from pytensor_amd import codegen, ffi
 
-    for op, nin in (("PolyGamma", 2), ("GammaIncInv", 2), ("GammaIncCInv", 2), ("BetaIncInv", 3), ("GammaInc", 2), ("BetaInc", 3)):
+    for op, nin in (("NdtriExp", 1), ("PolyGamma", 2), ("GammaIncInv", 2), ("GammaIncCInv", 2), ("BetaIncInv", 3), ("GammaInc", 2), ("BetaInc", 3)):
         body = {"in_dtypes": ["float64"] * nin, "out_dtypes": ["float64"],
                 "body": [{"op": op, "in": [["i", k] for k in range(nin)], "dtype": "float64"}], "outs": [["t", 0]]}
         names = [f"v{k}" for k in range(nin)]
