@@ -1303,9 +1303,9 @@ def _unique(p, inputs, node, graph):
     if not isinstance(outs, tuple):
         return [outs]
     outs = list(outs)
-    if p["return_inverse"] and p["axis"] is None:
+    if p["return_inverse"]:  # npy_2_compat.old_np_unique: 1-d inverse (flat, or along the axis)
         k = 1 + int(p["return_index"])
-        outs[k] = outs[k].reshape(-1)
+        outs[k] = outs[k].reshape(-1) if p["axis"] is None else outs[k].reshape((x.shape[p["axis"]],))
     return outs
 
 

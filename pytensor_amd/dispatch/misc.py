@@ -273,7 +273,7 @@ def unique(node, inputs, env):
 
     p = node.params
     if p.get("axis") is not None:
-        raise NotImplementedError("hip linker: Unique along an axis")
+        return _unique_axis(node, inputs, env)
     x = env.to_device(inputs[0]).contiguous()
     n = x.size
     flat = x.view((n,), (1,))
@@ -326,6 +326,98 @@ def unique(node, inputs, env):
         copy_into(nxt.view((1,), (1,), k - 1), env.to_device(HostValue(np.asarray([n], dtype="int64"))))
         outs.append(_ew(env, [{"op": "Sub", "in": [["i", 0], ["i", 1]], "dtype": "int64"}], [nxt, starts], ["int64", "int64"], "int64", (k,)))
     env.keepalive.extend((vals, order, first))
+    return outs
+
+
+MAX_UNIQUE_WIDTH = 4096  # elements per slice of Unique(axis=...): one stable sort pass per element
+
+
+def _unique_axis(node, inputs, env):
+    """np.unique(x, axis=a): the slices along ``a`` as rows, ordered lexicographically by one stable
+    device sort per column (last column first — an LSD radix sort whose digits are whole columns), runs
+    of equal rows flagged, compacted like the flat case."""
+    from pytensor_amd.dispatch.elemwise import _cast
+    from pytensor_amd.dispatch.subtensor import _scatter_rows, nonzero_flat
+
+    p = node.params
+    axis = int(p["axis"])
+    x = env.to_device(inputs[0])
+    if x.dtype.kind == "b":
+        raise NotImplementedError("hip linker: Unique of a bool array")
+    order_ax = [axis] + [d for d in range(x.ndim) if d != axis]
+    xt = x.view([x.shape[d] for d in order_ax], [x.strides[d] for d in order_ax]).contiguous()
+    n = xt.shape[0]
+    rest = tuple(xt.shape[1:])
+    m = int(np.prod(rest, dtype=np.int64)) if rest else 1
+    if m > MAX_UNIQUE_WIDTH:
+        raise NotImplementedError(f"hip linker: Unique(axis=...) over slices of {m} elements (up to {MAX_UNIQUE_WIDTH})")
+    want = [p["return_index"], p["return_inverse"], p["return_counts"]]
+
+    def back(rows: DeviceArray, k: int) -> DeviceArray:
+        full = rows.view((k, *rest), _cs((k, *rest)))
+        inv = [order_ax.index(d) for d in range(x.ndim)]
+        return full.view([full.shape[d] for d in inv], [full.strides[d] for d in inv]).contiguous()
+
+    if n == 0 or m == 0:
+        k = 0 if n == 0 else 1
+        outs = [back(DeviceArray.empty((k, m), x.dtype), k)]
+        if p["return_index"]:
+            outs.append(env.to_device(HostValue(np.zeros(k, dtype="int64"))))
+        if p["return_inverse"]:
+            outs.append(env.to_device(HostValue(np.zeros(n, dtype="int64"))))
+        if p["return_counts"]:
+            outs.append(env.to_device(HostValue(np.full(k, n, dtype="int64"))))
+        return outs
+    x2 = xt.view((n, m), (m, 1))
+    dt = str(x.dtype)
+    code = ffi.np_dtype_code(x.dtype)
+    order = _iota(env, n)
+    keys, idx = DeviceArray.empty((n,), x.dtype), DeviceArray.empty((n,), "int64")
+    for col in range(m - 1, -1, -1):
+        colv = x2.view((n,), (m,), col).contiguous()  # this column, in the original row order
+        ffi.check(env.lib.pthip_take_rows(x.itemsize, n, 1, colv.ptr, n, 1, order.ptr, keys.ptr))
+        ffi.check(env.lib.pthip_sort(code, 1, n, keys.ptr, None, idx.ptr))
+        nxt = DeviceArray.empty((n,), "int64")
+        ffi.check(env.lib.pthip_take_rows(8, n, 1, order.ptr, n, 1, idx.ptr, nxt.ptr))
+        env.keepalive.extend((colv, order))
+        order = nxt
+    S = DeviceArray.empty((n, m), x.dtype)
+    ffi.check(env.lib.pthip_take_rows(x.itemsize, n, m, x2.ptr, n, m, order.ptr, S.ptr))
+    first = DeviceArray.empty((n,), "bool")
+    ffi.check(env.lib.pthip_memset(first.ptr, 1, 1))
+    if n > 1:
+        # a row starts a run when any of its elements differs from the row above
+        neq = _ew(env, [{"op": "NEQ", "in": [["i", 0], ["i", 1]], "dtype": "bool"}, {"op": "Cast", "in": [["t", 0]], "dtype": "float64"}],
+                  [S.view((n - 1, m), (m, 1), m), S.view((n - 1, m), (m, 1))], [dt, dt], "float64", (n - 1, m))
+        from pytensor_amd.dispatch.decomp import _column_sums, _t
+
+        diff = _column_sums(env, _t(neq).contiguous())  # (n - 1,): how many elements differ
+        flags = _ew(env, [{"op": "GT", "in": [["i", 0], ["c", (0.0).hex(), "float64"]], "dtype": "bool"}], [diff], ["float64"], "bool", (n - 1,))
+        copy_into(first.view((n - 1,), (1,), 1), flags)
+    starts = nonzero_flat(env, first)
+    k = starts.size
+    uniq = DeviceArray.empty((k, m), x.dtype)
+    ffi.check(env.lib.pthip_take_rows(x.itemsize, k, m, S.ptr, n, m, starts.ptr, uniq.ptr))
+    outs = [back(uniq, k)]
+    if p["return_index"]:
+        first_idx = DeviceArray.empty((k,), "int64")
+        ffi.check(env.lib.pthip_take_rows(8, k, 1, order.ptr, n, 1, starts.ptr, first_idx.ptr))
+        outs.append(first_idx)
+    if p["return_inverse"]:
+        f64 = _cast(env, first, "int64")
+        run = DeviceArray.empty((n,), "int64")
+        ffi.check(env.lib.pthip_cumulative(ffi.np_dtype_code(np.dtype("int64")), 0, 1, n, 1, f64.ptr, run.ptr))
+        rank = _ew(env, [{"op": "Sub", "in": [["i", 0], ["c", 1, "int64"]], "dtype": "int64"}], [run], ["int64"], "int64", (n,))
+        inv = DeviceArray.empty((n,), "int64")
+        _scatter_rows(env, {"set_instead_of_inc": True}, inv, rank, order)
+        outs.append(inv)
+    if p["return_counts"]:
+        nxt = DeviceArray.empty((k,), "int64")
+        if k > 1:
+            copy_into(nxt.view((k - 1,), (1,)), starts.view((k - 1,), (1,), 1))
+        copy_into(nxt.view((1,), (1,), k - 1), env.to_device(HostValue(np.asarray([n], dtype="int64"))))
+        outs.append(_ew(env, [{"op": "Sub", "in": [["i", 0], ["i", 1]], "dtype": "int64"}], [nxt, starts], ["int64", "int64"], "int64", (k,)))
+    env.keepalive.extend((S, order, first, keys, idx))
     return outs
 
 

@@ -675,10 +675,8 @@ def _register_misc():
 
     @hip_funcify.register(Unique)
     def _(op, node, ctx):
-        if op.axis is not None:
-            return None
         return "Unique", {"return_index": bool(op.return_index), "return_inverse": bool(op.return_inverse),
-                          "return_counts": bool(op.return_counts), "axis": None}
+                          "return_counts": bool(op.return_counts), "axis": None if op.axis is None else int(op.axis)}
 
     @hip_funcify.register(LU)
     def _(op, node, ctx):

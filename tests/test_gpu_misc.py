@@ -72,6 +72,14 @@ def test_unique_repeat_ravel(hip):
         check(one_node("Unique", {"return_index": True, "return_inverse": True, "return_counts": True, "axis": None},
                        [(dt, nd)], [(dt, 1), ("int64", 1), ("int64", 1), ("int64", 1)]), x)
         check(one_node("Unique", {"return_index": False, "return_inverse": False, "return_counts": False, "axis": None}, [(dt, nd)], [(dt, 1)]), x)
+    # unique slices along an axis: lexicographic order, first occurrences, 1-d inverse
+    rows = rng.integers(0, 3, size=(200, 3))
+    cube = rng.integers(0, 2, size=(4, 30, 2)).astype("float64")
+    for x, axis in ((rows, 0), (rows.T.copy(), 1), (cube, 1), (cube, 0), (np.round(rng.normal(size=(50, 2)), 0), 0), (np.zeros((0, 3)), 0), (np.ones((5, 1)), 0)):
+        dt, nd = str(x.dtype), x.ndim
+        check(one_node("Unique", {"return_index": True, "return_inverse": True, "return_counts": True, "axis": axis},
+                       [(dt, nd)], [(dt, nd), ("int64", 1), ("int64", 1), ("int64", 1)]), x)
+        check(one_node("Unique", {"return_index": False, "return_inverse": False, "return_counts": False, "axis": axis}, [(dt, nd)], [(dt, nd)]), x)
     m = rng.normal(size=(4, 5, 3))
     check(one_node("Repeat", {"axis": 1}, [("float64", 3), ("int64", 1)], [("float64", 3)]), m, np.array([0, 3, 1, 0, 2]))
     check(one_node("Repeat", {"axis": 2}, [("float64", 3), ("int64", 1)], [("float64", 3)]), m, np.array([2, 2, 2]))
