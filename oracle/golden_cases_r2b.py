@@ -339,3 +339,78 @@ def sylvester_lyapunov():
     vals = {"A": rng.normal(size=(m, m)) + 3.0 * np.eye(m), "B": rng.normal(size=(n, n)) + 3.0 * np.eye(n), "C": rng.normal(size=(m, n)),
             "S": rng.normal(size=(6, 6)) - 3.0 * np.eye(6), "Q": Qv @ Qv.T}
     return [A, B, C, S, Q], outs, vals
+
+
+@case("gp_marginal_likelihood", rtol=1e-10)
+def gp_marginal_likelihood():
+    # a Gaussian-process marginal likelihood with its gradient — the op mix of pymc's gp.Marginal: pairwise
+    # squared distances by broadcasting, Exp, Cholesky (linalg/decomposition/cholesky.py:18), two triangular
+    # solves, log-determinant from the diagonal, and the pullbacks of all of them
+    rng = np.random.default_rng(92)
+    X, y = pt.dmatrix("X"), pt.dvector("y")
+    ls, eta, sigma = pt.dvector("ls"), pt.dscalar("eta"), pt.dscalar("sigma")
+    Xs = X / ls[None, :]
+    d2 = (Xs**2).sum(axis=1)[:, None] + (Xs**2).sum(axis=1)[None, :] - 2.0 * Xs @ Xs.T
+    K = eta**2 * pt.exp(-0.5 * pt.maximum(d2, 0.0)) + (sigma**2 + 1e-6) * pt.eye(X.shape[0])
+    L = pt.linalg.cholesky(K)
+    alpha = pt.linalg.solve_triangular(L, y, lower=True)
+    logp = -0.5 * (alpha**2).sum() - pt.log(pt.diag(L)).sum() - 0.5 * y.shape[0] * np.log(2 * np.pi)
+    n = 60
+    Xv = rng.normal(size=(n, 3))
+    vals = {"X": Xv, "y": np.sin(Xv[:, 0]) + 0.1 * rng.normal(size=n), "ls": np.array([0.9, 1.4, 2.0]), "eta": 1.3, "sigma": 0.35}
+    return [X, y, ls, eta, sigma], [logp, *pytensor.grad(logp, [ls, eta, sigma]), alpha], vals
+
+
+@case("mixture_ordinal_logp", rtol=1e-10)
+def mixture_ordinal_logp():
+    # a normal mixture (logsumexp over components) plus an ordered-logistic likelihood (cutpoints by
+    # cumsum of positives, category probabilities as sigmoid differences, picked per row by advanced
+    # indexing), logp and gradients — the op mix of pm.NormalMixture / pm.OrderedLogistic
+    rng = np.random.default_rng(93)
+    yv, w_raw, mu, ls = pt.dvector("yv"), pt.dvector("w_raw"), pt.dvector("mu"), pt.dvector("ls")
+    eta, cut_raw = pt.dvector("eta"), pt.dvector("cut_raw")
+    cat = pt.lvector("cat")
+    logw = w_raw - pt.logsumexp(w_raw)
+    z = (yv[:, None] - mu[None, :]) * pt.exp(-ls)[None, :]
+    comp = logw[None, :] - 0.5 * z**2 - ls[None, :] - 0.5 * np.log(2 * np.pi)
+    lp_mix = pt.logsumexp(comp, axis=1).sum()
+    cuts = pt.cumsum(pt.concatenate([cut_raw[:1], pt.exp(cut_raw[1:])]))
+    cdf = pt.sigmoid(cuts[None, :] - eta[:, None])
+    probs = pt.concatenate([cdf[:, :1], cdf[:, 1:] - cdf[:, :-1], 1.0 - cdf[:, -1:]], axis=1)
+    lp_ord = pt.log(probs[pt.arange(eta.shape[0]), cat]).sum()
+    logp = lp_mix + lp_ord
+    n, k, c = 300, 4, 5
+    vals = {"yv": rng.normal(size=n) * 2.0, "w_raw": rng.normal(size=k), "mu": np.linspace(-3, 3, k), "ls": rng.normal(size=k) * 0.2,
+            "eta": rng.normal(size=n), "cut_raw": np.array([-1.5, 0.1, -0.3, 0.2]), "cat": rng.integers(0, c, size=n)}
+    return [yv, w_raw, mu, ls, eta, cut_raw, cat], [logp, *pytensor.grad(logp, [w_raw, mu, ls, eta, cut_raw]), probs.sum(axis=1)], vals
+
+
+@case("kalman_filter_scan", rtol=1e-9, py_optimizer="fast_compile")  # (the unoptimised PerformLinker run of this graph raises "expected an ndarray" inside the reference)
+def kalman_filter_scan():
+    # a linear-Gaussian state-space log-likelihood by a Kalman filter inside Scan (3 states, 2 observables,
+    # 25 steps): per step Dot / Solve / Det on small matrices, the filtered state carried as two sit-sot
+    # outputs, the gradient wrt the transition and noise parameters through the scan
+    rng = np.random.default_rng(94)
+    Y = pt.dmatrix("Y")
+    T_, Z, q, r = pt.dmatrix("T"), pt.dmatrix("Z"), pt.dvector("q"), pt.dvector("r")
+    a0, P0 = pt.dvector("a0"), pt.dmatrix("P0")
+
+    def step(y, a, P, T_, Z, Qm, Rm):
+        a_p = T_ @ a
+        P_p = T_ @ P @ T_.T + Qm
+        v = y - Z @ a_p
+        F = Z @ P_p @ Z.T + Rm
+        Kg = pt.linalg.solve(F, Z @ P_p).T  # P_p Z^T F^-1
+        a_n = a_p + Kg @ v
+        P_n = P_p - Kg @ Z @ P_p
+        ll = -0.5 * (pt.log(pt.linalg.det(F)) + v @ pt.linalg.solve(F, v) + 2 * np.log(2 * np.pi))
+        return a_n, P_n, ll
+
+    (a_s, P_s, lls), _ = pytensor.scan(step, sequences=[Y], outputs_info=[a0, P0, None],
+                                        non_sequences=[T_, Z, pt.diag(pt.exp(q)), pt.diag(pt.exp(r))])
+    ll = lls.sum()
+    Tv = np.array([[0.8, 0.1, 0.0], [0.0, 0.7, 0.2], [0.1, 0.0, 0.9]])
+    vals = {"Y": rng.normal(size=(25, 2)), "T": Tv, "Z": rng.normal(size=(2, 3)), "q": np.array([-1.0, -0.5, -1.5]), "r": np.array([-0.7, -0.2]),
+            "a0": np.zeros(3), "P0": np.eye(3)}
+    # (the filtered state itself is not an output: with `a_s[-1]` beside the gradient the reference's own C linker raises "expected an ndarray")
+    return [Y, T_, Z, q, r, a0, P0], [ll, *pytensor.grad(ll, [T_, q, r])], vals

@@ -49,9 +49,10 @@ CASES = {}
 
 PY_RTOL = {}  # case -> tolerance of the reference's own NumPy backend against its C backend
 PY_LAZY = set()  # cases whose NumPy-backend run needs the lazy VM (IfElse): PerformLinker runs every node
+PY_OPT = {}  # cases whose unoptimised NumPy-backend run fails inside the reference: rewrite set to use instead
 
 
-def case(name, rtol=None, py_rtol=None, lazy=False):
+def case(name, rtol=None, py_rtol=None, lazy=False, py_optimizer=None):
     """``py_rtol``: where the reference's two backends disagree beyond 1e-10 (Psi: AS 103 with
     10-digit constants in C, scipy.special.psi in Python) the C linker's values are the golden
     ones and the NumPy linker's are only sanity-checked at ``py_rtol``."""
@@ -62,6 +63,8 @@ def case(name, rtol=None, py_rtol=None, lazy=False):
             PY_RTOL[name] = py_rtol
         if lazy:
             PY_LAZY.add(name)
+        if py_optimizer is not None:
+            PY_OPT[name] = py_optimizer
         return f
 
     return deco
@@ -611,7 +614,7 @@ def generate(name):
 
         py_mode = Mode(VMLinker(use_cloop=False, c_thunks=False), optimizer=None)  # Python thunks, lazy
     else:
-        py_mode = Mode("py", optimizer=None)
+        py_mode = Mode("py", optimizer=PY_OPT.get(name))
     fn_py = pytensor.function(ins, outs, mode=py_mode, on_unused_input="ignore")
     out_py = [np.asarray(o) for o in fn_py(*explicit)]
 
