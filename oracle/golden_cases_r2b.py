@@ -414,3 +414,60 @@ def kalman_filter_scan():
             "a0": np.zeros(3), "P0": np.eye(3)}
     # (the filtered state itself is not an output: with `a_s[-1]` beside the gradient the reference's own C linker raises "expected an ndarray")
     return [Y, T_, Z, q, r, a0, P0], [ll, *pytensor.grad(ll, [T_, q, r])], vals
+
+
+@case("glm_binomial_studentt", rtol=1e-10, py_rtol=1e-7)  # (d gammaln = Psi: 10-digit constants in the reference's C code, scipy in its NumPy backend)
+def glm_binomial_studentt():
+    # two likelihood families with their priors, logp and gradients: a hierarchical binomial regression
+    # (logit link, group effects gathered by index, binomial coefficient through gammaln) and a robust
+    # regression with a Student-t likelihood whose degrees of freedom are a parameter (gammaln of nu / 2),
+    # Gamma, Beta and half-Cauchy prior densities
+    rng = np.random.default_rng(95)
+    X = pt.dmatrix("X")
+    kk, nn, gidx = pt.lvector("kk"), pt.lvector("nn"), pt.lvector("gidx")
+    beta, u, log_su = pt.dvector("beta"), pt.dvector("u"), pt.dscalar("log_su")
+    yt = pt.dvector("yt")
+    log_nu, log_s, p_b = pt.dscalar("log_nu"), pt.dscalar("log_s"), pt.dscalar("p_b")
+    eta = X @ beta + pt.exp(log_su) * u[gidx]
+    n_f, k_f = nn.astype("float64"), kk.astype("float64")
+    lp_binom = (pt.gammaln(n_f + 1) - pt.gammaln(k_f + 1) - pt.gammaln(n_f - k_f + 1) + k_f * pt.log(pt.sigmoid(eta)) + (n_f - k_f) * pt.log1p(-pt.sigmoid(eta))).sum()
+    lp_u = (-0.5 * u**2).sum() - pt.log1p(pt.exp(2 * log_su)) + log_su  # half-Cauchy on exp(log_su), with the Jacobian
+    nu, s = pt.exp(log_nu) + 1.0, pt.exp(log_s)
+    r = (yt - X @ beta) / s
+    lp_t = (pt.gammaln((nu + 1) / 2) - pt.gammaln(nu / 2) - 0.5 * pt.log(nu * np.pi) - log_s - (nu + 1) / 2 * pt.log1p(r**2 / nu)).sum()
+    lp_nu = 2.0 * pt.log(0.1) - pt.gammaln(2.0) + (2.0 - 1.0) * pt.log(nu) - 0.1 * nu + log_nu  # Gamma(2, 0.1)
+    pb = pt.sigmoid(p_b)
+    lp_beta_prior = pt.gammaln(5.0) - pt.gammaln(2.0) - pt.gammaln(3.0) + 1.0 * pt.log(pb) + 2.0 * pt.log1p(-pb) + pt.log(pb) + pt.log1p(-pb)  # Beta(2, 3) + Jacobian
+    logp = lp_binom + lp_u + lp_t + lp_nu + lp_beta_prior + pb * beta.sum()
+    n, k, g = 400, 5, 12
+    nv = rng.integers(1, 30, size=n)
+    vals = {"X": rng.normal(size=(n, k)), "kk": rng.binomial(nv, 0.4), "nn": nv, "gidx": rng.integers(0, g, size=n), "beta": rng.normal(size=k) * 0.3,
+            "u": rng.normal(size=g), "log_su": -0.4, "yt": rng.standard_t(4, size=n), "log_nu": 1.1, "log_s": 0.2, "p_b": 0.3}
+    wrt = [beta, u, log_su, log_nu, log_s, p_b]
+    return [X, kk, nn, gidx, beta, u, log_su, yt, log_nu, log_s, p_b], [logp, *pytensor.grad(logp, wrt)], vals
+
+
+@case("softmax_dirichlet_censored", rtol=1e-10)
+def softmax_dirichlet_censored():
+    # a softmax (multinomial-logit) regression with a categorical likelihood (LogSoftmax, row gather), a
+    # Dirichlet density over simplex weights built by softmax, and a right-censored normal likelihood
+    # (log survival function through erfcx in the tail, log1p(-erfc / 2) elsewhere), logp and gradients
+    rng = np.random.default_rng(96)
+    X, W = pt.dmatrix("X"), pt.dmatrix("W")
+    cat = pt.lvector("cat")
+    a_raw, conc = pt.dvector("a_raw"), pt.dvector("conc")
+    yc, mu_c, ls_c = pt.dvector("yc"), pt.dscalar("mu_c"), pt.dscalar("ls_c")
+    cens = pt.bvector("cens")
+    lsm = pt.special.log_softmax(X @ W, axis=1)
+    lp_cat = lsm[pt.arange(X.shape[0]), cat].sum()
+    w = pt.special.softmax(a_raw)
+    lp_dir = pt.gammaln(conc.sum()) - pt.gammaln(conc).sum() + ((conc - 1.0) * pt.log(w)).sum()
+    z = (yc - mu_c) * pt.exp(-ls_c)
+    log_pdf = -0.5 * z**2 - ls_c - 0.5 * np.log(2 * np.pi)
+    log_sf = pt.switch(z > 1.0, pt.log(0.5 * pt.erfcx(z / np.sqrt(2.0))) - 0.5 * z**2, pt.log1p(-0.5 * pt.erfc(-z / np.sqrt(2.0))))
+    lp_cens = pt.switch(cens, log_sf, log_pdf).sum()
+    logp = lp_cat + lp_dir + lp_cens
+    n, k, c = 250, 4, 6
+    vals = {"X": rng.normal(size=(n, k)), "W": rng.normal(size=(k, c)) * 0.5, "cat": rng.integers(0, c, size=n), "a_raw": rng.normal(size=7),
+            "conc": rng.uniform(0.5, 3.0, size=7), "yc": rng.normal(size=n) * 1.5 + 0.3, "mu_c": 0.1, "ls_c": 0.2, "cens": (rng.random(n) < 0.3).astype("int8")}
+    return [X, W, cat, a_raw, conc, yc, mu_c, ls_c, cens], [logp, *pytensor.grad(logp, [W, a_raw, mu_c, ls_c]), w], vals
