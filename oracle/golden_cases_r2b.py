@@ -471,3 +471,69 @@ def softmax_dirichlet_censored():
     vals = {"X": rng.normal(size=(n, k)), "W": rng.normal(size=(k, c)) * 0.5, "cat": rng.integers(0, c, size=n), "a_raw": rng.normal(size=7),
             "conc": rng.uniform(0.5, 3.0, size=7), "yc": rng.normal(size=n) * 1.5 + 0.3, "mu_c": 0.1, "ls_c": 0.2, "cens": (rng.random(n) < 0.3).astype("int8")}
     return [X, W, cat, a_raw, conc, yc, mu_c, ls_c, cens], [logp, *pytensor.grad(logp, [W, a_raw, mu_c, ls_c]), w], vals
+
+
+@case("hmm_garch_scans", rtol=1e-9)
+def hmm_garch_scans():
+    # two more recurrences through Scan with their gradients: the forward algorithm of a 3-state hidden Markov
+    # model in log space (a logsumexp over a matrix inside every step) and a GARCH(1,1) variance recursion with
+    # taps -1 / -2 on its state and a Switch in the step
+    rng = np.random.default_rng(97)
+    obs = pt.dvector("obs")
+    logA_raw, mu_s, ls_s = pt.dmatrix("logA_raw"), pt.dvector("mu_s"), pt.dvector("ls_s")
+    ret = pt.dvector("ret")
+    om, al, be = pt.dscalar("om"), pt.dscalar("al"), pt.dscalar("be")
+    logA = logA_raw - pt.logsumexp(logA_raw, axis=1, keepdims=True)
+
+    def emis(y):
+        z = (y - mu_s) * pt.exp(-ls_s)
+        return -0.5 * z**2 - ls_s - 0.5 * np.log(2 * np.pi)
+
+    def fwd(y, la, logA, mu_s, ls_s):
+        z = (y - mu_s) * pt.exp(-ls_s)
+        e = -0.5 * z**2 - ls_s - 0.5 * np.log(2 * np.pi)
+        return pt.logsumexp(la[:, None] + logA, axis=0) + e
+
+    la0 = emis(obs[0]) - np.log(3.0)
+    las, _ = pytensor.scan(fwd, sequences=[obs[1:]], outputs_info=[la0], non_sequences=[logA, mu_s, ls_s])
+    ll_hmm = pt.logsumexp(las[-1])
+
+    def garch(r_prev, h1, h2, om, al, be):
+        h = pt.exp(om) + pt.sigmoid(al) * 0.3 * r_prev**2 + pt.sigmoid(be) * 0.6 * pt.switch(h1 > h2, h1, 0.5 * (h1 + h2))
+        return h
+
+    hs, _ = pytensor.scan(garch, sequences=[ret[:-1]], outputs_info=[dict(initial=pt.stack([ret.var(), ret.var()]), taps=[-1, -2])],
+                          non_sequences=[om, al, be])
+    ll_garch = (-0.5 * pt.log(hs) - 0.5 * ret[1:] ** 2 / hs).sum()
+    ll = ll_hmm + ll_garch
+    T = 40
+    vals = {"obs": rng.normal(size=T) + np.repeat([-2.0, 0.0, 2.0, 0.0], T // 4), "logA_raw": rng.normal(size=(3, 3)), "mu_s": np.array([-2.0, 0.1, 2.2]),
+            "ls_s": np.array([-0.2, 0.1, 0.0]), "ret": rng.normal(size=T) * 0.8, "om": -1.0, "al": 0.2, "be": 0.5}
+    return [obs, logA_raw, mu_s, ls_s, ret, om, al, be], [ll, *pytensor.grad(ll, [logA_raw, mu_s, ls_s, om, al, be]), hs[-1]], vals
+
+
+@case("lkj_packed_spline", rtol=1e-10)
+def lkj_packed_spline():
+    # a covariance built from a packed Cholesky vector (set_subtensor on tril indices, exp on the diagonal) with
+    # a multivariate-normal logp through triangular solves, and a piecewise-linear basis regression whose knots
+    # are located by SearchsortedOp and gathered by index; logp and gradients
+    rng = np.random.default_rng(98)
+    packed = pt.dvector("packed")
+    Yv = pt.dmatrix("Yv")
+    knots, coef, xs, ys = pt.dvector("knots"), pt.dvector("coef"), pt.dvector("xs"), pt.dvector("ys")
+    k = 4
+    rows, cols = np.tril_indices(k)
+    L0 = pt.set_subtensor(pt.zeros((k, k))[rows, cols], packed)
+    L = pt.set_subtensor(L0[np.arange(k), np.arange(k)], pt.exp(pt.diag(L0)))
+    Zs = pt.linalg.solve_triangular(L, Yv.T, lower=True)
+    lp_mvn = -0.5 * (Zs**2).sum() - Yv.shape[0] * pt.log(pt.diag(L)).sum() - 0.5 * k * Yv.shape[0] * np.log(2 * np.pi)
+    seg = pt.clip(pt.searchsorted(knots, xs, side="right") - 1, 0, knots.shape[0] - 2)
+    t = (xs - knots[seg]) / (knots[seg + 1] - knots[seg])
+    fit = coef[seg] * (1.0 - t) + coef[seg + 1] * t
+    lp_fit = (-0.5 * (ys - fit) ** 2).sum()
+    logp = lp_mvn + lp_fit
+    n = 120
+    xv = np.sort(rng.uniform(0.0, 1.0, size=n))
+    vals = {"packed": rng.normal(size=k * (k + 1) // 2) * 0.4, "Yv": rng.normal(size=(35, k)), "knots": np.linspace(0.0, 1.0, 9),
+            "coef": rng.normal(size=9), "xs": xv, "ys": np.sin(6 * xv) + 0.1 * rng.normal(size=n)}
+    return [packed, Yv, knots, coef, xs, ys], [logp, *pytensor.grad(logp, [packed, coef]), seg], vals
