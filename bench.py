@@ -15,9 +15,10 @@ SURVEY.md §8e) and ``value`` = total evals / max-over-ranks time.
 The JSON line also carries
   roofline      the dominant kernel (gchain_*: one pass over X for X@beta and X.T@w): algorithmic
                 bytes (N*K*8 + 2*N*8 per launch) / mean launch duration measured live with HIP
-                events on the context stream; ``traffic`` = HBM bytes per launch from the committed
-                PMC passes (FETCH_SIZE corrected x2 + WRITE_SIZE, ``traffic_source`` names the
-                file — PMC counters cannot be collected inside the driver's plain run);
+                events on the context stream; ``traffic`` = HBM bytes per launch from two
+                ``rocprofv3 --pmc`` passes (FETCH_SIZE corrected x2, WRITE_SIZE) run as child processes
+                after the timed region at N=1; if the profiler is unavailable the committed summary
+                ``profiles/pmc_c4_current.json`` is used — ``traffic_source`` says which;
   cpu_baseline  the REFERENCE ITSELF on the host cores of this box: the same graph compiled by
                 the reference's C linker (``mode="CVM"``, ``trust_input=True``) from the importable
                 copy ``oracle/_ref`` (a built artefact that travels with the snapshot; test
@@ -53,6 +54,43 @@ def _load_graph(name):
 
     d = json.load(open(os.path.join(ROOT, "tests", "golden", f"{name}.json")))
     return Graph.from_dict(d), d["input_names"]
+
+
+def live_pmc_traffic(kernel_prefix):
+    """(HBM bytes per launch of the dominant kernel, how it was obtained) from two ``rocprofv3 --pmc``
+    passes over ``tools/profile_c4_replay.py`` run as child processes of this bench: FETCH_SIZE and
+    WRITE_SIZE need separate runs (TCC counter slots), the unit is KiB and on gfx950 FETCH_SIZE reports
+    half the bytes of a wide streaming read (MI355X_MICROARCH.md, HBM section).  (None, reason) when
+    rocprofv3 is unavailable or a pass fails — the caller falls back to the committed summary."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    per_kernel = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="pthip_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "tools", "profile_c4_replay.py"), "12"]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if not dbs:
+                return None, f"rocprofv3 --pmc {counter}: no rocpd database written"
+            rows = sqlite3.connect(dbs[0]).execute(
+                "select name, avg(counter_value) from pmc_events where counter_name=? group by name", (counter,)).fetchall()
+            per_kernel[counter] = dict(rows)
+        except Exception as e:  # noqa: BLE001 (any failure of the profiler pass: report it, do not fail the bench)
+            return None, f"rocprofv3 --pmc {counter}: {type(e).__name__}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    for name, fetch in per_kernel["FETCH_SIZE"].items():
+        if kernel_prefix in name.lower() or name.startswith(kernel_prefix):
+            total = fetch * 1024 * 2 + per_kernel["WRITE_SIZE"].get(name, 0.0) * 1024
+            return total, "live: rocprofv3 --pmc FETCH_SIZE (x2, KiB) and WRITE_SIZE in two child passes of this run, after the timed region"
+    return None, "dominant kernel not in the PMC passes"
 
 
 def _time_launches(lib, fn, reps=20):
@@ -156,6 +194,7 @@ def main():
     ap.add_argument("--rows", dest="n", type=int, default=1_000_000, help="observations N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config measurements (configs #1, #2, #3, #5)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed PMC summary instead of two rocprofv3 --pmc passes inside this run")
     ap.add_argument("--eager", action="store_true", help="per-node dispatch instead of the frozen hipGraph plan")
     ap.add_argument("--single-stream", action="store_true", help="frozen plan without the two-stream fork")
     args = ap.parse_args()
@@ -222,13 +261,19 @@ def main():
     if info.rank != 0:
         return
 
-    traffic = None
+    traffic, traffic_source = None, None
+    if args.n == 1_000_000 and info.world == 1 and not args.no_live_pmc and os.environ.get("PTHIP_BENCH_LIVE_PMC", "1") != "0":
+        # after the timed region: the same replay loop under rocprofv3, one counter per pass
+        traffic, traffic_source = live_pmc_traffic("gchain_" if op_dom == "GemvChain" else op_dom.lower())
     pmc_path = os.path.join(ROOT, "profiles", "pmc_c4_current.json")
-    if os.path.exists(pmc_path) and args.n == 1_000_000:
+    if traffic is None and os.path.exists(pmc_path) and args.n == 1_000_000:
+        why = traffic_source
         pmc = json.load(open(pmc_path))
         for k, v in pmc.items():
             if (op_dom == "GemvChain" and k.startswith("gchain_")) or op_dom.lower() in k.lower():
                 traffic = v["hbm_bytes"]
+                traffic_source = ("profiles/pmc_c4_current.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, committed)"
+                                  + (f"; live passes not used: {why}" if why else ""))
                 break
 
     cpu = None
@@ -268,7 +313,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "traffic_source": "profiles/pmc_c4_current.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None,
+            "traffic_source": traffic_source if traffic else None,
             "detail": {
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "kernel_ms": ms_kernel,
