@@ -70,6 +70,8 @@ def live_pmc_traffic(kernel_prefix):
 
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
+    if "rocprofiler-sdk-tool" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF_") for k in os.environ):
+        return None, "this run is itself being profiled (no counter passes nested inside a trace)"
     per_kernel = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="pthip_pmc_", dir="/tmp")

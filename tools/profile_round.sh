@@ -11,7 +11,7 @@ mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
 python $R/bench.py --steps 300 --warmup 30 > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats -d /tmp/pk_$TAG -o k -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-configs > $O/bench_under_rocprof.json 2> $O/kt.err
+rocprofv3 --kernel-trace --stats -d /tmp/pk_$TAG -o k -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-configs --no-live-pmc > $O/bench_under_rocprof.json 2> $O/kt.err
 python $R/tools/rocpd_stats.py $(find /tmp/pk_$TAG -name "*.db" | head -1) > $O/c4_kernel_stats.md
 rocprofv3 --kernel-trace -d /tmp/pr_$TAG -o k -- python $R/tools/profile_c4_replay.py 40 > $O/c4_replay.log 2>&1
 python $R/tools/rocpd_timeline.py $(find /tmp/pr_$TAG -name "*.db" | head -1) 24 > $O/c4_timeline.md
