@@ -64,3 +64,23 @@ def test_optional_special_function_helpers_compile_without_gpu():
                + "".join(f"  const double {nm} = a[{k}];\n" for k, nm in enumerate(names)) + "  double r;\n"
                + codegen.emit_body(body, names, ["r"], indent="  ") + "\n  o[0] = r;\n}\n")
         assert len(ffi.jit_compile(src, f"probe_{op}.hip")) > 1000, op
+
+
+def test_bench_traffic_falls_back_when_the_profiler_pass_fails(monkeypatch):
+    """bench.live_pmc_traffic: without a device the rocprofv3 child fails — a reason comes back, never an
+    exception, so the bench line is still printed (with the committed summary as ``traffic``); and no
+    counter passes are started from inside a profiled run."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    from pytensor_amd import ffi
+
+    if ffi.device_count() <= 0:
+        traffic, why = bench.live_pmc_traffic("gchain_")
+        assert traffic is None and isinstance(why, str) and why
+    monkeypatch.setenv("ROCPROF_OUTPUT_PATH", "/tmp/x")
+    traffic, why = bench.live_pmc_traffic("gchain_")
+    assert traffic is None and "profiled" in why
