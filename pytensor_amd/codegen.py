@@ -1485,7 +1485,7 @@ DOTEW_MAX_K = 16384
 _MFMA16 = {"float32": "__builtin_amdgcn_mfma_f32_16x16x4f32", "float64": "__builtin_amdgcn_mfma_f64_16x16x4f64"}
 
 
-def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chunk: int = DOTEW_CHUNK, share=None) -> str:
+def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chunk: int = DOTEW_CHUNK, share=None, lds_a: bool = False) -> str:
     """One 16x16 output tile per workgroup of ``out = body(.., A_d @ B_d, ..)``, full K.
 
     The recurrent products of a Scan step (``h @ U``: M = batch <= a few hundred rows, K = N =
@@ -1503,6 +1503,12 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
     ``share``: ``{follower dot position: leader dot position}`` — products with the SAME left
     operand (``h @ U_r`` and ``h @ U_z``): the leader's A registers feed both MFMA chains, the
     follower loads only its packed B (64 KB less per tile, and two independent accumulator chains).
+
+    ``lds_a`` (float32, K % 128 == 0): the left operand is fetched in full 128-byte lines by
+    LDS-DMA (``global_load_lds`` x4: per wave and pair of k-groups two 1 KiB copies, lane = (row l/8,
+    16-byte piece l%8 XOR row&7 on the source side so that the linear LDS image is bank-swizzled) and
+    the MFMA fragments are read back with ``ds_read_b128`` — instead of fragment-shaped loads (16 rows x
+    64 B per instruction), which the texture addresser serves at half rate.  Wave-local: no barrier.
 
     Arguments: M, N, then per body input — dot: (A, lda, Bp) | by value: bits | other:
     (ptr, stride0, stride1) — then per output (ptr, row stride)."""
@@ -1529,7 +1535,11 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
     L = [prelude_for(body)]
     L.append(f"typedef {ct} __attribute__((ext_vector_type(4))) dvec4;")
     L.append(f'extern "C" __global__ __launch_bounds__({BLOCK}) void {name}({", ".join(P)}) {{')
+    lds_a = bool(lds_a) and T == "float32" and K % 128 == 0 and chunk % 2 == 0
     L.append(f"  __shared__ {ct} red_[{nd}][4][256];")
+    if lds_a:
+        # per wave: two buffers of `chunk` k-groups = chunk/2 line pairs of 16 rows x 128 B
+        L.append(f"  __shared__ __attribute__((aligned(16))) float lda_[4][2][{chunk // 2}][16 * 32];")
     L.append("  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;")
     L.append("  const long long ctile = blockIdx.x, r0 = (long long)blockIdx.y * 16;")
     L.append("  const long long er = r0 + (tid >> 4), ec = ctile * 16 + (tid & 15);")
@@ -1582,11 +1592,28 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
         out = []
         for u in range(n):
             g = c0 + u
-            la = f"ra_[{s & 1}][{u}] = ap{gr[0]}[{g * 4}]; " + " ".join(f"{bufs[q]}[{s & 1}][{u}] = bp{p}[{g * 64}];" for q, p in enumerate(gr))
+            bl = " ".join(f"{bufs[q]}[{s & 1}][{u}] = bp{p}[{g * 64}];" for q, p in enumerate(gr))
+            if lds_a:
+                la = bl
+                if u % 2 == 0:
+                    # the 128-byte lines of k-groups g, g+1 of this wave's slice: rows 0-7, then 8-15
+                    for hr in (0, 1):
+                        la += (f" __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ag{gr[0]}_{hr} + {g * 16}), "
+                               f"(__attribute__((address_space(3))) void*)&lda_[wave][{s & 1}][{u // 2}][{hr * 256}], 16, 0, 0);")
+            else:
+                la = f"ra_[{s & 1}][{u}] = ap{gr[0]}[{g * 4}]; " + bl
             if guard:
                 zero = f"ra_[{s & 1}][{u}] = dvec4{{0, 0, 0, 0}}; " + " ".join(f"{bufs[q]}[{s & 1}][{u}] = dvec4{{0, 0, 0, 0}};" for q in range(len(gr)))
                 la = f"if (wave * {GW} + {g} < {G}) {{ {la} }} else {{ {zero} }}"
             out.append("  " + la)
+        return out
+
+    def frags(s):
+        """LDS path: the DMAs of chunk s have landed (vmcnt(0)); read its MFMA fragments"""
+        gr, c0, n = chunks[s]
+        out = ['  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");']
+        for u in range(n):
+            out.append(f"  ra_[{s & 1}][{u}] = *(const dvec4*)&lda_[wave][{s & 1}][{u // 2}][li * 32 + ((({4 * (u % 2)} + kq) ^ (li & 7)) << 2)];")
         return out
 
     def mfmas(s):
@@ -1600,13 +1627,30 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
 
     # issue order: operand chunks 0 and 1, then the epilogue operands (vmcnt retires in order:
     # requested first, a load from HBM would hold up the first MFMA group), then the MFMA stream
-    L += loads(0) + [SB]
-    for s in range(len(chunks)):
-        if s + 1 < len(chunks):
-            L += loads(s + 1) + [SB]
-        if s == 0:
-            L += ew_loads + [SB]
-        L += mfmas(s) + [SB]
+    if lds_a:
+        # source addresses of the two DMAs per line pair: lane l -> row l/8 (+8), piece (l%8) ^ (row&7)
+        L.append("  const int lr_ = lane >> 3, lc_ = lane & 7;")
+        for p in sorted({gr[0] for gr, _, _ in chunks}):
+            for hr in (0, 1):
+                L.append(f"  long long arow{p}_{hr} = r0 + lr_ + {8 * hr}; if (arow{p}_{hr} >= M) arow{p}_{hr} = M - 1;")
+                L.append(f"  const {ct}* ag{p}_{hr} = A{p} + arow{p}_{hr} * lda{p} + (long long)wave * {GW * 16} + ((lc_ ^ (lr_ & 7)) << 2);")
+        assert not guard
+        # (the DMA wait is a plain vmcnt(0): the epilogue operands are requested first so that it
+        #  never waits for anything younger than the chunk it needs)
+        L += ew_loads + [SB] + loads(0) + [SB]
+        for s in range(len(chunks)):
+            L += frags(s) + [SB]
+            if s + 1 < len(chunks):
+                L += loads(s + 1) + [SB]
+            L += mfmas(s) + [SB]
+    else:
+        L += loads(0) + [SB]
+        for s in range(len(chunks)):
+            if s + 1 < len(chunks):
+                L += loads(s + 1) + [SB]
+            if s == 0:
+                L += ew_loads + [SB]
+            L += mfmas(s) + [SB]
     # pin the epilogue operands here: without a use in this block the whole scalar graph, loads
     # included, is sunk into `if (live)` behind the barrier
     for e in early:

@@ -125,7 +125,10 @@ def dot_epilogue(node, inputs, env):
                 break
     if share:
         name += "_h" + "_".join(f"{a}.{b}" for a, b in sorted(share.items())).replace(".", "x")
-    src = codegen.dot_epilogue_source(name, body, dpos, K, byvalue, chunk, share)
+    lds_a = os.environ.get("PTHIP_DOTEW_LDSA", "0") == "1" and T == "float32" and K % 128 == 0 and chunk % 2 == 0
+    if lds_a:
+        name += "_la"
+    src = codegen.dot_epilogue_source(name, body, dpos, K, byvalue, chunk, share, lds_a)
     fn = kernel_cache.get_function(src, name)
     args = [M, N]
     for k, a in enumerate(ins):
