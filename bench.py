@@ -77,7 +77,7 @@ def live_pmc_traffic(kernel_prefix):
         d = tempfile.mkdtemp(prefix="pthip_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "tools", "profile_c4_replay.py"), "12"]
         try:
-            subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+            subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=60, check=True)
             dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
             if not dbs:
                 return None, f"rocprofv3 --pmc {counter}: no rocpd database written"
