@@ -12,6 +12,12 @@ For N>1 the driver launches one rank per GPU with torch.distributed.run; each ra
 evaluates an independent chain (weak scaling, no data-path collective: "replicas only",
 SURVEY.md §8e) and ``value`` = total evals / max-over-ranks time.
 
+``value`` / ``ms_per_step`` time the executor-level loop (the compiled ``HipExecutable`` plan called
+directly — the object ``HipLinker.jit_compile`` returns).  ``value_via_function`` /
+``ms_per_step_via_function`` time the same K steps through the drop-in API itself:
+``pytensor.function(params, outs, mode="hip")`` -> ``Function.__call__`` with ``trust_input=True``
+(rank 0, N=1; needs the importable reference copy ``oracle/_ref``, which travels with the snapshot).
+
 The JSON line also carries
   roofline      the dominant kernel (gchain_*: one pass over X for X@beta and X.T@w): algorithmic
                 bytes (N*K*8 + 2*N*8 per launch) / mean launch duration measured live with HIP
@@ -182,6 +188,46 @@ def cpu_baseline(graph, names, vals, inputs, out_hip, args):
     }
 
 
+def via_function(vals, out_hip, args):
+    """The same evaluation through the drop-in API: ``pytensor.function(params, outs, mode="hip")``
+    compiled by the reference's own ``FunctionMaker`` (from ``oracle/_ref``), called through
+    ``Function.__call__`` (compile/executor.py:651-744) and the JIT thunk (link/basic.py:670-684) with
+    ``trust_input=True`` — the leg the reference's C linker is timed on in ``cpu_baseline``.  Same
+    steps / warm-up as the executor-level timed region; every call returns host arrays, so the loop
+    needs no extra synchronisation.  ``None`` when the importable reference copy is absent."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import make_ref
+
+    if not make_ref.importable():
+        return None
+    make_ref.activate()
+    import pytensor
+
+    import pytensor_amd
+    import ref_graphs
+
+    pytensor_amd.register()
+    params, outs = ref_graphs.build_c4(vals)
+    t0 = time.perf_counter()
+    f = pytensor.function(params, outs, mode="hip")
+    t_compile = time.perf_counter() - t0
+    f.trust_input = True
+    pv = [np.asarray(vals[n]) for n in configs_params()]
+    first = f(*pv)  # eager; the second call captures the plan, later ones replay it
+    for a, b in zip(first, out_hip):
+        np.testing.assert_array_equal(a, b)  # same IR, same kernels as the executor-level leg
+    for _ in range(max(args.warmup, 3)):
+        f(*pv)
+    exe = f.vm.jit_fn
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        f(*pv)
+    el = time.perf_counter() - t0
+    return {"value": args.steps / el, "ms_per_step": el / args.steps * 1e3, "compile_s": t_compile,
+            "replays": exe.stats["replays"], "eager_calls": exe.stats["eager_calls"], "resident_uploads": exe.stats["resident_uploads"],
+            "resident_mode": str(pytensor.config.hip__resident)}
+
+
 def configs_params():
     from pytensor_amd import configs
 
@@ -195,6 +241,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows", dest="n", type=int, default=1_000_000, help="observations N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-via-function", action="store_true", help="skip the second timed leg through pytensor.function(mode='hip')")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config measurements (configs #1, #2, #3, #5)")
     ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed PMC summary instead of two rocprofv3 --pmc passes inside this run")
     ap.add_argument("--eager", action="store_true", help="per-node dispatch instead of the frozen hipGraph plan")
@@ -278,6 +325,10 @@ def main():
                                   + (f"; live passes not used: {why}" if why else ""))
                 break
 
+    fn_leg = None
+    if info.world == 1 and not args.no_via_function:
+        fn_leg = via_function(vals, out, args)
+
     cpu = None
     if not args.no_cpu_baseline and info.world == 1:
         cpu = cpu_baseline(graph, names, vals, inputs, out, args)
@@ -297,6 +348,11 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        # `value` is the executor-level loop (HipExecutable / FrozenPlan called directly, what every rank of
+        # a multi-GPU run times); the next two are the same K steps through pytensor.function(mode="hip")
+        # -> Function.__call__ (trust_input=True) on rank 0 at N=1, null where oracle/_ref is absent
+        "value_via_function": fn_leg["value"] if fn_leg else None,
+        "ms_per_step_via_function": fn_leg["ms_per_step"] if fn_leg else None,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -305,6 +361,8 @@ def main():
         "config": {
             "workload": "BASELINE.json configs[3]: hierarchical-normal logp + grad, N=%d, K=128, G=128, Cholesky(128); one chain per GPU" % args.n,
             "mode": "eager" if args.eager else "hipGraph plan",
+            "value_is": "executor-level loop (HipExecutable plan called directly); value_via_function = the same steps through pytensor.function(mode='hip')",
+            "via_function": fn_leg,
             "parallelism": f"replicas x{info.world}",
         },
         "roofline": {

@@ -87,6 +87,17 @@ int pthip_d2h(void* host_dst, const void* src, size_t bytes);
 int pthip_d2d(void* dst, const void* src, size_t bytes);
 int pthip_memset(void* dst, int byte, size_t bytes);
 
+/* Write tracking for a HOST array mirrored in HBM (a resident shared variable): the reference
+ * reads the storage cell on every call (pytensor/compile/sharedvalue.py:97-130 — `get_value(borrow=True)`
+ * hands out the storage, in-place edits must be seen).  `protect` makes the whole pages inside
+ * [host_ptr, host_ptr+bytes) read-only (callers pass a page-aligned interior and hash the ragged
+ * ends themselves); the first CPU store into them sets `*dirty_flag` (stable address, readable
+ * without a call), restores write access and proceeds.  `release` restores write access and frees
+ * the slot.  pthip_h2d opens every slot overlapping its source range first (the runtime may pin it). */
+int pthip_guard_protect(const void* host_ptr, size_t bytes, int* slot, const int** dirty_flag);
+int pthip_guard_release(int slot);
+int pthip_guard_stats(int* slots_in_use, int* slots_active);
+
 /* A private arena: between begin/end every pthip_alloc/pthip_free is served from a
  * private free list, so that a second, captured run of the same launch sequence sees
  * the same pointers.  Used to freeze a plan into a hipGraph. */

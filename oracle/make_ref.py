@@ -29,6 +29,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = os.environ.get("PYTENSOR_REFERENCE", "/root/reference")
 DST = os.path.join(HERE, "_ref")
+COMPILEDIR = os.environ.get("PTHIP_REF_COMPILEDIR", "/tmp/pthip_ref_compiledir")
 
 PEP695_FILES = [
     "gradient.py",
@@ -120,10 +121,12 @@ def activate() -> None:
     dst = build()
     if dst not in sys.path:
         sys.path.insert(0, dst)
-    os.environ.setdefault(
-        "PYTENSOR_FLAGS",
-        f"base_compiledir={os.path.join(DST, 'compiledir')},linker=cvm",
-    )
+    # The reference C linker's compile cache lives OUTSIDE the repo tree: its hundreds of per-Op
+    # thunk modules are neither product nor portable (the directory name carries the kernel
+    # release and the key the host's -march flags, so a cache built here misses on the GPU box
+    # anyway), and in-tree they crowd the product's one library out of the driver's record of
+    # loaded native code.
+    os.environ.setdefault("PYTENSOR_FLAGS", f"base_compiledir={COMPILEDIR},linker=cvm")
 
 
 def available() -> bool:

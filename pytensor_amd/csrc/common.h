@@ -40,6 +40,7 @@ struct Context {
 };
 
 Context& ctx();
+void guard_before_host_read(const void* p, size_t bytes);  // guard.hip
 int set_error(const char* fmt, ...);
 int check(hipError_t e, const char* what);
 

@@ -286,6 +286,7 @@ int pthip_h2d(void* dst, const void* src, size_t bytes) {
   if (!bytes) return 0;
   // (a pageable source would be snapshotted at call time by the runtime, not at replay time)
   if (g_ctx.recorder) { g_ctx.recorder->ok = false; g_ctx.recorder->why = "host-to-device copy"; }
+  ::pthip::guard_before_host_read(src, bytes);  // (guard.hip: a write-protected source is opened first)
   PTHIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_ctx.stream));
   return 0;
 }

@@ -31,7 +31,7 @@ import weakref
 
 import numpy as np
 
-from pytensor_amd import ffi
+from pytensor_amd import coherence, ffi
 from pytensor_amd.device import DeviceArray
 from pytensor_amd.ir import Graph
 
@@ -70,56 +70,28 @@ class HostValue:
 # ---------------------------------------------------------------------------------------
 # Resident (shared-variable) inputs: coherence between the host array and its HBM copy
 # ---------------------------------------------------------------------------------------
-# The reference backends read a shared variable's storage cell on every call, so an in-place
-# edit of a borrowed value (`get_value(borrow=True)[...] = v`, `set_value(x, borrow=True)` then
-# `x *= 2`; pytensor/compile/sharedvalue.py:97-130) is seen by the next call.  A device-resident
-# copy needs to notice such edits without re-reading gigabytes per call:
-#   * arrays <= 64 KiB: a 64-bit hash of the whole content on every call (sound);
-#   * larger arrays: a fingerprint of 256 evenly spaced elements incl. the first and the last
-#     (catches bulk overwrites and scaling, the usual borrow patterns; a single-element edit
-#     between the sample points is NOT seen — `PTHIP_RESIDENT=strict` hashes everything on
-#     every call, `HipExecutable.invalidate_resident()` forces a re-upload);
-#   * `PTHIP_RESIDENT=trust`: identity only (round-1 behaviour).
-_FULL_HASH_MAX = 64 << 10
-_NSAMPLE = 256
-_sample_cache = {}
-
-try:  # xxh3: ~10 GB/s; zlib.crc32 as the always-present fallback
-    from xxhash import xxh3_64_intdigest as _hash64
-except Exception:  # pragma: no cover
-    import zlib
-
-    def _hash64(buf):
-        return zlib.crc32(buf)
-
-
-_RESIDENT_MODE = os.environ.get("PTHIP_RESIDENT", "sampled")  # sampled | strict | trust
-
-
-def _fingerprint(a: np.ndarray):
-    mode = _RESIDENT_MODE
-    if mode == "trust":
-        return None
-    if a.nbytes <= _FULL_HASH_MAX or mode == "strict":
-        if a.size == 0:
-            return 0
-        c = a if a.flags.c_contiguous else np.ascontiguousarray(a)
-        return _hash64(c.reshape(-1).view(np.uint8).data)
-    idx = _sample_cache.get(a.size)
-    if idx is None:
-        idx = _sample_cache[a.size] = np.linspace(0, a.size - 1, _NSAMPLE).astype(np.int64)
-    return a.flat[idx].tobytes()
+# The reference backends read a shared variable's storage cell on every call; what keeps the
+# resident copy honest (write-protected pages by default, content hashes for small arrays) is in
+# pytensor_amd/coherence.py.  `HipExecutable.invalidate_resident()` forces a re-upload.
 
 
 class ResidentEntry:
     """One shared-variable input kept in HBM: a *stable* device buffer (frozen plans capture its
     address; a new host value of the same shape is copied into it in place), the host array it
-    mirrors (strong reference: keeps `id` unique) and the fingerprint of that array's content."""
+    mirrors (strong reference: keeps `id` unique, and the memory mapped while its pages are
+    write-protected) and the coherence token watching that array (coherence.watch)."""
 
     __slots__ = ("key", "dev", "host", "fp")
 
     def __init__(self, key, dev, host, fp):
         self.key, self.dev, self.host, self.fp = key, dev, host, fp
+
+    def rewatch(self, key, host, a):
+        coherence.release(self.fp)
+        self.key, self.host, self.fp = key, host, coherence.watch(a)
+
+    def __del__(self):
+        coherence.release(self.fp)
 
 
 def _resident_key(value, a):
@@ -465,14 +437,14 @@ class HipExecutable:
         if ent is not None and value is ent.host and ent.key is not None:
             # the very object that was uploaded (an ndarray cannot move its memory): only the
             # content can have changed
-            if ent.fp is None or ent.fp == _fingerprint(value):
+            if coherence.clean(ent.fp, value):
                 return ent.dev
             a, key = value, ent.key
         else:
             if a is None:
                 a = np.asarray(value)
             key = _resident_key(value, a)
-            if ent is not None and ent.key == key and (ent.fp is None or ent.fp == _fingerprint(a)):
+            if ent is not None and ent.key == key and coherence.clean(ent.fp, a):
                 return ent.dev
         self.stats["resident_uploads"] += 1
         if ent is not None and ent.dev.shape == a.shape and ent.dev.dtype == a.dtype:
@@ -481,37 +453,54 @@ class HipExecutable:
                 ffi.check(ffi.lib().pthip_h2d(ent.dev.ptr, c.ctypes.data, c.nbytes))
                 if env is not None:
                     env.keepalive.append(c)
-            ent.key, ent.host, ent.fp = key, value, _fingerprint(a)
+            ent.rewatch(key, value, a)  # (after the copy was issued: it reads the pages unprotected)
             return ent.dev
         dev = DeviceArray.from_host(a)
         if env is not None:
             env.keepalive.append(a)
-        self._resident_cache[pos] = ResidentEntry(key, dev, value, _fingerprint(a))
+        if ent is not None:
+            coherence.release(ent.fp)
+            ent.fp = None
+        self._resident_cache[pos] = ResidentEntry(key, dev, value, coherence.watch(a))
         return dev
 
     def invalidate_resident(self, pos=None):
         """Forget what is known about the host side of resident inputs (all, or one position):
-        the next call uploads them again.  For in-place edits the sampled fingerprint can miss."""
+        the next call uploads them again (needed only in the opt-in `sampled` / `trust` modes)."""
         for p, ent in self._resident_cache.items():
             if pos is None or p == pos:
                 ent.key = None
 
     # -- update feedback -------------------------------------------------------------------
     def _feed_updates_device(self, outs):
-        """Enqueue ``resident[pos] <- outs[o]`` (device to device, after every read of the old
-        value on the stream).  Returns the (pos, o) pairs that were fed."""
+        """Enqueue ``resident[pos] <- outs[o]`` (device to device) for every update pair — behind,
+        in stream order, every read of the old values: the graph's own kernels AND the copies that
+        carry the outputs to the host (an output may BE the old resident: ``insert_deepcopy``,
+        compile/aliasing.py:165-260, does not copy an output that aliases an updated input).
+        Two phases, because ``Function`` stores all updates after the call, i.e. simultaneously
+        (compile/executor.py:712-716): a source that lives in ANY resident buffer written here
+        (``{w_prev: w, w: f(w)}``, a swap ``{x: y, y: x}``, a shifted view of its own buffer) is
+        first copied aside; only then is any resident written.  Returns the (pos, o) pairs fed."""
         from pytensor_amd.device import copy_into
 
-        fed = []
+        todo = []
         for o, pos in self.update_map.items():
             ent = self._resident_cache.get(pos)
             src = outs[o]
             if ent is None or not isinstance(src, DeviceArray) or src.shape != ent.dev.shape or src.dtype != ent.dev.dtype:
                 continue  # (shape changed: the next call uploads the new host value)
-            if not (src.buf is ent.dev.buf and src.offset == ent.dev.offset and src.strides == ent.dev.strides):
+            todo.append((pos, o, ent, src))
+        written = {id(ent.dev.buf) for _, _, ent, _ in todo}
+        staged = []
+        for pos, o, ent, src in todo:
+            same = src.buf is ent.dev.buf and src.offset == ent.dev.offset and src.strides == ent.dev.strides
+            if not same and id(src.buf) in written:
+                src = src.contiguous_copy()
+            staged.append((pos, o, ent, src, same))
+        for pos, o, ent, src, same in staged:
+            if not same:
                 copy_into(ent.dev, src)
-            fed.append((pos, o))
-        return fed
+        return [(pos, o) for pos, o, *_ in staged]
 
     def _feed_updates_host(self, fed, host):
         """The arrays just returned are what ``Function`` installs in the storage cells: record
@@ -519,7 +508,7 @@ class HipExecutable:
         for pos, o in fed:
             ent = self._resident_cache[pos]
             h = host[o]
-            ent.key, ent.host, ent.fp = _resident_key(h, h), h, _fingerprint(h)
+            ent.rewatch(_resident_key(h, h), h, h)
 
     # ------------------------------------------------------------------
     def run_device(self, inputs, env=None):
@@ -661,7 +650,6 @@ class HipExecutable:
         self.stats["eager_calls"] += 1
         outs, env = self.run_device(inputs)
         self._warm = True
-        fed = self._feed_updates_device(outs) if self.update_map else ()
         lib = ffi.lib()
         host = []
         for o, vid in zip(outs, self.graph.outputs):
@@ -675,10 +663,13 @@ class HipExecutable:
         ffi.check(lib.pthip_synchronize())
         st = C.c_int(0)
         ffi.check(lib.pthip_check_status(C.byref(st)))
-        raise_device_status(st.value)
+        raise_device_status(st.value)  # (a call that raises commits no update: Function does not either)
         env.keepalive.clear()
-        if fed:
-            self._feed_updates_host(fed, host)
+        if self.update_map:
+            # only now: the outputs (old resident values among them) are on the host, the call succeeded
+            fed = self._feed_updates_device(outs)
+            if fed:
+                self._feed_updates_host(fed, host)
         if not self.graph.outputs:
             return None  # link/basic.py:690-699: a function without outputs must return None
         return tuple(host)

@@ -64,6 +64,9 @@ SIGNATURES = {
     "pthip_d2h": (_int, [_vp, _vp, _sz]),
     "pthip_d2d": (_int, [_vp, _vp, _sz]),
     "pthip_memset": (_int, [_vp, _int, _sz]),
+    "pthip_guard_protect": (_int, [_vp, _sz, C.POINTER(_int), C.POINTER(_vp)]),
+    "pthip_guard_release": (_int, [_int]),
+    "pthip_guard_stats": (_int, [C.POINTER(_int), C.POINTER(_int)]),
     "pthip_arena_begin": (_int, [C.POINTER(_vp)]),
     "pthip_arena_end": (_int, []),
     "pthip_arena_destroy": (_int, [_vp]),

@@ -14,7 +14,17 @@ import os
 from pytensor_amd import ffi
 from pytensor_amd.codegen import source_key
 
-CACHE_DIR = os.environ.get("PTHIP_KCACHE", os.path.join(os.path.dirname(os.path.abspath(__file__)), "_kcache"))
+_DEFAULT_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_kcache")
+CACHE_DIR = os.environ.get("PTHIP_KCACHE") or _DEFAULT_DIR  # (tests patch this; the flag below wins when set)
+
+
+def cache_dir() -> str:
+    """``config.hip__cache_dir`` when PyTensor is loaded and the flag is set, else ``CACHE_DIR``."""
+    import sys
+
+    pt = sys.modules.get("pytensor")
+    d = getattr(getattr(pt, "config", None), "hip__cache_dir", "") if pt is not None else ""
+    return d or CACHE_DIR
 
 _code = {}  # key -> bytes
 _funcs = {}  # (key, name) -> function handle
@@ -31,7 +41,8 @@ def compile_source(src: str, name: str) -> str:
     key = source_key(src)
     if key in _code:
         return key
-    path = os.path.join(CACHE_DIR, f"{key}.hsaco")
+    cdir = cache_dir()
+    path = os.path.join(cdir, f"{key}.hsaco")
     if os.path.exists(path):
         with open(path, "rb") as fh:
             _code[key] = fh.read()
@@ -39,7 +50,7 @@ def compile_source(src: str, name: str) -> str:
     code = ffi.jit_compile(src, name + ".hip")
     _code[key] = code
     try:
-        os.makedirs(CACHE_DIR, exist_ok=True)
+        os.makedirs(cdir, exist_ok=True)
         tmp = f"{path}.{os.getpid()}.tmp"
         with open(tmp, "wb") as fh:
             fh.write(code)

@@ -54,10 +54,10 @@ class HipLinker(JITLinker):
         from pytensor_amd.lower import lower_fgraph
 
         # No silent CPU fallback: an Op without a device lowering is an error unless the user
-        # opts in to the D2H -> Op.perform -> H2D detour (PTHIP_ALLOW_HOST_PERFORM=1).
-        import os
+        # opts in to the D2H -> Op.perform -> H2D detour (config.hip__allow_host_perform).
+        from pytensor.configdefaults import config
 
-        graph = lower_fgraph(fgraph, allow_host_fallback=os.environ.get("PTHIP_ALLOW_HOST_PERFORM") == "1")
+        graph = lower_fgraph(fgraph, allow_host_fallback=bool(config.hip__allow_host_perform))
         self.last_ir = graph
         # shared variables = data: uploaded once and kept in HBM (re-uploaded when the storage cell
         # holds a different array or the array's content fingerprint changed: executor._refresh_resident)
@@ -70,11 +70,14 @@ class HipLinker(JITLinker):
         return graph
 
     def jit_compile(self, graph):
+        from pytensor.configdefaults import config
+
         from pytensor_amd.executor import HipExecutable
 
         # repeated calls with one input signature replay a captured hipGraph (the CVM analogue)
-        return HipExecutable(graph, resident=getattr(self, "_resident", ()), auto_freeze=True,
-                             update_map=getattr(self, "_update_map", None))
+        return HipExecutable(graph, resident=getattr(self, "_resident", ()), auto_freeze=bool(config.hip__auto_freeze),
+                             update_map=getattr(self, "_update_map", None),
+                             device=None if config.hip__device < 0 else int(config.hip__device))
 
     def create_thunk_inputs(self, storage_map):
         # cf. pytensor/link/pytorch/linker.py:97-104: every fgraph input,
@@ -83,7 +86,60 @@ class HipLinker(JITLinker):
         return [storage_map[n] for n in self.fgraph.inputs]
 
 
+def _add_config_flags():
+    """``hip__*`` flags, declared the way every backend flag of the reference is
+    (pytensor/configdefaults.py:183 ``config.add``; sources: ``PYTENSOR_FLAGS``, ``~/.pytensorrc``,
+    ``pytensor.config.change_flags``).  The ``PTHIP_*`` environment variables of earlier rounds
+    remain as the defaults, so existing set-ups keep working."""
+    import os
+
+    from pytensor.configdefaults import config
+    from pytensor.configparser import BoolParam, EnumStr, IntParam, StrParam
+
+    if hasattr(config, "hip__resident"):
+        return
+    env = os.environ.get
+    modes = ["guard", "strict", "sampled", "trust"]
+    default = env("PTHIP_RESIDENT", "guard")
+    config.add(
+        "hip__resident",
+        "How the hip linker keeps the HBM copy of a shared variable coherent with its host array "
+        "(which the reference reads on every call): 'guard' write-protects the array's pages and "
+        "re-uploads after the first store (sound, free when nothing changes); 'strict' hashes the "
+        "whole array on every call; 'sampled' checks 256 elements (may miss sparse in-place edits); "
+        "'trust' checks identity only.",
+        EnumStr(default, [m for m in modes if m != default], mutable=True),
+        in_c_key=False,
+    )
+    config.add(
+        "hip__device",
+        "HIP device ordinal the process binds to (-1: device 0, or the rank's device under pytensor_amd.replicas).",
+        IntParam(int(env("PTHIP_DEVICE", "-1")), mutable=True),
+        in_c_key=False,
+    )
+    config.add(
+        "hip__cache_dir",
+        "Directory of the generated-kernel cache (gfx950 code objects keyed by source hash; the analogue of compiledir). "
+        "Empty: pytensor_amd/_kcache next to the package.",
+        StrParam(env("PTHIP_KCACHE", ""), mutable=True),
+        in_c_key=False,
+    )
+    config.add(
+        "hip__auto_freeze",
+        "Capture the launch sequence of a repeated call signature into a hipGraph plan and replay it (the CVM analogue).",
+        BoolParam(env("PTHIP_AUTO_FREEZE", "1") != "0", mutable=True),
+        in_c_key=False,
+    )
+    config.add(
+        "hip__allow_host_perform",
+        "Run Ops without a device lowering through Op.perform on the host (D2H, perform, H2D) instead of raising at compile time.",
+        BoolParam(env("PTHIP_ALLOW_HOST_PERFORM") == "1", mutable=True),
+        in_c_key=False,
+    )
+
+
 def _register():
+    _add_config_flags()
     from pytensor.compile.rewriting import rewrite_ofg_inner_graph, _ofg_inner_optimizer
     from pytensor.scan.rewriting.inner_graph import rewrite_scan_inner_graph
 

@@ -487,13 +487,20 @@ class FrozenPlan:
                     raise SignatureChanged(f"frozen plan: input {pos} changed signature {self._sig[pos]} -> {(a.shape, str(a.dtype))}")
             v[...] = a
         exe = self.exe
-        late = []  # residents still held by the object that was uploaded: content check deferred
+        late = []  # residents still held by the object that was uploaded, watched by a content hash: check deferred
         for pos, dev in self._resident_devs.items():
             v = inputs[pos]
             ent = exe._resident_cache[pos]
             if v is ent.host and ent.key is not None:
-                if ent.fp is not None:
+                tok = ent.fp
+                if tok is None:
+                    continue
+                if tok.late:
                     late.append((pos, ent, v))
+                elif not tok.clean(v):
+                    # write-protected pages saw a store (coherence._Guard): upload before launching
+                    ent.key = None
+                    exe._refresh_resident(pos, v)
             elif exe._refresh_resident(pos, v) is not dev:
                 raise SignatureChanged(f"frozen plan: resident input {pos} changed shape or dtype; re-freeze")
         for pos, b in self._baked.items():
@@ -505,12 +512,10 @@ class FrozenPlan:
         if not late:
             self._replay(True, mine)  # one native call: H2D, graphs, D2H, stream synchronisation
         else:
-            # launch first, fingerprint the resident host arrays while the GPU works (a borrowed
-            # shared value edited in place, executor._fingerprint): the check costs the call nothing
+            # launch first, hash the resident host arrays while the GPU works (a borrowed shared
+            # value edited in place, pytensor_amd/coherence.py): the check costs the call nothing
             self._replay(False, mine)
-            from pytensor_amd.executor import _fingerprint
-
-            dirty = [pos for pos, ent, v in late if _fingerprint(v) != ent.fp]
+            dirty = [pos for pos, ent, v in late if not ent.fp.clean(v)]
             if dirty:
                 # the replay in flight read stale data: discard it, upload what changed (and put
                 # back every update-fed resident, which that replay advanced), run again
@@ -529,6 +534,11 @@ class FrozenPlan:
             ob.views[-1][0] = 0
             if mine is not None:
                 ring.free.append(mine)
+            # a call that raises commits no update (compile/executor.py:712-716 is not reached), but the
+            # replay has already advanced the update-fed residents: the next call uploads the storage
+            # cells' (old) values again
+            for p, _ in self._fed:
+                self.exe._resident_cache[p].key = None
             raise_device_status(word)
         fresh = ring.hand_out(mine) if mine is not None else None
         res = []

