@@ -1485,7 +1485,7 @@ DOTEW_MAX_K = 16384
 _MFMA16 = {"float32": "__builtin_amdgcn_mfma_f32_16x16x4f32", "float64": "__builtin_amdgcn_mfma_f64_16x16x4f64"}
 
 
-def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chunk: int = DOTEW_CHUNK, share=None, lds_a: bool = False) -> str:
+def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chunk: int = DOTEW_CHUNK, share=None, lds_a: bool = False, var: str = "") -> str:
     """One 16x16 output tile per workgroup of ``out = body(.., A_d @ B_d, ..)``, full K.
 
     The recurrent products of a Scan step (``h @ U``: M = batch <= a few hundred rows, K = N =
@@ -1509,6 +1509,13 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
     16-byte piece l%8 XOR row&7 on the source side so that the linear LDS image is bank-swizzled) and
     the MFMA fragments are read back with ``ds_read_b128`` — instead of fragment-shaped loads (16 rows x
     64 B per instruction), which the texture addresser serves at half rate.  Wave-local: no barrier.
+
+    ``var``: ``"acc2"`` gives a product that has an accumulator chain to itself two of them (even /
+    odd k-groups, added at the end): ``v_mfma_f32_16x16x4_f32`` issues every 32 cycles but its result
+    feeds a dependent MFMA only after 40 (MI355X_MICROARCH.md), so a single chain runs at 80 %.
+    The other values are TIMING-ONLY decompositions (wrong results; tools/dotew_variants.py):
+    ``nomfma`` (VALU stand-ins for the MFMAs), ``noload`` (operands from a kernel argument),
+    ``apacked`` (the left operand fetched with the packed operand's 1-KiB-contiguous pattern).
 
     Arguments: M, N, then per body input — dot: (A, lda, Bp) | by value: bits | other:
     (ptr, stride0, stride1) — then per output (ptr, row stride)."""
@@ -1562,9 +1569,16 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
     #  flight per MFMA group, and the epilogue operands requested after the barrier)
     SB = "  __builtin_amdgcn_sched_barrier(0);"
     L.append("  long long arow = r0 + li; if (arow >= M) arow = M - 1;")
+    if "noload" in var:
+        L.append(f"  const {ct} fake_ = ({ct})M;")
     for p in dot_pos:
         L.append(f"  dvec4 acc{p} = {{0, 0, 0, 0}};")
-        L.append(f"  const dvec4* ap{p} = (const dvec4*)(A{p} + arow * lda{p}) + ((long long)wave * {GW * 4} + kq);")
+        if "acc2" in var:
+            L.append(f"  dvec4 acd{p} = {{0, 0, 0, 0}};")
+        if "apacked" in var:
+            L.append(f"  const dvec4* ap{p} = (const dvec4*)A{p} + (((long long)blockIdx.y * {K // 4} + (long long)wave * {GW * 4} + kq) * 16 + li);")
+        else:
+            L.append(f"  const dvec4* ap{p} = (const dvec4*)(A{p} + arow * lda{p}) + ((long long)wave * {GW * 4} + kq);")
         L.append(f"  const dvec4* bp{p} = (const dvec4*)Bp{p} + ((ctile * {K // 4} + (long long)wave * {GW * 4} + kq) * 16 + li);")
     # the stream of (dot group, chunk) register buffers, double-buffered; a group = a leader and
     # the dots that share its left operand (at most one follower: register budget)
@@ -1601,7 +1615,10 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
                         la += (f" __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ag{gr[0]}_{hr} + {g * 16}), "
                                f"(__attribute__((address_space(3))) void*)&lda_[wave][{s & 1}][{u // 2}][{hr * 256}], 16, 0, 0);")
             else:
-                la = f"ra_[{s & 1}][{u}] = ap{gr[0]}[{g * 4}]; " + bl
+                la = f"ra_[{s & 1}][{u}] = ap{gr[0]}[{g * (64 if 'apacked' in var else 4)}]; " + bl
+                if "noload" in var:
+                    la = (f"ra_[{s & 1}][{u}] = dvec4{{fake_, fake_, fake_, fake_}}; "
+                          + " ".join(f"{bufs[q]}[{s & 1}][{u}] = dvec4{{fake_, fake_, fake_, fake_}};" for q in range(len(gr))))
             if guard:
                 zero = f"ra_[{s & 1}][{u}] = dvec4{{0, 0, 0, 0}}; " + " ".join(f"{bufs[q]}[{s & 1}][{u}] = dvec4{{0, 0, 0, 0}};" for q in range(len(gr)))
                 la = f"if (wave * {GW} + {g} < {G}) {{ {la} }} else {{ {zero} }}"
@@ -1622,7 +1639,11 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
         for u in range(n):
             for j in range(4):
                 for q, p in enumerate(gr):
-                    out.append(f"  acc{p} = {_MFMA16[T]}(ra_[{s & 1}][{u}][{j}], {bufs[q]}[{s & 1}][{u}][{j}], acc{p}, 0, 0, 0);")
+                    acc = f"acd{p}" if ("acc2" in var and len(gr) == 1 and (u & 1)) else f"acc{p}"
+                    if "nomfma" in var:
+                        out.append(f"  acc{p}[{j}] += ra_[{s & 1}][{u}][{j}] * {bufs[q]}[{s & 1}][{u}][{j}];")
+                    else:
+                        out.append(f"  {acc} = {_MFMA16[T]}(ra_[{s & 1}][{u}][{j}], {bufs[q]}[{s & 1}][{u}][{j}], {acc}, 0, 0, 0);")
         return out
 
     # issue order: operand chunks 0 and 1, then the epilogue operands (vmcnt retires in order:
@@ -1655,6 +1676,9 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
     # included, is sunk into `if (live)` behind the barrier
     for e in early:
         L.append(f'  asm volatile("" : "+v"({e}));')
+    if "acc2" in var:
+        for p in dot_pos:
+            L.append(f"  acc{p} += acd{p};")
     for d, p in enumerate(dot_pos):
         # accumulator register v of lane (li, kq): f32 16x16x4 -> row 4*kq + v; f64 -> row kq + 4*v
         row = "4 * kq + v" if T == "float32" else "kq + 4 * v"

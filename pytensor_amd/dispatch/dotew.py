@@ -128,7 +128,10 @@ def dot_epilogue(node, inputs, env):
     lds_a = os.environ.get("PTHIP_DOTEW_LDSA", "0") == "1" and T == "float32" and K % 128 == 0 and chunk % 2 == 0
     if lds_a:
         name += "_la"
-    src = codegen.dot_epilogue_source(name, body, dpos, K, byvalue, chunk, share, lds_a)
+    var = os.environ.get("PTHIP_DOTEW_VAR", "acc2")  # (tools/dotew_variants.py: timing-only decompositions)
+    if var:
+        name += "_" + var.replace(",", "_")
+    src = codegen.dot_epilogue_source(name, body, dpos, K, byvalue, chunk, share, lds_a, var)
     fn = kernel_cache.get_function(src, name)
     args = [M, N]
     for k, a in enumerate(ins):

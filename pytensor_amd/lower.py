@@ -552,9 +552,9 @@ def _(op, node, ctx):
 def _(op, node, ctx):
     info = op.info
     inner = lower_fgraph(op.fgraph, name="scan_inner")
-    if any(v.kind == "rng" for v in inner.vars.values()):
-        raise NotImplementedError("hip linker: random draws inside a Scan are not lowered "
-                                  "(the generator would have to be carried as a Scan state)")
+    # (a generator used inside the loop is an untraced sit-sot state or a non-sequence of the Scan,
+    #  scan/op.py:211 `ScanInfo.n_untraced_sit_sot`: the step driver hands the `RngState` of step t
+    #  to step t+1 like any other untraced value, dispatch/scan.py)
     return "Scan", {
         "info": {
             "n_seqs": info.n_seqs,

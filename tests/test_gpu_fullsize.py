@@ -134,29 +134,57 @@ def test_c4_hier_logp_grad_N1e6(hip):
 
 
 def test_c5_gru_scan_T1000_B64_H1024_f32(hip):
-    """1000 dependent steps in fp32: rounding differences between two correct implementations
-    (OpenBLAS sgemm vs MFMA split-K) are *amplified by the recurrence*, so a per-step bound does
-    not carry to t=1000.  Two assertions: (1) one step from the oracle's own state — the op-level
-    statement north_star makes — holds element-wise at rtol 1e-5 + the dot-product bound for every
-    t we probe; (2) the full 1000-step output agrees to 2e-4 relative (measured ~3e-5)."""
+    """1000 dependent steps in fp32.  Rounding differences between two correct fp32 implementations
+    (OpenBLAS sgemm's blocked summation vs the MFMA k-ordered fma chain) are *amplified by the
+    recurrence*, so north_star's per-op tolerance does not carry from step to trajectory.  That is
+    shown here, not argued:
+
+    (1) TRUTH: the same trajectory evaluated in fp64 (NumPy, same inputs).  Both fp32 results are
+        compared with it.  Asserted: every element of the HIP result is within ``C_TRAJ`` x the
+        reference oracle's own WORST element error, and the HIP error's RMS and 99.9th percentile
+        are within ``C_TRAJ`` x the oracle's — i.e. the device is as close to the exact
+        trajectory as the reference's arithmetic is.  (An element-by-element ratio of the two
+        error fields is not a meaningful statistic: each is a zero-mean rounding process and the
+        oracle's error passes through zero somewhere.)
+    (2) PER STEP: from the oracle's own state h_t at EVERY 50th step, one step on the device vs one
+        step of the oracle, element-wise at north_star's rtol 1e-5 plus the dot-product bound
+        c·eps·sum|term| (the op-level statement north_star makes)."""
     from pytensor_amd.executor import HipExecutable
 
+    C_TRAJ = 2.0
     T, B, H = 1000, 64, 1024
     v = configs.c5_inputs(T=T, B=B, H=H)
     g, names = load("c5_gru")
     ins = [v[n] for n in names]
     exe = HipExecutable(g, resident=range(len(ins)))
     got = exe(*ins)
-    want = np_graph.run_graph(g, ins)
-    for k, (a, b) in enumerate(zip(got, want)):
+    want = np_graph.run_graph(g, ins)  # the oracle in fp32 (NumPy / OpenBLAS sgemm)
+    states = _gru_states(v, steps=tuple(range(0, T, 50)) + (T - 1,))  # oracle-arithmetic h_t, fp32
+    h64 = _gru_final_f64(v)  # the exact-arithmetic stand-in
+    truth = [np.float64(h64.sum()), h64]
+    for k, (a, b, t64) in enumerate(zip(got, want, truth)):
         assert a.shape == b.shape and a.dtype == b.dtype
-        rel = float(np.max(np.abs(a.astype("float64") - b)) / np.max(np.abs(b)))  # norm-wise: entries of h cross zero
-        MARGINS[f"c5_full.out{k}"] = {"max_rel_err": rel}
-        print(f"c5 out{k}: rel err after {T} steps = {rel:.3e}")
-        assert rel < 2e-4
-    # (1) single steps from identical states: T=1 problems seeded with the oracle's h_t
-    hs = _gru_states(v, steps=(0, 1, 499, 998))
-    for t, h_t in hs.items():
+        e_hip = np.abs(a.astype("float64") - t64)
+        e_ref = np.abs(b.astype("float64") - t64)
+        stats = {
+            "max_err_hip": float(e_hip.max()), "max_err_oracle": float(e_ref.max()),
+            "rms_err_hip": float(np.sqrt(np.mean(e_hip**2))), "rms_err_oracle": float(np.sqrt(np.mean(e_ref**2))),
+            "hip_vs_oracle_rel": float(np.max(np.abs(a.astype("float64") - b)) / np.max(np.abs(b))),
+        }
+        if a.ndim:
+            stats["p999_err_hip"], stats["p999_err_oracle"] = float(np.quantile(e_hip, 0.999)), float(np.quantile(e_ref, 0.999))
+        MARGINS[f"c5_full.out{k}"] = stats
+        print(f"c5 out{k}: vs fp64 trajectory after {T} steps: {stats}")
+        if a.ndim == 0:
+            # out0 = sum of the B*H entries of h_T: its error is a sum of B*H element errors of either sign
+            assert e_hip <= C_TRAJ * max(float(e_ref), EPS32 * float(np.abs(h64).sum()) / np.sqrt(h64.size))
+            continue
+        assert e_hip.max() <= C_TRAJ * e_ref.max(), "an element further from the fp64 trajectory than the oracle's worst"
+        assert stats["rms_err_hip"] <= C_TRAJ * stats["rms_err_oracle"]
+        assert stats["p999_err_hip"] <= C_TRAJ * stats["p999_err_oracle"]
+    # (2) single steps from identical states: T=1 problems seeded with the oracle's h_t
+    worst = 0.0
+    for t, h_t in states.items():
         v1 = dict(v)
         v1["xs"] = v["xs"][t : t + 1]
         v1["h0"] = h_t
@@ -170,6 +198,8 @@ def test_c5_gru_scan_T1000_B64_H1024_f32(hip):
         S = np.abs(v["xs"][t]) @ (np.abs(v["Wz"]) + np.abs(v["Wr"]) + np.abs(v["Wh"])) + np.abs(h_t) @ (
             np.abs(v["Uz"]) + np.abs(v["Ur"]) + np.abs(v["Uh"]))
         check(f"c5_step{t}", 1, a[1], b[1], 1e-5, atol=C_SUM * EPS32 * S)
+        worst = max(worst, MARGINS.get(f"c5_step{t}.out1", {}).get("max_err_over_bound", 0.0))
+    print(f"c5 single steps at t = 0, 50, ..., 950, 999: worst err/bound = {worst:.3f}")
 
 
 def _sig(x):
@@ -181,6 +211,22 @@ def _gru_step(v, x, h):
     r = _sig(x @ v["Wr"] + h @ v["Ur"] + v["br"])
     hh = np.tanh(x @ v["Wh"] + (r * h) @ v["Uh"] + v["bh"])
     return ((1 - z) * h + z * hh).astype("float32")
+
+
+def _gru_final_f64(v):
+    """h_T of the same recurrence evaluated in fp64 from the fp32 inputs (the exact trajectory up to
+    fp64 rounding, 2^29 times finer than the fp32 effects measured against it)."""
+    w = {k: np.asarray(a, dtype="float64") for k, a in v.items() if isinstance(a, np.ndarray)}
+    h = w["h0"]
+    T, B, H = w["xs"].shape
+    x2 = w["xs"].reshape(T * B, H)
+    xz, xr, xh = ((x2 @ w[n] + w[b]).reshape(T, B, H) for n, b in (("Wz", "bz"), ("Wr", "br"), ("Wh", "bh")))  # (one large product each)
+    for t in range(T):
+        z = _sig(xz[t] + h @ w["Uz"])
+        r = _sig(xr[t] + h @ w["Ur"])
+        hh = np.tanh(xh[t] + (r * h) @ w["Uh"])
+        h = (1 - z) * h + z * hh
+    return h
 
 
 def _gru_states(v, steps):
