@@ -1011,7 +1011,7 @@ def _flat_params(body: dict, modes: str, reduce_spec, vec: int):
     return params
 
 
-def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=None, unroll=2, device_fn=False) -> str:
+def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=None, unroll=2, device_fn=False, prefetch=False) -> str:
     """``flat`` loop.  ``modes[k]`` ∈ {'V' contiguous vector, 'S' scalar broadcast} per input.
 
     reduce_spec: None or list (per output) of None | (op_name, acc_dtype): reduced
@@ -1021,6 +1021,13 @@ def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=
     ``device_fn``: emit the loop as a ``__device__`` function taking the workgroup index and count as
     two trailing arguments, without the headers (``multi_flat_source`` dispatches several of them
     from one launch).
+
+    ``prefetch``: software-pipelined main loop — the packs of iteration i+1 are requested before the
+    scalar graph of iteration i runs, so a wave keeps ``unroll`` x 16 B per operand in flight WHILE
+    it computes.  For a long fp64 body (BASELINE config #2: ~270 VALU instructions per 4 elements,
+    17 us of issue next to 25 us of HBM time) the plain loop alternates between the two — every
+    wave either waits or computes, and the bytes in flight per CU drop with the share of waves
+    that are computing; pipelined, the two overlap.
     """
     nin = len(body["in_dtypes"])
     nout = len(body["out_dtypes"])
@@ -1050,12 +1057,39 @@ def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=
         src.append(f"  const long long npack = n / {V};")
         # main vector loop, `unroll` packs per iteration
         src.append(f"  long long p = tid;")
-        src.append(f"  for (; p + {unroll - 1} * nthreads < npack; p += {unroll} * nthreads) {{")
-        for u in range(unroll):
-            for k, m in enumerate(modes):
-                if m == "V":
-                    ct = CTYPE[body["in_dtypes"][k]]
-                    src.append(f"    const {_vec_type(ct, V)} a{k}_{u} = {_stream_load(f'reinterpret_cast<const {_vec_type(ct, V)}*>(in{k}) + (p + {u} * nthreads)', struct=True)};")
+        vins = [(k, CTYPE[body["in_dtypes"][k]]) for k, m in enumerate(modes) if m == "V"]
+
+        def _ld(k, ct, u, pv):
+            return _stream_load(f'reinterpret_cast<const {_vec_type(ct, V)}*>(in{k}) + ({pv} + {u} * nthreads)', struct=True)
+
+        if prefetch and vins:
+            for u in range(unroll):
+                for k, ct in vins:
+                    src.append(f"  {_vec_type(ct, V)} n{k}_{u};")
+            src.append(f"  bool pt_more = p + {unroll - 1} * nthreads < npack;")
+            src.append("  if (pt_more) {")
+            for u in range(unroll):
+                for k, ct in vins:
+                    src.append(f"    n{k}_{u} = {_ld(k, ct, u, 'p')};")
+            src.append("  }")
+            src.append("  while (pt_more) {")
+            for u in range(unroll):
+                for k, ct in vins:
+                    src.append(f"    const {_vec_type(ct, V)} a{k}_{u} = n{k}_{u};")
+            src.append(f"    const long long pn = p + {unroll} * nthreads;")
+            src.append(f"    pt_more = pn + {unroll - 1} * nthreads < npack;")
+            src.append("    if (pt_more) {")
+            for u in range(unroll):
+                for k, ct in vins:
+                    src.append(f"      n{k}_{u} = {_ld(k, ct, u, 'pn')};")
+            src.append("    }")
+            # (the machine scheduler would otherwise sink the requests next to their first use)
+            src.append("    __builtin_amdgcn_sched_barrier(0);")
+        else:
+            src.append(f"  for (; p + {unroll - 1} * nthreads < npack; p += {unroll} * nthreads) {{")
+            for u in range(unroll):
+                for k, ct in vins:
+                    src.append(f"    const {_vec_type(ct, V)} a{k}_{u} = {_ld(k, ct, u, 'p')};")
         for u in range(unroll):
             for k, dt in enumerate(body["out_dtypes"]):
                 if reduce_spec[k] is None:
@@ -1077,6 +1111,8 @@ def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=
             for k, dt in enumerate(body["out_dtypes"]):
                 if reduce_spec[k] is None:
                     src.append(f"    reinterpret_cast<{_vec_type(CTYPE[dt], V)}*>(out{k})[p + {u} * nthreads] = r{k}_{u};")
+        if prefetch and vins:
+            src.append("    p = pn;")
         src.append("  }")
         # remaining packs one at a time, then the scalar tail
         src.append(f"  for (; p < npack; p += nthreads) {{")
@@ -1485,7 +1521,8 @@ DOTEW_MAX_K = 16384
 _MFMA16 = {"float32": "__builtin_amdgcn_mfma_f32_16x16x4f32", "float64": "__builtin_amdgcn_mfma_f64_16x16x4f64"}
 
 
-def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chunk: int = DOTEW_CHUNK, share=None, lds_a: bool = False, var: str = "") -> str:
+def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chunk: int = DOTEW_CHUNK, share=None, lds_a: bool = False, var: str = "",
+                        packed_a=(), pack_outs=()) -> str:
     """One 16x16 output tile per workgroup of ``out = body(.., A_d @ B_d, ..)``, full K.
 
     The recurrent products of a Scan step (``h @ U``: M = batch <= a few hundred rows, K = N =
@@ -1517,9 +1554,19 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
     ``nomfma`` (VALU stand-ins for the MFMAs), ``noload`` (operands from a kernel argument),
     ``apacked`` (the left operand fetched with the packed operand's 1-KiB-contiguous pattern).
 
+    ``packed_a``: dot positions whose LEFT operand arrives in the MFMA operand order as well
+    (``Ap[M/16][K/4][16][4]``, ``Ap[rt][k4][i][j] = A[16 rt + i][4 k4 + j]``): a wave's load is then
+    1 KiB contiguous like the packed right operand, instead of 16 row segments of 64 B (measured
+    with the timing-only ``apacked`` variant: -1.1 us per GRU step, profiles/r3a_dotew_variants.txt).
+    ``pack_outs``: outputs this kernel ALSO stores in that order (one extra pointer each, after the
+    regular outputs) because a later step kernel multiplies them from the left: the 16x16 tile a
+    workgroup owns is one contiguous 1 KiB piece of the packed image.  Needs N % 16 == 0.
+
     Arguments: M, N, then per body input — dot: (A, lda, Bp) | by value: bits | other:
-    (ptr, stride0, stride1) — then per output (ptr, row stride)."""
+    (ptr, stride0, stride1) — then per output (ptr, row stride), then per packed output its pointer."""
     dot_pos = list(dot_pos)
+    packed_a = set(packed_a)
+    pack_outs = list(pack_outs)
     byvalue = set(byvalue)
     T = body["in_dtypes"][dot_pos[0]]
     assert T in _MFMA16 and all(body["in_dtypes"][p] == T for p in dot_pos)
@@ -1539,6 +1586,8 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
             P += [f"const {CTYPE[dt]}* __restrict__ in{k}", f"long long s{k}_0", f"long long s{k}_1"]
     for k, dt in enumerate(body["out_dtypes"]):
         P += [f"{CTYPE[dt]}* __restrict__ out{k}", f"long long ldo{k}"]
+    for k in pack_outs:
+        P.append(f"{CTYPE[body['out_dtypes'][k]]}* __restrict__ pk{k}")
     L = [prelude_for(body)]
     L.append(f"typedef {ct} __attribute__((ext_vector_type(4))) dvec4;")
     L.append(f'extern "C" __global__ __launch_bounds__({BLOCK}) void {name}({", ".join(P)}) {{')
@@ -1575,7 +1624,7 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
         L.append(f"  dvec4 acc{p} = {{0, 0, 0, 0}};")
         if "acc2" in var:
             L.append(f"  dvec4 acd{p} = {{0, 0, 0, 0}};")
-        if "apacked" in var:
+        if "apacked" in var or p in packed_a:
             L.append(f"  const dvec4* ap{p} = (const dvec4*)A{p} + (((long long)blockIdx.y * {K // 4} + (long long)wave * {GW * 4} + kq) * 16 + li);")
         else:
             L.append(f"  const dvec4* ap{p} = (const dvec4*)(A{p} + arow * lda{p}) + ((long long)wave * {GW * 4} + kq);")
@@ -1615,7 +1664,7 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
                         la += (f" __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ag{gr[0]}_{hr} + {g * 16}), "
                                f"(__attribute__((address_space(3))) void*)&lda_[wave][{s & 1}][{u // 2}][{hr * 256}], 16, 0, 0);")
             else:
-                la = f"ra_[{s & 1}][{u}] = ap{gr[0]}[{g * (64 if 'apacked' in var else 4)}]; " + bl
+                la = f"ra_[{s & 1}][{u}] = ap{gr[0]}[{g * (64 if ('apacked' in var or gr[0] in packed_a) else 4)}]; " + bl
                 if "noload" in var:
                     la = (f"ra_[{s & 1}][{u}] = dvec4{{fake_, fake_, fake_, fake_}}; "
                           + " ".join(f"{bufs[q]}[{s & 1}][{u}] = dvec4{{fake_, fake_, fake_, fake_}};" for q in range(len(gr))))
@@ -1695,6 +1744,10 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
     for k in range(len(body["out_dtypes"])):
         L.append(f"    out{k}[er * ldo{k} + ec] = o{k};")
     L.append("  }")
+    for k in pack_outs:
+        # element (i = tid/16, column ec) of row tile blockIdx.y: k4 = ec/4, j = ec%4 (all 256 threads: rows
+        # past M hold zeros, so that a consumer's MFMA never multiplies uninitialised memory)
+        L.append(f"  pk{k}[((blockIdx.y * (N >> 2) + (ctile * 4 + ((tid & 15) >> 2))) * 16 + (tid >> 4)) * 4 + (tid & 3)] = live ? o{k} : ({CTYPE[body['out_dtypes'][k]]})0;")
     L.append("}")
     return "\n".join(L)
 

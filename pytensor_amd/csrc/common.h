@@ -41,6 +41,9 @@ struct Context {
 
 Context& ctx();
 void guard_before_host_read(const void* p, size_t bytes);  // guard.hip
+// gemm.hip: C (M x N, row stride ldc) <- beta*C + alpha * A @ B in place (element strides)
+int gemm_inplace(int dtype, long long M, long long N, long long K, double alpha, const void* A, long long sA0,
+                 long long sA1, const void* B, long long sB0, long long sB1, double beta, void* C, long long ldc);
 int set_error(const char* fmt, ...);
 int check(hipError_t e, const char* what);
 

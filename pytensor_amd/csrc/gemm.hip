@@ -206,7 +206,7 @@ __global__ __launch_bounds__(BLOCK, 2) void dgemm_kernel(
     const double* __restrict__ C, long long M, long long N, long long K, long long lda,
     long long ldb, long long sAb, long long sBb, long long sCb, long long sC0, long long sC1,
     double alpha, double beta, long long tiles_m, long long tiles_n, int vecA, int vecB,
-    long long kchunk) {
+    long long kchunk, long long ldo) {
   using SA = Stage<double, AKC>;
   using SB = Stage<double, BKC>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(BLOCK, 2) void dgemm_kernel(
         if (row < M && col < N) {
           double v = alpha * acc[i][j][r];
           if (has_c) v += beta * C[row * sC0 + col * sC1];
-          out[row * N + col] = v;
+          out[row * ldo + col] = v;
         }
       }
 }
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_kernel(
     const float* __restrict__ C, long long M, long long N, long long K, long long lda,
     long long ldb, long long sAb, long long sBb, long long sCb, long long sC0, long long sC1,
     float alpha, float beta, long long tiles_m, long long tiles_n, int vecA, int vecB,
-    long long kchunk) {
+    long long kchunk, long long ldo) {
   using SA = Stage<float, AKC, BKT>;
   using SB = Stage<float, BKC, BKT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_kernel(
         if (row < M && col < N) {
           float v = alpha * acc[i][j][r];
           if (has_c) v += beta * C[row * sC0 + col * sC1];
-          out[row * N + col] = v;
+          out[row * ldo + col] = v;
         }
       }
 }
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_persistent_kernel(
     const float* __restrict__ C, long long M, long long N, long long K, long long lda,
     long long ldb, long long sAb, long long sBb, long long sCb, long long sC0, long long sC1,
     float alpha, float beta, long long tiles_m, long long tiles_n, int vecA, int vecB,
-    long long batch) {
+    long long batch, long long ldo) {
   constexpr int BKT = 32;
   using SA = Stage<float, AKC, BKT>;
   using SB = Stage<float, BKC, BKT>;
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_persistent_kernel(
           for (int r = 0; r < 16; r++) {
             const long long row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const long long col = n0 + wn0 + j * 32 + (lane & 31);
-            ob[row * N + col] = alpha * acc[i][j][r];
+            ob[row * ldo + col] = alpha * acc[i][j][r];
           }
     } else {
 #pragma unroll
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_persistent_kernel(
             if (row < M && col < N) {
               float v = alpha * acc[i][j][r];
               if (has_c) v += beta * Cb[row * sC0 + col * sC1];
-              ob[row * N + col] = v;
+              ob[row * ldo + col] = v;
             }
           }
     }
@@ -591,7 +591,7 @@ template <class T>
 __global__ __launch_bounds__(BLOCK) void splitk_finish_kernel(
     T* __restrict__ out, const T* __restrict__ part, const T* __restrict__ C, long long M,
     long long N, long long total, int nsplit, long long sCb, long long sC0, long long sC1, T alpha,
-    T beta) {
+    T beta, long long ldo) {
   for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < total;
        i += (long long)gridDim.x * BLOCK) {
     T v = part[i];
@@ -602,7 +602,8 @@ __global__ __launch_bounds__(BLOCK) void splitk_finish_kernel(
       const long long m = r / N, n = r - m * N;
       v += beta * C[b * sCb + m * sC0 + n * sC1];
     }
-    out[i] = v;
+    if (ldo == N) out[i] = v;
+    else out[(i / N) * ldo + (i % N)] = v;  // (row stride of the destination: batch == 1)
   }
 }
 
@@ -648,8 +649,9 @@ template <class T, bool AKC, bool BKC, bool SKINNY, int BKT = 16>
 int launch(long long batch, long long M, long long N, long long K, T alpha, const T* A,
            long long sAb, long long lda, const T* B, long long sBb, long long ldb, T beta,
            const T* C, long long sCb, long long sC0, long long sC1, T* out,
-           T* partials = nullptr) {
+           T* partials = nullptr, long long ldo = 0) {
   hipStream_t st = pthip::ctx().stream;
+  if (ldo == 0) ldo = N;  // row stride of `out` (!= N: batch == 1, the in-place update of a sub-block)
   using SA = Stage<T, AKC, BKT>;
   using SB = Stage<T, BKC, BKT>;
   const size_t shmem = (size_t)(2 * SA::SIZE + 2 * SB::SIZE) * sizeof(T);
@@ -670,7 +672,7 @@ int launch(long long batch, long long M, long long N, long long K, T alpha, cons
     // nsplit == 1: the epilogue with alpha = 1, beta = 0 stores the plain product in slab 0
     PTHIP_KLAUNCH(k, grid, dim3(BLOCK), shmem, st, partials, A, B, (const T*)nullptr, M, N, K,
                        lda, ldb, sAb, sBb, (long long)(M * N), N, 1LL, T(1), T(0), tiles_m, tiles_n,
-                       vecA, vecB, kchunk);
+                       vecA, vecB, kchunk, N);
     return pthip::post_launch("gemm(partials)");
   }
   if (nsplit == 1) {
@@ -690,12 +692,12 @@ int launch(long long batch, long long M, long long N, long long K, T alpha, cons
         }
         PTHIP_KLAUNCH(kp, dim3((unsigned)resident), dim3(BLOCK), shmem, st, (float*)out, (const float*)A, (const float*)B,
                       (const float*)C, M, N, K, lda, ldb, sAb, sBb, sCb, sC0, sC1, (float)alpha, (float)beta, tiles_m, tiles_n,
-                      vecA, vecB, batch);
+                      vecA, vecB, batch, ldo);
         return pthip::post_launch("gemm(persistent)");
       }
     }
     PTHIP_KLAUNCH(k, grid, dim3(BLOCK), shmem, st, out, A, B, C, M, N, K, lda, ldb, sAb, sBb,
-                       sCb, sC0, sC1, alpha, beta, tiles_m, tiles_n, vecA, vecB, kchunk);
+                       sCb, sC0, sC1, alpha, beta, tiles_m, tiles_n, vecA, vecB, kchunk, ldo);
     return pthip::post_launch("gemm");
   }
   const long long total = batch * M * N;
@@ -703,13 +705,13 @@ int launch(long long batch, long long M, long long N, long long K, T alpha, cons
   int r = pthip_alloc((size_t)nsplit * total * sizeof(T), &part);
   if (r) return r;
   PTHIP_KLAUNCH(k, grid, dim3(BLOCK), shmem, st, (T*)part, A, B, C, M, N, K, lda, ldb, sAb, sBb,
-                     sCb, sC0, sC1, alpha, beta, tiles_m, tiles_n, vecA, vecB, kchunk);
+                     sCb, sC0, sC1, alpha, beta, tiles_m, tiles_n, vecA, vecB, kchunk, N);
   r = pthip::post_launch("gemm(split-K)");
   if (!r) {
     long long blocks = (total + BLOCK - 1) / BLOCK;
     if (blocks > 2048) blocks = 2048;
     PTHIP_KLAUNCH((splitk_finish_kernel<T>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, out,
-                       (const T*)part, C, M, N, total, (int)nsplit, sCb, sC0, sC1, alpha, beta);
+                       (const T*)part, C, M, N, total, (int)nsplit, sCb, sC0, sC1, alpha, beta, ldo);
     r = pthip::post_launch("gemm splitk_finish");
   }
   pthip_free(part);  // stream-ordered reuse keeps this safe
@@ -728,7 +730,7 @@ template <class T>
 int gemm_typed(long long batch, long long M, long long N, long long K, double alpha, const void* A,
                long long sAb, long long sA0, long long sA1, const void* B, long long sBb,
                long long sB0, long long sB1, double beta, const void* C, long long sCb,
-               long long sC0, long long sC1, void* out, void* partials = nullptr) {
+               long long sC0, long long sC1, void* out, void* partials = nullptr, long long ldo = 0) {
   if (batch == 0 || M == 0 || N == 0) return 0;
   // Normalise the strides of degenerate (length-1) dims, then classify:
   //   A (m,k) at m*sA0 + k*sA1 : K-contiguous iff sA1 == 1 (lda = sA0), else M-contiguous (lda = sA1)
@@ -754,14 +756,14 @@ int gemm_typed(long long batch, long long M, long long N, long long K, double al
   do {                                                                                             \
     if (skinny)                                                                                    \
       return launch<T, X, Y, true>(batch, M, N, K, (T)alpha, a, sAb, lda, b, sBb, ldb, (T)beta, c, \
-                                   sCb, sC0, sC1, o, (T*)partials);                                \
+                                   sCb, sC0, sC1, o, (T*)partials, ldo);                                \
     if constexpr (sizeof(T) == 4) {                                                                \
       if (sgemm_bk32())                                                                            \
         return launch<T, X, Y, false, 32>(batch, M, N, K, (T)alpha, a, sAb, lda, b, sBb, ldb,      \
-                                          (T)beta, c, sCb, sC0, sC1, o, (T*)partials);             \
+                                          (T)beta, c, sCb, sC0, sC1, o, (T*)partials, ldo);             \
     }                                                                                              \
     return launch<T, X, Y, false>(batch, M, N, K, (T)alpha, a, sAb, lda, b, sBb, ldb, (T)beta, c,  \
-                                  sCb, sC0, sC1, o, (T*)partials);                                 \
+                                  sCb, sC0, sC1, o, (T*)partials, ldo);                                 \
   } while (0)
   if (akc && bkc) GO(true, true);
   if (akc && !bkc) GO(true, false);
@@ -771,6 +773,17 @@ int gemm_typed(long long batch, long long M, long long N, long long K, double al
 }
 
 }  // namespace
+
+namespace pthip {
+// C (M x N, row stride ldc) <- beta*C + alpha * A @ B, in place: the trailing update of the blocked
+// Cholesky (linalg.hip).  Every element is read and written by the same lane of the same launch.
+int gemm_inplace(int dtype, long long M, long long N, long long K, double alpha, const void* A, long long sA0,
+                 long long sA1, const void* B, long long sB0, long long sB1, double beta, void* C, long long ldc) {
+  if (dtype == PTHIP_F64)
+    return gemm_typed<double>(1, M, N, K, alpha, A, 0, sA0, sA1, B, 0, sB0, sB1, beta, C, 0, ldc, 1, C, nullptr, ldc);
+  return gemm_typed<float>(1, M, N, K, alpha, A, 0, sA0, sA1, B, 0, sB0, sB1, beta, C, 0, ldc, 1, C, nullptr, ldc);
+}
+}  // namespace pthip
 
 extern "C" int pthip_gemm(int dtype, int64_t batch, int64_t M, int64_t N, int64_t K, double alpha,
                           const void* A, int64_t sAb, int64_t sA0, int64_t sA1, const void* B,

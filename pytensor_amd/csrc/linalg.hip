@@ -23,7 +23,8 @@
 //   trsv  : matrix staged to LDS by the whole workgroup (coalesced), then ONE wave does the
 //           substitution wave-synchronously (two rows per lane, pivots via v_readlane):
 //           no barriers inside the n-step dependency chain.
-// Larger matrices fall back to simple global-memory kernels (correct, not fast).
+// Larger matrices: blocked right-looking factorisation over HBM (chol_blocked: LDS-resident
+// diagonal blocks, multi-workgroup panel solves, trailing updates on the MFMA GEMM).
 // Batches (Blockwise) map to grid.x.
 #include "common.h"
 
@@ -72,21 +73,25 @@ template <class T> __device__ __forceinline__ T bcast_lane(T v, int src) {
 // round trips for a 128 x 128 fp64 matrix (8-byte loads, 8 deep, needed eight and took ~40 us
 // next to a kernel that saturates HBM).  `wide` = 16-byte path usable (n % VEC == 0, aligned).
 template <class T, class F>
-__device__ __forceinline__ void stage_dense(const T* __restrict__ src, int n, bool wide, F&& put) {
+__device__ __forceinline__ void stage_dense(const T* __restrict__ src, int n, bool wide, F&& put,
+                                            long long ld = 0) {
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int UN = 16;
   typedef T vec_t __attribute__((ext_vector_type(VEC)));
   const int tid = threadIdx.x;
   const int total = n * n;
+  if (ld == 0) ld = n;  // (a block of a larger matrix: slow stride ld > n)
   if (wide) {
     const int nv = total / VEC;
-    const vec_t* s = (const vec_t*)src;
     for (int v0 = 0; v0 < nv; v0 += BLOCK * UN) {
       vec_t v[UN];
 #pragma unroll
       for (int u = 0; u < UN; u++) {
-        const int idx = v0 + u * BLOCK + tid;
-        v[u] = s[idx < nv ? idx : nv - 1];
+        int idx = v0 + u * BLOCK + tid;
+        if (idx >= nv) idx = nv - 1;
+        const int e = idx * VEC;
+        const int a = e / n;
+        v[u] = *(const vec_t*)(src + (long long)a * ld + (e - a * n));
       }
 #pragma unroll
       for (int u = 0; u < UN; u++) {
@@ -104,8 +109,10 @@ __device__ __forceinline__ void stage_dense(const T* __restrict__ src, int n, bo
       T v[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) {
-        const int e = e0 + u * BLOCK + tid;
-        v[u] = src[e < total ? e : total - 1];
+        int e = e0 + u * BLOCK + tid;
+        if (e >= total) e = total - 1;
+        const int a = e / n;
+        v[u] = src[(long long)a * ld + (e - a * n)];
       }
 #pragma unroll
       for (int u = 0; u < 8; u++) {
@@ -214,12 +221,17 @@ template <class T>
 __global__ __launch_bounds__(BLOCK) void potrf_lds_kernel(T* __restrict__ Lout,
                                                          const T* __restrict__ Ain, int n,
                                                          int lower, const T* __restrict__ rhs,
-                                                         T* __restrict__ xout) {
+                                                         T* __restrict__ xout, long long ldio,
+                                                         int* __restrict__ failflag) {
+  // ldio != 0: the matrix is a diagonal block of a larger row-major working matrix (row stride
+  // ldio) factored IN PLACE as one step of the blocked algorithm (chol_blocked below): only the
+  // lower triangle is written back, a failure is reported through *failflag.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ int s_fail;
   T* W = (T*)smem_raw;
   const int ld = n | 1;  // odd leading dimension: column walks are bank-conflict free
   const long long mat = blockIdx.x;
+  const long long gld = ldio ? ldio : n;
   const T* A = Ain + mat * (long long)n * n;
   T* Lo = Lout + mat * (long long)n * n;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -227,11 +239,11 @@ __global__ __launch_bounds__(BLOCK) void potrf_lds_kernel(T* __restrict__ Lout,
   // load the referenced triangle as a lower-triangular working matrix W[i][j], i >= j
   // (for `upper` the strict upper triangle is read transposed: LAPACK reads only `uplo`)
   {
-    const bool wide = (n % (16 / (int)sizeof(T))) == 0 && (((size_t)A) & 15) == 0;
+    const bool wide = (n % (16 / (int)sizeof(T))) == 0 && (((size_t)A) & 15) == 0 && (gld % (16 / (int)sizeof(T))) == 0;
     if (lower)
-      stage_dense<T>(A, n, wide, [&](int i, int j, T v) { if (i >= j) W[i * ld + j] = v; });
+      stage_dense<T>(A, n, wide, [&](int i, int j, T v) { if (i >= j) W[i * ld + j] = v; }, gld);
     else
-      stage_dense<T>(A, n, wide, [&](int i, int j, T v) { if (j >= i) W[j * ld + i] = v; });
+      stage_dense<T>(A, n, wide, [&](int i, int j, T v) { if (j >= i) W[j * ld + i] = v; }, gld);
   }
   __syncthreads();
   bool fail = false;
@@ -341,6 +353,15 @@ __global__ __launch_bounds__(BLOCK) void potrf_lds_kernel(T* __restrict__ Lout,
   __syncthreads();
   const bool failed = s_fail != 0;
   const T nanv = (T)__builtin_nan("");
+  if (ldio) {
+    if (failed && tid == 0) atomicOr(failflag, 1);
+#pragma unroll 8
+    for (int e = tid; e < n * n; e += BLOCK) {
+      const int i = e / n, j = e - i * n;
+      if (i >= j) Lo[(long long)i * gld + j] = failed ? nanv : W[i * ld + j];
+    }
+    return;
+  }
 #pragma unroll 8
   for (int e = tid; e < n * n; e += BLOCK) {
     const int i = e / n, j = e - i * n;
@@ -356,52 +377,182 @@ __global__ __launch_bounds__(BLOCK) void potrf_lds_kernel(T* __restrict__ Lout,
     wave_trsv<T, 4>(W, ld, n, rhs + mat * (long long)n, xout + mat * (long long)n, 1, 0, failed);
 }
 
-// global-memory fallback (n too large for LDS): unblocked right-looking, one workgroup
+// ---------------------------------------------------------------------------------
+// Blocked Cholesky for matrices beyond one CU's LDS (n > 141 fp64 / 200 fp32): right-looking,
+// NBK-column panels over a row-major working matrix Wk (lower triangle, row stride n) in HBM.
+// Per panel k:  (1) the NBK x NBK diagonal block is factored in place by the LDS-resident kernel
+// above (one CU; the serial column chain is the critical path of the whole factorisation);
+// (2) the panel below it, X = A21 L11^-T, by chol_trsm_kernel — every workgroup takes CT_ROWS rows,
+// one thread per row, L11 and the slab in LDS; (3) the trailing matrix A22 -= X X^T on the MFMA
+// GEMM (gemm.hip, in place), by block columns so that only blocks touching the lower triangle
+// are computed.  A failed pivot anywhere sets a device flag; the finishing kernel writes the
+// requested triangle (transposed for `upper`), zeroes the other one, or NaN-fills everything
+// (cholesky.py:78-80).  No host synchronisation: capturable into a hipGraph.
+// ---------------------------------------------------------------------------------
+constexpr int NBK = 64;       // panel width
+constexpr int CT_ROWS = 192;  // rows of the panel per workgroup (= threads of chol_trsm_kernel)
+
+// W[i][j] (i >= j) <- the referenced triangle of A; W[i][j] (i < j) <- 0.  32x32 tiles through LDS:
+// `upper` reads the tile of A transposed, both sides coalesced.
 template <class T>
-__global__ __launch_bounds__(BLOCK) void potrf_global_kernel(T* __restrict__ Lout,
-                                                            const T* __restrict__ Ain, int n,
-                                                            int lower, T* __restrict__ scratch) {
-  __shared__ int s_fail;
-  const long long mat = blockIdx.x;
-  const T* A = Ain + mat * (long long)n * n;
-  T* Lo = Lout + mat * (long long)n * n;
-  T* W = scratch + mat * (long long)n * n;
-  const int ld = n;
-  if (threadIdx.x == 0) s_fail = 0;
-  for (long long e = threadIdx.x; e < (long long)n * n; e += BLOCK) {
-    const int i = (int)(e / n), j = (int)(e - (long long)i * n);
-    if (i >= j) W[(long long)i * ld + j] = lower ? A[(long long)i * n + j] : A[(long long)j * n + i];
+__global__ __launch_bounds__(BLOCK) void chol_stage_kernel(T* __restrict__ W, const T* __restrict__ A,
+                                                          int n, int lower) {
+  __shared__ T tile[32][33];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj > bi) {  // strictly upper block of W
+    for (int e = threadIdx.x; e < 32 * 32; e += BLOCK) {
+      const int i = bi * 32 + (e >> 5), j = bj * 32 + (e & 31);
+      if (i < n && j < n) W[(long long)i * n + j] = T(0);
+    }
+    return;
+  }
+  // source tile: lower -> A[bi][bj]; upper -> A[bj][bi] read row-wise, used transposed
+  const int si = lower ? bi : bj, sj = lower ? bj : bi;
+  for (int e = threadIdx.x; e < 32 * 32; e += BLOCK) {
+    const int r = e >> 5, c = e & 31;
+    const int i = si * 32 + r, j = sj * 32 + c;
+    tile[r][c] = (i < n && j < n) ? A[(long long)i * n + j] : T(0);
   }
   __syncthreads();
-  for (int k = 0; k < n; k++) {
-    const T akk = W[(long long)k * ld + k];
-    if (!(akk > T(0))) {
-      if (threadIdx.x == 0) s_fail = 1;
-      break;
-    }
-    const T piv = sqrt(akk);
-    __syncthreads();
-    for (int i = k + threadIdx.x; i < n; i += BLOCK)
-      W[(long long)i * ld + k] = (i == k) ? piv : W[(long long)i * ld + k] / piv;
-    __syncthreads();
-    for (int i = k + 1 + (threadIdx.x >> 6); i < n; i += BLOCK / 64) {
-      const T lik = W[(long long)i * ld + k];
-      for (int j = k + 1 + (threadIdx.x & 63); j <= i; j += 64)
-        W[(long long)i * ld + j] -= lik * W[(long long)j * ld + k];
-    }
-    __syncthreads();
+  for (int e = threadIdx.x; e < 32 * 32; e += BLOCK) {
+    const int r = e >> 5, c = e & 31;
+    const int i = bi * 32 + r, j = bj * 32 + c;
+    if (i < n && j < n) W[(long long)i * n + j] = (i >= j) ? (lower ? tile[r][c] : tile[c][r]) : T(0);
+  }
+}
+
+// X = A21 L11^-T for the rows below diagonal block k: W[r][k..k+nb) <- solution, r in [k+nb, n).
+// L11 (lower, nb <= NBK) and this workgroup's CT_ROWS x nb slab live in LDS (slab transposed:
+// thread t walks column t of Xs conflict-free, the entries of L11 are uniform-address reads);
+// eight solution entries at a time in registers, as in trsm_lds_kernel.
+template <class T>
+__global__ __launch_bounds__(CT_ROWS) void chol_trsm_kernel(T* __restrict__ W, long long ld, int k, int nb, int n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int LL = NBK + 2;       // row stride of Ls: pairs of entries stay 16-byte aligned
+  constexpr int XL = CT_ROWS + 1;   // row stride of Xs
+  T* Ls = (T*)smem_raw;             // [NBK][LL]
+  T* Xs = Ls + NBK * LL;            // [NBK][XL]
+  const int tid = threadIdx.x;
+  const long long r0 = (long long)k + nb + (long long)blockIdx.x * CT_ROWS;
+  const int rows = (int)((n - r0) < CT_ROWS ? (n - r0) : CT_ROWS);
+  for (int e = tid; e < nb * nb; e += CT_ROWS) {
+    const int i = e / nb, j = e - i * nb;
+    Ls[i * LL + j] = (j <= i) ? W[(long long)(k + i) * ld + k + j] : T(0);
+  }
+  for (int e = tid; e < rows * nb; e += CT_ROWS) {
+    const int r = e / nb, c = e - r * nb;
+    Xs[c * XL + r] = W[(r0 + r) * ld + k + c];
   }
   __syncthreads();
-  const bool fail = s_fail != 0;
+  if (tid < rows) {
+    constexpr int RB = 8;
+    for (int s0 = 0; s0 < nb; s0 += RB) {
+      T acc[RB];
+#pragma unroll
+      for (int r = 0; r < RB; r++) acc[r] = (s0 + r < nb) ? Xs[(s0 + r) * XL + tid] : T(0);
+      for (int c = 0; c < s0; c++) {
+        const T xc = Xs[c * XL + tid];
+#pragma unroll
+        for (int r = 0; r < RB; r++) acc[r] -= xc * Ls[(s0 + r) * LL + c];  // (rows past nb: zero-filled pad of Ls is never reached: s0 + r < NBK)
+      }
+#pragma unroll
+      for (int r = 0; r < RB; r++) {
+        if (s0 + r < nb) {
+#pragma unroll
+          for (int r2 = 0; r2 < r; r2++) acc[r] -= acc[r2] * Ls[(s0 + r) * LL + s0 + r2];
+          acc[r] = acc[r] / Ls[(s0 + r) * LL + s0 + r];
+          Xs[(s0 + r) * XL + tid] = acc[r];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < rows * nb; e += CT_ROWS) {
+    const int r = e / nb, c = e - r * nb;
+    W[(r0 + r) * ld + k + c] = Xs[c * XL + r];
+  }
+}
+
+// out <- the factor in the requested triangle (W holds it lower), zeros elsewhere; all-NaN when a
+// pivot failed.  32x32 tiles through LDS so that the transposed write of `upper` is coalesced.
+template <class T>
+__global__ __launch_bounds__(BLOCK) void chol_finish_kernel(T* __restrict__ out, const T* __restrict__ W,
+                                                           int n, int lower, const int* __restrict__ failflag) {
+  __shared__ T tile[32][33];
+  const bool failed = *failflag != 0;
+  const int bi = blockIdx.y, bj = blockIdx.x;
   const T nanv = (T)__builtin_nan("");
-  for (long long e = threadIdx.x; e < (long long)n * n; e += BLOCK) {
-    const int i = (int)(e / n), j = (int)(e - (long long)i * n);
-    T v;
-    if (fail) v = nanv;
-    else if (lower) v = (i >= j) ? W[(long long)i * ld + j] : T(0);
-    else v = (j >= i) ? W[(long long)j * ld + i] : T(0);
-    Lo[e] = v;
+  const bool needs = lower ? (bj <= bi) : (bi <= bj);  // does this output block touch the triangle?
+  if (failed || !needs) {
+    for (int e = threadIdx.x; e < 32 * 32; e += BLOCK) {
+      const int i = bi * 32 + (e >> 5), j = bj * 32 + (e & 31);
+      if (i < n && j < n) out[(long long)i * n + j] = failed ? nanv : T(0);
+    }
+    return;
   }
+  const int si = lower ? bi : bj, sj = lower ? bj : bi;  // block of W (lower storage) feeding this one
+  for (int e = threadIdx.x; e < 32 * 32; e += BLOCK) {
+    const int r = e >> 5, c = e & 31;
+    const int i = si * 32 + r, j = sj * 32 + c;
+    tile[r][c] = (i < n && j < n && i >= j) ? W[(long long)i * n + j] : T(0);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 32 * 32; e += BLOCK) {
+    const int r = e >> 5, c = e & 31;
+    const int i = bi * 32 + r, j = bj * 32 + c;
+    if (i < n && j < n) out[(long long)i * n + j] = lower ? tile[r][c] : tile[c][r];
+  }
+}
+
+template <class T>
+int chol_blocked(int lower, long long n, const T* A, T* L) {
+  hipStream_t st = pthip::ctx().stream;
+  void* scratch = nullptr;
+  const size_t wbytes = (size_t)n * n * sizeof(T);
+  int r = pthip_alloc(wbytes + 256, &scratch);
+  if (r) return r;
+  T* W = (T*)scratch;
+  int* flag = (int*)((char*)scratch + wbytes);
+  const int dt = sizeof(T) == 8 ? PTHIP_F64 : PTHIP_F32;
+  const unsigned nt = (unsigned)((n + 31) / 32);
+  auto fail = [&](int rc) { pthip_free(scratch); return rc; };
+  if (hipError_t e = pthip::memset_async(flag, 0, 256, st); e != hipSuccess) return fail(pthip::check(e, "chol flag memset"));
+  PTHIP_KLAUNCH((chol_stage_kernel<T>), dim3(nt, nt), dim3(BLOCK), 0, st, W, A, (int)n, lower);
+  if ((r = pthip::post_launch("chol_stage"))) return fail(r);
+  auto kd = potrf_lds_kernel<T>;
+  auto kt = chol_trsm_kernel<T>;
+  const size_t lds_d = (size_t)NBK * (NBK | 1) * sizeof(T);
+  const size_t lds_t = (size_t)NBK * (NBK + 2 + CT_ROWS + 1) * sizeof(T);
+  static bool attr_t = false;
+  if (!attr_t && lds_t > 64 * 1024) {
+    if (hipError_t e = hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t); e != hipSuccess)
+      return fail(pthip::check(e, "chol_trsm attribute"));
+    attr_t = true;
+  }
+  for (long long k = 0; k < n; k += NBK) {
+    const int nb = (int)((n - k) < NBK ? (n - k) : NBK);
+    T* D = W + k * n + k;
+    PTHIP_KLAUNCH(kd, dim3(1), dim3(BLOCK), lds_d, st, D, (const T*)D, nb, 1, (const T*)nullptr, (T*)nullptr, (long long)n, flag);
+    if ((r = pthip::post_launch("chol diag"))) return fail(r);
+    const long long m = n - k - nb;
+    if (m <= 0) break;
+    PTHIP_KLAUNCH(kt, dim3((unsigned)((m + CT_ROWS - 1) / CT_ROWS)), dim3(CT_ROWS), lds_t, st, W, n, (int)k, nb, (int)n);
+    if ((r = pthip::post_launch("chol trsm"))) return fail(r);
+    // trailing update, lower block triangle only: block columns of width cw, rows from the block down
+    long long cw = (m / 4 + 127) / 128 * 128;
+    if (cw < 256) cw = 256;
+    const T* P = W + (k + nb) * n + k;  // the panel just solved: m x nb, row stride n
+    for (long long c0 = 0; c0 < m; c0 += cw) {
+      const long long wN = (m - c0) < cw ? (m - c0) : cw;
+      r = pthip::gemm_inplace(dt, m - c0, wN, nb, -1.0, P + c0 * n, n, 1, P + c0 * n, 1, n, 1.0,
+                              W + (k + nb + c0) * n + (k + nb + c0), n);
+      if (r) return fail(r);
+    }
+  }
+  PTHIP_KLAUNCH((chol_finish_kernel<T>), dim3(nt, nt), dim3(BLOCK), 0, st, L, (const T*)W, (int)n, lower, (const int*)flag);
+  r = pthip::post_launch("chol_finish");
+  pthip_free(scratch);  // stream-ordered reuse keeps this safe
+  return r;
 }
 
 // ---------------------------------------------------------------------------------
@@ -557,18 +708,16 @@ int potrf_typed(int lower, long long batch, long long n, const void* A, void* L,
     if (need > 64 * 1024)
       PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     PTHIP_KLAUNCH(k, dim3((unsigned)batch), dim3(BLOCK), need, st, (T*)L, (const T*)A, (int)n, lower,
-                       (const T*)rhs, (T*)xout);
+                       (const T*)rhs, (T*)xout, 0LL, (int*)nullptr);
     return pthip::post_launch("potrf_lds");
   }
   if (rhs != nullptr) return pthip::set_error("pthip_potrf_trsv: matrix does not fit the LDS-resident kernel");
-  void* scratch = nullptr;
-  int r = pthip_alloc((size_t)batch * n * n * sizeof(T), &scratch);
-  if (r) return r;
-  PTHIP_KLAUNCH((potrf_global_kernel<T>), dim3((unsigned)batch), dim3(BLOCK), 0, st, (T*)L,
-                     (const T*)A, (int)n, lower, (T*)scratch);
-  r = pthip::post_launch("potrf_global");
-  pthip_free(scratch);  // stream-ordered reuse keeps this safe
-  return r;
+  // beyond one CU's LDS: the blocked multi-workgroup factorisation, one matrix after the other
+  for (long long b = 0; b < batch; b++) {
+    int r = chol_blocked<T>(lower, n, (const T*)A + b * n * n, (T*)L + b * n * n);
+    if (r) return r;
+  }
+  return 0;
 }
 
 template <class T>

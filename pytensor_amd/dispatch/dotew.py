@@ -125,25 +125,51 @@ def dot_epilogue(node, inputs, env):
                 break
     if share:
         name += "_h" + "_".join(f"{a}.{b}" for a, b in sorted(share.items())).replace(".", "x")
-    lds_a = os.environ.get("PTHIP_DOTEW_LDSA", "0") == "1" and T == "float32" and K % 128 == 0 and chunk % 2 == 0
+    # Left operands that an earlier step kernel ALSO stored in the MFMA operand order (Scan steps:
+    # `r*h` of this step, `h` of the previous one — dispatch/scan.py hands the context over) are read
+    # from that image; outputs a later step kernel multiplies from the left are stored in it too.
+    ctx = getattr(env, "scan_ctx", None)
+    use_pack = ctx is not None and os.environ.get("PTHIP_DOTEW_PACKA", "1") != "0"
+    packed_a = {}
+    if use_pack:
+        for q in dpos:
+            src = ctx["tap_src"].get(node.inputs[q], (node.inputs[q], 0))
+            ent = ctx["packed"].get((src[0], ctx["t"] - src[1]))
+            if ent is not None and ent.size == _ceil16(M) * K and str(ent.dtype) == T:
+                packed_a[q] = ent
+    pack_outs = []
+    if use_pack and N % 16 == 0:
+        pack_outs = [k for k, o in enumerate(node.outputs[: len(out_dtypes)]) if o in ctx["pack_vars"] and out_dtypes[k] == T]
+    if packed_a:
+        name += "_pa" + "_".join(str(q) for q in sorted(packed_a))
+    if pack_outs:
+        name += "_po" + "_".join(map(str, pack_outs))
+    lds_a = os.environ.get("PTHIP_DOTEW_LDSA", "0") == "1" and T == "float32" and K % 128 == 0 and chunk % 2 == 0 and not packed_a
     if lds_a:
         name += "_la"
-    var = os.environ.get("PTHIP_DOTEW_VAR", "acc2")  # (tools/dotew_variants.py: timing-only decompositions)
+    var = os.environ.get("PTHIP_DOTEW_VAR", "")  # (tools/dotew_variants.py: timing-only decompositions)
     if var:
         name += "_" + var.replace(",", "_")
-    src = codegen.dot_epilogue_source(name, body, dpos, K, byvalue, chunk, share, lds_a, var)
+    src = codegen.dot_epilogue_source(name, body, dpos, K, byvalue, chunk, share, lds_a, var, set(packed_a), pack_outs)
     fn = kernel_cache.get_function(src, name)
     args = [M, N]
     for k, a in enumerate(ins):
         if k in dots:
             A, _, Bp = dots[k]
-            args += [A.ptr, A.strides[0], Bp.ptr]
+            if k in packed_a:
+                args += [packed_a[k].ptr, 0, Bp.ptr]
+            else:
+                args += [A.ptr, A.strides[0], Bp.ptr]
         elif k in byvalue:
             args.append(_scalar_bits(a, body["in_dtypes"][k]))
         else:
             args += [a.ptr, 0 if a.shape[0] == 1 and M != 1 else a.strides[0], 0 if a.shape[1] == 1 and N != 1 else a.strides[1]]
     for o in outs:
         args += [o.ptr, o.strides[0]]
+    for k in pack_outs:
+        pk = DeviceArray.empty((_ceil16(M) * N,), out_dtypes[k])
+        args.append(pk.ptr)
+        ctx["packed"][(node.outputs[k], ctx["t"])] = pk
     buf = struct.pack(f"<{len(args)}q", *args)
     env.timed(name, lambda: ffi.check(env.lib.pthip_launch(fn, (N + 15) // 16, (M + 15) // 16, 1, codegen.BLOCK, 1, 1, 0, buf, len(buf))))
     return outs

@@ -23,6 +23,9 @@ import os as _os
 
 MAX_GRID = int(_os.environ.get("PTHIP_EW_MAXGRID", 256 * 8))  # ≫256 workgroups, grid-stride beyond (cdna guide G11)
 EW_UNROLL = int(_os.environ.get("PTHIP_EW_UNROLL", 2))
+# software-pipelined main loop (codegen.flat_kernel_source prefetch=True) for scalar graphs with at
+# least this many nodes: below it the loop is a pure stream and the extra registers buy nothing
+EW_PREFETCH_MIN_OPS = int(_os.environ.get("PTHIP_EW_PREFETCH_MIN_OPS", 24))
 
 _body_key_cache = {}
 
@@ -248,8 +251,9 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=
             if any(p % 16 for p in ptrs) or n < vec or "G" in modes:
                 vec = 1
         unroll = EW_UNROLL
-        name = f"ew_{bkey}_{''.join(modes)}_v{vec}_{rkey}".replace("-", "x")
-        src = codegen.flat_kernel_source(name, body, "".join(modes), vec, rs, unroll)
+        prefetch = vec > 1 and "V" in modes and len(body["body"]) >= EW_PREFETCH_MIN_OPS
+        name = f"ew_{bkey}_{''.join(modes)}_v{vec}_{rkey}".replace("-", "x") + (f"_pf{unroll}" if prefetch else "")
+        src = codegen.flat_kernel_source(name, body, "".join(modes), vec, rs, unroll, prefetch=prefetch)
         fn = kernel_cache.get_function(src, name)
         units = (n // vec + unroll - 1) // unroll if vec > 1 else n
         grid = _grid(max(units, 1))

@@ -34,6 +34,44 @@ def _inner_executable(node, env) -> HipExecutable:
     return exe[0]
 
 
+def _pack_plan(ig, info):
+    """Which step-kernel outputs are multiplied FROM THE LEFT by a later step kernel (``DotEpilogue``)
+    and should therefore also be stored in the MFMA operand order (codegen.dot_epilogue_source
+    ``pack_outs`` / ``packed_a``): values consumed inside the same step, and recurrent states whose
+    tap of a later step feeds such a product (a sit-sot / mit-sot tap -k of step t IS the state's
+    output of step t-k, scan/op.py:322-635).  Returns (inner output/temporary var ids to pack,
+    {tap input var: (producing inner var, k)}, largest k)."""
+    prod = {o: n for n in ig.nodes for o in n.outputs}
+    mm_in = [list(t) for t in info["mit_mot_in_slices"]]
+    taps = mm_in + [list(t) for t in info["mit_sot_in_slices"]] + [list(t) for t in info["sit_sot_in_slices"]]
+    n_mm = len(mm_in)
+    n_mm_outs = sum(len(t) for t in info["mit_mot_out_slices"])
+    idx = info["n_seqs"]
+    tap_of_input = {}
+    for j, tp in enumerate(taps):
+        for tap in tp:
+            tap_of_input[ig.inputs[idx]] = (j, tap)
+            idx += 1
+    pack_vars, tap_src = set(), {}
+    for n in ig.nodes:
+        if n.op != "DotEpilogue":
+            continue
+        for q in n.params["dot_inputs"]:
+            v = n.inputs[q]
+            if v in prod:
+                if prod[v].op == "DotEpilogue":
+                    pack_vars.add(v)
+            elif v in tap_of_input:
+                j, tap = tap_of_input[v]
+                if j < n_mm or tap >= 0:
+                    continue
+                ov = ig.outputs[n_mm_outs + (j - n_mm)]
+                if ov in prod and prod[ov].op == "DotEpilogue":
+                    pack_vars.add(ov)
+                    tap_src[v] = (ov, -tap)
+    return pack_vars, tap_src, max([k for _, k in tap_src.values()], default=0)
+
+
 def _roll_to_front(buf: DeviceArray, start: int) -> DeviceArray:
     """np.concatenate([buf[start:], buf[:start]]) on the device."""
     L = buf.shape[0]
@@ -86,7 +124,16 @@ def scan(node, inputs, env):
             raise ValueError(f"Scan: sequence of length {s.shape[0]} is shorter than n_steps={n_steps}")
     nit_bufs = [None] * info["n_nit_sot"]
     steps_done = 0
+    plan = getattr(inner, "_pack_plan", None)
+    if plan is None:
+        plan = inner._pack_plan = _pack_plan(ig, info)
+    outer_ctx = getattr(env, "scan_ctx", None)
+    ctx = {"pack_vars": plan[0], "tap_src": plan[1], "packed": {}, "t": 0} if plan[0] else None
     for t in range(n_steps):
+        if ctx is not None:
+            ctx["t"] = t
+            for key in [key for key in ctx["packed"] if key[1] < t - plan[2]]:
+                del ctx["packed"][key]
         step_in = [s.view(s.shape[1:], s.strides[1:], t * s.strides[0]) for s in seqs]
         for buf, tp, mt in zip(rec_bufs, taps, mintaps):
             L = buf.shape[0]
@@ -110,10 +157,12 @@ def scan(node, inputs, env):
             slots.append(slot)
         saved = env.placement
         env.placement = placement
+        env.scan_ctx = ctx
         try:
             outs, _ = inner.run_device(step_in, env)
         finally:
             env.placement = saved
+            env.scan_ctx = outer_ctx
         o = 0
         # (mit-mot outputs of one step may alias each other's taps only through the buffer:
         #  all of them are read from the inner graph's own results before any slot is written)

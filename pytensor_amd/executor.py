@@ -243,6 +243,9 @@ class Env:
         # launch, carries the error word to the host along with its results
         self.tail_status = None
         self.tail_status_done = False
+        # inside a Scan step: which step-kernel outputs to keep in the MFMA operand order as well, and
+        # the packed images of recent steps (dispatch/scan.py::_pack_plan, dispatch/dotew.py)
+        self.scan_ctx = None
 
     def timed(self, name, launch):
         """Run ``launch()`` (ONE kernel launch) between two HIP events when a KernelTimer is

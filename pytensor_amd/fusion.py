@@ -313,13 +313,25 @@ def fuse_gemv_chain(g: Graph) -> Graph:
             if scatter:
                 break
         # which vector outputs must still be written to HBM
-        fused_consumers = {k2} | ({scatter[1]} if scatter else set())
-        out_store = []
-        for pos_o, o in enumerate(ne.outputs):
-            if spec[pos_o] is not None:
-                out_store.append(False)
-            else:
-                out_store.append(o in out_set or any(c not in fused_consumers for c in consumers.get(o, [])))
+        # (a consumer is "fused" only through the operand the chain kernel takes over: `w` as the
+        #  vector of the second Gemv, the scattered values of the scatter-add.  The same node may
+        #  read an output through another operand — the second Gemv's `y`, reference test
+        #  tests/scan/test_basic.py::TestScan::test_inner_grad — which GemvFinish still loads)
+        def _needs_store(o):
+            if o in out_set:
+                return True
+            for c in consumers.get(o, []):
+                if c == k2:
+                    if any(v == o and pos != 3 for pos, v in enumerate(n2.inputs)):
+                        return True
+                elif scatter and c == scatter[1]:
+                    if any(v == o and pos != 1 for pos, v in enumerate(scatter[2].inputs)):
+                        return True
+                else:
+                    return True
+            return False
+
+        out_store = [spec[pos_o] is None and _needs_store(o) for pos_o, o in enumerate(ne.outputs)]
         part = fresh("float64", (None, None), name="gemv_chain_partials")
         chain_inputs = list(n1.inputs) + e_ins
         chain_outputs = ([r] if store_r else []) + list(ne.outputs) + [part]

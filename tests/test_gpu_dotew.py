@@ -144,3 +144,36 @@ def test_pack_b16_layout_bit_exact(hip):
         (got,) = HipExecutable(g, fuse=False)(w)
         (want,) = np_graph.run_graph(g, [w])
         np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("B,H,T", [(64, 128, 7), (24, 64, 5), (5, 48, 4)])
+def test_scan_steps_with_packed_left_operands_are_bit_identical(hip, monkeypatch, B, H, T):
+    """Inside a Scan the step kernels hand each other their left operands in the MFMA operand order
+    (``r*h`` within the step, ``h`` from the previous step: dispatch/scan.py::_pack_plan).  The packed
+    image holds the same values, so the MFMA chains are the same: the GRU trajectory must be
+    BIT-identical with the hand-over switched off (``PTHIP_DOTEW_PACKA=0``), eager and replayed,
+    for batches that fill the 16-row tiles and batches that do not."""
+    import json
+    import os
+
+    from pytensor_amd import configs
+    from pytensor_amd.executor import HipExecutable
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "tests", "golden", "c5_gru.json")))
+    g = Graph.from_dict(d)
+    v = configs.c5_inputs(T=T, B=B, H=H, seed=50 + B)
+    v["h0"] = (0.1 * np.random.default_rng(B).normal(size=(B, H))).astype("float32")
+    ins = [v[n] for n in d["input_names"]]
+    monkeypatch.setenv("PTHIP_DOTEW_PACKA", "1")
+    exe = HipExecutable(g)
+    got = exe(*ins)
+    got_replay = exe.freeze(*ins)(*ins)
+    monkeypatch.setenv("PTHIP_DOTEW_PACKA", "0")
+    plain = HipExecutable(g)(*ins)
+    for a, b, c in zip(got, got_replay, plain):
+        np.testing.assert_array_equal(a, c)
+        np.testing.assert_array_equal(b, c)
+    want = np_graph.run_graph(g, ins)
+    for a, b in zip(got, want):
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=2e-5)

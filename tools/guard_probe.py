@@ -54,6 +54,9 @@ tok.release()
 ffi.check(lib.pthip_d2h(hp.value, src.ptr, nb)); lib.pthip_synchronize()
 print("after release the block still works:", h[777])
 """
-for name, src in (("h2d_from_protected", P1), ("guard_on_pinned", P2)):
-    r = subprocess.run([sys.executable, "-c", src % ROOT], capture_output=True, text=True, timeout=120)
-    print(f"== {name}: rc={r.returncode}\n{r.stdout}{r.stderr[-600:]}")
+for name, src in (("guard_on_pinned", P2), ("h2d_from_protected", P1)):
+    try:
+        r = subprocess.run([sys.executable, "-u", "-c", src % ROOT], capture_output=True, text=True, timeout=40)
+        print(f"== {name}: rc={r.returncode}\n{r.stdout}{r.stderr[-600:]}", flush=True)
+    except subprocess.TimeoutExpired as e:
+        print(f"== {name}: TIMED OUT after 40 s\n{(e.stdout or b'').decode(errors='replace') if isinstance(e.stdout, bytes) else e.stdout}", flush=True)

@@ -54,7 +54,8 @@ def one_pass(counters, cmd):
 
 def main():
     out, subs = sys.argv[1], sys.argv[2].split(",")
-    cmd = sys.argv[sys.argv.index("--") + 1:]
+    cmd = [os.path.abspath(a) if os.path.exists(a) and not os.path.isabs(a) else a for a in sys.argv[sys.argv.index("--") + 1:]]
+    out = os.path.abspath(out)
     table, calls, notes = {}, {}, []
     for g in GROUPS:
         rows, err = one_pass(g, cmd)
