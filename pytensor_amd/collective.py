@@ -29,6 +29,8 @@ class AllReduce(Op):
 
     def make_node(self, x):
         x = as_tensor_variable(x)
+        if x.type.dtype not in comm.DTYPES:
+            raise TypeError(f"all_reduce: dtype {x.type.dtype} has no collective on every transport (supported: {', '.join(comm.DTYPES)})")
         return Apply(self, [x], [x.type()])
 
     def perform(self, node, inputs, output_storage):

@@ -19,6 +19,10 @@ from __future__ import annotations
 import numpy as np
 
 OPS = ("sum", "prod", "max", "min")
+# dtypes BOTH transports reduce (RCCL has no 16-bit integers, torch/gloo no unsigned types beyond
+# uint8): `AllReduce.make_node` rejects everything else, so that a graph never depends on which
+# transport the job happens to run on
+DTYPES = ("float16", "float32", "float64", "int8", "uint8", "int32", "int64", "bool")
 _TORCH_DTYPES = ("float32", "float64", "int32", "int64", "int8", "uint8", "int16", "float16", "bool")
 
 

@@ -140,5 +140,9 @@ extern "C" int pthip_all_reduce(int dtype, int op, int64_t n, void* buf) {
   if (pthip::ctx().capturing) return pthip::set_error("pthip_all_reduce: a collective cannot be captured into a hipGraph");
   const int dt = rccl_dtype(dtype);
   if (dt < 0) return pthip::set_error("pthip_all_reduce: dtype %d has no RCCL type", dtype);
+  // bool travels as uint8: a byte-wise sum over ranks would leave values > 1 in a buffer typed bool
+  // (the host transport returns `sum != 0`).  On canonical 0/1 bytes  sum == OR == max  and
+  // prod == AND == min, which keep the bytes canonical: same bits on both transports.
+  if (dtype == PTHIP_BOOL) op = (op == 0) ? 2 : (op == 1) ? 3 : op;
   return rccl_check(g_api.AllReduce(buf, buf, (size_t)n, dt, op, g_comm, pthip::ctx().stream), "ncclAllReduce");
 }

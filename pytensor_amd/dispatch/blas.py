@@ -9,6 +9,8 @@ to the kernels as element strides.
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from pytensor_amd import ffi
@@ -290,6 +292,18 @@ def dot(node, inputs, env):
     raise NotImplementedError("Dot with ndim > 2")
 
 
+class LazySeq(DeviceArray):
+    """Result buffer of a hoisted sequence product whose rows are produced on demand:
+    ``produce(t0, t1)`` enqueues ``out[t0:t1] = seq[t0:t1] @ W`` on the CURRENT stream.  Only the
+    ``Scan`` step driver ever sees one (``fusion.hoist_scan_seq_dots`` marks the node ``lazy`` when
+    the Scan is its sole consumer): it computes the first chunk before the loop and every further
+    chunk on a second stream one chunk ahead of the steps that read it — the steps are
+    latency-bound (PMC: 52-66 % of the wave cycles waiting on memory, the matrix cores 25-33 % busy),
+    the big product is MFMA-bound, and the two share the CUs."""
+
+    __slots__ = ("producer", "steps", "chunk", "_keep")
+
+
 @handler("SeqDot22")
 def seq_dot22(node, inputs, env):
     """``out[t] = seq[t] @ W`` for every step of a Scan at once (fusion.hoist_scan_seq_dots):
@@ -302,9 +316,35 @@ def seq_dot22(node, inputs, env):
     if seq.strides[0] != B * seq.strides[1] or seq.strides[2] != 1:
         seq = seq.contiguous()
     flat = seq.view((T * B, K), (seq.strides[1], seq.strides[2]))
-    out = gemm_device(env, 1.0, flat, _prep2d(W))
     N = W.shape[1]
-    return [out.view((T, B, N), (B * N, N, 1))]
+    W2 = _prep2d(W)
+    # chunks of >= 4096 rows: enough 128x128 tiles that the GEMM neither splits K (which would
+    # allocate a partial-slab workspace on the side stream) nor leaves CUs without a tile
+    chunk = max(1, -(-4096 // max(B, 1)))
+    lazy_ok = (node.params.get("lazy") and os.environ.get("PTHIP_SCAN_OVERLAP", "1") != "0" and env.scheduler is None
+               and T >= 3 * chunk and B * N > 0 and K > 0 and (N + 127) // 128 * ((chunk * B + 127) // 128) >= 128)
+    if not lazy_ok:
+        out = gemm_device(env, 1.0, flat, W2)
+        return [out.view((T, B, N), (B * N, N, 1))]
+    buf = DeviceArray.empty((T * B, N), seq.dtype)
+    out = LazySeq(buf.buf, buf.offset, (T, B, N), (B * N, N, 1), buf.dtype)
+    sA, sB = flat.strides, W2.strides
+
+    def produce(t0, t1):
+        rows = (t1 - t0) * B
+        if rows <= 0:
+            return
+        a_ptr = flat.ptr + t0 * B * sA[0] * flat.itemsize
+        o_ptr = buf.ptr + t0 * B * N * buf.itemsize
+        env.timed(
+            f"gemm_{flat.dtype}_b1_{rows}x{N}x{K}",
+            lambda: ffi.check(env.lib.pthip_gemm(_dt(flat), 1, rows, N, K, 1.0, a_ptr, 0, sA[0], sA[1], W2.ptr, 0, sB[0], sB[1],
+                                                 0.0, None, 0, 0, 0, o_ptr)),
+        )
+
+    out.producer, out.steps, out.chunk = produce, T, chunk
+    out._keep = (flat, W2, buf)  # operands of launches that are still to come
+    return [out]
 
 
 @handler("GemmPartials")

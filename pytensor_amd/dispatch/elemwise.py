@@ -119,17 +119,24 @@ def _broadcast_shape(node, graph, ins, skip=()):
         return shape
     nd = max((i.ndim for i in ins), default=0)
     shape = [1] * nd
+    # operands are right-aligned (NumPy rule): the IR passes may leave an operand with fewer
+    # dimensions than its siblings (a producer folded in through a DimShuffle view, inline.py);
+    # the missing leading dimensions are broadcastable by construction
+    shp = [(1,) * (nd - i.ndim) + tuple(i.shape) for i in ins]
     for d in range(nd):
-        lens = {i.shape[d] for i in ins}
+        lens = {s[d] for s in shp}
         big = [l for l in lens if l != 1]
         if len(set(big)) > 1:
             raise ValueError(f"Incompatible Elemwise input shapes {[i.shape for i in ins]}")
         shape[d] = big[0] if big else (1 if lens else 1)
         if big and 1 in lens:
             # Elemwise._check_runtime_broadcast (elemwise.py:825-840)
-            for vid, arr in zip(node.inputs, ins):
+            for vid, arr, s in zip(node.inputs, ins, shp):
+                dd = d - (nd - arr.ndim)
+                if dd < 0:
+                    continue
                 static = graph.vars[vid].shape
-                if arr.shape[d] == 1 and static[d] != 1:
+                if s[d] == 1 and static[dd] != 1:
                     raise ValueError(
                         f"Runtime broadcasting not allowed. One input had a distinct dimension length of 1 along axis {d}, "
                         "but the static type does not mark it as broadcastable"
@@ -209,6 +216,9 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=
     nd = len(out_shape)
     partial = set(partial)
     gather = gather or {}
+    # right-align operands that arrive with fewer dimensions than the output (see _broadcast_shape)
+    ins = [a.view((1,) * (nd - a.ndim) + tuple(a.shape), (0,) * (nd - a.ndim) + tuple(a.strides))
+           if (isinstance(a, DeviceArray) and k not in partial and k not in gather and a.ndim < nd) else a for k, a in enumerate(ins)]
     modes = []
     flat = not partial
     for k, a in enumerate(ins) if flat else ():

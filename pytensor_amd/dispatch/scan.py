@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import numpy as np
 
+from pytensor_amd import ffi
 from pytensor_amd.device import DeviceArray, copy_into
 from pytensor_amd.dispatch import handler
 from pytensor_amd.executor import HipExecutable, HostValue
@@ -129,7 +130,35 @@ def scan(node, inputs, env):
         plan = inner._pack_plan = _pack_plan(ig, info)
     outer_ctx = getattr(env, "scan_ctx", None)
     ctx = {"pack_vars": plan[0], "tap_src": plan[1], "packed": {}, "t": 0} if plan[0] else None
+    # hoisted sequence products still to be computed (dispatch/blas.py::LazySeq): chunk 0 now, on this
+    # stream; chunk c+1 goes to stream 1 when the loop enters chunk c, and the loop waits for stream 1
+    # before it enters the next one — the MFMA-bound product runs beside the latency-bound steps
+    lazy = [s for s in seqs if getattr(s, "producer", None) is not None]
+    Tc = min((s.chunk for s in lazy), default=0)
+    side_started = False
+
+    def produce(c):
+        for s in lazy:
+            s.producer(c * Tc, min((c + 1) * Tc, n_steps))
+
+    if lazy:
+        produce(0)
     for t in range(n_steps):
+        if lazy and t % Tc == 0 and (t // Tc + 1) * Tc < n_steps:
+            c = t // Tc
+            if side_started:
+                ffi.check(env.lib.pthip_stream_wait(0, 1))  # chunk c (enqueued a chunk ago) before its first reader
+            else:
+                ffi.check(env.lib.pthip_stream_wait(1, 0))  # fork: behind everything that produced the operands
+                side_started = True
+            ffi.check(env.lib.pthip_stream_select(1))
+            try:
+                produce(c + 1)
+            finally:
+                ffi.check(env.lib.pthip_stream_select(0))
+        if lazy and side_started and t % Tc == 0 and (t // Tc + 1) * Tc >= n_steps:
+            ffi.check(env.lib.pthip_stream_wait(0, 1))  # the last chunk; also the join of the fork
+            side_started = False
         if ctx is not None:
             ctx["t"] = t
             for key in [key for key in ctx["packed"] if key[1] < t - plan[2]]:
@@ -193,6 +222,8 @@ def scan(node, inputs, env):
         steps_done = t + 1
         if info["as_while"] and bool(env.to_host(outs[o])):
             break
+    if side_started:  # (the loop ended before the last chunk's boundary: join the fork)
+        ffi.check(env.lib.pthip_stream_wait(0, 1))
     res = []
     for buf, mt in zip(rec_bufs, mintaps):
         L = buf.shape[0]

@@ -394,6 +394,8 @@ class HipExecutable:
         v = self.graph.vars[vid]
         if vid in self._const_cache:
             return self._const_cache[vid]
+        if v.const is None:
+            raise KeyError(f"hip linker: variable {vid} ({v.name}) has no value yet and is not a constant")
         a = np.asarray(v.const)
         if v.kind != "tensor" or a.size <= HOST_MAX:
             # small constants (alpha/beta of Gemv, fill values, shapes) stay on the host and
@@ -553,10 +555,17 @@ class HipExecutable:
                 todo.extend(reversed(self._branch_nodes.get((k, b), ())))
                 continue
             ins = []
-            for i in node.inputs:
+            lazy = None
+            if node.op == "IfElse":
+                # the inputs of the branch NOT taken were never computed (lazy, ifelse.py:300-345)
+                # and are not constants: the handler gets a placeholder for them
+                n_out = len(node.outputs)
+                b = taken[k]
+                lazy = set(range(1 + (1 - b) * n_out, 1 + (2 - b) * n_out))
+            for pos, i in enumerate(node.inputs):
                 v = vals.get(i)
                 if v is None:
-                    v = self._const(i, env)
+                    v = None if (lazy is not None and pos in lazy and g.vars[i].const is None) else self._const(i, env)
                 ins.append(v)
             h = handlers.get(node.op)
             if h is None:

@@ -498,7 +498,9 @@ def hoist_scan_seq_dots(g: Graph) -> Graph:
             vid = next_id
             next_id += 1
             out.vars[vid] = Var(vid, ov.dtype, (None, *ov.shape), "tensor", None, "scan_hoisted_dot")
-            pre_nodes.append(Node("SeqDot22", {}, [outer_seqs[s_pos], outer_non[w_pos]], [vid]))
+            # ("lazy": the Scan is the only consumer, as a sequence — its step driver may have the
+            #  product computed chunk by chunk on a second stream while the loop runs, dispatch/scan.py)
+            pre_nodes.append(Node("SeqDot22", {"lazy": True}, [outer_seqs[s_pos], outer_non[w_pos]], [vid]))
             new_outer_seqs.append(vid)
             new_inner_seqs.append(m.outputs[0])  # the inner var now arrives as a sequence slice
         new_inner.nodes = [m for k, m in enumerate(inner.nodes) if k not in hoist]

@@ -177,3 +177,34 @@ def test_scan_steps_with_packed_left_operands_are_bit_identical(hip, monkeypatch
     want = np_graph.run_graph(g, ins)
     for a, b in zip(got, want):
         np.testing.assert_allclose(a, b, rtol=1e-5, atol=2e-5)
+
+
+def test_scan_overlapped_hoisted_products_are_bit_identical(hip, monkeypatch):
+    """The hoisted sequence products (``x_t @ W`` for all t) of a long Scan are computed chunk by
+    chunk on a second stream while the steps run (dispatch/blas.py::LazySeq, dispatch/scan.py).
+    Row chunks of a GEMM are the same per-element fma chains: results are BIT-identical with the
+    overlap switched off (``PTHIP_SCAN_OVERLAP=0``: one product before the loop), eager and
+    replayed; the replayed plan is exercised twice (the fork/join must survive re-launching)."""
+    import json
+    import os
+
+    from pytensor_amd import configs
+    from pytensor_amd.dispatch.blas import LazySeq  # noqa: F401  (the class under test exists)
+    from pytensor_amd.executor import HipExecutable
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "tests", "golden", "c5_gru.json")))
+    g = Graph.from_dict(d)
+    v = configs.c5_inputs(T=230, B=64, H=1024, seed=77)  # 3.6 chunks of 64 steps: a ragged last chunk
+    ins = [v[n] for n in d["input_names"]]
+    monkeypatch.setenv("PTHIP_SCAN_OVERLAP", "1")
+    exe = HipExecutable(g, resident=range(len(ins)))
+    got = exe(*ins)
+    plan = exe.freeze(*ins)
+    r1, r2 = plan(*ins), plan(*ins)
+    monkeypatch.setenv("PTHIP_SCAN_OVERLAP", "0")
+    plain = HipExecutable(g, resident=range(len(ins)))(*ins)
+    for a, b, c, e in zip(got, r1, r2, plain):
+        np.testing.assert_array_equal(a, e)
+        np.testing.assert_array_equal(b, e)
+        np.testing.assert_array_equal(c, e)
