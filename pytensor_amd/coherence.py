@@ -165,6 +165,56 @@ class _Guard:
         self.release()
 
 
+class _ReadOnly:
+    """An update-fed shared value that lives in one of the executor's PINNED result blocks (the array
+    ``Function`` installs in the storage cell after a call with ``updates=``).  Pinned pages must not be
+    write-protected: the device writes through its own mapping and a CPU-side ``mprotect`` makes the
+    driver drop that mapping — a later device store then never completes (measured on the MI355X box,
+    profiles/r3b_guard_probe.txt).  The array is handed out read-only instead: an in-place edit
+    (``w.get_value(borrow=True)[i] = v``) raises NumPy's "assignment destination is read-only" — loud,
+    where the reference would silently accept it — and re-enabling the flag marks the value dirty
+    (conservative: the next call uploads it again).  ``get_value()`` (a copy) and ``set_value`` behave
+    as in the reference."""
+
+    __slots__ = ()
+    late = False
+
+    def clean(self, a):
+        return not a.flags.writeable
+
+    def release(self):
+        pass
+
+
+_pinned = []  # [lo, hi) address ranges of live pinned blocks (plan._PinnedBlock)
+
+
+def register_pinned(ptr: int, nbytes: int):
+    _pinned.append((int(ptr), int(ptr) + int(nbytes)))
+
+
+def unregister_pinned(ptr: int):
+    for k, (lo, _) in enumerate(_pinned):
+        if lo == int(ptr):
+            del _pinned[k]
+            return
+
+
+def is_pinned(lo: int, hi: int) -> bool:
+    return any(lo < phi and plo < hi for plo, phi in _pinned)
+
+
+def watch_update_fed(a: np.ndarray):
+    """Token for the host mirror of an update-fed resident: pinned + large -> read-only hand-out."""
+    if mode() != "trust" and a.nbytes > FULL_HASH_MAX and a.size and is_pinned(*_span(a)):
+        try:
+            a.flags.writeable = False
+            return _ReadOnly()
+        except ValueError:  # pragma: no cover
+            pass
+    return watch(a)
+
+
 def watch(a: np.ndarray):
     """Start watching ``a`` (just uploaded).  Returns a token with ``clean(a)``, ``release()`` and
     ``late`` (True: the check reads the array and is worth overlapping with device work), or
@@ -177,6 +227,8 @@ def watch(a: np.ndarray):
     if m == "sampled":
         return _Sample(a)
     lo, hi = _span(a)
+    if is_pinned(lo, hi):
+        return _Hash(a)  # (never mprotect pinned pages: see _ReadOnly)
     if not a.flags.writeable or hi - lo < 4 * _PAGE:
         # (a read-only mapping must not be made writable by the handler; nothing else can store
         # through this array object, but another view might: hash it)

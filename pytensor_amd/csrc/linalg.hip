@@ -390,6 +390,7 @@ __global__ __launch_bounds__(BLOCK) void potrf_lds_kernel(T* __restrict__ Lout,
 // (cholesky.py:78-80).  No host synchronisation: capturable into a hipGraph.
 // ---------------------------------------------------------------------------------
 constexpr int NBK = 64;       // panel width
+constexpr int NBO = 512;      // outer panel: the trailing matrix is updated once per NBO columns
 constexpr int CT_ROWS = 192;  // rows of the panel per workgroup (= threads of chol_trsm_kernel)
 
 // W[i][j] (i >= j) <- the referenced triangle of A; W[i][j] (i < j) <- 0.  32x32 tiles through LDS:
@@ -432,13 +433,15 @@ __global__ __launch_bounds__(CT_ROWS) void chol_trsm_kernel(T* __restrict__ W, l
   constexpr int XL = CT_ROWS + 1;   // row stride of Xs
   T* Ls = (T*)smem_raw;             // [NBK][LL]
   T* Xs = Ls + NBK * LL;            // [NBK][XL]
+  T* Rd = Xs + NBK * XL;            // [NBK] reciprocal pivots
   const int tid = threadIdx.x;
   const long long r0 = (long long)k + nb + (long long)blockIdx.x * CT_ROWS;
   const int rows = (int)((n - r0) < CT_ROWS ? (n - r0) : CT_ROWS);
-  for (int e = tid; e < nb * nb; e += CT_ROWS) {
-    const int i = e / nb, j = e - i * nb;
-    Ls[i * LL + j] = (j <= i) ? W[(long long)(k + i) * ld + k + j] : T(0);
+  for (int e = tid; e < NBK * NBK; e += CT_ROWS) {  // (the pad rows/columns of a short last panel: zeros)
+    const int i = e / NBK, j = e - i * NBK;
+    Ls[i * LL + j] = (i < nb && j <= i) ? W[(long long)(k + i) * ld + k + j] : T(0);
   }
+  if (tid < NBK) Rd[tid] = tid < nb ? T(1) / W[(long long)(k + tid) * ld + k + tid] : T(0);
   for (int e = tid; e < rows * nb; e += CT_ROWS) {
     const int r = e / nb, c = e - r * nb;
     Xs[c * XL + r] = W[(r0 + r) * ld + k + c];
@@ -446,21 +449,36 @@ __global__ __launch_bounds__(CT_ROWS) void chol_trsm_kernel(T* __restrict__ W, l
   __syncthreads();
   if (tid < rows) {
     constexpr int RB = 8;
+    typedef T T2 __attribute__((ext_vector_type(2)));
     for (int s0 = 0; s0 < nb; s0 += RB) {
       T acc[RB];
 #pragma unroll
       for (int r = 0; r < RB; r++) acc[r] = (s0 + r < nb) ? Xs[(s0 + r) * XL + tid] : T(0);
-      for (int c = 0; c < s0; c++) {
-        const T xc = Xs[c * XL + tid];
+      // columns already solved, four at a time (s0 is a multiple of 8): 4 own reads + 16 two-entry
+      // reads of L feed 32 FMAs — one thread per row means the chain is latency-, not LDS-bound,
+      // so the reads of a whole group are requested before its first FMA
+      for (int c = 0; c < s0; c += 4) {
+        const T x0 = Xs[c * XL + tid], x1 = Xs[(c + 1) * XL + tid], x2 = Xs[(c + 2) * XL + tid], x3 = Xs[(c + 3) * XL + tid];
+        T2 la[RB], lb[RB];
 #pragma unroll
-        for (int r = 0; r < RB; r++) acc[r] -= xc * Ls[(s0 + r) * LL + c];  // (rows past nb: zero-filled pad of Ls is never reached: s0 + r < NBK)
+        for (int r = 0; r < RB; r++) {
+          la[r] = *(const T2*)&Ls[(s0 + r) * LL + c];
+          lb[r] = *(const T2*)&Ls[(s0 + r) * LL + c + 2];
+        }
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+          acc[r] -= x0 * la[r].x;
+          acc[r] -= x1 * la[r].y;
+          acc[r] -= x2 * lb[r].x;
+          acc[r] -= x3 * lb[r].y;
+        }
       }
 #pragma unroll
       for (int r = 0; r < RB; r++) {
         if (s0 + r < nb) {
 #pragma unroll
           for (int r2 = 0; r2 < r; r2++) acc[r] -= acc[r2] * Ls[(s0 + r) * LL + s0 + r2];
-          acc[r] = acc[r] / Ls[(s0 + r) * LL + s0 + r];
+          acc[r] = acc[r] * Rd[s0 + r];  // reciprocal of the pivot, formed once per workgroup
           Xs[(s0 + r) * XL + tid] = acc[r];
         }
       }
@@ -522,30 +540,47 @@ int chol_blocked(int lower, long long n, const T* A, T* L) {
   auto kd = potrf_lds_kernel<T>;
   auto kt = chol_trsm_kernel<T>;
   const size_t lds_d = (size_t)NBK * (NBK | 1) * sizeof(T);
-  const size_t lds_t = (size_t)NBK * (NBK + 2 + CT_ROWS + 1) * sizeof(T);
+  const size_t lds_t = (size_t)NBK * (NBK + 2 + CT_ROWS + 1 + 1) * sizeof(T);
   static bool attr_t = false;
   if (!attr_t && lds_t > 64 * 1024) {
     if (hipError_t e = hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t); e != hipSuccess)
       return fail(pthip::check(e, "chol_trsm attribute"));
     attr_t = true;
   }
-  for (long long k = 0; k < n; k += NBK) {
-    const int nb = (int)((n - k) < NBK ? (n - k) : NBK);
-    T* D = W + k * n + k;
-    PTHIP_KLAUNCH(kd, dim3(1), dim3(BLOCK), lds_d, st, D, (const T*)D, nb, 1, (const T*)nullptr, (T*)nullptr, (long long)n, flag);
-    if ((r = pthip::post_launch("chol diag"))) return fail(r);
-    const long long m = n - k - nb;
-    if (m <= 0) break;
-    PTHIP_KLAUNCH(kt, dim3((unsigned)((m + CT_ROWS - 1) / CT_ROWS)), dim3(CT_ROWS), lds_t, st, W, n, (int)k, nb, (int)n);
-    if ((r = pthip::post_launch("chol trsm"))) return fail(r);
-    // trailing update, lower block triangle only: block columns of width cw, rows from the block down
-    long long cw = (m / 4 + 127) / 128 * 128;
-    if (cw < 256) cw = 256;
-    const T* P = W + (k + nb) * n + k;  // the panel just solved: m x nb, row stride n
-    for (long long c0 = 0; c0 < m; c0 += cw) {
-      const long long wN = (m - c0) < cw ? (m - c0) : cw;
-      r = pthip::gemm_inplace(dt, m - c0, wN, nb, -1.0, P + c0 * n, n, 1, P + c0 * n, 1, n, 1.0,
-                              W + (k + nb + c0) * n + (k + nb + c0), n);
+  // Two levels: NBO-column outer panels.  Inside one, every NBK-column step updates only the rest of
+  // the outer panel (a tall m x <=NBO strip, K = NBK); the matrix to the right of the outer panel is
+  // updated ONCE per outer panel with K = NBO — the GEMM runs at its large-K rate and the trailing
+  // matrix crosses HBM n/NBO times instead of n/NBK times (n = 4096, one level: 220 launches of a
+  // K = 64 update at 36 us each = 58 % of the factorisation, profiles/r3c_chol4096_kernel_stats.md).
+  for (long long K0 = 0; K0 < n; K0 += NBO) {
+    const long long Kend = (K0 + NBO < n) ? K0 + NBO : n;
+    for (long long k = K0; k < Kend; k += NBK) {
+      const int nb = (int)((Kend - k) < NBK ? (Kend - k) : NBK);
+      T* D = W + k * n + k;
+      PTHIP_KLAUNCH(kd, dim3(1), dim3(BLOCK), lds_d, st, D, (const T*)D, nb, 1, (const T*)nullptr, (T*)nullptr, (long long)n, flag);
+      if ((r = pthip::post_launch("chol diag"))) return fail(r);
+      const long long m = n - k - nb;
+      if (m <= 0) break;
+      PTHIP_KLAUNCH(kt, dim3((unsigned)((m + CT_ROWS - 1) / CT_ROWS)), dim3(CT_ROWS), lds_t, st, W, n, (int)k, nb, (int)n);
+      if ((r = pthip::post_launch("chol trsm"))) return fail(r);
+      const long long ncol = Kend - (k + nb);  // columns of the outer panel still to come
+      if (ncol > 0) {
+        const T* P = W + (k + nb) * n + k;  // the panel just solved: m x nb, row stride n
+        r = pthip::gemm_inplace(dt, m, ncol, nb, -1.0, P, n, 1, P, 1, n, 1.0, W + (k + nb) * n + (k + nb), n);
+        if (r) return fail(r);
+      }
+    }
+    const long long mo = n - Kend;
+    if (mo <= 0) break;
+    // the matrix right of / below the outer panel, lower block triangle only: block columns of width cw
+    const long long wo = Kend - K0;
+    const T* Lp = W + Kend * n + K0;  // mo x wo, row stride n
+    long long cw = (mo / 4 + 127) / 128 * 128;
+    if (cw < 512) cw = 512;
+    for (long long c0 = 0; c0 < mo; c0 += cw) {
+      const long long wN = (mo - c0) < cw ? (mo - c0) : cw;
+      r = pthip::gemm_inplace(dt, mo - c0, wN, wo, -1.0, Lp + c0 * n, n, 1, Lp + c0 * n, 1, n, 1.0,
+                              W + (Kend + c0) * n + (Kend + c0), n);
       if (r) return fail(r);
     }
   }

@@ -394,7 +394,7 @@ class HipExecutable:
         v = self.graph.vars[vid]
         if vid in self._const_cache:
             return self._const_cache[vid]
-        if v.const is None:
+        if v.const is None and v.kind == "tensor":  # (a NoneConst argument is a constant whose value IS None)
             raise KeyError(f"hip linker: variable {vid} ({v.name}) has no value yet and is not a constant")
         a = np.asarray(v.const)
         if v.kind != "tensor" or a.size <= HOST_MAX:
@@ -513,7 +513,8 @@ class HipExecutable:
         for pos, o in fed:
             ent = self._resident_cache[pos]
             h = host[o]
-            ent.rewatch(_resident_key(h, h), h, h)
+            coherence.release(ent.fp)
+            ent.key, ent.host, ent.fp = _resident_key(h, h), h, coherence.watch_update_fed(h)
 
     # ------------------------------------------------------------------
     def run_device(self, inputs, env=None):
@@ -565,7 +566,7 @@ class HipExecutable:
             for pos, i in enumerate(node.inputs):
                 v = vals.get(i)
                 if v is None:
-                    v = None if (lazy is not None and pos in lazy and g.vars[i].const is None) else self._const(i, env)
+                    v = None if (lazy is not None and pos in lazy and g.vars[i].const is None and g.vars[i].kind == "tensor") else self._const(i, env)
                 ins.append(v)
             h = handlers.get(node.op)
             if h is None:

@@ -35,7 +35,7 @@ import weakref
 
 import numpy as np
 
-from pytensor_amd import ffi
+from pytensor_amd import coherence, ffi
 from pytensor_amd.device import Buffer, DeviceArray, contiguous_strides
 from pytensor_amd.executor import Env, HostValue
 
@@ -60,6 +60,7 @@ class _PinnedBlock:
         p = C.c_void_p()
         ffi.check(ffi.lib().pthip_host_alloc(self.nbytes, C.byref(p)))
         self.ptr = p.value
+        coherence.register_pinned(self.ptr, self.nbytes)  # (these pages are never write-protected)
         raw = (C.c_char * self.nbytes).from_address(self.ptr)
         self.views = []
         for (shape, dtype), o in zip(specs, self.offsets):
@@ -69,6 +70,7 @@ class _PinnedBlock:
     def free(self):
         if self.ptr:
             self.views = []
+            coherence.unregister_pinned(self.ptr)
             ffi.lib().pthip_host_free(self.ptr)
             self.ptr = 0
 

@@ -130,3 +130,26 @@ def test_faulthandler_enabled_after_us_does_not_break_tracking():
     t.release()
     if not was:
         faulthandler.disable()
+
+
+def test_pinned_ranges_are_never_guarded_and_fed_values_are_handed_out_read_only():
+    """Pinned result blocks must not be mprotect-ed (a device store into them would never complete):
+    an array inside a registered pinned range is hashed; as the host mirror of an update-fed
+    resident it is handed out read-only, and re-enabling writes marks it dirty."""
+    a = np.zeros(1 << 16)
+    lo = a.ctypes.data
+    coherence.register_pinned(lo, a.nbytes)
+    try:
+        assert type(coherence.watch(a)).__name__ == "_Hash"
+        assert _slots() == (0, 0)
+        t = coherence.watch_update_fed(a)
+        assert type(t).__name__ == "_ReadOnly" and not a.flags.writeable and t.clean(a)
+        with pytest.raises(ValueError, match="read-only"):
+            a[5] = 1.0
+        a.flags.writeable = True  # the user insists: conservative dirty
+        assert not t.clean(a)
+    finally:
+        coherence.unregister_pinned(lo)
+    assert type(coherence.watch(a)).__name__ == "_Guard"
+    small = np.zeros(100)
+    assert type(coherence.watch_update_fed(small)).__name__ == "_Hash"

@@ -406,6 +406,49 @@ def test_updates_sgd_loop_stays_on_device_and_replays(pt):
     assert_close(w_hip.get_value(), w_ref.get_value(), "weights after reset", rtol=1e-10, atol=1e-13)
 
 
+def test_large_updated_shared_value_is_coherent_and_loud(pt):
+    """An updated shared value of 160 kB: after the eager call its host mirror is an ordinary array
+    (write-protected pages see an in-place edit); on the replay path it lives in a pinned result
+    block, which must not be write-protected — it is handed out read-only, so the edit the
+    reference would accept raises instead of going stale.  ``get_value()`` copies and
+    ``set_value`` work as in the reference, and the trajectory matches the C linker throughout."""
+    pytensor, ptt = pt
+    rng = np.random.default_rng(113)
+    n = 20_000
+    w0, g0 = rng.normal(size=n), rng.normal(size=n)
+
+    def build(mode):
+        w = pytensor.shared(w0.copy(), name="w")
+        g = pytensor.shared(g0.copy(), name="g")
+        lr = ptt.dscalar("lr")
+        return pytensor.function([lr], (w * g).sum(), updates={w: w - lr * g * ptt.tanh(w)}, mode=mode), w
+
+    (f_hip, w_hip), (f_ref, w_ref) = build("hip"), build(E.reference_mode())
+
+    def step(c, atol=1e-9):
+        assert_close(f_hip(0.1), f_ref(0.1), f"call {c}", atol=atol)
+        assert_close(w_hip.get_value(), w_ref.get_value(), f"w after call {c}")
+
+    step(0)  # eager: the new value is an ordinary host array
+    for w in (w_hip, w_ref):
+        w.get_value(borrow=True)[17] += 3.0  # accepted by both, seen by the next call
+    for c in range(1, 5):
+        step(c)
+    assert E.hip_executable(f_hip)._auto_plan is not None
+    cur = w_hip.get_value(borrow=True)
+    if not cur.flags.writeable:  # (pinned hand-out)
+        with pytest.raises(ValueError, match="read-only"):
+            cur[0] = 1.0
+    copy = w_hip.get_value()
+    copy[0] = 123.0  # a copy is the caller's
+    step(5)
+    new = rng.normal(size=n)
+    w_hip.set_value(new.copy())
+    w_ref.set_value(new.copy())
+    for c in range(6, 9):
+        step(c)
+
+
 def test_function_without_outputs_only_updates(pt):
     pytensor, ptt = pt
     c = pytensor.shared(np.zeros(5), name="c")
