@@ -743,12 +743,17 @@ def _scan(p, inputs, node, graph):
         if info["as_while"] and bool(outs[o]):
             break
     res = []
-    for buf, mt in zip(rec_bufs, mintaps):
+    for j, (buf, mt) in enumerate(zip(rec_bufs, mintaps)):
         # rotate circular buffers so that the oldest entry comes first (op.py:2087-2130)
         L = buf.shape[0]
         end = (steps_done + mt) % L
         if steps_done + mt > L and end != 0:
             buf = np.concatenate([buf[end:], buf[:end]])
+        elif j >= n_mm and L > steps_done + mt and n_steps > 0 and not info["as_while"]:
+            # op.py:2280-2286: a buffer longer than the steps taken (truncated back-propagation
+            # through time): "Scan is expected to return 0 for all entries for which the gradient
+            # is not actually computed"
+            buf[steps_done + mt :] = 0
         if info["as_while"]:
             buf = buf[: steps_done + mt]
         res.append(buf)

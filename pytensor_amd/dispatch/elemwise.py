@@ -24,8 +24,11 @@ import os as _os
 MAX_GRID = int(_os.environ.get("PTHIP_EW_MAXGRID", 256 * 8))  # ≫256 workgroups, grid-stride beyond (cdna guide G11)
 EW_UNROLL = int(_os.environ.get("PTHIP_EW_UNROLL", 2))
 # software-pipelined main loop (codegen.flat_kernel_source prefetch=True) for scalar graphs with at
-# least this many nodes: below it the loop is a pure stream and the extra registers buy nothing
-EW_PREFETCH_MIN_OPS = int(_os.environ.get("PTHIP_EW_PREFETCH_MIN_OPS", 24))
+# least this many nodes.  OPT-IN: measured on config #2's 52-op fp64 body (profiles/r3c_c2_prefetch.txt)
+# 33.3 / 34.8 us with it (unroll 1 / 2) against 32.6-34.7 without — inside the run-to-run spread; the
+# kernel is co-limited by fp64 issue (PMC: 12.9 M VALU wave-instructions = 21 us per SIMD) and HBM
+# (25 us), and eight resident waves per SIMD already overlap the two as well as a prefetch does
+EW_PREFETCH_MIN_OPS = int(_os.environ.get("PTHIP_EW_PREFETCH_MIN_OPS", 1 << 30))
 
 _body_key_cache = {}
 

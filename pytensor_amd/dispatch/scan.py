@@ -225,11 +225,23 @@ def scan(node, inputs, env):
     if side_started:  # (the loop ended before the last chunk's boundary: join the fork)
         ffi.check(env.lib.pthip_stream_wait(0, 1))
     res = []
-    for buf, mt in zip(rec_bufs, mintaps):
+
+    def zero_tail(buf, filled):
+        # op.py:2280-2286 / scan_perform.pyx:572-577: rows the loop never reached (a buffer longer than
+        # the steps taken: truncated back-propagation through time) are returned as zeros
+        row = buf.itemsize
+        for s_ in buf.shape[1:]:
+            row *= s_
+        if buf.shape[0] > filled and row:
+            ffi.check(env.lib.pthip_memset(buf.ptr + filled * row, 0, (buf.shape[0] - filled) * row))
+
+    for j, (buf, mt) in enumerate(zip(rec_bufs, mintaps)):
         L = buf.shape[0]
         end = (steps_done + mt) % L
         if steps_done + mt > L and end != 0:
             buf = _roll_to_front(buf, end)
+        elif j >= n_mm and not info["as_while"] and n_steps > 0:  # (n_steps == 0 returns the buffers as given: scan_perform.pyx:275-283)
+            zero_tail(buf, steps_done + mt)
         if info["as_while"]:
             buf = buf.view((min(L, steps_done + mt), *buf.shape[1:]), buf.strides)
         res.append(buf)
@@ -239,6 +251,8 @@ def scan(node, inputs, env):
             buf = DeviceArray.empty((0,) * (ov.ndim + 1), ov.dtype)
         elif steps_done > nit_lens[j] and steps_done % nit_lens[j]:
             buf = _roll_to_front(buf, steps_done % nit_lens[j])
+        elif not info["as_while"]:
+            zero_tail(buf, steps_done)
         if info["as_while"]:
             buf = buf.view((min(buf.shape[0], steps_done), *buf.shape[1:]), buf.strides)
         res.append(buf)

@@ -182,9 +182,10 @@ def test_scan_steps_with_packed_left_operands_are_bit_identical(hip, monkeypatch
 def test_scan_overlapped_hoisted_products_are_bit_identical(hip, monkeypatch):
     """The hoisted sequence products (``x_t @ W`` for all t) of a long Scan are computed chunk by
     chunk on a second stream while the steps run (dispatch/blas.py::LazySeq, dispatch/scan.py).
-    Row chunks of a GEMM are the same per-element fma chains: results are BIT-identical with the
-    overlap switched off (``PTHIP_SCAN_OVERLAP=0``: one product before the loop), eager and
-    replayed; the replayed plan is exercised twice (the fork/join must survive re-launching)."""
+    Opt-in (measured: no gain on this chip, see dispatch/blas.py::LazySeq) but kept correct: row
+    chunks of a GEMM are the same per-element fma chains, so results are BIT-identical with the
+    overlap switched off (the default: one product before the loop), eager and replayed; the
+    replayed plan is exercised twice (the fork/join must survive re-launching)."""
     import json
     import os
 

@@ -499,6 +499,29 @@ def test_scan_cumulative_with_until_and_grad(pt):
                         atol=1e-14)
 
 
+def test_scan_truncated_gradient_unreached_steps_are_zero(pt):
+    """``truncate_gradient=k``: the backward Scan runs k steps into buffers of length T; "Scan is
+    expected to return 0 for all entries for which the gradient is not actually computed"
+    (scan/op.py:2280-2286, scan_perform.pyx:572-577).  Found by the reference's own
+    ``TestScan::test_grad_multiple_outs_some_truncate`` under the hip linker: the device loop left
+    those rows as the pool handed them out."""
+    pytensor, ptt = pt
+    rng = np.random.default_rng(114)
+    T = 9
+    u, x0, W = ptt.dmatrix("u"), ptt.dvector("x0"), ptt.dmatrix("W")
+
+    def step(u_t, x_tm1, W):
+        return ptt.tanh(ptt.dot(u_t, W) + x_tm1)
+
+    xs = pytensor.scan(step, sequences=u, outputs_info=x0, non_sequences=W, truncate_gradient=3, return_updates=False)
+    cost = (xs[-1] ** 2).sum()
+    grads = pytensor.grad(cost, [u, x0, W])
+    vals = [rng.normal(size=(T, 4)), rng.normal(size=4), 0.3 * rng.normal(size=(4, 4))]
+    for _ in range(3):  # (garbage in recycled pool blocks differs from call to call)
+        f, got = E.compare_hip_and_cvm([u, x0, W], grads, vals, atol=1e-12)
+        assert not got[0][: T - 3].any(), "gradient rows of the steps beyond the truncation must be exactly zero"
+
+
 def test_indexing_tier_is_bit_exact(pt):
     pytensor, ptt = pt
     x, M = ptt.dvector("x"), ptt.dmatrix("M")
