@@ -659,7 +659,9 @@ def _check_and_raise(p, inputs, node, graph):
     # pytensor/raise_op.py:26+ (CheckAndRaise.perform)
     x, *conds = inputs
     if not all(np.all(c) for c in conds):
-        exc = {"AssertionError": AssertionError, "ValueError": ValueError}.get(p["exc_type"], RuntimeError)
+        import builtins
+
+        exc = np.linalg.LinAlgError if p["exc_type"] == "LinAlgError" else getattr(builtins, p["exc_type"], RuntimeError)
         raise exc(p["msg"])
     return [x]
 

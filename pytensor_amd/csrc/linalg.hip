@@ -437,14 +437,40 @@ __global__ __launch_bounds__(CT_ROWS) void chol_trsm_kernel(T* __restrict__ W, l
   const int tid = threadIdx.x;
   const long long r0 = (long long)k + nb + (long long)blockIdx.x * CT_ROWS;
   const int rows = (int)((n - r0) < CT_ROWS ? (n - r0) : CT_ROWS);
-  for (int e = tid; e < NBK * NBK; e += CT_ROWS) {  // (the pad rows/columns of a short last panel: zeros)
-    const int i = e / NBK, j = e - i * NBK;
-    Ls[i * LL + j] = (i < nb && j <= i) ? W[(long long)(k + i) * ld + k + j] : T(0);
+  // staging: one workgroup cannot hide memory latency with occupancy (three waves on the CU), so the
+  // loads are issued in batches of 16 per thread before the first LDS store (a one-load-per-iteration
+  // loop measured 52 us per panel at n = 2048 fp64 — 64 dependent round trips, profiles/r3f_chol2048_timeline.md)
+  constexpr int UN = 16;
+  for (int e0 = 0; e0 < NBK * NBK; e0 += CT_ROWS * UN) {  // (the pad rows/columns of a short last panel: zeros)
+    T v[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int e = e0 + u * CT_ROWS + tid;
+      const int i = e / NBK, j = e - i * NBK;
+      v[u] = (e < NBK * NBK && i < nb && j <= i) ? W[(long long)(k + i) * ld + k + j] : T(0);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int e = e0 + u * CT_ROWS + tid;
+      if (e < NBK * NBK) Ls[(e / NBK) * LL + (e % NBK)] = v[u];
+    }
   }
   if (tid < NBK) Rd[tid] = tid < nb ? T(1) / W[(long long)(k + tid) * ld + k + tid] : T(0);
-  for (int e = tid; e < rows * nb; e += CT_ROWS) {
-    const int r = e / nb, c = e - r * nb;
-    Xs[c * XL + r] = W[(r0 + r) * ld + k + c];
+  const int tot = rows * nb;
+  for (int e0 = 0; e0 < tot; e0 += CT_ROWS * UN) {
+    T v[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int e = e0 + u * CT_ROWS + tid;
+      const int r = e / nb, c = e - r * nb;
+      v[u] = (e < tot) ? W[(r0 + r) * ld + k + c] : T(0);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int e = e0 + u * CT_ROWS + tid;
+      const int r = e / nb, c = e - r * nb;
+      if (e < tot) Xs[c * XL + r] = v[u];
+    }
   }
   __syncthreads();
   if (tid < rows) {

@@ -195,11 +195,20 @@ def check_and_raise(node, inputs, env):
     for c in conds:
         cv = env.to_host(c)
         if not np.all(cv):
-            exc = {"AssertionError": AssertionError, "ValueError": ValueError, "TypeError": TypeError}.get(
-                node.params["exc_type"], RuntimeError
-            )
-            raise exc(node.params["msg"])
+            raise _exception_class(node.params["exc_type"])(node.params["msg"])
     return [x]
+
+
+def _exception_class(name: str):
+    """The exception class a ``CheckAndRaise`` was built with (raise_op.py:26), by name: the IR is
+    serialisable, so the class travels as a string — builtins and the NumPy ``LinAlgError`` that
+    ``cholesky(on_error="raise")`` / ``solve`` checks use (linalg/decomposition/cholesky.py:194)."""
+    import builtins
+
+    if name == "LinAlgError":
+        return np.linalg.LinAlgError
+    cls = getattr(builtins, name, None)
+    return cls if isinstance(cls, type) and issubclass(cls, BaseException) else RuntimeError
 
 
 @handler("HostPerform")

@@ -35,10 +35,12 @@ def _t(x: DeviceArray) -> DeviceArray:
 
 
 def _matrix(env, v, what):
-    x = env.to_device(v)
-    _require_float(x, what)
+    from pytensor_amd.dispatch.linalg import _lapack_operands
+
+    (x,) = _lapack_operands(env, what, v)
     if x.ndim != 2:
-        raise ValueError(f"{what}: expected a matrix, got {x.ndim} dimensions")
+        # (np.linalg raises LinAlgError: "%d-dimensional array given. Array must be two-dimensional")
+        raise np.linalg.LinAlgError(f"{what}: {x.ndim}-dimensional array given. Array must be two-dimensional")
     return x
 
 
@@ -242,15 +244,9 @@ def gttrs_device(env, dl, d, du, du2, ipiv, b, transposed):
 
 
 def _same_float(env, vals, what):
-    devs = [env.to_device(v) for v in vals]
-    for v in devs:
-        _require_float(v, what)
-    dt = np.result_type(*[np.dtype(v.dtype) for v in devs])
-    if any(np.dtype(v.dtype) != dt for v in devs):
-        from pytensor_amd.dispatch.elemwise import _cast
+    from pytensor_amd.dispatch.linalg import _lapack_operands
 
-        devs = [v if np.dtype(v.dtype) == dt else _cast(env, v.contiguous(), dt) for v in devs]
-    return devs
+    return _lapack_operands(env, what, *vals)
 
 
 @handler("LUFactorTridiagonal")

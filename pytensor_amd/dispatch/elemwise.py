@@ -116,9 +116,16 @@ def _broadcast_shape(node, graph, ins, skip=()):
         keep = [k for k in range(len(ins)) if k not in skip]
         sel = type("_Sel", (), {"inputs": [node.inputs[k] for k in keep]})
         shape = _broadcast_shape(sel, graph, [ins[k] for k in keep])
+        # a slab operand (S, *product shape) is the unfinished product itself: it takes part in the
+        # broadcast with its trailing shape (every other operand may be a broadcast row / scalar —
+        # reference test tests/tensor/linalg/test_decomposition/test_qr.py::test_qr_grad)
         for k in skip:
-            if tuple(ins[k].shape[1:]) != shape:
+            ps = tuple(ins[k].shape[1:])
+            nd = max(len(ps), len(shape))
+            a, b = (1,) * (nd - len(shape)) + tuple(shape), (1,) * (nd - len(ps)) + ps
+            if any(x != y and x != 1 for x, y in zip(a, b)):
                 raise ValueError(f"Incompatible Elemwise input shapes {[i.shape for i in ins]}")
+            shape = b
         return shape
     nd = max((i.ndim for i in ins), default=0)
     shape = [1] * nd

@@ -19,8 +19,31 @@ def _dt(x):
 
 
 def _require_float(x, what):
-    if x.dtype.kind != "f":
+    if x.dtype.kind != "f" or x.dtype.itemsize < 4:
         raise NotImplementedError(f"{what}: only float32/float64 on the device")
+
+
+def _lapack_dtype(dt) -> np.dtype:
+    """The working dtype LAPACK would use for an operand of dtype ``dt``
+    (pytensor/tensor/linalg/dtype_utils.py:9-26, i.e. scipy's ``find_best_lapack_type``): float64 for
+    doubles and integers wider than 16 bits, float32 for everything narrower."""
+    dt = np.dtype(dt)
+    if dt.kind == "c":
+        raise NotImplementedError("complex dtypes are not lowered by the hip linker")
+    if (dt.kind == "f" and dt.itemsize > 4) or (dt.kind in "ibu" and dt.itemsize > 2):
+        return np.dtype("float64")
+    return np.dtype("float32")
+
+
+def _lapack_operands(env, what, *vals):
+    """Operands of a LAPACK-family op on the device, promoted as the reference promotes them: each to
+    its LAPACK type, then to their common type (integer, bool and float16 matrices are legal inputs
+    of ``cholesky`` / ``solve`` / ``lstsq``; the reference's test_solve_dtype walks all pairs)."""
+    from pytensor_amd.dispatch.elemwise import _cast
+
+    xs = [env.to_device(v) for v in vals]
+    work = np.result_type(*(_lapack_dtype(x.dtype) for x in xs))
+    return [x if np.dtype(x.dtype) == work else _cast(env, x.contiguous(), work) for x in xs]
 
 
 def _batchify(x: DeviceArray, core_ndim: int, bshape):
@@ -45,7 +68,7 @@ def _cs(shape):
 
 
 def cholesky_device(env, a: DeviceArray, lower: bool) -> DeviceArray:
-    _require_float(a, "Cholesky")
+    (a,) = _lapack_operands(env, "Cholesky", a)
     if a.shape[-1] != a.shape[-2]:
         raise ValueError("Cholesky: matrix must be square")
     n = a.shape[-1]
@@ -58,14 +81,12 @@ def cholesky_device(env, a: DeviceArray, lower: bool) -> DeviceArray:
 
 
 def trsm_device(env, T: DeviceArray, b: DeviceArray, lower, unit, b_ndim, trans=False) -> DeviceArray:
-    _require_float(T, "SolveTriangular")
+    T, b = _lapack_operands(env, "SolveTriangular", T, b)
     n = T.shape[-1]
     if T.shape[-2] != n:
         raise ValueError("SolveTriangular: matrix must be square")
     if b.shape[b.ndim - b_ndim] != n:
         raise ValueError(f"SolveTriangular: incompatible shapes {T.shape} and {b.shape}")
-    if str(b.dtype) != str(T.dtype):
-        raise TypeError("SolveTriangular: dtype mismatch")
     bT, bb = T.shape[:-2], b.shape[: b.ndim - b_ndim]
     bshape = tuple(np.broadcast_shapes(bT, bb))
     nb = int(np.prod(bshape)) if bshape else 1
@@ -101,8 +122,7 @@ def cholesky(node, inputs, env):
 def cholesky_trsv(node, inputs, env):
     """``L = cholesky(S, lower); x = L^-1 b`` in one launch (fusion.fuse_cholesky_solve); falls
     back to the two separate kernels when the matrix does not fit the LDS-resident one."""
-    S, b = (env.to_device(i) for i in inputs)
-    _require_float(S, "Cholesky")
+    S, b = _lapack_operands(env, "Cholesky", *inputs)
     n = S.shape[-1]
     if S.shape[0] != n:
         raise ValueError("Cholesky: matrix must be square")

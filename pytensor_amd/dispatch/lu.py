@@ -19,7 +19,9 @@ from pytensor_amd.dispatch.linalg import _batchify, _dt, _require_float, cho_sol
 
 def getrf_device(env, a: DeviceArray, flag_singular=False):
     """(LU, perm, sign, logabsdet) of a (..., n, n) array; batch dims flattened."""
-    _require_float(a, "LU")
+    from pytensor_amd.dispatch.linalg import _lapack_operands
+
+    (a,) = _lapack_operands(env, "LU", a)
     n = a.shape[-1]
     if a.shape[-2] != n:
         raise ValueError("expected a square matrix")
@@ -84,6 +86,9 @@ def solve_general(env, A: DeviceArray, b: DeviceArray, b_ndim: int) -> DeviceArr
 
 
 def _solve(env, p, A, b):
+    from pytensor_amd.dispatch.linalg import _lapack_operands
+
+    A, b = _lapack_operands(env, "Solve", A, b)  # (integer / float16 operands: LAPACK's working type)
     assume = p["assume_a"]
     if assume == "pos":
         # scipy posv reads the triangle named by `lower` (default: upper)
@@ -191,8 +196,9 @@ def eigh(node, inputs, env):
     Leading dims are a batch (``Blockwise``)."""
     if len(inputs) == 2:
         return _eigh_generalised(node, inputs, env)
-    a = env.to_device(inputs[0])
-    _require_float(a, "Eigh")
+    from pytensor_amd.dispatch.linalg import _lapack_operands
+
+    (a,) = _lapack_operands(env, "Eigh", inputs[0])
     n = a.shape[-1]
     if a.shape[-2] != n:
         raise ValueError("Eigh: expected a square matrix")
@@ -222,13 +228,12 @@ def _eigh_generalised(node, inputs, env):
     sygvd): the same reduction LAPACK's ``sygst`` does, out of kernels that exist — ``B = L L^T``
     (potrf), ``C = L^-1 A L^-T`` (two multi-rhs triangular solves), the standard problem for C
     (Jacobi), ``v = L^-T y``.  Eigenvectors come out B-orthonormal (``v^T B v = I``) like scipy's."""
-    a, b = (env.to_device(i) for i in inputs)
-    _require_float(a, "Eigh")
+    from pytensor_amd.dispatch.linalg import _lapack_operands
+
+    a, b = _lapack_operands(env, "Eigh", *inputs)
     n = a.shape[-1]
     if a.shape[-2] != n or b.shape[-2:] != (n, n):
         raise ValueError(f"Eigh: incompatible shapes {a.shape} and {b.shape}")
-    if str(a.dtype) != str(b.dtype):
-        raise TypeError("Eigh: dtype mismatch")
     if a.ndim != 2 or b.ndim != 2:
         raise NotImplementedError("hip linker: batched generalised Eigh")
     lower = bool(node.params["lower"])
