@@ -1547,9 +1547,12 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
     the MFMA fragments are read back with ``ds_read_b128`` — instead of fragment-shaped loads (16 rows x
     64 B per instruction), which the texture addresser serves at half rate.  Wave-local: no barrier.
 
-    ``var``: ``"acc2"`` gives a product that has an accumulator chain to itself two of them (even /
-    odd k-groups, added at the end): ``v_mfma_f32_16x16x4_f32`` issues every 32 cycles but its result
-    feeds a dependent MFMA only after 40 (MI355X_MICROARCH.md), so a single chain runs at 80 %.
+    ``var``: ``"acc4"`` (the default of dispatch/dotew.py) / ``"acc2"`` split every product's
+    accumulator into 4 / 2 chains (k-groups round-robin; two chains each when two products share
+    their left operand), added in a fixed order at the end.  Measured: no time (the kernels wait on
+    memory, profiles/r3a_dotew_variants.txt) but accuracy — an MFMA chain is a k-ordered fma chain,
+    and 1000 GRU steps of 256-term chains drifted 1.3x further from the fp64 trajectory than
+    OpenBLAS's blocked sums; shorter chains close most of that (tests/test_gpu_fullsize.py).
     The other values are TIMING-ONLY decompositions (wrong results; tools/dotew_variants.py):
     ``nomfma`` (VALU stand-ins for the MFMAs), ``noload`` (operands from a kernel argument),
     ``apacked`` (the left operand fetched with the packed operand's 1-KiB-contiguous pattern).
@@ -1567,6 +1570,7 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
     dot_pos = list(dot_pos)
     packed_a = set(packed_a)
     pack_outs = list(pack_outs)
+    nacc = 4 if "acc4" in var else 2 if "acc2" in var else 1
     byvalue = set(byvalue)
     T = body["in_dtypes"][dot_pos[0]]
     assert T in _MFMA16 and all(body["in_dtypes"][p] == T for p in dot_pos)
@@ -1622,8 +1626,8 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
         L.append(f"  const {ct} fake_ = ({ct})M;")
     for p in dot_pos:
         L.append(f"  dvec4 acc{p} = {{0, 0, 0, 0}};")
-        if "acc2" in var:
-            L.append(f"  dvec4 acd{p} = {{0, 0, 0, 0}};")
+        for a in range(1, nacc):
+            L.append(f"  dvec4 acc{p}_{a} = {{0, 0, 0, 0}};")
         if "apacked" in var or p in packed_a:
             L.append(f"  const dvec4* ap{p} = (const dvec4*)A{p} + (((long long)blockIdx.y * {K // 4} + (long long)wave * {GW * 4} + kq) * 16 + li);")
         else:
@@ -1688,7 +1692,8 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
         for u in range(n):
             for j in range(4):
                 for q, p in enumerate(gr):
-                    acc = f"acd{p}" if ("acc2" in var and len(gr) == 1 and (u & 1)) else f"acc{p}"
+                    a = u % (nacc if len(gr) == 1 else max(nacc // 2, 1))
+                    acc = f"acc{p}_{a}" if a else f"acc{p}"
                     if "nomfma" in var:
                         out.append(f"  acc{p}[{j}] += ra_[{s & 1}][{u}][{j}] * {bufs[q]}[{s & 1}][{u}][{j}];")
                     else:
@@ -1725,9 +1730,13 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
     # included, is sunk into `if (live)` behind the barrier
     for e in early:
         L.append(f'  asm volatile("" : "+v"({e}));')
-    if "acc2" in var:
+    if nacc > 1:
         for p in dot_pos:
-            L.append(f"  acc{p} += acd{p};")
+            # fixed order: ((a0 + a1) + (a2 + a3)); chains a product never used stay zero
+            if nacc == 4:
+                L.append(f"  acc{p} = (acc{p} + acc{p}_1) + (acc{p}_2 + acc{p}_3);")
+            else:
+                L.append(f"  acc{p} += acc{p}_1;")
     for d, p in enumerate(dot_pos):
         # accumulator register v of lane (li, kq): f32 16x16x4 -> row 4*kq + v; f64 -> row kq + 4*v
         row = "4 * kq + v" if T == "float32" else "kq + 4 * v"

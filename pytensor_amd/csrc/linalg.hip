@@ -517,6 +517,103 @@ __global__ __launch_bounds__(CT_ROWS) void chol_trsm_kernel(T* __restrict__ W, l
   }
 }
 
+// The same panel solve on the matrix cores (full panels, nb == NBK): blocked substitution over the
+// four 16-column blocks of the panel,  X_j = (A_j - sum_{c<j} X_c L_jc^T) inv(L_jj)^T.  The sums and the
+// product with the 16x16 inverse are v_mfma_*_16x16x4 steps on operands read from LDS; the inverses of
+// the four diagonal blocks are formed once per workgroup by one wave (lane = block x column, forward
+// substitution in registers).  Every 16-row tile of the slab belongs to ONE wave from the first barrier
+// to the write-back, so the blocks need no further synchronisation (LDS operations of a wave complete
+// in order).  The one-thread-per-row kernel above stays as the general path (short panels) and as
+// the A/B reference (PTHIP_CHOL_TRSM=scalar).
+constexpr int CM_ROWS = 192;  // rows per workgroup: 12 tiles, three per wave
+template <class T>
+__global__ __launch_bounds__(BLOCK) void chol_trsm_mfma_kernel(T* __restrict__ W, long long ld, int k, int n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int LLs = NBK + 1, XLs = NBK + 1;  // odd row strides: operand columns walk distinct banks
+  T* Ls = (T*)smem_raw;              // [NBK][LLs]     L11
+  T* Xs = Ls + NBK * LLs;            // [CM_ROWS][XLs] the slab, row-major
+  T* Dv = Xs + CM_ROWS * XLs;        // [4][16][17]    inverses of the diagonal 16x16 blocks
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const long long r0 = (long long)k + NBK + (long long)blockIdx.x * CM_ROWS;
+  const int rows = (int)((n - r0) < CM_ROWS ? (n - r0) : CM_ROWS);
+  constexpr int UN = 16;
+  for (int e0 = 0; e0 < NBK * NBK; e0 += BLOCK * UN) {
+    T v[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int e = e0 + u * BLOCK + tid;
+      const int i = e / NBK, j = e - i * NBK;
+      v[u] = (e < NBK * NBK && j <= i) ? W[(long long)(k + i) * ld + k + j] : T(0);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int e = e0 + u * BLOCK + tid;
+      if (e < NBK * NBK) Ls[(e / NBK) * LLs + (e % NBK)] = v[u];
+    }
+  }
+  for (int e0 = 0; e0 < CM_ROWS * NBK; e0 += BLOCK * UN) {
+    T v[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int e = e0 + u * BLOCK + tid;
+      const int r = e / NBK, c = e - r * NBK;
+      v[u] = (r < rows) ? W[(r0 + r) * ld + k + c] : T(0);  // (rows past the matrix: zeros, never written back)
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int e = e0 + u * BLOCK + tid;
+      const int r = e / NBK, c = e - r * NBK;
+      if (e < CM_ROWS * NBK) Xs[r * XLs + c] = v[u];
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    // lane = 16 * block + column: column `li` of inv(L_jj), j = lq, by forward substitution
+    const T* Lj = Ls + (lq * 16) * LLs + lq * 16;
+    T x[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      T s = (i == li) ? T(1) : T(0);
+#pragma unroll
+      for (int q = 0; q < i; q++) s -= Lj[i * LLs + q] * x[q];
+      x[i] = (i < li) ? T(0) : s / Lj[i * LLs + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) Dv[(lq * 16 + i) * 17 + li] = x[i];  // Dinv_j[i][li]
+  }
+  __syncthreads();
+  typedef typename Mfma16<T>::v4 v4;
+  for (int j = 0; j < NBK / 16; j++) {
+    for (int q = 0; q < CM_ROWS / 16 / 4; q++) {
+      const int rt = wave + 4 * q;
+      const T* xrow = Xs + (rt * 16 + li) * XLs;
+      v4 acc = {T(0), T(0), T(0), T(0)};
+      for (int c = 0; c < j; c++) {
+#pragma unroll
+        for (int st = 0; st < 4; st++)
+          acc = Mfma16<T>::run(xrow[c * 16 + 4 * st + lq], Ls[(j * 16 + li) * LLs + c * 16 + 4 * st + lq], acc);
+      }
+      // R = A_j - sum: every lane updates the four entries of the tile it holds in the D layout
+#pragma unroll
+      for (int r = 0; r < 4; r++) Xs[(rt * 16 + Mfma16<T>::drow(lane, r)) * XLs + j * 16 + li] -= acc[r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      v4 xo = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+      for (int st = 0; st < 4; st++)
+        xo = Mfma16<T>::run(xrow[j * 16 + 4 * st + lq], Dv[(j * 16 + li) * 17 + 4 * st + lq], xo);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < 4; r++) Xs[(rt * 16 + Mfma16<T>::drow(lane, r)) * XLs + j * 16 + li] = xo[r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < rows * NBK; e += BLOCK) {
+    const int r = e / NBK, c = e - r * NBK;
+    W[(r0 + r) * ld + k + c] = Xs[r * XLs + c];
+  }
+}
+
 // out <- the factor in the requested triangle (W holds it lower), zeros elsewhere; all-NaN when a
 // pivot failed.  32x32 tiles through LDS so that the transposed write of `upper` is coalesced.
 template <class T>
@@ -567,6 +664,15 @@ int chol_blocked(int lower, long long n, const T* A, T* L) {
   auto kt = chol_trsm_kernel<T>;
   const size_t lds_d = (size_t)NBK * (NBK | 1) * sizeof(T);
   const size_t lds_t = (size_t)NBK * (NBK + 2 + CT_ROWS + 1 + 1) * sizeof(T);
+  auto km = chol_trsm_mfma_kernel<T>;
+  const size_t lds_m = (size_t)(NBK * (NBK + 1) + CM_ROWS * (NBK + 1) + 4 * 16 * 17) * sizeof(T);
+  static const bool use_mfma = !(getenv("PTHIP_CHOL_TRSM") && !strcmp(getenv("PTHIP_CHOL_TRSM"), "scalar"));
+  static bool attr_m = false;
+  if (!attr_m && lds_m > 64 * 1024) {
+    if (hipError_t e = hipFuncSetAttribute((const void*)km, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m); e != hipSuccess)
+      return fail(pthip::check(e, "chol_trsm_mfma attribute"));
+    attr_m = true;
+  }
   static bool attr_t = false;
   if (!attr_t && lds_t > 64 * 1024) {
     if (hipError_t e = hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t); e != hipSuccess)
@@ -587,7 +693,11 @@ int chol_blocked(int lower, long long n, const T* A, T* L) {
       if ((r = pthip::post_launch("chol diag"))) return fail(r);
       const long long m = n - k - nb;
       if (m <= 0) break;
-      PTHIP_KLAUNCH(kt, dim3((unsigned)((m + CT_ROWS - 1) / CT_ROWS)), dim3(CT_ROWS), lds_t, st, W, n, (int)k, nb, (int)n);
+      if (nb == NBK && use_mfma) {
+        PTHIP_KLAUNCH(km, dim3((unsigned)((m + CM_ROWS - 1) / CM_ROWS)), dim3(BLOCK), lds_m, st, W, n, (int)k, (int)n);
+      } else {
+        PTHIP_KLAUNCH(kt, dim3((unsigned)((m + CT_ROWS - 1) / CT_ROWS)), dim3(CT_ROWS), lds_t, st, W, n, (int)k, nb, (int)n);
+      }
       if ((r = pthip::post_launch("chol trsm"))) return fail(r);
       const long long ncol = Kend - (k + nb);  // columns of the outer panel still to come
       if (ncol > 0) {

@@ -190,8 +190,8 @@ def lstsq(node, inputs, env):
         b = _cast(env, b.contiguous(), dt)
     eps = float(np.finfo(dt).eps)
     rcond = eps * max(m, n) if rc.dtype == object or rc.size == 0 else float(rc)
-    if rcond < 0:
-        rcond = eps  # LAPACK gelsd: a negative rcond means machine precision
+    if rcond <= 0 or rcond >= 1:
+        rcond = eps  # LAPACK gelsd -> dlalsd: "IF( (RCOND.LE.ZERO) .OR. (RCOND.GE.ONE) ) RCND = EPS"
     b2 = b if b.ndim == 2 else b.view((m, 1), (b.strides[0], 0))
     U, S, Vt = svd_device(env, a, False, True)
     s_host = np.asarray(env.to_host(S))

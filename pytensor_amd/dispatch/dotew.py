@@ -147,7 +147,7 @@ def dot_epilogue(node, inputs, env):
     lds_a = os.environ.get("PTHIP_DOTEW_LDSA", "0") == "1" and T == "float32" and K % 128 == 0 and chunk % 2 == 0 and not packed_a
     if lds_a:
         name += "_la"
-    var = os.environ.get("PTHIP_DOTEW_VAR", "")  # (tools/dotew_variants.py: timing-only decompositions)
+    var = os.environ.get("PTHIP_DOTEW_VAR", "acc4")  # accumulator chains; other values: tools/dotew_variants.py timing-only decompositions
     if var:
         name += "_" + var.replace(",", "_")
     src = codegen.dot_epilogue_source(name, body, dpos, K, byvalue, chunk, share, lds_a, var, set(packed_a), pack_outs)

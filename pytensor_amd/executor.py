@@ -477,7 +477,7 @@ class HipExecutable:
                 ent.key = None
 
     # -- update feedback -------------------------------------------------------------------
-    def _feed_updates_device(self, outs):
+    def _feed_updates_device(self, outs, dry=False):
         """Enqueue ``resident[pos] <- outs[o]`` (device to device) for every update pair — behind,
         in stream order, every read of the old values: the graph's own kernels AND the copies that
         carry the outputs to the host (an output may BE the old resident: ``insert_deepcopy``,
@@ -485,7 +485,9 @@ class HipExecutable:
         Two phases, because ``Function`` stores all updates after the call, i.e. simultaneously
         (compile/executor.py:712-716): a source that lives in ANY resident buffer written here
         (``{w_prev: w, w: f(w)}``, a swap ``{x: y, y: x}``, a shifted view of its own buffer) is
-        first copied aside; only then is any resident written.  Returns the (pos, o) pairs fed."""
+        first copied aside; only then is any resident written.  Returns the (pos, o) pairs fed.
+        ``dry``: stage the copies but write nothing — the sizing pass of a frozen plan runs for real and
+        must not advance the shared state, yet has to make the same allocations as the capture."""
         from pytensor_amd.device import copy_into
 
         todo = []
@@ -503,7 +505,7 @@ class HipExecutable:
                 src = src.contiguous_copy()
             staged.append((pos, o, ent, src, same))
         for pos, o, ent, src, same in staged:
-            if not same:
+            if not same and not dry:
                 copy_into(ent.dev, src)
         return [(pos, o) for pos, o, *_ in staged]
 

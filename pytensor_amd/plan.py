@@ -396,6 +396,8 @@ class FrozenPlan:
                     # update feedback inside the graph: resident[pos] <- outs[o] after every read
                     # of the old value (the warm-up pass must NOT do this: it runs for real)
                     self._fed = exe._feed_updates_device(outs)
+            elif exe.update_map:
+                exe._feed_updates_device(outs, dry=True)  # (same staging allocations as the capture, no writes)
             ok = True
         finally:
             if self._switch is not None:

@@ -330,6 +330,8 @@ def test_chained_updates_read_the_old_values(pt, order):
         assert_close(f_hip(0.1), f_ref(0.1), f"call {c}", atol=1e-12)
         assert_close(w_hip.get_value(), w_ref.get_value(), f"w after call {c}")
         assert_close(p_hip.get_value(), p_ref.get_value(), f"w_prev after call {c}")
+    exe = E.hip_executable(f_hip)
+    assert exe._auto_plan is not None and exe.stats["capture_failures"] == 0, "the staged (two-phase) feed must be capturable"
 
 
 def test_swap_updates(pt):
@@ -345,6 +347,8 @@ def test_swap_updates(pt):
         assert_close(f_hip(), f_ref(), f"call {c}")
         assert_close(x_hip.get_value(), x_ref.get_value(), f"x after call {c}")
         assert_close(y_hip.get_value(), y_ref.get_value(), f"y after call {c}")
+    exe = E.hip_executable(f_hip)
+    assert exe._auto_plan is not None and exe.stats["capture_failures"] == 0
 
 
 def test_update_call_that_raises_commits_nothing(pt):
