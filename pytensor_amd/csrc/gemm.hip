@@ -586,6 +586,190 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_persistent_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------
+// fp32, 256 x 256 output tile per workgroup (round 3): row-major A (K-contiguous) and row-major B
+// (N-contiguous), M and N multiples of 256, K a multiple of 16.  The short-K batched shape of
+// BASELINE config #3 (512 x 256^3) is ONE tile per matrix: A and B cross L2->LDS once instead of
+// twice, each wave owns 128 x 128 = 4 x 4 MFMA tiles so that a k-step is 8 LDS fragment reads for
+// 32 MFMAs (the 128 x 128 kernel: 4 reads for 8), and the 64 stores per lane of the epilogue are
+// amortised over four times the MFMA work.  One workgroup per CU (512 registers per lane: 256
+// accumulators), persistent over (batch, tile) pairs; the next tile's first K-step is loaded behind
+// the last MFMA step of the current one and is already in LDS while the epilogue stores.
+// ---------------------------------------------------------------------------------
+constexpr int T2 = 256, T2K = 16, T2ALD = T2K + 2;
+template <bool PF>  // PF: LDS fragments read one k-step ahead (two register sets)
+__global__ __launch_bounds__(BLOCK, 1) void sgemm256_kernel(
+    float* __restrict__ out, const float* __restrict__ A, const float* __restrict__ B,
+    const float* __restrict__ C, long long M, long long N, long long K, long long lda,
+    long long ldb, long long sAb, long long sBb, long long sCb, long long sC0, long long sC1,
+    float alpha, float beta, long long tiles_m, long long tiles_n, long long batch, long long ldo) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* As = (float*)smem_raw;          // [2][256][18]  K-contiguous rows, padded
+  float* Bs = As + 2 * T2 * T2ALD;       // [2][16][256]
+  const long long nt = tiles_m * tiles_n, total = nt * batch;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm0 = (w >> 1) * 128, wn0 = (w & 1) * 128, h = lane >> 5, i32 = lane & 31;
+  const long long nk = K / T2K;
+  auto coords = [&](long long L, long long& m0, long long& n0, long long& bz) {
+    // (32-bit arithmetic: the tile count of anything that fits in HBM is far below 2^31, and a 64-bit
+    //  division is a few hundred instructions per tile in front of the first MFMA)
+    const unsigned tot = (unsigned)total, ntu = (unsigned)nt, tnu = (unsigned)tiles_n;
+    unsigned pid = (unsigned)L;
+    if (tot % 8 == 0) {  // XCD x walks the contiguous range [x*total/8, (x+1)*total/8)
+      const unsigned per = tot / 8;
+      pid = (pid % 8) * per + pid / 8;
+    }
+    const unsigned b = pid / ntu;
+    pid -= b * ntu;
+    bz = b;
+    m0 = (long long)(pid / tnu) * T2;
+    n0 = (long long)(pid % tnu) * T2;
+  };
+  // staging registers as eight named float4 (arrays assigned on two branches ended up in scratch)
+  float4 ga0, ga1, ga2, ga3, gb0, gb1, gb2, gb3;
+  const int a_off = (tid >> 2) * T2ALD + (tid & 3) * 4;  // LDS image of A: row tid/4 (+64 p), k = 4 (tid%4)
+  const int b_off = (tid >> 6) * T2 + (tid & 63) * 4;    // LDS image of B: k row tid/64 (+4 p), column 4 (tid%64)
+#define T2_GLOAD(PA, PB)                                                                            \
+  do {                                                                                              \
+    const float* pa_ = (PA) + (long long)(tid >> 2) * lda + (tid & 3) * 4;                          \
+    const float* pb_ = (PB) + (long long)(tid >> 6) * ldb + (tid & 63) * 4;                         \
+    ga0 = *(const float4*)pa_; ga1 = *(const float4*)(pa_ + 64 * lda);                              \
+    ga2 = *(const float4*)(pa_ + 128 * lda); ga3 = *(const float4*)(pa_ + 192 * lda);               \
+    gb0 = *(const float4*)pb_; gb1 = *(const float4*)(pb_ + 4 * ldb);                               \
+    gb2 = *(const float4*)(pb_ + 8 * ldb); gb3 = *(const float4*)(pb_ + 12 * ldb);                  \
+  } while (0)
+#define T2_ST_A(DST, V)                                                                             \
+  do {                                                                                              \
+    float2* d_ = (float2*)(DST);                                                                    \
+    d_[0] = make_float2((V).x, (V).y);                                                              \
+    d_[1] = make_float2((V).z, (V).w);                                                              \
+  } while (0)
+#define T2_SSTORE(AS, BS)                                                                           \
+  do {                                                                                              \
+    float* as_ = (AS) + a_off;                                                                      \
+    float* bs_ = (BS) + b_off;                                                                      \
+    T2_ST_A(as_, ga0); T2_ST_A(as_ + 64 * T2ALD, ga1); T2_ST_A(as_ + 128 * T2ALD, ga2); T2_ST_A(as_ + 192 * T2ALD, ga3); \
+    *(float4*)bs_ = gb0; *(float4*)(bs_ + 4 * T2) = gb1; *(float4*)(bs_ + 8 * T2) = gb2; *(float4*)(bs_ + 12 * T2) = gb3; \
+  } while (0)
+  long long L = blockIdx.x;
+  if (L >= total) return;
+  long long m0, n0, bz;
+  coords(L, m0, n0, bz);
+  T2_GLOAD(A + bz * sAb + m0 * lda, B + bz * sBb + n0);
+  T2_SSTORE(As, Bs);
+  __syncthreads();
+  int buf = 0;
+  const bool has_c = (beta != 0.f) && C != nullptr;
+  for (;;) {
+    const long long Ln = L + gridDim.x;
+    const bool has_next = Ln < total;
+    long long m1 = 0, n1 = 0, b1 = 0;
+    if (has_next) coords(Ln, m1, n1, b1);
+    float16_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    const float* Ab = A + bz * sAb + m0 * lda;
+    const float* Bb = B + bz * sBb + n0;
+    for (long long kt = 0; kt < nk; kt++) {
+      const bool more = kt + 1 < nk;
+      if (more) T2_GLOAD(Ab + (kt + 1) * T2K, Bb + (kt + 1) * T2K * ldb);
+      else if (has_next) T2_GLOAD(A + b1 * sAb + m1 * lda, B + b1 * sBb + n1);
+      const float* as = As + buf * T2 * T2ALD;
+      const float* bs = Bs + buf * T2K * T2;
+      const float* arow = as + (wm0 + i32) * T2ALD + 2 * h;
+      const float* bcol = bs + (2 * h) * T2 + wn0 + i32;
+      if constexpr (PF) {
+      // fragments one k-step AHEAD of the MFMAs that use them (two register sets): read just in time,
+      // every group of 16 MFMAs starts behind an LDS round trip (~10 % of the loop at one wave per SIMD)
+      float2 af[2][4], bf[2][4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) af[0][i] = *(const float2*)(arow + i * 32 * T2ALD);
+#pragma unroll
+      for (int j = 0; j < 4; j++) bf[0][j] = make_float2(bcol[j * 32], bcol[T2 + j * 32]);
+#pragma unroll
+      for (int kk = 0; kk < T2K / 4; kk++) {
+        const int cs = kk & 1, ns = cs ^ 1;
+        if (kk + 1 < T2K / 4) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) af[ns][i] = *(const float2*)(arow + i * 32 * T2ALD + (kk + 1) * 4);
+#pragma unroll
+          for (int j = 0; j < 4; j++) bf[ns][j] = make_float2(bcol[(kk + 1) * 4 * T2 + j * 32], bcol[((kk + 1) * 4 + 1) * T2 + j * 32]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cs][i].x, bf[cs][j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cs][i].y, bf[cs][j].y, acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      } else {
+#pragma unroll
+      for (int kk = 0; kk < T2K / 4; kk++) {
+        float2 af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) af[i] = *(const float2*)(arow + i * 32 * T2ALD + kk * 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) bf[j] = make_float2(bcol[kk * 4 * T2 + j * 32], bcol[(kk * 4 + 1) * T2 + j * 32]);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+      }
+      }
+      if (more || has_next) T2_SSTORE(As + (buf ^ 1) * T2 * T2ALD, Bs + (buf ^ 1) * T2K * T2);
+      __syncthreads();
+      buf ^= 1;
+    }
+    float* ob = out + bz * M * N + (m0 + wm0 + 4 * h) * ldo + n0 + wn0 + i32;
+    if (!has_c) {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          float* orow = ob + (long long)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldo;
+#pragma unroll
+          for (int j = 0; j < 4; j++) orow[j * 32] = alpha * acc[i][j][r];
+        }
+    } else {
+      const float* Cb = C + bz * sCb;
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const long long row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const long long col = n0 + wn0 + j * 32 + i32;
+            ob[(long long)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldo + j * 32] = alpha * acc[i][j][r] + beta * Cb[row * sC0 + col * sC1];
+          }
+    }
+    if (!has_next) break;
+    L = Ln;
+    m0 = m1;
+    n0 = n1;
+    bz = b1;
+  }
+#undef T2_GLOAD
+#undef T2_ST_A
+#undef T2_SSTORE
+}
+
 // out[b][m][n] = alpha * sum_s part[s][b][m][n] + beta * C[b][m][n]   (fixed order over s)
 template <class T>
 __global__ __launch_bounds__(BLOCK) void splitk_finish_kernel(
@@ -676,6 +860,25 @@ int launch(long long batch, long long M, long long N, long long K, T alpha, cons
     return pthip::post_launch("gemm(partials)");
   }
   if (nsplit == 1) {
+    if constexpr (sizeof(T) == 4 && !SKINNY && BKT == 32 && AKC && !BKC) {
+      // row-major x row-major with 256-aligned M, N: one 256 x 256 tile per workgroup
+      static const bool big = !(getenv("PTHIP_SGEMM_256") && atoi(getenv("PTHIP_SGEMM_256")) == 0);
+      if (big && M % T2 == 0 && N % T2 == 0 && K % T2K == 0 && K >= T2K && vecA && vecB && (ldo % 1 == 0)) {
+        const size_t sh = (size_t)(2 * T2 * T2ALD + 2 * T2K * T2) * sizeof(float);
+        static const bool pf = !(getenv("PTHIP_SGEMM_256_PF") && atoi(getenv("PTHIP_SGEMM_256_PF")) == 0);
+        auto k256 = pf ? sgemm256_kernel<true> : sgemm256_kernel<false>;
+        static bool attr_b = false;
+        if (!attr_b) {
+          PTHIP_CHECK(hipFuncSetAttribute((const void*)k256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+          attr_b = true;
+        }
+        const long long t_m = M / T2, t_n = N / T2, tot = t_m * t_n * batch;
+        const long long grid = tot < pthip::kNumCU ? tot : pthip::kNumCU;
+        PTHIP_KLAUNCH(k256, dim3((unsigned)grid), dim3(BLOCK), sh, st, (float*)out, (const float*)A, (const float*)B,
+                      (const float*)C, M, N, K, lda, ldb, sAb, sBb, sCb, sC0, sC1, (float)alpha, (float)beta, t_m, t_n, batch, ldo);
+        return pthip::post_launch("gemm(256x256)");
+      }
+    }
     if constexpr (sizeof(T) == 4 && !SKINNY && BKT == 32) {
       // more tiles than resident workgroups: the persistent kernel (prologues / epilogues of
       // consecutive tiles overlap).  PTHIP_SGEMM_PERSIST=0 keeps one tile per workgroup.
