@@ -1659,7 +1659,10 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
         out = []
         for u in range(n):
             g = c0 + u
-            bl = " ".join(f"{bufs[q]}[{s & 1}][{u}] = bp{p}[{g * 64}];" for q, p in enumerate(gr))
+            if "ntb" in var:  # (timing experiment: non-temporal weight loads)
+                bl = " ".join(f"{bufs[q]}[{s & 1}][{u}] = __builtin_nontemporal_load(bp{p} + {g * 64});" for q, p in enumerate(gr))
+            else:
+                bl = " ".join(f"{bufs[q]}[{s & 1}][{u}] = bp{p}[{g * 64}];" for q, p in enumerate(gr))
             if lds_a:
                 la = bl
                 if u % 2 == 0:

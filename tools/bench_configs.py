@@ -104,7 +104,41 @@ def _with_kernel(entry, name, work, peak, prefix=None, scale=1e6):
     return entry
 
 
-def measure(which=("c1", "c2", "c3", "c5"), reps=20, check=True):
+def _chol_entries():
+    """``pthip_potrf`` beyond one CU's LDS (the blocked factorisation, csrc/linalg.hip chol_blocked): a GP
+    marginal likelihood at n = 1000-4000 is an ordinary PyMC graph.  HIP events around back-to-back calls."""
+    import ctypes as C
+
+    from pytensor_amd.device import DeviceArray
+
+    lib = ffi.lib()
+    out = {}
+    for n, reps in ((2048, 6), (4096, 3)):
+        rng = np.random.default_rng(n)
+        A = rng.normal(size=(n, n + 8))
+        S = A @ A.T / n + np.eye(n)
+        dS, L = DeviceArray.from_host(S), DeviceArray.empty((n, n), "float64")
+        call = lambda: ffi.check(lib.pthip_potrf(ffi.np_dtype_code("float64"), 1, 1, n, dS.ptr, L.ptr))
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        ffi.check(lib.pthip_event_create(C.byref(e0)))
+        ffi.check(lib.pthip_event_create(C.byref(e1)))
+        for _ in range(2):
+            call()
+        ffi.check(lib.pthip_event_record(e0))
+        for _ in range(reps):
+            call()
+        ffi.check(lib.pthip_event_record(e1))
+        ffi.check(lib.pthip_event_synchronize(e1))
+        ms = C.c_float()
+        ffi.check(lib.pthip_event_elapsed_ms(e0, e1, C.byref(ms)))
+        t = ms.value / reps
+        fl = n**3 / 3
+        out[f"chol_{n}"] = {"config": f"Cholesky({n}) f64, blocked multi-workgroup", "ms_device": t, "achieved": fl / t / 1e9, "unit": "TFLOP/s",
+                            "peak": F64_MFMA_PEAK, "frac": fl / t / 1e9 / F64_MFMA_PEAK, "bound": "serial column chain of the diagonal blocks + K=64/512 MFMA updates"}
+    return out
+
+
+def measure(which=("c1", "c2", "c3", "c5", "chol"), reps=20, check=True):
     """Device-event timed replays of BASELINE configs #1, #2, #3, #5 at their stated sizes
     (inputs resident in HBM).  Returns ``{key: {...}}``; imported by ``bench.py`` for the
     ``configs`` field of its JSON line."""
@@ -149,6 +183,8 @@ def measure(which=("c1", "c2", "c3", "c5"), reps=20, check=True):
                      "achieved": fl / td / 1e9, "unit": "TFLOP/s", "peak": F32_MFMA_PEAK, "frac": fl / td / 1e9 / F32_MFMA_PEAK,
                      "bound": "mfma f32 (skinny M=64, dependent steps)",
                      "kernels_us": {k: round(ms * 1e3, 2) for k, ms in sorted(KERNELS.get("c5_gru", {}).items(), key=lambda t: -t[1])[:4]}}
+    if "chol" in which:
+        res.update(_chol_entries())
     return res
 
 
@@ -157,7 +193,7 @@ def main():
     reps = 20
     if "--reps" in sys.argv:
         reps = int(sys.argv[sys.argv.index("--reps") + 1])
-    which = [a for a in args if not a.isdigit()] or ["c1", "c2", "c3", "c5"]
+    which = [a for a in args if not a.isdigit()] or ["c1", "c2", "c3", "c5", "chol"]
     ffi.init(0)
     # --no-check: skip the oracle comparison (it runs the graphs at a reduced size as well, which
     # would mix small launches into a rocprofv3 kernel summary of this command)
