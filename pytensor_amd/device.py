@@ -155,6 +155,13 @@ def copy_into(dst: DeviceArray, src: DeviceArray):
             raise ValueError(f"could not broadcast input array from shape {src.shape} into shape {dst.shape}")
     if dst.size == 0:
         return
+    if nd > 6 and sum(1 for s_ in dst.shape if s_ != 1) > 6:
+        # the strided-copy kernel walks at most 6 non-mergeable dims (a Tile over 7+ axes, reference
+        # test tests/tensor/test_basic.py::TestTile): peel the leading axis on the host
+        sv = DeviceArray(src.buf, src.offset, sshape, sstr, src.dtype)
+        for i in range(dst.shape[0]):
+            copy_into(dst.view(dst.shape[1:], dst.strides[1:], i * dst.strides[0]), sv.view(sshape[1:], sstr[1:], i * sstr[0]))
+        return
     ffi.check(
         ffi.lib().pthip_copy_strided(
             dst.itemsize, nd, _i64arr(dst.shape), dst.ptr, _i64arr(dst.strides), src.ptr, _i64arr(sstr)

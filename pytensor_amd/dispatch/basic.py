@@ -156,10 +156,17 @@ def join(node, inputs, env):
     total = sum(t.shape[axis] for t in tensors)
     shape = list(tensors[0].shape)
     shape[axis] = total
-    out = DeviceArray.empty(shape, tensors[0].dtype)
+    # Join.make_node upcasts its operands to their common dtype (basic.py: `as_tensor_variable_args` ->
+    # `ps.upcast`); the output variable carries it
+    odt = np.dtype(env.graph.vars[node.outputs[0]].dtype) if node.outputs[0] in env.graph.vars else np.result_type(*[t.dtype for t in tensors])
+    out = DeviceArray.empty(shape, odt)
     off = 0
     for t in tensors:
         if t.size:
+            if np.dtype(t.dtype) != odt:
+                from pytensor_amd.dispatch.elemwise import _cast
+
+                t = _cast(env, t, odt)
             sub = out.view(t.shape, out.strides, off * out.strides[axis])
             copy_into(sub, t)
         off += t.shape[axis]

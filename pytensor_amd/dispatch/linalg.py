@@ -191,6 +191,9 @@ def blockwise(node, inputs, env):
     return _blockwise_loop(node, ins, env)
 
 
+_INLINE_CACHE = {}
+
+
 def _blockwise_loop(node, ins, env):
     """Any other core op with a device handler: loop the broadcast batch on the host, one core
     call per item on views of the operands (``Blockwise.perform``, pytensor/tensor/blockwise.py:
@@ -201,6 +204,18 @@ def _blockwise_loop(node, ins, env):
 
     p = node.params
     core = HANDLERS.get(p["core_op"])
+    if p["core_op"] == "__inline__":
+        # an inlined OpFromGraph core: run its lowered inner graph per item (like a Scan step)
+        from pytensor_amd.executor import HipExecutable
+
+        inner = _INLINE_CACHE.get(id(p["core_params"]["inner"]))
+        if inner is None:
+            inner = HipExecutable(p["core_params"]["inner"], device=env.exe._device, tail=False)
+            _INLINE_CACHE[id(p["core_params"]["inner"])] = inner
+
+        def core(_node, item, _env):
+            return inner.run_device(item, _env)[0]
+
     if core is None:
         raise NotImplementedError(f"Blockwise({p['core_op']})")
     sig_in = p["signature"].split("->")[0]

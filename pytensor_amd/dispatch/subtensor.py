@@ -215,7 +215,16 @@ def _expand_bool_masks(env, idx_list, idx, x_shape):
     new_list, new_idx, d = [], [], 0
     for e in idx_list:
         if isinstance(e, slice):
-            new_list.append(e)
+            # (a slice's start / stop / step are positions in `idx` too: they move with the renumbering —
+            #  `x[1:, mask]`, reference test tests/tensor/test_subtensor.py::TestSubtensor::test_boolean)
+            comps = []
+            for c in (e.start, e.stop, e.step):
+                if c is None:
+                    comps.append(None)
+                else:
+                    comps.append(len(new_idx))
+                    new_idx.append(idx[c])
+            new_list.append(slice(*comps))
             d += 1
             continue
         v = idx[e]
@@ -339,6 +348,16 @@ def advanced_inc_subtensor(node, inputs, env):
     if _simple_axis0(idx_list):
         iv = _index_on_device(env, idx[idx_list[0]])
         if iv.ndim == 1:
+            if list(p["idx_list"]) == [0] and not _is_bool_index(inputs[2]):
+                # AdvancedIncSubtensor._check_runtime_broadcast_of_vector_index (subtensor.py:2448-2473)
+                static = env.graph.vars[node.inputs[1]].shape
+                expected = (iv.shape[0], *x.shape[1:])
+                for sd, yd, ed in zip(reversed(static), reversed(y.shape), reversed(expected)):
+                    if sd != 1 and yd == 1 and ed != 1:
+                        raise ValueError(
+                            "Runtime broadcasting not allowed. AdvancedIncSubtensor was asked to broadcast the second input (y) "
+                            "along a dimension that was not marked as broadcastable. If broadcasting was intended, use "
+                            "`specify_broadcastable` on the relevant dimension(s).")
             return [_scatter_rows(env, p, own, y, iv)]
     xt, k, iv, place, _ = _general_plan(env, own, idx_list, idx)
     rest = tuple(xt.shape[k:])
@@ -408,7 +427,22 @@ def _scatter_rows(env, p, out, y, iv):
     ws = DeviceArray.empty((ws_bytes,), "uint8") if ws_bytes else None
     inc = 0 if p["set_instead_of_inc"] else 1
     if inc and p.get("ignore_duplicates"):
-        raise NotImplementedError("hip linker: AdvancedIncSubtensor(ignore_duplicates=True)")
+        # `out[idx] += y` as NumPy's buffered fancy in-place add (subtensor.py AdvancedIncSubtensor.perform,
+        # `ignore_duplicates`): every addressed row becomes its OLD value plus the LAST update aimed at
+        # it — not the sum of all of them (np.add.at).  gather, add, then the deterministic
+        # last-writer-wins scatter-set.
+        from pytensor_amd.dispatch.elemwise import launch_elemwise
+
+        old = DeviceArray.empty(tgt, x.dtype)
+        ffi.check(lib.pthip_take_rows(x.itemsize, n_idx, inner, out.ptr, x.shape[0], inner, iv.ptr, old.ptr))
+        yfull = ysrc
+        if ys0 != inner or tuple(ysrc.shape) != tuple(tgt):
+            yfull = DeviceArray.empty(tgt, x.dtype)
+            copy_into(yfull, yv.view(tgt, [0 if yv.shape[d] == 1 and tgt[d] != 1 else yv.strides[d] for d in range(len(tgt))]))
+        dt = str(x.dtype)
+        body = {"in_dtypes": [dt, dt], "out_dtypes": [dt], "body": [{"op": "Add", "in": [["i", 0], ["i", 1]], "dtype": dt}], "outs": [["t", 0]]}
+        (ysrc,), _, _ = launch_elemwise(body, [old, yfull], tgt, [dt], None, env)
+        ys0, inc = inner, 0
     ffi.check(
         lib.pthip_scatter_rows(
             ffi.np_dtype_code(x.dtype), inc, n_idx, inner, out.ptr, x.shape[0], iv.ptr, ysrc.ptr, ys0,

@@ -331,6 +331,7 @@ class HipExecutable:
         self._guard, self._branch_nodes = branch_guards(self.graph)
         if self._branch_nodes:
             self.auto_freeze = False  # the condition is read on the host: nothing to capture
+        self._scalar_outs = [k for k, vid in enumerate(self.graph.outputs) if self.graph.vars[vid].kind == "scalar"]
         self._last_use = self._compute_last_use()
         self._donations = self._compute_donations()
         # fail loudly and early if the library / device is unusable
@@ -685,6 +686,8 @@ class HipExecutable:
             fed = self._feed_updates_device(outs)
             if fed:
                 self._feed_updates_host(fed, host)
+        for k in self._scalar_outs:  # a ScalarType output is a NumPy scalar, not a 0-d array (scalar/basic.py ScalarType.filter)
+            host[k] = host[k][()]
         if not self.graph.outputs:
             return None  # link/basic.py:690-699: a function without outputs must return None
         return tuple(host)

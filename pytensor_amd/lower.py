@@ -500,12 +500,22 @@ def _(op, node, ctx):
 
 @hip_funcify.register(Blockwise)
 def _(op, node, ctx):
-    core = hip_funcify(op.core_op, None, ctx)
+    # (lowerings that look at the Apply node — output dtypes — get the core node the Blockwise itself
+    #  builds for shape inference, blockwise.py `_create_dummy_core_node`)
+    try:
+        core_node = op._create_dummy_core_node(node.inputs) if node is not None else None
+    except Exception:  # noqa: BLE001
+        core_node = None
+    core = hip_funcify(op.core_op, core_node, ctx)
     # (batched kernels exist for the linalg family; any other lowered core op runs as a host loop
     #  over the batch of single-item device calls — dispatch/linalg.py::_blockwise_loop)
     if core is None or core[0] in ("Scan", "Blockwise", "HostPerform"):
         return None
     name, params = core
+    if core is _INLINE:
+        # the core op is an OpFromGraph without a kernel of its own (AllocDiag in the Cholesky pullback,
+        # ...): its inner graph, lowered once, is what the host loop runs per batch item
+        params = {"inner": lower_fgraph(op.core_op.fgraph, name="blockwise_inner")}
     return "Blockwise", {"core_op": name, "core_params": params, "signature": op.signature}
 
 

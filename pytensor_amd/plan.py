@@ -555,6 +555,8 @@ class FrozenPlan:
                 k += 1
         if self._fed:
             self.exe._feed_updates_host(self._fed, res)
+        for k in self.exe._scalar_outs:
+            res[k] = res[k][()]
         if not res and not self._out_meta:
             return None  # a function without outputs returns None (link/basic.py:690-699)
         return tuple(res)

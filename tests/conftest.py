@@ -15,6 +15,7 @@ def pytest_configure(config):
 def pytest_collection_modifyitems(config, items):
     """Parametrisations of the reference's own test modules that are not run under the hip linker
     (complex operands, pivoted QR): skipped with the reason, listed in the module itself."""
-    mod = sys.modules.get("test_gpu_refsuite_linalg") or sys.modules.get("tests.test_gpu_refsuite_linalg")
-    if mod is not None:
-        mod.pytest_collection_modifyitems_for_this_module(items)
+    for name in ("test_gpu_refsuite_linalg", "test_gpu_refsuite_index"):
+        mod = sys.modules.get(name) or sys.modules.get("tests." + name)
+        if mod is not None:
+            mod.pytest_collection_modifyitems_for_this_module(items)
