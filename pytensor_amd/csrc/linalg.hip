@@ -213,39 +213,13 @@ __device__ __forceinline__ void wave_trsv(const T* __restrict__ W, int ld, int n
   else wave_trsv_dir<T, RPL, false>(W, ld, n, b, x, unit, poisoned);
 }
 
-// ---------------------------------------------------------------------------------
-// blocked LDS-resident Cholesky (optionally followed by the first triangular solve with
-// the factor still in LDS: rhs != NULL  =>  xout = L^-1 rhs, lower factor only)
-// ---------------------------------------------------------------------------------
+// The factorisation proper on a lower-triangular working matrix W[i * ld + j] (i >= j) resident in
+// LDS, by all BLOCK threads of the workgroup (shared by the kernel below and by the diagonal tasks of
+// chol_dag_kernel).  Ends on a workgroup barrier; returns this thread's view of "a pivot failed"
+// (identical in every wave: all of them factor the diagonal blocks redundantly).
 template <class T>
-__global__ __launch_bounds__(BLOCK) void potrf_lds_kernel(T* __restrict__ Lout,
-                                                         const T* __restrict__ Ain, int n,
-                                                         int lower, const T* __restrict__ rhs,
-                                                         T* __restrict__ xout, long long ldio,
-                                                         int* __restrict__ failflag) {
-  // ldio != 0: the matrix is a diagonal block of a larger row-major working matrix (row stride
-  // ldio) factored IN PLACE as one step of the blocked algorithm (chol_blocked below): only the
-  // lower triangle is written back, a failure is reported through *failflag.
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __shared__ int s_fail;
-  T* W = (T*)smem_raw;
-  const int ld = n | 1;  // odd leading dimension: column walks are bank-conflict free
-  const long long mat = blockIdx.x;
-  const long long gld = ldio ? ldio : n;
-  const T* A = Ain + mat * (long long)n * n;
-  T* Lo = Lout + mat * (long long)n * n;
+__device__ __forceinline__ bool potrf_lds_core(T* __restrict__ W, const int ld, const int n) {
   const int tid = threadIdx.x, lane = tid & 63;
-  if (tid == 0) s_fail = 0;
-  // load the referenced triangle as a lower-triangular working matrix W[i][j], i >= j
-  // (for `upper` the strict upper triangle is read transposed: LAPACK reads only `uplo`)
-  {
-    const bool wide = (n % (16 / (int)sizeof(T))) == 0 && (((size_t)A) & 15) == 0 && (gld % (16 / (int)sizeof(T))) == 0;
-    if (lower)
-      stage_dense<T>(A, n, wide, [&](int i, int j, T v) { if (i >= j) W[i * ld + j] = v; }, gld);
-    else
-      stage_dense<T>(A, n, wide, [&](int i, int j, T v) { if (j >= i) W[j * ld + i] = v; }, gld);
-  }
-  __syncthreads();
   bool fail = false;
   for (int j0 = 0; j0 < n; j0 += NB) {
     const int jb = (n - j0) < NB ? (n - j0) : NB;
@@ -349,6 +323,43 @@ __global__ __launch_bounds__(BLOCK) void potrf_lds_kernel(T* __restrict__ Lout,
     }
     __syncthreads();
   }
+  return fail;
+}
+
+// ---------------------------------------------------------------------------------
+// blocked LDS-resident Cholesky (optionally followed by the first triangular solve with
+// the factor still in LDS: rhs != NULL  =>  xout = L^-1 rhs, lower factor only)
+// ---------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(BLOCK) void potrf_lds_kernel(T* __restrict__ Lout,
+                                                         const T* __restrict__ Ain, int n,
+                                                         int lower, const T* __restrict__ rhs,
+                                                         T* __restrict__ xout, long long ldio,
+                                                         int* __restrict__ failflag) {
+  // ldio != 0: the matrix is a diagonal block of a larger row-major working matrix (row stride
+  // ldio) factored IN PLACE as one step of the blocked algorithm (chol_blocked below): only the
+  // lower triangle is written back, a failure is reported through *failflag.
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ int s_fail;
+  T* W = (T*)smem_raw;
+  const int ld = n | 1;  // odd leading dimension: column walks are bank-conflict free
+  const long long mat = blockIdx.x;
+  const long long gld = ldio ? ldio : n;
+  const T* A = Ain + mat * (long long)n * n;
+  T* Lo = Lout + mat * (long long)n * n;
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) s_fail = 0;
+  // load the referenced triangle as a lower-triangular working matrix W[i][j], i >= j
+  // (for `upper` the strict upper triangle is read transposed: LAPACK reads only `uplo`)
+  {
+    const bool wide = (n % (16 / (int)sizeof(T))) == 0 && (((size_t)A) & 15) == 0 && (gld % (16 / (int)sizeof(T))) == 0;
+    if (lower)
+      stage_dense<T>(A, n, wide, [&](int i, int j, T v) { if (i >= j) W[i * ld + j] = v; }, gld);
+    else
+      stage_dense<T>(A, n, wide, [&](int i, int j, T v) { if (j >= i) W[j * ld + i] = v; }, gld);
+  }
+  __syncthreads();
+  const bool fail = potrf_lds_core<T>(W, ld, n);
   if (fail) s_fail = 1;  // benign race: every writer stores 1
   __syncthreads();
   const bool failed = s_fail != 0;
@@ -397,13 +408,15 @@ constexpr int CT_ROWS = 192;  // rows of the panel per workgroup (= threads of c
 // `upper` reads the tile of A transposed, both sides coalesced.
 template <class T>
 __global__ __launch_bounds__(BLOCK) void chol_stage_kernel(T* __restrict__ W, const T* __restrict__ A,
-                                                          int n, int lower) {
+                                                          int n, int lower, int np) {
+  // np >= n: edge (= row stride) of the working matrix; rows / columns past n continue the diagonal
+  // with ones (the factor of diag(A, I) is diag(L, I): whole tiles for chol_dag_kernel)
   __shared__ T tile[32][33];
   const int bi = blockIdx.y, bj = blockIdx.x;
   if (bj > bi) {  // strictly upper block of W
     for (int e = threadIdx.x; e < 32 * 32; e += BLOCK) {
       const int i = bi * 32 + (e >> 5), j = bj * 32 + (e & 31);
-      if (i < n && j < n) W[(long long)i * n + j] = T(0);
+      if (i < np && j < np) W[(long long)i * np + j] = T(0);
     }
     return;
   }
@@ -418,7 +431,8 @@ __global__ __launch_bounds__(BLOCK) void chol_stage_kernel(T* __restrict__ W, co
   for (int e = threadIdx.x; e < 32 * 32; e += BLOCK) {
     const int r = e >> 5, c = e & 31;
     const int i = bi * 32 + r, j = bj * 32 + c;
-    if (i < n && j < n) W[(long long)i * n + j] = (i >= j) ? (lower ? tile[r][c] : tile[c][r]) : T(0);
+    if (i < n && j < n) W[(long long)i * np + j] = (i >= j) ? (lower ? tile[r][c] : tile[c][r]) : T(0);
+    else if (i < np && j < np) W[(long long)i * np + j] = (i == j) ? T(1) : T(0);
   }
 }
 
@@ -618,7 +632,7 @@ __global__ __launch_bounds__(BLOCK) void chol_trsm_mfma_kernel(T* __restrict__ W
 // pivot failed.  32x32 tiles through LDS so that the transposed write of `upper` is coalesced.
 template <class T>
 __global__ __launch_bounds__(BLOCK) void chol_finish_kernel(T* __restrict__ out, const T* __restrict__ W,
-                                                           int n, int lower, const int* __restrict__ failflag) {
+                                                           int n, int lower, const int* __restrict__ failflag, int np) {
   __shared__ T tile[32][33];
   const bool failed = *failflag != 0;
   const int bi = blockIdx.y, bj = blockIdx.x;
@@ -635,7 +649,7 @@ __global__ __launch_bounds__(BLOCK) void chol_finish_kernel(T* __restrict__ out,
   for (int e = threadIdx.x; e < 32 * 32; e += BLOCK) {
     const int r = e >> 5, c = e & 31;
     const int i = si * 32 + r, j = sj * 32 + c;
-    tile[r][c] = (i < n && j < n && i >= j) ? W[(long long)i * n + j] : T(0);
+    tile[r][c] = (i < n && j < n && i >= j) ? W[(long long)i * np + j] : T(0);
   }
   __syncthreads();
   for (int e = threadIdx.x; e < 32 * 32; e += BLOCK) {
@@ -645,8 +659,283 @@ __global__ __launch_bounds__(BLOCK) void chol_finish_kernel(T* __restrict__ out,
   }
 }
 
+// ---------------------------------------------------------------------------------
+// The same factorisation as ONE persistent kernel over a graph of 64 x 64 tile tasks (default).
+// The launch-per-step form below spends its time on the serial chain diagonal block -> panel solve ->
+// update, three launches per 64 columns at 28 + 15 + 38 us (n = 4096 fp64: 5.2 of 6.0 ms,
+// profiles/r3i_chol4096_kernel_stats.md): streams and graphs cannot express "the next diagonal block
+// only needs ITS column updated".  Here task (i, j), i >= j, owns tile (i, j) of the lower triangle:
+//   acc = sum_{k<j} L(i,k) L(j,k)^T       as the tiles of row i and row j become final (left-looking,
+//                                          accumulators in registers, operands staged through LDS)
+//   R   = A(i,j) - acc
+//   i == j:  L(j,j) = chol(R) in LDS (potrf_lds_core) + the inverses of its four 16x16 diagonal blocks
+//   i >  j:  L(i,j) = R L(j,j)^-T         (blocked substitution on the matrix cores, as chol_trsm_mfma_kernel)
+// and publishes `done[i][j]` (release, agent scope).  Tasks are numbered column by column and dealt
+// round-robin to the resident workgroups; each workgroup runs its tasks in that order, so every
+// dependency of a task belongs to an earlier task and the oldest unfinished task can always run: no
+// deadlock as long as all workgroups are resident (grid <= CUs x occupancy, checked by the host).
+// A workgroup holding a task of column j+1 accumulates everything that is already final and then
+// waits for the one tile the critical path still owes it — the look-ahead that the launch-per-step
+// form lacks.  Waits are bounded: a wait that expires sets bit 4 of the device status word (loud
+// RuntimeError on the host) instead of hanging the device.
+// ---------------------------------------------------------------------------------
+constexpr int DT = 64;         // tile edge
+constexpr int DLS = DT + 1;    // LDS row stride of a staged tile
+constexpr int DAG_SPIN_LIMIT = 1 << 22;
+
+__device__ __forceinline__ int dag_flag(const int* f) {
+  return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Wait until tiles (i, k) and (j, k) are final; returns how many consecutive columns from k on are
+// final already (>= 1), or -1 when the wait expired / another workgroup gave up.  Wave 0 polls 64
+// columns per round trip; ends on a barrier + acquire so that every wave reads the published tiles.
+__device__ __forceinline__ int dag_wait(const int* __restrict__ done, int nT, int i, int j, int k, int kend,
+                                        int* __restrict__ abortflag, int* s_box) {
+  if (threadIdx.x < 64) {
+    const int kk = k + (int)threadIdx.x;
+    int spins = 0, nready;
+    for (;;) {
+      int ok = 1;
+      if (kk < kend) ok = dag_flag(done + (long long)i * nT + kk) & dag_flag(done + (long long)j * nT + kk);
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(ok != 0);
+      nready = (~m == 0ull) ? 64 : __builtin_ctzll(~m);
+      if (nready > 0) break;
+      if (++spins > DAG_SPIN_LIMIT || ((spins & 255) == 0 && dag_flag(abortflag))) { nready = -1; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (threadIdx.x == 0) *s_box = nready;
+  }
+  __syncthreads();
+  const int nr = *s_box;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return nr;
+}
+
+template <class T> struct DagTile {
+  static constexpr int VEC = 16 / (int)sizeof(T);
+  static constexpr int NV = DT * DT / VEC / BLOCK;  // 16-byte loads per thread and tile
+  typedef T vec_t __attribute__((ext_vector_type(VEC)));
+  vec_t v[NV];
+  __device__ __forceinline__ void load(const T* __restrict__ src, long long ld) {
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+      const int idx = u * BLOCK + (int)threadIdx.x;
+      const int r = idx / (DT / VEC), c = (idx % (DT / VEC)) * VEC;
+      v[u] = *(const vec_t*)(src + (long long)r * ld + c);
+    }
+  }
+  __device__ __forceinline__ void store(T* __restrict__ dst) const {
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+      const int idx = u * BLOCK + (int)threadIdx.x;
+      const int r = idx / (DT / VEC), c = (idx % (DT / VEC)) * VEC;
+#pragma unroll
+      for (int w = 0; w < VEC; w++) dst[r * DLS + c + w] = v[u][w];
+    }
+  }
+};
+
+template <class T>
+__global__ __launch_bounds__(BLOCK) void chol_dag_kernel(T* __restrict__ W, long long ld, int nT,
+                                                        int* __restrict__ done, T* __restrict__ Dinv,
+                                                        int* __restrict__ failflag, int* __restrict__ abortflag,
+                                                        int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ int s_box;
+  T* As = (T*)smem_raw;     // [DT][DLS]  L(i,k); then the tile being finished
+  T* Bs = As + DT * DLS;    // [DT][DLS]  L(j,k); then L(j,j)
+  T* Dv = Bs + DT * DLS;    // [4][16][17] inverses of the diagonal 16x16 blocks of L(j,j)
+  typedef typename Mfma16<T>::v4 v4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;  // this wave's 32 x 32 quadrant of the tile
+  const int ntasks = nT * (nT + 1) / 2;
+  for (int t = blockIdx.x; t < ntasks; t += gridDim.x) {
+    int j = 0, rem = t;
+    while (rem >= nT - j) { rem -= nT - j; j++; }
+    const int i = j + rem;
+    const bool diag = i == j;
+    v4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++) acc[a][b] = v4{T(0), T(0), T(0), T(0)};
+    int kready = 0;
+    bool have = false;
+    DagTile<T> ta, tb;
+    for (int k = 0; k < j; k++) {
+      if (!have) {
+        if (k >= kready) {
+          const int nr = dag_wait(done, nT, i, j, k, j, abortflag, &s_box);
+          if (nr < 0) {
+            if (tid == 0) { atomicOr(status, 16); __hip_atomic_store(abortflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            return;
+          }
+          kready = (k + nr) < j ? (k + nr) : j;
+        }
+        ta.load(W + (long long)i * DT * ld + (long long)k * DT, ld);
+        if (!diag) tb.load(W + (long long)j * DT * ld + (long long)k * DT, ld);
+      }
+      ta.store(As);
+      if (!diag) tb.store(Bs);
+      __syncthreads();
+      have = (k + 1) < kready;  // (kready <= j)
+      if (have) {  // the next pair of tiles is known final: in flight under this product
+        ta.load(W + (long long)i * DT * ld + (long long)(k + 1) * DT, ld);
+        if (!diag) tb.load(W + (long long)j * DT * ld + (long long)(k + 1) * DT, ld);
+      }
+      const T* Bp = diag ? As : Bs;
+#pragma unroll 4
+      for (int st = 0; st < DT / 4; st++) {
+        const T a0 = As[(r0 + li) * DLS + 4 * st + lq], a1 = As[(r0 + 16 + li) * DLS + 4 * st + lq];
+        const T b0 = Bp[(c0 + li) * DLS + 4 * st + lq], b1 = Bp[(c0 + 16 + li) * DLS + 4 * st + lq];
+        acc[0][0] = Mfma16<T>::run(a0, b0, acc[0][0]);
+        acc[0][1] = Mfma16<T>::run(a0, b1, acc[0][1]);
+        acc[1][0] = Mfma16<T>::run(a1, b0, acc[1][0]);
+        acc[1][1] = Mfma16<T>::run(a1, b1, acc[1][1]);
+      }
+      __syncthreads();
+    }
+    // R = A(i,j) - acc, into LDS
+    {
+      const T* Aij = W + (long long)i * DT * ld + (long long)j * DT;
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int row = r0 + a * 16 + Mfma16<T>::drow(lane, r), col = c0 + b * 16 + li;
+            As[row * DLS + col] = Aij[(long long)row * ld + col] - acc[a][b][r];
+          }
+    }
+    __syncthreads();
+    if (diag) {
+      const bool fail = potrf_lds_core<T>(As, DLS, DT);  // (ends on a barrier)
+      if (fail && tid == 0) atomicOr(failflag, 1);
+      if (wave == 0) {
+        // lane = 16 * block + column: column `li` of inv(L_bb), b = lq, by forward substitution
+        const T* Lb = As + (lq * 16) * DLS + lq * 16;
+        T x[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          T sacc = (r == li) ? T(1) : T(0);
+#pragma unroll
+          for (int q = 0; q < r; q++) sacc -= Lb[r * DLS + q] * x[q];
+          x[r] = (r < li) ? T(0) : sacc / Lb[r * DLS + r];
+        }
+        T* Dg = Dinv + (long long)j * (4 * 16 * 16);
+#pragma unroll
+        for (int r = 0; r < 16; r++) Dg[(lq * 16 + r) * 16 + li] = x[r];
+      }
+    } else {
+      const int nr = dag_wait(done, nT, j, j, j, j + 1, abortflag, &s_box);
+      if (nr < 0) {
+        if (tid == 0) { atomicOr(status, 16); __hip_atomic_store(abortflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        return;
+      }
+      tb.load(W + (long long)j * DT * ld + (long long)j * DT, ld);
+      const T* Dg = Dinv + (long long)j * (4 * 16 * 16);
+      T dv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) dv[u] = Dg[u * BLOCK + tid];
+      tb.store(Bs);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = u * BLOCK + tid;
+        Dv[(e >> 4) * 17 + (e & 15)] = dv[u];
+      }
+      __syncthreads();
+      // X = R L(j,j)^-T by 16-column blocks; wave w owns rows 16w .. 16w+15 (no cross-wave traffic)
+      const T* xrow = As + (wave * 16 + li) * DLS;
+      for (int jb = 0; jb < DT / 16; jb++) {
+        v4 s = {T(0), T(0), T(0), T(0)};
+        for (int c = 0; c < jb; c++) {
+#pragma unroll
+          for (int st = 0; st < 4; st++)
+            s = Mfma16<T>::run(xrow[c * 16 + 4 * st + lq], Bs[(jb * 16 + li) * DLS + c * 16 + 4 * st + lq], s);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) As[(wave * 16 + Mfma16<T>::drow(lane, r)) * DLS + jb * 16 + li] -= s[r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        v4 xo = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+        for (int st = 0; st < 4; st++)
+          xo = Mfma16<T>::run(xrow[jb * 16 + 4 * st + lq], Dv[(jb * 16 + li) * 17 + 4 * st + lq], xo);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 4; r++) As[(wave * 16 + Mfma16<T>::drow(lane, r)) * DLS + jb * 16 + li] = xo[r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+    }
+    // the finished tile (a diagonal tile: its lower triangle) back to the working matrix
+    {
+      T* Oij = W + (long long)i * DT * ld + (long long)j * DT;
+#pragma unroll 4
+      for (int e = tid; e < DT * DT; e += BLOCK) {
+        const int r = e >> 6, c = e & 63;
+        if (!diag || c <= r) Oij[(long long)r * ld + c] = As[r * DLS + c];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(done + (long long)i * nT + j, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <class T>
+int chol_dag(int lower, long long n, const T* A, T* L) {
+  hipStream_t st = pthip::ctx().stream;
+  const long long np = (n + DT - 1) / DT * DT;
+  const int nT = (int)(np / DT);
+  const size_t wbytes = (size_t)np * np * sizeof(T);
+  const size_t dbytes = (size_t)nT * 4 * 16 * 16 * sizeof(T);
+  const size_t fbytes = ((size_t)nT * nT * sizeof(int) + 255) / 256 * 256 + 256;
+  void* scratch = nullptr;
+  int r = pthip_alloc(wbytes + dbytes + fbytes, &scratch);
+  if (r) return r;
+  T* W = (T*)scratch;
+  T* Dinv = (T*)((char*)scratch + wbytes);
+  int* flags = (int*)((char*)scratch + wbytes + dbytes);
+  int* failflag = flags, *abortflag = flags + 1, *done = flags + 64;
+  auto fail = [&](int rc) { pthip_free(scratch); return rc; };
+  auto kk = chol_dag_kernel<T>;
+  const size_t lds = (size_t)(2 * DT * DLS + 4 * 16 * 17) * sizeof(T);
+  static int resident = 0;  // workgroups of this kernel the device holds at once
+  if (!resident) {
+    if (lds > 64 * 1024)
+      if (hipError_t e = hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess)
+        return fail(pthip::check(e, "chol_dag attribute"));
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kk, BLOCK, lds); e != hipSuccess)
+      return fail(pthip::check(e, "chol_dag occupancy"));
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return fail(pthip::check(e, "chol_dag device"));
+    if (hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess)
+      return fail(pthip::check(e, "chol_dag device attribute"));
+    if (per_cu > 2) per_cu = 2;
+    resident = per_cu * cus;
+    if (resident <= 0) return fail(pthip::check(hipErrorInvalidValue, "chol_dag: kernel does not fit the device"));
+  }
+  if (hipError_t e = pthip::memset_async(flags, 0, fbytes, st); e != hipSuccess) return fail(pthip::check(e, "chol flags memset"));
+  const unsigned ntile = (unsigned)(np / 32);
+  PTHIP_KLAUNCH((chol_stage_kernel<T>), dim3(ntile, ntile), dim3(BLOCK), 0, st, W, A, (int)n, lower, (int)np);
+  if ((r = pthip::post_launch("chol_stage"))) return fail(r);
+  const int ntasks = nT * (nT + 1) / 2;
+  const unsigned grid = (unsigned)(ntasks < resident ? ntasks : resident);
+  PTHIP_KLAUNCH(kk, dim3(grid), dim3(BLOCK), lds, st, W, np, nT, done, Dinv, failflag, abortflag, pthip::ctx().status_dev);
+  if ((r = pthip::post_launch("chol_dag"))) return fail(r);
+  const unsigned nt = (unsigned)((n + 31) / 32);
+  PTHIP_KLAUNCH((chol_finish_kernel<T>), dim3(nt, nt), dim3(BLOCK), 0, st, L, (const T*)W, (int)n, lower, (const int*)failflag, (int)np);
+  r = pthip::post_launch("chol_finish");
+  pthip_free(scratch);  // stream-ordered reuse keeps this safe
+  return r;
+}
+
 template <class T>
 int chol_blocked(int lower, long long n, const T* A, T* L) {
+  static const bool steps = getenv("PTHIP_CHOL") && !strcmp(getenv("PTHIP_CHOL"), "steps");
+  if (!steps) return chol_dag<T>(lower, n, A, L);
   hipStream_t st = pthip::ctx().stream;
   void* scratch = nullptr;
   const size_t wbytes = (size_t)n * n * sizeof(T);
@@ -658,7 +947,7 @@ int chol_blocked(int lower, long long n, const T* A, T* L) {
   const unsigned nt = (unsigned)((n + 31) / 32);
   auto fail = [&](int rc) { pthip_free(scratch); return rc; };
   if (hipError_t e = pthip::memset_async(flag, 0, 256, st); e != hipSuccess) return fail(pthip::check(e, "chol flag memset"));
-  PTHIP_KLAUNCH((chol_stage_kernel<T>), dim3(nt, nt), dim3(BLOCK), 0, st, W, A, (int)n, lower);
+  PTHIP_KLAUNCH((chol_stage_kernel<T>), dim3(nt, nt), dim3(BLOCK), 0, st, W, A, (int)n, lower, (int)n);
   if ((r = pthip::post_launch("chol_stage"))) return fail(r);
   auto kd = potrf_lds_kernel<T>;
   auto kt = chol_trsm_kernel<T>;
@@ -720,7 +1009,7 @@ int chol_blocked(int lower, long long n, const T* A, T* L) {
       if (r) return fail(r);
     }
   }
-  PTHIP_KLAUNCH((chol_finish_kernel<T>), dim3(nt, nt), dim3(BLOCK), 0, st, L, (const T*)W, (int)n, lower, (const int*)flag);
+  PTHIP_KLAUNCH((chol_finish_kernel<T>), dim3(nt, nt), dim3(BLOCK), 0, st, L, (const T*)W, (int)n, lower, (const int*)flag, (int)n);
   r = pthip::post_launch("chol_finish");
   pthip_free(scratch);  // stream-ordered reuse keeps this safe
   return r;

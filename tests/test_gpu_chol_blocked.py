@@ -128,3 +128,29 @@ def test_gp_marginal_likelihood_n512_through_the_graph(hip):
     got = exe(*ins)
     for k, (a, b) in enumerate(zip(got, want)):
         np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-9 * max(1.0, float(np.max(np.abs(b)))), err_msg=f"gp n=512 out{k}")
+
+
+def test_launch_per_step_form_still_matches(hip):
+    """``PTHIP_CHOL=steps`` (the launch-per-step form kept as the A/B reference of the task-graph
+    kernel) is read once per process: checked in a child process against LAPACK."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as np, scipy.linalg, sys\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from pytensor_amd import ffi\n"
+        "from pytensor_amd.device import DeviceArray\n"
+        "ffi.init(0)\n"
+        "for n in (300, 1000):\n"
+        "    rng = np.random.default_rng(n); A = rng.normal(size=(n, n + 5)); S = A @ A.T / n + np.eye(n)\n"
+        "    d = DeviceArray.from_host(S); L = DeviceArray.empty(S.shape, S.dtype)\n"
+        "    ffi.check(ffi.lib().pthip_potrf(ffi.np_dtype_code(S.dtype), 1, 1, n, d.ptr, L.ptr))\n"
+        "    np.testing.assert_allclose(L.to_host(), scipy.linalg.cholesky(S, lower=True), rtol=1e-10, atol=1e-12)\n"
+        "print('ok')\n"
+    )
+    env = dict(os.environ, PTHIP_CHOL="steps")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
