@@ -51,6 +51,9 @@ template <> struct Mfma16<float> {
   static __device__ __forceinline__ int drow(int lane, int r) { return 4 * (lane >> 4) + r; }
 };
 
+__device__ __forceinline__ double hw_rcp(double x) { return __builtin_amdgcn_rcp(x); }  // v_rcp_f64: a seed, refine
+__device__ __forceinline__ float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 template <class T> __device__ __forceinline__ T bcast_lane(T v, int src) {
   // wave-uniform broadcast of lane `src` (compile-time constant after unrolling)
   if constexpr (sizeof(T) == 8) {
@@ -712,6 +715,11 @@ __device__ __forceinline__ int dag_wait(const int* __restrict__ done, int nT, in
   return nr;
 }
 
+// profiling hook (PTHIP_CHOL_TRACE): thread 0 stamps the 100 MHz clock into slot `slot` of its task
+__device__ __forceinline__ void dag_stamp(long long* tr, int slot) {
+  if (tr && threadIdx.x == 0) tr[slot] = (long long)wall_clock64();
+}
+
 template <class T> struct DagTile {
   static constexpr int VEC = 16 / (int)sizeof(T);
   static constexpr int NV = DT * DT / VEC / BLOCK;  // 16-byte loads per thread and tile
@@ -736,152 +744,430 @@ template <class T> struct DagTile {
   }
 };
 
+// acc1 += L(ra,k) L(rb,k)^T  (HEAD: also acc2 += L(ra,k) L(ra,k)^T) for k in [0, kend), each product as
+// soon as both tiles are final; the next pair of tiles is in flight under the current product whenever it
+// is already known to be final.  Returns false when a wait expired.
+template <class T, bool HEAD>
+__device__ __forceinline__ bool dag_accumulate(typename Mfma16<T>::v4 (&acc1)[2][2], typename Mfma16<T>::v4 (&acc2)[2][2],
+                                               const T* __restrict__ W, long long ld, int nT, int ra, int rb, int kend,
+                                               const int* __restrict__ done, int* __restrict__ abortflag, int* s_box,
+                                               T* __restrict__ As, T* __restrict__ Bs) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+  const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;  // this wave's 32 x 32 quadrant of the tile
+  int kready = 0;
+  bool have = false;
+  DagTile<T> ta, tb;
+  for (int k = 0; k < kend; k++) {
+    if (!have) {
+      if (k >= kready) {
+        const int nr = dag_wait(done, nT, ra, rb, k, kend, abortflag, s_box);
+        if (nr < 0) return false;
+        kready = (k + nr) < kend ? (k + nr) : kend;
+      }
+      ta.load(W + (long long)ra * DT * ld + (long long)k * DT, ld);
+      tb.load(W + (long long)rb * DT * ld + (long long)k * DT, ld);
+    }
+    ta.store(As);
+    tb.store(Bs);
+    __syncthreads();
+    have = (k + 1) < kready;
+    if (have) {
+      ta.load(W + (long long)ra * DT * ld + (long long)(k + 1) * DT, ld);
+      tb.load(W + (long long)rb * DT * ld + (long long)(k + 1) * DT, ld);
+    }
+#pragma unroll 4
+    for (int st = 0; st < DT / 4; st++) {
+      const T a0 = As[(r0 + li) * DLS + 4 * st + lq], a1 = As[(r0 + 16 + li) * DLS + 4 * st + lq];
+      const T b0 = Bs[(c0 + li) * DLS + 4 * st + lq], b1 = Bs[(c0 + 16 + li) * DLS + 4 * st + lq];
+      acc1[0][0] = Mfma16<T>::run(a0, b0, acc1[0][0]);
+      acc1[0][1] = Mfma16<T>::run(a0, b1, acc1[0][1]);
+      acc1[1][0] = Mfma16<T>::run(a1, b0, acc1[1][0]);
+      acc1[1][1] = Mfma16<T>::run(a1, b1, acc1[1][1]);
+      if constexpr (HEAD) {
+        const T d0 = As[(c0 + li) * DLS + 4 * st + lq], d1 = As[(c0 + 16 + li) * DLS + 4 * st + lq];
+        acc2[0][0] = Mfma16<T>::run(a0, d0, acc2[0][0]);
+        acc2[0][1] = Mfma16<T>::run(a0, d1, acc2[0][1]);
+        acc2[1][0] = Mfma16<T>::run(a1, d0, acc2[1][0]);
+        acc2[1][1] = Mfma16<T>::run(a1, d1, acc2[1][1]);
+      }
+    }
+    __syncthreads();
+  }
+  return true;
+}
+
+// X = R L^-T in place on the 64 x 64 tile As (L in Bs, the inverses of its diagonal 16 x 16 blocks in
+// Dv), by 16-column blocks on the matrix cores; wave w owns rows 16w .. 16w+15 (no cross-wave traffic,
+// LDS operations of a wave complete in order).  Caller brackets it with barriers.
 template <class T>
-__global__ __launch_bounds__(BLOCK) void chol_dag_kernel(T* __restrict__ W, long long ld, int nT,
+__device__ __forceinline__ void dag_substitute(T* __restrict__ As, const T* __restrict__ Bs, const T* __restrict__ Dv) {
+  typedef typename Mfma16<T>::v4 v4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+  const T* xrow = As + (wave * 16 + li) * DLS;
+  for (int jb = 0; jb < DT / 16; jb++) {
+    v4 s = {T(0), T(0), T(0), T(0)};
+    for (int c = 0; c < jb; c++) {
+#pragma unroll
+      for (int st = 0; st < 4; st++)
+        s = Mfma16<T>::run(xrow[c * 16 + 4 * st + lq], Bs[(jb * 16 + li) * DLS + c * 16 + 4 * st + lq], s);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) As[(wave * 16 + Mfma16<T>::drow(lane, r)) * DLS + jb * 16 + li] -= s[r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    v4 xo = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+    for (int st = 0; st < 4; st++)
+      xo = Mfma16<T>::run(xrow[jb * 16 + 4 * st + lq], Dv[(jb * 16 + li) * 17 + 4 * st + lq], xo);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 4; r++) As[(wave * 16 + Mfma16<T>::drow(lane, r)) * DLS + jb * 16 + li] = xo[r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+// this thread's 16 entries of tile (i, j) of the working matrix, in the accumulator layout
+template <class T>
+__device__ __forceinline__ void dag_load_acc_layout(T (&a)[2][2][4], const T* __restrict__ Aij, long long ld) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15;
+  const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
+#pragma unroll
+  for (int x = 0; x < 2; x++)
+#pragma unroll
+    for (int y = 0; y < 2; y++)
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        a[x][y][r] = Aij[(long long)(r0 + x * 16 + Mfma16<T>::drow(lane, r)) * ld + c0 + y * 16 + li];
+}
+
+template <class T>
+__device__ __forceinline__ void dag_residual_to_lds(T* __restrict__ As, const T (&a)[2][2][4],
+                                                    const typename Mfma16<T>::v4 (&acc)[2][2]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15;
+  const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
+#pragma unroll
+  for (int x = 0; x < 2; x++)
+#pragma unroll
+    for (int y = 0; y < 2; y++)
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        As[(r0 + x * 16 + Mfma16<T>::drow(lane, r)) * DLS + c0 + y * 16 + li] = a[x][y][r] - acc[x][y][r];
+}
+
+// wait for diagonal tile jd, then its factor -> Bs and the inverses of its diagonal blocks -> Dv
+template <class T>
+__device__ __forceinline__ bool dag_fetch_factor(const T* __restrict__ W, long long ld, int nT, int jd,
+                                                 const T* __restrict__ Dinv, const int* __restrict__ done,
+                                                 int* __restrict__ abortflag, int* s_box, T* __restrict__ Bs,
+                                                 T* __restrict__ Dv) {
+  if (dag_wait(done, nT, jd, jd, jd, jd + 1, abortflag, s_box) < 0) return false;
+  const int tid = threadIdx.x;
+  DagTile<T> tb;
+  tb.load(W + (long long)jd * DT * ld + (long long)jd * DT, ld);
+  const T* Dg = Dinv + (long long)jd * (4 * 16 * 16);
+  T dv[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) dv[u] = Dg[u * BLOCK + tid];
+  tb.store(Bs);
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int e = u * BLOCK + tid;
+    Dv[(e >> 4) * 17 + (e & 15)] = dv[u];
+  }
+  __syncthreads();
+  return true;
+}
+
+// Tiles other workgroups will read are stored write-through (agent-scope stores): the release fence of
+// dag_publish then only waits for these stores — a plain store leaves a dirty L2 line and the fence has to
+// write the L2 back (3-4 us per publication with 32 workgroups of the same XCD writing tiles).
+template <class T> __device__ __forceinline__ void dag_store(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <class T>
+__device__ __forceinline__ void dag_store_tile(T* __restrict__ Oij, long long ld, const T* __restrict__ As) {
+#pragma unroll 4
+  for (int e = threadIdx.x; e < DT * DT; e += BLOCK) {
+    const int r = e >> 6, c = e & 63;
+    dag_store<T>(Oij + (long long)r * ld + c, As[r * DLS + c]);
+  }
+}
+
+// The 64 x 64 diagonal tile in LDS (lower triangle of Wt[r * DLS + c]) factored by ONE wave, no barriers:
+// lane r holds row j0 + r of the current 16-column panel — the 16 diagonal rows AND every row below —
+// so that scaling column k by 1/sqrt(pivot) is at once the factorisation step and the panel solve, and
+// the rank-1 update broadcasts each l_ck once (v_readlane) for all rows; the trailing 16 x 16 tiles are
+// then updated on the matrix cores from LDS (at most six tiles: one wave's MFMA time is what two
+// barriers would cost).  After each panel `*prog` advances: column block p of the factor (and, in rows
+// DT .. DT+15, the transposed inverse of diagonal block p >= 1) is final, for the waves that write back.
+template <class T>
+__device__ __forceinline__ bool potrf64_wave(T* __restrict__ Wt, T* __restrict__ colbuf, volatile int* prog, long long* tr) {
+  typedef typename Mfma16<T>::v4 v4;
+  const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+  bool fail = false;
+#pragma unroll
+  for (int p = 0; p < DT / 16; p++) {
+    const int j0 = 16 * p;
+    // lanes past the last row of the tile (panels 1-3): rows DT .. DT+15 of Wt, which hold the identity in
+    // these 16 columns — "rows below" whose panel solve e_a L_pp^-T is row a of L_pp^-T: the inverse of the
+    // diagonal block, which the substitution of every consumer needs, falls out of the elimination for free
+    const int nreal = DT - j0;
+    const int row = lane < nreal ? (j0 + lane) : (lane < nreal + 16 ? (DT + lane - nreal) : (DT - 1));
+    const bool live = lane < nreal + (p > 0 ? 16 : 0);
+    T d[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) d[c] = Wt[row * DLS + j0 + c];
+#pragma unroll
+    for (int c = 0; c < 16; c++) d[c] = (lane >= 16 || c <= lane) ? d[c] : T(0);
+    // Square-root-free elimination (L D L^T; the columns are scaled by 1/sqrt(pivot) afterwards, all 16
+    // at once): the loop is one dependent chain executed by a single wave, every instruction on it costs
+    // its full latency, so the chain is kept to: pivot p = row k's entry k (v_readlane), r = 1/p
+    // (v_rcp + two Newton steps), l = column * r, and the update d[c] -= l * u_ck of the later columns with
+    // u_ck = entry k of row j0 + c — for the next column by v_readlane BEFORE the reciprocal is known, the others
+    // through LDS (one 8-byte store of the unscaled column, uniform-address loads — the thirty v_readlane +
+    // SGPR pairs per column of an all-register version made the loop instruction-bound), applied one
+    // column later, under the next column's chain (a dependent fp64 op is 3.8 ns, an LDS round trip 53 ns,
+    // tools/ubench/lat.hip).
+    T cur[16], lprev = T(0), pown = T(1);
+#pragma unroll
+    for (int c = 0; c < 16; c++) cur[c] = T(0);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      if (k + 2 < 16) colbuf[lane] = d[k];
+      const T pk = bcast_lane(d[k], k);
+      T u1 = T(0);
+      if (k + 1 < 16) u1 = bcast_lane(d[k], k + 1);
+      T nxt[16];
+#pragma unroll
+      for (int c = k + 2; c < 16; c++) nxt[c] = colbuf[c];
+      if (!(pk > T(0))) fail = true;  // dpotf2: non-positive or NaN pivot (wave-uniform)
+      pown = (lane == k) ? pk : pown;
+      T r = hw_rcp(pk);
+      r = __builtin_fma(r, __builtin_fma(-pk, r, T(1)), r);
+      r = __builtin_fma(r, __builtin_fma(-pk, r, T(1)), r);
+      const T lk = d[k] * r;
+      if (k + 1 < 16) d[k + 1] -= lk * u1;
+      if (k >= 1) {
+#pragma unroll
+        for (int c = k + 1; c < 16; c++) d[c] -= lprev * cur[c];
+      }
+#pragma unroll
+      for (int c = k + 2; c < 16; c++) cur[c] = nxt[c];
+      lprev = lk;
+    }
+    {
+      // L = (unscaled columns) * diag(1/sqrt(p)): lane k < 16 owns pivot k
+      colbuf[lane] = rsqrt(pown);
+#pragma unroll
+      for (int c = 0; c < 16; c++) d[c] *= colbuf[c];
+    }
+    if (p == 0) dag_stamp(tr, 9);
+    if (live) {  // (entries right of the diagonal in the 16 diagonal rows: never read again)
+#pragma unroll
+      for (int c = 0; c < 16; c++) Wt[row * DLS + j0 + c] = d[c];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) *prog = p + 1;
+    // trailing tiles (ti >= tj) of the rows / columns past this panel
+#pragma unroll
+    for (int ti = 0; ti < DT / 16 - 1 - p; ti++) {
+#pragma unroll
+      for (int tj = 0; tj <= ti; tj++) {
+        const int i0 = j0 + 16 + 16 * ti, c0 = j0 + 16 + 16 * tj;
+        v4 acc = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+          acc = Mfma16<T>::run(Wt[(i0 + li) * DLS + j0 + 4 * kk + lq], Wt[(c0 + li) * DLS + j0 + 4 * kk + lq], acc);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int i = i0 + Mfma16<T>::drow(lane, r), jx = c0 + li;
+          if (jx <= i) Wt[i * DLS + jx] -= acc[r];
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (p < 3) dag_stamp(tr, 10 + p);
+  }
+  return fail;
+}
+
+// every thread's stores of the tile are visible device-wide before the flag is
+__device__ __forceinline__ void dag_publish(int* flag, long long* tr = nullptr, int slot = 0) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  dag_stamp(tr, slot);
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Tasks, in dependency order: for every tile column j the HEAD task H(j) — tiles (j, j-1) AND (j, j):
+// the solve of the first tile below diagonal block j-1, the update of diagonal tile j with it straight
+// from LDS, and the factorisation of that tile (the whole critical path of one column in ONE workgroup:
+// separate tasks cost a store + publish + poll + reload + product = 11 of 37 us per column,
+// profiles/r3t_chol_trace.txt) — followed by the ordinary tasks (i, j), i >= j + 2.
+template <class T>
+__global__ __launch_bounds__(BLOCK) void chol_dag_kernel(T* __restrict__ W, long long ld, int nT, int ntasks,
                                                         int* __restrict__ done, T* __restrict__ Dinv,
                                                         int* __restrict__ failflag, int* __restrict__ abortflag,
-                                                        int* __restrict__ status) {
+                                                        int* __restrict__ status, long long* __restrict__ trace) {
+  // trace != NULL (PTHIP_CHOL_TRACE=<file>): sixteen 100 MHz timestamps per task, see tools/chol_trace.py
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __shared__ int s_box;
-  T* As = (T*)smem_raw;     // [DT][DLS]  L(i,k); then the tile being finished
-  T* Bs = As + DT * DLS;    // [DT][DLS]  L(j,k); then L(j,j)
-  T* Dv = Bs + DT * DLS;    // [4][16][17] inverses of the diagonal 16x16 blocks of L(j,j)
+  __shared__ int s_box, s_prog, s_arrive[4];
+  T* As = (T*)smem_raw;     // [DT + 16][DLS]  L(ra,k); then the tile being finished (+ 16 identity rows, potrf64_wave)
+  T* Bs = As + (DT + 16) * DLS;    // [DT][DLS]  L(rb,k); then the factor of the diagonal tile above
+  T* Dv = Bs + DT * DLS;    // [4][16][17] inverses of the diagonal 16x16 blocks of that factor
+  T* s_rd = Dv + 4 * 16 * 17;  // [DT] reciprocals of that factor's diagonal
+  T* s_col = s_rd + DT;        // [64] the column being eliminated (potrf64_wave)
   typedef typename Mfma16<T>::v4 v4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
-  const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;  // this wave's 32 x 32 quadrant of the tile
-  const int ntasks = nT * (nT + 1) / 2;
+  const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
+#define DAG_STAMP(slot) dag_stamp(tr, slot)
+#define DAG_GIVE_UP() do { if (tid == 0) { atomicOr(status, 16); __hip_atomic_store(abortflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return; } while (0)
   for (int t = blockIdx.x; t < ntasks; t += gridDim.x) {
     int j = 0, rem = t;
-    while (rem >= nT - j) { rem -= nT - j; j++; }
-    const int i = j + rem;
-    const bool diag = i == j;
-    v4 acc[2][2];
+    for (;;) {
+      const int cj = 1 + ((nT - j - 2) > 0 ? (nT - j - 2) : 0);
+      if (rem < cj) break;
+      rem -= cj;
+      j++;
+    }
+    const bool head = rem == 0;
+    const int i = head ? j : j + 1 + rem;
+    long long* tr = trace ? trace + (long long)t * 16 : nullptr;
+    DAG_STAMP(0);
+    v4 acc1[2][2], acc2[2][2];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int x = 0; x < 2; x++)
 #pragma unroll
-      for (int b = 0; b < 2; b++) acc[a][b] = v4{T(0), T(0), T(0), T(0)};
-    int kready = 0;
-    bool have = false;
-    DagTile<T> ta, tb;
-    for (int k = 0; k < j; k++) {
-      if (!have) {
-        if (k >= kready) {
-          const int nr = dag_wait(done, nT, i, j, k, j, abortflag, &s_box);
-          if (nr < 0) {
-            if (tid == 0) { atomicOr(status, 16); __hip_atomic_store(abortflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            return;
-          }
-          kready = (k + nr) < j ? (k + nr) : j;
-        }
-        ta.load(W + (long long)i * DT * ld + (long long)k * DT, ld);
-        if (!diag) tb.load(W + (long long)j * DT * ld + (long long)k * DT, ld);
-      }
-      ta.store(As);
-      if (!diag) tb.store(Bs);
+      for (int y = 0; y < 2; y++) acc1[x][y] = acc2[x][y] = v4{T(0), T(0), T(0), T(0)};
+    if (!head) {
+      // ---- ordinary task: L(i,j) = (A(i,j) - sum_k L(i,k) L(j,k)^T) L(j,j)^-T
+      T a[2][2][4];
+      dag_load_acc_layout<T>(a, W + (long long)i * DT * ld + (long long)j * DT, ld);
+      if (!dag_accumulate<T, false>(acc1, acc2, W, ld, nT, i, j, j, done, abortflag, &s_box, As, Bs)) DAG_GIVE_UP();
+      DAG_STAMP(1);
+      dag_residual_to_lds<T>(As, a, acc1);
+      if (!dag_fetch_factor<T>(W, ld, nT, j, Dinv, done, abortflag, &s_box, Bs, Dv)) DAG_GIVE_UP();
+      DAG_STAMP(2);
+      dag_substitute<T>(As, Bs, Dv);
       __syncthreads();
-      have = (k + 1) < kready;  // (kready <= j)
-      if (have) {  // the next pair of tiles is known final: in flight under this product
-        ta.load(W + (long long)i * DT * ld + (long long)(k + 1) * DT, ld);
-        if (!diag) tb.load(W + (long long)j * DT * ld + (long long)(k + 1) * DT, ld);
+      DAG_STAMP(3);
+      dag_store_tile<T>(W + (long long)i * DT * ld + (long long)j * DT, ld, As);
+      dag_publish(done + (long long)i * nT + j, tr, 6);
+      DAG_STAMP(15);
+      continue;
+    }
+    // ---- head task of column j
+    T ad[2][2][4];
+    dag_load_acc_layout<T>(ad, W + (long long)j * DT * ld + (long long)j * DT, ld);
+    if (j > 0) {
+      T as_[2][2][4];
+      dag_load_acc_layout<T>(as_, W + (long long)j * DT * ld + (long long)(j - 1) * DT, ld);
+      if (!dag_accumulate<T, true>(acc1, acc2, W, ld, nT, j, j - 1, j - 1, done, abortflag, &s_box, As, Bs)) DAG_GIVE_UP();
+      DAG_STAMP(1);
+      dag_residual_to_lds<T>(As, as_, acc1);
+      if (!dag_fetch_factor<T>(W, ld, nT, j - 1, Dinv, done, abortflag, &s_box, Bs, Dv)) DAG_GIVE_UP();
+      DAG_STAMP(2);
+      dag_substitute<T>(As, Bs, Dv);
+      __syncthreads();
+      DAG_STAMP(3);
+      // L(j,j-1) on its way to memory (waves 1-3; wave 0 keeps no store in flight: it goes straight on to the
+      // factorisation, the others retire their stores and publish the tile behind its back); meanwhile the
+      // diagonal tile takes its last update from LDS
+      if (wave != 0) {
+        T* Ox = W + (long long)j * DT * ld + (long long)(j - 1) * DT;
+#pragma unroll 4
+        for (int e = tid - 64; e < DT * DT; e += BLOCK - 64) dag_store<T>(Ox + (long long)(e >> 6) * ld + (e & 63), As[(e >> 6) * DLS + (e & 63)]);
       }
-      const T* Bp = diag ? As : Bs;
+      DAG_STAMP(4);
 #pragma unroll 4
       for (int st = 0; st < DT / 4; st++) {
         const T a0 = As[(r0 + li) * DLS + 4 * st + lq], a1 = As[(r0 + 16 + li) * DLS + 4 * st + lq];
-        const T b0 = Bp[(c0 + li) * DLS + 4 * st + lq], b1 = Bp[(c0 + 16 + li) * DLS + 4 * st + lq];
-        acc[0][0] = Mfma16<T>::run(a0, b0, acc[0][0]);
-        acc[0][1] = Mfma16<T>::run(a0, b1, acc[0][1]);
-        acc[1][0] = Mfma16<T>::run(a1, b0, acc[1][0]);
-        acc[1][1] = Mfma16<T>::run(a1, b1, acc[1][1]);
+        const T d0 = As[(c0 + li) * DLS + 4 * st + lq], d1 = As[(c0 + 16 + li) * DLS + 4 * st + lq];
+        acc2[0][0] = Mfma16<T>::run(a0, d0, acc2[0][0]);
+        acc2[0][1] = Mfma16<T>::run(a0, d1, acc2[0][1]);
+        acc2[1][0] = Mfma16<T>::run(a1, d0, acc2[1][0]);
+        acc2[1][1] = Mfma16<T>::run(a1, d1, acc2[1][1]);
       }
-      __syncthreads();
+      DAG_STAMP(5);
+      DAG_STAMP(6);
+      __syncthreads();  // every wave is done reading As
+      DAG_STAMP(7);
     }
-    // R = A(i,j) - acc, into LDS
-    {
-      const T* Aij = W + (long long)i * DT * ld + (long long)j * DT;
-#pragma unroll
-      for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int row = r0 + a * 16 + Mfma16<T>::drow(lane, r), col = c0 + b * 16 + li;
-            As[row * DLS + col] = Aij[(long long)row * ld + col] - acc[a][b][r];
-          }
+    dag_residual_to_lds<T>(As, ad, acc2);
+    for (int e = tid; e < 16 * DT; e += BLOCK) {  // rows DT .. DT+15: the identity under column blocks 1-3
+      const int a = e >> 6, c = e & 63;
+      As[(DT + a) * DLS + c] = (c >= 16 && (c & 15) == a) ? T(1) : T(0);
     }
+    if (tid < 4) { s_prog = 0; s_arrive[tid] = 0; }
     __syncthreads();
-    if (diag) {
-      const bool fail = potrf_lds_core<T>(As, DLS, DT);  // (ends on a barrier)
-      if (fail && tid == 0) atomicOr(failflag, 1);
+    DAG_STAMP(8);
+    if (j > 0 && wave != 0) {
+      // (plain LDS words, no LDS atomic: an atomic through a generic pointer to LDS trips the gfx950 back end)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      volatile int* arrive = s_arrive;
+      if (lane == 0) arrive[wave] = 1;
+      if (wave == 1) {
+        while (!(arrive[2] && arrive[3])) __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_store(done + (long long)j * nT + (j - 1), 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    {
+      volatile int* prog = &s_prog;
+      T* Ojj = W + (long long)j * DT * ld + (long long)j * DT;
+      T* Dg = Dinv + (long long)j * (4 * 16 * 16);
       if (wave == 0) {
-        // lane = 16 * block + column: column `li` of inv(L_bb), b = lq, by forward substitution
-        const T* Lb = As + (lq * 16) * DLS + lq * 16;
-        T x[16];
+        const bool fail = potrf64_wave<T>(As, s_col, prog, tr);
+        if (fail && lane == 0) atomicOr(failflag, 1);
+        DAG_STAMP(13);
+      } else {
+        if (wave == 1) {
+          // diagonal block 0 has no spare lanes in the elimination: its inverse here, under panels 1-3
+          // (column c of inv(L_00) by forward substitution, lane c < 16; right-looking: 16 steps of mul + fma)
+          while (*prog <= 0) __builtin_amdgcn_s_sleep(8);
+          const T dg = As[li * DLS + li];
+          T rr = hw_rcp(dg);
+          rr = __builtin_fma(rr, __builtin_fma(-dg, rr, T(1)), rr);
+          rr = __builtin_fma(rr, __builtin_fma(-dg, rr, T(1)), rr);
+          s_rd[li] = rr;  // (the four 16-lane groups store the same value)
+          T x[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          T sacc = (r == li) ? T(1) : T(0);
+          for (int r = 0; r < 16; r++) x[r] = (r == li) ? T(1) : T(0);
 #pragma unroll
-          for (int q = 0; q < r; q++) sacc -= Lb[r * DLS + q] * x[q];
-          x[r] = (r < li) ? T(0) : sacc / Lb[r * DLS + r];
+          for (int q = 0; q < 16; q++) {
+            x[q] *= s_rd[q];
+#pragma unroll
+            for (int r = q + 1; r < 16; r++) x[r] -= As[r * DLS + q] * x[q];
+          }
+          if (lane < 16) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) dag_store<T>(Dg + r * 16 + li, x[r]);
+          }
         }
-        T* Dg = Dinv + (long long)j * (4 * 16 * 16);
-#pragma unroll
-        for (int r = 0; r < 16; r++) Dg[(lq * 16 + r) * 16 + li] = x[r];
-      }
-    } else {
-      const int nr = dag_wait(done, nT, j, j, j, j + 1, abortflag, &s_box);
-      if (nr < 0) {
-        if (tid == 0) { atomicOr(status, 16); __hip_atomic_store(abortflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-        return;
-      }
-      tb.load(W + (long long)j * DT * ld + (long long)j * DT, ld);
-      const T* Dg = Dinv + (long long)j * (4 * 16 * 16);
-      T dv[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) dv[u] = Dg[u * BLOCK + tid];
-      tb.store(Bs);
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int e = u * BLOCK + tid;
-        Dv[(e >> 4) * 17 + (e & 15)] = dv[u];
-      }
-      __syncthreads();
-      // X = R L(j,j)^-T by 16-column blocks; wave w owns rows 16w .. 16w+15 (no cross-wave traffic)
-      const T* xrow = As + (wave * 16 + li) * DLS;
-      for (int jb = 0; jb < DT / 16; jb++) {
-        v4 s = {T(0), T(0), T(0), T(0)};
-        for (int c = 0; c < jb; c++) {
-#pragma unroll
-          for (int st = 0; st < 4; st++)
-            s = Mfma16<T>::run(xrow[c * 16 + 4 * st + lq], Bs[(jb * 16 + li) * DLS + c * 16 + 4 * st + lq], s);
+        // column block b of the factor, and the inverse of diagonal block b >= 1 (rows DT.. of As hold it
+        // transposed), back to memory as soon as panel b is final
+        const int t2 = tid - 64;
+        for (int bq = 0; bq < DT / 16; bq++) {
+          while (*prog <= bq) __builtin_amdgcn_s_sleep(8);
+          const int nel = (DT - 16 * bq) * 16;
+          for (int e = t2; e < nel; e += BLOCK - 64) {
+            const int r = 16 * bq + (e >> 4), c = 16 * bq + (e & 15);
+            if (c <= r) dag_store<T>(Ojj + (long long)r * ld + c, As[r * DLS + c]);
+          }
+          if (bq > 0) {
+            for (int e = t2; e < 256; e += BLOCK - 64) {
+              const int r = e >> 4, c = e & 15;  // Dinv_b[r][c] = (L_bb^-T)[c][r]
+              dag_store<T>(Dg + (bq * 16 + r) * 16 + c, As[(DT + c) * DLS + 16 * bq + r]);
+            }
+          }
         }
-#pragma unroll
-        for (int r = 0; r < 4; r++) As[(wave * 16 + Mfma16<T>::drow(lane, r)) * DLS + jb * 16 + li] -= s[r];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        v4 xo = {T(0), T(0), T(0), T(0)};
-#pragma unroll
-        for (int st = 0; st < 4; st++)
-          xo = Mfma16<T>::run(xrow[jb * 16 + 4 * st + lq], Dv[(jb * 16 + li) * 17 + 4 * st + lq], xo);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int r = 0; r < 4; r++) As[(wave * 16 + Mfma16<T>::drow(lane, r)) * DLS + jb * 16 + li] = xo[r];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      __syncthreads();
-    }
-    // the finished tile (a diagonal tile: its lower triangle) back to the working matrix
-    {
-      T* Oij = W + (long long)i * DT * ld + (long long)j * DT;
-#pragma unroll 4
-      for (int e = tid; e < DT * DT; e += BLOCK) {
-        const int r = e >> 6, c = e & 63;
-        if (!diag || c <= r) Oij[(long long)r * ld + c] = As[r * DLS + c];
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(done + (long long)i * nT + j, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    dag_publish(done + (long long)j * nT + j, tr, 14);
+    DAG_STAMP(15);
   }
+#undef DAG_STAMP
+#undef DAG_GIVE_UP
 }
 
 template <class T>
@@ -901,7 +1187,7 @@ int chol_dag(int lower, long long n, const T* A, T* L) {
   int* failflag = flags, *abortflag = flags + 1, *done = flags + 64;
   auto fail = [&](int rc) { pthip_free(scratch); return rc; };
   auto kk = chol_dag_kernel<T>;
-  const size_t lds = (size_t)(2 * DT * DLS + 4 * 16 * 17) * sizeof(T);
+  const size_t lds = (size_t)((2 * DT + 16) * DLS + 4 * 16 * 17 + DT + 64) * sizeof(T);
   static int resident = 0;  // workgroups of this kernel the device holds at once
   if (!resident) {
     if (lds > 64 * 1024)
@@ -921,10 +1207,27 @@ int chol_dag(int lower, long long n, const T* A, T* L) {
   const unsigned ntile = (unsigned)(np / 32);
   PTHIP_KLAUNCH((chol_stage_kernel<T>), dim3(ntile, ntile), dim3(BLOCK), 0, st, W, A, (int)n, lower, (int)np);
   if ((r = pthip::post_launch("chol_stage"))) return fail(r);
-  const int ntasks = nT * (nT + 1) / 2;
+  int ntasks = 0;  // per column: the head task + the tiles from two below the diagonal down
+  for (int j = 0; j < nT; j++) ntasks += 1 + ((nT - j - 2) > 0 ? (nT - j - 2) : 0);
   const unsigned grid = (unsigned)(ntasks < resident ? ntasks : resident);
-  PTHIP_KLAUNCH(kk, dim3(grid), dim3(BLOCK), lds, st, W, np, nT, done, Dinv, failflag, abortflag, pthip::ctx().status_dev);
+  long long* trace = nullptr;
+  static const char* trace_path = getenv("PTHIP_CHOL_TRACE");
+  if (trace_path && hipMalloc((void**)&trace, (size_t)ntasks * 16 * sizeof(long long)) != hipSuccess) trace = nullptr;
+  PTHIP_KLAUNCH(kk, dim3(grid), dim3(BLOCK), lds, st, W, np, nT, ntasks, done, Dinv, failflag, abortflag, pthip::ctx().status_dev, trace);
   if ((r = pthip::post_launch("chol_dag"))) return fail(r);
+  if (trace) {  // profiling hook only: synchronises
+    std::vector<long long> h((size_t)ntasks * 16);
+    if (hipStreamSynchronize(st) == hipSuccess &&
+        hipMemcpy(h.data(), trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
+      if (FILE* f = fopen(trace_path, "wb")) {
+        const long long hdr[2] = {nT, (long long)grid};
+        fwrite(hdr, sizeof(long long), 2, f);
+        fwrite(h.data(), sizeof(long long), h.size(), f);
+        fclose(f);
+      }
+    }
+    (void)hipFree(trace);
+  }
   const unsigned nt = (unsigned)((n + 31) / 32);
   PTHIP_KLAUNCH((chol_finish_kernel<T>), dim3(nt, nt), dim3(BLOCK), 0, st, L, (const T*)W, (int)n, lower, (const int*)failflag, (int)np);
   r = pthip::post_launch("chol_finish");

@@ -211,13 +211,20 @@ def raise_device_status(word: int):
     """The device error word (kernels cannot raise): bit 0 = an index was out of range
     (IndexError, like the reference's take/inc_subtensor), bit 1 = np.linalg.inv met an exactly
     singular matrix (LinAlgError), bit 2 / bit 3 = the Jacobi SVD / eigensolver did not converge
-    (LinAlgError, the messages of np.linalg.svd / eigh)."""
+    (LinAlgError, the messages of np.linalg.svd / eigh), bit 4 = a bounded dependency wait of the
+    task-graph Cholesky expired (RuntimeError)."""
     if word & 2:
         raise np.linalg.LinAlgError("Singular matrix")
     if word & 4:
         raise np.linalg.LinAlgError("SVD did not converge")
     if word & 8:
         raise np.linalg.LinAlgError("Eigenvalues did not converge")
+    if word & 16:
+        raise RuntimeError(
+            "hip linker: the task-graph Cholesky gave up waiting for a tile (its workgroups were not all "
+            "resident — another kernel holding compute units on a second stream?); PTHIP_CHOL=steps selects "
+            "the launch-per-step factorisation"
+        )
     if word & 1:
         raise IndexError("index out of bounds (device-side check)")
 

@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/r3t; mkdir -p $O
+timeout 120 python tools/chol_trace.py 4096 float64 2>&1 | tail -24 | tee $O/chol_trace_4096_c.txt
