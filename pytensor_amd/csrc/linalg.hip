@@ -1373,11 +1373,14 @@ __global__ __launch_bounds__(BLOCK) void trsv_lds_kernel(T* __restrict__ Xout,
 // rows; the 8x8 diagonal block is substituted in registers.  (MatrixInverse / Solve with a
 // matrix rhs: the generic kernel below re-read T and x from global memory for every term.)
 template <class T>
-__global__ __launch_bounds__(BLOCK) void trsm_lds_kernel(T* __restrict__ Xout,
+__global__ __launch_bounds__(BLOCK) void trsm_lds_kernel(T* Xout,
                                                         const T* __restrict__ Tm, long long sTb,
                                                         long long sT0, long long sT1,
-                                                        const T* __restrict__ B, long long sBb,
-                                                        int n, int nrhs, int lower, int unit) {
+                                                        const T* B, long long sBb,
+                                                        int n, int nrhs, int lower, int unit,
+                                                        int* __restrict__ failflag) {
+  // (B may be Xout: the blocked solve below runs in place; failflag != NULL: a zero pivot is reported
+  // there and the caller poisons the whole result)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* W = (T*)smem_raw;
   const int ld = n | 1;
@@ -1422,8 +1425,10 @@ __global__ __launch_bounds__(BLOCK) void trsm_lds_kernel(T* __restrict__ Xout,
     }
   }
   // a zero pivot poisons the whole system (all columns share T): NaN-fill like the reference
-  if (fail)
+  if (fail) {
+    if (failflag) atomicOr(failflag, 1);
     for (int i = 0; i < n; i++) x[(long long)i * nrhs + c] = (T)__builtin_nan("");
+  }
 }
 
 // generic (any n, nrhs): one thread per right-hand-side column, row-oriented substitution.
@@ -1483,6 +1488,351 @@ int potrf_typed(int lower, long long batch, long long n, const void* A, void* L,
   return 0;
 }
 
+// ---------------------------------------------------------------------------------
+// Triangular solves beyond the LDS (n > 141 fp64 / 200 fp32).
+//
+// Few right-hand sides (the GP / PyMC case: L^-1 y, L^-T z with vectors): memory-bound, n^2/2 entries
+// of T read once, but n/64 dependent steps.  One persistent kernel, workgroup s owns rows 64s .. 64s+63
+// (in "solve coordinates": an upper or transposed system is walked backwards through signed strides, so
+// the kernel only ever sees a lower triangle): it inverts its 64 x 64 diagonal block in LDS up front
+// (off the chain), then takes x_0 .. x_{s-1} as they appear, acc += T[s,k] x_k with the blocks of T
+// prefetched (they are inputs), and finishes with x_s = Dinv (b_s - acc).  Hand-over without a fence: every
+// solution entry is published as ONE 16-byte write-through store {bits(x), bits(x) ^ MAGIC} into a
+// zeroed scratch array and consumers poll the pair itself — a torn or stale read fails the check unless
+// it already equals the final pair, so only 8-byte atomicity is assumed — which takes the release fence
+// (1.5-2 us per hop, the write-through latency) and the separate flag load off every hop.
+//
+// Many right-hand sides: blocked, launch per 128 rows — the diagonal block by trsm_lds_kernel (T in LDS,
+// one thread per column) in place, the rows still to come by one MFMA GEMM with K = 128.
+// A zero pivot anywhere NaN-fills the whole result, as the LDS-resident kernels do.
+// ---------------------------------------------------------------------------------
+constexpr int TV = 64;        // rows per workgroup
+constexpr int TVS = TV + 1;   // LDS row stride
+constexpr int TV_NR = 4;      // right-hand sides per launch
+constexpr unsigned long long TV_MAGIC = 0x7ff4c0de5ea1ed01ull;
+
+__device__ __forceinline__ unsigned long long tv_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
+__device__ __forceinline__ unsigned long long tv_bits(float v) { return (unsigned long long)__float_as_uint(v); }
+__device__ __forceinline__ void tv_from_bits(unsigned long long b, double& v) { v = __longlong_as_double((long long)b); }
+__device__ __forceinline__ void tv_from_bits(unsigned long long b, float& v) { v = __uint_as_float((unsigned)b); }
+
+// Di <- inverse of the 64 x 64 lower-triangular Ds (both [TV][TVS] in LDS), all BLOCK threads; ends on a
+// barrier.  The four diagonal 16 x 16 blocks by forward substitution (one wave, lane = 16 b + column), the
+// blocks below them level by level on the matrix cores: Inv_ij = -Inv_ii (sum_{k=j..i-1} L_ik Inv_kj).
+// (A thread-per-column substitution over the whole block is a 2016-step dependent chain of LDS reads:
+// 95 us, on the critical path of the first row block.)
+template <class T>
+__device__ __forceinline__ void tri_inverse64(const T* __restrict__ Ds, T* __restrict__ Di, T* __restrict__ scratch) {
+  typedef typename Mfma16<T>::v4 v4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
+  for (int e = tid; e < TV * TV; e += BLOCK) Di[(e >> 6) * TVS + (e & 63)] = T(0);
+  __syncthreads();
+  if (wave == 0) {
+    const T* Lb = Ds + (lq * 16) * TVS + lq * 16;
+    T x[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = (r == li) ? T(1) : T(0);
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      x[q] = x[q] / Lb[q * TVS + q];
+#pragma unroll
+      for (int r = q + 1; r < 16; r++) x[r] -= Lb[r * TVS + q] * x[q];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) Di[(lq * 16 + r) * TVS + lq * 16 + li] = x[r];
+  }
+  __syncthreads();
+  T* Mt = scratch + wave * (16 * 17);
+  for (int d = 1; d < 4; d++) {
+    const int j = wave, i = wave + d;  // block (i, j) of this level on wave j
+    if (i < 4) {
+      v4 m = {T(0), T(0), T(0), T(0)};
+      for (int k = j; k < i; k++) {
+#pragma unroll
+        for (int st = 0; st < 4; st++)
+          m = Mfma16<T>::run(Ds[(16 * i + li) * TVS + 16 * k + 4 * st + lq], Di[(16 * k + 4 * st + lq) * TVS + 16 * j + li], m);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) Mt[Mfma16<T>::drow(lane, r) * 17 + li] = m[r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      v4 o = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+      for (int st = 0; st < 4; st++)
+        o = Mfma16<T>::run(Di[(16 * i + li) * TVS + 16 * i + 4 * st + lq], Mt[(4 * st + lq) * 17 + li], o);
+#pragma unroll
+      for (int r = 0; r < 4; r++) Di[(16 * i + Mfma16<T>::drow(lane, r)) * TVS + 16 * j + li] = -o[r];
+    }
+    __syncthreads();
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(BLOCK) void trsv_dag_kernel(T* __restrict__ Xp, long long x0, const T* __restrict__ Tp,
+                                                        long long t0, long long t1, const T* __restrict__ Bp,
+                                                        long long b0, int n, int nr, int unit,
+                                                        unsigned long long* __restrict__ box, int* __restrict__ failflag,
+                                                        int* __restrict__ abortflag, int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ int s_ok;
+  T* Ds = (T*)smem_raw;        // [TV][TVS] diagonal block (lower, identity beyond n)
+  T* Di = Ds + TV * TVS;       // [TV][TVS] its inverse
+  T* Ts = Ds;                  // [TV][TVS] off-diagonal block T[s, k] (the diagonal block is dead once inverted)
+  T* xs = Di + TV * TVS;       // [TV][TV_NR] x_k, then the right-hand side of the diagonal solve
+  T* red = xs + TV * TV_NR;    // [4][TV][TV_NR] partial sums of the four column quarters
+  const int tid = threadIdx.x, lane = tid & 63, part = tid >> 6;
+  const int s = blockIdx.x;
+  const long long rbase = (long long)s * TV;
+  const int nb = (n - rbase) < TV ? (int)(n - rbase) : TV;
+  const bool rowfast = (t0 == 1 || t0 == -1) && !(t1 == 1 || t1 == -1);  // which index walks memory
+  constexpr int NL = TV * TV / BLOCK;  // 16 entries of a block per thread
+  auto coord = [&](int e, int& i, int& j) {  // e -> (row, column), fast-in-memory index on adjacent threads
+    const int a = e / TV, c = e - a * TV;
+    i = rowfast ? c : a;
+    j = rowfast ? a : c;
+  };
+  // ---- the diagonal block and its inverse (before any waiting)
+  bool fail = false;
+  {
+    T v[NL];
+#pragma unroll
+    for (int u = 0; u < NL; u++) {
+      int i, j;
+      coord(u * BLOCK + tid, i, j);
+      v[u] = (i < nb && j < i) ? Tp[(rbase + i) * t0 + (rbase + j) * t1] : T(0);
+      if (i == j) {
+        v[u] = (i < nb && !unit) ? Tp[(rbase + i) * t0 + (rbase + i) * t1] : T(1);
+        if (v[u] == T(0)) fail = true;  // trtrs: exact singularity
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NL; u++) {
+      int i, j;
+      coord(u * BLOCK + tid, i, j);
+      Ds[i * TVS + j] = v[u];
+    }
+  }
+  if (fail) atomicOr(failflag, 1);
+  __syncthreads();
+  tri_inverse64<T>(Ds, Di, xs);  // (scratch: xs and red, contiguous, 4 x 16 x 17 entries)
+  // ---- acc = sum_k T[s,k] x_k
+  T acc[TV_NR];
+#pragma unroll
+  for (int j = 0; j < TV_NR; j++) acc[j] = T(0);
+  T tv[NL];
+  auto fetch = [&](int k) {
+#pragma unroll
+    for (int u = 0; u < NL; u++) {
+      int i, j;
+      coord(u * BLOCK + tid, i, j);
+      tv[u] = (i < nb) ? Tp[(rbase + i) * t0 + ((long long)k * TV + j) * t1] : T(0);
+    }
+  };
+  if (s > 0) fetch(0);
+  for (int k = 0; k < s; k++) {
+#pragma unroll
+    for (int u = 0; u < NL; u++) {
+      int i, j;
+      coord(u * BLOCK + tid, i, j);
+      Ts[i * TVS + j] = tv[u];
+    }
+    if (k + 1 < s) fetch(k + 1);  // in flight under the wait
+    if (tid < TV) {
+      const unsigned long long* bx = box + ((long long)k * TV + lane) * (TV_NR * 2);
+      unsigned long long a[TV_NR];
+      int spins = 0, ok;
+      for (;;) {
+        bool mine = true;
+#pragma unroll
+        for (int j = 0; j < TV_NR; j++) {
+          if (j < nr) {
+            a[j] = __hip_atomic_load(bx + 2 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long b = __hip_atomic_load(bx + 2 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mine = mine && ((a[j] ^ b) == TV_MAGIC);
+          }
+        }
+        ok = __builtin_amdgcn_ballot_w64(!mine) == 0ull;
+        if (ok) break;
+        if (++spins > DAG_SPIN_LIMIT || ((spins & 255) == 0 && dag_flag(abortflag))) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (lane == 0) s_ok = ok;
+#pragma unroll
+      for (int j = 0; j < TV_NR; j++) {
+        T xv = T(0);
+        if (j < nr) tv_from_bits(a[j], xv);
+        xs[lane * TV_NR + j] = xv;
+      }
+    }
+    __syncthreads();
+    if (!s_ok) {
+      if (tid == 0) { atomicOr(status, 16); __hip_atomic_store(abortflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      return;
+    }
+#pragma unroll
+    for (int cc = 0; cc < TV / 4; cc++) {
+      const int c = part * (TV / 4) + cc;
+      const T t = Ts[lane * TVS + c];
+#pragma unroll
+      for (int j = 0; j < TV_NR; j++) acc[j] += t * xs[c * TV_NR + j];
+    }
+    __syncthreads();
+  }
+  // ---- x_s = Dinv (b_s - acc)
+#pragma unroll
+  for (int j = 0; j < TV_NR; j++) red[(part * TV + lane) * TV_NR + j] = acc[j];
+  __syncthreads();
+  {
+    const int r = lane, j = part;  // (TV_NR == 4 == number of waves)
+    T v = T(0);
+    if (r < nb && j < nr) v = Bp[(rbase + r) * b0 + j];
+#pragma unroll
+    for (int q = 0; q < 4; q++) v -= red[(q * TV + r) * TV_NR + j];
+    __syncthreads();
+    xs[r * TV_NR + j] = (j < nr) ? v : T(0);
+  }
+  __syncthreads();
+  {
+    T px[TV_NR];
+#pragma unroll
+    for (int j = 0; j < TV_NR; j++) px[j] = T(0);
+#pragma unroll
+    for (int cc = 0; cc < TV / 4; cc++) {
+      const int c = part * (TV / 4) + cc;
+      const T t = Di[lane * TVS + c];
+#pragma unroll
+      for (int j = 0; j < TV_NR; j++) px[j] += t * xs[c * TV_NR + j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TV_NR; j++) red[(part * TV + lane) * TV_NR + j] = px[j];
+  }
+  __syncthreads();
+  {
+    const int r = lane, j = part;
+    if (j < nr) {
+      T v = T(0);
+#pragma unroll
+      for (int q = 0; q < 4; q++) v += red[(q * TV + r) * TV_NR + j];
+      if (r < nb) Xp[(rbase + r) * x0 + j] = v;
+      // the pair in one 16-byte write-through store
+      typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
+      const unsigned long long bits = tv_bits(v);
+      u2 pr = {bits, bits ^ TV_MAGIC};
+      u2* dst = (u2*)(box + ((long long)s * TV + r) * (TV_NR * 2) + 2 * j);
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(pr) : "memory");
+    }
+  }
+}
+
+template <class T> __global__ void nan_fill_if_kernel(T* __restrict__ out, long long count, const int* __restrict__ flag) {
+  if (*flag == 0) return;
+  const T nanv = (T)__builtin_nan("");
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long long)gridDim.x * blockDim.x) out[e] = nanv;
+}
+
+// one matrix, nrhs <= 16: chunks of TV_NR right-hand sides, one persistent launch each
+template <class T>
+int trsv_dag(int lower, int unit, long long n, long long nrhs, const T* Tm, long long sT0, long long sT1, const T* B, T* out) {
+  hipStream_t st = pthip::ctx().stream;
+  const int nB = (int)((n + TV - 1) / TV);
+  const int nchunk = (int)((nrhs + TV_NR - 1) / TV_NR);
+  const size_t boxbytes = (size_t)nB * TV * TV_NR * 2 * sizeof(unsigned long long);
+  void* scratch = nullptr;
+  int r = pthip_alloc(boxbytes * nchunk + 256, &scratch);
+  if (r) return r;
+  auto fail = [&](int rc) { pthip_free(scratch); return rc; };
+  int* flags = (int*)((char*)scratch + boxbytes * nchunk);
+  auto kk = trsv_dag_kernel<T>;
+  const size_t lds = (size_t)(2 * TV * TVS + TV * TV_NR + 4 * TV * TV_NR) * sizeof(T);
+  static int resident = 0;
+  if (!resident) {
+    if (lds > 64 * 1024)
+      if (hipError_t e = hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess)
+        return fail(pthip::check(e, "trsv_dag attribute"));
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kk, BLOCK, lds); e != hipSuccess)
+      return fail(pthip::check(e, "trsv_dag occupancy"));
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return fail(pthip::check(e, "trsv_dag device"));
+    if (hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess)
+      return fail(pthip::check(e, "trsv_dag device attribute"));
+    resident = per_cu * cus;
+  }
+  if (nB > resident) return fail(pthip::set_error("pthip_trsm: %d row blocks exceed the %d resident workgroups of the device", nB, resident));
+  if (hipError_t e = pthip::memset_async(scratch, 0, boxbytes * nchunk + 256, st); e != hipSuccess) return fail(pthip::check(e, "trsv box memset"));
+  // solve coordinates: p = lower ? i : n-1-i
+  const long long sg = lower ? 1 : -1;
+  const T* Tp = lower ? Tm : Tm + (n - 1) * (sT0 + sT1);
+  const T* Bp = lower ? B : B + (n - 1) * nrhs;
+  T* Xp = lower ? out : out + (n - 1) * nrhs;
+  for (int c = 0; c < nchunk; c++) {
+    const int nr = (int)((nrhs - (long long)c * TV_NR) < TV_NR ? (nrhs - (long long)c * TV_NR) : TV_NR);
+    PTHIP_KLAUNCH(kk, dim3((unsigned)nB), dim3(BLOCK), lds, st, Xp + (long long)c * TV_NR, sg * nrhs, Tp, sg * sT0, sg * sT1,
+                  Bp + (long long)c * TV_NR, sg * nrhs, (int)n, nr, unit,
+                  (unsigned long long*)((char*)scratch + boxbytes * c), flags, flags + 1, pthip::ctx().status_dev);
+    if ((r = pthip::post_launch("trsv_dag"))) return fail(r);
+  }
+  PTHIP_KLAUNCH((nan_fill_if_kernel<T>), dim3(256), dim3(BLOCK), 0, st, out, n * nrhs, (const int*)flags);
+  r = pthip::post_launch("trsm nan fill");
+  pthip_free(scratch);
+  return r;
+}
+
+// one matrix, many right-hand sides: 128-row steps, diagonal block in LDS + one GEMM for the rows to come
+template <class T>
+int trsm_blocked(int lower, int unit, long long n, long long nrhs, const T* Tm, long long sT0, long long sT1, const T* B, T* out) {
+  hipStream_t st = pthip::ctx().stream;
+  constexpr long long NBT = 128;
+  const int dt = sizeof(T) == 8 ? PTHIP_F64 : PTHIP_F32;
+  void* scratch = nullptr;
+  int r = pthip_alloc(256, &scratch);
+  if (r) return r;
+  auto fail = [&](int rc) { pthip_free(scratch); return rc; };
+  int* flag = (int*)scratch;
+  if (hipError_t e = pthip::memset_async(flag, 0, 256, st); e != hipSuccess) return fail(pthip::check(e, "trsm flag memset"));
+  if (hipError_t e = pthip::memcpy_async(out, B, (size_t)n * nrhs * sizeof(T), hipMemcpyDeviceToDevice, st); e != hipSuccess)
+    return fail(pthip::check(e, "trsm rhs copy"));
+  auto kl = trsm_lds_kernel<T>;
+  const size_t need = (size_t)NBT * (size_t)(NBT | 1) * sizeof(T);
+  static bool attr = false;
+  if (!attr && need > 64 * 1024) {
+    if (hipError_t e = hipFuncSetAttribute((const void*)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need); e != hipSuccess)
+      return fail(pthip::check(e, "trsm_lds attribute"));
+    attr = true;
+  }
+  const unsigned gx = (unsigned)((nrhs + BLOCK - 1) / BLOCK);
+  if (lower) {
+    for (long long k0 = 0; k0 < n; k0 += NBT) {
+      const long long nb = (n - k0) < NBT ? (n - k0) : NBT;
+      T* Xk = out + k0 * nrhs;
+      PTHIP_KLAUNCH(kl, dim3(gx, 1), dim3(BLOCK), (size_t)nb * (size_t)(nb | 1) * sizeof(T), st, Xk, Tm + k0 * (sT0 + sT1), 0LL, sT0, sT1,
+                    (const T*)Xk, 0LL, (int)nb, (int)nrhs, 1, unit, flag);
+      if ((r = pthip::post_launch("trsm diag"))) return fail(r);
+      const long long rest = n - k0 - nb;
+      if (rest > 0) {
+        r = pthip::gemm_inplace(dt, rest, nrhs, nb, -1.0, Tm + (k0 + nb) * sT0 + k0 * sT1, sT0, sT1, Xk, nrhs, 1, 1.0, out + (k0 + nb) * nrhs, nrhs);
+        if (r) return fail(r);
+      }
+    }
+  } else {
+    for (long long kend = n; kend > 0;) {
+      const long long k0 = (kend - NBT) > 0 ? (kend - NBT) : 0, nb = kend - k0;
+      T* Xk = out + k0 * nrhs;
+      PTHIP_KLAUNCH(kl, dim3(gx, 1), dim3(BLOCK), (size_t)nb * (size_t)(nb | 1) * sizeof(T), st, Xk, Tm + k0 * (sT0 + sT1), 0LL, sT0, sT1,
+                    (const T*)Xk, 0LL, (int)nb, (int)nrhs, 0, unit, flag);
+      if ((r = pthip::post_launch("trsm diag"))) return fail(r);
+      if (k0 > 0) {
+        r = pthip::gemm_inplace(dt, k0, nrhs, nb, -1.0, Tm + k0 * sT1, sT0, sT1, Xk, nrhs, 1, 1.0, out, nrhs);
+        if (r) return fail(r);
+      }
+      kend = k0;
+    }
+  }
+  PTHIP_KLAUNCH((nan_fill_if_kernel<T>), dim3(256), dim3(BLOCK), 0, st, out, n * nrhs, (const int*)flag);
+  r = pthip::post_launch("trsm nan fill");
+  pthip_free(scratch);
+  return r;
+}
+
 template <class T>
 int trsm_typed(int lower, int unit, long long batch, long long n, long long nrhs, const void* Tm,
                long long sTb, long long sT0, long long sT1, const void* B, long long sBb,
@@ -1515,9 +1865,22 @@ int trsm_typed(int lower, int unit, long long batch, long long n, long long nrhs
       if (need > 64 * 1024)
         PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
       PTHIP_KLAUNCH(k, dim3((unsigned)((nrhs + BLOCK - 1) / BLOCK), (unsigned)batch), dim3(BLOCK), need,
-                         st, (T*)out, (const T*)Tm, sTb, sT0, sT1, (const T*)B, sBb, (int)n, (int)nrhs, lower, unit);
+                         st, (T*)out, (const T*)Tm, sTb, sT0, sT1, (const T*)B, sBb, (int)n, (int)nrhs, lower, unit, (int*)nullptr);
       return pthip::post_launch("trsm_lds");
     }
+  }
+  static const bool generic = getenv("PTHIP_TRSM") && !strcmp(getenv("PTHIP_TRSM"), "generic");
+  if (!generic) {
+    // beyond the LDS: the persistent row-block solve for a few right-hand sides, blocked GEMM updates for many
+    for (long long b = 0; b < batch; b++) {
+      const T* Tb = (const T*)Tm + b * sTb;
+      const T* Bb = (const T*)B + b * sBb;
+      T* Ob = (T*)out + b * n * nrhs;
+      const int r = nrhs <= 16 ? trsv_dag<T>(lower, unit, n, nrhs, Tb, sT0, sT1, Bb, Ob)
+                               : trsm_blocked<T>(lower, unit, n, nrhs, Tb, sT0, sT1, Bb, Ob);
+      if (r) return r;
+    }
+    return 0;
   }
   PTHIP_KLAUNCH((trsm_kernel<T>), dim3((unsigned)((nrhs + BLOCK - 1) / BLOCK), (unsigned)batch),
                      dim3(BLOCK), 0, st, (T*)out, (const T*)Tm, sTb, sT0, sT1, (const T*)B, sBb,
