@@ -1719,7 +1719,8 @@ __global__ __launch_bounds__(BLOCK) void trsv_dag_kernel(T* __restrict__ Xp, lon
       const unsigned long long bits = tv_bits(v);
       u2 pr = {bits, bits ^ TV_MAGIC};
       u2* dst = (u2*)(box + ((long long)s * TV + r) * (TV_NR * 2) + 2 * j);
-      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(pr) : "memory");
+      // (s_nop: the store reads its upper data dwords after issue — the hazard the compiler pads for its own stores)
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 2" : : "v"(dst), "v"(pr) : "memory");
     }
   }
 }

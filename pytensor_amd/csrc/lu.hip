@@ -17,6 +17,9 @@
 // perm[i] of A), its sign (0 when singular) and log|det|.
 #include "common.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace {
 
 constexpr int BLOCK = 256;
@@ -312,6 +315,341 @@ int launch_getrf_reg(long long batch, long long n, const void* A, void* LU, void
   return r;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// n > 140: blocked right-looking LU with partial pivoting over the working matrix W (= the output,
+// row-major), LB-column panels.  Per panel: (1) lu_panel_kernel factors the (n - k0) x LB panel —
+// one ROW per thread, the row's LB entries in registers, ceil(rows / 256) workgroups resident at once.
+// Per column every workgroup finds its best row (first maximum, like idamax) and publishes
+// {|value|, row, the row's LB entries} as self-validating 16-byte pairs (see linalg.hip, trsv_dag_kernel:
+// no fence per hop); all workgroups read all candidates, agree on the pivot, and already hold the pivot
+// row for the rank-1 update: ONE memory round trip per column.  The owner of row k also publishes its
+// row, which the owner of the pivot row takes in exchange.  (2) lu_laswp_kernel applies the panel's
+// interchanges to the columns left and right of it, (3) lu_u12_kernel solves L11 U12 = A12 (L11 in LDS,
+// one thread per column), (4) the trailing matrix takes A22 -= L21 U12 on the MFMA GEMM (gemm.hip, in
+// place).  lu_finish_kernel turns the interchanges into the gather vector, its sign, and log|det|.
+// A zero pivot: no scaling, elimination continues (dgetf2), sign 0 / log|det| -inf.
+// ------------------------------------------------------------------------------------------
+constexpr int LB = 32;  // panel width
+constexpr unsigned long long LU_MAGIC = 0x7ff4c0de5ea1ed02ull;
+constexpr int LU_SPIN_LIMIT = 1 << 22;
+
+__device__ __forceinline__ unsigned long long lu_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
+__device__ __forceinline__ unsigned long long lu_bits(float v) { return (unsigned long long)__float_as_uint(v); }
+__device__ __forceinline__ void lu_from_bits(unsigned long long b, double& v) { v = __longlong_as_double((long long)b); }
+__device__ __forceinline__ void lu_from_bits(unsigned long long b, float& v) { v = __uint_as_float((unsigned)b); }
+
+// {bits, bits ^ MAGIC} in one 16-byte write-through store; a reader accepts the pair only when the two
+// halves match (a torn or not-yet-written pair over the zeroed array fails unless it equals the final one)
+__device__ __forceinline__ void lu_publish(unsigned long long* slot, unsigned long long bits) {
+  typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
+  u2 pr = {bits, bits ^ LU_MAGIC};
+  // (s_nop: a store of more than 8 bytes reads its upper data dwords after issue; the compiler pads its own
+  //  stores against a following VALU write of those registers, but cannot see into this one)
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 2" : : "v"((u2*)slot), "v"(pr) : "memory");
+}
+__device__ __forceinline__ bool lu_poll(const unsigned long long* slot, unsigned long long& bits) {
+  bits = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (bits ^ b) == LU_MAGIC;
+}
+
+template <class T>
+__device__ __forceinline__ void wave_argmax(T& v, int& key) {  // result valid in lane 63
+  argmax_step<T, 0x111, 0xf>(v, key);
+  argmax_step<T, 0x112, 0xf>(v, key);
+  argmax_step<T, 0x114, 0xf>(v, key);
+  argmax_step<T, 0x118, 0xf>(v, key);
+  argmax_step<T, 0x142, 0xa>(v, key);
+  argmax_step<T, 0x143, 0xc>(v, key);
+}
+
+template <class F, int... Js>
+__device__ __forceinline__ bool lu_for_each_column(F&& f, std::integer_sequence<int, Js...>) {
+  return (f(std::integral_constant<int, Js>{}) && ...);
+}
+
+template <class T>
+__global__ __launch_bounds__(BLOCK) void lu_panel_kernel(T* __restrict__ W, long long ld, int n, int k0, int nW,
+                                                        unsigned long long* __restrict__ box,
+                                                        unsigned long long* __restrict__ boxk, int* __restrict__ ipiv,
+                                                        int* __restrict__ info, int* __restrict__ abortflag,
+                                                        int* __restrict__ status) {
+  __shared__ T s_val[BLOCK / 64];
+  __shared__ int s_row[BLOCK / 64];
+  __shared__ T s_u[LB], s_rk[LB];
+  __shared__ int s_p, s_ok;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, w = blockIdx.x;
+  const int pw = (n - k0) < LB ? (n - k0) : LB;
+  const long long grow = (long long)k0 + (long long)w * BLOCK + tid;  // this thread's row
+  const bool have = grow < n;
+  T a[LB];
+#pragma unroll
+  for (int c = 0; c < LB; c++) a[c] = (have && c < pw) ? W[grow * ld + k0 + c] : T(0);
+  // (the column index must be a compile-time constant: a[] lives in registers; the loop over the LB
+  //  columns is too large for the unroller, so it is spelled as a fold over an index sequence)
+  auto column = [&](auto jc) -> bool {
+    constexpr int j = decltype(jc)::value;
+    if (j < pw) {  // (uniform: the last panel may be narrower)
+    const int k = k0 + j;
+    // ---- this workgroup's candidate: largest |a_ik| among its rows i >= k, first such row
+    T v = (have && grow >= k) ? dev_abs(a[j]) : T(-1);
+    int key = (have && grow >= k) ? (int)grow : 0x7fffffff;
+    wave_argmax<T>(v, key);
+    if (lane == 63) { s_val[wid] = v; s_row[wid] = key; }
+    __syncthreads();
+    T bv = s_val[0];
+    int br = s_row[0];
+#pragma unroll
+    for (int q = 1; q < BLOCK / 64; q++)
+      if (s_val[q] > bv || (s_val[q] == bv && s_row[q] < br)) { bv = s_val[q]; br = s_row[q]; }
+    const bool mine = have && grow == br;
+    if (nW > 1) {
+      if (mine) {
+        unsigned long long* rec = box + ((long long)(j * nW + w) * (LB + 2)) * 2;
+        lu_publish(rec, lu_bits(bv));
+        lu_publish(rec + 2, (unsigned long long)br);
+#pragma unroll
+        for (int c = 0; c < LB; c++) lu_publish(rec + (2 + c) * 2, lu_bits(a[c]));
+      }
+      if (have && grow == k) {
+#pragma unroll
+        for (int c = 0; c < LB; c++) lu_publish(boxk + ((long long)j * LB + c) * 2, lu_bits(a[c]));
+      }
+      if (wid == 0) {
+        // all candidates -> the pivot (largest value, then smallest row: the first maximum in row order)
+        T cv = T(-1);
+        int cr = 0x7fffffff;
+        int spins = 0;
+        bool ok = true;
+        for (int base = 0; base < nW && ok; base += 64) {
+          const int cand = base + lane;
+          const unsigned long long* rec = box + ((long long)(j * nW + (cand < nW ? cand : 0)) * (LB + 2)) * 2;
+          unsigned long long vb = 0, rb = 0;
+          for (;;) {
+            const bool got = cand >= nW || (lu_poll(rec, vb) && lu_poll(rec + 2, rb));
+            if (__builtin_amdgcn_ballot_w64(!got) == 0ull) break;
+            if (++spins > LU_SPIN_LIMIT || ((spins & 255) == 0 && __hip_atomic_load(abortflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          if (ok && cand < nW) {
+            T x;
+            lu_from_bits(vb, x);
+            const int r = (int)rb;
+            if (x > cv || (x == cv && r < cr)) { cv = x; cr = r; }
+          }
+        }
+        wave_argmax<T>(cv, cr);
+        const int p = __builtin_amdgcn_readlane(cr, 63);
+        const int wstar = ok ? (p - k0) / BLOCK : 0;
+        if (ok && lane < LB) {
+          const unsigned long long* rec = box + ((long long)(j * nW + wstar) * (LB + 2)) * 2 + (2 + lane) * 2;
+          const unsigned long long* rk = boxk + ((long long)j * LB + lane) * 2;
+          unsigned long long ub = 0, kb = 0;
+          bool got = false;
+          for (;;) {
+            got = lu_poll(rec, ub) && lu_poll(rk, kb);
+            if (got) break;
+            if (++spins > LU_SPIN_LIMIT) break;
+            __builtin_amdgcn_s_sleep(1);
+          }
+          T x, y;
+          lu_from_bits(ub, x);
+          lu_from_bits(kb, y);
+          s_u[lane] = x;
+          s_rk[lane] = y;
+          if (!got) ok = false;
+        }
+        const bool allok = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+        if (lane == 0) { s_p = p; s_ok = allok; }
+      }
+      __syncthreads();
+      if (!s_ok) {
+        if (tid == 0) { atomicOr(status, 16); __hip_atomic_store(abortflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        return false;
+      }
+    } else {
+      if (mine) {
+#pragma unroll
+        for (int c = 0; c < LB; c++) s_u[c] = a[c];
+        s_p = br;
+      }
+      if (have && grow == k) {
+#pragma unroll
+        for (int c = 0; c < LB; c++) s_rk[c] = a[c];
+      }
+      __syncthreads();
+    }
+    const int p = s_p;
+    // ---- the interchange k <-> p inside the panel
+    if (p != k && have) {
+      if (grow == p) {
+#pragma unroll
+        for (int c = 0; c < LB; c++) a[c] = s_rk[c];
+      } else if (grow == k) {
+#pragma unroll
+        for (int c = 0; c < LB; c++) a[c] = s_u[c];
+      }
+    }
+    if (w == 0 && tid == 0) ipiv[k] = p;
+    // ---- scale by the reciprocal pivot (dgetf2), rank-1 update of the panel's later columns
+    const T piv = s_u[j];
+    if (piv == T(0) && w == 0 && tid == 0) atomicOr(info, 1);
+    const T rp = piv == T(0) ? T(1) : T(1) / piv;
+    if (have && grow > k) {
+      const T l = a[j] * rp;
+      a[j] = l;
+#pragma unroll
+      for (int c = j + 1; c < LB; c++) a[c] -= l * s_u[c];
+    }
+    __syncthreads();
+  
+    }
+    return true;
+  };
+  if (!lu_for_each_column(column, std::make_integer_sequence<int, LB>{})) return;
+  if (have) {
+#pragma unroll
+    for (int c = 0; c < LB; c++)
+      if (c < pw) W[grow * ld + k0 + c] = a[c];
+  }
+}
+
+// the interchanges of panel [k0, k0 + pw) applied to the columns outside it: one thread per column
+template <class T>
+__global__ __launch_bounds__(BLOCK) void lu_laswp_kernel(T* __restrict__ W, long long ld, int n, int k0, int pw,
+                                                        const int* __restrict__ ipiv) {
+  int c = blockIdx.x * BLOCK + threadIdx.x;
+  if (c >= n - pw) return;
+  if (c >= k0) c += pw;
+  for (int j = 0; j < pw; j++) {
+    const int k = k0 + j, p = ipiv[k];
+    if (p != k) {
+      const T t = W[(long long)k * ld + c];
+      W[(long long)k * ld + c] = W[(long long)p * ld + c];
+      W[(long long)p * ld + c] = t;
+    }
+  }
+}
+
+// U12 = L11^-1 A12 (L11 unit lower, pw x pw, in LDS): one thread per column right of the panel, its
+// column of the solution in LDS as well (a register-resident column unrolls into 496 hoisted LDS loads
+// and spills)
+template <class T>
+__global__ __launch_bounds__(BLOCK) void lu_u12_kernel(T* __restrict__ W, long long ld, int n, int k0, int pw) {
+  __shared__ T Ls[LB][LB + 1];
+  __shared__ T xs[LB][BLOCK];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < LB * LB; e += BLOCK) {
+    const int r = e / LB, q = e - r * LB;
+    Ls[r][q] = (r < pw && q < r) ? W[(long long)(k0 + r) * ld + k0 + q] : T(0);
+  }
+  const long long c = (long long)k0 + pw + (long long)blockIdx.x * BLOCK + tid;
+  const bool have = c < n;
+  for (int r = 0; r < pw; r++) xs[r][tid] = have ? W[(long long)(k0 + r) * ld + c] : T(0);
+  __syncthreads();
+  for (int r = 1; r < pw; r++) {
+    T sacc = xs[r][tid];
+    for (int q = 0; q < r; q++) sacc -= Ls[r][q] * xs[q][tid];
+    xs[r][tid] = sacc;
+  }
+  if (have)
+    for (int r = 1; r < pw; r++) W[(long long)(k0 + r) * ld + c] = xs[r][tid];
+}
+
+// gather vector from the interchanges (p = arange(n); for k: swap(p[k], p[ipiv[k]])), sign, log|det|
+template <class T>
+__global__ __launch_bounds__(BLOCK) void lu_finish_kernel(const T* __restrict__ W, long long ld, int n,
+                                                         const int* __restrict__ ipiv, const int* __restrict__ info,
+                                                         long long* __restrict__ perm_out, T* __restrict__ sign_out,
+                                                         T* __restrict__ logabs_out, int* __restrict__ status) {
+  extern __shared__ int sm_p[];
+  __shared__ T s_sum[BLOCK / 64];
+  __shared__ int s_neg[BLOCK / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  for (int i = tid; i < n; i += BLOCK) sm_p[i] = i;
+  T la = T(0);
+  int neg = 0;
+  for (int i = tid; i < n; i += BLOCK) {
+    const T d = W[(long long)i * ld + i];
+    neg += d < T(0);
+    la += log(dev_abs(d));
+    neg += ipiv[i] != i;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { la += __shfl_xor(la, o); neg += __shfl_xor(neg, o); }
+  if (lane == 0) { s_sum[wid] = la; s_neg[wid] = neg; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int k = 0; k < n; k++) {
+      const int p = ipiv[k];
+      const int t = sm_p[k]; sm_p[k] = sm_p[p]; sm_p[p] = t;
+    }
+    la = T(0); neg = 0;
+    for (int q = 0; q < BLOCK / 64; q++) { la += s_sum[q]; neg += s_neg[q]; }
+    T sg = (neg & 1) ? T(-1) : T(1);
+    if (*info) { sg = T(0); la = -__builtin_huge_val(); if (status != nullptr) atomicOr(status, 2); }
+    sign_out[0] = sg;
+    logabs_out[0] = la;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += BLOCK) perm_out[i] = sm_p[i];
+}
+
+template <class T>
+int getrf_blocked(long long n, const T* A, T* LU, long long* perm, T* sign, T* logabs, int flag_singular) {
+  hipStream_t st = pthip::ctx().stream;
+  const int dt = sizeof(T) == 8 ? PTHIP_F64 : PTHIP_F32;
+  const int nWmax = (int)((n + BLOCK - 1) / BLOCK);
+  const size_t boxbytes = (size_t)LB * nWmax * (LB + 2) * 16, boxkbytes = (size_t)LB * LB * 16;
+  const size_t ibytes = ((size_t)n * sizeof(int) + 255) / 256 * 256;
+  void* scratch = nullptr;
+  int r = pthip_alloc(boxbytes + boxkbytes + ibytes + 256, &scratch);
+  if (r) return r;
+  auto fail = [&](int rc) { pthip_free(scratch); return rc; };
+  unsigned long long* box = (unsigned long long*)scratch;
+  unsigned long long* boxk = (unsigned long long*)((char*)scratch + boxbytes);
+  int* ipiv = (int*)((char*)scratch + boxbytes + boxkbytes);
+  int* flags = (int*)((char*)scratch + boxbytes + boxkbytes + ibytes);  // [0] info, [1] abort
+  if (hipError_t e = pthip::memset_async(flags, 0, 256, st); e != hipSuccess) return fail(pthip::check(e, "lu flags memset"));
+  if (hipError_t e = pthip::memcpy_async(LU, A, (size_t)n * n * sizeof(T), hipMemcpyDeviceToDevice, st); e != hipSuccess)
+    return fail(pthip::check(e, "lu copy"));
+  for (long long k0 = 0; k0 < n; k0 += LB) {
+    const int pw = (int)((n - k0) < LB ? (n - k0) : LB);
+    const int nW = (int)((n - k0 + BLOCK - 1) / BLOCK);
+    if (nW > 1)
+      if (hipError_t e = pthip::memset_async(box, 0, boxbytes + boxkbytes, st); e != hipSuccess) return fail(pthip::check(e, "lu box memset"));
+    PTHIP_KLAUNCH((lu_panel_kernel<T>), dim3((unsigned)nW), dim3(BLOCK), 0, st, LU, n, (int)n, (int)k0, nW, box, boxk, ipiv, flags, flags + 1,
+                  pthip::ctx().status_dev);
+    if ((r = pthip::post_launch("lu_panel"))) return fail(r);
+    if (n - pw > 0) {
+      PTHIP_KLAUNCH((lu_laswp_kernel<T>), dim3((unsigned)((n - pw + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, LU, n, (int)n, (int)k0, pw, (const int*)ipiv);
+      if ((r = pthip::post_launch("lu_laswp"))) return fail(r);
+    }
+    const long long rest = n - k0 - pw;
+    if (rest > 0) {
+      PTHIP_KLAUNCH((lu_u12_kernel<T>), dim3((unsigned)((rest + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, LU, n, (int)n, (int)k0, pw);
+      if ((r = pthip::post_launch("lu_u12"))) return fail(r);
+      r = pthip::gemm_inplace(dt, rest, rest, pw, -1.0, LU + (k0 + pw) * n + k0, n, 1, LU + k0 * n + k0 + pw, n, 1, 1.0,
+                              LU + (k0 + pw) * n + k0 + pw, n);
+      if (r) return fail(r);
+    }
+  }
+  auto kf = lu_finish_kernel<T>;
+  const size_t sh = (size_t)n * sizeof(int);
+  static bool attr = false;
+  if (!attr && sh > 48 * 1024) {
+    if (hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); e != hipSuccess)
+      return fail(pthip::check(e, "lu_finish attribute"));
+    attr = true;
+  }
+  PTHIP_KLAUNCH(kf, dim3(1), dim3(BLOCK), sh, st, (const T*)LU, n, (int)n, (const int*)ipiv, (const int*)flags, perm, sign, logabs,
+                flag_singular ? pthip::ctx().status_dev : (int*)nullptr);
+  r = pthip::post_launch("lu_finish");
+  pthip_free(scratch);
+  return r;
+}
+
 template <class T>
 int getrf_typed(long long batch, long long n, const void* A, void* LU, void* perm, void* sign,
                 void* logabs, int flag_singular) {
@@ -323,25 +661,33 @@ int getrf_typed(long long batch, long long n, const void* A, void* LU, void* per
     if (n <= 64) return launch_getrf_reg<T, 4>(batch, n, A, LU, perm, sign, logabs, flag_singular);
     return launch_getrf_reg<T, 8>(batch, n, A, LU, perm, sign, logabs, flag_singular);
   }
-  if (n > 512) return pthip::set_error("pthip_getrf: n = %lld > 512 is not supported yet", n);
   hipStream_t st = pthip::ctx().stream;
   const size_t need = (size_t)n * (size_t)(n | 1) * sizeof(T);
-  const bool lds = need <= 160 * 1024 - 8192;
-  auto k = getrf_kernel<T>;
-  void* scratch = nullptr;
-  if (lds) {
-    if (need > 48 * 1024)
-      PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-  } else {
-    int r = pthip_alloc((size_t)batch * n * n * sizeof(T), &scratch);
+  static const bool unblocked = getenv("PTHIP_LU_UNBLOCKED") != nullptr;
+  if (need <= 160 * 1024 - 8192 || (unblocked && n <= 512)) {
+    const bool lds = need <= 160 * 1024 - 8192;
+    auto k = getrf_kernel<T>;
+    void* scratch = nullptr;
+    if (lds) {
+      if (need > 48 * 1024)
+        PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+    } else {
+      int r = pthip_alloc((size_t)batch * n * n * sizeof(T), &scratch);
+      if (r) return r;
+    }
+    PTHIP_KLAUNCH(k, dim3((unsigned)batch), dim3(BLOCK), lds ? need : 0, st, (T*)LU, (const T*)A,
+                       (long long*)perm, (T*)sign, (T*)logabs, (int)n, lds ? 1 : 0, (T*)scratch,
+                       flag_singular ? (int*)pthip_status_ptr() : (int*)nullptr);
+    int r = pthip::post_launch("getrf");
+    if (scratch) pthip_free(scratch);  // stream-ordered reuse keeps this safe
+    return r;
+  }
+  // beyond one CU's LDS: the blocked factorisation, one matrix after the other
+  for (long long b = 0; b < batch; b++) {
+    int r = getrf_blocked<T>(n, (const T*)A + b * n * n, (T*)LU + b * n * n, (long long*)perm + b * n, (T*)sign + b, (T*)logabs + b, flag_singular);
     if (r) return r;
   }
-  PTHIP_KLAUNCH(k, dim3((unsigned)batch), dim3(BLOCK), lds ? need : 0, st, (T*)LU, (const T*)A,
-                     (long long*)perm, (T*)sign, (T*)logabs, (int)n, lds ? 1 : 0, (T*)scratch,
-                     flag_singular ? (int*)pthip_status_ptr() : (int*)nullptr);
-  int r = pthip::post_launch("getrf");
-  if (scratch) pthip_free(scratch);  // stream-ordered reuse keeps this safe
-  return r;
+  return 0;
 }
 
 // P * I for the inverse: row i of the result is the unit vector e_perm[i]
