@@ -211,8 +211,8 @@ def raise_device_status(word: int):
     """The device error word (kernels cannot raise): bit 0 = an index was out of range
     (IndexError, like the reference's take/inc_subtensor), bit 1 = np.linalg.inv met an exactly
     singular matrix (LinAlgError), bit 2 / bit 3 = the Jacobi SVD / eigensolver did not converge
-    (LinAlgError, the messages of np.linalg.svd / eigh), bit 4 = a bounded dependency wait of the
-    task-graph Cholesky expired (RuntimeError)."""
+    (LinAlgError, the messages of np.linalg.svd / eigh), bit 4 = a bounded dependency wait of a
+    persistent linear-algebra kernel expired (RuntimeError)."""
     if word & 2:
         raise np.linalg.LinAlgError("Singular matrix")
     if word & 4:
@@ -221,9 +221,9 @@ def raise_device_status(word: int):
         raise np.linalg.LinAlgError("Eigenvalues did not converge")
     if word & 16:
         raise RuntimeError(
-            "hip linker: the task-graph Cholesky gave up waiting for a tile (its workgroups were not all "
-            "resident — another kernel holding compute units on a second stream?); PTHIP_CHOL=steps selects "
-            "the launch-per-step factorisation"
+            "hip linker: a persistent linear-algebra kernel (Cholesky / triangular solve / LU panel) gave up "
+            "waiting for another workgroup (not all of its workgroups were resident — another kernel holding "
+            "compute units on a second stream?); PTHIP_CHOL=steps / PTHIP_TRSM=generic select the launch-per-step forms"
         )
     if word & 1:
         raise IndexError("index out of bounds (device-side check)")
