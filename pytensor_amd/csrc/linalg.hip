@@ -217,78 +217,74 @@ __device__ __forceinline__ void wave_trsv(const T* __restrict__ W, int ld, int n
 }
 
 // The factorisation proper on a lower-triangular working matrix W[i * ld + j] (i >= j) resident in
-// LDS, by all BLOCK threads of the workgroup (shared by the kernel below and by the diagonal tasks of
-// chol_dag_kernel).  Ends on a workgroup barrier; returns this thread's view of "a pivot failed"
-// (identical in every wave: all of them factor the diagonal blocks redundantly).
+// LDS, by all BLOCK threads of the workgroup.  Ends on a workgroup barrier; returns "a pivot failed" as
+// seen by this thread (every wave that takes part sees the same pivots).
+// Per 16-column panel: (a) the elimination, one dependent chain per wave with NO barrier inside — lanes
+// 0-15 of every wave hold the 16 diagonal rows (redundantly: each wave needs the pivots and the u_ck
+// itself), lanes 16-63 hold 48 of the rows below, so the scaling of column k is at once the factorisation
+// step and the panel solve; square-root-free (pivot by v_readlane, v_rcp + two Newton steps; columns scaled
+// by 1/sqrt(pivot) afterwards), the next column's u_ck by v_readlane before the reciprocal is known, the
+// others through a per-wave LDS column (see potrf64_wave below, the same chain: 2.0-2.4 us per panel
+// against 4 us for the register factorisation + one-thread-per-row solve it replaces).  (b) the trailing
+// update on the matrix cores.
 template <class T>
 __device__ __forceinline__ bool potrf_lds_core(T* __restrict__ W, const int ld, const int n) {
-  const int tid = threadIdx.x, lane = tid & 63;
+  __shared__ T s_pcol[BLOCK / 64][64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  T* colbuf = s_pcol[wv];
   bool fail = false;
   for (int j0 = 0; j0 < n; j0 += NB) {
     const int jb = (n - j0) < NB ? (n - j0) : NB;
-    // ---- (a) diagonal block in registers: lane r (< NB) of EVERY wave holds row j0+r ----
-    T d[NB], rdiag[NB];
-    {
-      const int r = lane < NB ? lane : NB - 1;
-      const int row = (j0 + r) < n ? (j0 + r) : (n - 1);
-#pragma unroll
-      for (int c = 0; c < NB; c++) d[c] = (c < jb && c <= r) ? W[row * ld + j0 + c] : T(0);
-    }
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-      if (k < jb) {
-        const T akk = bcast_lane(d[k], k);
-        if (!(akk > T(0))) fail = true;  // dpotf2: non-positive or NaN pivot (wave-uniform)
-        // one wave-uniform reciprocal square root per column (dpotf2 itself scales the
-        // column by 1/ajj via dscal); piv = akk * rsqrt(akk) is within 2 ulp of sqrt(akk)
-        rdiag[k] = rsqrt(akk);
-        const T piv = akk * rdiag[k];
-        // column k: rows > k scaled, row k gets the pivot
-        d[k] = (lane == k) ? piv : d[k] * rdiag[k];
-        // a[r][c] -= a[r][k] * a[c][k] ; a[c][k] lives in lane c.  All broadcasts first (distinct
-        // SGPR pairs), then the FMAs: interleaved, every v_readlane -> v_fma pair pays the
-        // VALU-writes-SGPR wait states and reuses one SGPR pair serially
-        T ack[NB];
-#pragma unroll
-        for (int c = k + 1; c < NB; c++) ack[c] = bcast_lane(d[k], c);
-#pragma unroll
-        for (int c = k + 1; c < NB; c++) d[c] -= d[k] * ack[c];
-      }
-    }
-    // (rows r < k were also "updated" above; only the lower triangle c <= r is meaningful)
     const int m = n - j0 - jb;  // rows below the panel
-    // ---- (b) panel solve: thread t owns row i = j0+jb+t; x = a L11^-T ----
-    for (int t = tid; t < m; t += BLOCK) {
-      // (m <= 112 < BLOCK at n = 128: a single pass, threads of all four waves busy)
-      const int i = j0 + jb + t;
-      T x[NB];
+    {
+      const int below = 48 * wv + lane - NB;
+      const bool diagl = lane < NB;
+      const bool live = diagl ? (lane < jb) : (below < m);
+      int row = diagl ? (j0 + lane) : (j0 + jb + below);
+      row = row < n ? row : n - 1;
+      if (wv == 0 || 48 * wv < m) {  // (wave-uniform: this wave has rows of the panel)
+        T d[NB];
 #pragma unroll
-      for (int c = 0; c < NB; c++) x[c] = (c < jb) ? W[i * ld + j0 + c] : T(0);
+        for (int c = 0; c < NB; c++) {
+          d[c] = (live && c < jb && (!diagl || c <= lane)) ? W[row * ld + j0 + c] : T(0);
+          if (diagl && !live && c == lane) d[c] = T(1);  // a short last panel continues with the identity
+        }
+        T cur[NB], lprev = T(0), pown = T(1);
 #pragma unroll
-      for (int k = 0; k < NB; k++) {
-        if (k < jb) {
-          T s = x[k];
-          T lk[NB];  // row k of L11, broadcast first (see (a))
+        for (int c = 0; c < NB; c++) cur[c] = T(0);
 #pragma unroll
-          for (int c = 0; c < k; c++) lk[c] = bcast_lane(d[c], k);
+        for (int k = 0; k < NB; k++) {
+          if (k + 2 < NB) colbuf[lane] = d[k];
+          const T pk = bcast_lane(d[k], k);
+          T u1 = T(0);
+          if (k + 1 < NB) u1 = bcast_lane(d[k], k + 1);
+          T nxt[NB];
 #pragma unroll
-          for (int c = 0; c < k; c++) s -= x[c] * lk[c];
-          x[k] = s * rdiag[k];
+          for (int c = k + 2; c < NB; c++) nxt[c] = colbuf[c];
+          if (!(pk > T(0))) fail = true;  // dpotf2: non-positive or NaN pivot (wave-uniform)
+          pown = (lane == k) ? pk : pown;
+          T r = hw_rcp(pk);
+          r = __builtin_fma(r, __builtin_fma(-pk, r, T(1)), r);
+          r = __builtin_fma(r, __builtin_fma(-pk, r, T(1)), r);
+          const T lk = d[k] * r;
+          if (k + 1 < NB) d[k + 1] -= lk * u1;
+          if (k >= 1) {
+#pragma unroll
+            for (int c = k + 1; c < NB; c++) d[c] -= lprev * cur[c];
+          }
+#pragma unroll
+          for (int c = k + 2; c < NB; c++) cur[c] = nxt[c];
+          lprev = lk;
+        }
+        colbuf[lane] = rsqrt(pown);  // lane k < 16 owns pivot k; L = (unscaled columns) * diag(1/sqrt(p))
+#pragma unroll
+        for (int c = 0; c < NB; c++) d[c] *= colbuf[c];
+        if (live && (!diagl || wv == 0)) {
+#pragma unroll
+          for (int c = 0; c < NB; c++)
+            if (c < jb && (!diagl || c <= lane)) W[row * ld + j0 + c] = d[c];
         }
       }
-#pragma unroll
-      for (int c = 0; c < NB; c++)
-        if (c < jb) W[i * ld + j0 + c] = x[c];
-    }
-    // the readlane broadcasts above must be executed by all lanes of a wave, including
-    // lanes without a row: handle waves whose lanes all have t >= m uniformly
-    // (bcast_lane is only reached inside the t-loop by waves with at least one row;
-    //  v_readlane ignores EXEC for the source lane, so partial waves are fine).
-    // wave 0 writes the factored diagonal block back
-    if (tid < NB && tid < jb) {
-#pragma unroll
-      for (int c = 0; c < NB; c++)
-        if (c <= tid) W[(j0 + tid) * ld + j0 + c] = d[c];
     }
     __syncthreads();
     // ---- (c) trailing update A22 -= X X^T on the matrix cores: one 16x16 output tile of
@@ -1471,7 +1467,7 @@ int potrf_typed(int lower, long long batch, long long n, const void* A, void* L,
     return pthip::set_error("pthip_potrf_trsv: fused solve needs the lower factor and n <= 256");
   const size_t ld = (size_t)(n | 1);
   const size_t need = (size_t)n * ld * sizeof(T);
-  if (need <= 160 * 1024 - 256) {
+  if (need <= 160 * 1024 - 2560) {  // (the kernel's static LDS: a 64-entry column per wave + flags)
     auto k = potrf_lds_kernel<T>;
     if (need > 64 * 1024)
       PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));

@@ -128,7 +128,7 @@ def cholesky_trsv(node, inputs, env):
         raise ValueError("Cholesky: matrix must be square")
     if b.shape != (n,):
         raise ValueError(f"SolveTriangular: incompatible shapes {S.shape} and {b.shape}")
-    fits = 0 < n <= 256 and n * (n | 1) * S.itemsize <= 160 * 1024 - 256 and str(b.dtype) == str(S.dtype)
+    fits = 0 < n <= 256 and n * (n | 1) * S.itemsize <= 160 * 1024 - 2560 and str(b.dtype) == str(S.dtype)
     if not fits:
         L = cholesky_device(env, S, True)
         return [L, trsm_device(env, L, b, True, False, 1)]
