@@ -889,6 +889,46 @@ __device__ __forceinline__ void dag_store_tile(T* __restrict__ Oij, long long ld
   }
 }
 
+// tile (rows i0.., columns c0..) of the diagonal tile takes the update of the 16-column panel at j0:
+// Wt[i0.., c0..] -= X[i0..] X[c0..]^T, one wave, operands and result in LDS
+template <class T>
+__device__ __forceinline__ void potrf64_tile_update(T* __restrict__ Wt, int j0, int i0, int c0) {
+  typedef typename Mfma16<T>::v4 v4;
+  const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+  v4 acc = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++)
+    acc = Mfma16<T>::run(Wt[(i0 + li) * DLS + j0 + 4 * kk + lq], Wt[(c0 + li) * DLS + j0 + 4 * kk + lq], acc);
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int i = i0 + Mfma16<T>::drow(lane, r), jx = c0 + li;
+    if (jx <= i) Wt[i * DLS + jx] -= acc[r];
+  }
+}
+
+// Waves 2 and 3 of a head task, before their write-back duty: the trailing tiles that are NOT in the
+// column block the next elimination reads — wave 2: (2,2) and (3,2) from panel 0; wave 3: (3,3) from
+// panel 0, then from panel 1 — each as soon as its panel is final (`prog`), counted in upd[wave].
+template <class T>
+__device__ __forceinline__ void potrf64_trailing_helper(T* __restrict__ Wt, volatile int* prog, volatile int* upd, int wave) {
+  const int lane = threadIdx.x & 63;
+  while (*prog <= 0) __builtin_amdgcn_s_sleep(2);
+  if (wave == 2) {
+    potrf64_tile_update<T>(Wt, 0, 32, 32);
+    potrf64_tile_update<T>(Wt, 0, 48, 32);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) upd[2] = 2;
+  } else {
+    potrf64_tile_update<T>(Wt, 0, 48, 48);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) upd[3] = 1;
+    while (*prog <= 1) __builtin_amdgcn_s_sleep(2);
+    potrf64_tile_update<T>(Wt, 16, 48, 48);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) upd[3] = 2;
+  }
+}
+
 // The 64 x 64 diagonal tile in LDS (lower triangle of Wt[r * DLS + c]) factored by ONE wave, no barriers:
 // lane r holds row j0 + r of the current 16-column panel — the 16 diagonal rows AND every row below —
 // so that scaling column k by 1/sqrt(pivot) is at once the factorisation step and the panel solve, and
@@ -897,7 +937,8 @@ __device__ __forceinline__ void dag_store_tile(T* __restrict__ Oij, long long ld
 // barriers would cost).  After each panel `*prog` advances: column block p of the factor (and, in rows
 // DT .. DT+15, the transposed inverse of diagonal block p >= 1) is final, for the waves that write back.
 template <class T>
-__device__ __forceinline__ bool potrf64_wave(T* __restrict__ Wt, T* __restrict__ colbuf, volatile int* prog, long long* tr) {
+__device__ __forceinline__ bool potrf64_wave(T* __restrict__ Wt, T* __restrict__ colbuf, volatile int* prog, volatile int* upd,
+                                             long long* tr) {
   typedef typename Mfma16<T>::v4 v4;
   const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
   bool fail = false;
@@ -964,23 +1005,13 @@ __device__ __forceinline__ bool potrf64_wave(T* __restrict__ Wt, T* __restrict__
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) *prog = p + 1;
-    // trailing tiles (ti >= tj) of the rows / columns past this panel
+    // trailing update, this wave's share: the tiles of the NEXT column block only (the one the next
+    // elimination reads); the tiles further right belong to waves 2 and 3 (potrf64_trailing_helper), whose
+    // earlier updates of the same tiles must have landed first
+    if (p == 1) while (upd[2] < 2) __builtin_amdgcn_s_sleep(1);
+    if (p == 2) while (upd[3] < 2) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-    for (int ti = 0; ti < DT / 16 - 1 - p; ti++) {
-#pragma unroll
-      for (int tj = 0; tj <= ti; tj++) {
-        const int i0 = j0 + 16 + 16 * ti, c0 = j0 + 16 + 16 * tj;
-        v4 acc = {T(0), T(0), T(0), T(0)};
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++)
-          acc = Mfma16<T>::run(Wt[(i0 + li) * DLS + j0 + 4 * kk + lq], Wt[(c0 + li) * DLS + j0 + 4 * kk + lq], acc);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int i = i0 + Mfma16<T>::drow(lane, r), jx = c0 + li;
-          if (jx <= i) Wt[i * DLS + jx] -= acc[r];
-        }
-      }
-    }
+    for (int ti = 0; ti < DT / 16 - 1 - p; ti++) potrf64_tile_update<T>(Wt, j0, j0 + 16 + 16 * ti, j0 + 16);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (p < 3) dag_stamp(tr, 10 + p);
   }
@@ -1007,7 +1038,7 @@ __global__ __launch_bounds__(BLOCK) void chol_dag_kernel(T* __restrict__ W, long
                                                         int* __restrict__ status, long long* __restrict__ trace) {
   // trace != NULL (PTHIP_CHOL_TRACE=<file>): sixteen 100 MHz timestamps per task, see tools/chol_trace.py
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __shared__ int s_box, s_prog, s_arrive[4];
+  __shared__ int s_box, s_prog, s_arrive[4], s_upd[4];
   T* As = (T*)smem_raw;     // [DT + 16][DLS]  L(ra,k); then the tile being finished (+ 16 identity rows, potrf64_wave)
   T* Bs = As + (DT + 16) * DLS;    // [DT][DLS]  L(rb,k); then the factor of the diagonal tile above
   T* Dv = Bs + DT * DLS;    // [4][16][17] inverses of the diagonal 16x16 blocks of that factor
@@ -1094,7 +1125,7 @@ __global__ __launch_bounds__(BLOCK) void chol_dag_kernel(T* __restrict__ W, long
       const int a = e >> 6, c = e & 63;
       As[(DT + a) * DLS + c] = (c >= 16 && (c & 15) == a) ? T(1) : T(0);
     }
-    if (tid < 4) { s_prog = 0; s_arrive[tid] = 0; }
+    if (tid < 4) { s_prog = 0; s_arrive[tid] = 0; s_upd[tid] = 0; }
     __syncthreads();
     DAG_STAMP(8);
     if (j > 0 && wave != 0) {
@@ -1113,7 +1144,7 @@ __global__ __launch_bounds__(BLOCK) void chol_dag_kernel(T* __restrict__ W, long
       T* Ojj = W + (long long)j * DT * ld + (long long)j * DT;
       T* Dg = Dinv + (long long)j * (4 * 16 * 16);
       if (wave == 0) {
-        const bool fail = potrf64_wave<T>(As, s_col, prog, tr);
+        const bool fail = potrf64_wave<T>(As, s_col, prog, s_upd, tr);
         if (fail && lane == 0) atomicOr(failflag, 1);
         DAG_STAMP(13);
       } else {
@@ -1140,6 +1171,7 @@ __global__ __launch_bounds__(BLOCK) void chol_dag_kernel(T* __restrict__ W, long
             for (int r = 0; r < 16; r++) dag_store<T>(Dg + r * 16 + li, x[r]);
           }
         }
+        if (wave >= 2) potrf64_trailing_helper<T>(As, prog, s_upd, wave);
         // column block b of the factor, and the inverse of diagonal block b >= 1 (rows DT.. of As hold it
         // transposed), back to memory as soon as panel b is final
         const int t2 = tid - 64;

@@ -98,9 +98,10 @@ def test_blocked_cholesky_batch_and_upper_reads_only_its_triangle(hip):
         np.testing.assert_allclose(got[b], scipy.linalg.cholesky(S[b], lower=False), rtol=1e-10, atol=1e-12)
 
 
-def test_gp_marginal_likelihood_n512_through_the_graph(hip):
-    """An ordinary PyMC-shaped graph at a size the LDS kernel cannot hold: the GP marginal
-    log-likelihood and its gradient pieces — Cholesky(512), two triangular solves with a vector —
+@pytest.mark.parametrize("n", [512, 2048])
+def test_gp_marginal_likelihood_large_through_the_graph(hip, n):
+    """An ordinary PyMC-shaped graph at sizes the LDS kernels cannot hold: the GP marginal
+    log-likelihood and its gradient pieces — Cholesky(n), two triangular solves with a vector —
     as a lowered graph against the NumPy oracle."""
     import json
     import os
@@ -114,9 +115,8 @@ def test_gp_marginal_likelihood_n512_through_the_graph(hip):
     g = Graph.from_dict(d)
     z = np.load(os.path.join(root, "tests", "golden", "gp_marginal_likelihood.npz"))
     small = [z[f"in{k}"] for k in range(len(g.inputs))]
-    # same graph, n = 512 points: inputs regenerated at that size with the fixture's own recipe
-    rng = np.random.default_rng(512)
-    n = 512
+    # same graph, n points: inputs regenerated at that size with the fixture's own recipe
+    rng = np.random.default_rng(n)
     ins = []
     for a in small:
         if a.ndim >= 1 and a.shape[0] == small[0].shape[0] and a.size > 1:
@@ -127,7 +127,7 @@ def test_gp_marginal_likelihood_n512_through_the_graph(hip):
     exe = HipExecutable(g)
     got = exe(*ins)
     for k, (a, b) in enumerate(zip(got, want)):
-        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-9 * max(1.0, float(np.max(np.abs(b)))), err_msg=f"gp n=512 out{k}")
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-9 * max(1.0, float(np.max(np.abs(b)))), err_msg=f"gp n={n} out{k}")
 
 
 def test_launch_per_step_form_still_matches(hip):
