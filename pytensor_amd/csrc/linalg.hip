@@ -1530,8 +1530,9 @@ int potrf_typed(int lower, long long batch, long long n, const void* A, void* L,
 // it already equals the final pair, so only 8-byte atomicity is assumed — which takes the release fence
 // (1.5-2 us per hop, the write-through latency) and the separate flag load off every hop.
 //
-// Many right-hand sides: blocked, launch per 128 rows — the diagonal block by trsm_lds_kernel (T in LDS,
-// one thread per column) in place, the rows still to come by one MFMA GEMM with K = 128.
+// Many right-hand sides (trsm_blocked): the inverses of all 64 x 64 diagonal blocks in one launch
+// (tri_inverse64), then per block X_b = inv(T_bb) B_b as a small MFMA GEMM and the rows still to come on
+// the MFMA GEMM in place, two levels (K = 64 inside a 256-row outer block, K = 256 beyond it).
 // A zero pivot anywhere NaN-fills the whole result, as the LDS-resident kernels do.
 // ---------------------------------------------------------------------------------
 constexpr int TV = 64;        // rows per workgroup
@@ -1806,54 +1807,95 @@ int trsv_dag(int lower, int unit, long long n, long long nrhs, const T* Tm, long
   return r;
 }
 
-// one matrix, many right-hand sides: 128-row steps, diagonal block in LDS + one GEMM for the rows to come
+// inverses of all 64 x 64 diagonal blocks of T in one launch (block b -> Tinv[b], dense 64 x 64 row-major,
+// identity beyond n): an upper triangle is inverted through its transpose (tri_inverse64 is lower-only)
+template <class T>
+__global__ __launch_bounds__(BLOCK) void tri_inv_blocks_kernel(T* __restrict__ Tinv, const T* __restrict__ Tm, long long sT0,
+                                                              long long sT1, int n, int lower, int unit,
+                                                              int* __restrict__ failflag) {
+  __shared__ T Ds[TV * TVS], Di[TV * TVS], scratch[4 * 16 * 17];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const long long rb = (long long)b * TV;
+  const int nb = (n - rb) < TV ? (int)(n - rb) : TV;
+  bool fail = false;
+  for (int e = tid; e < TV * TV; e += BLOCK) {
+    const int i = e >> 6, j = e & 63;  // entry (i, j) of the lower-triangular matrix to invert
+    T v = T(0);
+    if (i < nb && j < i) v = lower ? Tm[(rb + i) * sT0 + (rb + j) * sT1] : Tm[(rb + j) * sT0 + (rb + i) * sT1];
+    if (i == j) {
+      v = (i < nb && !unit) ? Tm[(rb + i) * (sT0 + sT1)] : T(1);
+      if (v == T(0)) fail = true;  // trtrs: exact singularity
+    }
+    Ds[i * TVS + j] = v;
+  }
+  if (fail) atomicOr(failflag, 1);
+  __syncthreads();
+  tri_inverse64<T>(Ds, Di, scratch);
+  T* out = Tinv + (long long)b * TV * TV;
+  for (int e = tid; e < TV * TV; e += BLOCK) {
+    const int i = e >> 6, j = e & 63;
+    out[e] = lower ? Di[i * TVS + j] : Di[j * TVS + i];
+  }
+}
+
+// one matrix, many right-hand sides: X_b = inv(T_bb) B_b per 64-row block as a small MFMA GEMM (all block
+// inverses formed up front in one launch), the rows still to come inside a 256-row outer block updated
+// with K = 64, the rows beyond it once per outer block with K = 256 — the GEMM at its large-K rate, the
+// right-hand sides crossing HBM n/256 times (same two levels as the launch-per-step Cholesky)
 template <class T>
 int trsm_blocked(int lower, int unit, long long n, long long nrhs, const T* Tm, long long sT0, long long sT1, const T* B, T* out) {
   hipStream_t st = pthip::ctx().stream;
-  constexpr long long NBT = 128;
+  constexpr long long NBI = TV, NBO2 = 256;
   const int dt = sizeof(T) == 8 ? PTHIP_F64 : PTHIP_F32;
+  const long long nB = (n + NBI - 1) / NBI;
+  const size_t invbytes = (size_t)nB * NBI * NBI * sizeof(T), tmpbytes = (size_t)NBI * nrhs * sizeof(T);
   void* scratch = nullptr;
-  int r = pthip_alloc(256, &scratch);
+  int r = pthip_alloc(invbytes + tmpbytes + 256, &scratch);
   if (r) return r;
   auto fail = [&](int rc) { pthip_free(scratch); return rc; };
-  int* flag = (int*)scratch;
-  if (hipError_t e = pthip::memset_async(flag, 0, 256, st); e != hipSuccess) return fail(pthip::check(e, "trsm flag memset"));
+  T* Tinv = (T*)scratch;
+  T* Xt = (T*)((char*)scratch + invbytes);
+  int* flag = (int*)((char*)scratch + invbytes + tmpbytes);
+  if (hipError_t e = pthip::memset_async(Xt, 0, tmpbytes + 256, st); e != hipSuccess) return fail(pthip::check(e, "trsm scratch memset"));
   if (hipError_t e = pthip::memcpy_async(out, B, (size_t)n * nrhs * sizeof(T), hipMemcpyDeviceToDevice, st); e != hipSuccess)
     return fail(pthip::check(e, "trsm rhs copy"));
-  auto kl = trsm_lds_kernel<T>;
-  const size_t need = (size_t)NBT * (size_t)(NBT | 1) * sizeof(T);
-  static bool attr = false;
-  if (!attr && need > 64 * 1024) {
-    if (hipError_t e = hipFuncSetAttribute((const void*)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need); e != hipSuccess)
-      return fail(pthip::check(e, "trsm_lds attribute"));
-    attr = true;
-  }
-  const unsigned gx = (unsigned)((nrhs + BLOCK - 1) / BLOCK);
+  PTHIP_KLAUNCH((tri_inv_blocks_kernel<T>), dim3((unsigned)nB), dim3(BLOCK), 0, st, Tinv, Tm, sT0, sT1, (int)n, lower, unit, flag);
+  if ((r = pthip::post_launch("tri_inv_blocks"))) return fail(r);
+  // one 64-row block: solve it, then update rows [u0, u1) (the part of the outer block still to come)
+  auto step = [&](long long k0, long long nb, long long u0, long long u1) -> int {
+    T* Xk = out + k0 * nrhs;
+    int rc = pthip::gemm_inplace(dt, nb, nrhs, nb, 1.0, Tinv + (k0 / NBI) * NBI * NBI, NBI, 1, Xk, nrhs, 1, 0.0, Xt, nrhs);
+    if (rc) return rc;
+    if (hipError_t e = pthip::memcpy_async(Xk, Xt, (size_t)nb * nrhs * sizeof(T), hipMemcpyDeviceToDevice, st); e != hipSuccess)
+      return pthip::check(e, "trsm block copy");
+    if (u1 > u0) return pthip::gemm_inplace(dt, u1 - u0, nrhs, nb, -1.0, Tm + u0 * sT0 + k0 * sT1, sT0, sT1, Xt, nrhs, 1, 1.0, out + u0 * nrhs, nrhs);
+    return 0;
+  };
   if (lower) {
-    for (long long k0 = 0; k0 < n; k0 += NBT) {
-      const long long nb = (n - k0) < NBT ? (n - k0) : NBT;
-      T* Xk = out + k0 * nrhs;
-      PTHIP_KLAUNCH(kl, dim3(gx, 1), dim3(BLOCK), (size_t)nb * (size_t)(nb | 1) * sizeof(T), st, Xk, Tm + k0 * (sT0 + sT1), 0LL, sT0, sT1,
-                    (const T*)Xk, 0LL, (int)nb, (int)nrhs, 1, unit, flag);
-      if ((r = pthip::post_launch("trsm diag"))) return fail(r);
-      const long long rest = n - k0 - nb;
-      if (rest > 0) {
-        r = pthip::gemm_inplace(dt, rest, nrhs, nb, -1.0, Tm + (k0 + nb) * sT0 + k0 * sT1, sT0, sT1, Xk, nrhs, 1, 1.0, out + (k0 + nb) * nrhs, nrhs);
+    for (long long K0 = 0; K0 < n; K0 += NBO2) {
+      const long long Kend = (K0 + NBO2) < n ? (K0 + NBO2) : n;
+      for (long long k0 = K0; k0 < Kend; k0 += NBI) {
+        const long long nb = (Kend - k0) < NBI ? (Kend - k0) : NBI;
+        if ((r = step(k0, nb, k0 + nb, Kend))) return fail(r);
+      }
+      if (n > Kend) {
+        r = pthip::gemm_inplace(dt, n - Kend, nrhs, Kend - K0, -1.0, Tm + Kend * sT0 + K0 * sT1, sT0, sT1, out + K0 * nrhs, nrhs, 1, 1.0,
+                                out + Kend * nrhs, nrhs);
         if (r) return fail(r);
       }
     }
   } else {
-    for (long long kend = n; kend > 0;) {
-      const long long k0 = (kend - NBT) > 0 ? (kend - NBT) : 0, nb = kend - k0;
-      T* Xk = out + k0 * nrhs;
-      PTHIP_KLAUNCH(kl, dim3(gx, 1), dim3(BLOCK), (size_t)nb * (size_t)(nb | 1) * sizeof(T), st, Xk, Tm + k0 * (sT0 + sT1), 0LL, sT0, sT1,
-                    (const T*)Xk, 0LL, (int)nb, (int)nrhs, 0, unit, flag);
-      if ((r = pthip::post_launch("trsm diag"))) return fail(r);
-      if (k0 > 0) {
-        r = pthip::gemm_inplace(dt, k0, nrhs, nb, -1.0, Tm + k0 * sT1, sT0, sT1, Xk, nrhs, 1, 1.0, out, nrhs);
+    // backwards: outer blocks aligned to 256 from row 0, inner blocks of 64 from the bottom of each
+    for (long long K0 = (n - 1) / NBO2 * NBO2; K0 >= 0; K0 -= NBO2) {
+      const long long Kend = (K0 + NBO2) < n ? (K0 + NBO2) : n;
+      for (long long k0 = (Kend - 1 - K0) / NBI * NBI + K0; k0 >= K0; k0 -= NBI) {
+        const long long nb = (Kend - k0) < NBI ? (Kend - k0) : NBI;
+        if ((r = step(k0, nb, K0, k0))) return fail(r);
+      }
+      if (K0 > 0) {
+        r = pthip::gemm_inplace(dt, K0, nrhs, Kend - K0, -1.0, Tm + K0 * sT1, sT0, sT1, out + K0 * nrhs, nrhs, 1, 1.0, out, nrhs);
         if (r) return fail(r);
       }
-      kend = k0;
     }
   }
   PTHIP_KLAUNCH((nan_fill_if_kernel<T>), dim3(256), dim3(BLOCK), 0, st, out, n * nrhs, (const int*)flag);
