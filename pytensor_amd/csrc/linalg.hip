@@ -1931,7 +1931,11 @@ int trsm_typed(int lower, int unit, long long batch, long long n, long long nrhs
   }
   {
     const size_t need = (size_t)n * (size_t)(n | 1) * sizeof(T);
-    if (need <= 160 * 1024 - 256) {
+    // (a single triangle of more than one 64-row block with at least 64 right-hand sides goes to the blocked
+    //  MFMA solve below even when it fits the LDS: one thread per column is 8192 dependent steps at n = 128;
+    //  batches keep the one-launch LDS kernel)
+    static const bool lds_always = getenv("PTHIP_TRSM") && !strcmp(getenv("PTHIP_TRSM"), "lds");
+    if (need <= 160 * 1024 - 256 && (lds_always || n <= TV || nrhs < 64 || batch > 2)) {
       auto k = trsm_lds_kernel<T>;
       if (need > 64 * 1024)
         PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));

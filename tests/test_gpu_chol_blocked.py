@@ -130,6 +130,43 @@ def test_gp_marginal_likelihood_large_through_the_graph(hip, n):
         np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-9 * max(1.0, float(np.max(np.abs(b)))), err_msg=f"gp n={n} out{k}")
 
 
+def test_persistent_kernels_replay_inside_a_captured_graph(hip):
+    """Cholesky(1000) -> L^-1 b -> L^-T y as a lowered graph: the task-graph factorisation and the row-block
+    solves (memsets of their flag / box arrays included) are captured into a hipGraph plan; replays
+    reproduce the eager call bit for bit."""
+    import scipy.linalg
+
+    from pytensor_amd.executor import HipExecutable
+    from pytensor_amd.ir import Graph
+
+    g = Graph(name="chol_solves")
+    S = g.new_var("float64", (None, None), name="S")
+    b = g.new_var("float64", (None,), name="b")
+    L = g.new_var("float64", (None, None))
+    y = g.new_var("float64", (None,))
+    Lt = g.new_var("float64", (None, None))
+    x = g.new_var("float64", (None,))
+    g.add_node("Cholesky", {"lower": True, "on_error": "nan"}, [S], [L])
+    g.add_node("SolveTriangular", {"lower": True, "unit_diagonal": False, "b_ndim": 1}, [L, b], [y])
+    g.add_node("DimShuffle", {"new_order": [1, 0]}, [L], [Lt])
+    g.add_node("SolveTriangular", {"lower": False, "unit_diagonal": False, "b_ndim": 1}, [Lt, y], [x])
+    g.inputs, g.outputs = [S, b], [L, x]
+    n = 1000
+    Sv = _spd(n, "float64", 3)
+    bv = np.random.default_rng(4).normal(size=n)
+    exe = HipExecutable(g)
+    first = exe(Sv, bv)
+    np.testing.assert_allclose(first[1], scipy.linalg.cho_solve((np.linalg.cholesky(Sv), True), bv), rtol=1e-9, atol=1e-12)
+    plan = exe.freeze(Sv, bv)  # (raises if anything in the launch sequence cannot be captured)
+    try:
+        for _ in range(4):
+            again = plan(Sv, bv)
+            for a, c in zip(again, first):
+                np.testing.assert_array_equal(a, c)
+    finally:
+        plan.close()
+
+
 def test_launch_per_step_form_still_matches(hip):
     """``PTHIP_CHOL=steps`` (the launch-per-step form kept as the A/B reference of the task-graph
     kernel) is read once per process: checked in a child process against LAPACK."""
