@@ -40,6 +40,9 @@ def main(sizes):
         t0 = time.perf_counter()
         np_graph.run_graph(g, ins)
         cpu_ms = (time.perf_counter() - t0) * 1e3
+        if os.environ.get("PTHIP_GP_NODES"):
+            prof = sorted(exe.profile_nodes(ins, reps=3), key=lambda t: -t[2])[:12]
+            print("top nodes (device ms, handler brackets):", [(k, op, round(ms, 3)) for k, op, ms in prof], flush=True)
         print(json.dumps({"n": n, "ms_per_eval_hip (wall, eager: the graph's runtime asserts read the device)": round(ms, 3),
                           "ms_oracle_numpy_host": round(cpu_ms, 1), "host_cores": os.cpu_count()}), flush=True)
 
