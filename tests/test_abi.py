@@ -84,3 +84,25 @@ def test_bench_traffic_falls_back_when_the_profiler_pass_fails(monkeypatch):
     monkeypatch.setenv("ROCPROF_OUTPUT_PATH", "/tmp/x")
     traffic, why = bench.live_pmc_traffic("gchain_")
     assert traffic is None and "profiled" in why
+
+
+def test_device_status_word_maps_to_the_reference_exceptions():
+    """Kernels cannot raise: they set bits of a device word, the executor raises at its next
+    synchronisation — IndexError (take / inc_subtensor out of range), LinAlgError (np.linalg.inv of a
+    singular matrix, non-converged SVD / Eigh), RuntimeError for an expired bounded wait of a persistent
+    linear-algebra kernel (never a hang)."""
+    import numpy as np
+    import pytest
+
+    from pytensor_amd.executor import raise_device_status
+
+    raise_device_status(0)
+    with pytest.raises(IndexError):
+        raise_device_status(1)
+    for bit, msg in ((2, "Singular matrix"), (4, "SVD did not converge"), (8, "Eigenvalues did not converge")):
+        with pytest.raises(np.linalg.LinAlgError, match=msg):
+            raise_device_status(bit)
+    with pytest.raises(RuntimeError, match="persistent linear-algebra kernel"):
+        raise_device_status(16)
+    with pytest.raises(RuntimeError):  # the wait bit wins over an index error raised by the aborted launch's neighbours
+        raise_device_status(16 | 1)
