@@ -1530,9 +1530,9 @@ int potrf_typed(int lower, long long batch, long long n, const void* A, void* L,
 // it already equals the final pair, so only 8-byte atomicity is assumed — which takes the release fence
 // (1.5-2 us per hop, the write-through latency) and the separate flag load off every hop.
 //
-// Many right-hand sides (trsm_blocked): the inverses of all 64 x 64 diagonal blocks in one launch
-// (tri_inverse64), then per block X_b = inv(T_bb) B_b as a small MFMA GEMM and the rows still to come on
-// the MFMA GEMM in place, two levels (K = 64 inside a 256-row outer block, K = 256 beyond it).
+// Many right-hand sides (trsm_blocked): the inverses of all 256 x 256 diagonal blocks in one launch
+// (tri_inv256_kernel), then per block X_b = inv(T_bb) B_b and the update of the rows still to come, both on
+// the MFMA GEMM with K = 256.
 // A zero pivot anywhere NaN-fills the whole result, as the LDS-resident kernels do.
 // ---------------------------------------------------------------------------------
 constexpr int TV = 64;        // rows per workgroup
@@ -1807,48 +1807,132 @@ int trsv_dag(int lower, int unit, long long n, long long nrhs, const T* Tm, long
   return r;
 }
 
-// inverses of all 64 x 64 diagonal blocks of T in one launch (block b -> Tinv[b], dense 64 x 64 row-major,
-// identity beyond n): an upper triangle is inverted through its transpose (tri_inverse64 is lower-only)
+// Inverses of all 256 x 256 diagonal blocks of T in one launch (block b -> Tinv[b], dense 256 x 256
+// row-major, identity beyond n), one workgroup per block.  Inside, 4 x 4 tiles of 64: the diagonal tiles by
+// tri_inverse64, the tiles below them level by level, Inv(i,j) = -Inv(i,i) (sum_{k=j..i-1} T(i,k) Inv(k,j)),
+// every 64^3 product on the matrix cores from LDS-staged operands.  An upper triangle is inverted through
+// its transpose M = U^T (lower): inv(U) = inv(M)^T — all reads of T and all accesses to the result go
+// through the same (i, j) -> address maps.
+constexpr int TB = 256;  // rows per diagonal block of the many-right-hand-sides solve
+
 template <class T>
-__global__ __launch_bounds__(BLOCK) void tri_inv_blocks_kernel(T* __restrict__ Tinv, const T* __restrict__ Tm, long long sT0,
-                                                              long long sT1, int n, int lower, int unit,
-                                                              int* __restrict__ failflag) {
-  __shared__ T Ds[TV * TVS], Di[TV * TVS], scratch[4 * 16 * 17];
-  const int tid = threadIdx.x, b = blockIdx.x;
-  const long long rb = (long long)b * TV;
-  const int nb = (n - rb) < TV ? (int)(n - rb) : TV;
+__global__ __launch_bounds__(BLOCK) void tri_inv256_kernel(T* __restrict__ Tinv, const T* __restrict__ Tm, long long sT0,
+                                                          long long sT1, int n, int lower, int unit,
+                                                          int* __restrict__ failflag) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* As = (T*)smem_raw;          // [TV][TVS] left operand / the diagonal tile
+  T* Bs = As + TV * TVS;         // [TV][TVS] right operand / its inverse
+  T* scratch = Bs + TV * TVS;    // [4][16][17] (tri_inverse64)
+  typedef typename Mfma16<T>::v4 v4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
+  const long long base = (long long)blockIdx.x * TB;
+  T* out = Tinv + (long long)blockIdx.x * TB * TB;
+  // entry (i, j) of the lower-triangular matrix being inverted, i, j relative to this block
+  auto Mv = [&](int i, int j) -> T {
+    const long long gi = base + i, gj = base + j;
+    if (gi >= n || gj >= n) return (i == j) ? T(1) : T(0);
+    if (i == j && unit) return T(1);
+    return lower ? Tm[gi * sT0 + gj * sT1] : Tm[gj * sT0 + gi * sT1];
+  };
+  auto Oaddr = [&](int i, int j) -> T* { return lower ? out + (long long)i * TB + j : out + (long long)j * TB + i; };
   bool fail = false;
-  for (int e = tid; e < TV * TV; e += BLOCK) {
-    const int i = e >> 6, j = e & 63;  // entry (i, j) of the lower-triangular matrix to invert
-    T v = T(0);
-    if (i < nb && j < i) v = lower ? Tm[(rb + i) * sT0 + (rb + j) * sT1] : Tm[(rb + j) * sT0 + (rb + i) * sT1];
-    if (i == j) {
-      v = (i < nb && !unit) ? Tm[(rb + i) * (sT0 + sT1)] : T(1);
-      if (v == T(0)) fail = true;  // trtrs: exact singularity
+  // ---- diagonal tiles
+  for (int d = 0; d < TB / TV; d++) {
+    for (int e = tid; e < TV * TV; e += BLOCK) {
+      const int i = e >> 6, j = e & 63;
+      T v = (j <= i) ? Mv(TV * d + i, TV * d + j) : T(0);
+      if (i == j && v == T(0)) fail = true;  // trtrs: exact singularity
+      As[i * TVS + j] = v;
     }
-    Ds[i * TVS + j] = v;
+    __syncthreads();
+    tri_inverse64<T>(As, Bs, scratch);  // (ends on a barrier)
+    for (int e = tid; e < TV * TV; e += BLOCK) {
+      const int i = e >> 6, j = e & 63;
+      *Oaddr(TV * d + i, TV * d + j) = Bs[i * TVS + j];
+    }
+    __syncthreads();
   }
   if (fail) atomicOr(failflag, 1);
+  __threadfence();
   __syncthreads();
-  tri_inverse64<T>(Ds, Di, scratch);
-  T* out = Tinv + (long long)b * TV * TV;
-  for (int e = tid; e < TV * TV; e += BLOCK) {
-    const int i = e >> 6, j = e & 63;
-    out[e] = lower ? Di[i * TVS + j] : Di[j * TVS + i];
+  // ---- tiles below the diagonal, level by level (tile (i, j), i - j = d)
+  auto product = [&](v4 (&acc)[2][2]) {  // acc += As * Bs (64 x 64 x 64), this wave's 32 x 32 quadrant
+#pragma unroll 4
+    for (int st = 0; st < TV / 4; st++) {
+      const T a0 = As[(r0 + li) * TVS + 4 * st + lq], a1 = As[(r0 + 16 + li) * TVS + 4 * st + lq];
+      const T b0 = Bs[(4 * st + lq) * TVS + c0 + li], b1 = Bs[(4 * st + lq) * TVS + c0 + 16 + li];
+      acc[0][0] = Mfma16<T>::run(a0, b0, acc[0][0]);
+      acc[0][1] = Mfma16<T>::run(a0, b1, acc[0][1]);
+      acc[1][0] = Mfma16<T>::run(a1, b0, acc[1][0]);
+      acc[1][1] = Mfma16<T>::run(a1, b1, acc[1][1]);
+    }
+  };
+  for (int d = 1; d < TB / TV; d++) {
+    for (int i = d; i < TB / TV; i++) {
+      const int j = i - d;
+      v4 acc[2][2];
+#pragma unroll
+      for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int y = 0; y < 2; y++) acc[x][y] = v4{T(0), T(0), T(0), T(0)};
+      for (int k = j; k < i; k++) {
+        for (int e = tid; e < TV * TV; e += BLOCK) {
+          const int r = e >> 6, c = e & 63;
+          As[r * TVS + c] = Mv(TV * i + r, TV * k + c);
+          Bs[r * TVS + c] = *Oaddr(TV * k + r, TV * j + c);
+        }
+        __syncthreads();
+        product(acc);
+        __syncthreads();
+      }
+      // S -> Bs, Inv(i,i) -> As, Inv(i,j) = -(As * Bs)
+#pragma unroll
+      for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int y = 0; y < 2; y++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) Bs[(r0 + x * 16 + Mfma16<T>::drow(lane, r)) * TVS + c0 + y * 16 + li] = acc[x][y][r];
+      for (int e = tid; e < TV * TV; e += BLOCK) {
+        const int r = e >> 6, c = e & 63;
+        As[r * TVS + c] = *Oaddr(TV * i + r, TV * i + c);
+      }
+      __syncthreads();
+      v4 res[2][2];
+#pragma unroll
+      for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int y = 0; y < 2; y++) res[x][y] = v4{T(0), T(0), T(0), T(0)};
+      product(res);
+#pragma unroll
+      for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int y = 0; y < 2; y++)
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            *Oaddr(TV * i + r0 + x * 16 + Mfma16<T>::drow(lane, r), TV * j + c0 + y * 16 + li) = -res[x][y][r];
+      __syncthreads();
+    }
+    __threadfence();  // this level's tiles are operands of the next
+    __syncthreads();
+  }
+  // the other triangle of the dense block: zeros
+  for (int e = tid; e < TB * TB; e += BLOCK) {
+    const int i = e / TB, j = e - i * TB;
+    if (j > i) *Oaddr(i, j) = T(0);
   }
 }
 
-// one matrix, many right-hand sides: X_b = inv(T_bb) B_b per 64-row block as a small MFMA GEMM (all block
-// inverses formed up front in one launch), the rows still to come inside a 256-row outer block updated
-// with K = 64, the rows beyond it once per outer block with K = 256 — the GEMM at its large-K rate, the
-// right-hand sides crossing HBM n/256 times (same two levels as the launch-per-step Cholesky)
+// one matrix, many right-hand sides: the inverses of the 256 x 256 diagonal blocks up front (one launch),
+// then per block X_b = inv(T_bb) B_b and the update of all rows still to come, both on the MFMA GEMM at
+// K = 256 — three launches per 256 rows (a version with 64-row inner steps and K = 64 updates inside the
+// outer block: 110 launches at n = 2048, 1.6 ms; this one: 25 launches)
 template <class T>
 int trsm_blocked(int lower, int unit, long long n, long long nrhs, const T* Tm, long long sT0, long long sT1, const T* B, T* out) {
   hipStream_t st = pthip::ctx().stream;
-  constexpr long long NBI = TV, NBO2 = 256;
   const int dt = sizeof(T) == 8 ? PTHIP_F64 : PTHIP_F32;
-  const long long nB = (n + NBI - 1) / NBI;
-  const size_t invbytes = (size_t)nB * NBI * NBI * sizeof(T), tmpbytes = (size_t)NBI * nrhs * sizeof(T);
+  const long long nB = (n + TB - 1) / TB;
+  const size_t invbytes = (size_t)nB * TB * TB * sizeof(T), tmpbytes = (size_t)TB * nrhs * sizeof(T);
   void* scratch = nullptr;
   int r = pthip_alloc(invbytes + tmpbytes + 256, &scratch);
   if (r) return r;
@@ -1859,12 +1943,20 @@ int trsm_blocked(int lower, int unit, long long n, long long nrhs, const T* Tm, 
   if (hipError_t e = pthip::memset_async(Xt, 0, tmpbytes + 256, st); e != hipSuccess) return fail(pthip::check(e, "trsm scratch memset"));
   if (hipError_t e = pthip::memcpy_async(out, B, (size_t)n * nrhs * sizeof(T), hipMemcpyDeviceToDevice, st); e != hipSuccess)
     return fail(pthip::check(e, "trsm rhs copy"));
-  PTHIP_KLAUNCH((tri_inv_blocks_kernel<T>), dim3((unsigned)nB), dim3(BLOCK), 0, st, Tinv, Tm, sT0, sT1, (int)n, lower, unit, flag);
-  if ((r = pthip::post_launch("tri_inv_blocks"))) return fail(r);
-  // one 64-row block: solve it, then update rows [u0, u1) (the part of the outer block still to come)
+  auto ki = tri_inv256_kernel<T>;
+  const size_t lds = (size_t)(2 * TV * TVS + 4 * 16 * 17) * sizeof(T);
+  static bool attr = false;
+  if (!attr && lds > 64 * 1024) {
+    if (hipError_t e = hipFuncSetAttribute((const void*)ki, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess)
+      return fail(pthip::check(e, "tri_inv256 attribute"));
+    attr = true;
+  }
+  PTHIP_KLAUNCH(ki, dim3((unsigned)nB), dim3(BLOCK), lds, st, Tinv, Tm, sT0, sT1, (int)n, lower, unit, flag);
+  if ((r = pthip::post_launch("tri_inv256"))) return fail(r);
+  // block [k0, k0 + nb): solve it, then update rows [u0, u1)
   auto step = [&](long long k0, long long nb, long long u0, long long u1) -> int {
     T* Xk = out + k0 * nrhs;
-    int rc = pthip::gemm_inplace(dt, nb, nrhs, nb, 1.0, Tinv + (k0 / NBI) * NBI * NBI, NBI, 1, Xk, nrhs, 1, 0.0, Xt, nrhs);
+    int rc = pthip::gemm_inplace(dt, nb, nrhs, nb, 1.0, Tinv + (k0 / TB) * TB * TB, TB, 1, Xk, nrhs, 1, 0.0, Xt, nrhs);
     if (rc) return rc;
     if (hipError_t e = pthip::memcpy_async(Xk, Xt, (size_t)nb * nrhs * sizeof(T), hipMemcpyDeviceToDevice, st); e != hipSuccess)
       return pthip::check(e, "trsm block copy");
@@ -1872,30 +1964,14 @@ int trsm_blocked(int lower, int unit, long long n, long long nrhs, const T* Tm, 
     return 0;
   };
   if (lower) {
-    for (long long K0 = 0; K0 < n; K0 += NBO2) {
-      const long long Kend = (K0 + NBO2) < n ? (K0 + NBO2) : n;
-      for (long long k0 = K0; k0 < Kend; k0 += NBI) {
-        const long long nb = (Kend - k0) < NBI ? (Kend - k0) : NBI;
-        if ((r = step(k0, nb, k0 + nb, Kend))) return fail(r);
-      }
-      if (n > Kend) {
-        r = pthip::gemm_inplace(dt, n - Kend, nrhs, Kend - K0, -1.0, Tm + Kend * sT0 + K0 * sT1, sT0, sT1, out + K0 * nrhs, nrhs, 1, 1.0,
-                                out + Kend * nrhs, nrhs);
-        if (r) return fail(r);
-      }
+    for (long long k0 = 0; k0 < n; k0 += TB) {
+      const long long nb = (n - k0) < TB ? (n - k0) : TB;
+      if ((r = step(k0, nb, k0 + nb, n))) return fail(r);
     }
   } else {
-    // backwards: outer blocks aligned to 256 from row 0, inner blocks of 64 from the bottom of each
-    for (long long K0 = (n - 1) / NBO2 * NBO2; K0 >= 0; K0 -= NBO2) {
-      const long long Kend = (K0 + NBO2) < n ? (K0 + NBO2) : n;
-      for (long long k0 = (Kend - 1 - K0) / NBI * NBI + K0; k0 >= K0; k0 -= NBI) {
-        const long long nb = (Kend - k0) < NBI ? (Kend - k0) : NBI;
-        if ((r = step(k0, nb, K0, k0))) return fail(r);
-      }
-      if (K0 > 0) {
-        r = pthip::gemm_inplace(dt, K0, nrhs, Kend - K0, -1.0, Tm + K0 * sT1, sT0, sT1, out + K0 * nrhs, nrhs, 1, 1.0, out, nrhs);
-        if (r) return fail(r);
-      }
+    for (long long k0 = (n - 1) / TB * TB; k0 >= 0; k0 -= TB) {
+      const long long nb = (n - k0) < TB ? (n - k0) : TB;
+      if ((r = step(k0, nb, 0, k0))) return fail(r);
     }
   }
   PTHIP_KLAUNCH((nan_fill_if_kernel<T>), dim3(256), dim3(BLOCK), 0, st, out, n * nrhs, (const int*)flag);
