@@ -1032,10 +1032,13 @@ __device__ __forceinline__ void dag_publish(int* flag, long long* tr = nullptr, 
 // separate tasks cost a store + publish + poll + reload + product = 11 of 37 us per column,
 // profiles/r3t_chol_trace.txt) — followed by the ordinary tasks (i, j), i >= j + 2.
 template <class T>
-__global__ __launch_bounds__(BLOCK) void chol_dag_kernel(T* __restrict__ W, long long ld, int nT, int ntasks,
+__global__ __launch_bounds__(BLOCK) void chol_dag_kernel(T* __restrict__ W, long long ld, const T* Asrc, long long lda, int nT,
+                                                        int ntasks,
                                                         int* __restrict__ done, T* __restrict__ Dinv,
                                                         int* __restrict__ failflag, int* __restrict__ abortflag,
                                                         int* __restrict__ status, long long* __restrict__ trace) {
+  // Asrc: where the tiles of A are read from — the working matrix itself (staged copy), or the caller's A
+  // when W is the output and needs no staging (lower factor, n a multiple of the tile edge).
   // trace != NULL (PTHIP_CHOL_TRACE=<file>): sixteen 100 MHz timestamps per task, see tools/chol_trace.py
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ int s_box, s_prog, s_arrive[4], s_upd[4];
@@ -1069,7 +1072,7 @@ __global__ __launch_bounds__(BLOCK) void chol_dag_kernel(T* __restrict__ W, long
     if (!head) {
       // ---- ordinary task: L(i,j) = (A(i,j) - sum_k L(i,k) L(j,k)^T) L(j,j)^-T
       T a[2][2][4];
-      dag_load_acc_layout<T>(a, W + (long long)i * DT * ld + (long long)j * DT, ld);
+      dag_load_acc_layout<T>(a, Asrc + (long long)i * DT * lda + (long long)j * DT, lda);
       if (!dag_accumulate<T, false>(acc1, acc2, W, ld, nT, i, j, j, done, abortflag, &s_box, As, Bs)) DAG_GIVE_UP();
       DAG_STAMP(1);
       dag_residual_to_lds<T>(As, a, acc1);
@@ -1085,10 +1088,10 @@ __global__ __launch_bounds__(BLOCK) void chol_dag_kernel(T* __restrict__ W, long
     }
     // ---- head task of column j
     T ad[2][2][4];
-    dag_load_acc_layout<T>(ad, W + (long long)j * DT * ld + (long long)j * DT, ld);
+    dag_load_acc_layout<T>(ad, Asrc + (long long)j * DT * lda + (long long)j * DT, lda);
     if (j > 0) {
       T as_[2][2][4];
-      dag_load_acc_layout<T>(as_, W + (long long)j * DT * ld + (long long)(j - 1) * DT, ld);
+      dag_load_acc_layout<T>(as_, Asrc + (long long)j * DT * lda + (long long)(j - 1) * DT, lda);
       if (!dag_accumulate<T, true>(acc1, acc2, W, ld, nT, j, j - 1, j - 1, done, abortflag, &s_box, As, Bs)) DAG_GIVE_UP();
       DAG_STAMP(1);
       dag_residual_to_lds<T>(As, as_, acc1);
@@ -1198,18 +1201,40 @@ __global__ __launch_bounds__(BLOCK) void chol_dag_kernel(T* __restrict__ W, long
 #undef DAG_GIVE_UP
 }
 
+// out[0 .. count) <- NaN when *flag is set (a failed pivot poisons the whole result)
+template <class T> __global__ void nan_fill_if_kernel(T* __restrict__ out, long long count, const int* __restrict__ flag) {
+  if (*flag == 0) return;
+  const T nanv = (T)__builtin_nan("");
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long long)gridDim.x * blockDim.x) out[e] = nanv;
+}
+
+// strict upper triangle of an n x n row-major matrix <- 0 (32 x 32 tiles): the lower factor written in place
+// by chol_dag_kernel never touches it
+template <class T>
+__global__ __launch_bounds__(BLOCK) void zero_upper_kernel(T* __restrict__ L, int n) {
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj < bi) return;
+  for (int e = threadIdx.x; e < 32 * 32; e += BLOCK) {
+    const int i = bi * 32 + (e >> 5), j = bj * 32 + (e & 31);
+    if (i < n && j < n && j > i) L[(long long)i * n + j] = T(0);
+  }
+}
+
 template <class T>
 int chol_dag(int lower, long long n, const T* A, T* L) {
   hipStream_t st = pthip::ctx().stream;
   const long long np = (n + DT - 1) / DT * DT;
+  // lower factor of a matrix of whole tiles: factor straight into the output (no staged copy, no finishing pass)
+  static const bool no_direct = getenv("PTHIP_CHOL_STAGED") != nullptr;
+  const bool direct = lower && np == n && !no_direct && (const void*)A != (const void*)L;
   const int nT = (int)(np / DT);
-  const size_t wbytes = (size_t)np * np * sizeof(T);
+  const size_t wbytes = direct ? 0 : (size_t)np * np * sizeof(T);
   const size_t dbytes = (size_t)nT * 4 * 16 * 16 * sizeof(T);
   const size_t fbytes = ((size_t)nT * nT * sizeof(int) + 255) / 256 * 256 + 256;
   void* scratch = nullptr;
   int r = pthip_alloc(wbytes + dbytes + fbytes, &scratch);
   if (r) return r;
-  T* W = (T*)scratch;
+  T* W = direct ? L : (T*)scratch;
   T* Dinv = (T*)((char*)scratch + wbytes);
   int* flags = (int*)((char*)scratch + wbytes + dbytes);
   int* failflag = flags, *abortflag = flags + 1, *done = flags + 64;
@@ -1233,15 +1258,20 @@ int chol_dag(int lower, long long n, const T* A, T* L) {
   }
   if (hipError_t e = pthip::memset_async(flags, 0, fbytes, st); e != hipSuccess) return fail(pthip::check(e, "chol flags memset"));
   const unsigned ntile = (unsigned)(np / 32);
-  PTHIP_KLAUNCH((chol_stage_kernel<T>), dim3(ntile, ntile), dim3(BLOCK), 0, st, W, A, (int)n, lower, (int)np);
-  if ((r = pthip::post_launch("chol_stage"))) return fail(r);
+  if (direct) {
+    PTHIP_KLAUNCH((zero_upper_kernel<T>), dim3(ntile, ntile), dim3(BLOCK), 0, st, L, (int)n);
+    if ((r = pthip::post_launch("chol zero upper"))) return fail(r);
+  } else {
+    PTHIP_KLAUNCH((chol_stage_kernel<T>), dim3(ntile, ntile), dim3(BLOCK), 0, st, W, A, (int)n, lower, (int)np);
+    if ((r = pthip::post_launch("chol_stage"))) return fail(r);
+  }
   int ntasks = 0;  // per column: the head task + the tiles from two below the diagonal down
   for (int j = 0; j < nT; j++) ntasks += 1 + ((nT - j - 2) > 0 ? (nT - j - 2) : 0);
   const unsigned grid = (unsigned)(ntasks < resident ? ntasks : resident);
   long long* trace = nullptr;
   static const char* trace_path = getenv("PTHIP_CHOL_TRACE");
   if (trace_path && hipMalloc((void**)&trace, (size_t)ntasks * 16 * sizeof(long long)) != hipSuccess) trace = nullptr;
-  PTHIP_KLAUNCH(kk, dim3(grid), dim3(BLOCK), lds, st, W, np, nT, ntasks, done, Dinv, failflag, abortflag, pthip::ctx().status_dev, trace);
+  PTHIP_KLAUNCH(kk, dim3(grid), dim3(BLOCK), lds, st, W, np, direct ? A : (const T*)W, np, nT, ntasks, done, Dinv, failflag, abortflag, pthip::ctx().status_dev, trace);
   if ((r = pthip::post_launch("chol_dag"))) return fail(r);
   if (trace) {  // profiling hook only: synchronises
     std::vector<long long> h((size_t)ntasks * 16);
@@ -1256,9 +1286,14 @@ int chol_dag(int lower, long long n, const T* A, T* L) {
     }
     (void)hipFree(trace);
   }
-  const unsigned nt = (unsigned)((n + 31) / 32);
-  PTHIP_KLAUNCH((chol_finish_kernel<T>), dim3(nt, nt), dim3(BLOCK), 0, st, L, (const T*)W, (int)n, lower, (const int*)failflag, (int)np);
-  r = pthip::post_launch("chol_finish");
+  if (direct) {
+    PTHIP_KLAUNCH((nan_fill_if_kernel<T>), dim3(256), dim3(BLOCK), 0, st, L, n * n, (const int*)failflag);
+    r = pthip::post_launch("chol nan fill");
+  } else {
+    const unsigned nt = (unsigned)((n + 31) / 32);
+    PTHIP_KLAUNCH((chol_finish_kernel<T>), dim3(nt, nt), dim3(BLOCK), 0, st, L, (const T*)W, (int)n, lower, (const int*)failflag, (int)np);
+    r = pthip::post_launch("chol_finish");
+  }
   pthip_free(scratch);  // stream-ordered reuse keeps this safe
   return r;
 }
@@ -1754,11 +1789,6 @@ __global__ __launch_bounds__(BLOCK) void trsv_dag_kernel(T* __restrict__ Xp, lon
   }
 }
 
-template <class T> __global__ void nan_fill_if_kernel(T* __restrict__ out, long long count, const int* __restrict__ flag) {
-  if (*flag == 0) return;
-  const T nanv = (T)__builtin_nan("");
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long long)gridDim.x * blockDim.x) out[e] = nanv;
-}
 
 // one matrix, nrhs <= 16: chunks of TV_NR right-hand sides, one persistent launch each
 template <class T>

@@ -79,8 +79,8 @@ def test_blocked_cholesky_failure_is_all_nan(hip, n, bad):
     assert np.isnan(_potrf(hip, S, True)).all()
 
 
-def test_blocked_cholesky_batch_and_upper_reads_only_its_triangle(hip):
-    n = 260
+@pytest.mark.parametrize("n", [260, 512])  # (512: whole tiles — the lower factor is formed straight in the output)
+def test_blocked_cholesky_batch_and_upper_reads_only_its_triangle(hip, n):
     S = np.stack([_spd(n, "float64", 11), _spd(n, "float64", 12)])
     junk = S.copy()
     iu = np.triu_indices(n, 1)
