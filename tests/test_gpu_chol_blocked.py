@@ -67,7 +67,7 @@ def test_blocked_cholesky_matches_lapack(hip, dtype, n, lower):
     np.testing.assert_array_equal(got, _potrf(hip, S, lower))
 
 
-@pytest.mark.parametrize("n,bad", [(300, 0), (300, 150), (300, 299), (777, 640)])
+@pytest.mark.parametrize("n,bad", [(300, 0), (300, 150), (300, 299), (777, 640), (512, 0), (512, 200), (512, 511)])
 def test_blocked_cholesky_failure_is_all_nan(hip, n, bad):
     """A non-positive pivot in ANY diagonal block — first, middle, last panel — NaN-fills the whole
     result (cholesky.py:78-80), not just what was computed after it."""
