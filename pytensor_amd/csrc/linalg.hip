@@ -1869,11 +1869,19 @@ __global__ __launch_bounds__(BLOCK) void tri_inv256_kernel(T* __restrict__ Tinv,
   bool fail = false;
   // ---- diagonal tiles
   for (int d = 0; d < TB / TV; d++) {
-    for (int e = tid; e < TV * TV; e += BLOCK) {
-      const int i = e >> 6, j = e & 63;
-      T v = (j <= i) ? Mv(TV * d + i, TV * d + j) : T(0);
-      if (i == j && v == T(0)) fail = true;  // trtrs: exact singularity
-      As[i * TVS + j] = v;
+    {
+      T va[TV * TV / BLOCK];
+#pragma unroll
+      for (int u = 0; u < TV * TV / BLOCK; u++) {
+        const int e = u * BLOCK + tid, i = e >> 6, j = e & 63;
+        va[u] = (j <= i) ? Mv(TV * d + i, TV * d + j) : T(0);
+        if (i == j && va[u] == T(0)) fail = true;  // trtrs: exact singularity
+      }
+#pragma unroll
+      for (int u = 0; u < TV * TV / BLOCK; u++) {
+        const int e = u * BLOCK + tid;
+        As[(e >> 6) * TVS + (e & 63)] = va[u];
+      }
     }
     __syncthreads();
     tri_inverse64<T>(As, Bs, scratch);  // (ends on a barrier)
@@ -1907,10 +1915,20 @@ __global__ __launch_bounds__(BLOCK) void tri_inv256_kernel(T* __restrict__ Tinv,
 #pragma unroll
         for (int y = 0; y < 2; y++) acc[x][y] = v4{T(0), T(0), T(0), T(0)};
       for (int k = j; k < i; k++) {
-        for (int e = tid; e < TV * TV; e += BLOCK) {
-          const int r = e >> 6, c = e & 63;
-          As[r * TVS + c] = Mv(TV * i + r, TV * k + c);
-          Bs[r * TVS + c] = *Oaddr(TV * k + r, TV * j + c);
+        {  // (all 32 loads of a thread in flight before the first LDS store: a load-store loop is 16 round trips)
+          T va[TV * TV / BLOCK], vb[TV * TV / BLOCK];
+#pragma unroll
+          for (int u = 0; u < TV * TV / BLOCK; u++) {
+            const int e = u * BLOCK + tid, r = e >> 6, c = e & 63;
+            va[u] = Mv(TV * i + r, TV * k + c);
+            vb[u] = *Oaddr(TV * k + r, TV * j + c);
+          }
+#pragma unroll
+          for (int u = 0; u < TV * TV / BLOCK; u++) {
+            const int e = u * BLOCK + tid, r = e >> 6, c = e & 63;
+            As[r * TVS + c] = va[u];
+            Bs[r * TVS + c] = vb[u];
+          }
         }
         __syncthreads();
         product(acc);
@@ -1923,9 +1941,18 @@ __global__ __launch_bounds__(BLOCK) void tri_inv256_kernel(T* __restrict__ Tinv,
         for (int y = 0; y < 2; y++)
 #pragma unroll
           for (int r = 0; r < 4; r++) Bs[(r0 + x * 16 + Mfma16<T>::drow(lane, r)) * TVS + c0 + y * 16 + li] = acc[x][y][r];
-      for (int e = tid; e < TV * TV; e += BLOCK) {
-        const int r = e >> 6, c = e & 63;
-        As[r * TVS + c] = *Oaddr(TV * i + r, TV * i + c);
+      {
+        T va[TV * TV / BLOCK];
+#pragma unroll
+        for (int u = 0; u < TV * TV / BLOCK; u++) {
+          const int e = u * BLOCK + tid;
+          va[u] = *Oaddr(TV * i + (e >> 6), TV * i + (e & 63));
+        }
+#pragma unroll
+        for (int u = 0; u < TV * TV / BLOCK; u++) {
+          const int e = u * BLOCK + tid;
+          As[(e >> 6) * TVS + (e & 63)] = va[u];
+        }
       }
       __syncthreads();
       v4 res[2][2];
