@@ -1032,13 +1032,14 @@ __device__ __forceinline__ void dag_publish(int* flag, long long* tr = nullptr, 
 // separate tasks cost a store + publish + poll + reload + product = 11 of 37 us per column,
 // profiles/r3t_chol_trace.txt) — followed by the ordinary tasks (i, j), i >= j + 2.
 template <class T>
-__global__ __launch_bounds__(BLOCK) void chol_dag_kernel(T* __restrict__ W, long long ld, const T* Asrc, long long lda, int nT,
+__global__ __launch_bounds__(BLOCK) void chol_dag_kernel(T* W, long long ld, const T* Asrc, long long lda, int nT,
                                                         int ntasks,
                                                         int* __restrict__ done, T* __restrict__ Dinv,
                                                         int* __restrict__ failflag, int* __restrict__ abortflag,
                                                         int* __restrict__ status, long long* __restrict__ trace) {
-  // Asrc: where the tiles of A are read from — the working matrix itself (staged copy), or the caller's A
-  // when W is the output and needs no staging (lower factor, n a multiple of the tile edge).
+  // Asrc: where the tiles of A are read from — the working matrix itself (staged copy: Asrc == W, hence no
+  // __restrict__ on either), or the caller's A when W is the output and needs no staging (lower factor, n a
+  // multiple of the tile edge).
   // trace != NULL (PTHIP_CHOL_TRACE=<file>): sixteen 100 MHz timestamps per task, see tools/chol_trace.py
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ int s_box, s_prog, s_arrive[4], s_upd[4];
