@@ -1,0 +1,76 @@
+// One-way latency of a cross-workgroup hand-over on gfx950, the floor under every hop of the persistent
+// kernels (chol_dag / trsv_dag / lu_panel): workgroup A publishes a 16-byte self-validating pair
+// {seq, seq ^ MAGIC} with one write-through store, workgroup B polls it with agent-scope loads and answers
+// the same way; N round trips, timed on the 100 MHz wall clock.  Second variant: data + release fence +
+// flag (the chol_dag hand-over).
+// build: hipcc --offload-arch=gfx950 -O3 -o hop hop.hip ; run: ./hop
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef unsigned long long u64;
+typedef u64 u2 __attribute__((ext_vector_type(2)));
+constexpr u64 MAGIC = 0x7ff4c0de5ea1ed01ull;
+__device__ __forceinline__ void publish(u64* slot, u64 v) {
+  u2 pr = {v, v ^ MAGIC};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 2" : : "v"((u2*)slot), "v"(pr) : "memory");
+}
+__device__ __forceinline__ bool poll(const u64* slot, u64& v) {
+  v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const u64 b = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (v ^ b) == MAGIC;
+}
+__global__ void pingpong_pair(u64* box, int n, long long* ticks, int stride_wg) {
+  // workgroups 0 and stride_wg play; the others exit (stride_wg picks a partner on another XCD or the same)
+  const int me = blockIdx.x == 0 ? 0 : (blockIdx.x == stride_wg ? 1 : -1);
+  if (me < 0 || threadIdx.x != 0) return;
+  u64* mine = box + (me ? 2 : 0) * 8;   // separate cache lines
+  u64* theirs = box + (me ? 0 : 2) * 8;
+  const long long t0 = wall_clock64();
+  for (int i = 1; i <= n; i++) {
+    u64 v;
+    if (me == 0) { publish(mine, (u64)i); while (!(poll(theirs, v) && v == (u64)i)) {} }
+    else { while (!(poll(theirs, v) && v == (u64)i)) {} publish(mine, (u64)i); }
+  }
+  if (me == 0) ticks[0] = wall_clock64() - t0;
+}
+__global__ void pingpong_flag(u64* data, int* flag, int n, long long* ticks, int stride_wg) {
+  const int me = blockIdx.x == 0 ? 0 : (blockIdx.x == stride_wg ? 1 : -1);
+  if (me < 0 || threadIdx.x != 0) return;
+  u64* dmine = data + (me ? 64 : 0);
+  u64* dtheirs = data + (me ? 0 : 64);
+  int* fmine = flag + (me ? 64 : 0);
+  int* ftheirs = flag + (me ? 0 : 64);
+  const long long t0 = wall_clock64();
+  u64 sink = 0;
+  for (int i = 1; i <= n; i++) {
+    if (me == 0) {
+      __hip_atomic_store(dmine, (u64)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(fmine, i, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(ftheirs, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != i) {}
+      sink += *dtheirs;
+    } else {
+      while (__hip_atomic_load(ftheirs, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != i) {}
+      sink += *dtheirs;
+      __hip_atomic_store(dmine, (u64)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(fmine, i, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (me == 0) { ticks[0] = wall_clock64() - t0; ticks[1] = (long long)sink; }
+}
+int main() {
+  u64* box; int* flag; long long* ticks;
+  (void)hipMalloc(&box, 4096); (void)hipMalloc(&flag, 4096); (void)hipMalloc(&ticks, 64);
+  const int n = 2000;
+  for (int partner : {1, 8, 9, 255}) {
+    long long h[2];
+    (void)hipMemset(box, 0, 4096);
+    pingpong_pair<<<256, 64>>>(box, n, ticks, partner);
+    (void)hipMemcpy(h, ticks, 16, hipMemcpyDeviceToHost);
+    const double pair_ns = h[0] * 10.0 / (2.0 * n);
+    (void)hipMemset(box, 0, 4096); (void)hipMemset(flag, 0, 4096);
+    pingpong_flag<<<256, 64>>>(box, flag, n, ticks, partner);
+    (void)hipMemcpy(h, ticks, 16, hipMemcpyDeviceToHost);
+    printf("workgroups 0 <-> %3d: self-validating pair %.0f ns one way; data + release + flag + acquire %.0f ns one way\n", partner, pair_ns,
+           h[0] * 10.0 / (2.0 * n));
+  }
+  return 0;
+}
