@@ -8,7 +8,9 @@ the boundary on every step (both inside the timed region).
 
     python bench.py --gpus N --steps K --warmup W
 
-For N>1 the driver launches one rank per GPU with torch.distributed.run; each rank
+For N>1 the driver launches one rank per GPU with torch.distributed.run; started WITHOUT a launcher
+(``python bench.py --gpus N``, no WORLD_SIZE in the environment) the script starts its own N ranks the
+same way (``replicas.ensure_world``) and rank 0 prints the one JSON line.  Each rank
 evaluates an independent chain (weak scaling, no data-path collective: "replicas only",
 SURVEY.md §8e) and ``value`` = total evals / max-over-ranks time.
 
@@ -248,7 +250,10 @@ def main():
     ap.add_argument("--single-stream", action="store_true", help="frozen plan without the two-stream fork")
     args = ap.parse_args()
 
-    from pytensor_amd import configs, ffi, replicas
+    from pytensor_amd import replicas
+
+    replicas.ensure_world(args.gpus)  # `python bench.py --gpus N` with no launcher: start the N ranks ourselves
+    from pytensor_amd import configs, ffi
     from pytensor_amd.executor import HipExecutable
 
     info = replicas.rank_info()

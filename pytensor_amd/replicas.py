@@ -28,6 +28,40 @@ def rank_info() -> RankInfo:
     )
 
 
+def _free_port() -> int:
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def ensure_world(n: int, argv: list[str] | None = None) -> None:
+    """``python script.py --gpus N`` started WITHOUT a launcher (no ``WORLD_SIZE`` in the environment)
+    starts its own N ranks: the script is re-executed as ``python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>`` with the same arguments — the
+    command the driver uses for N > 1 — and this process exits with the launcher's return code.  Under
+    a launcher (``WORLD_SIZE`` set) or with N <= 1 it returns at once, so it is safe to call first thing
+    in ``main()``.  A launcher world that disagrees with ``--gpus`` is an error, not a silent override."""
+    import subprocess
+    import sys
+
+    world = os.environ.get("WORLD_SIZE")
+    if world is not None:
+        if n > 1 and int(world) != n:
+            raise SystemExit(f"--gpus {n} but the launcher set WORLD_SIZE={world}")
+        return
+    if n <= 1:
+        return
+    argv = list(sys.argv if argv is None else argv)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), *argv]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")  # what torchrun would set (and warn about) anyway
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL needs dmabuf IPC on this driver
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def device_for_rank(info: RankInfo, n_devices: int) -> int:
     """LOCAL_RANK → device index (one process per GPU; wraps only when ranks outnumber
     devices, which happens in the single-GPU CI test of the multi-rank path)."""

@@ -26,6 +26,31 @@ def test_replicas_world2_gloo(tmp_path):
     assert len(set(round(v, 9) for v in all_logps.values())) == 8
 
 
+def test_self_launch_without_torchrun():
+    """``python script.py --gpus 2`` with no launcher and no WORLD_SIZE starts two ranks itself
+    (``replicas.ensure_world`` — what ``bench.py --gpus N`` relies on when nobody wraps it in torchrun)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    worker = os.path.join(ROOT, "tests", "_selflaunch_worker.py")
+    r = subprocess.run([sys.executable, worker, "--gpus", "2", "--tag", "abc"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout  # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d == {"n_gpus": 2, "sum": 3.0, "max": 1.0, "tag": "abc", "master": "127.0.0.1", "local_rank": 0}
+    # N = 1: no launcher, no process group
+    r = subprocess.run([sys.executable, worker, "--gpus", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+    # a launcher world that contradicts --gpus is refused
+    r = subprocess.run([sys.executable, worker, "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_bench_calls_ensure_world_before_touching_the_device():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    i, j = src.index("replicas.ensure_world(args.gpus)"), src.index("ffi.lib()")
+    assert 0 < i < j
+
+
 def test_single_rank_defaults():
     from pytensor_amd import replicas
 

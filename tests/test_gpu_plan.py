@@ -76,19 +76,18 @@ def test_plan_new_parameters_same_signature(hip):
 
 def test_bench_multi_rank_flow_on_one_gpu(hip, tmp_path):
     """The N>1 launch contract (torch.distributed.run, barrier, max-over-ranks) end to end,
-    with two ranks sharing GPU 0 over gloo (RCCL refuses two ranks on one device)."""
+    with two ranks sharing GPU 0 over gloo (RCCL refuses two ranks on one device).  The bench is
+    started WITHOUT a launcher: ``python bench.py --gpus 2`` starts its own two ranks under
+    ``torch.distributed.run`` (``replicas.ensure_world``), so both entry shapes are exercised."""
     import json
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PTHIP_DIST_BACKEND="gloo")
-    cmd = [
-        sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-        "--master-addr", "127.0.0.1", "--master-port", "29581",
-        os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--rows", "20000",
-    ]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PTHIP_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--rows", "20000"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
