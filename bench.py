@@ -302,6 +302,9 @@ def main():
     # Python planning is longer than its two small kernels), so it cannot rank kernels.
     prof = exe.profile_nodes(inputs, reps=20)
     kt = dict(getattr(exe, "last_kernel_times", {}))
+    from pytensor_amd.executor import KernelTimer
+
+    bracket_overhead = KernelTimer.calibrate()
     N, K = vals["X"].shape
     kernel_name, ms_kernel = max(kt.items(), key=lambda t: t[1]) if kt else max(((op, ms) for _, op, ms in prof), key=lambda t: t[1])
     op_dom = "GemvChain" if kernel_name.startswith("gchain_") else kernel_name
@@ -358,6 +361,9 @@ def main():
         "n_gpus": info.world,
         "steps": args.steps,
         "warmup": args.warmup,
+        # evaluations actually run before the timed region: 1 eager + 1 plan check + the 64-replay determinism gate
+        # + --warmup (the gate is what brings clocks / caches / the interpreter to steady state before K = 20 steps)
+        "warmup_effective": args.warmup + 64 + (2 if plan is not None else 1),
         "ms_per_step": elapsed / args.steps * 1e3,
         # `value` is the executor-level loop (HipExecutable / FrozenPlan called directly, what every rank of
         # a multi-GPU run times); the next two are the same K steps through pytensor.function(mode="hip")
@@ -388,6 +394,8 @@ def main():
             "detail": {
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "kernel_ms": ms_kernel,
+                "kernel_ms_is": "mean two-event bracket of the single launch minus the bracket's own overhead (calibrated in this process on a 256-byte fill: bracket - back-to-back per-launch time)",
+                "event_bracket_overhead_ms": bracket_overhead,
                 "kernel_ms_top8": kernel_times,
                 "eager_node_ms_top8 (handler brackets: include host time when the stream runs dry)": node_times,
             },

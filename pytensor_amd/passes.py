@@ -2,6 +2,8 @@
 
 Order matters:
 
+0. ``split_host_shape_arithmetic`` (hostsplit.py) — 0-d integer shape arithmetic the reference fused into a
+   device ``Composite`` goes back to the host (no device read for an ``Assert`` on shapes: the graph can freeze);
 1. ``push_gather_through_elemwise`` / ``inline_elemwise_producers`` (inline.py) — finish the
    elementwise fusion the reference's ``FusionOptimizer`` stops short of;
 2. ``fuse_elemwise_reduce`` (fusion.py) — full reductions folded into the producing kernel;
@@ -42,6 +44,7 @@ from pytensor_amd.inline import (
     merge_sibling_reductions,
     push_gather_through_elemwise,
 )
+from pytensor_amd.hostsplit import split_host_shape_arithmetic
 from pytensor_amd.ir import Graph
 from pytensor_amd.tailfuse import fuse_tail
 from pytensor_amd.widefuse import collect_scalar_updates, fuse_independent_reductions
@@ -55,7 +58,8 @@ def run_pipeline(graph: Graph, fuse=True, tail=True):
         return graph, None
     if fuse == "elemwise":
         return fuse_elemwise_reduce(graph), None
-    g = inline_elemwise_producers(push_gather_through_elemwise(graph))
+    g = split_host_shape_arithmetic(graph)  # shape asserts fused into device Composites: back to the host
+    g = inline_elemwise_producers(push_gather_through_elemwise(g))
     g = fuse_elemwise_reduce(g)
     g = merge_sibling_reductions(g)
     g = hoist_scan_seq_dots(g)

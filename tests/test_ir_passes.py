@@ -297,3 +297,25 @@ def test_branch_guards_of_lazy_ifelse():
             want = (-(np.exp(xv) if b else xv**2)) if a else np.log1p(np.abs(xv))
             np.testing.assert_allclose(out, want, rtol=1e-15)
             np.testing.assert_allclose(sq, xv**2, rtol=1e-15)
+
+
+def test_shape_asserts_fused_into_device_composites_go_back_to_the_host():
+    """The GP marginal likelihood's broadcast ``Assert``s compare ``Shape_i`` values inside the same
+    ``Composite`` as the log-likelihood: split out (hostsplit.py), no assert condition / ``ARange`` /
+    ``Alloc`` shape operand is a device value any more — nothing forces a stream synchronisation, so
+    the graph can be frozen into a plan.  Values are those of the original graph."""
+    from pytensor_amd import hostsplit
+    from pytensor_amd.passes import run_pipeline
+
+    for name in ("gp_marginal_likelihood", "hmm_garch_scans"):
+        g, ins, *_ = load_case(name)
+        assert hostsplit.device_reads_for_control(g)
+        g2 = hostsplit.split_host_shape_arithmetic(g)
+        assert g2 is not g and not hostsplit.device_reads_for_control(g2)
+        for a, b in zip(np_graph.run_graph(g, ins), np_graph.run_graph(g2, ins)):
+            np.testing.assert_array_equal(a, b)
+        g3, _ = run_pipeline(g)
+        assert not hostsplit.device_reads_for_control(g3)
+    # a graph without such nodes is returned as is
+    g, *_ = load_case("c4_hier")
+    assert hostsplit.split_host_shape_arithmetic(g) is g
