@@ -144,6 +144,24 @@ int pthip_plan_replay2(void* ga, void* la, void* gb, void* lb, void* gc, void* l
 int pthip_plan_replay3(void* ga, void* la, void* gb, void* lb, void* gc, void* lc, void* dev_in,
                        const void* host_in, size_t in_bytes, const void* dev_out, void* host_out,
                        size_t out_bytes, int sync);
+/* The same through a descriptor filled once per plan (one pointer instead of 13 arguments per call), with two
+ * more ways to finish: sync = 2 polls `done_word` — an int32 in pinned host memory that the LAST kernel of the
+ * plan sets to 1 behind its results; it is cleared here before anything is launched — instead of waiting for
+ * the stream's completion signal (~5 us less per call, tools/ubench/call_lat.hip); flags bit 0: segment A reads
+ * its staged parameters straight from the pinned block (no event between the parameter upload and segment B).
+ * Replaces the output loop + return of the JIT thunk, pytensor/link/basic.py:670-684. */
+typedef struct pthip_replay_desc {
+  void *ga, *la, *gb, *lb, *gc, *lc; /* segments: captured graph (g*) or launch list (l*), A may be absent */
+  void* dev_in;
+  const void* host_in;
+  size_t in_bytes;
+  const void* dev_out;
+  size_t out_bytes;
+  int flags;
+} pthip_replay_desc;
+int pthip_plan_replay4(const pthip_replay_desc* desc, void* host_out, volatile int* done_word, int sync);
+/* a zero-initialised int32 device slot for a last-workgroup ticket (self-resetting; see csrc/tail_device.h) */
+int pthip_ticket_slot(void** slot);
 int pthip_graph_destroy(void* graph_exec);
 
 /* ---- events (HIP events on the context stream) ---- */

@@ -1771,7 +1771,74 @@ def dot_epilogue_source(name: str, body: dict, dot_pos, K: int, byvalue=(), chun
 TAIL_BLOCK = 256
 
 
-def tail_chain_source(name: str, spec: dict, sizes: dict | None = None) -> str:
+_tail_header_cache = None
+
+
+def tail_header() -> str:
+    global _tail_header_cache
+    if _tail_header_cache is None:
+        src = open(os.path.join(_HERE, "csrc", "tail_device.h")).read()
+        _tail_header_cache = src.replace("#pragma once", "")
+    return _tail_header_cache
+
+
+TAIL_SHRINK_MAX_TASKS = 4  # the by-value task table of the fused form (csrc/tail_device.h TailTasksT<4>, 192 bytes)
+
+
+def tail_shrink_pack(tasks):
+    """``TailTasksT<4>`` as kernel-argument bytes: ``tasks`` = [(op code, part ptr, nparts, M, S, out ptr)];
+    returns (bytes, number of blocks)."""
+    import struct
+
+    n = len(tasks)
+    assert 1 <= n <= TAIL_SHRINK_MAX_TASKS
+    pad = TAIL_SHRINK_MAX_TASKS - n
+    blk0, nb = [], 0
+    for _, _, _, M, S, _ in tasks:
+        blk0.append(nb)
+        nb += (int(M) + 15) // 16 * int(S)
+    blk0 += [nb] * (pad + 1)
+    col = lambda k, fill=0: [int(t[k]) for t in tasks] + [fill] * pad
+    buf = struct.pack("<i4i4x4Q4q4q4i4Q5i4x", n, *col(0), *col(1), *col(2), *col(3, 1), *col(4, 1), *col(5), *blk0)
+    assert len(buf) == 192
+    return buf, nb
+
+
+def _tail_prologue(L, shrink):
+    """``shrink`` = {"dtype": accumulator dtype}: the launch has one workgroup per slab piece; each shrinks its
+    piece (csrc/tail_device.h, the code of pthip_multi_finish), takes a ticket, and only the LAST one to finish
+    goes on to the chain (release: fence before the ticket; acquire: fence after it) and puts the ticket back."""
+    if not shrink:
+        return
+    ct = CTYPE[shrink["dtype"]]
+    L.append("  {  // prologue: the partial slabs shrink in THIS launch; the last workgroup to finish runs the chain")
+    L.append(f"    __shared__ {ct} shr_[{TAIL_BLOCK}];")
+    L.append("    __shared__ int last_;")
+    L.append(f"    pthip_dev::tail_shrink_block<{ct}, {TAIL_SHRINK_MAX_TASKS}>(tasks_, (int)blockIdx.x, shr_);")
+    L.append("    __threadfence();")
+    L.append("    __syncthreads();")
+    L.append("    if (tid == 0) last_ = atomicAdd(ticket_, 1) == (int)gridDim.x - 1;")
+    L.append("    __syncthreads();")
+    L.append("    if (!last_) return;")
+    L.append("    if (tid == 0) __hip_atomic_store(ticket_, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);")
+    L.append("    __threadfence();")
+    L.append("  }")
+
+
+def _tail_epilogue(L, spec):
+    for k, o in enumerate(spec["outs"]):
+        L.append(f"  for (long long i = tid; i < len{k}; i += {TAIL_BLOCK}) dst{k}[i] = l{o}[i];")
+    L.append("  if (tid == 0 && status_dst != nullptr) *status_dst = __hip_atomic_load(status_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);")
+    # the plan's completion word (pinned host memory, polled by pthip_plan_replay4): behind every result store
+    L.append("  if (done_dst != nullptr) {")
+    L.append("    __threadfence_system();")
+    L.append("    __syncthreads();")
+    L.append("    if (tid == 0) __hip_atomic_store(done_dst, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);")
+    L.append("  }")
+    L.append("}")
+
+
+def tail_chain_source(name: str, spec: dict, sizes: dict | None = None, shrink: dict | None = None) -> str:
     """One workgroup runs ``spec["steps"]`` in order, intermediates in LDS.
 
     ``spec`` is purely structural (extents are kernel arguments, so one code object serves every
@@ -1814,15 +1881,18 @@ def tail_chain_source(name: str, spec: dict, sizes: dict | None = None) -> str:
             P += [f"const long long n{j}"]
     for k, o in enumerate(spec["outs"]):
         P += [f"{CTYPE[slots[o]['dtype']]}* __restrict__ dst{k}", f"const long long len{k}"]
-    P += ["const int* status_src", "int* status_dst"]
+    P += ["const int* status_src", "int* status_dst", "int* done_dst"]
+    if shrink:
+        P += [f"const pthip_dev::TailTasksT<{TAIL_SHRINK_MAX_TASKS}> tasks_", "int* ticket_"]
     bodies = [st["body"] for st in steps if st["op"] == "ew"]
     if sizes is not None:
-        return _tail_preload_source(name, spec, sizes, P, bodies)
-    L = [reduce_header(), prelude_for(*bodies)]
+        return _tail_preload_source(name, spec, sizes, P, bodies, shrink)
+    L = [reduce_header(), tail_header() if shrink else "", prelude_for(*bodies)]
     L.append(f'extern "C" __global__ __launch_bounds__({TAIL_BLOCK}) void {name}({", ".join(P)}) {{')
     L.append("  extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];")
     L.append("  __shared__ double red_[8];")
     L.append("  const int tid = threadIdx.x;")
+    _tail_prologue(L, shrink)
     for k, e in enumerate(ext):
         if e["kind"] == "C":
             ct = CTYPE[e["dtype"]]
@@ -1913,10 +1983,7 @@ def tail_chain_source(name: str, spec: dict, sizes: dict | None = None) -> str:
                     L.append(f"    if (tid == 0) l{st['outs'][q]}[0] = ({CTYPE[r[2]]})acc{q};")
             L.append("  }")
             L.append("  __syncthreads();")
-    for k, o in enumerate(spec["outs"]):
-        L.append(f"  for (long long i = tid; i < len{k}; i += {TAIL_BLOCK}) dst{k}[i] = l{o}[i];")
-    L.append("  if (tid == 0 && status_dst != nullptr) *status_dst = __hip_atomic_load(status_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);")
-    L.append("}")
+    _tail_epilogue(L, spec)
     return "\n".join(L)
 
 
@@ -1950,18 +2017,19 @@ def tail_preload_sizes(spec: dict, ext_len, step_n):
     return {"ext_u": eu, "step_u": su, "wave": wave}
 
 
-def _tail_preload_source(name: str, spec: dict, sizes: dict, P, bodies) -> str:
+def _tail_preload_source(name: str, spec: dict, sizes: dict, P, bodies, shrink=None) -> str:
     """The chain with every *global* operand requested up front (one memory latency for the whole
     kernel instead of one per step — a single workgroup cannot hide it with occupancy): partial
     slabs and partial arrays are summed in registers as they arrive, vectors stay in registers;
     the steps then run out of registers and LDS.  Loop trip counts are static (``sizes``)."""
     ext, slots, steps = spec["ext"], spec["slots"], spec["steps"]
     eu, su = sizes["ext_u"], sizes["step_u"]
-    L = [reduce_header(), prelude_for(*bodies)]
+    L = [reduce_header(), tail_header() if shrink else "", prelude_for(*bodies)]
     L.append(f'extern "C" __global__ __launch_bounds__({TAIL_BLOCK}) void {name}({", ".join(P)}) {{')
     L.append("  extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];")
     L.append("  __shared__ double red_[8];")
     L.append("  const int tid = threadIdx.x;")
+    _tail_prologue(L, shrink)  # (before the operand requests below: the shrunk slabs are among them)
     for k, e in enumerate(ext):
         ct = CTYPE[e["dtype"]]
         if e["kind"] == "C":
@@ -2159,8 +2227,5 @@ def _tail_preload_source(name: str, spec: dict, sizes: dict, P, bodies) -> str:
                 L.append("  }")
         if emitted:
             L.append("  __syncthreads();")
-    for k, o in enumerate(spec["outs"]):
-        L.append(f"  for (long long i = tid; i < len{k}; i += {TAIL_BLOCK}) dst{k}[i] = l{o}[i];")
-    L.append("  if (tid == 0 && status_dst != nullptr) *status_dst = __hip_atomic_load(status_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);")
-    L.append("}")
+    _tail_epilogue(L, spec)
     return "\n".join(L)

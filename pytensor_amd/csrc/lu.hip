@@ -17,6 +17,7 @@
 // perm[i] of A), its sign (0 when singular) and log|det|.
 #include "common.h"
 
+#include <cstring>
 #include <type_traits>
 #include <utility>
 
@@ -650,6 +651,366 @@ int getrf_blocked(long long n, const T* A, T* LU, long long* perm, T* sign, T* l
   return r;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Round 4: the panel as a LOOP (lu_panel2_kernel) and one launch for interchange + U12 (lu_swap_u12_kernel).
+//
+// What was slow in lu_panel_kernel (142 us per 32 columns = 4.4 us per column, 2.2 us even with ONE workgroup
+// and no cross-workgroup hop): the 32 column bodies were unrolled into straight-line code that runs once —
+// every instruction a cold fetch — and the candidate row was published by one thread with 34 serial stores.
+// Here the column loop is a real loop: each thread still owns one row in registers, but in a ROTATED frame —
+// the current column is always a[0]; after a column the array rotates left by one (the finished multiplier
+// moves to the back), so every register index is a compile-time constant and the body is ~1 K instructions
+// that stay in the instruction cache.  Per column:
+//   A  wave arg-max (DPP), the wave's candidate row -> LDS, barrier, workgroup candidate;
+//   B  (several workgroups) the candidate {|value|, row, the PB row entries} published as epoch-tagged
+//      self-validating 16-byte pairs by PB + 2 lanes at once; wave q of every workgroup polls the candidates of
+//      workgroups q, q + 4, ... WITH their contents (one memory round trip, no second fetch of the winner's
+//      row), keeps the best in registers, -> LDS, barrier, final choice among the four waves.  Workgroup 0
+//      publishes row k the same way (the owner of the pivot row takes it in exchange).
+//   C  interchange in registers, scale by the reciprocal pivot, rank-1 update of the later columns, rotate.
+// LDS buffers alternate with the column parity: two barriers per column (one with a single workgroup).  The
+// pair tag carries the global column index and a per-call nonce: the boxes are zeroed once per call, not once
+// per panel.  Workgroup 0 also keeps the NET permutation of the panel (which original row ends up at each
+// touched position) for lu_swap_u12_kernel: one thread per outside column gathers the <= 2 PB touched rows
+// (all loads before any store — no chain of PB dependent swaps), solves L11 U12 = A12 in LDS for the columns
+// right of the panel, and stores.  Then A22 -= L21 U12 on the MFMA GEMM.  Three launches per PB = 64 columns
+// instead of five per 32.
+// ------------------------------------------------------------------------------------------
+constexpr unsigned long long LU_EPOCH_MUL = 0x9E3779B97F4A7C15ull;
+
+__device__ __forceinline__ void lu_publish_t(unsigned long long* slot, unsigned long long bits, unsigned long long tag) {
+  typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
+  u2 pr = {bits, bits ^ tag};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 2" : : "v"((u2*)slot), "v"(pr) : "memory");
+}
+__device__ __forceinline__ bool lu_poll_t(const unsigned long long* slot, unsigned long long& bits, unsigned long long tag) {
+  bits = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (bits ^ b) == tag;
+}
+template <int L>
+__device__ __forceinline__ unsigned long long lane_bcast_u64(unsigned long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, L);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), L);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+template <class T, int PB>
+__global__ __launch_bounds__(BLOCK) void lu_panel2_kernel(T* __restrict__ W, long long ld, int n, int k0, int nW,
+                                                         unsigned long long* __restrict__ box,
+                                                         unsigned long long* __restrict__ boxk, int* __restrict__ ipiv,
+                                                         int* __restrict__ plist, int* __restrict__ info,
+                                                         int* __restrict__ abortflag, int* __restrict__ status,
+                                                         unsigned long long nonce) {
+  constexpr int NWAVE = BLOCK / 64;
+  constexpr int REC = PB + 2;  // pairs of a candidate record: |value|, row, PB entries
+  static_assert(PB <= 64 && REC <= 128, "panel width");
+  __shared__ T s_val[2][NWAVE], g_val[2][NWAVE];
+  __shared__ int s_row[2][NWAVE], g_row[2][NWAVE];
+  __shared__ __attribute__((aligned(16))) T s_cand[2][NWAVE][PB];
+  __shared__ __attribute__((aligned(16))) T g_cont[2][NWAVE][PB];
+  __shared__ __attribute__((aligned(16))) T s_rk[2][PB];
+  __shared__ __attribute__((aligned(16))) T s_rkg[2][PB];
+  __shared__ int s_ok[2];
+  __shared__ int pl_pos[2 * PB], pl_val[2 * PB], pl_cnt;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, w = blockIdx.x;
+  const int pw = (n - k0) < PB ? (n - k0) : PB;
+  const long long grow = (long long)k0 + (long long)w * BLOCK + tid;  // this thread's row
+  const bool have = grow < n;
+  T a[PB];
+#pragma unroll
+  for (int c = 0; c < PB; c++) a[c] = (have && c < pw) ? W[grow * ld + k0 + c] : T(0);
+  if (w == 0) {
+    for (int i = tid; i < PB; i += BLOCK) { pl_pos[i] = k0 + i; pl_val[i] = k0 + i; }
+    if (tid == 0) pl_cnt = 0;
+  }
+  if (tid == 0) { s_ok[0] = 1; s_ok[1] = 1; }
+  __syncthreads();
+#pragma unroll 1
+  for (int j = 0; j < PB; j++) {
+    const int pb = j & 1;
+    if (j < pw) {  // (uniform: the last panel may be narrower; the frame still rotates PB times)
+      const int k = k0 + j;
+      const unsigned long long tag = LU_MAGIC ^ ((unsigned long long)(k + 1) * LU_EPOCH_MUL) ^ nonce;
+      // ---- A: this workgroup's candidate: largest |a_ik| among its rows i >= k, first such row
+      const bool act = have && grow >= k;
+      T v = act ? dev_abs(a[0]) : T(-1);
+      int key = act ? (int)grow : 0x7fffffff;
+      wave_argmax<T>(v, key);
+      const int wkey = __builtin_amdgcn_readlane(key, 63);
+      if (act && (int)grow == wkey) {
+#pragma unroll
+        for (int c = 0; c < PB; c++) s_cand[pb][wid][c] = a[c];
+      }
+      if (lane == 63) { s_val[pb][wid] = v; s_row[pb][wid] = key; }
+      if (have && grow == k) {
+#pragma unroll
+        for (int c = 0; c < PB; c++) s_rk[pb][c] = a[c];
+      }
+      __syncthreads();
+      T bv = s_val[pb][0];
+      int br = s_row[pb][0], bw = 0;
+#pragma unroll
+      for (int q = 1; q < NWAVE; q++)
+        if (s_val[pb][q] > bv || (s_val[pb][q] == bv && s_row[pb][q] < br)) { bv = s_val[pb][q]; br = s_row[pb][q]; bw = q; }
+      const T* u = s_cand[pb][bw];
+      const T* rk = s_rk[pb];
+      int p = br;
+      if (nW > 1) {
+        // ---- B: publish {|value|, row, entries} — PB + 2 lanes, one pair each
+        unsigned long long* rec = box + ((long long)(j * nW + w) * REC) * 2;
+        if (tid < REC) {
+          const unsigned long long bits = tid == 0 ? lu_bits(bv) : (tid == 1 ? (unsigned long long)(unsigned)br : lu_bits(s_cand[pb][bw][tid >= 2 ? tid - 2 : 0]));
+          lu_publish_t(rec + 2 * tid, bits, tag);
+        }
+        if (w == 0 && tid >= 128 && tid < 128 + PB)  // row k lives in workgroup 0 (PB <= 256)
+          lu_publish_t(boxk + ((long long)j * PB + (tid - 128)) * 2, lu_bits(s_rk[pb][tid - 128]), tag);
+        // every wave folds its share of the candidates, contents included
+        T cv = T(-1);
+        int cr = 0x7fffffff, spins = 0;
+        unsigned long long best0 = 0, best1 = 0;
+        bool ok = true;
+        const bool has0 = lane < REC, has1 = lane + 64 < REC;
+        for (int cand = wid; cand < nW && ok; cand += NWAVE) {
+          const unsigned long long* crec = box + ((long long)(j * nW + cand) * REC) * 2;
+          unsigned long long b0 = 0, b1 = 0;
+          for (;;) {
+            const bool got = (!has0 || lu_poll_t(crec + 2 * lane, b0, tag)) && (!has1 || lu_poll_t(crec + 2 * (lane + 64), b1, tag));
+            if (__builtin_amdgcn_ballot_w64(!got) == 0ull) break;
+            if (++spins > LU_SPIN_LIMIT || ((spins & 255) == 0 && __hip_atomic_load(abortflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          if (ok) {
+            T x;
+            lu_from_bits(lane_bcast_u64<0>(b0), x);
+            const int r = (int)lane_bcast_u64<1>(b0);
+            if (x > cv || (x == cv && r < cr)) { cv = x; cr = r; best0 = b0; best1 = b1; }
+          }
+        }
+        if (wid == NWAVE - 1 && ok) {  // row k, for the owner of the pivot row
+          unsigned long long kb = 0;
+          for (;;) {
+            const bool got = lane >= PB || lu_poll_t(boxk + ((long long)j * PB + lane) * 2, kb, tag);
+            if (__builtin_amdgcn_ballot_w64(!got) == 0ull) break;
+            if (++spins > LU_SPIN_LIMIT || ((spins & 255) == 0 && __hip_atomic_load(abortflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          if (lane < PB) { T y; lu_from_bits(kb, y); s_rkg[pb][lane] = y; }
+        }
+        if (lane == 0) { g_val[pb][wid] = cv; g_row[pb][wid] = cr; }
+        if (lane >= 2 && lane < REC) { T y; lu_from_bits(best0, y); g_cont[pb][wid][lane - 2] = y; }
+        if (has1) { T y; lu_from_bits(best1, y); g_cont[pb][wid][lane + 62] = y; }
+        if (!ok && lane == 0) s_ok[pb] = 0;
+        __syncthreads();
+        if (!s_ok[pb]) {
+          if (tid == 0) { atomicOr(status, 16); __hip_atomic_store(abortflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+          return;
+        }
+        T gv = g_val[pb][0];
+        int gr = g_row[pb][0], gw = 0;
+#pragma unroll
+        for (int q = 1; q < NWAVE; q++)
+          if (g_val[pb][q] > gv || (g_val[pb][q] == gv && g_row[pb][q] < gr)) { gv = g_val[pb][q]; gr = g_row[pb][q]; gw = q; }
+        p = gr;
+        u = g_cont[pb][gw];
+        rk = s_rkg[pb];
+      }
+      if (p < k || p >= n) p = k;  // (a column of NaNs has no maximum: no interchange, the NaNs spread)
+      // ---- C: the interchange k <-> p, scale, rank-1 update of the later columns (positions 1 .. PB-1-j)
+      if (p != k && have) {
+        if ((int)grow == p) {
+#pragma unroll
+          for (int c = 0; c < PB; c++) a[c] = rk[c];
+        } else if ((int)grow == k) {
+#pragma unroll
+          for (int c = 0; c < PB; c++) a[c] = u[c];
+        }
+      }
+      if (w == 0 && wid == 0) {
+        if (lane == 0) ipiv[k] = p;
+        // net permutation: entry j is position k; the entry of position p is in the top block or among the displaced
+        int ep;
+        if (p < k0 + PB) {
+          ep = p - k0;
+        } else {
+          const int cnt = pl_cnt;
+          const bool hit = lane < cnt && pl_pos[PB + lane] == p;
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+          if (m) {
+            ep = PB + (int)__builtin_ctzll(m);
+          } else {
+            ep = PB + cnt;
+            if (lane == 0) { pl_pos[ep] = p; pl_val[ep] = p; pl_cnt = cnt + 1; }
+          }
+        }
+        if (lane == 0 && ep != j) { const int t = pl_val[j]; pl_val[j] = pl_val[ep]; pl_val[ep] = t; }
+      }
+      const T piv = u[0];
+      if (piv == T(0) && w == 0 && tid == 0) atomicOr(info, 1);
+      const T rp = piv == T(0) ? T(1) : T(1) / piv;
+      if (have && grow > k) {
+        const T l = a[0] * rp;
+        a[0] = l;
+        const int live = PB - j;  // positions 1 .. live-1 hold the later columns
+#pragma unroll
+        for (int c0 = 1; c0 < PB; c0 += 8) {
+          if (c0 < live) {
+#pragma unroll
+            for (int c = c0; c < c0 + 8 && c < PB; c++)
+              if (c < live) a[c] -= l * u[c];
+          }
+        }
+      }
+    }
+    // rotate the frame: the finished column goes to the back
+    const T t0 = a[0];
+#pragma unroll
+    for (int c = 0; c + 1 < PB; c++) a[c] = a[c + 1];
+    a[PB - 1] = t0;
+  }
+  if (have) {
+#pragma unroll
+    for (int c = 0; c < PB; c++)
+      if (c < pw) W[grow * ld + k0 + c] = a[c];
+  }
+  if (w == 0) {
+    __syncthreads();
+    const int total = PB + pl_cnt;
+    if (tid == 0) plist[0] = total;
+    for (int i = tid; i < total; i += BLOCK) { plist[1 + 2 * i] = pl_pos[i]; plist[2 + 2 * i] = pl_val[i]; }
+  }
+}
+
+// Interchanges of one panel applied to every column outside it, and U12 = L11^-1 A12 for those to its right:
+// one thread per column.  plist = {count, (position, original row now at that position) ...} from the panel
+// kernel; entries 0 .. PB-1 are the panel's own rows.  A column is independent of every other: its <= 2 PB
+// touched values are all loaded before any is stored.
+template <class T, int PB, int CB>
+__global__ __launch_bounds__(CB) void lu_swap_u12_kernel(T* __restrict__ W, long long ld, int n, int k0, int pw,
+                                                        const int* __restrict__ plist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lu_smem[];
+  T* xs = (T*)lu_smem;          // [PB][CB]: the panel's rows of this column block, then the solution
+  T* Ls = xs + PB * CB;         // [PB][PB + 1]: L11 (strictly lower part)
+  __shared__ int e_dst[2 * PB], e_src[2 * PB];
+  const int tid = threadIdx.x;
+  const long long cc = (long long)blockIdx.x * CB + tid;
+  const bool have = cc < n - pw;
+  const long long c = cc < k0 ? cc : cc + pw;
+  const bool right = c >= k0 + pw;
+  const int total = plist[0];
+  for (int i = tid; i < 2 * PB; i += CB) {
+    e_dst[i] = i < total ? plist[1 + 2 * i] : 0;
+    e_src[i] = i < total ? plist[2 + 2 * i] : 0;
+  }
+  for (int e = tid; e < PB * PB; e += CB) {
+    const int r = e / PB, q = e - r * PB;
+    Ls[r * (PB + 1) + q] = (r < pw && q < r) ? W[(long long)(k0 + r) * ld + k0 + q] : T(0);
+  }
+  __syncthreads();
+  if (have) {
+#pragma unroll 8
+    for (int i = 0; i < pw; i++) xs[i * CB + tid] = W[(long long)e_src[i] * ld + c];
+  }
+  T d[PB];
+#pragma unroll
+  for (int i = 0; i < PB; i++) {
+    const bool mv = have && PB + i < total && e_dst[PB + i] != e_src[PB + i];
+    d[i] = mv ? W[(long long)e_src[PB + i] * ld + c] : T(0);
+  }
+#pragma unroll
+  for (int i = 0; i < PB; i++) {
+    const bool mv = have && PB + i < total && e_dst[PB + i] != e_src[PB + i];
+    if (mv) W[(long long)e_dst[PB + i] * ld + c] = d[i];
+  }
+  if (have && right) {
+    // forward substitution, unit diagonal; four partial sums break the FMA dependency chain
+    for (int r = 1; r < pw; r++) {
+      T s0 = xs[r * CB + tid], s1 = T(0), s2 = T(0), s3 = T(0);
+      int q = 0;
+      for (; q + 3 < r; q += 4) {
+        s0 -= Ls[r * (PB + 1) + q] * xs[q * CB + tid];
+        s1 -= Ls[r * (PB + 1) + q + 1] * xs[(q + 1) * CB + tid];
+        s2 -= Ls[r * (PB + 1) + q + 2] * xs[(q + 2) * CB + tid];
+        s3 -= Ls[r * (PB + 1) + q + 3] * xs[(q + 3) * CB + tid];
+      }
+      for (; q < r; q++) s0 -= Ls[r * (PB + 1) + q] * xs[q * CB + tid];
+      xs[r * CB + tid] = (s0 + s1) + (s2 + s3);
+    }
+  }
+  if (have) {
+#pragma unroll 8
+    for (int i = 0; i < pw; i++) W[(long long)(k0 + i) * ld + c] = xs[i * CB + tid];
+  }
+}
+
+template <class T, int PB>
+int getrf_blocked2(long long n, const T* A, T* LU, long long* perm, T* sign, T* logabs, int flag_singular) {
+  constexpr int CB = 64;
+  hipStream_t st = pthip::ctx().stream;
+  const int dt = sizeof(T) == 8 ? PTHIP_F64 : PTHIP_F32;
+  const int nWmax = (int)((n + BLOCK - 1) / BLOCK);
+  if (nWmax > pthip::kNumCU)
+    return pthip::set_error("pthip_getrf: n = %lld needs %d co-resident panel workgroups (the device has %d CUs)", n, nWmax, pthip::kNumCU);
+  const size_t boxbytes = (size_t)PB * nWmax * (PB + 2) * 16, boxkbytes = (size_t)PB * PB * 16;
+  const size_t ibytes = ((size_t)n * sizeof(int) + 255) / 256 * 256;
+  const size_t pbytes = ((size_t)(1 + 4 * PB) * sizeof(int) + 255) / 256 * 256;
+  void* scratch = nullptr;
+  int r = pthip_alloc(boxbytes + boxkbytes + ibytes + pbytes + 256, &scratch);
+  if (r) return r;
+  auto fail = [&](int rc) { pthip_free(scratch); return rc; };
+  unsigned long long* box = (unsigned long long*)scratch;
+  unsigned long long* boxk = (unsigned long long*)((char*)scratch + boxbytes);
+  int* ipiv = (int*)((char*)scratch + boxbytes + boxkbytes);
+  int* plist = (int*)((char*)scratch + boxbytes + boxkbytes + ibytes);
+  int* flags = (int*)((char*)scratch + boxbytes + boxkbytes + ibytes + pbytes);  // [0] info, [1] abort
+  static unsigned long long calls = 0;
+  const unsigned long long nonce = (++calls) * 0xD1B54A32D192ED03ull;
+  // (one fill for the whole call: the pair tags carry the column index, a stale pair of an earlier panel never validates)
+  if (hipError_t e = pthip::memset_async(scratch, 0, boxbytes + boxkbytes + ibytes + pbytes + 256, st); e != hipSuccess)
+    return fail(pthip::check(e, "lu scratch memset"));
+  if (hipError_t e = pthip::memcpy_async(LU, A, (size_t)n * n * sizeof(T), hipMemcpyDeviceToDevice, st); e != hipSuccess)
+    return fail(pthip::check(e, "lu copy"));
+  auto ks = lu_swap_u12_kernel<T, PB, CB>;
+  const size_t sh = ((size_t)PB * CB + (size_t)PB * (PB + 1)) * sizeof(T);
+  static bool attr = false;
+  if (!attr && sh > 48 * 1024) {
+    if (hipError_t e = hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); e != hipSuccess)
+      return fail(pthip::check(e, "lu_swap_u12 attribute"));
+    attr = true;
+  }
+  for (long long k0 = 0; k0 < n; k0 += PB) {
+    const int pw = (int)((n - k0) < PB ? (n - k0) : PB);
+    const int nW = (int)((n - k0 + BLOCK - 1) / BLOCK);
+    PTHIP_KLAUNCH((lu_panel2_kernel<T, PB>), dim3((unsigned)nW), dim3(BLOCK), 0, st, LU, n, (int)n, (int)k0, nW, box, boxk, ipiv, plist, flags,
+                  flags + 1, pthip::ctx().status_dev, nonce);
+    if ((r = pthip::post_launch("lu_panel2"))) return fail(r);
+    if (n - pw > 0) {
+      PTHIP_KLAUNCH(ks, dim3((unsigned)((n - pw + CB - 1) / CB)), dim3(CB), sh, st, LU, n, (int)n, (int)k0, pw, (const int*)plist);
+      if ((r = pthip::post_launch("lu_swap_u12"))) return fail(r);
+    }
+    const long long rest = n - k0 - pw;
+    if (rest > 0) {
+      r = pthip::gemm_inplace(dt, rest, rest, pw, -1.0, LU + (k0 + pw) * n + k0, n, 1, LU + k0 * n + k0 + pw, n, 1, 1.0,
+                              LU + (k0 + pw) * n + k0 + pw, n);
+      if (r) return fail(r);
+    }
+  }
+  auto kf = lu_finish_kernel<T>;
+  const size_t shf = (size_t)n * sizeof(int);
+  static bool attrf = false;
+  if (!attrf && shf > 48 * 1024) {
+    if (hipError_t e = hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); e != hipSuccess)
+      return fail(pthip::check(e, "lu_finish attribute"));
+    attrf = true;
+  }
+  PTHIP_KLAUNCH(kf, dim3(1), dim3(BLOCK), shf, st, (const T*)LU, n, (int)n, (const int*)ipiv, (const int*)flags, perm, sign, logabs,
+                flag_singular ? pthip::ctx().status_dev : (int*)nullptr);
+  r = pthip::post_launch("lu_finish");
+  pthip_free(scratch);
+  return r;
+}
+
 template <class T>
 int getrf_typed(long long batch, long long n, const void* A, void* LU, void* perm, void* sign,
                 void* logabs, int flag_singular) {
@@ -683,8 +1044,17 @@ int getrf_typed(long long batch, long long n, const void* A, void* LU, void* per
     return r;
   }
   // beyond one CU's LDS: the blocked factorisation, one matrix after the other
+  // (PTHIP_LU_PANEL: "v1" = the round-3 unrolled 32-column panel, "32" / "64" = the looped panel of that width)
+  static const char* panel_env = getenv("PTHIP_LU_PANEL");
+  static const int panel = panel_env == nullptr ? 64 : (!strcmp(panel_env, "v1") ? 0 : atoi(panel_env));
   for (long long b = 0; b < batch; b++) {
-    int r = getrf_blocked<T>(n, (const T*)A + b * n * n, (T*)LU + b * n * n, (long long*)perm + b * n, (T*)sign + b, (T*)logabs + b, flag_singular);
+    const T* Ab = (const T*)A + b * n * n;
+    T* LUb = (T*)LU + b * n * n;
+    long long* pb = (long long*)perm + b * n;
+    int r;
+    if (panel == 0) r = getrf_blocked<T>(n, Ab, LUb, pb, (T*)sign + b, (T*)logabs + b, flag_singular);
+    else if (panel == 32) r = getrf_blocked2<T, 32>(n, Ab, LUb, pb, (T*)sign + b, (T*)logabs + b, flag_singular);
+    else r = getrf_blocked2<T, 64>(n, Ab, LUb, pb, (T*)sign + b, (T*)logabs + b, flag_singular);
     if (r) return r;
   }
   return 0;

@@ -7,6 +7,7 @@
 #include <hip/hiprtc.h>
 #include <time.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -485,6 +486,91 @@ int pthip_plan_replay3(void* ga, void* la, void* gb, void* lb, void* gc, void* l
   if (sync) PTHIP_CHECK(hipStreamSynchronize(s0));
   tr.lap(4);
   tr.done();
+  return 0;
+}
+
+// ---- replay through a descriptor, completion by polling --------------------------------------
+// What a replay costs beyond its kernels is fixed cost (tools/ubench/call_lat.hip, MI355X): waiting for the
+// stream's completion signal is ~5 us slower than polling a word the LAST kernel of the plan stores into
+// pinned host memory behind its results (system-scope release).  `done_word` (pinned, inside the plan's
+// result block) is cleared here before anything is launched and polled afterwards; the stream itself is
+// synchronised every 256th poll-mode call so that the runtime retires its completion signals.
+//   flags bit 0  the latency-chain segment (A, stream 1) reads its staged parameters straight from the pinned
+//                block, so it does not depend on the parameter upload: no event between the upload and B
+int pthip_plan_replay4(const pthip_replay_desc* d, void* host_out, volatile int* done_word, int sync) {
+  PTHIP_REQUIRE_INIT();
+  if (sync != 2 && !(d->flags & 1))
+    return pthip_plan_replay3(d->ga, d->la, d->gb, d->lb, d->gc, d->lc, d->dev_in, d->host_in, d->in_bytes, d->dev_out,
+                              host_out, d->out_bytes, sync);
+  static hipEvent_t ev_in = nullptr, ev_a = nullptr;
+  static unsigned long long calls = 0;
+  hipStream_t s0 = g_ctx.streams[0];
+  if (sync == 2) {
+    if (!done_word) return set_error("pthip_plan_replay4: poll mode without a done word");
+    *done_word = 0;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+  }
+  if (d->in_bytes) PTHIP_CHECK(hipMemcpyAsync(d->dev_in, d->host_in, d->in_bytes, hipMemcpyHostToDevice, s0));
+  if ((d->ga || d->la) && (d->gc || d->lc)) {
+    if (!g_ctx.streams[1]) PTHIP_CHECK(create_stream(1));
+    hipStream_t s1 = g_ctx.streams[1];
+    if (!ev_in) {
+      PTHIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+      PTHIP_CHECK(hipEventCreateWithFlags(&ev_a, hipEventDisableTiming));
+    }
+    const bool a_free = (d->flags & 1) != 0;
+    if (!a_free) PTHIP_CHECK(hipEventRecord(ev_in, s0));
+    if (int r = run_segment(d->gb, d->lb, s0)) return r;
+    if (!a_free) PTHIP_CHECK(hipStreamWaitEvent(s1, ev_in, 0));
+    if (int r = run_segment(d->ga, d->la, s1)) return r;
+    PTHIP_CHECK(hipEventRecord(ev_a, s1));
+    PTHIP_CHECK(hipStreamWaitEvent(s0, ev_a, 0));
+    if (int r = run_segment(d->gc, d->lc, s0)) return r;
+  } else {
+    if (int r = run_segment(d->gb, d->lb, s0)) return r;
+  }
+  if (d->out_bytes) PTHIP_CHECK(hipMemcpyAsync(host_out, d->dev_out, d->out_bytes, hipMemcpyDeviceToHost, s0));
+  if (sync == 1) PTHIP_CHECK(hipStreamSynchronize(s0));
+  if (sync == 2) {
+    timespec t0{};
+    unsigned long long spins = 0;
+    while (__atomic_load_n((const int*)done_word, __ATOMIC_ACQUIRE) == 0) {
+      __builtin_ia32_pause();
+      if ((++spins & 0x3fff) == 0) {
+        timespec t;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        if (!t0.tv_sec) t0 = t;
+        else if (t.tv_sec - t0.tv_sec >= 10) {
+          // the word never arrived: let the stream say what happened (an asynchronous fault surfaces here)
+          PTHIP_CHECK(hipStreamSynchronize(s0));
+          if (__atomic_load_n((const int*)done_word, __ATOMIC_ACQUIRE) == 0)
+            return set_error("pthip_plan_replay4: the plan finished without storing its done word");
+          break;
+        }
+      }
+    }
+    if ((++calls & 255) == 0) {
+      PTHIP_CHECK(hipStreamSynchronize(s0));
+      if (g_ctx.streams[1]) PTHIP_CHECK(hipStreamSynchronize(g_ctx.streams[1]));
+    }
+  }
+  return 0;
+}
+
+// A zero-initialised int32 slot in device memory for a "last workgroup continues" ticket (the generated
+// tail kernel: every workgroup shrinks one piece of a partial slab, the last one to finish runs the chain
+// and puts the slot back to zero).  Slots come from one 256 KiB block, handed out round-robin.
+int pthip_ticket_slot(void** slot) {
+  PTHIP_REQUIRE_INIT();
+  constexpr size_t N = 65536;
+  static int* base = nullptr;
+  static size_t next = 0;
+  if (!base) {
+    PTHIP_CHECK(hipMalloc((void**)&base, N * sizeof(int)));
+    PTHIP_CHECK(hipMemset(base, 0, N * sizeof(int)));
+    PTHIP_CHECK(hipDeviceSynchronize());
+  }
+  *slot = (void*)(base + (next++ % N));
   return 0;
 }
 

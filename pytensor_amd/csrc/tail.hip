@@ -14,77 +14,23 @@
 // deterministic, independent of scheduling.
 #include "common.h"
 #include "reduce_device.h"
+#include "tail_device.h"
 
 using namespace pthip_dev;
 
 namespace {
 
-constexpr int BLOCK = 256;
-constexpr int TILE = 16;          // columns per block
-constexpr int LANES = BLOCK / TILE;  // row lanes per column
+constexpr int BLOCK = TAIL_SHRINK_BLOCK;
+constexpr int TILE = TAIL_SHRINK_TILE;
 constexpr int MAX_TASKS = 16;
+using Tasks = TailTasksT<MAX_TASKS>;
 
-struct Tasks {
-  int n;
-  int op[MAX_TASKS];              // pthip_reduce_op (ADD / MUL / MAX / MIN)
-  const void* part[MAX_TASKS];    // [nparts, M] row-major
-  long long nparts[MAX_TASKS];
-  long long M[MAX_TASKS];
-  int S[MAX_TASKS];               // row chunks
-  void* out[MAX_TASKS];           // [S, M] (accumulator dtype)
-  int blk0[MAX_TASKS + 1];        // first block of each task; a task owns tiles(M) * S blocks
-};
-
-template <class Op, class T>
-__device__ __forceinline__ void shrink_tile(const T* __restrict__ part, long long p0, long long p1, long long M,
-                                            T* __restrict__ out_row, long long col0, T* smem) {
-  const int c = threadIdx.x % TILE, r = threadIdx.x / TILE;
-  const long long col = col0 + c;
-  T a0 = Op::template identity<T>(), a1 = a0, a2 = a0, a3 = a0;
-  if (col < M) {
-    long long p = p0 + r;
-    for (; p + 3 * LANES < p1; p += 4 * LANES) {
-      const T v0 = part[p * M + col], v1 = part[(p + LANES) * M + col];
-      const T v2 = part[(p + 2 * LANES) * M + col], v3 = part[(p + 3 * LANES) * M + col];
-      a0 = Op::apply(a0, v0);
-      a1 = Op::apply(a1, v1);
-      a2 = Op::apply(a2, v2);
-      a3 = Op::apply(a3, v3);
-    }
-    for (; p < p1; p += LANES) a0 = Op::apply(a0, part[p * M + col]);
-  }
-  smem[r * TILE + c] = Op::apply(Op::apply(a0, a1), Op::apply(a2, a3));
-  __syncthreads();
-  if (r == 0 && col < M) {
-    T acc = smem[c];
-#pragma unroll
-    for (int j = 1; j < LANES; j++) acc = Op::apply(acc, smem[j * TILE + c]);
-    out_row[col] = acc;
-  }
-}
-
+// (the piece itself — task / column tile / row chunk of a block, four accumulators per row lane, fixed-order
+//  LDS combine — lives in tail_device.h: the generated tail kernels run the same code as their prologue)
 template <class T>
 __global__ __launch_bounds__(BLOCK) void multi_finish_kernel(Tasks t) {
   __shared__ T smem[BLOCK];
-  int k = 0;
-  while (k + 1 < t.n && (int)blockIdx.x >= t.blk0[k + 1]) k++;
-  const int lb = (int)blockIdx.x - t.blk0[k];
-  const int S = t.S[k];
-  const int s = lb % S;
-  const long long col0 = (long long)(lb / S) * TILE;
-  const long long np = t.nparts[k], M = t.M[k];
-  const long long chunk = (np + S - 1) / S;
-  long long p0 = s * chunk, p1 = p0 + chunk;
-  if (p1 > np) p1 = np;
-  if (p0 > np) p0 = np;
-  const T* part = (const T*)t.part[k];
-  T* out_row = (T*)t.out[k] + (long long)s * M;
-  switch (t.op[k]) {
-    case PTHIP_RED_ADD: shrink_tile<OpAdd, T>(part, p0, p1, M, out_row, col0, smem); break;
-    case PTHIP_RED_MUL: shrink_tile<OpMul, T>(part, p0, p1, M, out_row, col0, smem); break;
-    case PTHIP_RED_MAX: shrink_tile<OpMax, T>(part, p0, p1, M, out_row, col0, smem); break;
-    default: shrink_tile<OpMin, T>(part, p0, p1, M, out_row, col0, smem); break;
-  }
+  tail_shrink_block<T, MAX_TASKS>(t, (int)blockIdx.x, smem);
 }
 
 }  // namespace

@@ -274,20 +274,28 @@ def _plan(node, inputs, env):
     return P, results
 
 
+_FUSE_SHRINK = os.environ.get("PTHIP_TAIL_FUSE_SHRINK", "1") != "0"
+
+
 def _run_fused(node, P, results, env):
     lib = env.lib
-    # launch 1: every large slab -> <= 16 rows
+    # launch 1: every large slab -> <= 16 rows.  When the slabs fit ONE task table of one dtype, that work
+    # becomes the prologue of the chain's own launch instead (last-workgroup ticket, codegen._tail_prologue)
     by_dt = {}
     for t in P.shrink:
         by_dt.setdefault(str(t[1].dtype), []).append(t)
-    for dt, ts in by_dt.items():
-        for c0 in range(0, len(ts), 16):
-            chunk = ts[c0 : c0 + 16]
-            n = len(chunk)
-            ffi.check(lib.pthip_multi_finish(
-                ffi.np_dtype_code(dt), n, (C.c_int * n)(*[t[0] for t in chunk]), (C.c_void_p * n)(*[t[1].ptr for t in chunk]),
-                (C.c_int64 * n)(*[t[2] for t in chunk]), (C.c_int64 * n)(*[t[3] for t in chunk]), (C.c_int * n)(*[t[4] for t in chunk]),
-                (C.c_void_p * n)(*[t[5].ptr for t in chunk])))
+    fuse_shrink = None
+    if _FUSE_SHRINK and len(by_dt) == 1 and 1 <= len(P.shrink) <= codegen.TAIL_SHRINK_MAX_TASKS:
+        fuse_shrink = {"dtype": next(iter(by_dt))}
+    if fuse_shrink is None:
+        for dt, ts in by_dt.items():
+            for c0 in range(0, len(ts), 16):
+                chunk = ts[c0 : c0 + 16]
+                n = len(chunk)
+                ffi.check(lib.pthip_multi_finish(
+                    ffi.np_dtype_code(dt), n, (C.c_int * n)(*[t[0] for t in chunk]), (C.c_void_p * n)(*[t[1].ptr for t in chunk]),
+                    (C.c_int64 * n)(*[t[2] for t in chunk]), (C.c_int64 * n)(*[t[3] for t in chunk]), (C.c_int * n)(*[t[4] for t in chunk]),
+                    (C.c_void_p * n)(*[t[5].ptr for t in chunk])))
     # launch 2: the chain
     # one-element slots first, at static 16-byte cells; vector slots behind them at run-time offsets
     off = 16 * sum(1 for s in P.slots if s["scalar"])
@@ -312,22 +320,41 @@ def _run_fused(node, P, results, env):
     # short operands (the usual case: K- and G-vectors, <= 16-row slabs): the form that requests
     # every global operand before the first step; size classes are part of the kernel identity
     sizes = codegen.tail_preload_sizes(spec, P.ext_len, P.step_n) if os.environ.get("PTHIP_TAIL_PRELOAD", "1") != "0" else None
-    name = "tail_" + codegen.source_key(key + repr(sizes))[:16]
-    src = codegen.tail_chain_source(name, spec, sizes)
-    fn = kernel_cache.get_function(src, name)
     args = [a for e in P.ext_args for a in e] + [("q", o) for o in offs] + [a for s in P.step_args for a in s] + out_args
-    status = getattr(env, "tail_status", None) or (0, 0)
-    args += [("q", status[0]), ("q", status[1])]
+    status = getattr(env, "tail_status", None) or (0, 0, 0)
+    args += [("q", status[0]), ("q", status[1]), ("q", status[2] if len(status) > 2 else 0)]
     buf = struct.pack("<" + "".join(a[0] for a in args), *[a[1] for a in args])
+    grid = 1
+    if fuse_shrink is not None:
+        tasks, grid = codegen.tail_shrink_pack([(t[0], t[1].ptr, t[2], t[3], t[4], t[5].ptr) for t in P.shrink])
+        if len(buf) + len(tasks) + 8 > 4000:
+            # the task table does not fit the 4 KB argument block next to the chain's own arguments: two launches
+            fuse_shrink = None
+            t = P.shrink
+            ffi.check(lib.pthip_multi_finish(
+                ffi.np_dtype_code(str(t[0][1].dtype)), len(t), (C.c_int * len(t))(*[x[0] for x in t]), (C.c_void_p * len(t))(*[x[1].ptr for x in t]),
+                (C.c_int64 * len(t))(*[x[2] for x in t]), (C.c_int64 * len(t))(*[x[3] for x in t]), (C.c_int * len(t))(*[x[4] for x in t]),
+                (C.c_void_p * len(t))(*[x[5].ptr for x in t])))
+            grid = 1
+        else:
+            slot = C.c_void_p()
+            ffi.check(lib.pthip_ticket_slot(C.byref(slot)))
+            buf += tasks + struct.pack("<Q", slot.value)
+    name = "tail_" + codegen.source_key(key + repr(sizes) + repr(fuse_shrink))[:16]
+    src = codegen.tail_chain_source(name, spec, sizes, shrink=fuse_shrink)
+    fn = kernel_cache.get_function(src, name)
     if len(buf) > 4000:
         raise _Infeasible("kernel argument block")  # (4 KB kernarg limit: run the members instead)
     kt = env.kernel_timer
     tok = kt.begin() if kt is not None else None
-    ffi.check(lib.pthip_launch(fn, 1, 1, 1, codegen.TAIL_BLOCK, 1, 1, max(off, 16), buf, len(buf)))
+    ffi.check(lib.pthip_launch(fn, grid, 1, 1, codegen.TAIL_BLOCK, 1, 1, max(off, 16), buf, len(buf)))
     if kt is not None:
         kt.end(name, tok)
     if status[1]:
         env.tail_status_done = True
+    if len(status) > 2 and status[2]:
+        env.tail_done_word = True  # this launch stores the completion word; the plan polls it if nothing follows
+        env.tail_launch_mark = int(lib.pthip_launch_count())
     return outs
 
 

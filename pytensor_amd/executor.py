@@ -295,6 +295,12 @@ class Env:
         # launch, carries the error word to the host along with its results
         self.tail_status = None
         self.tail_status_done = False
+        self.tail_done_word = False
+        self.tail_launch_mark = -1
+        # frozen multi-stream plans: nodes of the latency-chain segment that read these graph inputs from the
+        # pinned staging block itself instead of its device copy (plan.py _A_DIRECT)
+        self.direct_nodes = None
+        self.direct_inputs = None
         # inside a Scan step: which step-kernel outputs to keep in the MFMA operand order as well, and
         # the packed images of recent steps (dispatch/scan.py::_pack_plan, dispatch/dotew.py)
         self.scan_ctx = None
@@ -618,8 +624,11 @@ class HipExecutable:
                 n_out = len(node.outputs)
                 b = taken[k]
                 lazy = set(range(1 + (1 - b) * n_out, 1 + (2 - b) * n_out))
+            direct = env.direct_inputs if (env.direct_nodes is not None and env.exe is self and k in env.direct_nodes) else None
             for pos, i in enumerate(node.inputs):
                 v = vals.get(i)
+                if direct is not None and i in direct:
+                    v = direct[i]
                 if v is None:
                     v = None if (lazy is not None and pos in lazy and g.vars[i].const is None and g.vars[i].kind == "tensor") else self._const(i, env)
                 ins.append(v)

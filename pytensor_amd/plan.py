@@ -172,6 +172,24 @@ _OUT_RING = int(os.environ.get("PTHIP_OUT_RING", 4))
 # no hipGraph launch floor, no graph-to-graph boundary); longer ones as captured hipGraphs
 _LIST_MAX = int(os.environ.get("PTHIP_LIST_MAX", 8))
 
+# completion by polling the word the plan's last kernel (the Tail) stores behind its results, instead of waiting
+# for the stream's completion signal (tools/ubench/call_lat.hip: ~5 us per call)
+_POLL = os.environ.get("PTHIP_PLAN_POLL", "1") != "0"
+
+# the latency-chain segment reads its staged parameters straight from the pinned staging block when every
+# consumer there reads them once (a right-hand side): it no longer depends on the parameter upload, and no
+# event sits between that upload and the streaming segment
+_A_DIRECT = os.environ.get("PTHIP_PLAN_A_DIRECT", "1") != "0"
+_A_DIRECT_OPS = ("CholeskyTrsv", "SolveTriangular", "CholeskySolve")
+
+
+class _ReplayDesc(C.Structure):
+    """``pthip_replay_desc`` (include/pthip.h)"""
+
+    _fields_ = [(n, C.c_void_p) for n in ("ga", "la", "gb", "lb", "gc", "lc", "dev_in", "host_in")] + [
+        ("in_bytes", C.c_size_t), ("dev_out", C.c_void_p), ("out_bytes", C.c_size_t), ("flags", C.c_int)]
+
+
 _CAPTURE_ACTIVE = [None]  # the plan currently inside warm-up/capture, if any
 _DEFERRED = []  # plans whose release was requested during somebody else's capture
 
@@ -229,6 +247,16 @@ class FrozenPlan:
         seg = exe.segments if multi_stream else None
         self.segmented = seg is not None and len(set(seg)) == 3 and seg[0] == 0
         self._switch = _SegmentSwitch(self, seg) if self.segmented else None
+        # segment-A nodes that may read staged parameters from the pinned block itself (see _A_DIRECT)
+        self._a_direct_nodes = None
+        if self.segmented and _A_DIRECT and self._staged:
+            staged_vids = {g.inputs[pos] for pos in self._staged}
+            users = [k for k, n in enumerate(g.nodes) if seg[k] == 0 and any(i in staged_vids for i in n.inputs)]
+            if all(g.nodes[k].op in _A_DIRECT_OPS and g.nodes[k].inputs[0] not in staged_vids for k in users):
+                self._a_direct_nodes = frozenset(users)
+        self._async_pending = False
+        self._poll = False  # set by the capture pass when the Tail kernel is the plan's last launch
+        self._desc = None
         self._out_block = None
         self._out_meta = None
         self._dev_out = None  # packed results on the device, copied out by the replay call itself
@@ -312,6 +340,11 @@ class FrozenPlan:
                 dev_inputs.append(self._resident_devs[pos])
             else:  # non-tensor shared input (cannot happen for freezable graphs: rng graphs stay eager)
                 dev_inputs.append(value)
+        if self._a_direct_nodes is not None:
+            pin_in = _PinnedAsBuffer(blk.ptr, blk.nbytes)
+            env.direct_nodes = self._a_direct_nodes
+            env.direct_inputs = {exe.graph.inputs[pos]: DeviceArray(pin_in, blk.offsets[k], blk.views[k].shape, contiguous_strides(blk.views[k].shape), blk.views[k].dtype)
+                                 for pos, k in self._in_view.items()}
         placed = {}
         if capture and self.fetch_outputs and self._out_block is not None and self._out_block.nbytes <= _ZEROCOPY_MAX:
             # results of the Tail node (the last launch) go straight into the pinned block
@@ -329,7 +362,7 @@ class FrozenPlan:
                 k += 1
             if placed:
                 env.placement.update(placed)
-                env.tail_status = (lib.pthip_status_ptr(), ob.ptr + ob.offsets[-1])
+                env.tail_status = (lib.pthip_status_ptr(), ob.ptr + ob.offsets[-1], (ob.ptr + ob.offsets[-1] + 4) if _POLL else 0)
         if capture:
             env.scheduler = self._switch
             self._begin_segment()
@@ -353,9 +386,10 @@ class FrozenPlan:
                         specs.append((o.shape, o.dtype))
                 # last slot: the device error word (index out of range / singular inverse) rides
                 # along with the results — a replay costs no extra sync to learn about it
-                specs.append(((1,), np.dtype("int32")))
+                # (second word: the completion flag the Tail kernel sets behind its results, polled by the replay)
+                specs.append(((2,), np.dtype("int32")))
                 self._out_block = _PinnedBlock(specs)
-                self._out_block.views[-1][0] = 0
+                self._out_block.views[-1][:] = 0
                 self._out_specs = specs
             ob = self._out_block
             dev_outs = [o.contiguous() for o in outs if not isinstance(o, HostValue)]
@@ -391,6 +425,9 @@ class FrozenPlan:
                     if self._ring is None and _OUT_RING > 0:
                         self._ring = _ResultRing(self._out_specs, _OUT_RING)
             if capture:
+                # poll mode needs the Tail kernel (which stores the completion word) to be the LAST launch
+                self._poll = bool(_POLL and self.fetch_outputs and getattr(env, "tail_done_word", False) and self._dev_out is None
+                                  and getattr(env, "tail_launch_mark", -1) == int(lib.pthip_launch_count()) and not exe.update_map)
                 self._keep += [dev_outs, env.keepalive]
                 if exe.update_map:
                     # update feedback inside the graph: resident[pos] <- outs[o] after every read
@@ -456,25 +493,40 @@ class FrozenPlan:
                     self._ring.free.append(first)
 
     # ------------------------------------------------------------------
-    def _replay(self, sync, out_block=None):
+    def _make_desc(self):
         if self.segmented:
             sa, sb, sc = self._graphs
         else:
             sa, sb, sc = None, self._graphs[0], None
         g = lambda seg: seg[1] if (seg is not None and seg[0] == "graph") else None
         l = lambda seg: seg[1] if (seg is not None and seg[0] == "list") else None
+        v = lambda h: h.value if isinstance(h, C.c_void_p) else h
         nb = self._in_block.nbytes if self._dev_in is not None else 0
         do = self._dev_out
-        ob = (out_block or self._out_block) if do is not None else None
-        rc = self.lib.pthip_plan_replay3(
-            g(sa), l(sa), g(sb), l(sb), g(sc), l(sc), self._dev_in.ptr if nb else None, self._in_block.ptr if nb else None, nb,
-            do.ptr if ob is not None else None, ob.ptr if ob is not None else None, ob.nbytes if ob is not None else 0, int(sync)
-        )
+        d = _ReplayDesc(v(g(sa)), v(l(sa)), v(g(sb)), v(l(sb)), v(g(sc)), v(l(sc)), self._dev_in.ptr if nb else None,
+                        self._in_block.ptr if nb else None, nb, do.ptr if do is not None else None,
+                        self._out_block.nbytes if (do is not None and self._out_block is not None) else 0,
+                        1 if (self._a_direct_nodes is not None and self.segmented) else 0)
+        self._desc = d
+        self._desc_ref = C.byref(d)
+        ob = self._out_block
+        self._done_ptr = (ob.ptr + ob.offsets[-1] + 4) if (ob is not None and self._poll) else None
+        self._sync_mode = 2 if self._poll else 1
+
+    def _replay(self, sync, out_block=None):
+        if self._desc is None:
+            self._make_desc()
+        ob = (out_block or self._out_block) if self._dev_out is not None else None
+        mode = self._sync_mode if sync else 0
+        if mode == 2 and self._async_pending:
+            mode, self._async_pending = 1, False
+        rc = self.lib.pthip_plan_replay4(self._desc_ref, ob.ptr if ob is not None else None, self._done_ptr, mode)
         if rc:
             ffi.check(rc)
 
     def launch_async(self):
         """Enqueue one replay (parameters already in the staging block); no host sync."""
+        self._async_pending = True  # its completion word may still arrive: the next waiting call uses the stream
         self._replay(False)
 
     def __call__(self, *inputs):

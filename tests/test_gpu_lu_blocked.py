@@ -113,3 +113,35 @@ def test_solve_det_inverse_of_a_large_matrix_through_the_graph(hip):
         g = unary("Solve", [2], {"assume_a": "gen", "lower": False, "b_ndim": 2, "transposed": False}, n_in=2)
         (x,) = HipExecutable(g)(A, b)
         np.testing.assert_allclose(x, np.linalg.solve(A, b), rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("panel", ["32", "v1"])
+def test_other_panel_forms_still_match(hip, panel):
+    """``PTHIP_LU_PANEL`` (read once per process) selects the 32-column looped panel or the round-3 unrolled
+    panel kept as the A/B reference of the default 64-column looped panel: same pivots as LAPACK, in a child."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as np, scipy.linalg, sys\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from pytensor_amd import ffi\n"
+        "from pytensor_amd.device import DeviceArray\n"
+        "ffi.init(0)\n"
+        "for n in (200, 300, 1000):\n"
+        "    A = np.random.default_rng(n).normal(size=(n, n))\n"
+        "    d = DeviceArray.from_host(A); LU = DeviceArray.empty(A.shape, A.dtype); perm = DeviceArray.empty((1, n), 'int64')\n"
+        "    sg = DeviceArray.empty((1,), A.dtype); la = DeviceArray.empty((1,), A.dtype)\n"
+        "    ffi.check(ffi.lib().pthip_getrf(ffi.np_dtype_code(A.dtype), 1, n, d.ptr, LU.ptr, perm.ptr, sg.ptr, la.ptr, 0))\n"
+        "    lu_ref, piv = scipy.linalg.lu_factor(A)\n"
+        "    pref = np.arange(n)\n"
+        "    for k, p in enumerate(piv): pref[[k, p]] = pref[[p, k]]\n"
+        "    np.testing.assert_array_equal(perm.to_host()[0], pref)\n"
+        "    np.testing.assert_allclose(LU.to_host(), lu_ref, rtol=1e-9, atol=1e-9)\n"
+        "print('ok')\n"
+    )
+    env = dict(os.environ, PTHIP_LU_PANEL=panel)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
