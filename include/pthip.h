@@ -93,8 +93,14 @@ int pthip_memset(void* dst, int byte, size_t bytes);
  * [host_ptr, host_ptr+bytes) read-only (callers pass a page-aligned interior and hash the ragged
  * ends themselves); the first CPU store into them sets `*dirty_flag` (stable address, readable
  * without a call), restores write access and proceeds.  `release` restores write access and frees
- * the slot.  pthip_h2d opens every slot overlapping its source range first (the runtime may pin it). */
+ * the slot.  pthip_h2d reads a source that overlaps a protected range through pinned bounce buffers (the
+ * protection stays; round 3 lifted it, which marked every overlapping slot dirty).  Ranges known to the HIP
+ * runtime (pinned / registered host memory) are refused. */
 int pthip_guard_protect(const void* host_ptr, size_t bytes, int* slot, const int** dirty_flag);
+/* the ragged ends of the watched array (the partial pages outside the protected interior, at most one page
+ * each) are snapshotted; pthip_guard_clean = "no store faulted since protect AND the ends are unchanged" */
+int pthip_guard_set_edges(int slot, const void* edge0, size_t n0, const void* edge1, size_t n1);
+int pthip_guard_clean(int slot);
 int pthip_guard_release(int slot);
 int pthip_guard_stats(int* slots_in_use, int* slots_active);
 

@@ -133,25 +133,28 @@ class _Sample:
 class _Guard:
     """write-protected interior pages + hashed partial pages at the two ends"""
 
-    __slots__ = ("slot", "flag", "edges", "edge_hash")
+    __slots__ = ("slot", "flag", "_clean")
     late = False
 
     def __init__(self, lo, hi):
         plo = (lo + _PAGE - 1) & ~(_PAGE - 1)
         phi = hi & ~(_PAGE - 1)
+        lib = ffi.lib()
         slot, flag = C.c_int(-1), C.c_void_p()
-        ffi.check(ffi.lib().pthip_guard_protect(plo, phi - plo, C.byref(slot), C.byref(flag)))
+        ffi.check(lib.pthip_guard_protect(plo, phi - plo, C.byref(slot), C.byref(flag)))
         self.slot = slot.value
         self.flag = C.c_int.from_address(flag.value)
-        self.edges = ((lo, plo), (phi, hi))
-        self.edge_hash = self._edges()
-
-    def _edges(self):
-        (a0, a1), (b0, b1) = self.edges
-        return (_hash_range(a0, a1), _hash_range(b0, b1))
+        # the partial pages at the two ends are not protected: the library keeps copies and compares them
+        # (pthip_guard_clean: the dirty flag + two memcmp of < 1 page, one native call per evaluation)
+        try:
+            ffi.check(lib.pthip_guard_set_edges(self.slot, lo, plo - lo, phi, hi - phi))
+        except Exception:
+            self.release()
+            raise
+        self._clean = lib.pthip_guard_clean
 
     def clean(self, a=None):
-        return self.flag.value == 0 and self._edges() == self.edge_hash
+        return self._clean(self.slot) == 1
 
     def release(self):
         if self.slot >= 0:

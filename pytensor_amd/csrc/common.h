@@ -40,7 +40,7 @@ struct Context {
 };
 
 Context& ctx();
-void guard_before_host_read(const void* p, size_t bytes);  // guard.hip
+bool guard_overlaps_active(const void* p, size_t bytes);  // guard.hip: the range is write-protected right now
 // gemm.hip: C (M x N, row stride ldc) <- beta*C + alpha * A @ B in place (element strides)
 int gemm_inplace(int dtype, long long M, long long N, long long K, double alpha, const void* A, long long sA0,
                  long long sA1, const void* B, long long sB0, long long sB1, double beta, void* C, long long ldc);

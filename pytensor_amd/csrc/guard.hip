@@ -9,7 +9,10 @@
 // writable again and returns — the store is re-executed and succeeds.  A clean array costs the call
 // one load of the slot's flag.  Sound for every CPU store (any view, any thread, C extensions);
 // the one thing it cannot see is the kernel writing into the pages on the process's behalf
-// (`read(2)` into the buffer fails with EFAULT instead) — documented in INTEGRATION.md.
+// (`read(2)` / `readinto` / `recv_into` into the buffer fails with EFAULT instead) — documented in
+// INTEGRATION.md and in the help text of the `hip__resident` flag.  Ranges the HIP runtime knows (pinned or
+// registered host memory) are refused: the caller hashes those.  Our own uploads read a protected source
+// through pinned bounce buffers (pthip_h2d, runtime.hip) instead of lifting the protection.
 //
 // Host code only (no kernels); lives in libpthip.so because the handler must be native.
 #include <signal.h>
@@ -29,6 +32,11 @@ struct Slot {
   int used = 0;                // handed out (protect .. release)
   uintptr_t lo = 0, hi = 0;    // page-rounded [lo, hi)
   volatile int dirty = 0;      // a store (or a conservative event) happened since protect
+  // the ragged ends of the array (the partial pages either side of the protected interior), kept as copies:
+  // pthip_guard_clean compares them natively (one call per resident and evaluation instead of two hashes in Python)
+  const unsigned char* edge[2] = {nullptr, nullptr};
+  size_t edge_n[2] = {0, 0};
+  unsigned char edge_copy[2][4096];
 };
 
 Slot g_slots[kSlots];
@@ -112,16 +120,21 @@ int ensure_handler() {
 }  // namespace
 
 namespace pthip {
-// A host range is about to be handed to the HIP runtime as a copy source: the runtime may pin the
-// pages for DMA, which wants them writable.  Overlapping slots are opened (conservatively dirty).
-void guard_before_host_read(const void* p, size_t bytes) {
-  if (!g_installed || !bytes) return;
+// A host range is about to be handed to the HIP runtime as a copy source.  The runtime may pin the pages
+// for DMA, which wants them writable — but a READ of the source is not a write: opening the overlapping
+// slots (the round-3 behaviour) marked them dirty, so two executables holding the same large shared value
+// re-uploaded it on every alternating call.  Instead the caller is told to stage the copy
+// through its own pinned bounce buffers (the CPU reads read-only pages without faulting): the protection
+// stays in place, nobody's slot turns dirty, and a store that lands during the copy still faults and is seen.
+bool guard_overlaps_active(const void* p, size_t bytes) {
+  if (!g_installed || !bytes) return false;
   uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + bytes;
   Lock l;
   for (int k = 0; k < kSlots; ++k) {
     Slot& s = g_slots[k];
-    if (s.active.load(std::memory_order_relaxed) && s.lo < hi && lo < s.hi) open_slot(k);
+    if (s.active.load(std::memory_order_relaxed) && s.lo < hi && lo < s.hi) return true;
   }
+  return false;
 }
 }  // namespace pthip
 
@@ -129,6 +142,21 @@ extern "C" {
 
 int pthip_guard_protect(const void* host_ptr, size_t bytes, int* slot, const int** dirty_flag) {
   if (!host_ptr || !bytes || !slot || !dirty_flag) return ::pthip::set_error("guard_protect: null argument");
+  // memory the HIP runtime knows (hipHostMalloc / hipHostRegister — ours or anybody else's, e.g. torch pinned
+  // memory behind set_value(borrow=True)) must never be write-protected: the device writes through its own
+  // mapping and a CPU-side mprotect makes the driver drop it (profiles/r3b_guard_probe.txt).  The caller
+  // falls back to a content hash (coherence.watch).
+  {
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof at);
+    hipError_t e = hipPointerGetAttributes(&at, host_ptr);
+    if (e == hipSuccess) {
+      if (at.type == hipMemoryTypeHost || at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged)
+        return ::pthip::set_error("guard_protect: the range is pinned / registered with the HIP runtime");
+    } else {
+      (void)hipGetLastError();  // an ordinary pageable pointer: "invalid value" is the expected answer
+    }
+  }
   if (int rc = ensure_handler()) return rc;
   uintptr_t lo = reinterpret_cast<uintptr_t>(host_ptr) & ~uintptr_t(g_page - 1);
   uintptr_t hi = (reinterpret_cast<uintptr_t>(host_ptr) + bytes + g_page - 1) & ~uintptr_t(g_page - 1);
@@ -140,6 +168,7 @@ int pthip_guard_protect(const void* host_ptr, size_t bytes, int* slot, const int
   s.lo = lo;
   s.hi = hi;
   s.dirty = 0;
+  s.edge_n[0] = s.edge_n[1] = 0;
   if (mprotect(reinterpret_cast<void*>(lo), hi - lo, PROT_READ) != 0)
     return ::pthip::set_error("guard_protect: mprotect(PROT_READ) failed for %zu bytes", size_t(hi - lo));
   s.used = 1;
@@ -147,6 +176,30 @@ int pthip_guard_protect(const void* host_ptr, size_t bytes, int* slot, const int
   *slot = k;
   *dirty_flag = const_cast<const int*>(&s.dirty);
   return 0;
+}
+
+int pthip_guard_set_edges(int slot, const void* e0, size_t n0, const void* e1, size_t n1) {
+  if (slot < 0 || slot >= kSlots || !g_slots[slot].used) return ::pthip::set_error("guard_set_edges: bad slot %d", slot);
+  if (n0 > 4096 || n1 > 4096) return ::pthip::set_error("guard_set_edges: an edge is longer than a page");
+  Slot& s = g_slots[slot];
+  s.edge[0] = (const unsigned char*)e0;
+  s.edge[1] = (const unsigned char*)e1;
+  s.edge_n[0] = n0;
+  s.edge_n[1] = n1;
+  if (n0) memcpy(s.edge_copy[0], e0, n0);
+  if (n1) memcpy(s.edge_copy[1], e1, n1);
+  return 0;
+}
+
+// 1: no store reached the protected pages since `protect` and the ragged ends still hold what they held at
+// pthip_guard_set_edges; 0: something changed (or the slot is not in use)
+int pthip_guard_clean(int slot) {
+  if (slot < 0 || slot >= kSlots) return 0;
+  const Slot& s = g_slots[slot];
+  if (!s.used || s.dirty) return 0;
+  for (int e = 0; e < 2; e++)
+    if (s.edge_n[e] && memcmp(s.edge_copy[e], s.edge[e], s.edge_n[e]) != 0) return 0;
+  return 1;
 }
 
 int pthip_guard_release(int slot) {

@@ -655,27 +655,26 @@ int getrf_blocked(long long n, const T* A, T* LU, long long* perm, T* sign, T* l
 // ------------------------------------------------------------------------------------------
 // Round 4: the panel as a LOOP (lu_panel2_kernel) and one launch for interchange + U12 (lu_swap_u12_kernel).
 //
-// What was slow in lu_panel_kernel (142 us per 32 columns = 4.4 us per column, 2.2 us even with ONE workgroup
-// and no cross-workgroup hop): the 32 column bodies were unrolled into straight-line code that runs once —
-// every instruction a cold fetch — and the candidate row was published by one thread with 34 serial stores.
-// Here the column loop is a real loop: each thread still owns one row in registers, but in a ROTATED frame —
-// the current column is always a[0]; after a column the array rotates left by one (the finished multiplier
-// moves to the back), so every register index is a compile-time constant and the body is ~1 K instructions
-// that stay in the instruction cache.  Per column:
-//   A  wave arg-max (DPP), the wave's candidate row -> LDS, barrier, workgroup candidate;
-//   B  (several workgroups) the candidate {|value|, row, the PB row entries} published as epoch-tagged
-//      self-validating 16-byte pairs by PB + 2 lanes at once; wave q of every workgroup polls the candidates of
-//      workgroups q, q + 4, ... WITH their contents (one memory round trip, no second fetch of the winner's
-//      row), keeps the best in registers, -> LDS, barrier, final choice among the four waves.  Workgroup 0
-//      publishes row k the same way (the owner of the pivot row takes it in exchange).
-//   C  interchange in registers, scale by the reciprocal pivot, rank-1 update of the later columns, rotate.
-// LDS buffers alternate with the column parity: two barriers per column (one with a single workgroup).  The
-// pair tag carries the global column index and a per-call nonce: the boxes are zeroed once per call, not once
-// per panel.  Workgroup 0 also keeps the NET permutation of the panel (which original row ends up at each
-// touched position) for lu_swap_u12_kernel: one thread per outside column gathers the <= 2 PB touched rows
-// (all loads before any store — no chain of PB dependent swaps), solves L11 U12 = A12 in LDS for the columns
-// right of the panel, and stores.  Then A22 -= L21 U12 on the MFMA GEMM.  Three launches per PB = 64 columns
-// instead of five per 32.
+// lu_panel_kernel (round 3) spent 4.4 us per column.  Measured with in-kernel clocks (PTHIP_LU_PROF=1,
+// profiles/r4d_getrf_phases.txt), the first looped form of this kernel still spent 1.4 us finding and staging a
+// candidate, 1.1-2.2 us in the cross-workgroup exchange and 1.9 us in the rank-1 update of a 64-wide panel:
+// the single lane that owns the candidate row wrote all PB entries to LDS (twice: candidate and row k for the
+// physical interchange), each wave polled its candidates one after the other, and the update waited for an LDS
+// load per element because every element sat under its own predicate.  This form:
+//   * one ROW per thread in registers, in a ROTATED frame — the current column is always a[0], after a column the
+//     array rotates left by one (compile-time register indices in a real loop; 15 KB of code instead of 270);
+//   * rows never move: a thread tracks the CURRENT POSITION of its row (LAPACK's interchange k <-> p moves the row
+//     at position k to position p: the thread holding position k just notes `cur = p`; the pivot row is done and
+//     remembers k).  Ties still go to the first row in the current order, like idamax.  Rows go to their final
+//     positions when the panel is written back.  No row-k exchange, no second record per column;
+//   * a candidate record = {row, |value| implied by entry 0, the LIVE entries (positions 0 .. PB-1-j)} as epoch-tagged
+//     self-validating 16-byte pairs, one lane each; wave q of every workgroup polls the records of workgroups
+//     q, q+4, ... up to four at a time in ONE round trip, contents included;
+//   * the update loads the pivot row from LDS in batches, then runs select-guarded FMAs.
+// LDS buffers alternate with the column parity: two barriers per column (one with a single workgroup).  The pair
+// tag carries the global column index and a per-call nonce: the boxes are zeroed once per call.  plist tells
+// lu_swap_u12_kernel which original row ends up at each touched position: [0] number of displaced rows,
+// [1 .. PB] the original row now at position k0+i, then (position, original row) pairs of the displaced ones.
 // ------------------------------------------------------------------------------------------
 constexpr unsigned long long LU_EPOCH_MUL = 0x9E3779B97F4A7C15ull;
 
@@ -696,58 +695,61 @@ __device__ __forceinline__ unsigned long long lane_bcast_u64(unsigned long long 
   return ((unsigned long long)hi << 32) | lo;
 }
 
-template <class T, int PB>
+// PROF (PTHIP_LU_PROF=1): thread 0 of workgroup 0 adds up the 100 MHz wall-clock ticks of the phases of every
+// column — [0] A (candidate + barrier), [1] B (publish / poll / barrier), [2] C (update), [3] rotate,
+// [4] shader cycles of the whole loop, [5] its wall ticks — into prof[0..5].
+template <class T, int PB, bool PROF>
 __global__ __launch_bounds__(BLOCK) void lu_panel2_kernel(T* __restrict__ W, long long ld, int n, int k0, int nW,
-                                                         unsigned long long* __restrict__ box,
-                                                         unsigned long long* __restrict__ boxk, int* __restrict__ ipiv,
+                                                         unsigned long long* __restrict__ box, int* __restrict__ ipiv,
                                                          int* __restrict__ plist, int* __restrict__ info,
                                                          int* __restrict__ abortflag, int* __restrict__ status,
-                                                         unsigned long long nonce) {
+                                                         unsigned long long nonce, long long* __restrict__ prof) {
   constexpr int NWAVE = BLOCK / 64;
-  constexpr int REC = PB + 2;  // pairs of a candidate record: |value|, row, PB entries
-  static_assert(PB <= 64 && REC <= 128, "panel width");
+  constexpr int REC = PB + 2;  // pairs of a candidate record: row, (spare), up to PB entries
+  constexpr int GRP = 4;       // candidates a wave polls at once
+  static_assert(PB <= 64 && PB % 8 == 0, "panel width");
   __shared__ T s_val[2][NWAVE], g_val[2][NWAVE];
   __shared__ int s_row[2][NWAVE], g_row[2][NWAVE];
   __shared__ __attribute__((aligned(16))) T s_cand[2][NWAVE][PB];
   __shared__ __attribute__((aligned(16))) T g_cont[2][NWAVE][PB];
-  __shared__ __attribute__((aligned(16))) T s_rk[2][PB];
-  __shared__ __attribute__((aligned(16))) T s_rkg[2][PB];
   __shared__ int s_ok[2];
-  __shared__ int pl_pos[2 * PB], pl_val[2 * PB], pl_cnt;
+  __shared__ int pl_cnt;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, w = blockIdx.x;
   const int pw = (n - k0) < PB ? (n - k0) : PB;
-  const long long grow = (long long)k0 + (long long)w * BLOCK + tid;  // this thread's row
+  const long long grow = (long long)k0 + (long long)w * BLOCK + tid;  // the row this thread loaded
   const bool have = grow < n;
+  int cur = have ? (int)grow : 0x7fffffff;  // its current position under the interchanges so far
+  bool done = false;                        // it became a pivot row (cur = its final position then)
   T a[PB];
 #pragma unroll
   for (int c = 0; c < PB; c++) a[c] = (have && c < pw) ? W[grow * ld + k0 + c] : T(0);
-  if (w == 0) {
-    for (int i = tid; i < PB; i += BLOCK) { pl_pos[i] = k0 + i; pl_val[i] = k0 + i; }
-    if (tid == 0) pl_cnt = 0;
-  }
-  if (tid == 0) { s_ok[0] = 1; s_ok[1] = 1; }
+  if (tid == 0) { s_ok[0] = 1; s_ok[1] = 1; pl_cnt = 0; }
   __syncthreads();
+  long long pt[4] = {0, 0, 0, 0}, tq = 0, c_start = 0, w_start = 0;
+  if constexpr (PROF) { c_start = clock64(); w_start = wall_clock64(); }
 #pragma unroll 1
   for (int j = 0; j < PB; j++) {
     const int pb = j & 1;
+    if constexpr (PROF) tq = wall_clock64();
     if (j < pw) {  // (uniform: the last panel may be narrower; the frame still rotates PB times)
       const int k = k0 + j;
+      const int live = PB - j;  // positions 0 .. live-1 of the frame hold columns j .. PB-1
       const unsigned long long tag = LU_MAGIC ^ ((unsigned long long)(k + 1) * LU_EPOCH_MUL) ^ nonce;
-      // ---- A: this workgroup's candidate: largest |a_ik| among its rows i >= k, first such row
-      const bool act = have && grow >= k;
+      // ---- A: this workgroup's candidate: largest |a_ik| among its rows not yet pivoted, first in the current order
+      const bool act = have && !done;
       T v = act ? dev_abs(a[0]) : T(-1);
-      int key = act ? (int)grow : 0x7fffffff;
+      int key = act ? cur : 0x7fffffff;
       wave_argmax<T>(v, key);
       const int wkey = __builtin_amdgcn_readlane(key, 63);
-      if (act && (int)grow == wkey) {
+      if (act && cur == wkey) {
 #pragma unroll
-        for (int c = 0; c < PB; c++) s_cand[pb][wid][c] = a[c];
+        for (int c0 = 0; c0 < PB; c0 += 8)
+          if (c0 < live) {
+#pragma unroll
+            for (int c = c0; c < c0 + 8; c++) s_cand[pb][wid][c] = a[c];
+          }
       }
       if (lane == 63) { s_val[pb][wid] = v; s_row[pb][wid] = key; }
-      if (have && grow == k) {
-#pragma unroll
-        for (int c = 0; c < PB; c++) s_rk[pb][c] = a[c];
-      }
       __syncthreads();
       T bv = s_val[pb][0];
       int br = s_row[pb][0], bw = 0;
@@ -755,51 +757,56 @@ __global__ __launch_bounds__(BLOCK) void lu_panel2_kernel(T* __restrict__ W, lon
       for (int q = 1; q < NWAVE; q++)
         if (s_val[pb][q] > bv || (s_val[pb][q] == bv && s_row[pb][q] < br)) { bv = s_val[pb][q]; br = s_row[pb][q]; bw = q; }
       const T* u = s_cand[pb][bw];
-      const T* rk = s_rk[pb];
       int p = br;
+      if constexpr (PROF) { const long long t = wall_clock64(); pt[0] += t - tq; tq = t; }
       if (nW > 1) {
-        // ---- B: publish {|value|, row, entries} — PB + 2 lanes, one pair each
+        // ---- B: publish {row, live entries} — one pair per lane
+        const int npairs = live + 2;
         unsigned long long* rec = box + ((long long)(j * nW + w) * REC) * 2;
-        if (tid < REC) {
-          const unsigned long long bits = tid == 0 ? lu_bits(bv) : (tid == 1 ? (unsigned long long)(unsigned)br : lu_bits(s_cand[pb][bw][tid >= 2 ? tid - 2 : 0]));
+        if (tid < npairs && tid != 1) {
+          const unsigned long long bits = tid == 0 ? (unsigned long long)(unsigned)br : lu_bits(s_cand[pb][bw][tid >= 2 ? tid - 2 : 0]);
           lu_publish_t(rec + 2 * tid, bits, tag);
         }
-        if (w == 0 && tid >= 128 && tid < 128 + PB)  // row k lives in workgroup 0 (PB <= 256)
-          lu_publish_t(boxk + ((long long)j * PB + (tid - 128)) * 2, lu_bits(s_rk[pb][tid - 128]), tag);
-        // every wave folds its share of the candidates, contents included
+        // every wave folds its share of the candidates, up to GRP at a time, contents included
         T cv = T(-1);
         int cr = 0x7fffffff, spins = 0;
         unsigned long long best0 = 0, best1 = 0;
         bool ok = true;
-        const bool has0 = lane < REC, has1 = lane + 64 < REC;
-        for (int cand = wid; cand < nW && ok; cand += NWAVE) {
-          const unsigned long long* crec = box + ((long long)(j * nW + cand) * REC) * 2;
-          unsigned long long b0 = 0, b1 = 0;
+        const bool has0 = lane < npairs && lane != 1, has1 = lane + 64 < npairs;
+        for (int base = wid; base < nW && ok; base += NWAVE * GRP) {
+          unsigned long long b0[GRP], b1[GRP];
+#pragma unroll
+          for (int g = 0; g < GRP; g++) { b0[g] = 0; b1[g] = 0; }
           for (;;) {
-            const bool got = (!has0 || lu_poll_t(crec + 2 * lane, b0, tag)) && (!has1 || lu_poll_t(crec + 2 * (lane + 64), b1, tag));
+            bool got = true;
+#pragma unroll
+            for (int g = 0; g < GRP; g++) {
+              const int cand = base + g * NWAVE;
+              if (cand < nW) {
+                const unsigned long long* crec = box + ((long long)(j * nW + cand) * REC) * 2;
+                if (has0) got = lu_poll_t(crec + 2 * lane, b0[g], tag) && got;
+                if (has1) got = lu_poll_t(crec + 2 * (lane + 64), b1[g], tag) && got;
+              }
+            }
             if (__builtin_amdgcn_ballot_w64(!got) == 0ull) break;
             if (++spins > LU_SPIN_LIMIT || ((spins & 255) == 0 && __hip_atomic_load(abortflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { ok = false; break; }
             __builtin_amdgcn_s_sleep(1);
           }
           if (ok) {
-            T x;
-            lu_from_bits(lane_bcast_u64<0>(b0), x);
-            const int r = (int)lane_bcast_u64<1>(b0);
-            if (x > cv || (x == cv && r < cr)) { cv = x; cr = r; best0 = b0; best1 = b1; }
+#pragma unroll
+            for (int g = 0; g < GRP; g++) {
+              if (base + g * NWAVE < nW) {  // (uniform)
+                T x;
+                lu_from_bits(lane_bcast_u64<2>(b0[g]), x);  // entry 0 of the candidate row: its column-k value
+                x = dev_abs(x);
+                const int r = (int)lane_bcast_u64<0>(b0[g]);
+                if (r != 0x7fffffff && (x > cv || (x == cv && r < cr))) { cv = x; cr = r; best0 = b0[g]; best1 = b1[g]; }
+              }
+            }
           }
-        }
-        if (wid == NWAVE - 1 && ok) {  // row k, for the owner of the pivot row
-          unsigned long long kb = 0;
-          for (;;) {
-            const bool got = lane >= PB || lu_poll_t(boxk + ((long long)j * PB + lane) * 2, kb, tag);
-            if (__builtin_amdgcn_ballot_w64(!got) == 0ull) break;
-            if (++spins > LU_SPIN_LIMIT || ((spins & 255) == 0 && __hip_atomic_load(abortflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { ok = false; break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-          if (lane < PB) { T y; lu_from_bits(kb, y); s_rkg[pb][lane] = y; }
         }
         if (lane == 0) { g_val[pb][wid] = cv; g_row[pb][wid] = cr; }
-        if (lane >= 2 && lane < REC) { T y; lu_from_bits(best0, y); g_cont[pb][wid][lane - 2] = y; }
+        if (lane >= 2 && lane < npairs) { T y; lu_from_bits(best0, y); g_cont[pb][wid][lane - 2] = y; }
         if (has1) { T y; lu_from_bits(best1, y); g_cont[pb][wid][lane + 62] = y; }
         if (!ok && lane == 0) s_ok[pb] = 0;
         __syncthreads();
@@ -814,116 +821,123 @@ __global__ __launch_bounds__(BLOCK) void lu_panel2_kernel(T* __restrict__ W, lon
           if (g_val[pb][q] > gv || (g_val[pb][q] == gv && g_row[pb][q] < gr)) { gv = g_val[pb][q]; gr = g_row[pb][q]; gw = q; }
         p = gr;
         u = g_cont[pb][gw];
-        rk = s_rkg[pb];
       }
-      if (p < k || p >= n) p = k;  // (a column of NaNs has no maximum: no interchange, the NaNs spread)
-      // ---- C: the interchange k <-> p, scale, rank-1 update of the later columns (positions 1 .. PB-1-j)
-      if (p != k && have) {
-        if ((int)grow == p) {
-#pragma unroll
-          for (int c = 0; c < PB; c++) a[c] = rk[c];
-        } else if ((int)grow == k) {
-#pragma unroll
-          for (int c = 0; c < PB; c++) a[c] = u[c];
-        }
+      if constexpr (PROF) { const long long t = wall_clock64(); pt[1] += t - tq; tq = t; }
+      // (a column of NaNs has no maximum: p is out of range — no interchange, the NaNs spread as in dgetf2)
+      const bool valid = p >= k && p < n;
+      if (!valid) p = k;
+      // ---- C: the interchange k <-> p as bookkeeping, scale, rank-1 update of the later columns (positions 1 .. live-1)
+      if (act && cur == p) {
+        done = true;
+        cur = k;
+        plist[1 + j] = (int)grow;  // the original row that ends up at position k
+      } else if (act && cur == k) {
+        cur = p;  // (p != k here: the row at position k was not the pivot)
       }
-      if (w == 0 && wid == 0) {
-        if (lane == 0) ipiv[k] = p;
-        // net permutation: entry j is position k; the entry of position p is in the top block or among the displaced
-        int ep;
-        if (p < k0 + PB) {
-          ep = p - k0;
-        } else {
-          const int cnt = pl_cnt;
-          const bool hit = lane < cnt && pl_pos[PB + lane] == p;
-          const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-          if (m) {
-            ep = PB + (int)__builtin_ctzll(m);
-          } else {
-            ep = PB + cnt;
-            if (lane == 0) { pl_pos[ep] = p; pl_val[ep] = p; pl_cnt = cnt + 1; }
-          }
-        }
-        if (lane == 0 && ep != j) { const int t = pl_val[j]; pl_val[j] = pl_val[ep]; pl_val[ep] = t; }
+      if (w == 0 && tid == 0) ipiv[k] = p;
+      T uu0 = valid ? u[0] : T(0);
+      if (!valid) {  // no row was published for a NaN column in the single-workgroup path either: use row k's own value
+        uu0 = T(0);
       }
-      const T piv = u[0];
+      const T piv = uu0;
       if (piv == T(0) && w == 0 && tid == 0) atomicOr(info, 1);
       const T rp = piv == T(0) ? T(1) : T(1) / piv;
-      if (have && grow > k) {
-        const T l = a[0] * rp;
-        a[0] = l;
-        const int live = PB - j;  // positions 1 .. live-1 hold the later columns
+      const bool upd = have && !done;
+      const T l = upd ? a[0] * rp : T(0);
+      if (upd) a[0] = l;
 #pragma unroll
-        for (int c0 = 1; c0 < PB; c0 += 8) {
-          if (c0 < live) {
+      for (int c0 = 0; c0 < PB; c0 += 16) {
+        if (c0 < live) {  // (uniform)
+          T uu[16];
 #pragma unroll
-            for (int c = c0; c < c0 + 8 && c < PB; c++)
-              if (c < live) a[c] -= l * u[c];
+          for (int c = 0; c < 16; c++) uu[c] = u[c0 + c];
+#pragma unroll
+          for (int c = 0; c < 16; c++) {
+            if (c0 + c >= 1) {
+              const T r = a[c0 + c] - l * uu[c];
+              a[c0 + c] = (upd && c0 + c < live) ? r : a[c0 + c];
+            }
           }
         }
       }
     }
+    if constexpr (PROF) { const long long t = wall_clock64(); pt[2] += t - tq; tq = t; }
     // rotate the frame: the finished column goes to the back
     const T t0 = a[0];
 #pragma unroll
     for (int c = 0; c + 1 < PB; c++) a[c] = a[c + 1];
     a[PB - 1] = t0;
+    if constexpr (PROF) {
+      asm volatile("" : "+v"(a[0]), "+v"(a[PB - 1]));
+      const long long t = wall_clock64();
+      pt[3] += t - tq;
+    }
   }
+  if constexpr (PROF) {
+    if (w == 0 && tid == 0) {
+      for (int q = 0; q < 4; q++) prof[q] += pt[q];
+      prof[4] += clock64() - c_start;
+      prof[5] += wall_clock64() - w_start;
+    }
+  }
+  // every row goes to its position (pivot rows: the column they were chosen for; a displaced row: where the
+  // interchanges left it; everything else stays).  All reads of the panel happened before column 0 was agreed on.
   if (have) {
 #pragma unroll
     for (int c = 0; c < PB; c++)
-      if (c < pw) W[grow * ld + k0 + c] = a[c];
+      if (c < pw) W[(long long)cur * ld + k0 + c] = a[c];
   }
+  // displaced rows (they started in the top block — workgroup 0 — and were moved out of it without being chosen)
   if (w == 0) {
+    if (have && !done && cur != (int)grow) {
+      const int e = atomicAdd(&pl_cnt, 1);
+      plist[1 + PB + 2 * e] = cur;
+      plist[2 + PB + 2 * e] = (int)grow;
+    }
     __syncthreads();
-    const int total = PB + pl_cnt;
-    if (tid == 0) plist[0] = total;
-    for (int i = tid; i < total; i += BLOCK) { plist[1 + 2 * i] = pl_pos[i]; plist[2 + 2 * i] = pl_val[i]; }
+    if (tid == 0) plist[0] = pl_cnt;
   }
 }
 
 // Interchanges of one panel applied to every column outside it, and U12 = L11^-1 A12 for those to its right:
-// one thread per column.  plist = {count, (position, original row now at that position) ...} from the panel
-// kernel; entries 0 .. PB-1 are the panel's own rows.  A column is independent of every other: its <= 2 PB
-// touched values are all loaded before any is stored.
+// one thread per column.  plist (from the panel kernel): [0] number of displaced rows, [1 .. PB] the original
+// row that is now at position k0 + i, then (position, original row) pairs.  A column is independent of every
+// other: its <= 2 PB touched values are all LOADED (unconditionally — a predicate per load serialises them)
+// before any is stored.
 template <class T, int PB, int CB>
 __global__ __launch_bounds__(CB) void lu_swap_u12_kernel(T* __restrict__ W, long long ld, int n, int k0, int pw,
                                                         const int* __restrict__ plist) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lu_smem[];
   T* xs = (T*)lu_smem;          // [PB][CB]: the panel's rows of this column block, then the solution
   T* Ls = xs + PB * CB;         // [PB][PB + 1]: L11 (strictly lower part)
-  __shared__ int e_dst[2 * PB], e_src[2 * PB];
+  __shared__ int e_top[PB], e_dst[PB], e_src[PB];
   const int tid = threadIdx.x;
   const long long cc = (long long)blockIdx.x * CB + tid;
   const bool have = cc < n - pw;
-  const long long c = cc < k0 ? cc : cc + pw;
-  const bool right = c >= k0 + pw;
-  const int total = plist[0];
-  for (int i = tid; i < 2 * PB; i += CB) {
-    e_dst[i] = i < total ? plist[1 + 2 * i] : 0;
-    e_src[i] = i < total ? plist[2 + 2 * i] : 0;
+  const long long c = have ? (cc < k0 ? cc : cc + pw) : 0;  // (idle threads read column 0: valid memory, results dropped)
+  const bool right = have && c >= k0 + pw;
+  const int ndisp = plist[0];
+  for (int i = tid; i < PB; i += CB) {
+    e_top[i] = i < pw ? plist[1 + i] : k0;
+    e_dst[i] = i < ndisp ? plist[1 + PB + 2 * i] : k0;
+    e_src[i] = i < ndisp ? plist[2 + PB + 2 * i] : k0;
   }
   for (int e = tid; e < PB * PB; e += CB) {
     const int r = e / PB, q = e - r * PB;
     Ls[r * (PB + 1) + q] = (r < pw && q < r) ? W[(long long)(k0 + r) * ld + k0 + q] : T(0);
   }
   __syncthreads();
-  if (have) {
-#pragma unroll 8
-    for (int i = 0; i < pw; i++) xs[i * CB + tid] = W[(long long)e_src[i] * ld + c];
-  }
   T d[PB];
 #pragma unroll
-  for (int i = 0; i < PB; i++) {
-    const bool mv = have && PB + i < total && e_dst[PB + i] != e_src[PB + i];
-    d[i] = mv ? W[(long long)e_src[PB + i] * ld + c] : T(0);
-  }
+  for (int i = 0; i < PB; i++) d[i] = W[(long long)e_src[i] * ld + c];
+#pragma unroll 16
+  for (int i = 0; i < PB; i++) xs[i * CB + tid] = W[(long long)e_top[i] * ld + c];
+  if (have) {
 #pragma unroll
-  for (int i = 0; i < PB; i++) {
-    const bool mv = have && PB + i < total && e_dst[PB + i] != e_src[PB + i];
-    if (mv) W[(long long)e_dst[PB + i] * ld + c] = d[i];
+    for (int i = 0; i < PB; i++)
+      if (i < ndisp) W[(long long)e_dst[i] * ld + c] = d[i];
   }
-  if (have && right) {
+  if (right) {
     // forward substitution, unit diagonal; four partial sums break the FMA dependency chain
     for (int r = 1; r < pw; r++) {
       T s0 = xs[r * CB + tid], s1 = T(0), s2 = T(0), s3 = T(0);
@@ -939,8 +953,9 @@ __global__ __launch_bounds__(CB) void lu_swap_u12_kernel(T* __restrict__ W, long
     }
   }
   if (have) {
-#pragma unroll 8
-    for (int i = 0; i < pw; i++) W[(long long)(k0 + i) * ld + c] = xs[i * CB + tid];
+#pragma unroll 16
+    for (int i = 0; i < PB; i++)
+      if (i < pw) W[(long long)(k0 + i) * ld + c] = xs[i * CB + tid];
   }
 }
 
@@ -952,18 +967,19 @@ int getrf_blocked2(long long n, const T* A, T* LU, long long* perm, T* sign, T* 
   const int nWmax = (int)((n + BLOCK - 1) / BLOCK);
   if (nWmax > pthip::kNumCU)
     return pthip::set_error("pthip_getrf: n = %lld needs %d co-resident panel workgroups (the device has %d CUs)", n, nWmax, pthip::kNumCU);
-  const size_t boxbytes = (size_t)PB * nWmax * (PB + 2) * 16, boxkbytes = (size_t)PB * PB * 16;
+  const size_t boxbytes = (size_t)PB * nWmax * (PB + 2) * 16, boxkbytes = 0;
   const size_t ibytes = ((size_t)n * sizeof(int) + 255) / 256 * 256;
-  const size_t pbytes = ((size_t)(1 + 4 * PB) * sizeof(int) + 255) / 256 * 256;
+  const size_t pbytes = ((size_t)(1 + 3 * PB) * sizeof(int) + 255) / 256 * 256;
   void* scratch = nullptr;
   int r = pthip_alloc(boxbytes + boxkbytes + ibytes + pbytes + 256, &scratch);
   if (r) return r;
   auto fail = [&](int rc) { pthip_free(scratch); return rc; };
   unsigned long long* box = (unsigned long long*)scratch;
-  unsigned long long* boxk = (unsigned long long*)((char*)scratch + boxbytes);
   int* ipiv = (int*)((char*)scratch + boxbytes + boxkbytes);
   int* plist = (int*)((char*)scratch + boxbytes + boxkbytes + ibytes);
-  int* flags = (int*)((char*)scratch + boxbytes + boxkbytes + ibytes + pbytes);  // [0] info, [1] abort
+  int* flags = (int*)((char*)scratch + boxbytes + boxkbytes + ibytes + pbytes);  // [0] info, [1] abort; [8..] phase ticks (PROF)
+  long long* prof = (long long*)(flags + 8);
+  static const bool prof_on = getenv("PTHIP_LU_PROF") != nullptr;
   static unsigned long long calls = 0;
   const unsigned long long nonce = (++calls) * 0xD1B54A32D192ED03ull;
   // (one fill for the whole call: the pair tags carry the column index, a stale pair of an earlier panel never validates)
@@ -982,8 +998,12 @@ int getrf_blocked2(long long n, const T* A, T* LU, long long* perm, T* sign, T* 
   for (long long k0 = 0; k0 < n; k0 += PB) {
     const int pw = (int)((n - k0) < PB ? (n - k0) : PB);
     const int nW = (int)((n - k0 + BLOCK - 1) / BLOCK);
-    PTHIP_KLAUNCH((lu_panel2_kernel<T, PB>), dim3((unsigned)nW), dim3(BLOCK), 0, st, LU, n, (int)n, (int)k0, nW, box, boxk, ipiv, plist, flags,
-                  flags + 1, pthip::ctx().status_dev, nonce);
+    if (prof_on)
+      PTHIP_KLAUNCH((lu_panel2_kernel<T, PB, true>), dim3((unsigned)nW), dim3(BLOCK), 0, st, LU, n, (int)n, (int)k0, nW, box, ipiv, plist, flags,
+                    flags + 1, pthip::ctx().status_dev, nonce, prof);
+    else
+      PTHIP_KLAUNCH((lu_panel2_kernel<T, PB, false>), dim3((unsigned)nW), dim3(BLOCK), 0, st, LU, n, (int)n, (int)k0, nW, box, ipiv, plist, flags,
+                    flags + 1, pthip::ctx().status_dev, nonce, prof);
     if ((r = pthip::post_launch("lu_panel2"))) return fail(r);
     if (n - pw > 0) {
       PTHIP_KLAUNCH(ks, dim3((unsigned)((n - pw + CB - 1) / CB)), dim3(CB), sh, st, LU, n, (int)n, (int)k0, pw, (const int*)plist);
@@ -1007,6 +1027,12 @@ int getrf_blocked2(long long n, const T* A, T* LU, long long* perm, T* sign, T* 
   PTHIP_KLAUNCH(kf, dim3(1), dim3(BLOCK), shf, st, (const T*)LU, n, (int)n, (const int*)ipiv, (const int*)flags, perm, sign, logabs,
                 flag_singular ? pthip::ctx().status_dev : (int*)nullptr);
   r = pthip::post_launch("lu_finish");
+  if (prof_on && !r) {
+    long long h[6];
+    if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h, prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+      fprintf(stderr, "[pthip lu prof] n=%lld PB=%d f%d: per column us  A %.2f  B %.2f  C %.2f  rotate %.2f | loop %.2f us/col, shader clock %.0f MHz\n", n, PB,
+              (int)sizeof(T) * 8, h[0] * 0.01 / n, h[1] * 0.01 / n, h[2] * 0.01 / n, h[3] * 0.01 / n, h[5] * 0.01 / n, h[5] ? (double)h[4] / (h[5] * 0.01) : 0.0);
+  }
   pthip_free(scratch);
   return r;
 }

@@ -287,7 +287,29 @@ int pthip_h2d(void* dst, const void* src, size_t bytes) {
   if (!bytes) return 0;
   // (a pageable source would be snapshotted at call time by the runtime, not at replay time)
   if (g_ctx.recorder) { g_ctx.recorder->ok = false; g_ctx.recorder->why = "host-to-device copy"; }
-  ::pthip::guard_before_host_read(src, bytes);  // (guard.hip: a write-protected source is opened first)
+  if (::pthip::guard_overlaps_active(src, bytes)) {
+    // the source is write-protected (guard.hip) on behalf of some executable: the runtime would want to pin
+    // its pages writable.  Stage through two pinned bounce buffers instead — the CPU copy reads the
+    // protected pages without faulting, the protection (and every slot's clean flag) stays as it is.
+    constexpr size_t CH = 8u << 20;
+    static void* bounce[2] = {nullptr, nullptr};
+    static hipEvent_t done[2] = {nullptr, nullptr};
+    for (int b = 0; b < 2; b++)
+      if (!bounce[b]) {
+        PTHIP_CHECK(hipHostMalloc(&bounce[b], CH, hipHostMallocDefault));
+        PTHIP_CHECK(hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
+      }
+    size_t off = 0;
+    for (int b = 0; off < bytes; b ^= 1) {
+      const size_t nb = bytes - off < CH ? bytes - off : CH;
+      PTHIP_CHECK(hipEventSynchronize(done[b]));  // (the DMA that last read this buffer)
+      memcpy(bounce[b], (const char*)src + off, nb);
+      PTHIP_CHECK(hipMemcpyAsync((char*)dst + off, bounce[b], nb, hipMemcpyHostToDevice, g_ctx.stream));
+      PTHIP_CHECK(hipEventRecord(done[b], g_ctx.stream));
+      off += nb;
+    }
+    return 0;
+  }
   PTHIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_ctx.stream));
   return 0;
 }

@@ -274,7 +274,10 @@ def _plan(node, inputs, env):
     return P, results
 
 
-_FUSE_SHRINK = os.environ.get("PTHIP_TAIL_FUSE_SHRINK", "1") != "0"
+# measured on config #4 (profiles/r4b_c4_ab.txt): the fused launch is 28 us where multi_finish + gap + tail are 18 — every
+# one of the ~256 shrink workgroups carries the chain kernel's registers and LDS, and the ticket's agent-scope release /
+# acquire fences write back and invalidate L2.  Kept as an opt-in (PTHIP_TAIL_FUSE_SHRINK=1), default off.
+_FUSE_SHRINK = os.environ.get("PTHIP_TAIL_FUSE_SHRINK", "0") == "1"
 
 
 def _run_fused(node, P, results, env):

@@ -65,6 +65,8 @@ SIGNATURES = {
     "pthip_d2d": (_int, [_vp, _vp, _sz]),
     "pthip_memset": (_int, [_vp, _int, _sz]),
     "pthip_guard_protect": (_int, [_vp, _sz, C.POINTER(_int), C.POINTER(_vp)]),
+    "pthip_guard_set_edges": (_int, [_int, _vp, _sz, _vp, _sz]),
+    "pthip_guard_clean": (_int, [_int]),
     "pthip_guard_release": (_int, [_int]),
     "pthip_guard_stats": (_int, [C.POINTER(_int), C.POINTER(_int)]),
     "pthip_arena_begin": (_int, [C.POINTER(_vp)]),

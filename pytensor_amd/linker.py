@@ -105,7 +105,10 @@ def _add_config_flags():
         "hip__resident",
         "How the hip linker keeps the HBM copy of a shared variable coherent with its host array "
         "(which the reference reads on every call): 'guard' write-protects the array's pages and "
-        "re-uploads after the first store (sound, free when nothing changes); 'strict' hashes the "
+        "re-uploads after the first store (sound for every CPU store, free when nothing changes; arrays up to 64 KiB, "
+        "read-only arrays and memory pinned / registered with the HIP runtime are hashed instead; while an array is "
+        "guarded, a kernel-side write INTO it — file.readinto, socket.recv_into, np.fromfile into a view, an MPI "
+        "receive — fails with EFAULT where the reference would accept it: use set_value, or 'strict'); 'strict' hashes the "
         "whole array on every call; 'sampled' checks 256 elements (may miss sparse in-place edits); "
         "'trust' checks identity only.",
         EnumStr(default, [m for m in modes if m != default], mutable=True),

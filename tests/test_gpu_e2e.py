@@ -277,6 +277,36 @@ def test_single_element_edit_of_a_large_borrowed_value_is_seen(pt):
     assert exe.stats["resident_uploads"] > uploads
 
 
+def test_two_functions_over_one_large_shared_value_upload_it_once_each(pt):
+    """Two compiled functions over the SAME large shared value (a predict and a loss function over one
+    weight vector): each keeps its own HBM copy and its own write-protection slot on the one host array.
+    The second function's upload READS pages the first already protects — through pinned bounce buffers
+    (csrc/runtime.hip pthip_h2d), not by lifting the protection, so it does not mark the first one's copy
+    stale: alternating calls upload nothing (they used to re-upload the whole array every call).
+    A real store is still seen by both."""
+    pytensor, ptt = pt
+    assert pytensor.config.hip__resident == "guard"
+    rng = np.random.default_rng(5)
+    w = pytensor.shared(rng.normal(size=1 << 20), name="w", borrow=True)  # 8 MiB: guarded, not hashed
+    x = ptt.dscalar("x")
+    f = pytensor.function([x], (w * x).sum(), mode="hip")
+    g = pytensor.function([x], (w + x).max(), mode="hip")
+    exf, exg = E.hip_executable(f), E.hip_executable(g)
+    vals = w.get_value(borrow=True)
+    for _ in range(2):
+        np.testing.assert_allclose(f(2.0), 2.0 * vals.sum(), rtol=1e-11)
+        np.testing.assert_allclose(g(1.0), vals.max() + 1.0, rtol=1e-12)
+    assert exf.stats["resident_uploads"] == 1 and exg.stats["resident_uploads"] == 1, (exf.stats, exg.stats)
+    for _ in range(6):
+        f(2.0)
+        g(1.0)
+    assert exf.stats["resident_uploads"] == 1 and exg.stats["resident_uploads"] == 1, (exf.stats, exg.stats)
+    vals[12345] = 1e6  # an in-place edit through the borrowed array: both copies are stale now
+    np.testing.assert_allclose(g(1.0), 1e6 + 1.0, rtol=1e-12)
+    np.testing.assert_allclose(f(2.0), 2.0 * vals.sum(), rtol=1e-11)
+    assert exf.stats["resident_uploads"] == 2 and exg.stats["resident_uploads"] == 2, (exf.stats, exg.stats)
+
+
 def test_resident_mode_flag_sampled_is_opt_in(pt):
     """``hip__resident`` is a real config flag (configdefaults.py:183 ``config.add``): the round-2
     behaviour is reachable, and only, through it."""

@@ -145,7 +145,7 @@ def _chol_entries():
     return out
 
 
-def measure(which=("c1", "c2", "c3", "c5", "chol"), reps=20, check=True):
+def measure(which=("c1", "c2", "c3", "c5", "chol", "gp"), reps=20, check=True):
     """Device-event timed replays of BASELINE configs #1, #2, #3, #5 at their stated sizes
     (inputs resident in HBM).  Returns ``{key: {...}}``; imported by ``bench.py`` for the
     ``configs`` field of its JSON line."""
@@ -192,6 +192,17 @@ def measure(which=("c1", "c2", "c3", "c5", "chol"), reps=20, check=True):
                      "kernels_us": {k: round(ms * 1e3, 2) for k, ms in sorted(KERNELS.get("c5_gru", {}).items(), key=lambda t: -t[1])[:4]}}
     if "chol" in which:
         res.update(_chol_entries())
+    if "gp" in which:
+        # an ordinary PyMC-shaped graph on the large-matrix kernels: GP marginal log-likelihood + gradient
+        # (tests/golden/gp_marginal_likelihood), n = 2048 points, as a frozen plan (the graph's shape asserts
+        # are host arithmetic since round 4, pytensor_amd/hostsplit.py); parity: tests/test_gpu_chol_blocked.py
+        import bench_gp
+
+        r = bench_gp.measure(2048, reps=max(3, reps // 2), parity=check, eager=False)
+        res["gp_2048"] = {"config": "GP marginal likelihood + gradient, n = 2048 points, f64 (Cholesky(2048), 2 vector + 2 square triangular solves, 2048^3 products)",
+                          "ms_device": r.get("ms_device"), "ms_call": r.get("ms_plan_call"), "mode": "frozen plan" if "ms_plan_call" in r else "eager: " + r.get("freeze_error", "?"),
+                          "bound": "latency chain of the Cholesky / solves (see chol_2048) + 3 products on the MFMA GEMM",
+                          **({"err_over_eps_cond": max(r["err_over_eps_cond_scale"]), "cond_K": r["cond_K"]} if "cond_K" in r else {})}
     from pytensor_amd.executor import KernelTimer
 
     if KernelTimer.overhead_ms is not None:
@@ -205,7 +216,7 @@ def main():
     reps = 20
     if "--reps" in sys.argv:
         reps = int(sys.argv[sys.argv.index("--reps") + 1])
-    which = [a for a in args if not a.isdigit()] or ["c1", "c2", "c3", "c5", "chol"]
+    which = [a for a in args if not a.isdigit()] or ["c1", "c2", "c3", "c5", "chol", "gp"]
     ffi.init(0)
     # --no-check: skip the oracle comparison (it runs the graphs at a reduced size as well, which
     # would mix small launches into a rocprofv3 kernel summary of this command)
