@@ -714,6 +714,9 @@ __global__ __launch_bounds__(BLOCK) void lu_panel2_kernel(T* __restrict__ W, lon
   __shared__ __attribute__((aligned(16))) T g_cont[2][NWAVE][PB];
   __shared__ int s_ok[2];
   __shared__ int pl_cnt;
+  // bookkeeping stays in LDS until the panel is done: a global store inside the loop is still in flight at the
+  // next barrier (s_waitcnt vmcnt(0) in front of every s_barrier) and was costing ~0.4 us per column
+  __shared__ int s_ipiv[PB], s_top[PB];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, w = blockIdx.x;
   const int pw = (n - k0) < PB ? (n - k0) : PB;
   const long long grow = (long long)k0 + (long long)w * BLOCK + tid;  // the row this thread loaded
@@ -724,6 +727,7 @@ __global__ __launch_bounds__(BLOCK) void lu_panel2_kernel(T* __restrict__ W, lon
 #pragma unroll
   for (int c = 0; c < PB; c++) a[c] = (have && c < pw) ? W[grow * ld + k0 + c] : T(0);
   if (tid == 0) { s_ok[0] = 1; s_ok[1] = 1; pl_cnt = 0; }
+  if (tid < PB) { s_ipiv[tid] = 0; s_top[tid] = -1; }
   __syncthreads();
   long long pt[4] = {0, 0, 0, 0}, tq = 0, c_start = 0, w_start = 0;
   if constexpr (PROF) { c_start = clock64(); w_start = wall_clock64(); }
@@ -763,17 +767,25 @@ __global__ __launch_bounds__(BLOCK) void lu_panel2_kernel(T* __restrict__ W, lon
         // ---- B: publish {row, live entries} — one pair per lane
         const int npairs = live + 2;
         unsigned long long* rec = box + ((long long)(j * nW + w) * REC) * 2;
-        if (tid < npairs && tid != 1) {
-          const unsigned long long bits = tid == 0 ? (unsigned long long)(unsigned)br : lu_bits(s_cand[pb][bw][tid >= 2 ? tid - 2 : 0]);
-          lu_publish_t(rec + 2 * tid, bits, tag);
+        // (the LAST wave publishes and does not poll: a wave's loads return behind its own write-through store,
+        //  whose acknowledgement comes from memory; the other NPOLL waves share the candidates)
+        constexpr int NPOLL = NWAVE - 1;
+        if (wid == NWAVE - 1) {
+#pragma unroll
+          for (int pi = lane; pi < REC; pi += 64) {
+            if (pi < npairs && pi != 1) {
+              const unsigned long long bits = pi == 0 ? (unsigned long long)(unsigned)br : lu_bits(s_cand[pb][bw][pi >= 2 ? pi - 2 : 0]);
+              lu_publish_t(rec + 2 * pi, bits, tag);
+            }
+          }
         }
-        // every wave folds its share of the candidates, up to GRP at a time, contents included
+        // every polling wave folds its share of the candidates, up to GRP at a time, contents included
         T cv = T(-1);
         int cr = 0x7fffffff, spins = 0;
         unsigned long long best0 = 0, best1 = 0;
         bool ok = true;
         const bool has0 = lane < npairs && lane != 1, has1 = lane + 64 < npairs;
-        for (int base = wid; base < nW && ok; base += NWAVE * GRP) {
+        for (int base = wid; wid < NPOLL && base < nW && ok; base += NPOLL * GRP) {
           unsigned long long b0[GRP], b1[GRP];
 #pragma unroll
           for (int g = 0; g < GRP; g++) { b0[g] = 0; b1[g] = 0; }
@@ -781,7 +793,7 @@ __global__ __launch_bounds__(BLOCK) void lu_panel2_kernel(T* __restrict__ W, lon
             bool got = true;
 #pragma unroll
             for (int g = 0; g < GRP; g++) {
-              const int cand = base + g * NWAVE;
+              const int cand = base + g * NPOLL;
               if (cand < nW) {
                 const unsigned long long* crec = box + ((long long)(j * nW + cand) * REC) * 2;
                 if (has0) got = lu_poll_t(crec + 2 * lane, b0[g], tag) && got;
@@ -795,7 +807,7 @@ __global__ __launch_bounds__(BLOCK) void lu_panel2_kernel(T* __restrict__ W, lon
           if (ok) {
 #pragma unroll
             for (int g = 0; g < GRP; g++) {
-              if (base + g * NWAVE < nW) {  // (uniform)
+              if (base + g * NPOLL < nW) {  // (uniform)
                 T x;
                 lu_from_bits(lane_bcast_u64<2>(b0[g]), x);  // entry 0 of the candidate row: its column-k value
                 x = dev_abs(x);
@@ -830,11 +842,11 @@ __global__ __launch_bounds__(BLOCK) void lu_panel2_kernel(T* __restrict__ W, lon
       if (act && cur == p) {
         done = true;
         cur = k;
-        plist[1 + j] = (int)grow;  // the original row that ends up at position k
+        s_top[j] = (int)grow;  // the original row that ends up at position k
       } else if (act && cur == k) {
         cur = p;  // (p != k here: the row at position k was not the pivot)
       }
-      if (w == 0 && tid == 0) ipiv[k] = p;
+      if (w == 0 && tid == 0) s_ipiv[j] = p;
       T uu0 = valid ? u[0] : T(0);
       if (!valid) {  // no row was published for a NaN column in the single-workgroup path either: use row k's own value
         uu0 = T(0);
@@ -842,21 +854,22 @@ __global__ __launch_bounds__(BLOCK) void lu_panel2_kernel(T* __restrict__ W, lon
       const T piv = uu0;
       if (piv == T(0) && w == 0 && tid == 0) atomicOr(info, 1);
       const T rp = piv == T(0) ? T(1) : T(1) / piv;
-      const bool upd = have && !done;
-      const T l = upd ? a[0] * rp : T(0);
-      if (upd) a[0] = l;
+      if (have && !done) {  // (divergent: finished rows sit this out under the exec mask — no per-element select)
+        const T l = a[0] * rp;
+        a[0] = l;
 #pragma unroll
-      for (int c0 = 0; c0 < PB; c0 += 16) {
-        if (c0 < live) {  // (uniform)
-          T uu[16];
+        for (int c0 = 0; c0 < PB; c0 += 8) {
+          if (c0 + 8 <= live) {  // (uniform) a whole chunk of later columns
+            T uu[8];
 #pragma unroll
-          for (int c = 0; c < 16; c++) uu[c] = u[c0 + c];
+            for (int c = 0; c < 8; c++) uu[c] = u[c0 + c];
 #pragma unroll
-          for (int c = 0; c < 16; c++) {
-            if (c0 + c >= 1) {
-              const T r = a[c0 + c] - l * uu[c];
-              a[c0 + c] = (upd && c0 + c < live) ? r : a[c0 + c];
-            }
+            for (int c = 0; c < 8; c++)
+              if (c0 + c >= 1) a[c0 + c] -= l * uu[c];
+          } else if (c0 < live) {  // the chunk the boundary runs through
+#pragma unroll
+            for (int c = 0; c < 8; c++)
+              if (c0 + c >= 1 && c0 + c < live) a[c0 + c] -= l * u[c0 + c];
           }
         }
       }
@@ -886,6 +899,10 @@ __global__ __launch_bounds__(BLOCK) void lu_panel2_kernel(T* __restrict__ W, lon
 #pragma unroll
     for (int c = 0; c < PB; c++)
       if (c < pw) W[(long long)cur * ld + k0 + c] = a[c];
+  }
+  if (tid < pw) {
+    if (s_top[tid] >= 0) plist[1 + tid] = s_top[tid];
+    if (w == 0) ipiv[k0 + tid] = s_ipiv[tid];
   }
   // displaced rows (they started in the top block — workgroup 0 — and were moved out of it without being chosen)
   if (w == 0) {
@@ -937,25 +954,29 @@ __global__ __launch_bounds__(CB) void lu_swap_u12_kernel(T* __restrict__ W, long
     for (int i = 0; i < PB; i++)
       if (i < ndisp) W[(long long)e_dst[i] * ld + c] = d[i];
   }
+  // forward substitution, unit diagonal, the column in REGISTERS and fully unrolled: L11 comes from LDS as
+  // broadcast loads (rows of a narrower last panel are zero below pw: the extra steps change nothing).
+  // (the looped form with the column in LDS waited for eight LDS loads per four FMAs: ~40 of this kernel's 68 us)
+  T x[PB];
+#pragma unroll
+  for (int i = 0; i < PB; i++) x[i] = xs[i * CB + tid];
   if (right) {
-    // forward substitution, unit diagonal; four partial sums break the FMA dependency chain
-    for (int r = 1; r < pw; r++) {
-      T s0 = xs[r * CB + tid], s1 = T(0), s2 = T(0), s3 = T(0);
-      int q = 0;
-      for (; q + 3 < r; q += 4) {
-        s0 -= Ls[r * (PB + 1) + q] * xs[q * CB + tid];
-        s1 -= Ls[r * (PB + 1) + q + 1] * xs[(q + 1) * CB + tid];
-        s2 -= Ls[r * (PB + 1) + q + 2] * xs[(q + 2) * CB + tid];
-        s3 -= Ls[r * (PB + 1) + q + 3] * xs[(q + 3) * CB + tid];
+#pragma unroll
+    for (int r = 1; r < PB; r++) {
+      T s0 = x[r], s1 = T(0);
+#pragma unroll
+      for (int q = 0; q + 1 < r; q += 2) {
+        s0 -= Ls[r * (PB + 1) + q] * x[q];
+        s1 -= Ls[r * (PB + 1) + q + 1] * x[q + 1];
       }
-      for (; q < r; q++) s0 -= Ls[r * (PB + 1) + q] * xs[q * CB + tid];
-      xs[r * CB + tid] = (s0 + s1) + (s2 + s3);
+      if (r & 1) s0 -= Ls[r * (PB + 1) + r - 1] * x[r - 1];
+      x[r] = s0 + s1;
     }
   }
   if (have) {
-#pragma unroll 16
+#pragma unroll
     for (int i = 0; i < PB; i++)
-      if (i < pw) W[(long long)(k0 + i) * ld + c] = xs[i * CB + tid];
+      if (i < pw) W[(long long)(k0 + i) * ld + c] = x[i];
   }
 }
 
@@ -1072,7 +1093,9 @@ int getrf_typed(long long batch, long long n, const void* A, void* LU, void* per
   // beyond one CU's LDS: the blocked factorisation, one matrix after the other
   // (PTHIP_LU_PANEL: "v1" = the round-3 unrolled 32-column panel, "32" / "64" = the looped panel of that width)
   static const char* panel_env = getenv("PTHIP_LU_PANEL");
-  static const int panel = panel_env == nullptr ? 64 : (!strcmp(panel_env, "v1") ? 0 : atoi(panel_env));
+  // default 32: measured 25.0 ms against 26.3 (64) and 30.2 (v1) at n = 4096, 4.6 / 4.9 / 6.2 ms at n = 1024
+  // (profiles/r4f_getrf.txt) — the per-column work of a thread grows with the panel width, the launches per panel do not
+  static const int panel = panel_env == nullptr ? 32 : (!strcmp(panel_env, "v1") ? 0 : atoi(panel_env));
   for (long long b = 0; b < batch; b++) {
     const T* Ab = (const T*)A + b * n * n;
     T* LUb = (T*)LU + b * n * n;

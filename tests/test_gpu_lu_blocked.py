@@ -115,10 +115,10 @@ def test_solve_det_inverse_of_a_large_matrix_through_the_graph(hip):
         np.testing.assert_allclose(x, np.linalg.solve(A, b), rtol=1e-9, atol=1e-11)
 
 
-@pytest.mark.parametrize("panel", ["32", "v1"])
+@pytest.mark.parametrize("panel", ["64", "v1"])
 def test_other_panel_forms_still_match(hip, panel):
-    """``PTHIP_LU_PANEL`` (read once per process) selects the 32-column looped panel or the round-3 unrolled
-    panel kept as the A/B reference of the default 64-column looped panel: same pivots as LAPACK, in a child."""
+    """``PTHIP_LU_PANEL`` (read once per process) selects the 64-column looped panel or the round-3 unrolled
+    panel kept as the A/B reference of the default 32-column looped panel: same pivots as LAPACK, in a child."""
     import os
     import subprocess
     import sys

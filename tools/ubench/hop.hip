@@ -56,11 +56,45 @@ __global__ void pingpong_flag(u64* data, int* flag, int n, long long* ticks, int
   }
   if (me == 0) { ticks[0] = wall_clock64() - t0; ticks[1] = (long long)sink; }
 }
+// Third variant: the SAME hand-over with workgroup-scope cache policy only (store sc0: write through the CU's L1
+// into L2; load sc0: miss L1, read L2).  Two workgroups on the same XCD share that L2, so the pair never has to
+// reach memory; on different XCDs the reader keeps seeing its own L2's stale line — bounded spins, a timeout is
+// the expected answer there.  Also reports which XCD each player ran on (HW_REG_XCC_ID).
+__device__ __forceinline__ void publish_l2(u64* slot, u64 v) {
+  u2 pr = {v, v ^ MAGIC};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 2" : : "v"((u2*)slot), "v"(pr) : "memory");
+}
+__device__ __forceinline__ bool poll_l2(const u64* slot, u64& v) {
+  u2 pr;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(pr) : "v"((const u2*)slot) : "memory");
+  v = pr.x;
+  return (pr.x ^ pr.y) == MAGIC;
+}
+__global__ void pingpong_pair_l2(u64* box, int n, long long* ticks, int stride_wg, int* xcc) {
+  const int me = blockIdx.x == 0 ? 0 : (blockIdx.x == stride_wg ? 1 : -1);
+  if (me < 0 || threadIdx.x != 0) return;
+  unsigned id;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+  xcc[me] = (int)(id & 0xf);
+  u64* mine = box + (me ? 2 : 0) * 8;
+  u64* theirs = box + (me ? 0 : 2) * 8;
+  const long long t0 = wall_clock64();
+  int done = n;
+  for (int i = 1; i <= n; i++) {
+    u64 v;
+    long long spins = 0;
+    if (me == 0) publish_l2(mine, (u64)i);
+    while (!(poll_l2(theirs, v) && v == (u64)i)) { if (++spins > 200000) { done = i - 1; break; } }
+    if (done != n) break;
+    if (me == 1) publish_l2(mine, (u64)i);
+  }
+  if (me == 0) { ticks[0] = wall_clock64() - t0; ticks[1] = done; }
+}
 int main() {
   u64* box; int* flag; long long* ticks;
   (void)hipMalloc(&box, 4096); (void)hipMalloc(&flag, 4096); (void)hipMalloc(&ticks, 64);
   const int n = 2000;
-  for (int partner : {1, 8, 9, 255}) {
+  for (int partner : {1, 8, 9, 16, 248, 255}) {
     long long h[2];
     (void)hipMemset(box, 0, 4096);
     pingpong_pair<<<256, 64>>>(box, n, ticks, partner);
@@ -71,6 +105,15 @@ int main() {
     (void)hipMemcpy(h, ticks, 16, hipMemcpyDeviceToHost);
     printf("workgroups 0 <-> %3d: self-validating pair %.0f ns one way; data + release + flag + acquire %.0f ns one way\n", partner, pair_ns,
            h[0] * 10.0 / (2.0 * n));
+    int* xcc; int hx[2] = {-1, -1};
+    (void)hipMalloc(&xcc, 8);
+    (void)hipMemset(box, 0, 4096); (void)hipMemset(xcc, 0xff, 8);
+    pingpong_pair_l2<<<256, 64>>>(box, n, ticks, partner, xcc);
+    (void)hipMemcpy(h, ticks, 16, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(hx, xcc, 8, hipMemcpyDeviceToHost);
+    if (h[1] == n) printf("      L2-scope pair (sc0 only), XCDs %d / %d: %.0f ns one way\n", hx[0], hx[1], h[0] * 10.0 / (2.0 * n));
+    else printf("      L2-scope pair (sc0 only), XCDs %d / %d: timed out after %lld of %d round trips (not coherent at this scope)\n", hx[0], hx[1], h[1], n);
+    (void)hipFree(xcc);
   }
   return 0;
 }
