@@ -72,6 +72,32 @@ PT_DEV bool pt_min(bool x, bool y) { return x && y; }
 PT_DEV double pt_sign(double x) { return (x > 0) ? 1. : ((x < 0) ? -1. : (isnan(x) ? __builtin_nan("") : 0.)); }
 PT_DEV float pt_sign(float x) { return (x > 0) ? 1.f : ((x < 0) ? -1.f : (isnan(x) ? __builtin_nanf("") : 0.f)); }
 template <class T> PT_DEV T pt_sign(T x) { return (x >= 0) ? ((x == 0) ? 0 : 1) : -1; }
+// fp64 exp in 24 VALU instructions (the device library's is ~34; in BASELINE config #2 that one call was 41 % of
+// the kernel's VALU work next to a 25 us HBM floor): n = rint(x log2 e); r = x - n ln2 in two FMAs (ln2_hi has 21
+// trailing zero bits: n ln2_hi is exact); exp(r) = 1 + r + r^2 Q(r), Q a degree-9 Chebyshev fit on
+// |r| <= ln2/2 computed with mpmath at 60 digits; 2^n by v_ldexp_f64.  <= 1 ulp from the correctly rounded
+// value on 6e5 points in [-700, 700] (mean 0.10 ulp); Exp.c_code of the reference is libm's exp
+// (pytensor/scalar/basic.py:3085-3118), itself < 1 ulp.  Overflow -> inf, underflow -> 0, NaN -> NaN.
+PT_DEV double pt_exp(double x) {
+  const double n = __builtin_rint(x * 0x1.71547652b82fep+0);
+  double r = __builtin_fma(n, -0x1.62e42fee00000p-1, x);
+  r = __builtin_fma(n, -0x1.a39ef35793c76p-33, r);
+  double q = 0x1.af38a9b0ec855p-26;
+  q = __builtin_fma(q, r, 0x1.289185613a3d6p-22);
+  q = __builtin_fma(q, r, 0x1.71de0dae63bb3p-19);
+  q = __builtin_fma(q, r, 0x1.a019b90d2ae7ap-16);
+  q = __builtin_fma(q, r, 0x1.a01a01a7c41d5p-13);
+  q = __builtin_fma(q, r, 0x1.6c16c1788bd90p-10);
+  q = __builtin_fma(q, r, 0x1.11111111109b3p-7);
+  q = __builtin_fma(q, r, 0x1.5555555553d63p-5);
+  q = __builtin_fma(q, r, 0x1.5555555555556p-3);
+  q = __builtin_fma(q, r, 0x1.0000000000001p-1);
+  const double p = __builtin_fma(q * r, r, r) + 1.0;
+  double y = __builtin_ldexp(p, (int)n);
+  y = x > 0x1.62e42fefa39efp+9 ? __builtin_huge_val() : y;
+  y = x < -0x1.74910d52d3051p+9 ? 0.0 : y;
+  return y;
+}
 // Python-style floor division / modulo for integers (IntDiv / Mod c_code, scalar/basic.py)
 template <class T> PT_DEV T pt_intdiv_i(T x, T y) {
   if (y == 0) return 0;
@@ -776,7 +802,7 @@ SCALAR_EXPR = {
     "Sign": _helper("pt_sign"),  # 2575
     "Sqr": _helper("pt_sqr"),  # 3202
     "Sqrt": _f("sqrt"),  # 3231
-    "Exp": _f("exp"),  # 3085
+    "Exp": _f("pt_exp" if os.environ.get("PTHIP_FAST_EXP", "1") != "0" else "exp", "expf"),  # 3085
     "Exp2": _f("exp2"),
     "Expm1": _f("expm1"),
     "Log": _f("log"),  # 2907
@@ -991,7 +1017,7 @@ def _stream_load(ptr_expr: str, struct=False) -> str:
     return f"*({ptr_expr})"
 
 
-def _flat_params(body: dict, modes: str, reduce_spec, vec: int):
+def _flat_params(body: dict, modes: str, reduce_spec, vec: int, finish=None):
     params = ["long long n"]
     for k, dt in enumerate(body["in_dtypes"]):
         if modes[k] == "C":  # host-known scalar: travels by value in the argument block
@@ -1008,10 +1034,15 @@ def _flat_params(body: dict, modes: str, reduce_spec, vec: int):
     if "G" in modes:
         assert vec == 1, "gather inputs use the scalar loop"
         params.append("int* __restrict__ status")
+    if finish:
+        for k, dt in enumerate(finish):
+            if dt is not None:
+                params.append(f"{CTYPE[dt]}* __restrict__ fin{k}")
+        params.append("int* __restrict__ ticket")
     return params
 
 
-def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=None, unroll=2, device_fn=False, prefetch=False) -> str:
+def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=None, unroll=2, device_fn=False, prefetch=False, finish=None) -> str:
     """``flat`` loop.  ``modes[k]`` ∈ {'V' contiguous vector, 'S' scalar broadcast} per input.
 
     reduce_spec: None or list (per output) of None | (op_name, acc_dtype): reduced
@@ -1032,7 +1063,7 @@ def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=
     nin = len(body["in_dtypes"])
     nout = len(body["out_dtypes"])
     reduce_spec = reduce_spec or [None] * nout
-    params = _flat_params(body, modes, reduce_spec, vec)
+    params = _flat_params(body, modes, reduce_spec, vec, finish)
     if device_fn:
         src = [f"static __device__ __forceinline__ void {name}({', '.join(params)}, const unsigned pt_bidx, const unsigned pt_gdim) {{"]
     else:
@@ -1125,7 +1156,7 @@ def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=
         src.append(f"  for (long long i = tid; i < n; i += nthreads) {{")
         src.append(_flat_elem(body, modes, reduce_spec, "i"))
         src.append("  }")
-    src.append(_reduce_epilogue(reduce_spec, unroll))
+    src.append(_reduce_epilogue(reduce_spec, unroll, finish))
     src.append("}")
     text = "\n".join(src)
     if device_fn:
@@ -1224,7 +1255,12 @@ def _flat_elem(body, modes, reduce_spec, ivar):
     return "\n".join(lines)
 
 
-def _reduce_epilogue(reduce_spec, unroll):
+def _reduce_epilogue(reduce_spec, unroll, finish=None):
+    """``finish`` (per output: final dtype | None): ONE pass — every workgroup stores its partial, takes a ticket,
+    and the last one to finish folds all partials in a fixed order (thread t takes partials t, t+BLOCK, ... in
+    order, then the block combine: deterministic for a given grid) and stores the final value.  The second-stage
+    launch (~3 us + a launch gap behind a 30 us streaming kernel) goes away.  The kernel only reads its
+    operands, so the ticket's release fence has next to nothing to write back."""
     if not any(reduce_spec):
         return ""
     lines = []
@@ -1239,6 +1275,25 @@ def _reduce_epilogue(reduce_spec, unroll):
             e = f"{op}::apply({e}, acc{k}_{u})"
         lines.append(f"  {act} tot{k} = pthip_dev::block_reduce<{op}, {act}, {BLOCK}>({e}, smem{k});")
         lines.append(f"  if (threadIdx.x == 0) part{k}[blockIdx.x] = tot{k};")
+    if finish:
+        lines.append("  __shared__ int pt_last;")
+        lines.append("  __threadfence();")
+        lines.append("  if (threadIdx.x == 0) pt_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;")
+        lines.append("  __syncthreads();")
+        lines.append("  if (pt_last) {")
+        lines.append("    __threadfence();")
+        lines.append("    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);")
+        for k, rs in enumerate(reduce_spec):
+            if rs is None:
+                continue
+            act = CTYPE[rs[1]]
+            op = f"pthip_dev::{REDUCE_OPS[rs[0]]}"
+            lines.append(f"    {act} fa{k} = {op}::identity<{act}>();")
+            lines.append(f"    for (unsigned i = threadIdx.x; i < gridDim.x; i += {BLOCK}) fa{k} = {op}::apply(fa{k}, __hip_atomic_load(&part{k}[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));")
+            lines.append(f"    __syncthreads();")
+            lines.append(f"    fa{k} = pthip_dev::block_reduce<{op}, {act}, {BLOCK}>(fa{k}, smem{k});")
+            lines.append(f"    if (threadIdx.x == 0) fin{k}[0] = ({CTYPE[finish[k]]})fa{k};")
+        lines.append("  }")
     return "\n".join(lines)
 
 

@@ -7,8 +7,10 @@ Reference: pytensor/tensor/elemwise.py — ``Elemwise`` 375 (perform 755-823,
 
 from __future__ import annotations
 
+import ctypes as C
 import hashlib
 import json
+import os
 import struct
 
 import numpy as np
@@ -207,7 +209,11 @@ def _take(env, table: DeviceArray, idx: DeviceArray) -> DeviceArray:
     return out
 
 
-def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=(), out_bufs=None, gather=None):
+# single-pass reductions: the kernel's last workgroup folds the partials itself (codegen._reduce_epilogue)
+_SINGLE_PASS = os.environ.get("PTHIP_EW_SINGLE_PASS", "1") != "0"
+
+
+def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=(), out_bufs=None, gather=None, finals_out=None):
     """Launch the fused kernel.  Returns (stored outputs or None per output,
     partial buffers or None per output, grid).
 
@@ -252,7 +258,7 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=
         if not flat:
             # layouts the in-loop gather does not cover: gather first, then the ordinary kernel
             ins = [_take(env, env.to_device(a), gather[k]) if k in gather else a for k, a in enumerate(ins)]
-            return launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial, out_bufs)
+            return launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial, out_bufs, finals_out=finals_out)
     byvalue = set()
     if not flat:
         # host-known scalars travel by value here too (no upload node per replay)
@@ -272,11 +278,16 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=
                 vec = 1
         unroll = EW_UNROLL
         prefetch = vec > 1 and "V" in modes and len(body["body"]) >= EW_PREFETCH_MIN_OPS
-        name = f"ew_{bkey}_{''.join(modes)}_v{vec}_{rkey}".replace("-", "x") + (f"_pf{unroll}" if prefetch else "")
-        src = codegen.flat_kernel_source(name, body, "".join(modes), vec, rs, unroll, prefetch=prefetch)
-        fn = kernel_cache.get_function(src, name)
         units = (n // vec + unroll - 1) // unroll if vec > 1 else n
         grid = _grid(max(units, 1))
+        # the caller wants finished values (nothing defers the second stage to a Tail kernel) and every output is
+        # a reduction: the kernel finishes them itself
+        finish = None
+        if finals_out is not None and _SINGLE_PASS and grid > 1 and all(r is not None for r in reduce_spec) and isinstance(reduce_spec[0], dict):
+            finish = [r["dtype"] for r in reduce_spec]
+        name = f"ew_{bkey}_{''.join(modes)}_v{vec}_{rkey}".replace("-", "x") + (f"_pf{unroll}" if prefetch else "") + ("_1p" + "".join(np.dtype(d).char for d in finish) if finish else "")
+        src = codegen.flat_kernel_source(name, body, "".join(modes), vec, rs, unroll, prefetch=prefetch, finish=finish)
+        fn = kernel_cache.get_function(src, name)
         args = [n]
         for k, (a, m) in enumerate(zip(ins, modes)):
             if m == "C":
@@ -333,6 +344,12 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=
         args.append(outs[k].ptr if reduce_spec[k] is None else parts[k].ptr)
     if flat and "G" in modes:
         args.append(env.lib.pthip_status_ptr())  # device error flag: out-of-range index
+    if flat and finish:
+        fins = [DeviceArray.empty((), dt) for dt in finish]
+        slot = C.c_void_p()
+        ffi.check(lib.pthip_ticket_slot(C.byref(slot)))
+        args += [f.ptr for f in fins] + [slot.value]
+        finals_out[:] = fins
     buf = struct.pack(f"<{len(args)}q", *args)
     env.timed(name, lambda: ffi.check(lib.pthip_launch(fn, grid, 1, 1, BLOCK, 1, 1, 0, buf, len(buf))))
     return outs, parts, grid
@@ -484,8 +501,13 @@ def elemwise_reduce(node, inputs, env):
     spec = node.params["reduce"]
     g = env.graph
     ins, shape, pi, gather = _prepare(node, inputs, env)
-    outs, parts, grid = launch_elemwise(body, ins, shape, body["out_dtypes"], spec, env, pi, _placed(env, node, shape, body["out_dtypes"]), gather)
-    finals = finish_partials(env, spec, parts, grid, node.params.get("defer_reduce") or ()) if grid else [None] * len(spec)
+    defer = node.params.get("defer_reduce") or ()
+    done = None if defer else []  # (filled when the kernel finished its reductions itself: single pass)
+    outs, parts, grid = launch_elemwise(body, ins, shape, body["out_dtypes"], spec, env, pi, _placed(env, node, shape, body["out_dtypes"]), gather, finals_out=done)
+    if done:
+        finals = done
+    else:
+        finals = finish_partials(env, spec, parts, grid, defer) if grid else [None] * len(spec)
     res = []
     for k, r in enumerate(spec):
         if r is None:

@@ -190,6 +190,11 @@ class _ReplayDesc(C.Structure):
         ("in_bytes", C.c_size_t), ("dev_out", C.c_void_p), ("out_bytes", C.c_size_t), ("flags", C.c_int)]
 
 
+try:  # the native call path of a plan (host code only; built by __graft_entry__.build next to libpthip.so)
+    from pytensor_amd import _fastplan as _FASTPLAN
+except ImportError:  # pragma: no cover (not built: the Python path below serves every plan)
+    _FASTPLAN = None
+
 _CAPTURE_ACTIVE = [None]  # the plan currently inside warm-up/capture, if any
 _DEFERRED = []  # plans whose release was requested during somebody else's capture
 
@@ -255,6 +260,9 @@ class FrozenPlan:
             if all(g.nodes[k].op in _A_DIRECT_OPS and g.nodes[k].inputs[0] not in staged_vids for k in users):
                 self._a_direct_nodes = frozenset(users)
         self._async_pending = False
+        self._fast = None  # csrc/fastplan.c: the replay path as one native call, built after the first Python-path call
+        self._fast_off = os.environ.get("PTHIP_FASTPLAN", "1") == "0"
+        self._fast_misses = 0
         self._poll = False  # set by the capture pass when the Tail kernel is the plan's last launch
         self._desc = None
         self._out_block = None
@@ -524,6 +532,50 @@ class FrozenPlan:
         if rc:
             ffi.check(rc)
 
+    # ------------------------------------------------------------------
+    def _build_fast(self):
+        """The replay path as one native call (csrc/fastplan.c) when the plan is of the simple, common kind:
+        results written straight into the pinned block by the plan's kernels, no update feedback, no baked
+        scalars, every resident watched by a write-protection slot (or not at all).  ``None`` otherwise."""
+        if _FASTPLAN is None or self._fast_off or not self.fetch_outputs or self._dev_out is not None or self._fed or self._baked:
+            return None
+        if self._out_block is None or self._ring is not None or self._out_meta is None:
+            return None
+        if self._desc is None:
+            self._make_desc()
+        exe, ob, lib = self.exe, self._out_block, self.lib
+        res = []
+        for pos in self._resident_devs:
+            ent = exe._resident_cache.get(pos)
+            if ent is None or ent.key is None or ent.host is None:
+                return None
+            tok = ent.fp
+            if tok is None:
+                slot = -1
+            elif isinstance(tok, coherence._Guard) and tok.slot >= 0:
+                slot = tok.slot
+            else:
+                return None  # a content hash is checked by the Python path (overlapped with the replay)
+            res.append((pos, ent.host, slot))
+        staged = [(pos, self._in_block.ptr + self._in_block.offsets[k], self._in_block.views[k].dtype, tuple(self._in_block.views[k].shape))
+                  for pos, k in self._in_view.items()]
+        outs, k = [], 0
+        scalars = set(exe._scalar_outs)
+        for q, meta in enumerate(self._out_meta):
+            if meta is not None:
+                outs.append((None, np.array(meta, order="C", copy=True), meta.dtype, tuple(meta.shape), int(q in scalars)))  # (ascontiguousarray would make a 0-d value 1-d)
+            else:
+                shape, dtype = self._out_specs[k]
+                outs.append((ob.ptr + ob.offsets[k], None, np.dtype(dtype), tuple(shape), int(q in scalars)))
+                k += 1
+        addr = lambda f: C.cast(f, C.c_void_p).value
+        try:
+            return _FASTPLAN.FastPlan(len(self._sig), staged, res, outs, addr(lib.pthip_plan_replay4), addr(lib.pthip_guard_clean), C.addressof(self._desc),
+                                      self._done_ptr or 0, ob.ptr + ob.offsets[-1], self._sync_mode)
+        except Exception:  # noqa: BLE001 (an exotic dtype or rank: the Python path serves the plan)
+            self._fast_off = True
+            return None
+
     def launch_async(self):
         """Enqueue one replay (parameters already in the staging block); no host sync."""
         self._async_pending = True  # its completion word may still arrive: the next waiting call uses the stream
@@ -531,6 +583,27 @@ class FrozenPlan:
 
     def __call__(self, *inputs):
         lib = self.lib
+        fast = self._fast
+        if fast is not None and not self._async_pending:
+            r = fast(inputs)
+            if r.__class__ is tuple:
+                return r if r else None
+            if r is None:
+                # not the captured situation (signature, a dirty resident, a non-contiguous argument): the full
+                # checks below decide what happens; the native path is rebuilt after a successful call
+                self._fast = None
+                self._fast_misses += 1
+                if self._fast_misses > 8:
+                    self._fast_off = True
+            elif r < 0:
+                ffi.check(-r)
+            else:
+                from pytensor_amd.executor import raise_device_status
+
+                st = C.c_int(0)
+                ffi.check(lib.pthip_check_status(C.byref(st)))  # clears the device word
+                self._out_block.views[-1][0] = 0
+                raise_device_status(int(r))
         if len(inputs) != len(self._sig):
             raise TypeError(f"expected {len(self._sig)} inputs, got {len(inputs)}")
         views = self._in_block.views
@@ -611,6 +684,10 @@ class FrozenPlan:
             res[k] = res[k][()]
         if not res and not self._out_meta:
             return None  # a function without outputs returns None (link/basic.py:690-699)
+        if self._fast is None and not self._fast_off:
+            self._fast = self._build_fast()
+            if self._fast is None and not late:
+                self._fast_off = True  # not a plan of the simple kind: do not ask again
         return tuple(res)
 
     def close(self):
@@ -624,6 +701,8 @@ class FrozenPlan:
             _DEFERRED.append(self)  # keeps the object alive until it is safe to free
             return
         self._closed = True
+        self._fast = None
+        self._fast_off = True
         lib = self.lib
         try:
             lib.pthip_synchronize()

@@ -100,7 +100,13 @@ def _with_kernel(entry, name, work, peak, prefix=None, scale=1e6):
     """adds the dominant kernel's own roofline: ``work`` (bytes or flops) / its launch duration"""
     k, ms = _dominant(name, prefix)
     if k is not None:
-        entry.update({"kernel": k, "kernel_ms": ms, "kernel_achieved": work / ms / scale, "kernel_frac": work / ms / scale / peak})
+        src = "single-launch event bracket minus its calibrated overhead (executor.KernelTimer)"
+        td = entry.get("ms_device")
+        if td is not None and ms > td:
+            # a kernel cannot take longer than the replay that contains it: the bracket correction is a mean, and on a
+            # one-kernel plan the replay IS the kernel plus the graph-launch floor — the replay time is the better bound
+            ms, src = td, "bounded by the device time of the replay that contains it (bracket read higher)"
+        entry.update({"kernel": k, "kernel_ms": ms, "kernel_ms_source": src, "kernel_achieved": work / ms / scale, "kernel_frac": work / ms / scale / peak})
     return entry
 
 
