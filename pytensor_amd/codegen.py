@@ -1038,7 +1038,7 @@ def _flat_params(body: dict, modes: str, reduce_spec, vec: int, finish=None):
         for k, dt in enumerate(finish):
             if dt is not None:
                 params.append(f"{CTYPE[dt]}* __restrict__ fin{k}")
-        params.append("int* __restrict__ ticket")
+        params += ["int* __restrict__ ticket", "int* __restrict__ pt_status"]
     return params
 
 
@@ -1067,7 +1067,7 @@ def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=
     if device_fn:
         src = [f"static __device__ __forceinline__ void {name}({', '.join(params)}, const unsigned pt_bidx, const unsigned pt_gdim) {{"]
     else:
-        src = [reduce_header() if any(reduce_spec) else "", prelude_for(body), VEC_HELPERS]
+        src = [reduce_header() if any(reduce_spec) else "", prelude_for(body), VEC_HELPERS, PT_PAIR_HELPERS if finish else ""]
         src.append(f'extern "C" __global__ __launch_bounds__({BLOCK}) void {name}({", ".join(params)}) {{')
     # scalars
     for k, m in enumerate(modes):
@@ -1255,12 +1255,36 @@ def _flat_elem(body, modes, reduce_spec, ivar):
     return "\n".join(lines)
 
 
+FINISH_MAX_PER_THREAD = 8  # pairs a thread of the last workgroup folds: one-pass reductions need gridDim.x <= 8 * BLOCK
+
+PT_PAIR_HELPERS = r"""
+// one-pass reductions: a workgroup's partial travels as a self-validating 16-byte pair {bits, bits ^ MAGIC} in one
+// write-through store; the last workgroup polls the pairs (agent-scope loads) — no fence anywhere.  (A fence per
+// workgroup — __threadfence() before a ticket — made BASELINE config #2 ten times slower: every agent-scope
+// release / acquire writes back and invalidates the XCD's L2 under 2000 streaming workgroups,
+// profiles/r4i_c2_ab.txt.)
+typedef unsigned long long pt_u64;
+typedef pt_u64 pt_u2 __attribute__((ext_vector_type(2)));
+static constexpr pt_u64 PT_PAIR_MAGIC = 0x7ff4c0de5ea1ed03ull;
+static __device__ __forceinline__ void pt_pair_store(pt_u64* slot, pt_u64 lo, pt_u64 hi) {
+  pt_u2 pr = {lo, hi};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 2" : : "v"((pt_u2*)slot), "v"(pr) : "memory");
+}
+static __device__ __forceinline__ bool pt_pair_poll(const pt_u64* slot, pt_u64& bits) {
+  bits = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const pt_u64 b = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (bits ^ b) == PT_PAIR_MAGIC;
+}
+"""
+
+
 def _reduce_epilogue(reduce_spec, unroll, finish=None):
-    """``finish`` (per output: final dtype | None): ONE pass — every workgroup stores its partial, takes a ticket,
-    and the last one to finish folds all partials in a fixed order (thread t takes partials t, t+BLOCK, ... in
-    order, then the block combine: deterministic for a given grid) and stores the final value.  The second-stage
-    launch (~3 us + a launch gap behind a 30 us streaming kernel) goes away.  The kernel only reads its
-    operands, so the ticket's release fence has next to nothing to write back."""
+    """``finish`` (per output: final dtype | None): ONE pass — every workgroup publishes its partial as a
+    self-validating pair and takes a ticket (a relaxed device atomic); the last one to arrive polls all pairs, folds
+    them in a fixed order (thread t takes partials t, t+BLOCK, ... in order, then the block combine: deterministic
+    for a given grid), stores the final value and zeroes the pairs for the next launch of this kernel.  The
+    second-stage launch (~3 us + a launch gap behind a 30 us streaming kernel) goes away, and no fence is needed.
+    ``part{k}`` is then the pair array (2 x 8 bytes per workgroup)."""
     if not any(reduce_spec):
         return ""
     lines = []
@@ -1274,14 +1298,15 @@ def _reduce_epilogue(reduce_spec, unroll, finish=None):
         for u in range(1, unroll):
             e = f"{op}::apply({e}, acc{k}_{u})"
         lines.append(f"  {act} tot{k} = pthip_dev::block_reduce<{op}, {act}, {BLOCK}>({e}, smem{k});")
-        lines.append(f"  if (threadIdx.x == 0) part{k}[blockIdx.x] = tot{k};")
+        if finish:
+            lines.append(f"  if (threadIdx.x == 0) {{ pt_u64 b = 0; __builtin_memcpy(&b, &tot{k}, sizeof(tot{k})); pt_pair_store((pt_u64*)part{k} + 2 * blockIdx.x, b, b ^ PT_PAIR_MAGIC); }}")
+        else:
+            lines.append(f"  if (threadIdx.x == 0) part{k}[blockIdx.x] = tot{k};")
     if finish:
         lines.append("  __shared__ int pt_last;")
-        lines.append("  __threadfence();")
         lines.append("  if (threadIdx.x == 0) pt_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;")
         lines.append("  __syncthreads();")
         lines.append("  if (pt_last) {")
-        lines.append("    __threadfence();")
         lines.append("    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);")
         for k, rs in enumerate(reduce_spec):
             if rs is None:
@@ -1289,8 +1314,27 @@ def _reduce_epilogue(reduce_spec, unroll, finish=None):
             act = CTYPE[rs[1]]
             op = f"pthip_dev::{REDUCE_OPS[rs[0]]}"
             lines.append(f"    {act} fa{k} = {op}::identity<{act}>();")
-            lines.append(f"    for (unsigned i = threadIdx.x; i < gridDim.x; i += {BLOCK}) fa{k} = {op}::apply(fa{k}, __hip_atomic_load(&part{k}[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));")
-            lines.append(f"    __syncthreads();")
+            lines.append("    {")
+            # all of a thread's pairs are requested before the first is examined: one memory round trip for the
+            # whole fold (polled one after the other the 8 pairs of a thread cost ~1 us each)
+            lines.append(f"      pt_u64 b[{FINISH_MAX_PER_THREAD}];")
+            lines.append(f"      bool got[{FINISH_MAX_PER_THREAD}];")
+            lines.append(f"#pragma unroll\n      for (int u = 0; u < {FINISH_MAX_PER_THREAD}; u++) {{ b[u] = 0; got[u] = threadIdx.x + u * {BLOCK} >= gridDim.x; }}")
+            lines.append("      for (long long spins = 0;; spins++) {")
+            lines.append("        bool all = true;")
+            lines.append(f"#pragma unroll\n        for (int u = 0; u < {FINISH_MAX_PER_THREAD}; u++)")
+            lines.append(f"          if (!got[u]) {{ got[u] = pt_pair_poll((const pt_u64*)part{k} + 2 * (threadIdx.x + u * {BLOCK}), b[u]); all = all && got[u]; }}")
+            lines.append("        if (all) break;")
+            lines.append("        if (spins > (1ll << 22)) { atomicOr(pt_status, 16); break; }")
+            lines.append("      }")
+            lines.append(f"#pragma unroll\n      for (int u = 0; u < {FINISH_MAX_PER_THREAD}; u++)")
+            lines.append(f"        if (threadIdx.x + u * {BLOCK} < gridDim.x) {{")
+            lines.append(f"          {act} v; __builtin_memcpy(&v, &b[u], sizeof(v));")
+            lines.append(f"          fa{k} = {op}::apply(fa{k}, v);")
+            lines.append(f"          pt_pair_store((pt_u64*)part{k} + 2 * (threadIdx.x + u * {BLOCK}), 0, 0);  // clean for the next launch")
+            lines.append("        }")
+            lines.append("    }")
+            lines.append("    __syncthreads();")
             lines.append(f"    fa{k} = pthip_dev::block_reduce<{op}, {act}, {BLOCK}>(fa{k}, smem{k});")
             lines.append(f"    if (threadIdx.x == 0) fin{k}[0] = ({CTYPE[finish[k]]})fa{k};")
         lines.append("  }")

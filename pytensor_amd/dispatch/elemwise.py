@@ -209,8 +209,15 @@ def _take(env, table: DeviceArray, idx: DeviceArray) -> DeviceArray:
     return out
 
 
-# single-pass reductions: the kernel's last workgroup folds the partials itself (codegen._reduce_epilogue)
-_SINGLE_PASS = os.environ.get("PTHIP_EW_SINGLE_PASS", "1") != "0"
+# single-pass reductions: the kernel's last workgroup folds the partials itself (codegen._reduce_epilogue).
+# Measured on BASELINE config #2 (160 MB streamed, 2048 workgroups; profiles/r4k_c2_ab.txt, r4i_c2_ab_fence_ticket.txt):
+#   two launches (kernel + second stage)            32.6 - 33.4 us per replay  (kernel 30.6 - 31.0)
+#   one pass, pairs + ticket, batched polls          40.0 - 40.8
+#   one pass, pairs + ticket, polls one by one       44.5
+#   one pass, __threadfence() + ticket               376          (an agent-scope fence per workgroup: L2 write-back +
+#                                                                  invalidate under 2000 streaming workgroups)
+# The second launch costs less than any in-kernel hand-over here: opt-in only (PTHIP_EW_SINGLE_PASS=1).
+_SINGLE_PASS = os.environ.get("PTHIP_EW_SINGLE_PASS", "0") == "1"
 
 
 def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=(), out_bufs=None, gather=None, finals_out=None):
@@ -283,7 +290,7 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=
         # the caller wants finished values (nothing defers the second stage to a Tail kernel) and every output is
         # a reduction: the kernel finishes them itself
         finish = None
-        if finals_out is not None and _SINGLE_PASS and grid > 1 and all(r is not None for r in reduce_spec) and isinstance(reduce_spec[0], dict):
+        if finals_out is not None and _SINGLE_PASS and 1 < grid <= codegen.FINISH_MAX_PER_THREAD * BLOCK and all(r is not None for r in reduce_spec) and isinstance(reduce_spec[0], dict):
             finish = [r["dtype"] for r in reduce_spec]
         name = f"ew_{bkey}_{''.join(modes)}_v{vec}_{rkey}".replace("-", "x") + (f"_pf{unroll}" if prefetch else "") + ("_1p" + "".join(np.dtype(d).char for d in finish) if finish else "")
         src = codegen.flat_kernel_source(name, body, "".join(modes), vec, rs, unroll, prefetch=prefetch, finish=finish)
@@ -339,7 +346,13 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=
                 args += [a.shape[0], a.strides[0] if a.shape[0] > 1 else 0, pn, pld]
             else:
                 args += list(next(it))
-    parts = alloc_partials(reduce_spec, grid)
+    if flat and finish:
+        # pair arrays (16 bytes per workgroup and reduced output) instead of partials; never cleared from here: the
+        # kernel's last workgroup zeroes every pair it consumed, other users of pool memory leave pairs under other
+        # magic constants, and arbitrary bits validate with probability 2^-64
+        parts = [DeviceArray.empty((2 * grid,), "uint64") for _ in range(nout)]
+    else:
+        parts = alloc_partials(reduce_spec, grid)
     for k in range(nout):
         args.append(outs[k].ptr if reduce_spec[k] is None else parts[k].ptr)
     if flat and "G" in modes:
@@ -348,8 +361,9 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=
         fins = [DeviceArray.empty((), dt) for dt in finish]
         slot = C.c_void_p()
         ffi.check(lib.pthip_ticket_slot(C.byref(slot)))
-        args += [f.ptr for f in fins] + [slot.value]
+        args += [f.ptr for f in fins] + [slot.value, env.lib.pthip_status_ptr()]
         finals_out[:] = fins
+        env.keepalive.append(parts)
     buf = struct.pack(f"<{len(args)}q", *args)
     env.timed(name, lambda: ffi.check(lib.pthip_launch(fn, grid, 1, 1, BLOCK, 1, 1, 0, buf, len(buf))))
     return outs, parts, grid
