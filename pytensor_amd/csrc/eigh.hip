@@ -18,6 +18,10 @@
 // (scipy raises LinAlgError when LAPACK reports non-convergence).
 #include "common.h"
 
+#include <cstring>
+#include <utility>
+#include <vector>
+
 namespace {
 
 constexpr int MAX_SWEEPS = 60;
@@ -34,7 +38,7 @@ template <class T, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void eigh_jacobi_kernel(const T* __restrict__ Ain, T* __restrict__ Wout,
                                                            T* __restrict__ Vout, int n, int lower, int a_lds,
                                                            int v_lds, T* scratchA, T* scratchV,
-                                                           int* __restrict__ status) {
+                                                           int* __restrict__ status, int sorted, int max_sweeps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ T s_c[MAX_N / 2], s_s[MAX_N / 2];
   __shared__ short s_p[MAX_N / 2], s_q[MAX_N / 2], s_rank[MAX_N];
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(BLOCK) void eigh_jacobi_kernel(const T* __restrict_
 
   const int m = (n + 1) & ~1, half = m >> 1;
   bool converged = n < 2;
-  for (int sweep = 0; sweep < MAX_SWEEPS && !converged; sweep++) {
+  for (int sweep = 0; sweep < max_sweeps && !converged; sweep++) {
     for (int r = 0; r < m - 1; r++) {
       // ---- phase 1: one thread per pair computes its rotation ----
       for (int i = tid; i < half; i += BLOCK) {
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(BLOCK) void eigh_jacobi_kernel(const T* __restrict_
     converged = rot == 0;
     __syncthreads();
   }
-  if (!converged && tid == 0 && status != nullptr) atomicOr(status, 8);  // bit 3: LinAlgError("Eigenvalues did not converge")
+  if (!converged && tid == 0 && status != nullptr && max_sweeps >= MAX_SWEEPS) atomicOr(status, 8);  // bit 3: LinAlgError("Eigenvalues did not converge")
 
   // ascending order: rank of each eigenvalue (ties by index), then the permuted write
   T* Wg = Wout + mat * (long long)n;
@@ -165,6 +169,9 @@ __global__ __launch_bounds__(BLOCK) void eigh_jacobi_kernel(const T* __restrict_
       rank += (wj < wi || (wj == wi && j < i)) ? 1 : 0;
     }
     if (wi != wi) rank = i;  // NaN input: every slot still gets written
+    // (sorted == 0: eigenpair i stays in slot i — the accumulated rotation matrix, close to the identity when the
+    //  input is nearly diagonal: what the block method below needs from its subproblems to converge)
+    if (!sorted) rank = i;
     Wg[rank] = wi;
     s_rank[i] = (short)rank;
   }
@@ -173,10 +180,303 @@ __global__ __launch_bounds__(BLOCK) void eigh_jacobi_kernel(const T* __restrict_
     for (int i = lane; i < n; i += 64) Vg[(long long)k * n + s_rank[i]] = V[i * ld + k];
 }
 
+// ------------------------------------------------------------------------------------------
+// Beyond one CU (n > EIGH_BLOCK_MIN): block one-sided Jacobi over the whole chip, out of kernels that exist.
+//
+// B = sym(A) + sigma I with sigma = 1.25 x a rigorous bound on ||A||_2 (eigh_shift_kernel), so that every eigenvalue
+// of B lies in [sigma/5, 9 sigma/5]:
+// positive (a one-sided method diagonalises B^T B = B^2 and could not tell +lambda from -lambda) and
+// well conditioned.  G^T (rows = columns of G = B V) and V^T start as B and I.  A round pairs the 32-column
+// blocks (adjacent blocks 2k, 2k+1 — between rounds the blocks move like the players of a round-robin
+// tournament, one row gather): per pair the 64 x 64 Gram matrix S = G_p^T G_p on the MFMA GEMM, its full
+// eigendecomposition U by the LDS Jacobi kernel above (batched: one workgroup per pair; its accumulated rotation
+// matrix UNSORTED — the block iteration only converges, quadratically, when U stays close to the identity), and
+// G_p <- G_p U, V_p <- V_p U as two more batched GEMMs.  A sweep is nblocks-1 rounds; the largest
+// |S_ij| / sqrt(S_ii S_jj) seen during a sweep is read back once per sweep and ends the iteration.  At the end
+// column j of G is (lambda_j + sigma) v_j: lambda_j = v_j . g_j - sigma, sorted ascending with their vectors.
+// Rows / columns added to pad n to a whole number of block pairs carry 4 sigma on the diagonal: exactly
+// decoupled, they sort to the end and are dropped.  Accuracy is absolute, eps ||A||, like LAPACK's syevd / syevr.
+// Reference: Eigh.perform, pytensor/tensor/linalg/decomposition/eigen.py:177-195 (scipy.linalg.eigh, any n).
+// ------------------------------------------------------------------------------------------
+constexpr int EIGH_BLOCK_MIN = 160;  // up to here the one-workgroup kernel wins (n = 128: 12 ms)
+constexpr int EB = 32;               // columns per block; a pair is a 64 x 64 subproblem in LDS
+
 template <class T>
-int eigh_typed(long long batch, long long n, int lower, const void* A, void* W, void* V) {
+__device__ __forceinline__ T eigh_sym_at(const T* A, long long n, int lower, long long i, long long j) {
+  const long long r = lower ? (i > j ? i : j) : (i < j ? i : j);
+  const long long c = lower ? (i > j ? j : i) : (i < j ? j : i);
+  return A[r * n + c];
+}
+
+// max_i sum_j |a_ij| as the bits of a non-negative double (ordered like an unsigned integer)
+template <class T>
+__global__ __launch_bounds__(256) void eigh_rowsum_kernel(const T* __restrict__ A, long long n, int lower,
+                                                          unsigned long long* __restrict__ maxbits) {
+  const int lane = threadIdx.x & 63;
+  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  double s = 0.0;
+  for (long long j = lane; j < n; j += 64) {
+    const double a = (double)eigh_sym_at(A, n, lower, i, j);
+    s += a < 0.0 ? -a : a;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0 && s == s) atomicMax(maxbits, (unsigned long long)__double_as_longlong(s));
+}
+
+// max_i sum_j |c_ij| of a dense N x N matrix (bits of a non-negative double)
+template <class T>
+__global__ __launch_bounds__(256) void eigh_absrow_kernel(const T* __restrict__ Cm, long long N, unsigned long long* __restrict__ maxbits) {
+  const int lane = threadIdx.x & 63;
+  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= N) return;
+  double s = 0.0;
+  for (long long j = lane; j < N; j += 64) {
+    const double a = (double)Cm[i * N + j];
+    s += a < 0.0 ? -a : a;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0 && s == s) atomicMax(maxbits, (unsigned long long)__double_as_longlong(s));
+}
+
+// sigma = 1.25 min(||A||_inf, ||A^4||_inf^(1/4)) >= 1.25 ||A||_2 (both bounds are rigorous for a symmetric A; the
+// second is within a small factor of the spectral norm where Gershgorin's is off by sqrt(n) for a random matrix:
+// a smaller shift keeps eps * sigma — the accuracy of everything below — near eps ||A||_2 and B's eigenvalues spread
+// out, which is what the iteration's early sweeps feed on).  B = A + sigma I, pads 4 sigma; G^T = B as well.
+template <class T>
+__global__ __launch_bounds__(256) void eigh_shift_kernel(T* __restrict__ Gt, T* __restrict__ B, long long n, long long N,
+                                                         const unsigned long long* __restrict__ bits, T* __restrict__ sigma_out) {
+  const double b1 = __longlong_as_double((long long)bits[0]);
+  const double b4 = sqrt(sqrt(__longlong_as_double((long long)bits[2])));
+  double bound = b1;
+  if (b4 == b4 && b4 > 0.0 && b4 * 1.01 < bound) bound = b4 * 1.01;
+  double sg = 1.25 * bound;
+  if (!(sg > 0.0) || sg != sg || sg > 1e300) sg = 1.0;
+  const T sigma = (T)sg;
+  if (blockIdx.x == 0 && threadIdx.x == 0) sigma_out[0] = sigma;
+  const long long total = N * N;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long i = e / N, j = e - i * N;
+    T g = Gt[e];
+    if (i == j) g = i < n ? g + sigma : T(4) * sigma;
+    Gt[e] = g;
+    B[e] = g;
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void eigh_prep_kernel(const T* __restrict__ A, long long n, long long N, int lower,
+                                                        T* __restrict__ Gt, T* __restrict__ Vt) {
+  const long long total = N * N;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long i = e / N, j = e - i * N;
+    Gt[e] = (i < n && j < n) ? eigh_sym_at(A, n, lower, i, j) : T(0);  // (the shift comes later: eigh_shift_kernel)
+    Vt[e] = i == j ? T(1) : T(0);
+  }
+}
+
+// largest |S_ij| / sqrt(S_ii S_jj), i != j, over a batch of m x m Gram matrices (float bits, atomicMax)
+template <class T>
+__global__ __launch_bounds__(256) void eigh_offdiag_kernel(const T* __restrict__ S, long long batch, int m,
+                                                           unsigned* __restrict__ maxbits) {
+  const long long total = batch * m * m;
+  float best = 0.f;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long b = e / (m * m);
+    const int r = (int)(e - b * m * m), i = r / m, j = r - i * m;
+    if (i == j) continue;
+    const T* Sb = S + b * m * m;
+    const double d = (double)Sb[i * m + i] * (double)Sb[j * m + j];
+    const double a = (double)Sb[r];
+    if (d > 0.0) {
+      const float v = (float)((a < 0.0 ? -a : a) / sqrt(d));
+      best = v > best ? v : best;
+    } else if (a != 0.0) {
+      best = 1.f;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const float ov = __shfl_xor(best, o); best = ov > best ? ov : best; }
+  if ((threadIdx.x & 63) == 0 && best > 0.f) atomicMax(maxbits, __float_as_uint(best));
+}
+
+// lambda_j = v_j . g_j - sigma (one wave per column of G, i.e. per row of Gt / Vt)
+template <class T>
+__global__ __launch_bounds__(256) void eigh_lambda_kernel(const T* __restrict__ Gt, const T* __restrict__ Vt, long long N,
+                                                          const T* __restrict__ sigma, T* __restrict__ lam) {
+  const int lane = threadIdx.x & 63;
+  const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= N) return;
+  T s = T(0);
+  for (long long i = lane; i < N; i += 64) s += Vt[j * N + i] * Gt[j * N + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) lam[j] = s - sigma[0];
+}
+
+// ascending ranks (ties by index; NaN keeps its slot), eigenvalues of the first n ranks written out
+template <class T>
+__global__ __launch_bounds__(256) void eigh_rank_kernel(const T* __restrict__ lam, long long N, long long n,
+                                                        int* __restrict__ rank, T* __restrict__ W) {
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  const T wj = lam[j];
+  int r = 0;
+  for (long long k = 0; k < N; k++) {
+    const T wk = lam[k];
+    r += (wk < wj || (wk == wj && k < j)) ? 1 : 0;
+  }
+  if (wj != wj) r = (int)j;
+  rank[j] = r;
+  if (r < n) W[r] = wj;
+}
+
+// V[i][rank_j] = Vt[j][i] for the n smallest (the real) eigenpairs
+template <class T>
+__global__ __launch_bounds__(256) void eigh_scatter_kernel(const T* __restrict__ Vt, const int* __restrict__ rank,
+                                                           long long N, long long n, T* __restrict__ V) {
+  const long long j = blockIdx.y;
+  const int r = rank[j];
+  if (r >= n) return;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) V[i * n + r] = Vt[j * N + i];
+}
+
+__global__ void eigh_status_or_kernel(int* status, int bits) { atomicOr(status, bits); }
+
+template <class T>
+int eigh_typed(long long batch, long long n, int lower, const void* A, void* W, void* V, int sorted = 1, int max_sweeps = MAX_SWEEPS);
+
+template <class T>
+int eigh_block_jacobi(long long n, int lower, const T* A, T* W, T* V) {
+  hipStream_t st = pthip::ctx().stream;
+  const int dt = sizeof(T) == 8 ? PTHIP_F64 : PTHIP_F32;
+  const long long m = 2 * EB;
+  const long long npairs = (n + m - 1) / m, N = npairs * m, nbk = 2 * npairs;
+  const size_t mat = (size_t)N * N * sizeof(T);
+  const size_t sbytes = (size_t)npairs * m * m * sizeof(T);
+  const size_t ibytes = ((size_t)N * 8 + 255) / 256 * 256;
+  const size_t lbytes = ((size_t)N * sizeof(T) + 255) / 256 * 256;
+  void* ws = nullptr;
+  int r = pthip_alloc(5 * mat + 2 * sbytes + (size_t)npairs * m * sizeof(T) + 256 + 2 * ibytes + lbytes + 256, &ws);
+  if (r) return r;
+  auto fail = [&](int rc) { pthip_free(ws); return rc; };
+  char* p = (char*)ws;
+  T* Gt = (T*)p; p += mat;
+  T* G2 = (T*)p; p += mat;
+  T* Vt = (T*)p; p += mat;
+  T* V2 = (T*)p; p += mat;
+  T* B = (T*)p; p += mat;
+  T* S = (T*)p; p += sbytes;
+  T* U = (T*)p; p += sbytes;
+  T* Wsub = (T*)p; p += ((size_t)npairs * m * sizeof(T) + 255) / 256 * 256;
+  long long* idx = (long long*)p; p += ibytes;
+  int* rank = (int*)p; p += ibytes;
+  T* lam = (T*)p; p += lbytes;
+  unsigned long long* maxbits = (unsigned long long*)p;  // [0] ||A||_inf bits, [1] low word: off-diagonal bits, [2] ||A^4||_inf bits
+  unsigned* offbits = (unsigned*)(maxbits + 1);
+  T* sigma = (T*)(maxbits + 3);
+  // the tournament step on block positions (pairs are the adjacent positions 2k, 2k+1): position 0 stays, the top
+  // row shifts right, the bottom row shifts left; as a row gather: new row r of block position q comes from ...
+  {
+    std::vector<long long> src(nbk), h(N);
+    const long long hp = npairs;
+    for (long long k = 0; k < hp; k++) {
+      // top_k = position 2k, bottom_k = position 2k+1
+      long long top_src, bot_src;
+      if (k == 0) top_src = 0;
+      else if (k == 1) top_src = 1;                 // bottom_0
+      else top_src = 2 * (k - 1);                    // top_{k-1}
+      if (k == hp - 1) bot_src = hp == 1 ? 1 : 2 * (hp - 1);  // top_{hp-1}
+      else bot_src = 2 * (k + 1) + 1;                // bottom_{k+1}
+      src[2 * k] = top_src;
+      src[2 * k + 1] = bot_src;
+    }
+    for (long long q = 0; q < nbk; q++)
+      for (long long t = 0; t < EB; t++) h[q * EB + t] = src[q] * EB + t;
+    if (hipError_t e = hipMemcpyAsync(idx, h.data(), (size_t)N * 8, hipMemcpyHostToDevice, st); e != hipSuccess) return fail(pthip::check(e, "eigh idx upload"));
+    if (hipError_t e = hipStreamSynchronize(st); e != hipSuccess) return fail(pthip::check(e, "eigh idx sync"));  // (h goes out of scope)
+  }
+  if (hipError_t e = hipMemsetAsync(maxbits, 0, 32, st); e != hipSuccess) return fail(pthip::check(e, "eigh memset"));
+  PTHIP_KLAUNCH((eigh_rowsum_kernel<T>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, A, n, lower, maxbits);
+  const unsigned pg = (unsigned)(N * N / 256 > 4096 ? 4096 : (N * N + 255) / 256);
+  PTHIP_KLAUNCH((eigh_prep_kernel<T>), dim3(pg), dim3(256), 0, st, A, n, N, lower, Gt, Vt);
+  // ||A||_2^4 = ||A^4||_2 <= ||A^4||_inf: two squarings on the MFMA GEMM
+  if ((r = pthip_gemm(dt, 1, N, N, N, 1.0, Gt, 0, N, 1, Gt, 0, N, 1, 0.0, nullptr, 0, 0, 0, G2))) return fail(r);
+  if ((r = pthip_gemm(dt, 1, N, N, N, 1.0, G2, 0, N, 1, G2, 0, N, 1, 0.0, nullptr, 0, 0, 0, V2))) return fail(r);
+  PTHIP_KLAUNCH((eigh_absrow_kernel<T>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, (const T*)V2, N, maxbits + 2);
+  PTHIP_KLAUNCH((eigh_shift_kernel<T>), dim3(pg), dim3(256), 0, st, Gt, B, n, N, (const unsigned long long*)maxbits, sigma);
+  if ((r = pthip::post_launch("eigh_prep"))) return fail(r);
+  const double eps = sizeof(T) == 8 ? 2.220446049250313e-16 : 1.1920929e-07;
+  const double tol = eps * (N > 256 ? (double)N / 4 : 64.0);
+  double prev = 1e300;
+  bool converged = false;
+  static const int inner_env = getenv("PTHIP_EIGH_INNER") ? atoi(getenv("PTHIP_EIGH_INNER")) : 0;
+  // one inner sweep per subproblem: n = 1024 in 131 ms (13 outer sweeps) against 207 / 277 / 384 ms with 2 / 3 / until
+  // converged (12 outer sweeps each) — profiles/r4n_eigh.txt
+  const int inner_cap = inner_env > 0 ? inner_env : 1;
+  const int max_sweeps = 16;
+  for (int sweep = 0; sweep < max_sweeps && !converged; sweep++) {
+    const long long rounds = nbk > 2 ? nbk - 1 : 1;
+    // G = B V afresh at the start of a sweep: G and V take the same rotations, but their rounding errors are their
+    // own — over hundreds of rounds G drifts away from B V (measured: eigenvalues off by 1e2 eps sigma without this)
+    if (sweep > 0)
+      if ((r = pthip_gemm(dt, 1, N, N, N, 1.0, Vt, 0, N, 1, B, 0, N, 1, 0.0, nullptr, 0, 0, 0, Gt))) return fail(r);
+    for (long long rd = 0; rd < rounds; rd++) {
+      // Gram matrices of the pairs: S_p = G_p^T G_p with G_p^T = rows [p m, (p+1) m) of Gt
+      if ((r = pthip_gemm(dt, npairs, m, m, N, 1.0, Gt, m * N, N, 1, Gt, m * N, 1, N, 0.0, nullptr, 0, 0, 0, S))) return fail(r);
+      PTHIP_KLAUNCH((eigh_offdiag_kernel<T>), dim3((unsigned)npairs), dim3(256), 0, st, (const T*)S, npairs, (int)m, offbits);
+      // (inner sweeps are capped: a subproblem need not be diagonalised to the last bit while the pairs around it
+      //  are still far from orthogonal; PTHIP_EIGH_INNER overrides)
+      if ((r = eigh_typed<T>(npairs, m, 1, S, Wsub, U, /*sorted=*/0, inner_cap))) return fail(r);
+      // G_p <- G_p U  <=>  rows: Gt_p <- U^T Gt_p ; the same for V
+      if ((r = pthip_gemm(dt, npairs, m, N, m, 1.0, U, m * m, 1, m, Gt, m * N, N, 1, 0.0, nullptr, 0, 0, 0, G2))) return fail(r);
+      if ((r = pthip_gemm(dt, npairs, m, N, m, 1.0, U, m * m, 1, m, Vt, m * N, N, 1, 0.0, nullptr, 0, 0, 0, V2))) return fail(r);
+      if (nbk > 2) {
+        if ((r = pthip_take_rows((int)sizeof(T), N, N, G2, N, N, (const int64_t*)idx, Gt))) return fail(r);
+        if ((r = pthip_take_rows((int)sizeof(T), N, N, V2, N, N, (const int64_t*)idx, Vt))) return fail(r);
+      } else {
+        std::swap(Gt, G2);
+        std::swap(Vt, V2);
+      }
+    }
+    unsigned hb = 0;
+    if (hipError_t e = hipMemcpyAsync(&hb, offbits, 4, hipMemcpyDeviceToHost, st); e != hipSuccess) return fail(pthip::check(e, "eigh off-diagonal read"));
+    if (hipError_t e = hipStreamSynchronize(st); e != hipSuccess) return fail(pthip::check(e, "eigh sweep sync"));
+    if (hipError_t e = hipMemsetAsync(offbits, 0, 4, st); e != hipSuccess) return fail(pthip::check(e, "eigh memset"));
+    float offf;
+    memcpy(&offf, &hb, 4);
+    const double off = offf;
+    static const bool trace = getenv("PTHIP_EIGH_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "[pthip eigh] n=%lld sweep %d: largest relative off-diagonal of the pair Gram matrices %.3e (tol %.1e)\n", n, sweep, off, tol);
+    converged = off <= tol || (sweep >= 2 && off <= 100 * tol && off > 0.5 * prev);
+    prev = off;
+  }
+  if (!converged) {
+    // (scipy raises LinAlgError when LAPACK reports non-convergence: bit 3 of the device error word)
+    PTHIP_KLAUNCH(eigh_status_or_kernel, dim3(1), dim3(1), 0, st, (int*)pthip_status_ptr(), 8);
+  }
+  if ((r = pthip_gemm(dt, 1, N, N, N, 1.0, Vt, 0, N, 1, B, 0, N, 1, 0.0, nullptr, 0, 0, 0, Gt))) return fail(r);  // lambda from a fresh B V
+  PTHIP_KLAUNCH((eigh_lambda_kernel<T>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, (const T*)Gt, (const T*)Vt, N, (const T*)sigma, lam);
+  PTHIP_KLAUNCH((eigh_rank_kernel<T>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, (const T*)lam, N, n, rank, W);
+  PTHIP_KLAUNCH((eigh_scatter_kernel<T>), dim3((unsigned)((n + 255) / 256), (unsigned)N), dim3(256), 0, st, (const T*)Vt, (const int*)rank, N, n, V);
+  r = pthip::post_launch("eigh_block_finish");
+  pthip_free(ws);
+  return r;
+}
+
+template <class T>
+int eigh_typed(long long batch, long long n, int lower, const void* A, void* W, void* V, int sorted, int max_sweeps) {
   if (batch == 0 || n == 0) return 0;
-  if (n > MAX_N) return pthip::set_error("pthip_eigh: n = %lld > %d is not supported yet", n, MAX_N);
+  static const bool no_block = getenv("PTHIP_EIGH_ONE_WG") != nullptr;
+  if (n > EIGH_BLOCK_MIN && !(no_block && n <= MAX_N)) {
+    for (long long b = 0; b < batch; b++) {
+      int r = eigh_block_jacobi<T>(n, lower, (const T*)A + b * n * n, (T*)W + b * n, (T*)V + b * n * n);
+      if (r) return r;
+    }
+    return 0;
+  }
   hipStream_t st = pthip::ctx().stream;
   const size_t one = (size_t)n * (size_t)(n | 1) * sizeof(T);
   const size_t budget = 160 * 1024 - 12 * 1024;  // static scratch of the kernel + slack
@@ -191,7 +491,7 @@ int eigh_typed(long long batch, long long n, int lower, const void* A, void* W, 
   if (!a_lds) { int r = pthip_alloc((size_t)batch * one, &sa); if (r) return r; }
   if (!v_lds) { int r = pthip_alloc((size_t)batch * one, &sv); if (r) { if (sa) pthip_free(sa); return r; } }
   PTHIP_KLAUNCH(k, dim3((unsigned)batch), dim3(wide ? 1024 : 256), dyn, st, (const T*)A, (T*)W, (T*)V, (int)n, lower,
-                     a_lds ? 1 : 0, v_lds ? 1 : 0, (T*)sa, (T*)sv, (int*)pthip_status_ptr());
+                     a_lds ? 1 : 0, v_lds ? 1 : 0, (T*)sa, (T*)sv, (int*)pthip_status_ptr(), sorted, max_sweeps);
   int r = pthip::post_launch("eigh");
   if (sa) pthip_free(sa);  // stream-ordered reuse keeps this safe
   if (sv) pthip_free(sv);

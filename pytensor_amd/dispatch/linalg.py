@@ -12,6 +12,7 @@ import numpy as np
 from pytensor_amd import ffi
 from pytensor_amd.device import DeviceArray, copy_into
 from pytensor_amd.dispatch import handler
+from pytensor_amd.executor import HostValue
 
 
 def _dt(x):
@@ -188,13 +189,13 @@ def blockwise(node, inputs, env):
         from pytensor_amd.dispatch import lu
 
         return lu.eigh(type("_N", (), {"params": cp}), ins, env)
-    return _blockwise_loop(node, ins, env)
+    return _blockwise_loop(node, ins, env, inputs)
 
 
 _INLINE_CACHE = {}
 
 
-def _blockwise_loop(node, ins, env):
+def _blockwise_loop(node, ins, env, raw=None):
     """Any other core op with a device handler: loop the broadcast batch on the host, one core
     call per item on views of the operands (``Blockwise.perform``, pytensor/tensor/blockwise.py:
     542: gufunc semantics).  What ``vectorize`` makes of small helper ops — the row gather
@@ -237,6 +238,10 @@ def _blockwise_loop(node, ins, env):
     try:
         for idx in np.ndindex(*bshape):
             item = [a.view(cs, cst, sum(i * st for i, st in zip(idx, bst))) for a, bst, cs, cst in views]
+            if raw is not None:
+                # an unbatched host-known operand (the step count of a vectorised Scan) stays on the host: the core
+                # handler reads it without a device round trip
+                item = [r if (isinstance(r, HostValue) and r.a.ndim == c) else it for it, r, c in zip(item, raw, core_ndims)]
             rs = [env.to_device(r) for r in core(fake, item, env)]
             if outs is None:
                 outs = [DeviceArray.empty((*bshape, *r.shape), r.dtype) for r in rs]

@@ -509,7 +509,9 @@ def _(op, node, ctx):
     core = hip_funcify(op.core_op, core_node, ctx)
     # (batched kernels exist for the linalg family; any other lowered core op runs as a host loop
     #  over the batch of single-item device calls — dispatch/linalg.py::_blockwise_loop)
-    if core is None or core[0] in ("Scan", "Blockwise", "HostPerform"):
+    # (a vectorised Scan — `vectorize_graph` of a graph holding a Scan — also runs as that host loop: one device
+    #  Scan per batch item, Blockwise.perform's gufunc semantics, pytensor/tensor/blockwise.py:542)
+    if core is None or core[0] in ("Blockwise", "HostPerform"):
         return None
     name, params = core
     if core is _INLINE:

@@ -75,6 +75,49 @@ def test_potrf_trsv_fused_kernel(hip, dtype, n):
     assert np.isnan(L.to_host()).all() and np.isnan(x.to_host()).all()
 
 
+@pytest.mark.parametrize("dtype,n,batch,kind", [("float64", 161, 1, "random"), ("float64", 200, 2, "random"), ("float64", 256, 1, "plusminus"),
+                                                ("float64", 300, 1, "lowrank"), ("float64", 513, 1, "random"), ("float64", 1024, 1, "random"),
+                                                ("float32", 320, 1, "random")])
+def test_eigh_block_jacobi_beyond_one_cu(hip, dtype, n, batch, kind):
+    """pthip_eigh for matrices beyond one CU's LDS (csrc/eigh.hip eigh_block_jacobi: 32-column blocks, batched
+    64 x 64 subproblems, MFMA GEMM updates; any n) against LAPACK and the defining properties.  ``plusminus``:
+    eigenvalues in +/- pairs (a one-sided method on the unshifted matrix cannot separate them); ``lowrank``: an
+    exactly singular matrix (the null space still gets orthonormal vectors); n not a multiple of 64 exercises the
+    decoupled padding; ``lower=False`` reads only the upper triangle.  Reference: Eigh.perform,
+    pytensor/tensor/linalg/decomposition/eigen.py:177-195 (scipy.linalg.eigh: any n)."""
+    from pytensor_amd.device import DeviceArray
+
+    rng = np.random.default_rng(500 + n)
+    if kind == "plusminus":
+        Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+        lam = np.concatenate([np.arange(1, n // 2 + 1), -np.arange(1, n - n // 2 + 1)]).astype("float64")
+        S = ((Q * lam) @ Q.T)[None]
+    elif kind == "lowrank":
+        B = rng.normal(size=(n, 40))
+        S = (B @ B.T)[None]
+    else:
+        M = rng.normal(size=(batch, n, n))
+        S = (M + M.transpose(0, 2, 1)) / 2
+    S = ((S + S.transpose(0, 2, 1)) / 2).astype(dtype)
+    lower = n % 2 == 0
+    junk = rng.normal(size=(n, n)).astype(dtype) * 1e3
+    keep = np.tril(S) + np.triu(junk, 1) if lower else np.triu(S) + np.tril(junk, -1)
+    dS = DeviceArray.from_host(np.ascontiguousarray(keep))
+    w, v = DeviceArray.empty((batch, n), dtype), DeviceArray.empty((batch, n, n), dtype)
+    hip.check(hip.lib().pthip_eigh(hip.np_dtype_code(dtype), batch, n, int(lower), dS.ptr, w.ptr, v.ptr))
+    w, v = w.to_host(), v.to_host()
+    tol = 1e-12 if dtype == "float64" else 5e-6
+    for b in range(batch):
+        S64 = S[b].astype("float64")
+        wr = np.linalg.eigvalsh(S64)
+        scale = max(1.0, float(np.abs(wr).max()))
+        np.testing.assert_allclose(w[b], wr, rtol=0, atol=tol * scale * n)
+        assert (np.diff(w[b]) >= 0).all()
+        V = v[b].astype("float64")
+        np.testing.assert_allclose(V.T @ V, np.eye(n), atol=tol * n)
+        np.testing.assert_allclose(S64 @ V, V * w[b][None, :], atol=tol * scale * n)
+
+
 @pytest.mark.parametrize("dtype,n,batch", [("float64", 1, 1), ("float64", 2, 3), ("float64", 5, 2), ("float64", 64, 2), ("float64", 96, 1),
                                            ("float64", 100, 1), ("float64", 141, 2), ("float32", 33, 2), ("float32", 150, 1)])
 def test_eigh_jacobi_kernel(hip, dtype, n, batch):

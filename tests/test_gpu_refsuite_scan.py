@@ -85,8 +85,6 @@ class TestScanHip(ref_scan.TestScan):
     #    test_grad_multiple_outs_some_uncomputable, test_pushforward_2 (which only need the draws to be
     #    the same in the functions they compare).
     test_simple_shared_random = None
-    # -- Blockwise(Scan): a vectorised Scan core op has no device lowering (compile-time NotImplementedError)
-    test_blockwise_scan = None
 
 
 class TestGradUntilHip(ref_scan.TestGradUntil):
