@@ -597,15 +597,23 @@ __global__ __launch_bounds__(BLOCK, 2) void sgemm_persistent_kernel(
 // the last MFMA step of the current one and is already in LDS while the epilogue stores.
 // ---------------------------------------------------------------------------------
 constexpr int T2 = 256, T2K = 16, T2ALD = T2K + 2;
-template <bool PF>  // PF: LDS fragments read one k-step ahead (two register sets)
+// Round 4: every operand orientation (the reference's stride -> transpose-flag dispatch,
+// pytensor/tensor/blas/c_code/codegen.py:159-250).  An operand whose K axis is contiguous (AKC: row-major A;
+// BKC: B stored N x K) is fetched as float4 along K into the padded [256][18] LDS image and read back as float2
+// fragments; one whose 256-wide axis is contiguous (A stored K x M; row-major B) is fetched as float4 along that
+// axis into the [16][256] image and read back as two scalars per fragment — the two layouts round 3 used for A and B
+// respectively, now chosen per operand.
+template <bool PF, bool AKC, bool BKC>  // PF: LDS fragments read one k-step ahead (two register sets)
 __global__ __launch_bounds__(BLOCK, 1) void sgemm256_kernel(
     float* __restrict__ out, const float* __restrict__ A, const float* __restrict__ B,
     const float* __restrict__ C, long long M, long long N, long long K, long long lda,
     long long ldb, long long sAb, long long sBb, long long sCb, long long sC0, long long sC1,
     float alpha, float beta, long long tiles_m, long long tiles_n, long long batch, long long ldo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* As = (float*)smem_raw;          // [2][256][18]  K-contiguous rows, padded
-  float* Bs = As + 2 * T2 * T2ALD;       // [2][16][256]
+  constexpr int ASZ = AKC ? T2 * T2ALD : T2K * T2;  // one buffer of the A image
+  constexpr int BSZ = BKC ? T2 * T2ALD : T2K * T2;
+  float* As = (float*)smem_raw;  // [2][ASZ]
+  float* Bs = As + 2 * ASZ;      // [2][BSZ]
   const long long nt = tiles_m * tiles_n, total = nt * batch;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm0 = (w >> 1) * 128, wn0 = (w & 1) * 128, h = lane >> 5, i32 = lane & 31;
@@ -627,18 +635,36 @@ __global__ __launch_bounds__(BLOCK, 1) void sgemm256_kernel(
   };
   // staging registers as eight named float4 (arrays assigned on two branches ended up in scratch)
   float4 ga0, ga1, ga2, ga3, gb0, gb1, gb2, gb3;
-  const int a_off = (tid >> 2) * T2ALD + (tid & 3) * 4;  // LDS image of A: row tid/4 (+64 p), k = 4 (tid%4)
-  const int b_off = (tid >> 6) * T2 + (tid & 63) * 4;    // LDS image of B: k row tid/64 (+4 p), column 4 (tid%64)
+  // K-contiguous operand: thread -> row tid/4 (+64 p), k = 4 (tid%4); otherwise: k row tid/64 (+4 p), element 4 (tid%64)
+  const int kc_off = (tid >> 2) * T2ALD + (tid & 3) * 4;
+  const int wc_off = (tid >> 6) * T2 + (tid & 63) * 4;
+  // tile origins and per-k-step advances in elements
+  auto a_tile = [&](long long bz, long long m0) { return A + bz * sAb + (AKC ? m0 * lda : m0); };
+  auto b_tile = [&](long long bz, long long n0) { return B + bz * sBb + (BKC ? n0 * ldb : n0); };
+  const long long a_kstep = AKC ? (long long)T2K : (long long)T2K * lda;
+  const long long b_kstep = BKC ? (long long)T2K : (long long)T2K * ldb;
 #define T2_GLOAD(PA, PB)                                                                            \
   do {                                                                                              \
-    const float* pa_ = (PA) + (long long)(tid >> 2) * lda + (tid & 3) * 4;                          \
-    const float* pb_ = (PB) + (long long)(tid >> 6) * ldb + (tid & 63) * 4;                         \
-    ga0 = *(const float4*)pa_; ga1 = *(const float4*)(pa_ + 64 * lda);                              \
-    ga2 = *(const float4*)(pa_ + 128 * lda); ga3 = *(const float4*)(pa_ + 192 * lda);               \
-    gb0 = *(const float4*)pb_; gb1 = *(const float4*)(pb_ + 4 * ldb);                               \
-    gb2 = *(const float4*)(pb_ + 8 * ldb); gb3 = *(const float4*)(pb_ + 12 * ldb);                  \
+    if constexpr (AKC) {                                                                            \
+      const float* pa_ = (PA) + (long long)(tid >> 2) * lda + (tid & 3) * 4;                        \
+      ga0 = *(const float4*)pa_; ga1 = *(const float4*)(pa_ + 64 * lda);                            \
+      ga2 = *(const float4*)(pa_ + 128 * lda); ga3 = *(const float4*)(pa_ + 192 * lda);             \
+    } else {                                                                                        \
+      const float* pa_ = (PA) + (long long)(tid >> 6) * lda + (tid & 63) * 4;                       \
+      ga0 = *(const float4*)pa_; ga1 = *(const float4*)(pa_ + 4 * lda);                             \
+      ga2 = *(const float4*)(pa_ + 8 * lda); ga3 = *(const float4*)(pa_ + 12 * lda);                \
+    }                                                                                               \
+    if constexpr (BKC) {                                                                            \
+      const float* pb_ = (PB) + (long long)(tid >> 2) * ldb + (tid & 3) * 4;                        \
+      gb0 = *(const float4*)pb_; gb1 = *(const float4*)(pb_ + 64 * ldb);                            \
+      gb2 = *(const float4*)(pb_ + 128 * ldb); gb3 = *(const float4*)(pb_ + 192 * ldb);             \
+    } else {                                                                                        \
+      const float* pb_ = (PB) + (long long)(tid >> 6) * ldb + (tid & 63) * 4;                       \
+      gb0 = *(const float4*)pb_; gb1 = *(const float4*)(pb_ + 4 * ldb);                             \
+      gb2 = *(const float4*)(pb_ + 8 * ldb); gb3 = *(const float4*)(pb_ + 12 * ldb);                \
+    }                                                                                               \
   } while (0)
-#define T2_ST_A(DST, V)                                                                             \
+#define T2_ST_KC(DST, V)                                                                            \
   do {                                                                                              \
     float2* d_ = (float2*)(DST);                                                                    \
     d_[0] = make_float2((V).x, (V).y);                                                              \
@@ -646,16 +672,26 @@ __global__ __launch_bounds__(BLOCK, 1) void sgemm256_kernel(
   } while (0)
 #define T2_SSTORE(AS, BS)                                                                           \
   do {                                                                                              \
-    float* as_ = (AS) + a_off;                                                                      \
-    float* bs_ = (BS) + b_off;                                                                      \
-    T2_ST_A(as_, ga0); T2_ST_A(as_ + 64 * T2ALD, ga1); T2_ST_A(as_ + 128 * T2ALD, ga2); T2_ST_A(as_ + 192 * T2ALD, ga3); \
-    *(float4*)bs_ = gb0; *(float4*)(bs_ + 4 * T2) = gb1; *(float4*)(bs_ + 8 * T2) = gb2; *(float4*)(bs_ + 12 * T2) = gb3; \
+    if constexpr (AKC) {                                                                            \
+      float* as_ = (AS) + kc_off;                                                                   \
+      T2_ST_KC(as_, ga0); T2_ST_KC(as_ + 64 * T2ALD, ga1); T2_ST_KC(as_ + 128 * T2ALD, ga2); T2_ST_KC(as_ + 192 * T2ALD, ga3); \
+    } else {                                                                                        \
+      float* as_ = (AS) + wc_off;                                                                   \
+      *(float4*)as_ = ga0; *(float4*)(as_ + 4 * T2) = ga1; *(float4*)(as_ + 8 * T2) = ga2; *(float4*)(as_ + 12 * T2) = ga3; \
+    }                                                                                               \
+    if constexpr (BKC) {                                                                            \
+      float* bs_ = (BS) + kc_off;                                                                   \
+      T2_ST_KC(bs_, gb0); T2_ST_KC(bs_ + 64 * T2ALD, gb1); T2_ST_KC(bs_ + 128 * T2ALD, gb2); T2_ST_KC(bs_ + 192 * T2ALD, gb3); \
+    } else {                                                                                        \
+      float* bs_ = (BS) + wc_off;                                                                   \
+      *(float4*)bs_ = gb0; *(float4*)(bs_ + 4 * T2) = gb1; *(float4*)(bs_ + 8 * T2) = gb2; *(float4*)(bs_ + 12 * T2) = gb3; \
+    }                                                                                               \
   } while (0)
   long long L = blockIdx.x;
   if (L >= total) return;
   long long m0, n0, bz;
   coords(L, m0, n0, bz);
-  T2_GLOAD(A + bz * sAb + m0 * lda, B + bz * sBb + n0);
+  T2_GLOAD(a_tile(bz, m0), b_tile(bz, n0));
   T2_SSTORE(As, Bs);
   __syncthreads();
   int buf = 0;
@@ -672,32 +708,41 @@ __global__ __launch_bounds__(BLOCK, 1) void sgemm256_kernel(
       for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    const float* Ab = A + bz * sAb + m0 * lda;
-    const float* Bb = B + bz * sBb + n0;
+    const float* Ab = a_tile(bz, m0);
+    const float* Bb = b_tile(bz, n0);
     for (long long kt = 0; kt < nk; kt++) {
       const bool more = kt + 1 < nk;
-      if (more) T2_GLOAD(Ab + (kt + 1) * T2K, Bb + (kt + 1) * T2K * ldb);
-      else if (has_next) T2_GLOAD(A + b1 * sAb + m1 * lda, B + b1 * sBb + n1);
-      const float* as = As + buf * T2 * T2ALD;
-      const float* bs = Bs + buf * T2K * T2;
-      const float* arow = as + (wm0 + i32) * T2ALD + 2 * h;
-      const float* bcol = bs + (2 * h) * T2 + wn0 + i32;
+      if (more) T2_GLOAD(Ab + (kt + 1) * a_kstep, Bb + (kt + 1) * b_kstep);
+      else if (has_next) T2_GLOAD(a_tile(b1, m1), b_tile(b1, n1));
+      const float* as = As + buf * ASZ;
+      const float* bs = Bs + buf * BSZ;
+      // fragment bases: K-contiguous image -> row (w?0 + i32), k = 2h; otherwise -> k row 2h, column (w?0 + i32)
+      const float* abase = AKC ? as + (wm0 + i32) * T2ALD + 2 * h : as + (2 * h) * T2 + wm0 + i32;
+      const float* bbase = BKC ? bs + (wn0 + i32) * T2ALD + 2 * h : bs + (2 * h) * T2 + wn0 + i32;
+      auto afrag = [&](int i, int kk) -> float2 {
+        if constexpr (AKC) return *(const float2*)(abase + i * 32 * T2ALD + kk * 4);
+        else return make_float2(abase[kk * 4 * T2 + i * 32], abase[(kk * 4 + 1) * T2 + i * 32]);
+      };
+      auto bfrag = [&](int j, int kk) -> float2 {
+        if constexpr (BKC) return *(const float2*)(bbase + j * 32 * T2ALD + kk * 4);
+        else return make_float2(bbase[kk * 4 * T2 + j * 32], bbase[(kk * 4 + 1) * T2 + j * 32]);
+      };
       if constexpr (PF) {
       // fragments one k-step AHEAD of the MFMAs that use them (two register sets): read just in time,
       // every group of 16 MFMAs starts behind an LDS round trip (~10 % of the loop at one wave per SIMD)
       float2 af[2][4], bf[2][4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) af[0][i] = *(const float2*)(arow + i * 32 * T2ALD);
+      for (int i = 0; i < 4; i++) af[0][i] = afrag(i, 0);
 #pragma unroll
-      for (int j = 0; j < 4; j++) bf[0][j] = make_float2(bcol[j * 32], bcol[T2 + j * 32]);
+      for (int j = 0; j < 4; j++) bf[0][j] = bfrag(j, 0);
 #pragma unroll
       for (int kk = 0; kk < T2K / 4; kk++) {
         const int cs = kk & 1, ns = cs ^ 1;
         if (kk + 1 < T2K / 4) {
 #pragma unroll
-          for (int i = 0; i < 4; i++) af[ns][i] = *(const float2*)(arow + i * 32 * T2ALD + (kk + 1) * 4);
+          for (int i = 0; i < 4; i++) af[ns][i] = afrag(i, kk + 1);
 #pragma unroll
-          for (int j = 0; j < 4; j++) bf[ns][j] = make_float2(bcol[(kk + 1) * 4 * T2 + j * 32], bcol[((kk + 1) * 4 + 1) * T2 + j * 32]);
+          for (int j = 0; j < 4; j++) bf[ns][j] = bfrag(j, kk + 1);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -717,9 +762,9 @@ __global__ __launch_bounds__(BLOCK, 1) void sgemm256_kernel(
       for (int kk = 0; kk < T2K / 4; kk++) {
         float2 af[4], bf[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) af[i] = *(const float2*)(arow + i * 32 * T2ALD + kk * 4);
+        for (int i = 0; i < 4; i++) af[i] = afrag(i, kk);
 #pragma unroll
-        for (int j = 0; j < 4; j++) bf[j] = make_float2(bcol[kk * 4 * T2 + j * 32], bcol[(kk * 4 + 1) * T2 + j * 32]);
+        for (int j = 0; j < 4; j++) bf[j] = bfrag(j, kk);
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -732,7 +777,7 @@ __global__ __launch_bounds__(BLOCK, 1) void sgemm256_kernel(
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
       }
       }
-      if (more || has_next) T2_SSTORE(As + (buf ^ 1) * T2 * T2ALD, Bs + (buf ^ 1) * T2K * T2);
+      if (more || has_next) T2_SSTORE(As + (buf ^ 1) * ASZ, Bs + (buf ^ 1) * BSZ);
       __syncthreads();
       buf ^= 1;
     }
@@ -766,7 +811,7 @@ __global__ __launch_bounds__(BLOCK, 1) void sgemm256_kernel(
     bz = b1;
   }
 #undef T2_GLOAD
-#undef T2_ST_A
+#undef T2_ST_KC
 #undef T2_SSTORE
 }
 
@@ -860,13 +905,13 @@ int launch(long long batch, long long M, long long N, long long K, T alpha, cons
     return pthip::post_launch("gemm(partials)");
   }
   if (nsplit == 1) {
-    if constexpr (sizeof(T) == 4 && !SKINNY && BKT == 32 && AKC && !BKC) {
-      // row-major x row-major with 256-aligned M, N: one 256 x 256 tile per workgroup
+    if constexpr (sizeof(T) == 4 && !SKINNY && BKT == 32) {
+      // 256-aligned M, N (any operand orientation since round 4): one 256 x 256 tile per workgroup
       static const bool big = !(getenv("PTHIP_SGEMM_256") && atoi(getenv("PTHIP_SGEMM_256")) == 0);
       if (big && M % T2 == 0 && N % T2 == 0 && K % T2K == 0 && K >= T2K && vecA && vecB && (ldo % 1 == 0)) {
-        const size_t sh = (size_t)(2 * T2 * T2ALD + 2 * T2K * T2) * sizeof(float);
+        const size_t sh = (size_t)(2 * (AKC ? T2 * T2ALD : T2K * T2) + 2 * (BKC ? T2 * T2ALD : T2K * T2)) * sizeof(float);
         static const bool pf = !(getenv("PTHIP_SGEMM_256_PF") && atoi(getenv("PTHIP_SGEMM_256_PF")) == 0);
-        auto k256 = pf ? sgemm256_kernel<true> : sgemm256_kernel<false>;
+        auto k256 = pf ? sgemm256_kernel<true, AKC, BKC> : sgemm256_kernel<false, AKC, BKC>;
         static bool attr_b = false;
         if (!attr_b) {
           PTHIP_CHECK(hipFuncSetAttribute((const void*)k256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));

@@ -78,3 +78,46 @@ def test_sgemm256_batched_with_epilogue(hip):
     want = 2.0 * (A2.astype("float64") @ B2.astype("float64")) + 3.0 * row
     bound = C_SUM * EPS * (2.0 * (np.abs(A2).astype("float64") @ np.abs(B2).astype("float64")) + 3.0 * np.abs(row))
     assert np.max(np.abs(got - want) / bound) <= 1.0
+
+
+def _gemm_oriented(hip, A, B, a_t, b_t, env256=None):
+    """A (.., M, K) @ B (.., K, N) with A stored transposed (K x M, M-contiguous) when ``a_t`` and B stored
+    transposed (N x K, K-contiguous) when ``b_t`` — the four stride patterns the reference maps to BLAS transpose
+    flags (pytensor/tensor/blas/c_code/codegen.py:159-250)."""
+    from pytensor_amd.device import DeviceArray
+
+    batch = A.shape[0] if A.ndim == 3 else 1
+    M, K = A.shape[-2:]
+    N = B.shape[-1]
+    b3 = A.ndim == 3
+    if a_t:
+        dA = DeviceArray.from_host(np.ascontiguousarray(np.swapaxes(A, -1, -2)))
+        sA0, sA1 = 1, M
+    else:
+        dA = DeviceArray.from_host(np.ascontiguousarray(A))
+        sA0, sA1 = K, 1
+    if b_t:
+        dB = DeviceArray.from_host(np.ascontiguousarray(np.swapaxes(B, -1, -2)))
+        sB0, sB1 = 1, K
+    else:
+        dB = DeviceArray.from_host(np.ascontiguousarray(B))
+        sB0, sB1 = N, 1
+    out = DeviceArray.empty((*A.shape[:-2], M, N), "float32")
+    hip.check(hip.lib().pthip_gemm(hip.np_dtype_code("float32"), batch, M, N, K, 1.0, dA.ptr, M * K if b3 else 0, sA0, sA1,
+                                   dB.ptr, K * N if b3 else 0, sB0, sB1, 0.0, None, 0, 0, 0, out.ptr))
+    return out.to_host()
+
+
+@pytest.mark.parametrize("a_t,b_t", [(False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("shape", [(256, 256, 16), (512, 768, 80), (1024, 256, 1024), (3, 256, 256, 256)])
+def test_sgemm256_every_operand_orientation(hip, shape, a_t, b_t):
+    """Round 4: the 256 x 256-tile kernel serves NT / TN / TT as well (round 3: row-major x row-major only, the
+    other three fell back to the 128-tile kernel).  Same dot-product bound; bit-identical to itself on a repeat."""
+    *bs, M, N, K = shape
+    rng = np.random.default_rng(M + N + K + 7 * a_t + 13 * b_t)
+    A, B = rng.normal(size=(*bs, M, K)).astype("float32"), rng.normal(size=(*bs, K, N)).astype("float32")
+    got = _gemm_oriented(hip, A, B, a_t, b_t)
+    want = np.matmul(A.astype("float64"), B.astype("float64"))
+    bound = C_SUM * EPS * np.matmul(np.abs(A).astype("float64"), np.abs(B).astype("float64")) + 1e-30
+    assert np.max(np.abs(got - want) / bound) <= 1.0
+    np.testing.assert_array_equal(got, _gemm_oriented(hip, A, B, a_t, b_t))

@@ -61,9 +61,32 @@ def main():
         def run():
             ffi.check(lib.pthip_gemm(dt, batch, M, N, K, 1.0, A.ptr, M * K, K, 1, B.ptr, K * N, N, 1, 0.0, None, 0, 0, 0, out.ptr))
 
+        # the very first launch of this shape on fresh buffers, timed on its own: rocprofv3 summaries of the bench show one
+        # 25-27 ms launch per GEMM kernel (profiles/r3z_c3_kernel_stats.md max column) — is it this one?
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        ffi.check(lib.pthip_event_create(C.byref(e0)))
+        ffi.check(lib.pthip_event_create(C.byref(e1)))
+        firsts = []
+        for _ in range(3):
+            ffi.check(lib.pthip_event_record(e0))
+            run()
+            ffi.check(lib.pthip_event_record(e1))
+            ffi.check(lib.pthip_event_synchronize(e1))
+            m1 = C.c_float()
+            ffi.check(lib.pthip_event_elapsed_ms(e0, e1, C.byref(m1)))
+            firsts.append(round(m1.value, 4))
         ms = timed(lib, run, 10)
         tf = 2.0 * batch * M * N * K / ms / 1e9
-        print(json.dumps({"dtype": dtype, "batch": batch, "M": M, "N": N, "K": K, "ms": round(ms, 4), "TFLOPs": round(tf, 1), "frac": round(tf / PEAK[dtype], 3)}))
+        rec = {"dtype": dtype, "batch": batch, "M": M, "N": N, "K": K, "ms": round(ms, 4), "TFLOPs": round(tf, 1), "frac": round(tf / PEAK[dtype], 3),
+               "first_three_launches_ms": firsts}
+        if dtype == "float32" and M % 256 == 0 and N % 256 == 0 and os.environ.get("PTHIP_BENCH_ORIENT", "1") != "0":
+            # the same product with A and / or B stored transposed (strides swapped: same buffers, other operand values)
+            for tag, (a0, a1), (b0, b1) in (("NT", (K, 1), (1, K)), ("TN", (1, M), (N, 1)), ("TT", (1, M), (1, K))):
+                def run_o(a0=a0, a1=a1, b0=b0, b1=b1):
+                    ffi.check(lib.pthip_gemm(dt, batch, M, N, K, 1.0, A.ptr, M * K, a0, a1, B.ptr, K * N, b0, b1, 0.0, None, 0, 0, 0, out.ptr))
+                mo = timed(lib, run_o, 10)
+                rec[f"frac_{tag}"] = round(2.0 * batch * M * N * K / mo / 1e9 / PEAK[dtype], 3)
+        print(json.dumps(rec))
 
 
 if __name__ == "__main__":
