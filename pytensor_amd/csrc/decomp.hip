@@ -30,6 +30,27 @@ template <class T> __device__ __forceinline__ T wave_sum(T v) {
   return v;
 }
 
+// the same sum out of DPP row operations and v_readlane (no LDS permutes: __shfl_xor is a ds_bpermute round trip
+// per step, six dependent ones per sum) — used where a wave sum sits on the critical path of every Jacobi rotation
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double lane_bcast(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ float lane_bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+template <class T> __device__ __forceinline__ T wave_sum_dpp(T v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror: every lane of a 16-lane row holds the row's sum
+  return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+}
+
 // sum over the block; every thread gets the result (two barriers)
 template <class T> __device__ T block_sum(T v, T* s_red) {
   v = wave_sum(v);
@@ -141,6 +162,11 @@ __global__ __launch_bounds__(SVD_BLOCK) void svd_rows_kernel(T* __restrict__ Xal
                                                         int want_vectors, int* __restrict__ status) {
   __shared__ int s_rot;
   __shared__ T s_norm[2048];  // r <= 2048 (checked by the caller)
+  // squared row norms carried along analytically through the rotations (a' = a - t g, b' = b + t g) and recomputed at
+  // the start of every sweep: one wave sum per pair instead of three (short rows; round 4).
+  // (measured and dropped: X itself in LDS when it fits — 14.3 ms either way at 128 x 128: the rows of a pair already
+  //  arrive in one L2 round trip, the time is in the sweeps)
+  __shared__ T s_n2[2048];
   T* X = Xall + (long long)blockIdx.x * r * c;
   T* Pt = Ptall + (long long)blockIdx.x * r * r;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -153,6 +179,14 @@ __global__ __launch_bounds__(SVD_BLOCK) void svd_rows_kernel(T* __restrict__ Xal
   bool converged = r < 2;
   for (int sweep = 0; sweep < 60 && !converged; sweep++) {
     if (tid == 0) s_rot = 0;
+    if (c <= 64 * SVD_CACHE) {
+      for (int i = wid; i < r; i += SVD_BLOCK / 64) {
+        T a = T(0);
+        for (int j = lane; j < c; j += 64) { const T u = X[(long long)i * c + j]; a += u * u; }
+        a = wave_sum_dpp(a);
+        if (lane == 0) s_n2[i] = a;
+      }
+    }
     __syncthreads();
     for (int step = 0; step < R - 1; step++) {
       for (int idx = wid; idx < R / 2; idx += SVD_BLOCK / 64) {
@@ -177,21 +211,57 @@ __global__ __launch_bounds__(SVD_BLOCK) void svd_rows_kernel(T* __restrict__ Xal
             pu[t] = (want_vectors && j < r) ? pp[j] : T(0);
             pv[t] = (want_vectors && j < r) ? pq[j] : T(0);
           }
-          T a = T(0), b = T(0), g = T(0);
+          T g = T(0);
 #pragma unroll
-          for (int t = 0; t < SVD_CACHE; t++) { a += xu[t] * xu[t]; b += xv[t] * xv[t]; g += xu[t] * xv[t]; }
-          a = wave_sum(a); b = wave_sum(b); g = wave_sum(g);
-          if (g == T(0) || dabs(g) <= eps * sqrt(a) * sqrt(b)) continue;
-          const T zeta = (b - a) / (T(2) * g);
-          const T tt = (zeta >= T(0) ? T(1) : T(-1)) / (dabs(zeta) + sqrt(T(1) + zeta * zeta));
-          const T cs = T(1) / sqrt(T(1) + tt * tt), sn = cs * tt;
+          for (int t = 0; t < SVD_CACHE; t++) g += xu[t] * xv[t];
+          const T a = s_n2[p], b = s_n2[q];
+          g = wave_sum_dpp(g);
+          if (g == T(0) || g * g <= eps * eps * a * b) continue;
+          // the angle in single precision (it steers convergence only), the rotation in working precision
+          const float zf = (float)(b - a) / (2.f * (float)g);
+          float tf = (zf >= 0.f ? 1.f : -1.f) / ((zf < 0.f ? -zf : zf) + __builtin_sqrtf(1.f + zf * zf));
+          T tt = (T)tf;
+          if (!(tf != 0.f && tf == tf)) {
+            // out of single precision's range (a graded matrix: |g| or the ratio under / overflows): the same formula in T
+            const T zeta = (b - a) / (T(2) * g);
+            tt = (zeta >= T(0) ? T(1) : T(-1)) / (dabs(zeta) + sqrt(T(1) + zeta * zeta));
+          }
+          T cs;
+          if constexpr (sizeof(T) == 8) {
+            const double xx = 1.0 + tt * tt;
+            double y = __builtin_amdgcn_rsq(xx);
+            y = y * (1.5 - 0.5 * xx * y * y);
+            y = y * (1.5 - 0.5 * xx * y * y);
+            cs = y;
+          } else {
+            cs = T(1) / __builtin_sqrtf(T(1) + tt * tt);
+          }
+          const T sn = cs * tt;
+          T na = a - tt * g, nb = b + tt * g;
 #pragma unroll
           for (int t = 0; t < SVD_CACHE; t++) {
             const int j = lane + 64 * t;
-            if (j < c) { xp[j] = cs * xu[t] - sn * xv[t]; xq[j] = sn * xu[t] + cs * xv[t]; }
+            const T nu = cs * xu[t] - sn * xv[t], nv = sn * xu[t] + cs * xv[t];
+            xu[t] = nu;
+            xv[t] = nv;
+            if (j < c) { xp[j] = nu; xq[j] = nv; }
             if (want_vectors && j < r) { pp[j] = cs * pu[t] - sn * pv[t]; pq[j] = sn * pu[t] + cs * pv[t]; }
           }
-          if (lane == 0) s_rot = 1;
+          // the analytic update cancels when a row shrinks (a rank-deficient or graded matrix: the small singular values
+          // are exactly what a one-sided method is accurate for): such a norm is summed again from the rotated row
+          if (!(na > T(0.01) * a)) {
+            T z = T(0);
+#pragma unroll
+            for (int t = 0; t < SVD_CACHE; t++) z += xu[t] * xu[t];
+            na = wave_sum_dpp(z);
+          }
+          if (!(nb > T(0.01) * b)) {
+            T z = T(0);
+#pragma unroll
+            for (int t = 0; t < SVD_CACHE; t++) z += xv[t] * xv[t];
+            nb = wave_sum_dpp(z);
+          }
+          if (lane == 0) { s_n2[p] = na; s_n2[q] = nb; s_rot = 1; }
           continue;
         }
         T a = T(0), b = T(0), g = T(0);

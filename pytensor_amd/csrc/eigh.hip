@@ -319,8 +319,11 @@ __global__ __launch_bounds__(EIGH1_BLOCK) void eigh_onesided_kernel(const T* __r
           const float azf = zf < 0.f ? -zf : zf;
           float tf = 1.f / (azf + __builtin_sqrtf(zf * zf + 1.f));
           if (zf < 0.f) tf = -tf;
-          if (!(tf == tf)) tf = 0.f;
-          const T t = (T)tf;
+          T t = (T)tf;
+          if (!(tf != 0.f && tf == tf)) {  // (out of single precision's range: the same formula in T)
+            const T zeta = (b - a) / (T(2) * c);
+            t = (zeta >= T(0) ? T(1) : T(-1)) / ((zeta < T(0) ? -zeta : zeta) + sqrt(zeta * zeta + T(1)));
+          }
           T cs;
           if constexpr (sizeof(T) == 8) {
             const double xx = t * t + 1.0;
