@@ -1818,7 +1818,12 @@ int trsv_dag(int lower, int unit, long long n, long long nrhs, const T* Tm, long
       return fail(pthip::check(e, "trsv_dag device attribute"));
     resident = per_cu * cus;
   }
-  if (nB > resident) return fail(pthip::set_error("pthip_trsm: %d row blocks exceed the %d resident workgroups of the device", nB, resident));
+  if (nB > resident) {
+    // more row blocks than the device holds workgroups (a smaller part, or n beyond 64 x CUs x occupancy): the
+    // persistent kernel would wait on blocks that are not running.  The blocked solve has no such requirement.
+    pthip_free(scratch);
+    return 1 << 30;  // (the caller falls back to trsm_blocked)
+  }
   if (hipError_t e = pthip::memset_async(scratch, 0, boxbytes * nchunk + 256, st); e != hipSuccess) return fail(pthip::check(e, "trsv box memset"));
   // solve coordinates: p = lower ? i : n-1-i
   const long long sg = lower ? 1 : -1;
@@ -2085,8 +2090,9 @@ int trsm_typed(int lower, int unit, long long batch, long long n, long long nrhs
       const T* Tb = (const T*)Tm + b * sTb;
       const T* Bb = (const T*)B + b * sBb;
       T* Ob = (T*)out + b * n * nrhs;
-      const int r = nrhs <= 16 ? trsv_dag<T>(lower, unit, n, nrhs, Tb, sT0, sT1, Bb, Ob)
-                               : trsm_blocked<T>(lower, unit, n, nrhs, Tb, sT0, sT1, Bb, Ob);
+      int r = nrhs <= 16 ? trsv_dag<T>(lower, unit, n, nrhs, Tb, sT0, sT1, Bb, Ob)
+                         : trsm_blocked<T>(lower, unit, n, nrhs, Tb, sT0, sT1, Bb, Ob);
+      if (r == (1 << 30)) r = trsm_blocked<T>(lower, unit, n, nrhs, Tb, sT0, sT1, Bb, Ob);  // (over-subscribed: see trsv_dag)
       if (r) return r;
     }
     return 0;

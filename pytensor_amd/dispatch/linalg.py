@@ -192,8 +192,6 @@ def blockwise(node, inputs, env):
     return _blockwise_loop(node, ins, env, inputs)
 
 
-_INLINE_CACHE = {}
-
 
 def _blockwise_loop(node, ins, env, raw=None):
     """Any other core op with a device handler: loop the broadcast batch on the host, one core
@@ -209,10 +207,13 @@ def _blockwise_loop(node, ins, env, raw=None):
         # an inlined OpFromGraph core: run its lowered inner graph per item (like a Scan step)
         from pytensor_amd.executor import HipExecutable
 
-        inner = _INLINE_CACHE.get(id(p["core_params"]["inner"]))
+        # (the executable rides on the inner graph object itself: it lives exactly as long as the node that owns the
+        #  graph — a process-wide dict keyed by id() kept every one alive for good)
+        ig = p["core_params"]["inner"]
+        inner = getattr(ig, "_pthip_exe", None)
         if inner is None:
-            inner = HipExecutable(p["core_params"]["inner"], device=env.exe._device, tail=False)
-            _INLINE_CACHE[id(p["core_params"]["inner"])] = inner
+            inner = HipExecutable(ig, device=env.exe._device, tail=False)
+            ig._pthip_exe = inner
 
         def core(_node, item, _env):
             return inner.run_device(item, _env)[0]
