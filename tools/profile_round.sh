@@ -29,3 +29,8 @@ python $R/tools/bench_gemm.py > $O/gemm.json 2>&1
 python $R/tools/bench_gemv.py > $O/gemv.json 2>&1
 python $R/tools/bench_lu.py > $O/lu.json 2>&1
 tail -c 600 $O/bench.json; echo; head -8 $O/c4_kernel_stats.md; cat $O/pmc_c4.txt | head -4; head -7 $O/c2_kernel_stats.md; head -8 $O/c3_kernel_stats.md; head -7 $O/c5_kernel_stats.md; cat $O/gemm.json $O/gemv.json
+# round 4: linalg tier next to the host (LU, Eigh, decompositions, the GP graph), fixed-cost ubenches
+python $R/tools/bench_getrf.py 256 512 1024 2048 4096 > $O/getrf.txt 2>&1
+python $R/tools/bench_eigh.py 64 128 256 512 1024 2048 > $O/eigh.txt 2>&1
+python $R/tools/bench_decomp.py > $O/decomp.txt 2>&1
+PTHIP_GP_NODES=1 python $R/tools/bench_gp.py 512 2048 4096 > $O/gp.txt 2>&1
