@@ -923,15 +923,16 @@ __global__ __launch_bounds__(BLOCK) void lu_panel2_kernel(T* __restrict__ W, lon
 // before any is stored.
 template <class T, int PB, int CB>
 __global__ __launch_bounds__(CB) void lu_swap_u12_kernel(T* __restrict__ W, long long ld, int n, int k0, int pw,
-                                                        const int* __restrict__ plist) {
+                                                        const int* __restrict__ plist, long long s0, long long l0,
+                                                        long long s1, long long l1) {  // columns [s0, s0+l0) and [s1, s1+l1)
   extern __shared__ __attribute__((aligned(16))) unsigned char lu_smem[];
   T* xs = (T*)lu_smem;          // [PB][CB]: the panel's rows of this column block, then the solution
   T* Ls = xs + PB * CB;         // [PB][PB + 1]: L11 (strictly lower part)
   __shared__ int e_top[PB], e_dst[PB], e_src[PB];
   const int tid = threadIdx.x;
   const long long cc = (long long)blockIdx.x * CB + tid;
-  const bool have = cc < n - pw;
-  const long long c = have ? (cc < k0 ? cc : cc + pw) : 0;  // (idle threads read column 0: valid memory, results dropped)
+  const bool have = cc < l0 + l1;
+  const long long c = have ? (cc < l0 ? s0 + cc : s1 + (cc - l0)) : 0;  // (idle threads read column 0: valid memory, results dropped)
   const bool right = have && c >= k0 + pw;
   const int ndisp = plist[0];
   for (int i = tid; i < PB; i += CB) {
@@ -990,7 +991,7 @@ int getrf_blocked2(long long n, const T* A, T* LU, long long* perm, T* sign, T* 
     return pthip::set_error("pthip_getrf: n = %lld needs %d co-resident panel workgroups (the device has %d CUs)", n, nWmax, pthip::kNumCU);
   const size_t boxbytes = (size_t)PB * nWmax * (PB + 2) * 16, boxkbytes = 0;
   const size_t ibytes = ((size_t)n * sizeof(int) + 255) / 256 * 256;
-  const size_t pbytes = ((size_t)(1 + 3 * PB) * sizeof(int) + 255) / 256 * 256;
+  const size_t pbytes = ((size_t)2 * (1 + 3 * PB) * sizeof(int) + 255) / 256 * 256;  // two panels' lists (look-ahead)
   void* scratch = nullptr;
   int r = pthip_alloc(boxbytes + boxkbytes + ibytes + pbytes + 256, &scratch);
   if (r) return r;
@@ -1016,27 +1017,66 @@ int getrf_blocked2(long long n, const T* A, T* LU, long long* perm, T* sign, T* 
       return fail(pthip::check(e, "lu_swap_u12 attribute"));
     attr = true;
   }
-  for (long long k0 = 0; k0 < n; k0 += PB) {
+  // Look-ahead (round 4): the trailing update of panel k — interchanges + U12 of every column outside the NEXT panel,
+  // and their GEMM — runs on a second stream while the next panel is being factored; only the next panel's own
+  // columns are swapped / solved / updated on the panel stream first.  (panel 125 us, swap 26, GEMM 30 per 32 columns
+  // at n = 4096: the 56 us hide behind the panel.)  Off while a plan is being captured or recorded (one stream there)
+  // and with PTHIP_LU_LOOKAHEAD=0.  The panel's workgroups wait on each other: they may start late while the GEMM
+  // holds the CUs, but GEMM workgroups always finish, so the panel's do get their CUs.
+  // MEASURED (profiles/r4r_getrf_lookahead.txt): 24.2 ms against 25.0 at n = 4096, 4.67 against 4.60 at n = 1024 — the
+  // panel's cross-workgroup hand-overs slow down by about what the overlap saves once the GEMM loads the memory system.
+  // Correct (same pivots, tests green with it on), but not a win: opt-in with PTHIP_LU_LOOKAHEAD=1.
+  static const bool la_env = getenv("PTHIP_LU_LOOKAHEAD") && atoi(getenv("PTHIP_LU_LOOKAHEAD")) == 1;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cap);
+  const int cur = pthip::ctx().current;
+  const int side = cur == 3 ? 2 : 3;
+  const bool lookahead = la_env && !prof_on && pthip::ctx().recorder == nullptr && cap == hipStreamCaptureStatusNone && n > 4 * PB;
+  auto on_stream = [&](int which) { return pthip_stream_select(which); };
+  auto launch_swap = [&](const int* pl, long long k0, int pw, long long s0, long long l0, long long s1, long long l1) -> int {
+    if (l0 + l1 <= 0) return 0;
+    PTHIP_KLAUNCH(ks, dim3((unsigned)((l0 + l1 + CB - 1) / CB)), dim3(CB), sh, pthip::ctx().stream, LU, n, (int)n, (int)k0, pw, pl, s0, l0, s1, l1);
+    return pthip::post_launch("lu_swap_u12");
+  };
+  auto launch_gemm = [&](long long k0, int pw, long long c0, long long nc) -> int {  // A22[:, c0 : c0+nc) -= L21 U12[:, c0 : c0+nc)
+    const long long rest = n - k0 - pw;
+    if (rest <= 0 || nc <= 0) return 0;
+    return pthip::gemm_inplace(dt, rest, nc, pw, -1.0, LU + (k0 + pw) * n + k0, n, 1, LU + k0 * n + c0, n, 1, 1.0, LU + (k0 + pw) * n + c0, n);
+  };
+  long long panel_index = 0;
+  for (long long k0 = 0; k0 < n; k0 += PB, panel_index++) {
     const int pw = (int)((n - k0) < PB ? (n - k0) : PB);
     const int nW = (int)((n - k0 + BLOCK - 1) / BLOCK);
+    int* pl = plist + (panel_index & 1) * (1 + 3 * PB);
+    hipStream_t ps = pthip::ctx().stream;
     if (prof_on)
-      PTHIP_KLAUNCH((lu_panel2_kernel<T, PB, true>), dim3((unsigned)nW), dim3(BLOCK), 0, st, LU, n, (int)n, (int)k0, nW, box, ipiv, plist, flags,
+      PTHIP_KLAUNCH((lu_panel2_kernel<T, PB, true>), dim3((unsigned)nW), dim3(BLOCK), 0, ps, LU, n, (int)n, (int)k0, nW, box, ipiv, pl, flags,
                     flags + 1, pthip::ctx().status_dev, nonce, prof);
     else
-      PTHIP_KLAUNCH((lu_panel2_kernel<T, PB, false>), dim3((unsigned)nW), dim3(BLOCK), 0, st, LU, n, (int)n, (int)k0, nW, box, ipiv, plist, flags,
+      PTHIP_KLAUNCH((lu_panel2_kernel<T, PB, false>), dim3((unsigned)nW), dim3(BLOCK), 0, ps, LU, n, (int)n, (int)k0, nW, box, ipiv, pl, flags,
                     flags + 1, pthip::ctx().status_dev, nonce, prof);
     if ((r = pthip::post_launch("lu_panel2"))) return fail(r);
-    if (n - pw > 0) {
-      PTHIP_KLAUNCH(ks, dim3((unsigned)((n - pw + CB - 1) / CB)), dim3(CB), sh, st, LU, n, (int)n, (int)k0, pw, (const int*)plist);
-      if ((r = pthip::post_launch("lu_swap_u12"))) return fail(r);
+    const long long right0 = k0 + pw, nright = n - right0;
+    if (!lookahead) {
+      if ((r = launch_swap(pl, k0, pw, 0, k0, right0, nright))) return fail(r);
+      if ((r = launch_gemm(k0, pw, right0, nright))) return fail(r);
+      continue;
     }
-    const long long rest = n - k0 - pw;
-    if (rest > 0) {
-      r = pthip::gemm_inplace(dt, rest, rest, pw, -1.0, LU + (k0 + pw) * n + k0, n, 1, LU + k0 * n + k0 + pw, n, 1, 1.0,
-                              LU + (k0 + pw) * n + k0 + pw, n);
-      if (r) return fail(r);
-    }
+    // the next panel's columns on this stream; everything else on the side stream, behind the panel
+    const long long nnext = nright < PB ? nright : PB;
+    if (panel_index > 0)
+      if ((r = pthip_stream_wait(cur, side))) return fail(r);  // the previous trailing update touched these columns
+    if ((r = launch_swap(pl, k0, pw, right0, nnext, 0, 0))) return fail(r);
+    if ((r = launch_gemm(k0, pw, right0, nnext))) return fail(r);
+    if ((r = pthip_stream_wait(side, cur))) return fail(r);  // (behind this panel; the two small launches above ride along)
+    if ((r = on_stream(side))) return fail(r);
+    r = launch_swap(pl, k0, pw, 0, k0, right0 + nnext, nright - nnext);
+    if (!r) r = launch_gemm(k0, pw, right0 + nnext, nright - nnext);
+    const int r2 = on_stream(cur);
+    if (r || r2) return fail(r ? r : r2);
   }
+  if (lookahead)
+    if ((r = pthip_stream_wait(cur, side))) return fail(r);
   auto kf = lu_finish_kernel<T>;
   const size_t shf = (size_t)n * sizeof(int);
   static bool attrf = false;
