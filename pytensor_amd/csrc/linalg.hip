@@ -1986,6 +1986,30 @@ __global__ __launch_bounds__(BLOCK) void tri_inv256_kernel(T* __restrict__ Tinv,
   }
 }
 
+// Inverses of diagonal blocks of size 2s from those of size s:  inv([[A, 0], [C, D]]) = [[A^-1, 0], [-D^-1 C A^-1, D^-1]]
+// (lower; the upper case mirrors it).  `off` holds the off-diagonal blocks (s x s each, computed by two batched GEMMs),
+// a pair without a second block gets the identity there (rows beyond n carry the identity from the level below).
+template <class T>
+__global__ __launch_bounds__(BLOCK) void tri_inv_assemble_kernel(T* __restrict__ Inv2, const T* __restrict__ Inv, const T* __restrict__ off,
+                                                                int s, int nb_s, int lower) {
+  const long long p = blockIdx.y;
+  const int b0 = 2 * (int)p, b1 = b0 + 1;
+  const long long s2 = 2LL * s;
+  T* dst = Inv2 + p * s2 * s2;
+  const T* A = Inv + (long long)b0 * s * s;
+  const T* D = b1 < nb_s ? Inv + (long long)b1 * s * s : nullptr;
+  const T* O = off + p * (long long)s * s;
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < s2 * s2; e += (long long)gridDim.x * BLOCK) {
+    const int i = (int)(e / s2), j = (int)(e - (long long)i * s2);
+    T v;
+    if (i < s && j < s) v = A[(long long)i * s + j];
+    else if (i >= s && j >= s) v = D ? D[(long long)(i - s) * s + (j - s)] : (i == j ? T(1) : T(0));
+    else if (lower ? (i >= s) : (i < s)) v = D ? O[(long long)(lower ? i - s : i) * s + (lower ? j : j - s)] : T(0);
+    else v = T(0);
+    dst[e] = v;
+  }
+}
+
 // one matrix, many right-hand sides: the inverses of the 256 x 256 diagonal blocks up front (one launch),
 // then per block X_b = inv(T_bb) B_b and the update of all rows still to come, both on the MFMA GEMM at
 // K = 256 — three launches per 256 rows (a version with 64-row inner steps and K = 64 updates inside the
@@ -1995,7 +2019,7 @@ int trsm_blocked(int lower, int unit, long long n, long long nrhs, const T* Tm, 
   hipStream_t st = pthip::ctx().stream;
   const int dt = sizeof(T) == 8 ? PTHIP_F64 : PTHIP_F32;
   const long long nB = (n + TB - 1) / TB;
-  const size_t invbytes = (size_t)nB * TB * TB * sizeof(T), tmpbytes = (size_t)TB * nrhs * sizeof(T);
+  const size_t invbytes = (size_t)nB * TB * TB * sizeof(T), tmpbytes = (size_t)4 * TB * nrhs * sizeof(T);  // (steps of up to 1024 rows)
   void* scratch = nullptr;
   int r = pthip_alloc(invbytes + tmpbytes + 256, &scratch);
   if (r) return r;
@@ -2016,10 +2040,66 @@ int trsm_blocked(int lower, int unit, long long n, long long nrhs, const T* Tm, 
   }
   PTHIP_KLAUNCH(ki, dim3((unsigned)nB), dim3(BLOCK), lds, st, Tinv, Tm, sT0, sT1, (int)n, lower, unit, flag);
   if ((r = pthip::post_launch("tri_inv256"))) return fail(r);
+  // Round 4: with many right-hand sides the 256-row steps are 25 dependent launches at n = 2048 whose solve GEMMs
+  // (M = 256) fill an eighth of the chip.  The block inverses are doubled once (256 -> 512: per pair
+  // inv = [[A^-1, 0], [-D^-1 C A^-1, D^-1]], two batched GEMMs and an assemble launch for all pairs), then the same
+  // right-looking sweep runs with 512-row steps.  (Each doubling squares nothing but widens the block whose explicit
+  // inverse is applied: PTHIP_TRSM_BLOCK=256 keeps the round-3 form, 1024 doubles twice.)
+  static const int blk_env = getenv("PTHIP_TRSM_BLOCK") ? atoi(getenv("PTHIP_TRSM_BLOCK")) : 512;
+  long long SB = TB;  // rows per step
+  T* InvCur = Tinv;
+  void* lvl_scratch[2] = {nullptr, nullptr};
+  auto fail2 = [&](int rc) { for (void* q : lvl_scratch) if (q) pthip_free(q); return fail(rc); };
+  for (int lvl = 0; lvl < 2 && SB * 2 <= blk_env && nrhs >= 2 * SB && n > SB; lvl++) {
+    const long long sblk = SB, nb_s = (n + sblk - 1) / sblk, npairs = (nb_s + 1) / 2;
+    const size_t inv2bytes = (size_t)npairs * 4 * sblk * sblk * sizeof(T), offbytes = (size_t)npairs * sblk * sblk * sizeof(T);
+    void* q = nullptr;
+    if ((r = pthip_alloc(inv2bytes + 2 * offbytes + 256, &q))) return fail2(r);
+    lvl_scratch[lvl] = q;
+    T* Inv2 = (T*)q;
+    T* tmp = (T*)((char*)q + inv2bytes);
+    T* off = (T*)((char*)q + inv2bytes + offbytes);
+    if (hipError_t e = pthip::memset_async(tmp, 0, 2 * offbytes, st); e != hipSuccess) return fail2(pthip::check(e, "trsm level memset"));
+    long long full = 0;  // pairs whose second block is complete
+    while (full < npairs && (2 * full + 2) * sblk <= n) full++;
+    const long long with_b1 = nb_s / 2;  // pairs that have a second block at all (complete or partial)
+    const long long pstride = 2 * sblk * (sT0 + sT1);
+    // C of pair p: lower -> rows of the second block x columns of the first; upper -> the mirror
+    const T* C0 = lower ? Tm + sblk * sT0 : Tm + sblk * sT1;
+    if (lower) {
+      // tmp = C A^-1 (valid rows only), off = -D^-1 tmp
+      if (full > 0)
+        if ((r = pthip_gemm(dt, full, sblk, sblk, sblk, 1.0, C0, pstride, sT0, sT1, InvCur, 2 * sblk * sblk, sblk, 1, 0.0, nullptr, 0, 0, 0, tmp))) return fail2(r);
+      if (with_b1 > full) {
+        const long long pidx = full, rows = n - (2 * pidx + 1) * sblk;
+        if ((r = pthip::gemm_inplace(dt, rows, sblk, sblk, 1.0, C0 + pidx * pstride, sT0, sT1, InvCur + 2 * pidx * sblk * sblk, sblk, 1, 0.0,
+                                     tmp + pidx * sblk * sblk, sblk))) return fail2(r);
+      }
+      if (with_b1 > 0)
+        if ((r = pthip_gemm(dt, with_b1, sblk, sblk, sblk, -1.0, InvCur + sblk * sblk, 2 * sblk * sblk, sblk, 1, tmp, sblk * sblk, sblk, 1, 0.0, nullptr, 0, 0,
+                            0, off))) return fail2(r);
+    } else {
+      // tmp = A^-1 C (valid columns only), off = -tmp D^-1
+      if (full > 0)
+        if ((r = pthip_gemm(dt, full, sblk, sblk, sblk, 1.0, InvCur, 2 * sblk * sblk, sblk, 1, C0, pstride, sT0, sT1, 0.0, nullptr, 0, 0, 0, tmp))) return fail2(r);
+      if (with_b1 > full) {
+        const long long pidx = full, cols = n - (2 * pidx + 1) * sblk;
+        if ((r = pthip::gemm_inplace(dt, sblk, cols, sblk, 1.0, InvCur + 2 * pidx * sblk * sblk, sblk, 1, C0 + pidx * pstride, sT0, sT1, 0.0,
+                                     tmp + pidx * sblk * sblk, sblk))) return fail2(r);
+      }
+      if (with_b1 > 0)
+        if ((r = pthip_gemm(dt, with_b1, sblk, sblk, sblk, -1.0, tmp, sblk * sblk, sblk, 1, InvCur + sblk * sblk, 2 * sblk * sblk, sblk, 1, 0.0, nullptr, 0, 0,
+                            0, off))) return fail2(r);
+    }
+    PTHIP_KLAUNCH((tri_inv_assemble_kernel<T>), dim3(64, (unsigned)npairs), dim3(BLOCK), 0, st, Inv2, (const T*)InvCur, (const T*)off, (int)sblk, (int)nb_s, lower);
+    if ((r = pthip::post_launch("tri_inv_assemble"))) return fail2(r);
+    InvCur = Inv2;
+    SB = 2 * sblk;
+  }
   // block [k0, k0 + nb): solve it, then update rows [u0, u1)
   auto step = [&](long long k0, long long nb, long long u0, long long u1) -> int {
     T* Xk = out + k0 * nrhs;
-    int rc = pthip::gemm_inplace(dt, nb, nrhs, nb, 1.0, Tinv + (k0 / TB) * TB * TB, TB, 1, Xk, nrhs, 1, 0.0, Xt, nrhs);
+    int rc = pthip::gemm_inplace(dt, nb, nrhs, nb, 1.0, InvCur + (k0 / SB) * SB * SB, SB, 1, Xk, nrhs, 1, 0.0, Xt, nrhs);
     if (rc) return rc;
     if (hipError_t e = pthip::memcpy_async(Xk, Xt, (size_t)nb * nrhs * sizeof(T), hipMemcpyDeviceToDevice, st); e != hipSuccess)
       return pthip::check(e, "trsm block copy");
@@ -2027,18 +2107,19 @@ int trsm_blocked(int lower, int unit, long long n, long long nrhs, const T* Tm, 
     return 0;
   };
   if (lower) {
-    for (long long k0 = 0; k0 < n; k0 += TB) {
-      const long long nb = (n - k0) < TB ? (n - k0) : TB;
-      if ((r = step(k0, nb, k0 + nb, n))) return fail(r);
+    for (long long k0 = 0; k0 < n; k0 += SB) {
+      const long long nb = (n - k0) < SB ? (n - k0) : SB;
+      if ((r = step(k0, nb, k0 + nb, n))) return fail2(r);
     }
   } else {
-    for (long long k0 = (n - 1) / TB * TB; k0 >= 0; k0 -= TB) {
-      const long long nb = (n - k0) < TB ? (n - k0) : TB;
-      if ((r = step(k0, nb, 0, k0))) return fail(r);
+    for (long long k0 = (n - 1) / SB * SB; k0 >= 0; k0 -= SB) {
+      const long long nb = (n - k0) < SB ? (n - k0) : SB;
+      if ((r = step(k0, nb, 0, k0))) return fail2(r);
     }
   }
   PTHIP_KLAUNCH((nan_fill_if_kernel<T>), dim3(256), dim3(BLOCK), 0, st, out, n * nrhs, (const int*)flag);
   r = pthip::post_launch("trsm nan fill");
+  for (void* q : lvl_scratch) if (q) pthip_free(q);
   pthip_free(scratch);
   return r;
 }
