@@ -67,10 +67,10 @@ template <class T> __device__ T block_sum(T v, T* s_red) {
 // threads: 64 columns x 4 row slices per pass; s_v: VMAX, s_w: 4 x 64
 template <class T>
 __device__ void apply_reflector(T* __restrict__ M, long long ld, int r0, int m, int c0, int c1,
-                                const T* __restrict__ V, long long ldv, int vc, T tau, T* s_v, T* s_w) {
+                                const T* __restrict__ V, long long ldv, int vc, T tau, T* s_v, T* s_w, int vmax = VMAX) {
   const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
   const int len = m - r0;
-  const bool staged = len <= VMAX;
+  const bool staged = len <= vmax;
   __syncthreads();
   if (staged)
     for (int i = tid; i < len; i += BLOCK) s_v[i] = i == 0 ? T(1) : V[(long long)(r0 + i) * ldv + vc];
@@ -100,15 +100,23 @@ __device__ void apply_reflector(T* __restrict__ M, long long ld, int r0, int m, 
 }
 
 // in place: reflectors below the diagonal, R on and above it, tau[min(m,n)]
-template <class T>
-__global__ __launch_bounds__(BLOCK) void geqrf_kernel(T* __restrict__ Aall, T* __restrict__ tauall, int m, int n) {
-  __shared__ T s_v[VMAX];
+// use_lds (round 4): the whole matrix in LDS for the factorisation (m n elements of dynamic shared memory; 128 x 128
+// fp64 = 128 KB) — every column step makes two passes over the trailing block, from L2 that was 2.9 ms at n = 128.
+template <class T, int VM>
+__global__ __launch_bounds__(BLOCK) void geqrf_kernel(T* __restrict__ Aall, T* __restrict__ tauall, int m, int n, int use_lds) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char qr_smem[];
+  __shared__ T s_v[VM];
   __shared__ T s_w[256];
   __shared__ T s_red[BLOCK / 64];
-  T* A = Aall + (long long)blockIdx.x * m * n;
+  T* Ag = Aall + (long long)blockIdx.x * m * n;
+  T* A = use_lds ? (T*)qr_smem : Ag;
   const int K = m < n ? m : n;
   T* tau = tauall + (long long)blockIdx.x * K;
   const int tid = threadIdx.x;
+  if (use_lds) {
+    for (long long e = tid; e < (long long)m * n; e += BLOCK) A[e] = Ag[e];
+    __syncthreads();
+  }
   for (int k = 0; k < K; k++) {
     T part = T(0);
     for (int i = k + 1 + tid; i < m; i += BLOCK) {
@@ -128,25 +136,35 @@ __global__ __launch_bounds__(BLOCK) void geqrf_kernel(T* __restrict__ Aall, T* _
     __syncthreads();  // (every thread has read alpha)
     for (int i = k + 1 + tid; i < m; i += BLOCK) A[(long long)i * n + k] *= scale;
     if (tid == 0) { A[(long long)k * n + k] = beta; tau[k] = tk; }
-    if (k + 1 < n) apply_reflector(A, n, k, m, k + 1, n, A, n, k, tk, s_v, s_w);
+    if (k + 1 < n) apply_reflector(A, n, k, m, k + 1, n, A, n, k, tk, s_v, s_w, VM);
     __syncthreads();
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (long long e = tid; e < (long long)m * n; e += BLOCK) Ag[e] = A[e];
   }
 }
 
 // Q (m x nc) = H_0 H_1 ... H_{k-1} applied to the first nc columns of the identity (dorg2r)
-template <class T>
+template <class T, int VM>
 __global__ __launch_bounds__(BLOCK) void orgqr_kernel(const T* __restrict__ QRall, long long ldqr, long long qr_stride,
-                                                     const T* __restrict__ tauall, T* __restrict__ Qall, int m, int nc, int k) {
-  __shared__ T s_v[VMAX];
+                                                     const T* __restrict__ tauall, T* __restrict__ Qall, int m, int nc, int k, int use_lds) {
+  __shared__ T s_v[VM];
   __shared__ T s_w[256];
   const T* QR = QRall + (long long)blockIdx.x * qr_stride;
   const T* tau = tauall + (long long)blockIdx.x * k;
-  T* Q = Qall + (long long)blockIdx.x * m * nc;
+  extern __shared__ __attribute__((aligned(16))) unsigned char qr_smem[];
+  T* Qg = Qall + (long long)blockIdx.x * m * nc;
+  T* Q = use_lds ? (T*)qr_smem : Qg;
   for (long long e = threadIdx.x; e < (long long)m * nc; e += BLOCK) Q[e] = (e / nc == e % nc) ? T(1) : T(0);
   __syncthreads();
   for (int j = k - 1; j >= 0; j--) {
     const T tj = tau[j];
-    if (tj != T(0) && j < nc) apply_reflector(Q, nc, j, m, j, nc, QR, ldqr, j, tj, s_v, s_w);
+    if (tj != T(0) && j < nc) apply_reflector(Q, nc, j, m, j, nc, QR, ldqr, j, tj, s_v, s_w, VM);
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (long long e = threadIdx.x; e < (long long)m * nc; e += BLOCK) Qg[e] = Q[e];
   }
 }
 
@@ -419,15 +437,40 @@ __global__ void gttrs_kernel(long long batch, int n, int nrhs, int trans, const 
   }
 }
 
+constexpr size_t QR_LDS_MAX = 160 * 1024 - 12 * 1024;  // what is left beside the kernels' static arrays (s_v[512] in this form)
+static const bool qr_no_lds = getenv("PTHIP_QR_NO_LDS") != nullptr;
+
 template <class T> int geqrf_typed(long long batch, int m, int n, void* A, void* tau) {
-  PTHIP_KLAUNCH(geqrf_kernel<T>, dim3((unsigned)batch), dim3(BLOCK), 0, pthip::ctx().stream, (T*)A, (T*)tau, m, n);
+  const size_t need = (size_t)m * n * sizeof(T);
+  if (need <= QR_LDS_MAX && m <= 512 && !qr_no_lds) {
+    auto k = geqrf_kernel<T, 512>;
+    static bool attr = false;
+    if (!attr) {
+      PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)QR_LDS_MAX));
+      attr = true;
+    }
+    PTHIP_KLAUNCH(k, dim3((unsigned)batch), dim3(BLOCK), need, pthip::ctx().stream, (T*)A, (T*)tau, m, n, 1);
+    return pthip::post_launch("geqrf(lds)");
+  }
+  PTHIP_KLAUNCH((geqrf_kernel<T, VMAX>), dim3((unsigned)batch), dim3(BLOCK), 0, pthip::ctx().stream, (T*)A, (T*)tau, m, n, 0);
   return pthip::post_launch("geqrf");
 }
 
 template <class T> int orgqr_typed(long long batch, int m, int nc, int k, const void* QR, long long ldqr, long long stride,
                                    const void* tau, void* Q) {
-  PTHIP_KLAUNCH(orgqr_kernel<T>, dim3((unsigned)batch), dim3(BLOCK), 0, pthip::ctx().stream, (const T*)QR, ldqr, stride,
-                (const T*)tau, (T*)Q, m, nc, k);
+  const size_t need = (size_t)m * nc * sizeof(T);
+  if (need <= QR_LDS_MAX && m <= 512 && !qr_no_lds) {
+    auto kk = orgqr_kernel<T, 512>;
+    static bool attr = false;
+    if (!attr) {
+      PTHIP_CHECK(hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)QR_LDS_MAX));
+      attr = true;
+    }
+    PTHIP_KLAUNCH(kk, dim3((unsigned)batch), dim3(BLOCK), need, pthip::ctx().stream, (const T*)QR, ldqr, stride, (const T*)tau, (T*)Q, m, nc, k, 1);
+    return pthip::post_launch("orgqr(lds)");
+  }
+  PTHIP_KLAUNCH((orgqr_kernel<T, VMAX>), dim3((unsigned)batch), dim3(BLOCK), 0, pthip::ctx().stream, (const T*)QR, ldqr, stride,
+                (const T*)tau, (T*)Q, m, nc, k, 0);
   return pthip::post_launch("orgqr");
 }
 
