@@ -233,8 +233,48 @@ __device__ __forceinline__ float eigh_wave_sum(float v) {
   return t;
 }
 
+// the sum over each 16-lane row of the wave, in every lane of that row: four DPP steps, nothing else
+__device__ __forceinline__ double eigh_row_sum(double v) {
+  v += eigh_dpp_f64<0xB1>(v);
+  v += eigh_dpp_f64<0x4E>(v);
+  v += eigh_dpp_f64<0x141>(v);
+  v += eigh_dpp_f64<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ float eigh_row_sum(float v) {
+  v += eigh_dpp_f32<0xB1>(v);
+  v += eigh_dpp_f32<0x4E>(v);
+  v += eigh_dpp_f32<0x141>(v);
+  v += eigh_dpp_f32<0x140>(v);
+  return v;
+}
+// the sum over each 32-lane half of the wave, in every lane of that half
+__device__ __forceinline__ double eigh_half_sum(double v) {
+  v += eigh_dpp_f64<0xB1>(v);
+  v += eigh_dpp_f64<0x4E>(v);
+  v += eigh_dpp_f64<0x141>(v);
+  v += eigh_dpp_f64<0x140>(v);
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const double h0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0)) +
+                    __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double h1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32)) +
+                    __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return (threadIdx.x & 32) ? h1 : h0;
+}
+__device__ __forceinline__ float eigh_half_sum(float v) {
+  v += eigh_dpp_f32<0xB1>(v);
+  v += eigh_dpp_f32<0x4E>(v);
+  v += eigh_dpp_f32<0x141>(v);
+  v += eigh_dpp_f32<0x140>(v);
+  const int b = __float_as_int(v);
+  const float h0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16));
+  const float h1 = __int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48));
+  return (threadIdx.x & 32) ? h1 : h0;
+}
+
 constexpr int EIGH1_BLOCK = 1024;
-constexpr int EIGH1_MAXN = 192;  // rows per lane: ceil(n / 64) <= 3
+constexpr int EIGH1_MAXN = 192;  // the kernel's per-row LDS arrays
+constexpr int EIGH1_UP = 9;      // row values per lane of a 16-lane row: n <= 144 (fp64 fits the LDS up to n = 138)
 
 template <class T>
 __global__ __launch_bounds__(EIGH1_BLOCK) void eigh_onesided_kernel(const T* __restrict__ Ain, T* __restrict__ Wout,
@@ -294,56 +334,66 @@ __global__ __launch_bounds__(EIGH1_BLOCK) void eigh_onesided_kernel(const T* __r
     }
     __syncthreads();
     for (int r = 0; r < m - 1; r++) {
-      for (int i = wid; i < half; i += NW) {
+      // FOUR pairs per wave and step, one in each 16-lane row: the sum of a pair is four DPP steps inside its row (no
+      // v_readlane at all), and the angle and the rotation of all four run in the same instructions — at n = 128 the 64
+      // pairs of a round are ONE step of the 16 waves (a pair per wave: 4.9 ms; two: 3.4 ms).  Branch-free: a pair below
+      // the threshold — or the ghost pair of an odd n — rotates by the identity.
+      for (int i0p = 4 * wid; i0p < half; i0p += 4 * NW) {
+        const int hsel = lane >> 4, l32 = lane & 15;
+        const int i = i0p + hsel;
         int p, q;
         if (i == 0) { p = r; q = m - 1; }
         else { p = r + i; if (p >= m - 1) p -= m - 1; q = r - i; if (q < 0) q += m - 1; }
         if (p > q) { const int t = p; p = q; q = t; }
-        if (q >= n) continue;  // (odd n: the ghost index sits this round out)
-        T x[3], y[3];
+        const bool real = i < half && q < n;
+        if (!real) { p = 0; q = 0; }
+        T x[EIGH1_UP], y[EIGH1_UP];
         T c = T(0);
 #pragma unroll
-        for (int u = 0; u < 3; u++) {
-          const int k = lane + 64 * u;
-          x[u] = k < n ? G[p * ld + k] : T(0);
-          y[u] = k < n ? G[q * ld + k] : T(0);
+        for (int u = 0; u < EIGH1_UP; u++) {
+          const int k = l32 + 16 * u;
+          x[u] = (real && k < n) ? G[p * ld + k] : T(0);
+          y[u] = (real && k < n) ? G[q * ld + k] : T(0);
           c += x[u] * y[u];
         }
-        const T a = s_n2[p], b = s_n2[q];  // (one wave sum per pair instead of three)
-        c = eigh_wave_sum(c);
-        if (c * c > tol * tol * a * b) {  // (uniform across the wave: the sums are)
-          // the rotation ANGLE in single precision (it only steers convergence: v_rcp_f32 / v_sqrt_f32 instead of three
-          // fp64 divisions and a square root, ~1400 cycles per pair), the rotation itself — cs = (1 + t^2)^-1/2, sn = t cs —
-          // in working precision (v_rsq_f64 + two Newton steps), so that cs^2 + sn^2 = 1 to the last bit that matters
-          const float zf = (float)(b - a) / (2.f * (float)c);
-          const float azf = zf < 0.f ? -zf : zf;
-          float tf = 1.f / (azf + __builtin_sqrtf(zf * zf + 1.f));
-          if (zf < 0.f) tf = -tf;
-          T t = (T)tf;
-          if (!(tf != 0.f && tf == tf)) {  // (out of single precision's range: the same formula in T)
-            const T zeta = (b - a) / (T(2) * c);
-            t = (zeta >= T(0) ? T(1) : T(-1)) / ((zeta < T(0) ? -zeta : zeta) + sqrt(zeta * zeta + T(1)));
-          }
-          T cs;
-          if constexpr (sizeof(T) == 8) {
-            const double xx = t * t + 1.0;
-            double y = __builtin_amdgcn_rsq(xx);
-            y = y * (1.5 - 0.5 * xx * y * y);
-            y = y * (1.5 - 0.5 * xx * y * y);
-            cs = y;
-          } else {
-            cs = T(1) / __builtin_sqrtf(t * t + T(1));
-          }
-          const T sn = t * cs;
+        const T a = s_n2[p], b = s_n2[q];
+        c = eigh_row_sum(c);  // the sum over this lane's 16-lane row
+        const bool rotate = real && (c * c > tol * tol * a * b);
+        // the rotation ANGLE in single precision (it only steers convergence: v_rcp_f32 / v_sqrt_f32 instead of three
+        // fp64 divisions and a square root), the rotation itself — cs = (1 + t^2)^-1/2, sn = t cs — in working
+        // precision (v_rsq_f64 + two Newton steps), so that cs^2 + sn^2 = 1 to the last bit that matters
+        const float cf = rotate ? (float)c : 1.f;
+        const float zf = (float)(b - a) / (2.f * cf);
+        const float azf = zf < 0.f ? -zf : zf;
+        float tf = 1.f / (azf + __builtin_sqrtf(zf * zf + 1.f));
+        if (zf < 0.f) tf = -tf;
+        T t = (T)tf;
+        if (rotate && !(tf != 0.f && tf == tf)) {  // (out of single precision's range: the same formula in T)
+          const T zeta = (b - a) / (T(2) * c);
+          t = (zeta >= T(0) ? T(1) : T(-1)) / ((zeta < T(0) ? -zeta : zeta) + sqrt(zeta * zeta + T(1)));
+        }
+        if (!rotate) t = T(0);
+        T cs;
+        if constexpr (sizeof(T) == 8) {
+          const double xx = t * t + 1.0;
+          double yy = __builtin_amdgcn_rsq(xx);
+          yy = yy * (1.5 - 0.5 * xx * yy * yy);
+          yy = yy * (1.5 - 0.5 * xx * yy * yy);
+          cs = yy;
+        } else {
+          cs = T(1) / __builtin_sqrtf(t * t + T(1));
+        }
+        const T sn = t * cs;
+        if (rotate) {
 #pragma unroll
-          for (int u = 0; u < 3; u++) {
-            const int k = lane + 64 * u;
+          for (int u = 0; u < EIGH1_UP; u++) {
+            const int k = l32 + 16 * u;
             if (k < n) {
               G[p * ld + k] = cs * x[u] - sn * y[u];
               G[q * ld + k] = sn * x[u] + cs * y[u];
             }
           }
-          if (lane == 0) { s_rot = 1; s_n2[p] = a - t * c; s_n2[q] = b + t * c; }
+          if (l32 == 0) { s_rot = 1; s_n2[p] = a - t * c; s_n2[q] = b + t * c; }
         }
       }
       __syncthreads();
@@ -681,7 +731,7 @@ int eigh_typed(long long batch, long long n, int lower, const void* A, void* W, 
   static const bool two_sided = getenv("PTHIP_EIGH_TWO_SIDED") != nullptr;
   // (fp64 only: its accuracy is absolute, eps sigma with sigma up to ~5 ||A||_2 — inside north_star's 1e-12 in fp64,
   //  outside its 1e-5 for the small eigenvalues in fp32, where A and V both fit the LDS up to n = 136 anyway)
-  if (sizeof(T) == 8 && sorted && !two_sided && n >= 8 && n <= EIGH1_MAXN && one <= 160 * 1024 - 8 * 1024) {
+  if (sizeof(T) == 8 && sorted && !two_sided && n >= 8 && n <= EIGH1_MAXN && n <= 16 * EIGH1_UP && one <= 160 * 1024 - 8 * 1024) {
     auto k1 = eigh_onesided_kernel<T>;
     static bool attr1 = false;
     if (!attr1) {
