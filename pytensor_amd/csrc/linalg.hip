@@ -1986,6 +1986,50 @@ __global__ __launch_bounds__(BLOCK) void tri_inv256_kernel(T* __restrict__ Tinv,
   }
 }
 
+// The 64 x 64 diagonal tiles alone, one workgroup each (n / 64 of them side by side; tri_inv256_kernel walks its four
+// tiles and six off-diagonal tiles one after the other in a single workgroup: 205 us at any n, profiles/r3y).  The
+// doubling below takes them to 128, 256, 512 with batched GEMMs.
+template <class T>
+__global__ __launch_bounds__(BLOCK) void tri_inv64_kernel(T* __restrict__ Tinv, const T* __restrict__ Tm, long long sT0, long long sT1, int n,
+                                                         int lower, int unit, int* __restrict__ failflag) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* As = (T*)smem_raw;
+  T* Bs = As + TV * TVS;
+  T* scratch = Bs + TV * TVS;
+  const int tid = threadIdx.x;
+  const long long base = (long long)blockIdx.x * TV;
+  T* out = Tinv + (long long)blockIdx.x * TV * TV;
+  bool fail = false;
+  {
+    T va[TV * TV / BLOCK];
+#pragma unroll
+    for (int u = 0; u < TV * TV / BLOCK; u++) {
+      const int e = u * BLOCK + tid, i = e >> 6, j = e & 63;
+      const long long gi = base + i, gj = base + j;
+      T v = T(0);
+      if (j <= i) {
+        if (gi >= n) v = (i == j) ? T(1) : T(0);
+        else if (i == j && unit) v = T(1);
+        else v = lower ? Tm[gi * sT0 + gj * sT1] : Tm[gj * sT0 + gi * sT1];
+      }
+      va[u] = v;
+      if (i == j && v == T(0)) fail = true;  // trtrs: exact singularity
+    }
+#pragma unroll
+    for (int u = 0; u < TV * TV / BLOCK; u++) {
+      const int e = u * BLOCK + tid;
+      As[(e >> 6) * TVS + (e & 63)] = va[u];
+    }
+  }
+  if (fail) atomicOr(failflag, 1);
+  __syncthreads();
+  tri_inverse64<T>(As, Bs, scratch);  // (ends on a barrier)
+  for (int e = tid; e < TV * TV; e += BLOCK) {
+    const int a = e >> 6, c = e & 63;  // memory order of `out`
+    out[e] = lower ? Bs[a * TVS + c] : Bs[c * TVS + a];
+  }
+}
+
 // Inverses of diagonal blocks of size 2s from those of size s:  inv([[A, 0], [C, D]]) = [[A^-1, 0], [-D^-1 C A^-1, D^-1]]
 // (lower; the upper case mirrors it).  `off` holds the off-diagonal blocks (s x s each, computed by two batched GEMMs),
 // a pair without a second block gets the identity there (rows beyond n carry the identity from the level below).
@@ -2018,8 +2062,14 @@ template <class T>
 int trsm_blocked(int lower, int unit, long long n, long long nrhs, const T* Tm, long long sT0, long long sT1, const T* B, T* out) {
   hipStream_t st = pthip::ctx().stream;
   const int dt = sizeof(T) == 8 ? PTHIP_F64 : PTHIP_F32;
-  const long long nB = (n + TB - 1) / TB;
-  const size_t invbytes = (size_t)nB * TB * TB * sizeof(T), tmpbytes = (size_t)4 * TB * nrhs * sizeof(T);  // (steps of up to 1024 rows)
+  static const int blk_env = getenv("PTHIP_TRSM_BLOCK") ? atoi(getenv("PTHIP_TRSM_BLOCK")) : 512;
+  // start from 64 x 64 tiles when the doubling below will carry them to 256 rows or more (PTHIP_TRSM_BASE=256: the
+  // round-3 single-workgroup inverse of each 256-row block)
+  static const int base_env = getenv("PTHIP_TRSM_BASE") ? atoi(getenv("PTHIP_TRSM_BASE")) : 64;
+  const bool base64 = base_env == 64 && blk_env >= 256 && nrhs >= 512 && n > TV;
+  const long long IB = base64 ? TV : TB;  // rows of the blocks inverted inside a workgroup
+  const long long nB = (n + IB - 1) / IB;
+  const size_t invbytes = (size_t)nB * IB * IB * sizeof(T), tmpbytes = (size_t)4 * TB * nrhs * sizeof(T);  // (steps of up to 1024 rows)
   void* scratch = nullptr;
   int r = pthip_alloc(invbytes + tmpbytes + 256, &scratch);
   if (r) return r;
@@ -2036,21 +2086,23 @@ int trsm_blocked(int lower, int unit, long long n, long long nrhs, const T* Tm, 
   if (!attr && lds > 64 * 1024) {
     if (hipError_t e = hipFuncSetAttribute((const void*)ki, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess)
       return fail(pthip::check(e, "tri_inv256 attribute"));
+    if (hipError_t e = hipFuncSetAttribute((const void*)tri_inv64_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess)
+      return fail(pthip::check(e, "tri_inv64 attribute"));
     attr = true;
   }
-  PTHIP_KLAUNCH(ki, dim3((unsigned)nB), dim3(BLOCK), lds, st, Tinv, Tm, sT0, sT1, (int)n, lower, unit, flag);
-  if ((r = pthip::post_launch("tri_inv256"))) return fail(r);
+  if (base64) PTHIP_KLAUNCH((tri_inv64_kernel<T>), dim3((unsigned)nB), dim3(BLOCK), lds, st, Tinv, Tm, sT0, sT1, (int)n, lower, unit, flag);
+  else PTHIP_KLAUNCH(ki, dim3((unsigned)nB), dim3(BLOCK), lds, st, Tinv, Tm, sT0, sT1, (int)n, lower, unit, flag);
+  if ((r = pthip::post_launch(base64 ? "tri_inv64" : "tri_inv256"))) return fail(r);
   // Round 4: with many right-hand sides the 256-row steps are 25 dependent launches at n = 2048 whose solve GEMMs
   // (M = 256) fill an eighth of the chip.  The block inverses are doubled once (256 -> 512: per pair
   // inv = [[A^-1, 0], [-D^-1 C A^-1, D^-1]], two batched GEMMs and an assemble launch for all pairs), then the same
   // right-looking sweep runs with 512-row steps.  (Each doubling squares nothing but widens the block whose explicit
   // inverse is applied: PTHIP_TRSM_BLOCK=256 keeps the round-3 form, 1024 doubles twice.)
-  static const int blk_env = getenv("PTHIP_TRSM_BLOCK") ? atoi(getenv("PTHIP_TRSM_BLOCK")) : 512;
-  long long SB = TB;  // rows per step
+  long long SB = IB;  // rows per step
   T* InvCur = Tinv;
-  void* lvl_scratch[2] = {nullptr, nullptr};
+  void* lvl_scratch[4] = {nullptr, nullptr, nullptr, nullptr};
   auto fail2 = [&](int rc) { for (void* q : lvl_scratch) if (q) pthip_free(q); return fail(rc); };
-  for (int lvl = 0; lvl < 2 && SB * 2 <= blk_env && nrhs >= 2 * SB && n > SB; lvl++) {
+  for (int lvl = 0; lvl < 4 && SB * 2 <= blk_env && nrhs >= 2 * SB && n > SB; lvl++) {
     const long long sblk = SB, nb_s = (n + sblk - 1) / sblk, npairs = (nb_s + 1) / 2;
     const size_t inv2bytes = (size_t)npairs * 4 * sblk * sblk * sizeof(T), offbytes = (size_t)npairs * sblk * sblk * sizeof(T);
     void* q = nullptr;

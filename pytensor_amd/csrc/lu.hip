@@ -678,10 +678,16 @@ int getrf_blocked(long long n, const T* A, T* LU, long long* perm, T* sign, T* l
 // ------------------------------------------------------------------------------------------
 constexpr unsigned long long LU_EPOCH_MUL = 0x9E3779B97F4A7C15ull;
 
+// X1: every workgroup of the panel sits on ONE XCD (the launch is 8x as wide and only the workgroups with id % 8 == 0
+// take part — ids go round-robin over the 8 XCDs), so the record can stop in that XCD's L2: a store without
+// write-through, read by the agent-scope loads of the others out of the same L2.  tools/ubench/hop.hip: 315-335 ns
+// one way against 470-580 ns for the write-through pair (across XCDs the plain store is never seen).
+template <bool X1>
 __device__ __forceinline__ void lu_publish_t(unsigned long long* slot, unsigned long long bits, unsigned long long tag) {
   typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
   u2 pr = {bits, bits ^ tag};
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 2" : : "v"((u2*)slot), "v"(pr) : "memory");
+  if constexpr (X1) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 2" : : "v"((u2*)slot), "v"(pr) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 2" : : "v"((u2*)slot), "v"(pr) : "memory");
 }
 __device__ __forceinline__ bool lu_poll_t(const unsigned long long* slot, unsigned long long& bits, unsigned long long tag) {
   bits = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -698,7 +704,7 @@ __device__ __forceinline__ unsigned long long lane_bcast_u64(unsigned long long 
 // PROF (PTHIP_LU_PROF=1): thread 0 of workgroup 0 adds up the 100 MHz wall-clock ticks of the phases of every
 // column — [0] A (candidate + barrier), [1] B (publish / poll / barrier), [2] C (update), [3] rotate,
 // [4] shader cycles of the whole loop, [5] its wall ticks — into prof[0..5].
-template <class T, int PB, bool PROF>
+template <class T, int PB, bool PROF, bool X1>
 __global__ __launch_bounds__(BLOCK) void lu_panel2_kernel(T* __restrict__ W, long long ld, int n, int k0, int nW,
                                                          unsigned long long* __restrict__ box, int* __restrict__ ipiv,
                                                          int* __restrict__ plist, int* __restrict__ info,
@@ -717,7 +723,8 @@ __global__ __launch_bounds__(BLOCK) void lu_panel2_kernel(T* __restrict__ W, lon
   // bookkeeping stays in LDS until the panel is done: a global store inside the loop is still in flight at the
   // next barrier (s_waitcnt vmcnt(0) in front of every s_barrier) and was costing ~0.4 us per column
   __shared__ int s_ipiv[PB], s_top[PB];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, w = blockIdx.x;
+  if (X1 && (blockIdx.x & 7) != 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, w = X1 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int pw = (n - k0) < PB ? (n - k0) : PB;
   const long long grow = (long long)k0 + (long long)w * BLOCK + tid;  // the row this thread loaded
   const bool have = grow < n;
@@ -775,7 +782,7 @@ __global__ __launch_bounds__(BLOCK) void lu_panel2_kernel(T* __restrict__ W, lon
           for (int pi = lane; pi < REC; pi += 64) {
             if (pi < npairs && pi != 1) {
               const unsigned long long bits = pi == 0 ? (unsigned long long)(unsigned)br : lu_bits(s_cand[pb][bw][pi >= 2 ? pi - 2 : 0]);
-              lu_publish_t(rec + 2 * pi, bits, tag);
+              lu_publish_t<X1>(rec + 2 * pi, bits, tag);
             }
           }
         }
@@ -1027,6 +1034,8 @@ int getrf_blocked2(long long n, const T* A, T* LU, long long* perm, T* sign, T* 
   // panel's cross-workgroup hand-overs slow down by about what the overlap saves once the GEMM loads the memory system.
   // Correct (same pivots, tests green with it on), but not a win: opt-in with PTHIP_LU_LOOKAHEAD=1.
   static const bool la_env = getenv("PTHIP_LU_LOOKAHEAD") && atoi(getenv("PTHIP_LU_LOOKAHEAD")) == 1;
+  const char* x1_env = getenv("PTHIP_LU_ONE_XCD");  // (read per call: the tests and the bench time both forms in one process)
+  const bool one_xcd = !(x1_env && atoi(x1_env) == 0);
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &cap);
   const int cur = pthip::ctx().current;
@@ -1049,11 +1058,18 @@ int getrf_blocked2(long long n, const T* A, T* LU, long long* perm, T* sign, T* 
     const int nW = (int)((n - k0 + BLOCK - 1) / BLOCK);
     int* pl = plist + (panel_index & 1) * (1 + 3 * PB);
     hipStream_t ps = pthip::ctx().stream;
-    if (prof_on)
-      PTHIP_KLAUNCH((lu_panel2_kernel<T, PB, true>), dim3((unsigned)nW), dim3(BLOCK), 0, ps, LU, n, (int)n, (int)k0, nW, box, ipiv, pl, flags,
+    const bool x1 = one_xcd && nW > 1 && nW <= 32;  // (32 CUs on an XCD: every workgroup of the panel resident there)
+    if (prof_on && x1)
+      PTHIP_KLAUNCH((lu_panel2_kernel<T, PB, true, true>), dim3((unsigned)(8 * nW)), dim3(BLOCK), 0, ps, LU, n, (int)n, (int)k0, nW, box, ipiv, pl,
+                    flags, flags + 1, pthip::ctx().status_dev, nonce, prof);
+    else if (prof_on)
+      PTHIP_KLAUNCH((lu_panel2_kernel<T, PB, true, false>), dim3((unsigned)nW), dim3(BLOCK), 0, ps, LU, n, (int)n, (int)k0, nW, box, ipiv, pl, flags,
                     flags + 1, pthip::ctx().status_dev, nonce, prof);
+    else if (x1)
+      PTHIP_KLAUNCH((lu_panel2_kernel<T, PB, false, true>), dim3((unsigned)(8 * nW)), dim3(BLOCK), 0, ps, LU, n, (int)n, (int)k0, nW, box, ipiv, pl,
+                    flags, flags + 1, pthip::ctx().status_dev, nonce, prof);
     else
-      PTHIP_KLAUNCH((lu_panel2_kernel<T, PB, false>), dim3((unsigned)nW), dim3(BLOCK), 0, ps, LU, n, (int)n, (int)k0, nW, box, ipiv, pl, flags,
+      PTHIP_KLAUNCH((lu_panel2_kernel<T, PB, false, false>), dim3((unsigned)nW), dim3(BLOCK), 0, ps, LU, n, (int)n, (int)k0, nW, box, ipiv, pl, flags,
                     flags + 1, pthip::ctx().status_dev, nonce, prof);
     if ((r = pthip::post_launch("lu_panel2"))) return fail(r);
     const long long right0 = k0 + pw, nright = n - right0;
