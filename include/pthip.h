@@ -153,7 +153,7 @@ int pthip_plan_replay3(void* ga, void* la, void* gb, void* lb, void* gc, void* l
 /* The same through a descriptor filled once per plan (one pointer instead of 13 arguments per call), with two
  * more ways to finish: sync = 2 polls `done_word` — an int32 in pinned host memory that the LAST kernel of the
  * plan sets to 1 behind its results; it is cleared here before anything is launched — instead of waiting for
- * the stream's completion signal (~5 us less per call, tools/ubench/call_lat.hip); flags bit 0: segment A reads
+ * the stream's completion signal (~5 us less per call, tools/ubench/call_lat.hip); flags bit 1: device-side join (pthip_join_signal); flags bit 0: segment A reads
  * its staged parameters straight from the pinned block (no event between the parameter upload and segment B).
  * Replaces the output loop + return of the JIT thunk, pytensor/link/basic.py:670-684. */
 typedef struct pthip_replay_desc {
@@ -168,6 +168,15 @@ typedef struct pthip_replay_desc {
 int pthip_plan_replay4(const pthip_replay_desc* desc, void* host_out, volatile int* done_word, int sync);
 /* a zero-initialised int32 device slot for a last-workgroup ticket (self-resetting; see csrc/tail_device.h) */
 int pthip_ticket_slot(void** slot);
+/* Device-side join of a segmented plan's two streams (pthip_replay_desc.flags bit 1: pthip_plan_replay4 then issues
+ * no event between segment A's stream and the closing segment).  pthip_join_signal: a one-thread launch on the
+ * current stream that stores 1 into `word` (a pthip_ticket_slot) — recorded as the last launch of segment A;
+ * pthip_join_arm: the next pthip_multi_finish launch waits for the word before it reads anything (the generated tail
+ * kernel takes the word as an argument, waits, and puts it back to 0).  Replaces the reference's single-threaded
+ * in-order thunk loop for the point where two independent branches of the graph meet
+ * (pytensor/link/vm.py: Loop / Stack run one thunk at a time, there is nothing to join). */
+int pthip_join_signal(void* word);
+int pthip_join_arm(void* word);
 int pthip_graph_destroy(void* graph_exec);
 
 /* ---- events (HIP events on the context stream) ---- */

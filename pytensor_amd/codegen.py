@@ -1907,6 +1907,19 @@ def _tail_prologue(L, shrink):
     """``shrink`` = {"dtype": accumulator dtype}: the launch has one workgroup per slab piece; each shrinks its
     piece (csrc/tail_device.h, the code of pthip_multi_finish), takes a ticket, and only the LAST one to finish
     goes on to the chain (release: fence before the ticket; acquire: fence after it) and puts the ticket back."""
+    # device-side join of a segmented plan's two streams (csrc/tail_device.h plan_join_wait; include/pthip.h
+    # pthip_join_signal): wait for the other stream's signal word, put it back, acquire.  Null outside such a plan.
+    L.append("  if (join_src != nullptr) {")
+    L.append("    if (tid == 0) {")
+    L.append("      const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();")
+    L.append("      while (__hip_atomic_load(join_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {")
+    L.append("        __builtin_amdgcn_s_sleep(2);")
+    L.append("        if (__builtin_amdgcn_s_memrealtime() - t0_ > 300000000ull) { if (status_src != nullptr) atomicOr((int*)status_src, 16); break; }")
+    L.append("      }")
+    L.append("      __hip_atomic_store(join_src, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);")
+    L.append("    }")
+    L.append("    __syncthreads();  // (no acquire fence: see csrc/tail_device.h plan_join_wait)")
+    L.append("  }")
     if not shrink:
         return
     ct = CTYPE[shrink["dtype"]]
@@ -1980,7 +1993,7 @@ def tail_chain_source(name: str, spec: dict, sizes: dict | None = None, shrink: 
             P += [f"const long long n{j}"]
     for k, o in enumerate(spec["outs"]):
         P += [f"{CTYPE[slots[o]['dtype']]}* __restrict__ dst{k}", f"const long long len{k}"]
-    P += ["const int* status_src", "int* status_dst", "int* done_dst"]
+    P += ["const int* status_src", "int* status_dst", "int* done_dst", "int* join_src"]
     if shrink:
         P += [f"const pthip_dev::TailTasksT<{TAIL_SHRINK_MAX_TASKS}> tasks_", "int* ticket_"]
     bodies = [st["body"] for st in steps if st["op"] == "ew"]

@@ -545,8 +545,10 @@ int pthip_plan_replay4(const pthip_replay_desc* d, void* host_out, volatile int*
     if (int r = run_segment(d->gb, d->lb, s0)) return r;
     if (!a_free) PTHIP_CHECK(hipStreamWaitEvent(s1, ev_in, 0));
     if (int r = run_segment(d->ga, d->la, s1)) return r;
-    PTHIP_CHECK(hipEventRecord(ev_a, s1));
-    PTHIP_CHECK(hipStreamWaitEvent(s0, ev_a, 0));
+    if (!(d->flags & 2)) {  // (bit 1: the closing segment's first launches wait for segment A's signal word themselves)
+      PTHIP_CHECK(hipEventRecord(ev_a, s1));
+      PTHIP_CHECK(hipStreamWaitEvent(s0, ev_a, 0));
+    }
     if (int r = run_segment(d->gc, d->lc, s0)) return r;
   } else {
     if (int r = run_segment(d->gb, d->lb, s0)) return r;

@@ -280,7 +280,7 @@ def _plan(node, inputs, env):
 _FUSE_SHRINK = os.environ.get("PTHIP_TAIL_FUSE_SHRINK", "0") == "1"
 
 
-def _run_fused(node, P, results, env):
+def _run_fused(node, P, results, env, inputs=()):
     lib = env.lib
     # launch 1: every large slab -> <= 16 rows.  When the slabs fit ONE task table of one dtype, that work
     # becomes the prologue of the chain's own launch instead (last-workgroup ticket, codegen._tail_prologue)
@@ -290,11 +290,29 @@ def _run_fused(node, P, results, env):
     fuse_shrink = None
     if _FUSE_SHRINK and len(by_dt) == 1 and 1 <= len(P.shrink) <= codegen.TAIL_SHRINK_MAX_TASKS:
         fuse_shrink = {"dtype": next(iter(by_dt))}
+    # the plan's device-side join (plan.py _DEV_JOIN; include/pthip.h pthip_join_signal): every launch of this node
+    # waits for the other stream's signal word, the single-workgroup chain launch puts it back
+    status0 = getattr(env, "tail_status", None) or (0, 0, 0)
+    join_ptr = getattr(env, "tail_join", 0) if (status0[0] and fuse_shrink is None) else 0
+    # the slab launch waits too only when one of its slabs comes from the other stream's segment (A); slabs are the
+    # operands too long for the chain kernel itself (Plan.add_ext)
+    mf_join = 0
+    if join_ptr and P.shrink:
+        seg = getattr(env.exe, "segments", None)
+        prod = {o: k for k, n in enumerate(env.graph.nodes) for o in n.outputs}
+        for vid, val in zip(node.inputs, inputs):
+            k = prod.get(vid)
+            if isinstance(val, DeviceArray) and k is not None and (seg is None or seg[k] == 0):
+                n = _vec_len(val.shape)
+                if n is None or n > MAX_LEN:
+                    mf_join = join_ptr
     if fuse_shrink is None:
         for dt, ts in by_dt.items():
             for c0 in range(0, len(ts), 16):
                 chunk = ts[c0 : c0 + 16]
                 n = len(chunk)
+                if mf_join:
+                    ffi.check(lib.pthip_join_arm(mf_join))
                 ffi.check(lib.pthip_multi_finish(
                     ffi.np_dtype_code(dt), n, (C.c_int * n)(*[t[0] for t in chunk]), (C.c_void_p * n)(*[t[1].ptr for t in chunk]),
                     (C.c_int64 * n)(*[t[2] for t in chunk]), (C.c_int64 * n)(*[t[3] for t in chunk]), (C.c_int * n)(*[t[4] for t in chunk]),
@@ -325,7 +343,10 @@ def _run_fused(node, P, results, env):
     sizes = codegen.tail_preload_sizes(spec, P.ext_len, P.step_n) if os.environ.get("PTHIP_TAIL_PRELOAD", "1") != "0" else None
     args = [a for e in P.ext_args for a in e] + [("q", o) for o in offs] + [a for s in P.step_args for a in s] + out_args
     status = getattr(env, "tail_status", None) or (0, 0, 0)
-    args += [("q", status[0]), ("q", status[1]), ("q", status[2] if len(status) > 2 else 0)]
+    join = join_ptr
+    args += [("q", status[0]), ("q", status[1]), ("q", status[2] if len(status) > 2 else 0), ("q", join)]
+    if join:
+        env.tail_join_used = True
     buf = struct.pack("<" + "".join(a[0] for a in args), *[a[1] for a in args])
     grid = 1
     if fuse_shrink is not None:
@@ -385,6 +406,6 @@ def _run_members(node, inputs, env):
 def tail(node, inputs, env):
     try:
         P, results = _plan(node, inputs, env)
-        return _run_fused(node, P, results, env)
+        return _run_fused(node, P, results, env, inputs)
     except _Infeasible:
         return _run_members(node, inputs, env)

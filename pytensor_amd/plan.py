@@ -156,7 +156,9 @@ class _SegmentSwitch:
     def before_node(self, k, node):
         if k > 0 and self.seg[k] != self.seg[k - 1]:
             if self.capturing:
+                self.plan._segment_boundary(self.seg[k - 1], self.seg[k])
                 self.plan._end_segment()
+                self.plan._between_segments(self.seg[k - 1], self.seg[k])
                 self.plan._begin_segment()
             elif self.sizing:
                 self.plan._note_boundary()
@@ -180,6 +182,10 @@ _POLL = os.environ.get("PTHIP_PLAN_POLL", "1") != "0"
 # consumer there reads them once (a right-hand side): it no longer depends on the parameter upload, and no
 # event sits between that upload and the streaming segment
 _A_DIRECT = os.environ.get("PTHIP_PLAN_A_DIRECT", "1") != "0"
+# the two streams of a segmented plan meet on the device: segment A ends with a one-thread launch that stores a
+# signal word (pthip_join_signal), the Tail node that opens segment C waits for it inside its own launches — no event
+# between the streams (5.6 us between `gchain` and the next launch with one, profiles/r4z_c4_timeline.md)
+_DEV_JOIN = os.environ.get("PTHIP_PLAN_DEVICE_JOIN", "1") != "0"
 _A_DIRECT_OPS = ("CholeskyTrsv", "SolveTriangular", "CholeskySolve")
 
 
@@ -259,6 +265,13 @@ class FrozenPlan:
             users = [k for k, n in enumerate(g.nodes) if seg[k] == 0 and any(i in staged_vids for i in n.inputs)]
             if all(g.nodes[k].op in _A_DIRECT_OPS and g.nodes[k].inputs[0] not in staged_vids for k in users):
                 self._a_direct_nodes = frozenset(users)
+        # device-side join: segment C opens with the Tail node (its launches take the signal word)
+        self._join_word = None
+        self._join_used = False
+        if self.segmented and _DEV_JOIN and g.nodes[seg.index(2)].op == "Tail":
+            slot = C.c_void_p()
+            ffi.check(self.lib.pthip_ticket_slot(C.byref(slot)))
+            self._join_word = slot.value
         self._async_pending = False
         self._fast = None  # csrc/fastplan.c: the replay path as one native call, built after the first Python-path call
         self._fast_off = os.environ.get("PTHIP_FASTPLAN", "1") == "0"
@@ -285,6 +298,23 @@ class FrozenPlan:
         n = int(self.lib.pthip_launch_count())
         self._seg_sizes.append(n - self._mark)
         self._mark = n
+
+    def _segment_boundary(self, prev, nxt):
+        """inside the capture / recording of segment ``prev``, about to close it"""
+        if prev == 0 and self._join_word:
+            ffi.check(self.lib.pthip_join_signal(self._join_word))  # segment A's last launch
+
+    def _between_segments(self, prev, nxt):
+        """no capture / recording is running"""
+        if nxt == 2 and self._join_word:
+            # a recorded segment C runs now: its join must find the word set whether or not A's signal ran (a captured
+            # hipGraph does not); _build puts it back to 0
+            self._set_join_word(1)
+
+    def _set_join_word(self, value):
+        self._join_host = np.array([value], dtype=np.int32)
+        ffi.check(self.lib.pthip_h2d(self._join_word, self._join_host.ctypes.data, 4))
+        ffi.check(self.lib.pthip_synchronize())
 
     def _segment_is_list(self, k):
         return self._use_lists and k < len(self._seg_sizes) and 0 < self._seg_sizes[k] <= _LIST_MAX
@@ -371,6 +401,8 @@ class FrozenPlan:
             if placed:
                 env.placement.update(placed)
                 env.tail_status = (lib.pthip_status_ptr(), ob.ptr + ob.offsets[-1], (ob.ptr + ob.offsets[-1] + 4) if _POLL else 0)
+                if self._join_word:
+                    env.tail_join = self._join_word
         if capture:
             env.scheduler = self._switch
             self._begin_segment()
@@ -433,6 +465,7 @@ class FrozenPlan:
                     if self._ring is None and _OUT_RING > 0:
                         self._ring = _ResultRing(self._out_specs, _OUT_RING)
             if capture:
+                self._join_used = bool(getattr(env, "tail_join_used", False))
                 # poll mode needs the Tail kernel (which stores the completion word) to be the LAST launch
                 self._poll = bool(_POLL and self.fetch_outputs and getattr(env, "tail_done_word", False) and self._dev_out is None
                                   and getattr(env, "tail_launch_mark", -1) == int(lib.pthip_launch_count()) and not exe.update_map)
@@ -489,6 +522,8 @@ class FrozenPlan:
             self._use_lists = False
         if self.segmented and len(self._graphs) != 3:
             raise ffi.HipError(f"segmented plan captured {len(self._graphs)} graphs instead of 3")
+        if self._join_word:
+            self._set_join_word(0)  # (whatever the build passes left there)
         if self._dev_out is not None:
             # the result copy is issued per call (not captured): take the runtime's one-time set-up of
             # that copy path (8 ms on the second large D2H of a process, measured) here
@@ -514,7 +549,8 @@ class FrozenPlan:
         d = _ReplayDesc(v(g(sa)), v(l(sa)), v(g(sb)), v(l(sb)), v(g(sc)), v(l(sc)), self._dev_in.ptr if nb else None,
                         self._in_block.ptr if nb else None, nb, do.ptr if do is not None else None,
                         self._out_block.nbytes if (do is not None and self._out_block is not None) else 0,
-                        1 if (self._a_direct_nodes is not None and self.segmented) else 0)
+                        (1 if (self._a_direct_nodes is not None and self.segmented) else 0)
+                        | (2 if (self._join_used and self.segmented) else 0))
         self._desc = d
         self._desc_ref = C.byref(d)
         ob = self._out_block
