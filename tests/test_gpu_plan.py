@@ -261,6 +261,44 @@ def test_small_segments_replay_as_launch_lists(hip, monkeypatch):
     p.close()
 
 
+def test_segmented_plan_joins_its_streams_on_the_device(hip, monkeypatch):
+    """The two streams of config #4's plan meet through a signal word the Tail node's launches wait for
+    (``pthip_join_signal`` at the end of segment A, descriptor flag bit 1), not through an event: the same bits
+    as the eager path over many replays with changing parameters, in all three segment forms (launch lists,
+    hipGraphs, mixed), and the event form stays available (PTHIP_PLAN_DEVICE_JOIN=0)."""
+    import pytensor_amd.plan as plan_mod
+    from pytensor_amd.executor import HipExecutable
+
+    g, ins, cvm, py, meta = load_case("c4_hier")
+    names = meta["input_names"]
+    res = [k for k, n in enumerate(names) if n in ("y", "X", "gidx", "Sigma")]
+    exe = HipExecutable(g, resident=res)
+    rng = np.random.default_rng(5)
+
+    def perturbed(j):
+        out = list(ins)
+        for k, a in enumerate(ins):
+            if k not in res and isinstance(a, np.ndarray) and a.dtype.kind == "f":
+                out[k] = a + 1e-3 * j * rng.standard_normal(a.shape)
+        return out
+
+    for list_max, join in ((None, True), (0, True), (2, True), (None, False)):  # lists; hipGraphs; A a hipGraph, B and C lists; events
+        if list_max is not None:
+            monkeypatch.setattr(plan_mod, "_LIST_MAX", list_max)
+        monkeypatch.setattr(plan_mod, "_DEV_JOIN", join)
+        p = exe.freeze(*ins)
+        assert p.segmented
+        assert p._join_used == join and bool(p._join_word) == join
+        for j in range(6):
+            args = perturbed(j)
+            want = exe(*args)
+            for a, b in zip(p(*args), want):
+                np.testing.assert_array_equal(a, b)
+        assert bool(p._desc.flags & 2) == join
+        p.close()
+        monkeypatch.undo()
+
+
 def test_large_results_are_handed_out_without_a_copy_and_stay_valid(hip):
     """Results above the zero-copy pack limit land in a pinned block of the call's own (plan.py
     ``_ResultRing``) and are returned as views on it: every call's arrays are distinct and keep
