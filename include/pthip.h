@@ -168,15 +168,15 @@ typedef struct pthip_replay_desc {
 int pthip_plan_replay4(const pthip_replay_desc* desc, void* host_out, volatile int* done_word, int sync);
 /* a zero-initialised int32 device slot for a last-workgroup ticket (self-resetting; see csrc/tail_device.h) */
 int pthip_ticket_slot(void** slot);
-/* Device-side join of a segmented plan's two streams (pthip_replay_desc.flags bit 1: pthip_plan_replay4 then issues
- * no event between segment A's stream and the closing segment).  pthip_join_signal: a one-thread launch on the
- * current stream that stores 1 into `word` (a pthip_ticket_slot) — recorded as the last launch of segment A;
- * pthip_join_arm: the next pthip_multi_finish launch waits for the word before it reads anything (the generated tail
- * kernel takes the word as an argument, waits, and puts it back to 0).  Replaces the reference's single-threaded
- * in-order thunk loop for the point where two independent branches of the graph meet
- * (pytensor/link/vm.py: Loop / Stack run one thunk at a time, there is nothing to join). */
+/* Device-side join of a segmented plan's two streams (pthip_replay_desc.flags bit 1: pthip_plan_replay4 in poll mode
+ * then issues no event between segment A's stream and the closing segment).  pthip_join_signal: a one-thread launch
+ * on the current stream that stores 1 into `word` (a pthip_ticket_slot) — recorded as the last launch of segment A;
+ * the generated tail kernel that opens the closing segment takes the word as an argument, waits for it and puts it
+ * back to 0.  A wait that lasts 1 ms (kernels of the two streams cannot overlap: a counter-collecting profiler) stores
+ * 2 into the done word and leaves; pthip_plan_replay4 then waits for segment A's stream and runs the closing segment
+ * again, and after three such calls goes back to the event for that descriptor.  Replaces nothing in the reference:
+ * its Loop / Stack VMs (pytensor/link/vm.py) run one thunk at a time, there is nothing to join. */
 int pthip_join_signal(void* word);
-int pthip_join_arm(void* word);
 int pthip_graph_destroy(void* graph_exec);
 
 /* ---- events (HIP events on the context stream) ---- */

@@ -1907,18 +1907,28 @@ def _tail_prologue(L, shrink):
     """``shrink`` = {"dtype": accumulator dtype}: the launch has one workgroup per slab piece; each shrinks its
     piece (csrc/tail_device.h, the code of pthip_multi_finish), takes a ticket, and only the LAST one to finish
     goes on to the chain (release: fence before the ticket; acquire: fence after it) and puts the ticket back."""
-    # device-side join of a segmented plan's two streams (csrc/tail_device.h plan_join_wait; include/pthip.h
-    # pthip_join_signal): wait for the other stream's signal word, put it back, acquire.  Null outside such a plan.
+    # device-side join of a segmented plan's two streams (csrc/tail_device.h; include/pthip.h pthip_join_signal): wait
+    # for the other stream's signal word and put it back.  Null outside such a plan.  Where kernels of different streams
+    # cannot overlap (a counter-collecting profiler serialises them) the signal launch cannot run while this one spins:
+    # the wait gives up after 1 ms and says so through the done word.
+    L.append("  __shared__ int join_fail_;")
     L.append("  if (join_src != nullptr) {")
     L.append("    if (tid == 0) {")
     L.append("      const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime();")
+    L.append("      // 1 ms when the host can run this segment again (it polls done_dst), else 3 s and the status bit")
+    L.append("      const unsigned long long lim_ = done_dst != nullptr ? 100000ull : 300000000ull;")
+    L.append("      int ok_ = 1;")
     L.append("      while (__hip_atomic_load(join_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {")
     L.append("        __builtin_amdgcn_s_sleep(2);")
-    L.append("        if (__builtin_amdgcn_s_memrealtime() - t0_ > 300000000ull) { if (status_src != nullptr) atomicOr((int*)status_src, 16); break; }")
+    L.append("        if (__builtin_amdgcn_s_memrealtime() - t0_ > lim_) { ok_ = 0; break; }")
     L.append("      }")
-    L.append("      __hip_atomic_store(join_src, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);")
+    L.append("      if (ok_) __hip_atomic_store(join_src, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);")
+    L.append("      else if (done_dst != nullptr) __hip_atomic_store(done_dst, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);")
+    L.append("      else if (status_src != nullptr) atomicOr((int*)status_src, 16);")
+    L.append("      join_fail_ = !ok_ && done_dst != nullptr;")
     L.append("    }")
     L.append("    __syncthreads();  // (no acquire fence: see csrc/tail_device.h plan_join_wait)")
+    L.append("    if (join_fail_) return;  // done word 2: pthip_plan_replay4 waits for the other stream and runs this segment again")
     L.append("  }")
     if not shrink:
         return

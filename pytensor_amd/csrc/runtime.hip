@@ -527,6 +527,15 @@ int pthip_plan_replay4(const pthip_replay_desc* d, void* host_out, volatile int*
   static hipEvent_t ev_in = nullptr, ev_a = nullptr;
   static unsigned long long calls = 0;
   hipStream_t s0 = g_ctx.streams[0];
+  // flags bit 1 (poll mode only: the tail kernel reports a wait it gave up through the done word).  A descriptor whose
+  // join gave up three times — kernels of the two streams do not overlap here, e.g. under rocprofv3 --pmc — goes back
+  // to the event for good (the tail kernel's wait is then always satisfied on arrival).
+  static std::unordered_map<const void*, int> join_gave_up;
+  bool dev_join = (d->flags & 2) && sync == 2;
+  if (dev_join) {
+    auto it = join_gave_up.find((const void*)d);
+    if (it != join_gave_up.end() && it->second >= 3) dev_join = false;
+  }
   if (sync == 2) {
     if (!done_word) return set_error("pthip_plan_replay4: poll mode without a done word");
     *done_word = 0;
@@ -545,7 +554,7 @@ int pthip_plan_replay4(const pthip_replay_desc* d, void* host_out, volatile int*
     if (int r = run_segment(d->gb, d->lb, s0)) return r;
     if (!a_free) PTHIP_CHECK(hipStreamWaitEvent(s1, ev_in, 0));
     if (int r = run_segment(d->ga, d->la, s1)) return r;
-    if (!(d->flags & 2)) {  // (bit 1: the closing segment's first launches wait for segment A's signal word themselves)
+    if (!dev_join) {  // (device join: the closing segment's tail kernel waits for segment A's signal word itself)
       PTHIP_CHECK(hipEventRecord(ev_a, s1));
       PTHIP_CHECK(hipStreamWaitEvent(s0, ev_a, 0));
     }
@@ -558,6 +567,7 @@ int pthip_plan_replay4(const pthip_replay_desc* d, void* host_out, volatile int*
   if (sync == 2) {
     timespec t0{};
     unsigned long long spins = 0;
+  poll_again:
     while (__atomic_load_n((const int*)done_word, __ATOMIC_ACQUIRE) == 0) {
       __builtin_ia32_pause();
       if ((++spins & 0x3fff) == 0) {
@@ -572,6 +582,18 @@ int pthip_plan_replay4(const pthip_replay_desc* d, void* host_out, volatile int*
           break;
         }
       }
+    }
+    if (__atomic_load_n((const int*)done_word, __ATOMIC_ACQUIRE) == 2) {
+      // the tail kernel gave up waiting for segment A's signal and did nothing: let A finish, run the closing segment again
+      if (!dev_join || !g_ctx.streams[1]) return set_error("pthip_plan_replay4: the tail kernel reported a join it was not asked for");
+      join_gave_up[(const void*)d]++;
+      PTHIP_CHECK(hipStreamSynchronize(g_ctx.streams[1]));
+      PTHIP_CHECK(hipStreamSynchronize(s0));
+      *done_word = 0;
+      std::atomic_thread_fence(std::memory_order_seq_cst);
+      if (int r = run_segment(d->gc, d->lc, s0)) return r;
+      t0 = timespec{};
+      goto poll_again;
     }
     if ((++calls & 255) == 0) {
       PTHIP_CHECK(hipStreamSynchronize(s0));

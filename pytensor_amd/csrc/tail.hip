@@ -28,29 +28,21 @@ using Tasks = TailTasksT<MAX_TASKS>;
 // (the piece itself — task / column tile / row chunk of a block, four accumulators per row lane, fixed-order
 //  LDS combine — lives in tail_device.h: the generated tail kernels run the same code as their prologue)
 template <class T>
-__global__ __launch_bounds__(BLOCK) void multi_finish_kernel(Tasks t, int* join, int* status) {
+__global__ __launch_bounds__(BLOCK) void multi_finish_kernel(Tasks t) {
   __shared__ T smem[BLOCK];
-  plan_join_wait(join, false, status);  // (every workgroup waits; the tail kernel behind this launch resets the word)
   tail_shrink_block<T, MAX_TASKS>(t, (int)blockIdx.x, smem);
 }
-
-int* g_pending_join = nullptr;  // pthip_join_arm: consumed by the next pthip_multi_finish
 
 __global__ void join_signal_kernel(int* word) { __hip_atomic_store(word, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
 }  // namespace
 
-// see tail_device.h plan_join_wait
+// the last launch of a plan's latency-chain segment (include/pthip.h)
 extern "C" int pthip_join_signal(void* word) {
   PTHIP_REQUIRE_INIT();
   if (!word) return pthip::set_error("pthip_join_signal: null word");
   PTHIP_KLAUNCH(join_signal_kernel, dim3(1), dim3(1), 0, pthip::ctx().stream, (int*)word);
   return pthip::post_launch("join_signal");
-}
-
-extern "C" int pthip_join_arm(void* word) {
-  g_pending_join = (int*)word;
-  return 0;
 }
 
 extern "C" int pthip_multi_finish(int dtype, int n_tasks, const int* ops, const void* const* parts,
@@ -76,13 +68,10 @@ extern "C" int pthip_multi_finish(int dtype, int n_tasks, const int* ops, const 
   }
   t.blk0[n_tasks] = nb;
   hipStream_t st = pthip::ctx().stream;
-  int* join = g_pending_join;
-  g_pending_join = nullptr;
-  int* status = join ? pthip::ctx().status_dev : nullptr;
   switch (dtype) {
-    case PTHIP_F64: PTHIP_KLAUNCH(multi_finish_kernel<double>, dim3(nb), dim3(BLOCK), 0, st, t, join, status); break;
-    case PTHIP_F32: PTHIP_KLAUNCH(multi_finish_kernel<float>, dim3(nb), dim3(BLOCK), 0, st, t, join, status); break;
-    case PTHIP_I64: PTHIP_KLAUNCH(multi_finish_kernel<long long>, dim3(nb), dim3(BLOCK), 0, st, t, join, status); break;
+    case PTHIP_F64: PTHIP_KLAUNCH(multi_finish_kernel<double>, dim3(nb), dim3(BLOCK), 0, st, t); break;
+    case PTHIP_F32: PTHIP_KLAUNCH(multi_finish_kernel<float>, dim3(nb), dim3(BLOCK), 0, st, t); break;
+    case PTHIP_I64: PTHIP_KLAUNCH(multi_finish_kernel<long long>, dim3(nb), dim3(BLOCK), 0, st, t); break;
     default: return pthip::set_error("pthip_multi_finish: unsupported accumulator dtype %d", dtype);
   }
   return pthip::post_launch("multi_finish");

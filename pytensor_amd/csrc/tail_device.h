@@ -23,30 +23,14 @@ struct TailTasksT {
   int blk0[MAXT + 1];      // first block of each task; a task owns tiles(M) * S blocks
 };
 
-// Device-side join of a plan's two streams (pthip_plan_replay4, flag bit 1): the latency-chain segment ends with
-// pthip_join_signal (a one-thread kernel storing 1 into `word`), the first launches of the closing segment wait for
-// the word here instead of the streaming segment's stream waiting for an event (5.6 us between `gchain` and the next
-// launch, profiles/r4z_c4_timeline.md).  `reset`: the last waiter (a single-workgroup launch) puts the word back to 0
-// for the next replay.  A wait that never ends (3 s of the 100 MHz wall clock) raises status bit 4.
-__device__ __forceinline__ void plan_join_wait(int* word, bool reset, int* status) {
-  if (word == nullptr) return;
-  if (threadIdx.x == 0) {
-    const long long t0 = (long long)wall_clock64();
-    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-      __builtin_amdgcn_s_sleep(2);
-      if ((long long)wall_clock64() - t0 > 300000000LL) {
-        if (status != nullptr) atomicOr(status, 16);
-        break;
-      }
-    }
-    if (reset) __hip_atomic_store(word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  // No acquire fence: at agent scope it invalidates the L2 and the slabs this launch is about to read come back from
-  // HBM (multi_finish 4.8 -> 11 us, profiles/r4_c4_device_join.txt).  None is needed: the caches were invalidated when
-  // this kernel started, and nothing on this device reads the other stream's result buffers between that point and
-  // the signal (only the launches that wait here do), so no stale line of them can have been fetched in between.
-}
+// Device-side join of a plan's two streams (pthip_plan_replay4, descriptor flag bit 1): the latency-chain segment ends
+// with pthip_join_signal (a one-thread kernel storing 1 into a word), the generated tail kernel that opens the closing
+// segment waits for the word in its prologue (codegen._tail_prologue) and puts it back to 0 — instead of the streaming
+// segment's stream waiting for an event (5.6 us between `gchain` and the next launch, profiles/r4z_c4_timeline.md).
+// No acquire fence behind the wait: at agent scope it invalidates the L2 and whatever the launch reads next comes back
+// from HBM (measured on the slab launch: 4.8 -> 11 us, profiles/r4_c4_device_join.txt).  None is needed: the caches
+// were invalidated when the waiting kernel started, and nothing on the device reads the other stream's result buffers
+// between that point and the signal, so no stale line of them can have been fetched in between.
 
 template <class Op, class T>
 __device__ __forceinline__ void tail_shrink_tile(const T* __restrict__ part, long long p0, long long p1, long long M,

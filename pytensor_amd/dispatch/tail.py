@@ -290,13 +290,12 @@ def _run_fused(node, P, results, env, inputs=()):
     fuse_shrink = None
     if _FUSE_SHRINK and len(by_dt) == 1 and 1 <= len(P.shrink) <= codegen.TAIL_SHRINK_MAX_TASKS:
         fuse_shrink = {"dtype": next(iter(by_dt))}
-    # the plan's device-side join (plan.py _DEV_JOIN; include/pthip.h pthip_join_signal): every launch of this node
-    # waits for the other stream's signal word, the single-workgroup chain launch puts it back
+    # the plan's device-side join (plan.py _DEV_JOIN; include/pthip.h pthip_join_signal): the chain launch waits for the
+    # other stream's signal word and puts it back
     status0 = getattr(env, "tail_status", None) or (0, 0, 0)
     join_ptr = getattr(env, "tail_join", 0) if (status0[0] and fuse_shrink is None) else 0
-    # the slab launch waits too only when one of its slabs comes from the other stream's segment (A); slabs are the
-    # operands too long for the chain kernel itself (Plan.add_ext)
-    mf_join = 0
+    # only the chain launch can wait (and tell the host when it gave up): a slab that comes from the other stream's
+    # segment (A) keeps the event (slabs are the operands too long for the chain kernel itself, Plan.add_ext)
     if join_ptr and P.shrink:
         seg = getattr(env.exe, "segments", None)
         prod = {o: k for k, n in enumerate(env.graph.nodes) for o in n.outputs}
@@ -305,14 +304,12 @@ def _run_fused(node, P, results, env, inputs=()):
             if isinstance(val, DeviceArray) and k is not None and (seg is None or seg[k] == 0):
                 n = _vec_len(val.shape)
                 if n is None or n > MAX_LEN:
-                    mf_join = join_ptr
+                    join_ptr = 0
     if fuse_shrink is None:
         for dt, ts in by_dt.items():
             for c0 in range(0, len(ts), 16):
                 chunk = ts[c0 : c0 + 16]
                 n = len(chunk)
-                if mf_join:
-                    ffi.check(lib.pthip_join_arm(mf_join))
                 ffi.check(lib.pthip_multi_finish(
                     ffi.np_dtype_code(dt), n, (C.c_int * n)(*[t[0] for t in chunk]), (C.c_void_p * n)(*[t[1].ptr for t in chunk]),
                     (C.c_int64 * n)(*[t[2] for t in chunk]), (C.c_int64 * n)(*[t[3] for t in chunk]), (C.c_int * n)(*[t[4] for t in chunk]),

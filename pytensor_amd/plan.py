@@ -550,7 +550,7 @@ class FrozenPlan:
                         self._in_block.ptr if nb else None, nb, do.ptr if do is not None else None,
                         self._out_block.nbytes if (do is not None and self._out_block is not None) else 0,
                         (1 if (self._a_direct_nodes is not None and self.segmented) else 0)
-                        | (2 if (self._join_used and self.segmented) else 0))
+                        | (2 if (self._join_used and self.segmented and self._poll) else 0))
         self._desc = d
         self._desc_ref = C.byref(d)
         ob = self._out_block

@@ -299,6 +299,44 @@ def test_segmented_plan_joins_its_streams_on_the_device(hip, monkeypatch):
         monkeypatch.undo()
 
 
+def test_device_join_that_gives_up_is_retried_by_the_host(hip, monkeypatch):
+    """When the latency-chain segment is still running 1 ms after the tail kernel started waiting (here: two 4096^3
+    fp64 products recorded in front of the signal; in the field: a profiler that serialises kernels), the kernel
+    stores 2 into the done word and leaves; ``pthip_plan_replay4`` waits for the chain's stream and runs the closing
+    segment again.  After three such calls the descriptor goes back to the event.  Results: the eager path's bits."""
+    import ctypes as C
+
+    import pytensor_amd.plan as plan_mod
+    from pytensor_amd import ffi
+    from pytensor_amd.device import DeviceArray
+    from pytensor_amd.executor import HipExecutable
+
+    lib = ffi.lib()
+    n = 4096
+    A = DeviceArray.from_host(np.full((n, n), 1e-3))
+    out = DeviceArray.empty((n, n), "float64")
+    orig = plan_mod.FrozenPlan._segment_boundary
+
+    def slow_chain(self, prev, nxt):
+        if prev == 0 and self._join_word:
+            for _ in range(2):
+                ffi.check(lib.pthip_gemm(ffi.np_dtype_code("float64"), 1, n, n, n, 1.0, A.ptr, 0, n, 1, A.ptr, 0, n, 1, 0.0, None, 0, 0, 0, out.ptr))
+        orig(self, prev, nxt)
+
+    monkeypatch.setattr(plan_mod.FrozenPlan, "_segment_boundary", slow_chain)
+    g, ins, cvm, py, meta = load_case("c4_hier")
+    names = meta["input_names"]
+    exe = HipExecutable(g, resident=[k for k, nm in enumerate(names) if nm in ("y", "X", "gidx", "Sigma")])
+    want = exe(*ins)
+    p = exe.freeze(*ins)
+    assert p.segmented and p._join_used
+    for _ in range(6):  # three retried calls, then the event
+        for a, b in zip(p(*ins), want):
+            np.testing.assert_array_equal(a, b)
+    assert p._desc.flags & 2
+    p.close()
+
+
 def test_large_results_are_handed_out_without_a_copy_and_stay_valid(hip):
     """Results above the zero-copy pack limit land in a pinned block of the call's own (plan.py
     ``_ResultRing``) and are returned as views on it: every call's arrays are distinct and keep
