@@ -511,21 +511,26 @@ class HipExecutable:
             if ent is not None and ent.key == key and coherence.clean(ent.fp, a):
                 return ent.dev
         self.stats["resident_uploads"] += 1
+        # Watch FIRST, copy second: a store from another thread between the two is then either in the copy (it came
+        # before the protection / the hash) or marks the value dirty (it faulted, or the next hash differs) — with the
+        # copy first it could land after the snapshot and before the watch and never be seen.  pthip_h2d reads
+        # write-protected pages through its pinned bounce buffers (runtime.hip), the protection stays.
         if ent is not None and ent.dev.shape == a.shape and ent.dev.dtype == a.dtype:
+            ent.rewatch(key, value, a)
             if a.size:
                 c = a if a.flags.c_contiguous else np.ascontiguousarray(a)
                 ffi.check(ffi.lib().pthip_h2d(ent.dev.ptr, c.ctypes.data, c.nbytes))
                 if env is not None:
                     env.keepalive.append(c)
-            ent.rewatch(key, value, a)  # (after the copy was issued: it reads the pages unprotected)
             return ent.dev
-        dev = DeviceArray.from_host(a)
-        if env is not None:
-            env.keepalive.append(a)
         if ent is not None:
             coherence.release(ent.fp)
             ent.fp = None
-        self._resident_cache[pos] = ResidentEntry(key, dev, value, coherence.watch(a))
+        fp = coherence.watch(a)
+        dev = DeviceArray.from_host(a)
+        if env is not None:
+            env.keepalive.append(a)
+        self._resident_cache[pos] = ResidentEntry(key, dev, value, fp)
         return dev
 
     def invalidate_resident(self, pos=None):
