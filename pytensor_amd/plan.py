@@ -187,7 +187,6 @@ _A_DIRECT = os.environ.get("PTHIP_PLAN_A_DIRECT", "1") != "0"
 # between the streams (5.6 us between `gchain` and the next launch with one, profiles/r4z_c4_timeline.md)
 _DEV_JOIN = os.environ.get("PTHIP_PLAN_DEVICE_JOIN", "1") != "0"
 _A_DIRECT_OPS = ("CholeskyTrsv", "SolveTriangular", "CholeskySolve")
-_ALL_DIRECT = os.environ.get("PTHIP_PLAN_ALL_DIRECT", "0") == "1"
 
 
 class _ReplayDesc(C.Structure):
@@ -261,13 +260,10 @@ class FrozenPlan:
         self._switch = _SegmentSwitch(self, seg) if self.segmented else None
         # segment-A nodes that may read staged parameters from the pinned block itself (see _A_DIRECT)
         self._a_direct_nodes = None
-        self._all_direct = False
-        if _ALL_DIRECT and self._staged and self.segmented:
-            # EXPERIMENT (PTHIP_PLAN_ALL_DIRECT=1): every node reads its staged parameters from the pinned block, no upload
-            staged_vids = {g.inputs[pos] for pos in self._staged}
-            self._a_direct_nodes = frozenset(k for k, n in enumerate(g.nodes) if any(i in staged_vids for i in n.inputs))
-            self._all_direct = True
-        elif self.segmented and _A_DIRECT and self._staged:
+        # (every node reading the pinned block, no upload at all: measured 0.1952-0.1974 ms per evaluation of config #4
+        #  against 0.1936-0.1944 with the 2 KB upload, profiles/r4_c4_all_direct_ab.txt: the streaming kernel's
+        #  workgroups each fetch their parameters over the host link)
+        if self.segmented and _A_DIRECT and self._staged:
             staged_vids = {g.inputs[pos] for pos in self._staged}
             users = [k for k, n in enumerate(g.nodes) if seg[k] == 0 and any(i in staged_vids for i in n.inputs)]
             if all(g.nodes[k].op in _A_DIRECT_OPS and g.nodes[k].inputs[0] not in staged_vids for k in users):
@@ -551,7 +547,7 @@ class FrozenPlan:
         g = lambda seg: seg[1] if (seg is not None and seg[0] == "graph") else None
         l = lambda seg: seg[1] if (seg is not None and seg[0] == "list") else None
         v = lambda h: h.value if isinstance(h, C.c_void_p) else h
-        nb = self._in_block.nbytes if (self._dev_in is not None and not self._all_direct) else 0
+        nb = self._in_block.nbytes if self._dev_in is not None else 0
         do = self._dev_out
         d = _ReplayDesc(v(g(sa)), v(l(sa)), v(g(sb)), v(l(sb)), v(g(sc)), v(l(sc)), self._dev_in.ptr if nb else None,
                         self._in_block.ptr if nb else None, nb, do.ptr if do is not None else None,
