@@ -66,6 +66,22 @@ def test_optional_special_function_helpers_compile_without_gpu():
         assert len(ffi.jit_compile(src, f"probe_{op}.hip")) > 1000, op
 
 
+def test_generated_tail_kernel_with_the_device_join_compiles_without_gpu():
+    """both forms of the generated tail kernel carry the plan's device-side join in their prologue (wait for the other
+    stream's signal word, put it back; a wait given up is reported through the done word as 2) and pass hiprtc"""
+    from pytensor_amd import codegen, ffi
+
+    spec = {"ext": [{"kind": "P", "dtype": "float64"}], "slots": [{"dtype": "float64", "scalar": True}],
+            "steps": [{"op": "rsum", "src": ("e", 0), "red": "Add", "acc_dtype": "float64", "dtype": "float64", "out": 0}], "outs": [0]}
+    plain = codegen.tail_chain_source("tail_probe", spec)
+    preload = codegen.tail_chain_source("tail_probe_p", spec, codegen.tail_preload_sizes(spec, [64], [64]))
+    for name, src in (("tail_probe", plain), ("tail_probe_p", preload)):
+        assert "int* join_src" in src and "__hip_atomic_store(done_dst, 2," in src and "if (join_fail_) return;" in src
+        # the wait sits in front of every operand request
+        assert src.index("join_src != nullptr") < src.index("e0[")
+        assert len(ffi.jit_compile(src, name + ".hip")) > 1000
+
+
 def test_bench_traffic_falls_back_when_the_profiler_pass_fails(monkeypatch):
     """bench.live_pmc_traffic: without a device the rocprofv3 child fails — a reason comes back, never an
     exception, so the bench line is still printed (with the committed summary as ``traffic``); and no
