@@ -988,6 +988,47 @@ __global__ __launch_bounds__(CB) void lu_swap_u12_kernel(T* __restrict__ W, long
   }
 }
 
+// One-XCD panels rest on "workgroup id % 8 is the XCD" and "a store without write-through is seen by an agent-scope load
+// of a workgroup on the same XCD".  Checked once per process before the first such panel: workgroup 0 publishes a
+// record that way, workgroup 8 polls for it (200 us at most).  Not seen (another partition mode, another dispatch
+// order): the panels stay spread over the XCDs with write-through records, the round-3/4 form.
+__global__ void lu_one_xcd_probe_kernel(unsigned long long* box, int* seen) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long tag = 0x5eed0f0e1ull;
+  if (blockIdx.x == 0) {
+    lu_publish_t<true>(box, 0x1234ull, tag);
+  } else if (blockIdx.x == 8) {
+    const long long t0 = (long long)wall_clock64();
+    unsigned long long bits = 0;
+    int ok = 0;
+    for (;;) {
+      if (lu_poll_t(box, bits, tag) && bits == 0x1234ull) { ok = 1; break; }
+      if ((long long)wall_clock64() - t0 > 20000) break;
+    }
+    *seen = ok;
+  }
+}
+
+// 1: the probe passed; 0: it did not (or could not be run: its result is read back with a stream synchronisation,
+// which a capture in progress forbids — asked again on the next call)
+int lu_one_xcd_ok(hipStream_t st, bool may_sync) {
+  static int known = -1;
+  if (known >= 0) return known;
+  if (!may_sync) return 0;
+  void* d = nullptr;
+  if (hipMalloc(&d, 512) != hipSuccess) return 0;  // (not pthip_alloc: a plan's arena must see the same allocations in every pass)
+  int seen = 0;
+  bool ran = hipMemsetAsync(d, 0, 512, st) == hipSuccess;
+  if (ran) {
+    hipLaunchKernelGGL(lu_one_xcd_probe_kernel, dim3(16), dim3(64), 0, st, (unsigned long long*)d, (int*)((char*)d + 256));
+    ran = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess &&
+          hipMemcpy(&seen, (char*)d + 256, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  (void)hipFree(d);
+  if (ran) known = seen ? 1 : 0;
+  return ran ? known : 0;
+}
+
 template <class T, int PB>
 int getrf_blocked2(long long n, const T* A, T* LU, long long* perm, T* sign, T* logabs, int flag_singular) {
   constexpr int CB = 64;
@@ -1035,9 +1076,10 @@ int getrf_blocked2(long long n, const T* A, T* LU, long long* perm, T* sign, T* 
   // Correct (same pivots, tests green with it on), but not a win: opt-in with PTHIP_LU_LOOKAHEAD=1.
   static const bool la_env = getenv("PTHIP_LU_LOOKAHEAD") && atoi(getenv("PTHIP_LU_LOOKAHEAD")) == 1;
   const char* x1_env = getenv("PTHIP_LU_ONE_XCD");  // (read per call: the tests and the bench time both forms in one process)
-  const bool one_xcd = !(x1_env && atoi(x1_env) == 0);
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &cap);
+  const bool one_xcd = !(x1_env && atoi(x1_env) == 0) && n > BLOCK &&
+                       lu_one_xcd_ok(st, cap == hipStreamCaptureStatusNone && pthip::ctx().recorder == nullptr) == 1;
   const int cur = pthip::ctx().current;
   const int side = cur == 3 ? 2 : 3;
   const bool lookahead = la_env && !prof_on && pthip::ctx().recorder == nullptr && cap == hipStreamCaptureStatusNone && n > 4 * PB;
