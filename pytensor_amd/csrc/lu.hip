@@ -701,16 +701,18 @@ __device__ __forceinline__ unsigned long long lane_bcast_u64(unsigned long long 
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// TB: threads (= rows) per workgroup.  256: four waves; 512 (PTHIP_LU_PANEL_THREADS=512, PB = 32 only): half as many
+// workgroups take part in the exchange and seven waves poll at most two records each in one round trip.
 // PROF (PTHIP_LU_PROF=1): thread 0 of workgroup 0 adds up the 100 MHz wall-clock ticks of the phases of every
 // column — [0] A (candidate + barrier), [1] B (publish / poll / barrier), [2] C (update), [3] rotate,
 // [4] shader cycles of the whole loop, [5] its wall ticks — into prof[0..5].
-template <class T, int PB, bool PROF, bool X1>
-__global__ __launch_bounds__(BLOCK) void lu_panel2_kernel(T* __restrict__ W, long long ld, int n, int k0, int nW,
+template <class T, int PB, bool PROF, bool X1, int TB>
+__global__ __launch_bounds__(TB) void lu_panel2_kernel(T* __restrict__ W, long long ld, int n, int k0, int nW,
                                                          unsigned long long* __restrict__ box, int* __restrict__ ipiv,
                                                          int* __restrict__ plist, int* __restrict__ info,
                                                          int* __restrict__ abortflag, int* __restrict__ status,
                                                          unsigned long long nonce, long long* __restrict__ prof) {
-  constexpr int NWAVE = BLOCK / 64;
+  constexpr int NWAVE = TB / 64;
   constexpr int REC = PB + 2;  // pairs of a candidate record: row, (spare), up to PB entries
   constexpr int GRP = 4;       // candidates a wave polls at once
   static_assert(PB <= 64 && PB % 8 == 0, "panel width");
@@ -726,7 +728,7 @@ __global__ __launch_bounds__(BLOCK) void lu_panel2_kernel(T* __restrict__ W, lon
   if (X1 && (blockIdx.x & 7) != 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, w = X1 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int pw = (n - k0) < PB ? (n - k0) : PB;
-  const long long grow = (long long)k0 + (long long)w * BLOCK + tid;  // the row this thread loaded
+  const long long grow = (long long)k0 + (long long)w * TB + tid;  // the row this thread loaded
   const bool have = grow < n;
   int cur = have ? (int)grow : 0x7fffffff;  // its current position under the interchanges so far
   bool done = false;                        // it became a pivot row (cur = its final position then)
@@ -1094,25 +1096,36 @@ int getrf_blocked2(long long n, const T* A, T* LU, long long* perm, T* sign, T* 
     if (rest <= 0 || nc <= 0) return 0;
     return pthip::gemm_inplace(dt, rest, nc, pw, -1.0, LU + (k0 + pw) * n + k0, n, 1, LU + k0 * n + c0, n, 1, 1.0, LU + (k0 + pw) * n + c0, n);
   };
+  const char* tb_env = getenv("PTHIP_LU_PANEL_THREADS");
+  const bool tb512 = PB == 32 && tb_env && atoi(tb_env) == 512;
+  const int TBsel = tb512 ? 512 : BLOCK;
   long long panel_index = 0;
   for (long long k0 = 0; k0 < n; k0 += PB, panel_index++) {
     const int pw = (int)((n - k0) < PB ? (n - k0) : PB);
-    const int nW = (int)((n - k0 + BLOCK - 1) / BLOCK);
+    const int nW = (int)((n - k0 + TBsel - 1) / TBsel);
     int* pl = plist + (panel_index & 1) * (1 + 3 * PB);
     hipStream_t ps = pthip::ctx().stream;
     const bool x1 = one_xcd && nW > 1 && nW <= 32;  // (32 CUs on an XCD: every workgroup of the panel resident there)
-    if (prof_on && x1)
-      PTHIP_KLAUNCH((lu_panel2_kernel<T, PB, true, true>), dim3((unsigned)(8 * nW)), dim3(BLOCK), 0, ps, LU, n, (int)n, (int)k0, nW, box, ipiv, pl,
-                    flags, flags + 1, pthip::ctx().status_dev, nonce, prof);
-    else if (prof_on)
-      PTHIP_KLAUNCH((lu_panel2_kernel<T, PB, true, false>), dim3((unsigned)nW), dim3(BLOCK), 0, ps, LU, n, (int)n, (int)k0, nW, box, ipiv, pl, flags,
-                    flags + 1, pthip::ctx().status_dev, nonce, prof);
-    else if (x1)
-      PTHIP_KLAUNCH((lu_panel2_kernel<T, PB, false, true>), dim3((unsigned)(8 * nW)), dim3(BLOCK), 0, ps, LU, n, (int)n, (int)k0, nW, box, ipiv, pl,
-                    flags, flags + 1, pthip::ctx().status_dev, nonce, prof);
-    else
-      PTHIP_KLAUNCH((lu_panel2_kernel<T, PB, false, false>), dim3((unsigned)nW), dim3(BLOCK), 0, ps, LU, n, (int)n, (int)k0, nW, box, ipiv, pl, flags,
-                    flags + 1, pthip::ctx().status_dev, nonce, prof);
+#define LU_PANEL2_LAUNCH(PROFV, X1V, TBV)                                                                                            \
+  PTHIP_KLAUNCH((lu_panel2_kernel<T, PB, PROFV, X1V, TBV>), dim3((unsigned)((X1V ? 8 : 1) * nW)), dim3(TBV), 0, ps, LU, n, (int)n, (int)k0, nW, \
+                box, ipiv, pl, flags, flags + 1, pthip::ctx().status_dev, nonce, prof)
+    bool launched = false;
+    if constexpr (PB == 32) {
+      if (tb512) {
+        launched = true;
+        if (prof_on && x1) LU_PANEL2_LAUNCH(true, true, 512);
+        else if (prof_on) LU_PANEL2_LAUNCH(true, false, 512);
+        else if (x1) LU_PANEL2_LAUNCH(false, true, 512);
+        else LU_PANEL2_LAUNCH(false, false, 512);
+      }
+    }
+    if (!launched) {
+      if (prof_on && x1) LU_PANEL2_LAUNCH(true, true, BLOCK);
+      else if (prof_on) LU_PANEL2_LAUNCH(true, false, BLOCK);
+      else if (x1) LU_PANEL2_LAUNCH(false, true, BLOCK);
+      else LU_PANEL2_LAUNCH(false, false, BLOCK);
+    }
+#undef LU_PANEL2_LAUNCH
     if ((r = pthip::post_launch("lu_panel2"))) return fail(r);
     const long long right0 = k0 + pw, nright = n - right0;
     if (!lookahead) {
