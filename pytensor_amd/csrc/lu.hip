@@ -949,9 +949,21 @@ __global__ __launch_bounds__(CB) void lu_swap_u12_kernel(T* __restrict__ W, long
     e_dst[i] = i < ndisp ? plist[1 + PB + 2 * i] : k0;
     e_src[i] = i < ndisp ? plist[2 + PB + 2 * i] : k0;
   }
-  for (int e = tid; e < PB * PB; e += CB) {
-    const int r = e / PB, q = e - r * PB;
-    Ls[r * (PB + 1) + q] = (r < pw && q < r) ? W[(long long)(k0 + r) * ld + k0 + q] : T(0);
+  {
+    // L11: all PB * PB / CB loads of a thread in flight before the first LDS store (the looped form waited for each
+    // load in turn: ~16 memory latencies in front of everything else in this kernel)
+    constexpr int NL = (PB * PB + CB - 1) / CB;
+    T lv[NL];
+#pragma unroll
+    for (int u = 0; u < NL; u++) {
+      const int e = u * CB + tid, r = e / PB, q = e - r * PB;
+      lv[u] = (e < PB * PB && r < pw && q < r) ? W[(long long)(k0 + r) * ld + k0 + q] : T(0);
+    }
+#pragma unroll
+    for (int u = 0; u < NL; u++) {
+      const int e = u * CB + tid, r = e / PB, q = e - r * PB;
+      if (e < PB * PB) Ls[r * (PB + 1) + q] = lv[u];
+    }
   }
   __syncthreads();
   T d[PB];
