@@ -1,0 +1,195 @@
+"""Rooflines of the three kernel families north_star names first and the BASELINE configs never time:
+the broadcasting / strided ``Elemwise`` loop, the stand-alone ``CAReduce`` and ``Softmax`` / logsumexp.
+
+Workloads are the reference's own benchmark graphs (tests/benchmarks/test_elemwise.py:7-28,
+test_careduce.py:7-61, test_logsumexp.py:9-37) plus the shapes VERDICT r4 asked for, lowered by
+``HipLinker`` from the reference's front end (IRs: tests/golden/{ew_*,careduce_layouts,logsumexp_axis{0,1},
+softmax_bench}.json, pinned to the reference C linker at small sizes by tests/test_gpu_parity.py).
+Every case is checked at the size it is timed at against NumPy on the host (the reference's ``perform``
+for these ops IS NumPy: elemwise.py:755-823, 1493-1511, special.py:26-120).
+
+Per case: device time of one evaluation (HIP events around hipGraph replays, inputs resident in HBM,
+no output copy), algorithmic bytes / that time, fraction of 8 TB/s.
+
+usage: python tools/bench_hotpath.py [ew] [careduce] [softmax] [--reps R] [--only SUBSTR] [--out FILE]
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from pytensor_amd import ffi  # noqa: E402
+from pytensor_amd.executor import HipExecutable  # noqa: E402
+from pytensor_amd.inline import dead_code_elimination  # noqa: E402
+from pytensor_amd.ir import Graph  # noqa: E402
+
+HBM_PEAK = 8000.0  # GB/s
+
+
+def sub_graph(name, out_k):
+    """the golden IR ``name`` restricted to its output ``out_k`` (dead nodes and unused inputs dropped)"""
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", f"{name}.json")))
+    g = Graph.from_dict(d)
+    g.outputs = [g.outputs[out_k]]
+    g = dead_code_elimination(g)
+    used = {i for n in g.nodes for i in n.inputs} | set(g.outputs)
+    names = [nm for vid, nm in zip(g.inputs, d["input_names"]) if vid in used]
+    g.inputs = [vid for vid in g.inputs if vid in used]
+    return g, names
+
+
+def device_time_ms(plan, reps):
+    lib = ffi.lib()
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    ffi.check(lib.pthip_event_create(C.byref(e0)))
+    ffi.check(lib.pthip_event_create(C.byref(e1)))
+    for _ in range(3):
+        plan.launch_async()
+    best = None
+    for _ in range(3):  # best of three brackets of `reps` back-to-back replays
+        ffi.check(lib.pthip_event_record(e0))
+        for _ in range(reps):
+            plan.launch_async()
+        ffi.check(lib.pthip_event_record(e1))
+        ffi.check(lib.pthip_event_synchronize(e1))
+        ms = C.c_float()
+        ffi.check(lib.pthip_event_elapsed_ms(e0, e1, C.byref(ms)))
+        best = ms.value / reps if best is None else min(best, ms.value / reps)
+    lib.pthip_event_destroy(e0)
+    lib.pthip_event_destroy(e1)
+    return best
+
+
+def run(key, label, graph, names, vals, expect, nbytes, reps, rtol=1e-12, atol=0.0):
+    inputs = [vals[n] for n in names]
+    exe = HipExecutable(graph, resident=range(len(inputs)))
+    out = exe(*inputs)[0]
+    ref = expect()
+    assert out.shape == ref.shape and out.dtype == ref.dtype, (key, out.shape, ref.shape, out.dtype, ref.dtype)
+    err = float(np.max(np.abs(out - ref) / np.maximum(np.abs(ref) * rtol + atol, 1e-300))) if out.size else 0.0
+    assert err <= 1.0, f"{key}: |hip - numpy| / (rtol*|ref| + atol) = {err}"
+    plan = exe.freeze(*inputs, fetch_outputs=False)
+    t = device_time_ms(plan, reps)
+    plan.close()
+    exe.profile_nodes(inputs, reps=3)
+    kt = {k: round(v * 1e3, 2) for k, v in sorted(exe.last_kernel_times.items(), key=lambda kv: -kv[1])[:3]}
+    ops = [n.op for n in exe.graph.nodes if n.op not in ("DimShuffle", "Subtensor", "Shape_i", "ScalarFromTensor", "MakeVector")]
+    gbs = nbytes / t / 1e6
+    return {"key": key, "config": label, "ms_device": round(t, 5), "algorithmic_MB": round(nbytes / 1e6, 2), "achieved": round(gbs, 1), "unit": "GB/s",
+            "peak": HBM_PEAK, "frac": round(gbs / HBM_PEAK, 4), "parity_err_over_tol": round(err, 4), "rtol": rtol, "nodes": ops, "generated_kernels_us": kt}
+
+
+def case(*a, **kw):
+    return a, kw
+
+
+def ew_cases(reps):
+    rng = np.random.default_rng(1)
+    n = 4096
+    A, B = rng.normal(size=(n, n)), rng.normal(size=(n, n))
+    r, c = rng.normal(size=n), rng.normal(size=n)
+    M = 8 * n * n
+    g, nm = sub_graph("ew_rowcol_bcast", 0)
+    yield case("ew_rowcol_4096", "A*r[None,:]+c[:,None], 4096^2 f64", g, nm, {"A": A, "r": r, "c": c}, lambda: A * r[None, :] + c[:, None], 2 * M, reps, atol=5e-14)
+    g, nm = sub_graph("ew_transposed", 0)
+    yield case("ew_transposed_4096", "A + B.T, 4096^2 f64", g, nm, {"A": A, "B": B}, lambda: A + B.T, 3 * M, reps)
+    g, nm = sub_graph("ew_transposed", 4)
+    yield case("ew_transposed_self_4096", "A.T*2 + B, 4096^2 f64", g, nm, {"A": A, "B": B}, lambda: A.T * 2.0 + B, 3 * M, reps)
+    F, rf = A.astype("float32"), r.astype("float32")
+    g, nm = sub_graph("ew_rowbcast_f32", 0)
+    yield case("ew_rowbcast_f32_4096", "tanh(F*rf[None,:])*rf[None,:], 4096^2 f32", g, nm, {"F": F, "rf": rf}, lambda: np.tanh(F * rf[None, :]) * rf[None, :], M, reps,
+               rtol=1e-5, atol=1e-7)
+    g, nm = sub_graph("ew_simple_bcast", 0)
+    x, y = np.random.default_rng(42).normal(size=(200, 500)), np.random.default_rng(43).normal(size=500)
+    yield case("ew_ref_bench_200x500", "exp(2xy+y), x (200,500), y (500): the reference's benchmark size", g, nm, {"y": x, "z": y}, lambda: np.exp(2 * x * y + y), 2 * x.nbytes,
+              reps * 4, rtol=2e-12)
+    x2, y2 = rng.normal(size=(4000, 5000)), rng.normal(size=5000) * 0.3
+    yield case("ew_ref_bench_4000x5000", "exp(2xy+y), x (4000,5000), y (5000)", g, nm, {"y": x2, "z": y2}, lambda: np.exp(2 * x2 * y2 + y2), 2 * x2.nbytes, reps, rtol=2e-12)
+    S, s3 = rng.normal(size=(1_000_000, 10)), rng.normal(size=10)
+    g, nm = sub_graph("ew_nd_layouts", 2)
+    yield case("ew_small_inner_1e6x10", "S + s[None,:], S (1e6,10)", g, nm, {"S": S, "s3": s3}, lambda: S + s3[None, :], 2 * S.nbytes, reps)
+    T = rng.normal(size=(64, 512, 512))
+    g, nm = sub_graph("ew_nd_layouts", 9)
+    yield case("ew_reversed_inner_64x512x512", "T * T[:,:,::-1]", g, nm, {"T": T}, lambda: T * T[:, :, ::-1], 2 * T.nbytes, reps)
+    g, nm = sub_graph("ew_nd_layouts", 11)
+    yield case("ew_swap_outer_64x512x512", "T.transpose(1,0,2) - 1", g, nm, {"T": T}, lambda: T.transpose(1, 0, 2) - 1.0, 2 * T.nbytes, reps)
+
+
+def careduce_cases(reps, n=256):
+    rng = np.random.default_rng(2)
+    x, x2 = rng.uniform(size=(n, n, n)), rng.uniform(size=(2 * n, n, n))
+    views = {"c_contiguous": x, "transposed": x.transpose(2, 0, 1), "strided": x2[::2].transpose(2, 0, 1)}
+    k = 0
+    for layout, v in views.items():
+        for axis in (0, 1, 2, (0, 1), (0, 2), (1, 2), None):
+            g, nm = sub_graph("careduce_layouts", k)
+            k += 1
+            ax = "None" if axis is None else str(axis).replace(" ", "")
+            # absolute tolerance: a sum of m uniform(0,1) terms (condition number 1) within 1e-12 relative
+            yield case(f"careduce_{layout}_axis{ax}", f"sum(axis={ax}) of a {layout} ({n},{n},{n}) f64 tensor", g, nm, {"x": x, "x2": x2},
+                      lambda v=v, axis=axis: np.asarray(v.sum(axis=axis)), x.nbytes, reps)
+
+
+def softmax_cases(reps):
+    import scipy.special as sp
+
+    rng = np.random.default_rng(3)
+    for rows, cols in ((8192, 2048), (1000, 1000), (1_000_000, 10)):
+        X = rng.normal(size=(rows, cols)) * 3
+        tag = f"{rows}x{cols}"
+        g, nm = sub_graph("softmax_bench", 0)
+        yield case(f"softmax_axis1_{tag}", f"softmax(X, axis=1), X ({rows},{cols}) f64", g, nm, {"X": X}, lambda X=X: sp.softmax(X, axis=1), 2 * X.nbytes, reps, rtol=1e-11)
+        g, nm = sub_graph("softmax_bench", 1)
+        yield case(f"log_softmax_axis1_{tag}", f"log_softmax(X, axis=1), X ({rows},{cols}) f64", g, nm, {"X": X}, lambda X=X: sp.log_softmax(X, axis=1), 2 * X.nbytes, reps,
+                  rtol=1e-11, atol=1e-13)
+        g, nm = sub_graph("softmax_bench", 2)
+        yield case(f"softmax_axis0_{tag}", f"softmax(X, axis=0), X ({rows},{cols}) f64", g, nm, {"X": X}, lambda X=X: sp.softmax(X, axis=0), 2 * X.nbytes, reps, rtol=1e-11)
+        for axis in (0, 1):
+            g, nm = sub_graph(f"logsumexp_axis{axis}", 0)
+            yield case(f"logsumexp_axis{axis}_{tag}", f"the reference's logsumexp benchmark graph, axis={axis}, X ({rows},{cols}) f64 (bytes: X once)", g, nm, {"X": X},
+                      lambda X=X, axis=axis: sp.logsumexp(X, axis=axis, keepdims=True), X.nbytes, reps, rtol=1e-11, atol=1e-13)
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 20
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+    outp = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None
+    args = [a for a in args if a not in (str(reps), only, outp)]
+    which = args or ["ew", "careduce", "softmax"]
+    ffi.init(0)
+    gens = {"ew": ew_cases, "careduce": careduce_cases, "softmax": softmax_cases}
+    rows = []
+    for w in which:
+        for a, kw in gens[w](reps):
+            if only and only not in a[0]:
+                continue
+            t0 = time.perf_counter()
+            try:
+                r = run(*a, **kw)
+            except (AssertionError, RuntimeError, NotImplementedError, ValueError) as e:  # reported, not hidden; the other cases still run
+                r = {"key": a[0], "error": f"{type(e).__name__}: {e}"[:400]}
+            r["wall_s"] = round(time.perf_counter() - t0, 2)
+            rows.append(r)
+            print(json.dumps(r), flush=True)
+    if outp:
+        with open(outp, "w") as fh:
+            fh.write("| case | ms | GB/s | frac of 8 TB/s | kernels (us) |\n|---|---:|---:|---:|---|\n")
+            for r in rows:
+                if "error" in r:
+                    fh.write(f"| {r['key']} | FAILED: {r['error']} | | | |\n")
+                else:
+                    fh.write(f"| {r['key']} | {r['ms_device']:.4f} | {r['achieved']:.0f} | {r['frac']:.3f} | {r['generated_kernels_us']} |\n")
+
+
+if __name__ == "__main__":
+    main()
