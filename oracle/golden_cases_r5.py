@@ -46,6 +46,20 @@ def ew_transposed():
                                 "X": rng.normal(size=(3, 33, 65)), "Y": rng.normal(size=(3, 65, 33))}
 
 
+@case("ew_a_plus_bt")
+def ew_a_plus_bt():
+    rng = np.random.default_rng(510)
+    A, B = pt.dmatrix("A"), pt.dmatrix("B")
+    return [A, B], [A + B.T], {"A": rng.normal(size=(70, 45)), "B": rng.normal(size=(45, 70))}
+
+
+@case("ew_small_inner")
+def ew_small_inner():
+    rng = np.random.default_rng(511)
+    S, s = pt.dmatrix("S"), pt.dvector("s")
+    return [S, s], [S + s[None, :]], {"S": rng.normal(size=(211, 10)), "s": rng.normal(size=10)}
+
+
 @case("ew_simple_bcast")
 def ew_simple_bcast():
     # the reference's own elemwise benchmark graph (tests/benchmarks/test_elemwise.py:7-28)

@@ -79,11 +79,12 @@ def tile_kernel_source(name: str, body: dict, cls: str, nb: int, V: int, TX: int
     L.append(f'extern "C" __global__ __launch_bounds__({BLOCK}) void {name}({", ".join(P)}) {{')
     L.append(f"  constexpr int TX = {TX}, TY = {TY}, RPT = {RPT}, V = {V}, TC = {TC}, TR = {TR};")
     # ---- workgroup-uniform decomposition of the tile index ----
-    L.append("  long long pt_t = blockIdx.x;")
-    L.append("  const long long cb = pt_t % ncb; pt_t /= ncb;")
-    L.append("  const long long rb = pt_t % nrb; pt_t /= nrb;")
+    # (32-bit: the grid has fewer than 2^31 tiles; a 64-bit division is ~10x the instructions)
+    L.append("  unsigned pt_t = blockIdx.x;")
+    L.append("  const long long cb = pt_t % (unsigned)ncb; pt_t /= (unsigned)ncb;")
+    L.append("  const long long rb = pt_t % (unsigned)nrb; pt_t /= (unsigned)nrb;")
     for j in range(nb - 1, 0, -1):
-        L.append(f"  const long long q{j} = pt_t % b{j}; pt_t /= b{j};")
+        L.append(f"  const long long q{j} = pt_t % (unsigned)b{j}; pt_t /= (unsigned)b{j};")
     if nb:
         L.append("  const long long q0 = pt_t;")
     L.append("  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;")
@@ -109,23 +110,6 @@ def tile_kernel_source(name: str, body: dict, cls: str, nb: int, V: int, TX: int
                 L.append(f"  const {_vec_type(ct, V)} h{k} = *reinterpret_cast<const {_vec_type(ct, V)}*>(p{k} + colc);")
             else:
                 L.append(f"  const {ct} h{k} = p{k}[colc];")
-    # ---- transposed operands: the tile through LDS ----
-    tks = [k for k in range(nin) if cls[k] == "T"]
-    for k in tks:
-        ct = CTYPE[body["in_dtypes"][k]]
-        L.append(f"  __shared__ {ct} lds{k}[TC * (TR + 1)];")
-    if tks:
-        L.append("  {")
-        L.append("    const long long cbase = cb * TC;")
-        L.append(f"#pragma unroll 4\n    for (int l = threadIdx.x; l < TR * TC; l += {BLOCK}) {{")
-        L.append("      const int rr = l % TR, cc = l / TR;")
-        L.append("      long long r_ = row0 + rr; r_ = r_ < R ? r_ : R - 1;")
-        L.append("      long long c_ = cbase + cc; c_ = c_ < D ? c_ : D - 1;")
-        for k in tks:
-            L.append(f"      lds{k}[cc * (TR + 1) + rr] = p{k}[r_ * s{k}_r + c_ * s{k}_i];")
-        L.append("    }")
-        L.append("  }")
-        L.append("  __syncthreads();")
     for k, rs in enumerate(reduce_spec):
         if rs is not None:
             act = CTYPE[rs[1]]
@@ -154,12 +138,29 @@ def tile_kernel_source(name: str, body: dict, cls: str, nb: int, V: int, TX: int
             if V > 1:
                 L.append(f"    a{k}[i] = {_stream_load(f'reinterpret_cast<const {_vec_type(ct, V)}*>(p{k} + rowc * s{k}_r + colc)', struct=True)};")
             else:
-                L.append(f"    a{k}[i] = {_stream_load(f'p{k} + rowc * s{k}_r + colc')};")
+                L.append(f"    a{k}[i] = p{k}[rowc * s{k}_r + colc];")
         elif c == "B":
             L.append(f"    a{k}[i] = p{k}[rowc * s{k}_r];")
         elif c == "G":
             L.append(f"#pragma unroll\n    for (int e = 0; e < V; e++) a{k}[i][e] = p{k}[rowc * s{k}_r + (colc + e) * s{k}_i];")
     L.append("  }")
+    # ---- transposed operands: the tile through LDS ----
+    tks = [k for k in range(nin) if cls[k] == "T"]
+    for k in tks:
+        ct = CTYPE[body["in_dtypes"][k]]
+        L.append(f"  __shared__ {ct} lds{k}[TC * (TR + 1)];")
+    if tks:
+        L.append("  {")
+        L.append("    const long long cbase = cb * TC;")
+        L.append(f"#pragma unroll\n    for (int l = threadIdx.x; l < TR * TC; l += {BLOCK}) {{")
+        L.append("      const int rr = l % TR, cc = l / TR;")
+        L.append("      long long r_ = row0 + rr; r_ = r_ < R ? r_ : R - 1;")
+        L.append("      long long c_ = cbase + cc; c_ = c_ < D ? c_ : D - 1;")
+        for k in tks:
+            L.append(f"      lds{k}[cc * (TR + 1) + rr] = p{k}[r_ * s{k}_r + c_ * s{k}_i];")
+        L.append("    }")
+        L.append("  }")
+        L.append("  __syncthreads();")
     # ---- compute + store ----
     L.append("#pragma unroll\n  for (int i = 0; i < RPT; i++) {")
     for k, dt in enumerate(body["out_dtypes"]):

@@ -327,6 +327,8 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=
             # materialise the worst operand and retry (rare: >5 non-mergeable dims)
             ins = [a if isinstance(a, HostValue) or a.is_contiguous() else a.contiguous() for a in ins]
             return launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial, out_bufs)
+        if not partial and _TILE:
+            return _launch_tiled(body, ins, byvalue, cshape, cstr, outs, out_dtypes, reduce_spec, rs, bkey, rkey, env)
         pkey = ("_p" + "".join(str(k) + "." for k in sorted(partial))) if partial else ""
         pkey += ("_c" + "".join(str(k) + "." for k in sorted(byvalue))) if byvalue else ""
         name = f"ewnd_{bkey}_d{ndc}_{rkey}{pkey}".replace("-", "x").replace(".", "_")
@@ -364,6 +366,132 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=
         args += [f.ptr for f in fins] + [slot.value, env.lib.pthip_status_ptr()]
         finals_out[:] = fins
         env.keepalive.append(parts)
+    buf = struct.pack(f"<{len(args)}q", *args)
+    env.timed(name, lambda: ffi.check(lib.pthip_launch(fn, grid, 1, 1, BLOCK, 1, 1, 0, buf, len(buf))))
+    return outs, parts, grid
+
+
+# the tiled N-d loop (codegen_tile.py); PTHIP_EW_TILE=0 restores the element-per-thread loop with a division per dimension
+_TILE = os.environ.get("PTHIP_EW_TILE", "1") != "0"
+_TILE_RPT = int(os.environ.get("PTHIP_EW_TILE_RPT", 4))
+_LDS_BUDGET = 64 * 1024
+
+
+def _pow2ceil(x):
+    p = 1
+    while p < x:
+        p *= 2
+    return p
+
+
+def tile_plan(cshape, cstr, dev_dtypes, out_dtypes_stored, ptrs, out_ptrs):
+    """Host-side planning of one tiled launch (codegen_tile.tile_kernel_source).
+
+    ``cshape`` / ``cstr``: the collapsed iteration space and, per device operand, its element strides over it
+    (0 on broadcast dimensions).  Returns ``dict(jr, batch, cls, V, TX, RPT, lds_rows)``: the tile's row
+    dimension, the batch dimensions, the operand classes, the pack width and the tile shape."""
+    nd = len(cshape)
+    D = cshape[-1]
+    # ---- the tile's row dimension: where a transposed operand is contiguous, else the last outer dimension ----
+    jr = nd - 2 if nd > 1 else None
+    tdim = None
+    if nd > 1:
+        weight = {}
+        for st, dt in zip(cstr, dev_dtypes):
+            if st[-1] in (0, 1):
+                continue
+            for j in range(nd - 1):
+                if st[j] == 1 and cshape[j] >= 16:
+                    weight[j] = weight.get(j, 0) + np.dtype(dt).itemsize
+        if weight:
+            tdim = max(weight, key=lambda j: (weight[j], j))
+            jr = tdim
+    R = cshape[jr] if jr is not None else 1
+    batch = [j for j in range(nd - 1) if j != jr]
+    # ---- operand classes ----
+    cls = []
+    for st in cstr:
+        si = st[-1]
+        sr = st[jr] if jr is not None else 0
+        if not any(st):
+            cls.append("S")
+        elif si == 1:
+            cls.append("R" if (sr == 0 and R > 1) else "V")
+        elif si == 0:
+            cls.append("B")
+        elif tdim is not None and sr == 1:
+            cls.append("T")
+        else:
+            cls.append("G")
+    # ---- pack width: 16 bytes of the widest streamed type, as far as every pack stays aligned ----
+    wide = [np.dtype(dt).itemsize for dt, c in zip(dev_dtypes, cls) if c in "VR"] + [np.dtype(dt).itemsize for dt in out_dtypes_stored]
+    V = max(1, min(4, 16 // max(wide))) if wide else 1
+
+    def aligned(v):
+        if D % v:
+            return False
+        for st, dt, c, p in zip(cstr, dev_dtypes, cls, ptrs):
+            if c in "VR" and (p % (v * np.dtype(dt).itemsize) or any(s_ % v for s_ in st[:-1])):
+                return False
+        return all(p % (v * np.dtype(dt).itemsize) == 0 for dt, p in zip(out_dtypes_stored, out_ptrs))
+
+    while V > 1 and not aligned(V):
+        V //= 2
+    # ---- tile shape ----
+    lds_rows = 0
+    if "T" in cls:
+        TX = 64 // V
+        TY = BLOCK // TX
+        tb = lambda tr: sum(64 * (tr + 1) * np.dtype(dt).itemsize for dt, c in zip(dev_dtypes, cls) if c == "T")
+        lds_rows = 64 if tb(64) <= _LDS_BUDGET else 32
+        while tb(lds_rows) > _LDS_BUDGET:
+            # more transposed operands than LDS holds: the last ones read at their strides
+            k = max(i for i, c in enumerate(cls) if c == "T")
+            cls[k] = "G"
+        if "T" not in cls:
+            lds_rows = 0
+        RPT = max(1, (lds_rows or 64) // TY)
+    if "T" not in cls:
+        TX = min(BLOCK, _pow2ceil(-(-D // V)))
+        TY = BLOCK // TX
+        RPT = max(1, min(max(_TILE_RPT, 8 // V), -(-R // TY)))
+    return {"jr": jr, "batch": batch, "cls": "".join(cls), "V": V, "TX": TX, "RPT": RPT, "lds_rows": lds_rows, "R": R, "D": D}
+
+
+def _launch_tiled(body, ins, byvalue, cshape, cstr, outs, out_dtypes, reduce_spec, rs, bkey, rkey, env):
+    from pytensor_amd import codegen_tile
+
+    lib = env.lib
+    nout = len(out_dtypes)
+    dev = [k for k in range(len(ins)) if k not in byvalue]
+    stored = [k for k in range(nout) if reduce_spec[k] is None]
+    plan = tile_plan(cshape, cstr, [body["in_dtypes"][k] for k in dev], [out_dtypes[k] for k in stored], [ins[k].ptr for k in dev], [outs[k].ptr for k in stored])
+    jr, batch, V, TX, RPT = plan["jr"], plan["batch"], plan["V"], plan["TX"], plan["RPT"]
+    nb = len(batch)
+    cls, it = [], iter(plan["cls"])
+    for k in range(len(ins)):
+        cls.append("C" if k in byvalue else next(it))
+    cls = "".join(cls)
+    TY = BLOCK // TX
+    TC, TR = TX * V, TY * RPT
+    R, D = plan["R"], plan["D"]
+    nrb, ncb = -(-R // TR), -(-D // TC)
+    grid = nrb * ncb * int(np.prod([cshape[j] for j in batch])) if batch else nrb * ncb
+    name = f"ewt_{bkey}_{cls}_b{nb}_v{V}_x{TX}_r{RPT}_{rkey}".replace("-", "x")
+    src = codegen_tile.tile_kernel_source(name, body, cls, nb, V, TX, RPT, rs, plan["lds_rows"])
+    fn = kernel_cache.get_function(src, name)
+    ocs = _cstrides(cshape)
+    args = [R, D, nrb, ncb] + [cshape[j] for j in batch] + [ocs[jr] if jr is not None else 0] + [ocs[j] for j in batch]
+    its = iter(cstr)
+    for k, a in enumerate(ins):
+        if k in byvalue:
+            args.append(_scalar_bits(a, body["in_dtypes"][k]))
+            continue
+        st = next(its)
+        args += [a.ptr] + [st[j] for j in batch] + [st[jr] if jr is not None else 0, st[-1]]
+    parts = alloc_partials(reduce_spec, grid)
+    for k in range(nout):
+        args.append(outs[k].ptr if reduce_spec[k] is None else parts[k].ptr)
     buf = struct.pack(f"<{len(args)}q", *args)
     env.timed(name, lambda: ffi.check(lib.pthip_launch(fn, grid, 1, 1, BLOCK, 1, 1, 0, buf, len(buf))))
     return outs, parts, grid

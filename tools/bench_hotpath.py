@@ -100,7 +100,7 @@ def ew_cases(reps):
     M = 8 * n * n
     g, nm = sub_graph("ew_rowcol_bcast", 0)
     yield case("ew_rowcol_4096", "A*r[None,:]+c[:,None], 4096^2 f64", g, nm, {"A": A, "r": r, "c": c}, lambda: A * r[None, :] + c[:, None], 2 * M, reps, atol=5e-14)
-    g, nm = sub_graph("ew_transposed", 0)
+    g, nm = sub_graph("ew_a_plus_bt", 0)
     yield case("ew_transposed_4096", "A + B.T, 4096^2 f64", g, nm, {"A": A, "B": B}, lambda: A + B.T, 3 * M, reps)
     g, nm = sub_graph("ew_transposed", 4)
     yield case("ew_transposed_self_4096", "A.T*2 + B, 4096^2 f64", g, nm, {"A": A, "B": B}, lambda: A.T * 2.0 + B, 3 * M, reps)
@@ -115,8 +115,8 @@ def ew_cases(reps):
     x2, y2 = rng.normal(size=(4000, 5000)), rng.normal(size=5000) * 0.3
     yield case("ew_ref_bench_4000x5000", "exp(2xy+y), x (4000,5000), y (5000)", g, nm, {"y": x2, "z": y2}, lambda: np.exp(2 * x2 * y2 + y2), 2 * x2.nbytes, reps, rtol=2e-12)
     S, s3 = rng.normal(size=(1_000_000, 10)), rng.normal(size=10)
-    g, nm = sub_graph("ew_nd_layouts", 2)
-    yield case("ew_small_inner_1e6x10", "S + s[None,:], S (1e6,10)", g, nm, {"S": S, "s3": s3}, lambda: S + s3[None, :], 2 * S.nbytes, reps)
+    g, nm = sub_graph("ew_small_inner", 0)
+    yield case("ew_small_inner_1e6x10", "S + s[None,:], S (1e6,10)", g, nm, {"S": S, "s": s3}, lambda: S + s3[None, :], 2 * S.nbytes, reps)
     T = rng.normal(size=(64, 512, 512))
     g, nm = sub_graph("ew_nd_layouts", 9)
     yield case("ew_reversed_inner_64x512x512", "T * T[:,:,::-1]", g, nm, {"T": T}, lambda: T * T[:, :, ::-1], 2 * T.nbytes, reps)
