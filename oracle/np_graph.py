@@ -894,6 +894,20 @@ def _elemwise_reduce(p, inputs, node, graph):
     return res
 
 
+@op("ElemwiseAxisReduce")
+def _elemwise_axis_reduce(p, inputs, node, graph):
+    # axisfuse.fuse_elemwise_axis_reduce restated from its parts: Elemwise.perform (elemwise.py:755-823) then
+    # CAReduce.perform per output (elemwise.py:1493-1511)
+    outs = eval_scalar_body(p["scalar"], inputs)
+    shape = np.broadcast(*inputs).shape if inputs else ()
+    res = []
+    for o, spec, dt in zip(outs, p["reduce"], p["scalar"]["out_dtypes"]):
+        full = np.array(np.broadcast_to(o, shape), dtype=dt, order="C")
+        sub = {"axis": p["axis"], "scalar_op": spec["op"], "acc_dtype": spec["acc_dtype"], "dtype": spec["dtype"]}
+        res.append(_careduce(sub, [full], node, graph)[0])
+    return res
+
+
 @op("GemvChain")
 def _gemv_chain(p, inputs, node, graph):
     y1, a1, A, x1, b1, *rest = inputs

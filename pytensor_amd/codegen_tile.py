@@ -161,6 +161,7 @@ def tile_kernel_source(name: str, body: dict, cls: str, nb: int, V: int, TX: int
         L.append("    }")
         L.append("  }")
         L.append("  __syncthreads();")
+    L.append("  __builtin_amdgcn_sched_barrier(0);")
     # ---- compute + store ----
     L.append("#pragma unroll\n  for (int i = 0; i < RPT; i++) {")
     for k, dt in enumerate(body["out_dtypes"]):
@@ -204,5 +205,231 @@ def tile_kernel_source(name: str, body: dict, cls: str, nb: int, V: int, TX: int
                 L.append(f"    if (ok[i]) *reinterpret_cast<{_vec_type(CTYPE[dt], V)}*>(out{k} + ob + rowv[i] * osr + col) = r{k};")
     L.append("  }")
     L.append(_reduce_epilogue(reduce_spec, 1))
+    L.append("}")
+    return "\n".join(L)
+
+
+# ---------------------------------------------------------------------------------------------
+# N-d reductions over SOME dimensions (CAReduce with an axis tuple, optionally behind a fused
+# scalar graph): the same tile, with the row and / or inner dimension reduced
+# ---------------------------------------------------------------------------------------------
+
+ND_REDUCE_OPS = {**REDUCE_OPS, "ScalarMaximum": "OpMax", "ScalarMinimum": "OpMin", "AND": "OpAnd", "OR": "OpOr", "XOR": "OpXor"}
+
+
+def tile_reduce_params(body, cls, nkb, nrd, outs):
+    P = ["long long R", "long long D", "long long nrb", "long long ncb", "long long iters", "long long chunk", "long long ps_split"]
+    P += [f"long long kb{j}" for j in range(nkb)] + [f"long long rd{j}" for j in range(nrd)]
+    P += ["long long osr", "long long osi"] + [f"long long oskb{j}" for j in range(nkb)]
+    for k, dt in enumerate(body["in_dtypes"]):
+        if cls[k] == "C":
+            P.append(f"const long long in{k}")
+            continue
+        P.append(f"const {CTYPE[dt]}* __restrict__ in{k}")
+        P += [f"long long s{k}_kb{j}" for j in range(nkb)] + [f"long long s{k}_rd{j}" for j in range(nrd)] + [f"long long s{k}_r", f"long long s{k}_i"]
+    for k, (op, acc, odt) in enumerate(outs):
+        P.append(f"{CTYPE[odt]}* __restrict__ dst{k}")
+    return P
+
+
+def tile_reduce_source(name: str, body: dict, cls: str, nkb: int, nrd: int, row_kept: bool, inner_kept: bool, V: int, TX: int, RPT: int, outs) -> str:
+    """``out[kept] = reduce_{reduced} body(operands)`` — CAReduce over an axis tuple (pytensor/tensor/elemwise.py:1233,
+    perform 1493-1511; the reference's C loop nest: elemwise.py:1520-1678, elemwise_cgen.py:467-761), any operand
+    strides, with the scalar graph of a producing ``Elemwise`` evaluated on the fly.
+
+    The iteration space is the tile of :func:`tile_kernel_source` — (row dimension, inner dimension) + batch
+    dimensions — where each dimension is either kept or reduced:
+
+    * kept batch dimensions (``nkb``), the row blocks of a kept row dimension and the column blocks of a kept
+      inner dimension come from ``blockIdx.x``; a last factor of ``blockIdx.x`` is the SPLIT index;
+    * everything reduced — reduced batch dimensions (``nrd``), the row blocks of a reduced row dimension, the
+      column blocks of a reduced inner dimension — is one flat loop of ``iters`` tile visits, of which a
+      workgroup takes ``chunk`` consecutive ones (split s: [s*chunk, (s+1)*chunk));
+    * per-thread accumulators in the accumulator dtype (one per kept row of the thread x kept element of its
+      pack), combined in a fixed order at the end: across the ``TX`` lanes of a row when the inner dimension
+      is reduced (wave64 butterfly within ``TX <= 64`` lanes, LDS across waves for ``TX = 256``), across the
+      ``TY`` thread rows through LDS when the row dimension is reduced.  No atomics: deterministic.
+
+    ``outs[k] = (op, acc_dtype, store_dtype)``: with one split the store dtype is the output dtype and ``dst``
+    the output; with several, ``dst`` is the partial array (``ps_split`` = the split stride; the output strides arrive pre-multiplied by the
+    output's stride in it) in the accumulator dtype and a second launch (csrc/reduce.hip) folds the splits.
+    """
+    nin, nout = len(body["in_dtypes"]), len(body["out_dtypes"])
+    assert len(outs) == nout and len(cls) == nin and "T" not in cls
+    TY = BLOCK // TX
+    TC, TR = TX * V, TY * RPT
+    assert TX * TY == BLOCK
+    if not inner_kept:
+        assert TX <= 64 or TX == BLOCK
+    NI = RPT if row_kept else 1  # accumulators per thread: kept rows x kept pack elements
+    NE = V if inner_kept else 1
+    P = tile_reduce_params(body, cls, nkb, nrd, outs)
+    L = [reduce_header(), prelude_for(body), VEC_HELPERS]
+    L.append(f'extern "C" __global__ __launch_bounds__({BLOCK}) void {name}({", ".join(P)}) {{')
+    L.append(f"  constexpr int TX = {TX}, TY = {TY}, RPT = {RPT}, V = {V}, TC = {TC}, TR = {TR};")
+    L.append("  unsigned pt_t = blockIdx.x;")
+    if inner_kept:
+        L.append("  const long long cb = pt_t % (unsigned)ncb; pt_t /= (unsigned)ncb;")
+    if row_kept:
+        L.append("  const long long rb = pt_t % (unsigned)nrb; pt_t /= (unsigned)nrb;")
+    for j in range(nkb - 1, -1, -1):
+        L.append(f"  const long long q{j} = pt_t % (unsigned)kb{j}; pt_t /= (unsigned)kb{j};")
+    L.append("  const long long split = pt_t;")
+    L.append("  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;")
+    for k, (op, acc, odt) in enumerate(outs):
+        act = CTYPE[acc]
+        L.append(f"  {act} acc{k}[{NI}][{NE}];")
+        L.append(f"#pragma unroll\n  for (int i = 0; i < {NI}; i++)\n#pragma unroll\n    for (int e = 0; e < {NE}; e++) acc{k}[i][e] = pthip_dev::{ND_REDUCE_OPS[op]}::identity<{act}>();")
+    for k, dt in enumerate(body["in_dtypes"]):
+        ct = CTYPE[dt]
+        if cls[k] == "C":
+            L.append(f"  {ct} sc{k}; {{ const long long b = in{k}; __builtin_memcpy(&sc{k}, &b, sizeof({ct})); }}")
+        elif cls[k] == "S":
+            L.append(f"  const {ct} sc{k} = in{k}[0];")
+        else:
+            off = " + ".join(f"q{j} * s{k}_kb{j}" for j in range(nkb)) or "0"
+            L.append(f"  const {ct}* __restrict__ pk{k} = in{k} + ({off});")
+    L.append("  long long it1 = (split + 1) * chunk; it1 = it1 < iters ? it1 : iters;")
+    # UI tile visits per trip: the loads of all of them are issued before the first scalar graph runs (a visit of a
+    # one-row tile is ONE pack per thread and operand; the chip needs ~64 KB in flight per CU)
+    UI = max(1, 8 // RPT)
+    L.append(f"  constexpr int UI = {UI};")
+    L.append("  for (long long it = split * chunk; it < it1; it += UI) {")
+    L.append("    bool ok[UI][RPT];")
+    for k, dt in enumerate(body["in_dtypes"]):
+        ct = CTYPE[dt]
+        c = cls[k]
+        if c == "V":
+            L.append(f"    {_vec_type(ct, V) if V > 1 else ct} a{k}[UI][RPT];")
+        elif c == "B":
+            L.append(f"    {ct} a{k}[UI][RPT];")
+        elif c == "G":
+            L.append(f"    {ct} a{k}[UI][RPT][V];")
+        elif c == "R":
+            L.append(f"    {_vec_type(ct, V) if V > 1 else ct} h{k}[UI];")
+    nvar = (0 if inner_kept else 1) + (0 if row_kept else 1) + nrd
+    L.append("#pragma unroll\n    for (int w = 0; w < UI; w++) {")
+    L.append("      const bool live = it + w < it1;")
+    L.append("      unsigned u = (unsigned)(live ? it + w : it1 - 1);")
+    left = nvar
+
+    def take(var, ext):
+        nonlocal left
+        left -= 1
+        if left == 0:
+            L.append(f"      const long long {var} = u;")
+        else:
+            L.append(f"      const long long {var} = u % (unsigned){ext}; u /= (unsigned){ext};")
+
+    if not inner_kept:
+        take("cb", "ncb")
+    if not row_kept:
+        take("rb", "nrb")
+    for j in range(nrd - 1, -1, -1):
+        take(f"z{j}", f"rd{j}")
+    L.append("      const long long col = cb * TC + (long long)tx * V;")
+    L.append("      const bool cok = live && col < D;")
+    L.append("      const long long colc = col < D ? col : 0;")
+    L.append("      const long long row0 = rb * TR;")
+    for k, dt in enumerate(body["in_dtypes"]):
+        ct = CTYPE[dt]
+        c = cls[k]
+        if c in "CS":
+            continue
+        off = " + ".join(f"z{j} * s{k}_rd{j}" for j in range(nrd)) or "0"
+        L.append(f"      const {ct}* __restrict__ p{k} = pk{k} + ({off});")
+        if c == "R":
+            if V > 1:
+                L.append(f"      h{k}[w] = *reinterpret_cast<const {_vec_type(ct, V)}*>(p{k} + colc);")
+            else:
+                L.append(f"      h{k}[w] = p{k}[colc];")
+    L.append("#pragma unroll\n      for (int i = 0; i < RPT; i++) {")
+    L.append("        const long long row = row0 + ty + i * TY;")
+    L.append("        ok[w][i] = cok && row < R;")
+    L.append("        const long long rowc = row < R ? row : R - 1;")
+    for k, dt in enumerate(body["in_dtypes"]):
+        ct = CTYPE[dt]
+        c = cls[k]
+        if c == "V":
+            if V > 1:
+                L.append(f"        a{k}[w][i] = {_stream_load(f'reinterpret_cast<const {_vec_type(ct, V)}*>(p{k} + rowc * s{k}_r + colc)', struct=True)};")
+            else:
+                L.append(f"        a{k}[w][i] = p{k}[rowc * s{k}_r + colc];")
+        elif c == "B":
+            L.append(f"        a{k}[w][i] = p{k}[rowc * s{k}_r];")
+        elif c == "G":
+            L.append(f"#pragma unroll\n        for (int e = 0; e < V; e++) a{k}[w][i][e] = p{k}[rowc * s{k}_r + (colc + e) * s{k}_i];")
+    L.append("      }")
+    L.append("    }")
+    # (the machine scheduler would otherwise sink every request next to its first use)
+    L.append("    __builtin_amdgcn_sched_barrier(0);")
+    L.append("#pragma unroll\n    for (int w = 0; w < UI; w++) {")
+    L.append("#pragma unroll\n    for (int i = 0; i < RPT; i++) {")
+    L.append("#pragma unroll\n      for (int e = 0; e < V; e++) {")
+    in_names = []
+    for k in range(nin):
+        c = cls[k]
+        if c in "CS":
+            in_names.append(f"sc{k}")
+        elif c == "V":
+            in_names.append(f"a{k}[w][i].v[e]" if V > 1 else f"a{k}[w][i]")
+        elif c == "R":
+            in_names.append(f"h{k}[w].v[e]" if V > 1 else f"h{k}[w]")
+        elif c == "B":
+            in_names.append(f"a{k}[w][i]")
+        else:
+            in_names.append(f"a{k}[w][i][e]")
+    out_names = []
+    for k, dt in enumerate(body["out_dtypes"]):
+        L.append(f"        {CTYPE[dt]} o{k};")
+        out_names.append(f"o{k}")
+    L.append(emit_body(body, in_names, out_names, indent="        "))
+    ia = "i" if row_kept else "0"
+    ea = "e" if inner_kept else "0"
+    for k, (op, acc, odt) in enumerate(outs):
+        L.append(f"        if (ok[w][i]) acc{k}[{ia}][{ea}] = pthip_dev::{ND_REDUCE_OPS[op]}::apply(acc{k}[{ia}][{ea}], ({CTYPE[acc]})o{k});")
+    L.append("      }")
+    L.append("    }")
+    L.append("    }")
+    L.append("  }")
+    # ---- combine + store (fixed order: deterministic) ----
+    obase = " + ".join(["split * ps_split"] + [f"q{j} * oskb{j}" for j in range(nkb)])
+    L.append(f"  const long long ob = {obase};")
+    for k, (op, acc, odt) in enumerate(outs):
+        act, opn, sct = CTYPE[acc], f"pthip_dev::{ND_REDUCE_OPS[op]}", CTYPE[odt]
+        if row_kept and not inner_kept:
+            if TX == BLOCK:
+                L.append(f"  __shared__ {act} sm{k}[{BLOCK // 64}];")
+            L.append(f"#pragma unroll\n  for (int i = 0; i < RPT; i++) {{")
+            L.append(f"    {act} v = acc{k}[i][0];")
+            if TX == BLOCK:
+                L.append(f"    v = pthip_dev::block_reduce<{opn}, {act}, {BLOCK}>(v, sm{k});")
+            else:
+                L.append(f"#pragma unroll\n    for (int off = TX / 2; off > 0; off >>= 1) v = {opn}::apply(v, pthip_dev::shfl_xor_any(v, off));")
+            L.append("    const long long row = rb * TR + ty + i * TY;")
+            L.append(f"    if (tx == 0 && row < R) dst{k}[ob + row * osr] = ({sct})v;")
+            L.append("  }")
+        elif inner_kept and not row_kept:
+            if TY > 1:
+                L.append(f"  __shared__ {act} sm{k}[TY][TC + 1];")
+                L.append(f"#pragma unroll\n  for (int e = 0; e < V; e++) sm{k}[ty][tx * V + e] = acc{k}[0][e];")
+                L.append("  __syncthreads();")
+                L.append("  if (ty == 0) {")
+                L.append(f"#pragma unroll\n    for (int e = 0; e < V; e++) {{")
+                L.append(f"      {act} v = sm{k}[0][tx * V + e];")
+                L.append(f"      for (int y = 1; y < TY; y++) v = {opn}::apply(v, sm{k}[y][tx * V + e]);")
+                L.append(f"      acc{k}[0][e] = v;")
+                L.append("    }")
+                L.append("  }")
+            L.append("  {")
+            L.append("    const long long col = cb * TC + (long long)tx * V;")
+            L.append(f"#pragma unroll\n    for (int e = 0; e < V; e++) if (ty == 0 && col + e < D) dst{k}[ob + (col + e) * osi] = ({sct})acc{k}[0][e];")
+            L.append("  }")
+        elif not row_kept and not inner_kept:
+            L.append(f"  __shared__ {act} sm{k}[{BLOCK // 64}];")
+            L.append(f"  {{ const {act} v = pthip_dev::block_reduce<{opn}, {act}, {BLOCK}>(acc{k}[0][0], sm{k});")
+            L.append(f"    if (threadIdx.x == 0) dst{k}[ob] = ({sct})v; }}")
+        else:
+            raise ValueError("nothing reduced in the tile: use tile_kernel_source")
     L.append("}")
     return "\n".join(L)

@@ -497,6 +497,193 @@ def _launch_tiled(body, ins, byvalue, cshape, cstr, outs, out_dtypes, reduce_spe
     return outs, parts, grid
 
 
+# ---------------------------------------------------------------------------
+# N-d reductions over an axis tuple (codegen_tile.tile_reduce_source)
+# ---------------------------------------------------------------------------
+
+_ND_REDUCE = os.environ.get("PTHIP_ND_REDUCE", "1") != "0"
+_ND_REDUCE_WGS = int(os.environ.get("PTHIP_ND_REDUCE_WGS", 1024))  # workgroups wanted before the reduced range is split
+
+
+def reduce_plan(shape, axes, strides, dev_dtypes, ptrs, out_shape):
+    """Host-side planning of one N-d reduction launch.
+
+    ``shape``: the iteration space; ``axes``: its reduced dimensions; ``strides``: per device operand, element
+    strides over ``shape`` (0 on broadcast dimensions); the output is C-contiguous over the kept dimensions.
+    Dimensions of one role (kept / reduced) are sorted by the dominant operand's stride and merged where every
+    operand (and, for kept ones, the output) is jointly contiguous — a sum over a transposed view collapses
+    back to the layout in memory.  Returns ``None`` when the shape does not fit the tile (more than 3 batch
+    dimensions of one role, > 2^31 tile visits)."""
+    nd = len(shape)
+    axes = set(axes)
+    ost, accu = [0] * nd, 1
+    for d in reversed(range(nd)):
+        if d not in axes:
+            ost[d] = accu
+            accu *= shape[d]
+    n_out = accu
+    weights = [sum(1 for d in range(nd) if st[d] != 0 and shape[d] > 1) * 1000 + np.dtype(dt).itemsize for st, dt in zip(strides, dev_dtypes)]
+    dom = int(np.argmax(weights)) if weights else 0
+    dims = [{"n": shape[d], "red": d in axes, "st": [st[d] for st in strides], "ost": ost[d]} for d in range(nd) if shape[d] != 1]
+    merged = []
+    for role in (False, True):
+        group = sorted((x for x in dims if x["red"] == role), key=lambda x: -abs(x["st"][dom]))
+        out = []
+        for x in group:
+            if out:
+                p = out[-1]
+                if all(a == b * x["n"] for a, b in zip(p["st"], x["st"])) and (role or p["ost"] == x["ost"] * x["n"]):
+                    p["n"] *= x["n"]
+                    p["st"], p["ost"] = x["st"], x["ost"]
+                    continue
+            out.append(dict(x))
+        merged += out
+    if not any(x["red"] for x in merged):
+        return None
+    # the inner dimension: where the dominant operand is contiguous
+    unit = [x for x in merged if x["st"][dom] == 1] or [x for x in merged if x["st"][dom] == -1]
+    inner = unit[0] if unit else min(merged, key=lambda x: (abs(x["st"][dom]) == 0, abs(x["st"][dom])))
+    rest = [x for x in merged if x is not inner]
+    if inner["red"]:
+        kept = [x for x in rest if not x["red"]]
+        cand = kept or [x for x in rest if x["red"]]
+        row = min(cand, key=lambda x: (x["st"][dom] == 0, abs(x["st"][dom]))) if kept else (max(cand, key=lambda x: x["n"]) if cand else None)
+    else:
+        row = max((x for x in rest if x["red"]), key=lambda x: x["n"])
+    rest = [x for x in rest if x is not row]
+    kb = [x for x in rest if not x["red"]]
+    rd = [x for x in rest if x["red"]]
+    if len(kb) > 3 or len(rd) > 3:
+        return None
+    R = row["n"] if row is not None else 1
+    D = inner["n"]
+    row_kept = row is not None and not row["red"]
+    inner_kept = not inner["red"]
+    cls = []
+    for k in range(len(strides)):
+        si = inner["st"][k]
+        sr = row["st"][k] if row is not None else 0
+        if not any(x["st"][k] for x in merged):
+            cls.append("S")
+        elif si == 1:
+            cls.append("R" if (sr == 0 and R > 1) else "V")
+        elif si == 0:
+            cls.append("B")
+        else:
+            cls.append("G")
+    wide = [np.dtype(dt).itemsize for dt, c in zip(dev_dtypes, cls) if c in "VR"]
+    V = max(1, min(4, 16 // max(wide))) if wide else 1
+
+    def aligned(v):
+        if D % v:
+            return False
+        for k, (dt, c, p) in enumerate(zip(dev_dtypes, cls, ptrs)):
+            if c in "VR" and (p % (v * np.dtype(dt).itemsize) or any(x["st"][k] % v for x in merged if x is not inner)):
+                return False
+        return True
+
+    while V > 1 and not aligned(V):
+        V //= 2
+    cols = -(-D // V)
+    if inner_kept:
+        # (the thread rows split the reduced rows inside the workgroup: >= 4 of them, combined through LDS)
+        TX = min(64, _pow2ceil(cols))
+    else:
+        TX = BLOCK if cols >= BLOCK else min(64, _pow2ceil(cols))
+    TY = BLOCK // TX
+    RPT = max(1, min(max(_TILE_RPT, 8 // V), -(-R // TY)))
+    TC, TR = TX * V, TY * RPT
+    nrb, ncb = -(-R // TR), -(-D // TC)
+    n_nat = int(np.prod([x["n"] for x in kb], dtype=np.int64)) * (nrb if row_kept else 1) * (ncb if inner_kept else 1)
+    iters = int(np.prod([x["n"] for x in rd], dtype=np.int64)) * (1 if row_kept else nrb) * (1 if inner_kept else ncb)
+    if iters >= 2**31 or n_nat >= 2**30:
+        return None
+    return {"row": row, "inner": inner, "kb": kb, "rd": rd, "R": R, "D": D, "row_kept": row_kept, "inner_kept": inner_kept, "cls": "".join(cls), "V": V, "TX": TX,
+            "RPT": RPT, "nrb": nrb, "ncb": ncb, "n_nat": n_nat, "iters": iters, "n_out": n_out}
+
+
+def launch_axis_reduce(env, body, ins, shape, axes, specs, out_shape):
+    """``out[k] = reduce_{axes} body_k(ins)`` in one pass over the operands (+ a small second launch when the reduced
+    range had to be split for parallelism).  ``specs[k] = (op, acc_dtype, out_dtype)``.  Returns the outputs, or
+    ``None`` when the shape is outside what the tile covers (the caller then takes the run-by-run path)."""
+    from pytensor_amd import codegen_tile
+
+    byvalue = {k for k, a in enumerate(ins) if isinstance(a, HostValue)}
+    dev = [k for k in range(len(ins)) if k not in byvalue]
+    nd = len(shape)
+    strides = []
+    for k in dev:
+        a = ins[k]
+        shp = (1,) * (nd - a.ndim) + tuple(a.shape)
+        st = (0,) * (nd - a.ndim) + tuple(a.strides)
+        strides.append(tuple(0 if shp[d] == 1 and shape[d] != 1 else st[d] for d in range(nd)))
+    plan = reduce_plan(shape, axes, strides, [body["in_dtypes"][k] for k in dev], [ins[k].ptr for k in dev], out_shape)
+    if plan is None:
+        return None
+    kb, rd, row, inner = plan["kb"], plan["rd"], plan["row"], plan["inner"]
+    n_out, iters, n_nat = plan["n_out"], plan["iters"], plan["n_nat"]
+    accsz = max(np.dtype(sp[1]).itemsize for sp in specs)
+    in_bytes = int(np.prod(shape, dtype=np.int64)) * max(np.dtype(body["in_dtypes"][k]).itemsize for k in dev)
+    nsplit = max(1, min(iters, -(-_ND_REDUCE_WGS // n_nat)))
+    nsplit = max(1, min(nsplit, in_bytes // max(1, 16 * n_out * accsz * len(specs))))
+    # partial layout: few outputs -> [n_out][split] (the second launch reads each output's splits contiguously, 64 lanes
+    # per output; at most 512 splits so that it is ONE launch); many outputs -> [split][n_out] (a thread per output)
+    split_fastest = n_out <= 8192
+    if split_fastest:
+        nsplit = min(nsplit, 512)
+    chunk = -(-iters // nsplit)
+    nsplit = -(-iters // chunk)
+    final = nsplit == 1
+    ps_split, ps_out = (0, 1) if final else ((1, nsplit) if split_fastest else (n_out, 1))
+    cls, it = [], iter(plan["cls"])
+    for k in range(len(ins)):
+        cls.append("C" if k in byvalue else next(it))
+    cls = "".join(cls)
+    V, TX, RPT = plan["V"], plan["TX"], plan["RPT"]
+    kouts = [(op, acc, (odt if final else acc)) for op, acc, odt in specs]
+    okey = "_".join(f"{op[:2]}{_dtag(acc)}{_dtag(sd)}" for op, acc, sd in kouts)
+    name = f"rnd_{_body_key(body)}_{cls}_k{len(kb)}r{len(rd)}_{'K' if plan['row_kept'] else 'R'}{'K' if plan['inner_kept'] else 'R'}_v{V}_x{TX}_r{RPT}_{okey}"
+    src = codegen_tile.tile_reduce_source(name, body, cls, len(kb), len(rd), plan["row_kept"], plan["inner_kept"], V, TX, RPT, kouts)
+    fn = kernel_cache.get_function(src, name)
+    args = [plan["R"], plan["D"], plan["nrb"], plan["ncb"], iters, chunk, ps_split] + [x["n"] for x in kb] + [x["n"] for x in rd]
+    args += [(row["ost"] if plan["row_kept"] else 0) * ps_out, (inner["ost"] if plan["inner_kept"] else 0) * ps_out] + [x["ost"] * ps_out for x in kb]
+    j = 0
+    for k, a in enumerate(ins):
+        if k in byvalue:
+            args.append(_scalar_bits(a, body["in_dtypes"][k]))
+            continue
+        args += [a.ptr] + [x["st"][j] for x in kb] + [x["st"][j] for x in rd] + [row["st"][j] if row is not None else 0, inner["st"][j]]
+        j += 1
+    outs = [DeviceArray.empty(out_shape, odt) for _, _, odt in specs]
+    dsts = outs if final else [DeviceArray.empty((nsplit * n_out,), acc) for _, acc, _ in specs]
+    args += [d.ptr for d in dsts]
+    grid = n_nat * nsplit
+    buf = struct.pack(f"<{len(args)}q", *args)
+    env.timed(name, lambda: ffi.check(env.lib.pthip_launch(fn, grid, 1, 1, BLOCK, 1, 1, 0, buf, len(buf))))
+    if not final:
+        if split_fastest:
+            outs = [device_reduce(env, op, part, n_out, nsplit, 1, nsplit, 1, 0, acc, odt, out_shape) for part, (op, acc, odt) in zip(dsts, specs)]
+        else:
+            outs = [device_reduce(env, op, part, 1, nsplit, n_out, 0, n_out, 1, acc, odt, out_shape) for part, (op, acc, odt) in zip(dsts, specs)]
+    return outs
+
+
+def _dtag(dt):
+    d = np.dtype(dt)
+    return f"{d.kind}{d.itemsize}"
+
+
+def _identity_body(dtype):
+    key = str(dtype)
+    b = _IDENT_BODIES.get(key)
+    if b is None:
+        b = _IDENT_BODIES[key] = {"in_dtypes": [key], "out_dtypes": [key], "body": [{"op": "Identity", "in": [["i", 0]], "dtype": key}], "outs": [["t", 0]]}
+    return b
+
+
+_IDENT_BODIES = {}
+
+
 def _homogeneous(spec):
     red = [r for r in spec if r is not None]
     return len(red) > 1 and all((r["op"], r["acc_dtype"], r["dtype"]) == (red[0]["op"], red[0]["acc_dtype"], red[0]["dtype"]) for r in red)
@@ -665,6 +852,33 @@ def elemwise_reduce(node, inputs, env):
     return res
 
 
+@handler("ElemwiseAxisReduce")
+def elemwise_axis_reduce(node, inputs, env):
+    """axisfuse.fuse_elemwise_axis_reduce: ``CAReduce_axes(Elemwise(inputs))`` per output, one pass over the inputs."""
+    p = node.params
+    body = p["scalar"]
+    ins = [_scalar_or_device(env, i) for i in inputs]
+    shape = _broadcast_shape(node, env.graph, ins)
+    axes = [int(a) for a in p["axis"]]
+    out_shape = tuple(s for d, s in enumerate(shape) if d not in axes)
+    specs = []
+    for r, dt in zip(p["reduce"], body["out_dtypes"]):
+        acc = dt if r["op"] in ("Maximum", "Minimum") else r["acc_dtype"]  # (elemwise.py:1383-1417: no widening for max / min)
+        specs.append((r["op"], acc, r["dtype"]))
+    n = int(np.prod(shape)) if shape else 1
+    res = None
+    if n and all(shape[a] for a in axes):
+        res = launch_axis_reduce(env, body, ins, tuple(shape), axes, specs, out_shape)
+    if res is None:
+        # shapes outside the tile (or empty): the unfused pair
+        outs, _, _ = launch_elemwise(body, ins, shape, body["out_dtypes"], None, env)
+        res = []
+        for o, r in zip(outs, p["reduce"]):
+            sub = type("_N", (), {"params": {"axis": axes, "scalar_op": r["op"], "acc_dtype": r["acc_dtype"], "dtype": r["dtype"]}})
+            res.append(careduce(sub, [o], env)[0])
+    return [r.view(out_shape, _cstrides(out_shape)) for r in res]
+
+
 @handler("CAReduce")
 def careduce(node, inputs, env):
     p = node.params
@@ -682,6 +896,12 @@ def careduce(node, inputs, env):
         return [x if str(x.dtype) == outdt else _cast(env, x, outdt)]
     if any(x.shape[d] == 0 for d in axes) and op not in ("Add", "Mul", "AND", "OR", "XOR"):
         raise ValueError(f"zero-size array to reduction operation {op.lower()} which has no identity")
+    if _ND_REDUCE and x.size and not (outdt == "bool" and acc != "bool"):
+        # one pass whatever the layout: kept / reduced dimensions sorted by stride, merged, tiled
+        rop = {"Maximum": "OR", "ScalarMaximum": "OR", "Minimum": "AND", "ScalarMinimum": "AND"}.get(op, op) if str(x.dtype) == "bool" else op
+        res = launch_axis_reduce(env, _identity_body(x.dtype), [x], tuple(x.shape), axes, [(rop, acc, outdt)], out_shape)
+        if res is not None:
+            return [res[0].view(out_shape, _cstrides(out_shape))]
     # split the reduced axes into runs of adjacent dims; reduce the last run first
     runs = []
     for a in axes:

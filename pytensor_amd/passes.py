@@ -7,6 +7,7 @@ Order matters:
 1. ``push_gather_through_elemwise`` / ``inline_elemwise_producers`` (inline.py) — finish the
    elementwise fusion the reference's ``FusionOptimizer`` stops short of;
 2. ``fuse_elemwise_reduce`` (fusion.py) — full reductions folded into the producing kernel;
+   ``duplicate_cheap_producers`` / ``fuse_elemwise_axis_reduce`` (axisfuse.py) — reductions over SOME axes too;
 3. ``merge_sibling_reductions`` (inline.py);
 4. ``hoist_scan_seq_dots`` — sequence-only products out of ``Scan``;
 5. ``fuse_cholesky_solve`` — Cholesky + its first triangular solve, factor kept in LDS;
@@ -29,6 +30,7 @@ from __future__ import annotations
 
 import os
 
+from pytensor_amd.axisfuse import duplicate_cheap_producers, fuse_elemwise_axis_reduce
 from pytensor_amd.fusion import (
     fuse_cholesky_solve,
     fuse_elemwise_reduce,
@@ -59,8 +61,12 @@ def run_pipeline(graph: Graph, fuse=True, tail=True):
     if fuse == "elemwise":
         return fuse_elemwise_reduce(graph), None
     g = split_host_shape_arithmetic(graph)  # shape asserts fused into device Composites: back to the host
+    if os.environ.get("PTHIP_AXIS_FUSE", "1") != "0":
+        g = duplicate_cheap_producers(g)  # `X - m` read by a Max and an Exp/Sum: recomputed per client, never stored
     g = inline_elemwise_producers(push_gather_through_elemwise(g))
     g = fuse_elemwise_reduce(g)
+    if os.environ.get("PTHIP_AXIS_FUSE", "1") != "0":
+        g = fuse_elemwise_axis_reduce(g)  # row / column reductions of a fused expression in one kernel
     g = merge_sibling_reductions(g)
     g = hoist_scan_seq_dots(g)
     g = fuse_cholesky_solve(g)
