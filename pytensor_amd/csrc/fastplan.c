@@ -63,6 +63,13 @@ typedef struct {
   volatile int* done;
   volatile int* status;
   int sync_mode;
+  /* the executable's resident generation (HipExecutable._res_gen): bumped by invalidate_resident, by every
+   * re-upload into a resident's device buffer (another plan of the same executable, an eager call, set_value)
+   * and by every re-watch.  A plan vouches for its residents only while the counter still has the value it had
+   * when this object was built from a validated Python-path call (in mode "trust" there is no guard
+   * slot to look at, and a released slot number can be reused for another array). */
+  const volatile unsigned long long* gen;
+  unsigned long long gen_built;
   unsigned long long calls, misses;
 } FastPlan;
 
@@ -91,15 +98,19 @@ static int fill_shape(PyObject* seq, npy_intp* shape, int* ndim) {
   return 0;
 }
 
-/* FastPlan(n_inputs, staged, residents, outputs, replay_addr, guard_clean_addr, desc_addr, done_addr, status_addr, sync_mode)
+/* FastPlan(n_inputs, staged, residents, outputs, replay_addr, guard_clean_addr, desc_addr, done_addr, status_addr, sync_mode,
+ *          gen_addr, gen_value)
  *   staged    [(pos, dst_addr, dtype, shape)]
  *   residents [(pos, obj, slot)]
  *   outputs   [(src_addr | None, const | None, dtype, shape, scalar)] */
 static int FastPlan_init(FastPlan* self, PyObject* args, PyObject* kwds) {
   PyObject *staged, *res, *outs;
-  unsigned long long replay, gclean, desc, done, status;
+  unsigned long long replay, gclean, desc, done, status, gen, gen_value;
   int n_inputs, sync_mode;
-  if (!PyArg_ParseTuple(args, "iOOOKKKKKi", &n_inputs, &staged, &res, &outs, &replay, &gclean, &desc, &done, &status, &sync_mode)) return -1;
+  if (!PyArg_ParseTuple(args, "iOOOKKKKKiKK", &n_inputs, &staged, &res, &outs, &replay, &gclean, &desc, &done, &status, &sync_mode, &gen, &gen_value)) return -1;
+  if (!gen) { PyErr_SetString(PyExc_ValueError, "fastplan: the resident generation counter is required"); return -1; }
+  self->gen = (const volatile unsigned long long*)(uintptr_t)gen;
+  self->gen_built = gen_value;
   self->n_inputs = n_inputs;
   self->replay = (replay4_fn)(uintptr_t)replay;
   self->gclean = (guard_clean_fn)(uintptr_t)gclean;
@@ -169,6 +180,7 @@ static PyObject* FastPlan_call(FastPlan* self, PyObject* args, PyObject* kwds) {
   self->calls++;
   if (!PyTuple_CheckExact(inputs) || PyTuple_GET_SIZE(inputs) != self->n_inputs) goto miss;
   /* residents first: nothing may be touched before every check has passed */
+  if (self->n_res && *self->gen != self->gen_built) goto miss;
   for (int k = 0; k < self->n_res; k++) {
     const Resident* r = &self->res[k];
     if (PyTuple_GET_ITEM(inputs, r->pos) != r->obj) goto miss;

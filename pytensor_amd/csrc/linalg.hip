@@ -2062,7 +2062,8 @@ template <class T>
 int trsm_blocked(int lower, int unit, long long n, long long nrhs, const T* Tm, long long sT0, long long sT1, const T* B, T* out) {
   hipStream_t st = pthip::ctx().stream;
   const int dt = sizeof(T) == 8 ? PTHIP_F64 : PTHIP_F32;
-  static const int blk_env = getenv("PTHIP_TRSM_BLOCK") ? atoi(getenv("PTHIP_TRSM_BLOCK")) : 512;
+  // (clamped to 4*TB = 1024 rows: the step scratch Xt below is sized for steps of at most that many rows — ADVICE r4)
+  static const int blk_env = std::min(getenv("PTHIP_TRSM_BLOCK") ? atoi(getenv("PTHIP_TRSM_BLOCK")) : 512, 4 * (int)TB);
   // start from 64 x 64 tiles when the doubling below will carry them to 256 rows or more (PTHIP_TRSM_BASE=256: the
   // round-3 single-workgroup inverse of each 256-row block)
   static const int base_env = getenv("PTHIP_TRSM_BASE") ? atoi(getenv("PTHIP_TRSM_BASE")) : 64;

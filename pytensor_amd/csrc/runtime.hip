@@ -549,7 +549,11 @@ int pthip_plan_replay4(const pthip_replay_desc* d, void* host_out, volatile int*
       PTHIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
       PTHIP_CHECK(hipEventCreateWithFlags(&ev_a, hipEventDisableTiming));
     }
-    const bool a_free = (d->flags & 1) != 0;
+    // (only in poll mode: such a call returns after its closing segment finished, so segment A of the NEXT call
+    // cannot overtake it.  An asynchronous replay, or a waiting one issued behind asynchronous ones, keeps the
+    // event: without it A_{n+1} on stream 1 could overwrite arena buffers the closing segment of call n, still
+    // in flight on stream 0, is reading — ADVICE r4)
+    const bool a_free = (d->flags & 1) != 0 && sync == 2;
     if (!a_free) PTHIP_CHECK(hipEventRecord(ev_in, s0));
     if (int r = run_segment(d->gb, d->lb, s0)) return r;
     if (!a_free) PTHIP_CHECK(hipStreamWaitEvent(s1, ev_in, 0));

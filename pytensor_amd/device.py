@@ -139,6 +139,9 @@ class DeviceArray:
         return f"DeviceArray(shape={self.shape}, strides={self.strides}, dtype={self.dtype})"
 
 
+_TILED_COPY_MIN = 1 << 14  # elements
+
+
 def _i64arr(vals):
     return (C.c_int64 * max(len(vals), 1))(*[int(v) for v in vals])
 
@@ -155,6 +158,14 @@ def copy_into(dst: DeviceArray, src: DeviceArray):
             raise ValueError(f"could not broadcast input array from shape {src.shape} into shape {dst.shape}")
     if dst.size == 0:
         return
+    if dst.size >= _TILED_COPY_MIN and dst.is_contiguous() and not src.is_contiguous():
+        # a large strided / transposed source into a contiguous destination: the tiled N-d Elemwise loop with the
+        # identity as its scalar graph (pack loads along the source's contiguous axis, LDS transposes) instead
+        # of the element-per-thread kernel with a 64-bit division per dimension per element
+        from pytensor_amd.dispatch.elemwise import tiled_copy
+
+        if tiled_copy(dst, DeviceArray(src.buf, src.offset, sshape, sstr, src.dtype)):
+            return
     if nd > 6 and sum(1 for s_ in dst.shape if s_ != 1) > 6:
         # the strided-copy kernel walks at most 6 non-mergeable dims (a Tile over 7+ axes, reference
         # test tests/tensor/test_basic.py::TestTile): peel the leading axis on the host

@@ -668,6 +668,35 @@ def launch_axis_reduce(env, body, ins, shape, axes, specs, out_shape):
     return outs
 
 
+class _StreamEnv:
+    """what a launch needs of an ``Env`` when there is no graph around it (device.copy_into)"""
+
+    kernel_timer = None
+    placement = None
+
+    def __init__(self):
+        self.lib = ffi.lib()
+        self.keepalive = []
+
+    def timed(self, name, launch):
+        return launch()
+
+
+def tiled_copy(dst: DeviceArray, src: DeviceArray) -> bool:
+    """``dst[...] = src`` (same shape, ``dst`` contiguous, ``src`` any strides, 0 on broadcast dimensions) through
+    the tiled N-d loop.  False when the dtype or the shape is outside what it covers."""
+    dt = str(dst.dtype)
+    if dt not in codegen.CTYPE or not _TILE:
+        return False
+    shape = tuple(dst.shape)
+    cshape, cstr = _collapse(shape, [tuple(src.strides), _cstrides(shape)])
+    if len(cshape) > codegen.MAX_ND:
+        return False
+    body = _identity_body(dt)
+    _launch_tiled(body, [src], set(), cshape, cstr[:-1], [dst], [dt], [None], [None], _body_key(body), "x", _StreamEnv())
+    return True
+
+
 def _dtag(dt):
     d = np.dtype(dt)
     return f"{d.kind}{d.itemsize}"

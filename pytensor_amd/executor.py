@@ -374,6 +374,7 @@ class HipExecutable:
             self.auto_freeze = False
         self._handlers = dispatch.HANDLERS
         self._resident_cache = {}  # input position -> ResidentEntry
+        self._res_gen = C.c_uint64(0)  # bumped whenever a resident is re-uploaded, re-watched or invalidated (csrc/fastplan.c)
         # update feedback (compile/executor.py:712-716 stores output i into the storage cell of
         # input j after every call): {output index: resident input position}.  The new value is
         # copied device-to-device into the resident buffer at the end of the call, so the next
@@ -511,6 +512,7 @@ class HipExecutable:
             if ent is not None and ent.key == key and coherence.clean(ent.fp, a):
                 return ent.dev
         self.stats["resident_uploads"] += 1
+        self._res_gen.value += 1  # native FastPlans of this executable re-validate through the Python path (csrc/fastplan.c)
         # Watch FIRST, copy second: a store from another thread between the two is then either in the copy (it came
         # before the protection / the hash) or marks the value dirty (it faulted, or the next hash differs) — with the
         # copy first it could land after the snapshot and before the watch and never be seen.  pthip_h2d reads
@@ -536,6 +538,7 @@ class HipExecutable:
     def invalidate_resident(self, pos=None):
         """Forget what is known about the host side of resident inputs (all, or one position):
         the next call uploads them again (needed only in the opt-in `sampled` / `trust` modes)."""
+        self._res_gen.value += 1
         for p, ent in self._resident_cache.items():
             if pos is None or p == pos:
                 ent.key = None

@@ -570,6 +570,8 @@ class FrozenPlan:
         rc = self.lib.pthip_plan_replay4(self._desc_ref, ob.ptr if ob is not None else None, self._done_ptr, mode)
         if rc:
             ffi.check(rc)
+        if mode:
+            self._async_pending = False  # this replay waited for the stream: nothing of an earlier launch_async is in flight
 
     # ------------------------------------------------------------------
     def _build_fast(self):
@@ -594,6 +596,7 @@ class FrozenPlan:
             elif isinstance(tok, coherence._Guard) and tok.slot >= 0:
                 slot = tok.slot
             else:
+                self._fast_off = True  # (do not ask again on every call)
                 return None  # a content hash is checked by the Python path (overlapped with the replay)
             res.append((pos, ent.host, slot))
         staged = [(pos, self._in_block.ptr + self._in_block.offsets[k], self._in_block.views[k].dtype, tuple(self._in_block.views[k].shape))
@@ -610,7 +613,7 @@ class FrozenPlan:
         addr = lambda f: C.cast(f, C.c_void_p).value
         try:
             return _FASTPLAN.FastPlan(len(self._sig), staged, res, outs, addr(lib.pthip_plan_replay4), addr(lib.pthip_guard_clean), C.addressof(self._desc),
-                                      self._done_ptr or 0, ob.ptr + ob.offsets[-1], self._sync_mode)
+                                      self._done_ptr or 0, ob.ptr + ob.offsets[-1], self._sync_mode, C.addressof(exe._res_gen), exe._res_gen.value)
         except Exception:  # noqa: BLE001 (an exotic dtype or rank: the Python path serves the plan)
             self._fast_off = True
             return None

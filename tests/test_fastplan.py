@@ -21,6 +21,7 @@ class Rig:
         self.clean = {7: 1}
         self.replays = 0
         self.res_obj = np.arange(10.0)
+        self.gen = C.c_uint64(5)  # the executable's resident generation counter
 
         def replay(desc, host_out, done, sync):
             self.replays += 1
@@ -41,7 +42,7 @@ class Rig:
         outs = [(self.outblk.ctypes.data, None, np.dtype("float64"), (2, 2), 0),
                 (self.outblk.ctypes.data + 32, None, np.dtype("float64"), (), 1),
                 (None, np.array([5, 6], dtype=np.int64), np.dtype("int64"), (2,), 0)]
-        self.plan = fp.FastPlan(3, staged, res, outs, addr(self._replay), addr(self._gclean), 0, self.done.ctypes.data, self.status.ctypes.data, 2)
+        self.plan = fp.FastPlan(3, staged, res, outs, addr(self._replay), addr(self._gclean), 0, self.done.ctypes.data, self.status.ctypes.data, 2, C.addressof(self.gen), self.gen.value)
 
 
 def test_fast_call_returns_fresh_arrays_and_scalars():
@@ -101,3 +102,17 @@ def test_the_resident_object_is_kept_alive():
     del plan
     gc.collect()
     assert ref() is None
+
+
+def test_resident_generation_bump_hands_the_call_back():
+    """``invalidate_resident`` / a re-upload by another plan or an eager call bumps the executable's
+    generation counter; the native path must then decline (the Python path re-validates and re-uploads) even though
+    the object is the captured one and its guard slot reads clean."""
+    r = Rig()
+    x, s = np.array([1.0, 2.0, 3.0]), np.asarray(4.0)
+    assert r.plan((x, r.res_obj, s)) is not None and r.replays == 1
+    r.gen.value += 1
+    assert r.plan((x, r.res_obj, s)) is None and r.replays == 1  # declined BEFORE anything was launched
+    assert r.plan.stats()["misses"] == 1
+    r.gen.value -= 1
+    assert r.plan((x, r.res_obj, s)) is not None and r.replays == 2

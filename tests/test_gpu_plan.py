@@ -381,3 +381,53 @@ def test_large_results_are_handed_out_without_a_copy_and_stay_valid(hip):
     assert np.array_equal(keep, xv + 2.0)
     del keep
     gc.collect()
+
+
+@pytest.mark.parametrize("mode", ["trust", "guard"])
+def test_native_path_sees_invalidate_resident_and_foreign_uploads(hip, mode):
+    """ADVICE r4 (csrc/fastplan.c): the native call path of a plan vouches for a resident only while the executable's
+    resident generation is the one it was built at.  ``invalidate_resident()`` — the documented way to force a
+    re-upload in mode ``trust``, where no guard slot exists — and an upload into the shared device buffer by ANOTHER
+    plan of the same executable must both send the next call through the Python path, which uploads the new value."""
+    import np_graph
+    from pytensor_amd import coherence, configs
+    from pytensor_amd.executor import HipExecutable
+    from util import assert_parity
+
+    coherence.set_mode(mode)
+    try:
+        g, ins, cvm, py, meta = load_case("c4_hier_small")
+        names = meta["input_names"]
+        resident = [k for k, n in enumerate(names) if n in configs.C4_DATA]
+        ins = [np.array(a) if isinstance(a, np.ndarray) else a for a in ins]  # private, writable copies
+        exe = HipExecutable(g, resident=resident)
+        exe(*ins)
+        plan = exe.freeze(*ins)
+        for _ in range(3):
+            first = plan(*ins)
+        assert plan._fast is not None, "the native path was not built: this test would not exercise it"
+        ypos = names.index("y")
+        if mode == "trust":
+            ins[ypos][...] = ins[ypos] * 0.5 + 1.0  # in place: nothing watches the array in this mode
+            exe.invalidate_resident()
+        else:
+            ins[ypos][...] = ins[ypos] * 0.5 + 1.0  # the write-protected pages fault: the guard slot turns dirty
+        got = plan(*ins)
+        ref = np_graph.run_graph(g, ins)
+        for k, (a, b) in enumerate(zip(got, ref)):
+            assert_parity(a, b, 1e-12, f"after the in-place change ({mode}) out{k}")
+        assert not np.array_equal(got[0], first[0])
+        # a second plan of the same executable uploads a NEW array object into the shared device buffer ...
+        other = [a for a in ins]
+        other[ypos] = ins[ypos] + 2.0
+        plan2 = exe.freeze(*other)
+        plan2(*other)
+        # ... the first plan, called again with ITS array (unchanged since its last call), must notice
+        for _ in range(2):
+            got = plan(*ins)
+        for k, (a, b) in enumerate(zip(got, ref)):
+            assert_parity(a, b, 1e-12, f"after another plan's upload ({mode}) out{k}")
+        plan.close()
+        plan2.close()
+    finally:
+        coherence.set_mode(None)
