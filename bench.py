@@ -14,11 +14,11 @@ same way (``replicas.ensure_world``) and rank 0 prints the one JSON line.  Each 
 evaluates an independent chain (weak scaling, no data-path collective: "replicas only",
 SURVEY.md §8e) and ``value`` = total evals / max-over-ranks time.
 
-``value`` / ``ms_per_step`` time the executor-level loop (the compiled ``HipExecutable`` plan called
-directly — the object ``HipLinker.jit_compile`` returns).  ``value_via_function`` /
-``ms_per_step_via_function`` time the same K steps through the drop-in API itself:
-``pytensor.function(params, outs, mode="hip")`` -> ``Function.__call__`` with ``trust_input=True``
-(rank 0, N=1; needs the importable reference copy ``oracle/_ref``, which travels with the snapshot).
+``value`` / ``ms_per_step`` time the drop-in API: ``pytensor.function(params, outs, mode="hip")`` ->
+``Function.__call__`` with ``trust_input=True``, on every rank (needs the importable reference copy ``oracle/_ref``,
+which travels with the snapshot; without it the executor-level loop is timed and ``config.value_is`` says so).
+``value_executor_level`` / ``ms_per_step_executor_level`` time the same K steps on the compiled ``HipExecutable``
+plan called directly — the object ``HipLinker.jit_compile`` returns.
 
 The JSON line also carries
   roofline      the dominant kernel (gchain_*: one pass over X for X@beta and X.T@w): algorithmic
@@ -190,13 +190,13 @@ def cpu_baseline(graph, names, vals, inputs, out_hip, args):
     }
 
 
-def via_function(vals, out_hip, args):
-    """The same evaluation through the drop-in API: ``pytensor.function(params, outs, mode="hip")``
-    compiled by the reference's own ``FunctionMaker`` (from ``oracle/_ref``), called through
+def make_function(vals, out_hip):
+    """``pytensor.function(params, outs, mode="hip")`` — the drop-in API itself: the graph built with the reference's own
+    front end (``oracle/_ref``: an importable copy that travels with the snapshot), rewritten by the reference's
+    rewriter under the HIP mode, linked by ``HipLinker`` (pytensor_amd/linker.py), called through
     ``Function.__call__`` (compile/executor.py:651-744) and the JIT thunk (link/basic.py:670-684) with
-    ``trust_input=True`` — the leg the reference's C linker is timed on in ``cpu_baseline``.  Same
-    steps / warm-up as the executor-level timed region; every call returns host arrays, so the loop
-    needs no extra synchronisation.  ``None`` when the importable reference copy is absent."""
+    ``trust_input=True`` — the leg the reference's C linker is timed on in ``cpu_baseline``.  ``None`` when the
+    reference copy is absent (the executor-level loop is then the headline and the line says so)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import make_ref
 
@@ -218,16 +218,19 @@ def via_function(vals, out_hip, args):
     first = f(*pv)  # eager; the second call captures the plan, later ones replay it
     for a, b in zip(first, out_hip):
         np.testing.assert_array_equal(a, b)  # same IR, same kernels as the executor-level leg
-    for _ in range(max(args.warmup, 3)):
+    for _ in range(3):
         f(*pv)
-    exe = f.vm.jit_fn
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        f(*pv)
-    el = time.perf_counter() - t0
-    return {"value": args.steps / el, "ms_per_step": el / args.steps * 1e3, "compile_s": t_compile,
-            "replays": exe.stats["replays"], "eager_calls": exe.stats["eager_calls"], "resident_uploads": exe.stats["resident_uploads"],
-            "resident_mode": str(pytensor.config.hip__resident)}
+    return f, pv, t_compile, str(pytensor.config.hip__resident)
+
+
+def settle(call, seconds=0.15):
+    """untimed evaluations for `seconds` (clocks / caches / interpreter at steady state before a timed region that is
+    K = 20 steps = 4 ms in the driver's run); counted in ``warmup_effective``"""
+    n, t = 0, time.perf_counter()
+    while time.perf_counter() - t < seconds:
+        call()
+        n += 1
+    return n
 
 
 def configs_params():
@@ -243,7 +246,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows", dest="n", type=int, default=1_000_000, help="observations N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-via-function", action="store_true", help="skip the second timed leg through pytensor.function(mode='hip')")
+    ap.add_argument("--no-via-function", action="store_true", help="time the executor-level loop instead of pytensor.function(mode='hip')")
+    ap.add_argument("--no-settle", action="store_true", help="no untimed settle evaluations before --warmup (see warmup_effective)")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config measurements (configs #1, #2, #3, #5)")
     ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed PMC summary instead of two rocprofv3 --pmc passes inside this run")
     ap.add_argument("--eager", action="store_true", help="per-node dispatch instead of the frozen hipGraph plan")
@@ -281,25 +285,42 @@ def main():
         for a, b in zip(out, call(*inputs)):
             np.testing.assert_array_equal(a, b)
 
-    # clocks: the gate above is ~20 ms of GPU work on a box that was idle a second ago; 0.15 s more of untimed
-    # evaluations before the W warm-up steps (one of three runs of this tree started its timed region 4 % slower
-    # than the leg timed a second later, profiles/r4z_bench_lines.txt)
-    n_settle = 0
-    t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < 0.15:
-        call(*inputs)
-        n_settle += 1
+    # ---- the timed region: K evaluations through the drop-in API (pytensor.function(mode="hip")) ----
+    fn = None if args.no_via_function else make_function(vals, out)
+    if fn is not None:
+        f, pv, t_compile, resident_mode = fn
+        step = lambda: f(*pv)  # every call returns host arrays: nothing is in flight when it returns
+    else:
+        step = lambda: call(*inputs)
+    # (0.15 s of untimed evaluations unless --no-settle: one of three runs of the round-4 tree started its timed region
+    # 4 % slower than the leg timed a second later, profiles/r4z_bench_lines.txt)
+    n_settle = 0 if args.no_settle else settle(step)
     for _ in range(args.warmup):
-        call(*inputs)
+        step()
     ffi.check(lib.pthip_synchronize())
     replicas.barrier(dist)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        call(*inputs)
+        step()
     ffi.check(lib.pthip_synchronize())
     elapsed = time.perf_counter() - t0
     replicas.barrier(dist)
     elapsed = replicas.max_over_ranks(dist, elapsed)
+    fn_stats = None
+    if fn is not None:
+        exe_f = f.vm.jit_fn
+        fn_stats = {"compile_s": t_compile, "replays": exe_f.stats["replays"], "eager_calls": exe_f.stats["eager_calls"],
+                    "resident_uploads": exe_f.stats["resident_uploads"], "resident_mode": resident_mode}
+
+    # ---- secondary: the same K steps on the executor-level loop (the compiled plan called directly, no Function) ----
+    for _ in range(args.warmup):
+        call(*inputs)
+    ffi.check(lib.pthip_synchronize())
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        call(*inputs)
+    ffi.check(lib.pthip_synchronize())
+    elapsed_exec = time.perf_counter() - t0
 
     # ---- roofline of the dominant kernel: per-node HIP-event timing on the context stream ----
     # The dominant node is GemvChain: ONE generated kernel (gchain_*) that streams X once
@@ -347,10 +368,6 @@ def main():
                                   + (f"; live passes not used: {why}" if why else ""))
                 break
 
-    fn_leg = None
-    if info.world == 1 and not args.no_via_function:
-        fn_leg = via_function(vals, out, args)
-
     cpu = None
     if not args.no_cpu_baseline and info.world == 1:
         cpu = cpu_baseline(graph, names, vals, inputs, out, args)
@@ -371,13 +388,14 @@ def main():
         "warmup": args.warmup,
         # evaluations actually run before the timed region: 1 eager + 1 plan check + the 64-replay determinism gate
         # + --warmup (the gate is what brings clocks / caches / the interpreter to steady state before K = 20 steps)
-        "warmup_effective": args.warmup + 64 + n_settle + (2 if plan is not None else 1),
+        "warmup_effective": args.warmup + n_settle + (4 if fn is not None else 0),
+        "untimed_gate_evals_executor_level": 64 + (2 if plan is not None else 1),
         "ms_per_step": elapsed / args.steps * 1e3,
-        # `value` is the executor-level loop (HipExecutable / FrozenPlan called directly, what every rank of
-        # a multi-GPU run times); the next two are the same K steps through pytensor.function(mode="hip")
-        # -> Function.__call__ (trust_input=True) on rank 0 at N=1, null where oracle/_ref is absent
-        "value_via_function": fn_leg["value"] if fn_leg else None,
-        "ms_per_step_via_function": fn_leg["ms_per_step"] if fn_leg else None,
+        # `value` = K evaluations through pytensor.function(mode="hip") -> Function.__call__ (trust_input=True): the drop-in
+        # API (every rank times its own Function; when oracle/_ref is absent the executor-level loop is timed instead and
+        # config.value_is says so).  value_executor_level: the same K steps on the compiled plan called directly.
+        "value_executor_level": args.steps / elapsed_exec,
+        "ms_per_step_executor_level": elapsed_exec / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -386,8 +404,9 @@ def main():
         "config": {
             "workload": "BASELINE.json configs[3]: hierarchical-normal logp + grad, N=%d, K=128, G=128, Cholesky(128); one chain per GPU" % args.n,
             "mode": "eager" if args.eager else "hipGraph plan",
-            "value_is": "executor-level loop (HipExecutable plan called directly); value_via_function = the same steps through pytensor.function(mode='hip')",
-            "via_function": fn_leg,
+            "value_is": ("pytensor.function(params, outs, mode='hip') called K times (Function.__call__, trust_input=True); value_executor_level = the compiled plan called directly"
+                         if fn is not None else "executor-level loop (oracle/_ref absent or --no-via-function: no pytensor.function on this box)"),
+            "function": fn_stats,
             "parallelism": f"replicas x{info.world}",
         },
         "roofline": {

@@ -188,3 +188,14 @@ def elemwise_axis_reduce():
     outs = [pt.exp(A - m[:, None]).sum(axis=1), (A * A).sum(axis=0), (A * r[None, :]).max(axis=1), pt.log1p(abs(T)).sum(axis=(0, 2)),
             (T * T).sum(axis=1), pt.exp(T.transpose(2, 0, 1)).sum(axis=0)]
     return [A, m, r, T], outs, {"A": rng.normal(size=(41, 67)), "m": rng.normal(size=41), "r": rng.normal(size=67), "T": rng.normal(size=(7, 11, 13))}
+
+
+@case("wide_200")
+def wide_200():
+    # north_star's literal target graph at a small N (IR is shape-agnostic): config #4 + 48 likelihood terms
+    from pytensor_amd import configs
+    from ref_graphs import build_wide200
+
+    vals = configs.wide200_inputs(N=257, K=16, G=8)
+    ins, outs = build_wide200(vals)
+    return ins, outs, vals

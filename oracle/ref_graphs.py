@@ -38,3 +38,37 @@ def build_c4(vals):
     logp = logp_y + logp_z + logp_beta + logp_hyp
     params = [mu_g, log_tau, z, beta, log_sigma]
     return params, [logp, *pytensor.grad(logp, params)]
+
+
+def build_wide200(vals, T=None):
+    """north_star's literal target ("PyMC-style logp+grad graph, ~200 fused Elemwise + 1 Gemm + 1 Cholesky"): config #4's
+    model plus ``T`` independent likelihood terms of four families (normal, Student-t(3)-like, Laplace, logistic) over
+    their own data vectors — the shape of a PyMC model with many observed variables.  Data shared, parameters explicit.
+    Returns (params, outputs = [logp, d logp / d params])."""
+    import pytensor
+    import pytensor.tensor as pt
+
+    from pytensor_amd import configs
+
+    T = T or configs.WIDE_T
+    params, outs = build_c4(vals)
+    logp = outs[0]
+    wmu, wls = pt.dvector("wmu"), pt.dvector("wls")
+    terms = []
+    for k in range(T):
+        w = pytensor.shared(vals[f"w{k}"], name=f"w{k}")
+        r = (w - wmu[k]) * pt.exp(-wls[k])
+        fam = k % 4
+        if fam == 0:
+            terms.append((-0.5 * r**2 - wls[k]).sum())
+        elif fam == 1:
+            terms.append((-pt.log1p(r**2 / 3.0) * 2.0 - wls[k]).sum())
+        elif fam == 2:
+            terms.append((-pt.abs(r) - wls[k]).sum())
+        else:
+            terms.append((-r - 2.0 * pt.softplus(-r) - wls[k]).sum())
+    total = logp
+    for t in terms:  # (binary adds: the reference's Python Elemwise refuses more than 32 operands)
+        total = total + t
+    params = [*params, wmu, wls]
+    return params, [total, *pytensor.grad(total, params)]

@@ -64,6 +64,27 @@ def c4_inputs(N=1_000_000, K=C4_K, G=C4_G, seed=0, chain=0):
 C4_DATA = ("y", "X", "gidx", "Sigma")  # shared (resident) inputs
 C4_PARAMS = ("mu_g", "log_tau", "z", "beta", "log_sigma")
 
+WIDE_T = 48  # likelihood terms of the wide model
+
+
+def wide200_inputs(N=1_000_000, T=WIDE_T, K=C4_K, G=C4_G, seed=0, chain=0):
+    """north_star's literal target graph ("~200 fused Elemwise + 1 Gemm + 1 Cholesky, N=1e6"): the
+    hierarchical-normal model of config #4 (design matrix, Cholesky(K) prior) plus ``T`` independent likelihood
+    terms of four families over their own N-vectors ``w0 .. w{T-1}`` with location ``wmu[k]`` and log-scale
+    ``wls[k]``.  Data shared (device resident), parameters explicit."""
+    d = c4_inputs(N=N, K=K, G=G, seed=seed, chain=chain)
+    rng = np.random.default_rng(seed + 77)
+    for k in range(T):
+        d[f"w{k}"] = rng.normal(size=N) + 0.1 * (k % 7)
+    prng = np.random.default_rng(2000 + chain)
+    d["wmu"] = prng.normal(size=T) * 0.1
+    d["wls"] = prng.normal(size=T) * 0.1
+    return d
+
+
+def wide200_params():
+    return (*C4_PARAMS, "wmu", "wls")
+
 
 def c5_inputs(T=1000, B=64, H=1024, seed=5):
     rng = np.random.default_rng(seed)

@@ -396,10 +396,13 @@ def test_native_path_sees_invalidate_resident_and_foreign_uploads(hip, mode):
 
     coherence.set_mode(mode)
     try:
-        g, ins, cvm, py, meta = load_case("c4_hier_small")
+        g, ins, cvm, py, meta = load_case("c4_hier")
         names = meta["input_names"]
         resident = [k for k, n in enumerate(names) if n in configs.C4_DATA]
-        ins = [np.array(a) if isinstance(a, np.ndarray) else a for a in ins]  # private, writable copies
+        # every resident above 64 KiB: in mode "guard" smaller ones are watched by a content hash, which the Python
+        # path checks — such a plan never gets the native path
+        v = configs.c4_inputs(N=9001, K=96, G=8)
+        ins = [np.array(v[n]) for n in names]  # private, writable copies
         exe = HipExecutable(g, resident=resident)
         exe(*ins)
         plan = exe.freeze(*ins)

@@ -151,7 +151,99 @@ def _chol_entries():
     return out
 
 
-def measure(which=("c1", "c2", "c3", "c5", "chol", "gp"), reps=20, check=True):
+def _wide200_entry(reps, check):
+    """north_star's literal target graph (oracle/ref_graphs.build_wide200: config #4 + 48 likelihood terms = 202 Elemwise
+    + 2 Gemv + 1 Cholesky in the lowered IR) at N = 1e6 through ``pytensor.function(mode="hip")``; the reference C linker
+    on the same graph and inputs beside it (1 warm-up + 2 evals) gates the outputs."""
+    import make_ref
+
+    N, T = 1_000_000, configs.WIDE_T
+    vals = configs.wide200_inputs(N=N)
+    pnames = configs.wide200_params()
+    nbytes = N * configs.C4_K * 8 + 2 * N * 8 + T * N * 8  # X once, y + gidx, every term's vector once
+    entry = {"config": f"north_star target: hierarchical-normal (Gemv x2 fused, Cholesky({configs.C4_K})) + {T} likelihood terms, N=1e6 f64; 202 Elemwise in the lowered IR",
+             "algorithmic_MB": nbytes / 1e6, "unit": "GB/s", "peak": HBM_PEAK, "bound": "hbm"}
+    if make_ref.importable():
+        make_ref.activate()
+        import pytensor
+        from pytensor.compile.mode import Mode
+
+        import pytensor_amd
+        import ref_graphs
+
+        pytensor_amd.register()
+        params, outs = ref_graphs.build_wide200(vals)
+        f = pytensor.function(params, outs, mode="hip")
+        f.trust_input = True
+        pv = [np.asarray(vals[n]) for n in pnames]
+        out = f(*pv)
+        for _ in range(4):
+            f(*pv)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            f(*pv)
+        t = (time.perf_counter() - t0) / reps * 1e3
+        exe = f.vm.jit_fn
+        entry.update({"ms_call": t, "api": "pytensor.function(mode='hip'), trust_input=True", "replays": exe.stats["replays"], "nodes_after_passes": len(exe.graph.nodes),
+                      "launch_kinds": sorted({n.op for n in exe.graph.nodes if n.op in ("GemvChain", "MultiElemwise", "ElemwiseReduce", "Tail", "CholeskyTrsv", "Elemwise")})})
+        if check:
+            fc = pytensor.function(params, outs, mode=Mode(linker="cvm" if pytensor.config.cxx else "py", optimizer="fast_run"))
+            fc.trust_input = True
+            ref = fc(*pv)
+            ts = []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                ref = fc(*pv)
+                ts.append(time.perf_counter() - t0)
+            worst = 0.0
+            for k, (a, b) in enumerate(zip(out, ref)):
+                b = np.asarray(b)
+                # sums of N terms in another order: rtol 1e-12 + 8 eps N max|term| (|r| <= 8 over 5e7 normal draws scaled by
+                # exp(0.3): the normal family's d/d log-scale term r^2 - 1 stays below 64)
+                tol = 1e-12 * np.abs(b) + 8 * np.finfo("float64").eps * N * 64.0
+                worst = max(worst, float(np.max(np.abs(np.asarray(a) - b) / tol)))
+            assert worst <= 1.0, f"wide_200: |hip - reference C linker| / tol = {worst}"
+            entry.update({"reference_cvm_ms": float(np.median(ts)) * 1e3, "speedup_vs_reference_cvm": float(np.median(ts)) * 1e3 / t, "parity_err_over_tol": worst,
+                          "cores": os.cpu_count()})
+    else:
+        g, names = load("wide_200")
+        inputs = [vals[n] for n in names]
+        resident = [k for k, n in enumerate(names) if n not in pnames]
+        exe = HipExecutable(g, resident=resident)
+        exe(*inputs)
+        plan = exe.freeze(*inputs)
+        for _ in range(4):
+            plan(*inputs)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            plan(*inputs)
+        t = (time.perf_counter() - t0) / reps * 1e3
+        plan.close()
+        entry.update({"ms_call": t, "api": "executor-level plan (oracle/_ref absent on this box)"})
+    entry.update({"achieved": nbytes / entry["ms_call"] / 1e6, "frac": nbytes / entry["ms_call"] / 1e6 / HBM_PEAK})
+    return entry
+
+
+def _alu_roofline(entry, kernel_prefix="ew_"):
+    """A kernel that is VALU-issue bound, not HBM bound (config #2 transcendental: 10 tanh + 10 exp per element): its
+    roofline is the issue rate.  ``SQ_INSTS_VALU`` (wave-instructions per launch, profiles/r5_c2_pmc.json, collected with
+    tools/pmc_kernels.py) x 4 cycles (a wave64 fp64 instruction occupies its SIMD for 4 cycles: 16 lanes/clk) /
+    (1024 SIMDs x 2.4 GHz) = the time the chip needs just to issue the kernel's arithmetic."""
+    path = os.path.join(ROOT, "profiles", "r5_c2_pmc.json")
+    if not os.path.exists(path) or "kernel" not in entry:
+        return entry
+    pmc = json.load(open(path))
+    row = pmc.get(entry["kernel"]) or next((v for k, v in pmc.items() if k.split("_")[1:2] == entry["kernel"].split("_")[1:2]), None)
+    if not row or "SQ_INSTS_VALU" not in row:
+        return entry
+    valu = row["SQ_INSTS_VALU"]
+    t_issue_ms = valu * 4 / (1024 * 2.4e9) * 1e3
+    entry["alu_roofline"] = {"bound": "fp64 VALU issue", "SQ_INSTS_VALU_per_launch": valu, "valu_lane_instructions_per_element": valu * 64 / 1e7, "issue_bound_ms": t_issue_ms,
+                             "frac": t_issue_ms / entry["kernel_ms"], "source": "profiles/r5_c2_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU, tools/pmc_kernels.py)"}
+    return entry
+
+
+def measure(which=("c1", "c2", "c3", "c5", "chol", "gp", "hotpath", "wide200"), reps=20, check=True):
     """Device-event timed replays of BASELINE configs #1, #2, #3, #5 at their stated sizes
     (inputs resident in HBM).  Returns ``{key: {...}}``; imported by ``bench.py`` for the
     ``configs`` field of its JSON line."""
@@ -169,8 +261,8 @@ def measure(which=("c1", "c2", "c3", "c5", "chol", "gp"), reps=20, check=True):
                                ("c2_transc", "c2_transc", "C2 transcendental (10 tanh + 10 exp) Composite+Sum N=1e7 f64")):
             td, tw = run_case(nm, v, reps, check=check, oracle_vals=small)
             b = 160e6
-            res[key] = _with_kernel({"config": label, "ms_device": td, "ms_call": tw, "achieved": b / td / 1e6, "unit": "GB/s", "peak": HBM_PEAK,
-                        "frac": b / td / 1e6 / HBM_PEAK, "bound": "hbm" if key == "c2_cheap" else "alu (transcendentals), hbm fraction shown"}, nm, b, HBM_PEAK)
+            res[key] = _alu_roofline(_with_kernel({"config": label, "ms_device": td, "ms_call": tw, "achieved": b / td / 1e6, "unit": "GB/s", "peak": HBM_PEAK,
+                        "frac": b / td / 1e6 / HBM_PEAK, "bound": "hbm" if key == "c2_cheap" else "alu (transcendentals), hbm fraction shown"}, nm, b, HBM_PEAK))
     if "c3" in which:
         v = configs.c3_inputs()
         small = configs.c3_inputs(M=512, B=8, Bn=64)
@@ -209,6 +301,21 @@ def measure(which=("c1", "c2", "c3", "c5", "chol", "gp"), reps=20, check=True):
                           "ms_device": r.get("ms_device"), "ms_call": r.get("ms_plan_call"), "mode": "frozen plan" if "ms_plan_call" in r else "eager: " + r.get("freeze_error", "?"),
                           "bound": "latency chain of the Cholesky / solves (see chol_2048) + 3 products on the MFMA GEMM",
                           **({"err_over_eps_cond": max(r["err_over_eps_cond_scale"]), "cond_K": r["cond_K"]} if "cond_K" in r else {})}
+    if "hotpath" in which:
+        # the kernel families the BASELINE configs never time (tools/bench_hotpath.py): broadcasting / strided / transposed
+        # Elemwise, CAReduce 256^3 x 7 axes x 3 layouts (the reference's own benchmark), Softmax / logsumexp — each checked
+        # against NumPy at the size it is timed at
+        import bench_hotpath
+
+        for grp, gen in (("ew", bench_hotpath.ew_cases), ("careduce", bench_hotpath.careduce_cases), ("softmax", bench_hotpath.softmax_cases)):
+            for a, kw in gen(max(5, reps // 2)):
+                try:
+                    r = bench_hotpath.run(*a, **kw)
+                except (AssertionError, RuntimeError, NotImplementedError, ValueError) as e:
+                    r = {"key": a[0], "error": f"{type(e).__name__}: {e}"[:300]}
+                res["hot_" + r.pop("key")] = r
+    if "wide200" in which:
+        res["wide_200"] = _wide200_entry(max(5, reps // 2), True)
     from pytensor_amd.executor import KernelTimer
 
     if KernelTimer.overhead_ms is not None:
@@ -222,7 +329,7 @@ def main():
     reps = 20
     if "--reps" in sys.argv:
         reps = int(sys.argv[sys.argv.index("--reps") + 1])
-    which = [a for a in args if not a.isdigit()] or ["c1", "c2", "c3", "c5", "chol", "gp"]
+    which = [a for a in args if not a.isdigit()] or ["c1", "c2", "c3", "c5", "chol", "gp", "hotpath", "wide200"]
     ffi.init(0)
     # --no-check: skip the oracle comparison (it runs the graphs at a reduced size as well, which
     # would mix small launches into a rocprofv3 kernel summary of this command)

@@ -3,7 +3,8 @@ counter group per pass — the guide's rule; never combined with trace domains) 
 markdown table with one row per kernel and one column per counter (mean per dispatch; counters
 that are per-XCD / per-SE instances are summed over instances).
 
-usage: python tools/pmc_kernels.py <out.md> <kernel-name-substring[,substring...]> -- <command ...>
+usage: [PMC_GROUPS=2,8,9] python tools/pmc_kernels.py <out.md> <kernel-name-substring[,substring...]> -- <command ...>
+(also writes <out>.json)
 """
 import glob
 import os
@@ -57,7 +58,9 @@ def main():
     cmd = [os.path.abspath(a) if os.path.exists(a) and not os.path.isabs(a) else a for a in sys.argv[sys.argv.index("--") + 1:]]
     out = os.path.abspath(out)
     table, calls, notes = {}, {}, []
-    for g in GROUPS:
+    sel = os.environ.get("PMC_GROUPS")  # e.g. "2,8,9": only these counter groups (one rocprofv3 pass each)
+    groups = [GROUPS[int(i)] for i in sel.split(",")] if sel else GROUPS
+    for g in groups:
         rows, err = one_pass(g, cmd)
         if rows is None:
             notes.append(f"pass {' '.join(g)}: {err}")
@@ -78,6 +81,10 @@ def main():
             fh.write("\n")
         for n in notes:
             fh.write(f"- {n}\n")
+    import json
+
+    with open(os.path.splitext(out)[0] + ".json", "w") as fh:  # the same numbers for tools that read them (bench_configs._alu_roofline)
+        json.dump({name: {**vals, "dispatches": calls[name]} for name, vals in table.items()}, fh, indent=1)
     print(open(out).read())
 
 
