@@ -1166,8 +1166,8 @@ def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=
 
 def multi_flat_source(name: str, terms) -> str:
     """Several independent flat kernels in ONE launch (widefuse.fuse_independent_reductions):
-    ``blockIdx.y`` selects the term, ``blockIdx.x`` / ``gridDim.x`` are the workgroup index / count
-    within it.  ``terms``: ``[{body, modes, vec, rs, unroll}]``; terms with the same (body, modes,
+    ``(blockIdx.x + blockIdx.y) % gridDim.x`` selects the term, ``blockIdx.y`` / the term's ``groups`` are the
+    workgroup index / count within it.  ``terms``: ``[{body, modes, vec, rs, unroll}]``; terms with the same (body, modes,
     vec, reductions) share one device function.  Arguments: the terms' flat-kernel arguments, one
     term after the other."""
     bodies = [t["body"] for t in terms]
@@ -1187,10 +1187,19 @@ def multi_flat_source(name: str, terms) -> str:
             decl, nm = prm.rsplit(" ", 1)
             P.append(f"{decl} t{ti}_{nm}")
             names.append(f"t{ti}_{nm}")
-        calls.append(f"    case {ti}: {fn_of[ti]}({', '.join(names)}, blockIdx.x, gridDim.x); break;")
+        gt = t.get("groups")  # this term's workgroup count (cost-proportional, dispatch/wide.py); default: the whole grid column
+        if gt:
+            calls.append(f"    case {ti}: if (blockIdx.y < {int(gt)}) {fn_of[ti]}({', '.join(names)}, blockIdx.y, {int(gt)}u); break;")
+        else:
+            calls.append(f"    case {ti}: {fn_of[ti]}({', '.join(names)}, blockIdx.y, gridDim.y); break;")
     L = head + [f for _, f in fns.values()]
     L.append(f'extern "C" __global__ __launch_bounds__({BLOCK}) void {name}({", ".join(P)}) {{')
-    L.append("  switch (blockIdx.y) {")
+    # grid (terms, workgroups per term), the term rotated by the round: consecutive workgroup ids — which the
+    # dispatcher deals out round-robin over XCDs and CUs — belong to different terms AND the ids a CU's slots receive
+    # (c, c + 256, ...) to different families.  With the term on blockIdx.y and four families cycling through the terms
+    # every CU's eight slots held the SAME family: the CUs of the expensive one ran 3x longer than the rest idled
+    # (north_star's 48-term graph: mean occupancy 7 of 32 waves per CU, profiles/r5h_wide_multi_pmc.md).
+    L.append("  switch ((blockIdx.x + blockIdx.y) % gridDim.x) {")
     L += calls
     L.append("    default: break;")
     L.append("  }")
@@ -1425,7 +1434,7 @@ def nd_kernel_source(name: str, body: dict, ndim: int, reduce_spec=None, partial
 
 
 def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, has_y1,
-                      out_store=None, scatter_out=None, scatter_groups=2) -> str:
+                      out_store=None, scatter_out=None, scatter_groups=2, pack=2) -> str:
     """One-pass ``r = b1*y1 + a1*A@x ; outs = body(.., r, ..) ; partial += A.T@w`` (fp64).
 
     Work decomposition (wave64): a wave owns groups of ``RG`` consecutive rows.  Lane l
@@ -1447,6 +1456,12 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
        visited in order, per-workgroup partials are combined in a fixed order afterwards
        (deterministic, like every other reduction here).
 
+    ``pack`` = 2: lane l holds columns {2l, 2l+1} of every 128-column chunk (one 16-byte load; rows must start on
+    16-byte boundaries: even ``lda``, even K).  ``pack`` = 1: columns {l, l+64} (two 8-byte loads, each a coalesced
+    512-byte row piece): any K, any ``lda`` — the odd-K instance.  ``C`` > 8 chunks (K > 1024): the multiplier vector
+    ``x`` lives in LDS instead of registers, and fewer rows ride per group (``RG`` = 2: K <= 2048, 1: K <= 4096) so that
+    the row registers (``RG*C`` <= 32 packs) and the ``A.T@w`` accumulators (``C`` packs) still fit.
+
     ``e_modes[k]`` ∈ {'R' the Gemv result, 'V' N-vector, 'S' scalar, 'G' gather
     ``table[gidx[row]]``} per elementwise input.
     Kernel params (all 8 bytes): N, K, A, lda, x, y1, alpha1, beta1, <per elementwise input
@@ -1458,7 +1473,16 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
     nout = len(body["out_dtypes"])
     out_store = list(out_store) if out_store is not None else [True] * nout
     lg = int(math.log2(RG))
-    assert 1 << lg == RG and 2 <= RG <= 32
+    assert 1 << lg == RG and 1 <= RG <= 32 and RG * C <= 32 and pack in (1, 2)
+    b_lds = C > 8
+    col0 = "c * 128 + 2 * lane" if pack == 2 else "c * 128 + lane"  # first column of lane's pack in chunk c
+    col1 = "c * 128 + 2 * lane + 1" if pack == 2 else "c * 128 + 64 + lane"
+
+    def ld_pack(base):  # the lane's two columns of chunk c from `base` (a double pointer)
+        if pack == 2:
+            return f"(({col0}) < K) ? " + _stream_load(f"(const pt_d2*)({base} + {col0})") + " : (pt_d2){0.0, 0.0}"
+        return f"(pt_d2){{(({col0}) < K) ? {base}[{col0}] : 0.0, (({col1}) < K) ? {base}[{col1}] : 0.0}}"
+
     rest = 6 - lg  # plain butterfly steps after the transposing ones
     params = [
         "long long N", "long long K", "const double* __restrict__ A", "long long lda",
@@ -1490,11 +1514,23 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
     L.append(f'extern "C" __global__ __launch_bounds__({BLOCK}) void {name}({", ".join(params)}) {{')
     L.append(f"  constexpr int C = {C}, RG = {RG};")
     L.append("  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;")
-    L.append("  pt_d2 b[C], accT[C];")
-    L.append("#pragma unroll\n  for (int c = 0; c < C; c++) {")
-    L.append("    const long long col = c * 128 + 2 * lane;")
-    L.append("    b[c] = (col < K) ? *(const pt_d2*)(x + col) : (pt_d2){0.0, 0.0};")
-    L.append("    accT[c] = (pt_d2){0.0, 0.0};\n  }")
+    L.append("  pt_d2 accT[C];")
+    red_w = f"(128 * C > {64 * int(scatter_groups)} ? 128 * C : {64 * int(scatter_groups)})" if scatter_out is not None else "128 * C"
+    L.append(f"  __shared__ double redT[{BLOCK // 64}][{red_w}];")
+    if b_lds:
+        # the multiplier vector: read per use (registers hold the rows and the accumulators); it lives in the memory the
+        # block combine uses after the row loop
+        L.append("  pt_d2 (*b)[64] = reinterpret_cast<pt_d2 (*)[64]>(&redT[0][0]);")
+        L.append(f"  for (int j = threadIdx.x; j < C * 64; j += {BLOCK}) {{ const int c = j >> 6, lane = j & 63; b[c][lane] = " + ld_pack("x").replace(_stream_load("(const pt_d2*)(x + " + col0 + ")"), "*(const pt_d2*)(x + " + col0 + ")") + "; }")
+        L.append("  __syncthreads();")
+        L.append("#pragma unroll\n  for (int c = 0; c < C; c++) accT[c] = (pt_d2){0.0, 0.0};")
+        bref = "b[c][lane]"
+    else:
+        L.append("  pt_d2 b[C];")
+        L.append("#pragma unroll\n  for (int c = 0; c < C; c++) {")
+        L.append("    b[c] = " + ld_pack("x").replace(_stream_load("(const pt_d2*)(x + " + col0 + ")"), "*(const pt_d2*)(x + " + col0 + ")") + ";")
+        L.append("    accT[c] = (pt_d2){0.0, 0.0};\n  }")
+        bref = "b[c]"
     if scatter_out is not None:
         SG = int(scatter_groups)
         assert 1 <= SG <= 4
@@ -1514,13 +1550,13 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
     L.append("    pt_d2 xr[RG][C];")
     L.append("#pragma unroll\n    for (int r = 0; r < RG; r++) {")
     L.append("      const long long row = (row0 + r < N) ? row0 + r : N - 1;")
+    L.append("      const double* __restrict__ Ar = A + row * lda;")
     L.append("#pragma unroll\n      for (int c = 0; c < C; c++) {")
-    L.append("        const long long col = c * 128 + 2 * lane;")
-    L.append("        xr[r][c] = (col < K) ? " + _stream_load("(const pt_d2*)(A + row * lda + col)") + " : (pt_d2){0.0, 0.0};\n      }\n    }")
+    L.append("        xr[r][c] = " + ld_pack("Ar") + ";\n      }\n    }")
     L.append("    double p[RG];")
     L.append("#pragma unroll\n    for (int r = 0; r < RG; r++) {")
     L.append("      double s = 0.0;")
-    L.append("#pragma unroll\n      for (int c = 0; c < C; c++) s += xr[r][c].x * b[c].x + xr[r][c].y * b[c].y;")
+    L.append(f"#pragma unroll\n      for (int c = 0; c < C; c++) {{ const pt_d2 bc = {bref}; s += xr[r][c].x * bc.x + xr[r][c].y * bc.y; }}")
     L.append("      p[r] = s;\n    }")
     half = RG // 2
     mask = 32
@@ -1586,9 +1622,9 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
     L.append("    }")
     L.append("  }")
     # block combine of accT (fixed wave order), of the scatter bins and of the reductions
-    red_w = f"(128 * C > {64 * int(scatter_groups)} ? 128 * C : {64 * int(scatter_groups)})" if scatter_out is not None else "128 * C"
-    L.append(f"  __shared__ double redT[{BLOCK // 64}][{red_w}];")
-    L.append("#pragma unroll\n  for (int c = 0; c < C; c++) { redT[wid][c * 128 + 2 * lane] = accT[c].x; redT[wid][c * 128 + 2 * lane + 1] = accT[c].y; }")
+    if b_lds:
+        L.append("  __syncthreads();  // every wave is done reading the multiplier vector out of this memory")
+    L.append(f"#pragma unroll\n  for (int c = 0; c < C; c++) {{ redT[wid][{col0}] = accT[c].x; redT[wid][{col1}] = accT[c].y; }}")
     L.append("  __syncthreads();")
     L.append(f"  for (int j = threadIdx.x; j < 128 * C; j += {BLOCK}) {{")
     L.append("    double v = redT[0][j];")

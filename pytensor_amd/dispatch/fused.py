@@ -30,6 +30,7 @@ CHAIN_RG = int(os.environ.get("PTHIP_CHAIN_RG", 0))  # 0 = auto
 # a persistent grid that leaves CUs free for the overlapped latency chain does not pay.
 CHAIN_GRID = int(os.environ.get("PTHIP_CHAIN_GRID", 2048))
 MAX_SCATTER_BINS = 256  # 64 bins per accumulator register of a lane, up to four (codegen.gemv_chain_source)
+MAX_CHAIN_K = 4096  # columns the one-pass kernel holds in registers (32 chunks of 128: one row per group)
 
 
 def _unpack(node, inputs, env):
@@ -67,11 +68,13 @@ class _Bins:
 
 
 def _fast_ok(A, x1, y1, e_vals, sidx, base, N, K):
-    if str(A.dtype) != "float64" or A.ndim != 2 or A.strides[1] != 1 or A.strides[0] % 2 or A.ptr % 16:
+    if os.environ.get("PTHIP_GCHAIN_FAST", "1") == "0":  # (measurements: the unfused launches beside the one-pass kernel)
         return False
-    if K % 2 or K > 1024 or N == 0:
+    if str(A.dtype) != "float64" or A.ndim != 2 or A.strides[1] != 1 or A.ptr % 8:
         return False
-    if not x1.is_contiguous() or x1.ptr % 16 or str(x1.dtype) != "float64":
+    if K > MAX_CHAIN_K or K == 0 or N == 0:
+        return False
+    if not x1.is_contiguous() or x1.ptr % 8 or str(x1.dtype) != "float64":
         return False
     if y1 is not None and (not y1.is_contiguous() or y1.shape != (N,)):
         return False
@@ -87,7 +90,9 @@ def _fast_ok(A, x1, y1, e_vals, sidx, base, N, K):
         elif v.size != 1 and (v.shape != (N,) or not v.is_contiguous()):
             return False
     if sidx is not None:
-        if sidx.shape != (N,) or not sidx.is_contiguous() or base.ndim != 1 or not (0 < base.shape[0] <= MAX_SCATTER_BINS):
+        # (more than MAX_SCATTER_BINS bins: still ONE pass over the matrix — the kernel stores the scattered output and
+        #  the deterministic scatter kernel of csrc/index.hip adds it up afterwards, gemv_chain below)
+        if sidx.shape != (N,) or not sidx.is_contiguous() or base.ndim != 1 or base.shape[0] <= 0:
             return False
     return True
 
@@ -109,10 +114,23 @@ def gemv_chain(node, inputs, env):
         raise ValueError(f"Shape mismatch: A.shape[1] != x.shape[0] ({A.shape}, {x1.shape})")
     if not _fast_ok(A, x1, y1d, e_vals, sidx, base, N, K):
         return _fallback(node, env, alpha1, A, x1, beta1, y1d, e_vals, sidx, base)
+    # the scatter-add rides in the kernel's registers up to MAX_SCATTER_BINS bins; beyond that the kernel stores the
+    # scattered output (N x 8 bytes next to the N x K x 8 of the matrix) and a second, small launch bins it
+    late_scatter = scatter_out is not None and base.shape[0] > MAX_SCATTER_BINS
+    if late_scatter:
+        out_store = list(out_store)
+        scatter_pos, scatter_out = scatter_out, None
+        late_forced = not out_store[scatter_pos] and spec[scatter_pos] is None
+        out_store[scatter_pos] = True
+        if spec[scatter_pos] is not None:
+            return _fallback(node, env, alpha1, A, x1, beta1, y1d, e_vals, sidx, base)  # (a reduced AND scattered output: not a shape the passes produce)
     C = (K + 127) // 128
-    RG = CHAIN_RG or max(4, 32 // C)
-    while RG * C > 32 and RG > 4:
+    RG = CHAIN_RG or 32
+    while RG * C > 32 and RG > 1:  # rows per group: the row registers hold RG*C <= 32 packs (K <= 1024: >= 4 rows; 2048: 2; 4096: 1)
         RG //= 2
+    # 16-byte packs need every row to start on a 16-byte boundary; otherwise two 8-byte loads per chunk (odd K, odd lda)
+    # (K <= 64: with packs only lanes 0 .. K/2-1 of the one chunk would load; a column per lane keeps all 64 busy)
+    pack = 2 if (K % 2 == 0 and K > 64 and A.strides[0] % 2 == 0 and A.ptr % 16 == 0 and x1.ptr % 16 == 0) else 1
     e_modes = []
     for pos, v in enumerate(e_vals):
         if v is None:
@@ -126,13 +144,13 @@ def gemv_chain(node, inputs, env):
     skey = "".join("1" if s else "0" for s in out_store)
     name = (
         f"gchain_{_body_key(body)}_{''.join(e_modes)}_{rkey}_w{w_out}_c{C}_g{RG}_{int(store_r)}{int(y1d is not None)}"
-        f"_s{skey}_{'n' if scatter_out is None else scatter_out}"
+        f"_s{skey}_{'n' if scatter_out is None else scatter_out}" + ("" if pack == 2 else "_p1")
     ).replace("-", "x")
     sgroups = 2
     if scatter_out is not None:
         sgroups = max(1, (base.shape[0] + 63) // 64)
         name += f"_b{sgroups}"
-    src = codegen.gemv_chain_source(name, body, e_modes, rs, w_out, C, RG, store_r, y1d is not None, out_store, scatter_out, sgroups)
+    src = codegen.gemv_chain_source(name, body, e_modes, rs, w_out, C, RG, store_r, y1d is not None, out_store, scatter_out, sgroups, pack)
     fn = kernel_cache.get_function(src, name)
     ngroups = (N + RG - 1) // RG
     grid = max(1, min((ngroups + 3) // 4, CHAIN_GRID))
@@ -177,6 +195,10 @@ def gemv_chain(node, inputs, env):
     res.append(partT)
     if scatter_out is not None:
         res.append(partS)
+    elif late_scatter:
+        res.append(_scatter_rows(env, stored[scatter_pos], sidx, base.shape[0]))
+        if late_forced:
+            res[(1 if store_r else 0) + scatter_pos] = None  # (nothing outside the node reads it: stored only for the scatter)
     return res
 
 
@@ -225,21 +247,26 @@ def _fallback(node, env, alpha1, A, x1, beta1, y1d, e_vals, sidx, base):
     t = gemv_device(env, 1.0, At, w, 0.0, None)
     res.append(t.view((1, K), (K, 1)))
     if scatter_out is not None:
-        bins = base.shape[0]
-        acc = DeviceArray.empty((bins,), "float64")
-        ffi.check(env.lib.pthip_memset(acc.ptr, 0, acc.nbytes))
-        n_idx = sidx.shape[0]
-        if n_idx and bins:
-            lib = env.lib
-            ws_bytes = lib.pthip_scatter_rows_workspace(n_idx, bins, 1)
-            ws = DeviceArray.empty((ws_bytes,), "uint8") if ws_bytes else None
-            sv = outs[scatter_out].contiguous()
-            ffi.check(
-                lib.pthip_scatter_rows(ffi.np_dtype_code("float64"), 1, n_idx, 1, acc.ptr, bins, sidx.contiguous().ptr, sv.ptr, 1,
-                                       ws.ptr if ws is not None else None, ws_bytes)
-            )
-        res.append(acc.view((1, bins), (bins, 1)))
+        res.append(_scatter_rows(env, outs[scatter_out], sidx, base.shape[0]))
     return res
+
+
+def _scatter_rows(env, values, sidx, bins):
+    """``zeros(bins)[sidx] += values`` (AdvancedIncSubtensor, subtensor.py:2275) as a (1, bins) partial slab: the
+    deterministic scatter kernel of csrc/index.hip."""
+    acc = DeviceArray.empty((bins,), "float64")
+    ffi.check(env.lib.pthip_memset(acc.ptr, 0, acc.nbytes))
+    n_idx = sidx.shape[0]
+    if n_idx and bins:
+        lib = env.lib
+        ws_bytes = lib.pthip_scatter_rows_workspace(n_idx, bins, 1)
+        ws = DeviceArray.empty((ws_bytes,), "uint8") if ws_bytes else None
+        sv = values.contiguous()
+        ffi.check(
+            lib.pthip_scatter_rows(ffi.np_dtype_code("float64"), 1, n_idx, 1, acc.ptr, bins, sidx.contiguous().ptr, sv.ptr, 1,
+                                   ws.ptr if ws is not None else None, ws_bytes)
+        )
+    return acc.view((1, bins), (bins, 1))
 
 
 @handler("GemvFinish")

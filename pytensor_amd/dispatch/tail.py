@@ -399,10 +399,46 @@ def _run_members(node, inputs, env):
     return [vals[o] for o in node.outputs]
 
 
+def _run_split(node, inputs, env):
+    """A chain too long for ONE launch (the 4 KB kernel-argument block, the LDS budget: a model with dozens of
+    likelihood terms hands the tail hundreds of scalars) as two chains, recursively: members [0, h) and [h, n), the
+    values crossing the cut become outputs of the first and inputs of the second.  Only the LAST launch carries the
+    plan's status / completion word; none of them joins the other stream on the device (the plan keeps its event)."""
+    from pytensor_amd.ir import Node
+
+    members = node.params["nodes"]
+    h = len(members) // 2
+    first, second = members[:h], members[h:]
+    made1 = {o for m in first for o in m.outputs}
+    need2 = {i for m in second for i in m.inputs}
+    outs1 = [v for v in dict.fromkeys(o for m in first for o in m.outputs) if v in need2 or v in node.outputs]
+    need1 = {i for m in first for i in m.inputs}
+    vals = dict(zip(node.inputs, inputs))
+    ins1 = [v for v in node.inputs if v in need1]
+    status, join = getattr(env, "tail_status", None), getattr(env, "tail_join", 0)
+    env.tail_status, env.tail_join = None, 0
+    try:
+        r1 = tail(Node("Tail", {"nodes": first}, ins1, outs1), [vals[v] for v in ins1], env)
+    finally:
+        env.tail_status = status
+    vals.update(zip(outs1, r1))
+    made2 = {o for m in second for o in m.outputs}
+    ins2 = [v for v in dict.fromkeys([*node.inputs, *outs1]) if v in need2]
+    outs2 = [v for v in dict.fromkeys(node.outputs) if v in made2]
+    try:
+        r2 = tail(Node("Tail", {"nodes": second}, ins2, outs2), [vals[v] for v in ins2], env)
+    finally:
+        env.tail_join = join
+    vals.update(zip(outs2, r2))
+    return [vals[o] for o in node.outputs]
+
+
 @handler("Tail")
 def tail(node, inputs, env):
     try:
         P, results = _plan(node, inputs, env)
         return _run_fused(node, P, results, env, inputs)
-    except _Infeasible:
+    except _Infeasible as e:
+        if str(e) in ("kernel argument block", "LDS") and len(node.params["nodes"]) >= 8:
+            return _run_split(node, inputs, env)
         return _run_members(node, inputs, env)

@@ -2,8 +2,8 @@
 
 ``MultiElemwise``: the member ``ElemwiseReduce`` nodes (reference: ``Elemwise`` +
 ``CAReduce``, pytensor/tensor/elemwise.py:375, 1233) in ONE launch when every member is a flat,
-contiguous, fully reduced loop — ``blockIdx.y`` picks the term (codegen.multi_flat_source); each term
-gets the same number of workgroups, few enough that the per-output partials (handed to the ``Tail``
+contiguous, fully reduced loop — grid (terms, workgroups per term) (codegen.multi_flat_source); each term
+gets workgroups in proportion to its work, few enough that the per-output partials (handed to the ``Tail``
 kernel unfinished) are at most 64 values.  Anything else runs the members one by one through their
 own handler.  ``ScatterScalars`` outside a ``Tail`` is its member ``IncSubtensor`` chain.
 """
@@ -22,6 +22,16 @@ from pytensor_amd.executor import HostValue
 
 MAX_ARG_BYTES = 3900
 TOTAL_GROUPS = 2048  # workgroups of one launch, shared among the terms
+
+
+# rough VALU instructions per element of a scalar op on gfx950 (fp64): what the split of a launch among its terms is
+# weighted by (an estimate only has to rank the families; measured: exp 24, the device library's log1p ~40, tanh ~85)
+_OP_COST = {"Exp": 24, "Log": 35, "Log1p": 40, "Log2": 35, "Log10": 35, "Expm1": 40, "Sigmoid": 40, "Softplus": 80, "Tanh": 85, "Pow": 100, "TrueDiv": 12,
+            "Sqrt": 12, "Erf": 60, "Erfc": 80, "GammaLn": 150, "Psi": 150, "Sin": 60, "Cos": 60, "Log1mexp": 70, "ScalarLoop": 400}
+
+
+def _term_cost(body) -> float:
+    return 8.0 + sum(_OP_COST.get(op, 1.5) for op in codegen.body_ops(body))
 
 
 def _run_members(node, inputs, env):
@@ -85,30 +95,41 @@ def multi_elemwise(node, inputs, env):
     nt = len(per_term)
     # the same workgroup count for every term (gridDim.x), bounded so that a term's partials fit
     # one pass of the tail kernel; at least enough to give each term a few waves per XCD
-    units = max((n // vec + EW_UNROLL - 1) // EW_UNROLL if vec > 1 else n for _, _, _, n, vec in per_term)
-    gx = max(1, min((units + BLOCK - 1) // BLOCK, max(8, TOTAL_GROUPS // nt), 64))
+    # Workgroups per term in proportion to its work (elements x estimated instructions per element): with the same
+    # count for every term the launch lasts as long as its most expensive family — north_star's 48-term graph: 221 us
+    # at a mean occupancy of 7 waves per CU, the logistic terms (exp + log1p per element) still running when the
+    # normal ones were long done (profiles/r5h_wide_multi_pmc.md).  At most 64 per term (the partials a Tail kernel
+    # folds in one pass), at least 4.
+    work = [n * _term_cost(t["scalar"]) for t, _, _, n, _ in per_term]
+    tot = float(sum(work)) or 1.0
+    groups = []
+    for (t, ins, modes, n, vec), w in zip(per_term, work):
+        units = (n // vec + EW_UNROLL - 1) // EW_UNROLL if vec > 1 else n
+        cap = max(1, (units + BLOCK - 1) // BLOCK)
+        groups.append(max(1, min(cap, 64, max(4, int(round(TOTAL_GROUPS * w / tot))))))
+    gx = max(groups)
     specs, args, out_pos, results, o0 = [], [], 0, [], 0
     gen_terms = []
-    for t, ins, modes, n, vec in per_term:
+    for (t, ins, modes, n, vec), gt in zip(per_term, groups):
         body, spec = t["scalar"], t["reduce"]
         rs = [(r["op"], r["acc_dtype"]) for r in spec]
-        gen_terms.append({"body": body, "modes": modes, "vec": vec, "rs": rs, "unroll": EW_UNROLL})
-        parts = alloc_partials(spec, gx)
+        gen_terms.append({"body": body, "modes": modes, "vec": vec, "rs": rs, "unroll": EW_UNROLL, "groups": gt})
+        parts = alloc_partials(spec, gt)
         args.append(n)
         for k, (a, m) in enumerate(zip(ins, modes)):
             args.append(_scalar_bits(a, body["in_dtypes"][k]) if m == "C" else a.ptr)
         args += [p.ptr for p in parts]
-        specs.append((spec, parts))
+        specs.append((spec, parts, gt))
     buf = struct.pack(f"<{len(args)}q", *args)
     if len(buf) > MAX_ARG_BYTES:
         return _run_members(node, inputs, env)
-    key = codegen.source_key(repr([(_body_key(g["body"]), g["modes"], g["vec"], g["rs"]) for g in gen_terms]))
+    key = codegen.source_key(repr([(_body_key(g["body"]), g["modes"], g["vec"], g["rs"], g["groups"]) for g in gen_terms]))
     name = f"multi_{key[:16]}_t{nt}"
     src = codegen.multi_flat_source(name, gen_terms)
     fn = kernel_cache.get_function(src, name)
-    env.timed(name, lambda: ffi.check(env.lib.pthip_launch(fn, gx, nt, 1, BLOCK, 1, 1, 0, buf, len(buf))))
-    for spec, parts in specs:
+    env.timed(name, lambda: ffi.check(env.lib.pthip_launch(fn, nt, gx, 1, BLOCK, 1, 1, 0, buf, len(buf))))
+    for spec, parts, gt in specs:
         d = {k - o0 for k in defer if o0 <= k < o0 + len(spec)}
-        results += finish_partials(env, spec, parts, gx, d)
+        results += finish_partials(env, spec, parts, gt, d)
         o0 += len(spec)
     return results

@@ -259,7 +259,7 @@ def test_multi_flat_source_shares_bodies_and_compiles():
     mk = lambda b, m: {"body": b, "modes": m, "vec": 2, "rs": [("Add", dt)], "unroll": 2}
     src = codegen.multi_flat_source("multi_probe", [mk(b1, "SV"), mk(b2, "CV"), mk(b1, "SV"), mk(b1, "CV")])
     assert src.count("static __device__ __forceinline__ void mt_") == 3  # (b1,SV) shared by two terms
-    assert "switch (blockIdx.y)" in src and src.count("case ") == 4
+    assert "switch ((blockIdx.x + blockIdx.y) % gridDim.x)" in src and src.count("case ") == 4
     assert len(ffi.jit_compile(src, "multi_probe.hip")) > 1000
 
 
