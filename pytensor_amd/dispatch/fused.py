@@ -129,8 +129,9 @@ def gemv_chain(node, inputs, env):
     while RG * C > 32 and RG > 1:  # rows per group: the row registers hold RG*C <= 32 packs (K <= 1024: >= 4 rows; 2048: 2; 4096: 1)
         RG //= 2
     # 16-byte packs need every row to start on a 16-byte boundary; otherwise two 8-byte loads per chunk (odd K, odd lda)
-    # (K <= 64: with packs only lanes 0 .. K/2-1 of the one chunk would load; a column per lane keeps all 64 busy)
-    pack = 2 if (K % 2 == 0 and K > 64 and A.strides[0] % 2 == 0 and A.ptr % 16 == 0 and x1.ptr % 16 == 0) else 1
+    # (K <= 64 leaves half the lanes of the one chunk without a pack; a column per lane instead measured slower:
+    #  K = 64: 238 us with packs, 262 us with 8-byte loads on all lanes — profiles/r5_gchain_sweep.txt)
+    pack = 2 if (K % 2 == 0 and A.strides[0] % 2 == 0 and A.ptr % 16 == 0 and x1.ptr % 16 == 0) else 1
     e_modes = []
     for pos, v in enumerate(e_vals):
         if v is None:

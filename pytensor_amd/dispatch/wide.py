@@ -21,7 +21,10 @@ from pytensor_amd.dispatch.elemwise import (
 from pytensor_amd.executor import HostValue
 
 MAX_ARG_BYTES = 3900
-TOTAL_GROUPS = 2048  # workgroups of one launch, shared among the terms
+import os
+
+TOTAL_GROUPS = int(os.environ.get("PTHIP_WIDE_GROUPS", 2048))  # workgroups of one launch, shared among the terms
+TERM_CAP = int(os.environ.get("PTHIP_WIDE_CAP", 64))  # per term (the partials a Tail kernel folds in one pass)
 
 
 # rough VALU instructions per element of a scalar op on gfx950 (fp64): what the split of a launch among its terms is
@@ -106,7 +109,7 @@ def multi_elemwise(node, inputs, env):
     for (t, ins, modes, n, vec), w in zip(per_term, work):
         units = (n // vec + EW_UNROLL - 1) // EW_UNROLL if vec > 1 else n
         cap = max(1, (units + BLOCK - 1) // BLOCK)
-        groups.append(max(1, min(cap, 64, max(4, int(round(TOTAL_GROUPS * w / tot))))))
+        groups.append(max(1, min(cap, TERM_CAP, max(4, int(round(TOTAL_GROUPS * w / tot))))))
     gx = max(groups)
     specs, args, out_pos, results, o0 = [], [], 0, [], 0
     gen_terms = []
