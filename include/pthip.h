@@ -418,6 +418,13 @@ int pthip_argmax(int dtype, int64_t rows, int64_t R, const void* src, void* out)
 int pthip_check_status(int* status);
 /* device address of that flag, for generated (JIT) kernels that bounds-check indices */
 void* pthip_status_ptr(void);
+/* Launch-per-step forms instead of the persistent / cooperative linear-algebra kernels (Cholesky task graph -> blocked
+ * steps, vector triangular solve -> blocked solve, LU panel -> one-workgroup sweep), process-wide, until switched off
+ * again.  What the host side turns on — and then evaluates the graph once more — when status bit 4 reports that a
+ * bounded dependency wait expired: a cooperative LU panel whose workgroups were not all resident because another
+ * process's kernels held the device (the reference has no such failure mode: LAPACK on the host,
+ * pytensor/tensor/linalg/decomposition/lu.py:239-300).  Returns the previous setting. */
+int pthip_set_safe_mode(int on);
 
 /* out[b] (n x n contiguous) = the symmetric matrix defined by the lower (or upper) triangle of A[b]:
  * the operand convention of scipy.linalg.eigh(a, b, lower=...) (Eigh.perform, eigen.py:177-186),

@@ -199,3 +199,19 @@ def wide_200():
     vals = configs.wide200_inputs(N=257, K=16, G=8)
     ins, outs = build_wide200(vals)
     return ins, outs, vals
+
+
+@case("linalg_contention")
+def linalg_contention():
+    # the three persistent / cooperative kernels in one graph (task-graph Cholesky, vector triangular solve, LU panel):
+    # tests/test_gpu_two_procs.py runs it at n = 2048 / 4096 / 1024 from two processes on ONE device
+    from pytensor.tensor.linalg import cholesky, solve_triangular
+    from pytensor.tensor.nlinalg import det
+
+    rng = np.random.default_rng(512)
+    S, Tm, M = pt.dmatrix("S"), pt.dmatrix("Tm"), pt.dmatrix("M")
+    b = pt.dvector("b")
+    n = 9
+    A = rng.normal(size=(n, n + 3))
+    return [S, Tm, b, M], [cholesky(S), solve_triangular(Tm, b, lower=True), det(M)], {
+        "S": A @ A.T / n + np.eye(n), "Tm": np.tril(rng.normal(size=(n, n))) + 3 * np.eye(n), "b": rng.normal(size=n), "M": rng.normal(size=(n, n)) + 2 * np.eye(n)}

@@ -903,6 +903,13 @@ def _elemwise_axis_reduce(p, inputs, node, graph):
     res = []
     for o, spec, dt in zip(outs, p["reduce"], p["scalar"]["out_dtypes"]):
         full = np.array(np.broadcast_to(o, shape), dtype=dt, order="C")
+        if spec["op"] == "LogSumExp":
+            # axisfuse.fuse_logsumexp: log(sum(exp(.))) over the axes, restated with scipy's stable form
+            # (the reference's own LogSumExp perform: pytensor/tensor/special.py:102-120)
+            import scipy.special
+
+            res.append(np.asarray(scipy.special.logsumexp(full.astype(spec["acc_dtype"]), axis=tuple(p["axis"]))).astype(spec["dtype"]))
+            continue
         sub = {"axis": p["axis"], "scalar_op": spec["op"], "acc_dtype": spec["acc_dtype"], "dtype": spec["dtype"]}
         res.append(_careduce(sub, [full], node, graph)[0])
     return res

@@ -149,3 +149,154 @@ def fuse_elemwise_axis_reduce(g: Graph) -> Graph:
             continue
         nodes.append(n)
     return dead_code_elimination(_copy(g, nodes))
+
+
+# ---------------------------------------------------------------------------------------------
+# log(sum(exp(f))) over some axes -> ONE reduction (the running (max, scaled sum) pair)
+# ---------------------------------------------------------------------------------------------
+
+
+def _canon(body, ref, in_vars):
+    """a scalar sub-expression as a hashable tree over GRAPH variables (two nodes' bodies can then be compared)"""
+    if ref[0] == "i":
+        return ("i", in_vars[ref[1]])
+    if ref[0] == "t":
+        n = body["body"][ref[1]]
+        if n["op"] in ("ScalarLoop", "LoopOut"):
+            return ("opaque", id(n))
+        return (n["op"], n["dtype"], tuple(_canon(body, r, in_vars) for r in n["in"]))
+    return ("c", repr(ref[1]), ref[2])
+
+
+def _tree_inputs(tree, acc):
+    if tree[0] == "i":
+        acc.add(tree[1])
+    elif tree[0] not in ("c", "opaque"):
+        for ch in tree[2]:
+            _tree_inputs(ch, acc)
+    return acc
+
+
+def _prune(node: Node) -> Node:
+    """drop scalar ops no output needs, then inputs nothing reads"""
+    b = node.params["scalar"]
+    live, stack = set(), [r for r in b["outs"]]
+    while stack:
+        r = stack.pop()
+        if r[0] == "t" and r[1] not in live:
+            live.add(r[1])
+            stack.extend(b["body"][r[1]]["in"])
+    tmap, nb = {}, []
+    for k, n in enumerate(b["body"]):
+        if k in live:
+            tmap[k] = len(nb)
+            nb.append(n)
+    used = sorted({r[1] for n in nb for r in n["in"] if r[0] == "i"} | {r[1] for r in b["outs"] if r[0] == "i"})
+    imap = {p: q for q, p in enumerate(used)}
+
+    def ref(r):
+        return ["t", tmap[r[1]]] if r[0] == "t" else (["i", imap[r[1]]] if r[0] == "i" else list(r))
+
+    body = {"in_dtypes": [b["in_dtypes"][p] for p in used], "out_dtypes": list(b["out_dtypes"]),
+            "body": [{**n, "in": [ref(r) for r in n["in"]]} for n in nb], "outs": [ref(r) for r in b["outs"]]}
+    params = dict(node.params)
+    params["scalar"] = body
+    return Node(node.op, params, [node.inputs[p] for p in used], list(node.outputs))
+
+
+def fuse_logsumexp(g: Graph) -> Graph:
+    """``log(sum_axes(exp(f(x))))`` — an ``ElemwiseAxisReduce`` whose one output is a Sum of an ``Exp`` and whose sum
+    is read by nothing but a ``Log`` — becomes ONE reduction with the op ``LogSumExp`` (csrc/reduce_device.h OpLse:
+    the running pair (max, scaled sum), one exp per element, cannot overflow); the consumer's ``Log`` becomes the
+    identity.  Then the identity  LSE_axes(f - c) + c = LSE_axes(f)  for any ``c`` constant along the reduced axes
+    removes the shifts that stabilised the two-pass form: the ``- max`` inside the reduction and the ``+ max``
+    outside cancel, and the Max reductions that fed them die with their last reader.  The stabilised graph the
+    reference's rewrites make of tests/benchmarks/test_logsumexp.py:9-13 (Max, Max of the shifted values, Sum of Exp)
+    — three passes over X — becomes one."""
+    changed = True
+    while changed:
+        changed = False
+        producer, consumers = _index(g)
+        out_set = set(g.outputs)
+        for kr, R in enumerate(g.nodes):
+            if R.op != "ElemwiseAxisReduce" or len(R.outputs) != 1 or R.params["reduce"][0]["op"] != "Add":
+                continue
+            rb = R.params["scalar"]
+            o = rb["outs"][0]
+            if o[0] != "t" or rb["body"][o[1]]["op"] != "Exp" or rb["out_dtypes"][0] not in ("float64", "float32"):
+                continue
+            if R.params["reduce"][0]["dtype"] != rb["out_dtypes"][0]:
+                continue
+            # the sum -> (views) -> ONE Elemwise, which reads it through exactly one Log
+            v, chain = R.outputs[0], []
+            while True:
+                cons = consumers.get(v, [])
+                if v in out_set or len(cons) != 1:
+                    v = None
+                    break
+                c = g.nodes[cons[0]]
+                if c.op == "DimShuffle":
+                    chain.append(cons[0])
+                    v = c.outputs[0]
+                    continue
+                break
+            if v is None:
+                continue
+            ke = consumers[v][0]
+            E = g.nodes[ke]
+            if E.op != "Elemwise" or E.inputs.count(v) != 1:
+                continue
+            eb = E.params["scalar"]
+            q = E.inputs.index(v)
+            uses = [(k, n) for k, n in enumerate(eb["body"]) if ["i", q] in [list(r) for r in n["in"]]]
+            if len(uses) != 1 or uses[0][1]["op"] != "Log" or any(list(r) == ["i", q] for r in eb["outs"]):
+                continue
+            kl = uses[0][0]
+            axes = [int(a) for a in R.params["axis"]]
+            # ---- LSE_axes(f - c1 - c2 ...) + c1 + c2 ... : peel the shifts off f
+            pre = rb["body"][o[1]]["in"][0]
+            small = {vid for vid in R.inputs if all(g.vars[vid].shape[a] == 1 for a in axes)}
+            shifts, cur = [], pre
+            while cur[0] == "t" and rb["body"][cur[1]]["op"] == "Sub":
+                lhs, rhs = rb["body"][cur[1]]["in"]
+                tree = _canon(rb, rhs, R.inputs)
+                if not _tree_inputs(tree, set()) <= small or "opaque" in repr(tree):
+                    break
+                shifts.append(tree)
+                cur = lhs
+            # the Add (if any) that takes the Log in the consumer
+            adds = [(k, n) for k, n in enumerate(eb["body"]) if n["op"] == "Add" and ["t", kl] in [list(r) for r in n["in"]]]
+            new_pre, new_add = pre, None
+            log_reads = sum(1 for n in eb["body"] for r in n["in"] if list(r) == ["t", kl])
+            if shifts and len(adds) == 1 and log_reads == 1 and not any(list(r) == ["t", kl] for r in eb["outs"]):
+                ka, A = adds[0]
+                ops_left = [list(r) for r in A["in"]]
+                trees = [None if r == ["t", kl] else _canon(eb, r, E.inputs) for r in ops_left]
+                matched, cur2 = 0, pre
+                # shifts were peeled outermost first: cancel them in that order while the consumer adds them back
+                for tree in shifts:
+                    hit = next((j for j, t in enumerate(trees) if t is not None and t == tree), None)
+                    if hit is None:
+                        break
+                    trees.pop(hit)
+                    ops_left.pop(hit)
+                    cur2 = rb["body"][cur2[1]]["in"][0]
+                    matched += 1
+                if matched:
+                    new_pre, new_add = cur2, (ka, ops_left)
+            # ---- rewrite R and E
+            nrb = {**rb, "outs": [list(new_pre)]}
+            spec = [{**R.params["reduce"][0], "op": "LogSumExp"}]
+            R2 = _prune(Node("ElemwiseAxisReduce", {**R.params, "scalar": nrb, "reduce": spec}, list(R.inputs), list(R.outputs)))
+            nbody = [dict(n) for n in eb["body"]]
+            nbody[kl] = {**nbody[kl], "op": "Identity"}
+            if new_add is not None:
+                ka, ops_left = new_add
+                nbody[ka] = {**nbody[ka], "op": "Add", "in": ops_left} if len(ops_left) > 1 else {**nbody[ka], "op": "Identity", "in": ops_left}
+            E2 = _prune(Node("Elemwise", {**E.params, "scalar": {**eb, "body": nbody}}, list(E.inputs), list(E.outputs)))
+            nodes = list(g.nodes)
+            nodes[kr], nodes[ke] = R2, E2
+            g = dead_code_elimination(_copy(g, nodes))
+            changed = True
+            break
+    return g

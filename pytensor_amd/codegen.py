@@ -1065,6 +1065,9 @@ def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=
     reduce_spec = reduce_spec or [None] * nout
     params = _flat_params(body, modes, reduce_spec, vec, finish)
     if device_fn:
+        # (inlined into every case of the dispatching switch: as ONE shared copy per family (__noinline__) the kernel of
+        #  north_star's 48-term graph shrank from 40,000 to 5,500 instructions but needed 99 VGPRs instead of 50 for the
+        #  call and ran 218 us instead of 196 — measured, profiles/r5m notes in DESIGN.md)
         src = [f"static __device__ __forceinline__ void {name}({', '.join(params)}, const unsigned pt_bidx, const unsigned pt_gdim) {{"]
     else:
         src = [reduce_header() if any(reduce_spec) else "", prelude_for(body), VEC_HELPERS, PT_PAIR_HELPERS if finish else ""]

@@ -214,7 +214,13 @@ def tile_kernel_source(name: str, body: dict, cls: str, nb: int, V: int, TX: int
 # scalar graph): the same tile, with the row and / or inner dimension reduced
 # ---------------------------------------------------------------------------------------------
 
-ND_REDUCE_OPS = {**REDUCE_OPS, "ScalarMaximum": "OpMax", "ScalarMinimum": "OpMin", "AND": "OpAnd", "OR": "OpOr", "XOR": "OpXor"}
+ND_REDUCE_OPS = {**REDUCE_OPS, "ScalarMaximum": "OpMax", "ScalarMinimum": "OpMin", "AND": "OpAnd", "OR": "OpOr", "XOR": "OpXor",
+                 # log(sum(exp(.))) as ONE reduction over the running pair (max, scaled sum) — csrc/reduce_device.h pt_lse / OpLse
+                 "LogSumExp": "OpLse"}
+
+
+def _acc_ctype(op, acc):
+    return f"pthip_dev::pt_lse<{CTYPE[acc]}>" if op == "LogSumExp" else CTYPE[acc]
 
 
 def tile_reduce_params(body, cls, nkb, nrd, outs):
@@ -277,7 +283,7 @@ def tile_reduce_source(name: str, body: dict, cls: str, nkb: int, nrd: int, row_
     L.append("  const long long split = pt_t;")
     L.append("  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;")
     for k, (op, acc, odt) in enumerate(outs):
-        act = CTYPE[acc]
+        act = _acc_ctype(op, acc)
         L.append(f"  {act} acc{k}[{NI}][{NE}];")
         L.append(f"#pragma unroll\n  for (int i = 0; i < {NI}; i++)\n#pragma unroll\n    for (int e = 0; e < {NE}; e++) acc{k}[i][e] = pthip_dev::{ND_REDUCE_OPS[op]}::identity<{act}>();")
     for k, dt in enumerate(body["in_dtypes"]):
@@ -387,7 +393,8 @@ def tile_reduce_source(name: str, body: dict, cls: str, nkb: int, nrd: int, row_
     ia = "i" if row_kept else "0"
     ea = "e" if inner_kept else "0"
     for k, (op, acc, odt) in enumerate(outs):
-        L.append(f"        if (ok[w][i]) acc{k}[{ia}][{ea}] = pthip_dev::{ND_REDUCE_OPS[op]}::apply(acc{k}[{ia}][{ea}], ({CTYPE[acc]})o{k});")
+        fold = "push" if op == "LogSumExp" else "apply"  # (one more term of a log-sum-exp: one exp, not a merge of two states)
+        L.append(f"        if (ok[w][i]) acc{k}[{ia}][{ea}] = pthip_dev::{ND_REDUCE_OPS[op]}::{fold}(acc{k}[{ia}][{ea}], ({CTYPE[acc]})o{k});")
     L.append("      }")
     L.append("    }")
     L.append("    }")
@@ -396,7 +403,7 @@ def tile_reduce_source(name: str, body: dict, cls: str, nkb: int, nrd: int, row_
     obase = " + ".join(["split * ps_split"] + [f"q{j} * oskb{j}" for j in range(nkb)])
     L.append(f"  const long long ob = {obase};")
     for k, (op, acc, odt) in enumerate(outs):
-        act, opn, sct = CTYPE[acc], f"pthip_dev::{ND_REDUCE_OPS[op]}", CTYPE[odt]
+        act, opn, sct = _acc_ctype(op, acc), f"pthip_dev::{ND_REDUCE_OPS[op]}", CTYPE[odt]
         if row_kept and not inner_kept:
             if TX == BLOCK:
                 L.append(f"  __shared__ {act} sm{k}[{BLOCK // 64}];")

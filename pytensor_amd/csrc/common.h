@@ -37,6 +37,7 @@ struct Context {
   bool capturing = false;
   LaunchList* recorder = nullptr;  // attached between pthip_record_begin / pthip_record_end
   long long launch_count = 0;      // kernel launches + async copies issued so far (plan sizing)
+  bool safe_mode = false;          // pthip_set_safe_mode: no persistent / cooperative linear-algebra kernels
 };
 
 Context& ctx();

@@ -37,21 +37,23 @@ typedef float float16_t __attribute__((ext_vector_type(16)));
 // else (row-contiguous):               element (row, k) at base + k*ld + row.
 template <class T, bool KC, int BKT = 16> struct Stage;  // BKT: K extent of a staged tile
 
-template <bool KC> struct Stage<double, KC, 16> {
-  static constexpr int NV = 4;                 // 16-byte vectors per thread per tile
-  static constexpr int LD = KC ? 18 : 144;     // LDS leading dimension (elements)
-  static constexpr int SIZE = KC ? 128 * 18 : 16 * 144;
+// ROWS = 128 (the 128 x 128 tile) or 64 (the 64 x 64 tile of mid-size products, see dgemm_kernel)
+template <bool KC, int ROWS> struct StageD {
+  static constexpr int NV = ROWS * 16 / (2 * BLOCK);  // 16-byte vectors per thread per tile (4 / 2)
+  static constexpr int LD = KC ? 18 : ROWS + 16;      // LDS leading dimension (elements)
+  static constexpr int SIZE = KC ? ROWS * 18 : 16 * (ROWS + 16);
+  static constexpr int RP = ROWS / 2;                 // 16-byte pairs along a row-contiguous k-row
   double2 v[NV];
   __device__ __forceinline__ void load(const double* __restrict__ base, long long ld,
                                        long long row0, long long k0, long long rows,
                                        long long K, bool vec_ok) {
-    if (vec_ok && row0 + 128 <= rows && k0 + BK <= K) {
+    if (vec_ok && row0 + ROWS <= rows && k0 + BK <= K) {
       // interior tile (workgroup-uniform test): straight 16-byte loads, no per-vector branches
 #pragma unroll
       for (int p = 0; p < NV; p++) {
         const int id = threadIdx.x + p * BLOCK;
         if constexpr (KC) v[p] = *(const double2*)(base + (row0 + (id >> 3)) * ld + k0 + (id & 7) * 2);
-        else v[p] = *(const double2*)(base + (k0 + (id >> 6)) * ld + row0 + (id & 63) * 2);
+        else v[p] = *(const double2*)(base + (k0 + id / RP) * ld + row0 + (id % RP) * 2);
       }
       return;
     }
@@ -68,7 +70,7 @@ template <bool KC> struct Stage<double, KC, 16> {
           v[p].y = (row < rows && k + 1 < K) ? g[1] : 0.0;
         }
       } else {
-        const int kk = id >> 6, rv = (id & 63) * 2;
+        const int kk = id / RP, rv = (id % RP) * 2;
         const long long row = row0 + rv, k = k0 + kk;
         const double* g = base + k * ld + row;
         if (k < K && row + 1 < rows && vec_ok) v[p] = *(const double2*)g;
@@ -87,7 +89,7 @@ template <bool KC> struct Stage<double, KC, 16> {
         const int r = id >> 3, kv = (id & 7) * 2;
         *(double2*)(s + r * LD + kv) = v[p];
       } else {
-        const int kk = id >> 6, rv = (id & 63) * 2;
+        const int kk = id / RP, rv = (id % RP) * 2;
         *(double2*)(s + kk * LD + rv) = v[p];
       }
     }
@@ -99,6 +101,7 @@ template <bool KC> struct Stage<double, KC, 16> {
     else return s[(kk * 4 + (lane >> 4)) * LD + r0 + (lane & 15)];
   }
 };
+template <bool KC> struct Stage<double, KC, 16> : StageD<KC, 128> {};
 
 template <bool KC, int BKT> struct Stage<float, KC, BKT> {
   static constexpr int VPR = BKT / 4;          // 16-byte vectors per tile row (K-contiguous image)
@@ -200,32 +203,38 @@ __device__ __forceinline__ void tile_coords(long long tiles_m, long long tiles_n
 // SKINNY (M <= 64): the four waves split N (wave tile 64 x 32) so no MFMA is spent on
 // padding rows.  gridDim.y > 1 = split-K: block y covers K range [y*kchunk, (y+1)*kchunk) and
 // writes its raw accumulators to partial slab y of `out` (combined by splitk_finish_kernel).
-template <bool AKC, bool BKC, bool SKINNY>
+// TILE = 64: 64 x 64 output tiles (wave tile 32 x 32) for products whose 128 x 128 tiling leaves most of the 256 CUs
+// without a workgroup (the M = 512 solve steps of the blocked triangular solve, 1024^2 products: 64 tiles) — four times
+// the workgroups, full K each, instead of split-K slabs and a finishing pass over them.
+template <bool AKC, bool BKC, bool SKINNY, int TILE = 128>
 __global__ __launch_bounds__(BLOCK, 2) void dgemm_kernel(
     double* __restrict__ out, const double* __restrict__ A, const double* __restrict__ B,
     const double* __restrict__ C, long long M, long long N, long long K, long long lda,
     long long ldb, long long sAb, long long sBb, long long sCb, long long sC0, long long sC1,
     double alpha, double beta, long long tiles_m, long long tiles_n, int vecA, int vecB,
     long long kchunk, long long ldo) {
-  using SA = Stage<double, AKC>;
-  using SB = Stage<double, BKC>;
+  using SA = StageD<AKC, TILE>;
+  using SB = StageD<BKC, TILE>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* As = (double*)smem_raw;                // [2][SA::SIZE]
   double* Bs = As + 2 * SA::SIZE;                // [2][SB::SIZE]
   long long tm, tn;
   long long bz;
   tile_coords(tiles_m, tiles_n, tm, tn, bz);
-  const long long m0 = tm * BM, n0 = tn * BN;
+  const long long m0 = tm * TILE, n0 = tn * TILE;
   A += bz * sAb;
   B += bz * sBb;
   const bool split = gridDim.y > 1;
   out += ((long long)blockIdx.y * gridDim.z + bz) * M * N;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  constexpr int NJ = SKINNY ? 2 : 4;
-  const int wm0 = SKINNY ? 0 : (w >> 1) * 64, wn0 = SKINNY ? w * 32 : (w & 1) * 64;
-  double4_t acc[4][NJ];
+  static_assert(TILE == 128 || (TILE == 64 && !SKINNY), "tile shapes: 128 x 128 (skinny: 64 x 128) or 64 x 64");
+  constexpr int NI = TILE == 128 ? 4 : 2;
+  constexpr int NJ = TILE == 128 ? (SKINNY ? 2 : 4) : 2;
+  constexpr int WT = TILE / 2;  // wave tile edge of the 2 x 2 wave layout
+  const int wm0 = SKINNY ? 0 : (w >> 1) * WT, wn0 = SKINNY ? w * 32 : (w & 1) * WT;
+  double4_t acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < NI; i++)
 #pragma unroll
     for (int j = 0; j < NJ; j++) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
   SA sa;
@@ -248,13 +257,13 @@ __global__ __launch_bounds__(BLOCK, 2) void dgemm_kernel(
     const double* bs = Bs + cur * SB::SIZE;
 #pragma unroll
     for (int kk = 0; kk < BK / 4; kk++) {
-      double af[4], bf[NJ];
+      double af[NI], bf[NJ];
 #pragma unroll
-      for (int i = 0; i < 4; i++) af[i] = SA::frag(as, wm0 + i * 16, kk, lane);
+      for (int i = 0; i < NI; i++) af[i] = SA::frag(as, wm0 + i * 16, kk, lane);
 #pragma unroll
       for (int j = 0; j < NJ; j++) bf[j] = SB::frag(bs, wn0 + j * 16, kk, lane);
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int i = 0; i < NI; i++)
 #pragma unroll
         for (int j = 0; j < NJ; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(BLOCK, 2) void dgemm_kernel(
   if (has_c) C += bz * sCb;
   if (split) alpha = 1.0;
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < NI; i++)
 #pragma unroll
     for (int j = 0; j < NJ; j++)
 #pragma unroll
@@ -903,6 +912,22 @@ int launch(long long batch, long long M, long long N, long long K, T alpha, cons
                        lda, ldb, sAb, sBb, (long long)(M * N), N, 1LL, T(1), T(0), tiles_m, tiles_n,
                        vecA, vecB, kchunk, N);
     return pthip::post_launch("gemm(partials)");
+  }
+  if constexpr (sizeof(T) == 8 && !SKINNY) {
+    // mid-size fp64 products (the 128 x 128 tiling gives fewer than 128 workgroups, so split_plan above cut K into slabs):
+    // 64 x 64 tiles when THEY fill the chip without splitting — no slabs, no finishing pass.  (Only here: callers of
+    // pthip_gemm_partials consume the 128-tile slabs split_plan promises.)
+    static const bool t64 = !(getenv("PTHIP_DGEMM_T64") && atoi(getenv("PTHIP_DGEMM_T64")) == 0);
+    const long long t64m = (M + 63) / 64, t64n = (N + 63) / 64;
+    if (t64 && nsplit > 1 && M > 64 && t64m * t64n * batch >= 128) {
+      auto k64 = dgemm_kernel<AKC, BKC, false, 64>;
+      const size_t sh64 = (size_t)(2 * StageD<AKC, 64>::SIZE + 2 * StageD<BKC, 64>::SIZE) * sizeof(double);
+      dim3 g64((unsigned)(t64m * t64n), 1u, (unsigned)batch);
+      const long long kc64 = (K + BK - 1) / BK * BK;
+      PTHIP_KLAUNCH(k64, g64, dim3(BLOCK), sh64, st, (double*)out, (const double*)A, (const double*)B, (const double*)C, M, N, K, lda, ldb, sAb, sBb,
+                    sCb, sC0, sC1, (double)alpha, (double)beta, t64m, t64n, vecA, vecB, kc64, ldo);
+      return pthip::post_launch("gemm(64x64 tiles)");
+    }
   }
   if (nsplit == 1) {
     if constexpr (sizeof(T) == 4 && !SKINNY && BKT == 32) {

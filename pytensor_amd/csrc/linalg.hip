@@ -1053,7 +1053,25 @@ __global__ __launch_bounds__(BLOCK) void chol_dag_kernel(T* W, long long ld, con
   const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
 #define DAG_STAMP(slot) dag_stamp(tr, slot)
 #define DAG_GIVE_UP() do { if (tid == 0) { atomicOr(status, 16); __hip_atomic_store(abortflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return; } while (0)
-  for (int t = blockIdx.x; t < ntasks; t += gridDim.x) {
+  // Tasks are CLAIMED, in order, through a ticket (flags[2], zeroed with the flags): a workgroup that is running takes
+  // the lowest unclaimed task, and every task waits only on lower-numbered ones — which are therefore finished or in
+  // the hands of a running workgroup.  Progress no longer depends on all gridDim.x workgroups being resident at once
+  // (another process's kernels on the same device — PyMC's chains — can hold CUs for as long as they like); with the
+  // static stride t = blockIdx.x + k*gridDim.x a workgroup the dispatcher had not started yet owned tasks the running
+  // ones waited for until their spin limit.  The next ticket is requested when the current task is about to store its
+  // tile: the round trip (an L2 atomic) hides behind the stores, and a task is not held by a workgroup that is still
+  // busy (requested at the START of the current task, the head task of the next column — the critical path — could sit
+  // behind a long update while other workgroups idled: n = 4096 went from 1.43 to 1.57 ms).
+  __shared__ int s_task;
+  int* const next_task = failflag + 2;
+  int t_next = 0;
+  if (tid == 0) t_next = atomicAdd(next_task, 1);
+  for (;;) {
+    if (tid == 0) s_task = t_next;
+    __syncthreads();
+    const int t = s_task;
+    __syncthreads();  // (s_task is rewritten at the top of the next round)
+    if (t >= ntasks) break;
     int j = 0, rem = t;
     for (;;) {
       const int cj = 1 + ((nT - j - 2) > 0 ? (nT - j - 2) : 0);
@@ -1082,6 +1100,7 @@ __global__ __launch_bounds__(BLOCK) void chol_dag_kernel(T* W, long long ld, con
       dag_substitute<T>(As, Bs, Dv);
       __syncthreads();
       DAG_STAMP(3);
+      if (tid == 0) t_next = atomicAdd(next_task, 1);
       dag_store_tile<T>(W + (long long)i * DT * ld + (long long)j * DT, ld, As);
       dag_publish(done + (long long)i * nT + j, tr, 6);
       DAG_STAMP(15);
@@ -1195,6 +1214,7 @@ __global__ __launch_bounds__(BLOCK) void chol_dag_kernel(T* W, long long ld, con
         }
       }
     }
+    if (tid == 0) t_next = atomicAdd(next_task, 1);
     dag_publish(done + (long long)j * nT + j, tr, 14);
     DAG_STAMP(15);
   }
@@ -1302,7 +1322,7 @@ int chol_dag(int lower, long long n, const T* A, T* L) {
 template <class T>
 int chol_blocked(int lower, long long n, const T* A, T* L) {
   static const bool steps = getenv("PTHIP_CHOL") && !strcmp(getenv("PTHIP_CHOL"), "steps");
-  if (!steps) return chol_dag<T>(lower, n, A, L);
+  if (!steps && !pthip::ctx().safe_mode) return chol_dag<T>(lower, n, A, L);
   hipStream_t st = pthip::ctx().stream;
   void* scratch = nullptr;
   const size_t wbytes = (size_t)n * n * sizeof(T);
@@ -1636,7 +1656,7 @@ __global__ __launch_bounds__(BLOCK) void trsv_dag_kernel(T* __restrict__ Xp, lon
                                                         long long t0, long long t1, const T* __restrict__ Bp,
                                                         long long b0, int n, int nr, int unit,
                                                         unsigned long long* __restrict__ box, int* __restrict__ failflag,
-                                                        int* __restrict__ abortflag, int* __restrict__ status) {
+                                                        int* __restrict__ abortflag, int* __restrict__ ticket, int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ int s_ok;
   T* Ds = (T*)smem_raw;        // [TV][TVS] diagonal block (lower, identity beyond n)
@@ -1645,7 +1665,13 @@ __global__ __launch_bounds__(BLOCK) void trsv_dag_kernel(T* __restrict__ Xp, lon
   T* xs = Di + TV * TVS;       // [TV][TV_NR] x_k, then the right-hand side of the diagonal solve
   T* red = xs + TV * TV_NR;    // [4][TV][TV_NR] partial sums of the four column quarters
   const int tid = threadIdx.x, lane = tid & 63, part = tid >> 6;
-  const int s = blockIdx.x;
+  // the row block is CLAIMED through a ticket, not read off blockIdx.x: block s waits only for blocks below s, and
+  // those were claimed by workgroups that are running — no assumption about which workgroups are resident together
+  // or in which order the dispatcher starts them (other processes' kernels may hold CUs)
+  if (tid == 0) s_ok = atomicAdd(ticket, 1);
+  __syncthreads();
+  const int s = s_ok;
+  __syncthreads();
   const long long rbase = (long long)s * TV;
   const int nb = (n - rbase) < TV ? (int)(n - rbase) : TV;
   const bool rowfast = (t0 == 1 || t0 == -1) && !(t1 == 1 || t1 == -1);  // which index walks memory
@@ -1799,7 +1825,8 @@ int trsv_dag(int lower, int unit, long long n, long long nrhs, const T* Tm, long
   const int nchunk = (int)((nrhs + TV_NR - 1) / TV_NR);
   const size_t boxbytes = (size_t)nB * TV * TV_NR * 2 * sizeof(unsigned long long);
   void* scratch = nullptr;
-  int r = pthip_alloc(boxbytes * nchunk + 256, &scratch);
+  const size_t flagbytes = 256 + ((size_t)nchunk * sizeof(int) + 255) / 256 * 256;  // fail, abort; from word 64 on: one ticket per chunk
+  int r = pthip_alloc(boxbytes * nchunk + flagbytes, &scratch);
   if (r) return r;
   auto fail = [&](int rc) { pthip_free(scratch); return rc; };
   int* flags = (int*)((char*)scratch + boxbytes * nchunk);
@@ -1824,7 +1851,7 @@ int trsv_dag(int lower, int unit, long long n, long long nrhs, const T* Tm, long
     pthip_free(scratch);
     return 1 << 30;  // (the caller falls back to trsm_blocked)
   }
-  if (hipError_t e = pthip::memset_async(scratch, 0, boxbytes * nchunk + 256, st); e != hipSuccess) return fail(pthip::check(e, "trsv box memset"));
+  if (hipError_t e = pthip::memset_async(scratch, 0, boxbytes * nchunk + flagbytes, st); e != hipSuccess) return fail(pthip::check(e, "trsv box memset"));
   // solve coordinates: p = lower ? i : n-1-i
   const long long sg = lower ? 1 : -1;
   const T* Tp = lower ? Tm : Tm + (n - 1) * (sT0 + sT1);
@@ -1834,7 +1861,7 @@ int trsv_dag(int lower, int unit, long long n, long long nrhs, const T* Tm, long
     const int nr = (int)((nrhs - (long long)c * TV_NR) < TV_NR ? (nrhs - (long long)c * TV_NR) : TV_NR);
     PTHIP_KLAUNCH(kk, dim3((unsigned)nB), dim3(BLOCK), lds, st, Xp + (long long)c * TV_NR, sg * nrhs, Tp, sg * sT0, sg * sT1,
                   Bp + (long long)c * TV_NR, sg * nrhs, (int)n, nr, unit,
-                  (unsigned long long*)((char*)scratch + boxbytes * c), flags, flags + 1, pthip::ctx().status_dev);
+                  (unsigned long long*)((char*)scratch + boxbytes * c), flags, flags + 1, flags + 64 + c, pthip::ctx().status_dev);
     if ((r = pthip::post_launch("trsv_dag"))) return fail(r);
   }
   PTHIP_KLAUNCH((nan_fill_if_kernel<T>), dim3(256), dim3(BLOCK), 0, st, out, n * nrhs, (const int*)flags);
@@ -2224,7 +2251,7 @@ int trsm_typed(int lower, int unit, long long batch, long long n, long long nrhs
       const T* Tb = (const T*)Tm + b * sTb;
       const T* Bb = (const T*)B + b * sBb;
       T* Ob = (T*)out + b * n * nrhs;
-      int r = nrhs <= 16 ? trsv_dag<T>(lower, unit, n, nrhs, Tb, sT0, sT1, Bb, Ob)
+      int r = (nrhs <= 16 && !pthip::ctx().safe_mode) ? trsv_dag<T>(lower, unit, n, nrhs, Tb, sT0, sT1, Bb, Ob)
                          : trsm_blocked<T>(lower, unit, n, nrhs, Tb, sT0, sT1, Bb, Ob);
       if (r == (1 << 30)) r = trsm_blocked<T>(lower, unit, n, nrhs, Tb, sT0, sT1, Bb, Ob);  // (over-subscribed: see trsv_dag)
       if (r) return r;

@@ -1195,7 +1195,8 @@ int getrf_typed(long long batch, long long n, const void* A, void* LU, void* per
   hipStream_t st = pthip::ctx().stream;
   const size_t need = (size_t)n * (size_t)(n | 1) * sizeof(T);
   static const bool unblocked = getenv("PTHIP_LU_UNBLOCKED") != nullptr;
-  if (need <= 160 * 1024 - 8192 || (unblocked && n <= 512)) {
+  // (safe mode: the one-workgroup sweep in global memory for ANY n — slow, but it waits for nobody)
+  if (need <= 160 * 1024 - 8192 || (unblocked && n <= 512) || pthip::ctx().safe_mode) {
     const bool lds = need <= 160 * 1024 - 8192;
     auto k = getrf_kernel<T>;
     void* scratch = nullptr;

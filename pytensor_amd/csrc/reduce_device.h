@@ -99,13 +99,14 @@ struct OpXor {
 };
 template <> __device__ __forceinline__ bool OpXor::apply<bool>(bool a, bool b) { return a != b; }
 
-// ---- cross-lane exchange for any 1/2/4/8-byte T --------------------------------
+// ---- cross-lane exchange for any 1/2/4-byte T and any T of whole 4-byte words (8: double, 16: a pt_lse<double>) ----
 template <class T> __device__ __forceinline__ T shfl_xor_any(T v, int mask) {
-  if constexpr (sizeof(T) == 8) {
-    union { T t; int i[2]; } u;
+  if constexpr (sizeof(T) >= 4 && sizeof(T) % 4 == 0) {
+    constexpr int NW = sizeof(T) / 4;
+    union { T t; int i[NW]; } u;
     u.t = v;
-    u.i[0] = __shfl_xor(u.i[0], mask, 64);
-    u.i[1] = __shfl_xor(u.i[1], mask, 64);
+#pragma unroll
+    for (int w = 0; w < NW; w++) u.i[w] = __shfl_xor(u.i[w], mask, 64);
     return u.t;
   } else {
     union { T t; int i; } u;
@@ -115,6 +116,44 @@ template <class T> __device__ __forceinline__ T shfl_xor_any(T v, int mask) {
     return u.t;
   }
 }
+
+// ---- log-sum-exp as a reduction: the running pair (m, s) with sum_i exp(x_i) = s * exp(m), m = max_i x_i ----
+// One pass, one exp per element, never an overflow: what `log(sum(exp(x)))` (pytensor/tensor/math.py logsumexp,
+// special.py:102 LogSumExp; stabilised by the reference's rewrites into max + log(sum(exp(x - max))): two reductions
+// and an N-sized intermediate) is on a machine that would rather read x once.  NaN propagates; -inf terms add nothing;
+// a +inf term gives +inf.  value() = log(s) + m.
+static __device__ __forceinline__ double lse_exp(double x) { return exp(x); }
+static __device__ __forceinline__ float lse_exp(float x) { return expf(x); }
+static __device__ __forceinline__ double lse_log(double x) { return log(x); }
+static __device__ __forceinline__ float lse_log(float x) { return logf(x); }
+template <class T> struct pt_lse {
+  T m, s;
+  __device__ __forceinline__ T value() const { return lse_log(s) + m; }
+  template <class U> explicit __device__ __forceinline__ operator U() const { return (U)value(); }
+};
+struct OpLse {
+  // the state of an empty sum: m = -inf, s = 0 (value: log(0) + -inf = -inf, the reduction's identity)
+  template <class P> static __device__ __forceinline__ P identity() { return P{-Limits<decltype(P().m)>::highest(), 0}; }
+  // one more term x (one exp): d = x - m; x == m (equal infinities included) adds exactly 1
+  template <class T> static __device__ __forceinline__ pt_lse<T> push(pt_lse<T> a, T x) {
+    const T d = x - a.m;
+    if (x == a.m) {
+      a.s += T(1);
+    } else {
+      const T e = lse_exp(d > T(0) ? -d : d);
+      a.s = d > T(0) ? a.s * e + T(1) : a.s + e;  // (NaN: both comparisons false, s + NaN)
+    }
+    a.m = (x != x) ? x : ((a.m != a.m) ? a.m : (x > a.m ? x : a.m));
+    return a;
+  }
+  // two partial states (lanes, thread rows, splits)
+  template <class T> static __device__ __forceinline__ pt_lse<T> apply(pt_lse<T> a, pt_lse<T> b) {
+    const T M = (a.m != a.m) ? a.m : ((b.m != b.m) ? b.m : (a.m > b.m ? a.m : b.m));
+    const T fa = (a.m == M) ? T(1) : lse_exp(a.m - M);  // (both -inf: M == m, factor 1, s stays 0)
+    const T fb = (b.m == M) ? T(1) : lse_exp(b.m - M);
+    return pt_lse<T>{M, a.s * fa + b.s * fb};
+  }
+};
 
 template <class Op, class T> __device__ __forceinline__ T wave_reduce(T v) {
 #pragma unroll

@@ -785,6 +785,12 @@ int pthip_list_destroy(void* list) {
 
 int64_t pthip_launch_count(void) { return (int64_t)g_ctx.launch_count; }
 
+int pthip_set_safe_mode(int on) {
+  const int was = g_ctx.safe_mode ? 1 : 0;
+  g_ctx.safe_mode = on != 0;
+  return was;
+}
+
 void* pthip_status_ptr(void) {
   if (g_ctx.device < 0 && pthip_init(0)) return nullptr;
   return (void*)g_ctx.status_dev;

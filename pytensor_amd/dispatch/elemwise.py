@@ -660,6 +660,16 @@ def launch_axis_reduce(env, body, ins, shape, axes, specs, out_shape):
     grid = n_nat * nsplit
     buf = struct.pack(f"<{len(args)}q", *args)
     env.timed(name, lambda: ffi.check(env.lib.pthip_launch(fn, grid, 1, 1, BLOCK, 1, 1, 0, buf, len(buf))))
+    if not final and any(op == "LogSumExp" for op, _, _ in specs):
+        # every split stored its own log-sum-exp: the splits fold by the same reduction (a second, small launch)
+        res = []
+        for part, (op, acc, odt) in zip(dsts, specs):
+            pv = part.view((n_out, nsplit), (nsplit, 1)) if split_fastest else part.view((nsplit, n_out), (n_out, 1))
+            r2 = launch_axis_reduce(env, _identity_body(acc), [pv], pv.shape, [1 if split_fastest else 0], [(op, acc, odt)], (n_out,))
+            if r2 is None:
+                raise RuntimeError("log-sum-exp: the second stage does not fit the tile")
+            res.append(r2[0].view(out_shape, _cstrides(out_shape)))
+        return res
     if not final:
         if split_fastest:
             outs = [device_reduce(env, op, part, n_out, nsplit, 1, nsplit, 1, 0, acc, odt, out_shape) for part, (op, acc, odt) in zip(dsts, specs)]

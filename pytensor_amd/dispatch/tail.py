@@ -301,7 +301,11 @@ def _run_fused(node, P, results, env, inputs=()):
         prod = {o: k for k, n in enumerate(env.graph.nodes) for o in n.outputs}
         for vid, val in zip(node.inputs, inputs):
             k = prod.get(vid)
-            if isinstance(val, DeviceArray) and k is not None and (seg is None or seg[k] == 0):
+            if k is None or not (seg is None or seg[k] == 0):
+                continue
+            if isinstance(val, DeferredReduce):
+                join_ptr = 0  # unfinished partials of a segment-A kernel: the shrink launch reads them, and it cannot wait
+            elif isinstance(val, DeviceArray):
                 n = _vec_len(val.shape)
                 if n is None or n > MAX_LEN:
                     join_ptr = 0

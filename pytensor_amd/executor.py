@@ -252,6 +252,10 @@ def branch_guards(g):
     return guard, members
 
 
+class DeviceWaitExpired(RuntimeError):
+    """status bit 4: a bounded dependency wait of a cooperative linear-algebra kernel expired"""
+
+
 def raise_device_status(word: int):
     """The device error word (kernels cannot raise): bit 0 = an index was out of range
     (IndexError, like the reference's take/inc_subtensor), bit 1 = np.linalg.inv met an exactly
@@ -265,7 +269,7 @@ def raise_device_status(word: int):
     if word & 8:
         raise np.linalg.LinAlgError("Eigenvalues did not converge")
     if word & 16:
-        raise RuntimeError(
+        raise DeviceWaitExpired(
             "hip linker: a persistent linear-algebra kernel (Cholesky / triangular solve / LU panel) gave up "
             "waiting for another workgroup (not all of its workgroups were resident — another kernel holding "
             "compute units on a second stream?); PTHIP_CHOL=steps / PTHIP_TRSM=generic select the launch-per-step forms"
@@ -691,6 +695,27 @@ class HipExecutable:
         return tuple(sig)
 
     def __call__(self, *inputs):
+        try:
+            return self._call(*inputs)
+        except DeviceWaitExpired:
+            # A cooperative kernel (the LU panel exchanges a column per step among its workgroups) did not get all of its
+            # workgroups onto the device within its spin limit — another process's kernels held the compute units
+            # (several PyMC chains on one GPU).  Not an error of the graph: evaluate it again with the launch-per-step
+            # forms, which wait for nobody, and stay on them (include/pthip.h pthip_set_safe_mode).
+            lib = ffi.lib()
+            if lib.pthip_set_safe_mode(1):
+                raise  # already on the launch-per-step forms: something else is wrong
+            import warnings
+
+            warnings.warn("hip linker: a cooperative linear-algebra kernel gave up waiting for its own workgroups (the device is shared "
+                          "with other work); evaluating again with the launch-per-step forms and staying on them for this process",
+                          RuntimeWarning, stacklevel=2)
+            if self._auto_plan is not None:
+                self._auto_plan.close()  # (captured with the cooperative kernels)
+                self._auto_plan = None
+            return self._call_eager(*inputs)
+
+    def _call(self, *inputs):
         if self.auto_freeze:
             if self._auto_plan is not None:
                 # the plan checks the signature of what it is given itself (before launching

@@ -158,6 +158,7 @@ SIGNATURES = {
     "pthip_all_reduce": (_int, [_int, _int, _i64, _vp]),
     "pthip_check_status": (_int, [C.POINTER(_int)]),
     "pthip_status_ptr": (_vp, []),
+    "pthip_set_safe_mode": (_int, [_int]),
 }
 
 

@@ -77,6 +77,11 @@ def fuse_elemwise_reduce(g: Graph) -> Graph:
 
 
 LATENCY_OPS = {"Cholesky", "SolveTriangular", "CholeskySolve", "Blockwise", "CholeskyTrsv"}
+_VIEW_OPS = {"DimShuffle", "Subtensor", "Shape_i", "ScalarFromTensor"}
+_WIDE_STREAM = __import__("os").environ.get("PTHIP_WIDE_STREAM", "0") == "1"
+if _WIDE_STREAM:
+    # experiment: the ALU-bound many-term launch on the second stream, beside the HBM-bound one-pass kernel
+    LATENCY_OPS = LATENCY_OPS | {"MultiElemwise"}
 
 
 def stream_classes(g: Graph, staged_inputs=()):
@@ -86,6 +91,10 @@ def stream_classes(g: Graph, staged_inputs=()):
     var_cls = {}
     for n in g.nodes:
         parents = [var_cls[v] for v in n.inputs if v in var_cls]
+        if _WIDE_STREAM and n.op in _VIEW_OPS and not parents:
+            # a view of a graph input launches nothing and orders nothing: it takes the side of whoever reads it
+            cls.append(1)
+            continue  # (its outputs stay out of var_cls: readers see no parent)
         c = 1 if (n.op in LATENCY_OPS or (parents and all(p == 1 for p in parents))) else 0
         cls.append(c)
         for o in n.outputs:
@@ -147,6 +156,8 @@ def segment_graph(g: Graph):
             p = produced_by.get(v)
             if p is None:
                 continue
+            if _WIDE_STREAM and g.nodes[p].op in _VIEW_OPS and not any(u in produced_by for u in g.nodes[p].inputs):
+                continue  # (a view of a graph input: no ancestry on either side)
             anc0[k] = anc0[k] or anc0[p] or cls[p] == 0
             anc1[k] = anc1[k] or anc1[p] or cls[p] == 1
     seg = []

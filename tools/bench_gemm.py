@@ -39,6 +39,9 @@ def main():
         ("float32", 1, 4096, 4096, 4096), ("float32", 1, 8192, 8192, 1024), ("float32", 512, 256, 256, 256),
         ("float32", 64, 1024, 1024, 256), ("float64", 1, 4096, 4096, 4096), ("float32", 1, 64, 2048, 1024),
         ("float32", 1, 64000, 1024, 1024),  # the hoisted x_t @ W of config #5 (T*B rows)
+        # mid-size fp64 products (the solve steps of the blocked triangular solve, GP graphs): 64 x 64 tiles since round 5
+        ("float64", 1, 512, 2048, 512), ("float64", 1, 1024, 1024, 1024), ("float64", 1, 512, 512, 512), ("float64", 1, 256, 2048, 256),
+        ("float64", 1, 1024, 2048, 1024), ("float64", 1, 2048, 2048, 2048),
     ]
     if len(sys.argv) > 1:  # indices of the shapes to run (profiling one kernel at a time)
         shapes = [shapes[int(a)] for a in sys.argv[1:]]
