@@ -223,6 +223,73 @@ def _acc_ctype(op, acc):
     return f"pthip_dev::pt_lse<{CTYPE[acc]}>" if op == "LogSumExp" else CTYPE[acc]
 
 
+def _lse_combine(L, k, T, sct, row_kept, inner_kept, TX, TY):
+    """Fold the per-thread (max, scaled sum) pairs of a log-sum-exp output and store log(s) + m.  Never a butterfly of
+    pair MERGES (two exps per lane and step — for 8192 x 2048 fp64 the combine cost more than the pass over the data):
+    the maximum first (a plain butterfly), ONE rescale of each lane's sum to it, then a plain sum."""
+    ex = "pt_exp" if T == "double" else "pthip_dev::lse_exp"
+    lg = "pthip_dev::lse_log"
+    mx, ad = "pthip_dev::OpMax", "pthip_dev::OpAdd"
+    NW = BLOCK // 64
+
+    def lanes(var_m, var_s, width, ind):  # fold (var_m, var_s) over `width` consecutive lanes (width <= 64, a power of two)
+        L.append(f"{ind}{T} M_ = {var_m};")
+        L.append(f"#pragma unroll\n{ind}for (int off = {width} / 2; off > 0; off >>= 1) M_ = {mx}::apply(M_, pthip_dev::shfl_xor_any(M_, off));")
+        L.append(f"{ind}{T} S_ = {var_s} * (({var_m} == M_) ? ({T})1 : {ex}({var_m} - M_));")
+        L.append(f"#pragma unroll\n{ind}for (int off = {width} / 2; off > 0; off >>= 1) S_ += pthip_dev::shfl_xor_any(S_, off);")
+
+    if row_kept and not inner_kept:
+        if TX == BLOCK:
+            L.append(f"  __shared__ {T} smm{k}[{NW}], sms{k}[{NW}];")
+        L.append("#pragma unroll\n  for (int i = 0; i < RPT; i++) {")
+        lanes(f"acc{k}[i][0].m", f"acc{k}[i][0].s", min(TX, 64), "    ")
+        if TX == BLOCK:
+            L.append("    __syncthreads();")
+            L.append(f"    if ((threadIdx.x & 63) == 0) {{ smm{k}[threadIdx.x >> 6] = M_; sms{k}[threadIdx.x >> 6] = S_; }}")
+            L.append("    __syncthreads();")
+            L.append(f"    M_ = smm{k}[0];")
+            L.append(f"#pragma unroll\n    for (int q = 1; q < {NW}; q++) M_ = {mx}::apply(M_, smm{k}[q]);")
+            L.append(f"    S_ = 0;")
+            L.append(f"#pragma unroll\n    for (int q = 0; q < {NW}; q++) S_ += sms{k}[q] * ((smm{k}[q] == M_) ? ({T})1 : {ex}(smm{k}[q] - M_));")
+        L.append("    const long long row = rb * TR + ty + i * TY;")
+        L.append(f"    if (tx == 0 && row < R) dst{k}[ob + row * osr] = ({sct})({lg}(S_) + M_);")
+        L.append("  }")
+    elif inner_kept and not row_kept:
+        if TY > 1:
+            L.append(f"  __shared__ {T} smm{k}[TY][TC + 1], sms{k}[TY][TC + 1];")
+            L.append(f"#pragma unroll\n  for (int e = 0; e < V; e++) {{ smm{k}[ty][tx * V + e] = acc{k}[0][e].m; sms{k}[ty][tx * V + e] = acc{k}[0][e].s; }}")
+            L.append("  __syncthreads();")
+        L.append("  if (ty == 0) {")
+        L.append("    const long long col = cb * TC + (long long)tx * V;")
+        L.append("#pragma unroll\n    for (int e = 0; e < V; e++) {")
+        if TY > 1:
+            L.append(f"      {T} M_ = smm{k}[0][tx * V + e];")
+            L.append(f"      for (int y = 1; y < TY; y++) M_ = {mx}::apply(M_, smm{k}[y][tx * V + e]);")
+            L.append(f"      {T} S_ = 0;")
+            L.append(f"      for (int y = 0; y < TY; y++) S_ += sms{k}[y][tx * V + e] * ((smm{k}[y][tx * V + e] == M_) ? ({T})1 : {ex}(smm{k}[y][tx * V + e] - M_));")
+        else:
+            L.append(f"      const {T} M_ = acc{k}[0][e].m, S_ = acc{k}[0][e].s;")
+        L.append(f"      if (col + e < D) dst{k}[ob + (col + e) * osi] = ({sct})({lg}(S_) + M_);")
+        L.append("    }")
+        L.append("  }")
+    elif not row_kept and not inner_kept:
+        L.append(f"  __shared__ {T} smm{k}[{NW}], sms{k}[{NW}];")
+        L.append("  {")
+        lanes(f"acc{k}[0][0].m", f"acc{k}[0][0].s", 64, "    ")
+        L.append(f"    if ((threadIdx.x & 63) == 0) {{ smm{k}[threadIdx.x >> 6] = M_; sms{k}[threadIdx.x >> 6] = S_; }}")
+        L.append("    __syncthreads();")
+        L.append("    if (threadIdx.x == 0) {")
+        L.append(f"      M_ = smm{k}[0];")
+        L.append(f"#pragma unroll\n      for (int q = 1; q < {NW}; q++) M_ = {mx}::apply(M_, smm{k}[q]);")
+        L.append("      S_ = 0;")
+        L.append(f"#pragma unroll\n      for (int q = 0; q < {NW}; q++) S_ += sms{k}[q] * ((smm{k}[q] == M_) ? ({T})1 : {ex}(smm{k}[q] - M_));")
+        L.append(f"      dst{k}[ob] = ({sct})({lg}(S_) + M_);")
+        L.append("    }")
+        L.append("  }")
+    else:
+        raise ValueError("nothing reduced in the tile")
+
+
 def tile_reduce_params(body, cls, nkb, nrd, outs):
     P = ["long long R", "long long D", "long long nrb", "long long ncb", "long long iters", "long long chunk", "long long ps_split"]
     P += [f"long long kb{j}" for j in range(nkb)] + [f"long long rd{j}" for j in range(nrd)]
@@ -238,7 +305,7 @@ def tile_reduce_params(body, cls, nkb, nrd, outs):
     return P
 
 
-def tile_reduce_source(name: str, body: dict, cls: str, nkb: int, nrd: int, row_kept: bool, inner_kept: bool, V: int, TX: int, RPT: int, outs) -> str:
+def tile_reduce_source(name: str, body: dict, cls: str, nkb: int, nrd: int, row_kept: bool, inner_kept: bool, V: int, TX: int, RPT: int, outs, ui: int = 0) -> str:
     """``out[kept] = reduce_{reduced} body(operands)`` — CAReduce over an axis tuple (pytensor/tensor/elemwise.py:1233,
     perform 1493-1511; the reference's C loop nest: elemwise.py:1520-1678, elemwise_cgen.py:467-761), any operand
     strides, with the scalar graph of a producing ``Elemwise`` evaluated on the fly.
@@ -298,7 +365,7 @@ def tile_reduce_source(name: str, body: dict, cls: str, nkb: int, nrd: int, row_
     L.append("  long long it1 = (split + 1) * chunk; it1 = it1 < iters ? it1 : iters;")
     # UI tile visits per trip: the loads of all of them are issued before the first scalar graph runs (a visit of a
     # one-row tile is ONE pack per thread and operand; the chip needs ~64 KB in flight per CU)
-    UI = max(1, 8 // RPT)
+    UI = int(ui) or max(1, 8 // RPT)
     L.append(f"  constexpr int UI = {UI};")
     L.append("  for (long long it = split * chunk; it < it1; it += UI) {")
     L.append("    bool ok[UI][RPT];")
@@ -369,6 +436,13 @@ def tile_reduce_source(name: str, body: dict, cls: str, nkb: int, nrd: int, row_
     L.append("    }")
     # (the machine scheduler would otherwise sink every request next to its first use)
     L.append("    __builtin_amdgcn_sched_barrier(0);")
+    # log-sum-exp outputs: the visit's values are kept (an element the tile does not cover counts as -inf: exp = 0) and
+    # folded per accumulator in two steps — the local maximum, then INDEPENDENT exps against it (they pipeline), then one
+    # merge into the running pair.  Pushing element by element is a chain of dependent exps per accumulator: measured 71 us
+    # for 8192 x 2048 fp64 (profiles/r5q notes) against a 25 us read.
+    lse = [k for k, (op, _, _) in enumerate(outs) if op == "LogSumExp"]
+    for k in lse:
+        L.append(f"    {CTYPE[outs[k][1]]} lv{k}[UI][RPT][V];")
     L.append("#pragma unroll\n    for (int w = 0; w < UI; w++) {")
     L.append("#pragma unroll\n    for (int i = 0; i < RPT; i++) {")
     L.append("#pragma unroll\n      for (int e = 0; e < V; e++) {")
@@ -393,17 +467,37 @@ def tile_reduce_source(name: str, body: dict, cls: str, nkb: int, nrd: int, row_
     ia = "i" if row_kept else "0"
     ea = "e" if inner_kept else "0"
     for k, (op, acc, odt) in enumerate(outs):
-        fold = "push" if op == "LogSumExp" else "apply"  # (one more term of a log-sum-exp: one exp, not a merge of two states)
-        L.append(f"        if (ok[w][i]) acc{k}[{ia}][{ea}] = pthip_dev::{ND_REDUCE_OPS[op]}::{fold}(acc{k}[{ia}][{ea}], ({CTYPE[acc]})o{k});")
+        if op == "LogSumExp":
+            act = CTYPE[acc]
+            L.append(f"        lv{k}[w][i][e] = ok[w][i] ? ({act})o{k} : pthip_dev::Limits<{act}>::lowest();")
+        else:
+            L.append(f"        if (ok[w][i]) acc{k}[{ia}][{ea}] = pthip_dev::{ND_REDUCE_OPS[op]}::apply(acc{k}[{ia}][{ea}], ({CTYPE[acc]})o{k});")
     L.append("      }")
     L.append("    }")
     L.append("    }")
+    for k in lse:
+        act = CTYPE[outs[k][1]]
+        ex = "pt_exp" if act == "double" else "pthip_dev::lse_exp"  # (the 24-instruction fp64 exp of the prelude)
+        # members of accumulator (ia, ea): every (w, i, e) with i == ia when rows are kept, e == ea when the inner dim is
+        L.append(f"#pragma unroll\n    for (int ia = 0; ia < {NI}; ia++)")
+        L.append(f"#pragma unroll\n    for (int ea = 0; ea < {NE}; ea++) {{")
+        L.append(f"      {act} ml = acc{k}[ia][ea].m;  // the new running maximum: the old one and every member")
+        loop = ("#pragma unroll\n      for (int w = 0; w < UI; w++)\n#pragma unroll\n      for (int i = " + ("ia; i <= ia" if row_kept else "0; i < RPT") + "; i++)\n"
+                "#pragma unroll\n      for (int e = " + ("ea; e <= ea" if inner_kept else "0; e < V") + "; e++)")
+        L.append(loop + f" ml = pthip_dev::OpMax::apply(ml, lv{k}[w][i][e]);")
+        L.append(f"      {act} sl = acc{k}[ia][ea].s * ((acc{k}[ia][ea].m == ml) ? ({act})1 : {ex}(acc{k}[ia][ea].m - ml));  // the old sum, rescaled")
+        L.append(loop + f" sl += (lv{k}[w][i][e] == ml) ? ({act})1 : {ex}(lv{k}[w][i][e] - ml);  // independent exps")
+        L.append(f"      acc{k}[ia][ea] = pthip_dev::pt_lse<{act}>{{ml, sl}};")
+        L.append("    }")
     L.append("  }")
     # ---- combine + store (fixed order: deterministic) ----
     obase = " + ".join(["split * ps_split"] + [f"q{j} * oskb{j}" for j in range(nkb)])
     L.append(f"  const long long ob = {obase};")
     for k, (op, acc, odt) in enumerate(outs):
         act, opn, sct = _acc_ctype(op, acc), f"pthip_dev::{ND_REDUCE_OPS[op]}", CTYPE[odt]
+        if op == "LogSumExp":
+            _lse_combine(L, k, CTYPE[acc], sct, row_kept, inner_kept, TX, TY)
+            continue
         if row_kept and not inner_kept:
             if TX == BLOCK:
                 L.append(f"  __shared__ {act} sm{k}[{BLOCK // 64}];")

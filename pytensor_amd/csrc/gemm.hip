@@ -919,7 +919,9 @@ int launch(long long batch, long long M, long long N, long long K, T alpha, cons
     // pthip_gemm_partials consume the 128-tile slabs split_plan promises.)
     static const bool t64 = !(getenv("PTHIP_DGEMM_T64") && atoi(getenv("PTHIP_DGEMM_T64")) == 0);
     const long long t64m = (M + 63) / 64, t64n = (N + 63) / 64;
-    if (t64 && nsplit > 1 && M > 64 && t64m * t64n * batch >= 128) {
+    // (also when the 128-tiling has no split but fewer workgroups than CUs: 1024 x 2048 x 1024 ran on 128 of them, 23.7
+    //  TFLOP/s — profiles/r5q_gemm_mid.txt)
+    if (t64 && (nsplit > 1 || tiles_m * tiles_n * batch < pthip::kNumCU) && M > 64 && t64m * t64n * batch >= 128) {
       auto k64 = dgemm_kernel<AKC, BKC, false, 64>;
       const size_t sh64 = (size_t)(2 * StageD<AKC, 64>::SIZE + 2 * StageD<BKC, 64>::SIZE) * sizeof(double);
       dim3 g64((unsigned)(t64m * t64n), 1u, (unsigned)batch);

@@ -502,7 +502,8 @@ def _launch_tiled(body, ins, byvalue, cshape, cstr, outs, out_dtypes, reduce_spe
 # ---------------------------------------------------------------------------
 
 _ND_REDUCE = os.environ.get("PTHIP_ND_REDUCE", "1") != "0"
-_ND_REDUCE_WGS = int(os.environ.get("PTHIP_ND_REDUCE_WGS", 1024))  # workgroups wanted before the reduced range is split
+_ND_REDUCE_WGS = int(os.environ.get("PTHIP_ND_REDUCE_WGS", 1024))
+_LSE_INFLIGHT = int(os.environ.get("PTHIP_LSE_INFLIGHT", 8))  # (8, 16, 32 measured the same: profiles/r5t_lse_inflight.txt)  # workgroups wanted before the reduced range is split
 
 
 def reduce_plan(shape, axes, strides, dev_dtypes, ptrs, out_shape):
@@ -642,8 +643,10 @@ def launch_axis_reduce(env, body, ins, shape, axes, specs, out_shape):
     V, TX, RPT = plan["V"], plan["TX"], plan["RPT"]
     kouts = [(op, acc, (odt if final else acc)) for op, acc, odt in specs]
     okey = "_".join(f"{op[:2]}{_dtag(acc)}{_dtag(sd)}" for op, acc, sd in kouts)
-    name = f"rnd_{_body_key(body)}_{cls}_k{len(kb)}r{len(rd)}_{'K' if plan['row_kept'] else 'R'}{'K' if plan['inner_kept'] else 'R'}_v{V}_x{TX}_r{RPT}_{okey}"
-    src = codegen_tile.tile_reduce_source(name, body, cls, len(kb), len(rd), plan["row_kept"], plan["inner_kept"], V, TX, RPT, kouts)
+    # tile visits whose loads are in flight together: 8 / RPT
+    ui = max(1, min((_LSE_INFLIGHT if any(op == "LogSumExp" for op, _, _ in specs) else 8) // RPT, chunk))
+    name = f"rnd_{_body_key(body)}_{cls}_k{len(kb)}r{len(rd)}_{'K' if plan['row_kept'] else 'R'}{'K' if plan['inner_kept'] else 'R'}_v{V}_x{TX}_r{RPT}_u{ui}_{okey}"
+    src = codegen_tile.tile_reduce_source(name, body, cls, len(kb), len(rd), plan["row_kept"], plan["inner_kept"], V, TX, RPT, kouts, ui)
     fn = kernel_cache.get_function(src, name)
     args = [plan["R"], plan["D"], plan["nrb"], plan["ncb"], iters, chunk, ps_split] + [x["n"] for x in kb] + [x["n"] for x in rd]
     args += [(row["ost"] if plan["row_kept"] else 0) * ps_out, (inner["ost"] if plan["inner_kept"] else 0) * ps_out] + [x["ost"] * ps_out for x in kb]

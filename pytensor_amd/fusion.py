@@ -78,10 +78,14 @@ def fuse_elemwise_reduce(g: Graph) -> Graph:
 
 LATENCY_OPS = {"Cholesky", "SolveTriangular", "CholeskySolve", "Blockwise", "CholeskyTrsv"}
 _VIEW_OPS = {"DimShuffle", "Subtensor", "Shape_i", "ScalarFromTensor"}
+# Experiment kept behind PTHIP_WIDE_STREAM=1: a graph with a many-term launch (MultiElemwise: north_star's 48 likelihood
+# terms, ~230 us of fp64 VALU issue, little memory traffic) next to the one-pass matrix kernel (gchain: ~170 us of HBM
+# streaming, little arithmetic) looks like the pair to overlap — the many-term launch alone on the second stream, the
+# short latency chain in line with the streaming kernel.  Measured (profiles/r5s_wide_overlap.md): they do overlap and
+# it does not pay — gchain holds 230 VGPRs (two workgroups per CU); with the other launch's workgroups in the slots it
+# runs 335 us instead of 170 and the evaluation takes 0.52 ms instead of 0.49.  Default: the latency chain keeps the
+# second stream.
 _WIDE_STREAM = __import__("os").environ.get("PTHIP_WIDE_STREAM", "0") == "1"
-if _WIDE_STREAM:
-    # experiment: the ALU-bound many-term launch on the second stream, beside the HBM-bound one-pass kernel
-    LATENCY_OPS = LATENCY_OPS | {"MultiElemwise"}
 
 
 def stream_classes(g: Graph, staged_inputs=()):
@@ -89,13 +93,15 @@ def stream_classes(g: Graph, staged_inputs=()):
     scalar work hanging off it (see ``plan.StreamScheduler``)."""
     cls = []
     var_cls = {}
+    wide = _WIDE_STREAM and any(n.op == "MultiElemwise" for n in g.nodes) and any(n.op == "GemvChain" for n in g.nodes)
+    side_ops = {"MultiElemwise"} if wide else LATENCY_OPS
     for n in g.nodes:
         parents = [var_cls[v] for v in n.inputs if v in var_cls]
-        if _WIDE_STREAM and n.op in _VIEW_OPS and not parents:
+        if wide and n.op in _VIEW_OPS and not parents:
             # a view of a graph input launches nothing and orders nothing: it takes the side of whoever reads it
             cls.append(1)
             continue  # (its outputs stay out of var_cls: readers see no parent)
-        c = 1 if (n.op in LATENCY_OPS or (parents and all(p == 1 for p in parents))) else 0
+        c = 1 if (n.op in side_ops or (parents and all(p == 1 for p in parents))) else 0
         cls.append(c)
         for o in n.outputs:
             var_cls[o] = c
@@ -145,6 +151,7 @@ def segment_graph(g: Graph):
     cls = stream_classes(g)
     if not any(cls):
         return g, None
+    wide = _WIDE_STREAM and any(n.op == "MultiElemwise" for n in g.nodes) and any(n.op == "GemvChain" for n in g.nodes)
     produced_by = {}
     for k, n in enumerate(g.nodes):
         for o in n.outputs:
@@ -156,7 +163,7 @@ def segment_graph(g: Graph):
             p = produced_by.get(v)
             if p is None:
                 continue
-            if _WIDE_STREAM and g.nodes[p].op in _VIEW_OPS and not any(u in produced_by for u in g.nodes[p].inputs):
+            if wide and g.nodes[p].op in _VIEW_OPS and not any(u in produced_by for u in g.nodes[p].inputs):
                 continue  # (a view of a graph input: no ancestry on either side)
             anc0[k] = anc0[k] or anc0[p] or cls[p] == 0
             anc1[k] = anc1[k] or anc1[p] or cls[p] == 1
