@@ -319,3 +319,49 @@ def test_shape_asserts_fused_into_device_composites_go_back_to_the_host():
     # a graph without such nodes is returned as is
     g, *_ = load_case("c4_hier")
     assert hostsplit.split_host_shape_arithmetic(g) is g
+
+
+def test_stabilised_logsumexp_becomes_one_reduction():
+    """tests/benchmarks/test_logsumexp.py:9-13 after the reference's rewrites is Max, a second Max of the shifted values
+    and a Sum of Exp (three passes over X).  axisfuse: the Sum of Exp read by a Log is ONE LogSumExp reduction, the
+    shifts cancel against the additions outside, the Max reductions die."""
+    for name in ("logsumexp_axis0", "logsumexp_axis1"):
+        g, ins, cvm, py, meta = load_case(name)
+        assert [n.op for n in g.nodes].count("CAReduce") == 3
+        g2, _ = _pipeline(g)
+        ops = [n.op for n in g2.nodes]
+        assert "CAReduce" not in ops and ops.count("ElemwiseAxisReduce") == 1
+        r = next(n for n in g2.nodes if n.op == "ElemwiseAxisReduce")
+        assert [s["op"] for s in r.params["reduce"]] == ["LogSumExp"] and len(r.inputs) == 1  # reads X, nothing else
+        assert not r.params["scalar"]["body"]  # the reduced expression is X itself
+        out = np_graph.run_graph(g2, ins)
+        np.testing.assert_allclose(out[0], cvm[0], rtol=1e-13)
+
+
+def test_elemwise_feeding_axis_reductions_is_fused_per_axis_tuple():
+    g, ins, cvm, py, meta = load_case("elemwise_axis_reduce")
+    g2, _ = _pipeline(g)
+    ops = [n.op for n in g2.nodes]
+    # six row / column reductions of fused expressions (two of them outputs of ONE multi-output Elemwise over different
+    # axes: one fused node per axis tuple), no Elemwise left that stores a full-size intermediate
+    assert ops.count("ElemwiseAxisReduce") >= 5 and ops.count("Elemwise") <= 1
+    for n in g2.nodes:
+        if n.op == "ElemwiseAxisReduce":
+            assert 0 < len(n.params["axis"]) < g2.vars[n.inputs[0]].ndim
+
+
+def test_cheap_producer_is_recomputed_instead_of_stored():
+    """X - m (m a broadcast row / column) read by a Max and by an Exp/Sum: cloned per reader, never materialised"""
+    from pytensor_amd.axisfuse import duplicate_cheap_producers
+
+    g, *_ = load_case("logsumexp_axis1")
+    subs = [n for n in g.nodes if n.op == "Elemwise" and [b["op"] for b in n.params["scalar"]["body"]] == ["Sub"]]
+    assert subs, "the graph has a plain X - m"
+    g2 = duplicate_cheap_producers(g)
+    cons = {}
+    for n in g2.nodes:
+        for i in n.inputs:
+            cons[i] = cons.get(i, 0) + 1
+    for n in g2.nodes:
+        if n.op == "Elemwise" and [b["op"] for b in n.params["scalar"]["body"]] == ["Sub"]:
+            assert cons.get(n.outputs[0], 0) == 1
