@@ -98,6 +98,35 @@ PT_DEV double pt_exp(double x) {
   y = x < -0x1.74910d52d3051p+9 ? 0.0 : y;
   return y;
 }
+// The same exp with its constants held in registers by the caller (pt_expk_load once per kernel): in straight-line code with
+// dozens of exp instances (the log-sum-exp reduction: n + 1 per tile visit, fully unrolled) the compiler materialises every
+// polynomial coefficient again for every instance — v_fmac overwrites its addend, so each Horner step is two v_mov_b32 of a
+// literal plus the fmac: 44 instructions per exp instead of 24 (profiles/r5w_lse_pmc.md: 94 VALU instructions per element).
+// With the coefficients live in VGPRs across instances each step is one v_fma_f64.
+struct pt_expk { double l2e, nh, nl, c[10], hi, lo; };
+PT_DEV pt_expk pt_expk_load() {
+  pt_expk k = {0x1.71547652b82fep+0, -0x1.62e42fee00000p-1, -0x1.a39ef35793c76p-33,
+               {0x1.af38a9b0ec855p-26, 0x1.289185613a3d6p-22, 0x1.71de0dae63bb3p-19, 0x1.a019b90d2ae7ap-16, 0x1.a01a01a7c41d5p-13,
+                0x1.6c16c1788bd90p-10, 0x1.11111111109b3p-7, 0x1.5555555553d63p-5, 0x1.5555555555556p-3, 0x1.0000000000001p-1},
+               0x1.62e42fefa39efp+9, -0x1.74910d52d3051p+9};
+  asm volatile("" : "+v"(k.l2e), "+v"(k.nh), "+v"(k.nl), "+v"(k.hi), "+v"(k.lo));
+#pragma unroll
+  for (int i = 0; i < 10; i++) asm volatile("" : "+v"(k.c[i]));
+  return k;
+}
+PT_DEV double pt_exp_k(double x, const pt_expk& k) {
+  const double n = __builtin_rint(x * k.l2e);
+  double r = __builtin_fma(n, k.nh, x);
+  r = __builtin_fma(n, k.nl, r);
+  double q = k.c[0];
+#pragma unroll
+  for (int i = 1; i < 10; i++) q = __builtin_fma(q, r, k.c[i]);
+  const double p = __builtin_fma(q * r, r, r) + 1.0;
+  double y = __builtin_ldexp(p, (int)n);
+  y = x > k.hi ? __builtin_huge_val() : y;
+  y = x < k.lo ? 0.0 : y;
+  return y;
+}
 // fp64 tanh in ~45 VALU instructions (the device library's is ~85: BASELINE config #2's transcendental variant is 10 tanh + 10
 // exp per element and VALU-issue bound).  |x| < 0.35: the odd Taylor series to x^27 (coefficients 2^2n (2^2n - 1) B_2n / (2n)!
 // from mpmath at 60 digits; the first neglected term is < 2e-18 relative): 0.55 ulp on 2e4 points.  Otherwise

@@ -227,15 +227,16 @@ def _lse_combine(L, k, T, sct, row_kept, inner_kept, TX, TY):
     """Fold the per-thread (max, scaled sum) pairs of a log-sum-exp output and store log(s) + m.  Never a butterfly of
     pair MERGES (two exps per lane and step — for 8192 x 2048 fp64 the combine cost more than the pass over the data):
     the maximum first (a plain butterfly), ONE rescale of each lane's sum to it, then a plain sum."""
-    ex = "pt_exp" if T == "double" else "pthip_dev::lse_exp"
+    ex = "pt_lse_e" if T == "double" else "pthip_dev::lse_exp"
     lg = "pthip_dev::lse_log"
-    mx, ad = "pthip_dev::OpMax", "pthip_dev::OpAdd"
+    mx, ad = f"pt_lse_max{k}", "pthip_dev::OpAdd"  # (plain max: a NaN state travels in the sums)
+    L.append(f"  struct pt_lse_max{k} {{ static __device__ __forceinline__ {T} apply({T} a, {T} b) {{ return __builtin_fmax{'' if T == 'double' else 'f'}(a, b); }} }};")
     NW = BLOCK // 64
 
     def lanes(var_m, var_s, width, ind):  # fold (var_m, var_s) over `width` consecutive lanes (width <= 64, a power of two)
         L.append(f"{ind}{T} M_ = {var_m};")
         L.append(f"#pragma unroll\n{ind}for (int off = {width} / 2; off > 0; off >>= 1) M_ = {mx}::apply(M_, pthip_dev::shfl_xor_any(M_, off));")
-        L.append(f"{ind}{T} S_ = {var_s} * (({var_m} == M_) ? ({T})1 : {ex}({var_m} - M_));")
+        L.append(f"{ind}{T} S_ = {var_s} * {ex}(({var_m} == M_) ? ({T})0 : {var_m} - M_);")
         L.append(f"#pragma unroll\n{ind}for (int off = {width} / 2; off > 0; off >>= 1) S_ += pthip_dev::shfl_xor_any(S_, off);")
 
     if row_kept and not inner_kept:
@@ -250,7 +251,7 @@ def _lse_combine(L, k, T, sct, row_kept, inner_kept, TX, TY):
             L.append(f"    M_ = smm{k}[0];")
             L.append(f"#pragma unroll\n    for (int q = 1; q < {NW}; q++) M_ = {mx}::apply(M_, smm{k}[q]);")
             L.append(f"    S_ = 0;")
-            L.append(f"#pragma unroll\n    for (int q = 0; q < {NW}; q++) S_ += sms{k}[q] * ((smm{k}[q] == M_) ? ({T})1 : {ex}(smm{k}[q] - M_));")
+            L.append(f"#pragma unroll\n    for (int q = 0; q < {NW}; q++) S_ += sms{k}[q] * {ex}((smm{k}[q] == M_) ? ({T})0 : smm{k}[q] - M_);")
         L.append("    const long long row = rb * TR + ty + i * TY;")
         L.append(f"    if (tx == 0 && row < R) dst{k}[ob + row * osr] = ({sct})({lg}(S_) + M_);")
         L.append("  }")
@@ -266,7 +267,7 @@ def _lse_combine(L, k, T, sct, row_kept, inner_kept, TX, TY):
             L.append(f"      {T} M_ = smm{k}[0][tx * V + e];")
             L.append(f"      for (int y = 1; y < TY; y++) M_ = {mx}::apply(M_, smm{k}[y][tx * V + e]);")
             L.append(f"      {T} S_ = 0;")
-            L.append(f"      for (int y = 0; y < TY; y++) S_ += sms{k}[y][tx * V + e] * ((smm{k}[y][tx * V + e] == M_) ? ({T})1 : {ex}(smm{k}[y][tx * V + e] - M_));")
+            L.append(f"      for (int y = 0; y < TY; y++) S_ += sms{k}[y][tx * V + e] * {ex}((smm{k}[y][tx * V + e] == M_) ? ({T})0 : smm{k}[y][tx * V + e] - M_);")
         else:
             L.append(f"      const {T} M_ = acc{k}[0][e].m, S_ = acc{k}[0][e].s;")
         L.append(f"      if (col + e < D) dst{k}[ob + (col + e) * osi] = ({sct})({lg}(S_) + M_);")
@@ -282,7 +283,7 @@ def _lse_combine(L, k, T, sct, row_kept, inner_kept, TX, TY):
         L.append(f"      M_ = smm{k}[0];")
         L.append(f"#pragma unroll\n      for (int q = 1; q < {NW}; q++) M_ = {mx}::apply(M_, smm{k}[q]);")
         L.append("      S_ = 0;")
-        L.append(f"#pragma unroll\n      for (int q = 0; q < {NW}; q++) S_ += sms{k}[q] * ((smm{k}[q] == M_) ? ({T})1 : {ex}(smm{k}[q] - M_));")
+        L.append(f"#pragma unroll\n      for (int q = 0; q < {NW}; q++) S_ += sms{k}[q] * {ex}((smm{k}[q] == M_) ? ({T})0 : smm{k}[q] - M_);")
         L.append(f"      dst{k}[ob] = ({sct})({lg}(S_) + M_);")
         L.append("    }")
         L.append("  }")
@@ -362,6 +363,9 @@ def tile_reduce_source(name: str, body: dict, cls: str, nkb: int, nrd: int, row_
         else:
             off = " + ".join(f"q{j} * s{k}_kb{j}" for j in range(nkb)) or "0"
             L.append(f"  const {ct}* __restrict__ pk{k} = in{k} + ({off});")
+    if any(op == "LogSumExp" and acc == "float64" for op, acc, _ in outs):
+        L.append("  const pt_expk pt_ek = pt_expk_load();  // the exp's constants, in registers for every instance below")
+        L.append("  auto pt_lse_e = [&](double x) { return pt_exp_k(x, pt_ek); };")
     L.append("  long long it1 = (split + 1) * chunk; it1 = it1 < iters ? it1 : iters;")
     # UI tile visits per trip: the loads of all of them are issued before the first scalar graph runs (a visit of a
     # one-row tile is ONE pack per thread and operand; the chip needs ~64 KB in flight per CU)
@@ -477,16 +481,19 @@ def tile_reduce_source(name: str, body: dict, cls: str, nkb: int, nrd: int, row_
     L.append("    }")
     for k in lse:
         act = CTYPE[outs[k][1]]
-        ex = "pt_exp" if act == "double" else "pthip_dev::lse_exp"  # (the 24-instruction fp64 exp of the prelude)
+        ex = "pt_lse_e" if act == "double" else "pthip_dev::lse_exp"  # (the 24-instruction fp64 exp of the prelude, constants in registers)
         # members of accumulator (ia, ea): every (w, i, e) with i == ia when rows are kept, e == ea when the inner dim is
         L.append(f"#pragma unroll\n    for (int ia = 0; ia < {NI}; ia++)")
         L.append(f"#pragma unroll\n    for (int ea = 0; ea < {NE}; ea++) {{")
         L.append(f"      {act} ml = acc{k}[ia][ea].m;  // the new running maximum: the old one and every member")
         loop = ("#pragma unroll\n      for (int w = 0; w < UI; w++)\n#pragma unroll\n      for (int i = " + ("ia; i <= ia" if row_kept else "0; i < RPT") + "; i++)\n"
                 "#pragma unroll\n      for (int e = " + ("ea; e <= ea" if inner_kept else "0; e < V") + "; e++)")
-        L.append(loop + f" ml = pthip_dev::OpMax::apply(ml, lv{k}[w][i][e]);")
-        L.append(f"      {act} sl = acc{k}[ia][ea].s * ((acc{k}[ia][ea].m == ml) ? ({act})1 : {ex}(acc{k}[ia][ea].m - ml));  // the old sum, rescaled")
-        L.append(loop + f" sl += (lv{k}[w][i][e] == ml) ? ({act})1 : {ex}(lv{k}[w][i][e] - ml);  // independent exps")
+        # (a plain max: a NaN member is skipped here and reaches the result through exp(NaN - ml) in the sum — the
+        #  NaN-propagating OpMax is three compares and six selects per element)
+        L.append(loop + f" ml = __builtin_fmax{'' if act == 'double' else 'f'}(ml, lv{k}[w][i][e]);")
+        # (x == ml -> exponent 0 -> exactly 1: covers equal infinities, whose difference is NaN, without a branch around the exp)
+        L.append(f"      {act} sl = acc{k}[ia][ea].s * {ex}((acc{k}[ia][ea].m == ml) ? ({act})0 : acc{k}[ia][ea].m - ml);  // the old sum, rescaled")
+        L.append(loop + f" sl += {ex}((lv{k}[w][i][e] == ml) ? ({act})0 : lv{k}[w][i][e] - ml);  // independent exps")
         L.append(f"      acc{k}[ia][ea] = pthip_dev::pt_lse<{act}>{{ml, sl}};")
         L.append("    }")
     L.append("  }")

@@ -503,6 +503,7 @@ def _launch_tiled(body, ins, byvalue, cshape, cstr, outs, out_dtypes, reduce_spe
 
 _ND_REDUCE = os.environ.get("PTHIP_ND_REDUCE", "1") != "0"
 _ND_REDUCE_WGS = int(os.environ.get("PTHIP_ND_REDUCE_WGS", 1024))
+_RED_RPT = int(os.environ.get("PTHIP_RED_RPT", 0))  # rows per thread of the reduction tiles (0: as the elementwise tiles)
 _LSE_INFLIGHT = int(os.environ.get("PTHIP_LSE_INFLIGHT", 8))  # (8, 16, 32 measured the same: profiles/r5t_lse_inflight.txt)  # workgroups wanted before the reduced range is split
 
 
@@ -592,7 +593,7 @@ def reduce_plan(shape, axes, strides, dev_dtypes, ptrs, out_shape):
     else:
         TX = BLOCK if cols >= BLOCK else min(64, _pow2ceil(cols))
     TY = BLOCK // TX
-    RPT = max(1, min(max(_TILE_RPT, 8 // V), -(-R // TY)))
+    RPT = max(1, min(_RED_RPT or max(_TILE_RPT, 8 // V), -(-R // TY)))
     TC, TR = TX * V, TY * RPT
     nrb, ncb = -(-R // TR), -(-D // TC)
     n_nat = int(np.prod([x["n"] for x in kb], dtype=np.int64)) * (nrb if row_kept else 1) * (ncb if inner_kept else 1)
