@@ -215,3 +215,16 @@ def linalg_contention():
     A = rng.normal(size=(n, n + 3))
     return [S, Tm, b, M], [cholesky(S), solve_triangular(Tm, b, lower=True), det(M)], {
         "S": A @ A.T / n + np.eye(n), "Tm": np.tril(rng.normal(size=(n, n))) + 3 * np.eye(n), "b": rng.normal(size=n), "M": rng.normal(size=(n, n)) + 2 * np.eye(n)}
+
+
+@case("c4_hier_f32", rtol=2e-4)
+def c4_hier_f32():
+    # config #4's model as a floatX=float32 user builds it: Gemv / Elemwise / scatter in float32 (the one-pass kernel's
+    # float32 instance, dispatch/fused.py); the reference's float32 sums over 3000 terms set the tolerance
+    from pytensor_amd import configs
+    from ref_graphs import build_c4
+
+    v = configs.c4_inputs(N=3000, K=32, G=16)
+    vals = {k: (np.asarray(a, dtype="float32") if np.asarray(a).dtype.kind == "f" else a) for k, a in v.items()}
+    ins, outs = build_c4(vals, dtype="float32")
+    return ins, outs, vals

@@ -947,7 +947,8 @@ def _gemv_chain(p, inputs, node, graph):
 def _gemv_finish(p, inputs, node, graph):
     part, y2, a2, b2 = inputs
     s = part.sum(axis=0)
-    return [np.asarray((a2 * s if b2 == 0.0 else b2 * y2 + a2 * s), dtype=part.dtype)]
+    # (the slabs of a float32 chain are float64: the node's value has the dtype the graph gives its output)
+    return [np.asarray((a2 * s if b2 == 0.0 else b2 * y2 + a2 * s), dtype=graph.vars[node.outputs[0]].dtype)]
 
 
 @op("SeqDot22")

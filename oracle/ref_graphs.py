@@ -10,13 +10,16 @@ from __future__ import annotations
 import numpy as np
 
 
-def build_c4(vals):
+def build_c4(vals, dtype="float64"):
     """BASELINE configs[3]: hierarchical-normal logp + grad; data as shared
-    variables, parameters as explicit inputs.  Returns (params, outputs)."""
+    variables, parameters as explicit inputs.  Returns (params, outputs).  ``dtype="float32"``: the same model as a
+    ``floatX=float32`` user would build it (values cast by the caller)."""
     import pytensor
     import pytensor.tensor as pt
     from pytensor.tensor.linalg import cholesky, solve_triangular
 
+    if dtype != "float64":
+        return _build_c4_typed(vals, dtype)
     K = vals["X"].shape[1]
     y = pytensor.shared(vals["y"], name="y")
     X = pytensor.shared(vals["X"], name="X")
@@ -72,3 +75,32 @@ def build_wide200(vals, T=None):
         total = total + t
     params = [*params, wmu, wls]
     return params, [total, *pytensor.grad(total, params)]
+
+
+def _build_c4_typed(vals, dtype):
+    import pytensor
+    import pytensor.tensor as pt
+    from pytensor.tensor.linalg import cholesky, solve_triangular
+
+    f = lambda a: np.asarray(a, dtype=dtype)
+    K = vals["X"].shape[1]
+    y = pytensor.shared(f(vals["y"]), name="y")
+    X = pytensor.shared(f(vals["X"]), name="X")
+    gidx = pytensor.shared(vals["gidx"], name="gidx")
+    Sigma = pytensor.shared(f(vals["Sigma"]), name="Sigma")
+    mu_g, log_tau, log_sigma = (pt.scalar(n, dtype=dtype) for n in ("mu_g", "log_tau", "log_sigma"))
+    z, beta = pt.vector("z", dtype=dtype), pt.vector("beta", dtype=dtype)
+    c = lambda v: np.asarray(v, dtype=dtype)
+    tau, sigma = pt.exp(log_tau), pt.exp(log_sigma)
+    a = mu_g + tau * z
+    L = cholesky(Sigma)
+    alpha = solve_triangular(L, beta, lower=True)
+    logp_beta = c(-0.5) * pt.sum(alpha**2) - pt.sum(pt.log(pt.diag(L))) - c(0.5 * K * np.log(2 * np.pi))
+    eta = a[gidx] + X @ beta
+    r = (y - eta) / sigma
+    logp_y = pt.sum(c(-0.5) * r**2 - log_sigma - c(0.5 * np.log(2 * np.pi)))
+    logp_z = pt.sum(c(-0.5) * z**2 - c(0.5 * np.log(2 * np.pi)))
+    logp_hyp = c(-0.5) * (mu_g**2 + log_tau**2 + log_sigma**2)
+    logp = logp_y + logp_z + logp_beta + logp_hyp
+    params = [mu_g, log_tau, z, beta, log_sigma]
+    return params, [logp, *pytensor.grad(logp, params)]

@@ -1494,7 +1494,7 @@ def nd_kernel_source(name: str, body: dict, ndim: int, reduce_spec=None, partial
 
 
 def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, has_y1,
-                      out_store=None, scatter_out=None, scatter_groups=2, pack=2) -> str:
+                      out_store=None, scatter_out=None, scatter_groups=2, pack=2, atype="float64") -> str:
     """One-pass ``r = b1*y1 + a1*A@x ; outs = body(.., r, ..) ; partial += A.T@w`` (fp64).
 
     Work decomposition (wave64): a wave owns groups of ``RG`` consecutive rows.  Lane l
@@ -1522,6 +1522,11 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
     ``x`` lives in LDS instead of registers, and fewer rows ride per group (``RG`` = 2: K <= 2048, 1: K <= 4096) so that
     the row registers (``RG*C`` <= 32 packs) and the ``A.T@w`` accumulators (``C`` packs) still fit.
 
+    ``atype`` = "float32": the matrix, ``x``, ``y1`` and the stored Gemv result are float arrays — converted on load
+    (an 8-byte ``float2`` per lane and chunk with ``pack`` = 2), everything between the loads and the stores stays the
+    double-precision kernel (dot products, butterfly, ``A.T@w`` accumulators, partial slabs); the scalar graph gets the
+    Gemv result rounded to float, as the reference's float32 ``Gemv`` output would be.
+
     ``e_modes[k]`` ∈ {'R' the Gemv result, 'V' N-vector, 'S' scalar, 'G' gather
     ``table[gidx[row]]``} per elementwise input.
     Kernel params (all 8 bytes): N, K, A, lda, x, y1, alpha1, beta1, <per elementwise input
@@ -1533,20 +1538,37 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
     nout = len(body["out_dtypes"])
     out_store = list(out_store) if out_store is not None else [True] * nout
     lg = int(math.log2(RG))
-    assert 1 << lg == RG and 1 <= RG <= 32 and RG * C <= 32 and pack in (1, 2)
+    assert 1 << lg == RG and 1 <= RG <= 32 and RG * C <= 32 and pack in (1, 2, 4)
+    assert pack != 4 or (atype == "float32" and C % 2 == 0)
     b_lds = C > 8
-    col0 = "c * 128 + 2 * lane" if pack == 2 else "c * 128 + lane"  # first column of lane's pack in chunk c
-    col1 = "c * 128 + 2 * lane + 1" if pack == 2 else "c * 128 + 64 + lane"
+    if pack == 4:
+        # float32 only: a lane's 16-byte load is FOUR columns {4l .. 4l+3} of a 256-column chunk PAIR; the two halves are
+        # chunks c (even) and c + 1 of the double-precision register image.  (8-byte loads — float2 per lane — fetch the
+        # same bytes per instruction and run 2.6x slower: the waves sit at s_waitcnt 6x as long, profiles/r6a_gchain_f32_pmc.md)
+        col0 = "(c >> 1) * 256 + 4 * lane + 2 * (c & 1)"
+        col1 = col0 + " + 1"
+    else:
+        col0 = "c * 128 + 2 * lane" if pack == 2 else "c * 128 + lane"  # first column of lane's pack in chunk c
+        col1 = "c * 128 + 2 * lane + 1" if pack == 2 else "c * 128 + 64 + lane"
 
-    def ld_pack(base):  # the lane's two columns of chunk c from `base` (a double pointer)
+    at = CTYPE[atype]
+
+    def ld_pack(base, stream=True):  # the lane's two columns of chunk c from `base` (a pointer to `atype`)
+        if pack == 2 and atype == "float64":
+            ld = _stream_load(f"(const pt_d2*)({base} + {col0})") if stream else f"*(const pt_d2*)({base} + {col0})"
+            return f"(({col0}) < K) ? {ld} : (pt_d2){{0.0, 0.0}}"
         if pack == 2:
-            return f"(({col0}) < K) ? " + _stream_load(f"(const pt_d2*)({base} + {col0})") + " : (pt_d2){0.0, 0.0}"
-        return f"(pt_d2){{(({col0}) < K) ? {base}[{col0}] : 0.0, (({col1}) < K) ? {base}[{col1}] : 0.0}}"
+            ld = _stream_load(f"(const pt_f2*)({base} + {col0})") if stream else f"*(const pt_f2*)({base} + {col0})"
+            return f"(({col0}) < K) ? pt_widen({ld}) : (pt_d2){{0.0, 0.0}}"
+        if pack == 4 and not stream:  # (the short multiplier vector: element loads)
+            return f"(pt_d2){{(({col0}) < K) ? (double){base}[{col0}] : 0.0, (({col1}) < K) ? (double){base}[{col1}] : 0.0}}"
+        assert pack != 4, "the matrix rows of the four-column form are loaded pairwise (below)"
+        return f"(pt_d2){{(({col0}) < K) ? (double){base}[{col0}] : 0.0, (({col1}) < K) ? (double){base}[{col1}] : 0.0}}"
 
     rest = 6 - lg  # plain butterfly steps after the transposing ones
     params = [
-        "long long N", "long long K", "const double* __restrict__ A", "long long lda",
-        "const double* __restrict__ x", "const double* __restrict__ y1", "double alpha1", "double beta1",
+        "long long N", "long long K", f"const {CTYPE[atype]}* __restrict__ A", "long long lda",
+        f"const {CTYPE[atype]}* __restrict__ x", f"const {CTYPE[atype]}* __restrict__ y1", "double alpha1", "double beta1",
     ]
     for k, m in enumerate(e_modes):
         if m == "R":
@@ -1555,7 +1577,7 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
         if m == "G":
             params += [f"const long long* __restrict__ gidx{k}", f"long long glen{k}"]
     if store_r:
-        params.append("double* __restrict__ r_out")
+        params.append(f"{CTYPE[atype]}* __restrict__ r_out")
     for k, dt in enumerate(body["out_dtypes"]):
         if reduce_spec[k] is not None:
             params.append(f"{CTYPE[reduce_spec[k][1]]}* __restrict__ part{k}")
@@ -1567,6 +1589,9 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
     params.append("int* __restrict__ status")
     L = [reduce_header(), prelude_for(body)]
     L.append("typedef double pt_d2 __attribute__((ext_vector_type(2)));")
+    L.append("typedef float pt_f2 __attribute__((ext_vector_type(2)));")
+    L.append("typedef float pt_f4 __attribute__((ext_vector_type(4)));")
+    L.append("static __device__ __forceinline__ pt_d2 pt_widen(pt_f2 v) { return (pt_d2){(double)v.x, (double)v.y}; }")
     L.append("static __device__ __forceinline__ double pt_shfl_xor(double v, int m) { return pthip_dev::shfl_xor_any(v, m); }")
     L.append("static __device__ __forceinline__ double pt_readlane(double v, int l) {")
     L.append("  union { double d; int i[2]; } u; u.d = v;")
@@ -1581,14 +1606,14 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
         # the multiplier vector: read per use (registers hold the rows and the accumulators); it lives in the memory the
         # block combine uses after the row loop
         L.append("  pt_d2 (*b)[64] = reinterpret_cast<pt_d2 (*)[64]>(&redT[0][0]);")
-        L.append(f"  for (int j = threadIdx.x; j < C * 64; j += {BLOCK}) {{ const int c = j >> 6, lane = j & 63; b[c][lane] = " + ld_pack("x").replace(_stream_load("(const pt_d2*)(x + " + col0 + ")"), "*(const pt_d2*)(x + " + col0 + ")") + "; }")
+        L.append(f"  for (int j = threadIdx.x; j < C * 64; j += {BLOCK}) {{ const int c = j >> 6, lane = j & 63; b[c][lane] = " + ld_pack("x", stream=False) + "; }")
         L.append("  __syncthreads();")
         L.append("#pragma unroll\n  for (int c = 0; c < C; c++) accT[c] = (pt_d2){0.0, 0.0};")
         bref = "b[c][lane]"
     else:
         L.append("  pt_d2 b[C];")
         L.append("#pragma unroll\n  for (int c = 0; c < C; c++) {")
-        L.append("    b[c] = " + ld_pack("x").replace(_stream_load("(const pt_d2*)(x + " + col0 + ")"), "*(const pt_d2*)(x + " + col0 + ")") + ";")
+        L.append("    b[c] = " + ld_pack("x", stream=False) + ";")
         L.append("    accT[c] = (pt_d2){0.0, 0.0};\n  }")
         bref = "b[c]"
     if scatter_out is not None:
@@ -1610,9 +1635,17 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
     L.append("    pt_d2 xr[RG][C];")
     L.append("#pragma unroll\n    for (int r = 0; r < RG; r++) {")
     L.append("      const long long row = (row0 + r < N) ? row0 + r : N - 1;")
-    L.append("      const double* __restrict__ Ar = A + row * lda;")
-    L.append("#pragma unroll\n      for (int c = 0; c < C; c++) {")
-    L.append("        xr[r][c] = " + ld_pack("Ar") + ";\n      }\n    }")
+    L.append(f"      const {at}* __restrict__ Ar = A + row * lda;")
+    if pack == 4:
+        L.append("#pragma unroll\n      for (int c = 0; c < C; c += 2) {")
+        L.append("        const long long cq = (c >> 1) * 256 + 4 * lane;")
+        L.append("        pt_f4 t4 = {0.f, 0.f, 0.f, 0.f};")
+        L.append("        if (cq < K) t4 = " + _stream_load("(const pt_f4*)(Ar + cq)") + ";  // (K % 4 == 0: a pack is inside the row or outside)")
+        L.append("        xr[r][c] = (pt_d2){(double)t4.x, (double)t4.y};")
+        L.append("        xr[r][c + 1] = (pt_d2){(double)t4.z, (double)t4.w};\n      }\n    }")
+    else:
+        L.append("#pragma unroll\n      for (int c = 0; c < C; c++) {")
+        L.append("        xr[r][c] = " + ld_pack("Ar") + ";\n      }\n    }")
     L.append("    double p[RG];")
     L.append("#pragma unroll\n    for (int r = 0; r < RG; r++) {")
     L.append("      double s = 0.0;")
@@ -1642,7 +1675,7 @@ def gemv_chain_source(name, body, e_modes, reduce_spec, w_out, C, RG, store_r, h
     in_names = []
     for k, m in enumerate(e_modes):
         if m == "R":
-            in_names.append("res")
+            in_names.append("res" if body["in_dtypes"][k] == "float64" else f"(({CTYPE[body['in_dtypes'][k]]})res)")
         elif m == "S":
             in_names.append(f"s{k}")
         elif m == "G":

@@ -70,11 +70,15 @@ class _Bins:
 def _fast_ok(A, x1, y1, e_vals, sidx, base, N, K):
     if os.environ.get("PTHIP_GCHAIN_FAST", "1") == "0":  # (measurements: the unfused launches beside the one-pass kernel)
         return False
-    if str(A.dtype) != "float64" or A.ndim != 2 or A.strides[1] != 1 or A.ptr % 8:
+    if str(A.dtype) not in ("float64", "float32") or A.ndim != 2 or A.strides[1] != 1 or A.ptr % A.itemsize:
         return False
     if K > MAX_CHAIN_K or K == 0 or N == 0:
         return False
-    if not x1.is_contiguous() or x1.ptr % 8 or str(x1.dtype) != "float64":
+    if not x1.is_contiguous() or x1.dtype != A.dtype or (y1 is not None and y1.dtype != A.dtype):
+        return False
+    if str(A.dtype) == "float32" and (K % 4 or A.strides[0] % 4 or A.ptr % 16):
+        # float32 rows that cannot be read in 16-byte packs: 4- and 8-byte loads per lane make the one pass slower than
+        # the two unfused ones (K = 127: 1.04 ms against 0.68, profiles/r6b_gchain_f32_sweep.txt)
         return False
     if y1 is not None and (not y1.is_contiguous() or y1.shape != (N,)):
         return False
@@ -125,13 +129,20 @@ def gemv_chain(node, inputs, env):
         if spec[scatter_pos] is not None:
             return _fallback(node, env, alpha1, A, x1, beta1, y1d, e_vals, sidx, base)  # (a reduced AND scattered output: not a shape the passes produce)
     C = (K + 127) // 128
+    f32x4 = (str(A.dtype) == "float32" and K % 4 == 0 and A.strides[0] % 4 == 0 and A.ptr % 16 == 0 and os.environ.get("PTHIP_GCHAIN_F32X4", "1") != "0")
+    if f32x4:
+        C = 2 * ((K + 255) // 256)  # 16-byte loads of four float columns: chunk PAIRS of 256 columns
     RG = CHAIN_RG or 32
     while RG * C > 32 and RG > 1:  # rows per group: the row registers hold RG*C <= 32 packs (K <= 1024: >= 4 rows; 2048: 2; 4096: 1)
         RG //= 2
     # 16-byte packs need every row to start on a 16-byte boundary; otherwise two 8-byte loads per chunk (odd K, odd lda)
     # (K <= 64 leaves half the lanes of the one chunk without a pack; a column per lane instead measured slower:
     #  K = 64: 238 us with packs, 262 us with 8-byte loads on all lanes — profiles/r5_gchain_sweep.txt)
-    pack = 2 if (K % 2 == 0 and A.strides[0] % 2 == 0 and A.ptr % 16 == 0 and x1.ptr % 16 == 0) else 1
+    pk_bytes = 2 * A.itemsize  # (a pack = two elements of the matrix: 16 bytes of fp64, 8 of fp32)
+    pack = 2 if (K % 2 == 0 and A.strides[0] % 2 == 0 and A.ptr % pk_bytes == 0 and x1.ptr % pk_bytes == 0) else 1
+    atype = str(A.dtype)
+    if f32x4:
+        pack = 4
     e_modes = []
     for pos, v in enumerate(e_vals):
         if v is None:
@@ -145,13 +156,13 @@ def gemv_chain(node, inputs, env):
     skey = "".join("1" if s else "0" for s in out_store)
     name = (
         f"gchain_{_body_key(body)}_{''.join(e_modes)}_{rkey}_w{w_out}_c{C}_g{RG}_{int(store_r)}{int(y1d is not None)}"
-        f"_s{skey}_{'n' if scatter_out is None else scatter_out}" + ("" if pack == 2 else "_p1")
+        f"_s{skey}_{'n' if scatter_out is None else scatter_out}" + ("" if pack == 2 else f"_p{pack}") + ("" if atype == "float64" else "_f32")
     ).replace("-", "x")
     sgroups = 2
     if scatter_out is not None:
         sgroups = max(1, (base.shape[0] + 63) // 64)
         name += f"_b{sgroups}"
-    src = codegen.gemv_chain_source(name, body, e_modes, rs, w_out, C, RG, store_r, y1d is not None, out_store, scatter_out, sgroups, pack)
+    src = codegen.gemv_chain_source(name, body, e_modes, rs, w_out, C, RG, store_r, y1d is not None, out_store, scatter_out, sgroups, pack, atype)
     fn = kernel_cache.get_function(src, name)
     ngroups = (N + RG - 1) // RG
     grid = max(1, min((ngroups + 3) // 4, CHAIN_GRID))
@@ -165,7 +176,7 @@ def gemv_chain(node, inputs, env):
             args.append(("q", v.ptr))
     r_out = None
     if store_r:
-        r_out = DeviceArray.empty((N,), "float64")
+        r_out = DeviceArray.empty((N,), atype)
         args.append(("q", r_out.ptr))
     parts = alloc_partials(spec, grid)
     stored = [None] * nout
@@ -255,7 +266,7 @@ def _fallback(node, env, alpha1, A, x1, beta1, y1d, e_vals, sidx, base):
 def _scatter_rows(env, values, sidx, bins):
     """``zeros(bins)[sidx] += values`` (AdvancedIncSubtensor, subtensor.py:2275) as a (1, bins) partial slab: the
     deterministic scatter kernel of csrc/index.hip."""
-    acc = DeviceArray.empty((bins,), "float64")
+    acc = DeviceArray.empty((bins,), values.dtype)
     ffi.check(env.lib.pthip_memset(acc.ptr, 0, acc.nbytes))
     n_idx = sidx.shape[0]
     if n_idx and bins:
@@ -264,7 +275,7 @@ def _scatter_rows(env, values, sidx, bins):
         ws = DeviceArray.empty((ws_bytes,), "uint8") if ws_bytes else None
         sv = values.contiguous()
         ffi.check(
-            lib.pthip_scatter_rows(ffi.np_dtype_code("float64"), 1, n_idx, 1, acc.ptr, bins, sidx.contiguous().ptr, sv.ptr, 1,
+            lib.pthip_scatter_rows(ffi.np_dtype_code(values.dtype), 1, n_idx, 1, acc.ptr, bins, sidx.contiguous().ptr, sv.ptr, 1,
                                    ws.ptr if ws is not None else None, ws_bytes)
         )
     return acc.view((1, bins), (bins, 1))
@@ -276,13 +287,22 @@ def gemv_finish(node, inputs, env):
     alpha2, beta2 = _scalar(env, alpha2), _scalar(env, beta2)
     nparts, M = part.shape
     out = DeviceArray.empty((M,), part.dtype)
+    odt = str(env.graph.vars[node.outputs[0]].dtype)
     y2d = None if beta2 == 0.0 else env.to_device(y2)
     if y2d is not None and y2d.shape != (M,):
         raise ValueError(f"Shape mismatch: y.shape[0] != A.shape[0] ({y2d.shape}, {M})")
+    if y2d is not None and y2d.dtype != part.dtype:
+        from pytensor_amd.dispatch.elemwise import _cast
+
+        y2d = _cast(env, y2d.contiguous(), str(part.dtype))  # (float32 graph, float64 slabs: the epilogue runs in the slabs' precision)
     ffi.check(
         env.lib.pthip_gemv_finish(
             ffi.np_dtype_code(part.dtype), M, nparts, part.ptr, alpha2, beta2,
             y2d.ptr if y2d is not None else None, (y2d.strides[0] if M > 1 else 1) if y2d is not None else 0, out.ptr,
         )
     )
+    if odt != str(part.dtype) and odt in ("float32", "float64"):
+        from pytensor_amd.dispatch.elemwise import _cast
+
+        out = _cast(env, out, odt)  # float64 partial slabs of a float32 graph: rounded once, at the end
     return [out]

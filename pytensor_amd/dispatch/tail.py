@@ -171,6 +171,8 @@ def _plan(node, inputs, env):
                 raise _Infeasible("partial slab layout")
             if a.host is None or b.host is None:
                 raise _Infeasible("device alpha/beta")
+            if str(g.vars[sub.outputs[0]].dtype) != str(slab.dtype):
+                raise _Infeasible("finish in another precision than its output")  # (float32 graph, float64 slabs: the member's own handler casts)
             alpha, beta = float(a.host.a.reshape(-1)[0]), float(b.host.a.reshape(-1)[0])
             rows, M = slab.shape
             if M > MAX_LEN:

@@ -250,7 +250,10 @@ def fuse_gemv_chain(g: Graph) -> Graph:
         if ke is None or ke in used or g.nodes[ke].op not in ("Elemwise", "ElemwiseReduce"):
             continue
         ne = g.nodes[ke]
-        if g.vars[w].ndim != 1 or g.vars[w].dtype != "float64":
+        # float64, or (round 5) float32 throughout: the kernel converts on load and keeps its double-precision core,
+        # partial slabs stay float64, GemvFinish casts back (dispatch/fused.py)
+        fdt = g.vars[w].dtype
+        if g.vars[w].ndim != 1 or fdt not in ("float64", "float32") or g.vars[A].dtype != fdt:
             continue
         # find the forward Gemv feeding the elementwise node
         r_pos = None
@@ -264,7 +267,7 @@ def fuse_gemv_chain(g: Graph) -> Graph:
         r = ne.inputs[r_pos]
         k1 = producer[r]
         n1 = g.nodes[k1]
-        if ne.inputs.count(r) != 1:
+        if ne.inputs.count(r) != 1 or g.vars[r].dtype != fdt or g.vars[n1.inputs[3]].dtype != fdt:
             continue
         # the chain / finish kernels take alpha and beta by value: they must be constants
         if any(g.vars[v].const is None for v in (n1.inputs[1], n1.inputs[4], a2, b2)):
@@ -308,7 +311,7 @@ def fuse_gemv_chain(g: Graph) -> Graph:
         # ---- scatter-add of a stored vector output -----------------------------------
         scatter = None
         for pos_o, o in enumerate(ne.outputs):
-            if spec[pos_o] is not None or g.vars[o].ndim != 1 or g.vars[o].dtype != "float64":
+            if spec[pos_o] is not None or g.vars[o].ndim != 1 or g.vars[o].dtype != fdt:
                 continue
             for ks in consumers.get(o, []):
                 S = g.nodes[ks]
@@ -321,7 +324,7 @@ def fuse_gemv_chain(g: Graph) -> Graph:
                     and len(S.inputs) == 3
                     and S.inputs[1] == o
                     and g.vars[S.inputs[0]].ndim == 1
-                    and g.vars[S.inputs[0]].dtype == "float64"
+                    and g.vars[S.inputs[0]].dtype == fdt
                     and g.vars[S.inputs[2]].dtype == "int64"
                     and producer.get(S.inputs[2], -1) < ke
                     and not any(_depends_on(g, producer, u, kk) for u in (S.inputs[0], S.inputs[2]) for kk in (k1, ke))
