@@ -945,7 +945,13 @@ int launch(long long batch, long long M, long long N, long long K, T alpha, cons
           attr_b = true;
         }
         const long long t_m = M / T2, t_n = N / T2, tot = t_m * t_n * batch;
-        const long long grid = tot < pthip::kNumCU ? tot : pthip::kNumCU;
+        // a product enqueued on a side stream runs BESIDE something else by construction (the hoisted sequence product
+        // of a Scan, one chunk ahead of the latency-bound steps that read it: dispatch/blas.py LazySeq): it takes a
+        // share of the CUs (each workgroup walks several tiles) and leaves the rest to the other stream
+        static const long long side_wgs = getenv("PTHIP_SIDE_GEMM_WGS") ? atoll(getenv("PTHIP_SIDE_GEMM_WGS")) : 96;
+        long long cap = pthip::kNumCU;
+        if (pthip::ctx().current != 0 && side_wgs > 0 && side_wgs < cap) cap = side_wgs;
+        const long long grid = tot < cap ? tot : cap;
         PTHIP_KLAUNCH(k256, dim3((unsigned)grid), dim3(BLOCK), sh, st, (float*)out, (const float*)A, (const float*)B,
                       (const float*)C, M, N, K, lda, ldb, sAb, sBb, sCb, sC0, sC1, (float)alpha, (float)beta, t_m, t_n, batch, ldo);
         return pthip::post_launch("gemm(256x256)");
