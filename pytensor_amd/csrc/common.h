@@ -79,6 +79,7 @@ inline int post_launch(const char* what) {
 }
 
 constexpr int kNumCU = 256;  // MI355X
+constexpr int kLdsPerCU = 160 * 1024;  // bytes of LDS per CU (and the most one workgroup can ask for)
 
 // async copies / fills issued by the library: performed now and, while a recorder is attached,
 // kept for replay (host memory involved must outlive the list: the plan's pinned blocks do)

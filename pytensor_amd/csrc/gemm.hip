@@ -941,18 +941,24 @@ int launch(long long batch, long long M, long long N, long long K, T alpha, cons
         auto k256 = pf ? sgemm256_kernel<true, AKC, BKC> : sgemm256_kernel<false, AKC, BKC>;
         static bool attr_b = false;
         if (!attr_b) {
-          PTHIP_CHECK(hipFuncSetAttribute((const void*)k256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+          PTHIP_CHECK(hipFuncSetAttribute((const void*)k256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pthip::kLdsPerCU));
           attr_b = true;
         }
         const long long t_m = M / T2, t_n = N / T2, tot = t_m * t_n * batch;
-        // a product enqueued on a side stream runs BESIDE something else by construction (the hoisted sequence product
-        // of a Scan, one chunk ahead of the latency-bound steps that read it: dispatch/blas.py LazySeq): it takes a
-        // share of the CUs (each workgroup walks several tiles) and leaves the rest to the other stream
-        static const long long side_wgs = getenv("PTHIP_SIDE_GEMM_WGS") ? atoll(getenv("PTHIP_SIDE_GEMM_WGS")) : 96;
+        // Experiment switches for a product enqueued on a side stream (the hoisted sequence product of a Scan, one chunk
+        // ahead of the steps that read it: dispatch/blas.py LazySeq, PTHIP_SCAN_OVERLAP=1): PTHIP_SIDE_GEMM_WGS caps its
+        // workgroups (each walks several tiles), PTHIP_SIDE_GEMM_WHOLE_CU=1 makes every workgroup ask for all of a CU's
+        // LDS so that the other stream's workgroups are placed on the CUs this launch does not use.  Both OFF by
+        // default: measured on config #5 (profiles/r6d_c5_overlap.md) a step kernel runs 8.6-9.0 us instead of 5.4-5.8
+        // whenever one of these products is in flight — with shared CUs and with disjoint ones alike — so the 6.9 ms of
+        // capped products hide 380 steps' worth of time and the evaluation ends where it started (13.8 ms).
+        static const long long side_wgs = getenv("PTHIP_SIDE_GEMM_WGS") ? atoll(getenv("PTHIP_SIDE_GEMM_WGS")) : 0;
+        static const bool side_whole = getenv("PTHIP_SIDE_GEMM_WHOLE_CU") && atoi(getenv("PTHIP_SIDE_GEMM_WHOLE_CU")) == 1;
         long long cap = pthip::kNumCU;
         if (pthip::ctx().current != 0 && side_wgs > 0 && side_wgs < cap) cap = side_wgs;
         const long long grid = tot < cap ? tot : cap;
-        PTHIP_KLAUNCH(k256, dim3((unsigned)grid), dim3(BLOCK), sh, st, (float*)out, (const float*)A, (const float*)B,
+        const size_t sh_launch = (cap != pthip::kNumCU && side_whole) ? (size_t)pthip::kLdsPerCU : sh;
+        PTHIP_KLAUNCH(k256, dim3((unsigned)grid), dim3(BLOCK), sh_launch, st, (float*)out, (const float*)A, (const float*)B,
                       (const float*)C, M, N, K, lda, ldb, sAb, sBb, sCb, sC0, sC1, (float)alpha, (float)beta, t_m, t_n, batch, ldo);
         return pthip::post_launch("gemm(256x256)");
       }

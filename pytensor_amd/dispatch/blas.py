@@ -320,7 +320,7 @@ def seq_dot22(node, inputs, env):
     W2 = _prep2d(W)
     # chunks of >= 4096 rows: enough 128x128 tiles that the GEMM neither splits K (which would
     # allocate a partial-slab workspace on the side stream) nor leaves CUs without a tile
-    chunk = max(1, -(-4096 // max(B, 1)))
+    chunk = max(1, -(-int(os.environ.get("PTHIP_SCAN_CHUNK_ROWS", "4096")) // max(B, 1)))
     lazy_ok = (node.params.get("lazy") and os.environ.get("PTHIP_SCAN_OVERLAP", "0") == "1" and env.scheduler is None
                and T >= 3 * chunk and B * N > 0 and K > 0 and (N + 127) // 128 * ((chunk * B + 127) // 128) >= 128)
     if not lazy_ok:
