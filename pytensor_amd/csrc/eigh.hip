@@ -38,7 +38,8 @@ template <class T, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void eigh_jacobi_kernel(const T* __restrict__ Ain, T* __restrict__ Wout,
                                                            T* __restrict__ Vout, int n, int lower, int a_lds,
                                                            int v_lds, T* scratchA, T* scratchV,
-                                                           int* __restrict__ status, int sorted, int max_sweeps) {
+                                                           int* __restrict__ status, int sorted, int max_sweeps,
+                                                           int cross) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ T s_c[MAX_N / 2], s_s[MAX_N / 2];
   __shared__ short s_p[MAX_N / 2], s_q[MAX_N / 2], s_rank[MAX_N];
@@ -75,11 +76,15 @@ __global__ __launch_bounds__(BLOCK) void eigh_jacobi_kernel(const T* __restrict_
   const int m = (n + 1) & ~1, half = m >> 1;
   bool converged = n < 2;
   for (int sweep = 0; sweep < max_sweeps && !converged; sweep++) {
-    for (int r = 0; r < m - 1; r++) {
+    // cross != 0 (n even; the block method's subproblems after a sweep's first round): only the pairs (i, n/2 + j) —
+    // n/2 rounds of n/2 disjoint pairs, round r pairs i with n/2 + (i + r) mod n/2 — the two halves are left as they are
+    const int nrounds = cross ? half : m - 1;
+    for (int r = 0; r < nrounds; r++) {
       // ---- phase 1: one thread per pair computes its rotation ----
       for (int i = tid; i < half; i += BLOCK) {
         int p, q;
-        if (i == 0) { p = r; q = m - 1; }
+        if (cross) { p = i; q = i + r; if (q >= half) q -= half; q += half; }
+        else if (i == 0) { p = r; q = m - 1; }
         else { p = r + i; if (p >= m - 1) p -= m - 1; q = r - i; if (q < 0) q += m - 1; }
         if (p > q) { const int t = p; p = q; q = t; }
         T c = T(1), s = T(0);
@@ -590,10 +595,58 @@ __global__ __launch_bounds__(256) void eigh_scatter_kernel(const T* __restrict__
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) V[i * n + r] = Vt[j * N + i];
 }
 
+// One round's update of the block method, both matrices in one launch: for every pair p, rows [p m, (p+1) m) of Gt and
+// of Vt become U_p^T times themselves (G_p <- G_p U_p, V_p <- V_p U_p), and each new row is stored where the next
+// round's pairing wants it (dst_row: the tournament step as a scatter) — what were two batched GEMMs (13 us each for
+// 64 x N x 64 products) and two row gathers.  grid (N / 64 column chunks, pairs, 2); a workgroup holds U_p and a
+// 64 x 64 chunk of the rows in LDS, a thread accumulates a 4 x 4 piece of the result over the 64 terms in index order.
+template <class T>
+__global__ __launch_bounds__(256) void eigh_pair_update_kernel(const T* __restrict__ U, const T* __restrict__ Gt, const T* __restrict__ Vt,
+                                                               T* __restrict__ Gout, T* __restrict__ Vout, long long N,
+                                                               const long long* __restrict__ dst_row) {
+  constexpr int M = 2 * EB;  // 64
+  __shared__ __attribute__((aligned(16))) T Us[M][M];  // U[i][i']
+  __shared__ __attribute__((aligned(16))) T Xs[M][M];  // X[i][c]
+  const int tid = threadIdx.x;
+  const long long c0 = (long long)blockIdx.x * M, p = blockIdx.y;
+  const T* X = (blockIdx.z ? Vt : Gt) + p * M * N + c0;
+  T* Y = blockIdx.z ? Vout : Gout;
+  const T* Up = U + p * M * M;
+  for (int e = tid; e < M * M; e += 256) {
+    const int i = e / M, j = e - i * M;
+    Us[i][j] = Up[e];
+    Xs[i][j] = X[(long long)i * N + j];
+  }
+  __syncthreads();
+  const int r0 = (tid >> 4) * 4, q0 = (tid & 15) * 4;
+  T acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) acc[a][b] = T(0);
+#pragma unroll 8
+  for (int i = 0; i < M; i++) {
+    T u[4], x[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) { u[a] = Us[i][r0 + a]; x[a] = Xs[i][q0 + a]; }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) acc[a][b] += u[a] * x[b];
+  }
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    T* yr = Y + dst_row[p * M + r0 + a] * N + c0 + q0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) yr[b] = acc[a][b];
+  }
+}
+
 __global__ void eigh_status_or_kernel(int* status, int bits) { atomicOr(status, bits); }
 
 template <class T>
-int eigh_typed(long long batch, long long n, int lower, const void* A, void* W, void* V, int sorted = 1, int max_sweeps = MAX_SWEEPS);
+int eigh_typed(long long batch, long long n, int lower, const void* A, void* W, void* V, int sorted = 1, int max_sweeps = MAX_SWEEPS,
+               int cross = 0);
 
 template <class T>
 int eigh_block_jacobi(long long n, int lower, const T* A, T* W, T* V) {
@@ -606,7 +659,7 @@ int eigh_block_jacobi(long long n, int lower, const T* A, T* W, T* V) {
   const size_t ibytes = ((size_t)N * 8 + 255) / 256 * 256;
   const size_t lbytes = ((size_t)N * sizeof(T) + 255) / 256 * 256;
   void* ws = nullptr;
-  int r = pthip_alloc(5 * mat + 2 * sbytes + (size_t)npairs * m * sizeof(T) + 256 + 2 * ibytes + lbytes + 256, &ws);
+  int r = pthip_alloc(5 * mat + 2 * sbytes + (size_t)npairs * m * sizeof(T) + 256 + 3 * ibytes + lbytes + 256, &ws);
   if (r) return r;
   auto fail = [&](int rc) { pthip_free(ws); return rc; };
   char* p = (char*)ws;
@@ -619,6 +672,7 @@ int eigh_block_jacobi(long long n, int lower, const T* A, T* W, T* V) {
   T* U = (T*)p; p += sbytes;
   T* Wsub = (T*)p; p += ((size_t)npairs * m * sizeof(T) + 255) / 256 * 256;
   long long* idx = (long long*)p; p += ibytes;
+  long long* dst = (long long*)p; p += ibytes;  // the same step as a scatter: row r of a round's result goes to row dst[r]
   int* rank = (int*)p; p += ibytes;
   T* lam = (T*)p; p += lbytes;
   unsigned long long* maxbits = (unsigned long long*)p;  // [0] ||A||_inf bits, [1] low word: off-diagonal bits, [2] ||A^4||_inf bits
@@ -643,6 +697,9 @@ int eigh_block_jacobi(long long n, int lower, const T* A, T* W, T* V) {
     for (long long q = 0; q < nbk; q++)
       for (long long t = 0; t < EB; t++) h[q * EB + t] = src[q] * EB + t;
     if (hipError_t e = hipMemcpyAsync(idx, h.data(), (size_t)N * 8, hipMemcpyHostToDevice, st); e != hipSuccess) return fail(pthip::check(e, "eigh idx upload"));
+    std::vector<long long> inv(N);
+    for (long long r_ = 0; r_ < N; r_++) inv[nbk > 2 ? h[r_] : r_] = r_;  // (one pair: nothing moves)
+    if (hipError_t e = hipMemcpyAsync(dst, inv.data(), (size_t)N * 8, hipMemcpyHostToDevice, st); e != hipSuccess) return fail(pthip::check(e, "eigh dst upload"));
     if (hipError_t e = hipStreamSynchronize(st); e != hipSuccess) return fail(pthip::check(e, "eigh idx sync"));  // (h goes out of scope)
   }
   if (hipError_t e = hipMemsetAsync(maxbits, 0, 32, st); e != hipSuccess) return fail(pthip::check(e, "eigh memset"));
@@ -663,7 +720,7 @@ int eigh_block_jacobi(long long n, int lower, const T* A, T* W, T* V) {
   // one inner sweep per subproblem: n = 1024 in 131 ms (13 outer sweeps) against 207 / 277 / 384 ms with 2 / 3 / until
   // converged (12 outer sweeps each) — profiles/r4n_eigh.txt
   const int inner_cap = inner_env > 0 ? inner_env : 1;
-  const int max_sweeps = 16;
+  const int max_sweeps = 24;  // (a 260-fold eigenvalue — rank 40 at n = 300 — takes 16: convergence inside a cluster is linear)
   for (int sweep = 0; sweep < max_sweeps && !converged; sweep++) {
     const long long rounds = nbk > 2 ? nbk - 1 : 1;
     // G = B V afresh at the start of a sweep: G and V take the same rotations, but their rounding errors are their
@@ -673,11 +730,30 @@ int eigh_block_jacobi(long long n, int lower, const T* A, T* W, T* V) {
     for (long long rd = 0; rd < rounds; rd++) {
       // Gram matrices of the pairs: S_p = G_p^T G_p with G_p^T = rows [p m, (p+1) m) of Gt
       if ((r = pthip_gemm(dt, npairs, m, m, N, 1.0, Gt, m * N, N, 1, Gt, m * N, 1, N, 0.0, nullptr, 0, 0, 0, S))) return fail(r);
-      PTHIP_KLAUNCH((eigh_offdiag_kernel<T>), dim3((unsigned)npairs), dim3(256), 0, st, (const T*)S, npairs, (int)m, offbits);
+      PTHIP_KLAUNCH((eigh_offdiag_kernel<T>), dim3((unsigned)(npairs * m * m / 256)), dim3(256), 0, st, (const T*)S, npairs, (int)m, offbits);
       // (inner sweeps are capped: a subproblem need not be diagonalised to the last bit while the pairs around it
       //  are still far from orthogonal; PTHIP_EIGH_INNER overrides)
-      if ((r = eigh_typed<T>(npairs, m, 1, S, Wsub, U, /*sorted=*/0, inner_cap))) return fail(r);
+      // A sweep of the block method should visit every pair of columns once.  The pairs INSIDE a block meet in every
+      // round of the sweep (the block travels as one): they are rotated in the sweep's first round only (a full
+      // round-robin sweep of the 2 EB x 2 EB subproblem, 2 EB - 1 rounds); every later round rotates just the
+      // EB x EB cross pairs of the two blocks that have met (EB rounds) — half the dependent rounds of a subproblem,
+      // the standard cyclic-by-blocks order.  Only while the iteration is far from done (the last sweep's largest
+      // relative off-diagonal above 1e-3 — 7 of 10 sweeps at n = 256, where most of the time goes): the end game keeps
+      // the full sweep in every round, which is what pulls a multiple eigenvalue's vectors apart (rank 40 at n = 300:
+      // 16 sweeps with it, not converged after 16 without; profiles/r6e_eigh_cross.txt).  PTHIP_EIGH_CROSS=0: the
+      // full sweep in every round (round 4).
+      static const bool cross_ok = !(getenv("PTHIP_EIGH_CROSS") && atoi(getenv("PTHIP_EIGH_CROSS")) == 0);
+      const int cross = (cross_ok && rd > 0 && prev > 1e-3) ? 1 : 0;
+      if ((r = eigh_typed<T>(npairs, m, 1, S, Wsub, U, /*sorted=*/0, inner_cap, cross))) return fail(r);
       // G_p <- G_p U  <=>  rows: Gt_p <- U^T Gt_p ; the same for V
+      static const bool fused_update = !(getenv("PTHIP_EIGH_FUSED_UPDATE") && atoi(getenv("PTHIP_EIGH_FUSED_UPDATE")) == 0);
+      if (fused_update) {
+        PTHIP_KLAUNCH((eigh_pair_update_kernel<T>), dim3((unsigned)(N / m), (unsigned)npairs, 2u), dim3(256), 0, st, (const T*)U, (const T*)Gt,
+                      (const T*)Vt, G2, V2, N, (const long long*)dst);
+        std::swap(Gt, G2);
+        std::swap(Vt, V2);
+        continue;
+      }
       if ((r = pthip_gemm(dt, npairs, m, N, m, 1.0, U, m * m, 1, m, Gt, m * N, N, 1, 0.0, nullptr, 0, 0, 0, G2))) return fail(r);
       if ((r = pthip_gemm(dt, npairs, m, N, m, 1.0, U, m * m, 1, m, Vt, m * N, N, 1, 0.0, nullptr, 0, 0, 0, V2))) return fail(r);
       if (nbk > 2) {
@@ -714,7 +790,7 @@ int eigh_block_jacobi(long long n, int lower, const T* A, T* W, T* V) {
 }
 
 template <class T>
-int eigh_typed(long long batch, long long n, int lower, const void* A, void* W, void* V, int sorted, int max_sweeps) {
+int eigh_typed(long long batch, long long n, int lower, const void* A, void* W, void* V, int sorted, int max_sweeps, int cross) {
   if (batch == 0 || n == 0) return 0;
   static const bool no_block = getenv("PTHIP_EIGH_ONE_WG") != nullptr;
   if (n > EIGH_BLOCK_MIN && !(no_block && n <= MAX_N)) {
@@ -745,7 +821,10 @@ int eigh_typed(long long batch, long long n, int lower, const void* A, void* W, 
   const bool a_lds = one <= budget;
   const bool v_lds = a_lds && 2 * one <= budget;
   const size_t dyn = (a_lds ? one : 0) + (v_lds ? one : 0);
-  const bool wide = n > 64;
+  // (the subproblems of the block method: a handful of matrices, one per CU, every round a chain of LDS round trips —
+  //  16 waves shorten it; PTHIP_EIGH_INNER_WIDE=0 keeps 4)
+  static const bool inner_wide = !(getenv("PTHIP_EIGH_INNER_WIDE") && atoi(getenv("PTHIP_EIGH_INNER_WIDE")) == 0);
+  const bool wide = n > 64 || (inner_wide && !sorted && batch <= 256);
   auto k = wide ? eigh_jacobi_kernel<T, 1024> : eigh_jacobi_kernel<T, 256>;
   if (dyn > 48 * 1024)
     PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
@@ -753,7 +832,7 @@ int eigh_typed(long long batch, long long n, int lower, const void* A, void* W, 
   if (!a_lds) { int r = pthip_alloc((size_t)batch * one, &sa); if (r) return r; }
   if (!v_lds) { int r = pthip_alloc((size_t)batch * one, &sv); if (r) { if (sa) pthip_free(sa); return r; } }
   PTHIP_KLAUNCH(k, dim3((unsigned)batch), dim3(wide ? 1024 : 256), dyn, st, (const T*)A, (T*)W, (T*)V, (int)n, lower,
-                     a_lds ? 1 : 0, v_lds ? 1 : 0, (T*)sa, (T*)sv, (int*)pthip_status_ptr(), sorted, max_sweeps);
+                     a_lds ? 1 : 0, v_lds ? 1 : 0, (T*)sa, (T*)sv, (int*)pthip_status_ptr(), sorted, max_sweeps, (cross && n % 2 == 0) ? 1 : 0);
   int r = pthip::post_launch("eigh");
   if (sa) pthip_free(sa);  // stream-ordered reuse keeps this safe
   if (sv) pthip_free(sv);

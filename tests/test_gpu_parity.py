@@ -76,7 +76,7 @@ def test_potrf_trsv_fused_kernel(hip, dtype, n):
 
 
 @pytest.mark.parametrize("dtype,n,batch,kind", [("float64", 161, 1, "random"), ("float64", 200, 2, "random"), ("float64", 256, 1, "plusminus"),
-                                                ("float64", 300, 1, "lowrank"), ("float64", 513, 1, "random"), ("float64", 1024, 1, "random"),
+                                                ("float64", 300, 1, "lowrank"), ("float64", 512, 1, "lowrank"), ("float64", 513, 1, "random"), ("float64", 1024, 1, "random"),
                                                 ("float32", 320, 1, "random")])
 def test_eigh_block_jacobi_beyond_one_cu(hip, dtype, n, batch, kind):
     """pthip_eigh for matrices beyond one CU's LDS (csrc/eigh.hip eigh_block_jacobi: 32-column blocks, batched
@@ -104,8 +104,13 @@ def test_eigh_block_jacobi_beyond_one_cu(hip, dtype, n, batch, kind):
     keep = np.tril(S) + np.triu(junk, 1) if lower else np.triu(S) + np.tril(junk, -1)
     dS = DeviceArray.from_host(np.ascontiguousarray(keep))
     w, v = DeviceArray.empty((batch, n), dtype), DeviceArray.empty((batch, n, n), dtype)
+    import ctypes
+
     hip.check(hip.lib().pthip_eigh(hip.np_dtype_code(dtype), batch, n, int(lower), dS.ptr, w.ptr, v.ptr))
     w, v = w.to_host(), v.to_host()
+    st = ctypes.c_int(-1)
+    hip.check(hip.lib().pthip_check_status(ctypes.byref(st)))
+    assert st.value == 0, f"device status word {st.value} (bit 3: the iteration did not converge)"
     tol = 1e-12 if dtype == "float64" else 5e-6
     for b in range(batch):
         S64 = S[b].astype("float64")
@@ -135,8 +140,13 @@ def test_eigh_jacobi_kernel(hip, dtype, n, batch):
     junk = np.triu(rng.normal(size=(n, n)), 1).astype(dtype)  # the upper triangle must not be read
     dS = DeviceArray.from_host(np.ascontiguousarray(np.tril(S) + junk))
     w, v = DeviceArray.empty((batch, n), dtype), DeviceArray.empty((batch, n, n), dtype)
+    import ctypes
+
     hip.check(hip.lib().pthip_eigh(hip.np_dtype_code(dtype), batch, n, 1, dS.ptr, w.ptr, v.ptr))
     w, v = w.to_host(), v.to_host()
+    st = ctypes.c_int(-1)
+    hip.check(hip.lib().pthip_check_status(ctypes.byref(st)))
+    assert st.value == 0, f"device status word {st.value}"
     tol = 1e-12 if dtype == "float64" else 5e-6
     for b in range(batch):
         wr = np.linalg.eigvalsh(S[b].astype("float64"))
