@@ -31,6 +31,13 @@ template <class T> struct Eps;
 template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; };
 template <> struct Eps<float> { static constexpr float v = 1.1920929e-07f; };
 
+// d^2 + h^2 inside these bounds is a normal number whose square root loses nothing
+template <class T> struct SafeRange;
+template <> struct SafeRange<double> { static constexpr double lo = 1e-290, hi = 1e290; };
+template <> struct SafeRange<float> { static constexpr float lo = 1e-30f, hi = 1e30f; };
+static __device__ __forceinline__ double jacobi_rsqrt(double x) { return rsqrt(x); }
+static __device__ __forceinline__ float jacobi_rsqrt(float x) { return rsqrtf(x); }
+
 // BLOCK: 256 for small matrices (several workgroups per CU when batched), 1024 above n = 64 — a round
 // has n/2 independent pairs and every pair is a chain of LDS / L2 round trips, so waves are what
 // shortens it (n = 128: 15.2 -> 12.0 ms with 16 waves instead of 4)
@@ -93,11 +100,23 @@ __global__ __launch_bounds__(BLOCK) void eigh_jacobi_kernel(const T* __restrict_
           const T mag = apq < T(0) ? -apq : apq;
           const T dd = app * aqq;
           if (mag > tiny_abs && mag > Eps<T>::v * sqrt(dd < T(0) ? -dd : dd)) {
-            const T theta = (aqq - app) / (T(2) * apq);
-            const T at = theta < T(0) ? -theta : theta;
-            T t = T(1) / (at + sqrt(theta * theta + T(1)));
-            if (theta < T(0)) t = -t;
-            c = T(1) / sqrt(t * t + T(1));
+            // t = tan(phi), the smaller root of t^2 + 2 theta t - 1 = 0 with theta = (aqq - app) / (2 apq):
+            // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)) = sgn(theta) |h| / (|d| + sqrt(d^2 + h^2)), d = aqq - app,
+            // h = 2 apq — one square root and one division in the dependent chain instead of two and two (this chain,
+            // on one wave, is a third of a round); the textbook form only where d^2 + h^2 leaves the normal range
+            const T d = aqq - app, h = apq + apq;
+            const T r2 = d * d + h * h;
+            T t;
+            if (r2 > SafeRange<T>::lo && r2 < SafeRange<T>::hi) {
+              t = (h < T(0) ? -h : h) / ((d < T(0) ? -d : d) + sqrt(r2));
+              if ((d < T(0) && h > T(0)) || (d > T(0) && h < T(0))) t = -t;
+            } else {
+              const T theta = d / h;
+              const T at = theta < T(0) ? -theta : theta;
+              t = T(1) / (at + sqrt(theta * theta + T(1)));
+              if (theta < T(0)) t = -t;
+            }
+            c = jacobi_rsqrt(t * t + T(1));
             s = t * c;
             s_rot = 1;
           }
@@ -105,51 +124,43 @@ __global__ __launch_bounds__(BLOCK) void eigh_jacobi_kernel(const T* __restrict_
         s_c[i] = c; s_s[i] = s; s_p[i] = (short)p; s_q[i] = (short)q;
       }
       __syncthreads();
-      // ---- phase 2: columns p, q of A and of V (lanes down the rows; each wave works on two
-      //      pairs at a time so that their LDS round trips overlap) ----
+      // ---- phase 2: A <- J^T A J and V <- V J in ONE pass.  The round's rotations act on disjoint index pairs, so the
+      //      2 x 2 block of A at (pair P, pair Q) depends on nothing but itself and the two rotations: a thread reads
+      //      its four elements, rotates the columns (Q), then the rows (P) — the arithmetic and its order are those of a
+      //      column pass followed by a row pass — and writes them back; no barrier between a column phase and a row
+      //      phase, one LDS round trip instead of two.  A ghost index (odd n: q == n) has c = 1, s = 0 and no storage.
       constexpr int NW = BLOCK / 64;
-      for (int i0 = wid; i0 < half; i0 += 2 * NW) {
-        const int i1 = i0 + NW < half ? i0 + NW : i0;  // (odd tail: the second slot idles)
-        const bool two = i1 != i0;
-        const T s0 = s_s[i0], c0 = s_c[i0], s1 = two ? s_s[i1] : T(0), c1 = two ? s_c[i1] : T(1);
-        if (s0 == T(0) && s1 == T(0)) continue;
-        const int p0 = s_p[i0], q0 = s_q[i0], p1 = s_p[i1], q1 = s_q[i1];
-        for (int k = lane; k < n; k += 64) {
-          const T x0 = A[k * ld + p0], y0 = A[k * ld + q0], x1 = A[k * ld + p1], y1 = A[k * ld + q1];
-          // (V is kept transposed: eigenvector p is row p — contiguous in k, which is what the
-          //  global-scratch case needs to stay coalesced)
-          const T vx0 = V[p0 * ld + k], vy0 = V[q0 * ld + k], vx1 = V[p1 * ld + k], vy1 = V[q1 * ld + k];
-          if (s0 != T(0)) {
-            A[k * ld + p0] = c0 * x0 - s0 * y0;
-            A[k * ld + q0] = s0 * x0 + c0 * y0;
-            V[p0 * ld + k] = c0 * vx0 - s0 * vy0;
-            V[q0 * ld + k] = s0 * vx0 + c0 * vy0;
-          }
-          if (s1 != T(0)) {
-            A[k * ld + p1] = c1 * x1 - s1 * y1;
-            A[k * ld + q1] = s1 * x1 + c1 * y1;
-            V[p1 * ld + k] = c1 * vx1 - s1 * vy1;
-            V[q1 * ld + k] = s1 * vx1 + c1 * vy1;
-          }
+      {
+        const float inv_half = 1.0f / (float)half;
+        for (int e = tid; e < half * half; e += BLOCK) {
+          const int P = (int)(((float)e + 0.5f) * inv_half), Q = e - P * half;  // (exact: e < 2^16, half <= 256)
+          const T sP = s_s[P], sQ = s_s[Q];
+          if (sP == T(0) && sQ == T(0)) continue;
+          const T cP = s_c[P], cQ = s_c[Q];
+          const int p1 = s_p[P], p2 = s_q[P], q1 = s_p[Q], q2 = s_q[Q];
+          const bool okP = p2 < n, okQ = q2 < n;
+          const T x11 = A[p1 * ld + q1], x12 = okQ ? A[p1 * ld + q2] : T(0);
+          const T x21 = okP ? A[p2 * ld + q1] : T(0), x22 = (okP && okQ) ? A[p2 * ld + q2] : T(0);
+          const T a11 = cQ * x11 - sQ * x12, a12 = sQ * x11 + cQ * x12;
+          const T a21 = cQ * x21 - sQ * x22, a22 = sQ * x21 + cQ * x22;
+          T b11 = cP * a11 - sP * a21, b21 = sP * a11 + cP * a21;
+          T b12 = cP * a12 - sP * a22, b22 = sP * a12 + cP * a22;
+          if (P == Q) { b12 = T(0); b21 = T(0); }  // the annihilated pair is stored as an exact zero
+          A[p1 * ld + q1] = b11;
+          if (okQ) A[p1 * ld + q2] = b12;
+          if (okP) A[p2 * ld + q1] = b21;
+          if (okP && okQ) A[p2 * ld + q2] = b22;
         }
-      }
-      __syncthreads();
-      // ---- phase 3: rows p, q of A; the annihilated pair is stored as an exact zero ----
-      for (int i0 = wid; i0 < half; i0 += 2 * NW) {
-        const int i1 = i0 + NW < half ? i0 + NW : i0;
-        const bool two = i1 != i0;
-        const T s0 = s_s[i0], c0 = s_c[i0], s1 = two ? s_s[i1] : T(0), c1 = two ? s_c[i1] : T(1);
-        if (s0 == T(0) && s1 == T(0)) continue;
-        const int p0 = s_p[i0], q0 = s_q[i0], p1 = s_p[i1], q1 = s_q[i1];
-        for (int k = lane; k < n; k += 64) {
-          const T x0 = A[p0 * ld + k], y0 = A[q0 * ld + k], x1 = A[p1 * ld + k], y1 = A[q1 * ld + k];
-          if (s0 != T(0)) {
-            A[p0 * ld + k] = k == q0 ? T(0) : c0 * x0 - s0 * y0;
-            A[q0 * ld + k] = k == p0 ? T(0) : s0 * x0 + c0 * y0;
-          }
-          if (s1 != T(0)) {
-            A[p1 * ld + k] = k == q1 ? T(0) : c1 * x1 - s1 * y1;
-            A[q1 * ld + k] = k == p1 ? T(0) : s1 * x1 + c1 * y1;
+        // (V is kept transposed: eigenvector p is row p — contiguous in k, which is what the global-scratch case needs
+        //  to stay coalesced)
+        for (int Q = wid; Q < half; Q += NW) {
+          const T sQ = s_s[Q], cQ = s_c[Q];
+          if (sQ == T(0)) continue;
+          const int q1 = s_p[Q], q2 = s_q[Q];
+          for (int k = lane; k < n; k += 64) {
+            const T vx = V[q1 * ld + k], vy = V[q2 * ld + k];
+            V[q1 * ld + k] = cQ * vx - sQ * vy;
+            V[q2 * ld + k] = sQ * vx + cQ * vy;
           }
         }
       }
