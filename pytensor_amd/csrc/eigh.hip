@@ -461,7 +461,9 @@ __global__ __launch_bounds__(EIGH1_BLOCK) void eigh_onesided_kernel(const T* __r
 // tournament, one row gather): per pair the 64 x 64 Gram matrix S = G_p^T G_p on the MFMA GEMM, its full
 // eigendecomposition U by the LDS Jacobi kernel above (batched: one workgroup per pair; its accumulated rotation
 // matrix UNSORTED — the block iteration only converges, quadratically, when U stays close to the identity), and
-// G_p <- G_p U, V_p <- V_p U as two more batched GEMMs.  A sweep is nblocks-1 rounds; the largest
+// G_p <- G_p U, V_p <- V_p U with the move to the next round's positions in one launch (eigh_pair_update_kernel;
+// round 4: two more batched GEMMs and two gathers).  A sweep is nblocks-1 rounds — the first rotates all pairs of a
+// subproblem, the later ones only the cross pairs of the two blocks that met (see the loop) — and the largest
 // |S_ij| / sqrt(S_ii S_jj) seen during a sweep is read back once per sweep and ends the iteration.  At the end
 // column j of G is (lambda_j + sigma) v_j: lambda_j = v_j . g_j - sigma, sorted ascending with their vectors.
 // Rows / columns added to pad n to a whole number of block pairs carry 4 sigma on the diagonal: exactly
