@@ -177,6 +177,11 @@ int pthip_ticket_slot(void** slot);
  * again, and after three such calls goes back to the event for that descriptor.  Replaces nothing in the reference:
  * its Loop / Stack VMs (pytensor/link/vm.py) run one thunk at a time, there is nothing to join. */
 int pthip_join_signal(void* word);
+/* The assumption behind that join — a kernel that has waited for the word reads the other stream's in-place results
+ * with plain loads and finds them, no fence behind the wait — checked on this device: `iters` rounds of overwrite +
+ * signal on stream 1 against waiting readers on stream 0; *bad = mismatching words (+ 2^20 per reader that never saw
+ * the signal).  The host side runs it once per process and keeps the event between the streams when *bad != 0. */
+int pthip_join_probe(int iters, int* bad);
 int pthip_graph_destroy(void* graph_exec);
 
 /* ---- events (HIP events on the context stream) ---- */

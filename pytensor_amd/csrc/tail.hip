@@ -35,7 +35,77 @@ __global__ __launch_bounds__(BLOCK) void multi_finish_kernel(Tasks t) {
 
 __global__ void join_signal_kernel(int* word) { __hip_atomic_store(word, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
+// ---- the probe behind the device-side join (pthip_join_probe) ----
+__global__ __launch_bounds__(256) void join_probe_write_kernel(unsigned* __restrict__ buf, int n, unsigned val) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) buf[i] = val ^ (unsigned)i;
+}
+// the consumer side exactly as the generated tail kernel has it (codegen._tail_prologue): a relaxed agent-scope spin
+// on the word, NO fence behind it, plain loads of what the other stream wrote
+__global__ __launch_bounds__(256) void join_probe_wait_kernel(int* word, const unsigned* __restrict__ buf, int n, unsigned val,
+                                                             int* bad) {
+  __shared__ int ok;
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();  // 100 MHz; 2 ms, the order of the join's own bound
+    bool seen;
+    while (!(seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) && wall_clock64() - t0 < 200000) {}
+    ok = seen;
+  }
+  __syncthreads();
+  if (!ok) {
+    if (threadIdx.x == 0) atomicAdd(bad, 1 << 20);  // (the streams did not overlap: reported apart from mismatches)
+    return;
+  }
+  int wrong = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) wrong += buf[i] != (val ^ (unsigned)i);
+  if (wrong) atomicAdd(bad, wrong);
+}
+__global__ void join_probe_reset_kernel(int* word) { __hip_atomic_store(word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 }  // namespace
+
+// Does what the device-side join relies on hold on THIS device, driver and partition mode?  `iters` times: stream 0
+// launches the waiting kernel (every CU's worth of workgroups), stream 1 overwrites a 1 MB buffer IN PLACE with a new
+// pattern and signals; the waiters read the buffer with plain loads, no fence behind the wait — stale lines kept from
+// the previous iteration in any XCD's L2 show up as mismatches.  *bad: mismatching words summed over the iterations
+// (+ 2^20 per waiter that never saw the signal: the two streams did not run side by side).  The host side
+// (plan.py) runs this once per process before the first plan that would use the join and falls back to the event
+// between the streams when *bad != 0.  Not capturable; synchronises both streams.
+extern "C" int pthip_join_probe(int iters, int* bad_out) {
+  PTHIP_REQUIRE_INIT();
+  if (!bad_out || iters <= 0) return pthip::set_error("pthip_join_probe: bad arguments");
+  if (pthip::ctx().capturing || pthip::ctx().recorder) return pthip::set_error("pthip_join_probe: not inside a capture / recording");
+  int r = pthip_stream_wait(1, 0);  // (creates stream 1; orders it behind what the caller has enqueued)
+  if (r) return r;
+  hipStream_t s0 = pthip::ctx().streams[0], s1 = pthip::ctx().streams[1];
+  constexpr int N = 1 << 18;  // 1 MB: every L2 channel of every XCD
+  void* mem = nullptr;
+  if ((r = pthip_alloc((size_t)N * 4 + 256, &mem))) return r;
+  unsigned* buf = (unsigned*)mem;
+  int* word = (int*)((char*)mem + (size_t)N * 4);
+  int* bad = word + 16;
+  hipEvent_t ev;
+  PTHIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  PTHIP_CHECK(hipMemsetAsync(word, 0, 128, s0));
+  PTHIP_CHECK(hipEventRecord(ev, s0));
+  PTHIP_CHECK(hipStreamWaitEvent(s1, ev, 0));
+  for (int it = 0; it < iters; it++) {
+    const unsigned val = 0x9E3779B9u * (unsigned)(it + 1);
+    hipLaunchKernelGGL(join_probe_wait_kernel, dim3(pthip::kNumCU), dim3(256), 0, s0, word, (const unsigned*)buf, N, val, bad);
+    hipLaunchKernelGGL(join_probe_write_kernel, dim3(pthip::kNumCU), dim3(256), 0, s1, buf, N, val);
+    hipLaunchKernelGGL(join_signal_kernel, dim3(1), dim3(1), 0, s1, word);
+    hipLaunchKernelGGL(join_probe_reset_kernel, dim3(1), dim3(1), 0, s0, word);
+    PTHIP_CHECK(hipEventRecord(ev, s0));  // the next overwrite waits for this iteration's readers
+    PTHIP_CHECK(hipStreamWaitEvent(s1, ev, 0));
+  }
+  PTHIP_CHECK(hipGetLastError());
+  int h = 0;
+  PTHIP_CHECK(hipMemcpyAsync(&h, bad, 4, hipMemcpyDeviceToHost, s0));
+  PTHIP_CHECK(hipStreamSynchronize(s0));
+  PTHIP_CHECK(hipStreamSynchronize(s1));
+  PTHIP_CHECK(hipEventDestroy(ev));
+  *bad_out = h;
+  return pthip_free(mem);
+}
 
 // the last launch of a plan's latency-chain segment (include/pthip.h)
 extern "C" int pthip_join_signal(void* word) {

@@ -186,6 +186,26 @@ _A_DIRECT = os.environ.get("PTHIP_PLAN_A_DIRECT", "1") != "0"
 # signal word (pthip_join_signal), the Tail node that opens segment C waits for it inside its own launches — no event
 # between the streams (5.6 us between `gchain` and the next launch with one, profiles/r4z_c4_timeline.md)
 _DEV_JOIN = os.environ.get("PTHIP_PLAN_DEVICE_JOIN", "1") != "0"
+# ... which leans on the caches having been invalidated when the waiting kernel started (csrc/tail_device.h): checked
+# once per process on the device itself (pthip_join_probe: in-place results that change every round, readers without a
+# fence); a device / driver / partition mode where that does not hold keeps the event.  PTHIP_JOIN_PROBE=0 skips it.
+_JOIN_PROBED = [None]
+
+
+def _device_join_ok(lib) -> bool:
+    if _JOIN_PROBED[0] is None:
+        if os.environ.get("PTHIP_JOIN_PROBE", "1") == "0":
+            _JOIN_PROBED[0] = True
+        else:
+            bad = C.c_int(-1)
+            ffi.check(lib.pthip_join_probe(64, C.byref(bad)))
+            _JOIN_PROBED[0] = bad.value == 0
+            if bad.value:
+                import warnings
+
+                warnings.warn(f"pytensor_amd: the device-side join probe failed on this device ({bad.value}); "
+                              "segmented plans keep an event between their streams", RuntimeWarning, stacklevel=2)
+    return _JOIN_PROBED[0]
 _A_DIRECT_OPS = ("CholeskyTrsv", "SolveTriangular", "CholeskySolve")
 
 
@@ -271,7 +291,7 @@ class FrozenPlan:
         # device-side join: segment C opens with the Tail node (its launches take the signal word)
         self._join_word = None
         self._join_used = False
-        if self.segmented and _DEV_JOIN and g.nodes[seg.index(2)].op == "Tail":
+        if self.segmented and _DEV_JOIN and g.nodes[seg.index(2)].op == "Tail" and _device_join_ok(self.lib):
             slot = C.c_void_p()
             ffi.check(self.lib.pthip_ticket_slot(C.byref(slot)))
             self._join_word = slot.value

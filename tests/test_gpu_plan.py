@@ -299,6 +299,44 @@ def test_segmented_plan_joins_its_streams_on_the_device(hip, monkeypatch):
         monkeypatch.undo()
 
 
+def test_device_join_probe_and_many_replays(hip, monkeypatch):
+    """What the device-side join assumes (readers that waited for the word find the other stream's in-place results
+    with plain loads, csrc/tail_device.h) is probed on the device once per process (``pthip_join_probe``; a failing
+    probe keeps the event between the streams) — and held against the event form over many replays whose segment-A
+    results change on every call."""
+    import ctypes as C
+
+    import pytensor_amd.plan as plan_mod
+    from pytensor_amd import ffi
+    from pytensor_amd.executor import HipExecutable
+
+    bad = C.c_int(-1)
+    ffi.check(ffi.lib().pthip_join_probe(256, C.byref(bad)))
+    assert bad.value == 0, f"device-side join probe: {bad.value}"
+    assert plan_mod._device_join_ok(ffi.lib())
+    # a failing probe switches the join off for new plans
+    g, ins, cvm, py, meta = load_case("c4_hier")
+    names = meta["input_names"]
+    res = [k for k, n in enumerate(names) if n in ("y", "X", "gidx", "Sigma")]
+    exe = HipExecutable(g, resident=res)
+    monkeypatch.setattr(plan_mod, "_JOIN_PROBED", [False])
+    p_ev = exe.freeze(*ins)
+    assert p_ev.segmented and not p_ev._join_word
+    monkeypatch.undo()
+    p_dev = exe.freeze(*ins)
+    assert p_dev._join_word
+    rng = np.random.default_rng(11)
+    for j in range(300):
+        args = list(ins)
+        for k, a in enumerate(ins):
+            if k not in res and isinstance(a, np.ndarray) and a.dtype.kind == "f":
+                args[k] = a + 1e-2 * rng.standard_normal(a.shape)
+        for a, b in zip(p_dev(*args), p_ev(*args)):
+            np.testing.assert_array_equal(a, b)
+    p_dev.close()
+    p_ev.close()
+
+
 def test_device_join_that_gives_up_is_retried_by_the_host(hip, monkeypatch):
     """When the latency-chain segment is still running 1 ms after the tail kernel started waiting (here: two 4096^3
     fp64 products recorded in front of the signal; in the field: a profiler that serialises kernels), the kernel
