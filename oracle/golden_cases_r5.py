@@ -169,6 +169,19 @@ def logsumexp_axis1():
     return [X], [_logsumexp(X, 1)], {"X": rng.normal(size=(37, 91))}
 
 
+@case("logsumexp_degenerate")
+def logsumexp_degenerate():
+    """Shapes the one-pass log-sum-exp tile does not take (dispatch/elemwise.py _logsumexp_axis_by_axis): a reduced
+    axis of extent 1 (found by layout_fuzz_f64_8), seven dimensions whose kept / reduced roles alternate (nothing
+    merges), an empty kept dimension."""
+    rng = np.random.default_rng(77123)
+    A = pt.tensor("A", dtype="float64", shape=(None, None, None))
+    B = pt.tensor("B", dtype="float64", shape=(None,) * 7)
+    E = pt.matrix("E", dtype="float64")
+    outs = [_logsumexp(A, 1), pt.logsumexp(A + 4.0, axis=(0, 1)), pt.logsumexp(B, axis=(1, 3, 5)), pt.logsumexp(B, axis=(0, 2, 4, 6)), _logsumexp(E, 1)]
+    return [A, B, E], outs, {"A": rng.normal(size=(3, 1, 4)), "B": rng.normal(size=(2, 3, 2, 2, 3, 2, 2)), "E": np.zeros((0, 5))}
+
+
 @case("softmax_bench")
 def softmax_bench():
     from pytensor.tensor.special import log_softmax, softmax

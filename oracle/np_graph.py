@@ -349,9 +349,9 @@ def _careduce(p, inputs, node, graph):
     if x.dtype.kind == "b" and p["scalar_op"] in ("AND", "OR", "XOR"):
         r = uf.reduce(x, axis=axis)
     else:
-        r = uf.reduce(x, axis=axis, dtype=acc) if x.size or uf.identity is not None else None
-        if r is None:
-            raise ValueError("zero-size array to reduction operation which has no identity")
+        # (NumPy itself raises "zero-size array to reduction operation ... which has no identity" exactly when a REDUCED
+        #  axis is empty and the ufunc has no identity; an empty KEPT axis just gives an empty result)
+        r = uf.reduce(x, axis=axis, dtype=acc)
     return [np.asarray(r).astype(p["dtype"], copy=False)]
 
 

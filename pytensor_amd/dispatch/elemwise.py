@@ -324,9 +324,27 @@ def launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial=
         cstr = cstr[:-1]
         ndc = len(cshape)
         if ndc > codegen.MAX_ND:
-            # materialise the worst operand and retry (rare: >5 non-mergeable dims)
-            ins = [a if isinstance(a, HostValue) or a.is_contiguous() else a.contiguous() for a in ins]
-            return launch_elemwise(body, ins, out_shape, out_dtypes, reduce_spec, env, partial, out_bufs)
+            # rare: more than MAX_ND dimensions that do not merge (seven alternating broadcast / full dimensions: golden
+            # logsumexp_degenerate).  Every operand that is not already the full shape in C order is expanded into one
+            # (copy_into broadcasts and peels dimensions beyond its own limit); the retry is then the flat kernel.
+            # (Until round 5 this made operands contiguous WITHOUT expanding them: a broadcast operand came back with the
+            #  same collapsed rank and the call recursed until the interpreter gave up.)
+            from pytensor_amd.device import copy_into
+
+            if partial:
+                raise NotImplementedError(f"Elemwise over split-K slabs with {ndc} non-mergeable dimensions")
+            full, changed = [], False
+            for k, a in enumerate(ins):
+                if k in byvalue or isinstance(a, HostValue) or a.size == 1 or (tuple(a.shape) == sshape and a.is_contiguous()):
+                    full.append(a)
+                    continue
+                t = DeviceArray.empty(sshape, a.dtype)
+                copy_into(t, a)
+                full.append(t)
+                changed = True
+            if not changed:
+                raise RuntimeError(f"Elemwise: {ndc} non-mergeable dimensions with every operand already expanded")
+            return launch_elemwise(body, full, out_shape, out_dtypes, reduce_spec, env, partial, out_bufs, finals_out=finals_out)
         if not partial and _TILE:
             return _launch_tiled(body, ins, byvalue, cshape, cstr, outs, out_dtypes, reduce_spec, rs, bkey, rkey, env)
         pkey = ("_p" + "".join(str(k) + "." for k in sorted(partial))) if partial else ""
@@ -916,10 +934,42 @@ def elemwise_axis_reduce(node, inputs, env):
         # shapes outside the tile (or empty): the unfused pair
         outs, _, _ = launch_elemwise(body, ins, shape, body["out_dtypes"], None, env)
         res = []
-        for o, r in zip(outs, p["reduce"]):
+        for o, r, (_, acc, odt) in zip(outs, p["reduce"], specs):
+            if r["op"] == "LogSumExp":
+                res.append(_logsumexp_axis_by_axis(env, o, axes, acc, odt, out_shape))
+                continue
             sub = type("_N", (), {"params": {"axis": axes, "scalar_op": r["op"], "acc_dtype": r["acc_dtype"], "dtype": r["dtype"]}})
             res.append(careduce(sub, [o], env)[0])
     return [r.view(out_shape, _cstrides(out_shape)) for r in res]
+
+
+def _logsumexp_axis_by_axis(env, x, axes, acc, odt, out_shape):
+    """log-sum-exp of a materialised tensor where the one-pass tile does not apply (found by the layout fuzz cases: a
+    reduced axis of extent 1; also > 5 dimensions that do not merge, empty tensors).  The reduction is associative:
+    one axis at a time (each a 3-d problem (A, R, B) of a contiguous tensor, which always fits the tile), last axis
+    first.  Reference semantics (the graph was max + log(sum(exp(x - max))), math.py logsumexp): over extent-1 axes the
+    result is x itself; an EMPTY reduced axis raises what the reference's max does."""
+    if any(x.shape[a] == 0 for a in axes) and all(s for s in out_shape):
+        raise ValueError("zero-size array to reduction operation maximum which has no identity")
+    if x.size == 0:
+        return DeviceArray.empty(out_shape, odt)
+    cur = x if x.is_contiguous() else x.contiguous()
+    for a in sorted(axes, reverse=True):
+        shp = tuple(cur.shape)
+        if shp[a] == 1:
+            cur = cur.view(shp[:a] + shp[a + 1:], _cstrides(shp[:a] + shp[a + 1:]))
+            continue
+        A = int(np.prod(shp[:a], dtype=np.int64))
+        B = int(np.prod(shp[a + 1:], dtype=np.int64))
+        v3 = cur.view((A, shp[a], B), (shp[a] * B, B, 1))
+        r = launch_axis_reduce(env, _identity_body(str(cur.dtype)), [v3], (A, shp[a], B), [1], [("LogSumExp", acc, acc)], (A, B))
+        if r is None:
+            raise RuntimeError("log-sum-exp: a contiguous (A, R, B) problem does not fit the tile")
+        nshape = shp[:a] + shp[a + 1:]
+        cur = r[0].view(nshape, _cstrides(nshape))
+    if str(cur.dtype) != odt:
+        cur = _cast(env, cur, odt)
+    return cur.view(out_shape, _cstrides(out_shape))
 
 
 @handler("CAReduce")
