@@ -115,3 +115,44 @@ for _s in range(3):
     case(f"layout_fuzz_f32_{_s}", rtol=1e-4)(_make(50 + _s, "float32"))
 for _s in range(3):
     case(f"layout_fuzz_i64_{_s}", rtol=0)(_make(80 + _s, "int64"))
+
+
+# ---- second family: the same random views into the indexing / ordering / scan ops ----
+def _make2(seed):
+    def build():
+        rng = np.random.default_rng(9000 + seed)
+        rank = int(rng.integers(2, 5))
+        shape = _shape(rng, rank, budget=9000)
+        a, xa, va = _operand(rng, "a", shape, "float64", allow_bcast=False)
+        b, xb, vb = _operand(rng, "b", shape, "float64")
+        c, xc, vc = _operand(rng, "c", shape, "float64", allow_bcast=False)
+        ins, vals = [xa, xb, xc], {"a": va, "b": vb, "c": vc}
+        ax = lambda: int(rng.integers(rank))  # noqa: E731
+        outs = []
+        outs.append(pt.argmax(a, axis=ax()))
+        outs.append(pt.argmin(c, axis=ax()))
+        outs.append(pt.cumsum(pt.sqr(a) + 0.125, axis=ax()))
+        outs.append(pt.cumprod(pt.tanh(c) * 0.25 + 1.0, axis=ax()))
+        outs.append(pt.sort(a, axis=ax()))
+        outs.append(pt.argsort(c, axis=ax()))
+        outs.append(pt.special.softmax(a * b, axis=ax()))
+        k = ax()
+        n = shape[k]
+        iv = pt.tensor("iv", dtype="int64", shape=(None,))
+        ins.append(iv)
+        vals["iv"] = rng.integers(-n, n, size=n + 2)
+        outs.append(pt.take(a, iv, axis=k))
+        outs.append(pt.where(pt.gt(a, b), a, c))
+        outs.append(pt.concatenate([a, c], axis=ax()))
+        outs.append(pt.sum(pt.sqr(a.reshape((-1,))[::2])))
+        if rank >= 2:
+            i, j = sorted(int(t) for t in rng.choice(rank, size=2, replace=False))
+            outs.append(pt.diagonal(a, axis1=i, axis2=j))
+        outs.append(pt.max(a, axis=_axes(rng, rank)) * pt.min(c, axis=None))
+        return ins, outs, vals
+
+    return build
+
+
+for _s in range(12):
+    case(f"layout_fuzz2_{_s}", rtol=1e-10)(_make2(_s))
