@@ -45,6 +45,9 @@ def _operand(rng, name, shape, dtype, allow_bcast=True):
     store = [shp[perm[k]] * abs(steps[k]) + (int(rng.integers(0, 2)) if abs(steps[k]) == 2 else 0) for k in range(r)]
     if dtype == "int64":
         val = rng.integers(-4, 5, size=store).astype("int64")
+    elif np.dtype(dtype).kind in "iu":
+        info = np.iinfo(dtype)
+        val = rng.integers(max(info.min, -100), min(info.max, 100) + 1, size=store).astype(dtype)
     else:
         val = (rng.normal(size=store) * 1.2).astype(dtype)
     x = pt.tensor(name, dtype=dtype, shape=(None,) * r)
@@ -156,3 +159,47 @@ def _make2(seed):
 
 for _s in range(12):
     case(f"layout_fuzz2_{_s}", rtol=1e-10)(_make2(_s))
+
+
+# ---- third family: scalar semantics across dtypes (integer division / modulo signs, rounding, overflow wrap-around,
+#      bitwise ops, comparisons, casts) on the same random views ----
+_INT_DTYPES = ["int8", "int16", "int32", "int64", "uint8", "uint16"]
+
+
+def _make3(seed):
+    def build():
+        rng = np.random.default_rng(11000 + seed)
+        rank = int(rng.integers(1, 4))
+        shape = _shape(rng, rank, budget=3000) if rank > 1 else [int(rng.choice([7, 64, 130, 1000]))]
+        di, dj = (str(rng.choice(_INT_DTYPES)) for _ in range(2))
+        fdt = str(rng.choice(["float64", "float32"]))
+
+        def ints(name, dt, nonzero=False):
+            v, x, val = _operand(rng, name, shape, dt, allow_bcast=name != "i")
+            if dt == "int64":
+                val = rng.integers(-100, 101, size=val.shape).astype(dt)
+            if nonzero:
+                val = np.where(val == 0, 3, val).astype(dt)
+            return v, x, val
+
+        i, xi, vi = ints("i", di)
+        j, xj, vj = ints("j", dj, nonzero=True)
+        f, xf, vf = _operand(rng, "f", shape, fdt, allow_bcast=False)
+        g, xg, vg = _operand(rng, "g", shape, fdt)
+        vg = np.where(np.abs(vg) < 0.05, 0.7, vg).astype(fdt)
+        ins, vals = [xi, xj, xf, xg], {"i": vi, "j": vj, "f": vf * 3, "g": vg}
+        outs = [
+            i // j, i % j, i * j + i, i - j, pt.bitwise_and(i, j), pt.bitwise_or(i, j), pt.bitwise_xor(i, j), pt.invert(i), abs(i), -i,
+            pt.eq(i, j), pt.lt(i, j), pt.ge(i, j), pt.maximum(i, j), pt.minimum(i, j), pt.sgn(i), pt.cast(i, "float32") / pt.cast(j, "float32"),
+            pt.floor(f), pt.ceil(f), pt.round(f), pt.trunc(f), f // g, f % g, pt.sgn(f), pt.clip(f, -1.0, g * g),
+            pt.cast(f, "int32"), pt.cast(pt.clip(f * 20, -120.0, 120.0), "int8"), pt.cast(i, fdt) * g, pt.switch(pt.gt(f, g), i, j), pt.isinf(1.0 / pt.floor(abs(f))),
+            pt.sum(i, axis=None), pt.sum(pt.cast(i, "int8"), axis=None, dtype="int8"), pt.prod(pt.clip(j, -2, 2), axis=None), pt.max(i, axis=0), pt.min(j, axis=rank - 1),
+            pt.any(pt.gt(i, 90), axis=None), pt.all(pt.neq(j, 0), axis=0), pt.mean(pt.sqr(f), axis=None), pt.var(f, axis=rank - 1) + 1.0, pt.power(abs(g) + 0.5, pt.cast(i % 4, fdt)),
+        ]
+        return ins, outs, vals
+
+    return build
+
+
+for _s in range(12):
+    case(f"dtype_fuzz_{_s}", rtol=2e-5)(_make3(_s))
