@@ -662,6 +662,7 @@ if __name__ == "__main__":
     import golden_cases_r2b  # noqa: F401
     import golden_cases_r5  # noqa: F401
     import golden_cases_layout_fuzz  # noqa: F401
+    import golden_cases_glm_fuzz  # noqa: F401
 
     names = sys.argv[1:] or list(CASES)
     for n in names:

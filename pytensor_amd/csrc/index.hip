@@ -236,7 +236,8 @@ __global__ __launch_bounds__(BLOCK) void scatter_add_finish_kernel(T* __restrict
   }
 }
 
-// many bins: native fp atomics (order not reproducible in the last bits; documented)
+// many bins, integer types (and PTHIP_SCATTER_EXACT=0): native atomics — exact for integers; for floating point the
+// last bits depend on the order the adds were served in
 template <class T>
 __global__ __launch_bounds__(BLOCK) void scatter_add_atomic_kernel(
     T* __restrict__ out, const long long* __restrict__ idx, const T* __restrict__ y,
@@ -260,6 +261,136 @@ __global__ __launch_bounds__(BLOCK) void scatter_add_atomic_kernel(
     else
       atomicAdd((int*)&out[j * inner + c], (int)y[r * ys0 + c]);
   }
+}
+
+// ---- scatter: add, floating point, ANY number of bins: exact and therefore order-independent -----------------------
+// The atomic kernel above gives sums whose last bits depend on the order the hardware served the adds in: two
+// evaluations of the same graph differ (found by the seeded regression graphs with 300 groups, tests/golden/glm_fuzz_*).
+// Integer addition is associative, so: every addend becomes a 128-bit fixed-point integer in units of 2^-95 of the
+// largest |y| (a first pass takes that maximum; 43 bits below the largest value's last bit are kept, anything smaller
+// loses bits — an absolute error of 2^-95 max|y| per addend, far inside one rounding of any sum it could matter to;
+// 30 bits of headroom: 1e9 addends of the largest magnitude), the bins add their integers with two 64-bit integer
+// atomics (low word, then high word + the carry the low add produced: the total is the exact sum mod 2^128 whatever the
+// order), and a last pass rounds each bin ONCE to the output type and adds it to what `out` held.  NaN / infinities go
+// through per-bin flag bits.  More accurate than the reference's sequential adds (subtensor.py AdvancedIncSubtensor1:
+// np.add.at), bit-identical from run to run.
+__global__ __launch_bounds__(BLOCK) void scatter_absmax_kernel(const void* __restrict__ y, int f32, long long n_idx, long long inner,
+                                                              long long ys0, unsigned long long* __restrict__ maxbits) {
+  const long long n = n_idx * inner;
+  unsigned long long best = 0;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) {
+    const long long r = i / inner, c = i - r * inner;
+    const double v = f32 ? (double)((const float*)y)[r * ys0 + c] : ((const double*)y)[r * ys0 + c];
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v) & 0x7fffffffffffffffull;
+    if ((b >> 52) != 0x7ff && b > best) best = b;  // (finite values only; non-negative doubles order like their bits)
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long ob = (unsigned long long)__shfl_xor((long long)best, o);
+    best = ob > best ? ob : best;
+  }
+  if ((threadIdx.x & 63) == 0 && best) atomicMax(maxbits, best);
+}
+
+__global__ __launch_bounds__(BLOCK) void scatter_add_exact_kernel(unsigned long long* __restrict__ lo, unsigned long long* __restrict__ hi,
+                                                                 unsigned* __restrict__ flags, const long long* __restrict__ idx,
+                                                                 const void* __restrict__ y, int f32, long long n_idx, long long inner,
+                                                                 long long n_rows, long long ys0,
+                                                                 const unsigned long long* __restrict__ maxbits, int* status) {
+  const long long n = n_idx * inner;
+  int Ef = (int)((*maxbits >> 52) & 0x7ff);
+  if (Ef == 0) Ef = 1;  // (largest value subnormal or zero: the subnormal exponent)
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) {
+    const long long r = i / inner, c = i - r * inner;
+    long long j = idx[r];
+    if (j < 0) j += n_rows;
+    if (j < 0 || j >= n_rows) {
+      atomicOr(status, 1);
+      continue;
+    }
+    const long long bin = j * inner + c;
+    const double v = f32 ? (double)((const float*)y)[r * ys0 + c] : ((const double*)y)[r * ys0 + c];
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    int ef = (int)((b >> 52) & 0x7ff);
+    unsigned long long m = b & 0x000fffffffffffffull;
+    const bool neg = (b >> 63) != 0;
+    if (ef == 0x7ff) {
+      atomicOr(&flags[bin], m ? 1u : (neg ? 4u : 2u));  // NaN / -inf / +inf
+      continue;
+    }
+    if (ef) m |= 1ull << 52; else ef = 1;
+    if (m == 0) continue;
+    // v = m 2^(ef - 1075); unit 2^(Ef - 1075 - 43): q = m 2^(ef - Ef + 43)
+    const int sh = ef - Ef + 43;  // <= 43
+    unsigned long long qlo, qhi;
+    if (sh >= 0) {
+      qlo = m << sh;
+      qhi = sh ? (m >> (64 - sh)) : 0ull;
+    } else if (sh > -53) {
+      qlo = m >> (-sh);
+      qhi = 0;
+    } else {
+      continue;
+    }
+    if (neg) {  // two's complement
+      qlo = ~qlo + 1ull;
+      qhi = ~qhi + (qlo == 0 ? 1ull : 0ull);
+    }
+    if (qlo == 0 && qhi == 0) continue;
+    const unsigned long long old = atomicAdd(&lo[bin], qlo);
+    const unsigned long long carry = (old + qlo) < old ? 1ull : 0ull;
+    if (qhi + carry) atomicAdd(&hi[bin], qhi + carry);
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(BLOCK) void scatter_exact_finish_kernel(T* __restrict__ out, const unsigned long long* __restrict__ lo,
+                                                                    const unsigned long long* __restrict__ hi,
+                                                                    const unsigned* __restrict__ flags, long long n_bins,
+                                                                    const unsigned long long* __restrict__ maxbits) {
+  const long long bin = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (bin >= n_bins) return;
+  const unsigned f = flags[bin];
+  double add;
+  if (f) {
+    add = (f & 1u) || ((f & 2u) && (f & 4u)) ? __longlong_as_double(0x7ff8000000000000ll)
+                                            : ((f & 2u) ? __longlong_as_double(0x7ff0000000000000ll) : __longlong_as_double((long long)0xfff0000000000000ull));
+  } else {
+    unsigned long long l = lo[bin], h = hi[bin];
+    if (l == 0 && h == 0) return;  // (nothing landed here: out keeps its bits, -0.0 included)
+    const bool neg = (h >> 63) != 0;
+    if (neg) {
+      l = ~l + 1ull;
+      h = ~h + (l == 0 ? 1ull : 0ull);
+    }
+    // magnitude h:l -> double, round to nearest even once
+    const int p = h ? 127 - __clzll((long long)h) : 63 - __clzll((long long)l);  // position of the leading bit
+    unsigned long long mant;
+    int e2 = 0;
+    if (p <= 52) {
+      mant = l;
+    } else {
+      const int s = p - 52;  // bits to drop (1..75)
+      unsigned long long kept, half_bit, rest;
+      if (s < 64) {
+        kept = (l >> s) | (s ? (h << (64 - s)) : 0ull);
+        half_bit = (l >> (s - 1)) & 1ull;
+        rest = s > 1 ? (l & ((1ull << (s - 1)) - 1ull)) : 0ull;
+      } else {
+        const int t = s - 64;  // 0..11
+        kept = h >> t;
+        half_bit = t ? ((h >> (t - 1)) & 1ull) : (l >> 63);
+        rest = t ? ((h & ((1ull << (t - 1)) - 1ull)) | l) : (l & 0x7fffffffffffffffull);
+      }
+      mant = kept + ((half_bit && (rest || (kept & 1ull))) ? 1ull : 0ull);  // (2^53 after the carry is still exact)
+      e2 = s;
+    }
+    int Ef = (int)((*maxbits >> 52) & 0x7ff);
+    if (Ef == 0) Ef = 1;
+    add = ldexp((double)mant, Ef - 1075 - 43 + e2);
+    if (neg) add = -add;
+  }
+  out[bin] = (T)((double)out[bin] + add);
 }
 
 // ---- pack: gather up to 16 small contiguous buffers into one staging buffer -----------------
@@ -410,6 +541,8 @@ size_t pthip_scatter_rows_workspace(int64_t n_idx, int64_t n_rows, int64_t inner
     if (nblk > cap) nblk = cap;
     if (nblk < 1) nblk = 1;
     add_ws = (size_t)nblk * BLOCK * 8;  // parts * n_bins <= BLOCK partial values per block
+  } else {
+    add_ws = (size_t)n_bins * 24 + 64;  // the exact accumulator: two 64-bit words + a flag word per bin (padded), the maximum
   }
   return set_ws > add_ws ? set_ws : add_ws;
 }
@@ -467,6 +600,26 @@ int pthip_scatter_rows(int dtype, int inc, int64_t n_idx, int64_t inner, void* o
     else LAUNCH(long long);
 #undef LAUNCH
     return pthip::post_launch("scatter_add_scan");
+  }
+  static const bool exact = !(getenv("PTHIP_SCATTER_EXACT") && atoi(getenv("PTHIP_SCATTER_EXACT")) == 0);
+  if (exact && (dtype == PTHIP_F64 || dtype == PTHIP_F32)) {
+    unsigned long long* lo = (unsigned long long*)ws;
+    unsigned long long* hi = lo + n_bins;
+    unsigned* flags = (unsigned*)(hi + n_bins);
+    unsigned long long* maxbits = (unsigned long long*)((char*)ws + (size_t)n_bins * 24);
+    PTHIP_CHECK(pthip::memset_async(ws, 0, (size_t)n_bins * 24 + 8, st));
+    const int f32 = dtype == PTHIP_F32;
+    PTHIP_KLAUNCH(scatter_absmax_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, st, y, f32, (long long)n_idx, (long long)inner, (long long)ys0, maxbits);
+    PTHIP_KLAUNCH(scatter_add_exact_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, st, lo, hi, flags, (const long long*)idx, y, f32,
+                  (long long)n_idx, (long long)inner, (long long)n_rows, (long long)ys0, (const unsigned long long*)maxbits, status);
+    const unsigned fg = (unsigned)((n_bins + BLOCK - 1) / BLOCK);
+    if (f32)
+      PTHIP_KLAUNCH(scatter_exact_finish_kernel<float>, dim3(fg), dim3(BLOCK), 0, st, (float*)out, (const unsigned long long*)lo,
+                    (const unsigned long long*)hi, (const unsigned*)flags, n_bins, (const unsigned long long*)maxbits);
+    else
+      PTHIP_KLAUNCH(scatter_exact_finish_kernel<double>, dim3(fg), dim3(BLOCK), 0, st, (double*)out, (const unsigned long long*)lo,
+                    (const unsigned long long*)hi, (const unsigned*)flags, n_bins, (const unsigned long long*)maxbits);
+    return pthip::post_launch("scatter_add_exact");
   }
 #define LAUNCH(T)                                                                                  \
   PTHIP_KLAUNCH((scatter_add_atomic_kernel<T>), dim3(grid_for(n)), dim3(BLOCK), 0, st,        \

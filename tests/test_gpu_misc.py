@@ -183,3 +183,66 @@ def test_ifelse_runs_only_the_branch_taken(hip):
     with pytest.raises(ValueError, match="incompatible shapes"):
         exe(np.asarray(False), Av, bv, np.zeros(4))
     assert exe.stats["captures"] == 0  # the condition is read on the host: such graphs stay eager
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_scatter_add_many_bins_is_exact_and_reproducible(hip, dtype):
+    """``out[idx] += y`` with more bins than the fixed-order kernel takes (> 256; AdvancedIncSubtensor1,
+    pytensor/tensor/subtensor.py: np.add.at semantics) accumulates 128-bit fixed-point integers with integer atomics
+    (csrc/index.hip scatter_add_exact_kernel): every bin is the EXACT sum of its addends rounded once — compared
+    here with math.fsum — so two calls give the same bits, whatever order the hardware served the adds in.  Duplicated
+    indices by the thousand, negative indices, mixed signs and magnitudes over 2^40, zeros, -0.0, subnormals, and bins
+    that receive NaN / +inf / -inf / both infinities."""
+    import ctypes as C
+    import math
+
+    from pytensor_amd.device import DeviceArray
+
+    lib = hip.lib()
+    rng = np.random.default_rng(31)
+    n, bins = 200_000, 5000
+    idx = rng.integers(0, bins - 8, size=n)
+    idx[::7] -= bins  # negative indices wrap
+    y = rng.normal(size=n) * np.exp2(rng.integers(-20, 20, size=n))
+    y[::11] = 0.0
+    y[5::13] = -0.0
+    if dtype == "float64":
+        y[3::1001] = 5e-324 * rng.integers(1, 1000, size=y[3::1001].shape)  # subnormals (far below the window: they may be dropped)
+    y = y.astype(dtype)
+    # the special bins bins-8 .. bins-1
+    sp_idx = np.array([bins - 8, bins - 7, bins - 6, bins - 6, bins - 5, bins - 5, bins - 4], dtype="int64")
+    sp_y = np.array([np.nan, np.inf, -np.inf, 1.0, np.inf, -np.inf, 3.5], dtype=dtype)
+    idx = np.concatenate([idx, sp_idx])
+    y = np.concatenate([y, sp_y])
+    base = rng.normal(size=bins).astype(dtype)
+    d_idx, d_y = DeviceArray.from_host(idx), DeviceArray.from_host(y)
+
+    def run():
+        out = DeviceArray.from_host(base.copy())
+        ws_bytes = lib.pthip_scatter_rows_workspace(len(idx), bins, 1)
+        ws = DeviceArray.empty((ws_bytes,), "uint8")
+        hip.check(lib.pthip_scatter_rows(hip.np_dtype_code(dtype), 1, len(idx), 1, out.ptr, bins, d_idx.ptr, d_y.ptr, 1, ws.ptr, ws_bytes))
+        return out.to_host()
+
+    a, b = run(), run()
+    np.testing.assert_array_equal(a, b)
+    st = C.c_int(-1)
+    hip.check(lib.pthip_check_status(C.byref(st)))
+    assert st.value == 0
+    # exact sums: the window keeps 43 bits below the largest addend's last bit, so everything here but the subnormals
+    # is inside it; the subnormals are 1e-300 of a rounding step
+    want = np.empty(bins, dtype="float64")
+    pos = np.where(idx < 0, idx + bins, idx)
+    order = np.argsort(pos, kind="stable")
+    bounds = np.searchsorted(pos[order], np.arange(bins + 1))
+    y64 = y.astype("float64")
+    for k in range(bins):
+        vals = y64[order[bounds[k]:bounds[k + 1]]]
+        vals = vals[np.abs(vals) > 1e-300] if np.isfinite(vals).all() else vals
+        want[k] = math.fsum(vals) if np.isfinite(vals).all() else np.sum(vals)
+    with np.errstate(invalid="ignore"):
+        want = (base.astype("float64") + want).astype(dtype)
+    np.testing.assert_array_equal(a[: bins - 8], want[: bins - 8])
+    assert np.isnan(a[bins - 8]) and a[bins - 7] == np.inf and a[bins - 6] == -np.inf and np.isnan(a[bins - 5])
+    assert a[bins - 4] == want[bins - 4]
