@@ -279,7 +279,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_absmax_kernel(const void* __res
   const long long n = n_idx * inner;
   unsigned long long best = 0;
   for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) {
-    const long long r = i / inner, c = i - r * inner;
+    const long long r = inner == 1 ? i : i / inner, c = i - r * inner;
     const double v = f32 ? (double)((const float*)y)[r * ys0 + c] : ((const double*)y)[r * ys0 + c];
     const unsigned long long b = (unsigned long long)__double_as_longlong(v) & 0x7fffffffffffffffull;
     if ((b >> 52) != 0x7ff && b > best) best = b;  // (finite values only; non-negative doubles order like their bits)
@@ -289,19 +289,81 @@ __global__ __launch_bounds__(BLOCK) void scatter_absmax_kernel(const void* __res
     const unsigned long long ob = (unsigned long long)__shfl_xor((long long)best, o);
     best = ob > best ? ob : best;
   }
-  if ((threadIdx.x & 63) == 0 && best) atomicMax(maxbits, best);
+  // one atomic per workgroup (a wave each was 16,000 atomics on one word for a million addends: most of the pass)
+  __shared__ unsigned long long s_best[BLOCK / 64];
+  if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < BLOCK / 64; w++) best = s_best[w] > best ? s_best[w] : best;
+    if (best) atomicMax(maxbits, best);
+  }
 }
 
+// one addend as a 128-bit two's-complement integer in units of 2^(Ef - 1075 - 43); false: nothing to add (zero, below the
+// window) or a non-finite value (*special: 1 NaN, 2 +inf, 4 -inf)
+static __device__ __forceinline__ bool scatter_fixed(double v, int Ef, unsigned long long& qlo, unsigned long long& qhi, unsigned& special) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  int ef = (int)((b >> 52) & 0x7ff);
+  unsigned long long m = b & 0x000fffffffffffffull;
+  const bool neg = (b >> 63) != 0;
+  special = 0;
+  if (ef == 0x7ff) {
+    special = m ? 1u : (neg ? 4u : 2u);
+    return false;
+  }
+  if (ef) m |= 1ull << 52; else ef = 1;
+  if (m == 0) return false;
+  // v = m 2^(ef - 1075); unit 2^(Ef - 1075 - 43): q = m 2^(ef - Ef + 43)
+  const int sh = ef - Ef + 43;  // <= 43
+  if (sh >= 0) {
+    qlo = m << sh;
+    qhi = sh ? (m >> (64 - sh)) : 0ull;
+  } else if (sh > -53) {
+    qlo = m >> (-sh);
+    qhi = 0;
+  } else {
+    return false;
+  }
+  if (neg) {  // two's complement
+    qlo = ~qlo + 1ull;
+    qhi = ~qhi + (qlo == 0 ? 1ull : 0ull);
+  }
+  return (qlo | qhi) != 0;
+}
+
+// 128-bit add of (qlo, qhi) into (lo[bin], hi[bin]) with two 64-bit integer atomics: exact mod 2^128 in any order
+static __device__ __forceinline__ void scatter_add128(unsigned long long* lo, unsigned long long* hi, unsigned long long qlo, unsigned long long qhi) {
+  unsigned long long carry = 0;
+  if (qlo) {
+    const unsigned long long old = atomicAdd(lo, qlo);
+    carry = (old + qlo) < old ? 1ull : 0ull;
+  }
+  if (qhi + carry) atomicAdd(hi, qhi + carry);
+}
+
+// LDS != 0: the workgroup first adds its share of the addends into a private table of all bins in LDS (LDS integer
+// atomics: no trip to memory, no contention between workgroups) and then adds its non-zero entries to the global table
+// — for a few hundred to a few thousand bins the global atomics drop from two per addend to two per (workgroup, bin)
+// and no longer queue up on a few hundred addresses (300 bins, 1e6 addends: profiles/r6i_scatter_exact.txt).
+template <bool LDS>
 __global__ __launch_bounds__(BLOCK) void scatter_add_exact_kernel(unsigned long long* __restrict__ lo, unsigned long long* __restrict__ hi,
                                                                  unsigned* __restrict__ flags, const long long* __restrict__ idx,
                                                                  const void* __restrict__ y, int f32, long long n_idx, long long inner,
                                                                  long long n_rows, long long ys0,
-                                                                 const unsigned long long* __restrict__ maxbits, int* status) {
+                                                                 const unsigned long long* __restrict__ maxbits, int* status, int n_bins) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sc_smem[];
+  unsigned long long* s_lo = (unsigned long long*)sc_smem;
+  unsigned long long* s_hi = s_lo + n_bins;
+  if constexpr (LDS) {
+    for (int b = threadIdx.x; b < 2 * n_bins; b += BLOCK) s_lo[b] = 0;
+    __syncthreads();
+  }
   const long long n = n_idx * inner;
   int Ef = (int)((*maxbits >> 52) & 0x7ff);
   if (Ef == 0) Ef = 1;  // (largest value subnormal or zero: the subnormal exponent)
   for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) {
-    const long long r = i / inner, c = i - r * inner;
+    const long long r = inner == 1 ? i : i / inner, c = i - r * inner;  // (a 64-bit division is ~100 instructions)
     long long j = idx[r];
     if (j < 0) j += n_rows;
     if (j < 0 || j >= n_rows) {
@@ -310,36 +372,21 @@ __global__ __launch_bounds__(BLOCK) void scatter_add_exact_kernel(unsigned long 
     }
     const long long bin = j * inner + c;
     const double v = f32 ? (double)((const float*)y)[r * ys0 + c] : ((const double*)y)[r * ys0 + c];
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    int ef = (int)((b >> 52) & 0x7ff);
-    unsigned long long m = b & 0x000fffffffffffffull;
-    const bool neg = (b >> 63) != 0;
-    if (ef == 0x7ff) {
-      atomicOr(&flags[bin], m ? 1u : (neg ? 4u : 2u));  // NaN / -inf / +inf
-      continue;
-    }
-    if (ef) m |= 1ull << 52; else ef = 1;
-    if (m == 0) continue;
-    // v = m 2^(ef - 1075); unit 2^(Ef - 1075 - 43): q = m 2^(ef - Ef + 43)
-    const int sh = ef - Ef + 43;  // <= 43
     unsigned long long qlo, qhi;
-    if (sh >= 0) {
-      qlo = m << sh;
-      qhi = sh ? (m >> (64 - sh)) : 0ull;
-    } else if (sh > -53) {
-      qlo = m >> (-sh);
-      qhi = 0;
-    } else {
+    unsigned special;
+    if (!scatter_fixed(v, Ef, qlo, qhi, special)) {
+      if (special) atomicOr(&flags[bin], special);
       continue;
     }
-    if (neg) {  // two's complement
-      qlo = ~qlo + 1ull;
-      qhi = ~qhi + (qlo == 0 ? 1ull : 0ull);
+    if constexpr (LDS) scatter_add128(&s_lo[bin], &s_hi[bin], qlo, qhi);
+    else scatter_add128(&lo[bin], &hi[bin], qlo, qhi);
+  }
+  if constexpr (LDS) {
+    __syncthreads();
+    for (int b = threadIdx.x; b < n_bins; b += BLOCK) {
+      const unsigned long long l = s_lo[b], h = s_hi[b];
+      if (l | h) scatter_add128(&lo[b], &hi[b], l, h);
     }
-    if (qlo == 0 && qhi == 0) continue;
-    const unsigned long long old = atomicAdd(&lo[bin], qlo);
-    const unsigned long long carry = (old + qlo) < old ? 1ull : 0ull;
-    if (qhi + carry) atomicAdd(&hi[bin], qhi + carry);
   }
 }
 
@@ -609,9 +656,28 @@ int pthip_scatter_rows(int dtype, int inc, int64_t n_idx, int64_t inner, void* o
     unsigned long long* maxbits = (unsigned long long*)((char*)ws + (size_t)n_bins * 24);
     PTHIP_CHECK(pthip::memset_async(ws, 0, (size_t)n_bins * 24 + 8, st));
     const int f32 = dtype == PTHIP_F32;
-    PTHIP_KLAUNCH(scatter_absmax_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, st, y, f32, (long long)n_idx, (long long)inner, (long long)ys0, maxbits);
-    PTHIP_KLAUNCH(scatter_add_exact_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, st, lo, hi, flags, (const long long*)idx, y, f32,
-                  (long long)n_idx, (long long)inner, (long long)n_rows, (long long)ys0, (const unsigned long long*)maxbits, status);
+    const unsigned gmax = grid_for(n) < 512u ? grid_for(n) : 512u;
+    PTHIP_KLAUNCH(scatter_absmax_kernel, dim3(gmax), dim3(BLOCK), 0, st, y, f32, (long long)n_idx, (long long)inner, (long long)ys0, maxbits);
+    constexpr long long LDS_BINS = 8192;  // 16 bytes per bin: 128 KB of LDS
+    if (n_bins <= LDS_BINS && n >= 16 * n_bins) {
+      auto kl = scatter_add_exact_kernel<true>;
+      const size_t sh = (size_t)n_bins * 16;
+      static size_t sh_set = 0;
+      if (sh > sh_set && sh > 48 * 1024) {
+        PTHIP_CHECK(hipFuncSetAttribute((const void*)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_BINS * 16)));
+        sh_set = LDS_BINS * 16;
+      }
+      // (one workgroup per CU at most: every workgroup ends with up to n_bins pairs of global atomics)
+      long long wgs = (n + 16 * BLOCK - 1) / (16 * BLOCK);
+      if (wgs > pthip::kNumCU) wgs = pthip::kNumCU;
+      if (wgs < 1) wgs = 1;
+      PTHIP_KLAUNCH(kl, dim3((unsigned)wgs), dim3(BLOCK), sh, st, lo, hi, flags, (const long long*)idx, y, f32, (long long)n_idx,
+                    (long long)inner, (long long)n_rows, (long long)ys0, (const unsigned long long*)maxbits, status, (int)n_bins);
+    } else {
+      PTHIP_KLAUNCH(scatter_add_exact_kernel<false>, dim3(grid_for(n)), dim3(BLOCK), 0, st, lo, hi, flags, (const long long*)idx, y, f32,
+                    (long long)n_idx, (long long)inner, (long long)n_rows, (long long)ys0, (const unsigned long long*)maxbits, status,
+                    (int)(n_bins > 0x7fffffff ? 0 : n_bins));
+    }
     const unsigned fg = (unsigned)((n_bins + BLOCK - 1) / BLOCK);
     if (f32)
       PTHIP_KLAUNCH(scatter_exact_finish_kernel<float>, dim3(fg), dim3(BLOCK), 0, st, (float*)out, (const unsigned long long*)lo,
