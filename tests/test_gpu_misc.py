@@ -246,3 +246,28 @@ def test_scatter_add_many_bins_is_exact_and_reproducible(hip, dtype):
     np.testing.assert_array_equal(a[: bins - 8], want[: bins - 8])
     assert np.isnan(a[bins - 8]) and a[bins - 7] == np.inf and a[bins - 6] == -np.inf and np.isnan(a[bins - 5])
     assert a[bins - 4] == want[bins - 4]
+
+    # rows of a matrix (inner = 3: bins = rows x 3), few addends per bin (the table in memory, not in LDS) and many
+    for rows, n2 in ((40_000, 30_000), (700, 60_000)):
+        idx2 = rng.integers(-rows, rows, size=n2)
+        y2 = (rng.normal(size=(n2, 3)) * np.exp2(rng.integers(-10, 10, size=(n2, 1)))).astype(dtype)
+        base2 = rng.normal(size=(rows, 3)).astype(dtype)
+        d_i2, d_y2 = DeviceArray.from_host(idx2), DeviceArray.from_host(y2)
+        got = []
+        for _ in range(2):
+            out = DeviceArray.from_host(base2.copy())
+            ws_bytes = lib.pthip_scatter_rows_workspace(n2, rows, 3)
+            ws = DeviceArray.empty((ws_bytes,), "uint8")
+            hip.check(lib.pthip_scatter_rows(hip.np_dtype_code(dtype), 1, n2, 3, out.ptr, rows, d_i2.ptr, d_y2.ptr, 3, ws.ptr, ws_bytes))
+            got.append(out.to_host())
+        np.testing.assert_array_equal(got[0], got[1])
+        pos2 = np.where(idx2 < 0, idx2 + rows, idx2)
+        exact = np.zeros((rows, 3))
+        order2 = np.argsort(pos2, kind="stable")
+        b2 = np.searchsorted(pos2[order2], np.arange(rows + 1))
+        y2d = y2.astype("float64")
+        for k in range(rows):
+            sel = order2[b2[k]:b2[k + 1]]
+            if len(sel):
+                exact[k] = [math.fsum(y2d[sel, c]) for c in range(3)]
+        np.testing.assert_array_equal(got[0], (base2.astype("float64") + exact).astype(dtype))
