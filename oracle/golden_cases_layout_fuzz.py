@@ -121,14 +121,29 @@ for _s in range(3):
 
 
 # ---- second family: the same random views into the indexing / ordering / scan ops ----
-def _make2(seed):
+def _make2(seed, dtype="float64"):
     def build():
         rng = np.random.default_rng(9000 + seed)
         rank = int(rng.integers(2, 5))
         shape = _shape(rng, rank, budget=9000)
-        a, xa, va = _operand(rng, "a", shape, "float64", allow_bcast=False)
-        b, xb, vb = _operand(rng, "b", shape, "float64")
-        c, xc, vc = _operand(rng, "c", shape, "float64", allow_bcast=False)
+        a, xa, va = _operand(rng, "a", shape, dtype, allow_bcast=False)
+        b, xb, vb = _operand(rng, "b", shape, dtype)
+        c, xc, vc = _operand(rng, "c", shape, dtype, allow_bcast=False)
+        if np.dtype(dtype).kind in "iu":
+            # distinct values (argmax / argsort of ties is a convention, not arithmetic): a permutation plus noise-free offsets
+            va = (rng.permutation(va.size).reshape(va.shape) - va.size // 2).astype(dtype)
+            vc = (rng.permutation(vc.size).reshape(vc.shape) * 3 - vc.size).astype(dtype)
+            ins, vals = [xa, xb, xc], {"a": va, "b": vb, "c": vc}
+            ax = lambda: int(rng.integers(rank))  # noqa: E731
+            k = ax()
+            n = shape[k]
+            iv = pt.tensor("iv", dtype="int64", shape=(None,))
+            ins.append(iv)
+            vals["iv"] = rng.integers(-n, n, size=n + 2)
+            outs = [pt.argmax(a, axis=ax()), pt.argmin(c, axis=ax()), pt.cumsum(a, axis=ax()), pt.sort(a, axis=ax()), pt.argsort(c, axis=ax()),
+                    pt.take(a, iv, axis=k), pt.where(pt.gt(a, b), a, c), pt.concatenate([a, c], axis=ax()), pt.sum(a.reshape((-1,))[::2]),
+                    pt.max(a, axis=_axes(rng, rank)) - pt.min(c, axis=None)]
+            return ins, outs, vals
         ins, vals = [xa, xb, xc], {"a": va, "b": vb, "c": vc}
         ax = lambda: int(rng.integers(rank))  # noqa: E731
         outs = []
@@ -159,6 +174,10 @@ def _make2(seed):
 
 for _s in range(12):
     case(f"layout_fuzz2_{_s}", rtol=1e-10)(_make2(_s))
+for _s in range(3):
+    case(f"layout_fuzz2_f32_{_s}", rtol=1e-4)(_make2(40 + _s, "float32"))
+for _s in range(3):
+    case(f"layout_fuzz2_i64_{_s}", rtol=0)(_make2(60 + _s, "int64"))
 
 
 # ---- third family: scalar semantics across dtypes (integer division / modulo signs, rounding, overflow wrap-around,
