@@ -106,3 +106,42 @@ def _make(seed):
 
 for _s in range(12):
     case(f"glm_fuzz_{_s}", rtol=1e-10)(_make(_s))
+
+
+# ---- many observed variables: T independent likelihood terms over their own data vectors of DIFFERENT lengths ----
+# (pytensor_amd/dispatch/wide.py: one launch for all terms' reductions, workgroups per term in proportion to its cost;
+#  dispatch/tail.py: the scalar chains behind them, split when too long for one launch.  Golden wide_200 pins T = 48 equal
+#  lengths; these pin ragged lengths — 1 element to 5000 — and term counts 1 .. 40 (the reference NumPy linker stops at 64 operands per node).)
+def _make_wide(seed):
+    def build():
+        rng = np.random.default_rng(15000 + seed)
+        T = int([1, 5, 17, 33, 40, 12][seed % 6])
+        mu, ls = pt.dvector("mu"), pt.dvector("ls")
+        vals = {"mu": rng.normal(size=T) * 0.5, "ls": rng.normal(size=T) * 0.3}
+        terms = []
+        for k in range(T):
+            n = int(rng.choice([1, 2, 7, 64, 257, 1000, 5000]))
+            wv = rng.normal(size=n) * 1.5 + 0.2
+            w = pytensor.shared(wv, name=f"w{k}")
+            vals[f"w{k}"] = wv
+            r = (w - mu[k]) * pt.exp(-ls[k])
+            fam = int(rng.integers(4))
+            if fam == 0:
+                terms.append((-0.5 * r**2 - ls[k]).sum())
+            elif fam == 1:
+                terms.append((-pt.log1p(r**2 / 3.0) * 2.0 - ls[k]).sum())
+            elif fam == 2:
+                terms.append((-pt.sqrt(1.0 + r**2) - ls[k]).sum())
+            else:
+                terms.append((-r - 2.0 * pt.softplus(-r) - ls[k]).sum())
+        total = terms[0]
+        for t in terms[1:]:
+            total = total + t
+        logp = total - 0.5 * pt.sum(mu**2) - 0.5 * pt.sum(ls**2)
+        return [mu, ls], [logp, *pytensor.grad(logp, [mu, ls])], vals
+
+    return build
+
+
+for _s in range(6):
+    case(f"wide_fuzz_{_s}", rtol=1e-10)(_make_wide(_s))
