@@ -222,3 +222,44 @@ def _make3(seed):
 
 for _s in range(12):
     case(f"dtype_fuzz_{_s}", rtol=2e-5)(_make3(_s))
+
+
+# ---- fourth family: whole-tensor and keepdims forms, and the shape-changing ops, on the same random views ----
+def _make4(seed):
+    def build():
+        rng = np.random.default_rng(17000 + seed)
+        rank = int(rng.integers(2, 4))
+        shape = _shape(rng, rank, budget=5000)
+        a, xa, va = _operand(rng, "a", shape, "float64", allow_bcast=False)
+        c, xc, vc = _operand(rng, "c", shape, "float64", allow_bcast=False)
+        ins, vals = [xa, xc], {"a": va, "c": vc}
+        ax = lambda: int(rng.integers(rank))  # noqa: E731
+        outs = [
+            pt.special.softmax(a, axis=None),
+            pt.special.log_softmax(a * 0.5, axis=None),
+            pt.mean(pt.sqr(a), axis=ax(), keepdims=True),
+            pt.var(a, axis=ax(), keepdims=True) + 1.0,
+            pt.std(c, axis=_axes(rng, rank)) + 1.0,
+            pt.cumsum(pt.sqr(a) + 0.5, axis=None),
+            pt.argmax(a, axis=None),
+            pt.argmax(c, axis=ax(), keepdims=True),
+            a - pt.max(a, axis=ax(), keepdims=True),
+            pt.roll(a, int(rng.integers(-5, 6)), axis=ax()),
+            pt.roll(c, int(rng.integers(1, 7))),
+            pt.repeat(a, int(rng.integers(2, 4)), axis=ax()),
+            pt.tile(c, tuple(int(rng.integers(1, 3)) for _ in range(rank))),
+            pt.tril(a) if rank == 2 else pt.tril(a[0]),
+            pt.triu(c, k=1) if rank == 2 else pt.triu(c[-1], k=-1),
+            pt.outer(a.ravel()[:37], c.ravel()[1:20:2]),
+            pt.swapaxes(a, 0, rank - 1) * 2.0,
+            pt.flatten(c, 1) if rank > 1 else c,
+            pt.stack([a, c], axis=ax()),
+            pt.sum(pt.sqr(a), axis=ax(), keepdims=True) / (pt.sum(pt.sqr(a)) + 1.0),
+        ]
+        return ins, outs, vals
+
+    return build
+
+
+for _s in range(8):
+    case(f"layout_fuzz4_{_s}", rtol=1e-10)(_make4(_s))
