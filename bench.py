@@ -239,7 +239,7 @@ def configs_params():
     return configs.C4_PARAMS
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -252,8 +252,14 @@ def main():
     ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed PMC summary instead of two rocprofv3 --pmc passes inside this run")
     ap.add_argument("--eager", action="store_true", help="per-node dispatch instead of the frozen hipGraph plan")
     ap.add_argument("--single-stream", action="store_true", help="frozen plan without the two-stream fork")
-    args = ap.parse_args()
+    ap.add_argument("--hotpath", action="store_true", help="also run the 45-case hot_* sweep (cold + warm), the blocked Cholesky and the GP graph (minutes; detail file only)")
+    ap.add_argument("--detail", default=None, help="where the full record goes (default: gpurun_out/bench_detail.json when gpurun_out/ exists, else bench_detail.json)")
+    return ap.parse_args(argv)
 
+
+def measure(args):
+    """Runs the timed region and every secondary measurement; returns the FULL record (rank 0) or None (other ranks).
+    ``main`` prints only ``compact(record)`` as the final stdout line; the full record goes to the detail file."""
     from pytensor_amd import replicas
 
     replicas.ensure_world(args.gpus)  # `python bench.py --gpus N` with no launcher: start the N ranks ourselves
@@ -351,7 +357,7 @@ def main():
     kernel_times = {k: round(v, 5) for k, v in sorted(kt.items(), key=lambda t: -t[1])[:8]}
 
     if info.rank != 0:
-        return
+        return None
 
     traffic, traffic_source = None, None
     if args.n == 1_000_000 and info.world == 1 and not args.no_live_pmc and os.environ.get("PTHIP_BENCH_LIVE_PMC", "1") != "0":
@@ -377,7 +383,8 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_configs
 
-        cfgs = bench_configs.measure(reps=10, check=False)  # (parity at these sizes: tests/test_gpu_fullsize.py)
+        which = ("c1", "c2", "c3", "c5", "wide200") + (("chol", "gp", "hotpath") if args.hotpath else ())
+        cfgs = bench_configs.measure(which, reps=10, check=False)  # (parity at these sizes: tests/test_gpu_fullsize.py)
 
     line = {
         "metric": "graph evals/sec (logp+grad, N=1e6 fp64)",
@@ -430,7 +437,87 @@ def main():
         "cpu_baseline": cpu,
         "configs": cfgs,
     }
-    print(json.dumps(line))
+    return line
+
+
+MAX_LINE = 4000  # bytes: the driver keeps ~8.7 KB of stdout tail; round 5's 26 KB line could not be parsed
+
+_TOP = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+_BASELINE_CONFIGS = ("c1", "c2_cheap", "c2_transc", "c3_dot22", "c3_gemv", "c3_bdot", "c5", "wide_200", "wide_200_gemm")
+
+
+def _short(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[: n - 1] + "~"
+
+
+def _r(x, nd=4):
+    return round(float(x), nd) if isinstance(x, (int, float)) and not isinstance(x, bool) else x
+
+
+def compact(full, detail_path=None):
+    """The one JSON line the driver parses: the contract's fields + ``roofline`` + ``cpu_baseline`` + one roofline
+    fraction per BASELINE config — bounded to ``MAX_LINE`` bytes whatever the full record holds (tests/test_bench_line.py)."""
+    out = {k: full.get(k) for k in _TOP}
+    for k in ("value", "ms_per_step"):
+        out[k] = _r(out[k], 6)
+    cfg = full.get("config") or {}
+    out["config"] = {"workload": _short(cfg.get("workload"), 160), "parallelism": cfg.get("parallelism"), "api": _short(cfg.get("value_is"), 90)}
+    rf = full.get("roofline") or {}
+    out["roofline"] = {k: _r(rf.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    out["roofline"]["kernel"] = _short(rf.get("kernel"), 70)
+    out["roofline"]["kernel_ms"] = _r((rf.get("detail") or {}).get("kernel_ms"), 6)
+    out["roofline"]["traffic_source"] = _short(rf.get("traffic_source"), 60)
+    cpu = full.get("cpu_baseline")
+    if cpu:
+        out["cpu_baseline"] = {k: _r(cpu.get(k)) for k in ("value", "unit", "cores", "kind", "ms_per_eval", "parity_err_over_bound")}
+        out["cpu_baseline"]["sample"] = _short(cpu.get("sample"), 200)
+        if out["value"] and cpu.get("value"):
+            out["speedup_vs_cpu_baseline"] = _r(full["value"] / cpu["value"], 1)
+    else:
+        out["cpu_baseline"] = None
+    cfgs = full.get("configs") or {}
+    fr = {}
+    for k in _BASELINE_CONFIGS:
+        e = cfgs.get(k)
+        if isinstance(e, dict):
+            # the dominant kernel's own fraction where one was measured, else the whole replay's
+            fr[k] = _r(e.get("kernel_frac", e.get("frac")))
+    out["configs"] = fr
+    for k in ("mfma_util", "frac_cold"):
+        if full.get(k) is not None:
+            out[k] = full[k]
+    out["value_executor_level"] = _r(full.get("value_executor_level"), 2)
+    if detail_path:
+        out["detail"] = detail_path
+    text = json.dumps(out)
+    if len(text) > MAX_LINE:  # cannot happen with the fields above; never let a growth of the record void a round again
+        for k in ("configs", "detail", "value_executor_level", "speedup_vs_cpu_baseline"):
+            out.pop(k, None)
+        out["config"] = {"workload": _short(cfg.get("workload"), 100)}
+        if out.get("cpu_baseline"):
+            out["cpu_baseline"]["sample"] = _short(out["cpu_baseline"]["sample"], 60)
+    return out
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    full = measure(args)
+    if full is None:
+        return
+    detail = args.detail
+    if detail is None:
+        d = os.path.join(ROOT, "gpurun_out")
+        detail = os.path.join(d, "bench_detail.json") if os.path.isdir(d) else os.path.join(ROOT, "bench_detail.json")
+    try:
+        with open(detail, "w") as fh:
+            json.dump(full, fh, indent=1)
+        shown = os.path.relpath(detail, ROOT)
+    except OSError as e:  # read-only tree: the compact line still goes out
+        shown = None
+        print(f"bench.py: detail file not written ({e})", file=sys.stderr)
+    sys.stderr.flush()
+    # stdout carries exactly one line — the last thing this process writes
+    print(json.dumps(compact(full, shown)), flush=True)
 
 
 if __name__ == "__main__":

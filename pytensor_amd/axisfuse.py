@@ -129,25 +129,21 @@ def fuse_elemwise_axis_reduce(g: Graph) -> Graph:
                 c = g.nodes[kc]
                 specs.append({"op": _CANON.get(c.params["scalar_op"], c.params["scalar_op"]), "acc_dtype": c.params["acc_dtype"], "dtype": c.params["dtype"]})
             made.append((Node("ElemwiseAxisReduce", {"scalar": sub, "axis": list(a), "reduce": specs}, list(n.inputs), [g.nodes[kc].outputs[0] for _, kc in members]),
-                         max(kc for _, kc in members)))
+                         min(kc for _, kc in members)))
             absorbed.update(kc for _, kc in members)
         new_nodes[k] = made
     if not new_nodes:
         return g
-    # a fused node takes the place of its LAST absorbed reduction (every input is defined by then)
-    place = {}
-    for made in new_nodes.values():
-        for node, at in made:
-            place[at] = node
+    # The fused nodes take the place of the ELEMWISE itself: their only inputs are the Elemwise's inputs (all defined
+    # before position k) and every reader of an absorbed reduction's output sits after that reduction, hence after k.
+    # (Round 5 placed them at the LAST absorbed reduction: a reader of an EARLIER reduction's output — the DimShuffle
+    # of the first of two keepdims sums — then ran before its producer.)
     nodes = []
     for k, n in enumerate(g.nodes):
         if k in new_nodes:
-            continue
-        if k in absorbed:
-            if k in place:
-                nodes.append(place[k])
-            continue
-        nodes.append(n)
+            nodes.extend(node for node, _ in new_nodes[k])
+        elif k not in absorbed:
+            nodes.append(n)
     return dead_code_elimination(_copy(g, nodes))
 
 

@@ -365,3 +365,58 @@ def test_cheap_producer_is_recomputed_instead_of_stored():
     for n in g2.nodes:
         if n.op == "Elemwise" and [b["op"] for b in n.params["scalar"]["body"]] == ["Sub"]:
             assert cons.get(n.outputs[0], 0) == 1
+
+
+def _assert_def_before_use(g, what=""):
+    defined = set(g.inputs) | {v for v, var in g.vars.items() if var.const is not None or var.kind == "none"}
+    for k, n in enumerate(g.nodes):
+        for i in n.inputs:
+            assert i in defined, f"{what}: node {k} ({n.op}) reads variable {i} before its producer runs"
+        defined.update(n.outputs)
+        for m in n.params.get("nodes", []) if isinstance(n.params.get("nodes"), list) else []:
+            defined.update(getattr(m, "outputs", []))
+    for o in g.outputs:
+        assert o in defined, f"{what}: output {o} is never produced"
+
+
+def test_axis_fusion_keeps_definition_before_use():
+    """[Elemwise(2 outs), Sum1, DimShuffle1, Sum2, DimShuffle2] — the reference's natural toposort of
+    two keepdims sums of a two-output Composite.  The fused node was placed at the LAST absorbed reduction, so
+    DimShuffle1 ran before the node that produces its input (np_graph: KeyError; DCE could drop the producer)."""
+    from pytensor_amd.axisfuse import fuse_elemwise_axis_reduce
+    from pytensor_amd.ir import Graph
+
+    g = Graph(name="two_keepdims_sums")
+    x = g.new_var("float64", (None, None), name="x")
+    y = g.new_var("float64", (None, None), name="y")
+    g.inputs = [x, y]
+    e0, e1 = g.new_var("float64", (None, None)), g.new_var("float64", (None, None))
+    body = {"in_dtypes": ["float64", "float64"], "out_dtypes": ["float64", "float64"],
+            "body": [{"op": "Mul", "in": [["i", 0], ["i", 1]], "dtype": "float64"}, {"op": "Add", "in": [["i", 0], ["i", 1]], "dtype": "float64"}],
+            "outs": [["t", 0], ["t", 1]]}
+    g.add_node("Elemwise", {"scalar": body}, [x, y], [e0, e1])
+    outs = []
+    for e in (e0, e1):
+        s = g.new_var("float64", (None,))
+        g.add_node("CAReduce", {"scalar_op": "Add", "axis": [1], "acc_dtype": "float64", "dtype": "float64"}, [e], [s])
+        d = g.new_var("float64", (None, 1))
+        g.add_node("DimShuffle", {"new_order": [0, "x"], "input_ndim": 1}, [s], [d])
+        outs.append(d)
+    g.outputs = outs
+    rng = np.random.default_rng(0)
+    ins = [rng.normal(size=(5, 7)), rng.normal(size=(5, 7))]
+    want = np_graph.run_graph(g, ins)
+    for g2 in (fuse_elemwise_axis_reduce(g), _pipeline(g)[0]):
+        ops = [n.op for n in g2.nodes]
+        assert ops.count("ElemwiseAxisReduce") == 1 and "CAReduce" not in ops
+        _assert_def_before_use(g2, "two keepdims sums")
+        got = np_graph.run_graph(g2, ins)
+        for a, b in zip(got, want):
+            np.testing.assert_allclose(a, b, rtol=1e-14)
+        np.testing.assert_allclose(got[0], (ins[0] * ins[1]).sum(1, keepdims=True), rtol=1e-14)
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_passes_keep_definition_before_use(name):
+    g, *_ = load_case(name)
+    _assert_def_before_use(_pipeline(g)[0], name)
