@@ -451,7 +451,7 @@ def _short(s, n):
 
 
 def _r(x, nd=4):
-    return round(float(x), nd) if isinstance(x, (int, float)) and not isinstance(x, bool) else x
+    return round(float(x), nd) if isinstance(x, float) else x
 
 
 def compact(full, detail_path=None):

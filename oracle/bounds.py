@@ -23,6 +23,14 @@ def c4_term_sums(v):
     logp is a sum of same-sign terms (S = 0: plain rtol); every gradient is a sum over the N
     observations:  d/dmu_g = sum r/sigma,  d/dlog_tau = sum (r/sigma) tau z[g],
     d/dz[g] = (tau/sigma) sum_{i in g} r_i,  d/dbeta = X^T r / sigma,  d/dlog_sigma = sum (r^2 - 1).
+
+    Every addend is a function of ``r_i = (y_i - a[g_i] - sum_k x_ik beta_k) / sigma`` — itself a sum of K + 2 terms.
+    The rule "c * eps * sum |term|" applies to the EXPANDED sum: the K-term dot product inside each addend
+    contributes ``D_i = sum_k |x_ik beta_k| / sigma`` per observation, weighted by |d addend / d r_i|.  For K = 128
+    and N = 1e6 that part is invisible next to the N-term sums; at K >= 1000 with about one observation per group
+    (round 5's sweep rows K in {1000, 2048, 4096} x G = 1e5) it IS the error of d/dz[g]: |r_i| ~ sqrt(K) |beta| while
+    D_i ~ K |beta|, so the outer bound alone is sqrt(K)/8 too tight for ANY pair of summation orders (OpenBLAS
+    blocks vs the reference's own C loop differ by as much).
     """
     X, y, gidx = v["X"], v["y"], v["gidx"]
     sigma = float(np.exp(v["log_sigma"]))
@@ -30,9 +38,13 @@ def c4_term_sums(v):
     a = v["mu_g"] + tau * v["z"]
     r = (y - a[gidx] - X @ v["beta"]) / sigma
     absr = np.abs(r)
-    per_group = np.bincount(gidx, weights=absr, minlength=v["z"].shape[0])
-    return [0.0, absr.sum() / sigma, (absr * np.abs(tau * v["z"][gidx])).sum() / sigma, tau / sigma * per_group,
-            (np.abs(X).T @ absr) / sigma, float((r * r + 1.0).sum())]
+    absX = np.abs(X)
+    D = (absX @ np.abs(v["beta"])) / sigma  # forward-error scale of r_i: the dot product's own sum |term|
+    G = v["z"].shape[0]
+    per_group = np.bincount(gidx, weights=absr + D, minlength=G)
+    tz = np.abs(tau * v["z"][gidx])
+    return [0.0, (absr + D).sum() / sigma, ((absr + D) * tz).sum() / sigma, tau / sigma * per_group,
+            (absX.T @ (absr + D)) / sigma, float((r * r + 1.0 + 2.0 * absr * D).sum())]
 
 
 def check_c4(got, want, v, what="c4"):

@@ -1,0 +1,72 @@
+"""Golden cases of round 6 (imported by ``make_golden.py``).  TEST INFRASTRUCTURE.
+
+``c4_bigk_{K}_g{G}``   config #4's graph (ref_graphs.build_c4) with K in {1000, 2048, 4096} predictors and G in {128, 5000}
+    groups: the instances of the one-pass ``gchain`` kernel that hold x in LDS and split the columns over 8 / 16 / 32
+    chunks (``c8_g4``, ``c16_g2``, ``c32_g1``), which no fixture reached (``glm_fuzz_*`` stops at K = 257, G = 300).
+    X (160 MB) is stored as its recipe — ``configs.c4_inputs(N, K, G)`` + SHA-256 — not as data.
+``softmax_f32_offset``  column softmax / log-softmax of float32 operands shifted by 1e2 and 1e4, C-ordered and
+    transposed (the statistic must stay in the accumulator dtype or the result is not shift-invariant).
+``wide_200_gemm``       north_star's target with a real ``Gemm``: multi-response regression X(N,K) @ B(K,8) with a
+    Cholesky prior on every column of B, next to the 48 likelihood terms (tensor/blas/gemm.py:76 via GemmOptimizer,
+    tensor/rewriting/blas.py:437).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytensor.tensor as pt
+
+import ref_graphs
+from make_golden import case
+from pytensor_amd import configs
+
+_BIGK = {1000: 20000, 2048: 10000, 4096: 5000}  # K -> N (X is 160 MB in each)
+
+
+def _make_bigk(K, G):
+    kw = {"N": _BIGK[K], "K": K, "G": G, "seed": 60 + G % 7}
+
+    def build():
+        vals = configs.c4_inputs(**kw)
+        params, outs = ref_graphs.build_c4(vals)
+        return params, outs, vals
+
+    return kw, build
+
+
+for _K in _BIGK:
+    for _G in (128, 5000):
+        _kw, _b = _make_bigk(_K, _G)
+        case(f"c4_bigk_{_K}_g{_G}", rtol=1e-10, generated={"fn": "c4_inputs", "kwargs": _kw, "names": ["X", "y", "gidx", "Sigma"]})(_b)
+
+
+@case("softmax_f32_offset", rtol=1e-5)
+def softmax_f32_offset():
+    from pytensor.tensor.special import log_softmax, softmax
+
+    rng = np.random.default_rng(601)
+    A, B = pt.fmatrix("A"), pt.fmatrix("B")
+    T = pt.ftensor3("T")
+    outs = [softmax(A, axis=0), log_softmax(A, axis=0), softmax(B.T, axis=1), softmax(B, axis=0), log_softmax(B, axis=0),
+            softmax(T, axis=1), softmax(T.transpose(2, 0, 1), axis=-1), softmax(A, axis=1), softmax(B, axis=None)]
+    return [A, B, T], outs, {"A": (rng.normal(size=(257, 33)) + 100.0).astype("float32"), "B": (rng.normal(size=(130, 17)) + 1.0e4).astype("float32"),
+                            "T": (rng.normal(size=(5, 65, 9)) * 3 - 1.0e4).astype("float32")}
+
+
+@case("wide_200_gemm", rtol=1e-10)
+def wide_200_gemm():
+    from ref_graphs import build_wide200_gemm
+
+    vals = configs.wide200_gemm_inputs(N=257, K=16, G=8, R=8)
+    ins, outs = build_wide200_gemm(vals)
+    return ins, outs, vals
+
+
+@case("c4_gemm_multiresponse", rtol=1e-10)
+def c4_gemm_multiresponse():
+    # the same model without the 48 terms, odd sizes: R = 5 response columns, K = 37, N = 1031, 11 groups
+    from ref_graphs import build_wide200_gemm
+
+    vals = configs.wide200_gemm_inputs(N=1031, K=37, G=11, R=5, T=0, seed=3)
+    ins, outs = build_wide200_gemm(vals, T=0)
+    return ins, outs, vals

@@ -50,9 +50,10 @@ CASES = {}
 PY_RTOL = {}  # case -> tolerance of the reference's own NumPy backend against its C backend
 PY_LAZY = set()  # cases whose NumPy-backend run needs the lazy VM (IfElse): PerformLinker runs every node
 PY_OPT = {}  # cases whose unoptimised NumPy-backend run fails inside the reference: rewrite set to use instead
+GENERATED = {}  # case -> {"fn", "kwargs", "names"}: inputs stored as their recipe (tests/util._generated_inputs)
 
 
-def case(name, rtol=None, py_rtol=None, lazy=False, py_optimizer=None):
+def case(name, rtol=None, py_rtol=None, lazy=False, py_optimizer=None, generated=None):
     """``py_rtol``: where the reference's two backends disagree beyond 1e-10 (Psi: AS 103 with
     10-digit constants in C, scipy.special.psi in Python) the C linker's values are the golden
     ones and the NumPy linker's are only sanity-checked at ``py_rtol``."""
@@ -65,6 +66,8 @@ def case(name, rtol=None, py_rtol=None, lazy=False, py_optimizer=None):
             PY_LAZY.add(name)
         if py_optimizer is not None:
             PY_OPT[name] = py_optimizer
+        if generated is not None:
+            GENERATED[name] = generated
         return f
 
     return deco
@@ -637,6 +640,20 @@ def generate(name):
     d["rtol"] = tol
     if name in PY_RTOL:
         d["py_rtol"] = PY_RTOL[name]
+    skip = set()
+    if name in GENERATED:
+        import hashlib
+
+        spec = GENERATED[name]
+        regen = getattr(configs, spec["fn"])(**spec["kwargs"])
+        sha = {}
+        for k, nm in enumerate(names):
+            if nm in spec["names"]:
+                a = np.ascontiguousarray(regen[nm])
+                np.testing.assert_array_equal(a, in_vals[k])
+                sha[nm] = hashlib.sha256(a.tobytes()).hexdigest()
+                skip.add(k)
+        d["generated_inputs"] = {"fn": spec["fn"], "kwargs": spec["kwargs"], "sha256": sha}
     with open(os.path.join(GOLDEN, f"{name}.json"), "w") as fh:
         json.dump(d, fh, separators=(",", ":"))
     import philox_ref
@@ -647,7 +664,7 @@ def generate(name):
             return np.array([*key, *[(ctr >> (64 * j)) & philox_ref.MASK for j in range(4)]], dtype=np.uint64)
         return v
 
-    arrays = {f"in{k}": storable(v) for k, v in enumerate(in_vals)}
+    arrays = {f"in{k}": storable(v) for k, v in enumerate(in_vals) if k not in skip}
     arrays.update({f"cvm{k}": v for k, v in enumerate(out_c)})
     arrays.update({f"py{k}": v for k, v in enumerate(out_py)})
     np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **arrays)
@@ -663,6 +680,7 @@ if __name__ == "__main__":
     import golden_cases_r5  # noqa: F401
     import golden_cases_layout_fuzz  # noqa: F401
     import golden_cases_glm_fuzz  # noqa: F401
+    import golden_cases_r6  # noqa: F401
 
     names = sys.argv[1:] or list(CASES)
     for n in names:

@@ -77,6 +77,57 @@ def build_wide200(vals, T=None):
     return params, [total, *pytensor.grad(total, params)]
 
 
+def build_wide200_gemm(vals, T=None):
+    """north_star's target WITH a real ``Gemm`` (round 6): the multi-response form of the same model — R response
+    columns ``Y (N, R)`` regressed on the shared design matrix, coefficients ``B (K, R)``, a fixed offset matrix
+    ``O (N, R)`` (exposure / known effects): ``eta = O + X @ B + a[gidx][:, None]``.  The reference's
+    ``GemmOptimizer`` (tensor/rewriting/blas.py:437) turns ``O + X @ B`` into ``Gemm(O, 1, X, B, 1)``
+    (tensor/blas/gemm.py:76) and the gradient ``X.T @ (r / sigma) - (prior term)`` into a second one; the Cholesky
+    prior acts on every column of ``B`` (a matrix triangular solve).  Plus the ``T`` likelihood terms of
+    :func:`build_wide200`.  Data shared, parameters explicit.  Returns (params, outputs = [logp, d logp / d params])."""
+    import pytensor
+    import pytensor.tensor as pt
+    from pytensor.tensor.linalg import cholesky, solve_triangular
+
+    from pytensor_amd import configs
+
+    T = configs.WIDE_T if T is None else T
+    K, R = vals["B"].shape
+    Y = pytensor.shared(vals["Y"], name="Y")
+    O = pytensor.shared(vals["O"], name="O")
+    X = pytensor.shared(vals["X"], name="X")
+    gidx = pytensor.shared(vals["gidx"], name="gidx")
+    Sigma = pytensor.shared(vals["Sigma"], name="Sigma")
+    mu_g, log_tau, log_sigma = pt.dscalar("mu_g"), pt.dscalar("log_tau"), pt.dscalar("log_sigma")
+    z, B = pt.dvector("z"), pt.dmatrix("B")
+    tau, sigma = pt.exp(log_tau), pt.exp(log_sigma)
+    a = mu_g + tau * z
+    L = cholesky(Sigma)
+    alpha = solve_triangular(L, B, lower=True)
+    logp_B = -0.5 * pt.sum(alpha**2) - R * pt.sum(pt.log(pt.diag(L))) - 0.5 * K * R * np.log(2 * np.pi)
+    eta = O + pt.dot(X, B) + a[gidx][:, None]
+    r = (Y - eta) / sigma
+    logp_y = pt.sum(-0.5 * r**2 - log_sigma - 0.5 * np.log(2 * np.pi))
+    logp_z = pt.sum(-0.5 * z**2 - 0.5 * np.log(2 * np.pi))
+    logp_hyp = -0.5 * (mu_g**2 + log_tau**2 + log_sigma**2)
+    total = logp_y + logp_z + logp_B + logp_hyp
+    wmu, wls = pt.dvector("wmu"), pt.dvector("wls")
+    for k in range(T):
+        w = pytensor.shared(vals[f"w{k}"], name=f"w{k}")
+        rr = (w - wmu[k]) * pt.exp(-wls[k])
+        fam = k % 4
+        if fam == 0:
+            total = total + (-0.5 * rr**2 - wls[k]).sum()
+        elif fam == 1:
+            total = total + (-pt.log1p(rr**2 / 3.0) * 2.0 - wls[k]).sum()
+        elif fam == 2:
+            total = total + (-pt.abs(rr) - wls[k]).sum()
+        else:
+            total = total + (-rr - 2.0 * pt.softplus(-rr) - wls[k]).sum()
+    params = [mu_g, log_tau, z, B, log_sigma] + ([wmu, wls] if T else [])
+    return params, [total, *pytensor.grad(total, params)]
+
+
 def _build_c4_typed(vals, dtype):
     import pytensor
     import pytensor.tensor as pt

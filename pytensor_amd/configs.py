@@ -86,6 +86,29 @@ def wide200_params():
     return (*C4_PARAMS, "wmu", "wls")
 
 
+WIDE_R = 8  # response columns of the multi-response variant
+
+
+def wide200_gemm_inputs(N=1_000_000, T=WIDE_T, K=C4_K, G=C4_G, R=WIDE_R, seed=0, chain=0):
+    """The multi-response form of :func:`wide200_inputs` (oracle/ref_graphs.build_wide200_gemm): ``Y (N, R)`` responses
+    and a fixed offset matrix ``O (N, R)`` over the same design matrix, coefficients ``B (K, R)`` — the graph then
+    holds a real ``Gemm`` (``O + X @ B``, tensor/blas/gemm.py:76)."""
+    d = wide200_inputs(N=N, T=T, K=K, G=G, seed=seed, chain=chain)
+    rng = np.random.default_rng(seed + 177)
+    d["Y"] = rng.normal(size=(N, R))
+    d["O"] = 0.1 * rng.normal(size=(N, R))
+    prng = np.random.default_rng(3000 + chain)
+    d["B"] = 0.1 * prng.normal(size=(K, R))
+    del d["y"], d["beta"]
+    if T == 0:
+        del d["wmu"], d["wls"]
+    return d
+
+
+def wide200_gemm_params():
+    return ("mu_g", "log_tau", "z", "B", "log_sigma", "wmu", "wls")
+
+
 def c5_inputs(T=1000, B=64, H=1024, seed=5):
     rng = np.random.default_rng(seed)
     d = {

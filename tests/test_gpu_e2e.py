@@ -602,6 +602,84 @@ def test_function_copy_givens_and_trust_input(pt):
     np.testing.assert_array_equal(g(np.ones(3)), np.ones(3))
 
 
+def test_function_pickle_roundtrip_with_resident_data_and_frozen_plan(pt):
+    """compile/executor.py:829-879 (``_pickle_Function`` / ``_constructor_Function``): a Function pickles as its maker +
+    the values of its storage cells and re-links on load.  Under the hip linker that means: the lowered graph, the
+    generated kernels and the device-resident copy of the shared data are all re-created lazily by the loaded
+    function (SURVEY §5 "Linker must be copy/pickle-safe, device handles re-creatable lazily").  The original has a
+    captured plan and resident buffers when it is pickled; the copy must not share any of it."""
+    import copy
+    import pickle
+
+    pytensor, ptt = pt
+    rng = np.random.default_rng(77)
+    N, K = 50_000, 16
+    X = pytensor.shared(rng.normal(size=(N, K)), name="X")  # resident: 6.4 MB (page-guarded coherence)
+    y = pytensor.shared(rng.normal(size=N), name="y")
+    step = pytensor.shared(np.zeros(()), name="step")
+    beta, ls = ptt.dvector("beta"), ptt.dscalar("ls")
+    r = (y - X @ beta) * ptt.exp(-ls)
+    logp = (-0.5 * r**2 - ls).sum() - 0.5 * (beta**2).sum()
+    f = pytensor.function([beta, ls], [logp, *pytensor.grad(logp, [beta, ls])], updates={step: step + 1.0}, mode="hip")
+    bv, lv = rng.normal(size=K) * 0.1, np.asarray(0.2)
+    want = [np.array(a) for a in f(bv, lv)]
+    for _ in range(3):
+        f(bv, lv)  # capture + replays
+    exe = hip_executable(f)
+    assert exe.stats["replays"] >= 1
+    blob = pickle.dumps(f)
+    assert len(blob) > X.get_value(borrow=True).nbytes  # the shared data travel with the function (as in the reference)
+    g = pickle.loads(blob)
+    exe_g = hip_executable(g)
+    assert exe_g is not exe and exe_g.stats["replays"] == 0
+    assert float(g.get_shared()[[v.name for v in g.get_shared()].index("step")].get_value()) == 4.0
+    for call in range(4):  # eager -> capture -> replay, on the loaded function's own buffers
+        got = g(bv, lv)
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(np.asarray(a), b)
+    assert exe_g.stats["replays"] >= 1
+    # independent state: the copy's update did not touch the original's shared variable, and vice versa
+    assert float(step.get_value()) == 4.0
+    gs = {v.name: v for v in g.get_shared()}
+    assert float(gs["step"].get_value()) == 8.0
+    # an in-place edit of the ORIGINAL's data is seen by the original only
+    Xv = X.get_value(borrow=True)
+    Xv[17, 3] += 1.0
+    changed = f(bv, lv)
+    assert not np.array_equal(np.asarray(changed[0]), want[0])
+    np.testing.assert_array_equal(np.asarray(g(bv, lv)[0]), want[0])
+    Xv[17, 3] -= 1.0
+    np.testing.assert_array_equal(np.asarray(f(bv, lv)[0]), want[0])
+    # copy.copy / copy.deepcopy of a Function go through Function.copy / __deepcopy__ (compile/executor.py:760-827)
+    h = copy.copy(f)
+    np.testing.assert_array_equal(np.asarray(h(bv, lv)[0]), want[0])
+    # pickling a function whose plan was never captured, and a second round trip of the loaded one
+    g2 = pickle.loads(pickle.dumps(g))
+    np.testing.assert_array_equal(np.asarray(g2(bv, lv)[0]), want[0])
+
+
+def test_scan_function_pickle_roundtrip(pt):
+    """the reference's own pickling test is a Scan (tests/scan/test_basic.py:310, re-enabled in
+    test_gpu_refsuite_scan.py); here with a sequence, a shared weight and a gradient through the loop"""
+    import pickle
+
+    pytensor, ptt = pt
+    from pytensor.scan.basic import scan
+
+    rng = np.random.default_rng(78)
+    W = pytensor.shared(rng.normal(size=(6, 6)) * 0.3, name="W")
+    xs, h0 = ptt.dmatrix("xs"), ptt.dvector("h0")
+    hs = scan(lambda x, h: ptt.tanh(x + h @ W), sequences=[xs], outputs_info=[h0], return_updates=False)
+    loss = (hs[-1] ** 2).sum()
+    f = pytensor.function([xs, h0], [loss, pytensor.grad(loss, W)], mode="hip")
+    args = [rng.normal(size=(9, 6)), rng.normal(size=6)]
+    want = [np.array(a) for a in f(*args)]
+    g = pickle.loads(pickle.dumps(f))
+    for _ in range(3):
+        for a, b in zip(g(*args), want):
+            np.testing.assert_array_equal(np.asarray(a), b)
+
+
 def test_outputs_are_fresh_and_do_not_alias_inputs(pt):
     """link/vm.py:860-880 no_recycling semantics + aliasing.py:165-260 (DeepCopyOp)."""
     pytensor, ptt = pt

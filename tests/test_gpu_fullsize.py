@@ -237,3 +237,91 @@ def _gru_states(v, steps):
             out[t] = h
         h = _gru_step(v, v["xs"][t], h)
     return out
+
+
+# ---- round 6: the one-pass gchain kernel's large-K instances against the reference's own outputs -------------------
+
+
+@pytest.mark.parametrize("K,G,inst", [(1000, 128, "_c8_g4_"), (1000, 5000, "_c8_g4_"), (2048, 128, "_c16_g2_"), (2048, 5000, "_c16_g2_"),
+                                     (4096, 128, "_c32_g1_"), (4096, 5000, "_c32_g1_")])
+def test_c4_big_k_against_reference_outputs(hip, K, G, inst):
+    """Golden ``c4_bigk_{K}_g{G}``: config #4's graph at K >= 1000 (x held in LDS, the columns split over 8 / 16 / 32
+    chunks) against the REFERENCE C linker's stored outputs, per output at rtol 1e-12 + 8 eps sum|term| of the
+    expanded sum (oracle/bounds.c4_term_sums: the K-term dot product inside each addend counts), eager and replayed.
+    The instance the test is named for must be the one that ran."""
+    from pytensor_amd.executor import HipExecutable
+    from util import load_case
+
+    name = f"c4_bigk_{K}_g{G}"
+    g, ins, cvm, py, meta = load_case(name)
+    names = meta["input_names"]
+    vals = dict(zip(names, ins))
+    res = [k for k, n in enumerate(names) if n in configs.C4_DATA]
+    exe = HipExecutable(g, resident=res)
+    got = exe(*ins)
+    used = bounds.check_c4(got, cvm, vals, what=name)
+    for k, u in enumerate(used):
+        MARGINS[f"{name}.out{k}"] = {"max_err_over_bound": u, "rtol": 1e-12}
+    plan = exe.freeze(*ins)
+    for a, b in zip(got, plan(*ins)):
+        np.testing.assert_array_equal(a, b)
+    plan.close()
+    exe.profile_nodes(ins, reps=1)
+    kernels = [k for k in exe.last_kernel_times if k.startswith("gchain_")]
+    assert kernels and all(inst in k + "_" for k in kernels), f"{name}: expected the {inst} instance, ran {kernels}"
+    # the unfused executor (two passes over X, separate gather / scatter) lands inside the same bound
+    bounds.check_c4(HipExecutable(g, fuse=False)(*ins), cvm, vals, what=name + " unfused")
+
+
+# ---- round 6: north_star's literal target graph at N = 1e6 against the reference C linker ---------------------------
+
+
+def _wide_tolerance(want, N):
+    """sums of N terms in another order: rtol 1e-12 + 8 eps N max|term| (|r| <= 8 over 5e7 normal draws scaled by
+    exp(0.3): the normal family's d/d log-scale term r^2 - 1 stays below 64)"""
+    want = np.asarray(want)
+    return 1e-12 * np.abs(want) + C_SUM * EPS64 * N * 64.0
+
+
+@pytest.mark.parametrize("variant", ["wide_200", "wide_200_gemm"])
+def test_wide_200_N1e6_against_reference_cvm(hip, variant):
+    """``pytensor.function(mode="hip")`` on north_star's target (config #4 + 48 likelihood terms = 202 Elemwise + Cholesky;
+    ``wide_200_gemm``: the multi-response form whose lowered graph holds two real ``Gemm`` nodes) at N = 1e6 against
+    ``Mode("cvm", "fast_run")`` of the reference on the same inputs in this process; eager call, captured call and
+    replays must all agree."""
+    import e2e_util
+
+    pytensor = e2e_util.activate()
+    import ref_graphs
+
+    N = 1_000_000
+    if variant == "wide_200":
+        vals, pnames, build = configs.wide200_inputs(N=N), configs.wide200_params(), ref_graphs.build_wide200
+    else:
+        vals, pnames, build = configs.wide200_gemm_inputs(N=N), configs.wide200_gemm_params(), ref_graphs.build_wide200_gemm
+    params, outs = build(vals)
+    f = pytensor.function(params, outs, mode="hip")
+    f.trust_input = True
+    pv = [np.asarray(vals[n]) for n in pnames]
+    exe = f.vm.jit_fn
+    if variant == "wide_200_gemm":
+        assert [n.op for n in f.maker.linker.last_ir.nodes].count("Gemm") == 2
+    fc = pytensor.function(params, outs, mode=e2e_util.reference_mode())
+    fc.trust_input = True
+    want = fc(*pv)
+    first = None
+    for call in range(4):  # eager, capture, replay, replay
+        got = f(*pv)
+        worst = 0.0
+        for k, (a, b) in enumerate(zip(got, want)):
+            a, b = np.asarray(a), np.asarray(b)
+            assert a.shape == b.shape and a.dtype == b.dtype, (variant, k)
+            worst = max(worst, float(np.max(np.abs(a - b) / _wide_tolerance(b, N))))
+        assert worst <= 1.0, f"{variant} call {call}: |hip - reference C linker| / tol = {worst}"
+        if first is None:
+            first = [np.array(a) for a in got]
+        else:
+            for a, b in zip(got, first):
+                np.testing.assert_array_equal(np.asarray(a), b)
+    assert exe.stats["replays"] >= 2, exe.stats
+    MARGINS[f"{variant}_N1e6"] = {"max_err_over_bound": worst, "rtol": 1e-12, "reference": e2e_util.reference_mode_name()}

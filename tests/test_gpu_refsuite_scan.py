@@ -77,7 +77,6 @@ class TestScanHip(ref_scan.TestScan):
     test_inner_graph_cloning = None  # Mode(optimizer=None) with the default (C) linker
     # -- assert properties of the C VM / the C cache
     test_monitor_mode = None  # MonitorMode wraps the VM's per-node callback (link/vm.py)
-    test_pickling = None  # pickles the Function: storage of a VM-linked function
     test_inner_storage_leak = None  # counts storage cells of the inner VM function
     # -- compare draws with NumPy's PCG64 stream value by value: the device samplers are
     #    counter-based (Philox); a PCG64 generator is re-keyed, parity is distributional.
