@@ -2056,7 +2056,12 @@ def _tail_prologue(L, shrink):
     L.append("      else if (status_src != nullptr) atomicOr((int*)status_src, 16);")
     L.append("      join_fail_ = !ok_ && done_dst != nullptr;")
     L.append("    }")
-    L.append("    __syncthreads();  // (no acquire fence: see csrc/tail_device.h plan_join_wait)")
+    if os.environ.get("PTHIP_JOIN_FENCE", "0") == "1":
+        # opt-in: the formally ordered form — an agent-scope acquire behind the wait.  It invalidates this XCD's L2, so
+        # the slab this launch shrinks next comes back from HBM (4.8 -> 11 us, profiles/r4_c4_device_join.txt): the
+        # default leans on the invalidate every kernel start performs instead, checked by pthip_join_probe per process.
+        L.append("    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"agent\");")
+    L.append("    __syncthreads();  // (default: no acquire fence — see csrc/tail_device.h plan_join_wait; PTHIP_JOIN_FENCE=1 adds one)")
     L.append("    if (join_fail_) return;  // done word 2: pthip_plan_replay4 waits for the other stream and runs this segment again")
     L.append("  }")
     if not shrink:

@@ -404,7 +404,9 @@ __global__ __launch_bounds__(BLOCK) void scatter_exact_finish_kernel(T* __restri
                                             : ((f & 2u) ? __longlong_as_double(0x7ff0000000000000ll) : __longlong_as_double((long long)0xfff0000000000000ull));
   } else {
     unsigned long long l = lo[bin], h = hi[bin];
-    if (l == 0 && h == 0) return;  // (nothing landed here: out keeps its bits, -0.0 included)
+    // nothing landed here, or what landed cancelled exactly: out keeps its bits.  (Edge, documented in DESIGN §2: an
+    // out of -0.0 under addends that cancel exactly stays -0.0 where the reference's sequential np.add.at ends on +0.0.)
+    if (l == 0 && h == 0) return;
     const bool neg = (h >> 63) != 0;
     if (neg) {
       l = ~l + 1ull;
@@ -437,6 +439,9 @@ __global__ __launch_bounds__(BLOCK) void scatter_exact_finish_kernel(T* __restri
     add = ldexp((double)mant, Ef - 1075 - 43 + e2);
     if (neg) add = -add;
   }
+  // `add` is the EXACT sum of the bin's addends rounded once to double; adding it to what `out` already holds (zeros in
+  // every gradient graph: the reference scatters into an Alloc of 0) is a second rounding when out != 0, and for a
+  // float32 output the result is rounded to double and then to float (double rounding: <= 0.5 ulp32 + 2^-29 ulp32).
   out[bin] = (T)((double)out[bin] + add);
 }
 

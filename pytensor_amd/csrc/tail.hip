@@ -83,28 +83,38 @@ extern "C" int pthip_join_probe(int iters, int* bad_out) {
   unsigned* buf = (unsigned*)mem;
   int* word = (int*)((char*)mem + (size_t)N * 4);
   int* bad = word + 16;
-  hipEvent_t ev;
-  PTHIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  PTHIP_CHECK(hipMemsetAsync(word, 0, 128, s0));
-  PTHIP_CHECK(hipEventRecord(ev, s0));
-  PTHIP_CHECK(hipStreamWaitEvent(s1, ev, 0));
-  for (int it = 0; it < iters; it++) {
-    const unsigned val = 0x9E3779B9u * (unsigned)(it + 1);
-    hipLaunchKernelGGL(join_probe_wait_kernel, dim3(pthip::kNumCU), dim3(256), 0, s0, word, (const unsigned*)buf, N, val, bad);
-    hipLaunchKernelGGL(join_probe_write_kernel, dim3(pthip::kNumCU), dim3(256), 0, s1, buf, N, val);
-    hipLaunchKernelGGL(join_signal_kernel, dim3(1), dim3(1), 0, s1, word);
-    hipLaunchKernelGGL(join_probe_reset_kernel, dim3(1), dim3(1), 0, s0, word);
-    PTHIP_CHECK(hipEventRecord(ev, s0));  // the next overwrite waits for this iteration's readers
+  hipEvent_t ev = nullptr;
+  // every exit path gives the buffer and the event back (the early returns of PTHIP_CHECK leaked both)
+  auto run = [&]() -> int {
+    PTHIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    PTHIP_CHECK(hipMemsetAsync(word, 0, 128, s0));
+    PTHIP_CHECK(hipEventRecord(ev, s0));
     PTHIP_CHECK(hipStreamWaitEvent(s1, ev, 0));
+    for (int it = 0; it < iters; it++) {
+      const unsigned val = 0x9E3779B9u * (unsigned)(it + 1);
+      hipLaunchKernelGGL(join_probe_wait_kernel, dim3(pthip::kNumCU), dim3(256), 0, s0, word, (const unsigned*)buf, N, val, bad);
+      hipLaunchKernelGGL(join_probe_write_kernel, dim3(pthip::kNumCU), dim3(256), 0, s1, buf, N, val);
+      hipLaunchKernelGGL(join_signal_kernel, dim3(1), dim3(1), 0, s1, word);
+      hipLaunchKernelGGL(join_probe_reset_kernel, dim3(1), dim3(1), 0, s0, word);
+      PTHIP_CHECK(hipEventRecord(ev, s0));  // the next overwrite waits for this iteration's readers
+      PTHIP_CHECK(hipStreamWaitEvent(s1, ev, 0));
+    }
+    PTHIP_CHECK(hipGetLastError());
+    int h = 0;
+    PTHIP_CHECK(hipMemcpyAsync(&h, bad, 4, hipMemcpyDeviceToHost, s0));
+    PTHIP_CHECK(hipStreamSynchronize(s0));
+    PTHIP_CHECK(hipStreamSynchronize(s1));
+    *bad_out = h;
+    return 0;
+  };
+  r = run();
+  if (r) {  // whatever was enqueued must have drained before the buffer goes back to the pool
+    (void)hipStreamSynchronize(s0);
+    (void)hipStreamSynchronize(s1);
   }
-  PTHIP_CHECK(hipGetLastError());
-  int h = 0;
-  PTHIP_CHECK(hipMemcpyAsync(&h, bad, 4, hipMemcpyDeviceToHost, s0));
-  PTHIP_CHECK(hipStreamSynchronize(s0));
-  PTHIP_CHECK(hipStreamSynchronize(s1));
-  PTHIP_CHECK(hipEventDestroy(ev));
-  *bad_out = h;
-  return pthip_free(mem);
+  if (ev) (void)hipEventDestroy(ev);
+  const int rf = pthip_free(mem);
+  return r ? r : rf;
 }
 
 // the last launch of a plan's latency-chain segment (include/pthip.h)

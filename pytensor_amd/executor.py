@@ -702,17 +702,25 @@ class HipExecutable:
             # workgroups onto the device within its spin limit — another process's kernels held the compute units
             # (several PyMC chains on one GPU).  Not an error of the graph: evaluate it again with the launch-per-step
             # forms, which wait for nobody, and stay on them (include/pthip.h pthip_set_safe_mode).
+            # Safe mode is PROCESS-wide but plans are per executable: after executable A has switched the process over,
+            # executable B (or a Scan's inner executable) still holds a plan captured WITH the cooperative kernels and
+            # can hit the expired wait on its next replay.  So: always drop this executable's stale plan and evaluate
+            # once eagerly under safe mode; only a failure of THAT evaluation is an error.
             lib = ffi.lib()
-            if lib.pthip_set_safe_mode(1):
-                raise  # already on the launch-per-step forms: something else is wrong
-            import warnings
+            already = bool(lib.pthip_set_safe_mode(1))
+            had_stale_plan = self._auto_plan is not None
+            if already and not had_stale_plan:
+                raise  # the launch-per-step forms themselves expired: something else is wrong
+            if not already:
+                import warnings
 
-            warnings.warn("hip linker: a cooperative linear-algebra kernel gave up waiting for its own workgroups (the device is shared "
-                          "with other work); evaluating again with the launch-per-step forms and staying on them for this process",
-                          RuntimeWarning, stacklevel=2)
-            if self._auto_plan is not None:
+                warnings.warn("hip linker: a cooperative linear-algebra kernel gave up waiting for its own workgroups (the device is shared "
+                              "with other work); evaluating again with the launch-per-step forms and staying on them for this process",
+                              RuntimeWarning, stacklevel=2)
+            if had_stale_plan:
                 self._auto_plan.close()  # (captured with the cooperative kernels)
                 self._auto_plan = None
+            self.stats["safe_mode_retries"] = self.stats.get("safe_mode_retries", 0) + 1
             return self._call_eager(*inputs)
 
     def _call(self, *inputs):
