@@ -407,6 +407,21 @@ int pthip_pack(int n, const void* const* srcs, const int64_t* nbytes, const int6
  *      here one kernel, one HBM read + one write).  x, out: contiguous rows x cols; log_ = 1 for
  *      LogSoftmax.  float32 sums accumulate in double like the reference's Sum. ---- */
 int pthip_softmax(int dtype, int log_, int64_t rows, int64_t cols, const void* x, void* out);
+/* ---- round 6: log-sum-exp as one reduction, and Softmax / LogSoftmax over a NON-trailing axis.  The reference has no
+ *      op for the former: pytensor/tensor/math.py logsumexp is rewritten into Max -> Composite -> Sum -> Composite
+ *      (its benchmark: tests/benchmarks/test_logsumexp.py:9-37); the latter is Softmax(axis=0) (special.py:26, perform =
+ *      scipy.special.softmax).  Semantics of the stabilised graph: shift = isinf(max) ? 0 : max; NaN propagates.
+ *      float32: exp in float32, the sum in double (the reference's Sum accumulator, elemwise.py:1383-1417). ---- */
+/* out[r] = log(sum_j exp(x[r, j])), x contiguous rows x cols (a row per thread up to 32 columns, else per wave, streamed:
+ * meant for many rows; pthip_logsumexp_rows_max = the longest row accepted) */
+int pthip_logsumexp_rows(int dtype, int64_t rows, int64_t cols, const void* x, void* out);
+int64_t pthip_logsumexp_rows_max(int dtype);
+/* x contiguous (batch, R, C), the statistic runs over R: out[b, c] = log(sum_r exp(x[b, r, c])) /
+ * out[b, r, c] = softmax or log-softmax of x[b, :, c].  ws: pthip_colstat_workspace(dtype, batch, R, C) bytes of device
+ * memory (per-split (max, sum) pairs, folded in a fixed order: deterministic). */
+size_t pthip_colstat_workspace(int dtype, int64_t batch, int64_t R, int64_t C);
+int pthip_logsumexp_cols(int dtype, int64_t batch, int64_t R, int64_t C, const void* x, void* out, void* ws, size_t ws_bytes);
+int pthip_softmax_cols(int dtype, int log_, int64_t batch, int64_t R, int64_t C, const void* x, void* out, void* ws, size_t ws_bytes);
 /* ---- order-defined scans (pytensor/tensor/extra_ops.py CumOp.perform = np.cumsum/np.cumprod;
  *      pytensor/tensor/math.py Argmax.perform = np.argmax over the flattened trailing axes) ---- */
 /* dst[o, k, i] = fold_{j<=k} src[o, j, i] (mul = 0: +, 1: *), strictly left to right; src and

@@ -149,6 +149,11 @@ SIGNATURES = {
     "pthip_pack": (_int, [_int, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_i64), _vp]),
     "pthip_multi_finish": (_int, [_int, _int, C.POINTER(_int), C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_int), C.POINTER(_vp)]),
     "pthip_softmax": (_int, [_int, _int, _i64, _i64, _vp, _vp]),
+    "pthip_logsumexp_rows": (_int, [_int, _i64, _i64, _vp, _vp]),
+    "pthip_logsumexp_rows_max": (_i64, [_int]),
+    "pthip_colstat_workspace": (_sz, [_int, _i64, _i64, _i64]),
+    "pthip_logsumexp_cols": (_int, [_int, _i64, _i64, _i64, _vp, _vp, _vp, _sz]),
+    "pthip_softmax_cols": (_int, [_int, _int, _i64, _i64, _i64, _vp, _vp, _vp, _sz]),
     "pthip_cumulative": (_int, [_int, _int, _i64, _i64, _i64, _vp, _vp]),
     "pthip_imatmul": (_int, [_int, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp]),
     "pthip_argmax": (_int, [_int, _i64, _i64, _vp, _vp]),
