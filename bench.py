@@ -383,7 +383,7 @@ def measure(args):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_configs
 
-        which = ("c1", "c2", "c3", "c5", "wide200") + (("chol", "gp", "hotpath") if args.hotpath else ())
+        which = ("c1", "c2", "c3", "c5", "wide200", "wide200gemm") + (("chol", "gp", "hotpath") if args.hotpath else ())
         cfgs = bench_configs.measure(which, reps=10, check=False)  # (parity at these sizes: tests/test_gpu_fullsize.py)
 
     line = {

@@ -2244,6 +2244,8 @@ def tail_chain_source(name: str, spec: dict, sizes: dict | None = None, shrink: 
 
 
 TAIL_PRELOAD_MAX_REGS = 160  # 8-byte values a thread may hold in flight in the preloading form
+TAIL_WAVE_FOLD_INTERLEAVED = os.environ.get("PTHIP_TAIL_FOLD_INTERLEAVED", "1") != "0"
+TAIL_SCALAR_STEPS_BY_WAVE = os.environ.get("PTHIP_TAIL_SCALAR_BY_WAVE", "1") != "0"
 
 
 def tail_preload_sizes(spec: dict, ext_len, step_n):
@@ -2352,11 +2354,27 @@ def _tail_preload_source(name: str, spec: dict, sizes: dict, P, bodies, shrink=N
             L.append("      __builtin_amdgcn_sched_barrier(0);")
             for j in mine:
                 st = steps[j]
-                act, oct_ = CTYPE[st["acc_dtype"]], CTYPE[st["dtype"]]
-                op = REDUCE_OPS[st["red"]]
-                L.append(f"      if (ln_ >= rows{j}) w{j} = pthip_dev::{op}::identity<{act}>();")
-                L.append(f"      w{j} = pthip_dev::wave_reduce<pthip_dev::{op}>(w{j});")
-                L.append(f"      if (ln_ == 0) l{st['out']}[0] = ({oct_})w{j};")
+                act = CTYPE[st["acc_dtype"]]
+                L.append(f"      if (ln_ >= rows{j}) w{j} = pthip_dev::{REDUCE_OPS[st['red']]}::identity<{act}>();")
+            if TAIL_WAVE_FOLD_INTERLEAVED:
+                # step-major: every butterfly level runs over ALL of this wave's reductions before the next level —
+                # their cross-lane exchanges (two ds_bpermute per double, ~100 cycles each) are in flight together.
+                # Value by value (round 5) a wide graph's ~36 reductions per wave were 36 x 6 dependent exchanges:
+                # most of the 25 + 39 us of north_star's two tail launches (profiles/r7_wide200_*).  Same butterfly
+                # per value: the same bits.
+                L.append("#pragma unroll")
+                L.append("      for (int off_ = 32; off_ > 0; off_ >>= 1) {")
+                for j in mine:
+                    L.append(f"        const auto x{j}_ = pthip_dev::shfl_xor_any(w{j}, off_);")
+                for j in mine:
+                    L.append(f"        w{j} = pthip_dev::{REDUCE_OPS[steps[j]['red']]}::apply(w{j}, x{j}_);")
+                L.append("      }")
+            else:
+                for j in mine:
+                    L.append(f"      w{j} = pthip_dev::wave_reduce<pthip_dev::{REDUCE_OPS[steps[j]['red']]}>(w{j});")
+            for j in mine:
+                st = steps[j]
+                L.append(f"      if (ln_ == 0) l{st['out']}[0] = ({CTYPE[st['dtype']]})w{j};")
             L.append("    }")
         L.append("  }")
     L.append("  __builtin_amdgcn_sched_barrier(0);")
@@ -2412,12 +2430,36 @@ def _tail_preload_source(name: str, spec: dict, sizes: dict, P, bodies, shrink=N
     # the wave-folded reductions were emitted above: everything that reads them is in phase >= 1
     if wsteps:
         L.append("  __syncthreads();")
+    def scalar_only(st):
+        """an Elemwise step whose operands are all one-element values and that reduces nothing: n == 1 by construction"""
+        return st["op"] == "ew" and all(m in "SC" for m in st["modes"]) and all(r is None for r in st["reduce"])
+
     for ph in range(max(phase, default=-1) + 1):
         emitted = False
+        n_scalar = 0
         for j, st in enumerate(steps):
             if phase[j] != ph or (st["op"] == "rsum" and wave[j]):
                 continue
             emitted = True
+            if TAIL_SCALAR_STEPS_BY_WAVE and scalar_only(st):
+                # The steps of a phase are independent of each other, and a one-element step is one lane's work: the
+                # first lane of wave (k mod 4) takes the k-th of them, so four run side by side instead of thread 0
+                # running all of them in a row (a wide graph: ~30 scalar Composites with an exp each per phase).
+                body = st["body"]
+                w_ = n_scalar % (TAIL_BLOCK // 64)
+                n_scalar += 1
+                L.append(f"  // step {j}: one-element Elemwise (operand modes {st['modes']}), on wave {w_}")
+                L.append(f"  if (tid == {64 * w_}) {{")
+                in_names = [operand(ref, m, 0) for ref, m in zip(st["ins"], st["modes"])]
+                out_names = []
+                for q, dt in enumerate(body["out_dtypes"]):
+                    L.append(f"    {CTYPE[dt]} o{q};")
+                    out_names.append(f"o{q}")
+                L.append(emit_body(body, in_names, out_names, indent="    "))
+                for q in range(len(body["out_dtypes"])):
+                    L.append(f"    l{st['outs'][q]}[0] = o{q};")
+                L.append("  }")
+                continue
             if st["op"] == "finish":
                 ct = CTYPE[st["dtype"]]
                 R, U = su[j]

@@ -41,6 +41,14 @@ def compile_source(src: str, name: str) -> str:
     key = source_key(src)
     if key in _code:
         return key
+    dump = os.environ.get("PTHIP_KERNEL_SRC_DIR")  # diagnostic: keep every generated source
+    if dump:
+        try:
+            os.makedirs(dump, exist_ok=True)
+            with open(os.path.join(dump, f"{name}.hip"), "w") as fh:
+                fh.write(src)
+        except OSError:
+            pass
     cdir = cache_dir()
     path = os.path.join(cdir, f"{key}.hsaco")
     if os.path.exists(path):

@@ -105,6 +105,12 @@ def assert_parity(got, want, rtol, what, case=None, k=None, py=None, slack=1.0):
         np.testing.assert_array_equal(got, want, err_msg=what)
     elif case is not None:
         r, a = tolerance_for(case, k, want, py)
+        if np.ndim(a):  # a per-element absolute term (assert_allclose cannot format an array tolerance)
+            g64, w64 = got.astype(np.float64), want.astype(np.float64)
+            bad = ~((np.abs(g64 - w64) <= slack * np.asarray(a) + slack * r * np.abs(w64)) | (np.isnan(g64) & np.isnan(w64)) | (g64 == w64))
+            assert not bad.any(), (f"{what}: {int(bad.sum())} of {bad.size} entries over rtol {slack * r:g} + the per-element bound; "
+                                   f"worst |err| / bound = {float(np.max(np.abs(g64 - w64) / np.maximum(slack * np.asarray(a) + slack * r * np.abs(w64), 1e-300))):.3g}")
+            return
         np.testing.assert_allclose(got, want, rtol=slack * r, atol=slack * a, equal_nan=True, err_msg=what)
     else:
         scale = float(np.max(np.abs(want[np.isfinite(want)]))) if np.isfinite(want).any() else 1.0

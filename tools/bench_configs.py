@@ -177,18 +177,27 @@ def _chol_entries():
     return out
 
 
-def _wide200_entry(reps, check):
+def _wide200_entry(reps, check, variant="wide_200"):
     """north_star's literal target graph (oracle/ref_graphs.build_wide200: config #4 + 48 likelihood terms = 202 Elemwise
     + 2 Gemv + 1 Cholesky in the lowered IR) at N = 1e6 through ``pytensor.function(mode="hip")``; the reference C linker
-    on the same graph and inputs beside it (1 warm-up + 2 evals) gates the outputs."""
+    on the same graph and inputs beside it (1 warm-up + 2 evals) gates the outputs.  ``variant="wide_200_gemm"``: the
+    multi-response form (oracle/ref_graphs.build_wide200_gemm, R = 8 response columns): two real ``Gemm`` nodes in the
+    lowered IR, X read once for ``O + X @ B`` and once for ``X.T @ R``."""
     import make_ref
 
     N, T = 1_000_000, configs.WIDE_T
-    vals = configs.wide200_inputs(N=N)
-    pnames = configs.wide200_params()
-    nbytes = N * configs.C4_K * 8 + 2 * N * 8 + T * N * 8  # X once, y + gidx, every term's vector once
-    entry = {"config": f"north_star target: hierarchical-normal (Gemv x2 fused, Cholesky({configs.C4_K})) + {T} likelihood terms, N=1e6 f64; 202 Elemwise in the lowered IR",
-             "algorithmic_MB": nbytes / 1e6, "unit": "GB/s", "peak": HBM_PEAK, "bound": "hbm"}
+    gemm = variant == "wide_200_gemm"
+    vals = configs.wide200_gemm_inputs(N=N) if gemm else configs.wide200_inputs(N=N)
+    pnames = configs.wide200_gemm_params() if gemm else configs.wide200_params()
+    if gemm:
+        R = configs.WIDE_R
+        # X twice (forward product, backward product), Y and O once, the residual matrix written + read once, gidx, the terms
+        nbytes = 2 * N * configs.C4_K * 8 + 4 * N * R * 8 + N * 8 + T * N * 8
+        label = f"north_star target with a real Gemm: multi-response (R={R}) hierarchical-normal, Gemm x2 (O + X@B, X.T@R), Cholesky({configs.C4_K}) + {T} likelihood terms, N=1e6 f64"
+    else:
+        nbytes = N * configs.C4_K * 8 + 2 * N * 8 + T * N * 8  # X once, y + gidx, every term's vector once
+        label = f"north_star target: hierarchical-normal (Gemv x2 fused, Cholesky({configs.C4_K})) + {T} likelihood terms, N=1e6 f64; 202 Elemwise in the lowered IR"
+    entry = {"config": label, "algorithmic_MB": nbytes / 1e6, "unit": "GB/s", "peak": HBM_PEAK, "bound": "hbm"}
     if make_ref.importable():
         make_ref.activate()
         import pytensor
@@ -198,7 +207,7 @@ def _wide200_entry(reps, check):
         import ref_graphs
 
         pytensor_amd.register()
-        params, outs = ref_graphs.build_wide200(vals)
+        params, outs = (ref_graphs.build_wide200_gemm if gemm else ref_graphs.build_wide200)(vals)
         f = pytensor.function(params, outs, mode="hip")
         f.trust_input = True
         pv = [np.asarray(vals[n]) for n in pnames]
@@ -211,7 +220,7 @@ def _wide200_entry(reps, check):
         t = (time.perf_counter() - t0) / reps * 1e3
         exe = f.vm.jit_fn
         entry.update({"ms_call": t, "api": "pytensor.function(mode='hip'), trust_input=True", "replays": exe.stats["replays"], "nodes_after_passes": len(exe.graph.nodes),
-                      "launch_kinds": sorted({n.op for n in exe.graph.nodes if n.op in ("GemvChain", "MultiElemwise", "ElemwiseReduce", "Tail", "CholeskyTrsv", "Elemwise")})})
+                      "launch_kinds": sorted({n.op for n in exe.graph.nodes if n.op in ("GemvChain", "MultiElemwise", "ElemwiseReduce", "Tail", "CholeskyTrsv", "Elemwise", "Gemm", "GemmFinish", "SolveTriangular")})})
         if check:
             fc = pytensor.function(params, outs, mode=Mode(linker="cvm" if pytensor.config.cxx else "py", optimizer="fast_run"))
             fc.trust_input = True
@@ -228,11 +237,11 @@ def _wide200_entry(reps, check):
                 # exp(0.3): the normal family's d/d log-scale term r^2 - 1 stays below 64)
                 tol = 1e-12 * np.abs(b) + 8 * np.finfo("float64").eps * N * 64.0
                 worst = max(worst, float(np.max(np.abs(np.asarray(a) - b) / tol)))
-            assert worst <= 1.0, f"wide_200: |hip - reference C linker| / tol = {worst}"
+            assert worst <= 1.0, f"{variant}: |hip - reference C linker| / tol = {worst}"
             entry.update({"reference_cvm_ms": float(np.median(ts)) * 1e3, "speedup_vs_reference_cvm": float(np.median(ts)) * 1e3 / t, "parity_err_over_tol": worst,
                           "cores": os.cpu_count()})
     else:
-        g, names = load("wide_200")
+        g, names = load(variant)
         inputs = [vals[n] for n in names]
         resident = [k for k, n in enumerate(names) if n not in pnames]
         exe = HipExecutable(g, resident=resident)
@@ -340,6 +349,8 @@ def measure(which=("c1", "c2", "c3", "c5", "chol", "gp", "hotpath", "wide200"), 
                 res["hot_" + r.pop("key")] = r
     if "wide200" in which:
         res["wide_200"] = _wide200_entry(max(5, reps // 2), True)
+    if "wide200gemm" in which:
+        res["wide_200_gemm"] = _wide200_entry(max(5, reps // 2), True, variant="wide_200_gemm")
     from pytensor_amd.executor import KernelTimer
 
     if KernelTimer.overhead_ms is not None:

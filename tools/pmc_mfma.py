@@ -13,6 +13,7 @@ import sys
 
 CLOCK_GHZ = 2.4
 SIMDS = 256 * 4
+FILTER = ["gemm"]
 
 
 def main(path):
@@ -22,17 +23,23 @@ def main(path):
     ).fetchall()
     out = {}
     for name, counter, total, ndisp, dur_ns in rows:
-        if "gemm" not in name:
+        if not any(t in name for t in FILTER):
             continue
-        k = name.split("(")[0].split("::")[-1][:40]
+        k = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:48]
         d = out.setdefault(k, {"dispatches": ndisp, "avg_us": round(dur_ns / 1e3, 1)})
         d[counter] = total / max(ndisp, 1)
     for k, d in out.items():
         cyc = d["avg_us"] * 1e-6 * CLOCK_GHZ * 1e9
         if "SQ_VALU_MFMA_BUSY_CYCLES" in d:
-            d["mfma_util"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * SIMDS), 3)
+            d["mfma_util"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * SIMDS), 3)  # of the time at the 2.4 GHz peak clock
+            if d.get("GRBM_GUI_ACTIVE"):
+                # GRBM_GUI_ACTIVE: shader-clock cycles the GPU was active during the dispatch = the clock it actually ran at
+                d["clock_ghz"] = round(d["GRBM_GUI_ACTIVE"] / (d["avg_us"] * 1e3), 3)
+                d["mfma_util_at_actual_clock"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] * SIMDS), 3)
         print(json.dumps({k: d}))
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2:
+        FILTER[:] = sys.argv[2].split(",")
     main(sys.argv[1])
