@@ -386,6 +386,18 @@ def measure(args):
         which = ("c1", "c2", "c3", "c5", "wide200", "wide200gemm") + (("chol", "gp", "hotpath") if args.hotpath else ())
         cfgs = bench_configs.measure(which, reps=10, check=False)  # (parity at these sizes: tests/test_gpu_fullsize.py)
 
+    # matrix-pipe utilisation of the BLAS path by COUNTERS (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x 2.4 GHz)):
+    # a separate rocprofv3 --pmc pass cannot run inside this process's timed configs, so the committed summary of
+    # tools/pmc_mfma.py on the final tree is carried (profiles/r7_mfma_pmc.md says how it was taken)
+    mfma = None
+    mpath = os.path.join(ROOT, "profiles", "r7_mfma_pmc.json")
+    if os.path.exists(mpath):
+        mj = json.load(open(mpath))
+        pick = lambda pre: [v["mfma_util"] for k, v in mj.items() if k.startswith(pre) and v["avg_us"] < 2500 and (pre != "sgemm256" or v["avg_us"] < 200)]
+        d, b = pick("dgemm"), pick("sgemm256")
+        mfma = {"dot22_f64_4096": d[0] if d else None, "bdot_f32_512x256": round(sum(b) / len(b), 4) if b else None,
+                "source": "profiles/r7_mfma_pmc.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES, committed)"}
+
     line = {
         "metric": "graph evals/sec (logp+grad, N=1e6 fp64)",
         "value": args.steps * info.world / elapsed,
@@ -436,6 +448,7 @@ def measure(args):
         },
         "cpu_baseline": cpu,
         "configs": cfgs,
+        "mfma_util": mfma,
     }
     return line
 
@@ -483,9 +496,8 @@ def compact(full, detail_path=None):
             # the dominant kernel's own fraction where one was measured, else the whole replay's
             fr[k] = _r(e.get("kernel_frac", e.get("frac")))
     out["configs"] = fr
-    for k in ("mfma_util", "frac_cold"):
-        if full.get(k) is not None:
-            out[k] = full[k]
+    if full.get("mfma_util"):
+        out["mfma_util"] = {k: v for k, v in full["mfma_util"].items() if k != "source"}
     out["value_executor_level"] = _r(full.get("value_executor_level"), 2)
     if detail_path:
         out["detail"] = detail_path

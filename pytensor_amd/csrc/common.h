@@ -45,6 +45,10 @@ bool guard_overlaps_active(const void* p, size_t bytes);  // guard.hip: the rang
 // gemm.hip: C (M x N, row stride ldc) <- beta*C + alpha * A @ B in place (element strides)
 int gemm_inplace(int dtype, long long M, long long N, long long K, double alpha, const void* A, long long sA0,
                  long long sA1, const void* B, long long sB0, long long sB1, double beta, void* C, long long ldc);
+// gemm_skinny.hip: tall-and-skinny products (one side ~1e6 long, the other <= 16 wide) on their own HBM-streaming kernels;
+// *handled = false leaves the product to the MFMA tiles of gemm.hip
+int gemm_skinny(int dtype, long long M, long long N, long long K, double alpha, const void* A, long long sA0, long long sA1, const void* B,
+                long long sB0, long long sB1, double beta, const void* C, long long sC0, long long sC1, void* out, bool* handled);
 int set_error(const char* fmt, ...);
 int check(hipError_t e, const char* what);
 

@@ -1077,6 +1077,11 @@ extern "C" int pthip_gemm(int dtype, int64_t batch, int64_t M, int64_t N, int64_
                           int64_t sBb, int64_t sB0, int64_t sB1, double beta, const void* C,
                           int64_t sCb, int64_t sC0, int64_t sC1, void* out) {
   PTHIP_REQUIRE_INIT();
+  if (batch == 1 && M > 0 && N > 0 && K > 0) {
+    bool handled = false;
+    const int r = pthip::gemm_skinny(dtype, M, N, K, alpha, A, sA0, sA1, B, sB0, sB1, beta, C, sC0, sC1, out, &handled);
+    if (r || handled) return r;
+  }
   if (dtype == PTHIP_F64)
     return gemm_typed<double>(batch, M, N, K, alpha, A, sAb, sA0, sA1, B, sBb, sB0, sB1, beta, C, sCb, sC0, sC1, out);
   if (dtype == PTHIP_F32)

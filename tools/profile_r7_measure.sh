@@ -28,7 +28,7 @@ sweep)
   cut -c1-330 $O/gchain_sweep.txt
   ;;
 wide)
-  python $R/tools/bench_configs.py wide200 --reps 10 > $O/wide200.jsonl 2> $O/wide200.err
+  python $R/tools/bench_configs.py wide200 wide200gemm --reps 10 > $O/wide200.jsonl 2> $O/wide200.err
   cut -c1-900 $O/wide200.jsonl
   ;;
 esac

@@ -9,13 +9,14 @@ from pytensor_amd.executor import HipExecutable
 from pytensor_amd.ir import Graph
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+variant = sys.argv[2] if len(sys.argv) > 2 else "wide_200"  # or wide_200_gemm (the multi-response form with two Gemm nodes)
 ffi.init(0)
-d = json.load(open(os.path.join(ROOT, "tests", "golden", "wide_200.json")))
+d = json.load(open(os.path.join(ROOT, "tests", "golden", f"{variant}.json")))
 g = Graph.from_dict(d)
-vals = configs.wide200_inputs()
+vals = configs.wide200_gemm_inputs() if variant == "wide_200_gemm" else configs.wide200_inputs()
 names = d["input_names"]
 ins = [vals[k] for k in names]
-params = set(configs.wide200_params())
+params = set(configs.wide200_gemm_params() if variant == "wide_200_gemm" else configs.wide200_params())
 exe = HipExecutable(g, resident=[k for k, nm in enumerate(names) if nm not in params])
 t0 = time.perf_counter(); exe(*ins); t_first = time.perf_counter() - t0
 plan = exe.freeze(*ins)
