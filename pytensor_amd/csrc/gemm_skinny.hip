@@ -23,7 +23,7 @@ template <class T, int V> struct __attribute__((aligned(sizeof(T) * V))) sk_pack
 // ---- forward: out[m, n] = beta*C[m, n] + alpha * sum_k A[m, k] B[k, n];  A rows have unit column stride ------------------
 // thread (row = t % 64, ng = t / 64): one row of the tile, columns [ng*NC, ng*NC + NC) of the <= 4*NC wide result
 template <class T, int V, int NC>
-__global__ __launch_bounds__(BLOCK) void skinny_fwd_kernel(T* __restrict__ out, const T* __restrict__ A, long long lda, const T* __restrict__ B,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 2))) void skinny_fwd_kernel(T* __restrict__ out, const T* __restrict__ A, long long lda, const T* __restrict__ B,
                                                           long long sB0, long long sB1, const T* __restrict__ C, long long sC0, long long sC1,
                                                           long long M, int N, int K, T alpha, T beta, long long tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sk_lds_[];
@@ -40,65 +40,92 @@ __global__ __launch_bounds__(BLOCK) void skinny_fwd_kernel(T* __restrict__ out, 
       Bs[idx] = (k < K && n < N) ? B[(long long)k * sB0 + (long long)n * sB1] : T(0);
     }
   }
-  for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+  // Steps = (tile, K chunk) pairs in order.  The operand of step s + 1 is requested into registers BEFORE step s is
+  // computed out of LDS: every workgroup does the same work per step, so without it all of them loaded, then all of them
+  // computed, and HBM idled through every compute phase (8 us per tile instead of ~3: 520 -> 245 us per GB, r7 profiles).
+  // Loads are unconditional at clamped addresses (a pack that starts below kc may run up to V - 1 elements past it: still
+  // inside the row pitch, a multiple of the pack whenever V > 1 — launch_fwd's alignment test); only elements below kc
+  // are stored.
+  constexpr int CPR = KC / (64 * V) > 0 ? KC / (64 * V) : 1;  // packs of one row chunk per lane
+  constexpr int NP = (TR / 4) * CPR;
+  const int nchunk = (K + KC - 1) / KC;
+  const long long last_row = M - 1;
+  auto request = [&](long long tile, int k0, P (&buf)[NP]) {
     const long long m0 = tile * TR;
-    T acc[NC];
+    const int kc = K - k0 < KC ? K - k0 : KC;
 #pragma unroll
-    for (int c = 0; c < NC; c++) acc[c] = T(0);
-    for (int k0 = 0; k0 < K; k0 += KC) {
-      const int kc = K - k0 < KC ? K - k0 : KC;
-      __syncthreads();  // the previous chunk / tile has been consumed
-      if (!one_chunk) {
-        for (int idx = t; idx < KC * NW; idx += BLOCK) {
-          const int k = idx / NW, n = idx - k * NW;
-          Bs[idx] = (k < kc && n < N) ? B[(long long)(k0 + k) * sB0 + (long long)n * sB1] : T(0);
-        }
+    for (int q = 0; q < NP; q++) {
+      const int r = wv + 4 * (q / CPR), kk = (lane + 64 * (q % CPR)) * V;
+      const long long m = m0 + r < M ? m0 + r : last_row;
+      buf[q] = *reinterpret_cast<const P*>(A + m * lda + k0 + (kk < kc ? kk : 0));
+    }
+  };
+  P buf[NP];
+  long long tile = blockIdx.x;
+  int chunk = 0;
+  if (tile < tiles) request(tile, 0, buf);
+  T acc[NC];
+  while (tile < tiles) {
+    const long long m0 = tile * TR;
+    const int k0 = chunk * KC;
+    const int kc = K - k0 < KC ? K - k0 : KC;
+    if (chunk == 0) {
+#pragma unroll
+      for (int c = 0; c < NC; c++) acc[c] = T(0);
+    }
+    __syncthreads();  // the previous step has been consumed
+    if (!one_chunk) {
+      for (int idx = t; idx < KC * NW; idx += BLOCK) {
+        const int k = idx / NW, n = idx - k * NW;
+        Bs[idx] = (k < kc && n < N) ? B[(long long)(k0 + k) * sB0 + (long long)n * sB1] : T(0);
       }
-      // wave w stages rows w, w + 4, ...: one row chunk (kc elements, contiguous) per load instruction
-#pragma unroll 4
-      for (int r = wv; r < TR; r += 4) {
-        const long long m = m0 + r;
-        for (int kk = lane * V; kk < KC; kk += 64 * V) {
-          P v;
-          if (m < M && kk + V <= kc) {
-            v = *reinterpret_cast<const P*>(A + m * lda + k0 + kk);
-          } else {
+    }
 #pragma unroll
-            for (int e = 0; e < V; e++) v.v[e] = (m < M && kk + e < kc) ? A[m * lda + k0 + kk + e] : T(0);
-          }
+    for (int q = 0; q < NP; q++) {
+      const int r = wv + 4 * (q / CPR), kk = (lane + 64 * (q % CPR)) * V;
 #pragma unroll
-          for (int e = 0; e < V; e++) As[r * PITCH + kk + e] = v.v[e];
-        }
-      }
-      __syncthreads();
-      const T* ar = As + lane * PITCH;
-      const T* br = Bs + wv * NC;
+      for (int e = 0; e < V; e++)
+        if (kk + e < kc) As[r * PITCH + kk + e] = buf[q].v[e];
+    }
+    __syncthreads();
+    // the next step's operand: in flight during this step's arithmetic
+    long long ntile = tile;
+    int nchk = chunk + 1;
+    if (nchk == nchunk) { nchk = 0; ntile = tile + gridDim.x; }
+    if (ntile < tiles) request(ntile, nchk * KC, buf);
+    const T* ar = As + lane * PITCH;
+    const T* br = Bs + wv * NC;
 #pragma unroll 8
-      for (int k = 0; k < kc; k++) {
-        const T a = ar[k];
+    for (int k = 0; k < kc; k++) {
+      const T a = ar[k];
 #pragma unroll
-        for (int c = 0; c < NC; c++) acc[c] = __builtin_fma(a, br[k * NW + c], acc[c]);
-      }
+      for (int c = 0; c < NC; c++) acc[c] = __builtin_fma(a, br[k * NW + c], acc[c]);
     }
-    const long long m = m0 + lane;
-    if (m < M) {
+    if (nchk == 0) {
+      const long long m = m0 + lane;
+      if (m < M) {
 #pragma unroll
-      for (int c = 0; c < NC; c++) {
-        const int n = wv * NC + c;
-        if (n < N) {
-          T r = alpha * acc[c];
-          if (beta != T(0)) r += beta * C[m * sC0 + (long long)n * sC1];
-          out[m * N + n] = r;
+        for (int c = 0; c < NC; c++) {
+          const int n = wv * NC + c;
+          if (n < N) {
+            T r = alpha * acc[c];
+            if (beta != T(0)) r += beta * C[m * sC0 + (long long)n * sC1];
+            out[m * N + n] = r;
+          }
         }
       }
     }
+    tile = ntile;
+    chunk = nchk;
   }
 }
 
 // ---- backward: slab[b][m][n] = sum over the workgroup's rows i of X[i, m] * W[i, n];  X rows have unit column stride ----
 // thread (ml = t % 128, nh = t / 128): result rows m = ml + 128*j (j < MJ), columns [nh*NC, nh*NC + NC) of the <= 2*NC wide W
 template <class T, int V, int MJ, int NC>
-__global__ __launch_bounds__(BLOCK) void skinny_atb_kernel(T* __restrict__ slab, const T* __restrict__ X, long long ldx, const T* __restrict__ W,
+// (two workgroups per CU at most — the LDS tile decides that — so a wave may use up to 256 VGPRs: without the hint the
+//  register allocator kept the 16 prefetched packs in scratch memory)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 2))) void skinny_atb_kernel(T* __restrict__ slab, const T* __restrict__ X, long long ldx, const T* __restrict__ W,
                                                           long long ldw, long long rows, int M, int N, int tr, long long rows_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sk_lds_[];
   constexpr int NW = 2 * NC;
@@ -116,25 +143,52 @@ __global__ __launch_bounds__(BLOCK) void skinny_atb_kernel(T* __restrict__ slab,
   long long r_end = r_begin + rows_per_block;
   if (r_end > rows) r_end = rows;
   const int packs_per_row = MP / V;
+  // The next tile (up to SG packs of X and two values of W per thread) is requested into registers before the current one
+  // is consumed out of LDS — see skinny_fwd_kernel.  Unconditional loads, clamped to the workgroup's last row; a pack may
+  // run past M inside the row pitch.  (tr * packs_per_row <= SG * BLOCK and tr * NW <= 2 * BLOCK by the host's choice of tr.)
+  constexpr int SG = 16;
+  P xb[SG];
+  T wb[2];
+  const long long r_last = r_end - 1;
+  // (the buffers are PARAMETERS of the lambda: captured by reference they stayed in scratch memory — 272 bytes of
+  //  private segment, every access a scratch load behind vmcnt(0), 409 -> 803 us)
+  auto request = [&](long long r0, P (&xb)[SG], T (&wb)[2]) {
+#pragma unroll
+    for (int u = 0; u < SG; u++) {
+      const int idx = u * BLOCK + t;
+      const int i = idx / packs_per_row, q = (idx - i * packs_per_row) * V;
+      const long long rr = r0 + i < r_end ? r0 + i : r_last;
+      xb[u] = *reinterpret_cast<const P*>(X + rr * ldx + q);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int idx = u * BLOCK + t;
+      const int i = idx / NW, n = idx - i * NW;
+      const long long rr = r0 + i < r_end ? r0 + i : r_last;
+      wb[u] = W[rr * ldw + (n < N ? n : 0)];
+    }
+  };
+  if (r_begin < r_end) request(r_begin, xb, wb);
   for (long long r0 = r_begin; r0 < r_end; r0 += tr) {
     const int nr = r_end - r0 < tr ? (int)(r_end - r0) : tr;
     __syncthreads();
-    for (int idx = t; idx < nr * packs_per_row; idx += BLOCK) {
-      const int i = idx / packs_per_row, q = (idx - i * packs_per_row) * V;
-      P v;
-      if (q + V <= M) {
-        v = *reinterpret_cast<const P*>(X + (r0 + i) * ldx + q);
-      } else {
 #pragma unroll
-        for (int e = 0; e < V; e++) v.v[e] = q + e < M ? X[(r0 + i) * ldx + q + e] : T(0);
+    for (int u = 0; u < SG; u++) {
+      const int idx = u * BLOCK + t;
+      if (idx < nr * packs_per_row) {
+        const int i = idx / packs_per_row, q = (idx - i * packs_per_row) * V;
+        T* d = Xs + (long long)i * MP + q;  // (element by element: an aggregate copy out of the register array kept it in scratch)
+#pragma unroll
+        for (int e = 0; e < V; e++) d[e] = xb[u].v[e];
       }
-      *reinterpret_cast<P*>(Xs + (long long)i * MP + q) = v;
     }
-    for (int idx = t; idx < nr * NW; idx += BLOCK) {
-      const int i = idx / NW, n = idx - i * NW;
-      Ws[idx] = n < N ? W[(r0 + i) * ldw + n] : T(0);
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int idx = u * BLOCK + t;
+      if (idx < nr * NW) Ws[idx] = (idx % NW) < N ? wb[u] : T(0);
     }
     __syncthreads();
+    if (r0 + tr < r_end) request(r0 + tr, xb, wb);
 #pragma unroll 4
     for (int i = 0; i < nr; i++) {
       T w[NC];
@@ -163,27 +217,39 @@ __global__ __launch_bounds__(BLOCK) void skinny_atb_kernel(T* __restrict__ slab,
   }
 }
 
-// out[m, n] = beta*C[m, n] + alpha * (slab[0] + slab[1] + ...)[m, n], slabs in workgroup order
+// out[m, n] = beta*C[m, n] + alpha * sum of the slabs at [m, n]: 16 entries per workgroup, 16 slab lanes each adding every
+// 16th slab (four loads in flight), the lanes folded in lane order through LDS — a fixed order, whatever the schedule
 template <class T>
 __global__ __launch_bounds__(BLOCK) void skinny_finish_kernel(T* __restrict__ out, const T* __restrict__ slab, int nslab, int MN, int N,
                                                              const T* __restrict__ C, long long sC0, long long sC1, T alpha, T beta) {
-  const int e = blockIdx.x * BLOCK + threadIdx.x;
-  if (e >= MN) return;
+  __shared__ T red[16][17];
+  const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + el;
+  const int ec = e < MN ? e : MN - 1;
   T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-  int s = 0;
-  for (; s + 3 < nslab; s += 4) {
-    a0 += slab[(long long)s * MN + e];
-    a1 += slab[(long long)(s + 1) * MN + e];
-    a2 += slab[(long long)(s + 2) * MN + e];
-    a3 += slab[(long long)(s + 3) * MN + e];
+  int s = sl;
+  for (; s + 48 < nslab; s += 64) {
+    const T v0 = slab[(long long)s * MN + ec], v1 = slab[(long long)(s + 16) * MN + ec];
+    const T v2 = slab[(long long)(s + 32) * MN + ec], v3 = slab[(long long)(s + 48) * MN + ec];
+    a0 += v0;
+    a1 += v1;
+    a2 += v2;
+    a3 += v3;
   }
-  for (; s < nslab; s++) a0 += slab[(long long)s * MN + e];
-  T r = alpha * ((a0 + a1) + (a2 + a3));
-  if (beta != T(0)) {
-    const int m = e / N, n = e - m * N;
-    r += beta * C[(long long)m * sC0 + (long long)n * sC1];
+  for (; s < nslab; s += 16) a0 += slab[(long long)s * MN + ec];
+  red[sl][el] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (sl == 0 && e < MN) {
+    T acc = red[0][el];
+#pragma unroll
+    for (int j = 1; j < 16; j++) acc += red[j][el];
+    T r = alpha * acc;
+    if (beta != T(0)) {
+      const int m = e / N, n = e - m * N;
+      r += beta * C[(long long)m * sC0 + (long long)n * sC1];
+    }
+    out[e] = r;
   }
-  out[e] = r;
 }
 
 template <class K> int raise_lds(K kernel, size_t bytes, size_t* have) {
@@ -251,9 +317,16 @@ int skinny_typed(long long M, long long N, long long K, double alpha, const T* A
     const int Mi = (int)M, Ni = (int)N;
     const bool al = ((uintptr_t)A % 16) == 0 && sA1 % VW == 0;
     const int MJ = Mi <= 128 ? 1 : (Mi <= 256 ? 2 : 4);
-    int tr = (int)((56 * 1024) / ((size_t)((Mi + VW - 1) / VW * VW) * sizeof(T)));
+    // rows per tile: the X tile within 56 KB of LDS, and within what a thread prefetches into registers
+    // (16 packs of X, 2 values of W per thread: skinny_atb_kernel)
+    const int Vsel = al ? VW : 1;
+    const int MPh = (Mi + Vsel - 1) / Vsel * Vsel;
+    const int NWh = 2 * (Ni <= 8 ? 4 : 8);
+    int tr = (int)((56 * 1024) / ((size_t)MPh * sizeof(T)));
     if (tr > 64) tr = 64;
-    if (tr < 4) tr = 4;
+    if (tr > 16 * BLOCK / (MPh / Vsel)) tr = 16 * BLOCK / (MPh / Vsel);
+    if (tr > 2 * BLOCK / NWh) tr = 2 * BLOCK / NWh;
+    if (tr < 1) tr = 1;
     // ~2 workgroups per CU, each a whole number of tiles
     long long nblocks = (long long)pthip::kNumCU * 2;
     long long rpb = (rows + nblocks - 1) / nblocks;
@@ -279,7 +352,7 @@ int skinny_typed(long long M, long long N, long long K, double alpha, const T* A
 #undef ATB
     if (!r) {
       const int MN = Mi * Ni;
-      PTHIP_KLAUNCH((skinny_finish_kernel<T>), dim3((unsigned)((MN + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, pthip::ctx().stream, out, (const T*)slab, (int)nblocks,
+      PTHIP_KLAUNCH((skinny_finish_kernel<T>), dim3((unsigned)((MN + 15) / 16)), dim3(BLOCK), 0, pthip::ctx().stream, out, (const T*)slab, (int)nblocks,
                     MN, Ni, C, sC0, sC1, (T)alpha, (T)(C ? beta : 0.0));
       r = pthip::post_launch("gemm(skinny transposed, finish)");
     }

@@ -1451,6 +1451,51 @@ __global__ __launch_bounds__(BLOCK) void trsv_lds_kernel(T* __restrict__ Xout,
   wave_trsv<T, RPL>(W, ld, n, b, x, lower, unit, false);
 }
 
+// a FEW right-hand sides (<= 16: the matrix solve of a multi-response prior, `solve_triangular(L, B)` with B (K, R) —
+// pytensor/tensor/linalg/solvers/triangular.py:41-66, and its gradient's solve), triangle resident in LDS: one WAVE per
+// column with the wave-synchronous substitution of the vector kernel (wave_trsv: a 128-row solve is ~5 us of dependent
+// v_readlane -> fma steps), the four waves taking columns w, w + 4, ...  One thread per column (trsm_lds_kernel below) is
+// n^2 / 2 dependent steps on eight lanes: 160-230 us at n = 128, R = 8 (profiles/r7_wide200_gemm_*).
+template <class T, int RPL>
+__global__ __launch_bounds__(BLOCK) void trsm_few_lds_kernel(T* Xout, const T* __restrict__ Tm, long long sTb, long long sT0, long long sT1,
+                                                            const T* B, long long sBb, int n, int nrhs, int lower, int unit) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* W = (T*)smem_raw;
+  const int ld = n | 1;
+  T* cols = W + (size_t)n * ld;  // [BLOCK / 64][2][n]: a wave's right-hand side and solution, contiguous
+  const long long mat = blockIdx.x;
+  const T* Tg = Tm + mat * sTb;
+  const T* b = B + mat * sBb;
+  T* x = Xout + mat * (long long)n * nrhs;
+  for (int e0 = 0; e0 < n * n; e0 += BLOCK * 8) {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int e = e0 + u * BLOCK + threadIdx.x;
+      const int ec = e < n * n ? e : n * n - 1;
+      const int i = ec / n, j = ec - i * n;
+      v[u] = Tg[i * sT0 + j * sT1];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int e = e0 + u * BLOCK + threadIdx.x;
+      if (e < n * n) {
+        const int i = e / n, j = e - i * n;
+        W[i * ld + j] = v[u];
+      }
+    }
+  }
+  __syncthreads();
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  T* bw = cols + (size_t)wv * 2 * n;
+  T* xw = bw + n;
+  for (int c = wv; c < nrhs; c += BLOCK / 64) {  // (wave-uniform: no barriers below, LDS traffic of a wave is in order)
+    for (int i = lane; i < n; i += 64) bw[i] = b[(long long)i * nrhs + c];
+    wave_trsv<T, RPL>(W, ld, n, bw, xw, lower, unit, false);
+    for (int i = lane; i < n; i += 64) x[(long long)i * nrhs + c] = xw[i];
+  }
+}
+
 // many right-hand sides, triangle resident in LDS: one thread per rhs column, eight rows of the
 // solution at a time in registers.  The triangle entries are uniform-address (broadcast) LDS
 // reads, the already-solved x_j are coalesced loads across the columns and are reused for eight
@@ -2235,6 +2280,23 @@ int trsm_typed(int lower, int unit, long long batch, long long n, long long nrhs
     //  MFMA solve below even when it fits the LDS: one thread per column is 8192 dependent steps at n = 128;
     //  batches keep the one-launch LDS kernel)
     static const bool lds_always = getenv("PTHIP_TRSM") && !strcmp(getenv("PTHIP_TRSM"), "lds");
+    static const bool few_off = getenv("PTHIP_TRSM_FEW") && !strcmp(getenv("PTHIP_TRSM_FEW"), "0");
+    const size_t need_few = need + (size_t)(BLOCK / 64) * 2 * n * sizeof(T);
+    if (!few_off && nrhs >= 2 && nrhs <= 16 && n <= 256 && need_few <= 160 * 1024 - 256 && B != out) {
+#define LAUNCH_FEW(RPL)                                                                                                            \
+  do {                                                                                                                             \
+    auto k = trsm_few_lds_kernel<T, RPL>;                                                                                          \
+    if (need_few > 64 * 1024)                                                                                                      \
+      PTHIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need_few));                 \
+    PTHIP_KLAUNCH(k, dim3((unsigned)batch), dim3(BLOCK), need_few, st, (T*)out, (const T*)Tm, sTb, sT0, sT1, (const T*)B, sBb,     \
+                  (int)n, (int)nrhs, lower, unit);                                                                                 \
+  } while (0)
+      if (n <= 64) LAUNCH_FEW(1);
+      else if (n <= 128) LAUNCH_FEW(2);
+      else LAUNCH_FEW(4);
+#undef LAUNCH_FEW
+      return pthip::post_launch("trsm_few_lds");
+    }
     if (need <= 160 * 1024 - 256 && (lds_always || n <= TV || nrhs < 64 || batch > 2)) {
       auto k = trsm_lds_kernel<T>;
       if (need > 64 * 1024)
