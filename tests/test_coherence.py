@@ -153,3 +153,63 @@ def test_pinned_ranges_are_never_guarded_and_fed_values_are_handed_out_read_only
     assert type(coherence.watch(a)).__name__ == "_Guard"
     small = np.zeros(100)
     assert type(coherence.watch_update_fed(small)).__name__ == "_Hash"
+
+
+def test_concurrent_writers_from_many_threads_all_land_and_dirty_once():
+    """several threads store into DIFFERENT pages of one guarded array at the same time: the handler runs on whichever
+    thread faults first (the others fault on pages already unprotected by then, or re-enter the handler and find the slot
+    dirty) — every store must land and the array must read dirty afterwards"""
+    a = np.zeros(1 << 19)  # 4 MB = 1024 pages
+    t = coherence.watch(a)
+    assert type(t).__name__ == "_Guard"
+    start = threading.Barrier(8)
+
+    def writer(k):
+        start.wait()
+        for j in range(64):
+            a[(k * 64 + j) * 512 + 7] = k + 1.0  # one element in each of 64 pages of this thread's own range
+
+    ths = [threading.Thread(target=writer, args=(k,)) for k in range(8)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not t.clean(a)
+    for k in range(8):
+        assert all(a[(k * 64 + j) * 512 + 7] == k + 1.0 for j in range(64))
+    assert float(a.sum()) == sum((k + 1.0) * 64 for k in range(8))
+    t.release()
+    assert _slots() == (0, 0)
+
+
+@pytest.mark.skipif(not hasattr(__import__("os"), "fork"), reason="needs fork")
+def test_a_forked_child_can_write_a_guarded_array_and_the_parent_stays_clean():
+    """``os.fork`` (multiprocessing's default start method on Linux: PyMC's chains): the child inherits the protection and
+    the handler; its stores into the (copy-on-write) pages must not kill it, and the PARENT's array and its clean state
+    are untouched — the child's pages are its own"""
+    import os
+
+    a = np.arange(1 << 18, dtype="float64")
+    t = coherence.watch(a)
+    assert type(t).__name__ == "_Guard" and t.clean(a)
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:  # child: write, report what it read back, leave without running pytest's teardown
+        code = 1
+        try:
+            a[123_456] = -5.0
+            ok = a[123_456] == -5.0 and a[123_455] == 123_455.0 and not t.clean(a)
+            os.write(w, b"ok" if ok else b"no")
+            code = 0
+        finally:
+            os._exit(code)
+    os.close(w)
+    _, status = os.waitpid(pid, 0)
+    msg = os.read(r, 2)
+    os.close(r)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, f"the child died: status {status}"
+    assert msg == b"ok"
+    assert a[123_456] == 123_456.0 and t.clean(a), "the parent's copy is untouched and still clean"
+    a[0] = 1.0  # and the parent's own guard still works after the fork
+    assert not t.clean(a)
+    t.release()
