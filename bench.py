@@ -493,8 +493,11 @@ def compact(full, detail_path=None):
     for k in _BASELINE_CONFIGS:
         e = cfgs.get(k)
         if isinstance(e, dict):
-            # the dominant kernel's own fraction where one was measured, else the whole replay's
-            fr[k] = _r(e.get("kernel_frac", e.get("frac")))
+            # HBM-bound configs whose working set fits the Infinity Cache: the COLD fraction (operands rotated through
+            # >= 1.5 GiB per cycle, tools/bench_hotpath.cold_device_time_ms), never the back-to-back replay of one set;
+            # otherwise the dominant kernel's own fraction where one was measured, else the whole replay's
+            cold = str(e.get("frac_is", "")).startswith("cold")
+            fr[k] = _r(e.get("frac") if cold else e.get("kernel_frac", e.get("frac")))
     out["configs"] = fr
     if full.get("mfma_util"):
         out["mfma_util"] = {k: v for k, v in full["mfma_util"].items() if k != "source"}

@@ -124,7 +124,7 @@ class TestGemmHip(ref_blas.TestGemm):
         from pytensor.tensor import as_tensor_variable
         from pytensor.tensor.blas import gemm_no_inplace
 
-        for dtype in ["float32", "float64"]:  # (complex: compile-time NotImplementedError, DESIGN §9)
+        for dtype in ["float32", "float64"]:  # (complex: compile-time NotImplementedError, DESIGN §7)
             z, a, x, y, b = (np.asarray(p, dtype=dtype) for p in (z_, a_, x_, y_, b_))
             z_orig = z.copy()
             tz, ta, tx, ty, tb = (as_tensor_variable(p).type() for p in (z, a, x, y, b))

@@ -347,10 +347,12 @@ def measure(which=("c1", "c2", "c3", "c5", "chol", "gp", "hotpath", "wide200"), 
                 except (AssertionError, RuntimeError, NotImplementedError, ValueError) as e:
                     r = {"key": a[0], "error": f"{type(e).__name__}: {e}"[:300]}
                 res["hot_" + r.pop("key")] = r
+    # (parity of both at N = 1e6 against the reference C linker: tests/test_gpu_fullsize.py; inside a bench run the
+    #  reference is compiled and timed beside wide_200 only when `check` is on — 25 s of host time)
     if "wide200" in which:
-        res["wide_200"] = _wide200_entry(max(5, reps // 2), True)
+        res["wide_200"] = _wide200_entry(max(5, reps // 2), check)
     if "wide200gemm" in which:
-        res["wide_200_gemm"] = _wide200_entry(max(5, reps // 2), True, variant="wide_200_gemm")
+        res["wide_200_gemm"] = _wide200_entry(max(5, reps // 2), False, variant="wide_200_gemm")
     from pytensor_amd.executor import KernelTimer
 
     if KernelTimer.overhead_ms is not None:
