@@ -296,3 +296,38 @@ def fuse_logsumexp(g: Graph) -> Graph:
             changed = True
             break
     return g
+
+
+def drop_identity_elemwise(g: Graph) -> Graph:
+    """An ``Elemwise`` whose scalar graph is nothing but ``Identity`` of its one input — what is left of
+    ``log(sum(exp(x - m))) + m`` once ``fuse_logsumexp`` has folded the logarithm and both shifts into the reduction — is
+    a copy launch (3 us behind a 30 us log-sum-exp).  Its readers read its operand instead.  Kept when the operand is a
+    graph input or a constant (an output must not alias what the caller owns: link/vm.py no-recycling / aliasing.py
+    semantics, tests/test_gpu_e2e.py::test_outputs_are_fresh_and_do_not_alias_inputs), when dtype or static shape
+    differ (a cast / a broadcast), or when the operand is itself a graph output (two outputs would share a buffer)."""
+    producer, _ = _index(g)
+    inputs = set(g.inputs)
+    outs = set(g.outputs)
+    rename = {}
+    keep = []
+    for n in g.nodes:
+        if n.op == "Elemwise" and len(n.inputs) == 1 and len(n.outputs) == 1 and not n.params.get("gather") and not n.params.get("partial_inputs"):
+            b = n.params["scalar"]
+            src = rename.get(n.inputs[0], n.inputs[0])
+            vi, vo = g.vars[src], g.vars[n.outputs[0]]
+            chain, ok = b["outs"][0], bool(b["body"])
+            while ok and chain[0] == "t":
+                node = b["body"][chain[1]]
+                ok = node["op"] == "Identity" and node["dtype"] == vi.dtype
+                chain = node["in"][0] if ok else chain
+            ok = ok and list(chain) == ["i", 0] and len(b["body"]) <= 4
+            if (ok and vi.dtype == vo.dtype and tuple(vi.shape) == tuple(vo.shape) and src not in inputs and vi.const is None and src in producer
+                    and src not in outs and vi.kind == "tensor"):
+                rename[n.outputs[0]] = src
+                continue
+        keep.append(Node(n.op, n.params, [rename.get(i, i) for i in n.inputs], list(n.outputs)) if any(i in rename for i in n.inputs) else n)
+    if not rename:
+        return g
+    out = _copy(g, keep)
+    out.outputs = [rename.get(o, o) for o in g.outputs]
+    return out

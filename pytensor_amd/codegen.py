@@ -187,6 +187,19 @@ PT_DEV float pt_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 PT_DEV double pt_softplus(double x) {
   return x < -37.0 ? pt_exp(x) : x < 18.0 ? log1p(pt_exp(x)) : x < 33.3 ? x + pt_exp(-x) : x;
 }
+// sigmoid(x) and softplus(x) of ONE argument (the logistic log-density and its gradient; a Bernoulli-logit likelihood):
+// both from e = exp(-|x|) in (0, 1] — one exp instead of two or three, no overflow on either side.
+//   sigmoid = 1 / (1 + e)        (x >= 0)      e / (1 + e)   (x < 0)
+//   softplus = max(x, 0) + log1p(e)
+// Within 2 ulp of pt_sigmoid / pt_softplus (Sigmoid.c_code: 1 / (1 + exp(-x)); Softplus.c_code: the four-branch form of
+// scalar/math.py); NaN -> NaN, +inf -> (1, +inf), -inf -> (0, 0).  emit_body uses it when a body holds both of one operand.
+PT_DEV void pt_sig_sp(double x, double& sg, double& sp) {
+  const double e = pt_exp(-__builtin_fabs(x));
+  const double inv = 1.0 / (1.0 + e);
+  sg = x >= 0.0 ? inv : e * inv;
+  sp = (x > 0.0 ? x : 0.0) + log1p(e);
+  if (x != x) { sg = x; sp = x; }
+}
 PT_DEV float pt_softplus(float x) {
   return x < -37.0f ? expf(x) : x < 18.0f ? log1pf(expf(x)) : x < 33.3f ? x + expf(-x) : x;
 }
@@ -949,6 +962,9 @@ def supported(body: dict) -> bool:
     return all(op in SCALAR_EXPR for op in body_ops(body)) and all(d in CTYPE for d in dtypes(body))
 
 
+_SHARE_SIG_SP = os.environ.get("PTHIP_SHARE_SIG_SP", "1") != "0"
+
+
 def emit_body(body: dict, in_names, out_names, indent="      ", tp="t") -> str:
     """SSA statements computing ``out_names`` from ``in_names`` (one element).  ``tp`` prefixes
     the temporaries (the inner body of a loop lives in a nested scope with its own prefix)."""
@@ -962,8 +978,30 @@ def emit_body(body: dict, in_names, out_names, indent="      ", tp="t") -> str:
             return f"{tp}{r[1]}", tdt[r[1]]
         return _lit(r[1], r[2]), r[2]
 
+    # sigmoid and softplus of the same float64 operand: one shared evaluation (pt_sig_sp)
+    shared = {}
+    if _SHARE_SIG_SP:
+        by_arg = {}
+        for k, n in enumerate(body["body"]):
+            if n["op"] in ("Sigmoid", "Softplus") and n["dtype"] == "float64" and len(n["in"]) == 1 and n["in"][0][0] in ("i", "t"):
+                src_dt = body["in_dtypes"][n["in"][0][1]] if n["in"][0][0] == "i" else body["body"][n["in"][0][1]]["dtype"]
+                if src_dt == "float64":
+                    by_arg.setdefault((n["in"][0][0], n["in"][0][1]), {}).setdefault(n["op"], k)
+        for d in by_arg.values():
+            if len(d) == 2:
+                first = min(d.values())
+                for op, k in d.items():
+                    shared[k] = (first, "sg" if op == "Sigmoid" else "sp")
     for k, n in enumerate(body["body"]):
         ct = CTYPE[n["dtype"]]
+        if k in shared:
+            first, which = shared[k]
+            if k == first:
+                arg, _ = ref(n["in"][0])
+                lines.append(f"{indent}double {tp}{first}_sg, {tp}{first}_sp; pt_sig_sp((double){arg}, {tp}{first}_sg, {tp}{first}_sp);")
+            lines.append(f"{indent}const {ct} {tp}{k} = {tp}{first}_{which};")
+            tdt.append(n["dtype"])
+            continue
         if n["op"] == "ScalarLoop":
             lines.append(_emit_loop(n, [ref(r) for r in n["in"]], f"{tp}{k}_", indent))
             lines.append(f"{indent}const {ct} {tp}{k} = {tp}{k}_s0;")

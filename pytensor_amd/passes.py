@@ -30,7 +30,7 @@ from __future__ import annotations
 
 import os
 
-from pytensor_amd.axisfuse import duplicate_cheap_producers, fuse_elemwise_axis_reduce, fuse_logsumexp
+from pytensor_amd.axisfuse import drop_identity_elemwise, duplicate_cheap_producers, fuse_elemwise_axis_reduce, fuse_logsumexp
 from pytensor_amd.fusion import (
     fuse_cholesky_solve,
     fuse_elemwise_reduce,
@@ -68,7 +68,7 @@ def run_pipeline(graph: Graph, fuse=True, tail=True):
     if os.environ.get("PTHIP_AXIS_FUSE", "1") != "0":
         g = fuse_elemwise_axis_reduce(g)  # row / column reductions of a fused expression in one kernel
         if os.environ.get("PTHIP_LSE_FUSE", "1") != "0":
-            g = fuse_logsumexp(g)  # log(sum(exp(x - max))) + max: one pass, the Max reductions die
+            g = drop_identity_elemwise(fuse_logsumexp(g))  # log(sum(exp(x - max))) + max: one pass, the Max reductions die
     g = merge_sibling_reductions(g)
     g = hoist_scan_seq_dots(g)
     g = fuse_cholesky_solve(g)
