@@ -963,6 +963,7 @@ def supported(body: dict) -> bool:
 
 
 _SHARE_SIG_SP = os.environ.get("PTHIP_SHARE_SIG_SP", "1") != "0"
+_EMIT_CTX = {"share_recip": False}  # set by flat_kernel_source for bodies all of whose outputs are summed
 
 
 def emit_body(body: dict, in_names, out_names, indent="      ", tp="t") -> str:
@@ -992,8 +993,32 @@ def emit_body(body: dict, in_names, out_names, indent="      ", tp="t") -> str:
                 first = min(d.values())
                 for op, k in d.items():
                     shared[k] = (first, "sg" if op == "Sigmoid" else "sp")
+    recip = {}  # TrueDiv node -> first node of its denominator group
+    if _EMIT_CTX["share_recip"]:
+        by_den = {}
+        for k, n in enumerate(body["body"]):
+            if n["op"] == "TrueDiv" and n["dtype"] == "float64" and len(n["in"]) == 2 and n["in"][1][0] in ("i", "t"):
+                den = n["in"][1]
+                den_dt = body["in_dtypes"][den[1]] if den[0] == "i" else body["body"][den[1]]["dtype"]
+                num = n["in"][0]
+                num_dt = (body["in_dtypes"][num[1]] if num[0] == "i" else body["body"][num[1]]["dtype"]) if num[0] in ("i", "t") else num[2]
+                if den_dt == "float64" and num_dt == "float64":
+                    by_den.setdefault((den[0], den[1]), []).append(k)
+        for ks in by_den.values():
+            if len(ks) >= 2:
+                for k in ks:
+                    recip[k] = ks[0]
     for k, n in enumerate(body["body"]):
         ct = CTYPE[n["dtype"]]
+        if k in recip:
+            first = recip[k]
+            if k == first:
+                den, _ = ref(n["in"][1])
+                lines.append(f"{indent}const double {tp}{first}_rcp = 1.0 / (double){den};")
+            num, _ = ref(n["in"][0])
+            lines.append(f"{indent}const {ct} {tp}{k} = ({ct})((double){num} * {tp}{first}_rcp);")
+            tdt.append(n["dtype"])
+            continue
         if k in shared:
             first, which = shared[k]
             if k == first:
@@ -1138,6 +1163,20 @@ def _flat_params(body: dict, modes: str, reduce_spec, vec: int, finish=None):
 
 
 def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=None, unroll=2, device_fn=False, prefetch=False, finish=None) -> str:
+    """:func:`_flat_kernel_source` with the emit context set: when EVERY output of the body is summed (a logp term and its
+    gradients in a many-term launch, a fused Elemwise + Sum) no element is ever seen — only sums over ~1e6 of them, held to
+    rtol 1e-12 — so divisions that share a float64 denominator may share ONE reciprocal (x * (1/d) is within 1.5 ulp of
+    x / d; an fp64 division is ~28 VALU instructions).  Never when an element-wise output is stored: 6 * (1/3) != 2."""
+    all_summed = bool(reduce_spec) and all(rs is not None and rs[0] == "Add" and rs[1] == "float64" for rs in reduce_spec)
+    old = _EMIT_CTX["share_recip"]
+    _EMIT_CTX["share_recip"] = bool(all_summed and os.environ.get("PTHIP_SHARE_RECIP", "1") != "0")
+    try:
+        return _flat_kernel_source(name, body, modes, vec, reduce_spec, unroll, device_fn, prefetch, finish)
+    finally:
+        _EMIT_CTX["share_recip"] = old
+
+
+def _flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=None, unroll=2, device_fn=False, prefetch=False, finish=None) -> str:
     """``flat`` loop.  ``modes[k]`` ∈ {'V' contiguous vector, 'S' scalar broadcast} per input.
 
     reduce_spec: None or list (per output) of None | (op_name, acc_dtype): reduced
