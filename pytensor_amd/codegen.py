@@ -2322,6 +2322,7 @@ def tail_chain_source(name: str, spec: dict, sizes: dict | None = None, shrink: 
 
 TAIL_PRELOAD_MAX_REGS = 160  # 8-byte values a thread may hold in flight in the preloading form
 TAIL_WAVE_FOLD_INTERLEAVED = os.environ.get("PTHIP_TAIL_FOLD_INTERLEAVED", "1") != "0"
+TAIL_WAVE_Q = int(os.environ.get("PTHIP_TAIL_WAVE_Q", 4))  # a wave folds deferred reductions of up to 64 * this many partials
 TAIL_SCALAR_STEPS_BY_WAVE = os.environ.get("PTHIP_TAIL_SCALAR_BY_WAVE", "1") != "0"
 
 
@@ -2342,14 +2343,16 @@ def tail_preload_sizes(spec: dict, ext_len, step_n):
             regs += R * cl(M)
         elif st["op"] == "rsum":
             su.append(cl(n))
-            regs += cl(n) if n > 64 else 0  # (<= 64 partials: one value in ONE wave's lanes, see "wave")
+            regs += cl(n) if n > 64 * TAIL_WAVE_Q else 0  # (few partials: values in ONE wave's lanes, see "wave")
         else:
             su.append(cl(n))
     if regs > TAIL_PRELOAD_MAX_REGS or any((u[0] > 64 or u[1] > 4) if isinstance(u, tuple) else u > 16 for u in su) or any(u > 16 for u in eu):
         return None
-    # deferred reductions over <= 64 partials are folded by single waves, four at a time
-    wave = [st["op"] == "rsum" and int(n) <= 64 for st, n in zip(steps, step_n)]
-    return {"ext_u": eu, "step_u": su, "wave": wave}
+    # deferred reductions over <= 64 * TAIL_WAVE_Q partials are folded by single waves, four at a time (a lane adds its
+    # up to TAIL_WAVE_Q values in index order first)
+    wave = [st["op"] == "rsum" and int(n) <= 64 * TAIL_WAVE_Q for st, n in zip(steps, step_n)]
+    wave_q = [max(1, (int(n) + 63) // 64) if w else 0 for w, n in zip(wave, step_n)]
+    return {"ext_u": eu, "step_u": su, "wave": wave, "wave_q": wave_q}
 
 
 def _tail_preload_source(name: str, spec: dict, sizes: dict, P, bodies, shrink=None) -> str:
@@ -2424,15 +2427,22 @@ def _tail_preload_source(name: str, spec: dict, sizes: dict, P, bodies, shrink=N
             if not mine:
                 continue
             L.append(f"    if (wv_ == {w}) {{")
+            wq = sizes.get("wave_q") or [1] * len(steps)
             for j in mine:
                 st = steps[j]
                 act = CTYPE[st["acc_dtype"]]
-                L.append(f"      {act} w{j} = ({act})e{st['src'][1]}[ln_ < rows{j} ? ln_ : rows{j} - 1];")
+                for q in range(wq[j]):
+                    L.append(f"      {act} w{j}_{q} = ({act})e{st['src'][1]}[ln_ + {64 * q} < rows{j} ? ln_ + {64 * q} : rows{j} - 1];")
             L.append("      __builtin_amdgcn_sched_barrier(0);")
             for j in mine:
                 st = steps[j]
                 act = CTYPE[st["acc_dtype"]]
-                L.append(f"      if (ln_ >= rows{j}) w{j} = pthip_dev::{REDUCE_OPS[st['red']]}::identity<{act}>();")
+                op = REDUCE_OPS[st["red"]]
+                for q in range(wq[j]):
+                    L.append(f"      if (ln_ + {64 * q} >= rows{j}) w{j}_{q} = pthip_dev::{op}::identity<{act}>();")
+                L.append(f"      {act} w{j} = w{j}_0;")
+                for q in range(1, wq[j]):
+                    L.append(f"      w{j} = pthip_dev::{op}::apply(w{j}, w{j}_{q});")
             if TAIL_WAVE_FOLD_INTERLEAVED:
                 # step-major: every butterfly level runs over ALL of this wave's reductions before the next level —
                 # their cross-lane exchanges (two ds_bpermute per double, ~100 cycles each) are in flight together.

@@ -33,8 +33,39 @@ _OP_COST = {"Exp": 24, "Log": 35, "Log1p": 40, "Log2": 35, "Log10": 35, "Expm1":
             "Sqrt": 12, "Erf": 60, "Erfc": 80, "GammaLn": 150, "Psi": 150, "Sin": 60, "Cos": 60, "Log1mexp": 70, "ScalarLoop": 400}
 
 
-def _term_cost(body) -> float:
-    return 8.0 + sum(_OP_COST.get(op, 1.5) for op in codegen.body_ops(body))
+def _term_cost(body, modes=None) -> float:
+    """Estimated VALU instructions per ELEMENT.  Scalar ops none of whose operands vary with the element (``exp(-log_sigma)``
+    of a broadcast parameter) are hoisted out of the loop by the compiler and cost nothing; ``sigmoid`` and ``softplus`` of
+    one operand share their exp and a division, divisions by one denominator share a reciprocal when every output is
+    summed (codegen.emit_body) — the estimate has to rank the families the way the generated code costs them, or the
+    cheap families finish early and the launch ends on a few workgroups of the dear one."""
+    nodes = body["body"]
+    if modes is None or any(n["op"] in ("ScalarLoop", "LoopOut") for n in nodes):
+        return 8.0 + sum(_OP_COST.get(op, 1.5) for op in codegen.body_ops(body))
+    varies = []
+    cost = 8.0
+    seen_den, seen_sig = set(), {}
+    for n in nodes:
+        v = any((r[0] == "i" and modes[r[1]] in "VG") or (r[0] == "t" and varies[r[1]]) for r in n["in"])
+        varies.append(v)
+        if not v:
+            continue
+        op = n["op"]
+        if op == "TrueDiv" and n["in"][1][0] in ("i", "t"):
+            den = (n["in"][1][0], n["in"][1][1])
+            cost += 3.0 if den in seen_den else 28.0
+            seen_den.add(den)
+        elif op in ("Sigmoid", "Softplus") and n["in"][0][0] in ("i", "t"):
+            arg = (n["in"][0][0], n["in"][0][1])
+            other = seen_sig.get(arg)
+            if other is not None and other != op:
+                cost += 40.0 if op == "Softplus" else 4.0  # the shared exp and reciprocal are paid: what is left is log1p / a select
+            else:
+                cost += 24.0 + (28.0 if op == "Sigmoid" else 44.0)
+            seen_sig[arg] = op
+        else:
+            cost += _OP_COST.get(op, 1.5)
+    return cost
 
 
 def _run_members(node, inputs, env):
@@ -103,7 +134,7 @@ def multi_elemwise(node, inputs, env):
     # at a mean occupancy of 7 waves per CU, the logistic terms (exp + log1p per element) still running when the
     # normal ones were long done (profiles/r5h_wide_multi_pmc.md).  At most 64 per term (the partials a Tail kernel
     # folds in one pass), at least 4.
-    work = [n * _term_cost(t["scalar"]) for t, _, _, n, _ in per_term]
+    work = [n * _term_cost(t["scalar"], modes) for t, _, modes, n, _ in per_term]
     tot = float(sum(work)) or 1.0
     groups = []
     for (t, ins, modes, n, vec), w in zip(per_term, work):
