@@ -63,7 +63,7 @@ def tile_params(body, cls, nb, reduce_spec):
     return P
 
 
-def tile_kernel_source(name: str, body: dict, cls: str, nb: int, V: int, TX: int, RPT: int, reduce_spec=None, lds_rows: int = 0) -> str:
+def tile_kernel_source(name: str, body: dict, cls: str, nb: int, V: int, TX: int, RPT: int, reduce_spec=None, lds_rows: int = 0, tvec: int = 1) -> str:
     """``cls[k]`` ∈ 'VRBTGSC' per input (module docstring); ``nb`` batch dimensions; tile =
     ``TY*RPT`` rows x ``TX*V`` columns with ``TY = 256 // TX``.  ``lds_rows`` = the tile's row count
     when 'T' operands are present (then ``TY*RPT == lds_rows``)."""
@@ -152,13 +152,27 @@ def tile_kernel_source(name: str, body: dict, cls: str, nb: int, V: int, TX: int
     if tks:
         L.append("  {")
         L.append("    const long long cbase = cb * TC;")
-        L.append(f"#pragma unroll\n    for (int l = threadIdx.x; l < TR * TC; l += {BLOCK}) {{")
-        L.append("      const int rr = l % TR, cc = l / TR;")
-        L.append("      long long r_ = row0 + rr; r_ = r_ < R ? r_ : R - 1;")
-        L.append("      long long c_ = cbase + cc; c_ = c_ < D ? c_ : D - 1;")
-        for k in tks:
-            L.append(f"      lds{k}[cc * (TR + 1) + rr] = p{k}[r_ * s{k}_r + c_ * s{k}_i];")
-        L.append("    }")
+        if tvec > 1:
+            # ``tvec`` elements (16 bytes) per load along the operand's contiguous axis — the tile's ROW dimension (round 6:
+            # 8-byte loads were half the bytes per instruction of every other stream of the kernel; A + B.T 4096^2 fp64
+            # 57 -> 6x % of HBM cold).  The host guarantees R % tvec == 0, 16-byte aligned bases and strides.
+            L.append(f"#pragma unroll\n    for (int l = threadIdx.x; l < (TR / {tvec}) * TC; l += {BLOCK}) {{")
+            L.append(f"      const int rr = (l % (TR / {tvec})) * {tvec}, cc = l / (TR / {tvec});")
+            L.append(f"      long long r_ = row0 + rr; r_ = r_ < R ? r_ : R - {tvec};")
+            L.append("      long long c_ = cbase + cc; c_ = c_ < D ? c_ : D - 1;")
+            for k in tks:
+                ct = CTYPE[body["in_dtypes"][k]]
+                L.append(f"      const {_vec_type(ct, tvec)} tv{k} = *reinterpret_cast<const {_vec_type(ct, tvec)}*>(p{k} + r_ * s{k}_r + c_ * s{k}_i);")
+                L.append(f"#pragma unroll\n      for (int e = 0; e < {tvec}; e++) lds{k}[cc * (TR + 1) + rr + e] = tv{k}.v[e];")
+            L.append("    }")
+        else:
+            L.append(f"#pragma unroll\n    for (int l = threadIdx.x; l < TR * TC; l += {BLOCK}) {{")
+            L.append("      const int rr = l % TR, cc = l / TR;")
+            L.append("      long long r_ = row0 + rr; r_ = r_ < R ? r_ : R - 1;")
+            L.append("      long long c_ = cbase + cc; c_ = c_ < D ? c_ : D - 1;")
+            for k in tks:
+                L.append(f"      lds{k}[cc * (TR + 1) + rr] = p{k}[r_ * s{k}_r + c_ * s{k}_i];")
+            L.append("    }")
         L.append("  }")
         L.append("  __syncthreads();")
     L.append("  __builtin_amdgcn_sched_barrier(0);")

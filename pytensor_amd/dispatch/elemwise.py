@@ -473,7 +473,19 @@ def tile_plan(cshape, cstr, dev_dtypes, out_dtypes_stored, ptrs, out_ptrs):
         TX = min(BLOCK, _pow2ceil(-(-D // V)))
         TY = BLOCK // TX
         RPT = max(1, min(max(_TILE_RPT, 8 // V), -(-R // TY)))
-    return {"jr": jr, "batch": batch, "cls": "".join(cls), "V": V, "TX": TX, "RPT": RPT, "lds_rows": lds_rows, "R": R, "D": D}
+    # ---- 16-byte loads along the contiguous axis of the transposed operands (the tile's row dimension) ----
+    tvec = 1
+    if "T" in cls and lds_rows and os.environ.get("PTHIP_EW_TVEC", "1") != "0":
+        sizes = {np.dtype(dt).itemsize for dt, c in zip(dev_dtypes, cls) if c == "T"}
+        if len(sizes) == 1 and next(iter(sizes)) in (4, 8):
+            tv = 16 // next(iter(sizes))
+            ok = R % tv == 0 and lds_rows % tv == 0
+            for st, c, p_ in zip(cstr, cls, ptrs):
+                if c == "T":
+                    ok = ok and p_ % 16 == 0 and all(s_ % tv == 0 for j, s_ in enumerate(st) if j != jr)
+            if ok:
+                tvec = tv
+    return {"jr": jr, "batch": batch, "cls": "".join(cls), "V": V, "TX": TX, "RPT": RPT, "lds_rows": lds_rows, "R": R, "D": D, "tvec": tvec}
 
 
 def _launch_tiled(body, ins, byvalue, cshape, cstr, outs, out_dtypes, reduce_spec, rs, bkey, rkey, env):
@@ -495,8 +507,9 @@ def _launch_tiled(body, ins, byvalue, cshape, cstr, outs, out_dtypes, reduce_spe
     R, D = plan["R"], plan["D"]
     nrb, ncb = -(-R // TR), -(-D // TC)
     grid = nrb * ncb * int(np.prod([cshape[j] for j in batch])) if batch else nrb * ncb
-    name = f"ewt_{bkey}_{cls}_b{nb}_v{V}_x{TX}_r{RPT}_{rkey}".replace("-", "x")
-    src = codegen_tile.tile_kernel_source(name, body, cls, nb, V, TX, RPT, rs, plan["lds_rows"])
+    tvec = plan.get("tvec", 1)
+    name = f"ewt_{bkey}_{cls}_b{nb}_v{V}_x{TX}_r{RPT}_{rkey}".replace("-", "x") + (f"_tv{tvec}" if tvec > 1 else "")
+    src = codegen_tile.tile_kernel_source(name, body, cls, nb, V, TX, RPT, rs, plan["lds_rows"], tvec)
     fn = kernel_cache.get_function(src, name)
     ocs = _cstrides(cshape)
     args = [R, D, nrb, ncb] + [cshape[j] for j in batch] + [ocs[jr] if jr is not None else 0] + [ocs[j] for j in batch]
