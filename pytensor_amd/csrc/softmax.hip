@@ -158,6 +158,52 @@ __global__ __launch_bounds__(BLOCK) void softmax_block_kernel(T* __restrict__ ou
   }
 }
 
+// The workgroup's 256 consecutive rows (one contiguous chunk of n = rows * cols elements) between global memory and the
+// padded LDS tile [row][pitch], 16 bytes per lane and instruction when the chunk is 16-byte aligned (round 6: the 8-byte
+// loop moved half the bytes per instruction of every other streaming kernel here).  idx / cols without a division:
+// magic = ceil(2^20 / cols) is exact for idx < 256 * 33.
+template <class T>
+__device__ __forceinline__ void stage_rows_in(T* __restrict__ tile, const T* __restrict__ src, int n, int cols, int pitch, unsigned magic, bool vec) {
+  constexpr int VW = 16 / (int)sizeof(T);
+  typedef sm_pack<T, VW> P;
+  const int np = vec ? n / VW : 0;
+#pragma unroll 4
+  for (int p = threadIdx.x; p < np; p += BLOCK) {
+    const P v = reinterpret_cast<const P*>(src)[p];
+#pragma unroll
+    for (int e = 0; e < VW; e++) {
+      const int idx = p * VW + e;
+      const int r = (int)(((unsigned)idx * magic) >> 20), j = idx - r * cols;
+      tile[r * pitch + j] = v.v[e];
+    }
+  }
+  for (int idx = np * VW + threadIdx.x; idx < n; idx += BLOCK) {
+    const int r = (int)(((unsigned)idx * magic) >> 20), j = idx - r * cols;
+    tile[r * pitch + j] = src[idx];
+  }
+}
+template <class T>
+__device__ __forceinline__ void stage_rows_out(T* __restrict__ dst, const T* __restrict__ tile, int n, int cols, int pitch, unsigned magic, bool vec) {
+  constexpr int VW = 16 / (int)sizeof(T);
+  typedef sm_pack<T, VW> P;
+  const int np = vec ? n / VW : 0;
+#pragma unroll 4
+  for (int p = threadIdx.x; p < np; p += BLOCK) {
+    P v;
+#pragma unroll
+    for (int e = 0; e < VW; e++) {
+      const int idx = p * VW + e;
+      const int r = (int)(((unsigned)idx * magic) >> 20), j = idx - r * cols;
+      v.v[e] = tile[r * pitch + j];
+    }
+    reinterpret_cast<P*>(dst)[p] = v;
+  }
+  for (int idx = np * VW + threadIdx.x; idx < n; idx += BLOCK) {
+    const int r = (int)(((unsigned)idx * magic) >> 20), j = idx - r * cols;
+    dst[idx] = tile[r * pitch + j];
+  }
+}
+
 // rows of <= MAXC elements: thread per row — but a lane's row is cols*sizeof(T) bytes away from its neighbour's,
 // so the workgroup's 256 consecutive rows (one contiguous chunk of memory) are staged through LDS: coalesced
 // loads in, a row per thread out of LDS (odd pitch: conflict-free), results back the same way.
@@ -165,7 +211,7 @@ __global__ __launch_bounds__(BLOCK) void softmax_block_kernel(T* __restrict__ ou
 template <class T, bool LOG, int MAXC>
 __global__ __launch_bounds__(BLOCK) void softmax_small_kernel(T* __restrict__ out,
                                                              const T* __restrict__ x,
-                                                             long long rows, int cols, unsigned magic) {
+                                                             long long rows, int cols, unsigned magic, int vec) {
   typedef typename Acc<T>::type A;
   const pthip_dev::ExpCtx<T> ek;
   __shared__ T tile[BLOCK * (MAXC + 1)];
@@ -176,11 +222,7 @@ __global__ __launch_bounds__(BLOCK) void softmax_small_kernel(T* __restrict__ ou
   const int n = nr * cols;
   const T* src = x + r0 * cols;
   T* dst = out + r0 * cols;
-#pragma unroll 4
-  for (int idx = threadIdx.x; idx < n; idx += BLOCK) {
-    const int r = (int)(((unsigned)idx * magic) >> 20), j = idx - r * cols;  // magic = ceil(2^20 / cols): exact for idx < 256 * 17
-    tile[r * pitch + j] = src[idx];
-  }
+  stage_rows_in<T>(tile, src, n, cols, pitch, magic, vec != 0);
   __syncthreads();
   if ((int)threadIdx.x < nr) {
     T* row = tile + threadIdx.x * pitch;
@@ -206,11 +248,7 @@ __global__ __launch_bounds__(BLOCK) void softmax_small_kernel(T* __restrict__ ou
       if (j < cols) row[j] = LOG ? (v[j] - ls) : (v[j] * inv);
   }
   __syncthreads();
-#pragma unroll 4
-  for (int idx = threadIdx.x; idx < n; idx += BLOCK) {
-    const int r = (int)(((unsigned)idx * magic) >> 20), j = idx - r * cols;  // magic = ceil(2^20 / cols): exact for idx < 256 * 17
-    dst[idx] = tile[r * pitch + j];
-  }
+  stage_rows_out<T>(dst, tile, n, cols, pitch, magic, vec != 0);
 }
 
 template <class T>
@@ -220,10 +258,11 @@ int softmax_typed(int log_, long long rows, long long cols, const void* x, void*
   if (cols <= 16) {
     const unsigned grid = (unsigned)((rows + BLOCK - 1) / BLOCK);
     const unsigned magic = (unsigned)(((1u << 20) + (unsigned)cols - 1) / (unsigned)cols);
+    const int vec = ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((BLOCK * cols * sizeof(T)) % 16) == 0;
     if (log_)
-      PTHIP_KLAUNCH((softmax_small_kernel<T, true, 16>), dim3(grid), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, (int)cols, magic);
+      PTHIP_KLAUNCH((softmax_small_kernel<T, true, 16>), dim3(grid), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, (int)cols, magic, vec);
     else
-      PTHIP_KLAUNCH((softmax_small_kernel<T, false, 16>), dim3(grid), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, (int)cols, magic);
+      PTHIP_KLAUNCH((softmax_small_kernel<T, false, 16>), dim3(grid), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, (int)cols, magic, vec);
     return pthip::post_launch("softmax(thread per row, LDS-staged)");
   }
   if (rows < 2 * (long long)pthip::kNumCU && cols >= 4096) {
@@ -301,7 +340,7 @@ template <class T> __device__ __forceinline__ T lse_value(LseSt<T> a) { return (
 
 // ---- rows of <= 32 elements: thread per row, the workgroup's 256 consecutive rows staged through LDS ---------------
 template <class T, int MAXC>
-__global__ __launch_bounds__(BLOCK) void lse_rows_small_kernel(T* __restrict__ out, const T* __restrict__ x, long long rows, int cols, unsigned magic) {
+__global__ __launch_bounds__(BLOCK) void lse_rows_small_kernel(T* __restrict__ out, const T* __restrict__ x, long long rows, int cols, unsigned magic, int vec) {
   const pthip_dev::ExpCtx<T> ex;
   extern __shared__ __attribute__((aligned(16))) unsigned char lse_lds_[];
   T* tile = reinterpret_cast<T*>(lse_lds_);
@@ -311,12 +350,7 @@ __global__ __launch_bounds__(BLOCK) void lse_rows_small_kernel(T* __restrict__ o
   const int nr = left < BLOCK ? (int)left : BLOCK;
   const int n = nr * cols;
   const T* src = x + r0 * cols;
-#pragma unroll 4
-  for (int idx = threadIdx.x; idx < n; idx += BLOCK) {
-    // idx / cols without a division: magic = ceil(2^20 / cols) is exact for idx < 256 * 33 (host side: lse_rows_typed)
-    const int r = (int)(((unsigned)idx * magic) >> 20), j = idx - r * cols;
-    tile[r * pitch + j] = src[idx];
-  }
+  stage_rows_in<T>(tile, src, n, cols, pitch, magic, vec != 0);
   __syncthreads();
   if ((int)threadIdx.x < nr) {
     const T* row = tile + threadIdx.x * pitch;
@@ -775,19 +809,25 @@ int lse_rows_typed(long long rows, long long cols, const void* x, void* out) {
   constexpr int VW = 16 / (int)sizeof(T);
   if (cols <= 32) {
     const unsigned grid = (unsigned)((rows + BLOCK - 1) / BLOCK);
-    const size_t lds = (size_t)BLOCK * ((size_t)cols | 1) * sizeof(T);
+    size_t lds = (size_t)BLOCK * ((size_t)cols | 1) * sizeof(T);
+    static const size_t lds_min = [] { const char* e = getenv("PTHIP_LSE_SMALL_LDS_MIN"); return e ? (size_t)atol(e) : (size_t)0; }();
+    if (lds < lds_min) lds = lds_min;  // (occupancy experiment: fewer resident workgroups per CU)
     const unsigned magic = (unsigned)(((1u << 20) + (unsigned)cols - 1) / (unsigned)cols);
+    // 8-byte staging here: measured (profiles/r8_lse_small_staging.txt) the 16-byte form that wins 15 % in the softmax
+    // kernel (39.4 -> 33.6 us at 1e6 x 10, reads AND writes staged) loses 15 % in this read-only one (25.3 -> 29.4 us cold)
+    static const int vec_env = [] { const char* e = getenv("PTHIP_LSE_SMALL_VEC"); return e ? atoi(e) : 0; }();
+    const int vec = vec_env && ((uintptr_t)x % 16) == 0 && ((BLOCK * cols * sizeof(T)) % 16) == 0;
     static bool lds_raised = false;  // (up to 256 x 33 x 8 = 67.6 KB: beyond the 64 KB a launch may ask for by default)
     if (lds > 48 * 1024 && !lds_raised) {
       PTHIP_CHECK(hipFuncSetAttribute((const void*)lse_rows_small_kernel<T, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
       lds_raised = true;
     }
     if (cols <= 8)
-      PTHIP_KLAUNCH((lse_rows_small_kernel<T, 8>), dim3(grid), dim3(BLOCK), lds, st, (T*)out, (const T*)x, rows, (int)cols, magic);
+      PTHIP_KLAUNCH((lse_rows_small_kernel<T, 8>), dim3(grid), dim3(BLOCK), lds, st, (T*)out, (const T*)x, rows, (int)cols, magic, vec);
     else if (cols <= 16)
-      PTHIP_KLAUNCH((lse_rows_small_kernel<T, 16>), dim3(grid), dim3(BLOCK), lds, st, (T*)out, (const T*)x, rows, (int)cols, magic);
+      PTHIP_KLAUNCH((lse_rows_small_kernel<T, 16>), dim3(grid), dim3(BLOCK), lds, st, (T*)out, (const T*)x, rows, (int)cols, magic, vec);
     else
-      PTHIP_KLAUNCH((lse_rows_small_kernel<T, 32>), dim3(grid), dim3(BLOCK), lds, st, (T*)out, (const T*)x, rows, (int)cols, magic);
+      PTHIP_KLAUNCH((lse_rows_small_kernel<T, 32>), dim3(grid), dim3(BLOCK), lds, st, (T*)out, (const T*)x, rows, (int)cols, magic, vec);
     return pthip::post_launch("logsumexp(thread per row, LDS-staged)");
   }
   long long blocks = (rows + 3) / 4;
