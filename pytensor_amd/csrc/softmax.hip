@@ -74,28 +74,36 @@ template <class T, bool LOG, int VPL, int V>
 __global__ __launch_bounds__(BLOCK) void softmax_wave_reg_kernel(T* __restrict__ out,
                                                                 const T* __restrict__ x,
                                                                 long long rows, int cols) {
+  // Round 6: a wave walks rows wave, wave + nwaves, ... with the NEXT row's packs requested into a second register set
+  // before the current row is reduced, exponentiated and stored (two named buffers, unconditional loads at clamped
+  // addresses: a branch around a load or a copy of its result makes the compiler wait for every outstanding load).
+  // One row per wave and all waves resident at once (round 5) meant the whole chip loaded, then computed, then stored.
   typedef typename Acc<T>::type A;
   typedef sm_pack<T, V> P;
   const pthip_dev::ExpCtx<T> ek;  // (exp_device.h: 24-instruction fp64 exp, constants in registers)
   const int lane = threadIdx.x & 63;
   const long long wave = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
   const long long nwaves = (long long)gridDim.x * (BLOCK / 64);
-  for (long long r = wave; r < rows; r += nwaves) {
-    const T* xr = x + r * cols;
-    T* orow = out + r * cols;
-    P v[VPL];
-    T m = -__builtin_huge_val();
+  const T NEG = -__builtin_huge_val();
+  const int last = cols - V > 0 ? cols - V : 0;
+  auto request = [&](long long r, P (&buf)[VPL]) {
+    const T* xr = x + (r < rows ? r : rows - 1) * cols;
 #pragma unroll
     for (int u = 0; u < VPL; u++) {
       const int j = (lane + 64 * u) * V;
-      if (j < cols) v[u] = *reinterpret_cast<const P*>(xr + j);
+      buf[u] = *reinterpret_cast<const P*>(xr + (j < cols ? j : last));
     }
+  };
+  auto finish_row = [&](long long r, P (&v)[VPL]) {
+    T* orow = out + r * cols;
+    T m = NEG;
 #pragma unroll
     for (int u = 0; u < VPL; u++) {
-      const int j = (lane + 64 * u) * V;
-      if (j < cols) {
+      const bool in = (lane + 64 * u) * V < cols;
 #pragma unroll
-        for (int e = 0; e < V; e++) m = nan_max(m, v[u].v[e]);
+      for (int e = 0; e < V; e++) {
+        v[u].v[e] = in ? v[u].v[e] : NEG;
+        m = nan_max(m, v[u].v[e]);
       }
     }
 #pragma unroll
@@ -103,15 +111,12 @@ __global__ __launch_bounds__(BLOCK) void softmax_wave_reg_kernel(T* __restrict__
     A s = A(0);
 #pragma unroll
     for (int u = 0; u < VPL; u++) {
-      const int j = (lane + 64 * u) * V;
-      if (j < cols) {
 #pragma unroll
-        for (int e = 0; e < V; e++) {
-          const T d = v[u].v[e] - m;
-          const T ex = ek(d);
-          s += (A)ex;
-          v[u].v[e] = LOG ? d : ex;
-        }
+      for (int e = 0; e < V; e++) {
+        const T d = v[u].v[e] - m;
+        const T ex = ek(d);
+        s += (A)ex;
+        v[u].v[e] = LOG ? d : ex;
       }
     }
 #pragma unroll
@@ -122,12 +127,24 @@ __global__ __launch_bounds__(BLOCK) void softmax_wave_reg_kernel(T* __restrict__
 #pragma unroll
     for (int u = 0; u < VPL; u++) {
       const int j = (lane + 64 * u) * V;
-      if (j < cols) {
 #pragma unroll
-        for (int e = 0; e < V; e++) v[u].v[e] = LOG ? (v[u].v[e] - ls) : (v[u].v[e] * inv);
-        *reinterpret_cast<P*>(orow + j) = v[u];
-      }
+      for (int e = 0; e < V; e++) v[u].v[e] = LOG ? (v[u].v[e] - ls) : (v[u].v[e] * inv);
+      if (j < cols) *reinterpret_cast<P*>(orow + j) = v[u];
     }
+  };
+  long long r = wave;
+  if (r >= rows) return;
+  P bufA[VPL], bufB[VPL];
+  request(r, bufA);
+  while (true) {
+    request(r + nwaves, bufB);
+    finish_row(r, bufA);
+    r += nwaves;
+    if (r >= rows) break;
+    request(r + nwaves, bufA);
+    finish_row(r, bufB);
+    r += nwaves;
+    if (r >= rows) break;
   }
 }
 
@@ -274,7 +291,9 @@ int softmax_typed(int log_, long long rows, long long cols, const void* x, void*
     return pthip::post_launch("softmax(workgroup per row)");
   }
   long long blocks = (rows + 3) / 4;
-  const long long cap = (long long)pthip::kNumCU * 16;
+  // persistent waves with a prefetched row each: ~12 waves per CU hold two register sets of a 2048-column fp64 row
+  static const int sm_per_cu = [] { const char* e = getenv("PTHIP_SOFTMAX_WG_PER_CU"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 3; }();
+  const long long cap = (long long)pthip::kNumCU * sm_per_cu;
   if (blocks > cap) blocks = cap;
 #define LAUNCH_REG(VPL, V)                                                                       \
   do {                                                                                           \
@@ -372,6 +391,8 @@ __global__ __launch_bounds__(BLOCK) void lse_rows_small_kernel(T* __restrict__ o
 //      rescaling at all (the arithmetic of the reference's stabilised graph: max, then sum(exp(x - max))) ---------------
 template <class T, int VPL, int V>
 __global__ __launch_bounds__(BLOCK) void lse_rows_wave_kernel(T* __restrict__ out, const T* __restrict__ x, long long rows, int cols) {
+  // persistent: the next row of the wave is requested into a second register set before the current one is reduced
+  // (see softmax_wave_reg_kernel)
   const pthip_dev::ExpCtx<T> ex;
   typedef sm_pack<T, V> P;
   const int lane = threadIdx.x & 63;
@@ -379,14 +400,15 @@ __global__ __launch_bounds__(BLOCK) void lse_rows_wave_kernel(T* __restrict__ ou
   const long long nwaves = (long long)gridDim.x * (BLOCK / 64);
   const T NEG = -__builtin_huge_val();
   const int last = cols - V > 0 ? cols - V : 0;
-  for (long long r = wave; r < rows; r += nwaves) {
-    const T* xr = x + r * cols;
-    P v[VPL];
+  auto request = [&](long long r, P (&buf)[VPL]) {
+    const T* xr = x + (r < rows ? r : rows - 1) * cols;
 #pragma unroll
     for (int u = 0; u < VPL; u++) {  // (unconditional, clamped: all VPL loads in flight together)
       const int j = (lane + 64 * u) * V;
-      v[u] = *reinterpret_cast<const P*>(xr + (j < cols ? j : last));
+      buf[u] = *reinterpret_cast<const P*>(xr + (j < cols ? j : last));
     }
+  };
+  auto finish_row = [&](long long r, P (&v)[VPL]) {
     T m = NEG;
 #pragma unroll
     for (int u = 0; u < VPL; u++) {
@@ -409,6 +431,20 @@ __global__ __launch_bounds__(BLOCK) void lse_rows_wave_kernel(T* __restrict__ ou
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) out[r] = (T)log(s) + sh;
+  };
+  long long r = wave;
+  if (r >= rows) return;
+  P bufA[VPL], bufB[VPL];
+  request(r, bufA);
+  while (true) {
+    request(r + nwaves, bufB);
+    finish_row(r, bufA);
+    r += nwaves;
+    if (r >= rows) break;
+    request(r + nwaves, bufA);
+    finish_row(r, bufB);
+    r += nwaves;
+    if (r >= rows) break;
   }
 }
 
@@ -834,7 +870,8 @@ int lse_rows_typed(long long rows, long long cols, const void* x, void* out) {
   const bool packs = cols % VW == 0 && ((uintptr_t)x % 16) == 0;
   {
     long long wb = blocks;
-    const long long wcap = (long long)pthip::kNumCU * 16;
+    static const int lw_per_cu = [] { const char* e = getenv("PTHIP_LSE_WAVE_WG_PER_CU"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 3; }();
+    const long long wcap = (long long)pthip::kNumCU * lw_per_cu;
     if (wb > wcap) wb = wcap;
 #define LAUNCH_LSE(VPL, V)                                                                                                \
   do {                                                                                                                    \
