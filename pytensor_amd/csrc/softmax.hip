@@ -276,6 +276,9 @@ int softmax_typed(int log_, long long rows, long long cols, const void* x, void*
     const unsigned grid = (unsigned)((rows + BLOCK - 1) / BLOCK);
     const unsigned magic = (unsigned)(((1u << 20) + (unsigned)cols - 1) / (unsigned)cols);
     const int vec = ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((BLOCK * cols * sizeof(T)) % 16) == 0;
+    // (a persistent form of this kernel — tiles walked by 2-6 workgroups per CU, the next tile's packs prefetched into
+    //  registers — was measured at 41.8-42.4 us against 34.4 for one tile per workgroup at 1e6 x 10: three barriers per tile
+    //  and NPK = 8 pack slots for 5 packs; not kept)
     if (log_)
       PTHIP_KLAUNCH((softmax_small_kernel<T, true, 16>), dim3(grid), dim3(BLOCK), 0, st, (T*)out, (const T*)x, rows, (int)cols, magic, vec);
     else
