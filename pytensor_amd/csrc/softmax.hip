@@ -194,7 +194,8 @@ __device__ __forceinline__ void stage_rows_in(T* __restrict__ tile, const T* __r
       tile[r * pitch + j] = v.v[e];
     }
   }
-  for (int idx = np * VW + threadIdx.x; idx < n; idx += BLOCK) {
+#pragma unroll 4
+  for (int idx = np * VW + threadIdx.x; idx < n; idx += BLOCK) {  // (the whole chunk when !vec: several loads in flight)
     const int r = (int)(((unsigned)idx * magic) >> 20), j = idx - r * cols;
     tile[r * pitch + j] = src[idx];
   }
@@ -215,6 +216,7 @@ __device__ __forceinline__ void stage_rows_out(T* __restrict__ dst, const T* __r
     }
     reinterpret_cast<P*>(dst)[p] = v;
   }
+#pragma unroll 4
   for (int idx = np * VW + threadIdx.x; idx < n; idx += BLOCK) {
     const int r = (int)(((unsigned)idx * magic) >> 20), j = idx - r * cols;
     dst[idx] = tile[r * pitch + j];
