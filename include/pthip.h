@@ -168,6 +168,8 @@ typedef struct pthip_replay_desc {
 int pthip_plan_replay4(const pthip_replay_desc* desc, void* host_out, volatile int* done_word, int sync);
 /* a zero-initialised int32 device slot for a last-workgroup ticket (self-resetting; see csrc/tail_device.h) */
 int pthip_ticket_slot(void** slot);
+/* n consecutive such slots (one ticket per output tile of a one-pass N-d reduction: csrc/runtime.hip) */
+int pthip_ticket_slots(int n, void** first);
 /* Device-side join of a segmented plan's two streams (pthip_replay_desc.flags bit 1: pthip_plan_replay4 in poll mode
  * then issues no event between segment A's stream and the closing segment).  pthip_join_signal: a one-thread launch
  * on the current stream that stores 1 into `word` (a pthip_ticket_slot) — recorded as the last launch of segment A;

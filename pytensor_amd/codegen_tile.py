@@ -32,6 +32,7 @@ from __future__ import annotations
 from pytensor_amd.codegen import (
     BLOCK,
     CTYPE,
+    PT_PAIR_HELPERS,
     REDUCE_OPS,
     VEC_HELPERS,
     _reduce_epilogue,
@@ -305,7 +306,7 @@ def _lse_combine(L, k, T, sct, row_kept, inner_kept, TX, TY):
         raise ValueError("nothing reduced in the tile")
 
 
-def tile_reduce_params(body, cls, nkb, nrd, outs):
+def tile_reduce_params(body, cls, nkb, nrd, outs, finish=None):
     P = ["long long R", "long long D", "long long nrb", "long long ncb", "long long iters", "long long chunk", "long long ps_split"]
     P += [f"long long kb{j}" for j in range(nkb)] + [f"long long rd{j}" for j in range(nrd)]
     P += ["long long osr", "long long osi"] + [f"long long oskb{j}" for j in range(nkb)]
@@ -317,10 +318,17 @@ def tile_reduce_params(body, cls, nkb, nrd, outs):
         P += [f"long long s{k}_kb{j}" for j in range(nkb)] + [f"long long s{k}_rd{j}" for j in range(nrd)] + [f"long long s{k}_r", f"long long s{k}_i"]
     for k, (op, acc, odt) in enumerate(outs):
         P.append(f"{CTYPE[odt]}* __restrict__ dst{k}")
+    if finish:
+        # one-pass finish (tile_reduce_source): the final outputs and their element strides, the per-group tickets,
+        # the number of splits, lanes per output element of the closing fold, the device status word
+        for k, fdt in enumerate(finish):
+            P.append(f"{CTYPE[fdt]}* __restrict__ fin{k}")
+        P += ["long long fosr", "long long fosi"] + [f"long long foskb{j}" for j in range(nkb)]
+        P += ["int* __restrict__ pt_ticket", "long long nsplit", "long long n_nat", "int pt_L", "int* __restrict__ pt_status"]
     return P
 
 
-def tile_reduce_source(name: str, body: dict, cls: str, nkb: int, nrd: int, row_kept: bool, inner_kept: bool, V: int, TX: int, RPT: int, outs, ui: int = 0) -> str:
+def tile_reduce_source(name: str, body: dict, cls: str, nkb: int, nrd: int, row_kept: bool, inner_kept: bool, V: int, TX: int, RPT: int, outs, ui: int = 0, finish=None) -> str:
     """``out[kept] = reduce_{reduced} body(operands)`` — CAReduce over an axis tuple (pytensor/tensor/elemwise.py:1233,
     perform 1493-1511; the reference's C loop nest: elemwise.py:1520-1678, elemwise_cgen.py:467-761), any operand
     strides, with the scalar graph of a producing ``Elemwise`` evaluated on the fly.
@@ -351,8 +359,10 @@ def tile_reduce_source(name: str, body: dict, cls: str, nkb: int, nrd: int, row_
         assert TX <= 64 or TX == BLOCK
     NI = RPT if row_kept else 1  # accumulators per thread: kept rows x kept pack elements
     NE = V if inner_kept else 1
-    P = tile_reduce_params(body, cls, nkb, nrd, outs)
-    L = [reduce_header(), prelude_for(body), VEC_HELPERS]
+    P = tile_reduce_params(body, cls, nkb, nrd, outs, finish)
+    if finish:
+        assert not any(op == "LogSumExp" for op, _, _ in outs)
+    L = [reduce_header(), prelude_for(body), VEC_HELPERS, PT_PAIR_HELPERS if finish else ""]
     L.append(f'extern "C" __global__ __launch_bounds__({BLOCK}) void {name}({", ".join(P)}) {{')
     L.append(f"  constexpr int TX = {TX}, TY = {TY}, RPT = {RPT}, V = {V}, TC = {TC}, TR = {TR};")
     L.append("  unsigned pt_t = blockIdx.x;")
@@ -529,7 +539,10 @@ def tile_reduce_source(name: str, body: dict, cls: str, nkb: int, nrd: int, row_
             else:
                 L.append(f"#pragma unroll\n    for (int off = TX / 2; off > 0; off >>= 1) v = {opn}::apply(v, pthip_dev::shfl_xor_any(v, off));")
             L.append("    const long long row = rb * TR + ty + i * TY;")
-            L.append(f"    if (tx == 0 && row < R) dst{k}[ob + row * osr] = ({sct})v;")
+            if finish:
+                L.append(f"    if (tx == 0 && row < R) {{ pt_u64 b_ = 0; __builtin_memcpy(&b_, &v, sizeof(v)); pt_pair_store((pt_u64*)dst{k} + 2 * (ob + row * osr), b_, b_ ^ PT_PAIR_MAGIC); }}")
+            else:
+                L.append(f"    if (tx == 0 && row < R) dst{k}[ob + row * osr] = ({sct})v;")
             L.append("  }")
         elif inner_kept and not row_kept:
             if TY > 1:
@@ -545,13 +558,74 @@ def tile_reduce_source(name: str, body: dict, cls: str, nkb: int, nrd: int, row_
                 L.append("  }")
             L.append("  {")
             L.append("    const long long col = cb * TC + (long long)tx * V;")
-            L.append(f"#pragma unroll\n    for (int e = 0; e < V; e++) if (ty == 0 && col + e < D) dst{k}[ob + (col + e) * osi] = ({sct})acc{k}[0][e];")
+            if finish:
+                L.append(f"#pragma unroll\n    for (int e = 0; e < V; e++) if (ty == 0 && col + e < D) {{ pt_u64 b_ = 0; __builtin_memcpy(&b_, &acc{k}[0][e], sizeof(acc{k}[0][e])); pt_pair_store((pt_u64*)dst{k} + 2 * (ob + (col + e) * osi), b_, b_ ^ PT_PAIR_MAGIC); }}")
+            else:
+                L.append(f"#pragma unroll\n    for (int e = 0; e < V; e++) if (ty == 0 && col + e < D) dst{k}[ob + (col + e) * osi] = ({sct})acc{k}[0][e];")
             L.append("  }")
         elif not row_kept and not inner_kept:
             L.append(f"  __shared__ {act} sm{k}[{BLOCK // 64}];")
             L.append(f"  {{ const {act} v = pthip_dev::block_reduce<{opn}, {act}, {BLOCK}>(acc{k}[0][0], sm{k});")
-            L.append(f"    if (threadIdx.x == 0) dst{k}[ob] = ({sct})v; }}")
+            if finish:
+                L.append(f"    if (threadIdx.x == 0) {{ pt_u64 b_ = 0; __builtin_memcpy(&b_, &v, sizeof(v)); pt_pair_store((pt_u64*)dst{k} + 2 * ob, b_, b_ ^ PT_PAIR_MAGIC); }} }}")
+            else:
+                L.append(f"    if (threadIdx.x == 0) dst{k}[ob] = ({sct})v; }}")
         else:
             raise ValueError("nothing reduced in the tile: use tile_kernel_source")
+    if finish:
+        # ---- ONE pass (round 6): every workgroup has published its partials as self-validating pairs (no fence: see
+        # PT_PAIR_HELPERS); it takes a ticket of its GROUP — the workgroups that differ only in the split index — and the
+        # last of the nsplit to arrive folds the group's partials into the final outputs: pt_L lanes per output element,
+        # each lane the splits lane, lane + pt_L, ... in order, then a butterfly over the pt_L lanes (a fixed order
+        # whichever workgroup is last), and zeroes the pairs for the next launch.  The second-stage launch (4.5 us + a
+        # launch gap behind a 22 us pass over 134 MB: profiles/r8_hotpath_cold_kernel_stats.md) goes away.
+        NEL = TR if (row_kept and not inner_kept) else (TC if (inner_kept and not row_kept) else 1)
+        L.append("  __shared__ int pt_last_;")
+        L.append("  __syncthreads();")
+        L.append("  if (threadIdx.x == 0) pt_last_ = atomicAdd(pt_ticket + (blockIdx.x % (unsigned)n_nat), 1) == (int)nsplit - 1;")
+        L.append("  __syncthreads();")
+        L.append("  if (pt_last_) {")
+        L.append("    if (threadIdx.x == 0) __hip_atomic_store(pt_ticket + (blockIdx.x % (unsigned)n_nat), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);")
+        L.append("    const long long ob0 = ob - split * ps_split;")
+        fob = " + ".join(f"q{j} * foskb{j}" for j in range(nkb)) or "0"
+        L.append(f"    const long long fob = {fob};")
+        L.append("    const int ls_ = threadIdx.x % pt_L, es_ = threadIdx.x / pt_L, epp_ = 256 / pt_L;")
+        L.append(f"    for (int e0_ = 0; e0_ < {NEL}; e0_ += epp_) {{")
+        L.append("      const int el_ = e0_ + es_;")
+        if row_kept and not inner_kept:
+            L.append("      const long long pos_ = rb * TR + el_;")
+            L.append(f"      const bool val_ = el_ < {NEL} && pos_ < R;")
+            L.append("      const long long pidx_ = ob0 + pos_ * osr, fidx_ = fob + pos_ * fosr;")
+        elif inner_kept and not row_kept:
+            L.append("      const long long pos_ = cb * TC + el_;")
+            L.append(f"      const bool val_ = el_ < {NEL} && pos_ < D;")
+            L.append("      const long long pidx_ = ob0 + pos_ * osi, fidx_ = fob + pos_ * fosi;")
+        else:
+            L.append("      const bool val_ = el_ < 1;")
+            L.append("      const long long pidx_ = ob0, fidx_ = fob;")
+        for k, (op, acc, odt) in enumerate(outs):
+            act, opn = _acc_ctype(op, acc), f"pthip_dev::{ND_REDUCE_OPS[op]}"
+            L.append("      {")
+            L.append(f"        {act} r_ = {opn}::identity<{act}>();")
+            L.append("        pt_u64 b_[8]; bool got_[8];")
+            L.append("#pragma unroll\n        for (int q = 0; q < 8; q++) { b_[q] = 0; got_[q] = !(val_ && ls_ + pt_L * q < nsplit); }")
+            L.append("        for (long long spins = 0;; spins++) {")
+            L.append("          bool all_ = true;")
+            L.append("#pragma unroll\n          for (int q = 0; q < 8; q++)")
+            L.append(f"            if (!got_[q]) {{ got_[q] = pt_pair_poll((const pt_u64*)dst{k} + 2 * (pidx_ + (long long)(ls_ + pt_L * q) * ps_split), b_[q]); all_ = all_ && got_[q]; }}")
+            L.append("          if (all_) break;")
+            L.append("          if (spins > (1ll << 22)) { atomicOr(pt_status, 16); break; }")
+            L.append("        }")
+            L.append("#pragma unroll\n        for (int q = 0; q < 8; q++)")
+            L.append("          if (val_ && ls_ + pt_L * q < nsplit) {")
+            L.append(f"            {act} v_; __builtin_memcpy(&v_, &b_[q], sizeof(v_));")
+            L.append(f"            r_ = {opn}::apply(r_, v_);")
+            L.append(f"            pt_pair_store((pt_u64*)dst{k} + 2 * (pidx_ + (long long)(ls_ + pt_L * q) * ps_split), 0, 0);  // clean for the next launch")
+            L.append("          }")
+            L.append(f"#pragma unroll\n        for (int off = 32; off > 0; off >>= 1) {{ const {act} o_ = pthip_dev::shfl_xor_any(r_, off); if (off < pt_L) r_ = {opn}::apply(r_, o_); }}")
+            L.append(f"        if (ls_ == 0 && val_) fin{k}[fidx_] = ({CTYPE[finish[k]]})r_;")
+            L.append("      }")
+        L.append("    }")
+        L.append("  }")
     L.append("}")
     return "\n".join(L)

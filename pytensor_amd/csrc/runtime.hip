@@ -610,17 +610,43 @@ int pthip_plan_replay4(const pthip_replay_desc* d, void* host_out, volatile int*
 // A zero-initialised int32 slot in device memory for a "last workgroup continues" ticket (the generated
 // tail kernel: every workgroup shrinks one piece of a partial slab, the last one to finish runs the chain
 // and puts the slot back to zero).  Slots come from one 256 KiB block, handed out round-robin.
-int pthip_ticket_slot(void** slot) {
-  PTHIP_REQUIRE_INIT();
+static int ticket_block(int** base_out) {
   constexpr size_t N = 65536;
   static int* base = nullptr;
-  static size_t next = 0;
   if (!base) {
     PTHIP_CHECK(hipMalloc((void**)&base, N * sizeof(int)));
     PTHIP_CHECK(hipMemset(base, 0, N * sizeof(int)));
     PTHIP_CHECK(hipDeviceSynchronize());
   }
+  *base_out = base;
+  return 0;
+}
+
+int pthip_ticket_slot(void** slot) {
+  PTHIP_REQUIRE_INIT();
+  constexpr size_t N = 32768;  // single slots: the first half of the block, handed out round-robin
+  static size_t next = 0;
+  int* base = nullptr;
+  int r = ticket_block(&base);
+  if (r) return r;
   *slot = (void*)(base + (next++ % N));
+  return 0;
+}
+
+// n CONSECUTIVE zero-initialised int32 slots (the per-group tickets of a one-pass N-d reduction — one per output tile,
+// each self-resetting like a single slot): the second half of the block, round-robin; a request that would run over
+// the end starts again at the beginning of that half.
+int pthip_ticket_slots(int n, void** first) {
+  PTHIP_REQUIRE_INIT();
+  constexpr size_t HALF = 32768;
+  if (n <= 0 || (size_t)n > HALF / 4 || !first) return pthip::set_error("pthip_ticket_slots: 1 <= n <= %zu", HALF / 4);
+  static size_t next = 0;
+  int* base = nullptr;
+  int r = ticket_block(&base);
+  if (r) return r;
+  if (next + (size_t)n > HALF) next = 0;
+  *first = (void*)(base + HALF + next);
+  next += (size_t)n;
   return 0;
 }
 

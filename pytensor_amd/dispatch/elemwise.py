@@ -533,6 +533,7 @@ def _launch_tiled(body, ins, byvalue, cshape, cstr, outs, out_dtypes, reduce_spe
 # ---------------------------------------------------------------------------
 
 _ND_REDUCE = os.environ.get("PTHIP_ND_REDUCE", "1") != "0"
+_ND_ONEPASS = os.environ.get("PTHIP_ND_ONEPASS", "1") != "0"  # splits of an N-d reduction folded by the kernel's last workgroup per tile
 _ND_REDUCE_WGS = int(os.environ.get("PTHIP_ND_REDUCE_WGS", 1024))
 _RED_RPT = int(os.environ.get("PTHIP_RED_RPT", 0))  # rows per thread of the reduction tiles (0: as the elementwise tiles)
 _LSE_INFLIGHT = int(os.environ.get("PTHIP_LSE_INFLIGHT", 8))  # (8, 16, 32 measured the same: profiles/r5t_lse_inflight.txt)  # workgroups wanted before the reduced range is split
@@ -674,11 +675,16 @@ def launch_axis_reduce(env, body, ins, shape, axes, specs, out_shape):
     cls = "".join(cls)
     V, TX, RPT = plan["V"], plan["TX"], plan["RPT"]
     kouts = [(op, acc, (odt if final else acc)) for op, acc, odt in specs]
-    okey = "_".join(f"{op[:2]}{_dtag(acc)}{_dtag(sd)}" for op, acc, sd in kouts)
+    # ONE pass (round 6): with several splits and no log-sum-exp state the kernel's last workgroup per output tile folds
+    # the splits itself (codegen_tile.tile_reduce_source `finish`) — no second launch
+    onepass = (not final and _ND_ONEPASS and nsplit <= 512 and n_nat <= 8192 and not any(op == "LogSumExp" for op, _, _ in specs)
+               and all(np.dtype(acc).itemsize <= 8 for _, acc, _ in specs))
+    finish = [odt for _, _, odt in specs] if onepass else None
+    okey = "_".join(f"{op[:2]}{_dtag(acc)}{_dtag(sd)}" for op, acc, sd in kouts) + ("_1p" + "".join(_dtag(d) for d in finish) if finish else "")
     # tile visits whose loads are in flight together: 8 / RPT
     ui = max(1, min((_LSE_INFLIGHT if any(op == "LogSumExp" for op, _, _ in specs) else 8) // RPT, chunk))
     name = f"rnd_{_body_key(body)}_{cls}_k{len(kb)}r{len(rd)}_{'K' if plan['row_kept'] else 'R'}{'K' if plan['inner_kept'] else 'R'}_v{V}_x{TX}_r{RPT}_u{ui}_{okey}"
-    src = codegen_tile.tile_reduce_source(name, body, cls, len(kb), len(rd), plan["row_kept"], plan["inner_kept"], V, TX, RPT, kouts, ui)
+    src = codegen_tile.tile_reduce_source(name, body, cls, len(kb), len(rd), plan["row_kept"], plan["inner_kept"], V, TX, RPT, kouts, ui, finish=finish)
     fn = kernel_cache.get_function(src, name)
     args = [plan["R"], plan["D"], plan["nrb"], plan["ncb"], iters, chunk, ps_split] + [x["n"] for x in kb] + [x["n"] for x in rd]
     args += [(row["ost"] if plan["row_kept"] else 0) * ps_out, (inner["ost"] if plan["inner_kept"] else 0) * ps_out] + [x["ost"] * ps_out for x in kb]
@@ -690,11 +696,28 @@ def launch_axis_reduce(env, body, ins, shape, axes, specs, out_shape):
         args += [a.ptr] + [x["st"][j] for x in kb] + [x["st"][j] for x in rd] + [row["st"][j] if row is not None else 0, inner["st"][j]]
         j += 1
     outs = [DeviceArray.empty(out_shape, odt) for _, _, odt in specs]
-    dsts = outs if final else [DeviceArray.empty((nsplit * n_out,), acc) for _, acc, _ in specs]
+    if onepass:
+        # self-validating pairs (16 bytes per partial) instead of plain partials; never cleared from here (the last
+        # workgroup zeroes what it consumed; arbitrary bits validate with probability 2^-64: see launch_elemwise)
+        dsts = [DeviceArray.empty((2 * nsplit * n_out,), "uint64") for _ in specs]
+    else:
+        dsts = outs if final else [DeviceArray.empty((nsplit * n_out,), acc) for _, acc, _ in specs]
     args += [d.ptr for d in dsts]
+    if onepass:
+        tk = C.c_void_p()
+        ffi.check(env.lib.pthip_ticket_slots(int(n_nat), C.byref(tk)))
+        pt_L = 1
+        while pt_L < min(64, nsplit):
+            pt_L *= 2
+        args += [o.ptr for o in outs]
+        args += [(row["ost"] if plan["row_kept"] else 0), (inner["ost"] if plan["inner_kept"] else 0)] + [x["ost"] for x in kb]
+        args += [tk.value, nsplit, n_nat, pt_L, env.lib.pthip_status_ptr()]
+        env.keepalive.append(dsts)
     grid = n_nat * nsplit
     buf = struct.pack(f"<{len(args)}q", *args)
     env.timed(name, lambda: ffi.check(env.lib.pthip_launch(fn, grid, 1, 1, BLOCK, 1, 1, 0, buf, len(buf))))
+    if onepass:
+        return outs
     if not final and any(op == "LogSumExp" for op, _, _ in specs):
         # every split stored its own log-sum-exp: the splits fold by the same reduction (a second, small launch)
         res = []

@@ -86,6 +86,7 @@ SIGNATURES = {
     "pthip_plan_replay3": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _int]),
     "pthip_plan_replay4": (_int, [_vp, _vp, _vp, _int]),
     "pthip_ticket_slot": (_int, [C.POINTER(_vp)]),
+    "pthip_ticket_slots": (_int, [_int, C.POINTER(_vp)]),
     "pthip_join_signal": (_int, [_vp]),
     "pthip_join_probe": (_int, [_int, C.POINTER(_int)]),
     "pthip_graph_destroy": (_int, [_vp]),
