@@ -533,7 +533,12 @@ def _launch_tiled(body, ins, byvalue, cshape, cstr, outs, out_dtypes, reduce_spe
 # ---------------------------------------------------------------------------
 
 _ND_REDUCE = os.environ.get("PTHIP_ND_REDUCE", "1") != "0"
-_ND_ONEPASS = os.environ.get("PTHIP_ND_ONEPASS", "1") != "0"  # splits of an N-d reduction folded by the kernel's last workgroup per tile
+# splits of an N-d reduction folded by the kernel's last workgroup per output tile instead of a second launch: OPT-IN.
+# Measured on the 21 CAReduce cases of tools/bench_hotpath.py (256^3 fp64, cold): nothing gained — 22-26 us + a 4.5 us second
+# stage became 25-35 us (the closing fold is a serial poll -> fold -> store at the very end of the launch, and every
+# workgroup pays a write-through pair store and an atomic), and 136 us where a tile's elements x splits exceed a few
+# thousand pairs (sum over axes (0, 1): 128 columns x 512 splits for ONE workgroup).  profiles/r8_nd_onepass.txt.
+_ND_ONEPASS = os.environ.get("PTHIP_ND_ONEPASS", "0") == "1"
 _ND_REDUCE_WGS = int(os.environ.get("PTHIP_ND_REDUCE_WGS", 1024))
 _RED_RPT = int(os.environ.get("PTHIP_RED_RPT", 0))  # rows per thread of the reduction tiles (0: as the elementwise tiles)
 _LSE_INFLIGHT = int(os.environ.get("PTHIP_LSE_INFLIGHT", 8))  # (8, 16, 32 measured the same: profiles/r5t_lse_inflight.txt)  # workgroups wanted before the reduced range is split
@@ -677,7 +682,8 @@ def launch_axis_reduce(env, body, ins, shape, axes, specs, out_shape):
     kouts = [(op, acc, (odt if final else acc)) for op, acc, odt in specs]
     # ONE pass (round 6): with several splits and no log-sum-exp state the kernel's last workgroup per output tile folds
     # the splits itself (codegen_tile.tile_reduce_source `finish`) — no second launch
-    onepass = (not final and _ND_ONEPASS and nsplit <= 512 and n_nat <= 8192 and not any(op == "LogSumExp" for op, _, _ in specs)
+    nel = (TX * V) if (plan["inner_kept"] and not plan["row_kept"]) else (((BLOCK // TX) * RPT) if plan["row_kept"] else 1)
+    onepass = (not final and _ND_ONEPASS and nsplit <= 512 and n_nat <= 8192 and nel * nsplit <= 4096 and not any(op == "LogSumExp" for op, _, _ in specs)
                and all(np.dtype(acc).itemsize <= 8 for _, acc, _ in specs))
     finish = [odt for _, _, odt in specs] if onepass else None
     okey = "_".join(f"{op[:2]}{_dtag(acc)}{_dtag(sd)}" for op, acc, sd in kouts) + ("_1p" + "".join(_dtag(d) for d in finish) if finish else "")
