@@ -420,3 +420,51 @@ def test_axis_fusion_keeps_definition_before_use():
 def test_passes_keep_definition_before_use(name):
     g, *_ = load_case(name)
     _assert_def_before_use(_pipeline(g)[0], name)
+
+
+def test_identity_elemwise_behind_a_fused_logsumexp_is_dropped():
+    """round 6: what is left of ``log(sum(exp(x - m))) + m`` after fuse_logsumexp is an Elemwise of Identity nodes — a copy
+    launch; its readers (here: the graph output) take its operand instead.  Never for a graph input (outputs must not
+    alias what the caller owns)."""
+    from pytensor_amd.axisfuse import drop_identity_elemwise
+    from pytensor_amd.ir import Graph
+
+    for name in ("logsumexp_axis0", "logsumexp_axis1"):
+        g, ins, cvm, py, meta = load_case(name)
+        g2, _ = _pipeline(g)
+        assert [n.op for n in g2.nodes if n.op not in ("DimShuffle",)] == ["ElemwiseAxisReduce"], [n.op for n in g2.nodes]
+        _assert_def_before_use(g2, name)
+        np.testing.assert_allclose(np_graph.run_graph(g2, ins)[0], cvm[0], rtol=1e-13)
+    # an identity of a graph INPUT stays (the output would alias the caller's array)
+    g = Graph(name="id_of_input")
+    x = g.new_var("float64", (None,), name="x")
+    g.inputs = [x]
+    y = g.new_var("float64", (None,))
+    body = {"in_dtypes": ["float64"], "out_dtypes": ["float64"], "body": [{"op": "Identity", "in": [["i", 0]], "dtype": "float64"}], "outs": [["t", 0]]}
+    g.add_node("Elemwise", {"scalar": body}, [x], [y])
+    g.outputs = [y]
+    assert [n.op for n in drop_identity_elemwise(g).nodes] == ["Elemwise"]
+
+
+def test_generated_scalar_code_shares_exp_and_reciprocals():
+    """round 6 (codegen.emit_body): sigmoid and softplus of ONE float64 operand -> one pt_sig_sp; divisions by one float64
+    denominator -> one reciprocal, but only where every output is summed (flat_kernel_source decides): an element-wise
+    output keeps its exact quotient."""
+    from pytensor_amd import codegen
+
+    f64 = "float64"
+    body = {"in_dtypes": [f64, f64], "out_dtypes": [f64, f64],
+            "body": [{"op": "Sigmoid", "in": [["i", 0]], "dtype": f64}, {"op": "Softplus", "in": [["i", 0]], "dtype": f64},
+                     {"op": "TrueDiv", "in": [["t", 0], ["i", 1]], "dtype": f64}, {"op": "TrueDiv", "in": [["t", 1], ["i", 1]], "dtype": f64}],
+            "outs": [["t", 2], ["t", 3]]}
+    summed = codegen.flat_kernel_source("k_sum", body, "VV", 2, [("Add", f64), ("Add", f64)], 2)
+    stored = codegen.flat_kernel_source("k_store", body, "VV", 2, [None, None], 2)
+    loop = lambda src: src[src.index('extern "C" __global__'):]
+    assert "pt_sig_sp(" in loop(summed) and "pt_sigmoid(" not in loop(summed) and "pt_softplus(" not in loop(summed)
+    assert "_rcp = 1.0 / " in loop(summed) and " / (double)a1" not in loop(summed).replace("1.0 / (double)a1", "")
+    assert "pt_sig_sp(" in loop(stored)  # sharing the exp changes no quotient: allowed everywhere
+    assert "_rcp" not in loop(stored), "an element-wise output must keep x / d"
+    # different operands: nothing to share
+    body2 = {"in_dtypes": [f64, f64], "out_dtypes": [f64, f64],
+             "body": [{"op": "Sigmoid", "in": [["i", 0]], "dtype": f64}, {"op": "Softplus", "in": [["i", 1]], "dtype": f64}], "outs": [["t", 0], ["t", 1]]}
+    assert "pt_sig_sp(" not in loop(codegen.flat_kernel_source("k2", body2, "VV", 2, [("Add", f64), ("Add", f64)], 2))
