@@ -80,11 +80,11 @@ COLD_CYCLE_BYTES = 1.5 * 2**30  # one round-robin cycle touches at least this mu
 L3_TELL = 6300.0  # GB/s: above the measured HBM copy ceiling = served from the Infinity Cache
 
 
-def cold_device_time_ms(graph, inputs, nbytes, reps, footprint=None):
+def cold_device_time_ms(graph, inputs, nbytes, reps):
     """ms per evaluation with the Infinity Cache defeated: ``nsets`` executables over their own copies of the operands
     (distinct host arrays -> distinct resident device buffers; each frozen plan has a private output arena), replayed
-    round-robin, HIP events around ``reps`` whole cycles, best of three.  ``footprint``: bytes one set occupies
-    (defaults to the operands + as many bytes of output as of input, an upper bound)."""
+    round-robin, HIP events around ``reps`` whole cycles, best of three.  The number of sets follows from the case's
+    algorithmic bytes: >= 4 and enough for >= 1.5 GiB per cycle (at most 64)."""
     touched = max(float(nbytes), 1.0)
     nsets = int(max(4, -(-COLD_CYCLE_BYTES // touched)))
     nsets = min(nsets, 64)
