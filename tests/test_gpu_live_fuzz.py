@@ -1,0 +1,93 @@
+"""GPU: seeded random graphs the fixtures do NOT hold — built with the reference's front end on the GPU box, compiled with
+``mode="hip"`` and with the reference C linker (``Mode("cvm")``) in the same process, compared output by output.
+
+The generators are the ones behind the committed ``layout_fuzz*`` / ``glm_fuzz*`` goldens (oracle/golden_cases_layout_fuzz.py,
+golden_cases_glm_fuzz.py: random ranks, extents that straddle the tile sizes, operands as strided / reversed / permuted /
+broadcast views, reductions over random axis subsets, softmax / log-sum-exp along random axes, regression models with
+gathers and scatter-adds) with OTHER seeds: the fixtures pin 60 draws for ever, this module draws new ones — by default a
+dozen per run (``PTHIP_FUZZ_CASES`` raises it; round 6 ran 400, profiles/r8_live_fuzz.txt).  No fixture means no per-output
+tolerance table: floats are held to ``|err| <= rtol*|want| + 64 eps * max|want|`` (rtol 1e-10 fp64 / 1e-4 fp32) — an
+indexing, layout or reduction bug is an O(1) error — integers and booleans exactly, every call twice (eager, then captured)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_CASES = int(os.environ.get("PTHIP_FUZZ_CASES", "12"))
+SEED0 = int(os.environ.get("PTHIP_FUZZ_SEED0", "31000"))
+
+
+@pytest.fixture(scope="module")
+def gens():
+    import e2e_util
+
+    pytensor = e2e_util.activate()
+    if not e2e_util.have_gpu():
+        pytest.fail("no HIP device visible: GPU tests must run on the MI355X box")
+    sys.modules.setdefault("make_golden", __import__("make_golden"))
+    import golden_cases_glm_fuzz as G
+    import golden_cases_layout_fuzz as L
+
+    return pytensor, e2e_util, L, G
+
+
+def _multi_response(seed):
+    """the multi-response regression of oracle/ref_graphs.build_wide200_gemm (two Gemm nodes, a matrix triangular solve)
+    at random sizes on both sides of the skinny-GEMM kernels' thresholds (N >= 8192 rows, R <= 16 columns)"""
+    def build():
+        import ref_graphs
+        from pytensor_amd import configs
+
+        rng = np.random.default_rng(23000 + seed)
+        N = int(rng.choice([300, 5000, 8192, 9001, 20011, 40000]))
+        K = int(rng.choice([1, 5, 16, 37, 128, 130, 257]))
+        R = int(rng.choice([1, 2, 5, 8, 9, 16, 17]))
+        G = int(rng.choice([1, 7, 50, 300]))
+        vals = configs.wide200_gemm_inputs(N=N, T=0, K=K, G=G, R=R, seed=seed)
+        ins, outs = ref_graphs.build_wide200_gemm(vals, T=0)
+        return ins, outs, vals
+
+    return build
+
+
+def _families(L, G):
+    return [("multi_response", _multi_response),("layout_f64", lambda s: L._make(s, "float64")), ("layout_f32", lambda s: L._make(s, "float32")), ("layout_i64", lambda s: L._make(s, "int64")),
+            ("layout2_f64", lambda s: L._make2(s)), ("layout2_f32", lambda s: L._make2(s, "float32")), ("layout4", lambda s: L._make4(s)),
+            ("glm", lambda s: G._make(s)), ("wide", lambda s: G._make_wide(s))]
+
+
+def _compare(got, want, what):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape and got.dtype == want.dtype, f"{what}: {got.shape} {got.dtype} vs {want.shape} {want.dtype}"
+    if want.dtype.kind in "biu":
+        np.testing.assert_array_equal(got, want, err_msg=what)
+        return
+    f32 = want.dtype == np.float32
+    fin = np.isfinite(want)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want), err_msg=what + " (NaN pattern)")
+    np.testing.assert_array_equal(got[np.isinf(want)], want[np.isinf(want)], err_msg=what + " (infinities)")
+    if fin.any():
+        w, g = want[fin].astype(np.float64), got[fin].astype(np.float64)
+        tol = (1e-4 if f32 else 1e-10) * np.abs(w) + 64 * float(np.finfo(want.dtype).eps) * float(np.max(np.abs(w)))
+        worst = float(np.max(np.abs(g - w) / np.maximum(tol, 1e-300)))
+        assert worst <= 1.0, f"{what}: |err| / tol = {worst:.3g}"
+
+
+@pytest.mark.parametrize("k", range(N_CASES))
+def test_random_graph_hip_equals_reference_cvm(gens, k):
+    pytensor, E, L, G = gens
+    fams = _families(L, G)
+    name, make = fams[k % len(fams)]
+    seed = SEED0 + k
+    ins, outs, vals = make(seed)()
+    f = pytensor.function(ins, outs, mode="hip", on_unused_input="ignore")
+    fc = pytensor.function(ins, outs, mode=E.reference_mode(), on_unused_input="ignore")
+    args = [np.asarray(vals[v.name], dtype=v.type.dtype) for v in ins]
+    want = fc(*args)
+    for call in range(3):  # eager, capture, replay
+        got = f(*args)
+        for j, (a, b) in enumerate(zip(got, want)):
+            _compare(a, b, f"{name} seed {seed} out{j} call {call}")
