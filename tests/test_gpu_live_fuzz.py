@@ -5,7 +5,7 @@ The generators are the ones behind the committed ``layout_fuzz*`` / ``glm_fuzz*`
 golden_cases_glm_fuzz.py: random ranks, extents that straddle the tile sizes, operands as strided / reversed / permuted /
 broadcast views, reductions over random axis subsets, softmax / log-sum-exp along random axes, regression models with
 gathers and scatter-adds) with OTHER seeds: the fixtures pin 60 draws for ever, this module draws new ones — by default a
-dozen per run (``PTHIP_FUZZ_CASES`` raises it; round 6 ran 880, profiles/r8_live_fuzz.txt).  No fixture means no per-output
+dozen per run (``PTHIP_FUZZ_CASES`` raises it; round 6 ran 1500, profiles/r8_live_fuzz.txt).  No fixture means no per-output
 tolerance table: floats are held to ``|err| <= rtol*|want| + 64 eps * max|want|`` (rtol 1e-10 fp64 / 1e-4 fp32) — an
 indexing, layout or reduction bug is an O(1) error — integers and booleans exactly, every call twice (eager, then captured)."""
 import os
@@ -114,8 +114,113 @@ def _special(seed):
     return build
 
 
+def _linalg(seed):
+    """Cholesky / triangular and general solves / det / inverse (+ a Gaussian-process style log-density and its gradient) at
+    sizes on both sides of the one-CU, LDS-resident and blocked kernels' switches (csrc/linalg.hip), with and without batch
+    dimensions, vector, few-column and many-column right-hand sides; matrices with condition number <= ~100"""
+    def build():
+        import pytensor
+        import pytensor.tensor as pt
+        from pytensor.tensor import slinalg
+
+        rng = np.random.default_rng(37000 + seed)
+        n = int(rng.choice([1, 2, 3, 16, 31, 32, 33, 64, 65, 100, 128, 129, 160, 161, 255, 256, 257, 300, 513]))
+        batch = [(), (), (3,), (2, 2)][int(rng.integers(4))] if n <= 160 else ()
+        nrhs = [None, 1, 2, 5, 16, 17, 40][int(rng.integers(7))]
+        bshape = batch + ((n,) if nrhs is None else (n, nrhs))
+        q, _ = np.linalg.qr(rng.standard_normal(batch + (n, n)))
+        lam = np.exp(rng.uniform(0.0, np.log(100.0), batch + (n,)))
+        spd = (q * lam[..., None, :]) @ np.swapaxes(q, -1, -2)
+        spd = 0.5 * (spd + np.swapaxes(spd, -1, -2))
+        gen = q @ (np.triu(rng.standard_normal(batch + (n, n)) * 0.3 / np.sqrt(n), 1) + lam[..., None] * np.eye(n))
+        bv = rng.standard_normal(bshape)
+        A = pt.tensor("A", dtype="float64", shape=(None,) * (len(batch) + 2))
+        S = pt.tensor("S", dtype="float64", shape=(None,) * (len(batch) + 2))
+        b = pt.tensor("b", dtype="float64", shape=(None,) * len(bshape))
+        lower = bool(rng.integers(2))
+        L = slinalg.cholesky(S, lower=lower)
+        outs = [L, slinalg.solve_triangular(L, b, lower=lower, trans=int(rng.integers(2)), b_ndim=1 if nrhs is None else 2),
+                slinalg.solve(A, b, b_ndim=1 if nrhs is None else 2),
+                slinalg.solve(S, b, assume_a="pos", b_ndim=1 if nrhs is None else 2),
+                pt.linalg.det(A), pt.linalg.inv(S)]
+        if not batch:
+            tri = pt.tril(A) if lower else pt.triu(A)
+            outs.append(slinalg.solve_triangular(tri + n * pt.eye(n), b, lower=lower, unit_diagonal=bool(rng.integers(2))))
+            y = b if nrhs is None else b[:, 0]
+            alpha = slinalg.solve_triangular(L, y, lower=lower, trans=0 if lower else 1)
+            logp = -0.5 * pt.sum(alpha * alpha) - pt.sum(pt.log(pt.diagonal(L)))
+            outs += [logp, *pytensor.grad(logp, [S, b])]
+        # backward error eps*cond on every entry, whatever its own size
+        return [A, S, b], outs, {"A": gen, "S": spd, "b": bv, "_scales": {j: ("rel", 4000.0) for j in range(len(outs))}}
+
+    return build
+
+
+def _scan(seed):
+    """Scan with random structure: 0-2 sequences (forwards or backwards), a sit-sot or a two-tap mit-sot state (vector or matrix),
+    an optional second state fed by the first, an optional nit-sot output, non-sequences, an inner product against a constant
+    matrix in half the draws — outputs: every trajectory, the last state, and the gradient of a scalar of them (Scan's own
+    gradient is a second, backwards Scan)"""
+    def build():
+        import pytensor
+        import pytensor.tensor as pt
+
+        rng = np.random.default_rng(41000 + seed)
+        T = int(rng.choice([1, 2, 3, 7, 20, 64]))
+        d = int(rng.choice([1, 3, 16, 33, 64]))
+        mat = bool(rng.integers(2))  # state (B, d) instead of (d,)
+        B = int(rng.choice([2, 5, 64])) if mat else None
+        st = (B, d) if mat else (d,)
+        nseq, two_tap, second, nit, dot = int(rng.integers(3)), bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
+        back = bool(rng.integers(2))
+        seqs = [pt.tensor(f"s{i}", dtype="float64", shape=(None,) * (1 + len(st))) for i in range(nseq)]
+        h0 = pt.tensor("h0", dtype="float64", shape=(None,) * (1 + len(st)))  # (taps, *st)
+        g0 = pt.tensor("g0", dtype="float64", shape=(None,) * len(st))
+        W = pt.tensor("W", dtype="float64", shape=(None, None))
+        a = pt.scalar("a", dtype="float64")
+        vals = {f"s{i}": rng.standard_normal((T,) + st) * 0.5 for i in range(nseq)}
+        vals.update(h0=rng.standard_normal((2 if two_tap else 1,) + st) * 0.5, g0=rng.standard_normal(st) * 0.5,
+                    W=rng.standard_normal((d, d)) / np.sqrt(d), a=np.float64(rng.uniform(0.3, 0.9)))
+
+        def step(*args):
+            args = list(args)
+            xs = [args.pop(0) for _ in range(nseq)]
+            hs = [args.pop(0) for _ in range(2 if two_tap else 1)]  # oldest first
+            g = args.pop(0) if second else None
+            Wn, an = args
+            pre = hs[-1] @ Wn if dot else hs[-1] * 0.7
+            for x in xs:
+                pre = pre + x
+            if two_tap:
+                pre = pre - 0.3 * hs[0]
+            h = pt.tanh(pre) * an
+            res = [h]
+            if second:
+                res.append(g * an + pt.sqr(h))
+            if nit:
+                res.append(pt.sum(h, axis=-1) if mat else pt.exp(-pt.sqr(h)))
+            return res
+
+        info = [dict(initial=h0, taps=[-2, -1]) if two_tap else h0[0]]
+        if second:
+            info.append(g0)
+        if nit:
+            info.append(None)
+        res, _ = pytensor.scan(step, sequences=seqs, outputs_info=info, non_sequences=[W, a], n_steps=T, go_backwards=back)
+        res = res if isinstance(res, list) else [res]
+        cost = sum(pt.sum(pt.sqr(r)) for r in res) + pt.sum(res[0][-1])
+        wrt = [h0, W, a] + seqs + ([g0] if second else [])
+        outs = res + [res[0][-1], cost, *pytensor.grad(cost, wrt, disconnected_inputs="ignore")]
+        ins = seqs + [h0, g0, W, a]
+        # gradients add T*d terms of either sign: the floor follows the cost, not each entry
+        vals["_scales"] = {j: ("rel", 200.0) for j in range(len(outs))}
+        return ins, outs, vals
+
+    return build
+
+
 def _families(L, G):
-    return [("multi_response", _multi_response), ("special", _special), ("layout_f64", lambda s: L._make(s, "float64")), ("layout_f32", lambda s: L._make(s, "float32")), ("layout_i64", lambda s: L._make(s, "int64")),
+    return [("multi_response", _multi_response), ("special", _special), ("linalg", _linalg), ("scan", _scan), ("layout_f64", lambda s: L._make(s, "float64")), ("layout_f32", lambda s: L._make(s, "float32")), ("layout_i64", lambda s: L._make(s, "int64")),
             ("layout2_f64", lambda s: L._make2(s)), ("layout2_f32", lambda s: L._make2(s, "float32")), ("layout4", lambda s: L._make4(s)),
             ("glm", lambda s: G._make(s)), ("wide", lambda s: G._make_wide(s))]
 
@@ -132,7 +237,9 @@ def _compare(got, want, what, scale=0.0):
     np.testing.assert_array_equal(got[np.isinf(want)], want[np.isinf(want)], err_msg=what + " (infinities)")
     if fin.any():
         w, g = want[fin].astype(np.float64), got[fin].astype(np.float64)
-        tol = (1e-4 if f32 else 1e-10) * np.abs(w) + 64 * float(np.finfo(want.dtype).eps) * max(float(np.max(np.abs(w))), scale)
+        wmax = float(np.max(np.abs(w)))
+        floor = scale[1] * wmax if isinstance(scale, tuple) else max(wmax, scale)  # ("rel", f): f x the largest entry
+        tol = (1e-4 if f32 else 1e-10) * np.abs(w) + 64 * float(np.finfo(want.dtype).eps) * floor
         worst = float(np.max(np.abs(g - w) / np.maximum(tol, 1e-300)))
         assert worst <= 1.0, f"{what}: |err| / tol = {worst:.3g}"
 
