@@ -5,7 +5,7 @@ The generators are the ones behind the committed ``layout_fuzz*`` / ``glm_fuzz*`
 golden_cases_glm_fuzz.py: random ranks, extents that straddle the tile sizes, operands as strided / reversed / permuted /
 broadcast views, reductions over random axis subsets, softmax / log-sum-exp along random axes, regression models with
 gathers and scatter-adds) with OTHER seeds: the fixtures pin 60 draws for ever, this module draws new ones — by default a
-dozen per run (``PTHIP_FUZZ_CASES`` raises it; round 6 ran 1500, profiles/r8_live_fuzz.txt).  No fixture means no per-output
+dozen per run (``PTHIP_FUZZ_CASES`` raises it; round 6 ran 1600, profiles/r8_live_fuzz.txt).  No fixture means no per-output
 tolerance table: floats are held to ``|err| <= rtol*|want| + 64 eps * max|want|`` (rtol 1e-10 fp64 / 1e-4 fp32) — an
 indexing, layout or reduction bug is an O(1) error — integers and booleans exactly, every call twice (eager, then captured)."""
 import os
@@ -16,7 +16,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-N_CASES = int(os.environ.get("PTHIP_FUZZ_CASES", "12"))
+N_CASES = int(os.environ.get("PTHIP_FUZZ_CASES", "13"))  # one per family
 SEED0 = int(os.environ.get("PTHIP_FUZZ_SEED0", "31000"))
 ONLY = os.environ.get("PTHIP_FUZZ_FAMILY", "")  # e.g. "special,multi_response"
 
@@ -219,8 +219,51 @@ def _scan(seed):
     return build
 
 
+def _layout_big(seed):
+    """the layout family at sizes where the tiled-transpose and split-reduction kernels engage (2e5 .. 4e6 elements; the
+    committed layout fuzz stays under 5000): operands contiguous / stored permuted / broadcast / every-other-element views,
+    an elementwise expression, reductions of it over random axis subsets, a permuted result"""
+    def build():
+        import pytensor.tensor as pt
+
+        rng = np.random.default_rng(43000 + seed)
+        dt = "float64" if rng.random() < 0.6 else "float32"
+        rank = int(rng.choice([2, 2, 3, 3, 4]))
+        pool = [1, 2, 3, 5, 8, 17, 32, 33, 64, 100, 129, 256, 300, 513, 1000, 1025, 2048, 4099]
+        while True:
+            shape = [int(rng.choice(pool)) for _ in range(rank)]
+            if 200_000 <= np.prod(shape) <= 4_000_000:
+                break
+        perm = [int(i) for i in rng.permutation(rank)]
+        inv = [perm.index(i) for i in range(rank)]
+        vals, ins = {}, []
+
+        def inp(name, shp):
+            v = pt.tensor(name, dtype=dt, shape=(None,) * len(shp))
+            vals[name] = rng.standard_normal(shp).astype(dt)
+            ins.append(v)
+            return v
+
+        a = inp("a", shape)
+        b = inp("b", [shape[i] for i in perm]).transpose(inv)  # stored permuted, viewed back
+        bc = [bool(rng.integers(2)) for _ in range(rank)]
+        c = inp("c", [1 if f else n for f, n in zip(bc, shape)])
+        c = pt.specify_broadcastable(c, *[i for i, f in enumerate(bc) if f]) if any(bc) else c
+        ax = int(rng.integers(rank))
+        d = inp("d", [2 * n if i == ax else n for i, n in enumerate(shape)])[tuple(slice(None, None, 2) if i == ax else slice(None) for i in range(rank))]
+        e = a * b + pt.tanh(c) * d - 0.25 * pt.sqr(b)
+        axes = lambda: tuple(sorted(rng.choice(rank, size=int(rng.integers(1, rank + 1)), replace=False).tolist()))  # noqa: E731
+        outs = [e, pt.sum(e, axis=axes()), pt.max(a + d, axis=axes()), pt.mean(pt.sqr(e), axis=axes(), keepdims=True),
+                pt.sum(pt.exp(-pt.sqr(b)) * c, axis=int(rng.integers(rank))), e.transpose(perm) * 2.0, pt.prod(1.0 + 1e-3 * b, axis=axes()),
+                pt.argmax(b + c, axis=int(rng.integers(rank))), pt.sum(e), pt.min(d, axis=axes())]
+        vals["_scales"] = {1: ("rel", 50.0), 3: ("rel", 50.0), 4: ("rel", 50.0), 8: ("rel", 50.0)}
+        return ins, outs, vals
+
+    return build
+
+
 def _families(L, G):
-    return [("multi_response", _multi_response), ("special", _special), ("linalg", _linalg), ("scan", _scan), ("layout_f64", lambda s: L._make(s, "float64")), ("layout_f32", lambda s: L._make(s, "float32")), ("layout_i64", lambda s: L._make(s, "int64")),
+    return [("multi_response", _multi_response), ("special", _special), ("linalg", _linalg), ("scan", _scan), ("layout_big", _layout_big), ("layout_f64", lambda s: L._make(s, "float64")), ("layout_f32", lambda s: L._make(s, "float32")), ("layout_i64", lambda s: L._make(s, "int64")),
             ("layout2_f64", lambda s: L._make2(s)), ("layout2_f32", lambda s: L._make2(s, "float32")), ("layout4", lambda s: L._make4(s)),
             ("glm", lambda s: G._make(s)), ("wide", lambda s: G._make_wide(s))]
 
