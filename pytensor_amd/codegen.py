@@ -182,10 +182,70 @@ PT_DEV float pt_mod_f(float x, float y) {
   if (r != 0 && ((r < 0) != (y < 0))) r += y;
   return r;
 }
+// fp64 log1p in ~50 VALU instructions (the device library's is ~125; a logistic or Student-t log-density term is one log1p
+// per element and VALU-issue bound: profiles/r7_wide200_pmc.md).  The classical reduction: 1 + x = 2^k (1 + f) with 1 + f in
+// (sqrt(1/2), sqrt(2)], s = f / (2 + f), log(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2)) with the degree-7 minimax R of the
+// fdlibm family, k ln2 added as a hi/lo pair, and c = the rounding error of 1 + x (relative to 1 + x) added back; f = x itself
+// while k = 0.  The two divisions have tame denominators (2 + f in [1.7, 2.42]; 1 + x only scales a term below one ulp), so
+// they are v_rcp_f64 + Newton steps without the scale/fixup of a general fp64 division.  2.1 ulp max against long-double
+// log1pl on 4e7 host-emulated points (all magnitudes, both signs, the k = 0 / 1 boundaries), 0.5 ulp typical;
+// Log1p.c_code of the reference is libm's log1p (scalar/basic.py:3042; glibc < 1 ulp).  x < -1 -> NaN, -1 -> -inf,
+// +inf -> +inf, NaN -> NaN, |x| < 2^-54 -> x (keeps -0.0).
+PT_DEV double pt_log1p(double x) {
+  const double u = 1.0 + x;
+  double m = 2.0 * __builtin_amdgcn_frexp_mant(u);  // [1, 2)
+  int k = __builtin_amdgcn_frexp_exp(u) - 1;
+  const bool up = m > 0x1.6a09e667f3bcdp+0;
+  m = up ? 0.5 * m : m;
+  k = up ? k + 1 : k;
+  double c = k > 0 ? 1.0 - (u - x) : x - (u - 1.0);
+  c = k == 0 ? 0.0 : c * __builtin_amdgcn_rcp(u);
+  const double f = k == 0 ? x : m - 1.0;
+  const double d = 2.0 + f;
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  double sq = f * r;
+  sq = __builtin_fma(__builtin_fma(-d, sq, f), r, sq);
+  const double z = sq * sq, w = z * z;
+  const double t1 = w * __builtin_fma(w, __builtin_fma(w, 0x1.39a09d078c69fp-3, 0x1.c71c51d8e78afp-3), 0x1.999999997fa04p-2);
+  const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 0x1.2f112df3e5244p-3, 0x1.7466496cb03dep-3), 0x1.2492494229359p-2), 0x1.5555555555593p-1);
+  const double hf = 0.5 * f * f, dk = (double)k;
+  double y = __builtin_fma(dk, 0x1.62e42fee00000p-1, f - (hf - __builtin_fma(sq, hf + (t1 + t2), __builtin_fma(dk, 0x1.a39ef35793c76p-33, c))));
+  y = __builtin_fabs(x) < 0x1p-54 ? x : y;
+  y = x > -1.0 ? y : (x == -1.0 ? -__builtin_huge_val() : __builtin_nan(""));
+  y = x == __builtin_huge_val() ? x : y;
+  return y;
+}
+// fp64 log by the same reduction (x = 2^k (1 + f), no rounding term): ~45 VALU instructions against the device library's ~90;
+// 0.86 ulp max against long-double logl on 4e7 host-emulated points (normal and subnormal arguments, the neighbourhoods of 1,
+// sqrt(2) and sqrt(1/2)).  Log.c_code of the reference is libm's log (scalar/basic.py:2896).  x < 0 -> NaN, +-0 -> -inf,
+// +inf -> +inf, NaN -> NaN; subnormal arguments are normalised by v_frexp_mant_f64 / v_frexp_exp_i32_f64.
+PT_DEV double pt_log(double x) {
+  double m = 2.0 * __builtin_amdgcn_frexp_mant(x);
+  int k = __builtin_amdgcn_frexp_exp(x) - 1;
+  const bool up = m > 0x1.6a09e667f3bcdp+0;
+  m = up ? 0.5 * m : m;
+  k = up ? k + 1 : k;
+  const double f = m - 1.0, d = 2.0 + f;
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  double sq = f * r;
+  sq = __builtin_fma(__builtin_fma(-d, sq, f), r, sq);
+  const double z = sq * sq, w = z * z;
+  const double t1 = w * __builtin_fma(w, __builtin_fma(w, 0x1.39a09d078c69fp-3, 0x1.c71c51d8e78afp-3), 0x1.999999997fa04p-2);
+  const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 0x1.2f112df3e5244p-3, 0x1.7466496cb03dep-3), 0x1.2492494229359p-2), 0x1.5555555555593p-1);
+  const double hf = 0.5 * f * f, dk = (double)k;
+  double y = __builtin_fma(dk, 0x1.62e42fee00000p-1, f - (hf - __builtin_fma(sq, hf + (t1 + t2), dk * 0x1.a39ef35793c76p-33)));
+  y = x > 0.0 ? y : (x == 0.0 ? -__builtin_huge_val() : __builtin_nan(""));
+  y = x == __builtin_huge_val() ? x : y;
+  return y;
+}
 PT_DEV double pt_sigmoid(double x) { return 1.0 / (1.0 + pt_exp(-x)); }
 PT_DEV float pt_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 PT_DEV double pt_softplus(double x) {
-  return x < -37.0 ? pt_exp(x) : x < 18.0 ? log1p(pt_exp(x)) : x < 33.3 ? x + pt_exp(-x) : x;
+  return x < -37.0 ? pt_exp(x) : x < 18.0 ? pt_log1p(pt_exp(x)) : x < 33.3 ? x + pt_exp(-x) : x;
 }
 // sigmoid(x) and softplus(x) of ONE argument (the logistic log-density and its gradient; a Bernoulli-logit likelihood):
 // both from e = exp(-|x|) in (0, 1] — one exp instead of two or three, no overflow on either side.
@@ -197,13 +257,13 @@ PT_DEV void pt_sig_sp(double x, double& sg, double& sp) {
   const double e = pt_exp(-__builtin_fabs(x));
   const double inv = 1.0 / (1.0 + e);
   sg = x >= 0.0 ? inv : e * inv;
-  sp = (x > 0.0 ? x : 0.0) + log1p(e);
+  sp = (x > 0.0 ? x : 0.0) + pt_log1p(e);
   if (x != x) { sg = x; sp = x; }
 }
 PT_DEV float pt_softplus(float x) {
   return x < -37.0f ? expf(x) : x < 18.0f ? log1pf(expf(x)) : x < 33.3f ? x + expf(-x) : x;
 }
-PT_DEV double pt_log1mexp(double x) { return x < -0.6931471805599453 ? log1p(-exp(x)) : log(-expm1(x)); }
+PT_DEV double pt_log1mexp(double x) { return x < -0.6931471805599453 ? pt_log1p(-exp(x)) : log(-expm1(x)); }
 PT_DEV float pt_log1mexp(float x) { return x < -0.6931471805599453f ? log1pf(-expf(x)) : logf(-expm1f(x)); }
 // RoundHalfToEven (scalar/basic.py:2737-2766 restates npy_rint with floor arithmetic): the
 // hardware's v_rndne is that function exactly, and — unlike `x - floor(x)` — cannot have the
@@ -858,6 +918,8 @@ def _helper(fn):
     return gen
 
 
+_FAST_LOG = os.environ.get("PTHIP_FAST_LOG", "1") != "0"  # diagnostic: 0 = the device library's log / log1p
+
 # op name (reference ScalarOp class) → expression generator
 SCALAR_EXPR = {
     "Add": _chain("+"),  # scalar/basic.py:1835 Add.c_code
@@ -875,10 +937,10 @@ SCALAR_EXPR = {
     "Exp": _f("pt_exp" if os.environ.get("PTHIP_FAST_EXP", "1") != "0" else "exp", "expf"),  # 3085
     "Exp2": _f("exp2"),
     "Expm1": _f("expm1"),
-    "Log": _f("log"),  # 2907
+    "Log": _f("pt_log" if _FAST_LOG else "log", "logf"),  # 2907
     "Log2": _f("log2"),
     "Log10": _f("log10"),
-    "Log1p": _f("log1p"),  # 3042
+    "Log1p": _f("pt_log1p" if _FAST_LOG else "log1p", "log1pf"),  # 3042
     "Sin": _f("sin"),
     "Cos": _f("cos"),
     "Tan": _f("tan"),

@@ -28,8 +28,10 @@ TERM_CAP = int(os.environ.get("PTHIP_WIDE_CAP", 64))  # per term (the partials a
 
 
 # rough VALU instructions per element of a scalar op on gfx950 (fp64): what the split of a launch among its terms is
-# weighted by (an estimate only has to rank the families; measured: exp 24, the device library's log1p ~40, tanh ~85)
-_OP_COST = {"Exp": 24, "Log": 35, "Log1p": 40, "Log2": 35, "Log10": 35, "Expm1": 40, "Sigmoid": 40, "Softplus": 80, "Tanh": 85, "Pow": 100, "TrueDiv": 12,
+# weighted by (an estimate only has to rank the families; measured on the ISA: pt_exp 24, pt_log1p ~60 — the device library's
+# is ~125 — a division by a varying denominator ~12, pt_tanh ~45)
+_L1P = float(os.environ.get("PTHIP_WIDE_COST_LOG1P", 60))
+_OP_COST = {"Exp": 24, "Log": 50, "Log1p": _L1P, "Log2": 35, "Log10": 35, "Expm1": 40, "Sigmoid": 40, "Softplus": 80, "Tanh": 85, "Pow": 100, "TrueDiv": 12,
             "Sqrt": 12, "Erf": 60, "Erfc": 80, "GammaLn": 150, "Psi": 150, "Sin": 60, "Cos": 60, "Log1mexp": 70, "ScalarLoop": 400}
 
 
@@ -59,7 +61,7 @@ def _term_cost(body, modes=None) -> float:
             arg = (n["in"][0][0], n["in"][0][1])
             other = seen_sig.get(arg)
             if other is not None and other != op:
-                cost += 40.0 if op == "Softplus" else 4.0  # the shared exp and reciprocal are paid: what is left is log1p / a select
+                cost += _L1P if op == "Softplus" else 4.0  # the shared exp and reciprocal are paid: what is left is log1p / a select
             else:
                 cost += 24.0 + (28.0 if op == "Sigmoid" else 44.0)
             seen_sig[arg] = op
