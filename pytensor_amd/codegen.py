@@ -1373,10 +1373,10 @@ def multi_flat_source(name: str, terms) -> str:
     head = [reduce_header(), prelude_for(*bodies), VEC_HELPERS]
     fns, fn_of = {}, []
     for t in terms:
-        key = source_key(repr((t["body"], t["modes"], t["vec"], t["rs"], t["unroll"])))
+        key = source_key(repr((t["body"], t["modes"], t["vec"], t["rs"], t["unroll"], bool(t.get("prefetch")))))
         if key not in fns:
             fname = f"mt_{key[:12]}"
-            fns[key] = (fname, flat_kernel_source(fname, t["body"], t["modes"], t["vec"], t["rs"], t["unroll"], device_fn=True))
+            fns[key] = (fname, flat_kernel_source(fname, t["body"], t["modes"], t["vec"], t["rs"], t["unroll"], device_fn=True, prefetch=bool(t.get("prefetch"))))
         fn_of.append(fns[key][0])
     P, calls = [], []
     for ti, t in enumerate(terms):

@@ -24,7 +24,9 @@ MAX_ARG_BYTES = 3900
 import os
 
 TOTAL_GROUPS = int(os.environ.get("PTHIP_WIDE_GROUPS", 2048))  # workgroups of one launch, shared among the terms
-TERM_CAP = int(os.environ.get("PTHIP_WIDE_CAP", 64))  # per term (the partials a Tail kernel folds in one pass)
+TERM_CAP = int(os.environ.get("PTHIP_WIDE_CAP", 64))
+WIDE_UNROLL = int(os.environ.get("PTHIP_WIDE_UNROLL", 0))  # packs per loop iteration of a term (0: the Elemwise default)
+WIDE_PREFETCH_MIN = float(os.environ.get("PTHIP_WIDE_PREFETCH_MIN", "inf"))  # software-pipelined loop for terms costing at least this  # per term (the partials a Tail kernel folds in one pass)
 
 
 # rough VALU instructions per element of a scalar op on gfx950 (fp64): what the split of a launch among its terms is
@@ -149,7 +151,8 @@ def multi_elemwise(node, inputs, env):
     for (t, ins, modes, n, vec), gt in zip(per_term, groups):
         body, spec = t["scalar"], t["reduce"]
         rs = [(r["op"], r["acc_dtype"]) for r in spec]
-        gen_terms.append({"body": body, "modes": modes, "vec": vec, "rs": rs, "unroll": EW_UNROLL, "groups": gt})
+        gen_terms.append({"body": body, "modes": modes, "vec": vec, "rs": rs, "unroll": WIDE_UNROLL or EW_UNROLL, "groups": gt,
+                          "prefetch": vec > 1 and _term_cost(body, modes) >= WIDE_PREFETCH_MIN})
         parts = alloc_partials(spec, gt)
         args.append(n)
         for k, (a, m) in enumerate(zip(ins, modes)):
@@ -159,7 +162,7 @@ def multi_elemwise(node, inputs, env):
     buf = struct.pack(f"<{len(args)}q", *args)
     if len(buf) > MAX_ARG_BYTES:
         return _run_members(node, inputs, env)
-    key = codegen.source_key(repr([(_body_key(g["body"]), g["modes"], g["vec"], g["rs"], g["groups"]) for g in gen_terms]))
+    key = codegen.source_key(repr([(_body_key(g["body"]), g["modes"], g["vec"], g["rs"], g["groups"], g["unroll"], g["prefetch"]) for g in gen_terms]))
     name = f"multi_{key[:16]}_t{nt}"
     src = codegen.multi_flat_source(name, gen_terms)
     fn = kernel_cache.get_function(src, name)
