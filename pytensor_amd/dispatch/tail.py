@@ -311,15 +311,6 @@ def _run_fused(node, P, results, env, inputs=()):
                 n = _vec_len(val.shape)
                 if n is None or n > MAX_LEN:
                     join_ptr = 0
-    if fuse_shrink is None:
-        for dt, ts in by_dt.items():
-            for c0 in range(0, len(ts), 16):
-                chunk = ts[c0 : c0 + 16]
-                n = len(chunk)
-                ffi.check(lib.pthip_multi_finish(
-                    ffi.np_dtype_code(dt), n, (C.c_int * n)(*[t[0] for t in chunk]), (C.c_void_p * n)(*[t[1].ptr for t in chunk]),
-                    (C.c_int64 * n)(*[t[2] for t in chunk]), (C.c_int64 * n)(*[t[3] for t in chunk]), (C.c_int * n)(*[t[4] for t in chunk]),
-                    (C.c_void_p * n)(*[t[5].ptr for t in chunk])))
     # launch 2: the chain
     # one-element slots first, at static 16-byte cells; vector slots behind them at run-time offsets
     off = 16 * sum(1 for s in P.slots if s["scalar"])
@@ -351,6 +342,20 @@ def _run_fused(node, P, results, env, inputs=()):
     if join:
         env.tail_join_used = True
     buf = struct.pack("<" + "".join(a[0] for a in args), *[a[1] for a in args])
+    if len(buf) > 4000:
+        # BEFORE the shrink launch: a chain that does not fit is run as two (`_run_split`), each half shrinking its own
+        # slabs — a shrink launched here first would be recorded into the plan and replayed for nothing (north_star's
+        # 48-term graph carried one such 4.7 us launch per evaluation until round 6)
+        raise _Infeasible("kernel argument block")
+    if fuse_shrink is None:
+        for dt, ts in by_dt.items():
+            for c0 in range(0, len(ts), 16):
+                chunk = ts[c0 : c0 + 16]
+                n = len(chunk)
+                ffi.check(lib.pthip_multi_finish(
+                    ffi.np_dtype_code(dt), n, (C.c_int * n)(*[t[0] for t in chunk]), (C.c_void_p * n)(*[t[1].ptr for t in chunk]),
+                    (C.c_int64 * n)(*[t[2] for t in chunk]), (C.c_int64 * n)(*[t[3] for t in chunk]), (C.c_int * n)(*[t[4] for t in chunk]),
+                    (C.c_void_p * n)(*[t[5].ptr for t in chunk])))
     grid = 1
     if fuse_shrink is not None:
         tasks, grid = codegen.tail_shrink_pack([(t[0], t[1].ptr, t[2], t[3], t[4], t[5].ptr) for t in P.shrink])
