@@ -86,6 +86,9 @@ _VIEW_OPS = {"DimShuffle", "Subtensor", "Shape_i", "ScalarFromTensor"}
 # runs 335 us instead of 170 and the evaluation takes 0.52 ms instead of 0.49.  Default: the latency chain keeps the
 # second stream.
 _WIDE_STREAM = __import__("os").environ.get("PTHIP_WIDE_STREAM", "0") == "1"
+# PTHIP_WIDE_STREAM=2: the many-term launch BEHIND the latency chain on the second stream (Cholesky -> solve -> many-term),
+# so that only the streaming kernel's last quarter shares the chip with it.
+_WIDE_BEHIND = __import__("os").environ.get("PTHIP_WIDE_STREAM", "0") == "2"
 
 
 def stream_classes(g: Graph, staged_inputs=()):
@@ -93,8 +96,8 @@ def stream_classes(g: Graph, staged_inputs=()):
     scalar work hanging off it (see ``plan.StreamScheduler``)."""
     cls = []
     var_cls = {}
-    wide = _WIDE_STREAM and any(n.op == "MultiElemwise" for n in g.nodes) and any(n.op == "GemvChain" for n in g.nodes)
-    side_ops = {"MultiElemwise"} if wide else LATENCY_OPS
+    wide = (_WIDE_STREAM or _WIDE_BEHIND) and any(n.op == "MultiElemwise" for n in g.nodes) and any(n.op == "GemvChain" for n in g.nodes)
+    side_ops = (LATENCY_OPS | {"MultiElemwise"} if _WIDE_BEHIND else {"MultiElemwise"}) if wide else LATENCY_OPS
     for n in g.nodes:
         parents = [var_cls[v] for v in n.inputs if v in var_cls]
         if wide and n.op in _VIEW_OPS and not parents:
@@ -151,7 +154,7 @@ def segment_graph(g: Graph):
     cls = stream_classes(g)
     if not any(cls):
         return g, None
-    wide = _WIDE_STREAM and any(n.op == "MultiElemwise" for n in g.nodes) and any(n.op == "GemvChain" for n in g.nodes)
+    wide = (_WIDE_STREAM or _WIDE_BEHIND) and any(n.op == "MultiElemwise" for n in g.nodes) and any(n.op == "GemvChain" for n in g.nodes)
     produced_by = {}
     for k, n in enumerate(g.nodes):
         for o in n.outputs:
