@@ -1224,7 +1224,7 @@ def _flat_params(body: dict, modes: str, reduce_spec, vec: int, finish=None):
     return params
 
 
-def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=None, unroll=2, device_fn=False, prefetch=False, finish=None) -> str:
+def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=None, unroll=2, device_fn=False, prefetch=False, finish=None, finish_per_thread=None) -> str:
     """:func:`_flat_kernel_source` with the emit context set: when EVERY output of the body is summed (a logp term and its
     gradients in a many-term launch, a fused Elemwise + Sum) no element is ever seen — only sums over ~1e6 of them, held to
     rtol 1e-12 — so divisions that share a float64 denominator may share ONE reciprocal (x * (1/d) is within 1.5 ulp of
@@ -1233,12 +1233,12 @@ def flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=
     old = _EMIT_CTX["share_recip"]
     _EMIT_CTX["share_recip"] = bool(all_summed and os.environ.get("PTHIP_SHARE_RECIP", "1") != "0")
     try:
-        return _flat_kernel_source(name, body, modes, vec, reduce_spec, unroll, device_fn, prefetch, finish)
+        return _flat_kernel_source(name, body, modes, vec, reduce_spec, unroll, device_fn, prefetch, finish, finish_per_thread)
     finally:
         _EMIT_CTX["share_recip"] = old
 
 
-def _flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=None, unroll=2, device_fn=False, prefetch=False, finish=None) -> str:
+def _flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec=None, unroll=2, device_fn=False, prefetch=False, finish=None, finish_per_thread=None) -> str:
     """``flat`` loop.  ``modes[k]`` ∈ {'V' contiguous vector, 'S' scalar broadcast} per input.
 
     reduce_spec: None or list (per output) of None | (op_name, acc_dtype): reduced
@@ -1355,7 +1355,7 @@ def _flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec
         src.append(f"  for (long long i = tid; i < n; i += nthreads) {{")
         src.append(_flat_elem(body, modes, reduce_spec, "i"))
         src.append("  }")
-    src.append(_reduce_epilogue(reduce_spec, unroll, finish))
+    src.append(_reduce_epilogue(reduce_spec, unroll, finish, finish_per_thread))
     src.append("}")
     text = "\n".join(src)
     if device_fn:
@@ -1363,34 +1363,61 @@ def _flat_kernel_source(name: str, body: dict, modes: str, vec: int, reduce_spec
     return text
 
 
-def multi_flat_source(name: str, terms) -> str:
+def multi_finish_layout(nred: int, groups: int):
+    """One term's block of a self-finishing many-term launch, in 8-byte words: ``nred`` pair arrays of ``2 * groups`` words,
+    then the finished values; returns ``(offset of the finals, words in all — even, so the next term's pairs stay 16-byte
+    aligned)``."""
+    fin = 2 * groups * nred
+    return fin, (fin + nred + 1) // 2 * 2
+
+
+def multi_flat_source(name: str, terms, finish: bool = False) -> str:
     """Several independent flat kernels in ONE launch (widefuse.fuse_independent_reductions):
     ``(blockIdx.x + blockIdx.y) % gridDim.x`` selects the term, ``blockIdx.y`` / the term's ``groups`` are the
     workgroup index / count within it.  ``terms``: ``[{body, modes, vec, rs, unroll}]``; terms with the same (body, modes,
     vec, reductions) share one device function.  Arguments: the terms' flat-kernel arguments, one
-    term after the other."""
+    term after the other.
+
+    ``finish``: every term finishes its own reductions (``_reduce_epilogue``'s one-pass form: the term's last workgroup
+    folds its <= BLOCK pairs).  A term's pair arrays and finished values then live in ONE block (``multi_finish_layout``)
+    passed as a single pointer, its ticket is ``tickets[term]`` and the status word is shared: the argument block shrinks
+    instead of growing (4 KB limit: north_star's 48 terms)."""
     bodies = [t["body"] for t in terms]
-    head = [reduce_header(), prelude_for(*bodies), VEC_HELPERS]
+    head = [reduce_header(), prelude_for(*bodies), VEC_HELPERS, PT_PAIR_HELPERS if finish else ""]
     fns, fn_of = {}, []
     for t in terms:
-        key = source_key(repr((t["body"], t["modes"], t["vec"], t["rs"], t["unroll"], bool(t.get("prefetch")))))
+        key = source_key(repr((t["body"], t["modes"], t["vec"], t["rs"], t["unroll"], bool(t.get("prefetch")), finish)))
         if key not in fns:
             fname = f"mt_{key[:12]}"
-            fns[key] = (fname, flat_kernel_source(fname, t["body"], t["modes"], t["vec"], t["rs"], t["unroll"], device_fn=True, prefetch=bool(t.get("prefetch"))))
+            fin = [rs[1] for rs in t["rs"]] if finish else None  # (finished in the accumulator dtype: 8-byte words)
+            fns[key] = (fname, flat_kernel_source(fname, t["body"], t["modes"], t["vec"], t["rs"], t["unroll"], device_fn=True, prefetch=bool(t.get("prefetch")),
+                                                  finish=fin, finish_per_thread=1 if finish else None))
         fn_of.append(fns[key][0])
     P, calls = [], []
     for ti, t in enumerate(terms):
         ps = _flat_params(t["body"], t["modes"], t["rs"], t["vec"])
         names = []
+        nred = len(t["rs"])
         for q, prm in enumerate(ps):
             decl, nm = prm.rsplit(" ", 1)
+            if finish and nm.startswith("part"):
+                if nm == "part0":
+                    P.append(f"double* __restrict__ t{ti}_blk")
+                k = int(nm[4:])
+                names.append(f"({decl})(t{ti}_blk + {2 * int(t['groups']) * k})")
+                continue
             P.append(f"{decl} t{ti}_{nm}")
             names.append(f"t{ti}_{nm}")
         gt = t.get("groups")  # this term's workgroup count (cost-proportional, dispatch/wide.py); default: the whole grid column
+        if finish:
+            fin0, _ = multi_finish_layout(nred, int(gt))
+            names += [f"({CTYPE[rs[1]]}*)(t{ti}_blk + {fin0 + k})" for k, rs in enumerate(t["rs"])] + [f"pt_tickets + {ti}", "pt_status"]
         if gt:
             calls.append(f"    case {ti}: if (blockIdx.y < {int(gt)}) {fn_of[ti]}({', '.join(names)}, blockIdx.y, {int(gt)}u); break;")
         else:
             calls.append(f"    case {ti}: {fn_of[ti]}({', '.join(names)}, blockIdx.y, gridDim.y); break;")
+    if finish:
+        P += ["int* __restrict__ pt_tickets", "int* __restrict__ pt_status"]
     L = head + [f for _, f in fns.values()]
     L.append(f'extern "C" __global__ __launch_bounds__({BLOCK}) void {name}({", ".join(P)}) {{')
     # grid (terms, workgroups per term), the term rotated by the round: consecutive workgroup ids — which the
@@ -1486,7 +1513,7 @@ static __device__ __forceinline__ bool pt_pair_poll(const pt_u64* slot, pt_u64& 
 """
 
 
-def _reduce_epilogue(reduce_spec, unroll, finish=None):
+def _reduce_epilogue(reduce_spec, unroll, finish=None, per_thread=None):
     """``finish`` (per output: final dtype | None): ONE pass — every workgroup publishes its partial as a
     self-validating pair and takes a ticket (a relaxed device atomic); the last one to arrive polls all pairs, folds
     them in a fixed order (thread t takes partials t, t+BLOCK, ... in order, then the block combine: deterministic
@@ -1495,6 +1522,7 @@ def _reduce_epilogue(reduce_spec, unroll, finish=None):
     ``part{k}`` is then the pair array (2 x 8 bytes per workgroup)."""
     if not any(reduce_spec):
         return ""
+    FM = per_thread or FINISH_MAX_PER_THREAD
     lines = []
     for k, rs in enumerate(reduce_spec):
         if rs is None:
@@ -1525,17 +1553,17 @@ def _reduce_epilogue(reduce_spec, unroll, finish=None):
             lines.append("    {")
             # all of a thread's pairs are requested before the first is examined: one memory round trip for the
             # whole fold (polled one after the other the 8 pairs of a thread cost ~1 us each)
-            lines.append(f"      pt_u64 b[{FINISH_MAX_PER_THREAD}];")
-            lines.append(f"      bool got[{FINISH_MAX_PER_THREAD}];")
-            lines.append(f"#pragma unroll\n      for (int u = 0; u < {FINISH_MAX_PER_THREAD}; u++) {{ b[u] = 0; got[u] = threadIdx.x + u * {BLOCK} >= gridDim.x; }}")
+            lines.append(f"      pt_u64 b[{FM}];")
+            lines.append(f"      bool got[{FM}];")
+            lines.append(f"#pragma unroll\n      for (int u = 0; u < {FM}; u++) {{ b[u] = 0; got[u] = threadIdx.x + u * {BLOCK} >= gridDim.x; }}")
             lines.append("      for (long long spins = 0;; spins++) {")
             lines.append("        bool all = true;")
-            lines.append(f"#pragma unroll\n        for (int u = 0; u < {FINISH_MAX_PER_THREAD}; u++)")
+            lines.append(f"#pragma unroll\n        for (int u = 0; u < {FM}; u++)")
             lines.append(f"          if (!got[u]) {{ got[u] = pt_pair_poll((const pt_u64*)part{k} + 2 * (threadIdx.x + u * {BLOCK}), b[u]); all = all && got[u]; }}")
             lines.append("        if (all) break;")
             lines.append("        if (spins > (1ll << 22)) { atomicOr(pt_status, 16); break; }")
             lines.append("      }")
-            lines.append(f"#pragma unroll\n      for (int u = 0; u < {FINISH_MAX_PER_THREAD}; u++)")
+            lines.append(f"#pragma unroll\n      for (int u = 0; u < {FM}; u++)")
             lines.append(f"        if (threadIdx.x + u * {BLOCK} < gridDim.x) {{")
             lines.append(f"          {act} v; __builtin_memcpy(&v, &b[u], sizeof(v));")
             lines.append(f"          fa{k} = {op}::apply(fa{k}, v);")

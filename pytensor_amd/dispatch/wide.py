@@ -10,6 +10,7 @@ own handler.  ``ScatterScalars`` outside a ``Tail`` is its member ``IncSubtensor
 
 from __future__ import annotations
 
+import ctypes as C
 import struct
 
 from pytensor_amd import codegen, ffi, kernel_cache
@@ -25,6 +26,12 @@ import os
 
 TOTAL_GROUPS = int(os.environ.get("PTHIP_WIDE_GROUPS", 2048))  # workgroups of one launch, shared among the terms
 TERM_CAP = int(os.environ.get("PTHIP_WIDE_CAP", 64))
+# OPT-IN: every term finishes its own reductions (its last workgroup folds the term's <= 64 pairs; codegen.multi_flat_source
+# `finish`), the Tail behind it receives finished scalars instead of 144 partial arrays to fold in single waves.  Measured on
+# north_star's 48-term graph (profiles/r9_wide200_self_finish.md): the two tail launches (18 + 30 us) become one of 51 us —
+# the folds were never what a tail kernel's time is made of — and the many-term kernel goes from 140 to 145 us: 0.387 ms
+# against 0.385.  Kept for graphs whose terms have no Tail behind them; tests/test_gpu_wide_partials.py runs it.
+WIDE_FINISH = os.environ.get("PTHIP_WIDE_FINISH", "0") == "1"
 WIDE_UNROLL = int(os.environ.get("PTHIP_WIDE_UNROLL", 0))  # packs per loop iteration of a term (0: the Elemwise default)
 WIDE_PREFETCH_MIN = float(os.environ.get("PTHIP_WIDE_PREFETCH_MIN", "inf"))  # software-pipelined loop for terms costing at least this  # per term (the partials a Tail kernel folds in one pass)
 
@@ -146,27 +153,48 @@ def multi_elemwise(node, inputs, env):
         cap = max(1, (units + BLOCK - 1) // BLOCK)
         groups.append(max(1, min(cap, TERM_CAP, max(4, int(round(TOTAL_GROUPS * w / tot))))))
     gx = max(groups)
+    finish = WIDE_FINISH and gx <= BLOCK and all(
+        t["reduce"] and all(r is not None and r["acc_dtype"] == "float64" and r["dtype"] == "float64" for r in t["reduce"]) for t, *_ in per_term)
     specs, args, out_pos, results, o0 = [], [], 0, [], 0
     gen_terms = []
-    for (t, ins, modes, n, vec), gt in zip(per_term, groups):
+    blk, blk_words = None, 0
+    if finish:
+        lay = [codegen.multi_finish_layout(len(t["reduce"]), gt) for (t, *_), gt in zip(per_term, groups)]
+        # pairs are never cleared from here (dispatch/elemwise.py: the last workgroup zeroes what it consumed; stale bits
+        # validate with probability 2^-64)
+        blk = DeviceArray.empty((sum(w for _, w in lay),), "float64")
+        env.keepalive.append(blk)
+    for ti, ((t, ins, modes, n, vec), gt) in enumerate(zip(per_term, groups)):
         body, spec = t["scalar"], t["reduce"]
         rs = [(r["op"], r["acc_dtype"]) for r in spec]
         gen_terms.append({"body": body, "modes": modes, "vec": vec, "rs": rs, "unroll": WIDE_UNROLL or EW_UNROLL, "groups": gt,
                           "prefetch": vec > 1 and _term_cost(body, modes) >= WIDE_PREFETCH_MIN})
-        parts = alloc_partials(spec, gt)
         args.append(n)
         for k, (a, m) in enumerate(zip(ins, modes)):
             args.append(_scalar_bits(a, body["in_dtypes"][k]) if m == "C" else a.ptr)
-        args += [p.ptr for p in parts]
-        specs.append((spec, parts, gt))
+        if finish:
+            fin0, words = lay[ti]
+            args.append(blk.ptr + 8 * blk_words)
+            results += [blk.view((), (), blk_words + fin0 + k) for k in range(len(spec))]
+            blk_words += words
+        else:
+            parts = alloc_partials(spec, gt)
+            args += [p.ptr for p in parts]
+            specs.append((spec, parts, gt))
+    if finish:
+        first = C.c_void_p()
+        ffi.check(env.lib.pthip_ticket_slots(nt, C.byref(first)))
+        args += [first.value, env.lib.pthip_status_ptr()]
     buf = struct.pack(f"<{len(args)}q", *args)
     if len(buf) > MAX_ARG_BYTES:
         return _run_members(node, inputs, env)
-    key = codegen.source_key(repr([(_body_key(g["body"]), g["modes"], g["vec"], g["rs"], g["groups"], g["unroll"], g["prefetch"]) for g in gen_terms]))
-    name = f"multi_{key[:16]}_t{nt}"
-    src = codegen.multi_flat_source(name, gen_terms)
+    key = codegen.source_key(repr([(_body_key(g["body"]), g["modes"], g["vec"], g["rs"], g["groups"], g["unroll"], g["prefetch"]) for g in gen_terms]) + repr(finish))
+    name = f"multi_{key[:16]}_t{nt}" + ("_1p" if finish else "")
+    src = codegen.multi_flat_source(name, gen_terms, finish=finish)
     fn = kernel_cache.get_function(src, name)
     env.timed(name, lambda: ffi.check(env.lib.pthip_launch(fn, nt, gx, 1, BLOCK, 1, 1, 0, buf, len(buf))))
+    if finish:
+        return results
     for spec, parts, gt in specs:
         d = {k - o0 for k in defer if o0 <= k < o0 + len(spec)}
         results += finish_partials(env, spec, parts, gt, d)

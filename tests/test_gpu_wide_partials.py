@@ -54,3 +54,14 @@ def test_many_term_graph_with_more_than_64_partials_per_term(cap, groups):
     assert r["multi"] == 1 and r["tails"] >= 1, r
     assert r["replay_identical"], "a replayed plan must reproduce the eager bits"
     assert r["worst"] <= 1.0, f"|hip - oracle| / tol = {r['worst']}"
+
+
+def test_many_term_graph_finishing_its_own_reductions():
+    """PTHIP_WIDE_FINISH=1: each term's last workgroup folds the term's pairs (one-pass form, per-term tickets)"""
+    env = {**os.environ, "PTHIP_WIDE_FINISH": "1"}
+    p = subprocess.run([sys.executable, "-c", WORKER.format(root=ROOT)], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["multi"] == 1 and r["tails"] >= 1, r
+    assert r["replay_identical"], "a replayed plan must reproduce the eager bits"
+    assert r["worst"] <= 1.0, f"|hip - oracle| / tol = {r['worst']}"
