@@ -1037,6 +1037,8 @@ def careduce(node, inputs, env):
     out_shape = tuple(x.shape[d] for d in keep)
     if not axes:
         return [x if str(x.dtype) == outdt else _cast(env, x, outdt)]
+    if op == "MulWithoutZeros":
+        return [_prod_without_zeros(x, axes, acc, outdt, env)]
     if any(x.shape[d] == 0 for d in axes) and op not in ("Add", "Mul", "AND", "OR", "XOR"):
         raise ValueError(f"zero-size array to reduction operation {op.lower()} which has no identity")
     if _ND_REDUCE and x.size and not (outdt == "bool" and acc != "bool"):
@@ -1098,6 +1100,29 @@ def _merge3(arr, gA, gR, gB):
     if any(r is None for r in res):
         return None
     return res
+
+
+def _prod_without_zeros(x, axes, acc, outdt, env):
+    """``ProdWithoutZeros`` (tensor/math.py:3786-3825: CAReduce over ``MulWithoutZeros`` — y if x == 0, x if y == 0, else
+    x * y, identity 0 — what ``Prod.grad`` uses when its input may hold zeros): the product of the NON-ZERO entries
+    along the axes, and 0 where there is none (a row of zeros, an empty extent).  Three launches out of existing
+    parts: zeros -> 1 in the accumulator dtype, a ``Mul`` reduction, an ``OR`` reduction of (x != 0) as the mask."""
+    from pytensor_amd.ir import Node
+
+    xdt = str(x.dtype)
+    zero = ["c", 0 if np.dtype(xdt).kind in "iub" else float(0).hex(), xdt]
+    one = ["c", 1 if np.dtype(acc).kind in "iub" else float(1).hex(), acc]
+    sel = {"in_dtypes": [xdt], "out_dtypes": [acc, "bool"], "outs": [["t", 2], ["t", 3]],
+           "body": [{"op": "EQ", "in": [["i", 0], zero], "dtype": "bool"}, {"op": "Cast", "in": [["i", 0]], "dtype": acc},
+                    {"op": "Switch", "in": [["t", 0], one, ["t", 1]], "dtype": acc}, {"op": "Invert", "in": [["t", 0]], "dtype": "bool"}]}
+    (filled, nonzero), _, _ = launch_elemwise(sel, [x], tuple(x.shape), [acc, "bool"], None, env)
+    (prod,) = careduce(Node("CAReduce", {"scalar_op": "Mul", "axis": list(axes), "acc_dtype": acc, "dtype": acc}, [0], [1]), [filled], env)
+    (some,) = careduce(Node("CAReduce", {"scalar_op": "OR", "axis": list(axes), "acc_dtype": "bool", "dtype": "bool"}, [0], [1]), [nonzero], env)
+    zo = ["c", 0 if np.dtype(outdt).kind in "iub" else float(0).hex(), outdt]
+    fin = {"in_dtypes": [acc, "bool"], "out_dtypes": [outdt], "outs": [["t", 1]],
+           "body": [{"op": "Cast", "in": [["i", 0]], "dtype": outdt}, {"op": "Switch", "in": [["i", 1], ["t", 0], zo], "dtype": outdt}]}
+    (out,), _, _ = launch_elemwise(fin, [prod, some], tuple(prod.shape), [outdt], None, env)
+    return out
 
 
 def _cast(env, x, dtype):

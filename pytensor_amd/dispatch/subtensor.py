@@ -403,6 +403,16 @@ def _scatter_rows(env, p, out, y, iv):
     n_idx = iv.size
     if n_idx == 0 or inner == 0:
         return out
+    if not p["set_instead_of_inc"] and str(x.dtype) in ("int8", "int16", "uint8", "uint16"):
+        # the device adds 4- and 8-byte words: accumulate in 32 bits and narrow again — the same value modulo 2^8 / 2^16 as
+        # NumPy's wrap-around add (reference test tests/tensor/test_extra_ops.py TestBinCount[int8 … uint16]: bincount is
+        # an inc_subtensor of ones into zeros)
+        from pytensor_amd.dispatch.elemwise import _cast
+
+        wide = "uint32" if str(x.dtype).startswith("u") else "int32"
+        acc = _scatter_rows(env, p, _cast(env, out, wide), _cast(env, y, wide), iv)
+        copy_into(out, _cast(env, acc, x.dtype))
+        return out
     if str(y.dtype) != str(x.dtype):
         from pytensor_amd.dispatch.elemwise import _cast
 

@@ -15,7 +15,7 @@ def pytest_configure(config):
 def pytest_collection_modifyitems(config, items):
     """Parametrisations of the reference's own test modules that are not run under the hip linker
     (complex operands, pivoted QR): skipped with the reason, listed in the module itself."""
-    for name in ("test_gpu_refsuite_linalg", "test_gpu_refsuite_index"):
+    for name in ("test_gpu_refsuite_linalg", "test_gpu_refsuite_index", "test_gpu_refsuite_math"):
         mod = sys.modules.get(name) or sys.modules.get("tests." + name)
         if mod is not None:
             mod.pytest_collection_modifyitems_for_this_module(items)
