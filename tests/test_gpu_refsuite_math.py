@@ -39,6 +39,14 @@ MODULES = {
     "sbasic": "tests.scalar.test_basic",
     "sloop": "tests.scalar.test_loop",
     "reshape": "tests.tensor.test_reshape",
+    "einsum": "tests.tensor.test_einsum",
+    "sort": "tests.tensor.test_sort",
+    "pad": "tests.tensor.test_pad",
+    "interp": "tests.tensor.test_interpolate",
+    "functional": "tests.tensor.test_functional",
+    "fft": "tests.tensor.test_fft",
+    "merge": "tests.tensor.test_merge",
+    "typeother": "tests.tensor.test_type_other",
 }
 
 # test name (as exported) -> reason it is not run under the hip linker
