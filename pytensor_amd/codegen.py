@@ -217,6 +217,44 @@ PT_DEV double pt_log1p(double x) {
   y = x == __builtin_huge_val() ? x : y;
   return y;
 }
+// pow with the exact cases exact.  The device library's pow is within ~1.3 ulp but NOT exact where the result is
+// representable: pow(3, 1) = 2.9999999999999996, pow(19, 3) = 6858.999999999999 — and an integer power, which Pow.c_code
+// (scalar/basic.py:2250) computes as (T)pow((double)x, (double)y), then truncates to 6858.  libm's pow (the reference's) is
+// correctly rounded in these cases.  So: an integer exponent |y| <= 64 of an integer-valued base is repeated squaring, taken
+// when every product in it was exact (zero fma residual: always so while the result is below 2^53, and beyond for bases
+// with factors of two) — and 1 / that for y < 0 (one correctly rounded division); y = +-1, +-2, +-3 of any base are products (<= 1.5 ulp); everything else is the library's value.
+PT_DEV double pt_pow(double x, double y) {
+  double r = pow(x, y);
+  const double ay = __builtin_fabs(y);
+  if (y == __builtin_rint(y) && ay >= 1.0 && ay <= 64.0) {
+    const int n = (int)ay;
+    if (x == __builtin_rint(x) && x != 0.0 && __builtin_fabs(x) < 0x1p53) {
+      double b = __builtin_fabs(x), p = 1.0;
+      bool exact = true;  // every product that went into p had a zero rounding error (fma residual)
+#pragma unroll
+      for (int k = 0; k < 7; k++) {
+        if ((n >> k) & 1) {
+          const double q = p * b;
+          exact = exact && __builtin_fma(p, b, -q) == 0.0;
+          p = q;
+        }
+        if ((n >> (k + 1)) != 0) {
+          const double q = b * b;
+          exact = exact && __builtin_fma(b, b, -q) == 0.0;
+          b = q;
+        }
+      }
+      if (exact && p < __builtin_huge_val()) {
+        p = (x < 0.0 && (n & 1)) ? -p : p;
+        r = y < 0.0 ? 1.0 / p : p;
+      }
+    } else if (n <= 3) {
+      const double p = n == 1 ? x : n == 2 ? x * x : x * x * x;
+      r = y < 0.0 ? 1.0 / p : p;
+    }
+  }
+  return r;
+}
 // fp64 log by the same reduction (x = 2^k (1 + f), no rounding term): ~45 VALU instructions against the device library's ~90;
 // 0.86 ulp max against long-double logl on 4e7 host-emulated points (normal and subnormal arguments, the neighbourhoods of 1,
 // sqrt(2) and sqrt(1/2)).  Log.c_code of the reference is libm's log (scalar/basic.py:2896).  x < 0 -> NaN, +-0 -> -inf,
@@ -853,11 +891,9 @@ def _mod(args, in_dts, out_dt):
 
 def _pow(args, in_dts, out_dt):
     # Pow.c_code (scalar/basic.py:2250+): pow(x, y); integer outputs are cast back
-    if _is_float(out_dt):
-        ct = CTYPE[out_dt]
-        fn = "pow" if out_dt == "float64" else "powf"
-        return f"{fn}(({ct}){args[0]}, ({ct}){args[1]})"
-    return f"({CTYPE[out_dt]})pow((double){args[0]}, (double){args[1]})"
+    # (pt_pow: the library's pow with the exactly representable cases made exact — an integer power must not truncate
+    #  6858.999999999999; float32 through the double: the rounded double is libm's powf value)
+    return f"({CTYPE[out_dt]})pt_pow((double){args[0]}, (double){args[1]})"
 
 
 def _abs(args, in_dts, out_dt):

@@ -101,3 +101,35 @@ def test_softplus_and_the_shared_pair(pte):
     assert float((np.abs(sg.astype(np.longdouble) - want_sg).astype(np.float64)[fin] / np.maximum(np.abs(np.nextafter(want_sg.astype(np.float64), np.inf) - want_sg.astype(np.float64)), 2.0**-1074)[fin]).max()) <= 4.0
     nan = f2(np.array([np.nan]))
     assert np.isnan(nan[0][0]) and np.isnan(nan[1][0])
+
+
+def test_pow_is_exact_where_the_result_is_representable(pte):
+    """the device library's pow is ~1.3 ulp everywhere, exact nowhere in particular: pow(3, 1) = 2.9999999999999996 and an
+    integer power, computed like Pow.c_code as (T)pow((double)x, (double)y), truncated 19**3 to 6858.  codegen's pt_pow."""
+    import pytensor.tensor as pt
+
+    x, y = pt.dvector("x"), pt.dvector("y")
+    f = pte.function([x, y], pt.pow(x, y), mode="hip")
+    xs, ys = (a.ravel() for a in np.meshgrid(np.arange(-20, 21, dtype=np.float64), np.arange(0, 16, dtype=np.float64)))
+    want = np.array([float(int(a) ** int(b)) for a, b in zip(xs, ys)])
+    got = f(xs, ys)
+    small = np.abs(want) < 2.0**53
+    np.testing.assert_array_equal(got[small], want[small])
+    assert float(np.max(np.abs(got - want) / np.maximum(np.abs(np.nextafter(want, np.inf) - want), 5e-324))) <= 2.0
+    neg = f(np.array([2.0, 4.0, -2.0, 10.0, 3.0]), np.array([-3.0, -1.0, -3.0, -2.0, -1.0]))
+    np.testing.assert_array_equal(neg, np.array([0.125, 0.25, -0.125, 1.0 / 100.0, 1.0 / 3.0]))
+    xi, yi = pt.lvector("xi"), pt.lvector("yi")
+    gi = pte.function([xi, yi], pt.pow(xi, yi), mode="hip")(xs.astype(np.int64), ys.astype(np.int64))
+    wi = [int(a) ** int(b) for a, b in zip(xs, ys)]
+    assert all(int(g) == w for g, w in zip(gi, wi) if abs(w) < 2**53)
+    a32, b32 = pt.fvector("a"), pt.fvector("b")
+    g32 = pte.function([a32, b32], pt.pow(a32, b32), mode="hip")(xs.astype(np.float32), ys.astype(np.float32))
+    np.testing.assert_array_equal(g32, want.astype(np.float32))
+    rng = np.random.default_rng(0)
+    xr, yr = rng.uniform(0.1, 10, 100_000), rng.uniform(-5, 5, 100_000)
+    assert float(_ulps(f(xr, yr), np.power(xr.astype(np.longdouble), yr.astype(np.longdouble))).max()) <= 2.0
+    np.testing.assert_array_equal(f(xr, np.ones_like(xr)), xr)
+    np.testing.assert_array_equal(f(xr, np.full_like(xr, 2.0)), xr * xr)
+    sp = f(np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 5.0, np.nan]), np.array([0.0, -1.0, 0.0, 2.0, 3.0, np.nan, 1.0]))
+    with np.errstate(all="ignore"):
+        np.testing.assert_array_equal(sp, np.power(np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 5.0, np.nan]), np.array([0.0, -1.0, 0.0, 2.0, 3.0, np.nan, 1.0])))

@@ -4,7 +4,11 @@
 against NumPy, broadcast errors at build and at run time, ``verify_grad``; ``CAReduce`` front ends — max / argmax / min /
 sum / prod / mean / var / all / any over every axis set; ``dot`` / ``tensordot`` / ``matmul``; ``logsumexp``),
 ``tests/tensor/test_math_scipy.py`` (erf … gammaln, psi, the incomplete gamma / beta family and their gradients),
-``tests/scalar/test_math.py``, ``tests/tensor/test_keepdims.py`` and ``tests/tensor/test_xlogx.py`` of the reference
+``tests/scalar/test_math.py``, ``test_basic.py``, ``test_loop.py``, ``tests/tensor/test_keepdims.py``, ``test_xlogx.py``,
+``test_casting.py``, ``test_extra_ops.py``, ``test_reshape.py``, ``test_einsum.py``, ``test_sort.py``, ``test_pad.py``,
+``test_interpolate.py``, ``test_functional.py``, ``test_fft.py``, ``test_merge.py``, ``test_type.py``, ``test_type_other.py``,
+``test_sharedvar.py``, ``tests/compile/test_{maker,ops,rebuild,nn_workflow,shared,builders}.py``, ``tests/test_gradient.py``,
+``test_ifelse.py``, ``test_raise_op.py`` and ``test_rop.py`` of the reference
 (``oracle/_ref/tests``, a built artefact; the test code is the reference's, never committed) compile with the DEFAULT mode,
 so each module is imported — and every test run — with ``config.mode`` set to the registered ``hip`` mode (the mechanism of
 ``tests/test_gpu_refsuite_linalg.py``).  What is NOT run is listed below with the reason.
@@ -47,10 +51,24 @@ MODULES = {
     "fft": "tests.tensor.test_fft",
     "merge": "tests.tensor.test_merge",
     "typeother": "tests.tensor.test_type_other",
+    "maker": "tests.compile.test_maker",
+    "cops": "tests.compile.test_ops",
+    "rebuild": "tests.compile.test_rebuild",
+    "nn": "tests.compile.test_nn_workflow",
+    "raiseop": "tests.test_raise_op",
+    "rop": "tests.test_rop",
+    "shared": "tests.compile.test_shared",
+    "builders": "tests.compile.test_builders",
+    "grad": "tests.test_gradient",
+    "ifelse": "tests.test_ifelse",
+    "ttype": "tests.tensor.test_type",
+    "sharedvar": "tests.tensor.test_sharedvar",
 }
 
 # test name (as exported) -> reason it is not run under the hip linker
 NOT_RUN = {}
+_INPLACE = "asserts an `if{inplace}` node in the rewritten graph (`inplace` rewrites are incompatible with this linker); the value tests of the class run"
+_ALIAS = "asserts that a borrowed output aliases the host copy of another (memory-sharing contract of a host linker; results here are fresh host arrays)"
 _COMPLEX = "loops over every dtype inside ONE test, complex64 / complex128 among them (DESIGN §7: complex dtypes are a compile-time NotImplementedError)"
 _SCIPY = "a SciPy-only scalar op with no c_code in the reference either (Jv / Iv / Ive / Kve / Hyp2F1: compile-time NotImplementedError, DESIGN §7)"
 # substrings of a test id -> reason
@@ -66,6 +84,12 @@ NOT_RUN_IDS = {
     "ProdWithoutZerosDtype::test_prod_without_zeros_custom_acc_dtype": _COMPLEX,
     "sloop__elemwise_inplace": "asserts destroy_map of the rewritten graph (`inplace` rewrites are incompatible with this linker)",
     "SearchsortedOp::test_searchsortedOp_on_right_side": "asks for the binary search's answer on an UNSORTED array (implementation-defined: NumPy carries its bounds from one key to the next); the sorted-input and sorter cases of the class run",
+    "Ifelse::test_lazy_if": _INPLACE, "Ifelse::test_multiple_out": _INPLACE, "Ifelse::test_mixed_dtype": _INPLACE, "Ifelse::test_grad_lazy_if": _INPLACE,
+    "Ifelse::test_lazy_if_on_generics": "operands of the Generic type (Python objects: nothing to put on a device)",
+    "AliasingRules::test_no_aliasing_2": _ALIAS, "AliasingRules::test_sparse_input_aliasing": "sparse operands (DESIGN §7)",
+    "OpDecorator": "`as_op` wraps a Python function: no device code, and this linker runs nothing on the host unless PTHIP_ALLOW_HOST_PERFORM=1",
+    "PushforwardPullback::test_print": "the Print Op: host perform only (same switch)",
+    "CheckAndRaise_sparse_variable": "sparse operands (DESIGN §7)",
     "mathsp__verify_jv_grad": _SCIPY, "mathsp__verify_iv_grad": _SCIPY, "mathsp__verify_ive_grad": _SCIPY, "mathsp__kve": _SCIPY,
     "mathsp__kv": _SCIPY, "mathsp__kn": _SCIPY, "Hyp2F1Grad": _SCIPY,
 }
