@@ -271,7 +271,20 @@ def solve_tridiagonal(env, A: DeviceArray, b: DeviceArray, b_ndim: int) -> Devic
     of ``A``; everything else in ``A`` is ignored, as scipy ignores it)"""
     n = A.shape[-1]
     if A.ndim != 2 or b.ndim != b_ndim:
-        raise NotImplementedError("hip linker: batched tridiagonal Solve (Blockwise loops the items)")
+        # batched (Blockwise; reference tests/tensor/rewriting/linalg/test_solvers.py): the (small) batch on the host, like
+        # dispatch/lu.solve_general — each item is a factorisation and a solve launch
+        from pytensor_amd.device import contiguous_strides, copy_into
+        from pytensor_amd.dispatch.lu import _batchify
+
+        bshape = tuple(np.broadcast_shapes(A.shape[:-2], b.shape[: b.ndim - b_ndim]))
+        core_b = b.shape[b.ndim - b_ndim:]
+        Ab, bbm = _batchify(A, 2, bshape), _batchify(b, b_ndim, bshape)
+        out = DeviceArray.empty((*bshape, *core_b), b.dtype)
+        step = int(np.prod(core_b)) if core_b else 1
+        for k in range(Ab.shape[0]):
+            xk = solve_tridiagonal(env, Ab.view((n, n), (n, 1), k * n * n), bbm.view(core_b, contiguous_strides(core_b), k * step), b_ndim)
+            copy_into(out.view(core_b, contiguous_strides(core_b), k * step), xk)
+        return out
     diag = lambda off: A.view((max(n - abs(off), 0),), (A.strides[0] + A.strides[1],), (-off) * A.strides[0] if off < 0 else off * A.strides[1])
     f = gttrf_device(env, diag(-1), diag(0), diag(1))
     return gttrs_device(env, *f, b, False)

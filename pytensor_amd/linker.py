@@ -29,6 +29,15 @@ from pytensor.graph.rewriting.db import RewriteDatabaseQuery
 from pytensor.link.basic import JITLinker
 
 
+# The trace-reducing Scan rewrite (scan/rewriting/trace.py:888 `scan_reduce_trace_prealloc`, the C backend's variant: a state
+# nobody reads back keeps taps + 1 rows instead of n_steps + taps).  Rounds 2-5 excluded it (as the Numba linker does) without
+# taking the JIT backends' `no_prealloc` variant in its place, so NO trace was ever shortened: a 1000-step recurrence read
+# at [-1] kept 1002 rows (reference tests/scan/rewriting/test_trace.py).  The no-prealloc form (taps rows) lets a step's
+# output land on the row of its oldest tap — the step kernels here read and write rows in separate launches, and three
+# reference tests fail with it — so it is the prealloc form that is on.  PTHIP_SCAN_SAVE_MEM=0: as before.
+_SCAN_SAVE_MEM = __import__("os").environ.get("PTHIP_SCAN_SAVE_MEM", "1") != "0"
+
+
 class HipLinker(JITLinker):
     """A `Linker` that runs a ``FunctionGraph`` on MI355X through hand-written HIP kernels."""
 
@@ -39,7 +48,7 @@ class HipLinker(JITLinker):
     incompatible_rewrites = (
         "cxx_only",
         "inplace",
-        "scan_reduce_trace_prealloc",
+        *(() if _SCAN_SAVE_MEM else ("scan_reduce_trace_prealloc",)),
         # Softmax / LogSoftmax stay whole and run as one kernel (csrc/softmax.hip), like the
         # JAX / PyTorch / MLX linkers that dispatch their own softmax (rewriting/ofg.py:46-62).
         # XLogY, XLog1PY, LogSumExp, LogAddExp are still inlined at specialize (ofg.py:16-17).

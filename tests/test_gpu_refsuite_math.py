@@ -63,12 +63,42 @@ MODULES = {
     "ifelse": "tests.test_ifelse",
     "ttype": "tests.tensor.test_type",
     "sharedvar": "tests.tensor.test_sharedvar",
+    "scanviews": "tests.scan.test_views",
+    "scanckpt": "tests.scan.test_checkpoints",
+    "scanutils": "tests.scan.test_utils",
+    "conv": "tests.tensor.signal.test_conv",
+    "rwspecial": "tests.tensor.rewriting.test_special",
+    "rwblockwise": "tests.tensor.rewriting.test_blockwise",
+    "rweinsum": "tests.tensor.rewriting.test_einsum",
+    "rwmath": "tests.tensor.rewriting.test_math",
+    "rwbasic": "tests.tensor.rewriting.test_basic",
+    "rwshape": "tests.tensor.rewriting.test_shape",
+    "rwsubtensor": "tests.tensor.rewriting.test_subtensor",
+    "rwlift": "tests.tensor.rewriting.test_subtensor_lift",
+    "rwextra": "tests.tensor.rewriting.test_extra_ops",
+    "rwreshape": "tests.tensor.rewriting.test_reshape",
+    "rwuncanon": "tests.tensor.rewriting.test_uncanonicalize",
+    "rwofg": "tests.tensor.rewriting.test_ofg",
+    "rwblas": "tests.tensor.rewriting.test_blas",
+    "rwelemwise": "tests.tensor.rewriting.test_elemwise",
+    "rwla_dec": "tests.tensor.rewriting.linalg.test_decomposition",
+    "rwla_inv": "tests.tensor.rewriting.linalg.test_inverse",
+    "rwla_prod": "tests.tensor.rewriting.linalg.test_products",
+    "rwla_solve": "tests.tensor.rewriting.linalg.test_solvers",
+    "rwla_sum": "tests.tensor.rewriting.linalg.test_summary",
+    "scanrw_io": "tests.scan.rewriting.test_io",
+    "scanrw_merge": "tests.scan.rewriting.test_merge",
+    "scanrw_push": "tests.scan.rewriting.test_push_out",
+    "scanrw_trace": "tests.scan.rewriting.test_trace",
+    "scanrw_inplace": "tests.scan.rewriting.test_inplace",
 }
 
 # test name (as exported) -> reason it is not run under the hip linker
 NOT_RUN = {}
 _INPLACE = "asserts an `if{inplace}` node in the rewritten graph (`inplace` rewrites are incompatible with this linker); the value tests of the class run"
 _ALIAS = "asserts that a borrowed output aliases the host copy of another (memory-sharing contract of a host linker; results here are fresh host arrays)"
+_SYMBOLIC = "asserts what `inline_symbolic_for_fusion` leaves in the graph; this linker keeps Softmax / LogSoftmax whole (one kernel each), like the JAX / PyTorch linkers"
+_TRACE = "asserts the buffer length the JIT backends' trace rewrite leaves (`taps` rows); this linker takes the C backend's variant (`taps + 1`: linker.py) — the values the test computes first are checked by the other tests of the class"
 _COMPLEX = "loops over every dtype inside ONE test, complex64 / complex128 among them (DESIGN §7: complex dtypes are a compile-time NotImplementedError)"
 _SCIPY = "a SciPy-only scalar op with no c_code in the reference either (Jv / Iv / Ive / Kve / Hyp2F1: compile-time NotImplementedError, DESIGN §7)"
 # substrings of a test id -> reason
@@ -90,6 +120,15 @@ NOT_RUN_IDS = {
     "OpDecorator": "`as_op` wraps a Python function: no device code, and this linker runs nothing on the host unless PTHIP_ALLOW_HOST_PERFORM=1",
     "PushforwardPullback::test_print": "the Print Op: host perform only (same switch)",
     "CheckAndRaise_sparse_variable": "sparse operands (DESIGN §7)",
+    "FuncInverse::test": _COMPLEX, "CastCast::test_upcast": _COMPLEX, "rwmath__local_useless_conj": "complex operands (DESIGN §7)",
+    "rwmath__log_kv_stabilization": _SCIPY, "rwmath__log_iv_stabilization": _SCIPY,
+    "ShapeRewriter::test_local_track_shape_i": "a test-only Op (IdentityNoShape) with no device lowering",
+    "rwelemwise__Fusion::test_fuse_across_symbolic_op": _SYMBOLIC, "rwelemwise__Fusion::test_merge_inlined_symbolic_ops": _SYMBOLIC,
+    "rwelemwise__Fusion::test_add_mul_fusion_inplace": "asserts the inplace_pattern of the rewritten graph (`inplace` rewrites are incompatible with this linker)",
+    "CompositeCodegen::test_nested_composite": "a test-only scalar Op (TimesN) with no device code",
+    "ReduceTrace::test_store_steps": _TRACE, "ReduceTrace::test_while_scan_taps": _TRACE, "ReduceTrace::test_while_scan_map": _TRACE,
+    "ReduceTrace::test_broadcasted_init": _TRACE,
+    "ScanInplaceOptimizer": "asserts destroy_map of the rewritten Scan (`inplace` rewrites are incompatible with this linker)",
     "mathsp__verify_jv_grad": _SCIPY, "mathsp__verify_iv_grad": _SCIPY, "mathsp__verify_ive_grad": _SCIPY, "mathsp__kve": _SCIPY,
     "mathsp__kv": _SCIPY, "mathsp__kn": _SCIPY, "Hyp2F1Grad": _SCIPY,
 }
