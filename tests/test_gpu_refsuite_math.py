@@ -5,10 +5,13 @@ against NumPy, broadcast errors at build and at run time, ``verify_grad``; ``CAR
 sum / prod / mean / var / all / any over every axis set; ``dot`` / ``tensordot`` / ``matmul``; ``logsumexp``),
 ``tests/tensor/test_math_scipy.py`` (erf … gammaln, psi, the incomplete gamma / beta family and their gradients),
 ``tests/scalar/test_math.py``, ``test_basic.py``, ``test_loop.py``, ``tests/tensor/test_keepdims.py``, ``test_xlogx.py``,
-``test_casting.py``, ``test_extra_ops.py``, ``test_reshape.py``, ``test_einsum.py``, ``test_sort.py``, ``test_pad.py``,
+``test_casting.py``, ``test_extra_ops.py``, ``test_reshape.py``, ``test_einsum.py``, ``test_sort.py``,
 ``test_interpolate.py``, ``test_functional.py``, ``test_fft.py``, ``test_merge.py``, ``test_type.py``, ``test_type_other.py``,
 ``test_sharedvar.py``, ``tests/compile/test_{maker,ops,rebuild,nn_workflow,shared,builders}.py``, ``tests/test_gradient.py``,
-``test_ifelse.py``, ``test_raise_op.py`` and ``test_rop.py`` of the reference
+``test_ifelse.py``, ``test_raise_op.py``, ``test_rop.py``, the rewrite tests ``tests/tensor/rewriting/test_{math,basic,shape,
+subtensor,subtensor_lift,extra_ops,reshape,uncanonicalize,ofg,blas,elemwise,special,blockwise,einsum}.py`` and
+``rewriting/linalg/*`` (they evaluate what they rewrote), and ``tests/scan/{test_views,test_checkpoints,test_utils}.py`` +
+``tests/scan/rewriting/*`` of the reference
 (``oracle/_ref/tests``, a built artefact; the test code is the reference's, never committed) compile with the DEFAULT mode,
 so each module is imported — and every test run — with ``config.mode`` set to the registered ``hip`` mode (the mechanism of
 ``tests/test_gpu_refsuite_linalg.py``).  What is NOT run is listed below with the reason.
@@ -45,7 +48,6 @@ MODULES = {
     "reshape": "tests.tensor.test_reshape",
     "einsum": "tests.tensor.test_einsum",
     "sort": "tests.tensor.test_sort",
-    "pad": "tests.tensor.test_pad",
     "interp": "tests.tensor.test_interpolate",
     "functional": "tests.tensor.test_functional",
     "fft": "tests.tensor.test_fft",
@@ -66,7 +68,6 @@ MODULES = {
     "scanviews": "tests.scan.test_views",
     "scanckpt": "tests.scan.test_checkpoints",
     "scanutils": "tests.scan.test_utils",
-    "conv": "tests.tensor.signal.test_conv",
     "rwspecial": "tests.tensor.rewriting.test_special",
     "rwblockwise": "tests.tensor.rewriting.test_blockwise",
     "rweinsum": "tests.tensor.rewriting.test_einsum",
