@@ -680,6 +680,39 @@ def test_scan_function_pickle_roundtrip(pt):
             np.testing.assert_array_equal(np.asarray(a), b)
 
 
+def test_scan_trace_read_at_the_end_is_shortened(pt):
+    """a recurrence whose trajectory is read at [-1] only keeps taps + 1 rows, not n_steps + taps (the C backend's
+    `scan_reduce_trace_prealloc`, scan/rewriting/trace.py:888; pytensor_amd/linker.py says why not the JIT variant) — and the
+    value, the short-run value and the gradient are those of the full-trace evaluation.  Modelled on the reference's
+    tests/scan/rewriting/test_trace.py::TestReduceTrace, which asserts the JIT backends' `taps` and is not run."""
+    pytensor, ptt = pt
+    from pytensor.scan.basic import scan
+    from pytensor.scan.op import Scan
+
+    n, x0, a = ptt.lscalar("n"), ptt.dvector("x0"), ptt.dscalar("a")
+    ys = scan(lambda xm2, xm1, a_: a_ * xm1 + 0.5 * xm2, outputs_info=[{"initial": x0, "taps": [-2, -1]}], non_sequences=[a], n_steps=n, return_updates=False)
+    f1 = pytensor.function([n, x0, a], ys[-1], mode="hip")
+    [node] = [nd for nd in f1.maker.fgraph.apply_nodes if isinstance(nd.op, Scan)]
+    [buf] = [v for v in node.inputs[1:] if v.type.ndim == 1 and v.type.dtype == "float64"]
+    rows = pytensor.function([n, x0, a], buf.shape[0], mode="hip", on_unused_input="ignore")
+    assert int(rows(1000, [1.0, 1.0], 0.9)) == 3  # 2 taps + 1, not 1002
+    # (with the gradient in the same function the backward Scan reads the whole forward trajectory: that one stays long)
+    f = pytensor.function([n, x0, a], [ys[-1], pytensor.grad(ys[-1], a)], mode="hip")
+
+    def ref(nsteps, av):
+        p2, p1, d2, d1 = 1.0, 1.0, 0.0, 0.0
+        for _ in range(nsteps):
+            p2, p1, d2, d1 = p1, av * p1 + 0.5 * p2, d1, p1 + av * d1 + 0.5 * d2
+        return p1, d1
+
+    for nsteps in (1000, 1, 7):
+        got = f(nsteps, [1.0, 1.0], 0.9)
+        want = ref(nsteps, 0.9)
+        np.testing.assert_allclose(np.asarray(f1(nsteps, [1.0, 1.0], 0.9)), want[0], rtol=1e-12)
+        np.testing.assert_allclose(np.asarray(got[0]), want[0], rtol=1e-12)
+        np.testing.assert_allclose(np.asarray(got[1]), want[1], rtol=1e-10)
+
+
 def test_outputs_are_fresh_and_do_not_alias_inputs(pt):
     """link/vm.py:860-880 no_recycling semantics + aliasing.py:165-260 (DeepCopyOp)."""
     pytensor, ptt = pt

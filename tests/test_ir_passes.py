@@ -263,6 +263,24 @@ def test_multi_flat_source_shares_bodies_and_compiles():
     assert len(ffi.jit_compile(src, "multi_probe.hip")) > 1000
 
 
+def test_multi_flat_source_self_finishing_form_compiles():
+    """`finish=True`: one block pointer per term (pair arrays + finished values at the offsets of multi_finish_layout), one
+    shared ticket base and status word; the argument list shrinks (48 terms stay under the 4 KB kernel-argument block)."""
+    from pytensor_amd import codegen, ffi
+
+    dt = "float64"
+    b1 = {"in_dtypes": [dt, dt], "out_dtypes": [dt, dt], "outs": [["t", 1], ["t", 0]],
+          "body": [{"op": "Sub", "in": [["i", 1], ["i", 0]], "dtype": dt}, {"op": "Sqr", "in": [["t", 0]], "dtype": dt}]}
+    mk = lambda g: {"body": b1, "modes": "SV", "vec": 2, "rs": [("Add", dt), ("Add", dt)], "unroll": 2, "groups": g}
+    plain = codegen.multi_flat_source("multi_probe_p", [mk(7), mk(64)])
+    src = codegen.multi_flat_source("multi_probe_f", [mk(7), mk(64)], finish=True)
+    assert "t0_blk" in src and "t1_blk" in src and "pt_tickets + 1" in src and "t0_part0" not in src
+    assert src.count("__restrict__ t") < plain.count("__restrict__ t")  # fewer kernel arguments than with partial arrays
+    assert codegen.multi_finish_layout(2, 7) == (28, 30) and codegen.multi_finish_layout(3, 64) == (384, 388)
+    assert f"(t0_blk + {28})" in src and f"(t1_blk + {2 * 64})" in src  # term 0's first finished value; term 1's second pair array
+    assert len(ffi.jit_compile(src, "multi_probe_f.hip")) > 1000
+
+
 def test_branch_guards_of_lazy_ifelse():
     """executor.branch_guards: nodes that reach the outputs only through one branch of an IfElse are
     guarded by it (innermost conditional when they nest); anything shared with an unconditional
