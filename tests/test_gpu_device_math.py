@@ -3,7 +3,6 @@
 signs, the k = 0 / k = 1 switch points, and the special values; softplus and the shared sigmoid / softplus pair that call it.
 The reference's Log1p / Softplus c_code is libm (scalar/basic.py:3042, scalar/math.py:1224): < 1 ulp — the bar here is 2.5 ulp
 for log1p (2.1 measured on the host emulation, tools note in the prelude) and 4 ulp for softplus (exp's ulp on top)."""
-import sys
 
 import numpy as np
 import pytest
