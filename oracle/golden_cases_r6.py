@@ -70,3 +70,36 @@ def c4_gemm_multiresponse():
     vals = configs.wide200_gemm_inputs(N=1031, K=37, G=11, R=5, T=0, seed=3)
     ins, outs = build_wide200_gemm(vals, T=0)
     return ins, outs, vals
+
+
+@case("r6_refsuite_fixes", rtol=1e-13)
+def r6_refsuite_fixes():
+    """What the reference's own test modules found at the end of round 6 (tests/test_gpu_refsuite_math.py), pinned as vectors:
+    integer powers (the device library's pow(19, 3) = 6858.999... truncated to 6858), the gradient of ``prod`` with zeros in
+    the input (``ProdWithoutZeros``, tensor/math.py:3786-3825), ``argmax`` of float16, ``bincount`` of 1- and 2-byte
+    integers (an inc_subtensor of ones), a batched tridiagonal solve."""
+    import pytensor
+    from pytensor.tensor.slinalg import solve
+
+    rng = np.random.default_rng(611)
+    x = pt.dmatrix("x")
+    xi, yi = pt.lvector("xi"), pt.lvector("yi")
+    xf, yf = pt.dvector("xf"), pt.dvector("yf")
+    h = pt.matrix("h", dtype="float16")
+    b8, b16 = pt.vector("b8", dtype="int8"), pt.vector("b16", dtype="uint16")
+    A, B = pt.dtensor3("A"), pt.dtensor3("B")
+    xv = rng.normal(size=(5, 6))
+    xv[0, 2] = 0.0
+    xv[1, [1, 4]] = 0.0
+    xv[3, :] = 0.0
+    gi, gj = np.meshgrid(np.arange(-12, 13), np.arange(0, 9))
+    xfv = np.array([3.0, 19.0, 11.0, 13.0, 8.0, 2.0, 10.0, 1.5, 0.3, 7.0, -3.0, 2.0])
+    yfv = np.array([1.0, 3.0, 5.0, 6.0, 7.0, -3.0, -2.0, 2.0, 3.0, 0.5, 3.0, 0.0])
+    Av = rng.normal(size=(3, 7, 7)) + 4.0 * np.eye(7)
+    outs = [pt.prod(x, axis=1), pytensor.grad(pt.prod(x, axis=1).sum(), x), pytensor.grad(pt.prod(x), x), pt.pow(xi, yi), pt.pow(xf, yf),
+            pt.cast(pt.pow(xf, yf), "int64"), pt.argmax(h, axis=1), pt.argmax(h, axis=None), pt.bincount(b8), pt.bincount(b16, minlength=20),
+            solve(A, B, assume_a="tridiagonal")]
+    vals = {"x": xv, "xi": gi.ravel().astype(np.int64), "yi": gj.ravel().astype(np.int64), "xf": xfv, "yf": yfv,
+            "h": rng.normal(size=(9, 33)).astype(np.float16), "b8": rng.integers(0, 12, 300).astype(np.int8),
+            "b16": rng.integers(0, 15, 500).astype(np.uint16), "A": Av, "B": rng.normal(size=(3, 7, 4))}
+    return [x, xi, yi, xf, yf, h, b8, b16, A, B], outs, vals

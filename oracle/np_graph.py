@@ -343,9 +343,15 @@ def _careduce(p, inputs, node, graph):
     # pytensor/tensor/elemwise.py:1493-1511 (CAReduce.perform): ufunc.reduce
     # over the axes with ``dtype=acc_dtype`` and a final cast to ``dtype``.
     (x,) = inputs
-    uf = _REDUCE[p["scalar_op"]]
     axis = tuple(p["axis"])
     acc = np.dtype(p["acc_dtype"])
+    if p["scalar_op"] == "MulWithoutZeros":
+        # pytensor/tensor/math.py:3786-3825 (ProdWithoutZeros: y if x == 0, x if y == 0, else x * y; identity 0): the product
+        # of the non-zero entries, 0 where there is none
+        xa = np.asarray(x).astype(acc)
+        r = np.where((xa != 0).any(axis=axis), np.multiply.reduce(np.where(xa == 0, acc.type(1), xa), axis=axis, dtype=acc), acc.type(0))
+        return [np.asarray(r).astype(p["dtype"], copy=False)]
+    uf = _REDUCE[p["scalar_op"]]
     if x.dtype.kind == "b" and p["scalar_op"] in ("AND", "OR", "XOR"):
         r = uf.reduce(x, axis=axis)
     else:
