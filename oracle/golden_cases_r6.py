@@ -103,3 +103,23 @@ def r6_refsuite_fixes():
             "h": rng.normal(size=(9, 33)).astype(np.float16), "b8": rng.integers(0, 12, 300).astype(np.int8),
             "b16": rng.integers(0, 15, 500).astype(np.uint16), "A": Av, "B": rng.normal(size=(3, 7, 4))}
     return [x, xi, yi, xf, yf, h, b8, b16, A, B], outs, vals
+
+
+@case("r6_device_math", rtol=1.2e-15)
+def r6_device_math():
+    """The generated kernels' own fp64 log / log1p (codegen.PRELUDE pt_log / pt_log1p, round 6) and what calls them (softplus,
+    the shared sigmoid / softplus pair, log1mexp) against the reference's libm values, at a tolerance of ~5 ulp: arguments of
+    every magnitude and both signs, the neighbourhoods of the reduction's switch points, subnormals."""
+    rng = np.random.default_rng(612)
+    n = 1500
+    r = rng.random
+    pos = np.concatenate([r(n) * 4.0, np.exp((r(n) - 0.5) * 1400.0), 1.0 + (r(n) - 0.5) * 0.6, np.ldexp(r(n) + 0.5, rng.integers(-1074, 1023, n)),
+                          1.41421356 + (r(n) - 0.5) * 1e-6, 0.70710678 + (r(n) - 0.5) * 1e-6])
+    pos = pos[(pos > 0) & np.isfinite(pos)]
+    l1 = np.concatenate([r(n), -r(n) * 0.999999, np.exp((r(n) - 0.5) * 80.0), -np.exp(-r(n) * 40.0), (r(n) - 0.5) * 1.2,
+                         0.41421356 + (r(n) - 0.5) * 1e-6, -0.29289321 + (r(n) - 0.5) * 1e-6, np.exp(-r(n) * 700.0)])
+    sp = np.concatenate([rng.standard_normal(n) * 8.0, rng.uniform(-700.0, 700.0, n), rng.standard_normal(n) * 1e-3])
+    neg = -np.exp((r(n) - 0.5) * 20.0)
+    p, q, s, m = pt.dvector("p"), pt.dvector("q"), pt.dvector("s"), pt.dvector("m")
+    outs = [pt.log(p), pt.log1p(q), pt.softplus(s), pt.sigmoid(s) * 1.0, pt.sigmoid(s) + pt.softplus(s), pt.log1mexp(m), pt.log(p) * pt.log1p(p)]
+    return [p, q, s, m], outs, {"p": pos, "q": l1, "s": sp, "m": neg}
