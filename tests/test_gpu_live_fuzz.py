@@ -5,7 +5,7 @@ The generators are the ones behind the committed ``layout_fuzz*`` / ``glm_fuzz*`
 golden_cases_glm_fuzz.py: random ranks, extents that straddle the tile sizes, operands as strided / reversed / permuted /
 broadcast views, reductions over random axis subsets, softmax / log-sum-exp along random axes, regression models with
 gathers and scatter-adds) with OTHER seeds: the fixtures pin 60 draws for ever, this module draws new ones — by default a
-dozen per run (``PTHIP_FUZZ_CASES`` raises it; round 6 ran 1925, profiles/r8_live_fuzz.txt).  No fixture means no per-output
+dozen per run (``PTHIP_FUZZ_CASES`` raises it; round 6 ran 2025, profiles/r8_live_fuzz.txt).  No fixture means no per-output
 tolerance table: floats are held to ``|err| <= rtol*|want| + 64 eps * max|want|`` (rtol 1e-10 fp64 / 1e-4 fp32) — an
 indexing, layout or reduction bug is an O(1) error — integers and booleans exactly, every call twice (eager, then captured)."""
 import os
